@@ -1,0 +1,102 @@
+"""Deterministic synthetic sweeps and parameter fills shared by goldens, tests and bench.
+
+Nothing here depends on torch's RNG: every value comes from ``numpy.random.default_rng``
+seeded from integers / CRC32 of names, so the exact same inputs and weights can be
+re-created in the golden generator (this container, next to the reference import), in the
+CPU tests and on the GPU box without shipping large fixtures.
+
+Synthetic sweep recipe: SURVEY.md section 8(d) "Synthetic inputs".
+Polar decoration: restatement of the reference's ``transform_points(pc, 'cylinder')``
+(/root/reference/det3d/datasets/pipelines/utils.py:34-47).
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+# nuScenes polar-pillar grid of the reference config
+# (/root/reference/configs/nusc/pp/polarstream_det_n_seg_1_sector.py:10-19)
+NUSC_RANGE = (0.3, -3.1488, -5.0, 50.476, 3.1488, 3.0)
+NUSC_VOXEL = (0.098, 0.0123, 8.0)
+# secondary synthetic grid named by BASELINE.json (0.3125 m x 0.05 rad -> 160 x 126 x 1)
+COARSE_RANGE = (0.0, -3.15, -5.0, 50.0, 3.15, 3.0)
+COARSE_VOXEL = (0.3125, 0.05, 8.0)
+# Waymo PARTNER grid (/root/reference/configs/waymo/voxelnet/waymo_partner_36epoch.py:10-21)
+WAYMO_RANGE = (0.3, -3.14368, -2.0, 75.18, 3.14368, 4.0)
+WAYMO_VOXEL = (0.065, 0.00307, 0.15)
+
+
+def synth_sweep_cart(n_points: int, seed: int = 0, rho_max: float = 50.0,
+                     n_sweeps: int = 1) -> np.ndarray:
+    """(N,5) float32 [x, y, z, intensity, dt] synthetic lidar sweep."""
+    rng = np.random.default_rng(seed)
+    rho = rng.uniform(1.0, rho_max, n_points)
+    phi = rng.uniform(-np.pi, np.pi, n_points)
+    z = rng.uniform(-3.0, 1.0, n_points)
+    inten = rng.uniform(0.0, 1.0, n_points)
+    if n_sweeps > 1:
+        dt = 0.05 * rng.integers(0, n_sweeps, n_points).astype(np.float64)
+    else:
+        dt = np.zeros(n_points)
+    pts = np.stack([rho * np.cos(phi), rho * np.sin(phi), z, inten, dt], axis=1)
+    return pts.astype(np.float32)
+
+
+def cart_to_polar_host(pc: np.ndarray) -> np.ndarray:
+    """(N,5+) [x,y,z,rest] -> (N,7+) [rho,phi,z,x,y,rest] in the dtype of ``pc``.
+
+    Same arithmetic as the reference's cylinder branch of ``transform_points``.
+    """
+    rho = np.sqrt(pc[:, 0] ** 2 + pc[:, 1] ** 2)
+    phi = np.arctan2(pc[:, 1], pc[:, 0])
+    return np.hstack((rho[:, None], phi[:, None], pc[:, 2:3], pc[:, :2], pc[:, 3:]))
+
+
+def synth_sweep_polar(n_points: int, seed: int = 0, **kw) -> np.ndarray:
+    return np.ascontiguousarray(cart_to_polar_host(synth_sweep_cart(n_points, seed, **kw)))
+
+
+def _rng_for(name: str, base_seed: int) -> np.random.Generator:
+    return np.random.default_rng([base_seed, zlib.crc32(name.encode())])
+
+
+def fill_state_dict(state: "OrderedDict[str, object]", base_seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Deterministic, name-keyed values for every entry of a ``state_dict``.
+
+    * conv / linear weights (ndim >= 2): N(0, sqrt(2/fan_in))   (keeps activations O(1))
+    * norm weights (1-D ``*.weight``):    U(0.5, 1.5)
+    * biases (1-D ``*.bias``):            N(0, 0.1)
+    * ``running_mean``:                   N(0, 0.1);  ``running_var``: U(0.5, 1.5)
+    * ``num_batches_tracked``:            0
+    Returned arrays have the dtype/shape of the originals.
+    """
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, ref in state.items():
+        shape = tuple(ref.shape)
+        rng = _rng_for(name, base_seed)
+        if name.endswith("num_batches_tracked"):
+            val = np.zeros(shape, dtype=np.int64)
+        elif name.endswith("running_var"):
+            val = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif name.endswith("running_mean"):
+            val = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        elif len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            val = (np.sqrt(2.0 / fan_in) * rng.standard_normal(shape)).astype(np.float32)
+        elif name.endswith("weight"):
+            val = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        else:
+            val = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        out[name] = val
+    return out
+
+
+def load_filled(module, base_seed: int = 0) -> None:
+    """Overwrite every parameter/buffer of a torch module with ``fill_state_dict`` values."""
+    import torch
+
+    sd = module.state_dict()
+    filled = fill_state_dict(sd, base_seed)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()}, strict=True)
