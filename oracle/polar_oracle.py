@@ -1,0 +1,562 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  NOT the product, never shipped, never timed as
+"our" number.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module; ``partner_amd`` must not.
+
+A CPU restatement of the reference's polar-voxel encode -> BEV backbone -> centre head
+path, written functionally over a ``state_dict`` (name -> tensor) instead of as
+``nn.Module``s.  Integer / index stages are numpy (and mirrored in plain C in
+``polar_voxel.c``); floating-point network stages use torch CPU fp32 functional ops.
+
+Parity pin: every function here is checked by ``tests/test_oracle_golden.py`` against the
+fixtures in ``tests/golden/*.npz`` that ``tests/golden/make_golden.py`` captured by running
+the reference itself (imported from /root/reference) on the same deterministic inputs.
+The reference ships no tests of its own, so those captures are the only pin.
+Third-party arithmetic restated here without an upstream pin: ``torch_scatter``
+(scatter_mean / scatter_max semantics; unpinned in the reference).
+
+Reference locations are cited per function as file:line under /root/reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+# ======================================================================================
+# V0  cart -> polar decoration            det3d/datasets/pipelines/utils.py:34-47
+# ======================================================================================
+def cart_to_polar(pc: np.ndarray) -> np.ndarray:
+    """[x,y,z,rest...] -> [rho,phi,z,x,y,rest...] (cylinder branch), dtype preserved."""
+    x, y = pc[:, 0], pc[:, 1]
+    rho = np.sqrt(x * x + y * y)
+    phi = np.arctan2(y, x)
+    out = np.empty((pc.shape[0], pc.shape[1] + 2), dtype=pc.dtype)
+    out[:, 0], out[:, 1], out[:, 2] = rho, phi, pc[:, 2]
+    out[:, 3], out[:, 4] = x, y
+    out[:, 5:] = pc[:, 3:]
+    return out
+
+
+# ======================================================================================
+# V1  dynamic voxelization indices        det3d/datasets/pipelines/voxelization.py:165-168
+#     grid size                           det3d/core/input/voxel_generator.py:6-17
+#     batch index prepend                 det3d/torchie/parallel/collate.py:157-164
+# ======================================================================================
+def grid_size_of(pc_range: Sequence[float], voxel_size: Sequence[float]) -> np.ndarray:
+    r = np.asarray(pc_range, dtype=np.float32)
+    v = np.asarray(voxel_size, dtype=np.float32)
+    return np.round((r[3:] - r[:3]) / v).astype(np.int64)
+
+
+def grid_index(points: np.ndarray, pc_range, voxel_size, grid_size=None) -> np.ndarray:
+    """(N,>=3) fp32 polar points -> (N,3) int64 [z, theta, r]; out-of-range points are clamped.
+
+    fp32 subtract, fp32 true divide, clip to [0, G-1], floor -- in that order.
+    """
+    lo = np.asarray(pc_range, dtype=np.float32)[:3]
+    vs = np.asarray(voxel_size, dtype=np.float32)
+    g = grid_size_of(pc_range, voxel_size) if grid_size is None else np.asarray(grid_size, np.int64)
+    q = (points[:, :3].astype(np.float32) - lo) / vs  # fp32
+    q = np.minimum(np.maximum(q.astype(np.float64), 0.0), (g - 1).astype(np.float64))
+    return np.floor(q).astype(np.int64)[:, ::-1].copy()
+
+
+def with_batch_index(per_sample: List[np.ndarray]) -> np.ndarray:
+    return np.concatenate([np.concatenate([np.full((g.shape[0], 1), b, g.dtype), g], 1)
+                           for b, g in enumerate(per_sample)], 0)
+
+
+# ======================================================================================
+# unique rows in lexicographic order      torch.unique(dim=0) at
+#                                         det3d/models/readers/pillar_encoder.py:398
+# ======================================================================================
+def linear_key(grid_ind: np.ndarray, grid_size) -> np.ndarray:
+    """(N,4) [b,z,theta,r] -> int64 key ((b*Z+z)*T+theta)*R+r  (grid_size = [R,T,Z])."""
+    R, T, Z = (int(v) for v in grid_size[:3])
+    g = grid_ind.astype(np.int64)
+    return ((g[:, 0] * Z + g[:, 1]) * T + g[:, 2]) * R + g[:, 3]
+
+
+def unique_voxels(grid_ind: np.ndarray, grid_size) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """-> unq (V,4) int64 lexicographically sorted, unq_inv (N,) int64, unq_cnt (V,) int64."""
+    R, T, Z = (int(v) for v in grid_size[:3])
+    key = linear_key(grid_ind, grid_size)
+    uk, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+    unq = np.empty((uk.shape[0], 4), np.int64)
+    unq[:, 3] = uk % R
+    unq[:, 2] = (uk // R) % T
+    unq[:, 1] = (uk // (R * T)) % Z
+    unq[:, 0] = uk // (R * T * Z)
+    return unq, inv.astype(np.int64).reshape(-1), cnt.astype(np.int64)
+
+
+# ======================================================================================
+# torch_scatter semantics (third-party, unpinned): segment mean / max over unq_inv
+#   call sites  pillar_encoder.py:66,236 ; voxel_encoder.py:43
+# ======================================================================================
+def scatter_mean(x: Tensor, inv: Tensor, n: int) -> Tensor:
+    acc = torch.zeros((n, x.shape[1]), dtype=x.dtype)
+    acc.index_add_(0, inv, x)
+    cnt = torch.bincount(inv, minlength=n).clamp_(min=1).to(x.dtype)
+    return acc / cnt[:, None]
+
+
+def scatter_max(x: Tensor, inv: Tensor, n: int) -> Tensor:
+    out = torch.full((n, x.shape[1]), float("-inf"), dtype=x.dtype)
+    return out.scatter_reduce(0, inv[:, None].expand_as(x), x, reduce="amax", include_self=True)
+
+
+# ======================================================================================
+# V3  DynamicVoxelEncoderV1               det3d/models/readers/voxel_encoder.py:38-45
+#     VoxelFeatureExtractorV3             det3d/models/readers/voxel_encoder.py:15-22
+# ======================================================================================
+def dynamic_voxel_mean(points: np.ndarray, grid_ind: np.ndarray, grid_size):
+    unq, inv, _ = unique_voxels(grid_ind, grid_size)
+    f = scatter_mean(torch.from_numpy(points), torch.from_numpy(inv), unq.shape[0])
+    return f.numpy(), unq
+
+
+def hard_voxel_mean(voxels: np.ndarray, num_points: np.ndarray) -> np.ndarray:
+    v = torch.from_numpy(voxels)
+    return (v.sum(dim=1) / torch.from_numpy(num_points).to(v.dtype).view(-1, 1)).numpy()
+
+
+# ======================================================================================
+# V2  hard voxelization                   det3d/ops/point_cloud/point_cloud_ops.py:7-72,146-224
+# ======================================================================================
+def hard_voxelize(points: np.ndarray, voxel_size, pc_range, max_points: int, max_voxels: int):
+    """First-come voxel ids in point order, <=max_points kept per voxel, <=max_voxels voxels;
+    out-of-range points dropped (a voxel that already exists keeps accepting points after the
+    voxel budget is exhausted).  -> voxels (V,P,F) f32, coors (V,3) int32 [z,theta,r], num (V,) int32
+    """
+    vs = np.asarray(voxel_size, dtype=points.dtype)
+    rg = np.asarray(pc_range, dtype=points.dtype)
+    grid = np.round((rg[3:] - rg[:3]) / vs).astype(np.int32)
+    c = np.floor((points[:, :3] - rg[:3]) / vs)  # same dtype arithmetic as the reference loop
+    ok = np.all((c >= 0) & (c < grid), axis=1)
+    ci = c[ok].astype(np.int64)[:, ::-1]  # z, theta, r
+    pidx = np.nonzero(ok)[0]
+    key = (ci[:, 0] * int(grid[1]) + ci[:, 1]) * int(grid[0]) + ci[:, 2]
+    uk, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")  # voxel id = rank of first appearance
+    rank_of = np.empty_like(order)
+    rank_of[order] = np.arange(order.shape[0])
+    vid = rank_of[inv.reshape(-1)]
+    nv = min(int(uk.shape[0]), int(max_voxels))
+    keep = vid < nv
+    vid, pidx, ci = vid[keep], pidx[keep], ci[keep]
+    # slot of each point inside its voxel = number of earlier points of the same voxel
+    so = np.argsort(vid, kind="stable")
+    vs_sorted = vid[so]
+    start = np.searchsorted(vs_sorted, np.arange(nv), side="left")
+    slot = np.empty_like(vid)
+    slot[so] = np.arange(vid.shape[0]) - start[vs_sorted]
+    counts = np.bincount(vid, minlength=nv)
+    voxels = np.zeros((nv, max_points, points.shape[1]), points.dtype)
+    sel = slot < max_points
+    voxels[vid[sel], slot[sel]] = points[pidx[sel]]
+    coors = np.zeros((nv, 3), np.int32)
+    coors[vid] = ci  # every point of a voxel carries the same coordinate
+    num = np.minimum(counts, max_points).astype(np.int32)
+    return voxels, coors, num
+
+
+# ======================================================================================
+# V4  DynamicPFNet                        det3d/models/readers/pillar_encoder.py:338-406,63-71,228-249
+# ======================================================================================
+def pfn_feature_deco(points: Tensor, inv: Tensor, grid_ind: Tensor, n_vox: int, voxel_size, pc_range,
+                     voxel_shape="cylinder", xyz_cluster=True, raz_cluster=True, xy_center=True,
+                     ra_center=True) -> Tensor:
+    vx, vy = voxel_size[0], voxel_size[1]
+    x_off, y_off = vx / 2 + pc_range[0], vy / 2 + pc_range[1]
+    dt = points.dtype
+    cols = [points]
+    c1 = grid_ind[:, 3:4].to(dt) * vx + x_off
+    c2 = grid_ind[:, 2:3].to(dt) * vy + y_off
+    if xyz_cluster or xy_center:
+        xyz = points[:, :3] if voxel_shape == "cuboid" else points[:, [3, 4, 2]]
+        if xyz_cluster:
+            cols.append(xyz - scatter_mean(xyz, inv, n_vox)[inv])
+        if xy_center:
+            if voxel_shape == "cuboid":
+                xc, yc = c1, c2
+            else:
+                xc, yc = c1 * torch.cos(c2), c1 * torch.sin(c2)
+            cols += [xyz[:, 0:1] - xc, xyz[:, 1:2] - yc]
+    if raz_cluster or ra_center:
+        ra = points[:, :2] if voxel_shape != "cuboid" else points[:, -2:]
+        if raz_cluster:
+            src = ra if xyz_cluster else torch.cat([ra, points[:, 2:3]], 1)
+            cols.append(src - scatter_mean(src, inv, n_vox)[inv])
+        if ra_center:
+            if voxel_shape == "cuboid":
+                rc, ac = torch.sqrt(c1 ** 2 + c2 ** 2), torch.atan2(c2, c1)
+            else:
+                rc, ac = c1, c2
+            cols += [ra[:, 0:1] - rc, ra[:, 1:2] - ac]
+    return torch.cat(cols, dim=1)
+
+
+def dynamic_pfn(sd: SD, prefix: str, points: np.ndarray, grid_ind: np.ndarray, grid_size, voxel_size, pc_range,
+                **deco_kw) -> Tuple[Tensor, np.ndarray, np.ndarray]:
+    """-> features (V,C_last), unq (V,4) int64, unq_inv (N,).  BN layers exist in the
+    state_dict but are NOT applied on the dynamic path (pillar_encoder.py:63-71)."""
+    unq, inv_np, _ = unique_voxels(grid_ind, grid_size)
+    V = unq.shape[0]
+    inv = torch.from_numpy(inv_np)
+    x = pfn_feature_deco(torch.from_numpy(points), inv, torch.from_numpy(grid_ind.astype(np.int64)), V, voxel_size,
+                         pc_range, **deco_kw)
+    n_layers = len([k for k in sd if k.startswith(prefix + "pfn_layers.") and k.endswith("linear.weight")])
+    for i in range(n_layers):
+        w = sd[f"{prefix}pfn_layers.{i}.linear.weight"]
+        x = F.relu(x @ w.t())
+        xm = scatter_max(x, inv, V)
+        x = xm if i == n_layers - 1 else torch.cat([x, xm[inv]], dim=1)
+    return x, unq, inv_np
+
+
+# ======================================================================================
+# V5  DynamicPPScatter                    det3d/models/readers/pillar_encoder.py:418-432
+# ======================================================================================
+def scatter_canvas(feats: Tensor, unq: np.ndarray, batch: int, grid_size) -> Tensor:
+    nx, ny = int(grid_size[0]), int(grid_size[1])
+    canvas = torch.zeros((batch, feats.shape[1], ny, nx), dtype=feats.dtype)
+    u = torch.from_numpy(unq.astype(np.int64))
+    canvas[u[:, 0], :, u[:, 2], u[:, 3]] = feats
+    return canvas
+
+
+# ======================================================================================
+# B1  RPN                                 det3d/models/necks/rpn.py:23-159
+# ======================================================================================
+def _bn(sd: SD, p: str, x: Tensor, training: bool, eps=1e-3, momentum=0.01) -> Tensor:
+    return F.batch_norm(x, None if training else sd[p + "running_mean"], None if training else sd[p + "running_var"],
+                        sd[p + "weight"], sd[p + "bias"], training=training, momentum=momentum, eps=eps)
+
+
+def rpn(sd: SD, prefix: str, x: Tensor, layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides,
+        us_num_filters, training=False, return_all=False, **_ignored):
+    """Blocks: ZeroPad(1)+conv3x3(stride s)+BN+ReLU then k x [conv3x3 pad1 + BN + ReLU];
+    deblock i: ConvTranspose2d(k=s,s) if us>1 else Conv2d(k=round(1/us), stride same); concat."""
+    start = len(layer_nums) - len(us_layer_strides)
+    ups, blocks = [], []
+    for i, n in enumerate(layer_nums):
+        bp = f"{prefix}blocks.{i}."
+        x = F.conv2d(F.pad(x, (1, 1, 1, 1)), sd[bp + "1.weight"], stride=int(ds_layer_strides[i]))
+        x = F.relu(_bn(sd, bp + "2.", x, training))
+        for j in range(n):
+            x = F.conv2d(x, sd[f"{bp}{4 + 3 * j}.weight"], padding=1)
+            x = F.relu(_bn(sd, f"{bp}{5 + 3 * j}.", x, training))
+        blocks.append(x)
+        if i - start >= 0:
+            us = us_layer_strides[i - start]
+            dp = f"{prefix}deblocks.{i - start}."
+            if us > 1:
+                y = F.conv_transpose2d(x, sd[dp + "0.weight"], stride=int(us))
+            else:
+                k = int(np.round(1 / us))
+                y = F.conv2d(x, sd[dp + "0.weight"], stride=k)
+            ups.append(F.relu(_bn(sd, dp + "1.", y, training)))
+    out = torch.cat(ups, dim=1) if ups else x
+    return (out, blocks, ups) if return_all else out
+
+
+# ======================================================================================
+# H2  CenterHeadSingle / CenterHeadSinglePos   det3d/models/bbox_heads/center_head_parallel.py:27-59,70-196,199-284
+#     RSNorm                                   det3d/models/utils/norm.py:58-75
+# ======================================================================================
+def rs_norm(x: Tensor, w: Tensor, b: Tensor, num_heads: int, num_groups: int, eps=1e-5) -> Tensor:
+    """Range-stratified GroupNorm: split the last (range) axis into ``num_groups`` strata,
+    stack them on channels, GroupNorm(num_heads*num_groups groups), un-stack."""
+    parts = x.chunk(num_groups, dim=-1)
+    y = F.group_norm(torch.cat(parts, 1), num_heads * num_groups, w, b, eps)
+    return torch.cat(y.chunk(num_groups, dim=1), dim=-1)
+
+
+def range_stratified(sd: SD, p: str, x: Tensor, kernel=(3, 3), nheads=1, ngroups=8) -> Tensor:
+    """Per-range-stratum 3x3 conv (groups=ngroups*nheads, own weights per stratum) + GroupNorm + ReLU.
+    Azimuth is zero-padded; each stratum sees one halo column of its range neighbours (zeros at the ends)."""
+    pa, pr = kernel[0] // 2, kernel[1] // 2
+    x = F.pad(x, (0, 0, pa, pa))
+    step = x.shape[-1] // ngroups
+    if pr > 0:
+        x = F.pad(x, (pr, pr, 0, 0))
+        x = torch.cat([x[:, :, :, step * i: step * (i + 1) + 2 * pr] for i in range(ngroups)], 1)
+    else:
+        x = torch.cat([x[:, :, :, step * i: step * (i + 1)] for i in range(ngroups)], 1)
+    x = F.conv2d(x, sd[p + "conv.0.weight"], sd[p + "conv.0.bias"], groups=ngroups * nheads)
+    x = F.relu(F.group_norm(x, ngroups * nheads, sd[p + "conv.1.weight"], sd[p + "conv.1.bias"], 1e-5))
+    return torch.cat(x.chunk(ngroups, dim=1), dim=-1)
+
+
+def polar_pos_encoding(voxel_generator: dict, out_size_factor: int) -> Tensor:
+    """(1,5,A,R) [r cos, r sin, r, cos, sin] at cell corners (center_head_parallel.py:229-260)."""
+    pr, vs, ns = list(voxel_generator["range"]), voxel_generator["voxel_size"], voxel_generator["nsectors"]
+    min_az, max_az = pr[1], pr[4]
+    ref4 = min_az + (max_az - min_az) / ns
+    r_size = round((pr[3] - pr[0]) / vs[0] / out_size_factor)
+    a_size = round((ref4 - pr[1]) / vs[1] / out_size_factor)
+    ga, gr = torch.meshgrid(torch.arange(a_size), torch.arange(r_size), indexing="ij")
+    ga = ga * out_size_factor * vs[1] + pr[1]
+    gr = gr * out_size_factor * vs[0] + pr[0]
+    c, s = torch.cos(ga), torch.sin(ga)
+    return torch.stack([gr * c, gr * s, gr, c, s])[None]
+
+
+def _head_branch(sd: SD, p: str, x: Tensor, name: str, num_conv: int) -> Tensor:
+    """One merged head: 'reg' -> RangeStratified + 1x1; 'a_b' -> grouped convs; else plain convs."""
+    if "reg" in name:
+        y = range_stratified(sd, f"{p}{name}.0.", x)
+        return F.conv2d(y, sd[f"{p}{name}.1.weight"], sd[f"{p}{name}.1.bias"])
+    groups = len(name.split("_")) if "_" in name else 1
+    y, idx = x, 0
+    for _ in range(num_conv - 1):
+        y = F.conv2d(y, sd[f"{p}{name}.{idx}.weight"], sd[f"{p}{name}.{idx}.bias"], padding=1, groups=groups)
+        ch = y.shape[1]
+        y = F.relu(F.group_norm(y, ch, sd[f"{p}{name}.{idx + 1}.weight"], sd[f"{p}{name}.{idx + 1}.bias"], 1e-5))
+        idx += 3
+    return F.conv2d(y, sd[f"{p}{name}.{idx}.weight"], sd[f"{p}{name}.{idx}.bias"], padding=1, groups=groups)
+
+
+def center_head_single(sd: SD, prefix: str, x: Tensor, common_heads: dict, num_hm_conv=2, pos_encoding=None,
+                       return_internals=False):
+    """CenterHeadSingle.forward; with ``pos_encoding`` also the position-conditioned
+    calibration of CenterHeadSinglePos (hm input = x*W(pos)+b(pos))."""
+    p = prefix
+    xs = F.conv2d(x, sd[p + "shared_conv.0.weight"], sd[p + "shared_conv.0.bias"], padding=1)
+    xs = F.relu(rs_norm(xs, sd[p + "shared_conv.1.groupnorm.weight"], sd[p + "shared_conv.1.groupnorm.bias"], 1, 4))
+    heads = dict(common_heads)
+    heads["hm"] = (None, num_hm_conv)
+    cal_w = cal_b = None
+    x_hm = xs
+    if pos_encoding is not None:
+        cw = torch.tanh(F.conv2d(pos_encoding, sd[p + "calibration_weight.0.weight"], sd[p + "calibration_weight.0.bias"], padding=1))
+        cal_w = torch.tanh(F.conv2d(cw, sd[p + "calibration_weight.2.weight"], sd[p + "calibration_weight.2.bias"]))
+        cb = torch.tanh(F.conv2d(pos_encoding, sd[p + "calibration_bias.0.weight"], sd[p + "calibration_bias.0.bias"], padding=1))
+        cal_b = F.conv2d(cb, sd[p + "calibration_bias.2.weight"], sd[p + "calibration_bias.2.bias"])
+        x_hm = xs * cal_w + cal_b
+    ret = {}
+    for name, (_, num_conv) in heads.items():
+        out = _head_branch(sd, p, x_hm if name == "hm" else xs, name, num_conv)
+        if "_" in name:
+            for j, (nm, t) in enumerate(zip(name.split("_"), out.chunk(len(name.split("_")), dim=1))):
+                ret[nm] = t
+        else:
+            ret[name] = out
+    if return_internals:
+        return ret, dict(shared=xs, cal_weight=cal_w, cal_bias=cal_b)
+    return ret
+
+
+# ======================================================================================
+# H1  CenterHead / SepHead                det3d/models/bbox_heads/center_head.py:65-109,166-242
+# ======================================================================================
+def center_head(sd: SD, prefix: str, x: Tensor, tasks_num_classes: Sequence[int], common_heads: dict,
+                num_hm_conv=2) -> List[Dict[str, Tensor]]:
+    xs = F.relu(F.conv2d(x, sd[prefix + "shared_conv.0.weight"], sd[prefix + "shared_conv.0.bias"], padding=1))
+    rets = []
+    for t, ncls in enumerate(tasks_num_classes):
+        heads = dict(common_heads)
+        heads["hm"] = (ncls, num_hm_conv)
+        d = {}
+        for name, (_, num_conv) in heads.items():
+            y, idx = xs, 0
+            for _ in range(num_conv - 1):
+                kp = f"{prefix}tasks.{t}.{name}.{idx}."
+                y = F.relu(F.conv2d(y, sd[kp + "weight"], sd[kp + "bias"], padding=1))
+                idx += 2
+            kp = f"{prefix}tasks.{t}.{name}.{idx}."
+            d[name] = F.conv2d(y, sd[kp + "weight"], sd[kp + "bias"], padding=1)
+        rets.append(d)
+    return rets
+
+
+# ======================================================================================
+# L1  CenterHead.loss                     det3d/models/bbox_heads/center_head.py:244-288
+#     FastFocalLoss / RegLoss             det3d/models/losses/centernet_loss.py:26-54,6-24
+# ======================================================================================
+def _gather_at(feat: Tensor, ind: Tensor) -> Tensor:
+    b, c, h, w = feat.shape
+    flat = feat.permute(0, 2, 3, 1).reshape(b, h * w, c)
+    return flat.gather(1, ind[:, :, None].expand(-1, -1, c))
+
+
+def center_loss(preds: Dict[str, Tensor], hm_t: Tensor, ind: Tensor, mask: Tensor, cat: Tensor, anno_box: Tensor,
+                code_weights: Sequence[float], weight: float):
+    hm = torch.clamp(torch.sigmoid(preds["hm"]), min=1e-4, max=1 - 1e-4)
+    m = mask.float()
+    neg = (torch.log(1 - hm) * hm ** 2 * (1 - hm_t) ** 4).sum()
+    pos_pred = _gather_at(hm, ind).gather(2, cat[:, :, None])
+    pos = (torch.log(pos_pred) * (1 - pos_pred) ** 2 * m[:, :, None]).sum()
+    num_pos = m.sum()
+    hm_loss = -neg if num_pos == 0 else -(pos + neg) / num_pos
+    if "vel" in preds:
+        box = torch.cat((preds["reg"], preds["height"], preds["dim"], preds["vel"], preds["rot"]), 1)
+        tgt = anno_box
+    else:
+        box = torch.cat((preds["reg"], preds["height"], preds["dim"], preds["rot"]), 1)
+        tgt = anno_box[..., [0, 1, 2, 3, 4, 5, -2, -1]]
+    pred = _gather_at(box, ind)
+    l1 = (pred * m[:, :, None] - tgt * m[:, :, None]).abs() / (m.sum() + 1e-4)
+    box_loss = l1.sum(dim=(0, 1))
+    loc = (box_loss * box_loss.new_tensor(list(code_weights))).sum()
+    return dict(det_loss=hm_loss + weight * loc, hm_loss=hm_loss, loc_loss=loc, loc_loss_elem=box_loss, num_positive=num_pos)
+
+
+# ======================================================================================
+# A1  SetBlock (global representation re-alignment)   det3d/models/utils/set_transformer.py:56-493
+#     bev_pos                                         det3d/models/detectors/voxelnet.py:10-25
+# ======================================================================================
+def waymo_bev_pos(x_size=144, y_size=256, pc_range=(0.3, -3.14368, -2.0, 75.18, 3.14368, 4.0),
+                  voxel_size=(0.065, 0.00307, 0.15), scale=8) -> Tensor:
+    """(1, x_size(r), y_size(theta), 4) = [x, y, r, phi] at BEV cell centres."""
+    ri = torch.linspace(0, x_size - 1, x_size)[:, None].expand(x_size, y_size) + 0.5
+    ti = torch.linspace(0, y_size - 1, y_size)[None, :].expand(x_size, y_size) + 0.5
+    r = ri * voxel_size[0] * scale + pc_range[0]
+    phi = ti * voxel_size[1] * scale + pc_range[1]
+    return torch.stack([r * torch.cos(phi), r * torch.sin(phi), r, phi], dim=2)[None]
+
+
+def _lin(sd: SD, p: str, x: Tensor) -> Tensor:
+    return F.linear(x, sd[p + "weight"], sd.get(p + "bias"))
+
+
+def _mlp(sd: SD, p: str, x: Tensor) -> Tensor:
+    return _lin(sd, p + "fc2.", F.gelu(_lin(sd, p + "fc1.", x)))
+
+
+def _ln(sd: SD, p: str, x: Tensor) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), sd[p + "weight"], sd[p + "bias"], 1e-5)
+
+
+def _pos_bias(sd: SD, p: str, rel: Tensor) -> Tensor:
+    """rel (G,2,L) -> (G,heads,L): Conv1d(2->16) + BN1d(eval) + ReLU + Conv1d(16->heads)."""
+    y = F.conv1d(rel, sd[p + "0.weight"], sd[p + "0.bias"])
+    y = F.batch_norm(y, sd[p + "1.running_mean"], sd[p + "1.running_var"], sd[p + "1.weight"], sd[p + "1.bias"], False, 0.1, 1e-5)
+    return F.conv1d(F.relu(y), sd[p + "3.weight"], sd[p + "3.bias"])
+
+
+def _cols(t: Tensor, B: int, H: int, W: int, heads: int) -> Tensor:
+    """(B, H*W, C) tokens -> per theta-column windows (B*W, heads, H, C/heads)."""
+    C = t.shape[-1]
+    return t.view(B, H, W, heads, C // heads).permute(0, 2, 3, 1, 4).reshape(B * W, heads, H, C // heads)
+
+
+def _raw_view_keypoints(t: Tensor, B: int, K: int, W: int, heads: int) -> Tensor:
+    """The reference reinterprets the (B, K*W, C) key-point buffer as (B, C, K, W) WITHOUT a
+    transpose (set_transformer.py:331-334,417-425); reproduce that literally.
+    -> (B*W, heads, K, C/heads)"""
+    C = t.shape[-1]
+    q = t.reshape(B, C, K, W).view(B, heads, C // heads, K, W)
+    return q.permute(0, 4, 1, 3, 2).reshape(B * W, heads, K, C // heads)
+
+
+def set_attention(sd: SD, p: str, x: Tensor, pos_cart: Tensor, reso, heads: int, K=4, win_w=8, shift=False,
+                  return_topidx=False):
+    """SetAttention.forward for H_sp=H (full range column), W_sp=1.  x (B,L,C); pos_cart (B,H,W,2)."""
+    H, W = reso
+    B, L, C = x.shape
+    hd = C // heads
+    scale = hd ** -0.5
+    shortcut = x
+    xn = _ln(sd, p + "norm1.", x).view(B, H, W, C)
+    xpos = pos_cart
+    sh = win_w // 2 if shift else 0
+    if sh:
+        xn = torch.roll(xn, -sh, 2)
+        xpos = torch.roll(xpos, -sh, 2)
+    # key-point selection: per theta-column, top-K strict-ish local maxima of the channel mean along range
+    s = xn.mean(dim=3)  # (B,H,W)
+    st = s.permute(0, 2, 1)
+    lm = torch.zeros_like(st)
+    lm[:, :, 1:-1] = F.max_pool1d(st, 3, 1, 0)
+    s = (st * (lm == st)).permute(0, 2, 1)
+    top = s.argsort(dim=1, descending=True)[:, :K, :]  # (B,K,W)
+    kp = xn.gather(1, top[..., None].expand(-1, -1, -1, C)).reshape(B, K * W, C)
+    kpos = xpos.gather(1, top[..., None].expand(-1, -1, -1, 2))  # (B,K,W,2)
+    xt = xn.reshape(B, L, C)
+    # per-column position tensors (G=B*W, 2, n)
+    xp = xpos.permute(0, 2, 3, 1).reshape(B * W, 2, H)
+    sp = kpos.permute(0, 2, 3, 1).reshape(B * W, 2, K)
+
+    # ---- sector attention 1: key points <- their column ------------------------------------
+    q = "sector_attn1."
+    rel = (sp[:, :, :, None] - xp[:, :, None, :]).reshape(B * W, 2, K * H)
+    bias = _pos_bias(sd, p + q + "pos_embedding_cart.", rel).view(B * W, heads, K, H)
+    qq = _raw_view_keypoints(_lin(sd, p + q + "proj_q.", kp), B, K, W, heads) * scale
+    kk = _cols(_lin(sd, p + q + "proj_k.", xt), B, H, W, heads)
+    vv = _cols(_lin(sd, p + q + "proj_v.", xt), B, H, W, heads)
+    a = torch.softmax(qq @ kk.transpose(-2, -1) + bias, dim=-1)
+    o = (a @ vv).transpose(1, 2).reshape(B, W, K, C).permute(0, 2, 1, 3).reshape(B, K * W, C)
+    s1 = kp + _lin(sd, p + q + "proj.", o)
+    s1 = s1 + _mlp(sd, p + q + "mlp.", _ln(sd, p + q + "norm2.", s1))
+
+    # ---- range attention among key points, windows K x win_w -------------------------------
+    q = "range_attn."
+    nw = W // win_w
+    n = K * win_w
+    sn = _ln(sd, p + q + "norm1.", s1)
+    wp = kpos.view(B, 1, K, nw, win_w, 2).permute(0, 1, 3, 5, 2, 4).reshape(B * nw, 2, n)
+    rel = (wp[:, :, :, None] - wp[:, :, None, :]).reshape(B * nw, 2, n * n)
+    bias = _pos_bias(sd, p + q + "pos_embedding_cart.", rel).view(B * nw, heads, n, n)
+
+    def win(t):
+        return t.view(B, K, nw, win_w, heads, hd).permute(0, 2, 4, 1, 3, 5).reshape(B * nw, heads, n, hd)
+
+    qq = win(_lin(sd, p + q + "proj_q.", sn)) * scale
+    kk = win(_lin(sd, p + q + "proj_k.", sn))
+    vv = win(_lin(sd, p + q + "proj_v.", sn))
+    a = torch.softmax(qq @ kk.transpose(-2, -1) + bias, dim=-1)
+    o = (a @ vv).transpose(1, 2).reshape(B, nw, K, win_w, C).permute(0, 2, 1, 3, 4).reshape(B, K * W, C)
+    s2 = s1 + _lin(sd, p + q + "proj.", o)
+    s2 = s2 + _mlp(sd, p + q + "mlp.", _ln(sd, p + q + "norm2.", s2))
+
+    # ---- sector attention 2: column <- key points (no proj / mlp inside) --------------------
+    q = "sector_attn2."
+    rel = (xp[:, :, :, None] - sp[:, :, None, :]).reshape(B * W, 2, H * K)
+    bias = _pos_bias(sd, p + q + "pos_embedding_cart.", rel).view(B * W, heads, H, K)
+    qq = _cols(_lin(sd, p + q + "proj_q.", xt), B, H, W, heads) * scale
+    kk = _raw_view_keypoints(_lin(sd, p + q + "proj_k.", s2), B, K, W, heads)
+    vv = _raw_view_keypoints(_lin(sd, p + q + "proj_v.", s2), B, K, W, heads)
+    a = torch.softmax(qq @ kk.transpose(-2, -1) + bias, dim=-1)
+    o = (a @ vv).transpose(1, 2).reshape(B, W, H, C).permute(0, 2, 1, 3)  # (B,H,W,C)
+    if sh:
+        o = torch.roll(o, sh, 2)
+    o = o.reshape(B, L, C)
+    y = shortcut + _lin(sd, p + "proj.", o)
+    y = y + _mlp(sd, p + "mlp.", _ln(sd, p + "norm2.", y))
+    return (y, top) if return_topidx else y
+
+
+def set_block(sd: SD, prefix: str, x: Tensor, pos: Tensor, reso, heads=4, K=4, win_w=8, shift=False) -> Tensor:
+    """SetBlock.forward with embed_dim_scale == 1 (the only configuration VoxelNetV3 builds)."""
+    B = x.shape[0]
+    return set_attention(sd, prefix + "attns.", x, pos[..., :2].repeat(B, 1, 1, 1), reso, heads, K, win_w, shift)
+
+
+# ======================================================================================
+# D1  PointPillars (dynamic branch) end-to-end      det3d/models/detectors/point_pillars.py:40-110
+# ======================================================================================
+def pointpillars_forward(sd: SD, cfg: dict, points: np.ndarray, grid_ind: np.ndarray, batch: int,
+                         return_stages=False):
+    """cfg: the model dict of the config (reader / neck / bbox_head sub-dicts, reference schema)."""
+    rd, nk, hd = cfg["reader"], cfg["neck"], cfg["bbox_head"]
+    vg = hd["voxel_generator"]
+    gsz = grid_size_of(vg["range"], vg["voxel_size"])
+    feats, unq, inv = dynamic_pfn(sd, "reader.", points, grid_ind, gsz, rd["voxel_size"], rd["pc_range"],
+                                  voxel_shape=rd.get("voxel_shape", "cylinder"), xyz_cluster=rd["xyz_cluster"],
+                                  raz_cluster=rd["raz_cluster"], xy_center=rd["xy_center"], ra_center=rd["ra_center"])
+    x1 = scatter_canvas(feats, unq, batch, gsz)
+    x2, blocks, ups = rpn(sd, "neck.", x1, return_all=True, **{k: v for k, v in nk.items() if k not in ("type", "logger")})
+    pos = polar_pos_encoding(vg, hd.get("out_size_factor", 4)) if hd["type"] == "CenterHeadSinglePos" else None
+    preds = center_head_single(sd, "bbox_head.", x2, hd["common_heads"], pos_encoding=pos)
+    if return_stages:
+        return preds, dict(features=feats, unq=unq, inv=inv, canvas=x1, blocks=blocks, ups=ups, x2=x2, pos=pos)
+    return preds
