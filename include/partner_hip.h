@@ -1,0 +1,247 @@
+/*
+ * partner_hip.h -- C ABI of libpartner_hip.so (gfx950 / MI355X).
+ *
+ * The reference (fudan-zvg/PARTNER, a det3d fork) has no FFI for this path: its plugin
+ * boundary is the Python registry API (det3d/utils/registry.py:28-78,
+ * det3d/models/builder.py:17-53) and the GPU work is library calls (torch.unique,
+ * torch_scatter, cuDNN).  This header is the boundary a det3d maintainer would bind with
+ * ctypes: every entry point below names the reference function whose
+ * arithmetic it replaces (file:line under the reference root).
+ *
+ * Conventions
+ *   - extern "C"; plain pointers and sizes; no torch / C++ types.
+ *   - every data pointer is a DEVICE pointer owned by the caller; the library never
+ *     allocates, frees or synchronises (hipGraph-capturable).  Scratch memory is passed in
+ *     as `workspace`; its size comes from the matching *_workspace_bytes() query.
+ *   - `stream` is a hipStream_t passed as void*.
+ *   - return value: 0 = ok, <0 = error (PN_ERR_*); the message is kept per host thread and
+ *     read with pn_last_error().  The library never exits the process.
+ *   - activations are NHWC fp32 ("channels-last"): element (b,y,x,c) lives at
+ *     ((b*H+y)*W+x)*pixel_stride + channel_offset + c.  BEV axes: y = theta (azimuth),
+ *     x = r (range), exactly the (B,C,theta,r) logical layout of the reference tensors.
+ *   - voxel indices are [b, z, theta, r] (reference order, collate.py:157-164).
+ */
+#ifndef PARTNER_HIP_H
+#define PARTNER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN_OK 0
+#define PN_ERR_INVALID (-1)   /* bad argument / unsupported shape              */
+#define PN_ERR_LAUNCH (-2)    /* HIP reported a launch error                   */
+#define PN_ERR_WORKSPACE (-3) /* workspace too small                           */
+
+#define PN_ACT_NONE 0
+#define PN_ACT_RELU 1
+#define PN_ACT_TANH 2
+
+typedef void *pn_stream_t;
+
+int pn_version(void);
+/* copies the calling thread's last error message (NUL terminated) into buf; returns its length */
+int pn_last_error(char *buf, size_t buf_len);
+/* number of HIP devices visible, -1 if the runtime is unusable */
+int pn_device_count(void);
+
+/* ---------------------------------------------------------------------------------------
+ * V0  cart -> polar point decoration.
+ * Replaces transform_points(pc,'cylinder')  det3d/datasets/pipelines/utils.py:34-47
+ * cart: (n, f_in>=3) [x,y,z,rest...]  ->  polar: (n, f_in+2) [rho,phi,z,x,y,rest...]
+ * rho = sqrt(x*x+y*y) in IEEE fp32 (bit-exact); phi = atan2 evaluated in fp64 and rounded
+ * once to fp32 (differs from glibc atan2f by at most 1 ulp).
+ */
+int pn_cart_to_polar_f32(const float *cart, int n, int f_in, float *polar, pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * V1  dynamic voxelization indices.
+ * Replaces Voxelization.voxelize_dynamic  det3d/datasets/pipelines/voxelization.py:165-168
+ *          + batch index prepend          det3d/torchie/parallel/collate.py:157-164
+ * grid_ind[i] = [b, floor(clip((p[i,2]-lo[2])/vs[2],0,Z-1)), ...theta..., ...r...]  (int64, N x 4)
+ * fp32 subtract, fp32 IEEE divide, clamp, floor -- bit-exact with numpy.
+ * sample_offsets: device int32[batch+1], prefix offsets of each sample's points
+ *                 (n = sample_offsets[batch] <= n_capacity).
+ * range_lo[3], voxel_size[3]: host floats (r,theta,z order).  grid[3] = {R,T,Z}.
+ * Either output may be NULL: grid_ind (int64 N x 4) and/or keys (uint32 linear key
+ * ((b*Z+z)*T+theta)*R+r).
+ */
+int pn_polar_grid_index_f32(const float *points, int point_stride, int n_capacity,
+                            const int32_t *sample_offsets, int batch, const float *range_lo,
+                            const float *voxel_size, const int32_t *grid, int64_t *grid_ind,
+                            uint32_t *keys, pn_stream_t stream);
+
+/* keys from caller-supplied int64 grid_ind (N x 4), for the reference API where grid_ind is an input */
+int pn_keys_from_grid_ind(const int64_t *grid_ind, int n, const int32_t *grid, int batch,
+                          uint32_t *keys, pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Unique voxels in lexicographic (b,z,theta,r) order == rank in linear-key order.
+ * Replaces torch.unique(grid_ind, return_inverse, return_counts, dim=0)
+ *          det3d/models/readers/pillar_encoder.py:398 ; voxel_encoder.py:42
+ * Occupancy bitmap + popcount prefix scan; no sort, no host sync.
+ *   keys       uint32[n]            (from pn_polar_grid_index_f32 / pn_keys_from_grid_ind)
+ *   n_dev      optional device int32: actual n (<= n_capacity); NULL -> n_capacity
+ *   num_cells  batch*Z*T*R  (< 2^32)
+ * outputs (capacity n_capacity rows each; bit-exact vs torch.unique):
+ *   unq        int64[V x 4]  (may be NULL)     unq_inv  int32[n]
+ *   unq_cnt    int32[V]                        num_voxels  device int32[1] = V
+ */
+size_t pn_unique_workspace_bytes(uint64_t num_cells, int n_capacity);
+int pn_unique_rank_bitmap(const uint32_t *keys, int n_capacity, const int32_t *n_dev,
+                          uint64_t num_cells, const int32_t *grid, int64_t *unq, int32_t *unq_inv,
+                          int32_t *unq_cnt, int32_t *num_voxels, void *workspace,
+                          size_t workspace_bytes, pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Bucket the points by voxel rank: voxel_start[v] = exclusive scan of unq_cnt (V+1 entries,
+ * capacity n_capacity+1) and order[] = point indices grouped by voxel (order inside a voxel
+ * is unspecified; every consumer below reduces with order-independent arithmetic).
+ */
+size_t pn_bucket_workspace_bytes(int n_capacity);
+int pn_bucket_points(const int32_t *unq_inv, const int32_t *unq_cnt, int n_capacity,
+                     const int32_t *n_dev, const int32_t *num_voxels, int32_t *voxel_start,
+                     int32_t *order, void *workspace, size_t workspace_bytes, pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * V3  per-voxel mean of point features.
+ * Replaces torch_scatter.scatter_mean(features, unq_inv) in DynamicVoxelEncoderV1.forward
+ *          det3d/models/readers/voxel_encoder.py:38-45
+ * Sums are taken in 2^-24 fixed point (order independent => bitwise reproducible).
+ * points (n x f, row stride point_stride) -> mean (V x f).
+ */
+int pn_scatter_mean_f32(const float *points, int point_stride, int f, const int32_t *voxel_start,
+                        const int32_t *order, const int32_t *num_voxels, int v_capacity,
+                        float *mean, pn_stream_t stream);
+
+/* VoxelFeatureExtractorV3.forward  det3d/models/readers/voxel_encoder.py:15-22
+ * voxels (V x P x F) , num_points int32[V] -> (V x F) = sum_P / num_points */
+int pn_hard_voxel_mean_f32(const float *voxels, const int32_t *num_points, int v, int p, int f,
+                           float *mean, pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * V4 (+V5)  DynamicPFNet forward, cylinder grid, full decoration (16 channels):
+ *   [points(7) | xyz-mean_voxel(3) | x-xc, y-yc | (rho,phi)-mean_voxel(2) | rho-rc, phi-pc]
+ *   -> Linear(16->C0, no bias) ReLU segmax, concat -> Linear(2*C0->C1, no bias) ReLU segmax
+ * Replaces DynamicPFNet.forward / feature_deco / PFNLayer.forward_dynamic / get_cluster /
+ *          polar2cart   det3d/models/readers/pillar_encoder.py:393-406,338-391,63-71,228-249
+ * and, when `canvas` != NULL, DynamicPPScatter.forward  pillar_encoder.py:418-432
+ *   w0: (C0 x 16) row-major (torch Linear weight), w1: (C1 x 2*C0).  C0 <= 64, C1 <= 128,
+ *   both multiples of 4.
+ *   vx, vy, x_offset, y_offset: as computed by DynamicPFNet.__init__ (pillar_encoder.py:330-334)
+ *   unq_keys: uint32[V] linear key per voxel rank (workspace product of pn_unique_rank_bitmap,
+ *             see pn_unique_keys_ptr) -- gives (b,theta,r) of each voxel.
+ *   features: (v_capacity x C1) or NULL.   canvas: NHWC (batch, T, R, C1) or NULL; the caller
+ *   zero-fills the canvas (pn_fill_zero) -- only occupied cells are written here.
+ */
+int pn_dynamic_pfn_fwd(const float *points, int point_stride, const int32_t *voxel_start,
+                       const int32_t *order, const int32_t *num_voxels, int v_capacity,
+                       const uint32_t *unq_keys, const int32_t *grid, const float *w0, int c0,
+                       const float *w1, int c1, float vx, float vy, float x_offset, float y_offset,
+                       float *features, float *canvas, pn_stream_t stream);
+
+/* pointer to the uint32 key-per-voxel array inside a pn_unique_rank_bitmap workspace */
+const uint32_t *pn_unique_keys_ptr(const void *workspace, uint64_t num_cells, int n_capacity);
+
+/* V5 alone: DynamicPPScatter.forward (pillar_encoder.py:418-432) / PointPillarsScatter
+ * features (V x C), unq int64 (V x 4) -> canvas NHWC (batch,T,R,C); caller zero-fills. */
+int pn_scatter_canvas_fwd(const float *features, const int64_t *unq, const int32_t *num_voxels,
+                          int v_capacity, int c, int t, int r, float *canvas, pn_stream_t stream);
+
+int pn_fill_zero(void *ptr, size_t bytes, pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * B1 / H*  2-D convolution on the BEV map as an implicit GEMM on fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32), fused per-output-channel affine (folded BatchNorm or bias) and
+ * activation:  out = act(conv(in, w) * scale[n] + shift[n])
+ * Replaces nn.Conv2d(+ZeroPad2d)+BatchNorm2d(eval)+ReLU triples of RPN._make_layer and the
+ * deblocks  det3d/models/necks/rpn.py:80-142, and the head convolutions
+ *          det3d/models/bbox_heads/center_head_parallel.py:120-177, center_head.py:65-109
+ *
+ * Weights are used in a packed layout produced once by pn_pack_conv_weight_f32 from the
+ * torch layout (Cout, Cin/groups, KH, KW).
+ */
+typedef struct pn_conv_desc {
+  int32_t batch, in_h, in_w;
+  int32_t cin;          /* input channels per group  */
+  int32_t cout;         /* output channels per group */
+  int32_t groups;
+  int32_t kh, kw, stride, pad_h, pad_w;
+  int32_t in_pixel_stride, in_channel_offset;   /* NHWC slice addressing (floats) */
+  int32_t out_pixel_stride, out_channel_offset;
+  int32_t act;          /* PN_ACT_*  */
+  int32_t deconv2x2;    /* 1: weights are a ConvTranspose2d(k=2,s=2) packed by
+                           pn_pack_deconv2x2_weight_f32; kh=kw=1; output is (2H x 2W) */
+  int32_t range_strata; /* >1: RangeStratified convolution (center_head_parallel.py:27-59):
+                           the x (range) axis is cut into `range_strata` equal windows, window s
+                           uses weight group s (packed with groups = range_strata) and
+                           scale/shift[s*cout + n]; every window reads the same `cin` input
+                           channels, halo columns come from the neighbouring windows (zeros at
+                           the map border).  groups must be 1.  0/1: ordinary convolution. */
+} pn_conv_desc;
+
+size_t pn_conv_packed_weight_floats(int cout, int cin, int kh, int kw, int groups);
+int pn_pack_conv_weight_f32(const float *w_oihw, int cout_total, int cin_per_group, int kh, int kw,
+                            int groups, float *packed, pn_stream_t stream);
+/* ConvTranspose2d weight (Cin, Cout, 2, 2) -> packed 1x1 weight with 4*Cout outputs */
+size_t pn_deconv2x2_packed_weight_floats(int cin, int cout);
+int pn_pack_deconv2x2_weight_f32(const float *w_iohw, int cin, int cout, float *packed,
+                                 pn_stream_t stream);
+/* scale/shift may be NULL (=> 1 / 0); they have groups*cout entries (cout for deconv) */
+int pn_conv2d_nhwc_f32(const pn_conv_desc *desc, const float *in, const float *packed_w,
+                       const float *scale, const float *shift, float *out, pn_stream_t stream);
+
+/* plain direct convolution (any channel count, no MFMA): used for constant folding of the
+ * position-conditioned calibration (center_head_parallel.py:243-266) and as an on-device
+ * cross-check of the MFMA kernel.  Weights in torch layout (Cout, Cin/groups, KH, KW). */
+int pn_conv2d_direct_nhwc_f32(const pn_conv_desc *desc, const float *in, const float *w_oihw,
+                              const float *scale, const float *shift, float *out,
+                              pn_stream_t stream);
+
+/* fold eval-mode BatchNorm (and an optional conv bias) into scale/shift:
+ * scale = gamma/sqrt(var+eps), shift = beta + (bias-mean)*scale     (rpn.py:128-140, eps 1e-3) */
+int pn_fold_bn_f32(const float *gamma, const float *beta, const float *mean, const float *var,
+                   const float *conv_bias, float eps, int c, float *scale, float *shift,
+                   pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * GroupNorm family on NHWC maps: statistics over {channel block} x {all theta} x {range
+ * stratum}; covers
+ *   RSNorm(num_heads, num_groups, C)      det3d/models/utils/norm.py:58-75
+ *   nn.GroupNorm(G, C)                    center_head_parallel.py:148,160,174
+ *   the GroupNorm inside RangeStratified  center_head_parallel.py:36-41
+ * channel_groups: number of contiguous channel blocks; range_strata: number of equal
+ * slices of the x (range) axis.  gamma/beta are indexed [stratum*C + c] (the stacked-channel
+ * order the reference builds with torch.cat) and have range_strata*C entries.
+ * out = act(norm(x)*gamma+beta); if mul/add != NULL (1,H,W,C maps) a second output
+ * out2 = out*mul + add is written (feature undistortion, center_head_parallel.py:268).
+ */
+size_t pn_groupnorm_workspace_bytes(int batch, int channel_groups, int range_strata);
+int pn_groupnorm_strat_fwd(const float *x, int batch, int h, int w, int c, int pixel_stride,
+                           int channel_offset, int channel_groups, int range_strata,
+                           const float *gamma, const float *beta, float eps, int act, float *out,
+                           int out_pixel_stride, int out_channel_offset, const float *mul,
+                           const float *add, float *out2, void *workspace, size_t workspace_bytes,
+                           pn_stream_t stream);
+
+/* layout helpers at the API boundary */
+int pn_nchw_to_nhwc_f32(const float *in, int b, int c, int h, int w, float *out, pn_stream_t stream);
+int pn_nhwc_to_nchw_f32(const float *in, int b, int c, int h, int w, int pixel_stride,
+                        int channel_offset, float *out, pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * timing helper: HIP events on `stream`, used by bench.py for the roofline object.
+ */
+typedef void *pn_event_t;
+int pn_event_create(pn_event_t *ev);
+int pn_event_destroy(pn_event_t ev);
+int pn_event_record(pn_event_t ev, pn_stream_t stream);
+int pn_event_elapsed_ms(pn_event_t start, pn_event_t stop, float *ms); /* synchronises on stop */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARTNER_HIP_H */

@@ -1,0 +1,432 @@
+// BEV 2-D convolutions as implicit GEMM on the gfx950 fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain, 64 FLOP/clk/SIMD).
+//
+// GEMM view (per group / range stratum z):
+//   Out[m][n] = sum_k A[m][k] * Wp[k][n]
+//   m = output pixel (b, oh, ow)  -- NHWC pixel order
+//   n = output channel (or (di,dj,n) for the 2x2 transposed conv)
+//   k = (kh, kw, cin)             -- cin fastest, 32 channels of one tap per K step
+//
+// Block = WM x WN waves; each wave owns TM x TN MFMA tiles of 32x32.  Per K step the block
+// stages a [BM pixels][32 ch] activation tile (zero-filled outside the map: this is the
+// ZeroPad2d / padding=1 of rpn.py:126-134) and a [32][BN] weight tile through LDS, register
+// staged and double buffered (loads of step t+1 are in flight while step t is on the MFMA
+// pipe; one barrier per step).
+//
+// LDS images
+//   A: [BM][36] floats (rows padded by 4 floats = one ds_read_b128 width): lane (i = l&31,
+//      h = l>>5) reads the float4 at row i, k = 8s+4h; 36*i mod 64 hits 16 distinct 4-bank
+//      slots for 16 rows that are distinct mod 16 => conflict-free ds_read_b128.
+//   B: [8][BN][4] floats -- the packed global layout, so staging is a straight copy and lane
+//      (h, j) reads the float4 at k4 = 2s+h, column j: consecutive lanes, consecutive 16 B.
+// k order inside an 8-wide k group: MFMA j (0..3) consumes k = 8s+j from lane half 0 and
+// k = 8s+4+j from lane half 1, for A and B alike (the sum is order independent up to fp32
+// rounding).
+#include "pn_common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+enum { MODE_CONV = 0, MODE_DECONV2 = 1, MODE_STRAT = 2 };
+
+struct ConvArgs {
+  const float* in;
+  const float* w;
+  const float* scale;
+  const float* shift;
+  float* out;
+  int B, H, W, Cin, Cout, OH, OW;
+  int KH, KW, stride, pad_h, pad_w;
+  int in_ps, in_co, out_ps, out_co;
+  int act, mode;
+  int M;           // GEMM rows per z
+  int OWsub;       // output columns per z window (OW unless stratified)
+  int cin_chunks;  // ceil(Cin/32)
+  int cout_pad;    // packed column count (multiple of 32)
+  int ncols;       // GEMM columns per z
+  int nmt;         // m tiles
+  int in_group_stride;   // input-channel offset per z (Cin for grouped conv, 0 otherwise)
+};
+
+constexpr int BK = 32;
+constexpr int A_LD = BK + 4;
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  constexpr int A_FLOATS = BM * A_LD;
+  constexpr int B_FLOATS = BK * BN;
+  constexpr int STAGE = A_FLOATS + B_FLOATS;
+  constexpr int A_PER_T = (BM * 8) / NT;  // float4 per thread
+  constexpr int B_PER_T = (8 * BN) / NT;
+  static_assert((BM * 8) % NT == 0 && (8 * BN) % NT == 0, "tile/threads mismatch");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int z = blockIdx.z;
+
+  // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so give each XCD a
+  // contiguous run of m tiles (neighbouring tiles share halo rows in that XCD's L2).
+  int mt;
+  {
+    const int bid = blockIdx.x, q = a.nmt >> 3, r = a.nmt & 7, x = bid & 7;
+    mt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int m0 = mt * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- per-thread A rows ------------------------------------------------------------
+  const int c4 = tid & 7;
+  int a_ih0[A_PER_T], a_iw0[A_PER_T], a_pix[A_PER_T];
+  bool a_ok[A_PER_T];
+  const int ohw = a.OH * a.OWsub;
+#pragma unroll
+  for (int j = 0; j < A_PER_T; ++j) {
+    const int row = (tid >> 3) + (NT / 8) * j;
+    const int m = m0 + row;
+    a_ok[j] = m < a.M;
+    const int mm = a_ok[j] ? m : 0;
+    const int b = mm / ohw;
+    const int rem = mm - b * ohw;
+    const int oh = rem / a.OWsub;
+    const int ow = rem - oh * a.OWsub + (a.mode == MODE_STRAT ? z * a.OWsub : 0);
+    a_ih0[j] = oh * a.stride - a.pad_h;
+    a_iw0[j] = ow * a.stride - a.pad_w;
+    a_pix[j] = (b * a.H + a_ih0[j]) * a.W + a_iw0[j];
+  }
+  const float* in_base = a.in + a.in_co + z * a.in_group_stride + c4 * 4;
+  const int taps = a.KH * a.KW;
+  const float* w_base = a.w + (size_t)z * taps * (a.cin_chunks * BK) * a.cout_pad;
+  const int nsteps = taps * a.cin_chunks;
+
+  f32x4 ra[A_PER_T], rb[B_PER_T];
+
+  auto load_global = [&](int t) {
+    const int tap = t / a.cin_chunks;
+    const int chunk = t - tap * a.cin_chunks;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const bool cok = chunk * BK + c4 * 4 < a.Cin;
+#pragma unroll
+    for (int j = 0; j < A_PER_T; ++j) {
+      const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
+      const bool ok = a_ok[j] && cok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const float* p = in_base + (size_t)(a_pix[j] + kh * a.W + kw) * a.in_ps + chunk * BK;
+        v = *reinterpret_cast<const f32x4*>(p);
+      }
+      ra[j] = v;
+    }
+    const float* wt = w_base + ((size_t)(tap * a.cin_chunks + chunk) * 8) * a.cout_pad * 4;
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j) {
+      const int idx = tid + NT * j;
+      const int k4 = idx / BN, n = idx - k4 * BN;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n0 + n < a.cout_pad) v = *reinterpret_cast<const f32x4*>(wt + ((size_t)k4 * a.cout_pad + n0 + n) * 4);
+      rb[j] = v;
+    }
+  };
+  auto store_lds = [&](int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + A_FLOATS;
+#pragma unroll
+    for (int j = 0; j < A_PER_T; ++j) {
+      const int row = (tid >> 3) + (NT / 8) * j;
+      *reinterpret_cast<f32x4*>(As + row * A_LD + c4 * 4) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j) *reinterpret_cast<f32x4*>(Bs + (tid + NT * j) * 4) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+
+  const int li = lane & 31, lh = lane >> 5;
+  for (int t = 0; t < nsteps; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nsteps) load_global(t + 1);
+    const float* As = smem + buf * STAGE + (wm * TM * 32 + li) * A_LD + lh * 4;
+    const float* Bs = smem + buf * STAGE + A_FLOATS + (lh * BN + wn * TN * 32 + li) * 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * A_LD + s * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + (s * 2 * BN + j * 32) * 4);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nsteps) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: per-channel affine + activation, NHWC store ----------------------------
+  // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int gm = m0 + row;
+      if (gm >= a.M) continue;
+      size_t pix;  // output pixel index (deconv: the top-left of the 2x2 cell)
+      int b = 0, oh = 0, ow = 0;
+      if (a.mode == MODE_CONV) {
+        pix = (size_t)gm;
+      } else {
+        b = gm / ohw;
+        const int rem = gm - b * ohw;
+        oh = rem / a.OWsub;
+        ow = rem - oh * a.OWsub + (a.mode == MODE_STRAT ? z * a.OWsub : 0);
+        pix = ((size_t)b * a.OH + oh) * a.OW + ow;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int gn = n0 + wn * TN * 32 + j * 32 + li;
+        if (gn >= a.ncols) continue;
+        int ch = gn, sidx;
+        size_t off;
+        if (a.mode == MODE_DECONV2) {
+          const int d = gn / a.Cout;
+          ch = gn - d * a.Cout;
+          const size_t opix = ((size_t)b * (2 * a.OH) + 2 * oh + (d >> 1)) * (2 * a.OW) + 2 * ow + (d & 1);
+          off = opix * a.out_ps + a.out_co + ch;
+          sidx = ch;
+        } else {
+          off = pix * a.out_ps + a.out_co + (a.mode == MODE_CONV ? z * a.Cout : 0) + ch;
+          sidx = z * a.Cout + ch;
+        }
+        float v = acc[i][j][r];
+        const float sc = a.scale ? a.scale[sidx] : 1.f;
+        const float sh = a.shift ? a.shift[sidx] : 0.f;
+        v = pn::apply_act(fmaf(v, sc, sh), a.act);
+        a.out[off] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing: torch (Cout_total, Cin_g, KH, KW) -> [g][tap][cin_pad/4][cout_pad][4]
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int cout_g, int cin_g, int kh, int kw,
+                                        int groups, int cin_pad, int cout_pad, float* __restrict__ packed, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int k1 = r & 3;
+    r >>= 2;
+    const int n = r % cout_pad;
+    r /= cout_pad;
+    const int k4 = r % (cin_pad / 4);
+    r /= (cin_pad / 4);
+    const int tap = r % (kh * kw);
+    const int g = (int)(r / (kh * kw));
+    const int c = k4 * 4 + k1;
+    float v = 0.f;
+    if (n < cout_g && c < cin_g) v = w[(((size_t)(g * cout_g + n) * cin_g + c) * kh + tap / kw) * kw + tap % kw];
+    packed[i] = v;
+  }
+}
+
+// ConvTranspose2d weight (Cin, Cout, 2, 2) -> 1x1 packed with columns (d = di*2+dj, n)
+__global__ void pack_deconv_weight_kernel(const float* __restrict__ w, int cin, int cout, int cin_pad, int cout_pad,
+                                          float* __restrict__ packed, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int k1 = r & 3;
+    r >>= 2;
+    const int col = r % cout_pad;
+    const int k4 = (int)(r / cout_pad);
+    const int c = k4 * 4 + k1;
+    float v = 0.f;
+    if (col < 4 * cout && c < cin) {
+      const int d = col / cout, n = col - d * cout;
+      v = w[((size_t)c * cout + n) * 4 + d];
+    }
+    packed[i] = v;
+  }
+}
+
+__global__ void fold_bn_kernel(const float* gamma, const float* beta, const float* mean, const float* var,
+                               const float* bias, float eps, int c, float* scale, float* shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const float s = gamma[i] / sqrtf(var[i] + eps);
+  scale[i] = s;
+  shift[i] = beta[i] + ((bias ? bias[i] : 0.f) - mean[i]) * s;
+}
+
+// direct convolution, one thread per output element (load-time constant folding / cross-check)
+__global__ void conv_direct_kernel(ConvArgs a, const float* __restrict__ w_oihw, int groups, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int n = r % (a.Cout * groups);
+    r /= (a.Cout * groups);
+    const int ow = r % a.OW;
+    r /= a.OW;
+    const int oh = r % a.OH;
+    const int b = (int)(r / a.OH);
+    const int g = n / a.Cout;
+    float acc = 0.f;
+    for (int kh = 0; kh < a.KH; ++kh) {
+      const int ih = oh * a.stride - a.pad_h + kh;
+      if ((unsigned)ih >= (unsigned)a.H) continue;
+      for (int kw = 0; kw < a.KW; ++kw) {
+        const int iw = ow * a.stride - a.pad_w + kw;
+        if ((unsigned)iw >= (unsigned)a.W) continue;
+        const float* ip = a.in + ((size_t)(b * a.H + ih) * a.W + iw) * a.in_ps + a.in_co + g * a.Cin;
+        const float* wp = w_oihw + (size_t)n * a.Cin * a.KH * a.KW + kh * a.KW + kw;
+        for (int c = 0; c < a.Cin; ++c) acc = fmaf(ip[c], wp[(size_t)c * a.KH * a.KW], acc);
+      }
+    }
+    const float sc = a.scale ? a.scale[n] : 1.f, sh = a.shift ? a.shift[n] : 0.f;
+    a.out[((size_t)(b * a.OH + oh) * a.OW + ow) * a.out_ps + a.out_co + n] = pn::apply_act(fmaf(acc, sc, sh), a.act);
+  }
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_conv(const ConvArgs& a, int zdim, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t smem = 2 * (size_t)(BM * A_LD + BK * BN) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  ConvArgs b = a;
+  b.nmt = pn::cdiv(a.M, BM);
+  dim3 grid(b.nmt, pn::cdiv(a.ncols, BN), zdim);
+  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN>), grid, dim3(WM * WN * 64), smem, st, b);
+  return pn::check_launch("conv_mfma_kernel");
+}
+
+int fill_args(const pn_conv_desc* d, ConvArgs& a, int& zdim) {
+  PN_REQUIRE(d != nullptr, "conv: null descriptor");
+  PN_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0, "conv: bad sizes");
+  PN_REQUIRE(d->groups >= 1 && d->kh >= 1 && d->kw >= 1 && d->stride >= 1, "conv: bad kernel params");
+  a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Cin = d->cin; a.Cout = d->cout;
+  a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
+  a.OH = (d->in_h + 2 * d->pad_h - d->kh) / d->stride + 1;
+  a.OW = (d->in_w + 2 * d->pad_w - d->kw) / d->stride + 1;
+  PN_REQUIRE(a.OH > 0 && a.OW > 0, "conv: empty output");
+  a.in_ps = d->in_pixel_stride; a.in_co = d->in_channel_offset;
+  a.out_ps = d->out_pixel_stride; a.out_co = d->out_channel_offset;
+  a.act = d->act;
+  a.mode = MODE_CONV; a.OWsub = a.OW; a.ncols = d->cout; a.in_group_stride = d->groups > 1 ? d->cin : 0;
+  zdim = d->groups;
+  if (d->deconv2x2) {
+    PN_REQUIRE(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->groups == 1,
+               "conv: deconv2x2 wants kh=kw=stride=1, pad=0, groups=1");
+    a.mode = MODE_DECONV2; a.ncols = 4 * d->cout;
+  }
+  if (d->range_strata > 1) {
+    PN_REQUIRE(d->groups == 1 && !d->deconv2x2, "conv: range_strata needs groups=1 and no deconv");
+    PN_REQUIRE(a.OW % d->range_strata == 0 && d->stride == 1, "conv: range axis not divisible into strata");
+    a.mode = MODE_STRAT; a.OWsub = a.OW / d->range_strata; zdim = d->range_strata; a.in_group_stride = 0;
+  }
+  a.M = d->batch * a.OH * a.OWsub;
+  a.cin_chunks = pn::cdiv(d->cin, BK);
+  a.cout_pad = pn::cdiv(a.ncols, 32) * 32;
+  return PN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pn_conv_packed_weight_floats(int cout, int cin, int kh, int kw, int groups) {
+  return (size_t)groups * kh * kw * (size_t)(pn::cdiv(cin, BK) * BK) * (size_t)(pn::cdiv(cout, 32) * 32);
+}
+
+int pn_pack_conv_weight_f32(const float* w_oihw, int cout_total, int cin_per_group, int kh, int kw, int groups,
+                            float* packed, pn_stream_t stream) {
+  PN_REQUIRE(w_oihw && packed && groups >= 1 && cout_total % groups == 0, "pack_conv_weight: bad arguments");
+  const int cout_g = cout_total / groups;
+  const int cin_pad = pn::cdiv(cin_per_group, BK) * BK, cout_pad = pn::cdiv(cout_g, 32) * 32;
+  const size_t total = pn_conv_packed_weight_floats(cout_g, cin_per_group, kh, kw, groups);
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0,
+                     pn::S(stream), w_oihw, cout_g, cin_per_group, kh, kw, groups, cin_pad, cout_pad, packed, total);
+  return pn::check_launch("pack_conv_weight_kernel");
+}
+
+size_t pn_deconv2x2_packed_weight_floats(int cin, int cout) {
+  return (size_t)(pn::cdiv(cin, BK) * BK) * (size_t)(pn::cdiv(4 * cout, 32) * 32);
+}
+
+int pn_pack_deconv2x2_weight_f32(const float* w_iohw, int cin, int cout, float* packed, pn_stream_t stream) {
+  PN_REQUIRE(w_iohw && packed && cin > 0 && cout > 0, "pack_deconv_weight: bad arguments");
+  const int cin_pad = pn::cdiv(cin, BK) * BK, cout_pad = pn::cdiv(4 * cout, 32) * 32;
+  const size_t total = (size_t)cin_pad * cout_pad;
+  hipLaunchKernelGGL(pack_deconv_weight_kernel, dim3(std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0,
+                     pn::S(stream), w_iohw, cin, cout, cin_pad, cout_pad, packed, total);
+  return pn::check_launch("pack_deconv_weight_kernel");
+}
+
+int pn_fold_bn_f32(const float* gamma, const float* beta, const float* mean, const float* var, const float* conv_bias,
+                   float eps, int c, float* scale, float* shift, pn_stream_t stream) {
+  PN_REQUIRE(gamma && beta && mean && var && scale && shift && c > 0, "fold_bn: bad arguments");
+  hipLaunchKernelGGL(fold_bn_kernel, dim3(pn::cdiv(c, 256)), dim3(256), 0, pn::S(stream), gamma, beta, mean, var,
+                     conv_bias, eps, c, scale, shift);
+  return pn::check_launch("fold_bn_kernel");
+}
+
+int pn_conv2d_nhwc_f32(const pn_conv_desc* d, const float* in, const float* packed_w, const float* scale,
+                       const float* shift, float* out, pn_stream_t stream) {
+  ConvArgs a;
+  int zdim = 1;
+  if (int rc = fill_args(d, a, zdim)) return rc;
+  PN_REQUIRE(in && packed_w && out, "conv: null pointer");
+  PN_REQUIRE(d->cin % 4 == 0 && d->in_pixel_stride % 4 == 0 && d->in_channel_offset % 4 == 0,
+             "conv: MFMA path needs cin, input pixel stride and channel offset to be multiples of 4 "
+             "(use pn_conv2d_direct_nhwc_f32)");
+  PN_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "conv: pointers must be 16-byte aligned");
+  a.in = in; a.w = packed_w; a.scale = scale; a.shift = shift; a.out = out;
+  hipStream_t st = pn::S(stream);
+  const long long tiles128 = (long long)pn::cdiv(a.M, 128) * pn::cdiv(a.ncols, 128) * zdim;
+  if (a.ncols > 64) {
+    if (tiles128 >= 384) return launch_conv<2, 2, 2, 2>(a, zdim, st);            // 128 x 128
+    if ((long long)pn::cdiv(a.M, 64) * pn::cdiv(a.ncols, 128) * zdim >= 256) return launch_conv<2, 2, 1, 2>(a, zdim, st);  // 64 x 128
+    return launch_conv<2, 2, 1, 1>(a, zdim, st);                                // 64 x 64
+  }
+  if (a.ncols > 32) return launch_conv<2, 2, 1, 1>(a, zdim, st);                // 64 x 64
+  return launch_conv<2, 1, 1, 1>(a, zdim, st);                                  // 64 x 32
+}
+
+int pn_conv2d_direct_nhwc_f32(const pn_conv_desc* d, const float* in, const float* w_oihw, const float* scale,
+                              const float* shift, float* out, pn_stream_t stream) {
+  ConvArgs a;
+  int zdim = 1;
+  if (int rc = fill_args(d, a, zdim)) return rc;
+  PN_REQUIRE(in && w_oihw && out, "conv_direct: null pointer");
+  PN_REQUIRE(!d->deconv2x2 && d->range_strata <= 1, "conv_direct: plain (grouped) convolutions only");
+  a.in = in; a.w = nullptr; a.scale = scale; a.shift = shift; a.out = out;
+  const size_t total = (size_t)a.B * a.OH * a.OW * a.Cout * d->groups;
+  hipLaunchKernelGGL(conv_direct_kernel, dim3(std::min<size_t>(65535, (total + 255) / 256)), dim3(256), 0,
+                     pn::S(stream), a, w_oihw, d->groups, total);
+  return pn::check_launch("conv_direct_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,241 @@
+// Per-voxel reductions and the dynamic pillar feature net.
+//
+// Points are bucketed by voxel rank (voxel_start / order from pn_bucket_points), so one
+// wavefront owns a voxel's whole run of points: no float atomics anywhere.
+//   * means: every addend is converted to 2^-24 fixed point (exact for |x| >= 1, half-ulp of
+//     2^-24 below) and summed as int64 -> the sum does not depend on the order of the run,
+//     results are bitwise reproducible and closer to the exact mean than an fp32 running sum.
+//   * max:   order independent by nature.
+// PFN mapping: lane = output channel.  The 16-channel decoration of the current point is
+// wave-uniform; weights sit transposed in LDS ([k][n], consecutive lanes -> consecutive
+// banks), the layer-0 activations of the current point go through a per-wave LDS row and are
+// read back as broadcasts.
+#include "pn_common.h"
+
+namespace {
+
+constexpr double kFix = 16777216.0;  // 2^24
+
+__device__ __forceinline__ long long to_fix(float v) { return (long long)rintf(v * 16777216.0f); }
+
+// ------------------------------------------------------------------------------- V3
+__global__ void scatter_mean_kernel(const float* __restrict__ pts, int stride, int f, const int32_t* __restrict__ vstart,
+                                    const int32_t* __restrict__ order, const int32_t* __restrict__ v_dev, int v_cap,
+                                    float* __restrict__ mean) {
+  const int V = min(*v_dev, v_cap);
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int v = wave; v < V; v += nwaves) {
+    const int s = vstart[v], e = vstart[v + 1];
+    for (int k0 = 0; k0 < f; k0 += 8) {
+      long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = s + lane; i < e; i += 64) {
+        const float* p = pts + (size_t)order[i] * stride + k0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k0 + k < f) acc[k] += to_fix(p[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const long long t = pn::wave_sum(acc[k]);
+        if (lane == k && k0 + k < f) mean[(size_t)v * f + k0 + k] = (float)((double)t / kFix / (double)(e - s));
+      }
+    }
+  }
+}
+
+__global__ void hard_voxel_mean_kernel(const float* __restrict__ vox, const int32_t* __restrict__ num, int v, int p, int f,
+                                       float* __restrict__ mean) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= v * f) return;
+  const int vi = i / f, k = i - vi * f;
+  float s = 0.f;
+  for (int j = 0; j < p; ++j) s += vox[((size_t)vi * p + j) * f + k];  // sequential fp32 sum == torch.sum over dim 1
+  mean[i] = s / (float)num[vi];
+}
+
+// ------------------------------------------------------------------------------- V4 (+V5)
+struct PfnArgs {
+  const float* pts;
+  int stride;
+  const int32_t* vstart;
+  const int32_t* order;
+  const int32_t* v_dev;
+  int v_cap;
+  const uint32_t* ukeys;
+  int R, T, Z;
+  const float* w0;
+  int c0;
+  const float* w1;
+  int c1;
+  float vx, vy, xoff, yoff;
+  float* feat;
+  float* canvas;
+};
+
+constexpr int kPfnWaves = 4;
+
+__global__ __launch_bounds__(kPfnWaves * 64) void dynamic_pfn_kernel(PfnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int c0 = a.c0, c1 = a.c1;
+  float* w0t = lds;                 // [16][c0]
+  float* w1t = w0t + 16 * c0;       // [2*c0][c1]
+  float* rows = w1t + 2 * c0 * c1;  // per wave: [64] layer-0 activations / maxima
+  for (int i = threadIdx.x; i < 16 * c0; i += blockDim.x) {
+    const int k = i / c0, n = i - k * c0;
+    w0t[i] = a.w0[n * 16 + k];
+  }
+  for (int i = threadIdx.x; i < 2 * c0 * c1; i += blockDim.x) {
+    const int k = i / c1, n = i - k * c1;
+    w1t[i] = a.w1[n * 2 * c0 + k];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  float* row = rows + wib * 64;
+  const int V = min(*a.v_dev, a.v_cap);
+  const int wave = blockIdx.x * kPfnWaves + wib;
+  const int nwaves = gridDim.x * kPfnWaves;
+  const bool two = c1 > 64;  // second output channel per lane
+
+  for (int v = wave; v < V; v += nwaves) {
+    const int s = a.vstart[v], e = a.vstart[v + 1];
+    uint32_t key = a.ukeys[v];
+    const int ri = key % a.R; key /= a.R;
+    const int ti = key % a.T; key /= a.T;
+    const int bi = key / a.Z;
+    // ---- voxel means of (x, y, z, rho, phi), fixed point ---------------------------------
+    long long sx = 0, sy = 0, sz = 0, sr = 0, sp = 0;
+    for (int i = s + lane; i < e; i += 64) {
+      const float* p = a.pts + (size_t)a.order[i] * a.stride;
+      sr += to_fix(p[0]); sp += to_fix(p[1]); sz += to_fix(p[2]); sx += to_fix(p[3]); sy += to_fix(p[4]);
+    }
+    const double inv_n = 1.0 / ((double)(e - s) * kFix);
+    const float mx = (float)((double)pn::wave_sum(sx) * inv_n), my = (float)((double)pn::wave_sum(sy) * inv_n);
+    const float mz = (float)((double)pn::wave_sum(sz) * inv_n), mr = (float)((double)pn::wave_sum(sr) * inv_n);
+    const float mp = (float)((double)pn::wave_sum(sp) * inv_n);
+    // pillar centre in polar and Cartesian coordinates (pillar_encoder.py:350-351,365)
+    const float rc = __fadd_rn(__fmul_rn((float)ri, a.vx), a.xoff);
+    const float pc = __fadd_rn(__fmul_rn((float)ti, a.vy), a.yoff);
+    const float xc = __fmul_rn(rc, cosf(pc)), yc = __fmul_rn(rc, sinf(pc));
+
+    auto layer0 = [&](const float* p) -> float {
+      // 16-channel decoration of one point, then row `lane` of Linear(16 -> c0) + ReLU
+      const float rho = p[0], phi = p[1], z = p[2], x = p[3], y = p[4];
+      const float d[16] = {rho, phi, z, x, y, p[5], p[6], x - mx, y - my, z - mz, x - xc, y - yc,
+                           rho - mr, phi - mp, rho - rc, phi - pc};
+      float h = 0.f;
+      if (lane < c0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) h = fmaf(w0t[k * c0 + lane], d[k], h);
+      }
+      return h > 0.f ? h : 0.f;
+    };
+
+    // ---- pass 1: per-voxel maximum of the layer-0 activations -----------------------------
+    float m0 = 0.f;  // ReLU output is >= 0
+    for (int i = s; i < e; ++i) m0 = fmaxf(m0, layer0(a.pts + (size_t)a.order[i] * a.stride));
+    // voxel-constant half of layer 1: g[n] = sum_c W1[n][c0 + c] * m0[c]
+    row[lane] = m0;
+    float g0 = 0.f, g1 = 0.f;
+    for (int c = 0; c < c0; ++c) {
+      const float m = row[c];
+      if (lane < c1) g0 = fmaf(w1t[(c0 + c) * c1 + lane], m, g0);
+      if (two && lane + 64 < c1) g1 = fmaf(w1t[(c0 + c) * c1 + lane + 64], m, g1);
+    }
+    // ---- pass 2: layer 1 per point, running maximum ---------------------------------------
+    float f0 = 0.f, f1 = 0.f;
+    for (int i = s; i < e; ++i) {
+      const float h = layer0(a.pts + (size_t)a.order[i] * a.stride);
+      row[lane] = h;  // same wave writes and reads: in-order LDS, no barrier needed
+      float y0 = g0, y1 = g1;
+      for (int c = 0; c < c0; ++c) {
+        const float hc = row[c];
+        if (lane < c1) y0 = fmaf(w1t[c * c1 + lane], hc, y0);
+        if (two && lane + 64 < c1) y1 = fmaf(w1t[c * c1 + lane + 64], hc, y1);
+      }
+      f0 = fmaxf(f0, y0);
+      f1 = fmaxf(f1, y1);
+    }
+    if (a.feat) {
+      if (lane < c1) a.feat[(size_t)v * c1 + lane] = f0;
+      if (two && lane + 64 < c1) a.feat[(size_t)v * c1 + lane + 64] = f1;
+    }
+    if (a.canvas) {
+      float* cv = a.canvas + (((size_t)bi * a.T + ti) * a.R + ri) * c1;
+      if (lane < c1) cv[lane] = f0;
+      if (two && lane + 64 < c1) cv[lane + 64] = f1;
+    }
+  }
+}
+
+__global__ void scatter_canvas_kernel(const float* __restrict__ feat, const int64_t* __restrict__ unq,
+                                      const int32_t* __restrict__ v_dev, int v_cap, int c, int T, int R,
+                                      float* __restrict__ canvas) {
+  const int V = min(*v_dev, v_cap);
+  const size_t total = (size_t)V * c;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i / c), k = (int)(i - (size_t)v * c);
+    const int64_t* u = unq + (size_t)v * 4;
+    canvas[(((size_t)u[0] * T + u[2]) * R + u[3]) * c + k] = feat[i];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pn_scatter_mean_f32(const float* points, int point_stride, int f, const int32_t* voxel_start, const int32_t* order,
+                        const int32_t* num_voxels, int v_capacity, float* mean, pn_stream_t stream) {
+  PN_REQUIRE(points && voxel_start && order && num_voxels && mean, "scatter_mean: null pointer");
+  PN_REQUIRE(f >= 1 && point_stride >= f && v_capacity >= 0, "scatter_mean: bad sizes");
+  if (v_capacity == 0) return PN_OK;
+  const int blocks = std::min(2048, pn::cdiv(v_capacity, 4));
+  hipLaunchKernelGGL(scatter_mean_kernel, dim3(blocks), dim3(256), 0, pn::S(stream), points, point_stride, f, voxel_start,
+                     order, num_voxels, v_capacity, mean);
+  return pn::check_launch("scatter_mean_kernel");
+}
+
+int pn_hard_voxel_mean_f32(const float* voxels, const int32_t* num_points, int v, int p, int f, float* mean,
+                           pn_stream_t stream) {
+  PN_REQUIRE(voxels && num_points && mean && v >= 0 && p >= 1 && f >= 1, "hard_voxel_mean: bad arguments");
+  if (v == 0) return PN_OK;
+  hipLaunchKernelGGL(hard_voxel_mean_kernel, dim3(pn::cdiv((long long)v * f, 256)), dim3(256), 0, pn::S(stream), voxels,
+                     num_points, v, p, f, mean);
+  return pn::check_launch("hard_voxel_mean_kernel");
+}
+
+int pn_dynamic_pfn_fwd(const float* points, int point_stride, const int32_t* voxel_start, const int32_t* order,
+                       const int32_t* num_voxels, int v_capacity, const uint32_t* unq_keys, const int32_t* grid,
+                       const float* w0, int c0, const float* w1, int c1, float vx, float vy, float x_offset,
+                       float y_offset, float* features, float* canvas, pn_stream_t stream) {
+  PN_REQUIRE(points && voxel_start && order && num_voxels && unq_keys && grid && w0 && w1, "dynamic_pfn: null pointer");
+  PN_REQUIRE(point_stride >= 7, "dynamic_pfn: points need 7 features [rho,phi,z,x,y,i,t]");
+  PN_REQUIRE(c0 >= 1 && c0 <= 64 && c1 >= 1 && c1 <= 128, "dynamic_pfn: supports C0 <= 64, C1 <= 128");
+  PN_REQUIRE(features || canvas, "dynamic_pfn: no output requested");
+  if (v_capacity == 0) return PN_OK;
+  PfnArgs a{points, point_stride, voxel_start, order, num_voxels, v_capacity, unq_keys, grid[0], grid[1], grid[2],
+            w0, c0, w1, c1, vx, vy, x_offset, y_offset, features, canvas};
+  const size_t smem = (size_t)(16 * c0 + 2 * c0 * c1 + kPfnWaves * 64) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dynamic_pfn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((16 * 64 + 2 * 64 * 128 + kPfnWaves * 64) * sizeof(float)));
+    attr_done = true;
+  }
+  const int blocks = std::max(1, std::min(1024, pn::cdiv(v_capacity, kPfnWaves * 4)));
+  hipLaunchKernelGGL(dynamic_pfn_kernel, dim3(blocks), dim3(kPfnWaves * 64), smem, pn::S(stream), a);
+  return pn::check_launch("dynamic_pfn_kernel");
+}
+
+int pn_scatter_canvas_fwd(const float* features, const int64_t* unq, const int32_t* num_voxels, int v_capacity, int c,
+                          int t, int r, float* canvas, pn_stream_t stream) {
+  PN_REQUIRE(features && unq && num_voxels && canvas && c >= 1 && t >= 1 && r >= 1, "scatter_canvas: bad arguments");
+  if (v_capacity == 0) return PN_OK;
+  const size_t total = (size_t)v_capacity * c;
+  hipLaunchKernelGGL(scatter_canvas_kernel, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0,
+                     pn::S(stream), features, unq, num_voxels, v_capacity, c, t, r, canvas);
+  return pn::check_launch("scatter_canvas_kernel");
+}
+
+}  // extern "C"

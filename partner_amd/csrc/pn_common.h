@@ -1,0 +1,49 @@
+// Shared helpers for libpartner_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cstdint>
+
+#include "../../include/partner_hip.h"
+
+namespace pn {
+
+// per-thread last error text
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PN_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return PN_OK;
+}
+
+inline hipStream_t S(pn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == PN_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == PN_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+}  // namespace pn
+
+#define PN_REQUIRE(cond, ...) \
+  do {                        \
+    if (!(cond)) return pn::fail(PN_ERR_INVALID, __VA_ARGS__); \
+  } while (0)

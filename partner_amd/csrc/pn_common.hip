@@ -1,0 +1,127 @@
+// Error reporting, device query, HIP-event helpers and small layout kernels of libpartner_hip.
+#include "pn_common.h"
+
+namespace pn {
+
+char* err_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+}  // namespace pn
+
+namespace {
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int c, int hw, float* __restrict__ out, size_t total) {
+  // out index order (b, p, c); 32x32 LDS transpose tiles keep both sides coalesced
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int cc = c0 + i, pp = p0 + threadIdx.x;
+    tile[i][threadIdx.x] = (cc < c && pp < hw) ? in[((size_t)b * c + cc) * hw + pp] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int pp = p0 + i, cc = c0 + threadIdx.x;
+    if (pp < hw && cc < c) out[((size_t)b * hw + pp) * c + cc] = tile[threadIdx.x][i];
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int c, int hw, int ps, int co, float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int pp = p0 + i, cc = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (cc < c && pp < hw) ? in[((size_t)b * hw + pp) * ps + co + cc] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int cc = c0 + i, pp = p0 + threadIdx.x;
+    if (pp < hw && cc < c) out[((size_t)b * c + cc) * hw + pp] = tile[threadIdx.x][i];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pn_version(void) { return 100; }
+
+int pn_last_error(char* buf, size_t buf_len) {
+  const char* e = pn::err_buf();
+  const size_t n = strlen(e);
+  if (buf && buf_len) {
+    const size_t k = n < buf_len - 1 ? n : buf_len - 1;
+    memcpy(buf, e, k);
+    buf[k] = 0;
+  }
+  return (int)n;
+}
+
+int pn_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  return n;
+}
+
+int pn_fill_zero(void* ptr, size_t bytes, pn_stream_t stream) {
+  PN_REQUIRE(ptr || bytes == 0, "fill_zero: null pointer");
+  if (bytes == 0) return PN_OK;
+  hipError_t e = hipMemsetAsync(ptr, 0, bytes, pn::S(stream));
+  if (e != hipSuccess) return pn::fail(PN_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+  return PN_OK;
+}
+
+int pn_nchw_to_nhwc_f32(const float* in, int b, int c, int h, int w, float* out, pn_stream_t stream) {
+  PN_REQUIRE(in && out && b > 0 && c > 0 && h > 0 && w > 0, "nchw_to_nhwc: bad arguments");
+  const int hw = h * w;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(pn::cdiv(hw, 32), pn::cdiv(c, 32), b), dim3(32, 8), 0, pn::S(stream), in,
+                     c, hw, out, (size_t)b * c * hw);
+  return pn::check_launch("nchw_to_nhwc_kernel");
+}
+
+int pn_nhwc_to_nchw_f32(const float* in, int b, int c, int h, int w, int pixel_stride, int channel_offset, float* out,
+                        pn_stream_t stream) {
+  PN_REQUIRE(in && out && b > 0 && c > 0 && h > 0 && w > 0 && pixel_stride >= c, "nhwc_to_nchw: bad arguments");
+  const int hw = h * w;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(pn::cdiv(hw, 32), pn::cdiv(c, 32), b), dim3(32, 8), 0, pn::S(stream), in,
+                     c, hw, pixel_stride, channel_offset, out);
+  return pn::check_launch("nhwc_to_nchw_kernel");
+}
+
+int pn_event_create(pn_event_t* ev) {
+  PN_REQUIRE(ev, "event_create: null");
+  hipEvent_t e;
+  hipError_t rc = hipEventCreate(&e);
+  if (rc != hipSuccess) return pn::fail(PN_ERR_LAUNCH, "hipEventCreate: %s", hipGetErrorString(rc));
+  *ev = e;
+  return PN_OK;
+}
+int pn_event_destroy(pn_event_t ev) {
+  if (ev) hipEventDestroy((hipEvent_t)ev);
+  return PN_OK;
+}
+int pn_event_record(pn_event_t ev, pn_stream_t stream) {
+  hipError_t rc = hipEventRecord((hipEvent_t)ev, pn::S(stream));
+  if (rc != hipSuccess) return pn::fail(PN_ERR_LAUNCH, "hipEventRecord: %s", hipGetErrorString(rc));
+  return PN_OK;
+}
+int pn_event_elapsed_ms(pn_event_t start, pn_event_t stop, float* ms) {
+  PN_REQUIRE(ms, "event_elapsed: null");
+  hipError_t rc = hipEventSynchronize((hipEvent_t)stop);
+  if (rc == hipSuccess) rc = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+  if (rc != hipSuccess) return pn::fail(PN_ERR_LAUNCH, "hipEventElapsedTime: %s", hipGetErrorString(rc));
+  return PN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,357 @@
+// Polar voxelization on the device: point decoration, grid indices, unique voxel ranks.
+//
+// torch.unique(grid_ind, dim=0) returns rows in lexicographic (b,z,theta,r) order, i.e. in
+// increasing linear key ((b*Z+z)*T+theta)*R+r.  The rank of a voxel is therefore the number
+// of occupied cells with a smaller key = an exclusive prefix sum of popcounts over an
+// occupancy bitmap.  No sort, no host synchronisation; the voxel count stays on the device.
+#include "pn_common.h"
+
+namespace {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;  // words per thread
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+// ---------------------------------------------------------------------------- V0
+__global__ void cart_to_polar_kernel(const float* __restrict__ cart, int n, int f_in, float* __restrict__ polar) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = cart + (size_t)i * f_in;
+  float* o = polar + (size_t)i * (f_in + 2);
+  const float x = p[0], y = p[1];
+  // numpy: sqrt(x**2 + y**2) with every fp32 op rounded separately (no FMA contraction)
+  // the fp64 square root rounded once more to fp32 is the correctly rounded fp32 root (53 >= 2*24+2)
+  o[0] = (float)sqrt((double)__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)));
+  o[1] = (float)atan2((double)y, (double)x);
+  o[2] = p[2];
+  o[3] = x;
+  o[4] = y;
+  for (int k = 3; k < f_in; ++k) o[k + 2] = p[k];
+}
+
+// ---------------------------------------------------------------------------- V1
+struct GridParams {
+  float lo[3], vs[3];
+  int g[3];  // R, T, Z
+};
+
+__device__ __forceinline__ int cell_index(float p, float lo, float vs, int g) {
+  // floor(clip((p - lo) / vs, 0, g-1)) with IEEE fp32 subtract and divide
+  // IEEE fp32 quotient via fp64 (double rounding is innocuous for division at 53 >= 2*24+2 bits)
+  float q = (float)((double)__fsub_rn(p, lo) / (double)vs);
+  const float hi = (float)(g - 1);
+  q = q < 0.f ? 0.f : q;  // also maps -0.0 and NaN>... (NaN compares false -> kept, floor(NaN) UB; inputs are NaN-free)
+  q = q > hi ? hi : q;
+  return (int)floorf(q);
+}
+
+__global__ void grid_index_kernel(const float* __restrict__ pts, int stride, int n_cap, const int32_t* __restrict__ offs,
+                                  int batch, GridParams gp, int64_t* __restrict__ grid_ind, uint32_t* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = min(offs[batch], n_cap);
+  if (i >= n) return;
+  int b = 0;
+  while (b + 1 < batch && i >= offs[b + 1]) ++b;
+  const float* p = pts + (size_t)i * stride;
+  const int r = cell_index(p[0], gp.lo[0], gp.vs[0], gp.g[0]);
+  const int t = cell_index(p[1], gp.lo[1], gp.vs[1], gp.g[1]);
+  const int z = cell_index(p[2], gp.lo[2], gp.vs[2], gp.g[2]);
+  if (grid_ind) {
+    int64_t* o = grid_ind + (size_t)i * 4;
+    o[0] = b; o[1] = z; o[2] = t; o[3] = r;
+  }
+  if (keys) keys[i] = (uint32_t)((((size_t)b * gp.g[2] + z) * gp.g[1] + t) * gp.g[0] + r);
+}
+
+__global__ void keys_from_grid_ind_kernel(const int64_t* __restrict__ gi, int n, int R, int T, int Z, int batch,
+                                          uint32_t* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t* g = gi + (size_t)i * 4;
+  // clamp defensively: an out-of-grid index must not write outside the bitmap
+  const int64_t b = min(max(g[0], (int64_t)0), (int64_t)batch - 1), z = min(max(g[1], (int64_t)0), (int64_t)Z - 1);
+  const int64_t t = min(max(g[2], (int64_t)0), (int64_t)T - 1), r = min(max(g[3], (int64_t)0), (int64_t)R - 1);
+  keys[i] = (uint32_t)(((b * Z + z) * T + t) * R + r);
+}
+
+// ---------------------------------------------------------------------------- bitmap unique
+__global__ void mark_kernel(const uint32_t* __restrict__ keys, int n_cap, const int32_t* __restrict__ n_dev,
+                            uint32_t* __restrict__ bitmap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = n_dev ? min(*n_dev, n_cap) : n_cap;
+  if (i >= n) return;
+  const uint32_t k = keys[i];
+  atomicOr(&bitmap[k >> 5], 1u << (k & 31));
+}
+
+// block-wide exclusive scan of one value per thread (256 threads = 4 waves); returns the
+// exclusive prefix and leaves the block total in *total.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
+  __shared__ uint32_t wsum[kScanThreads / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kScanThreads / 64; ++k) {
+    if (k < w) base += wsum[k];
+    tot += wsum[k];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// phase 1: per-tile totals.  MODE 0: popcount of bitmap words; MODE 1: values of an int array
+// limited to the first *limit entries.
+template <int MODE>
+__device__ __forceinline__ uint32_t scan_item(const uint32_t* __restrict__ src, size_t idx, size_t n, uint32_t limit) {
+  if (idx >= n) return 0;
+  if (MODE == 0) return __popc(src[idx]);
+  return idx < limit ? src[idx] : 0u;
+}
+
+template <int MODE>
+__global__ void scan_tile_totals_kernel(const uint32_t* __restrict__ src, size_t n, const int32_t* __restrict__ limit_dev,
+                                        uint32_t* __restrict__ tile_total) {
+  const uint32_t limit = limit_dev ? (uint32_t)*limit_dev : 0xffffffffu;
+  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) s += scan_item<MODE>(src, base + k, n, limit);
+  uint32_t tot;
+  block_exclusive_scan(s, &tot);
+  if (threadIdx.x == 0) tile_total[blockIdx.x] = tot;
+}
+
+// phase 2: one block scans the tile totals in place (exclusive) and publishes the grand total
+__global__ void scan_tile_offsets_kernel(uint32_t* __restrict__ tile_total, int ntiles, int32_t* __restrict__ grand_total,
+                                         int32_t* __restrict__ grand_total2) {
+  uint32_t carry = 0;
+  for (int base = 0; base < ntiles; base += kScanThreads) {
+    const int i = base + threadIdx.x;
+    const uint32_t v = i < ntiles ? tile_total[i] : 0;
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_scan(v, &tot);
+    if (i < ntiles) tile_total[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    if (grand_total) *grand_total = (int32_t)carry;
+    if (grand_total2) *grand_total2 = (int32_t)carry;
+  }
+}
+
+// phase 3 (bitmap): word ranks + one output row per occupied cell
+__global__ void scan_emit_voxels_kernel(const uint32_t* __restrict__ bitmap, size_t nwords,
+                                        const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ word_rank,
+                                        uint32_t* __restrict__ unq_keys, int64_t* __restrict__ unq, int R, int T, int Z,
+                                        int v_cap) {
+  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
+  uint32_t words[kScanItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    words[k] = base + k < nwords ? bitmap[base + k] : 0u;
+    s += __popc(words[k]);
+  }
+  uint32_t tot;
+  uint32_t rank = tile_offset[blockIdx.x] + block_exclusive_scan(s, &tot);
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k >= nwords) break;
+    word_rank[base + k] = rank;
+    uint32_t wbits = words[k];
+    while (wbits) {
+      const int bit = __ffs(wbits) - 1;
+      wbits &= wbits - 1;
+      const uint32_t key = (uint32_t)((base + k) * 32 + bit);
+      if ((int)rank < v_cap) {
+        unq_keys[rank] = key;
+        if (unq) {
+          int64_t* o = unq + (size_t)rank * 4;
+          uint32_t q = key;
+          o[3] = q % R; q /= R;
+          o[2] = q % T; q /= T;
+          o[1] = q % Z; q /= Z;
+          o[0] = q;
+        }
+      }
+      ++rank;
+    }
+  }
+}
+
+__global__ void rank_points_kernel(const uint32_t* __restrict__ keys, int n_cap, const int32_t* __restrict__ n_dev,
+                                   const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_rank,
+                                   int32_t* __restrict__ inv, int32_t* __restrict__ cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = n_dev ? min(*n_dev, n_cap) : n_cap;
+  if (i >= n) return;
+  const uint32_t k = keys[i];
+  const uint32_t w = k >> 5, bit = k & 31;
+  const int32_t r = (int32_t)(word_rank[w] + __popc(bitmap[w] & ((1u << bit) - 1u)));
+  inv[i] = r;
+  atomicAdd(&cnt[r], 1);
+}
+
+// phase 3 (counts): voxel_start = exclusive scan of unq_cnt, voxel_start[V] = n
+__global__ void scan_emit_starts_kernel(const uint32_t* __restrict__ cnt, size_t n_cap, const int32_t* __restrict__ v_dev,
+                                        const uint32_t* __restrict__ tile_offset, int32_t* __restrict__ voxel_start) {
+  const uint32_t V = (uint32_t)*v_dev;
+  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
+  uint32_t vals[kScanItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    vals[k] = scan_item<1>(cnt, base + k, n_cap, V);
+    s += vals[k];
+  }
+  uint32_t tot;
+  uint32_t run = tile_offset[blockIdx.x] + block_exclusive_scan(s, &tot);
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k <= V && base + k <= n_cap) voxel_start[base + k] = (int32_t)run;
+    run += vals[k];
+  }
+}
+
+__global__ void bucket_fill_kernel(const int32_t* __restrict__ inv, int n_cap, const int32_t* __restrict__ n_dev,
+                                   const int32_t* __restrict__ voxel_start, int32_t* __restrict__ cursor,
+                                   int32_t* __restrict__ order) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = n_dev ? min(*n_dev, n_cap) : n_cap;
+  if (i >= n) return;
+  const int v = inv[i];
+  order[voxel_start[v] + atomicAdd(&cursor[v], 1)] = i;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct UniqueWs {
+  size_t nwords, ntiles;
+  size_t off_bitmap, off_rank, off_tiles, off_keys, total;
+  UniqueWs(uint64_t cells, int n_cap) {
+    nwords = (size_t)((cells + 31) / 32);
+    ntiles = (nwords + kScanTile - 1) / kScanTile;
+    off_bitmap = 0;
+    off_rank = align256(off_bitmap + nwords * 4);
+    off_tiles = align256(off_rank + nwords * 4);
+    off_keys = align256(off_tiles + ntiles * 4);
+    total = align256(off_keys + (size_t)n_cap * 4);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int pn_cart_to_polar_f32(const float* cart, int n, int f_in, float* polar, pn_stream_t stream) {
+  PN_REQUIRE(cart && polar && n >= 0 && f_in >= 3, "cart_to_polar: bad arguments");
+  if (n == 0) return PN_OK;
+  hipLaunchKernelGGL(cart_to_polar_kernel, dim3(pn::cdiv(n, 256)), dim3(256), 0, pn::S(stream), cart, n, f_in, polar);
+  return pn::check_launch("cart_to_polar_kernel");
+}
+
+int pn_polar_grid_index_f32(const float* points, int point_stride, int n_capacity, const int32_t* sample_offsets,
+                            int batch, const float* range_lo, const float* voxel_size, const int32_t* grid,
+                            int64_t* grid_ind, uint32_t* keys, pn_stream_t stream) {
+  PN_REQUIRE(points && sample_offsets && range_lo && voxel_size && grid, "grid_index: null pointer");
+  PN_REQUIRE(point_stride >= 3 && n_capacity >= 0 && batch >= 1, "grid_index: bad sizes");
+  PN_REQUIRE((uint64_t)batch * grid[0] * grid[1] * grid[2] < (1ull << 32), "grid_index: more than 2^32 cells");
+  if (n_capacity == 0) return PN_OK;
+  GridParams gp;
+  for (int k = 0; k < 3; ++k) {
+    gp.lo[k] = range_lo[k];
+    gp.vs[k] = voxel_size[k];
+    gp.g[k] = grid[k];
+  }
+  hipLaunchKernelGGL(grid_index_kernel, dim3(pn::cdiv(n_capacity, 256)), dim3(256), 0, pn::S(stream), points,
+                     point_stride, n_capacity, sample_offsets, batch, gp, grid_ind, keys);
+  return pn::check_launch("grid_index_kernel");
+}
+
+int pn_keys_from_grid_ind(const int64_t* grid_ind, int n, const int32_t* grid, int batch, uint32_t* keys,
+                          pn_stream_t stream) {
+  PN_REQUIRE(grid_ind && grid && keys && n >= 0 && batch >= 1, "keys_from_grid_ind: bad arguments");
+  PN_REQUIRE((uint64_t)batch * grid[0] * grid[1] * grid[2] < (1ull << 32), "keys_from_grid_ind: more than 2^32 cells");
+  if (n == 0) return PN_OK;
+  hipLaunchKernelGGL(keys_from_grid_ind_kernel, dim3(pn::cdiv(n, 256)), dim3(256), 0, pn::S(stream), grid_ind, n,
+                     grid[0], grid[1], grid[2], batch, keys);
+  return pn::check_launch("keys_from_grid_ind_kernel");
+}
+
+size_t pn_unique_workspace_bytes(uint64_t num_cells, int n_capacity) { return UniqueWs(num_cells, n_capacity).total; }
+
+const uint32_t* pn_unique_keys_ptr(const void* workspace, uint64_t num_cells, int n_capacity) {
+  return reinterpret_cast<const uint32_t*>(static_cast<const char*>(workspace) + UniqueWs(num_cells, n_capacity).off_keys);
+}
+
+int pn_unique_rank_bitmap(const uint32_t* keys, int n_capacity, const int32_t* n_dev, uint64_t num_cells,
+                          const int32_t* grid, int64_t* unq, int32_t* unq_inv, int32_t* unq_cnt, int32_t* num_voxels,
+                          void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(keys && grid && unq_inv && unq_cnt && num_voxels && workspace, "unique: null pointer");
+  PN_REQUIRE(num_cells > 0 && num_cells < (1ull << 32) && n_capacity >= 0, "unique: bad sizes");
+  UniqueWs ws(num_cells, n_capacity);
+  if (workspace_bytes < ws.total) return pn::fail(PN_ERR_WORKSPACE, "unique: workspace %zu < %zu", workspace_bytes, ws.total);
+  hipStream_t st = pn::S(stream);
+  char* base = static_cast<char*>(workspace);
+  uint32_t* bitmap = reinterpret_cast<uint32_t*>(base + ws.off_bitmap);
+  uint32_t* rank = reinterpret_cast<uint32_t*>(base + ws.off_rank);
+  uint32_t* tiles = reinterpret_cast<uint32_t*>(base + ws.off_tiles);
+  uint32_t* ukeys = reinterpret_cast<uint32_t*>(base + ws.off_keys);
+  hipError_t e = hipMemsetAsync(bitmap, 0, ws.nwords * 4, st);
+  if (e == hipSuccess && n_capacity > 0) e = hipMemsetAsync(unq_cnt, 0, (size_t)n_capacity * 4, st);
+  if (e != hipSuccess) return pn::fail(PN_ERR_LAUNCH, "unique: memset: %s", hipGetErrorString(e));
+  const int pblocks = pn::cdiv(n_capacity > 0 ? n_capacity : 1, 256);
+  if (n_capacity > 0) hipLaunchKernelGGL(mark_kernel, dim3(pblocks), dim3(256), 0, st, keys, n_capacity, n_dev, bitmap);
+  hipLaunchKernelGGL(scan_tile_totals_kernel<0>, dim3((unsigned)ws.ntiles), dim3(kScanThreads), 0, st, bitmap, ws.nwords,
+                     (const int32_t*)nullptr, tiles);
+  hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kScanThreads), 0, st, tiles, (int)ws.ntiles, num_voxels,
+                     (int32_t*)nullptr);
+  hipLaunchKernelGGL(scan_emit_voxels_kernel, dim3((unsigned)ws.ntiles), dim3(kScanThreads), 0, st, bitmap, ws.nwords,
+                     tiles, rank, ukeys, unq, grid[0], grid[1], grid[2], n_capacity);
+  if (n_capacity > 0)
+    hipLaunchKernelGGL(rank_points_kernel, dim3(pblocks), dim3(256), 0, st, keys, n_capacity, n_dev, bitmap, rank, unq_inv,
+                       unq_cnt);
+  return pn::check_launch("unique_rank_bitmap");
+}
+
+size_t pn_bucket_workspace_bytes(int n_capacity) {
+  const size_t ntiles = ((size_t)n_capacity + 1 + kScanTile - 1) / kScanTile;
+  return align256(ntiles * 4) + align256((size_t)(n_capacity + 1) * 4);
+}
+
+int pn_bucket_points(const int32_t* unq_inv, const int32_t* unq_cnt, int n_capacity, const int32_t* n_dev,
+                     const int32_t* num_voxels, int32_t* voxel_start, int32_t* order, void* workspace,
+                     size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(unq_inv && unq_cnt && num_voxels && voxel_start && order && workspace, "bucket: null pointer");
+  if (workspace_bytes < pn_bucket_workspace_bytes(n_capacity))
+    return pn::fail(PN_ERR_WORKSPACE, "bucket: workspace %zu < %zu", workspace_bytes, pn_bucket_workspace_bytes(n_capacity));
+  if (n_capacity == 0) return PN_OK;
+  hipStream_t st = pn::S(stream);
+  const size_t nitems = (size_t)n_capacity + 1;
+  const size_t ntiles = (nitems + kScanTile - 1) / kScanTile;
+  uint32_t* tiles = static_cast<uint32_t*>(workspace);
+  int32_t* cursor = reinterpret_cast<int32_t*>(static_cast<char*>(workspace) + align256(ntiles * 4));
+  hipError_t e = hipMemsetAsync(cursor, 0, (size_t)n_capacity * 4, st);
+  if (e != hipSuccess) return pn::fail(PN_ERR_LAUNCH, "bucket: memset: %s", hipGetErrorString(e));
+  const uint32_t* cnt = reinterpret_cast<const uint32_t*>(unq_cnt);
+  hipLaunchKernelGGL(scan_tile_totals_kernel<1>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, st, cnt, (size_t)n_capacity,
+                     num_voxels, tiles);
+  hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kScanThreads), 0, st, tiles, (int)ntiles, (int32_t*)nullptr,
+                     (int32_t*)nullptr);
+  hipLaunchKernelGGL(scan_emit_starts_kernel, dim3((unsigned)ntiles), dim3(kScanThreads), 0, st, cnt, (size_t)n_capacity,
+                     num_voxels, tiles, voxel_start);
+  hipLaunchKernelGGL(bucket_fill_kernel, dim3(pn::cdiv(n_capacity, 256)), dim3(256), 0, st, unq_inv, n_capacity, n_dev,
+                     voxel_start, cursor, order);
+  return pn::check_launch("bucket_points");
+}
+
+}  // extern "C"

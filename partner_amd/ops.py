@@ -1,0 +1,310 @@
+"""Tensor-level wrappers over the C ABI (device memory from PyTorch, kernels from libpartner_hip).
+
+Activations are NHWC fp32 tensors of shape (B, H, W, C); ``as_nchw`` / ``to_nhwc`` convert at the
+det3d API boundary (a channels-last NCHW view is free).  Nothing here touches the oracle and
+nothing falls back to PyTorch arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import hip
+from .hip import ACT_NONE, ACT_RELU, ACT_TANH, ConvDesc  # noqa: F401
+
+
+def _f32(n, dev):
+    return torch.empty(n, dtype=torch.float32, device=dev)
+
+
+# ------------------------------------------------------------------------------ layout
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """(B,C,H,W) logical tensor -> contiguous (B,H,W,C)."""
+    hip.require_device(x)
+    assert x.dim() == 4 and x.dtype == torch.float32
+    xp = x.permute(0, 2, 3, 1)
+    if xp.is_contiguous():
+        return xp
+    x = x.contiguous()
+    b, c, h, w = x.shape
+    out = torch.empty((b, h, w, c), dtype=torch.float32, device=x.device)
+    hip.call("pn_nchw_to_nhwc_f32", x.data_ptr(), b, c, h, w, out.data_ptr(), hip.stream())
+    return out
+
+
+def as_nchw(x_nhwc: torch.Tensor) -> torch.Tensor:
+    """(B,H,W,C) -> logical (B,C,H,W) view (channels-last strides, no copy)."""
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+def nhwc_slice_to_nchw(x_nhwc: torch.Tensor, c0: int, c: int) -> torch.Tensor:
+    """contiguous NCHW copy of channels [c0, c0+c) of an NHWC tensor"""
+    b, h, w, ct = x_nhwc.shape
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=x_nhwc.device)
+    hip.call("pn_nhwc_to_nchw_f32", x_nhwc.data_ptr(), b, c, h, w, ct, c0, out.data_ptr(), hip.stream())
+    return out
+
+
+# ------------------------------------------------------------------------------ V0 / V1
+def cart_to_polar(cart: torch.Tensor) -> torch.Tensor:
+    hip.require_device(cart)
+    cart = cart.contiguous()
+    n, f = cart.shape
+    out = torch.empty((n, f + 2), dtype=torch.float32, device=cart.device)
+    hip.call("pn_cart_to_polar_f32", cart.data_ptr(), n, f, out.data_ptr(), hip.stream())
+    return out
+
+
+@dataclass
+class GridSpec:
+    """polar grid of a voxel generator: lo = range[:3], voxel size, grid = (R, T, Z)"""
+    lo: Tuple[float, float, float]
+    vs: Tuple[float, float, float]
+    grid: Tuple[int, int, int]
+
+    @staticmethod
+    def from_range(pc_range: Sequence[float], voxel_size: Sequence[float]) -> "GridSpec":
+        import numpy as np
+
+        r = np.asarray(pc_range, dtype=np.float32)
+        v = np.asarray(voxel_size, dtype=np.float32)
+        g = np.round((r[3:] - r[:3]) / v).astype(np.int64)  # VoxelGenerator.__init__ (voxel_generator.py:6-17)
+        return GridSpec(tuple(float(x) for x in r[:3]), tuple(float(x) for x in v), tuple(int(x) for x in g))
+
+    def c_arrays(self):
+        return (C.c_float * 3)(*self.lo), (C.c_float * 3)(*self.vs), (C.c_int32 * 3)(*self.grid)
+
+    def num_cells(self, batch: int) -> int:
+        return batch * self.grid[0] * self.grid[1] * self.grid[2]
+
+
+def grid_index(points: torch.Tensor, sample_offsets: torch.Tensor, batch: int, spec: GridSpec, want_grid_ind=True,
+               want_keys=True):
+    """points (N,F>=3) polar fp32, sample_offsets int32 (batch+1) on device."""
+    hip.require_device(points, sample_offsets)
+    assert points.dtype == torch.float32 and points.is_contiguous() and sample_offsets.dtype == torch.int32
+    n = points.shape[0]
+    gi = torch.empty((n, 4), dtype=torch.int64, device=points.device) if want_grid_ind else None
+    keys = torch.empty((n,), dtype=torch.int32, device=points.device) if want_keys else None
+    lo, vs, g = spec.c_arrays()
+    hip.call("pn_polar_grid_index_f32", points.data_ptr(), points.shape[1], n, sample_offsets.data_ptr(), batch, lo, vs, g,
+             hip.ptr(gi), hip.ptr(keys), hip.stream())
+    return gi, keys
+
+
+def keys_from_grid_ind(grid_ind: torch.Tensor, spec: GridSpec, batch: int) -> torch.Tensor:
+    hip.require_device(grid_ind)
+    assert grid_ind.dtype == torch.int64 and grid_ind.is_contiguous()
+    n = grid_ind.shape[0]
+    keys = torch.empty((n,), dtype=torch.int32, device=grid_ind.device)
+    _, _, g = spec.c_arrays()
+    hip.call("pn_keys_from_grid_ind", grid_ind.data_ptr(), n, g, batch, keys.data_ptr(), hip.stream())
+    return keys
+
+
+# ------------------------------------------------------------------------------ unique / bucket
+@dataclass
+class VoxelIndex:
+    """device-side result of the bitmap unique + bucketing (no host sync needed to use it)"""
+    n_cap: int
+    num_cells: int
+    spec: GridSpec
+    batch: int
+    unq: Optional[torch.Tensor]       # (n_cap,4) int64, first V rows valid
+    unq_inv: torch.Tensor             # (n_cap,) int32
+    unq_cnt: torch.Tensor             # (n_cap,) int32, first V valid
+    num_voxels: torch.Tensor          # (1,) int32 on device
+    voxel_start: torch.Tensor         # (n_cap+1,) int32
+    order: torch.Tensor               # (n_cap,) int32
+    workspace: torch.Tensor           # keeps unq_keys alive
+    unq_keys_ptr: int
+
+    def count(self) -> int:
+        """V on the host (synchronises)"""
+        return int(self.num_voxels.item())
+
+
+def build_voxel_index(keys: torch.Tensor, spec: GridSpec, batch: int, n_dev: Optional[torch.Tensor] = None,
+                      want_unq=True) -> VoxelIndex:
+    hip.require_device(keys)
+    lib = hip.load()
+    dev = keys.device
+    n = keys.shape[0]
+    cells = spec.num_cells(batch)
+    ws_bytes = lib.pn_unique_workspace_bytes(cells, n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    unq = torch.empty((max(n, 1), 4), dtype=torch.int64, device=dev) if want_unq else None
+    inv = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    cnt = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    nv = torch.zeros((1,), dtype=torch.int32, device=dev)
+    _, _, g = spec.c_arrays()
+    st = hip.stream()
+    hip.call("pn_unique_rank_bitmap", keys.data_ptr(), n, hip.ptr(n_dev), cells, g, hip.ptr(unq), inv.data_ptr(),
+             cnt.data_ptr(), nv.data_ptr(), ws.data_ptr(), ws_bytes, st)
+    bws_bytes = lib.pn_bucket_workspace_bytes(n)
+    bws = torch.empty(max(bws_bytes, 1), dtype=torch.uint8, device=dev)
+    vstart = torch.zeros((n + 1,), dtype=torch.int32, device=dev)
+    order = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    hip.call("pn_bucket_points", inv.data_ptr(), cnt.data_ptr(), n, hip.ptr(n_dev), nv.data_ptr(), vstart.data_ptr(),
+             order.data_ptr(), bws.data_ptr(), bws_bytes, st)
+    kp = lib.pn_unique_keys_ptr(ws.data_ptr(), cells, n)
+    return VoxelIndex(n, cells, spec, batch, unq, inv, cnt, nv, vstart, order, ws, kp)
+
+
+def scatter_mean(points: torch.Tensor, vi: VoxelIndex, v_cap: Optional[int] = None) -> torch.Tensor:
+    hip.require_device(points)
+    v_cap = vi.n_cap if v_cap is None else v_cap
+    f = points.shape[1]
+    out = torch.empty((max(v_cap, 1), f), dtype=torch.float32, device=points.device)
+    hip.call("pn_scatter_mean_f32", points.data_ptr(), points.stride(0), f, vi.voxel_start.data_ptr(), vi.order.data_ptr(),
+             vi.num_voxels.data_ptr(), v_cap, out.data_ptr(), hip.stream())
+    return out
+
+
+def hard_voxel_mean(voxels: torch.Tensor, num_points: torch.Tensor) -> torch.Tensor:
+    hip.require_device(voxels, num_points)
+    voxels = voxels.contiguous()
+    v, p, f = voxels.shape
+    out = torch.empty((v, f), dtype=torch.float32, device=voxels.device)
+    hip.call("pn_hard_voxel_mean_f32", voxels.data_ptr(), num_points.to(torch.int32).contiguous().data_ptr(), v, p, f,
+             out.data_ptr(), hip.stream())
+    return out
+
+
+def dynamic_pfn(points: torch.Tensor, vi: VoxelIndex, w0: torch.Tensor, w1: torch.Tensor, vx: float, vy: float,
+                x_offset: float, y_offset: float, features: Optional[torch.Tensor], canvas: Optional[torch.Tensor],
+                v_cap: Optional[int] = None) -> None:
+    hip.require_device(points, w0, w1)
+    assert w0.is_contiguous() and w1.is_contiguous() and points.is_contiguous()
+    c0, c1 = w0.shape[0], w1.shape[0]
+    assert w0.shape[1] == 16 and w1.shape[1] == 2 * c0
+    _, _, g = vi.spec.c_arrays()
+    hip.call("pn_dynamic_pfn_fwd", points.data_ptr(), points.stride(0), vi.voxel_start.data_ptr(), vi.order.data_ptr(),
+             vi.num_voxels.data_ptr(), vi.n_cap if v_cap is None else v_cap, vi.unq_keys_ptr, g, w0.data_ptr(), c0,
+             w1.data_ptr(), c1, float(vx), float(vy), float(x_offset), float(y_offset), hip.ptr(features), hip.ptr(canvas),
+             hip.stream())
+
+
+def scatter_canvas(features: torch.Tensor, unq: torch.Tensor, batch: int, t: int, r: int,
+                   num_voxels: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> zero-filled NHWC canvas (batch, T, R, C) with features written at unq[:, (0,2,3)]"""
+    hip.require_device(features, unq)
+    features = features.contiguous()
+    unq = unq.contiguous()
+    v, c = features.shape
+    canvas = torch.empty((batch, t, r, c), dtype=torch.float32, device=features.device)
+    st = hip.stream()
+    hip.call("pn_fill_zero", canvas.data_ptr(), canvas.numel() * 4, st)
+    if num_voxels is None:
+        num_voxels = torch.full((1,), v, dtype=torch.int32, device=features.device)
+    hip.call("pn_scatter_canvas_fwd", features.data_ptr(), unq.data_ptr(), num_voxels.data_ptr(), v, c, t, r,
+             canvas.data_ptr(), st)
+    return canvas
+
+
+# ------------------------------------------------------------------------------ convolution
+class ConvLayer:
+    """One packed convolution (+ per-channel affine + activation) on NHWC maps.
+
+    weight: torch layout (Cout, Cin/groups, KH, KW), or (Cin, Cout, 2, 2) when ``deconv2x2``.
+    scale / shift: per-output-channel affine (folded BatchNorm, or bias as shift)."""
+
+    def __init__(self, weight: torch.Tensor, stride=1, pad=0, groups=1, scale=None, shift=None, act=ACT_NONE,
+                 deconv2x2=False, range_strata=0):
+        hip.require_device(weight)
+        lib = hip.load()
+        w = weight.detach().contiguous().float()
+        dev = w.device
+        st = hip.stream()
+        self.deconv2x2, self.range_strata, self.groups = bool(deconv2x2), int(range_strata), int(groups)
+        self.stride, self.act = int(stride), int(act)
+        self.pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
+        if deconv2x2:
+            cin, cout = w.shape[0], w.shape[1]
+            assert tuple(w.shape[2:]) == (2, 2)
+            self.cin, self.cout, self.kh, self.kw = cin, cout, 1, 1
+            self.packed = _f32(lib.pn_deconv2x2_packed_weight_floats(cin, cout), dev)
+            hip.call("pn_pack_deconv2x2_weight_f32", w.data_ptr(), cin, cout, self.packed.data_ptr(), st)
+        else:
+            pack_groups = self.range_strata if self.range_strata > 1 else self.groups
+            cout_t, cin_g, kh, kw = w.shape
+            self.cin, self.cout, self.kh, self.kw = cin_g, cout_t // pack_groups, kh, kw
+            self.packed = _f32(lib.pn_conv_packed_weight_floats(self.cout, cin_g, kh, kw, pack_groups), dev)
+            hip.call("pn_pack_conv_weight_f32", w.data_ptr(), cout_t, cin_g, kh, kw, pack_groups, self.packed.data_ptr(), st)
+        self.scale = None if scale is None else scale.detach().contiguous().float()
+        self.shift = None if shift is None else shift.detach().contiguous().float()
+        self.out_channels = self.cout * (self.groups if not deconv2x2 else 1)
+
+    def out_hw(self, h: int, w: int) -> Tuple[int, int]:
+        if self.deconv2x2:
+            return 2 * h, 2 * w
+        return ((h + 2 * self.pad[0] - self.kh) // self.stride + 1, (w + 2 * self.pad[1] - self.kw) // self.stride + 1)
+
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_channel_offset=0, in_channel_offset=0,
+                 in_channels: Optional[int] = None) -> torch.Tensor:
+        """x: NHWC (B,H,W,Ct).  Reads channels [in_channel_offset, +cin*groups); writes channels
+        [out_channel_offset, +out_channels) of ``out`` (allocated if None)."""
+        hip.require_device(x)
+        assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+        b, h, w, ct = x.shape
+        oh, ow = self.out_hw(h, w)
+        if out is None:
+            out = torch.empty((b, oh, ow, self.out_channels), dtype=torch.float32, device=x.device)
+        assert out.shape[:3] == (b, oh, ow) and out.is_contiguous()
+        d = ConvDesc(b, h, w, self.cin, self.cout, self.groups, self.kh, self.kw, self.stride, self.pad[0], self.pad[1],
+                     ct, in_channel_offset, out.shape[3], out_channel_offset, self.act, int(self.deconv2x2),
+                     self.range_strata)
+        hip.call("pn_conv2d_nhwc_f32", C.byref(d), x.data_ptr(), self.packed.data_ptr(), hip.ptr(self.scale),
+                 hip.ptr(self.shift), out.data_ptr(), hip.stream())
+        return out
+
+
+def conv2d_direct(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=0, groups=1,
+                  act=ACT_NONE) -> torch.Tensor:
+    """plain direct convolution (any channel counts); NHWC in / NHWC out"""
+    hip.require_device(x, weight)
+    w = weight.detach().contiguous().float()
+    cout_t, cin_g, kh, kw = w.shape
+    b, h, wd, ct = x.shape
+    oh, ow = (h + 2 * pad - kh) // stride + 1, (wd + 2 * pad - kw) // stride + 1
+    out = torch.empty((b, oh, ow, cout_t), dtype=torch.float32, device=x.device)
+    d = ConvDesc(b, h, wd, cin_g, cout_t // groups, groups, kh, kw, stride, pad, pad, ct, 0, cout_t, 0, act, 0, 0)
+    sh = None if bias is None else bias.detach().contiguous().float()
+    hip.call("pn_conv2d_direct_nhwc_f32", C.byref(d), x.data_ptr(), w.data_ptr(), None, hip.ptr(sh), out.data_ptr(),
+             hip.stream())
+    return out
+
+
+def fold_bn(gamma, beta, mean, var, eps: float, conv_bias=None):
+    hip.require_device(gamma)
+    c = gamma.numel()
+    scale, shift = _f32(c, gamma.device), _f32(c, gamma.device)
+    args = [t.detach().contiguous().float() for t in (gamma, beta, mean, var)]
+    cb = None if conv_bias is None else conv_bias.detach().contiguous().float()
+    hip.call("pn_fold_bn_f32", *(t.data_ptr() for t in args), hip.ptr(cb), float(eps), c, scale.data_ptr(),
+             shift.data_ptr(), hip.stream())
+    return scale, shift
+
+
+# ------------------------------------------------------------------------------ norms
+def groupnorm_strat(x: torch.Tensor, channel_groups: int, range_strata: int, gamma: torch.Tensor, beta: torch.Tensor,
+                    eps=1e-5, act=ACT_NONE, out: Optional[torch.Tensor] = None, mul: Optional[torch.Tensor] = None,
+                    add: Optional[torch.Tensor] = None):
+    """x NHWC (B,H,W,C).  gamma/beta have range_strata*C entries in stacked order [stratum][channel].
+    Returns out, or (out, out*mul+add) when mul/add ((H,W,C) maps) are given."""
+    hip.require_device(x)
+    lib = hip.load()
+    assert x.is_contiguous()
+    b, h, w, c = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    out2 = torch.empty_like(x) if mul is not None else None
+    ws_bytes = lib.pn_groupnorm_workspace_bytes(b, channel_groups, range_strata)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    hip.call("pn_groupnorm_strat_fwd", x.data_ptr(), b, h, w, c, c, 0, channel_groups, range_strata, hip.ptr(gamma),
+             hip.ptr(beta), float(eps), int(act), out.data_ptr(), c, 0, hip.ptr(mul), hip.ptr(add), hip.ptr(out2),
+             ws.data_ptr(), ws_bytes, hip.stream())
+    return out if out2 is None else (out, out2)

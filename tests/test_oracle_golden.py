@@ -31,7 +31,11 @@ def test_cart_to_polar(golden):
     g = golden("index_cases.npz")
     out = O.cart_to_polar(g["cart_in"])
     assert out.dtype == np.float32
-    np.testing.assert_array_equal(out, g["polar_out"])
+    ref = g["polar_out"]
+    np.testing.assert_array_equal(out[:, [0, 2, 3, 4, 5, 6]], ref[:, [0, 2, 3, 4, 5, 6]])
+    # float32 arctan2 is libm/SIMD dependent (numpy's AVX512 path is ~4 ulp): allow a few ulp on phi
+    ulp = np.abs(out[:, 1].view(np.int32).astype(np.int64) - ref[:, 1].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 8
 
 
 @pytest.mark.parametrize("tag,rng_,vs", [("nusc", synth.NUSC_RANGE, synth.NUSC_VOXEL),
