@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of the polar voxelize + PFN + BEV backbone + centre head hot
+path (BASELINE.json configs[1]: nuScenes polar-pillar cfg, synthetic 30k-point sweeps, forward
+only, fp32) on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch (default: 1 sweep) that is already resident
+in HBM as Cartesian points: cart->polar (V0), grid indices (V1), bitmap unique-rank, bucketing,
+fused PFN + canvas (V4/V5), RPN (B1), CenterHeadSinglePos (H2) -- head tensors out.
+Frames are independent, so ranks just process their own frames (weak scaling, no data-path
+collective); the timed region is bracketed by barrier + device synchronise and the maximum
+over ranks is reported.
+
+Extra objects in the JSON line:
+  roofline     -- the dominant kernel (fp32-MFMA implicit-GEMM convolution): algorithmic FLOPs
+                  of every launch / its HIP-event duration, both summed over the timed region.
+  cpu_baseline -- the CPU oracle (oracle/polar_oracle.py, a port of the reference path checked
+                  against reference goldens) timed on this box's host cores, rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from partner_amd.utils import synth  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+TASKS = [dict(num_class=10, class_names=["car", "truck", "construction_vehicle", "bus", "trailer", "barrier",
+                                         "motorcycle", "bicycle", "pedestrian", "traffic_cone"])]
+
+
+def c2_model_cfg():
+    """nuScenes polar-pillar model (values of SURVEY.md Appendix A.1)."""
+    rng_, vs = list(synth.NUSC_RANGE), list(synth.NUSC_VOXEL)
+    vg = dict(range=rng_, voxel_size=vs, max_points_in_voxel=20, max_voxel_num=[30000, 60000], voxel_shape="cylinder",
+              return_density=True, dynamic=True, nsectors=1)
+    return dict(
+        type="PointPillars", pretrained=None,
+        reader=dict(type="DynamicPFNet", num_filters=[64, 128], num_input_features=7, voxel_shape="cylinder",
+                    xyz_cluster=True, raz_cluster=True, xy_center=True, ra_center=True, voxel_size=vs, pc_range=rng_),
+        backbone=dict(type="DynamicPPScatter", ds_factor=1),
+        neck=dict(type="RPN", layer_nums=[3, 5, 5], ds_layer_strides=[2, 2, 2], ds_num_filters=[128, 128, 256],
+                  us_layer_strides=[0.5, 1, 2], us_num_filters=[128, 128, 128], num_input_features=128,
+                  logger=logging.getLogger("RPN")),
+        bbox_head=dict(type="CenterHeadSinglePos", in_channels=384, tasks=TASKS, dataset="nuscenes", weight=0.5,
+                       code_weights=[1.5, 1.5, 1.0, 1.0, 1.0, 1.0, 0.5, 0.5, 1.0, 1.0],
+                       common_heads={"reg": (2, 2), "rot_vel": (2, 2), "height": (1, 2), "dim": (3, 2)},
+                       voxel_shape="cylinder", voxel_generator=vg),
+        seg_head=None, part_head=None)
+
+
+def cpu_baseline(n_points: int, batch: int, budget_s: float = 20.0, max_frames: int = 10):
+    """time the CPU oracle on the same workload (bounded sample)"""
+    from oracle import polar_oracle as O
+
+    cfg = c2_model_cfg()
+
+    class _S:
+        def __init__(self, s):
+            self.shape = s
+
+    import partner_amd as P
+    shapes = {k: _S(tuple(v.shape)) for k, v in P.build_detector(cfg).state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, 0).items()}
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    times = []
+    t_all = time.perf_counter()
+    with torch.no_grad():
+        for f in range(max_frames + 1):
+            sweeps = [synth.synth_sweep_cart(n_points, seed=1000 + f * batch + b) for b in range(batch)]
+            t0 = time.perf_counter()
+            polar = [O.cart_to_polar(s) for s in sweeps]
+            gi = O.with_batch_index([O.grid_index(p, synth.NUSC_RANGE, synth.NUSC_VOXEL) for p in polar])
+            O.pointpillars_forward(sd, cfg, np.concatenate(polar, 0), gi, batch)
+            dt = time.perf_counter() - t0
+            if f > 0:  # first frame is warm-up
+                times.append(dt)
+            if time.perf_counter() - t_all > budget_s and len(times) >= 2:
+                break
+    fps = batch * len(times) / sum(times)
+    return dict(value=round(fps, 4), unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{len(times)} timed frames (+1 warm-up) of the same {n_points}-pt synthetic sweeps, batch {batch}, "
+                       f"oracle/polar_oracle.py (numpy + torch CPU fp32, {torch.get_num_threads()} threads)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1, help="sweeps per step per GPU")
+    ap.add_argument("--points", type=int, default=30000, help="points per sweep")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the product path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import partner_amd as P
+    from partner_amd import hip, ops
+    hip.load()
+
+    model = P.build_detector(c2_model_cfg())
+    synth.load_filled(model, base_seed=0)
+    model = model.to(dev).eval()
+
+    B, N = args.batch, args.points
+    pool = 8  # distinct resident frames per rank
+    frames = []
+    for f in range(pool):
+        cart = np.concatenate([synth.synth_sweep_cart(N, seed=(rank * pool + f) * B + b) for b in range(B)], 0)
+        frames.append(torch.from_numpy(cart).to(dev))
+    offs = torch.tensor([N * b for b in range(B + 1)], dtype=torch.int32, device=dev)
+    spec = ops.GridSpec.from_range(synth.NUSC_RANGE, synth.NUSC_VOXEL)
+
+    def step(i):
+        polar = ops.cart_to_polar(frames[i % pool])                 # V0
+        return model.forward_points(polar, offs, B, spec)           # V1 .. H2
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    prof = None
+    if not args.no_roofline_events:
+        prof = ops.enable_conv_profiling()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roofline = None
+    if prof is not None:
+        flops, ms, launches = prof.collect()
+        ops.disable_conv_profiling()
+        ach = flops / (ms * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel="conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
+                        achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                        traffic=None, launches=launches, flops_per_launch=round(flops / launches), avg_launch_us=round(1e3 * ms / launches, 2),
+                        conv_ms_per_step=round(ms / args.steps, 4))
+
+    if rank == 0:
+        fps = world * args.steps * B / elapsed
+        line = {
+            "metric": "frames/sec polar voxelize+PFN+BEV+head, 30k-pt sweep (whole job)",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "nuScenes polar-pillar PARTNER cfg (DynamicPFNet -> DynamicPPScatter -> RPN -> "
+                                   "CenterHeadSinglePos), grid 512x512x1, forward only (BASELINE configs[1])",
+                       "points_per_sweep": N, "sweeps_per_step_per_gpu": B, "parallelism": f"frame-replicas x{world}"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(N, B)
+            line["gpu_over_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,123 @@
+"""Detectors (orchestration) under the reference's names.
+
+Reference: det3d/models/detectors/single_stage.py:25-50, point_pillars.py:40-110,
+voxelnet.py:47-131,171-301.
+
+``PointPillars.forward`` keeps the reference's ``example`` contract.  In eval mode the dynamic
+branch runs as one device-side chain with no host synchronisation: linear keys -> bitmap
+unique-rank -> bucketing -> fused PFN writing the NHWC canvas -> RPN -> head.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import builder, hip, ops
+from .builder import DETECTORS
+from .nn_utils import eval_only
+from .readers import DynamicPFNet
+
+
+@DETECTORS.register_module
+class SingleStageDetector(nn.Module):
+    def __init__(self, reader, backbone, neck=None, bbox_head=None, seg_head=None, part_head=None, train_cfg=None,
+                 test_cfg=None, pretrained=None, nsectors=1):
+        super().__init__()
+        self.reader = builder.build_reader(reader)
+        self.backbone = builder.build_backbone(backbone)
+        if neck is not None:
+            self.neck = builder.build_neck(neck)
+        self.bbox_head = builder.build_bbox_head(bbox_head) if bbox_head is not None else None
+        if seg_head is not None:
+            raise NotImplementedError("segmentation heads are outside the hot path (SURVEY.md 2.1); build with seg_head=None")
+        self.seg_head = None
+        self.part_head = None
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.init_weights(pretrained)
+
+    @property
+    def with_neck(self):
+        return hasattr(self, "neck") and self.neck is not None
+
+    def init_weights(self, pretrained=None):
+        if pretrained is None:
+            return
+        sd = torch.load(pretrained, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        self.load_state_dict({k[7:] if k.startswith("module.") else k: v for k, v in sd.items()}, strict=False)
+
+
+@DETECTORS.register_module
+class PointPillars(SingleStageDetector):
+    def __init__(self, reader, backbone, neck, bbox_head, seg_head=None, part_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None):
+        super().__init__(reader, backbone, neck, bbox_head, seg_head, part_head, train_cfg, test_cfg, pretrained)
+
+    # -- stage API of the reference (point_pillars.py:40-53) ---------------------------------
+    def extract_feat_dynamic(self, data):
+        feats, unq = self.reader(data)
+        x1 = self.backbone(feats, unq, data["batch_size"], data["grid_size"])
+        return x1, self.neck(x1)
+
+    # -- fused device-side chain --------------------------------------------------------------
+    def encode_canvas(self, points: torch.Tensor, keys: torch.Tensor, spec: ops.GridSpec, batch: int,
+                      n_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """points (N,7) + linear voxel keys -> NHWC canvas (B, T, R, C); no host sync"""
+        if not isinstance(self.reader, DynamicPFNet):
+            raise NotImplementedError("fused encode path needs a DynamicPFNet reader")
+        vi = ops.build_voxel_index(keys, spec, batch, n_dev=n_dev, want_unq=False)
+        canvas = torch.empty((batch, spec.grid[1], spec.grid[0], self.reader.out_channels), dtype=torch.float32,
+                             device=points.device)
+        hip.call("pn_fill_zero", canvas.data_ptr(), canvas.numel() * 4, hip.stream())
+        self.reader.encode(points, vi, None, canvas)
+        return canvas
+
+    def forward_points(self, points: torch.Tensor, sample_offsets: torch.Tensor, batch: int,
+                       spec: Optional[ops.GridSpec] = None) -> Dict[str, torch.Tensor]:
+        """Hot path from polar-decorated points: grid indices are computed on the device (V1).
+        points (N,7) [rho,phi,z,x,y,i,t]; sample_offsets int32 (batch+1).  -> head tensors."""
+        eval_only(self, "PointPillars")
+        spec = spec or ops.GridSpec.from_range(self.reader.pc_range, self.reader.voxel_size)
+        _, keys = ops.grid_index(points, sample_offsets, batch, spec, want_grid_ind=False)
+        canvas = self.encode_canvas(points, keys, spec, batch, n_dev=sample_offsets[batch:])
+        x2 = self.neck.forward_nhwc(canvas)
+        return self.bbox_head(ops.as_nchw(x2))["det_preds"][0]
+
+    def extract_preds(self, example) -> Dict[str, object]:
+        """reference ``example`` dict (dynamic branch keys) -> {'det_preds': [...]}"""
+        eval_only(self, "PointPillars")
+        if "voxels" in example:
+            raise NotImplementedError("PointPillars hard-voxel (static) branch has no HIP kernels yet")
+        points, grid_ind = example["points"], example["grid_ind"]
+        hip.require_device(points, grid_ind)
+        batch = len(example["num_points"])
+        g = [int(v) for v in example["grid_size"][0]]
+        spec = ops.GridSpec.from_range(self.reader.pc_range, self.reader.voxel_size)
+        if list(spec.grid) != g:
+            raise ValueError(f"example grid_size {g} does not match the reader's voxel grid {list(spec.grid)}")
+        keys = ops.keys_from_grid_ind(grid_ind.to(torch.int64).contiguous(), spec, batch)
+        canvas = self.encode_canvas(points.contiguous(), keys, spec, batch)
+        x2 = self.neck.forward_nhwc(canvas)
+        return self.bbox_head(ops.as_nchw(x2))
+
+    def forward(self, example, return_loss=True, **kwargs):
+        preds = self.extract_preds(example)
+        if return_loss:
+            return self.bbox_head.loss(example, preds)
+        if kwargs.get("raw_preds", False) or self.test_cfg is None:
+            return preds
+        return {"det": self.bbox_head.predict(example, preds, self.test_cfg, **kwargs)}
+
+
+@DETECTORS.register_module
+class VoxelNet(SingleStageDetector):
+    """VoxelNet family (voxelnet.py:27-131): needs the sparse 3-D middle encoder."""
+
+    def __init__(self, reader, backbone, neck, bbox_head, seg_head=None, part_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None):
+        super().__init__(reader, backbone, neck, bbox_head, seg_head, part_head, train_cfg, test_cfg, pretrained)
+
+    def forward(self, example, return_loss=True, **kwargs):
+        raise NotImplementedError("VoxelNet forward needs the sparse 3-D backbone (SURVEY.md 8f next-1), not built yet")

@@ -1,0 +1,278 @@
+"""Centre heads (registered under the reference's names).
+
+Reference: det3d/models/bbox_heads/center_head.py:65-109,166-242 (CenterHead / SepHead),
+center_head_parallel.py:27-59,70-196,199-284 (RangeStratified, CenterHeadSingle,
+CenterHeadSinglePos), det3d/models/utils/norm.py:58-75 (RSNorm).
+
+Forward = HIP launches only: fp32-MFMA convolutions with fused bias/activation, the stratified
+GroupNorm kernel, and -- for CenterHeadSinglePos -- the position-conditioned calibration folded
+to two constant (H,W,C) maps at plan-build time (they do not depend on the input).
+"""
+from __future__ import annotations
+
+import copy
+import logging
+from typing import Dict, List
+
+import torch
+from torch import nn
+
+from . import hip, ops
+from .builder import BBOX_HEADS
+from .nn_utils import PlanCache, RSNorm, Sequential, eval_only
+
+
+class RangeStratified(nn.Module):
+    """parameters of the range-stratified 3x3 convolution + GroupNorm (center_head_parallel.py:27-59)"""
+
+    def __init__(self, kernel, nheads, ngroups, inchannels, outchannels, act="ReLU"):
+        super().__init__()
+        self.conv = nn.Sequential(
+            nn.Conv2d(inchannels * ngroups * nheads, outchannels * ngroups * nheads, kernel, groups=ngroups * nheads),
+            nn.GroupNorm(ngroups * nheads, outchannels * ngroups * nheads),
+            nn.ReLU(inplace=True))
+        self.kernel, self.nheads, self.ngroups = tuple(kernel), nheads, ngroups
+        self.inchannels, self.outchannels = inchannels, outchannels
+
+
+class SepHead(nn.Module):
+    """per-task separate heads of the plain CenterHead (center_head.py:65-109)"""
+
+    def __init__(self, in_channels, heads, head_conv=64, final_kernel=1, bn=False, init_bias=-2.19, **kwargs):
+        super().__init__()
+        self.heads = heads
+        for head, (classes, num_conv) in heads.items():
+            fc = Sequential()
+            for _ in range(num_conv - 1):
+                fc.add(nn.Conv2d(in_channels, head_conv, kernel_size=final_kernel, stride=1, padding=final_kernel // 2, bias=True))
+                fc.add(nn.ReLU())
+            fc.add(nn.Conv2d(head_conv, classes, kernel_size=final_kernel, stride=1, padding=final_kernel // 2, bias=True))
+            if "hm" in head:
+                fc[-1].bias.data.fill_(init_bias)
+            else:
+                for m in fc.modules():
+                    if isinstance(m, nn.Conv2d):
+                        nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                        nn.init.constant_(m.bias, 0)
+            setattr(self, head, fc)
+
+
+def _conv_bias(conv: nn.Conv2d, act, **kw) -> ops.ConvLayer:
+    return ops.ConvLayer(conv.weight, stride=conv.stride[0], pad=conv.padding[0], groups=conv.groups, shift=conv.bias,
+                         act=act, **kw)
+
+
+@BBOX_HEADS.register_module
+class CenterHead(nn.Module):
+    """Plain CenterPoint head: shared 3x3 conv + ReLU, then per task / per head
+    (conv3x3 + ReLU) x (n-1) + conv3x3."""
+
+    def __init__(self, in_channels=[128, ], tasks=[], dataset="nuscenes", weight=0.25, code_weights=[], common_heads=dict(),
+                 logger=None, init_bias=-2.19, share_conv_channel=64, num_hm_conv=2, dcn_head=False, voxel_shape="cuboid"):
+        super().__init__()
+        num_classes = [len(t["class_names"]) for t in tasks]
+        self.class_names = [t["class_names"] for t in tasks]
+        self.code_weights, self.weight, self.dataset, self.voxel_shape = code_weights, weight, dataset, voxel_shape
+        self.in_channels, self.num_classes = in_channels, num_classes
+        self.box_n_dim = 9 if "vel" in common_heads else 7
+        self.use_direction_classifier = False
+        self.logger = logger or logging.getLogger("CenterHead")
+        self.logger.info(f"num_classes: {num_classes}")
+        if dcn_head:
+            raise NotImplementedError("dcn_head=True (deformable convolution head) is outside the hot path (SURVEY.md 2.1)")
+        self.shared_conv = nn.Sequential(nn.Conv2d(in_channels, share_conv_channel, kernel_size=3, padding=1, bias=True),
+                                         nn.ReLU(inplace=True))
+        self.tasks = nn.ModuleList()
+        for ncls in num_classes:
+            heads = copy.deepcopy(common_heads)
+            heads.update(dict(hm=(ncls, num_hm_conv)))
+            self.tasks.append(SepHead(share_conv_channel, heads, bn=True, init_bias=init_bias, final_kernel=3))
+        self._plan = PlanCache()
+        self.logger.info("Finish CenterHead Initialization")
+
+    def _build_plan(self):
+        plan = dict(shared=_conv_bias(self.shared_conv[0], ops.ACT_RELU), tasks=[])
+        for task in self.tasks:
+            heads = {}
+            for name in task.heads:
+                convs = [m for m in getattr(task, name)._modules.values() if isinstance(m, nn.Conv2d)]
+                heads[name] = [_conv_bias(c, ops.ACT_RELU if k < len(convs) - 1 else ops.ACT_NONE) for k, c in enumerate(convs)]
+            plan["tasks"].append(heads)
+        return plan
+
+    def forward(self, x, *kwargs):
+        hip.require_device(x)
+        eval_only(self, type(self).__name__)
+        plan = self._plan.get(self, self._build_plan)
+        xs = plan["shared"](ops.to_nhwc(x))
+        rets: List[Dict[str, torch.Tensor]] = []
+        for heads in plan["tasks"]:
+            d = {}
+            for name, layers in heads.items():
+                y = xs
+                for layer in layers:
+                    y = layer(y)
+                d[name] = ops.as_nchw(y)
+            rets.append(d)
+        return {"det_preds": rets}
+
+    def loss(self, example, preds_dicts, **kwargs):
+        raise NotImplementedError("CenterHead.loss (SURVEY.md 8a row L1) is part of the training step, not built yet")
+
+    def predict(self, example, preds_dicts, test_cfg, **kwargs):
+        raise NotImplementedError("decode + rotated NMS (SURVEY.md 8f next-2) is outside this round's hot path")
+
+
+@BBOX_HEADS.register_module
+class CenterHeadSingle(CenterHead):
+    """Single-group merged heads with RSNorm / RangeStratified / GroupNorm (center_head_parallel.py:70-196)."""
+
+    def __init__(self, in_channels=[128, ], tasks=[], dataset="nuscenes", weight=0.25, code_weights=[], common_heads=dict(),
+                 logger=None, init_bias=-2.19, share_conv_channel=64, num_hm_conv=2, dcn_head=False, voxel_shape="cuboid",
+                 act="ReLU"):
+        super().__init__(in_channels, tasks, dataset, weight, code_weights, common_heads, logger, init_bias,
+                         share_conv_channel, num_hm_conv, dcn_head, voxel_shape)
+        if act != "ReLU":
+            raise NotImplementedError("only act='ReLU' is supported (the reference marks 'Mish' as not working)")
+        self.num_heads = len(self.num_classes)
+        self.common_heads = common_heads
+        self.heads = copy.deepcopy(common_heads)
+        self.shared_conv = nn.Sequential(nn.Conv2d(in_channels, share_conv_channel, kernel_size=3, padding=1, bias=True),
+                                         RSNorm(1, 4, share_conv_channel), nn.ReLU(inplace=True))
+        self.tasks = None
+        head_conv, k = 64, 3
+        for head, (classes, num_conv) in common_heads.items():
+            fc = Sequential()
+            if "reg" in head:
+                fc.add(RangeStratified((3, 3), 1, 8, share_conv_channel, head_conv, act))
+                fc.add(nn.Conv2d(head_conv, classes, kernel_size=1, bias=True))
+            else:
+                n = len(head.split("_")) if "_" in head else 1
+                for _ in range(num_conv - 1):
+                    fc.add(nn.Conv2d(share_conv_channel, head_conv, kernel_size=k, stride=1, padding=k // 2, bias=True, groups=n))
+                    fc.add(nn.GroupNorm(head_conv, head_conv))
+                    fc.add(nn.ReLU(inplace=True))
+                fc.add(nn.Conv2d(head_conv, classes * n, kernel_size=k, stride=1, padding=k // 2, bias=True, groups=n))
+            setattr(self, head, fc)
+        self.hm = Sequential()
+        self.heads.update(dict(hm=(sum(self.num_classes), num_hm_conv)))
+        for _ in range(num_hm_conv - 1):
+            self.hm.add(nn.Conv2d(share_conv_channel, head_conv, kernel_size=k, stride=1, padding=k // 2, bias=True))
+            self.hm.add(nn.GroupNorm(head_conv, head_conv))
+            self.hm.add(nn.ReLU(inplace=True))
+        self.hm.add(nn.Conv2d(head_conv, sum(self.num_classes), kernel_size=k, stride=1, padding=k // 2, bias=True))
+        self.logger.info("Finish CenterHead Initialization")
+
+    # ---------------------------------------------------------------------------------------
+    def _branch_plan(self, fc: Sequential):
+        """-> list of steps: ('conv', ConvLayer) | ('gn', channel_groups, strata, gamma, beta, eps)"""
+        steps = []
+        for m in fc._modules.values():
+            if isinstance(m, RangeStratified):
+                conv, gn = m.conv[0], m.conv[1]
+                steps.append(("conv", ops.ConvLayer(conv.weight, stride=1, pad=1, range_strata=m.ngroups * m.nheads,
+                                                    shift=conv.bias, act=ops.ACT_NONE)))
+                steps.append(("gn", m.nheads, m.ngroups, gn.weight.detach(), gn.bias.detach(), gn.eps))
+            elif isinstance(m, nn.Conv2d):
+                steps.append(("conv", _conv_bias(m, ops.ACT_NONE)))
+            elif isinstance(m, nn.GroupNorm):
+                steps.append(("gn", m.num_groups, 1, m.weight.detach(), m.bias.detach(), m.eps))
+        return steps
+
+    def _build_plan(self):
+        rs = self.shared_conv[1]
+        plan = dict(shared=_conv_bias(self.shared_conv[0], ops.ACT_NONE),
+                    shared_gn=(rs.num_heads, rs.num_groups, rs.groupnorm.weight.detach(), rs.groupnorm.bias.detach(),
+                               rs.groupnorm.eps),
+                    branches={name: self._branch_plan(getattr(self, name)) for name in self.heads})
+        return plan
+
+    @staticmethod
+    def _run_branch(steps, x):
+        for st in steps:
+            if st[0] == "conv":
+                x = st[1](x)
+            else:  # GroupNorm is always followed by ReLU in these heads
+                x = ops.groupnorm_strat(x, st[1], st[2], st[3], st[4], st[5], act=ops.ACT_RELU)
+        return x
+
+    def _calibration(self, plan, like: torch.Tensor):
+        return None, None
+
+    def forward(self, x, **kwargs):
+        hip.require_device(x)
+        eval_only(self, type(self).__name__)
+        plan = self._plan.get(self, self._build_plan)
+        raw = plan["shared"](ops.to_nhwc(x))
+        cg, st, ga, be, eps = plan["shared_gn"]
+        mul, add = self._calibration(plan, raw)
+        if mul is not None:
+            xs, x_hm = ops.groupnorm_strat(raw, cg, st, ga, be, eps, act=ops.ACT_RELU, mul=mul, add=add)
+        else:
+            xs = x_hm = ops.groupnorm_strat(raw, cg, st, ga, be, eps, act=ops.ACT_RELU)
+        ret = {}
+        for name, steps in plan["branches"].items():
+            y = ops.as_nchw(self._run_branch(steps, x_hm if name == "hm" else xs))
+            if "_" in name:
+                names = name.split("_")
+                dim = y.shape[1] // len(names)
+                for j, nm in enumerate(names):
+                    ret[nm] = y[:, j * dim:(j + 1) * dim]
+            elif "heightdim" in name:
+                ret["height"], ret["dim"] = y[:, :1], y[:, 1:]
+            else:
+                ret[name] = y
+        return {"det_preds": [ret]}
+
+
+def polar_pos_encoding(voxel_generator, out_size_factor) -> torch.Tensor:
+    """(1,5,A,R) = [r cos(a), r sin(a), r, cos(a), sin(a)] at the BEV cell corners of the head map
+    (center_head_parallel.py:229-241).  Input independent; built once on the host."""
+    pr, vs, ns = list(voxel_generator["range"]), voxel_generator["voxel_size"], voxel_generator["nsectors"]
+    az_hi = pr[1] + (pr[4] - pr[1]) / ns
+    r_size = round((pr[3] - pr[0]) / vs[0] / out_size_factor)
+    a_size = round((az_hi - pr[1]) / vs[1] / out_size_factor)
+    ga, gr = torch.meshgrid(torch.arange(a_size), torch.arange(r_size), indexing="ij")
+    ga = ga * out_size_factor * vs[1] + pr[1]
+    gr = gr * out_size_factor * vs[0] + pr[0]
+    c, s = torch.cos(ga), torch.sin(ga)
+    return torch.stack([gr * c, gr * s, gr, c, s])[None]
+
+
+@BBOX_HEADS.register_module
+class CenterHeadSinglePos(CenterHeadSingle):
+    """CenterHeadSingle + position-conditioned feature undistortion of the heat-map branch:
+    hm = head(x * W(pos) + b(pos))  (center_head_parallel.py:199-284)."""
+
+    def __init__(self, in_channels=[128, ], tasks=[], dataset="nuscenes", weight=0.25, code_weights=[], common_heads=dict(),
+                 logger=None, init_bias=-2.19, share_conv_channel=64, num_hm_conv=2, dcn_head=False, voxel_shape="cuboid",
+                 voxel_generator=None, out_size_factor=4):
+        super().__init__(in_channels, tasks, dataset, weight, code_weights, common_heads, logger, init_bias,
+                         share_conv_channel, num_hm_conv, dcn_head, voxel_shape)
+        head_conv = 64
+        with torch.no_grad():
+            self.pos_encoding = polar_pos_encoding(voxel_generator, out_size_factor)  # plain attribute, as in the reference
+        self.calibration_weight = Sequential(nn.Conv2d(5, head_conv, kernel_size=3, padding=1), nn.Tanh(),
+                                             nn.Conv2d(head_conv, head_conv, kernel_size=1), nn.Tanh())
+        self.calibration_bias = Sequential(nn.Conv2d(5, head_conv, kernel_size=3, padding=1), nn.Tanh(),
+                                           nn.Conv2d(head_conv, head_conv, kernel_size=1))
+
+    def _build_plan(self):
+        plan = super()._build_plan()
+        dev = self.calibration_weight[0].weight.device
+        hip.require_device(self.calibration_weight[0].weight)
+        pos = ops.to_nhwc(self.pos_encoding.to(dev))
+
+        def fold(seq, last_act):
+            h = ops.conv2d_direct(pos, seq[0].weight, seq[0].bias, 1, 1, 1, act=ops.ACT_TANH)  # Cin = 5: direct kernel
+            return ops.ConvLayer(seq[2].weight, shift=seq[2].bias, act=last_act)(h)[0].contiguous()  # (A,R,C)
+
+        plan["cal_mul"] = fold(self.calibration_weight, ops.ACT_TANH)
+        plan["cal_add"] = fold(self.calibration_bias, ops.ACT_NONE)
+        return plan
+
+    def _calibration(self, plan, like):
+        if tuple(plan["cal_mul"].shape[:2]) != tuple(like.shape[1:3]):
+            raise ValueError(f"head input map {tuple(like.shape[1:3])} does not match the position encoding "
+                             f"{tuple(plan['cal_mul'].shape[:2])} of the configured voxel grid")
+        return plan["cal_mul"], plan["cal_add"]

@@ -1,0 +1,120 @@
+"""RPN: the dense 2-D BEV backbone (det3d/models/necks/rpn.py:23-159), executed as a chain of
+fused conv + folded-BatchNorm + ReLU launches of the fp32-MFMA implicit-GEMM kernel.  Every
+deblock writes straight into its channel slice of the concatenated output (no torch.cat)."""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import hip, ops
+from .builder import NECKS
+from .nn_utils import PlanCache, Sequential, build_norm_layer, eval_only
+
+
+@NECKS.register_module
+class RPN(nn.Module):
+    def __init__(self, layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides, us_num_filters,
+                 num_input_features, norm_cfg=None, name="rpn", logger=None, **kwargs):
+        super().__init__()
+        self._layer_strides = ds_layer_strides
+        self._num_filters = ds_num_filters
+        self._layer_nums = layer_nums
+        self._upsample_strides = us_layer_strides
+        self._num_upsample_filters = us_num_filters
+        self._num_input_features = num_input_features
+        self._norm_cfg = norm_cfg or dict(type="BN", eps=1e-3, momentum=0.01)
+        assert len(ds_layer_strides) == len(layer_nums) == len(ds_num_filters)
+        assert len(us_num_filters) == len(us_layer_strides)
+        self._upsample_start_idx = len(layer_nums) - len(us_layer_strides)
+        ratios = [us_layer_strides[i] / np.prod(ds_layer_strides[: i + self._upsample_start_idx + 1])
+                  for i in range(len(us_layer_strides))]
+        assert all(r == ratios[0] for r in ratios), "all deblocks must end at the same resolution"
+
+        cin = [num_input_features, *ds_num_filters[:-1]]
+        blocks, deblocks = [], []
+        for i, n in enumerate(layer_nums):
+            blk = Sequential(nn.ZeroPad2d(1), nn.Conv2d(cin[i], ds_num_filters[i], 3, stride=ds_layer_strides[i], bias=False),
+                             build_norm_layer(self._norm_cfg, ds_num_filters[i])[1], nn.ReLU())
+            for _ in range(n):
+                blk.add(nn.Conv2d(ds_num_filters[i], ds_num_filters[i], 3, padding=1, bias=False))
+                blk.add(build_norm_layer(self._norm_cfg, ds_num_filters[i])[1])
+                blk.add(nn.ReLU())
+            blocks.append(blk)
+            j = i - self._upsample_start_idx
+            if j >= 0:
+                us, cout = us_layer_strides[j], us_num_filters[j]
+                if us > 1:
+                    up = nn.ConvTranspose2d(ds_num_filters[i], cout, int(us), stride=int(us), bias=False)
+                else:
+                    k = int(np.round(1 / us))
+                    up = nn.Conv2d(ds_num_filters[i], cout, k, stride=k, bias=False)
+                deblocks.append(Sequential(up, build_norm_layer(self._norm_cfg, cout)[1], nn.ReLU()))
+        self.blocks = nn.ModuleList(blocks)
+        self.deblocks = nn.ModuleList(deblocks)
+        self._plan = PlanCache()
+        (logger or logging.getLogger("RPN")).info("Finish RPN Initialization")
+
+    @property
+    def downsample_factor(self):
+        f = np.prod(self._layer_strides)
+        if len(self._upsample_strides) > 0:
+            f /= self._upsample_strides[-1]
+        return f
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+
+    # ---------------------------------------------------------------------------------------
+    @staticmethod
+    def _fused(conv, bn, stride, pad, deconv=False):
+        scale, shift = ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, conv.bias)
+        return ops.ConvLayer(conv.weight, stride=stride, pad=pad, scale=scale, shift=shift, act=ops.ACT_RELU,
+                             deconv2x2=deconv)
+
+    def _build_plan(self):
+        plan = dict(blocks=[], deblocks=[])
+        for blk in self.blocks:
+            mods = list(blk._modules.values())
+            layers = [self._fused(mods[1], mods[2], mods[1].stride[0], 1)]  # ZeroPad2d(1) + conv == pad 1
+            for k in range(4, len(mods), 3):
+                layers.append(self._fused(mods[k], mods[k + 1], 1, 1))
+            plan["blocks"].append(layers)
+        for de in self.deblocks:
+            up, bn = de[0], de[1]
+            if isinstance(up, nn.ConvTranspose2d):
+                if up.stride[0] != 2:
+                    raise NotImplementedError("RPN deblock: only ConvTranspose2d(k=2, s=2) has a HIP kernel")
+                plan["deblocks"].append(self._fused(up, bn, 1, 0, deconv=True))
+            else:
+                plan["deblocks"].append(self._fused(up, bn, up.stride[0], 0))
+        return plan
+
+    def forward_nhwc(self, x: torch.Tensor, return_blocks=False):
+        """x: NHWC (B,H,W,C) -> NHWC (B,H',W',sum(us_filters))"""
+        eval_only(self, "RPN")
+        plan = self._plan.get(self, self._build_plan)
+        out, off, block_outs = None, 0, []
+        for i, layers in enumerate(plan["blocks"]):
+            for layer in layers:
+                x = layer(x)
+            block_outs.append(x)
+            j = i - self._upsample_start_idx
+            if j >= 0:
+                de = plan["deblocks"][j]
+                if out is None:
+                    oh, ow = de.out_hw(x.shape[1], x.shape[2])
+                    out = torch.empty((x.shape[0], oh, ow, sum(self._num_upsample_filters)), dtype=torch.float32, device=x.device)
+                de(x, out=out, out_channel_offset=off)
+                off += self._num_upsample_filters[j]
+        res = out if out is not None else x
+        return (res, block_outs) if return_blocks else res
+
+    def forward(self, x):
+        """logical (B,C,H,W) in / out, as rpn.py:150-159"""
+        hip.require_device(x)
+        return ops.as_nchw(self.forward_nhwc(ops.to_nhwc(x)))

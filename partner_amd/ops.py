@@ -206,6 +206,59 @@ def scatter_canvas(features: torch.Tensor, unq: torch.Tensor, batch: int, t: int
 
 
 # ------------------------------------------------------------------------------ convolution
+class ConvProfiler:
+    """HIP-event pairs around every MFMA-conv launch on the launch stream (bench.py roofline)."""
+
+    def __init__(self):
+        self.lib = hip.load()
+        self.pairs = []   # (start, stop, flops)
+        self.free = []
+
+    def _event(self):
+        if self.free:
+            return self.free.pop()
+        ev = C.c_void_p()
+        hip.call("pn_event_create", C.byref(ev))
+        return ev
+
+    def begin(self, stream):
+        ev = self._event()
+        hip.call("pn_event_record", ev, stream)
+        return ev
+
+    def end(self, start, flops, stream):
+        ev = self._event()
+        hip.call("pn_event_record", ev, stream)
+        self.pairs.append((start, ev, flops))
+
+    def collect(self):
+        """-> (total algorithmic FLOPs, total milliseconds, launches); synchronises"""
+        flops, ms = 0.0, 0.0
+        out = C.c_float()
+        for a, b, f in self.pairs:
+            hip.call("pn_event_elapsed_ms", a, b, C.byref(out))
+            ms += out.value
+            flops += f
+            self.free += [a, b]
+        n = len(self.pairs)
+        self.pairs = []
+        return flops, ms, n
+
+
+_PROFILER: Optional[ConvProfiler] = None
+
+
+def enable_conv_profiling() -> ConvProfiler:
+    global _PROFILER
+    _PROFILER = ConvProfiler()
+    return _PROFILER
+
+
+def disable_conv_profiling() -> None:
+    global _PROFILER
+    _PROFILER = None
+
+
 class ConvLayer:
     """One packed convolution (+ per-channel affine + activation) on NHWC maps.
 
@@ -257,8 +310,20 @@ class ConvLayer:
         d = ConvDesc(b, h, w, self.cin, self.cout, self.groups, self.kh, self.kw, self.stride, self.pad[0], self.pad[1],
                      ct, in_channel_offset, out.shape[3], out_channel_offset, self.act, int(self.deconv2x2),
                      self.range_strata)
+        st = hip.stream()
+        prof = _PROFILER
+        if prof is not None:
+            ev = prof.begin(st)
         hip.call("pn_conv2d_nhwc_f32", C.byref(d), x.data_ptr(), self.packed.data_ptr(), hip.ptr(self.scale),
-                 hip.ptr(self.shift), out.data_ptr(), hip.stream())
+                 hip.ptr(self.shift), out.data_ptr(), st)
+        if prof is not None:
+            # algorithmic FLOPs = 2 * output pixels * Cout * Cin * KH * KW (per group), dense-conv count
+            if self.deconv2x2:
+                macs = b * h * w * 4 * self.cout * self.cin
+            else:
+                z = self.groups
+                macs = b * oh * ow * z * self.cout * self.cin * self.kh * self.kw
+            prof.end(ev, 2.0 * macs, st)
         return out
 
 
