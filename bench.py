@@ -75,7 +75,9 @@ def cpu_baseline(n_points: int, batch: int, budget_s: float = 20.0, max_frames: 
     import partner_amd as P
     shapes = {k: _S(tuple(v.shape)) for k, v in P.build_detector(cfg).state_dict().items()}
     sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, 0).items()}
-    threads = os.cpu_count() or 1
+    # torch CPU convolutions stop scaling (and collapse) beyond ~16 threads on the GPU box's host
+    # (measured: 8 thr 0.36 s, 16 thr 0.28 s, 32 thr 0.33 s, 64 thr 0.70 s, 256 thr 34 s per frame)
+    threads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     times = []
     t_all = time.perf_counter()

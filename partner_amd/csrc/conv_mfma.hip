@@ -23,6 +23,7 @@
 // k = 8s+4+j from lane half 1, for A and B alike (the sum is order independent up to fp32
 // rounding).
 #include "pn_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -48,6 +49,10 @@ struct ConvArgs {
   int ncols;       // GEMM columns per z
   int nmt;         // m tiles
   int in_group_stride;   // input-channel offset per z (Cin for grouped conv, 0 otherwise)
+  unsigned in_bytes;     // size of the input allocation seen through the buffer descriptor
+  unsigned w_bytes;      // size of the packed weights
+  int force_tile;        // >0: tile override (tuning / tests)
+  int abl;               // ablation bits for tuning builds (PN_CONV_ABL): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no fragment reads
 };
 
 constexpr int BK = 32;
@@ -82,57 +87,72 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   const int m0 = mt * BM;
   const int n0 = blockIdx.y * BN;
 
-  // ---- per-thread A rows ------------------------------------------------------------
+  // ---- global -> register staging through buffer loads --------------------------------------
+  // Every per-step address is  descriptor base + per-thread voffset (fixed) + wave-uniform
+  // soffset(tap, chunk): no per-step vector address arithmetic.  Taps that fall into the zero
+  // padding (and rows / channels past the end) are redirected to voffset = ~0, which the
+  // buffer range check turns into zeros -- no branches, no exec masking.
+  // The descriptor base is moved back by the largest negative tap offset so that voffset >= 0.
   const int c4 = tid & 7;
-  int a_ih0[A_PER_T], a_iw0[A_PER_T], a_pix[A_PER_T];
-  bool a_ok[A_PER_T];
   const int ohw = a.OH * a.OWsub;
+  const int taps = a.KH * a.KW;
+  const long long back = ((long long)a.pad_h * a.W + a.pad_w) * a.in_ps;  // floats
+  unsigned a_off[A_PER_T];   // byte offset of (row, tap 0, chunk 0) relative to the shifted base
+  unsigned a_mask[A_PER_T];  // bit t: tap t reads inside the map
 #pragma unroll
   for (int j = 0; j < A_PER_T; ++j) {
     const int row = (tid >> 3) + (NT / 8) * j;
     const int m = m0 + row;
-    a_ok[j] = m < a.M;
-    const int mm = a_ok[j] ? m : 0;
+    const bool ok = m < a.M;
+    const int mm = ok ? m : 0;
     const int b = mm / ohw;
     const int rem = mm - b * ohw;
     const int oh = rem / a.OWsub;
     const int ow = rem - oh * a.OWsub + (a.mode == MODE_STRAT ? z * a.OWsub : 0);
-    a_ih0[j] = oh * a.stride - a.pad_h;
-    a_iw0[j] = ow * a.stride - a.pad_w;
-    a_pix[j] = (b * a.H + a_ih0[j]) * a.W + a_iw0[j];
+    const int ih0 = oh * a.stride - a.pad_h, iw0 = ow * a.stride - a.pad_w;
+    const long long pix = ((long long)b * a.H + ih0) * a.W + iw0;  // may be negative by at most `back`/in_ps
+    a_off[j] = (unsigned)((pix * a.in_ps + back + a.in_co + z * a.in_group_stride + c4 * 4) * 4);
+    unsigned mk = 0;
+    for (int t = 0; t < taps; ++t) {
+      const int kh = t / a.KW, kw = t - kh * a.KW;
+      if (ok && (unsigned)(ih0 + kh) < (unsigned)a.H && (unsigned)(iw0 + kw) < (unsigned)a.W) mk |= 1u << t;
+    }
+    a_mask[j] = mk;
   }
-  const float* in_base = a.in + a.in_co + z * a.in_group_stride + c4 * 4;
-  const int taps = a.KH * a.KW;
-  const float* w_base = a.w + (size_t)z * taps * (a.cin_chunks * BK) * a.cout_pad;
+  unsigned b_off[B_PER_T];
+#pragma unroll
+  for (int j = 0; j < B_PER_T; ++j) {
+    const int idx = tid + NT * j;
+    const int k4 = idx / BN, n = idx - k4 * BN;
+    b_off[j] = (n0 + n < a.cout_pad) ? (unsigned)(((size_t)k4 * a.cout_pad + n0 + n) * 16) : 0xffffffffu;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in) - back, 0, a.in_bytes + (unsigned)(back * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.w) + (size_t)z * taps * (a.cin_chunks * BK) * a.cout_pad, 0, a.w_bytes, 0x00020000);
   const int nsteps = taps * a.cin_chunks;
 
   f32x4 ra[A_PER_T], rb[B_PER_T];
 
-  auto load_global = [&](int t) {
-    const int tap = t / a.cin_chunks;
-    const int chunk = t - tap * a.cin_chunks;
-    const int kh = tap / a.KW, kw = tap - kh * a.KW;
-    const bool cok = chunk * BK + c4 * 4 < a.Cin;
+  // K order: channel chunk outermost, taps innermost -- the 9 taps of one 32-channel slab re-read
+  // (nearly) the same lines, so the slab stays in this XCD's L2 while it is being used.
+  // (tap, chunk) of the next tile to fetch, advanced incrementally: scalar adds only
+  int ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
+  auto load_global = [&]() {
+    const unsigned so_a = (unsigned)(((ld_kh * a.W + ld_kw) * a.in_ps + ld_chunk * BK) * 4);
+    const unsigned so_b = (unsigned)((ld_tap * a.cin_chunks + ld_chunk) * 8) * (unsigned)a.cout_pad * 16u;
+    const unsigned cok = (unsigned)(ld_chunk * BK + c4 * 4 < a.Cin);
 #pragma unroll
     for (int j = 0; j < A_PER_T; ++j) {
-      const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
-      const bool ok = a_ok[j] && cok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const float* p = in_base + (size_t)(a_pix[j] + kh * a.W + kw) * a.in_ps + chunk * BK;
-        v = *reinterpret_cast<const f32x4*>(p);
-      }
-      ra[j] = v;
+      const unsigned sel = (a_mask[j] >> ld_tap) & cok;          // 1: inside the map
+      const unsigned vo = a_off[j] | (0u - (1u - (sel & 1u)));   // branch-free: ~0 when outside
+      ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, so_a, 0));
     }
-    const float* wt = w_base + ((size_t)(tap * a.cin_chunks + chunk) * 8) * a.cout_pad * 4;
 #pragma unroll
-    for (int j = 0; j < B_PER_T; ++j) {
-      const int idx = tid + NT * j;
-      const int k4 = idx / BN, n = idx - k4 * BN;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n0 + n < a.cout_pad) v = *reinterpret_cast<const f32x4*>(wt + ((size_t)k4 * a.cout_pad + n0 + n) * 4);
-      rb[j] = v;
-    }
+    for (int j = 0; j < B_PER_T; ++j)
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_off[j], so_b, 0));
+    if (++ld_kw == a.KW) { ld_kw = 0; ++ld_kh; }
+    if (++ld_tap == taps) { ld_tap = 0; ld_kh = 0; ld_kw = 0; ++ld_chunk; }
   };
   auto store_lds = [&](int buf) {
     float* As = smem + buf * STAGE;
@@ -154,33 +174,72 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_global(0);
-  store_lds(0);
-  __syncthreads();
-
+  // ---- software pipeline -----------------------------------------------------------------
+  // One barrier per K step; everything else sits in the shadow of the MFMAs:
+  //   sub-step 0: read fragments of sub-step 1            | MFMAs of sub-step 0
+  //   sub-step 1: read fragments of sub-step 2            | MFMAs of sub-step 1
+  //               store the (landed) tile of step t+1 into the other LDS stage,
+  //               issue the buffer loads of step t+2 into the same registers
+  //   sub-step 2: read fragments of sub-step 3            | MFMAs of sub-step 2
+  //   barrier     (all LDS stores of step t+1 landed, all reads of this stage issued)
+  //   sub-step 3: read fragments of step t+1, sub-step 0  | MFMAs of sub-step 3
+  // The stage written in step t was last read before the barrier of step t-1 (WAR safe); it is
+  // first read after the barrier of step t (RAW safe).
   const int li = lane & 31, lh = lane >> 5;
+  const int a_frag = (wm * TM * 32 + li) * A_LD + lh * 4;
+  const int b_frag = A_FLOATS + (lh * BN + wn * TN * 32 + li) * 4;
+  f32x4 af[2][TM], bf[2][TN];
+  auto read_frags = [&](int buf, int sub, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
+    const float* As = smem + buf * STAGE + a_frag + sub * 8;
+    const float* Bs = smem + buf * STAGE + b_frag + sub * 2 * BN * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * A_LD);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * 4);
+  };
+  auto mfma_sub = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+  };
+
+  load_global();
+  store_lds(0);
+  if (nsteps > 1) load_global();
+  __syncthreads();
+  read_frags(0, 0, af[0], bf[0]);
+
   for (int t = 0; t < nsteps; ++t) {
     const int buf = t & 1;
-    if (t + 1 < nsteps) load_global(t + 1);
-    const float* As = smem + buf * STAGE + (wm * TM * 32 + li) * A_LD + lh * 4;
-    const float* Bs = smem + buf * STAGE + A_FLOATS + (lh * BN + wn * TN * 32 + li) * 4;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      f32x4 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * A_LD + s * 8);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + (s * 2 * BN + j * 32) * 4);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+    if (!(a.abl & 8)) read_frags(buf, 1, af[1], bf[1]);
+    mfma_sub(af[0], bf[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // fragment reads first ...
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);  // ... then the MFMAs that hide them
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(a.abl & 8)) read_frags(buf, 2, af[0], bf[0]);
+    mfma_sub(af[1], bf[1]);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 1);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 1);
+    if (t + 1 < nsteps) {
+      if (!(a.abl & 2)) store_lds(buf ^ 1);
+      if (t + 2 < nsteps && !(a.abl & 1)) load_global();
     }
-    if (t + 1 < nsteps) store_lds(buf ^ 1);
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(a.abl & 8)) read_frags(buf, 3, af[1], bf[1]);
+    mfma_sub(af[0], bf[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 2);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(a.abl & 4)) __syncthreads();
+    if (t + 1 < nsteps && !(a.abl & 8)) read_frags(buf ^ 1, 0, af[0], bf[0]);
+    mfma_sub(af[1], bf[1]);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 3);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 3);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // ---- epilogue: per-channel affine + activation, NHWC store ----------------------------
@@ -350,6 +409,14 @@ int fill_args(const pn_conv_desc* d, ConvArgs& a, int& zdim) {
   a.M = d->batch * a.OH * a.OWsub;
   a.cin_chunks = pn::cdiv(d->cin, BK);
   a.cout_pad = pn::cdiv(a.ncols, 32) * 32;
+  const unsigned long long in_bytes = (unsigned long long)d->batch * d->in_h * d->in_w * d->in_pixel_stride * 4ull;
+  PN_REQUIRE(in_bytes < (1ull << 31), "conv: input map larger than 2 GiB is not addressable by the buffer descriptor");
+  PN_REQUIRE(d->kh * d->kw <= 32, "conv: at most 32 taps");
+  a.in_bytes = (unsigned)in_bytes;
+  a.w_bytes = (unsigned)((size_t)d->kh * d->kw * a.cin_chunks * BK * a.cout_pad * 4);
+  a.force_tile = 0;
+  static const int abl = [] { const char* e = getenv("PN_CONV_ABL"); return e ? atoi(e) : 0; }();
+  a.abl = abl;
   return PN_OK;
 }
 
@@ -405,14 +472,26 @@ int pn_conv2d_nhwc_f32(const pn_conv_desc* d, const float* in, const float* pack
   PN_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "conv: pointers must be 16-byte aligned");
   a.in = in; a.w = packed_w; a.scale = scale; a.shift = shift; a.out = out;
   hipStream_t st = pn::S(stream);
-  const long long tiles128 = (long long)pn::cdiv(a.M, 128) * pn::cdiv(a.ncols, 128) * zdim;
-  if (a.ncols > 64) {
-    if (tiles128 >= 384) return launch_conv<2, 2, 2, 2>(a, zdim, st);            // 128 x 128
-    if ((long long)pn::cdiv(a.M, 64) * pn::cdiv(a.ncols, 128) * zdim >= 256) return launch_conv<2, 2, 1, 2>(a, zdim, st);  // 64 x 128
-    return launch_conv<2, 2, 1, 1>(a, zdim, st);                                // 64 x 64
+  // tile choice: fill the 256 CUs (8 waves per CU where possible) with the largest wave tile
+  static const int forced = [] { const char* e = getenv("PN_CONV_TILE"); return e ? atoi(e) : 0; }();
+  int tile = forced;
+  if (tile == 0) {
+    const long long t128 = (long long)pn::cdiv(a.M, 128) * pn::cdiv(a.ncols, 128) * zdim;
+    const long long t64x128 = (long long)pn::cdiv(a.M, 64) * pn::cdiv(a.ncols, 128) * zdim;
+    if (a.ncols > 64) tile = t128 >= 384 ? 1 : (t64x128 >= 256 ? 2 : 3);
+    else if (a.ncols > 32) tile = 3;
+    else tile = 4;
   }
-  if (a.ncols > 32) return launch_conv<2, 2, 1, 1>(a, zdim, st);                // 64 x 64
-  return launch_conv<2, 1, 1, 1>(a, zdim, st);                                  // 64 x 32
+  switch (tile) {
+    case 1: return launch_conv<2, 2, 2, 2>(a, zdim, st);  // 128 x 128, 4 waves of 64x64
+    case 2: return launch_conv<2, 2, 1, 2>(a, zdim, st);  //  64 x 128, 4 waves of 32x64
+    case 3: return launch_conv<2, 2, 1, 1>(a, zdim, st);  //  64 x  64, 4 waves of 32x32
+    case 4: return launch_conv<2, 1, 1, 1>(a, zdim, st);  //  64 x  32, 2 waves of 32x32
+    case 5: return launch_conv<2, 4, 1, 1>(a, zdim, st);  //  64 x 128, 8 waves of 32x32
+    case 6: return launch_conv<2, 2, 2, 1>(a, zdim, st);  // 128 x  64, 4 waves of 64x32
+    case 7: return launch_conv<4, 2, 1, 1>(a, zdim, st);  // 128 x  64, 8 waves of 32x32
+    default: return pn::fail(PN_ERR_INVALID, "conv: unknown tile id %d", tile);
+  }
 }
 
 int pn_conv2d_direct_nhwc_f32(const pn_conv_desc* d, const float* in, const float* w_oihw, const float* scale,

@@ -223,7 +223,7 @@ int pn_dynamic_pfn_fwd(const float* points, int point_stride, const int32_t* vox
                               (int)((16 * 64 + 2 * 64 * 128 + kPfnWaves * 64) * sizeof(float)));
     attr_done = true;
   }
-  const int blocks = std::max(1, std::min(1024, pn::cdiv(v_capacity, kPfnWaves * 4)));
+  const int blocks = std::max(1, std::min(2048, pn::cdiv(v_capacity, kPfnWaves * 2)));
   hipLaunchKernelGGL(dynamic_pfn_kernel, dim3(blocks), dim3(kPfnWaves * 64), smem, pn::S(stream), a);
   return pn::check_launch("dynamic_pfn_kernel");
 }
