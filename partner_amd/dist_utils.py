@@ -1,0 +1,58 @@
+"""Frame-level data parallelism helpers (one process per GPU, torch.distributed; backend "nccl"
+is RCCL on ROCm, "gloo" in the CPU tests).
+
+The inference hot path shards by frame with no data-path collective (frames are independent,
+like the reference's DistributedSampler, det3d/datasets/loader/sampler.py:74-96); the only
+exchanges are the barrier around the timed region and a MAX-reduce of the elapsed time.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend: str, device: Optional[torch.device] = None) -> bool:
+    """initialise the default process group from the torchrun environment; False when world size is 1"""
+    _, _, world = env_rank_world()
+    if world <= 1:
+        return False
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    kw = {}
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend, **kw)
+    return True
+
+
+def frame_shard(frame_ids: List[int], rank: int, world: int) -> List[int]:
+    """frames of this rank: frame i goes to rank i mod world (round-robin, no padding)"""
+    return [f for k, f in enumerate(frame_ids) if k % world == rank]
+
+
+def barrier() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

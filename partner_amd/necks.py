@@ -116,5 +116,6 @@ class RPN(nn.Module):
 
     def forward(self, x):
         """logical (B,C,H,W) in / out, as rpn.py:150-159"""
+        eval_only(self, "RPN")
         hip.require_device(x)
         return ops.as_nchw(self.forward_nhwc(ops.to_nhwc(x)))
