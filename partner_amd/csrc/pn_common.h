@@ -26,6 +26,11 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 constexpr int kWave = 64;
 
+// Zero-fill as an ordinary kernel (16-byte stores).  Used instead of hipMemsetAsync everywhere
+// in the library: memset *nodes* of a captured hipGraph were observed (ROCm 7.2) not to be
+// re-executed reliably between replays, kernel nodes always are.
+int zero_async(void* ptr, size_t bytes, hipStream_t st);
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 template <typename T>

@@ -1,5 +1,6 @@
 // Error reporting, device query, HIP-event helpers and small layout kernels of libpartner_hip.
 #include "pn_common.h"
+#include <algorithm>
 
 namespace pn {
 
@@ -14,6 +15,32 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(err_buf(), 512, fmt, ap);
   va_end(ap);
   return code;
+}
+
+namespace {
+__global__ void zero_fill_kernel(uint4* __restrict__ p16, size_t n16, unsigned char* __restrict__ tail, int ntail) {
+  const uint4 z = {0u, 0u, 0u, 0u};
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p16[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+}  // namespace
+
+int zero_async(void* ptr, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return PN_OK;
+  unsigned char* b = static_cast<unsigned char*>(ptr);
+  // head bytes up to 16-byte alignment are handled as a tail of a first tiny launch
+  const size_t mis = (16 - (reinterpret_cast<uintptr_t>(b) & 15)) & 15;
+  const size_t head = mis < bytes ? mis : bytes;
+  if (head) hipLaunchKernelGGL(zero_fill_kernel, dim3(1), dim3(64), 0, st, (uint4*)nullptr, (size_t)0, b, (int)head);
+  b += head;
+  bytes -= head;
+  const size_t n16 = bytes / 16;
+  const int ntail = (int)(bytes - n16 * 16);
+  if (n16 || ntail) {
+    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>(4096, (n16 + 255) / 256));
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<uint4*>(b), n16, b + n16 * 16, ntail);
+  }
+  return check_launch("zero_fill_kernel");
 }
 
 }  // namespace pn
@@ -77,9 +104,7 @@ int pn_device_count(void) {
 int pn_fill_zero(void* ptr, size_t bytes, pn_stream_t stream) {
   PN_REQUIRE(ptr || bytes == 0, "fill_zero: null pointer");
   if (bytes == 0) return PN_OK;
-  hipError_t e = hipMemsetAsync(ptr, 0, bytes, pn::S(stream));
-  if (e != hipSuccess) return pn::fail(PN_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
-  return PN_OK;
+  return pn::zero_async(ptr, bytes, pn::S(stream));
 }
 
 int pn_nchw_to_nhwc_f32(const float* in, int b, int c, int h, int w, float* out, pn_stream_t stream) {

@@ -306,9 +306,9 @@ int pn_unique_rank_bitmap(const uint32_t* keys, int n_capacity, const int32_t* n
   uint32_t* rank = reinterpret_cast<uint32_t*>(base + ws.off_rank);
   uint32_t* tiles = reinterpret_cast<uint32_t*>(base + ws.off_tiles);
   uint32_t* ukeys = reinterpret_cast<uint32_t*>(base + ws.off_keys);
-  hipError_t e = hipMemsetAsync(bitmap, 0, ws.nwords * 4, st);
-  if (e == hipSuccess && n_capacity > 0) e = hipMemsetAsync(unq_cnt, 0, (size_t)n_capacity * 4, st);
-  if (e != hipSuccess) return pn::fail(PN_ERR_LAUNCH, "unique: memset: %s", hipGetErrorString(e));
+  if (int rc = pn::zero_async(bitmap, ws.nwords * 4, st)) return rc;
+  if (n_capacity > 0)
+    if (int rc = pn::zero_async(unq_cnt, (size_t)n_capacity * 4, st)) return rc;
   const int pblocks = pn::cdiv(n_capacity > 0 ? n_capacity : 1, 256);
   if (n_capacity > 0) hipLaunchKernelGGL(mark_kernel, dim3(pblocks), dim3(256), 0, st, keys, n_capacity, n_dev, bitmap);
   hipLaunchKernelGGL(scan_tile_totals_kernel<0>, dim3((unsigned)ws.ntiles), dim3(kScanThreads), 0, st, bitmap, ws.nwords,
@@ -340,8 +340,7 @@ int pn_bucket_points(const int32_t* unq_inv, const int32_t* unq_cnt, int n_capac
   const size_t ntiles = (nitems + kScanTile - 1) / kScanTile;
   uint32_t* tiles = static_cast<uint32_t*>(workspace);
   int32_t* cursor = reinterpret_cast<int32_t*>(static_cast<char*>(workspace) + align256(ntiles * 4));
-  hipError_t e = hipMemsetAsync(cursor, 0, (size_t)n_capacity * 4, st);
-  if (e != hipSuccess) return pn::fail(PN_ERR_LAUNCH, "bucket: memset: %s", hipGetErrorString(e));
+  if (int rc = pn::zero_async(cursor, (size_t)n_capacity * 4, st)) return rc;
   const uint32_t* cnt = reinterpret_cast<const uint32_t*>(unq_cnt);
   hipLaunchKernelGGL(scan_tile_totals_kernel<1>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, st, cnt, (size_t)n_capacity,
                      num_voxels, tiles);
