@@ -74,7 +74,7 @@ struct PfnArgs {
   float* canvas;
 };
 
-constexpr int kPfnWaves = 4;
+constexpr int kPfnWaves = 8;  // 8 waves share one LDS copy of the weights: 4 blocks (32 waves) per CU
 
 __global__ __launch_bounds__(kPfnWaves * 64) void dynamic_pfn_kernel(PfnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -98,9 +98,14 @@ __global__ __launch_bounds__(kPfnWaves * 64) void dynamic_pfn_kernel(PfnArgs a) 
   const int nwaves = gridDim.x * kPfnWaves;
   const bool two = c1 > 64;  // second output channel per lane
 
+  // voxel metadata of the next iteration is fetched while the current voxel is processed
+  int n_s = 0, n_e = 0;
+  uint32_t n_key = 0;
+  if (wave < V) { n_s = a.vstart[wave]; n_e = a.vstart[wave + 1]; n_key = a.ukeys[wave]; }
   for (int v = wave; v < V; v += nwaves) {
-    const int s = a.vstart[v], e = a.vstart[v + 1];
-    uint32_t key = a.ukeys[v];
+    const int s = n_s, e = n_e;
+    uint32_t key = n_key;
+    if (v + nwaves < V) { n_s = a.vstart[v + nwaves]; n_e = a.vstart[v + nwaves + 1]; n_key = a.ukeys[v + nwaves]; }
     const int ri = key % a.R; key /= a.R;
     const int ti = key % a.T; key /= a.T;
     const int bi = key / a.Z;
@@ -223,7 +228,7 @@ int pn_dynamic_pfn_fwd(const float* points, int point_stride, const int32_t* vox
                               (int)((16 * 64 + 2 * 64 * 128 + kPfnWaves * 64) * sizeof(float)));
     attr_done = true;
   }
-  const int blocks = std::max(1, std::min(2048, pn::cdiv(v_capacity, kPfnWaves * 2)));
+  const int blocks = std::max(1, std::min(1024, pn::cdiv(v_capacity, kPfnWaves * 2)));
   hipLaunchKernelGGL(dynamic_pfn_kernel, dim3(blocks), dim3(kPfnWaves * 64), smem, pn::S(stream), a);
   return pn::check_launch("dynamic_pfn_kernel");
 }

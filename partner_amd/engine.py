@@ -28,7 +28,10 @@ class FrameEngine:
         polar = ops.cart_to_polar(self.cart)
         return self.model.forward_points(polar, self.offsets, self.batch, self.spec)
 
-    def capture(self, warmup: int = 3) -> "FrameEngine":
+    def capture(self, warmup: int = 3, stream: "torch.cuda.Stream" = None) -> "FrameEngine":
+        """capture the frame into a HIP graph; `stream` (optional) is the stream the graph will be
+        replayed on (several engines on different streams overlap their frames on the GPU)"""
+        self.stream = stream
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -46,6 +49,11 @@ class FrameEngine:
         overwritten by the next call)."""
         if self.graph is None:
             self.capture()
-        self.cart.copy_(cart, non_blocking=True)
-        self.graph.replay()
+        if getattr(self, "stream", None) is not None:
+            with torch.cuda.stream(self.stream):
+                self.cart.copy_(cart, non_blocking=True)
+                self.graph.replay()
+        else:
+            self.cart.copy_(cart, non_blocking=True)
+            self.graph.replay()
         return self.outputs
