@@ -107,6 +107,24 @@ int pn_bucket_points(const int32_t *unq_inv, const int32_t *unq_cnt, int n_capac
                      int32_t *order, void *workspace, size_t workspace_bytes, pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * V2  hard voxelization (first-come voxel ids, <= max_points points per voxel in point order,
+ * <= max_voxels voxels, points outside the grid dropped).
+ * Replaces points_to_voxel / _points_to_voxel_reverse_kernel
+ *          det3d/ops/point_cloud/point_cloud_ops.py:146-224, 7-72 (via VoxelGenerator.generate,
+ *          det3d/core/input/voxel_generator.py:19-32)
+ * points (n x f, row stride point_stride; first three features are the grid coordinates),
+ * voxel_size[3], range[6] host floats (fp32 arithmetic as in the reference).  Outputs, bit-exact:
+ *   voxels (max_voxels x max_points x f) zero filled, coors int32 (max_voxels x 3) [z,theta,r],
+ *   num_points int32 (max_voxels), num_voxels device int32[1].
+ * Deterministic: no sort, no order-dependent atomics (see voxelize.hip).
+ */
+size_t pn_hard_voxelize_workspace_bytes(uint64_t num_cells, int n, int max_points);
+int pn_hard_voxelize_f32(const float *points, int n, int point_stride, int f, const float *voxel_size,
+                         const float *range, int max_points, int max_voxels, float *voxels,
+                         int32_t *coors, int32_t *num_points, int32_t *num_voxels, void *workspace,
+                         size_t workspace_bytes, pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * V3  per-voxel mean of point features.
  * Replaces torch_scatter.scatter_mean(features, unq_inv) in DynamicVoxelEncoderV1.forward
  *          det3d/models/readers/voxel_encoder.py:38-45

@@ -5,6 +5,8 @@
 // of occupied cells with a smaller key = an exclusive prefix sum of popcounts over an
 // occupancy bitmap.  No sort, no host synchronisation; the voxel count stays on the device.
 #include "pn_common.h"
+#include <algorithm>
+#include <cmath>
 
 namespace {
 
@@ -81,6 +83,7 @@ __global__ void mark_kernel(const uint32_t* __restrict__ keys, int n_cap, const 
   const int n = n_dev ? min(*n_dev, n_cap) : n_cap;
   if (i >= n) return;
   const uint32_t k = keys[i];
+  if (k == 0xffffffffu) return;  // dropped point (hard voxelization: out of range)
   atomicOr(&bitmap[k >> 5], 1u << (k & 31));
 }
 
@@ -195,6 +198,10 @@ __global__ void rank_points_kernel(const uint32_t* __restrict__ keys, int n_cap,
   const int n = n_dev ? min(*n_dev, n_cap) : n_cap;
   if (i >= n) return;
   const uint32_t k = keys[i];
+  if (k == 0xffffffffu) {
+    inv[i] = -1;
+    return;
+  }
   const uint32_t w = k >> 5, bit = k & 31;
   const int32_t r = (int32_t)(word_rank[w] + __popc(bitmap[w] & ((1u << bit) - 1u)));
   inv[i] = r;
@@ -230,6 +237,105 @@ __global__ void bucket_fill_kernel(const int32_t* __restrict__ inv, int n_cap, c
   if (i >= n) return;
   const int v = inv[i];
   order[voxel_start[v] + atomicAdd(&cursor[v], 1)] = i;
+}
+
+
+// ---------------------------------------------------------------------------- V2 hard voxelization
+// Reference semantics (point_cloud_ops.py:7-72): points are visited in order; a point outside the
+// grid is dropped; a voxel's id is its order of first appearance; at most max_voxels voxels are
+// created (later new voxels are refused, existing ones keep accepting); a voxel keeps its first
+// max_points points in point order.  Deterministic parallel formulation:
+//   rank r of the cell in key order (bitmap scan)  ->  first[r] = min point index (atomicMin)
+//   voxel id = number of "first" points with a smaller index (prefix sum over the points)
+//   slot k of voxel r = k-th smallest point index of the cell: max_points rounds of atomicMin
+__global__ void hard_keys_kernel(const float* __restrict__ pts, int n, int stride, GridParams gp, uint32_t* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = pts + (size_t)i * stride;
+  int c[3];
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float q = floorf((float)((double)__fsub_rn(p[a], gp.lo[a]) / (double)gp.vs[a]));  // IEEE fp32 quotient
+    ok = ok && q >= 0.f && q < (float)gp.g[a];
+    c[a] = (int)q;
+  }
+  keys[i] = ok ? (uint32_t)(((size_t)c[2] * gp.g[1] + c[1]) * gp.g[0] + c[0]) : 0xffffffffu;
+}
+
+__global__ void hard_first_kernel(const int32_t* __restrict__ inv, int n, int32_t* __restrict__ first) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || inv[i] < 0) return;
+  atomicMin(&first[inv[i]], i);
+}
+
+__global__ void hard_flag_kernel(const int32_t* __restrict__ inv, int n, const int32_t* __restrict__ first,
+                                 uint32_t* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flag[i] = (inv[i] >= 0 && first[inv[i]] == i) ? 1u : 0u;
+}
+
+// exclusive scan of flag[] over the points (third phase), written to vid_at[i]
+__global__ void scan_emit_flags_kernel(const uint32_t* __restrict__ flag, size_t n, const uint32_t* __restrict__ tile_offset,
+                                       int32_t* __restrict__ vid_at) {
+  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
+  uint32_t vals[kScanItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    vals[k] = base + k < n ? flag[base + k] : 0u;
+    s += vals[k];
+  }
+  uint32_t tot;
+  uint32_t run = tile_offset[blockIdx.x] + block_exclusive_scan(s, &tot);
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < n) vid_at[base + k] = (int32_t)run;
+    run += vals[k];
+  }
+}
+
+// one selection round: sel_k[r] = smallest point index of cell r that is larger than sel_{k-1}[r]
+__global__ void hard_select_kernel(const int32_t* __restrict__ inv, int n, const int32_t* __restrict__ prev,
+                                   int32_t* __restrict__ cur) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int r = inv[i];
+  if (r < 0) return;
+  if (prev == nullptr || i > prev[r]) atomicMin(&cur[r], i);
+}
+
+__global__ void hard_fill_int_kernel(int32_t* __restrict__ p, size_t n, int32_t v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// gather: one thread per (cell rank, slot, feature)
+__global__ void hard_gather_kernel(const float* __restrict__ pts, int stride, int f, const int32_t* __restrict__ v_dev,
+                                   int v_cap, const int32_t* __restrict__ first, const int32_t* __restrict__ vid_at,
+                                   const int32_t* __restrict__ sel, int max_points, int max_voxels,
+                                   const uint32_t* __restrict__ ukeys, const int32_t* __restrict__ cnt, int R, int T,
+                                   float* __restrict__ voxels, int32_t* __restrict__ coors, int32_t* __restrict__ num,
+                                   int32_t* __restrict__ num_voxels) {
+  const int V = min(*v_dev, v_cap);
+  const size_t total = (size_t)V * max_points * f;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % f);
+    const int slot = (int)((idx / f) % max_points);
+    const int r = (int)(idx / ((size_t)f * max_points));
+    const int vid = vid_at[first[r]];
+    if (vid >= max_voxels) continue;
+    const int src = sel[(size_t)slot * v_cap + r];
+    if (src != 0x7fffffff) voxels[((size_t)vid * max_points + slot) * f + k] = pts[(size_t)src * stride + k];
+    if (slot == 0 && k == 0) {
+      uint32_t q = ukeys[r];
+      coors[3 * vid + 2] = q % R; q /= R;
+      coors[3 * vid + 1] = q % T; q /= T;
+      coors[3 * vid + 0] = q;
+      num[vid] = min(cnt[r], max_points);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *num_voxels = min(V, max_voxels);
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -351,6 +457,75 @@ int pn_bucket_points(const int32_t* unq_inv, const int32_t* unq_cnt, int n_capac
   hipLaunchKernelGGL(bucket_fill_kernel, dim3(pn::cdiv(n_capacity, 256)), dim3(256), 0, st, unq_inv, n_capacity, n_dev,
                      voxel_start, cursor, order);
   return pn::check_launch("bucket_points");
+}
+
+
+size_t pn_hard_voxelize_workspace_bytes(uint64_t num_cells, int n, int max_points) {
+  // unique workspace + inv + cnt + first + flag + vid_at + tiles + sel[max_points][n] + nv
+  const size_t ntiles = ((size_t)n + kScanTile - 1) / kScanTile;
+  return UniqueWs(num_cells, n).total + 5 * align256((size_t)n * 4) + align256(ntiles * 4) + align256((size_t)n * 4) +
+         align256((size_t)max_points * n * 4) + 256;
+}
+
+int pn_hard_voxelize_f32(const float* points, int n, int point_stride, int f, const float* voxel_size, const float* range,
+                         int max_points, int max_voxels, float* voxels, int32_t* coors, int32_t* num_points,
+                         int32_t* num_voxels, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(points && voxel_size && range && voxels && coors && num_points && num_voxels && workspace,
+             "hard_voxelize: null pointer");
+  PN_REQUIRE(n >= 0 && f >= 3 && point_stride >= f && max_points >= 1 && max_voxels >= 1, "hard_voxelize: bad sizes");
+  GridParams gp;
+  uint64_t cells = 1;
+  for (int a = 0; a < 3; ++a) {
+    gp.lo[a] = range[a];
+    gp.vs[a] = voxel_size[a];
+    gp.g[a] = (int)nearbyintf((range[3 + a] - range[a]) / voxel_size[a]);  // np.round(...) of the fp32 quotient
+    PN_REQUIRE(gp.g[a] >= 1, "hard_voxelize: empty grid");
+    cells *= (uint64_t)gp.g[a];
+  }
+  PN_REQUIRE(cells < (1ull << 32) - 1, "hard_voxelize: more than 2^32 cells");
+  if (workspace_bytes < pn_hard_voxelize_workspace_bytes(cells, n, max_points))
+    return pn::fail(PN_ERR_WORKSPACE, "hard_voxelize: workspace too small");
+  hipStream_t st = pn::S(stream);
+  if (int rc = pn::zero_async(voxels, (size_t)max_voxels * max_points * f * 4, st)) return rc;
+  if (int rc = pn::zero_async(num_voxels, 4, st)) return rc;
+  if (n == 0) return PN_OK;
+  char* w = static_cast<char*>(workspace);
+  UniqueWs uws(cells, n);
+  void* uniq_ws = w; w += uws.total;
+  auto take = [&](size_t bytes) { char* p = w; w += align256(bytes); return p; };
+  uint32_t* keys = (uint32_t*)take((size_t)n * 4);
+  int32_t* inv = (int32_t*)take((size_t)n * 4);
+  int32_t* cnt = (int32_t*)take((size_t)n * 4);
+  int32_t* first = (int32_t*)take((size_t)n * 4);
+  uint32_t* flag = (uint32_t*)take((size_t)n * 4);
+  int32_t* vid_at = (int32_t*)take((size_t)n * 4);
+  const size_t ntiles = ((size_t)n + kScanTile - 1) / kScanTile;
+  uint32_t* tiles = (uint32_t*)take(ntiles * 4);
+  int32_t* sel = (int32_t*)take((size_t)max_points * n * 4);
+  int32_t* nv = (int32_t*)take(4);
+  const int pb = pn::cdiv(n, 256);
+  hipLaunchKernelGGL(hard_keys_kernel, dim3(pb), dim3(256), 0, st, points, n, point_stride, gp, keys);
+  int32_t grid3[3] = {gp.g[0], gp.g[1], gp.g[2]};
+  if (int rc = pn_unique_rank_bitmap(keys, n, nullptr, cells, grid3, nullptr, inv, cnt, nv, uniq_ws, uws.total, stream)) return rc;
+  const uint32_t* ukeys = pn_unique_keys_ptr(uniq_ws, cells, n);
+  const unsigned fb = (unsigned)std::min<size_t>(2048, ((size_t)(max_points + 1) * n + 255) / 256);
+  hipLaunchKernelGGL(hard_fill_int_kernel, dim3(fb), dim3(256), 0, st, first, (size_t)n, 0x7fffffff);
+  hipLaunchKernelGGL(hard_fill_int_kernel, dim3(fb), dim3(256), 0, st, sel, (size_t)max_points * n, 0x7fffffff);
+  hipLaunchKernelGGL(hard_first_kernel, dim3(pb), dim3(256), 0, st, inv, n, first);
+  hipLaunchKernelGGL(hard_flag_kernel, dim3(pb), dim3(256), 0, st, inv, n, first, flag);
+  hipLaunchKernelGGL(scan_tile_totals_kernel<1>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, st, flag, (size_t)n,
+                     (const int32_t*)nullptr, tiles);
+  hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(kScanThreads), 0, st, tiles, (int)ntiles, (int32_t*)nullptr,
+                     (int32_t*)nullptr);
+  hipLaunchKernelGGL(scan_emit_flags_kernel, dim3((unsigned)ntiles), dim3(kScanThreads), 0, st, flag, (size_t)n, tiles, vid_at);
+  for (int k = 0; k < max_points; ++k)
+    hipLaunchKernelGGL(hard_select_kernel, dim3(pb), dim3(256), 0, st, inv, n, k ? sel + (size_t)(k - 1) * n : (const int32_t*)nullptr,
+                       sel + (size_t)k * n);
+  const size_t total = (size_t)n * max_points * f;
+  hipLaunchKernelGGL(hard_gather_kernel, dim3((unsigned)std::min<size_t>(8192, (total + 255) / 256)), dim3(256), 0, st, points,
+                     point_stride, f, nv, n, first, vid_at, sel, max_points, max_voxels, ukeys, cnt, gp.g[0], gp.g[1], voxels,
+                     coors, num_points, num_voxels);
+  return pn::check_launch("hard_voxelize");
 }
 
 }  // extern "C"

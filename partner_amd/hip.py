@@ -49,6 +49,8 @@ SIGNATURES = {
     "pn_unique_keys_ptr": (_P, [_P, _U64, _I]),
     "pn_bucket_workspace_bytes": (_SZ, [_I]),
     "pn_bucket_points": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "pn_hard_voxelize_workspace_bytes": (_SZ, [_U64, _I, _I]),
+    "pn_hard_voxelize_f32": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "pn_scatter_mean_f32": (_I, [_P, _I, _I, _P, _P, _P, _I, _P, _P]),
     "pn_hard_voxel_mean_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "pn_dynamic_pfn_fwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _F, _F, _F, _F, _P, _P, _P]),

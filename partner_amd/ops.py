@@ -373,3 +373,30 @@ def groupnorm_strat(x: torch.Tensor, channel_groups: int, range_strata: int, gam
              hip.ptr(beta), float(eps), int(act), out.data_ptr(), c, 0, hip.ptr(mul), hip.ptr(add), hip.ptr(out2),
              ws.data_ptr(), ws_bytes, hip.stream())
     return out if out2 is None else (out, out2)
+
+
+# ------------------------------------------------------------------------------ V2 hard voxelization
+def hard_voxelize(points: torch.Tensor, voxel_size, pc_range, max_points: int, max_voxels: int):
+    """-> voxels (max_voxels, max_points, F), coors int32 (max_voxels, 3) [z,theta,r], num_points int32
+    (max_voxels,), num_voxels (1,) int32 on the device; rows >= num_voxels are zero / undefined."""
+    import numpy as np
+
+    hip.require_device(points)
+    lib = hip.load()
+    assert points.dtype == torch.float32 and points.is_contiguous()
+    n, f = points.shape
+    vs = np.asarray(voxel_size, dtype=np.float32)
+    rg = np.asarray(pc_range, dtype=np.float32)
+    grid = np.round((rg[3:] - rg[:3]) / vs).astype(np.int64)
+    cells = int(grid[0]) * int(grid[1]) * int(grid[2])
+    dev = points.device
+    voxels = torch.empty((max_voxels, max_points, f), dtype=torch.float32, device=dev)
+    coors = torch.zeros((max_voxels, 3), dtype=torch.int32, device=dev)
+    num = torch.zeros((max_voxels,), dtype=torch.int32, device=dev)
+    nv = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws_bytes = lib.pn_hard_voxelize_workspace_bytes(cells, n, max_points)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    hip.call("pn_hard_voxelize_f32", points.data_ptr(), n, points.stride(0), f, (C.c_float * 3)(*vs.tolist()),
+             (C.c_float * 6)(*rg.tolist()), int(max_points), int(max_voxels), voxels.data_ptr(), coors.data_ptr(),
+             num.data_ptr(), nv.data_ptr(), ws.data_ptr(), ws_bytes, hip.stream())
+    return voxels, coors, num, nv
