@@ -39,6 +39,7 @@ extern "C" {
 #define PN_ACT_NONE 0
 #define PN_ACT_RELU 1
 #define PN_ACT_TANH 2
+#define PN_ACT_GELU 3
 
 typedef void *pn_stream_t;
 
@@ -245,10 +246,57 @@ int pn_groupnorm_strat_fwd(const float *x, int batch, int h, int w, int c, int p
                            const float *add, float *out2, void *workspace, size_t workspace_bytes,
                            pn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Dense linear layer on the same MFMA kernel (a 1x1 convolution over a token "image"):
+ *   out[m][:n] = act(x[m][:k] @ W^T + bias) (+ residual[m][:n])
+ * Replaces nn.Linear / Mlp / proj of the attention block  det3d/models/utils/set_transformer.py:37-53
+ * packed_w: pn_pack_conv_weight_f32 of the (n, k) torch weight seen as (n, k, 1, 1).
+ */
+int pn_gemm_bias_act_f32(const float *x, int m, int k, int ldx, const float *packed_w, int n,
+                         const float *bias, int act, const float *residual, int ldr, float *out,
+                         int ldo, pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * A1  global representation re-alignment (SetBlock / SetAttention), non-GEMM parts.
+ * Tokens are (B, H, W, C) fp32 in physical column order; `shift` (0 or win_w/2) is the azimuth
+ * roll of the odd blocks, applied as an index mapping.  pos: (H, W, 2) Cartesian cell centres
+ * (det3d/models/detectors/voxelnet.py:10-25).  pos_mlp: the folded relative-position MLP
+ * [w1(16x2) | bn_scale(16) | bn_shift(16) | w2(heads x 16) | b2(heads)]
+ * (Conv1d(2,16)+BatchNorm1d(eval)+ReLU+Conv1d(16,heads), set_transformer.py:96-100).
+ */
+/* nn.LayerNorm over C; chan_mean (rows) optional = mean_C(out)  (set_transformer.py:121,135) */
+int pn_layernorm_f32(const float *x, size_t rows, int c, const float *gamma, const float *beta,
+                     float eps, float *out, float *chan_mean, pn_stream_t stream);
+/* key-point selection: top-k local maxima of chan_mean along range per azimuth column
+ * (set_transformer.py:134-147) -> top_idx int32 (B,k,W), kp (B, k*W, C), kpos (B,k,W,2) */
+int pn_setblock_keypoints(const float *chan_mean, const float *xn, const float *pos, int batch, int h,
+                          int w, int c, int k, int shift, int32_t *top_idx, float *kp, float *kpos,
+                          pn_stream_t stream);
+/* SectorAttention core: key points attend to their column (set_transformer.py:307-354).
+ * q_raw: proj_q(kp) (B, k*W, C) read through the reference's raw (B,C,k,W) view; kv: (B,H,W,2C) */
+int pn_setblock_sector_kp_attn(const float *q_raw, const float *kv, const float *xpos,
+                               const float *kpos, const float *pos_mlp, int batch, int h, int w, int c,
+                               int heads, int k, int shift, float scale, float *out,
+                               pn_stream_t stream);
+/* RangeAttention core among key points, windows k x win_w (set_transformer.py:216-259);
+ * qkv: (B, k*W, 3C) -> out (B, k*W, C) */
+int pn_setblock_range_attn(const float *qkv, const float *kpos, const float *pos_mlp, int batch, int w,
+                           int c, int heads, int k, int win_w, float scale, float *out,
+                           pn_stream_t stream);
+/* SectorAttentionV2 core: every column token attends to its k key points
+ * (set_transformer.py:392-440); q: (B,H,W,C), kv_raw: (B, k*W, 2C) -> out (B,H,W,C) */
+int pn_setblock_sector_col_attn(const float *q, const float *kv_raw, const float *xpos,
+                                const float *kpos, const float *pos_mlp, int batch, int h, int w, int c,
+                                int heads, int k, int shift, float scale, float *out,
+                                pn_stream_t stream);
+
 /* layout helpers at the API boundary */
 int pn_nchw_to_nhwc_f32(const float *in, int b, int c, int h, int w, float *out, pn_stream_t stream);
 int pn_nhwc_to_nchw_f32(const float *in, int b, int c, int h, int w, int pixel_stride,
                         int channel_offset, float *out, pn_stream_t stream);
+/* (B,H,W,C) -> (B,W,H,C): the (theta,r) <-> (r,theta) token order change around the attention
+ * blocks, x.permute(0,1,3,2) at det3d/models/detectors/voxelnet.py:211,219 */
+int pn_transpose_hw_f32(const float *in, int b, int h, int w, int c, float *out, pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * timing helper: HIP events on `stream`, used by bench.py for the roofline object.

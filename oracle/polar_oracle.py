@@ -459,7 +459,7 @@ def _raw_view_keypoints(t: Tensor, B: int, K: int, W: int, heads: int) -> Tensor
 
 
 def set_attention(sd: SD, p: str, x: Tensor, pos_cart: Tensor, reso, heads: int, K=4, win_w=8, shift=False,
-                  return_topidx=False):
+                  return_topidx=False, top_override=None, return_scores=False):
     """SetAttention.forward for H_sp=H (full range column), W_sp=1.  x (B,L,C); pos_cart (B,H,W,2)."""
     H, W = reso
     B, L, C = x.shape
@@ -478,7 +478,14 @@ def set_attention(sd: SD, p: str, x: Tensor, pos_cart: Tensor, reso, heads: int,
     lm = torch.zeros_like(st)
     lm[:, :, 1:-1] = F.max_pool1d(st, 3, 1, 0)
     s = (st * (lm == st)).permute(0, 2, 1)
+    scores = s
     top = s.argsort(dim=1, descending=True)[:, :K, :]  # (B,K,W)
+    if top_override is not None:
+        # checker option: use externally supplied key-point rows.  torch's argsort is not stable, so when
+        # fewer than K positive local maxima exist the reference's choice among the tied zeros is
+        # implementation defined (it differs between torch's CPU and GPU sorts); the HIP kernel breaks
+        # ties towards the smaller row index.
+        top = top_override
     kp = xn.gather(1, top[..., None].expand(-1, -1, -1, C)).reshape(B, K * W, C)
     kpos = xpos.gather(1, top[..., None].expand(-1, -1, -1, 2))  # (B,K,W,2)
     xt = xn.reshape(B, L, C)
@@ -532,6 +539,8 @@ def set_attention(sd: SD, p: str, x: Tensor, pos_cart: Tensor, reso, heads: int,
     o = o.reshape(B, L, C)
     y = shortcut + _lin(sd, p + "proj.", o)
     y = y + _mlp(sd, p + "mlp.", _ln(sd, p + "norm2.", y))
+    if return_scores:
+        return y, top, scores
     return (y, top) if return_topidx else y
 
 

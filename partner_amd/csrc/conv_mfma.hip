@@ -52,6 +52,8 @@ struct ConvArgs {
   unsigned in_bytes;     // size of the input allocation seen through the buffer descriptor
   unsigned w_bytes;      // size of the packed weights
   int force_tile;        // >0: tile override (tuning / tests)
+  const float* res;      // optional residual added after the activation (GEMM use)
+  int res_ps;
   int abl;               // ablation bits for tuning builds (PN_CONV_ABL): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no fragment reads
 };
 
@@ -328,6 +330,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
       f32x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = pn::apply_act(fmaf(v[k], vs[k], vh[k]), a.act);
+      if (a.res) {
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + pix * a.res_ps + coff);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] += rv[k];
+      }
       *reinterpret_cast<f32x4*>(a.out + pix * a.out_ps + coff) = o;
     }
     return;
@@ -377,7 +384,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
           const size_t opix = ((size_t)b * (2 * a.OH) + 2 * oh + (col_d[j] >> 1)) * (2 * a.OW) + 2 * ow + (col_d[j] & 1);
           dst = a.out + opix * a.out_ps + col_off[j];
         }
-        *dst = pn::apply_act(fmaf(acc[i][j][r], sc[j], sh[j]), a.act);
+        float o = pn::apply_act(fmaf(acc[i][j][r], sc[j], sh[j]), a.act);
+        if (a.res) o += a.res[pix * a.res_ps + col_off[j]];
+        *dst = o;
       }
     }
   }
@@ -510,9 +519,34 @@ int fill_args(const pn_conv_desc* d, ConvArgs& a, int& zdim) {
   a.in_bytes = (unsigned)in_bytes;
   a.w_bytes = (unsigned)((size_t)d->kh * d->kw * a.cin_chunks * BK * a.cout_pad * 4);
   a.force_tile = 0;
+  a.res = nullptr;
+  a.res_ps = 0;
   static const int abl = [] { const char* e = getenv("PN_CONV_ABL"); return e ? atoi(e) : 0; }();
   a.abl = abl;
   return PN_OK;
+}
+
+int dispatch_conv(const ConvArgs& a, int zdim, hipStream_t st) {
+  // tile choice: fill the 256 CUs (8 waves per CU where possible) with the largest wave tile
+  static const int forced = [] { const char* e = getenv("PN_CONV_TILE"); return e ? atoi(e) : 0; }();
+  int tile = forced;
+  if (tile == 0) {
+    const long long t128 = (long long)pn::cdiv(a.M, 128) * pn::cdiv(a.ncols, 128) * zdim;
+    const long long t64x128 = (long long)pn::cdiv(a.M, 64) * pn::cdiv(a.ncols, 128) * zdim;
+    if (a.ncols > 64) tile = t128 >= 384 ? 1 : (t64x128 >= 256 ? 2 : 3);
+    else if (a.ncols > 32) tile = 3;
+    else tile = 4;
+  }
+  switch (tile) {
+    case 1: return launch_conv<2, 2, 2, 2>(a, zdim, st);  // 128 x 128, 4 waves of 64x64
+    case 2: return launch_conv<2, 2, 1, 2>(a, zdim, st);  //  64 x 128, 4 waves of 32x64
+    case 3: return launch_conv<2, 2, 1, 1>(a, zdim, st);  //  64 x  64, 4 waves of 32x32
+    case 4: return launch_conv<2, 1, 1, 1>(a, zdim, st);  //  64 x  32, 2 waves of 32x32
+    case 5: return launch_conv<2, 4, 1, 1>(a, zdim, st);  //  64 x 128, 8 waves of 32x32
+    case 6: return launch_conv<2, 2, 2, 1>(a, zdim, st);  // 128 x  64, 4 waves of 64x32
+    case 7: return launch_conv<4, 2, 1, 1>(a, zdim, st);  // 128 x  64, 8 waves of 32x32
+    default: return pn::fail(PN_ERR_INVALID, "conv: unknown tile id %d", tile);
+  }
 }
 
 }  // namespace
@@ -567,26 +601,24 @@ int pn_conv2d_nhwc_f32(const pn_conv_desc* d, const float* in, const float* pack
   PN_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "conv: pointers must be 16-byte aligned");
   a.in = in; a.w = packed_w; a.scale = scale; a.shift = shift; a.out = out;
   hipStream_t st = pn::S(stream);
-  // tile choice: fill the 256 CUs (8 waves per CU where possible) with the largest wave tile
-  static const int forced = [] { const char* e = getenv("PN_CONV_TILE"); return e ? atoi(e) : 0; }();
-  int tile = forced;
-  if (tile == 0) {
-    const long long t128 = (long long)pn::cdiv(a.M, 128) * pn::cdiv(a.ncols, 128) * zdim;
-    const long long t64x128 = (long long)pn::cdiv(a.M, 64) * pn::cdiv(a.ncols, 128) * zdim;
-    if (a.ncols > 64) tile = t128 >= 384 ? 1 : (t64x128 >= 256 ? 2 : 3);
-    else if (a.ncols > 32) tile = 3;
-    else tile = 4;
-  }
-  switch (tile) {
-    case 1: return launch_conv<2, 2, 2, 2>(a, zdim, st);  // 128 x 128, 4 waves of 64x64
-    case 2: return launch_conv<2, 2, 1, 2>(a, zdim, st);  //  64 x 128, 4 waves of 32x64
-    case 3: return launch_conv<2, 2, 1, 1>(a, zdim, st);  //  64 x  64, 4 waves of 32x32
-    case 4: return launch_conv<2, 1, 1, 1>(a, zdim, st);  //  64 x  32, 2 waves of 32x32
-    case 5: return launch_conv<2, 4, 1, 1>(a, zdim, st);  //  64 x 128, 8 waves of 32x32
-    case 6: return launch_conv<2, 2, 2, 1>(a, zdim, st);  // 128 x  64, 4 waves of 64x32
-    case 7: return launch_conv<4, 2, 1, 1>(a, zdim, st);  // 128 x  64, 8 waves of 32x32
-    default: return pn::fail(PN_ERR_INVALID, "conv: unknown tile id %d", tile);
-  }
+  return dispatch_conv(a, zdim, st);
+}
+
+int pn_gemm_bias_act_f32(const float* x, int m, int k, int ldx, const float* packed_w, int n, const float* bias, int act,
+                         const float* residual, int ldr, float* out, int ldo, pn_stream_t stream) {
+  PN_REQUIRE(x && packed_w && out && m > 0 && k > 0 && n > 0, "gemm: bad arguments");
+  PN_REQUIRE(k % 4 == 0 && ldx % 4 == 0 && ldx >= k && ldo >= n, "gemm: k and the row strides must be multiples of 4");
+  PN_REQUIRE(residual == nullptr || ldr >= n, "gemm: bad residual stride");
+  pn_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.batch = 1; d.in_h = m; d.in_w = 1; d.cin = k; d.cout = n; d.groups = 1; d.kh = d.kw = 1; d.stride = 1;
+  d.in_pixel_stride = ldx; d.out_pixel_stride = ldo; d.act = act;
+  ConvArgs a;
+  int zdim = 1;
+  if (int rc = fill_args(&d, a, zdim)) return rc;
+  a.in = x; a.w = packed_w; a.scale = nullptr; a.shift = bias; a.out = out;
+  a.res = residual; a.res_ps = ldr;
+  return dispatch_conv(a, zdim, pn::S(stream));
 }
 
 int pn_conv2d_direct_nhwc_f32(const pn_conv_desc* d, const float* in, const float* w_oihw, const float* scale,

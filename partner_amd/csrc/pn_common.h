@@ -43,6 +43,7 @@ __device__ __forceinline__ T wave_sum(T v) {
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == PN_ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == PN_ACT_TANH) return tanhf(v);
+  if (act == PN_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // exact (erf) GELU
   return v;
 }
 

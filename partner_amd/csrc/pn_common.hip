@@ -78,9 +78,31 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int c, int hw,
   }
 }
 
+// (B,H,W,C) -> (B,W,H,C): swap the two spatial axes, channel vectors stay contiguous
+__global__ void transpose_hw_kernel(const float* __restrict__ in, int h, int w, int c, float* __restrict__ out, size_t total4) {
+  const int c4 = c / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int k = (int)(r % c4); r /= c4;
+    const int y = (int)(r % h); r /= h;   // output is (b, x, y, c): y fastest after c
+    const int x = (int)(r % w);
+    const size_t b = r / w;
+    const float4 v = *reinterpret_cast<const float4*>(in + (((b * h + y) * w + x) * (size_t)c) + k * 4);
+    *reinterpret_cast<float4*>(out + i * 4) = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pn_transpose_hw_f32(const float* in, int b, int h, int w, int c, float* out, pn_stream_t stream) {
+  PN_REQUIRE(in && out && b > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "transpose_hw: bad arguments (c must be a multiple of 4)");
+  const size_t total4 = (size_t)b * h * w * (c / 4);
+  hipLaunchKernelGGL(transpose_hw_kernel, dim3((unsigned)std::min<size_t>(8192, (total4 + 255) / 256)), dim3(256), 0, pn::S(stream),
+                     in, h, w, c, out, total4);
+  return pn::check_launch("transpose_hw_kernel");
+}
 
 int pn_version(void) { return 100; }
 

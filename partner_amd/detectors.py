@@ -121,3 +121,52 @@ class VoxelNet(SingleStageDetector):
 
     def forward(self, example, return_loss=True, **kwargs):
         raise NotImplementedError("VoxelNet forward needs the sparse 3-D backbone (SURVEY.md 8f next-1), not built yet")
+
+
+@builder.BACKBONES.register_module
+class SpMiddleResNetFHD(nn.Module):
+    """Sparse 3-D middle encoder of the Waymo PARTNER config (det3d/models/backbones/scn.py:97-192).  Its
+    arithmetic lives in the third-party spconv package; a gfx950 sparse convolution is SURVEY.md 8f next-1.
+    Registered so that the config builds; calling it raises."""
+
+    def __init__(self, num_input_features=128, norm_cfg=None, name="SpMiddleResNetFHD", **kwargs):
+        super().__init__()
+        self.name = name
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("SpMiddleResNetFHD (sparse 3-D convolutions) has no gfx950 kernel yet (SURVEY.md 8f next-1)")
+
+
+@DETECTORS.register_module
+class VoxelNetV3(SingleStageDetector):
+    """PARTNER detector (voxelnet.py:171-301): hard voxels -> mean VFE -> sparse 3-D backbone -> two SetBlocks
+    (global representation re-alignment) -> RPN -> head.  The re-alignment stage is built and runs on the HIP
+    kernels (``realign``); the end-to-end forward waits for the sparse backbone."""
+
+    def __init__(self, reader, backbone, neck, bbox_head, seg_head=None, part_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None):
+        super().__init__(reader, backbone, neck, bbox_head, seg_head, part_head, train_cfg, test_cfg, pretrained)
+        from .attention import SetBlock, waymo_bev_pos
+        self.bev_pos = waymo_bev_pos()
+        self.attns = nn.ModuleList([
+            SetBlock(in_dim=256, embed_dim_scale=1, num_heads=4, reso=(144, 256), mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
+                     H_sp=144, W_sp=1, H=4, W=8, drop=0.1, attn_drop=0.1, drop_path=0.1, norm_layer=nn.LayerNorm,
+                     pos=self.bev_pos, shift=(i % 2 == 1)) for i in range(2)])
+
+    def realign(self, x: torch.Tensor) -> torch.Tensor:
+        """x: logical (B, C=256, theta=256, r=144) dense BEV map -> same shape (voxelnet.py:210-221)"""
+        hip.require_device(x)
+        xh = ops.to_nhwc(x)                      # (B, theta, r, C)
+        b, t, r, c = xh.shape
+        tok = torch.empty((b, r, t, c), dtype=torch.float32, device=x.device)
+        hip.call("pn_transpose_hw_f32", xh.data_ptr(), b, t, r, c, tok.data_ptr(), hip.stream())   # (B, r, theta, C)
+        y = tok.view(b, r * t, c)
+        for attn in self.attns:
+            y = attn(y)
+        out = torch.empty((b, t, r, c), dtype=torch.float32, device=x.device)
+        hip.call("pn_transpose_hw_f32", y.contiguous().data_ptr(), b, r, t, c, out.data_ptr(), hip.stream())
+        return ops.as_nchw(out)
+
+    def forward(self, example, return_loss=True, **kwargs):
+        raise NotImplementedError("VoxelNetV3 end-to-end forward needs the sparse 3-D backbone (SURVEY.md 8f next-1); "
+                                  "reader, realign(), neck and head run stand-alone")

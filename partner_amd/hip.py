@@ -14,7 +14,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpartner_hip.so")
 _lib: Optional[C.CDLL] = None
 
-ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_GELU = 0, 1, 2, 3
 
 
 class PartnerHipError(RuntimeError):
@@ -65,8 +65,15 @@ SIGNATURES = {
     "pn_fold_bn_f32": (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "pn_groupnorm_workspace_bytes": (_SZ, [_I, _I, _I]),
     "pn_groupnorm_strat_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
+    "pn_gemm_bias_act_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),
+    "pn_layernorm_f32": (_I, [_P, _SZ, _I, _P, _P, _F, _P, _P, _P]),
+    "pn_setblock_keypoints": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "pn_setblock_sector_kp_attn": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "pn_setblock_range_attn": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "pn_setblock_sector_col_attn": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "pn_nchw_to_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "pn_nhwc_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "pn_transpose_hw_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "pn_event_create": (_I, [C.POINTER(_P)]),
     "pn_event_destroy": (_I, [_P]),
     "pn_event_record": (_I, [_P, _P]),

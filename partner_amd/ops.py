@@ -400,3 +400,39 @@ def hard_voxelize(points: torch.Tensor, voxel_size, pc_range, max_points: int, m
              (C.c_float * 6)(*rg.tolist()), int(max_points), int(max_voxels), voxels.data_ptr(), coors.data_ptr(),
              num.data_ptr(), nv.data_ptr(), ws.data_ptr(), ws_bytes, hip.stream())
     return voxels, coors, num, nv
+
+
+# ------------------------------------------------------------------------------ GEMM / attention glue (A1)
+ACT_GELU = hip.ACT_GELU
+
+
+class GemmLayer:
+    """packed nn.Linear: y = act(x @ W^T + b) (+ residual), on the MFMA conv kernel (1x1 convolution)"""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
+        hip.require_device(weight)
+        lib = hip.load()
+        w = weight.detach().contiguous().float()
+        self.n, self.k = w.shape
+        self.packed = _f32(lib.pn_conv_packed_weight_floats(self.n, self.k, 1, 1, 1), w.device)
+        hip.call("pn_pack_conv_weight_f32", w.data_ptr(), self.n, self.k, 1, 1, 1, self.packed.data_ptr(), hip.stream())
+        self.bias = None if bias is None else bias.detach().contiguous().float()
+
+    def __call__(self, x: torch.Tensor, act=ACT_NONE, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert x.dim() == 2 and x.is_contiguous() and x.shape[1] == self.k
+        m = x.shape[0]
+        out = torch.empty((m, self.n), dtype=torch.float32, device=x.device)
+        hip.call("pn_gemm_bias_act_f32", x.data_ptr(), m, self.k, self.k, self.packed.data_ptr(), self.n, hip.ptr(self.bias),
+                 int(act), hip.ptr(residual), self.n, out.data_ptr(), self.n, hip.stream())
+        return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_chan_mean=False):
+    hip.require_device(x)
+    assert x.dim() == 2 and x.is_contiguous()
+    rows, c = x.shape
+    out = torch.empty_like(x)
+    cm = torch.empty((rows,), dtype=torch.float32, device=x.device) if want_chan_mean else None
+    hip.call("pn_layernorm_f32", x.data_ptr(), rows, c, gamma.data_ptr(), beta.data_ptr(), float(eps), out.data_ptr(),
+             hip.ptr(cm), hip.stream())
+    return (out, cm) if want_chan_mean else out

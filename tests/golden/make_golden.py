@@ -476,6 +476,13 @@ def gen_setblock():
             y = blk(y)
         o[f"y{i}_probe"] = y[0, ::97, :].numpy()
         o[f"y{i}_sum_c"] = y.double().sum(dim=(0, 1)).numpy()
+    # the shifted block again on an input of its own (key-point selection is discontinuous: the chained
+    # result above is sensitive to 1e-6 differences in the first block's output)
+    x2 = torch.from_numpy(np.random.default_rng(53).standard_normal((1, H * W, C)).astype(np.float32))
+    with torch.no_grad():
+        y2 = blk(x2)  # blk is the shift=True block with seed 71
+    o["y1_indep_probe"] = y2[0, ::97, :].numpy()
+    o["y1_indep_sum_c"] = y2.double().sum(dim=(0, 1)).numpy()
     o["bev_pos_probe"] = vn.bev_pos[0, ::13, ::17, :].numpy()
     save("setblock_full.npz", **o)
 

@@ -391,3 +391,6 @@ def test_setblock_full_size(golden):
             x = O.set_block(sd, "", x, pos, (144, 256), heads=4, shift=(i % 2 == 1))
             close(x[0, ::97, :], g[f"y{i}_probe"], 1e-4, 2e-4)
             close(x.double().sum(dim=(0, 1)), g[f"y{i}_sum_c"], 1e-4, 5e-2)
+        x2 = torch.from_numpy(np.random.default_rng(53).standard_normal((1, 144 * 256, 256)).astype(np.float32))
+        y2 = O.set_block(filled_sd(shapes, 71), "", x2, pos, (144, 256), heads=4, shift=True)
+        close(y2[0, ::97, :], g["y1_indep_probe"], 1e-4, 2e-4)
