@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replays")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for a same-GPU dry run)")
     ap.add_argument("--streams", type=int, default=4, help="frames in flight per GPU (one hipGraph engine per HIP stream)")
     args = ap.parse_args()
 
@@ -116,9 +117,12 @@ def main():
     rank, local_rank, world = D.env_rank_world()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the product path"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    D.init("nccl", dev)  # RCCL over xGMI; only the barrier and the MAX-reduce of the time use it
+    ndev = torch.cuda.device_count()
+    assert args.backend != "nccl" or local_rank < ndev, f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible"
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
+    D.init(args.backend, dev)  # RCCL over xGMI; only the barrier and the MAX-reduce of the time use it
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     import partner_amd as P
     from partner_amd import hip, ops
@@ -164,7 +168,7 @@ def main():
     for i in range(args.steps):
         step(i)
     barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, red_dev)
 
     # roofline pass: HIP events cannot be recorded inside a replayed graph, so the same K steps are
     # run again eagerly with an event pair around every conv launch (same kernels, same inputs)

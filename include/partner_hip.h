@@ -290,6 +290,26 @@ int pn_setblock_sector_col_attn(const float *q, const float *kv_raw, const float
                                 int heads, int k, int shift, float scale, float *out,
                                 pn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * L1  CenterPoint loss, forward value.
+ * Replaces CenterHead.loss / _sigmoid      det3d/models/bbox_heads/center_head.py:244-288
+ *          FastFocalLoss, RegLoss           det3d/models/losses/centernet_loss.py:26-54, 6-24
+ * hm_logits: NHWC head output (pre-sigmoid), hm_target: (B,classes,H,W) as in the reference example;
+ * box sources: up to 5 NHWC head outputs concatenated in the reference order (reg,height,dim[,vel],rot);
+ * ind/cat int64 (B,max_objs), mask uint8, anno_box (B,max_objs,anno_dim), anno_sel[box_dims] = the
+ * anno_box column of every predicted box dimension (identity, or the vel-free selection
+ * [0,1,2,3,4,5,-2,-1] of center_head.py:265).
+ * out[4 + box_dims] = [det_loss, hm_loss, loc_loss, num_positive, loc_loss_elem...]
+ */
+size_t pn_center_loss_workspace_bytes(void);
+int pn_center_loss_fwd(const float *hm_logits, int hm_pixel_stride, const float *hm_target, int batch,
+                       int classes, int h, int w, const float *const *box_ptrs,
+                       const int *box_pixel_strides, const int *box_channels, int n_box_src,
+                       const int64_t *ind, const uint8_t *mask, const int64_t *cat,
+                       const float *anno_box, int anno_dim, const int *anno_sel, int max_objs,
+                       int box_dims, const float *code_weights, float weight, float *out,
+                       void *workspace, size_t workspace_bytes, pn_stream_t stream);
+
 /* layout helpers at the API boundary */
 int pn_nchw_to_nhwc_f32(const float *in, int b, int c, int h, int w, float *out, pn_stream_t stream);
 int pn_nhwc_to_nchw_f32(const float *in, int b, int c, int h, int w, int pixel_stride,

@@ -117,7 +117,45 @@ class CenterHead(nn.Module):
         return {"det_preds": rets}
 
     def loss(self, example, preds_dicts, **kwargs):
-        raise NotImplementedError("CenterHead.loss (SURVEY.md 8a row L1) is part of the training step, not built yet")
+        """Forward value of the CenterPoint loss (center_head.py:248-288) on the HIP kernel.  Returns the
+        reference's dict of per-task lists.  (No autograd graph: the backward kernels of the training step
+        are not built yet)"""
+        import ctypes as C
+        from collections import defaultdict
+        lib = hip.load()
+        rets = defaultdict(list)
+        for t, pd in enumerate(preds_dicts["det_preds"]):
+            hm = pd["hm"]
+            hip.require_device(hm)
+            b, ncls, h, w = hm.shape
+            order = ["reg", "height", "dim"] + (["vel"] if "vel" in pd else []) + ["rot"]
+            srcs = [pd[k] for k in order]
+            for s_ in [hm] + srcs:
+                assert s_.stride(1) == 1 and s_.stride(2) == w * s_.stride(3), "head tensors must be channels-last views"
+            ndim = sum(s_.shape[1] for s_ in srcs)
+            dev = hm.device
+            tgt = example["hm"][t].to(dev).float().contiguous()
+            ind = example["ind"][t].to(dev).long().contiguous()
+            mask = example["mask"][t].to(dev).to(torch.uint8).contiguous()
+            cat = example["cat"][t].to(dev).long().contiguous()
+            anno = example["anno_box"][t].to(dev).float().contiguous()
+            ad = anno.shape[-1]
+            sel = list(range(ndim)) if "vel" in pd else [0, 1, 2, 3, 4, 5, ad - 2, ad - 1]
+            cw = torch.tensor(list(self.code_weights)[:ndim], dtype=torch.float32, device=dev)
+            out = torch.empty((4 + ndim,), dtype=torch.float32, device=dev)
+            wsb = lib.pn_center_loss_workspace_bytes()
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            hip.call("pn_center_loss_fwd", hm.data_ptr(), hm.stride(3), tgt.data_ptr(), b, ncls, h, w,
+                     (C.c_void_p * len(srcs))(*[s_.data_ptr() for s_ in srcs]), (C.c_int * len(srcs))(*[s_.stride(3) for s_ in srcs]),
+                     (C.c_int * len(srcs))(*[s_.shape[1] for s_ in srcs]), len(srcs), ind.data_ptr(), mask.data_ptr(), cat.data_ptr(),
+                     anno.data_ptr(), ad, (C.c_int * ndim)(*sel), ind.shape[1], ndim, cw.data_ptr(), float(self.weight),
+                     out.data_ptr(), ws.data_ptr(), wsb, hip.stream())
+            rets["det_loss"].append(out[0])
+            rets["hm_loss"].append(out[1].detach().cpu())
+            rets["loc_loss"].append(out[2])
+            rets["loc_loss_elem"].append(out[4:].detach().cpu())
+            rets["num_positive"].append(out[3])
+        return rets
 
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
         raise NotImplementedError("decode + rotated NMS (SURVEY.md 8f next-2) is outside this round's hot path")

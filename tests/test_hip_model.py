@@ -208,3 +208,24 @@ def test_frame_engine_graph_replay_matches_eager(dev):
         ref = m.forward_points(ops.cart_to_polar(cart), offs, 2, spec)
         for k in ref:
             assert torch.equal(out[k], ref[k]), (seed, k)
+
+
+def test_center_loss_forward_value(dev, golden):
+    """CenterHead.loss on the eval predictions of the reduced model vs the reference's loss dict (golden)."""
+    g = golden("small_model.npz")
+    cfg = detector_cfg(synth.NUSC_RANGE, SMALL_VOXEL, pfn=(32, 32), ds=(32, 32, 64), us=(32, 32, 32), nums=(1, 2, 2))
+    m = build(cfg, 5, dev)
+    pts = torch.from_numpy(g["points"]).to(dev)
+    preds = {"det_preds": [m.forward_points(pts, torch.tensor([0, 3000, 5000], dtype=torch.int32, device=dev), 2)]}
+    example = dict(hm=[torch.from_numpy(g["tgt_hm"])], ind=[torch.from_numpy(g["tgt_ind"])], mask=[torch.from_numpy(g["tgt_mask"])],
+                   cat=[torch.from_numpy(g["tgt_cat"])], anno_box=[torch.from_numpy(g["tgt_anno"])])
+    losses = m.bbox_head.loss(example, preds)
+    assert abs(float(losses["det_loss"][0]) - float(g["loss_det"])) < 1e-4 * abs(float(g["loss_det"]))
+    assert abs(float(losses["hm_loss"][0]) - float(g["loss_hm"])) < 1e-4 * abs(float(g["loss_hm"]))
+    np.testing.assert_allclose(losses["loc_loss_elem"][0].numpy(), g["loss_loc_elem"], rtol=1e-4, atol=1e-6)
+    assert float(losses["num_positive"][0]) == float(g["tgt_mask"].sum())
+    # the detector-level call of the reference: forward(example, return_loss=True)
+    ex = dict(example, points=pts, grid_ind=torch.from_numpy(g["grid_ind"].astype(np.int64)).to(dev), num_points=[3000, 2000],
+              grid_size=np.stack([np.array([64, 64, 1])] * 2))
+    l2 = m(ex, return_loss=True)
+    assert abs(float(l2["det_loss"][0]) - float(g["loss_det"])) < 1e-4 * abs(float(g["loss_det"]))
