@@ -162,6 +162,17 @@ int pn_dynamic_pfn_fwd(const float *points, int point_stride, const int32_t *vox
                        const float *w1, int c1, float vx, float vy, float x_offset, float y_offset,
                        float *features, float *canvas, pn_stream_t stream);
 
+/* cos/sin table of the pillar-centre azimuths (2*T floats) and the table-driven variant of the call
+ * above (register-resident weights for the reference's C0 = 32, C1 = 128 reader) */
+size_t pn_pfn_center_table_floats(int t);
+int pn_pfn_center_table_f32(int t, float vy, float y_offset, float *table, pn_stream_t stream);
+int pn_dynamic_pfn_fwd_table(const float *points, int point_stride, const int32_t *voxel_start,
+                             const int32_t *order, const int32_t *num_voxels, int v_capacity,
+                             const uint32_t *unq_keys, const int32_t *grid, const float *w0, int c0,
+                             const float *w1, int c1, float vx, float vy, float x_offset,
+                             float y_offset, const float *center_table, float *features, float *canvas,
+                             pn_stream_t stream);
+
 /* pointer to the uint32 key-per-voxel array inside a pn_unique_rank_bitmap workspace */
 const uint32_t *pn_unique_keys_ptr(const void *workspace, uint64_t num_cells, int n_capacity);
 

@@ -174,6 +174,114 @@ __global__ __launch_bounds__(kPfnWaves * 64) void dynamic_pfn_kernel(PfnArgs a) 
   }
 }
 
+
+// ---- specialisation for the reference's nuScenes reader (C0 = 32, C1 = 128) ------------------
+// Weights live in registers (lane n holds rows n and n+64 of W1, lanes < 32 hold row n of W0), the
+// layer-0 activation of the current point is broadcast with v_readlane (no LDS at all), the pillar
+// (r, theta, b) comes packed from the unique kernel and cos/sin of the pillar azimuth from a table.
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+
+__global__ __launch_bounds__(256) void dynamic_pfn_32_128_kernel(PfnArgs a, const float* __restrict__ cs_table) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int V = min(*a.v_dev, a.v_cap);
+  float w0[16], w1a[64], w1b[64];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) w0[k] = lane < 32 ? a.w0[lane * 16 + k] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    w1a[k] = a.w1[lane * 64 + k];
+    w1b[k] = a.w1[(lane + 64) * 64 + k];
+  }
+  int n_s = 0, n_e = 0;
+  uint32_t n_key = 0;
+  if (wave < V) { n_s = a.vstart[wave]; n_e = a.vstart[wave + 1]; n_key = a.ukeys[wave]; }
+  for (int v = wave; v < V; v += nwaves) {
+    const int s = n_s, e = n_e;
+    uint32_t key = n_key;
+    if (v + nwaves < V) { n_s = a.vstart[v + nwaves]; n_e = a.vstart[v + nwaves + 1]; n_key = a.ukeys[v + nwaves]; }
+    const int ri = key % a.R; key /= a.R;
+    const int ti = key % a.T; key /= a.T;
+    const int bi = key / a.Z;
+    float mx, my, mz, mr, mp;
+    if (e - s == 1) {  // single-point pillar: the fixed-point mean of one value (same rounding as the general path)
+      const float* p = a.pts + (size_t)a.order[s] * a.stride;
+      mr = (float)((double)to_fix(p[0]) / kFix); mp = (float)((double)to_fix(p[1]) / kFix); mz = (float)((double)to_fix(p[2]) / kFix);
+      mx = (float)((double)to_fix(p[3]) / kFix); my = (float)((double)to_fix(p[4]) / kFix);
+    } else {
+      long long sx = 0, sy = 0, sz = 0, sr = 0, sp = 0;
+      for (int i = s + lane; i < e; i += 64) {
+        const float* p = a.pts + (size_t)a.order[i] * a.stride;
+        sr += to_fix(p[0]); sp += to_fix(p[1]); sz += to_fix(p[2]); sx += to_fix(p[3]); sy += to_fix(p[4]);
+      }
+      const double inv_n = 1.0 / ((double)(e - s) * kFix);
+      mx = (float)((double)pn::wave_sum(sx) * inv_n); my = (float)((double)pn::wave_sum(sy) * inv_n);
+      mz = (float)((double)pn::wave_sum(sz) * inv_n); mr = (float)((double)pn::wave_sum(sr) * inv_n);
+      mp = (float)((double)pn::wave_sum(sp) * inv_n);
+    }
+    const float rc = __fadd_rn(__fmul_rn((float)ri, a.vx), a.xoff);
+    const float pc = __fadd_rn(__fmul_rn((float)ti, a.vy), a.yoff);
+    const float xc = __fmul_rn(rc, cs_table[2 * ti]), yc = __fmul_rn(rc, cs_table[2 * ti + 1]);
+    auto layer0 = [&](const float* p) -> float {
+      const float rho = p[0], phi = p[1], z = p[2], x = p[3], y = p[4];
+      const float d[16] = {rho, phi, z, x, y, p[5], p[6], x - mx, y - my, z - mz, x - xc, y - yc,
+                           rho - mr, phi - mp, rho - rc, phi - pc};
+      float h = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) h = fmaf(w0[k], d[k], h);
+      return h > 0.f ? h : 0.f;  // lanes >= 32 carry zeros (their w0 is zero)
+    };
+    float m0 = 0.f;
+    float h_first = 0.f;
+    for (int i = s; i < e; ++i) {
+      const float h = layer0(a.pts + (size_t)a.order[i] * a.stride);
+      if (i == s) h_first = h;
+      m0 = fmaxf(m0, h);
+    }
+    float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const float m = lane_bcast(m0, c);
+      g0 = fmaf(w1a[32 + c], m, g0);
+      g1 = fmaf(w1b[32 + c], m, g1);
+    }
+    float f0 = 0.f, f1 = 0.f;
+    for (int i = s; i < e; ++i) {
+      const float h = (i == s) ? h_first : layer0(a.pts + (size_t)a.order[i] * a.stride);
+      float y0 = g0, y1 = g1;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        const float hc = lane_bcast(h, c);
+        y0 = fmaf(w1a[c], hc, y0);
+        y1 = fmaf(w1b[c], hc, y1);
+      }
+      f0 = fmaxf(f0, y0);
+      f1 = fmaxf(f1, y1);
+    }
+    if (a.feat) {
+      a.feat[(size_t)v * 128 + lane] = f0;
+      a.feat[(size_t)v * 128 + lane + 64] = f1;
+    }
+    if (a.canvas) {
+      float* cv = a.canvas + (((size_t)bi * a.T + ti) * a.R + ri) * 128;
+      cv[lane] = f0;
+      cv[lane + 64] = f1;
+    }
+  }
+}
+
+// cos / sin of every pillar-centre azimuth of the grid: table[2*t] = cos(t*vy + yoff), [2*t+1] = sin(...)
+__global__ void center_table_kernel(int T, float vy, float yoff, float* __restrict__ table) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const float pc = __fadd_rn(__fmul_rn((float)t, vy), yoff);
+  table[2 * t] = cosf(pc);
+  table[2 * t + 1] = sinf(pc);
+}
+
 __global__ void scatter_canvas_kernel(const float* __restrict__ feat, const int64_t* __restrict__ unq,
                                       const int32_t* __restrict__ v_dev, int v_cap, int c, int T, int R,
                                       float* __restrict__ canvas) {
@@ -231,6 +339,33 @@ int pn_dynamic_pfn_fwd(const float* points, int point_stride, const int32_t* vox
   const int blocks = std::max(1, std::min(1024, pn::cdiv(v_capacity, kPfnWaves * 2)));
   hipLaunchKernelGGL(dynamic_pfn_kernel, dim3(blocks), dim3(kPfnWaves * 64), smem, pn::S(stream), a);
   return pn::check_launch("dynamic_pfn_kernel");
+}
+
+size_t pn_pfn_center_table_floats(int t) { return (size_t)2 * t; }
+
+int pn_pfn_center_table_f32(int t, float vy, float y_offset, float* table, pn_stream_t stream) {
+  PN_REQUIRE(table && t >= 1, "pfn_center_table: bad arguments");
+  hipLaunchKernelGGL(center_table_kernel, dim3(pn::cdiv(t, 256)), dim3(256), 0, pn::S(stream), t, vy, y_offset, table);
+  return pn::check_launch("center_table_kernel");
+}
+
+// same contract as pn_dynamic_pfn_fwd plus the azimuth table of pn_pfn_center_table_f32; takes the
+// register-resident fast path when (C0, C1) == (32, 128), otherwise falls back to the generic kernel
+int pn_dynamic_pfn_fwd_table(const float* points, int point_stride, const int32_t* voxel_start, const int32_t* order,
+                             const int32_t* num_voxels, int v_capacity, const uint32_t* unq_keys, const int32_t* grid,
+                             const float* w0, int c0, const float* w1, int c1, float vx, float vy, float x_offset, float y_offset,
+                             const float* center_table, float* features, float* canvas, pn_stream_t stream) {
+  if (!(c0 == 32 && c1 == 128 && center_table))
+    return pn_dynamic_pfn_fwd(points, point_stride, voxel_start, order, num_voxels, v_capacity, unq_keys, grid, w0, c0, w1, c1, vx, vy,
+                              x_offset, y_offset, features, canvas, stream);
+  PN_REQUIRE(points && voxel_start && order && num_voxels && unq_keys && grid && w0 && w1, "dynamic_pfn: null pointer");
+  PN_REQUIRE(point_stride >= 7 && (features || canvas), "dynamic_pfn: bad arguments");
+  if (v_capacity == 0) return PN_OK;
+  PfnArgs a{points, point_stride, voxel_start, order, num_voxels, v_capacity, unq_keys, grid[0], grid[1], grid[2],
+            w0, c0, w1, c1, vx, vy, x_offset, y_offset, features, canvas};
+  const int blocks = std::max(1, std::min(512, pn::cdiv(v_capacity, 4 * 2)));  // persistent: 2 waves per SIMD, weights loaded once per wave
+  hipLaunchKernelGGL(dynamic_pfn_32_128_kernel, dim3(blocks), dim3(256), 0, pn::S(stream), a, center_table);
+  return pn::check_launch("dynamic_pfn_32_128_kernel");
 }
 
 int pn_scatter_canvas_fwd(const float* features, const int64_t* unq, const int32_t* num_voxels, int v_capacity, int c,

@@ -174,6 +174,19 @@ def hard_voxel_mean(voxels: torch.Tensor, num_points: torch.Tensor) -> torch.Ten
     return out
 
 
+_CENTER_TABLES = {}
+
+
+def pfn_center_table(t: int, vy: float, y_offset: float, device) -> torch.Tensor:
+    key = (t, float(vy), float(y_offset), str(device))
+    tab = _CENTER_TABLES.get(key)
+    if tab is None:
+        tab = torch.empty((2 * t,), dtype=torch.float32, device=device)
+        hip.call("pn_pfn_center_table_f32", t, float(vy), float(y_offset), tab.data_ptr(), hip.stream())
+        _CENTER_TABLES[key] = tab
+    return tab
+
+
 def dynamic_pfn(points: torch.Tensor, vi: VoxelIndex, w0: torch.Tensor, w1: torch.Tensor, vx: float, vy: float,
                 x_offset: float, y_offset: float, features: Optional[torch.Tensor], canvas: Optional[torch.Tensor],
                 v_cap: Optional[int] = None) -> None:
@@ -182,10 +195,11 @@ def dynamic_pfn(points: torch.Tensor, vi: VoxelIndex, w0: torch.Tensor, w1: torc
     c0, c1 = w0.shape[0], w1.shape[0]
     assert w0.shape[1] == 16 and w1.shape[1] == 2 * c0
     _, _, g = vi.spec.c_arrays()
-    hip.call("pn_dynamic_pfn_fwd", points.data_ptr(), points.stride(0), vi.voxel_start.data_ptr(), vi.order.data_ptr(),
+    tab = pfn_center_table(vi.spec.grid[1], vy, y_offset, points.device)
+    hip.call("pn_dynamic_pfn_fwd_table", points.data_ptr(), points.stride(0), vi.voxel_start.data_ptr(), vi.order.data_ptr(),
              vi.num_voxels.data_ptr(), vi.n_cap if v_cap is None else v_cap, vi.unq_keys_ptr, g, w0.data_ptr(), c0,
-             w1.data_ptr(), c1, float(vx), float(vy), float(x_offset), float(y_offset), hip.ptr(features), hip.ptr(canvas),
-             hip.stream())
+             w1.data_ptr(), c1, float(vx), float(vy), float(x_offset), float(y_offset), tab.data_ptr(), hip.ptr(features),
+             hip.ptr(canvas), hip.stream())
 
 
 def scatter_canvas(features: torch.Tensor, unq: torch.Tensor, batch: int, t: int, r: int,
