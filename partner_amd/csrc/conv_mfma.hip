@@ -54,7 +54,6 @@ struct ConvArgs {
   int force_tile;        // >0: tile override (tuning / tests)
   const float* res;      // optional residual added after the activation (GEMM use)
   int res_ps;
-  int abl;               // ablation bits for tuning builds (PN_CONV_ABL): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no fragment reads
 };
 
 constexpr int BK = 32;
@@ -131,8 +130,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
       const_cast<float*>(a.in) - back, 0, a.in_bytes + (unsigned)(back * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.w) + (size_t)z * taps * (a.cin_chunks * BK) * a.cout_pad, 0, a.w_bytes, 0x00020000);
-  int nsteps = taps * a.cin_chunks;
-  if (a.abl >> 12) nsteps = min(nsteps, a.abl >> 12);  // tuning: truncate the K loop
+  const int nsteps = taps * a.cin_chunks;
 
   f32x4 ra[A_PER_T], rb[B_PER_T];
 
@@ -266,17 +264,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   // scale/shift of this lane's TN columns are fetched once (the output may alias nothing, but the
   // compiler cannot know that and would otherwise reload them after every store).
-  if (a.abl & 64) {  // tuning: skip the epilogue (keep the accumulators alive with one store)
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-    if (t == 12345.678f) a.out[0] = t;
-    return;
-  }
   // Fast path: transpose the wave's (TM*32) x (TN*32) tile through LDS (the staging buffers are
   // free now) so that every lane stores 16 contiguous bytes: 4x fewer store instructions than
   // the accumulator layout allows (the store tail is issue-bound, not bandwidth-bound).
@@ -521,8 +508,6 @@ int fill_args(const pn_conv_desc* d, ConvArgs& a, int& zdim) {
   a.force_tile = 0;
   a.res = nullptr;
   a.res_ps = 0;
-  static const int abl = [] { const char* e = getenv("PN_CONV_ABL"); return e ? atoi(e) : 0; }();
-  a.abl = abl;
   return PN_OK;
 }
 

@@ -19,7 +19,15 @@ class FrameEngine:
         hip.require_device(next(model.parameters()))
         self.batch, self.n = batch, points_per_sweep
         self.spec = spec or ops.GridSpec.from_range(model.reader.pc_range, model.reader.voxel_size)
-        self.cart = torch.zeros((batch * points_per_sweep, point_features), dtype=torch.float32, device=dev)
+        # static input buffer; pre-filled with a spread-out synthetic sweep so that the capture warm-up does not
+        # run the degenerate "every point in one pillar" case
+        from .utils import synth
+        import numpy as np
+        init = np.concatenate([synth.synth_sweep_cart(points_per_sweep, seed=977 + b) for b in range(batch)], 0)
+        if point_features != init.shape[1]:
+            init = np.concatenate([init, np.zeros((init.shape[0], point_features - init.shape[1]), np.float32)], 1) \
+                if point_features > init.shape[1] else init[:, :point_features]
+        self.cart = torch.from_numpy(np.ascontiguousarray(init)).to(dev)
         self.offsets = torch.tensor([points_per_sweep * b for b in range(batch + 1)], dtype=torch.int32, device=dev)
         self.graph = None
         self.outputs: Dict[str, torch.Tensor] = {}

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Timings of the other BASELINE.json configurations' stages (not the headline bench):
+ C5: nuScenes polar-pillar model, 10-sweep accumulation (300k points), hipGraph per frame, latency p50 / p99
+ C4 stages: Waymo PARTNER grid -- hard voxelization (180k pts, P=5, Vmax=150k) + mean VFE, 2 x SetBlock on the
+            (144 x 256) x 256 BEV tokens, RPN of the Waymo config (fp32)."""
+import logging, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench, partner_amd as P
+from partner_amd import ops
+from partner_amd.engine import FrameEngine
+from partner_amd.attention import SetBlock, waymo_bev_pos
+from partner_amd.voxel_generator import VoxelGenerator
+from partner_amd.utils import synth
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+# ---- C5
+m = P.build_detector(bench.c2_model_cfg()); synth.load_filled(m, 0); m = m.to(dev).eval()
+eng = FrameEngine(m, 1, 300000).capture()
+frames = [torch.from_numpy(synth.synth_sweep_cart(300000, seed=s, n_sweeps=10)).to(dev) for s in range(4)]
+lat = []
+for i in range(220):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    eng.run(frames[i % 4]); torch.cuda.synchronize()
+    if i >= 20:
+        lat.append(1e3 * (time.perf_counter() - t0))
+lat = np.sort(np.array(lat))
+print(f"C5  300k-pt frame, hipGraph, 1 stream: latency p50 {lat[len(lat)//2]:.3f} ms  p99 {lat[int(len(lat)*0.99)]:.3f} ms  ({1e3/lat[len(lat)//2]:.0f} frames/s)")
+
+# ---- C4 stages
+sw = torch.from_numpy(synth.synth_sweep_polar(180000, seed=0, rho_max=74.0)).to(dev)
+vg = VoxelGenerator(synth.WAYMO_VOXEL, synth.WAYMO_RANGE, 5, 150000)
+def vox():
+    v, c, n, nv = ops.hard_voxelize(sw, vg.voxel_size, vg.point_cloud_range, 5, 150000)
+    return ops.hard_voxel_mean(v, n)
+print(f"C4  hard voxelize 180k pts (1152x2048x40, P=5, Vmax=150k) + mean VFE: {timeit(vox):.3f} ms")
+pos = waymo_bev_pos()
+blks = []
+for i in range(2):
+    b = SetBlock(in_dim=256, embed_dim_scale=1, num_heads=4, reso=(144, 256), mlp_ratio=4.0, qkv_bias=True, H_sp=144, W_sp=1, H=4, W=8,
+                 pos=pos, shift=(i == 1)); synth.load_filled(b, 70 + i); blks.append(b.to(dev).eval())
+x = torch.randn((1, 144 * 256, 256), device=dev)
+def attn():
+    y = x
+    for b in blks:
+        y = b(y)
+    return y
+t = timeit(attn)
+print(f"C4  2 x SetBlock (36864 tokens x 256), eager launches: {t:.3f} ms  ({123.2 / t:.1f} TFLOP/s on 123.2 GFLOP)")
+neck = P.build_neck(dict(type="RPN", layer_nums=[5, 5], ds_layer_strides=[1, 2], ds_num_filters=[128, 256], us_layer_strides=[1, 2],
+                         us_num_filters=[256, 256], num_input_features=256, logger=logging.getLogger("RPN")))
+synth.load_filled(neck, 3); neck = neck.to(dev).eval()
+xb = torch.randn((1, 256, 144, 256), device=dev)  # NHWC (B, theta, r, C)
+t = timeit(lambda: neck.forward_nhwc(xb))
+print(f"C4  RPN of the Waymo config on (256 x 144) x 256: {t:.3f} ms  ({143.14 / t:.1f} TFLOP/s on 143.14 GFLOP)")

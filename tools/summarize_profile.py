@@ -52,6 +52,20 @@ def main(stats_dir, fetch_dir, write_dir, bench_log, out_prefix):
         f.write("kernel,launches,FETCH_SIZE_KB_raw_avg,fetch_KB_corrected_x2_avg,WRITE_SIZE_KB_avg,TCC_HIT_avg,TCC_MISS_avg\n")
         for r in rows:
             f.write(f"\"{r[0]}\",{r[1]},{r[2]:.1f},{r[3]:.1f},{r[4]:.1f},{r[5]:.0f},{r[6]:.0f}\n")
+    # optional SQ pass: MFMA utilisation = MFMA busy cycles / (GPU-active cycles per XCD * 1024 SIMDs)
+    sq_dir = os.environ.get("SQ_PMC_DIR")
+    if sq_dir:
+        sq = pmc(sq_dir)
+        with open(out_prefix + "_pmc_mfma.csv", "w") as f:
+            f.write("kernel,launches,SQ_VALU_MFMA_BUSY_CYCLES_avg,GRBM_GUI_ACTIVE_avg(sum of 8 XCDs),mfma_util,SQ_WAIT_ANY/SQ_WAVE_CYCLES,"
+                    "SQ_WAIT_INST_ANY/SQ_WAVE_CYCLES,SQ_LDS_BANK_CONFLICT_avg\n")
+            for k in sorted(sq):
+                a = lambda c: (sum(sq[k][c]) / len(sq[k][c])) if sq[k].get(c) else float("nan")
+                busy, gui, wc = a("SQ_VALU_MFMA_BUSY_CYCLES"), a("GRBM_GUI_ACTIVE"), a("SQ_WAVE_CYCLES")
+                if not busy or busy != busy or busy == 0:
+                    continue
+                f.write(f"\"{k}\",{len(sq[k]['SQ_WAVE_CYCLES'])},{busy:.0f},{gui:.0f},{busy / (gui / 8 * 1024):.3f},"
+                        f"{a('SQ_WAIT_ANY') / wc:.3f},{a('SQ_WAIT_INST_ANY') / wc:.3f},{a('SQ_LDS_BANK_CONFLICT'):.0f}\n")
     if bench:
         json.dump(bench, open(out_prefix + "_bench_line.json", "w"), indent=1)
     print("wrote", out_prefix + "_kernel_stats.csv", out_prefix + "_pmc_traffic.csv")
