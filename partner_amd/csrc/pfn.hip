@@ -183,6 +183,9 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
 }
 
+constexpr int kHeavyPillar = 64;  // pillars with more points than this take the block-per-pillar kernel
+constexpr int kHeavyWaves = 8;
+
 __global__ __launch_bounds__(256) void dynamic_pfn_32_128_kernel(PfnArgs a, const float* __restrict__ cs_table) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(256) void dynamic_pfn_32_128_kernel(PfnArgs a, cons
     const int s = n_s, e = n_e;
     uint32_t key = n_key;
     if (v + nwaves < V) { n_s = a.vstart[v + nwaves]; n_e = a.vstart[v + nwaves + 1]; n_key = a.ukeys[v + nwaves]; }
+    if (e - s > kHeavyPillar) continue;  // dynamic_pfn_32_128_heavy_kernel spreads those over a whole block
     const int ri = key % a.R; key /= a.R;
     const int ti = key % a.T; key /= a.T;
     const int bi = key / a.Z;
@@ -270,6 +274,118 @@ __global__ __launch_bounds__(256) void dynamic_pfn_32_128_kernel(PfnArgs a, cons
       cv[lane] = f0;
       cv[lane + 64] = f1;
     }
+  }
+}
+
+// Pillars with more than kHeavyPillar points (a wall right in front of the sensor, a degenerate
+// sweep): one 8-wave block per pillar, the three phases (means, layer-0 maxima, layer-1 maxima)
+// meet in LDS.  Sums are exact int64 and maxima order independent, so the values are bit-identical
+// to what the one-wave path would have produced.
+__global__ __launch_bounds__(kHeavyWaves * 64) void dynamic_pfn_32_128_heavy_kernel(PfnArgs a, const float* __restrict__ cs_table) {
+  __shared__ long long part_sum[kHeavyWaves][5];
+  __shared__ float part_max[kHeavyWaves][128];
+  __shared__ int heavy_list[kHeavyWaves * 64];
+  __shared__ int heavy_n;
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int V = min(*a.v_dev, a.v_cap);
+  float w0[16], w1a[64], w1b[64];
+  bool loaded = false;
+  // block b owns the pillars v == b (mod gridDim.x) -- neighbouring heavy pillars land on different
+  // blocks; every thread tests one of them, the hits are compacted into an LDS list
+  for (int base = 0; base < V; base += gridDim.x * blockDim.x) {
+    if (threadIdx.x == 0) heavy_n = 0;
+    __syncthreads();
+    const int cand = base + blockIdx.x + gridDim.x * threadIdx.x;
+    if (cand < V && a.vstart[cand + 1] - a.vstart[cand] > kHeavyPillar) heavy_list[atomicAdd(&heavy_n, 1)] = cand;
+    __syncthreads();
+    const int n_heavy = heavy_n;
+  for (int hi = 0; hi < n_heavy; ++hi) {
+    const int v = heavy_list[hi];
+    const int s = a.vstart[v], e = a.vstart[v + 1];
+    if (!loaded) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) w0[k] = lane < 32 ? a.w0[lane * 16 + k] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) {
+        w1a[k] = a.w1[lane * 64 + k];
+        w1b[k] = a.w1[(lane + 64) * 64 + k];
+      }
+      loaded = true;
+    }
+    uint32_t key = a.ukeys[v];
+    const int ri = key % a.R; key /= a.R;
+    const int ti = key % a.T; key /= a.T;
+    const int bi = key / a.Z;
+    // ---- phase 1: means ---------------------------------------------------------------------
+    long long sx = 0, sy = 0, sz = 0, sr = 0, sp = 0;
+    for (int i = s + (int)threadIdx.x; i < e; i += kHeavyWaves * 64) {
+      const float* p = a.pts + (size_t)a.order[i] * a.stride;
+      sr += to_fix(p[0]); sp += to_fix(p[1]); sz += to_fix(p[2]); sx += to_fix(p[3]); sy += to_fix(p[4]);
+    }
+    sx = pn::wave_sum(sx); sy = pn::wave_sum(sy); sz = pn::wave_sum(sz); sr = pn::wave_sum(sr); sp = pn::wave_sum(sp);
+    if (lane == 0) { part_sum[wib][0] = sx; part_sum[wib][1] = sy; part_sum[wib][2] = sz; part_sum[wib][3] = sr; part_sum[wib][4] = sp; }
+    __syncthreads();
+    long long t[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < kHeavyWaves; ++w)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) t[k] += part_sum[w][k];
+    const double inv_n = 1.0 / ((double)(e - s) * kFix);
+    const float mx = (float)((double)t[0] * inv_n), my = (float)((double)t[1] * inv_n), mz = (float)((double)t[2] * inv_n);
+    const float mr = (float)((double)t[3] * inv_n), mp = (float)((double)t[4] * inv_n);
+    const float rc = __fadd_rn(__fmul_rn((float)ri, a.vx), a.xoff);
+    const float pc = __fadd_rn(__fmul_rn((float)ti, a.vy), a.yoff);
+    const float xc = __fmul_rn(rc, cs_table[2 * ti]), yc = __fmul_rn(rc, cs_table[2 * ti + 1]);
+    auto layer0 = [&](const float* p) -> float {
+      const float rho = p[0], phi = p[1], z = p[2], x = p[3], y = p[4];
+      const float d[16] = {rho, phi, z, x, y, p[5], p[6], x - mx, y - my, z - mz, x - xc, y - yc,
+                           rho - mr, phi - mp, rho - rc, phi - pc};
+      float h = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) h = fmaf(w0[k], d[k], h);
+      return h > 0.f ? h : 0.f;
+    };
+    // ---- phase 2: layer-0 maxima, wave w takes points s+w, s+w+8, ... -------------------------
+    float m0 = 0.f;
+    for (int i = s + wib; i < e; i += kHeavyWaves) m0 = fmaxf(m0, layer0(a.pts + (size_t)a.order[i] * a.stride));
+    part_max[wib][lane] = m0;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kHeavyWaves; ++w) m0 = fmaxf(m0, part_max[w][lane]);
+    float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const float m = lane_bcast(m0, c);
+      g0 = fmaf(w1a[32 + c], m, g0);
+      g1 = fmaf(w1b[32 + c], m, g1);
+    }
+    __syncthreads();  // part_max is reused below
+    // ---- phase 3: layer 1 ---------------------------------------------------------------------
+    float f0 = 0.f, f1 = 0.f;
+    for (int i = s + wib; i < e; i += kHeavyWaves) {
+      const float h = layer0(a.pts + (size_t)a.order[i] * a.stride);
+      float y0 = g0, y1 = g1;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        const float hc = lane_bcast(h, c);
+        y0 = fmaf(w1a[c], hc, y0);
+        y1 = fmaf(w1b[c], hc, y1);
+      }
+      f0 = fmaxf(f0, y0);
+      f1 = fmaxf(f1, y1);
+    }
+    part_max[wib][lane] = f0;
+    part_max[wib][lane + 64] = f1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      float f = 0.f;
+#pragma unroll
+      for (int w = 0; w < kHeavyWaves; ++w) f = fmaxf(f, part_max[w][threadIdx.x]);
+      if (a.feat) a.feat[(size_t)v * 128 + threadIdx.x] = f;
+      if (a.canvas) a.canvas[(((size_t)bi * a.T + ti) * a.R + ri) * 128 + threadIdx.x] = f;
+    }
+    __syncthreads();
+  }
   }
 }
 
@@ -365,7 +481,11 @@ int pn_dynamic_pfn_fwd_table(const float* points, int point_stride, const int32_
             w0, c0, w1, c1, vx, vy, x_offset, y_offset, features, canvas};
   const int blocks = std::max(1, std::min(512, pn::cdiv(v_capacity, 4 * 2)));  // persistent: 2 waves per SIMD, weights loaded once per wave
   hipLaunchKernelGGL(dynamic_pfn_32_128_kernel, dim3(blocks), dim3(256), 0, pn::S(stream), a, center_table);
-  return pn::check_launch("dynamic_pfn_32_128_kernel");
+  if (int rc = pn::check_launch("dynamic_pfn_32_128_kernel")) return rc;
+  // at most n / kHeavyPillar pillars can be heavy; the blocks find them by scanning voxel_start
+  const int hblocks = std::max(1, std::min(256, pn::cdiv(v_capacity, kHeavyPillar)));
+  hipLaunchKernelGGL(dynamic_pfn_32_128_heavy_kernel, dim3(hblocks), dim3(kHeavyWaves * 64), 0, pn::S(stream), a, center_table);
+  return pn::check_launch("dynamic_pfn_32_128_heavy_kernel");
 }
 
 int pn_scatter_canvas_fwd(const float* features, const int64_t* unq, const int32_t* num_voxels, int v_capacity, int c,

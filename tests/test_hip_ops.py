@@ -168,6 +168,40 @@ def test_dynamic_pfn_and_canvas(dev, golden):
     assert torch.equal(cv2.cpu(), cv)
 
 
+def test_dynamic_pfn_heavy_pillars(dev):
+    """Pillars far above the 64-point threshold (block-per-pillar kernel) next to ordinary ones:
+    same oracle, same tolerance; the counts cover 65 (just over), 1000 and 20000 points."""
+    from partner_amd import ops
+    from tests.test_oracle_golden import PFN_SHAPES, filled_sd
+    sd = filled_sd(PFN_SHAPES, 1)
+    rng = np.random.default_rng(77)
+    base = synth.synth_sweep_polar(6000, seed=5)
+    vx, vy = synth.NUSC_VOXEL[0], synth.NUSC_VOXEL[1]
+    extra = []
+    for (ri, ti, cnt) in ((40, 100, 65), (41, 100, 64), (200, 300, 1000), (10, 7, 20000), (511, 511, 300)):
+        rho = synth.NUSC_RANGE[0] + (ri + rng.uniform(0.05, 0.95, cnt)) * vx
+        phi = synth.NUSC_RANGE[1] + (ti + rng.uniform(0.05, 0.95, cnt)) * vy
+        z = rng.uniform(-4.5, 2.5, cnt)
+        extra.append(np.stack([rho, phi, z, rho * np.cos(phi), rho * np.sin(phi), rng.uniform(0, 1, cnt), rng.uniform(0, 0.5, cnt)], 1))
+    pts_np = np.concatenate([base] + extra, 0).astype(np.float32)
+    pts_np = pts_np[rng.permutation(len(pts_np))]
+    gi = O.grid_index(pts_np, synth.NUSC_RANGE, synth.NUSC_VOXEL)
+    gi_b = O.with_batch_index([gi])
+    ref, unq, _ = O.dynamic_pfn(sd, "", pts_np, gi_b, [512, 512, 1], synth.NUSC_VOXEL, synth.NUSC_RANGE)
+    spec = ops.GridSpec.from_range(*GRIDS["nusc"])
+    keys = ops.keys_from_grid_ind(cuda(gi_b.astype(np.int64), dev), spec, 1)
+    vi = ops.build_voxel_index(keys, spec, 1)
+    V = vi.count()
+    assert V == len(unq) and int(vi.unq_cnt[:V].max()) >= 20000
+    feats = torch.empty((vi.n_cap, 128), dtype=torch.float32, device=dev)
+    canvas = torch.zeros((1, 512, 512, 128), dtype=torch.float32, device=dev)
+    ops.dynamic_pfn(cuda(pts_np, dev), vi, sd["pfn_layers.0.linear.weight"].to(dev), sd["pfn_layers.1.linear.weight"].to(dev), vx, vy,
+                    vx / 2 + synth.NUSC_RANGE[0], vy / 2 + synth.NUSC_RANGE[1], feats, canvas)
+    np.testing.assert_allclose(feats[:V].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+    u = torch.from_numpy(unq)
+    assert torch.equal(canvas.cpu()[u[:, 0], u[:, 2], u[:, 3]], feats[:V].cpu())
+
+
 # ------------------------------------------------------------------------------ convolutions
 def _conv_case(dev, b, cin, cout, h, w, k, stride, pad, groups=1, act=0, seed=0, bn=True):
     from partner_amd import ops
