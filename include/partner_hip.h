@@ -211,6 +211,8 @@ typedef struct pn_conv_desc {
                            scale/shift[s*cout + n]; every window reads the same `cin` input
                            channels, halo columns come from the neighbouring windows (zeros at
                            the map border).  groups must be 1.  0/1: ordinary convolution. */
+  int32_t pad_h_end, pad_w_end; /* extra zero rows / columns after the map, on top of pad_h / pad_w
+                                   (asymmetric nn.ZeroPad2d); 0 = symmetric padding */
 } pn_conv_desc;
 
 size_t pn_conv_packed_weight_floats(int cout, int cin, int kh, int kw, int groups);
@@ -236,6 +238,43 @@ int pn_conv2d_direct_nhwc_f32(const pn_conv_desc *desc, const float *in, const f
 int pn_fold_bn_f32(const float *gamma, const float *beta, const float *mean, const float *var,
                    const float *conv_bias, float eps, int c, float *scale, float *shift,
                    pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Backward of the convolutions (training step: loss.backward() through rpn.py:124-159 and
+ * center_head_parallel.py:120-196; torch autograd's conv2d backward in the reference).
+ *
+ * Weight gradient: dW = sum over output pixels of in[pixel + tap] (x) dout[pixel], written in
+ * torch layout (Cout, Cin, KH, KW); `desc` is the FORWARD descriptor (out_pixel_stride /
+ * out_channel_offset address `dout`; act is ignored).  accumulate != 0 adds to dweight.
+ * Deterministic: pixel slices are reduced in a fixed order, no float atomics.
+ * A ConvTranspose2d(k=2,s=2) weight gradient is the weight gradient of the 2x2 / stride-2
+ * convolution that maps its OUTPUT gradient to its INPUT (swap the roles of the two tensors).
+ */
+size_t pn_conv2d_wgrad_workspace_bytes(const pn_conv_desc *desc);
+int pn_conv2d_wgrad_f32(const pn_conv_desc *desc, const float *in, const float *dout, float *dweight,
+                        int accumulate, void *workspace, size_t workspace_bytes,
+                        pn_stream_t stream);
+/* per-channel sum over pixels (bias gradient = sum of dout): out[c] (+)= sum_p x[p*stride+off+c] */
+size_t pn_channel_sum_workspace_bytes(int c);
+int pn_channel_sum_f32(const float *x, long long pixels, int pixel_stride, int channel_offset, int c,
+                       float *out, int accumulate, void *workspace, size_t workspace_bytes,
+                       pn_stream_t stream);
+/* Data gradient = pn_conv2d_nhwc_f32 on dout with re-packed weights:
+ *   stride 1:  pack with pn_pack_conv_dgrad_weight_f32 (taps mirrored, Cin/Cout swapped;
+ *              pn_conv_packed_weight_floats(cin, cout, kh, kw, 1) floats), run a kh x kw
+ *              convolution with pad' = k-1-pad, cin' = Cout, cout' = Cin.
+ *   3x3 stride 2 pad 1 (ZeroPad2d(1)+Conv2d(3,2), rpn.py:126-134): pack with
+ *              pn_pack_conv_dgrad_s2_weight_f32, run with deconv2x2 = 1, kh = kw = 2,
+ *              pad_h_end = pad_w_end = 1, cin' = Cout, cout' = Cin on the (OH, OW) map of dout;
+ *              the output is the (2*OH, 2*OW) input gradient.
+ *   2x2 stride 2 pad 0: the forward weight (Cout, Cin, 2, 2) IS a ConvTranspose2d weight for the
+ *              data gradient: pn_pack_deconv2x2_weight_f32(w, Cout, Cin).
+ */
+int pn_pack_conv_dgrad_weight_f32(const float *w_oihw, int cout, int cin, int kh, int kw,
+                                  float *packed, pn_stream_t stream);
+size_t pn_conv_dgrad_s2_packed_weight_floats(int cout, int cin);
+int pn_pack_conv_dgrad_s2_weight_f32(const float *w_oihw, int cout, int cin, float *packed,
+                                     pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * GroupNorm family on NHWC maps: statistics over {channel block} x {all theta} x {range

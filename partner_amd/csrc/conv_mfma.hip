@@ -479,8 +479,9 @@ int fill_args(const pn_conv_desc* d, ConvArgs& a, int& zdim) {
   PN_REQUIRE(d->groups >= 1 && d->kh >= 1 && d->kw >= 1 && d->stride >= 1, "conv: bad kernel params");
   a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Cin = d->cin; a.Cout = d->cout;
   a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
-  a.OH = (d->in_h + 2 * d->pad_h - d->kh) / d->stride + 1;
-  a.OW = (d->in_w + 2 * d->pad_w - d->kw) / d->stride + 1;
+  PN_REQUIRE(d->pad_h_end >= 0 && d->pad_w_end >= 0, "conv: negative end padding");
+  a.OH = (d->in_h + 2 * d->pad_h + d->pad_h_end - d->kh) / d->stride + 1;
+  a.OW = (d->in_w + 2 * d->pad_w + d->pad_w_end - d->kw) / d->stride + 1;
   PN_REQUIRE(a.OH > 0 && a.OW > 0, "conv: empty output");
   a.in_ps = d->in_pixel_stride; a.in_co = d->in_channel_offset;
   a.out_ps = d->out_pixel_stride; a.out_co = d->out_channel_offset;
@@ -488,8 +489,11 @@ int fill_args(const pn_conv_desc* d, ConvArgs& a, int& zdim) {
   a.mode = MODE_CONV; a.OWsub = a.OW; a.ncols = d->cout; a.in_group_stride = d->groups > 1 ? d->cin : 0;
   zdim = d->groups;
   if (d->deconv2x2) {
-    PN_REQUIRE(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->groups == 1,
-               "conv: deconv2x2 wants kh=kw=stride=1, pad=0, groups=1");
+    // kh = kw = 1: ConvTranspose2d(k=2, s=2); kh = kw = 2 with one row/column of end padding: the
+    // four-phase data gradient of a 3x3 stride-2 convolution (pn_pack_conv_dgrad_s2_weight_f32)
+    PN_REQUIRE(d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->groups == 1 &&
+                   ((d->kh == 1 && d->kw == 1) || (d->kh == 2 && d->kw == 2 && d->pad_h_end == 1 && d->pad_w_end == 1)),
+               "conv: deconv2x2 wants stride=1, pad=0, groups=1 and kh=kw=1 (or kh=kw=2 with end padding 1)");
     a.mode = MODE_DECONV2; a.ncols = 4 * d->cout;
   }
   if (d->range_strata > 1) {

@@ -155,7 +155,7 @@ int pn_event_create(pn_event_t* ev) {
   return PN_OK;
 }
 int pn_event_destroy(pn_event_t ev) {
-  if (ev) hipEventDestroy((hipEvent_t)ev);
+  if (ev) (void)hipEventDestroy((hipEvent_t)ev);
   return PN_OK;
 }
 int pn_event_record(pn_event_t ev, pn_stream_t stream) {

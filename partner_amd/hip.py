@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "batch", "in_h", "in_w", "cin", "cout", "groups", "kh", "kw", "stride", "pad_h", "pad_w",
         "in_pixel_stride", "in_channel_offset", "out_pixel_stride", "out_channel_offset", "act", "deconv2x2",
-        "range_strata")]
+        "range_strata", "pad_h_end", "pad_w_end")]
 
 
 _P = C.c_void_p
@@ -66,6 +66,13 @@ SIGNATURES = {
     "pn_conv2d_nhwc_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "pn_conv2d_direct_nhwc_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "pn_fold_bn_f32": (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    "pn_conv2d_wgrad_workspace_bytes": (_SZ, [_P]),
+    "pn_conv2d_wgrad_f32": (_I, [_P, _P, _P, _P, _I, _P, _SZ, _P]),
+    "pn_channel_sum_workspace_bytes": (_SZ, [_I]),
+    "pn_channel_sum_f32": (_I, [_P, C.c_longlong, _I, _I, _I, _P, _I, _P, _SZ, _P]),
+    "pn_pack_conv_dgrad_weight_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "pn_conv_dgrad_s2_packed_weight_floats": (_SZ, [_I, _I]),
+    "pn_pack_conv_dgrad_s2_weight_f32": (_I, [_P, _I, _I, _P, _P]),
     "pn_groupnorm_workspace_bytes": (_SZ, [_I, _I, _I]),
     "pn_groupnorm_strat_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "pn_gemm_bias_act_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),

@@ -450,3 +450,119 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     hip.call("pn_layernorm_f32", x.data_ptr(), rows, c, gamma.data_ptr(), beta.data_ptr(), float(eps), out.data_ptr(),
              hip.ptr(cm), hip.stream())
     return (out, cm) if want_chan_mean else out
+
+
+# ------------------------------------------------------------------------------ conv backward (T1)
+def conv_wgrad(x: torch.Tensor, dout: torch.Tensor, kh: int, kw: int, stride=1, pad=0, cin: Optional[int] = None,
+               in_channel_offset=0, cout: Optional[int] = None, dout_channel_offset=0, out: Optional[torch.Tensor] = None,
+               accumulate=False) -> torch.Tensor:
+    """dW (Cout, Cin, KH, KW) of a convolution x -> y given dout = dL/dy; NHWC maps."""
+    hip.require_device(x, dout)
+    lib = hip.load()
+    assert x.dim() == 4 and dout.dim() == 4 and x.is_contiguous() and dout.is_contiguous()
+    b, h, w, ct = x.shape
+    cin = ct - in_channel_offset if cin is None else cin
+    cout = dout.shape[3] - dout_channel_offset if cout is None else cout
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    d = ConvDesc(b, h, w, cin, cout, 1, kh, kw, stride, ph, pw, ct, in_channel_offset, dout.shape[3], dout_channel_offset, 0, 0, 0)
+    oh, ow = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
+    assert dout.shape[:3] == (b, oh, ow), (dout.shape, (b, oh, ow))
+    if out is None:
+        out = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device)
+    nbytes = lib.pn_conv2d_wgrad_workspace_bytes(C.byref(d))
+    ws = _workspace(nbytes, x.device)
+    hip.call("pn_conv2d_wgrad_f32", C.byref(d), x.data_ptr(), dout.data_ptr(), out.data_ptr(), int(accumulate), ws.data_ptr(),
+             nbytes, hip.stream())
+    return out
+
+
+_WS = {}
+
+
+def _workspace(nbytes: int, dev) -> torch.Tensor:
+    """grow-only scratch buffer per (device, stream): the backward kernels need their workspace only
+    until the launch that consumes it has been queued on the same stream"""
+    key = (str(dev), hip.stream())
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _WS[key] = t
+    return t
+
+
+def channel_sum(x: torch.Tensor, c: Optional[int] = None, channel_offset=0, out: Optional[torch.Tensor] = None,
+                accumulate=False) -> torch.Tensor:
+    """sum over all pixels of an NHWC map, per channel (bias gradient)"""
+    hip.require_device(x)
+    lib = hip.load()
+    ct = x.shape[-1]
+    c = ct - channel_offset if c is None else c
+    pixels = x.numel() // ct
+    if out is None:
+        out = torch.empty(c, dtype=torch.float32, device=x.device)
+    nbytes = lib.pn_channel_sum_workspace_bytes(c)
+    ws = _workspace(nbytes, x.device)
+    hip.call("pn_channel_sum_f32", x.data_ptr(), pixels, ct, channel_offset, c, out.data_ptr(), int(accumulate), ws.data_ptr(),
+             nbytes, hip.stream())
+    return out
+
+
+class ConvDgrad:
+    """Data gradient of ``Conv2d(weight, stride, pad)`` as a convolution of dout on the MFMA kernel.
+
+    Supported geometries (all the reference's BEV path uses): stride 1 (any k, pad);
+    3x3 / stride 2 / pad 1; 2x2 / stride 2 / pad 0.  ``repack(weight)`` refreshes the packed copy
+    after an optimizer step without reallocating."""
+
+    def __init__(self, weight: torch.Tensor, stride=1, pad=0):
+        hip.require_device(weight)
+        lib = hip.load()
+        cout, cin, kh, kw = weight.shape
+        self.cout, self.cin, self.kh, self.kw, self.stride, self.pad = cout, cin, kh, kw, int(stride), int(pad)
+        dev = weight.device
+        if self.stride == 1:
+            self.kind = "s1"
+            self.packed = _f32(lib.pn_conv_packed_weight_floats(cin, cout, kh, kw, 1), dev)
+        elif self.stride == 2 and (kh, kw, self.pad) == (3, 3, 1):
+            self.kind = "s2k3"
+            self.packed = _f32(lib.pn_conv_dgrad_s2_packed_weight_floats(cout, cin), dev)
+        elif self.stride == 2 and (kh, kw, self.pad) == (2, 2, 0):
+            self.kind = "s2k2"
+            self.packed = _f32(lib.pn_deconv2x2_packed_weight_floats(cout, cin), dev)
+        else:
+            raise hip.PartnerHipError(f"ConvDgrad: unsupported geometry k={kh}x{kw} stride={stride} pad={pad}")
+        self.repack(weight)
+
+    def repack(self, weight: torch.Tensor) -> None:
+        w = weight.detach().contiguous().float()
+        st = hip.stream()
+        if self.kind == "s1":
+            hip.call("pn_pack_conv_dgrad_weight_f32", w.data_ptr(), self.cout, self.cin, self.kh, self.kw, self.packed.data_ptr(), st)
+        elif self.kind == "s2k3":
+            hip.call("pn_pack_conv_dgrad_s2_weight_f32", w.data_ptr(), self.cout, self.cin, self.packed.data_ptr(), st)
+        else:
+            hip.call("pn_pack_deconv2x2_weight_f32", w.data_ptr(), self.cout, self.cin, self.packed.data_ptr(), st)
+
+    def __call__(self, dout: torch.Tensor, out: Optional[torch.Tensor] = None, dout_channel_offset=0,
+                 out_channel_offset=0) -> torch.Tensor:
+        """dout: NHWC (B,OH,OW,Ct) -> dx (B,H,W,Cin); H = OH*stride (the reference's maps are even-sized)"""
+        hip.require_device(dout)
+        assert dout.dim() == 4 and dout.is_contiguous()
+        b, oh, ow, ct = dout.shape
+        if self.kind == "s1":
+            h, w = oh + self.kh - 1 - 2 * self.pad, ow + self.kw - 1 - 2 * self.pad
+            pd = self.kh - 1 - self.pad
+            d = ConvDesc(b, oh, ow, self.cout, self.cin, 1, self.kh, self.kw, 1, pd, self.kw - 1 - self.pad, ct, dout_channel_offset,
+                         0, out_channel_offset, 0, 0, 0)
+        elif self.kind == "s2k3":
+            h, w = 2 * oh, 2 * ow
+            d = ConvDesc(b, oh, ow, self.cout, self.cin, 1, 2, 2, 1, 0, 0, ct, dout_channel_offset, 0, out_channel_offset, 0, 1, 0, 1, 1)
+        else:
+            h, w = 2 * oh, 2 * ow
+            d = ConvDesc(b, oh, ow, self.cout, self.cin, 1, 1, 1, 1, 0, 0, ct, dout_channel_offset, 0, out_channel_offset, 0, 1, 0)
+        if out is None:
+            out = torch.empty((b, h, w, self.cin), dtype=torch.float32, device=dout.device)
+        assert out.shape[:3] == (b, h, w) and out.is_contiguous()
+        d.out_pixel_stride = out.shape[3]
+        hip.call("pn_conv2d_nhwc_f32", C.byref(d), dout.data_ptr(), self.packed.data_ptr(), None, None, out.data_ptr(), hip.stream())
+        return out
