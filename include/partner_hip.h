@@ -297,6 +297,30 @@ int pn_groupnorm_strat_fwd(const float *x, int batch, int h, int w, int c, int p
                            pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * BatchNorm2d in training mode + the activation that follows it (rpn.py:128-140 under
+ * model.train(); torch.nn.functional.batch_norm(training=True) in the reference), on an NHWC
+ * channel slice of `pixels` = B*H*W pixels.  Batch statistics are biased; running_var receives the
+ * unbiased one, running = (1-momentum)*running + momentum*batch (torch semantics; NULL = no
+ * update).  saved_stat (2*c floats: mean, rstd per channel) is what the backward needs.
+ * Backward: g = dout * act'(y);  dgamma = sum g*xhat;  dbeta = sum g;
+ *           dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)).   dx may alias dout.
+ * Deterministic (slice partials in fp64, summed in slice order).
+ */
+size_t pn_batchnorm_workspace_bytes(int c);
+int pn_batchnorm_train_fwd(const float *x, long long pixels, int c, int pixel_stride,
+                           int channel_offset, const float *gamma, const float *beta, float eps,
+                           float momentum, int act, float *running_mean, float *running_var,
+                           float *out, int out_pixel_stride, int out_channel_offset,
+                           float *saved_stat, void *workspace, size_t workspace_bytes,
+                           pn_stream_t stream);
+int pn_batchnorm_bwd(const float *x, const float *dout, long long pixels, int c, int pixel_stride,
+                     int channel_offset, int dout_pixel_stride, int dout_channel_offset,
+                     const float *gamma, const float *beta, int act, const float *saved_stat,
+                     float *dx, int dx_pixel_stride, int dx_channel_offset, float *dgamma,
+                     float *dbeta, int accumulate, void *workspace, size_t workspace_bytes,
+                     pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Dense linear layer on the same MFMA kernel (a 1x1 convolution over a token "image"):
  *   out[m][:n] = act(x[m][:k] @ W^T + bias) (+ residual[m][:n])
  * Replaces nn.Linear / Mlp / proj of the attention block  det3d/models/utils/set_transformer.py:37-53

@@ -316,9 +316,11 @@ int pn_conv2d_wgrad_f32(const pn_conv_desc* d, const float* in, const float* dou
   if (int rc = plan_wgrad(d, p)) return rc;
   PN_REQUIRE(in && dout && dweight && workspace, "wgrad: null pointer");
   PN_REQUIRE(workspace_bytes >= pn_conv2d_wgrad_workspace_bytes(d), "wgrad: workspace too small");
-  PN_REQUIRE(d->in_pixel_stride % 4 == 0 && d->in_channel_offset % 4 == 0 && d->out_pixel_stride % 4 == 0 &&
-                 d->out_channel_offset % 4 == 0, "wgrad: pixel strides and channel offsets must be multiples of 4");
-  PN_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)dout & 15) == 0, "wgrad: pointers must be 16-byte aligned");
+  // 16-byte buffer loads only need dword alignment; channels past Cin / Cout inside a 4-channel
+  // load land in rows / columns of the tile that are never written out, and the buffer range check
+  // zero-fills the dwords past the end of the map
+  PN_REQUIRE(d->in_pixel_stride >= d->in_channel_offset + d->cin && d->out_pixel_stride >= d->out_channel_offset + d->cout,
+             "wgrad: channel slice does not fit the pixel stride");
   const unsigned long long in_bytes = (unsigned long long)d->batch * d->in_h * d->in_w * d->in_pixel_stride * 4ull;
   const unsigned long long dy_bytes = (unsigned long long)p.M * d->out_pixel_stride * 4ull;
   PN_REQUIRE(in_bytes < (1ull << 31) && dy_bytes < (1ull << 31), "wgrad: maps larger than 2 GiB are not addressable by the buffer descriptor");

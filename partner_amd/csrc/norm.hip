@@ -200,3 +200,218 @@ int pn_groupnorm_strat_fwd(const float* x, int batch, int h, int w, int c, int p
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// BatchNorm2d in training mode (rpn.py:128-140 under model.train(): batch statistics over B,H,W,
+// running-stat update with momentum 0.01, eps 1e-3) and its backward, fused with the ReLU that
+// follows it everywhere in the reference.  Same two-pass, fixed-order scheme as above; the pixel
+// range is cut into slices, fp64 partials, no atomics.
+// =================================================================================================
+namespace {
+
+struct BnArgs {
+  const float* x;      // conv output (pre-norm), NHWC slice
+  long long pixels;
+  int C, ps, co;
+  int slices;
+  long long per_slice;
+  const float* gamma;
+  const float* beta;
+  float eps, momentum;
+  int act;
+  float* out;
+  int ops, oco;
+  float* running_mean;  // nullable
+  float* running_var;
+  float* stat;          // [C][2] (mean, rstd) saved for backward
+  double* part;         // [slices][C][2]
+  // backward
+  const float* dout;
+  int dps, dco;
+  float* dx;
+  int xps, xco;
+  float* dgamma;
+  float* dbeta;
+  int accumulate;
+  float* coef;          // [C][2]: mean(g), mean(g * xhat)
+};
+
+// slice partials of (sum, sum of squares) per channel.  mode 0: of x; mode 1 (backward): of
+// g = dout * [act'(.)] and g * xhat
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void bn_partial_kernel(BnArgs a) {
+  __shared__ double red[2][kThreads * 4];
+  const int vpc = a.C / 4;
+  const int cv = threadIdx.x % vpc, pl = threadIdx.x / vpc, ppb = kThreads / vpc;
+  const long long p0 = blockIdx.x * a.per_slice, p1 = min(a.pixels, p0 + a.per_slice);
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  float mean[4], rstd[4], ga[4], be[4];
+  if (MODE == 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = cv * 4 + k;
+      mean[k] = a.stat[2 * c]; rstd[k] = a.stat[2 * c + 1];
+      ga[k] = a.gamma ? a.gamma[c] : 1.f; be[k] = a.beta ? a.beta[c] : 0.f;
+    }
+  }
+  if (threadIdx.x < vpc * ppb) {
+    for (long long p = p0 + pl; p < p1; p += ppb) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + p * a.ps + a.co + cv * 4);
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0[k] += v[k]; s1[k] += (double)v[k] * v[k]; }
+      } else {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(a.dout + p * a.dps + a.dco + cv * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xh = (v[k] - mean[k]) * rstd[k];
+          const float y = xh * ga[k] + be[k];
+          const float g = (a.act == PN_ACT_RELU && !(y > 0.f)) ? 0.f : d[k];
+          s0[k] += g; s1[k] += (double)g * xh;
+        }
+      }
+    }
+  }
+  if (threadIdx.x < vpc * ppb) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      red[0][(cv * 4 + k) * ppb + pl] = s0[k];
+      red[1][(cv * 4 + k) * ppb + pl] = s1[k];
+    }
+  }
+  __syncthreads();
+  // one thread per (channel, moment): fixed-order sum over the ppb pixel lanes
+  for (int i = threadIdx.x; i < 2 * a.C; i += kThreads) {
+    const int m = i / a.C, c = i - m * a.C;
+    double t = 0.0;
+    for (int j = 0; j < ppb; ++j) t += red[m][c * ppb + j];
+    a.part[((size_t)blockIdx.x * a.C + c) * 2 + m] = t;
+  }
+}
+
+__global__ void bn_finalize_kernel(BnArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.C) return;
+  double t0 = 0.0, t1 = 0.0;
+  for (int k = 0; k < a.slices; ++k) { t0 += a.part[((size_t)k * a.C + c) * 2]; t1 += a.part[((size_t)k * a.C + c) * 2 + 1]; }
+  const double n = (double)a.pixels;
+  const double mean = t0 / n;
+  double var = t1 / n - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  a.stat[2 * c] = (float)mean;
+  a.stat[2 * c + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+  if (a.running_mean) {  // torch: running = (1 - m) * running + m * batch; the variance one is unbiased
+    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+    a.running_mean[c] = (float)((1.0 - a.momentum) * a.running_mean[c] + a.momentum * mean);
+    a.running_var[c] = (float)((1.0 - a.momentum) * a.running_var[c] + a.momentum * unb);
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(BnArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.C) return;
+  double t0 = 0.0, t1 = 0.0;
+  for (int k = 0; k < a.slices; ++k) { t0 += a.part[((size_t)k * a.C + c) * 2]; t1 += a.part[((size_t)k * a.C + c) * 2 + 1]; }
+  if (a.dbeta) a.dbeta[c] = (a.accumulate ? a.dbeta[c] : 0.f) + (float)t0;
+  if (a.dgamma) a.dgamma[c] = (a.accumulate ? a.dgamma[c] : 0.f) + (float)t1;
+  a.coef[2 * c] = (float)(t0 / (double)a.pixels);
+  a.coef[2 * c + 1] = (float)(t1 / (double)a.pixels);
+}
+
+// MODE 0: out = act((x - mean) * rstd * gamma + beta);  MODE 1: dx = gamma * rstd * (g - mean(g) - xhat * mean(g xhat))
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(BnArgs a) {
+  const int vpc = a.C / 4;
+  const long long total = a.pixels * vpc;
+  for (long long i = blockIdx.x * (long long)kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+    const long long p = i / vpc;
+    const int cv = (int)(i - p * vpc);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + p * a.ps + a.co + cv * 4);
+    f32x4 o;
+    if (MODE == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = cv * 4 + k;
+        o[k] = pn::apply_act((v[k] - a.stat[2 * c]) * a.stat[2 * c + 1] * (a.gamma ? a.gamma[c] : 1.f) + (a.beta ? a.beta[c] : 0.f), a.act);
+      }
+      *reinterpret_cast<f32x4*>(a.out + p * a.ops + a.oco + cv * 4) = o;
+    } else {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(a.dout + p * a.dps + a.dco + cv * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = cv * 4 + k;
+        const float rstd = a.stat[2 * c + 1], ga = a.gamma ? a.gamma[c] : 1.f;
+        const float xh = (v[k] - a.stat[2 * c]) * rstd;
+        const float y = xh * ga + (a.beta ? a.beta[c] : 0.f);
+        const float g = (a.act == PN_ACT_RELU && !(y > 0.f)) ? 0.f : d[k];
+        o[k] = ga * rstd * (g - a.coef[2 * c] - xh * a.coef[2 * c + 1]);
+      }
+      *reinterpret_cast<f32x4*>(a.dx + p * a.xps + a.xco + cv * 4) = o;
+    }
+  }
+}
+
+constexpr int kBnSlices = 1024;
+
+int bn_common(BnArgs& a, long long pixels, int c, void* workspace, size_t workspace_bytes) {
+  PN_REQUIRE(pixels >= 1 && c >= 4 && c % 4 == 0 && c <= 4 * kThreads, "batchnorm: channel count must be a multiple of 4, at most 1024");
+  PN_REQUIRE(workspace != nullptr, "batchnorm: null workspace");
+  if (workspace_bytes < pn_batchnorm_workspace_bytes(c)) return pn::fail(PN_ERR_WORKSPACE, "batchnorm: workspace too small");
+  a.pixels = pixels; a.C = c;
+  a.slices = (int)std::min<long long>(kBnSlices, pn::cdiv(pixels, 64));
+  a.per_slice = (pixels + a.slices - 1) / a.slices;
+  a.slices = (int)((pixels + a.per_slice - 1) / a.per_slice);
+  a.part = static_cast<double*>(workspace);
+  a.coef = reinterpret_cast<float*>(a.part + (size_t)kBnSlices * c * 2);
+  return PN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pn_batchnorm_workspace_bytes(int c) { return (size_t)kBnSlices * c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float); }
+
+int pn_batchnorm_train_fwd(const float* x, long long pixels, int c, int pixel_stride, int channel_offset, const float* gamma,
+                           const float* beta, float eps, float momentum, int act, float* running_mean, float* running_var,
+                           float* out, int out_pixel_stride, int out_channel_offset, float* saved_stat, void* workspace,
+                           size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(x && out && saved_stat, "batchnorm_train_fwd: null pointer");
+  PN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "batchnorm_train_fwd: running_mean and running_var go together");
+  PN_REQUIRE(pixel_stride % 4 == 0 && channel_offset % 4 == 0 && out_pixel_stride % 4 == 0 && out_channel_offset % 4 == 0,
+             "batchnorm: strides / offsets must be multiples of 4 floats");
+  BnArgs a{};
+  if (int rc = bn_common(a, pixels, c, workspace, workspace_bytes)) return rc;
+  a.x = x; a.ps = pixel_stride; a.co = channel_offset; a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum; a.act = act;
+  a.out = out; a.ops = out_pixel_stride; a.oco = out_channel_offset; a.running_mean = running_mean; a.running_var = running_var;
+  a.stat = saved_stat;
+  hipStream_t st = pn::S(stream);
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(a.slices), dim3(kThreads), 0, st, a);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(pn::cdiv(c, 64)), dim3(64), 0, st, a);
+  const long long total = pixels * (c / 4);
+  hipLaunchKernelGGL(bn_apply_kernel<0>, dim3((unsigned)std::min<long long>(4096, pn::cdiv(total, kThreads))), dim3(kThreads), 0, st, a);
+  return pn::check_launch("batchnorm_train_fwd");
+}
+
+int pn_batchnorm_bwd(const float* x, const float* dout, long long pixels, int c, int pixel_stride, int channel_offset,
+                     int dout_pixel_stride, int dout_channel_offset, const float* gamma, const float* beta, int act,
+                     const float* saved_stat, float* dx, int dx_pixel_stride, int dx_channel_offset, float* dgamma, float* dbeta,
+                     int accumulate, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(x && dout && saved_stat && dx, "batchnorm_bwd: null pointer");
+  PN_REQUIRE(pixel_stride % 4 == 0 && channel_offset % 4 == 0 && dout_pixel_stride % 4 == 0 && dout_channel_offset % 4 == 0 &&
+                 dx_pixel_stride % 4 == 0 && dx_channel_offset % 4 == 0, "batchnorm: strides / offsets must be multiples of 4 floats");
+  BnArgs a{};
+  if (int rc = bn_common(a, pixels, c, workspace, workspace_bytes)) return rc;
+  a.x = x; a.ps = pixel_stride; a.co = channel_offset; a.gamma = gamma; a.beta = beta; a.act = act;
+  a.stat = const_cast<float*>(saved_stat);
+  a.dout = dout; a.dps = dout_pixel_stride; a.dco = dout_channel_offset;
+  a.dx = dx; a.xps = dx_pixel_stride; a.xco = dx_channel_offset; a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate;
+  hipStream_t st = pn::S(stream);
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(a.slices), dim3(kThreads), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn::cdiv(c, 64)), dim3(64), 0, st, a);
+  const long long total = pixels * (c / 4);
+  hipLaunchKernelGGL(bn_apply_kernel<1>, dim3((unsigned)std::min<long long>(4096, pn::cdiv(total, kThreads))), dim3(kThreads), 0, st, a);
+  return pn::check_launch("batchnorm_bwd");
+}
+
+}  // extern "C"

@@ -549,20 +549,68 @@ class ConvDgrad:
         hip.require_device(dout)
         assert dout.dim() == 4 and dout.is_contiguous()
         b, oh, ow, ct = dout.shape
+        # the MFMA loader fetches 4 channels at a time: a Cout that is not a multiple of 4 needs dout
+        # stored with zero-filled pad channels (packed weight rows past Cout are zero as well)
+        cin_eff = (self.cout + 3) // 4 * 4
+        if dout_channel_offset + cin_eff > ct:
+            raise hip.PartnerHipError(f"ConvDgrad: dout needs {cin_eff - self.cout} zero pad channel(s) after its {self.cout} channels")
         if self.kind == "s1":
             h, w = oh + self.kh - 1 - 2 * self.pad, ow + self.kw - 1 - 2 * self.pad
             pd = self.kh - 1 - self.pad
-            d = ConvDesc(b, oh, ow, self.cout, self.cin, 1, self.kh, self.kw, 1, pd, self.kw - 1 - self.pad, ct, dout_channel_offset,
+            d = ConvDesc(b, oh, ow, cin_eff, self.cin, 1, self.kh, self.kw, 1, pd, self.kw - 1 - self.pad, ct, dout_channel_offset,
                          0, out_channel_offset, 0, 0, 0)
         elif self.kind == "s2k3":
             h, w = 2 * oh, 2 * ow
-            d = ConvDesc(b, oh, ow, self.cout, self.cin, 1, 2, 2, 1, 0, 0, ct, dout_channel_offset, 0, out_channel_offset, 0, 1, 0, 1, 1)
+            d = ConvDesc(b, oh, ow, cin_eff, self.cin, 1, 2, 2, 1, 0, 0, ct, dout_channel_offset, 0, out_channel_offset, 0, 1, 0, 1, 1)
         else:
             h, w = 2 * oh, 2 * ow
-            d = ConvDesc(b, oh, ow, self.cout, self.cin, 1, 1, 1, 1, 0, 0, ct, dout_channel_offset, 0, out_channel_offset, 0, 1, 0)
+            d = ConvDesc(b, oh, ow, cin_eff, self.cin, 1, 1, 1, 1, 0, 0, ct, dout_channel_offset, 0, out_channel_offset, 0, 1, 0)
         if out is None:
             out = torch.empty((b, h, w, self.cin), dtype=torch.float32, device=dout.device)
         assert out.shape[:3] == (b, h, w) and out.is_contiguous()
         d.out_pixel_stride = out.shape[3]
         hip.call("pn_conv2d_nhwc_f32", C.byref(d), dout.data_ptr(), self.packed.data_ptr(), None, None, out.data_ptr(), hip.stream())
         return out
+
+
+def batchnorm_train(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, momentum: float,
+                    running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], act=ACT_RELU,
+                    out: Optional[torch.Tensor] = None, c: Optional[int] = None, channel_offset=0, out_channel_offset=0):
+    """training-mode BatchNorm2d + activation on an NHWC map -> (out, saved_stat)"""
+    hip.require_device(x)
+    lib = hip.load()
+    ct = x.shape[-1]
+    c = ct - channel_offset if c is None else c
+    pixels = x.numel() // ct
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (c,), dtype=torch.float32, device=x.device)
+    stat = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    nbytes = lib.pn_batchnorm_workspace_bytes(c)
+    ws = _workspace(nbytes, x.device)
+    hip.call("pn_batchnorm_train_fwd", x.data_ptr(), pixels, c, ct, channel_offset, hip.ptr(gamma), hip.ptr(beta), float(eps),
+             float(momentum), int(act), hip.ptr(running_mean), hip.ptr(running_var), out.data_ptr(), out.shape[-1],
+             out_channel_offset, stat.data_ptr(), ws.data_ptr(), nbytes, hip.stream())
+    return out, stat
+
+
+def batchnorm_bwd(x: torch.Tensor, dout: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, stat: torch.Tensor, act=ACT_RELU,
+                  dx: Optional[torch.Tensor] = None, dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None,
+                  accumulate=False, c: Optional[int] = None, channel_offset=0, dout_channel_offset=0, dx_channel_offset=0):
+    """backward of batchnorm_train (+ its activation) -> (dx, dgamma, dbeta); dx may be dout (in place)"""
+    hip.require_device(x, dout)
+    lib = hip.load()
+    ct = x.shape[-1]
+    c = ct - channel_offset if c is None else c
+    pixels = x.numel() // ct
+    if dx is None:
+        dx = torch.empty(x.shape[:-1] + (c,), dtype=torch.float32, device=x.device)
+    if dgamma is None:
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    if dbeta is None:
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    nbytes = lib.pn_batchnorm_workspace_bytes(c)
+    ws = _workspace(nbytes, x.device)
+    hip.call("pn_batchnorm_bwd", x.data_ptr(), dout.data_ptr(), pixels, c, ct, channel_offset, dout.shape[-1], dout_channel_offset,
+             hip.ptr(gamma), hip.ptr(beta), int(act), stat.data_ptr(), dx.data_ptr(), dx.shape[-1], dx_channel_offset,
+             dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate), ws.data_ptr(), nbytes, hip.stream())
+    return dx, dgamma, dbeta
