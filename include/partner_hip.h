@@ -296,6 +296,21 @@ int pn_groupnorm_strat_fwd(const float *x, int batch, int h, int w, int c, int p
                            const float *add, float *out2, void *workspace, size_t workspace_bytes,
                            pn_stream_t stream);
 
+/* Backward of pn_groupnorm_strat_fwd (autograd through RSNorm / GroupNorm + ReLU and the
+ * calibration x*W(pos)+b(pos), center_head_parallel.py:148-176,268).  dout: gradient of `out`;
+ * dout2 (nullable, pixel stride c): gradient of `out2`, then mul is required and dmul / dadd
+ * ((1,H,W,c) maps) receive the gradients of the calibration maps.  dgamma / dbeta have
+ * range_strata*c entries (nullable).  dx may alias dout.  act: PN_ACT_NONE or PN_ACT_RELU.
+ * The statistics are recomputed from x.  accumulate != 0 adds to dgamma/dbeta/dmul/dadd. */
+size_t pn_groupnorm_bwd_workspace_bytes(int batch, int c, int channel_groups, int range_strata);
+int pn_groupnorm_strat_bwd(const float *x, const float *dout, const float *dout2, const float *mul,
+                           int batch, int h, int w, int c, int pixel_stride, int channel_offset,
+                           int dout_pixel_stride, int dout_channel_offset, int channel_groups,
+                           int range_strata, const float *gamma, const float *beta, float eps,
+                           int act, float *dx, int dx_pixel_stride, int dx_channel_offset,
+                           float *dgamma, float *dbeta, float *dmul, float *dadd, int accumulate,
+                           void *workspace, size_t workspace_bytes, pn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * BatchNorm2d in training mode + the activation that follows it (rpn.py:128-140 under
  * model.train(); torch.nn.functional.batch_norm(training=True) in the reference), on an NHWC

@@ -415,3 +415,243 @@ int pn_batchnorm_bwd(const float* x, const float* dout, long long pixels, int c,
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// Backward of the GroupNorm family (+ ReLU, + the x*W(pos)+b(pos) calibration output).
+//   do    = dout + dout2 * mul                         (gradient reaching out = act(y))
+//   g     = do * act'(y),  y = xhat * gamma + beta
+//   dgamma[s][c] = sum_{b, pixels of stratum s} g * xhat,   dbeta[s][c] = sum g
+//   dxhat = g * gamma;  per statistics group: m1 = mean(dxhat), m2 = mean(dxhat * xhat)
+//   dx    = rstd * (dxhat - m1 - xhat * m2)
+//   dmul[pixel][c] = sum_b dout2 * out,  dadd[pixel][c] = sum_b dout2
+// The statistics are recomputed from x (two cheap passes over a few MB) instead of being carried
+// from the forward call.
+// =================================================================================================
+namespace {
+
+struct GnBwdArgs {
+  GnArgs f;            // forward description (x, sizes, gamma/beta, eps, act, mul; part/stat)
+  const float* dout;
+  int dps, dco;
+  const float* dout2;  // nullable, pixel stride C
+  float* dx;
+  int xps, xco;
+  float* dgamma;
+  float* dbeta;
+  float* dmul;
+  float* dadd;
+  int accumulate;
+  double* part2;       // [B][strata][splits][C][2]
+  float* coef;         // [B][strata][cgroups][2] = (m1, m2)
+};
+
+__device__ __forceinline__ void gn_point(const GnBwdArgs& a, const float* smean, int s, int cv, size_t pix, int y, int x,
+                                         float (&g)[4], float (&xh)[4], float (&ga)[4]) {
+  const GnArgs& f = a.f;
+  const int cpg = f.C / f.cgroups;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(f.x + pix * f.ps + f.co + cv * 4);
+  f32x4 d = *reinterpret_cast<const f32x4*>(a.dout + pix * a.dps + a.dco + cv * 4);
+  if (a.dout2) {
+    const f32x4 d2 = *reinterpret_cast<const f32x4*>(a.dout2 + pix * f.C + cv * 4);
+    const f32x4 m = *reinterpret_cast<const f32x4*>(f.mul + ((size_t)y * f.W + x) * f.C + cv * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] += d2[k] * m[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = cv * 4 + k;
+    ga[k] = f.gamma ? f.gamma[s * f.C + c] : 1.f;
+    const float be = f.beta ? f.beta[s * f.C + c] : 0.f;
+    xh[k] = (v[k] - smean[2 * (c / cpg)]) * smean[2 * (c / cpg) + 1];
+    const float yv = xh[k] * ga[k] + be;
+    g[k] = (f.act == PN_ACT_RELU && !(yv > 0.f)) ? 0.f : d[k];
+  }
+}
+
+// grid (splits, strata, B): per-channel (sum g, sum g*xhat) of this block's rows
+__global__ __launch_bounds__(kThreads) void gn_bwd_partial_kernel(GnBwdArgs a) {
+  __shared__ double red[2][kThreads * 4];
+  const GnArgs& f = a.f;
+  const int split = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+  const int wps = f.W / f.strata;
+  const float* smean = f.stat + ((size_t)b * f.strata + s) * f.cgroups * 2;
+  const int vpc = f.C / 4;
+  const int cv = threadIdx.x % vpc, pl = threadIdx.x / vpc, ppb = kThreads / vpc;
+  const int y0 = split * f.rows_per_split, y1 = min(f.H, y0 + f.rows_per_split);
+  const int npix = (y1 - y0) * wps;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  for (int p = pl; p < npix; p += ppb) {
+    const int y = y0 + p / wps, x = s * wps + p % wps;
+    float g[4], xh[4], ga[4];
+    gn_point(a, smean, s, cv, (size_t)(b * f.H + y) * f.W + x, y, x, g, xh, ga);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s0[k] += g[k]; s1[k] += (double)g[k] * xh[k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    red[0][(cv * 4 + k) * ppb + pl] = s0[k];
+    red[1][(cv * 4 + k) * ppb + pl] = s1[k];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * f.C; i += kThreads) {
+    const int m = i / f.C, c = i - m * f.C;
+    double t = 0.0;
+    for (int j = 0; j < ppb; ++j) t += red[m][c * ppb + j];
+    a.part2[((((size_t)b * f.strata + s) * f.splits + split) * f.C + c) * 2 + m] = t;
+  }
+}
+
+// block per stratum s, thread per channel: dgamma/dbeta (sum over batch and splits, fixed order) and
+// the per-(b, group) coefficients m1, m2
+__global__ void gn_bwd_finalize_kernel(GnBwdArgs a) {
+  extern __shared__ double sh[];  // [C][2] gamma-weighted per-channel sums of the current b
+  const GnArgs& f = a.f;
+  const int s = blockIdx.x;
+  const int cpg = f.C / f.cgroups;
+  const double n = (double)cpg * f.H * (f.W / f.strata);
+  double tg = 0.0, tb = 0.0;
+  for (int b = 0; b < f.B; ++b) {
+    for (int c = threadIdx.x; c < f.C; c += blockDim.x) {
+      double t0 = 0.0, t1 = 0.0;
+      const double* p = a.part2 + (((size_t)b * f.strata + s) * f.splits) * f.C * 2 + (size_t)c * 2;
+      for (int k = 0; k < f.splits; ++k) { t0 += p[(size_t)k * f.C * 2]; t1 += p[(size_t)k * f.C * 2 + 1]; }
+      if (c == (int)threadIdx.x) { tb += t0; tg += t1; }  // blockDim.x >= C: one channel per thread
+      const double ga = f.gamma ? (double)f.gamma[s * f.C + c] : 1.0;
+      sh[2 * c] = ga * t0;
+      sh[2 * c + 1] = ga * t1;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < f.cgroups; g += blockDim.x) {
+      double m1 = 0.0, m2 = 0.0;
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) { m1 += sh[2 * c]; m2 += sh[2 * c + 1]; }
+      float* co = a.coef + (((size_t)b * f.strata + s) * f.cgroups + g) * 2;
+      co[0] = (float)(m1 / n);
+      co[1] = (float)(m2 / n);
+    }
+    __syncthreads();
+  }
+  const int c = threadIdx.x;
+  if (c < f.C) {
+    if (a.dbeta) a.dbeta[s * f.C + c] = (a.accumulate ? a.dbeta[s * f.C + c] : 0.f) + (float)tb;
+    if (a.dgamma) a.dgamma[s * f.C + c] = (a.accumulate ? a.dgamma[s * f.C + c] : 0.f) + (float)tg;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(GnBwdArgs a) {
+  const GnArgs& f = a.f;
+  const int split = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+  const int wps = f.W / f.strata;
+  const int cpg = f.C / f.cgroups;
+  const float* smean = f.stat + ((size_t)b * f.strata + s) * f.cgroups * 2;
+  const float* coef = a.coef + ((size_t)b * f.strata + s) * f.cgroups * 2;
+  const int vpc = f.C / 4;
+  const int cv = threadIdx.x % vpc, pl = threadIdx.x / vpc, ppb = kThreads / vpc;
+  const int y0 = split * f.rows_per_split, y1 = min(f.H, y0 + f.rows_per_split);
+  const int npix = (y1 - y0) * wps;
+  for (int p = pl; p < npix; p += ppb) {
+    const int y = y0 + p / wps, x = s * wps + p % wps;
+    const size_t pix = (size_t)(b * f.H + y) * f.W + x;
+    float g[4], xh[4], ga[4];
+    gn_point(a, smean, s, cv, pix, y, x, g, xh, ga);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int grp = (cv * 4 + k) / cpg;
+      o[k] = smean[2 * grp + 1] * (g[k] * ga[k] - coef[2 * grp] - xh[k] * coef[2 * grp + 1]);
+    }
+    *reinterpret_cast<f32x4*>(a.dx + pix * a.xps + a.xco + cv * 4) = o;
+  }
+}
+
+// dmul / dadd: thread per (pixel of one sample, 4 channels), loop over the batch
+__global__ void gn_bwd_calib_kernel(GnBwdArgs a) {
+  const GnArgs& f = a.f;
+  const int vpc = f.C / 4;
+  const size_t total = (size_t)f.H * f.W * vpc;
+  const int cpg = f.C / f.cgroups, wps = f.W / f.strata;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pq = i / vpc;
+    const int cv = (int)(i - pq * vpc);
+    const int y = (int)(pq / f.W), x = (int)(pq - (size_t)y * f.W), s = x / wps;
+    f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sa = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < f.B; ++b) {
+      const size_t pix = (size_t)(b * f.H + y) * f.W + x;
+      const float* smean = f.stat + ((size_t)b * f.strata + s) * f.cgroups * 2;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(f.x + pix * f.ps + f.co + cv * 4);
+      const f32x4 d2 = *reinterpret_cast<const f32x4*>(a.dout2 + pix * f.C + cv * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = cv * 4 + k;
+        const float xh = (v[k] - smean[2 * (c / cpg)]) * smean[2 * (c / cpg) + 1];
+        const float o = pn::apply_act(xh * (f.gamma ? f.gamma[s * f.C + c] : 1.f) + (f.beta ? f.beta[s * f.C + c] : 0.f), f.act);
+        sm[k] += d2[k] * o;
+        sa[k] += d2[k];
+      }
+    }
+    float* pm = a.dmul + pq * f.C + cv * 4;
+    float* pa = a.dadd + pq * f.C + cv * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pm[k] = (a.accumulate ? pm[k] : 0.f) + sm[k];
+      pa[k] = (a.accumulate ? pa[k] : 0.f) + sa[k];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pn_groupnorm_bwd_workspace_bytes(int batch, int c, int channel_groups, int range_strata) {
+  return pn_groupnorm_workspace_bytes(batch, channel_groups, range_strata) +
+         (size_t)batch * range_strata * 256 * c * 2 * sizeof(double) + (size_t)batch * range_strata * channel_groups * 2 * sizeof(float);
+}
+
+int pn_groupnorm_strat_bwd(const float* x, const float* dout, const float* dout2, const float* mul, int batch, int h, int w, int c,
+                           int pixel_stride, int channel_offset, int dout_pixel_stride, int dout_channel_offset,
+                           int channel_groups, int range_strata, const float* gamma, const float* beta, float eps, int act,
+                           float* dx, int dx_pixel_stride, int dx_channel_offset, float* dgamma, float* dbeta, float* dmul,
+                           float* dadd, int accumulate, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(x && dout && dx && workspace, "groupnorm_bwd: null pointer");
+  PN_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && c >= 1, "groupnorm_bwd: bad sizes");
+  PN_REQUIRE(c % 4 == 0 && c <= kThreads && (4 * kThreads) % c == 0, "groupnorm_bwd: channel count must be a multiple of 4 dividing 1024, at most 256");
+  PN_REQUIRE(pixel_stride % 4 == 0 && channel_offset % 4 == 0 && dout_pixel_stride % 4 == 0 && dout_channel_offset % 4 == 0 &&
+                 dx_pixel_stride % 4 == 0 && dx_channel_offset % 4 == 0, "groupnorm_bwd: strides / offsets must be multiples of 4 floats");
+  PN_REQUIRE(channel_groups >= 1 && c % channel_groups == 0 && channel_groups <= 128 && (channel_groups & (channel_groups - 1)) == 0,
+             "groupnorm_bwd: channel_groups must be a power of two <= 128 dividing the channel count");
+  PN_REQUIRE(range_strata >= 1 && w % range_strata == 0, "groupnorm_bwd: range axis not divisible by range_strata");
+  PN_REQUIRE(act == PN_ACT_NONE || act == PN_ACT_RELU, "groupnorm_bwd: activation must be none or ReLU");
+  PN_REQUIRE((dout2 == nullptr) || (mul && dmul && dadd), "groupnorm_bwd: dout2 needs mul, dmul and dadd");
+  if (workspace_bytes < pn_groupnorm_bwd_workspace_bytes(batch, c, channel_groups, range_strata))
+    return pn::fail(PN_ERR_WORKSPACE, "groupnorm_bwd: workspace too small");
+  GnBwdArgs a{};
+  GnArgs& f = a.f;
+  f.x = x; f.B = batch; f.H = h; f.W = w; f.C = c; f.ps = pixel_stride; f.co = channel_offset;
+  f.cgroups = channel_groups; f.strata = range_strata;
+  f.splits = std::min(256, pick_splits(batch, h, range_strata));
+  f.rows_per_split = pn::cdiv(h, f.splits);
+  f.gamma = gamma; f.beta = beta; f.eps = eps; f.act = act; f.mul = mul;
+  f.part = static_cast<double*>(workspace);
+  const size_t ngroups = (size_t)batch * range_strata * channel_groups;
+  f.stat = reinterpret_cast<float*>(f.part + ngroups * 256 * 2);
+  char* p = static_cast<char*>(workspace) + pn_groupnorm_workspace_bytes(batch, channel_groups, range_strata);
+  a.part2 = reinterpret_cast<double*>(p);
+  a.coef = reinterpret_cast<float*>(p + (size_t)batch * range_strata * 256 * c * 2 * sizeof(double));
+  a.dout = dout; a.dps = dout_pixel_stride; a.dco = dout_channel_offset; a.dout2 = dout2;
+  a.dx = dx; a.xps = dx_pixel_stride; a.xco = dx_channel_offset;
+  a.dgamma = dgamma; a.dbeta = dbeta; a.dmul = dmul; a.dadd = dadd; a.accumulate = accumulate;
+  hipStream_t st = pn::S(stream);
+  dim3 grid(f.splits, range_strata, batch);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(kThreads), 0, st, f);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ngroups), dim3(64), 0, st, f);
+  hipLaunchKernelGGL(gn_bwd_partial_kernel, grid, dim3(kThreads), 0, st, a);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(range_strata), dim3(kThreads), (size_t)c * 2 * sizeof(double), st, a);
+  if (dout2) {
+    const size_t total = (size_t)h * w * (c / 4);
+    hipLaunchKernelGGL(gn_bwd_calib_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, st, a);
+  }
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(kThreads), 0, st, a);  // last: dx may alias dout
+  return pn::check_launch("groupnorm_strat_bwd");
+}
+
+}  // extern "C"

@@ -614,3 +614,35 @@ def batchnorm_bwd(x: torch.Tensor, dout: torch.Tensor, gamma: torch.Tensor, beta
              hip.ptr(gamma), hip.ptr(beta), int(act), stat.data_ptr(), dx.data_ptr(), dx.shape[-1], dx_channel_offset,
              dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate), ws.data_ptr(), nbytes, hip.stream())
     return dx, dgamma, dbeta
+
+
+def groupnorm_strat_bwd(x: torch.Tensor, dout: torch.Tensor, channel_groups: int, range_strata: int, gamma: torch.Tensor,
+                        beta: torch.Tensor, eps=1e-5, act=ACT_NONE, dout2: Optional[torch.Tensor] = None,
+                        mul: Optional[torch.Tensor] = None, dx: Optional[torch.Tensor] = None, dgamma=None, dbeta=None,
+                        dmul=None, dadd=None, accumulate=False):
+    """backward of groupnorm_strat -> (dx, dgamma, dbeta[, dmul, dadd]); dx may be dout"""
+    hip.require_device(x, dout)
+    lib = hip.load()
+    assert x.is_contiguous() and dout.is_contiguous()
+    b, h, w, c = x.shape
+    dev = x.device
+    if dx is None:
+        dx = torch.empty_like(x)
+    if dgamma is None:
+        dgamma = _f32(range_strata * c, dev)
+    if dbeta is None:
+        dbeta = _f32(range_strata * c, dev)
+    if dout2 is not None:
+        assert mul is not None and dout2.is_contiguous()
+        if dmul is None:
+            dmul = torch.empty((h, w, c), dtype=torch.float32, device=dev)
+        if dadd is None:
+            dadd = torch.empty((h, w, c), dtype=torch.float32, device=dev)
+    nbytes = lib.pn_groupnorm_bwd_workspace_bytes(b, c, channel_groups, range_strata)
+    ws = _workspace(nbytes, dev)
+    hip.call("pn_groupnorm_strat_bwd", x.data_ptr(), dout.data_ptr(), hip.ptr(dout2), hip.ptr(mul), b, h, w, c, c, 0, dout.shape[-1], 0,
+             channel_groups, range_strata, hip.ptr(gamma), hip.ptr(beta), float(eps), int(act), dx.data_ptr(), dx.shape[-1], 0,
+             dgamma.data_ptr(), dbeta.data_ptr(), hip.ptr(dmul), hip.ptr(dadd), int(accumulate), ws.data_ptr(), nbytes, hip.stream())
+    if dout2 is not None:
+        return dx, dgamma, dbeta, dmul, dadd
+    return dx, dgamma, dbeta

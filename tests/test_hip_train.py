@@ -109,3 +109,54 @@ def test_batchnorm_train_fwd_bwd(dev, shape):
     dx2, dg2, db2 = ops.batchnorm_bwd(xd, dyd, g.detach().to(dev), be.detach().to(dev), stat, dx=dyd, dgamma=dg, dbeta=db, accumulate=True)
     assert dx2.data_ptr() == dyd.data_ptr() and torch.equal(dx2, dx)
     assert rel_err(dg2.cpu(), 2 * g.grad) < 2e-5
+
+
+def test_groupnorm_family_bwd(dev):
+    """RSNorm(1,4)+ReLU with the calibration second output, GroupNorm(C,C)+ReLU, the 8-stratum
+    GroupNorm of RangeStratified: dx, dgamma, dbeta (and dmul, dadd) against autograd over the oracle"""
+    from oracle import polar_oracle as O
+    from partner_amd import ops
+    rng = np.random.default_rng(12)
+    B, C, H, W = 3, 64, 24, 32
+    x = torch.from_numpy((rng.standard_normal((B, C, H, W)) * 2 + 0.3).astype(np.float32))
+    xd = ops.to_nhwc(x.to(dev))
+
+    def leaf(a):
+        return torch.from_numpy(a.astype(np.float32)).requires_grad_(True)
+
+    # --- RSNorm(1, 4) + ReLU, out2 = out * mul + add
+    xr = x.clone().requires_grad_(True)
+    g, b_ = leaf(rng.uniform(0.5, 1.5, 4 * C)), leaf(rng.standard_normal(4 * C) * 0.2)
+    mul, add = leaf(rng.standard_normal((1, C, H, W))), leaf(rng.standard_normal((1, C, H, W)))
+    out = F.relu(O.rs_norm(xr, g, b_, 1, 4))
+    out2 = out * mul + add
+    d1 = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32))
+    d2 = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32))
+    ((out * d1).sum() + (out2 * d2).sum()).backward()
+    mul_d = mul.detach()[0].permute(1, 2, 0).contiguous().to(dev)
+    dx, dg, db, dm, da = ops.groupnorm_strat_bwd(xd, ops.to_nhwc(d1.to(dev)), 1, 4, g.detach().to(dev), b_.detach().to(dev), 1e-5, ops.ACT_RELU,
+                                                 dout2=ops.to_nhwc(d2.to(dev)), mul=mul_d)
+    assert rel_err(ops.as_nchw(dx).cpu(), xr.grad) < 5e-5
+    assert rel_err(dg.cpu(), g.grad) < 2e-5 and rel_err(db.cpu(), b_.grad) < 2e-5
+    assert rel_err(dm.cpu().permute(2, 0, 1)[None], mul.grad) < 2e-5
+    assert rel_err(da.cpu().permute(2, 0, 1)[None], add.grad) < 2e-5
+    # --- GroupNorm(C, C) / GroupNorm(8, C) / GroupNorm(1, C), ReLU and no activation
+    for G, act in ((C, True), (8, True), (1, False)):
+        xr = x.clone().requires_grad_(True)
+        g, b_ = leaf(rng.uniform(0.5, 1.5, C)), leaf(rng.standard_normal(C) * 0.2)
+        y = F.group_norm(xr, G, g, b_, 1e-5)
+        y = F.relu(y) if act else y
+        y.backward(d1)
+        d1d = ops.to_nhwc(d1.to(dev))
+        dx, dg, db = ops.groupnorm_strat_bwd(xd, d1d, G, 1, g.detach().to(dev), b_.detach().to(dev), 1e-5,
+                                             ops.ACT_RELU if act else ops.ACT_NONE, dx=d1d)
+        assert dx.data_ptr() == d1d.data_ptr()
+        assert rel_err(ops.as_nchw(dx).cpu(), xr.grad) < 5e-5, G
+        assert rel_err(dg.cpu(), g.grad) < 2e-5 and rel_err(db.cpu(), b_.grad) < 2e-5
+    # --- the GroupNorm inside RangeStratified: 1 channel group x 8 range strata, stacked gamma/beta
+    xr = x.clone().requires_grad_(True)
+    g, b_ = leaf(rng.uniform(0.5, 1.5, 8 * C)), leaf(rng.standard_normal(8 * C) * 0.2)
+    F.relu(O.rs_norm(xr, g, b_, 1, 8)).backward(d1)
+    dx, dg, db = ops.groupnorm_strat_bwd(xd, ops.to_nhwc(d1.to(dev)), 1, 8, g.detach().to(dev), b_.detach().to(dev), 1e-5, ops.ACT_RELU)
+    assert rel_err(ops.as_nchw(dx).cpu(), xr.grad) < 5e-5
+    assert rel_err(dg.cpu(), g.grad) < 2e-5 and rel_err(db.cpu(), b_.grad) < 2e-5
