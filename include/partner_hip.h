@@ -399,6 +399,22 @@ int pn_center_loss_fwd(const float *hm_logits, int hm_pixel_stride, const float 
                        int box_dims, const float *code_weights, float weight, float *out,
                        void *workspace, size_t workspace_bytes, pn_stream_t stream);
 
+/* Backward of pn_center_loss_fwd (loss.backward() of center_head.py:248-288): gradients with
+ * respect to the hm logits and the box head outputs.  fwd_out is the `out` vector of the forward
+ * call (num_positive is read from it on the device); grad_scale multiplies everything (1/world
+ * for a mean over ranks, or 1).  d_hm (B,H,W,d_hm_pixel_stride) and d_box_ptrs[i]
+ * (B,H,W,d_box_pixel_strides[i]) are fully overwritten (zeros where no gradient flows, including
+ * pad channels), so they can feed the MFMA data/weight-gradient kernels directly.
+ * Objects that share a cell are folded in object order: bitwise reproducible. */
+int pn_center_loss_bwd(const float *hm_logits, int hm_pixel_stride, const float *hm_target, int batch,
+                       int classes, int h, int w, const float *const *box_ptrs,
+                       const int *box_pixel_strides, const int *box_channels, int n_box_src,
+                       const int64_t *ind, const uint8_t *mask, const int64_t *cat,
+                       const float *anno_box, int anno_dim, const int *anno_sel, int max_objs,
+                       int box_dims, const float *code_weights, float weight, const float *fwd_out,
+                       float grad_scale, float *d_hm, int d_hm_pixel_stride, float *const *d_box_ptrs,
+                       const int *d_box_pixel_strides, pn_stream_t stream);
+
 /* layout helpers at the API boundary */
 int pn_nchw_to_nhwc_f32(const float *in, int b, int c, int h, int w, float *out, pn_stream_t stream);
 int pn_nhwc_to_nchw_f32(const float *in, int b, int c, int h, int w, int pixel_stride,

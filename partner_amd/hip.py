@@ -91,6 +91,7 @@ SIGNATURES = {
     "pn_nhwc_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "pn_center_loss_workspace_bytes": (_SZ, []),
     "pn_center_loss_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _F, _P, _P, _SZ, _P]),
+    "pn_center_loss_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _F, _P, _F, _P, _I, _P, _P, _P]),
     "pn_transpose_hw_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "pn_event_create": (_I, [C.POINTER(_P)]),
     "pn_event_destroy": (_I, [_P]),

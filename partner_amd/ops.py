@@ -646,3 +646,58 @@ def groupnorm_strat_bwd(x: torch.Tensor, dout: torch.Tensor, channel_groups: int
     if dout2 is not None:
         return dx, dgamma, dbeta, dmul, dadd
     return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------ L1 loss, NHWC level
+class CenterLossTargets:
+    """device copies of one task's targets (example['hm'|'ind'|'mask'|'cat'|'anno_box'][t])"""
+
+    def __init__(self, hm, ind, mask, cat, anno_box, device):
+        self.hm = hm.to(device).float().contiguous()
+        self.ind = ind.to(device).long().contiguous()
+        self.mask = mask.to(device).to(torch.uint8).contiguous()
+        self.cat = cat.to(device).long().contiguous()
+        self.anno = anno_box.to(device).float().contiguous()
+
+
+def _loss_common(hm: torch.Tensor, ncls: int, boxes, tg: CenterLossTargets, code_weights, with_vel: bool):
+    b, h, w, _ = hm.shape
+    ndim = sum(n for _, n in boxes)
+    ad = tg.anno.shape[-1]
+    sel = list(range(ndim)) if with_vel else [0, 1, 2, 3, 4, 5, ad - 2, ad - 1]
+    cw = torch.tensor(list(code_weights)[:ndim], dtype=torch.float32, device=hm.device)
+    n = len(boxes)
+    args = (hm.data_ptr(), hm.shape[3], tg.hm.data_ptr(), b, ncls, h, w, (C.c_void_p * n)(*[t.data_ptr() for t, _ in boxes]),
+            (C.c_int * n)(*[t.shape[3] for t, _ in boxes]), (C.c_int * n)(*[c for _, c in boxes]), n, tg.ind.data_ptr(),
+            tg.mask.data_ptr(), tg.cat.data_ptr(), tg.anno.data_ptr(), ad, (C.c_int * ndim)(*sel), tg.ind.shape[1], ndim, cw.data_ptr())
+    return args, ndim, cw
+
+
+def center_loss(hm: torch.Tensor, ncls: int, boxes, tg: CenterLossTargets, code_weights, weight: float, with_vel=True):
+    """hm: NHWC logits (B,H,W,>=ncls); boxes: [(NHWC tensor, channels)] in the reference order
+    (reg, height, dim[, vel], rot).  -> out[4+ndim] = [det, hm, loc, num_pos, elem...] (device)"""
+    hip.require_device(hm)
+    lib = hip.load()
+    args, ndim, cw = _loss_common(hm, ncls, boxes, tg, code_weights, with_vel)
+    out = torch.empty((4 + ndim,), dtype=torch.float32, device=hm.device)
+    wsb = lib.pn_center_loss_workspace_bytes()
+    ws = _workspace(wsb, hm.device)
+    hip.call("pn_center_loss_fwd", *args, float(weight), out.data_ptr(), ws.data_ptr(), wsb, hip.stream())
+    return out
+
+
+def center_loss_bwd(hm: torch.Tensor, ncls: int, boxes, tg: CenterLossTargets, code_weights, weight: float, fwd_out: torch.Tensor,
+                    grad_scale=1.0, with_vel=True, d_hm: Optional[torch.Tensor] = None, d_boxes=None):
+    """-> (d_hm, [d_box...]) NHWC, channel counts padded to multiples of 4 (pad channels zero)"""
+    hip.require_device(hm)
+    args, ndim, cw = _loss_common(hm, ncls, boxes, tg, code_weights, with_vel)
+    b, h, w, _ = hm.shape
+    pad4 = lambda c: (c + 3) // 4 * 4  # noqa: E731
+    if d_hm is None:
+        d_hm = torch.empty((b, h, w, pad4(ncls)), dtype=torch.float32, device=hm.device)
+    if d_boxes is None:
+        d_boxes = [torch.empty((b, h, w, pad4(c)), dtype=torch.float32, device=hm.device) for _, c in boxes]
+    n = len(boxes)
+    hip.call("pn_center_loss_bwd", *args, float(weight), fwd_out.data_ptr(), float(grad_scale), d_hm.data_ptr(), d_hm.shape[3],
+             (C.c_void_p * n)(*[t.data_ptr() for t in d_boxes]), (C.c_int * n)(*[t.shape[3] for t in d_boxes]), hip.stream())
+    return d_hm, d_boxes
