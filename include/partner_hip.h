@@ -176,6 +176,22 @@ int pn_dynamic_pfn_fwd_table(const float *points, int point_stride, const int32_
 /* pointer to the uint32 key-per-voxel array inside a pn_unique_rank_bitmap workspace */
 const uint32_t *pn_unique_keys_ptr(const void *workspace, uint64_t num_cells, int n_capacity);
 
+/* Backward of the (C0, C1) = (32, 128) pillar feature net: gradients of the two Linear weights
+ * (autograd through pillar_encoder.py:393-406 / 63-71; the points are data, no gradient).
+ * The incoming gradient is either d_features (V,128) or the dense canvas gradient d_canvas
+ * (B,T,R,128) NHWC, of which only the occupied cells are read (= backward of DynamicPPScatter,
+ * pillar_encoder.py:418-432, fused).  dw0 (32,16), dw1 (128,64) in torch layout.  The maximum's
+ * gradient goes to the first point attaining it (torch_scatter.scatter_max semantics).
+ * Deterministic: per-wave partial sums, added in wave order. */
+size_t pn_dynamic_pfn_bwd_workspace_bytes(void);
+int pn_dynamic_pfn_bwd(const float *points, int point_stride, const int32_t *voxel_start,
+                       const int32_t *order, const int32_t *num_voxels, int v_capacity,
+                       const uint32_t *unq_keys, const int32_t *grid, const float *w0, int c0,
+                       const float *w1, int c1, float vx, float vy, float x_offset, float y_offset,
+                       const float *center_table, const float *d_features, const float *d_canvas,
+                       float *dw0, float *dw1, int accumulate, void *workspace,
+                       size_t workspace_bytes, pn_stream_t stream);
+
 /* V5 alone: DynamicPPScatter.forward (pillar_encoder.py:418-432) / PointPillarsScatter
  * features (V x C), unq int64 (V x 4) -> canvas NHWC (batch,T,R,C); caller zero-fills. */
 int pn_scatter_canvas_fwd(const float *features, const int64_t *unq, const int32_t *num_voxels,

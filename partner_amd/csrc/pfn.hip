@@ -389,6 +389,190 @@ __global__ __launch_bounds__(kHeavyWaves * 64) void dynamic_pfn_32_128_heavy_ker
   }
 }
 
+// ---- backward of the (32, 128) pillar feature net: weight gradients only (the points are data) -----
+// Forward per pillar:  h0[p] = relu(W0 d16[p]);  m0 = max_p h0[p];  y1[p] = W1a h0[p] + W1b m0;
+//                      out = max_p relu(y1[p])
+// Backward: the gradient of out[n] flows to the first point p*[n] that attains the maximum (if it
+// is positive), dm0 to the first point q*[c] attaining m0[c].  One wave per pillar like the forward
+// kernel; lane n owns rows n and n+64 of dW1, lane c < 32 row c of dW0, accumulated in registers
+// over all pillars of the wave and written once to a per-wave slab; a second kernel adds the slabs
+// in wave order (deterministic).  The 128 -> 32 contraction dh0[c] = sum_n dy1[n] W1a[n][c] is a
+// 5-step butterfly reduce-scatter (31 shuffles) instead of 32 full wave reductions.
+__device__ __forceinline__ float rs32(float (&v)[32], int lane) {
+  // reduce-scatter of 32 per-lane values over the 64 lanes: lane l returns sum_lanes v[l & 31]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const bool up = lane & 16;
+    const float keep = up ? v[i + 16] : v[i], send = up ? v[i] : v[i + 16];
+    v[i] = keep + __shfl_xor(send, 16, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bool up = lane & 8;
+    const float keep = up ? v[i + 8] : v[i], send = up ? v[i] : v[i + 8];
+    v[i] = keep + __shfl_xor(send, 8, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool up = lane & 4;
+    const float keep = up ? v[i + 4] : v[i], send = up ? v[i] : v[i + 4];
+    v[i] = keep + __shfl_xor(send, 4, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const bool up = lane & 2;
+    const float keep = up ? v[i + 2] : v[i], send = up ? v[i] : v[i + 2];
+    v[i] = keep + __shfl_xor(send, 2, 64);
+  }
+  {
+    const bool up = lane & 1;
+    const float keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+    v[0] = keep + __shfl_xor(send, 1, 64);
+  }
+  return v[0] + __shfl_xor(v[0], 32, 64);
+}
+
+constexpr int kPfnBwdSlab = 128 * 64 + 32 * 16;  // floats per wave: dW1 (128, 64) then dW0 (32, 16)
+
+__global__ __launch_bounds__(256) void dynamic_pfn_32_128_bwd_kernel(PfnArgs a, const float* __restrict__ cs_table,
+                                                                     const float* __restrict__ dfeat, const float* __restrict__ dcanvas,
+                                                                     float* __restrict__ slabs) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int V = min(*a.v_dev, a.v_cap);
+  float w0[16], w1a[64], w1b[64];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) w0[k] = lane < 32 ? a.w0[lane * 16 + k] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    w1a[k] = a.w1[lane * 64 + k];
+    w1b[k] = a.w1[(lane + 64) * 64 + k];
+  }
+  float dwa[64], dwb[64], dw0[16];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) dwa[k] = dwb[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) dw0[k] = 0.f;
+
+  for (int v = wave; v < V; v += nwaves) {
+    const int s = a.vstart[v], e = a.vstart[v + 1];
+    uint32_t key = a.ukeys[v];
+    const int ri = key % a.R; key /= a.R;
+    const int ti = key % a.T; key /= a.T;
+    const int bi = key / a.Z;
+    long long sx = 0, sy = 0, sz = 0, sr = 0, sp = 0;
+    for (int i = s + lane; i < e; i += 64) {
+      const float* p = a.pts + (size_t)a.order[i] * a.stride;
+      sr += to_fix(p[0]); sp += to_fix(p[1]); sz += to_fix(p[2]); sx += to_fix(p[3]); sy += to_fix(p[4]);
+    }
+    const double inv_n = 1.0 / ((double)(e - s) * kFix);
+    const float mx = (float)((double)pn::wave_sum(sx) * inv_n), my = (float)((double)pn::wave_sum(sy) * inv_n);
+    const float mz = (float)((double)pn::wave_sum(sz) * inv_n), mr = (float)((double)pn::wave_sum(sr) * inv_n);
+    const float mp = (float)((double)pn::wave_sum(sp) * inv_n);
+    const float rc = __fadd_rn(__fmul_rn((float)ri, a.vx), a.xoff);
+    const float pc = __fadd_rn(__fmul_rn((float)ti, a.vy), a.yoff);
+    const float xc = __fmul_rn(rc, cs_table[2 * ti]), yc = __fmul_rn(rc, cs_table[2 * ti + 1]);
+    float d[16];
+    auto decorate = [&](const float* p) {
+      const float rho = p[0], phi = p[1], z = p[2], x = p[3], y = p[4];
+      const float t[16] = {rho, phi, z, x, y, p[5], p[6], x - mx, y - my, z - mz, x - xc, y - yc, rho - mr, phi - mp, rho - rc, phi - pc};
+#pragma unroll
+      for (int k = 0; k < 16; ++k) d[k] = t[k];
+    };
+    auto layer0 = [&]() -> float {
+      float h = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) h = fmaf(w0[k], d[k], h);
+      return h > 0.f ? h : 0.f;
+    };
+    // pass A: layer-0 maxima and the point that attains them
+    float m0 = 0.f;
+    int q0 = -1;
+    for (int i = s; i < e; ++i) {
+      decorate(a.pts + (size_t)a.order[i] * a.stride);
+      const float h = layer0();
+      if (h > m0) { m0 = h; q0 = i; }
+    }
+    float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const float m = lane_bcast(m0, c);
+      g0 = fmaf(w1a[32 + c], m, g0);
+      g1 = fmaf(w1b[32 + c], m, g1);
+    }
+    // pass B: layer-1 maxima and their points
+    float f0 = 0.f, f1 = 0.f;
+    int pa = -1, pb = -1;
+    for (int i = s; i < e; ++i) {
+      decorate(a.pts + (size_t)a.order[i] * a.stride);
+      const float h = layer0();
+      float y0 = g0, y1 = g1;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        const float hc = lane_bcast(h, c);
+        y0 = fmaf(w1a[c], hc, y0);
+        y1 = fmaf(w1b[c], hc, y1);
+      }
+      if (y0 > f0) { f0 = y0; pa = i; }
+      if (y1 > f1) { f1 = y1; pb = i; }
+    }
+    // incoming gradient of this pillar's 128 features (zero where the ReLU output is zero)
+    const float* dsrc = dcanvas ? dcanvas + (((size_t)bi * a.T + ti) * a.R + ri) * 128 : dfeat + (size_t)v * 128;
+    const float da = pa >= 0 ? dsrc[lane] : 0.f, db = pb >= 0 ? dsrc[lane + 64] : 0.f;
+    // voxel-constant half: dW1[:, 32 + c] += dy1 * m0[c];  dm0[c] = sum_n dy1[n] W1[n][32 + c]
+    float u[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const float m = lane_bcast(m0, c);
+      dwa[32 + c] = fmaf(da, m, dwa[32 + c]);
+      dwb[32 + c] = fmaf(db, m, dwb[32 + c]);
+      u[c] = da * w1a[32 + c] + db * w1b[32 + c];
+    }
+    const float dm0 = rs32(u, lane);  // lane c (and c + 32): dm0[c]
+    // pass C: per point, the per-point half of dW1 and dW0
+    for (int i = s; i < e; ++i) {
+      // points that receive no gradient at all (no layer-1 argmax, no layer-0 argmax) are skipped
+      const bool hit = (pa == i) || (pb == i) || (q0 == i && lane < 32);
+      if (__ballot(hit) == 0ull) continue;
+      decorate(a.pts + (size_t)a.order[i] * a.stride);
+      const float h = layer0();
+      const float ea = pa == i ? da : 0.f, eb = pb == i ? db : 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        const float hc = lane_bcast(h, c);
+        dwa[c] = fmaf(ea, hc, dwa[c]);
+        dwb[c] = fmaf(eb, hc, dwb[c]);
+        u[c] = ea * w1a[c] + eb * w1b[c];
+      }
+      float dh = rs32(u, lane);                 // lane c: dh0[i][c]
+      if (q0 == i) dh += dm0;
+      const float dy0 = (lane < 32 && h > 0.f) ? dh : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dw0[k] = fmaf(dy0, d[k], dw0[k]);
+    }
+  }
+  float* slab = slabs + (size_t)wave * kPfnBwdSlab;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    slab[lane * 64 + k] = dwa[k];
+    slab[(lane + 64) * 64 + k] = dwb[k];
+  }
+  if (lane < 32) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) slab[128 * 64 + lane * 16 + k] = dw0[k];
+  }
+}
+
+__global__ void pfn_bwd_reduce_kernel(const float* __restrict__ slabs, int nwaves, float* __restrict__ dw0, float* __restrict__ dw1, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kPfnBwdSlab) return;
+  float t = 0.f;
+  for (int w = 0; w < nwaves; ++w) t += slabs[(size_t)w * kPfnBwdSlab + i];
+  float* dst = i < 128 * 64 ? dw1 + i : dw0 + (i - 128 * 64);
+  *dst = accumulate ? *dst + t : t;
+}
+
 // cos / sin of every pillar-centre azimuth of the grid: table[2*t] = cos(t*vy + yoff), [2*t+1] = sin(...)
 __global__ void center_table_kernel(int T, float vy, float yoff, float* __restrict__ table) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -496,6 +680,28 @@ int pn_scatter_canvas_fwd(const float* features, const int64_t* unq, const int32
   hipLaunchKernelGGL(scatter_canvas_kernel, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0,
                      pn::S(stream), features, unq, num_voxels, v_capacity, c, t, r, canvas);
   return pn::check_launch("scatter_canvas_kernel");
+}
+
+constexpr int kPfnBwdBlocks = 256;  // 1024 waves, one per SIMD
+
+size_t pn_dynamic_pfn_bwd_workspace_bytes(void) { return (size_t)kPfnBwdBlocks * 4 * kPfnBwdSlab * sizeof(float); }
+
+int pn_dynamic_pfn_bwd(const float* points, int point_stride, const int32_t* voxel_start, const int32_t* order,
+                       const int32_t* num_voxels, int v_capacity, const uint32_t* unq_keys, const int32_t* grid, const float* w0,
+                       int c0, const float* w1, int c1, float vx, float vy, float x_offset, float y_offset, const float* center_table,
+                       const float* d_features, const float* d_canvas, float* dw0, float* dw1, int accumulate, void* workspace,
+                       size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(points && voxel_start && order && num_voxels && unq_keys && grid && w0 && w1 && center_table && dw0 && dw1 && workspace,
+             "dynamic_pfn_bwd: null pointer");
+  PN_REQUIRE(c0 == 32 && c1 == 128, "dynamic_pfn_bwd: only the (32, 128) reader of the nuScenes config is built");
+  PN_REQUIRE(point_stride >= 7 && ((d_features != nullptr) != (d_canvas != nullptr)), "dynamic_pfn_bwd: give exactly one of d_features / d_canvas");
+  PN_REQUIRE(workspace_bytes >= pn_dynamic_pfn_bwd_workspace_bytes(), "dynamic_pfn_bwd: workspace too small");
+  PfnArgs a{points, point_stride, voxel_start, order, num_voxels, v_capacity, unq_keys, grid[0], grid[1], grid[2],
+            w0, c0, w1, c1, vx, vy, x_offset, y_offset, nullptr, nullptr};
+  float* slabs = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(dynamic_pfn_32_128_bwd_kernel, dim3(kPfnBwdBlocks), dim3(256), 0, pn::S(stream), a, center_table, d_features, d_canvas, slabs);
+  hipLaunchKernelGGL(pfn_bwd_reduce_kernel, dim3(pn::cdiv(kPfnBwdSlab, 256)), dim3(256), 0, pn::S(stream), slabs, kPfnBwdBlocks * 4, dw0, dw1, accumulate);
+  return pn::check_launch("dynamic_pfn_bwd");
 }
 
 }  // extern "C"

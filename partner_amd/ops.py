@@ -701,3 +701,27 @@ def center_loss_bwd(hm: torch.Tensor, ncls: int, boxes, tg: CenterLossTargets, c
     hip.call("pn_center_loss_bwd", *args, float(weight), fwd_out.data_ptr(), float(grad_scale), d_hm.data_ptr(), d_hm.shape[3],
              (C.c_void_p * n)(*[t.data_ptr() for t in d_boxes]), (C.c_int * n)(*[t.shape[3] for t in d_boxes]), hip.stream())
     return d_hm, d_boxes
+
+
+def dynamic_pfn_bwd(points: torch.Tensor, vi: VoxelIndex, w0: torch.Tensor, w1: torch.Tensor, vx: float, vy: float,
+                    x_offset: float, y_offset: float, d_features: Optional[torch.Tensor] = None,
+                    d_canvas: Optional[torch.Tensor] = None, dw0: Optional[torch.Tensor] = None,
+                    dw1: Optional[torch.Tensor] = None, accumulate=False, center_table: Optional[torch.Tensor] = None):
+    """weight gradients of the (32,128) DynamicPFNet given d_features (V,128) or the canvas gradient (B,T,R,128)"""
+    hip.require_device(points, w0, w1)
+    lib = hip.load()
+    dev = points.device
+    if center_table is None:
+        center_table = pfn_center_table(vi.spec.grid[1], vy, y_offset, dev)
+    if dw0 is None:
+        dw0 = torch.empty_like(w0)
+    if dw1 is None:
+        dw1 = torch.empty_like(w1)
+    _, _, g = vi.spec.c_arrays()
+    nbytes = lib.pn_dynamic_pfn_bwd_workspace_bytes()
+    ws = _workspace(nbytes, dev)
+    hip.call("pn_dynamic_pfn_bwd", points.data_ptr(), points.shape[1], vi.voxel_start.data_ptr(), vi.order.data_ptr(),
+             vi.num_voxels.data_ptr(), vi.n_cap, vi.unq_keys_ptr, g, w0.data_ptr(), w0.shape[0], w1.data_ptr(), w1.shape[0],
+             float(vx), float(vy), float(x_offset), float(y_offset), center_table.data_ptr(), hip.ptr(d_features), hip.ptr(d_canvas),
+             dw0.data_ptr(), dw1.data_ptr(), int(accumulate), ws.data_ptr(), nbytes, hip.stream())
+    return dw0, dw1
