@@ -229,6 +229,8 @@ typedef struct pn_conv_desc {
                            the map border).  groups must be 1.  0/1: ordinary convolution. */
   int32_t pad_h_end, pad_w_end; /* extra zero rows / columns after the map, on top of pad_h / pad_w
                                    (asymmetric nn.ZeroPad2d); 0 = symmetric padding */
+  int32_t accumulate;           /* 1: out += result (after scale/shift/act); used to sum the data
+                                   gradients of branches that share an input */
 } pn_conv_desc;
 
 size_t pn_conv_packed_weight_floats(int cout, int cin, int kh, int kw, int groups);
@@ -430,6 +432,30 @@ int pn_center_loss_bwd(const float *hm_logits, int hm_pixel_stride, const float 
                        int box_dims, const float *code_weights, float weight, const float *fwd_out,
                        float grad_scale, float *d_hm, int d_hm_pixel_stride, float *const *d_box_ptrs,
                        const int *d_box_pixel_strides, pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * T1  optimizer side of the training step, over the FLAT fp32 parameter / gradient buffers.
+ * pn_grad_norm_f32: total L2 norm of the gradients into a device scalar (clip_grad_norm_,
+ *   det3d/torchie/trainer/hooks/optimizer.py:10-13); deterministic fp64 two-stage sum.
+ * pn_adam_step_f32: g *= min(1, max_norm/(total_norm+1e-6)) (skipped if total_norm == NULL);
+ *   p *= 1 - weight_decay*lr (OptimWrapper.step, fastai_optim.py:155-171);  torch.optim.Adam update
+ *   with betas (beta1, beta2), bias correction for the 1-based `step`.  lr and beta1 are the
+ *   OneCycle values of this step (learning_schedules_fastai.py:77-95), computed by the host.
+ */
+size_t pn_grad_norm_workspace_bytes(void);
+int pn_grad_norm_f32(const float *grads, size_t n, float *total_norm, void *workspace,
+                     size_t workspace_bytes, pn_stream_t stream);
+int pn_adam_step_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, size_t n,
+                     int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     const float *total_norm, float max_norm, pn_stream_t stream);
+/* element-wise helpers of the backward pass: dx = dy*(1-y^2);  out = a+b;  RangeStratified
+ * gradient (B,H,W,c) -> (B,H,W,strata*c) with the stratum's block filled and zeros elsewhere, so
+ * that its weight / data gradients are those of an ordinary convolution with strata*c outputs
+ * (center_head_parallel.py:45-59). */
+int pn_tanh_bwd_f32(const float *y, const float *dy, float *dx, size_t n, pn_stream_t stream);
+int pn_add_f32(const float *a, const float *b, float *out, size_t n, pn_stream_t stream);
+int pn_strat_expand_f32(const float *dy, int batch, int h, int w, int c, int strata, float *out,
+                        pn_stream_t stream);
 
 /* layout helpers at the API boundary */
 int pn_nchw_to_nhwc_f32(const float *in, int b, int c, int h, int w, float *out, pn_stream_t stream);

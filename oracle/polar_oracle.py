@@ -569,3 +569,43 @@ def pointpillars_forward(sd: SD, cfg: dict, points: np.ndarray, grid_ind: np.nda
     if return_stages:
         return preds, dict(features=feats, unq=unq, inv=inv, canvas=x1, blocks=blocks, ups=ups, x2=x2, pos=pos)
     return preds
+
+
+# ======================================================================================
+# T1  optimizer step of the training loop
+#     OneCycle / annealing_cos            det3d/solver/learning_schedules_fastai.py:52-95
+#     OptimWrapper.step (decoupled wd)    det3d/solver/fastai_optim.py:155-171
+#     Adam(betas=(mom, 0.99))             det3d/torchie/apis/train.py:198-215 (torch.optim.Adam)
+#     clip_grad_norm_(35, 2)              det3d/torchie/trainer/hooks/optimizer.py:10-13
+# ======================================================================================
+def one_cycle(step: int, total_step: int, lr_max: float, moms, div_factor: float, pct_start: float):
+    """-> (lr, mom) the scheduler sets before optimizer step ``step`` (0-based)."""
+    a1 = int(total_step * pct_start)
+    low = lr_max / div_factor
+
+    def cos(start, end, pct):
+        return end + (start - end) / 2 * (np.cos(np.pi * pct) + 1)
+
+    if step >= a1:  # the last phase whose start has been reached wins
+        pct = (step - a1) / (total_step - a1)
+        return cos(lr_max, low / 1e4, pct), cos(moms[1], moms[0], pct)
+    pct = step / a1
+    return cos(low, lr_max, pct), cos(moms[0], moms[1], pct)
+
+
+def grad_clip_coef(total_norm: float, max_norm: float) -> float:
+    """torch.nn.utils.clip_grad_norm_: grads *= min(1, max_norm / (total_norm + 1e-6))"""
+    return min(1.0, max_norm / (total_norm + 1e-6))
+
+
+def adam_decoupled_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, t: int, lr: float, beta1: float, beta2=0.99, eps=1e-8,
+                        wd=0.01) -> None:
+    """in place, fp32: p *= 1 - wd*lr (OptimWrapper.step), then torch.optim.Adam's single-tensor update
+    with weight_decay 0; ``t`` is the 1-based step count of this parameter."""
+    p.mul_(1 - wd * lr)
+    m.lerp_(g, 1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** t
+    bc2 = 1 - beta2 ** t
+    denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))

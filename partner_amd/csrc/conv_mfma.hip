@@ -367,12 +367,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
       for (int j = 0; j < TN; ++j) {
         if (col_off[j] < 0) continue;
         float* dst = orow + col_off[j];
+        size_t rpix = pix;
         if (a.mode == MODE_DECONV2) {
-          const size_t opix = ((size_t)b * (2 * a.OH) + 2 * oh + (col_d[j] >> 1)) * (2 * a.OW) + 2 * ow + (col_d[j] & 1);
-          dst = a.out + opix * a.out_ps + col_off[j];
+          rpix = ((size_t)b * (2 * a.OH) + 2 * oh + (col_d[j] >> 1)) * (2 * a.OW) + 2 * ow + (col_d[j] & 1);
+          dst = a.out + rpix * a.out_ps + col_off[j];
         }
         float o = pn::apply_act(fmaf(acc[i][j][r], sc[j], sh[j]), a.act);
-        if (a.res) o += a.res[pix * a.res_ps + col_off[j]];
+        if (a.res) o += a.res[rpix * a.res_ps + col_off[j]];
         *dst = o;
       }
     }
@@ -589,6 +590,9 @@ int pn_conv2d_nhwc_f32(const pn_conv_desc* d, const float* in, const float* pack
              "(use pn_conv2d_direct_nhwc_f32)");
   PN_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "conv: pointers must be 16-byte aligned");
   a.in = in; a.w = packed_w; a.scale = scale; a.shift = shift; a.out = out;
+  if (d->accumulate) {  // out += result: the residual input of the epilogue is the output itself
+    a.res = out; a.res_ps = d->out_pixel_stride;
+  }
   hipStream_t st = pn::S(stream);
   return dispatch_conv(a, zdim, st);
 }

@@ -398,60 +398,48 @@ __global__ __launch_bounds__(kHeavyWaves * 64) void dynamic_pfn_32_128_heavy_ker
 // over all pillars of the wave and written once to a per-wave slab; a second kernel adds the slabs
 // in wave order (deterministic).  The 128 -> 32 contraction dh0[c] = sum_n dy1[n] W1a[n][c] is a
 // 5-step butterfly reduce-scatter (31 shuffles) instead of 32 full wave reductions.
-__device__ __forceinline__ float rs32(float (&v)[32], int lane) {
-  // reduce-scatter of 32 per-lane values over the 64 lanes: lane l returns sum_lanes v[l & 31]
+template <int N>
+__device__ __forceinline__ float reduce_scatter(float (&v)[N], int lane) {
+  // reduce-scatter of N (16 or 32) per-lane values over the 64 lanes: lane l returns sum_lanes v[l & (N-1)]
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const bool up = lane & 16;
-    const float keep = up ? v[i + 16] : v[i], send = up ? v[i] : v[i + 16];
-    v[i] = keep + __shfl_xor(send, 16, 64);
-  }
+  for (int h = N / 2; h >= 1; h >>= 1) {
+    const bool up = lane & h;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const bool up = lane & 8;
-    const float keep = up ? v[i + 8] : v[i], send = up ? v[i] : v[i + 8];
-    v[i] = keep + __shfl_xor(send, 8, 64);
+    for (int i = 0; i < h; ++i) {
+      const float keep = up ? v[i + h] : v[i], send = up ? v[i] : v[i + h];
+      v[i] = keep + __shfl_xor(send, h, 64);
+    }
   }
+  float r = v[0];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bool up = lane & 4;
-    const float keep = up ? v[i + 4] : v[i], send = up ? v[i] : v[i + 4];
-    v[i] = keep + __shfl_xor(send, 4, 64);
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const bool up = lane & 2;
-    const float keep = up ? v[i + 2] : v[i], send = up ? v[i] : v[i + 2];
-    v[i] = keep + __shfl_xor(send, 2, 64);
-  }
-  {
-    const bool up = lane & 1;
-    const float keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
-    v[0] = keep + __shfl_xor(send, 1, 64);
-  }
-  return v[0] + __shfl_xor(v[0], 32, 64);
+  for (int m = N; m < 64; m <<= 1) r += __shfl_xor(r, m, 64);
+  return r;
 }
 
-constexpr int kPfnBwdSlab = 128 * 64 + 32 * 16;  // floats per wave: dW1 (128, 64) then dW0 (32, 16)
-
-__global__ __launch_bounds__(256) void dynamic_pfn_32_128_bwd_kernel(PfnArgs a, const float* __restrict__ cs_table,
-                                                                     const float* __restrict__ dfeat, const float* __restrict__ dcanvas,
-                                                                     float* __restrict__ slabs) {
+// floats per wave slab: dW1 (C1, 2*C0) then dW0 (C0, 16)
+template <int C0, int C1>
+__global__ __launch_bounds__(256) void dynamic_pfn_bwd_kernel(PfnArgs a, const float* __restrict__ cs_table,
+                                                              const float* __restrict__ dfeat, const float* __restrict__ dcanvas,
+                                                              float* __restrict__ slabs) {
+  constexpr bool TWO = C1 > 64;          // second output row per lane
+  constexpr int K1 = 2 * C0;             // row length of W1
+  constexpr int SLAB = C1 * K1 + C0 * 16;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int V = min(*a.v_dev, a.v_cap);
-  float w0[16], w1a[64], w1b[64];
+  const bool la = lane < C1, lb = TWO && lane + 64 < C1;
+  float w0[16], w1a[K1], w1b[TWO ? K1 : 1];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) w0[k] = lane < 32 ? a.w0[lane * 16 + k] : 0.f;
+  for (int k = 0; k < 16; ++k) w0[k] = lane < C0 ? a.w0[lane * 16 + k] : 0.f;
 #pragma unroll
-  for (int k = 0; k < 64; ++k) {
-    w1a[k] = a.w1[lane * 64 + k];
-    w1b[k] = a.w1[(lane + 64) * 64 + k];
+  for (int k = 0; k < K1; ++k) {
+    w1a[k] = la ? a.w1[lane * K1 + k] : 0.f;
+    if (TWO) w1b[k] = lb ? a.w1[(lane + 64) * K1 + k] : 0.f;
   }
-  float dwa[64], dwb[64], dw0[16];
+  float dwa[K1], dwb[TWO ? K1 : 1], dw0[16];
 #pragma unroll
-  for (int k = 0; k < 64; ++k) dwa[k] = dwb[k] = 0.f;
+  for (int k = 0; k < K1; ++k) { dwa[k] = 0.f; if (TWO) dwb[k] = 0.f; }
 #pragma unroll
   for (int k = 0; k < 16; ++k) dw0[k] = 0.f;
 
@@ -496,10 +484,10 @@ __global__ __launch_bounds__(256) void dynamic_pfn_32_128_bwd_kernel(PfnArgs a, 
     }
     float g0 = 0.f, g1 = 0.f;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
+    for (int c = 0; c < C0; ++c) {
       const float m = lane_bcast(m0, c);
-      g0 = fmaf(w1a[32 + c], m, g0);
-      g1 = fmaf(w1b[32 + c], m, g1);
+      g0 = fmaf(w1a[C0 + c], m, g0);
+      if (TWO) g1 = fmaf(w1b[C0 + c], m, g1);
     }
     // pass B: layer-1 maxima and their points
     float f0 = 0.f, f1 = 0.f;
@@ -509,67 +497,72 @@ __global__ __launch_bounds__(256) void dynamic_pfn_32_128_bwd_kernel(PfnArgs a, 
       const float h = layer0();
       float y0 = g0, y1 = g1;
 #pragma unroll
-      for (int c = 0; c < 32; ++c) {
+      for (int c = 0; c < C0; ++c) {
         const float hc = lane_bcast(h, c);
         y0 = fmaf(w1a[c], hc, y0);
-        y1 = fmaf(w1b[c], hc, y1);
+        if (TWO) y1 = fmaf(w1b[c], hc, y1);
       }
       if (y0 > f0) { f0 = y0; pa = i; }
-      if (y1 > f1) { f1 = y1; pb = i; }
+      if (TWO && y1 > f1) { f1 = y1; pb = i; }
     }
-    // incoming gradient of this pillar's 128 features (zero where the ReLU output is zero)
-    const float* dsrc = dcanvas ? dcanvas + (((size_t)bi * a.T + ti) * a.R + ri) * 128 : dfeat + (size_t)v * 128;
-    const float da = pa >= 0 ? dsrc[lane] : 0.f, db = pb >= 0 ? dsrc[lane + 64] : 0.f;
-    // voxel-constant half: dW1[:, 32 + c] += dy1 * m0[c];  dm0[c] = sum_n dy1[n] W1[n][32 + c]
-    float u[32];
+    // incoming gradient of this pillar's C1 features (zero where the ReLU output is zero)
+    const float* dsrc = dcanvas ? dcanvas + (((size_t)bi * a.T + ti) * a.R + ri) * C1 : dfeat + (size_t)v * C1;
+    const float da = (la && pa >= 0) ? dsrc[lane] : 0.f;
+    const float db = (lb && pb >= 0) ? dsrc[lane + 64] : 0.f;
+    // voxel-constant half: dW1[:, C0 + c] += dy1 * m0[c];  dm0[c] = sum_n dy1[n] W1[n][C0 + c]
+    float u[C0];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
+    for (int c = 0; c < C0; ++c) {
       const float m = lane_bcast(m0, c);
-      dwa[32 + c] = fmaf(da, m, dwa[32 + c]);
-      dwb[32 + c] = fmaf(db, m, dwb[32 + c]);
-      u[c] = da * w1a[32 + c] + db * w1b[32 + c];
+      dwa[C0 + c] = fmaf(da, m, dwa[C0 + c]);
+      u[c] = da * w1a[C0 + c];
+      if (TWO) { dwb[C0 + c] = fmaf(db, m, dwb[C0 + c]); u[c] += db * w1b[C0 + c]; }
     }
-    const float dm0 = rs32(u, lane);  // lane c (and c + 32): dm0[c]
+    const float dm0 = reduce_scatter<C0>(u, lane);  // lane l: dm0[l & (C0-1)]
     // pass C: per point, the per-point half of dW1 and dW0
     for (int i = s; i < e; ++i) {
       // points that receive no gradient at all (no layer-1 argmax, no layer-0 argmax) are skipped
-      const bool hit = (pa == i) || (pb == i) || (q0 == i && lane < 32);
+      const bool hit = (pa == i) || (pb == i) || (q0 == i);
       if (__ballot(hit) == 0ull) continue;
       decorate(a.pts + (size_t)a.order[i] * a.stride);
       const float h = layer0();
       const float ea = pa == i ? da : 0.f, eb = pb == i ? db : 0.f;
 #pragma unroll
-      for (int c = 0; c < 32; ++c) {
+      for (int c = 0; c < C0; ++c) {
         const float hc = lane_bcast(h, c);
         dwa[c] = fmaf(ea, hc, dwa[c]);
-        dwb[c] = fmaf(eb, hc, dwb[c]);
-        u[c] = ea * w1a[c] + eb * w1b[c];
+        u[c] = ea * w1a[c];
+        if (TWO) { dwb[c] = fmaf(eb, hc, dwb[c]); u[c] += eb * w1b[c]; }
       }
-      float dh = rs32(u, lane);                 // lane c: dh0[i][c]
+      float dh = reduce_scatter<C0>(u, lane);   // lane c: dh0[i][c]
       if (q0 == i) dh += dm0;
-      const float dy0 = (lane < 32 && h > 0.f) ? dh : 0.f;
+      const float dy0 = (lane < C0 && h > 0.f) ? dh : 0.f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) dw0[k] = fmaf(dy0, d[k], dw0[k]);
     }
   }
-  float* slab = slabs + (size_t)wave * kPfnBwdSlab;
+  float* slab = slabs + (size_t)wave * SLAB;
+  if (la) {
 #pragma unroll
-  for (int k = 0; k < 64; ++k) {
-    slab[lane * 64 + k] = dwa[k];
-    slab[(lane + 64) * 64 + k] = dwb[k];
+    for (int k = 0; k < K1; ++k) slab[lane * K1 + k] = dwa[k];
   }
-  if (lane < 32) {
+  if (lb) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) slab[128 * 64 + lane * 16 + k] = dw0[k];
+    for (int k = 0; k < K1; ++k) slab[(lane + 64) * K1 + k] = dwb[k];
+  }
+  if (lane < C0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) slab[C1 * K1 + lane * 16 + k] = dw0[k];
   }
 }
 
-__global__ void pfn_bwd_reduce_kernel(const float* __restrict__ slabs, int nwaves, float* __restrict__ dw0, float* __restrict__ dw1, int accumulate) {
+__global__ void pfn_bwd_reduce_kernel(const float* __restrict__ slabs, int nwaves, int slab, int w1_floats, float* __restrict__ dw0,
+                                      float* __restrict__ dw1, int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= kPfnBwdSlab) return;
+  if (i >= slab) return;
   float t = 0.f;
-  for (int w = 0; w < nwaves; ++w) t += slabs[(size_t)w * kPfnBwdSlab + i];
-  float* dst = i < 128 * 64 ? dw1 + i : dw0 + (i - 128 * 64);
+  for (int w = 0; w < nwaves; ++w) t += slabs[(size_t)w * slab + i];
+  float* dst = i < w1_floats ? dw1 + i : dw0 + (i - w1_floats);
   *dst = accumulate ? *dst + t : t;
 }
 
@@ -683,8 +676,9 @@ int pn_scatter_canvas_fwd(const float* features, const int64_t* unq, const int32
 }
 
 constexpr int kPfnBwdBlocks = 256;  // 1024 waves, one per SIMD
+constexpr int kPfnBwdSlabMax = 128 * 64 + 32 * 16;
 
-size_t pn_dynamic_pfn_bwd_workspace_bytes(void) { return (size_t)kPfnBwdBlocks * 4 * kPfnBwdSlab * sizeof(float); }
+size_t pn_dynamic_pfn_bwd_workspace_bytes(void) { return (size_t)kPfnBwdBlocks * 4 * kPfnBwdSlabMax * sizeof(float); }
 
 int pn_dynamic_pfn_bwd(const float* points, int point_stride, const int32_t* voxel_start, const int32_t* order,
                        const int32_t* num_voxels, int v_capacity, const uint32_t* unq_keys, const int32_t* grid, const float* w0,
@@ -693,14 +687,20 @@ int pn_dynamic_pfn_bwd(const float* points, int point_stride, const int32_t* vox
                        size_t workspace_bytes, pn_stream_t stream) {
   PN_REQUIRE(points && voxel_start && order && num_voxels && unq_keys && grid && w0 && w1 && center_table && dw0 && dw1 && workspace,
              "dynamic_pfn_bwd: null pointer");
-  PN_REQUIRE(c0 == 32 && c1 == 128, "dynamic_pfn_bwd: only the (32, 128) reader of the nuScenes config is built");
+  PN_REQUIRE((c0 == 32 && c1 == 128) || (c0 == 16 && c1 == 32),
+             "dynamic_pfn_bwd: built for (C0, C1) = (32, 128) (nuScenes reader) and (16, 32) (reduced test model)");
   PN_REQUIRE(point_stride >= 7 && ((d_features != nullptr) != (d_canvas != nullptr)), "dynamic_pfn_bwd: give exactly one of d_features / d_canvas");
   PN_REQUIRE(workspace_bytes >= pn_dynamic_pfn_bwd_workspace_bytes(), "dynamic_pfn_bwd: workspace too small");
   PfnArgs a{points, point_stride, voxel_start, order, num_voxels, v_capacity, unq_keys, grid[0], grid[1], grid[2],
             w0, c0, w1, c1, vx, vy, x_offset, y_offset, nullptr, nullptr};
   float* slabs = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(dynamic_pfn_32_128_bwd_kernel, dim3(kPfnBwdBlocks), dim3(256), 0, pn::S(stream), a, center_table, d_features, d_canvas, slabs);
-  hipLaunchKernelGGL(pfn_bwd_reduce_kernel, dim3(pn::cdiv(kPfnBwdSlab, 256)), dim3(256), 0, pn::S(stream), slabs, kPfnBwdBlocks * 4, dw0, dw1, accumulate);
+  const int slab = c1 * 2 * c0 + c0 * 16;
+  if (c0 == 32)
+    hipLaunchKernelGGL((dynamic_pfn_bwd_kernel<32, 128>), dim3(kPfnBwdBlocks), dim3(256), 0, pn::S(stream), a, center_table, d_features, d_canvas, slabs);
+  else
+    hipLaunchKernelGGL((dynamic_pfn_bwd_kernel<16, 32>), dim3(kPfnBwdBlocks), dim3(256), 0, pn::S(stream), a, center_table, d_features, d_canvas, slabs);
+  hipLaunchKernelGGL(pfn_bwd_reduce_kernel, dim3(pn::cdiv(slab, 256)), dim3(256), 0, pn::S(stream), slabs, kPfnBwdBlocks * 4, slab,
+                     c1 * 2 * c0, dw0, dw1, accumulate);
   return pn::check_launch("dynamic_pfn_bwd");
 }
 

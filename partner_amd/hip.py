@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "batch", "in_h", "in_w", "cin", "cout", "groups", "kh", "kw", "stride", "pad_h", "pad_w",
         "in_pixel_stride", "in_channel_offset", "out_pixel_stride", "out_channel_offset", "act", "deconv2x2",
-        "range_strata", "pad_h_end", "pad_w_end")]
+        "range_strata", "pad_h_end", "pad_w_end", "accumulate")]
 
 
 _P = C.c_void_p
@@ -91,6 +91,12 @@ SIGNATURES = {
     "pn_setblock_sector_col_attn": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "pn_nchw_to_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "pn_nhwc_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "pn_grad_norm_workspace_bytes": (_SZ, []),
+    "pn_grad_norm_f32": (_I, [_P, _SZ, _P, _P, _SZ, _P]),
+    "pn_adam_step_f32": (_I, [_P, _P, _P, _P, _SZ, _I, _F, _F, _F, _F, _F, _P, _F, _P]),
+    "pn_tanh_bwd_f32": (_I, [_P, _P, _P, _SZ, _P]),
+    "pn_add_f32": (_I, [_P, _P, _P, _SZ, _P]),
+    "pn_strat_expand_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "pn_center_loss_workspace_bytes": (_SZ, []),
     "pn_center_loss_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _F, _P, _P, _SZ, _P]),
     "pn_center_loss_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _F, _P, _F, _P, _I, _P, _P, _P]),

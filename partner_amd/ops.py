@@ -304,6 +304,28 @@ class ConvLayer:
         self.scale = None if scale is None else scale.detach().contiguous().float()
         self.shift = None if shift is None else shift.detach().contiguous().float()
         self.out_channels = self.cout * (self.groups if not deconv2x2 else 1)
+        self._pack_cin = self.cin
+
+    def repack(self, weight: torch.Tensor, shift: Optional[torch.Tensor] = None) -> None:
+        """refresh the packed copy from an updated weight of the same shape (training: once per step)"""
+        w = weight.detach()
+        assert w.is_contiguous() and w.dtype == torch.float32
+        st = hip.stream()
+        if self.deconv2x2:
+            hip.call("pn_pack_deconv2x2_weight_f32", w.data_ptr(), self._pack_cin, self.cout, self.packed.data_ptr(), st)
+        else:
+            pack_groups = self.range_strata if self.range_strata > 1 else self.groups
+            hip.call("pn_pack_conv_weight_f32", w.data_ptr(), w.shape[0], self._pack_cin, self.kh, self.kw, pack_groups,
+                     self.packed.data_ptr(), st)
+        if shift is not None:
+            self.shift = shift
+
+    def pad_input_channels(self, cin_padded: int) -> "ConvLayer":
+        """declare that the input map carries zero pad channels up to a multiple of 4 (e.g. the 5-channel
+        position encoding stored with 8): the packed rows past the real Cin are already zero"""
+        assert cin_padded >= self.cin and cin_padded % 4 == 0 and (cin_padded + 31) // 32 == (self.cin + 31) // 32
+        self.cin = cin_padded
+        return self
 
     def out_hw(self, h: int, w: int) -> Tuple[int, int]:
         if self.deconv2x2:
@@ -311,7 +333,7 @@ class ConvLayer:
         return ((h + 2 * self.pad[0] - self.kh) // self.stride + 1, (w + 2 * self.pad[1] - self.kw) // self.stride + 1)
 
     def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_channel_offset=0, in_channel_offset=0,
-                 in_channels: Optional[int] = None) -> torch.Tensor:
+                 in_channels: Optional[int] = None, accumulate=False) -> torch.Tensor:
         """x: NHWC (B,H,W,Ct).  Reads channels [in_channel_offset, +cin*groups); writes channels
         [out_channel_offset, +out_channels) of ``out`` (allocated if None)."""
         hip.require_device(x)
@@ -323,7 +345,7 @@ class ConvLayer:
         assert out.shape[:3] == (b, oh, ow) and out.is_contiguous()
         d = ConvDesc(b, h, w, self.cin, self.cout, self.groups, self.kh, self.kw, self.stride, self.pad[0], self.pad[1],
                      ct, in_channel_offset, out.shape[3], out_channel_offset, self.act, int(self.deconv2x2),
-                     self.range_strata)
+                     self.range_strata, 0, 0, int(accumulate))
         st = hip.stream()
         prof = _PROFILER
         if prof is not None:
@@ -544,7 +566,7 @@ class ConvDgrad:
             hip.call("pn_pack_deconv2x2_weight_f32", w.data_ptr(), self.cout, self.cin, self.packed.data_ptr(), st)
 
     def __call__(self, dout: torch.Tensor, out: Optional[torch.Tensor] = None, dout_channel_offset=0,
-                 out_channel_offset=0) -> torch.Tensor:
+                 out_channel_offset=0, accumulate=False) -> torch.Tensor:
         """dout: NHWC (B,OH,OW,Ct) -> dx (B,H,W,Cin); H = OH*stride (the reference's maps are even-sized)"""
         hip.require_device(dout)
         assert dout.dim() == 4 and dout.is_contiguous()
@@ -569,6 +591,7 @@ class ConvDgrad:
             out = torch.empty((b, h, w, self.cin), dtype=torch.float32, device=dout.device)
         assert out.shape[:3] == (b, h, w) and out.is_contiguous()
         d.out_pixel_stride = out.shape[3]
+        d.accumulate = int(accumulate)
         hip.call("pn_conv2d_nhwc_f32", C.byref(d), dout.data_ptr(), self.packed.data_ptr(), None, None, out.data_ptr(), hip.stream())
         return out
 
@@ -667,8 +690,9 @@ def _loss_common(hm: torch.Tensor, ncls: int, boxes, tg: CenterLossTargets, code
     sel = list(range(ndim)) if with_vel else [0, 1, 2, 3, 4, 5, ad - 2, ad - 1]
     cw = torch.tensor(list(code_weights)[:ndim], dtype=torch.float32, device=hm.device)
     n = len(boxes)
-    args = (hm.data_ptr(), hm.shape[3], tg.hm.data_ptr(), b, ncls, h, w, (C.c_void_p * n)(*[t.data_ptr() for t, _ in boxes]),
-            (C.c_int * n)(*[t.shape[3] for t, _ in boxes]), (C.c_int * n)(*[c for _, c in boxes]), n, tg.ind.data_ptr(),
+    # pixel strides come from the tensors' strides, so channel-slice views of wider NHWC maps work
+    args = (hm.data_ptr(), hm.stride(2), tg.hm.data_ptr(), b, ncls, h, w, (C.c_void_p * n)(*[t.data_ptr() for t, _ in boxes]),
+            (C.c_int * n)(*[t.stride(2) for t, _ in boxes]), (C.c_int * n)(*[c for _, c in boxes]), n, tg.ind.data_ptr(),
             tg.mask.data_ptr(), tg.cat.data_ptr(), tg.anno.data_ptr(), ad, (C.c_int * ndim)(*sel), tg.ind.shape[1], ndim, cw.data_ptr())
     return args, ndim, cw
 
@@ -725,3 +749,54 @@ def dynamic_pfn_bwd(points: torch.Tensor, vi: VoxelIndex, w0: torch.Tensor, w1: 
              float(vx), float(vy), float(x_offset), float(y_offset), center_table.data_ptr(), hip.ptr(d_features), hip.ptr(d_canvas),
              dw0.data_ptr(), dw1.data_ptr(), int(accumulate), ws.data_ptr(), nbytes, hip.stream())
     return dw0, dw1
+
+
+# ------------------------------------------------------------------------------ T1 small kernels
+def grad_norm(flat_grads: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """L2 norm of a flat fp32 buffer -> device scalar (1,)"""
+    hip.require_device(flat_grads)
+    lib = hip.load()
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=flat_grads.device)
+    nbytes = lib.pn_grad_norm_workspace_bytes()
+    ws = _workspace(nbytes, flat_grads.device)
+    hip.call("pn_grad_norm_f32", flat_grads.data_ptr(), flat_grads.numel(), out.data_ptr(), ws.data_ptr(), nbytes, hip.stream())
+    return out
+
+
+def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int, lr: float,
+              beta1: float, beta2=0.99, eps=1e-8, weight_decay=0.01, total_norm: Optional[torch.Tensor] = None, max_norm=35.0) -> None:
+    """fused clip + decoupled weight decay + Adam over flat buffers (in place)"""
+    hip.require_device(params, grads, exp_avg, exp_avg_sq)
+    assert params.numel() == grads.numel() == exp_avg.numel() == exp_avg_sq.numel()
+    hip.call("pn_adam_step_f32", params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), params.numel(), int(step),
+             float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), hip.ptr(total_norm), float(max_norm), hip.stream())
+
+
+def tanh_bwd(y: torch.Tensor, dy: torch.Tensor, dx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    hip.require_device(y, dy)
+    assert y.is_contiguous() and dy.is_contiguous() and y.numel() == dy.numel()
+    if dx is None:
+        dx = torch.empty_like(dy)
+    hip.call("pn_tanh_bwd_f32", y.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.numel(), hip.stream())
+    return dx
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    hip.require_device(a, b)
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    if out is None:
+        out = torch.empty_like(a)
+    hip.call("pn_add_f32", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), hip.stream())
+    return out
+
+
+def strat_expand(dy: torch.Tensor, strata: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(B,H,W,C) -> (B,H,W,strata*C): block of the pixel's range stratum = dy, zeros elsewhere"""
+    hip.require_device(dy)
+    assert dy.is_contiguous()
+    b, h, w, c = dy.shape
+    if out is None:
+        out = torch.empty((b, h, w, strata * c), dtype=torch.float32, device=dy.device)
+    hip.call("pn_strat_expand_f32", dy.data_ptr(), b, h, w, c, strata, out.data_ptr(), hip.stream())
+    return out

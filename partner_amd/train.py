@@ -1,0 +1,478 @@
+"""Training step of the nuScenes polar-pillar model on the HIP kernels.
+
+Host mirror of the reference's training iteration
+  Trainer.train / batch_processor_inline   det3d/torchie/trainer/trainer.py:446-501, 414-444
+  parse_second_losses                      det3d/torchie/trainer/trainer.py:116-137
+  DistOptimizerHook / allreduce_grads      det3d/core/utils/dist_utils.py:51-57, 31-42
+  OptimizerHook.clip_grads                 det3d/torchie/trainer/hooks/optimizer.py:10-13
+  OptimWrapper.step + OneCycle             det3d/solver/fastai_optim.py:155-171,
+                                           det3d/solver/learning_schedules_fastai.py:77-95
+without autograd: forward in training mode (batch-statistics BatchNorm), the CenterPoint loss, an
+explicit backward through every layer of  DynamicPFNet -> DynamicPPScatter -> RPN ->
+CenterHeadSinglePos  and one fused clip + decoupled-weight-decay + Adam update over a flat fp32
+parameter buffer.  All arithmetic runs in kernels of libpartner_hip; PyTorch allocates tensors and
+(for world_size > 1) all-reduces the flat gradient buffer through torch.distributed (RCCL).
+
+The module's parameters are re-bound to views of the flat buffer, so ``state_dict()`` keeps the
+reference's keys and the inference path (after ``PlanCache`` invalidation) sees the trained weights.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import hip, ops
+from .heads import CenterHeadSingle, CenterHeadSinglePos, RangeStratified
+from .nn_utils import RSNorm
+from .readers import DynamicPFNet
+
+RELU, NONE, TANH = ops.ACT_RELU, ops.ACT_NONE, ops.ACT_TANH
+
+
+def one_cycle(step: int, total_step: int, lr_max: float, moms: Sequence[float], div_factor: float, pct_start: float):
+    """(lr, beta1) the OneCycle scheduler sets before optimizer step ``step`` (0-based);
+    learning_schedules_fastai.py:52-95 (the last phase whose start has been reached wins)."""
+    a1 = int(total_step * pct_start)
+    low = lr_max / div_factor
+
+    def cos(start, end, pct):
+        return end + (start - end) / 2 * (math.cos(math.pi * pct) + 1)
+
+    if step >= a1:
+        pct = (step - a1) / (total_step - a1)
+        return cos(lr_max, low / 1e4, pct), cos(moms[1], moms[0], pct)
+    pct = step / a1
+    return cos(low, lr_max, pct), cos(moms[0], moms[1], pct)
+
+
+class ParamStore:
+    """All trainable parameters of a module in ONE flat fp32 buffer (+ flat grad / Adam moments);
+    every parameter starts on a 16-byte boundary.  The flat gradient buffer is what gets all-reduced
+    (one collective per step, dist_utils.py:8-28 coalesces the same way)."""
+
+    def __init__(self, model: nn.Module, device):
+        self.names: List[str] = []
+        self.offsets: Dict[str, Tuple[int, torch.Size]] = {}
+        off = 0
+        for name, p in model.named_parameters():
+            self.names.append(name)
+            self.offsets[name] = (off, p.shape)
+            off += (p.numel() + 3) // 4 * 4
+        self.total = off
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_m = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_v = torch.zeros(off, dtype=torch.float32, device=device)
+        self.p: Dict[str, torch.Tensor] = {}
+        self.g: Dict[str, torch.Tensor] = {}
+        for name, p in model.named_parameters():
+            o, shape = self.offsets[name]
+            view = self.flat_p[o:o + p.numel()].view(shape)
+            view.copy_(p.detach().to(device=device, dtype=torch.float32))
+            p.data = view
+            self.p[name] = view
+            self.g[name] = self.flat_g[o:o + p.numel()].view(shape)
+
+
+class _Conv:
+    """plain convolution (optional bias, optional fused activation) with explicit backward"""
+
+    def __init__(self, ps: ParamStore, wname: str, bname: Optional[str], stride=1, pad=0, act=NONE, transposed=False,
+                 cin_pad: Optional[int] = None):
+        self.ps, self.wname, self.bname = ps, wname, bname
+        w = ps.p[wname]
+        self.stride, self.pad, self.act, self.transposed = stride, pad, act, transposed
+        self.k = w.shape[2]
+        if transposed:  # ConvTranspose2d(k=2, s=2): weight (Cin, Cout, 2, 2)
+            self.layer = ops.ConvLayer(w, deconv2x2=True, act=act)
+            # its data gradient is the stride-2 convolution with the same tensor read as (Cout_conv, Cin_conv, 2, 2)
+            self.dgrad = ops.ConvLayer(w, stride=2, pad=0)
+        else:
+            self.layer = ops.ConvLayer(w, stride=stride, pad=pad, shift=None if bname is None else ps.p[bname], act=act)
+            if cin_pad is not None:
+                self.layer.pad_input_channels(cin_pad)
+            self.dgrad = ops.ConvDgrad(w, stride, pad)
+        self.cin_real = w.shape[1] if not transposed else w.shape[0]
+        self.x = None
+        self.in_co = 0
+
+    def fwd(self, x, out=None, out_co=0, in_co=0):
+        w = self.ps.p[self.wname]
+        self.layer.repack(w, None if self.bname is None else self.ps.p[self.bname])
+        self.x, self.in_co = x, in_co
+        return self.layer(x, out=out, out_channel_offset=out_co, in_channel_offset=in_co)
+
+    def bwd(self, dout, cout: Optional[int] = None, need_dx=True, dx=None, dx_co=0, accumulate=False):
+        """dout: NHWC gradient of the (pre-activation) output, own tensor (channel offset 0)"""
+        w = self.ps.p[self.wname]
+        gw = self.ps.g[self.wname]
+        if self.transposed:
+            ops.conv_wgrad(dout, self.x, 2, 2, 2, 0, cout=w.shape[0], dout_channel_offset=self.in_co, out=gw)
+            if need_dx:
+                self.dgrad.repack(w)
+                return self.dgrad(dout, out=dx, out_channel_offset=dx_co, accumulate=accumulate)
+            return None
+        cout = w.shape[0] if cout is None else cout
+        ops.conv_wgrad(self.x, dout, self.k, self.k, self.stride, self.pad, cin=self.cin_real, in_channel_offset=self.in_co,
+                       cout=cout, out=gw)
+        if self.bname is not None:
+            ops.channel_sum(dout, c=cout, out=self.ps.g[self.bname])
+        if need_dx:
+            self.dgrad.repack(w)
+            return self.dgrad(dout, out=dx, out_channel_offset=dx_co, accumulate=accumulate)
+        return None
+
+
+class _ConvBNReLU:
+    """Conv2d / ConvTranspose2d (no bias) + BatchNorm2d (batch statistics) + ReLU  (rpn.py:124-142, 80-110)"""
+
+    def __init__(self, ps: ParamStore, prefix: str, conv_idx: int, bn: nn.BatchNorm2d, conv: nn.Module):
+        transposed = isinstance(conv, nn.ConvTranspose2d)
+        pad = 1 if conv.kernel_size[0] == 3 else 0  # nn.ZeroPad2d(1) + Conv2d(3, padding=0) == padding 1
+        self.conv = _Conv(ps, f"{prefix}{conv_idx}.weight", None, conv.stride[0], pad, NONE, transposed)
+        self.gname, self.bname = f"{prefix}{conv_idx + 1}.weight", f"{prefix}{conv_idx + 1}.bias"
+        self.ps, self.bn = ps, bn
+        self.y = self.stat = None
+
+    def fwd(self, x, out=None, out_co=0):
+        self.y = self.conv.fwd(x)
+        res, self.stat = ops.batchnorm_train(self.y, self.ps.p[self.gname], self.ps.p[self.bname], self.bn.eps, self.bn.momentum,
+                                             self.bn.running_mean, self.bn.running_var, act=RELU, out=out, out_channel_offset=out_co)
+        return res
+
+    def bwd(self, dout, dout_co=0, need_dx=True, dx=None, accumulate=False):
+        c = self.y.shape[3]
+        inplace = dout.shape[3] == c and dout_co == 0
+        dy = dout if inplace else torch.empty_like(self.y)
+        ops.batchnorm_bwd(self.y, dout, self.ps.p[self.gname], self.ps.p[self.bname], self.stat, act=RELU, dx=dy,
+                          dgamma=self.ps.g[self.gname], dbeta=self.ps.g[self.bname], dout_channel_offset=dout_co)
+        return self.conv.bwd(dy, need_dx=need_dx, dx=dx, accumulate=accumulate)
+
+
+class _ConvGNReLU:
+    """Conv2d(bias) + GroupNorm-family + ReLU (+ calibration second output) of the merged heads"""
+
+    def __init__(self, ps, wname, bname, gname, bename, cgroups, strata, eps, groups=1):
+        self.ps = ps
+        self.groups, self.cgroups, self.strata, self.eps = groups, cgroups, strata, eps
+        self.wname, self.bname, self.gname, self.bename = wname, bname, gname, bename
+        w = ps.p[wname]
+        self.cout = w.shape[0]
+        if groups == 1:
+            self.convs = [_Conv(ps, wname, bname, 1, 1)]
+        else:  # grouped convolution: forward in one launch, backward per group on weight / channel slices
+            self.layer = ops.ConvLayer(w, stride=1, pad=1, groups=groups, shift=ps.p[bname])
+            cg = self.cout // groups
+            self.dgrads = [ops.ConvDgrad(w[g * cg:(g + 1) * cg], 1, 1) for g in range(groups)]
+        self.x = self.y = None
+
+    def fwd(self, x, mul=None, add=None):
+        self.x = x
+        if self.groups == 1:
+            self.y = self.convs[0].fwd(x)
+        else:
+            self.layer.repack(self.ps.p[self.wname], self.ps.p[self.bname])
+            self.y = self.layer(x)
+        self.mul = mul
+        return ops.groupnorm_strat(self.y, self.cgroups, self.strata, self.ps.p[self.gname], self.ps.p[self.bename], self.eps,
+                                   act=RELU, mul=mul, add=add)
+
+    def bwd(self, dout, dout2=None, dx=None, accumulate=False, need_dx=True):
+        res = ops.groupnorm_strat_bwd(self.y, dout, self.cgroups, self.strata, self.ps.p[self.gname], self.ps.p[self.bename], self.eps,
+                                      RELU, dout2=dout2, mul=self.mul if dout2 is not None else None, dx=dout,
+                                      dgamma=self.ps.g[self.gname], dbeta=self.ps.g[self.bename])
+        dy = res[0]
+        extra = res[3:] if dout2 is not None else ()
+        if self.groups == 1:
+            dxr = self.convs[0].bwd(dy, need_dx=need_dx, dx=dx, accumulate=accumulate)
+            return (dxr,) + tuple(extra)
+        w, gw = self.ps.p[self.wname], self.ps.g[self.wname]
+        cg, cin_g = self.cout // self.groups, w.shape[1]
+        ops.channel_sum(dy, out=self.ps.g[self.bname])
+        if dx is None:
+            dx = torch.empty_like(self.x)
+        for g in range(self.groups):
+            ops.conv_wgrad(self.x, dy, 3, 3, 1, 1, cin=cin_g, in_channel_offset=g * cin_g, cout=cg, dout_channel_offset=g * cg,
+                           out=gw[g * cg:(g + 1) * cg])
+            self.dgrads[g].repack(w[g * cg:(g + 1) * cg])
+            self.dgrads[g](dy, out=dx, dout_channel_offset=g * cg, out_channel_offset=g * cin_g, accumulate=accumulate)
+        return (dx,) + tuple(extra)
+
+
+class _StratConvGNReLU:
+    """RangeStratified: per-range-stratum 3x3 convolution + GroupNorm(strata) + ReLU (center_head_parallel.py:27-59)"""
+
+    def __init__(self, ps, prefix: str, m: RangeStratified):
+        self.ps, self.strata, self.nheads = ps, m.ngroups * m.nheads, m.nheads
+        self.wname, self.bname = prefix + "conv.0.weight", prefix + "conv.0.bias"
+        self.gname, self.bename = prefix + "conv.1.weight", prefix + "conv.1.bias"
+        self.eps = m.conv[1].eps
+        w = ps.p[self.wname]
+        self.layer = ops.ConvLayer(w, stride=1, pad=1, range_strata=self.strata, shift=ps.p[self.bname])
+        self.dgrad = ops.ConvDgrad(w, 1, 1)  # the (strata*C, Cin, 3, 3) weight as one ordinary convolution
+        self.x = self.y = None
+
+    def fwd(self, x):
+        self.x = x
+        self.layer.repack(self.ps.p[self.wname], self.ps.p[self.bname])
+        self.y = self.layer(x)
+        return ops.groupnorm_strat(self.y, self.nheads, self.strata, self.ps.p[self.gname], self.ps.p[self.bename], self.eps, act=RELU)
+
+    def bwd(self, dout, dx, accumulate):
+        dy, _, _ = ops.groupnorm_strat_bwd(self.y, dout, self.nheads, self.strata, self.ps.p[self.gname], self.ps.p[self.bename], self.eps,
+                                           RELU, dx=dout, dgamma=self.ps.g[self.gname], dbeta=self.ps.g[self.bename])
+        full = ops.strat_expand(dy, self.strata)  # zeros outside the pixel's stratum: an ordinary conv gradient
+        w = self.ps.p[self.wname]
+        ops.conv_wgrad(self.x, full, 3, 3, 1, 1, out=self.ps.g[self.wname])
+        ops.channel_sum(full, out=self.ps.g[self.bname])
+        self.dgrad.repack(w)
+        return self.dgrad(full, out=dx, accumulate=accumulate)
+
+
+class PolarPillarTrainStep:
+    """One training iteration of PointPillars(DynamicPFNet, DynamicPPScatter, RPN, CenterHeadSinglePos).
+
+    ``step(points, sample_offsets, batch, targets)`` runs forward (train mode), loss, backward, gradient
+    all-reduce (if torch.distributed is initialised with world_size > 1), clip + decoupled wd + Adam with
+    the OneCycle schedule, and returns the loss vector [det, hm, loc, num_pos, elem...] (device)."""
+
+    def __init__(self, model: nn.Module, total_steps: int, lr_max=0.005, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4,
+                 weight_decay=0.01, max_norm=35.0, beta2=0.99, eps=1e-8):
+        self.model = model
+        reader, neck, head = model.reader, model.neck, model.bbox_head
+        if not isinstance(reader, DynamicPFNet):
+            raise NotImplementedError("training step: the reader must be a DynamicPFNet")
+        if not isinstance(head, CenterHeadSingle):
+            raise NotImplementedError("training step: the head must be CenterHeadSingle / CenterHeadSinglePos")
+        reader._check_supported()
+        dev = next(model.parameters()).device
+        hip.require_device(next(model.parameters()))
+        self.dev = dev
+        self.ps = ps = ParamStore(model, dev)
+        self.sched = dict(total=total_steps, lr_max=lr_max, moms=tuple(moms), div=div_factor, pct=pct_start)
+        self.wd, self.max_norm, self.beta2, self.eps = weight_decay, max_norm, beta2, eps
+        self.iter = 0
+        self.reader, self.neck, self.head = reader, neck, head
+        self.spec = ops.GridSpec.from_range(reader.pc_range, reader.voxel_size)
+        self.w0, self.w1 = "reader.pfn_layers.0.linear.weight", "reader.pfn_layers.1.linear.weight"
+        # ---- RPN
+        self.blocks: List[List[_ConvBNReLU]] = []
+        for i, blk in enumerate(neck.blocks):
+            mods = list(blk._modules.values())
+            layers = [_ConvBNReLU(ps, f"neck.blocks.{i}.", 1, mods[2], mods[1])]
+            for k in range(4, len(mods), 3):
+                layers.append(_ConvBNReLU(ps, f"neck.blocks.{i}.", k, mods[k + 1], mods[k]))
+            self.blocks.append(layers)
+        self.deblocks = [_ConvBNReLU(ps, f"neck.deblocks.{j}.", 0, de[1], de[0]) for j, de in enumerate(neck.deblocks)]
+        self.up_start = neck._upsample_start_idx
+        self.up_filters = list(neck._num_upsample_filters)
+        # ---- head
+        hp = "bbox_head."
+        rs = head.shared_conv[1]
+        assert isinstance(rs, RSNorm)
+        self.shared = _ConvGNReLU(ps, hp + "shared_conv.0.weight", hp + "shared_conv.0.bias", hp + "shared_conv.1.groupnorm.weight",
+                                  hp + "shared_conv.1.groupnorm.bias", rs.num_heads, rs.num_groups, rs.groupnorm.eps)
+        self.branches = {}
+        for name in head.heads:
+            fc = getattr(head, name)
+            mods = list(fc._modules.values())
+            bp = f"{hp}{name}."
+            if isinstance(mods[0], RangeStratified):
+                first = _StratConvGNReLU(ps, bp + "0.", mods[0])
+                last = _Conv(ps, bp + "1.weight", bp + "1.bias", 1, 0)
+                self.branches[name] = ("strat", first, last, 1)
+            else:
+                assert len(mods) == 4, "training step: heads with one hidden conv (num_conv = 2)"
+                groups = mods[0].groups
+                first = _ConvGNReLU(ps, bp + "0.weight", bp + "0.bias", bp + "1.weight", bp + "1.bias", mods[1].num_groups, 1, mods[1].eps,
+                                    groups=groups)
+                w = ps.p[bp + "3.weight"]
+                if groups == 1:
+                    last = _Conv(ps, bp + "3.weight", bp + "3.bias", 1, 1)
+                else:
+                    last = ops.ConvLayer(w, stride=1, pad=1, groups=groups, shift=ps.p[bp + "3.bias"])
+                self.branches[name] = ("conv", first, last, groups)
+        self.has_pos = isinstance(head, CenterHeadSinglePos)
+        if self.has_pos:
+            pos = ops.to_nhwc(head.pos_encoding.to(dev).float())               # (1, A, R, 5)
+            self.pos8 = torch.zeros(pos.shape[:3] + (8,), dtype=torch.float32, device=dev)
+            self.pos8[..., :5] = pos
+            self.cal = {}
+            for kind, last_act in (("calibration_weight", TANH), ("calibration_bias", NONE)):
+                cp = f"{hp}{kind}."
+                self.cal[kind] = (_Conv(ps, cp + "0.weight", cp + "0.bias", 1, 1, act=TANH, cin_pad=8),
+                                  _Conv(ps, cp + "2.weight", cp + "2.bias", 1, 0, act=last_act), last_act)
+        self.code_weights, self.loss_weight = list(head.code_weights), float(head.weight)
+        self.ncls = sum(head.num_classes)
+
+    # ------------------------------------------------------------------------------------------
+    def _forward(self, points, sample_offsets, batch, grid_ind=None):
+        ps, spec = self.ps, self.spec
+        if grid_ind is None:
+            _, keys = ops.grid_index(points, sample_offsets, batch, spec, want_grid_ind=False)
+            n_dev = sample_offsets[batch:]
+        else:
+            keys = ops.keys_from_grid_ind(grid_ind.to(torch.int64).contiguous(), spec, batch)
+            n_dev = None
+        self.vi = ops.build_voxel_index(keys, spec, batch, n_dev=n_dev, want_unq=False)
+        self.points = points
+        canvas = torch.empty((batch, spec.grid[1], spec.grid[0], self.reader.out_channels), dtype=torch.float32, device=self.dev)
+        hip.call("pn_fill_zero", canvas.data_ptr(), canvas.numel() * 4, hip.stream())
+        r = self.reader
+        ops.dynamic_pfn(points, self.vi, ps.p[self.w0], ps.p[self.w1], r.vx, r.vy, r.x_offset, r.y_offset, None, canvas)
+        x = canvas
+        out, off = None, 0
+        self.block_out = []
+        for i, layers in enumerate(self.blocks):
+            for layer in layers:
+                x = layer.fwd(x)
+            self.block_out.append(x)
+            j = i - self.up_start
+            if j >= 0:
+                de = self.deblocks[j]
+                if out is None:
+                    oh, ow = de.conv.layer.out_hw(x.shape[1], x.shape[2])
+                    out = torch.empty((batch, oh, ow, sum(self.up_filters)), dtype=torch.float32, device=self.dev)
+                de.fwd(x, out=out, out_co=off)
+                off += self.up_filters[j]
+        self.x2 = out
+        # ---- head
+        mul = add = None
+        if self.has_pos:
+            self.cal_mid = {}
+            maps = {}
+            for kind, (c0, c1, _) in self.cal.items():
+                mid = c0.fwd(self.pos8)
+                self.cal_mid[kind] = mid
+                maps[kind] = c1.fwd(mid)
+            self.cal_w, self.cal_b = maps["calibration_weight"], maps["calibration_bias"]
+            mul, add = self.cal_w[0], self.cal_b[0]
+        if mul is not None:
+            xs, x_hm = self.shared.fwd(out, mul=mul, add=add)
+        else:
+            xs = x_hm = self.shared.fwd(out)
+        self.xs, self.x_hm = xs, x_hm
+        preds = {}
+        self.branch_mid = {}
+        for name, (kind, first, last, groups) in self.branches.items():
+            z = first.fwd(x_hm if name == "hm" else xs)
+            self.branch_mid[name] = z
+            if kind == "conv" and groups > 1:
+                last.repack(ps.p[f"bbox_head.{name}.3.weight"], ps.p[f"bbox_head.{name}.3.bias"])
+                y = last(z)
+            else:
+                y = last.fwd(z)
+            if "_" in name:
+                names = name.split("_")
+                dim = y.shape[3] // len(names)
+                for k, nm in enumerate(names):
+                    preds[nm] = y[..., k * dim:(k + 1) * dim]
+            else:
+                preds[name] = y
+        self.preds = preds
+        return preds
+
+    def _loss_sources(self):
+        order = ["reg", "height", "dim"] + (["vel"] if "vel" in self.preds else []) + ["rot"]
+        return order, [(self.preds[k], self.preds[k].shape[3]) for k in order]
+
+    # ------------------------------------------------------------------------------------------
+    def _backward(self, targets: ops.CenterLossTargets, loss_out, grad_scale: float):
+        ps = self.ps
+        order, boxes = self._loss_sources()
+        with_vel = "vel" in self.preds
+        d_hm, d_boxes = ops.center_loss_bwd(self.preds["hm"], self.ncls, boxes, targets, self.code_weights, self.loss_weight, loss_out,
+                                            grad_scale=grad_scale, with_vel=with_vel)
+        d_pred = dict(zip(order, d_boxes))
+        d_pred["hm"] = d_hm
+        d_xs = torch.empty_like(self.xs)
+        d_xhm = None
+        first_into_xs = True
+        for name, (kind, first, last, groups) in self.branches.items():
+            z = self.branch_mid[name]
+            if kind == "conv" and groups > 1:
+                # grouped final convolution: one output tensor per merged head (e.g. rot | vel)
+                names = name.split("_")
+                w, gw, gb = ps.p[f"bbox_head.{name}.3.weight"], ps.g[f"bbox_head.{name}.3.weight"], ps.g[f"bbox_head.{name}.3.bias"]
+                co, ci = w.shape[0] // groups, w.shape[1]
+                dz = torch.empty_like(z)
+                for g_, nm in enumerate(names):
+                    dy = d_pred[nm]
+                    ops.conv_wgrad(z, dy, 3, 3, 1, 1, cin=ci, in_channel_offset=g_ * ci, cout=co, out=gw[g_ * co:(g_ + 1) * co])
+                    ops.channel_sum(dy, c=co, out=gb[g_ * co:(g_ + 1) * co])
+                    ops.ConvDgrad(w[g_ * co:(g_ + 1) * co], 1, 1)(dy, out=dz, out_channel_offset=g_ * ci)
+            else:
+                cout = ps.p[last.wname].shape[0]
+                dz = last.bwd(d_pred[name], cout=cout)
+            if name == "hm" and self.x_hm is not self.xs:
+                d_xhm = first.bwd(dz)[0]
+            elif kind == "strat":
+                first.bwd(dz, dx=d_xs, accumulate=not first_into_xs)
+                first_into_xs = False
+            else:
+                first.bwd(dz, dx=d_xs, accumulate=not first_into_xs)
+                first_into_xs = False
+        # shared conv + RSNorm (+ calibration)
+        res = self.shared.bwd(d_xs, dout2=d_xhm)
+        d_x2 = res[0]
+        if self.has_pos:
+            d_calw, d_calb = res[1], res[2]
+            for kind, dmap, ymap in (("calibration_weight", d_calw, self.cal_w), ("calibration_bias", d_calb, self.cal_b)):
+                c0, c1, last_act = self.cal[kind]
+                d = dmap[None].contiguous()
+                if last_act == TANH:
+                    d = ops.tanh_bwd(ymap, d)
+                dmid = c1.bwd(d)
+                dmid = ops.tanh_bwd(self.cal_mid[kind], dmid, dx=dmid)
+                c0.bwd(dmid, need_dx=False)
+        # RPN
+        nblk = len(self.blocks)
+        d_block = None
+        for i in range(nblk - 1, -1, -1):
+            j = i - self.up_start
+            if j >= 0:
+                off = sum(self.up_filters[:j])
+                if d_block is None:
+                    d_block = self.deblocks[j].bwd(d_x2, dout_co=off)
+                else:
+                    self.deblocks[j].bwd(d_x2, dout_co=off, dx=d_block, accumulate=True)
+            d = d_block
+            for layer in reversed(self.blocks[i]):
+                d = layer.bwd(d)
+            d_block = d
+        d_canvas = d_block
+        r = self.reader
+        ops.dynamic_pfn_bwd(self.points, self.vi, ps.p[self.w0], ps.p[self.w1], r.vx, r.vy, r.x_offset, r.y_offset, d_canvas=d_canvas,
+                            dw0=ps.g[self.w0], dw1=ps.g[self.w1])
+
+    # ------------------------------------------------------------------------------------------
+    def forward_backward(self, points, sample_offsets, batch, targets: ops.CenterLossTargets, grid_ind=None, grad_scale=1.0):
+        """forward + loss + backward; gradients land in ``self.ps.flat_g`` (overwritten, not accumulated)"""
+        preds = self._forward(points, sample_offsets, batch, grid_ind)
+        order, boxes = self._loss_sources()
+        loss = ops.center_loss(preds["hm"], self.ncls, boxes, targets, self.code_weights, self.loss_weight, with_vel="vel" in preds)
+        self._backward(targets, loss, grad_scale)
+        return loss
+
+    def optimizer_step(self):
+        s = self.sched
+        lr, beta1 = one_cycle(self.iter, s["total"], s["lr_max"], s["moms"], s["div"], s["pct"])
+        total_norm = ops.grad_norm(self.ps.flat_g)
+        ops.adam_step(self.ps.flat_p, self.ps.flat_g, self.ps.flat_m, self.ps.flat_v, self.iter + 1, lr, beta1, self.beta2, self.eps,
+                      self.wd, total_norm=total_norm, max_norm=self.max_norm)
+        self.iter += 1
+        return total_norm
+
+    def step(self, points, sample_offsets, batch, targets: ops.CenterLossTargets, grid_ind=None):
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # the reference averages the gradients over ranks (dist_utils.py:17-28): fold 1/world into the loss gradient
+        loss = self.forward_backward(points, sample_offsets, batch, targets, grid_ind, grad_scale=1.0 / world)
+        if world > 1:
+            dist.all_reduce(self.ps.flat_g)  # ONE collective per step over the flat buffer (RCCL on ROCm)
+        self.optimizer_step()
+        return loss

@@ -487,7 +487,50 @@ def gen_setblock():
     save("setblock_full.npz", **o)
 
 
+# ----------------------------------------------------------------------------- T1 optimizer step
+def gen_optim():
+    """Reference OptimWrapper (decoupled wd, Adam betas=(mom,0.99)) + OneCycle + clip_grad_norm_(35)
+    on a toy module: conv + BatchNorm + conv, 7 steps of a 50-step schedule with seeded grads.
+    Stores lr/mom per step, the total gradient norm and the parameters after each step."""
+    from functools import partial
+    from torch import nn
+    from torch.nn.utils import clip_grad
+    from det3d.solver.fastai_optim import OptimWrapper
+    from det3d.solver.learning_schedules_fastai import OneCycle
+    from det3d.torchie.apis.train import flatten_model
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Conv2d(4, 6, 3, bias=False), nn.BatchNorm2d(6), nn.ReLU(), nn.Conv2d(6, 3, 1, bias=True))
+    rng = np.random.default_rng(42)
+    names = [n for n, _ in model.named_parameters()]
+    for n, p_ in model.named_parameters():
+        p_.data = torch.from_numpy(rng.standard_normal(tuple(p_.shape)).astype(np.float32) * 0.3)
+    opt = OptimWrapper.create(partial(torch.optim.Adam, betas=(0.9, 0.99), amsgrad=0.0), 3e-3, [nn.Sequential(*flatten_model(model))],
+                              wd=0.01, true_wd=True, bn_wd=True)
+    total_step = 50
+    sched = OneCycle(opt, total_step, 0.005, [0.95, 0.85], 10.0, 0.4)
+    out = {"names": np.array(names), "total_step": total_step}
+    for n, p_ in model.named_parameters():
+        out["init::" + n] = p_.detach().numpy().copy()
+    lrs, moms, norms = [], [], []
+    steps = (0, 1, 2, 19, 20, 21, 49)   # crosses the pct_start boundary (a1 = 20)
+    for step in steps:
+        sched.step(step)
+        lrs.append(opt.lr); moms.append(opt.mom)
+        for n, p_ in model.named_parameters():
+            scale = 40.0 if step in (1, 20) else 1.0   # clip (max_norm 35) active on these steps
+            p_.grad = torch.from_numpy(rng.standard_normal(tuple(p_.shape)).astype(np.float32) * scale)
+            out[f"grad{step}::" + n] = p_.grad.numpy().copy()
+        tn = clip_grad.clip_grad_norm_(filter(lambda q: q.requires_grad, model.parameters()), max_norm=35, norm_type=2)
+        norms.append(float(tn))
+        opt.step()
+        for n, p_ in model.named_parameters():
+            out[f"after{step}::" + n] = p_.detach().numpy().copy()
+    out["steps"] = np.array(steps)
+    out["lr"], out["mom"], out["total_norm"] = np.array(lrs, np.float64), np.array(moms, np.float64), np.array(norms, np.float64)
+    save("optim.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock"]
+    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim"]
     for w in which:
         globals()["gen_" + w]()

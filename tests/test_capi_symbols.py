@@ -39,4 +39,4 @@ def test_host_only_entry_points():
     # argument validation happens on the host, before any launch
     rc = lib.pn_conv2d_nhwc_f32(None, None, None, None, None, None, None)
     assert rc == -1 and "null descriptor" in hip.last_error()
-    assert C.sizeof(hip.ConvDesc) == 20 * 4
+    assert C.sizeof(hip.ConvDesc) == 21 * 4

@@ -394,3 +394,25 @@ def test_setblock_full_size(golden):
         x2 = torch.from_numpy(np.random.default_rng(53).standard_normal((1, 144 * 256, 256)).astype(np.float32))
         y2 = O.set_block(filled_sd(shapes, 71), "", x2, pos, (144, 256), heads=4, shift=True)
         close(y2[0, ::97, :], g["y1_indep_probe"], 1e-4, 2e-4)
+
+
+def test_optimizer_step_restatement(golden):
+    """OneCycle lr/mom, clip coefficient and the decoupled-wd Adam update against the reference's
+    OptimWrapper + OneCycle + clip_grad_norm_ run (tests/golden/make_golden.py::gen_optim)."""
+    g = golden("optim.npz")
+    names = [str(n) for n in g["names"]]
+    total = int(g["total_step"])
+    P = {n: torch.from_numpy(g["init::" + n].copy()) for n in names}
+    M = {n: torch.zeros_like(P[n]) for n in names}
+    V = {n: torch.zeros_like(P[n]) for n in names}
+    for k, step in enumerate(int(s) for s in g["steps"]):
+        lr, mom = O.one_cycle(step, total, 0.005, [0.95, 0.85], 10.0, 0.4)
+        assert abs(lr - float(g["lr"][k])) < 1e-12 and abs(mom - float(g["mom"][k])) < 1e-12
+        grads = {n: torch.from_numpy(g[f"grad{step}::" + n].copy()) for n in names}
+        tn = float(torch.sqrt(sum((x.double() ** 2).sum() for x in grads.values())))
+        assert abs(tn - float(g["total_norm"][k])) < 1e-4 * tn
+        coef = O.grad_clip_coef(tn, 35.0)
+        assert (coef < 1.0) == (step in (1, 20))
+        for n in names:
+            O.adam_decoupled_step(P[n], grads[n] * np.float32(coef), M[n], V[n], k + 1, lr, mom)
+            close(P[n], g[f"after{step}::" + n], 2e-6, 2e-7)
