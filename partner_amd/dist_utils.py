@@ -56,3 +56,20 @@ def sum_over_ranks(value: float, device: Optional[torch.device] = None) -> float
     t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+# ---- training step: the one exchange per iteration ------------------------------------
+def allreduce_flat_grads(flat_g: torch.Tensor) -> None:
+    """SUM all-reduce of the flat fp32 gradient buffer, in place (one collective per step; the
+    reference coalesces per-parameter grads into buckets, det3d/core/utils/dist_utils.py:8-28).
+    The 1/world of the reference's average is folded into the loss gradient by the caller, so after
+    this call every rank holds the mean gradient."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
+
+
+def broadcast_flat_params(flat_p: torch.Tensor, src: int = 0) -> None:
+    """rank `src` -> all, once before training (what DistributedDataParallel's constructor does,
+    det3d/torchie/apis/train.py:330-336)"""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat_p, src=src)

@@ -469,10 +469,18 @@ class PolarPillarTrainStep:
 
     def step(self, points, sample_offsets, batch, targets: ops.CenterLossTargets, grid_ind=None):
         import torch.distributed as dist
+        from .dist_utils import allreduce_flat_grads
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # the reference averages the gradients over ranks (dist_utils.py:17-28): fold 1/world into the loss gradient
         loss = self.forward_backward(points, sample_offsets, batch, targets, grid_ind, grad_scale=1.0 / world)
-        if world > 1:
-            dist.all_reduce(self.ps.flat_g)  # ONE collective per step over the flat buffer (RCCL on ROCm)
+        allreduce_flat_grads(self.ps.flat_g)  # ONE collective per step over the flat buffer (RCCL on ROCm)
         self.optimizer_step()
         return loss
+
+    def sync_initial_params(self):
+        """rank 0's parameters (and BatchNorm running statistics) to every rank, once before the first step"""
+        from .dist_utils import broadcast_flat_params
+        broadcast_flat_params(self.ps.flat_p)
+        for b in self.model.buffers():
+            if b.dtype.is_floating_point:
+                broadcast_flat_params(b)
