@@ -199,12 +199,13 @@ __global__ void channel_sum_partial_kernel(const float* __restrict__ x, long lon
   part[(size_t)blockIdx.x * c + ch] = s;
 }
 
-__global__ void channel_sum_final_kernel(const float* __restrict__ part, int slices, int c, float* __restrict__ out, int accumulate) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+// one wave per channel, lane-strided then butterfly: fixed association order
+__global__ __launch_bounds__(64) void channel_sum_final_kernel(const float* __restrict__ part, int slices, int c, float* __restrict__ out, int accumulate) {
+  const int ch = blockIdx.x;
   float s = 0.f;
-  for (int k = 0; k < slices; ++k) s += part[(size_t)k * c + ch];
-  out[ch] = accumulate ? out[ch] + s : s;
+  for (int k = threadIdx.x; k < slices; k += 64) s += part[(size_t)k * c + ch];
+  s = pn::wave_sum(s);
+  if (threadIdx.x == 0) out[ch] = accumulate ? out[ch] + s : s;
 }
 
 // ---- weight packers for the data-gradient convolutions ---------------------------------------
@@ -298,7 +299,7 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
   return pn::check_launch("conv_wgrad_kernel");
 }
 
-constexpr int kSumSlices = 256;
+constexpr int kSumSlices = 2048;
 
 }  // namespace
 
@@ -355,7 +356,7 @@ int pn_channel_sum_f32(const float* x, long long pixels, int pixel_stride, int c
   hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(slices, pn::cdiv(c, 64)), dim3(64), 0, pn::S(stream), x, pixels,
                      pixel_stride, channel_offset, c, slices, part);
   if (int rc = pn::check_launch("channel_sum_partial_kernel")) return rc;
-  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(pn::cdiv(c, 64)), dim3(64), 0, pn::S(stream), part, slices, c, out, accumulate);
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(c), dim3(64), 0, pn::S(stream), part, slices, c, out, accumulate);
   return pn::check_launch("channel_sum_final_kernel");
 }
 

@@ -153,6 +153,9 @@ __global__ __launch_bounds__(256) void loss_sparse_bwd_kernel(const float* __res
                                                               const int64_t* __restrict__ cat, const float* __restrict__ anno, int anno_dim,
                                                               int M, int ndim, const float* __restrict__ code_w, float weight,
                                                               const float* __restrict__ fwd_out, float gscale, float* __restrict__ dhm, int dps) {
+  // masked objects of this sample, in object order (LDS list: the duplicate search is O(n_masked^2), not O(M^2))
+  __shared__ int live[1024];
+  __shared__ int n_live;
   const int b = blockIdx.x;
   const float npos = fwd_out[3];
   const float s_hm = npos == 0.f ? 0.f : gscale / npos;  // npos == 0: the positive term is dropped (centernet_loss.py:50-52)
@@ -160,16 +163,29 @@ __global__ __launch_bounds__(256) void loss_sparse_bwd_kernel(const float* __res
   const int64_t* bind = ind + (size_t)b * M;
   const int64_t* bcat = cat + (size_t)b * M;
   const uint8_t* bmask = mask + (size_t)b * M;
-  for (int i = threadIdx.x; i < M; i += blockDim.x) {
-    if (!bmask[i]) continue;
+  if (threadIdx.x < 64) {  // first wave compacts with ballots: order preserving
+    int base = 0;
+    for (int i0 = 0; i0 < M; i0 += 64) {
+      const int i = i0 + threadIdx.x;
+      const bool m = i < M && bmask[i];
+      const unsigned long long bal = __ballot(m);
+      if (m) live[base + __popcll(bal & ((1ull << threadIdx.x) - 1ull))] = i;
+      base += __popcll(bal);
+    }
+    if (threadIdx.x == 0) n_live = base;
+  }
+  __syncthreads();
+  const int L = n_live;
+  for (int li = threadIdx.x; li < L; li += blockDim.x) {
+    const int i = live[li];
     const int64_t pix = bind[i];
     const size_t gp = (size_t)b * H * W + pix;
     // ---- focal positive: owner = first masked object with the same (ind, cat)
     bool owner = true;
-    for (int j = 0; j < i; ++j) owner = owner && !(bmask[j] && bind[j] == pix && bcat[j] == bcat[i]);
+    for (int lj = 0; lj < li; ++lj) { const int j = live[lj]; owner = owner && !(bind[j] == pix && bcat[j] == bcat[i]); }
     if (owner) {
       int mult = 1;
-      for (int j = i + 1; j < M; ++j) mult += (bmask[j] && bind[j] == pix && bcat[j] == bcat[i]) ? 1 : 0;
+      for (int lj = li + 1; lj < L; ++lj) { const int j = live[lj]; mult += (bind[j] == pix && bcat[j] == bcat[i]) ? 1 : 0; }
       const float sg = 1.f / (1.f + expf(-logit[gp * ps + bcat[i]]));
       if (sg >= 1e-4f && sg <= 1.f - 1e-4f) {
         const float dp = (1.f - sg) * (1.f - sg) / sg - 2.f * (1.f - sg) * logf(sg);
@@ -178,15 +194,16 @@ __global__ __launch_bounds__(256) void loss_sparse_bwd_kernel(const float* __res
     }
     // ---- boxes: owner = first masked object with the same ind; it adds every duplicate in object order
     bool bowner = true;
-    for (int j = 0; j < i; ++j) bowner = bowner && !(bmask[j] && bind[j] == pix);
+    for (int lj = 0; lj < li; ++lj) bowner = bowner && !(bind[live[lj]] == pix);
     if (!bowner) continue;
     for (int d = 0; d < ndim; ++d) {
       int src = 0, ch = d;
       while (src < bs.n && ch >= bs.nch[src]) ch -= bs.nch[src++];
       const float pr = bs.p[src][gp * bs.ps[src] + ch];
       float g = 0.f;
-      for (int j = i; j < M; ++j) {
-        if (!(bmask[j] && bind[j] == pix)) continue;
+      for (int lj = li; lj < L; ++lj) {
+        const int j = live[lj];
+        if (bind[j] != pix) continue;
         const float df = pr - anno[((size_t)b * M + j) * anno_dim + bs.sel[d]];
         g += (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
       }
@@ -243,6 +260,7 @@ int pn_center_loss_bwd(const float* hm_logits, int hm_pixel_stride, const float*
              "center_loss_bwd: null pointer");
   PN_REQUIRE(n_box_src >= 1 && n_box_src <= 5 && box_dims >= 1 && box_dims <= 16, "center_loss_bwd: bad box description");
   PN_REQUIRE(d_hm_pixel_stride >= classes, "center_loss_bwd: gradient pixel stride smaller than the class count");
+  PN_REQUIRE(max_objs <= 1024, "center_loss_bwd: at most 1024 objects per sample");
   BoxSrc bs;
   BoxDst bd;
   bs.n = n_box_src;

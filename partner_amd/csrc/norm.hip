@@ -289,11 +289,14 @@ __global__ __launch_bounds__(kThreads) void bn_partial_kernel(BnArgs a) {
   }
 }
 
-__global__ void bn_finalize_kernel(BnArgs a) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.C) return;
+// one wave per channel: lane-strided partial sums, then the xor butterfly (same association on every run)
+__global__ __launch_bounds__(64) void bn_finalize_kernel(BnArgs a) {
+  const int c = blockIdx.x;
   double t0 = 0.0, t1 = 0.0;
-  for (int k = 0; k < a.slices; ++k) { t0 += a.part[((size_t)k * a.C + c) * 2]; t1 += a.part[((size_t)k * a.C + c) * 2 + 1]; }
+  for (int k = threadIdx.x; k < a.slices; k += 64) { t0 += a.part[((size_t)k * a.C + c) * 2]; t1 += a.part[((size_t)k * a.C + c) * 2 + 1]; }
+  t0 = pn::wave_sum(t0);
+  t1 = pn::wave_sum(t1);
+  if (threadIdx.x != 0) return;
   const double n = (double)a.pixels;
   const double mean = t0 / n;
   double var = t1 / n - mean * mean;
@@ -307,11 +310,13 @@ __global__ void bn_finalize_kernel(BnArgs a) {
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(BnArgs a) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.C) return;
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(BnArgs a) {
+  const int c = blockIdx.x;
   double t0 = 0.0, t1 = 0.0;
-  for (int k = 0; k < a.slices; ++k) { t0 += a.part[((size_t)k * a.C + c) * 2]; t1 += a.part[((size_t)k * a.C + c) * 2 + 1]; }
+  for (int k = threadIdx.x; k < a.slices; k += 64) { t0 += a.part[((size_t)k * a.C + c) * 2]; t1 += a.part[((size_t)k * a.C + c) * 2 + 1]; }
+  t0 = pn::wave_sum(t0);
+  t1 = pn::wave_sum(t1);
+  if (threadIdx.x != 0) return;
   if (a.dbeta) a.dbeta[c] = (a.accumulate ? a.dbeta[c] : 0.f) + (float)t0;
   if (a.dgamma) a.dgamma[c] = (a.accumulate ? a.dgamma[c] : 0.f) + (float)t1;
   a.coef[2 * c] = (float)(t0 / (double)a.pixels);
@@ -387,7 +392,7 @@ int pn_batchnorm_train_fwd(const float* x, long long pixels, int c, int pixel_st
   a.stat = saved_stat;
   hipStream_t st = pn::S(stream);
   hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(a.slices), dim3(kThreads), 0, st, a);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(pn::cdiv(c, 64)), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(64), 0, st, a);
   const long long total = pixels * (c / 4);
   hipLaunchKernelGGL(bn_apply_kernel<0>, dim3((unsigned)std::min<long long>(4096, pn::cdiv(total, kThreads))), dim3(kThreads), 0, st, a);
   return pn::check_launch("batchnorm_train_fwd");
@@ -408,7 +413,7 @@ int pn_batchnorm_bwd(const float* x, const float* dout, long long pixels, int c,
   a.dx = dx; a.xps = dx_pixel_stride; a.xco = dx_channel_offset; a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate;
   hipStream_t st = pn::S(stream);
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(a.slices), dim3(kThreads), 0, st, a);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn::cdiv(c, 64)), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(64), 0, st, a);
   const long long total = pixels * (c / 4);
   hipLaunchKernelGGL(bn_apply_kernel<1>, dim3((unsigned)std::min<long long>(4096, pn::cdiv(total, kThreads))), dim3(kThreads), 0, st, a);
   return pn::check_launch("batchnorm_bwd");

@@ -398,15 +398,22 @@ __global__ __launch_bounds__(kHeavyWaves * 64) void dynamic_pfn_32_128_heavy_ker
 // over all pillars of the wave and written once to a per-wave slab; a second kernel adds the slabs
 // in wave order (deterministic).  The 128 -> 32 contraction dh0[c] = sum_n dy1[n] W1a[n][c] is a
 // 5-step butterfly reduce-scatter (31 shuffles) instead of 32 full wave reductions.
+__device__ __forceinline__ float bit_select(unsigned mask, float a, float b) {
+  // mask ? a : b on the bit patterns (one v_bfi_b32).  A plain `c ? v[i + h] : v[i]` is turned by the
+  // compiler into a dynamically indexed register array = a 32-way compare/select chain per access.
+  return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, a) & mask) | (__builtin_bit_cast(unsigned, b) & ~mask));
+}
+
 template <int N>
 __device__ __forceinline__ float reduce_scatter(float (&v)[N], int lane) {
   // reduce-scatter of N (16 or 32) per-lane values over the 64 lanes: lane l returns sum_lanes v[l & (N-1)]
 #pragma unroll
   for (int h = N / 2; h >= 1; h >>= 1) {
-    const bool up = lane & h;
+    const unsigned up = (lane & h) ? 0xffffffffu : 0u;
 #pragma unroll
     for (int i = 0; i < h; ++i) {
-      const float keep = up ? v[i + h] : v[i], send = up ? v[i] : v[i + h];
+      const float lo = v[i], hi = v[i + h];
+      const float keep = bit_select(up, hi, lo), send = bit_select(up, lo, hi);
       v[i] = keep + __shfl_xor(send, h, 64);
     }
   }
@@ -416,154 +423,257 @@ __device__ __forceinline__ float reduce_scatter(float (&v)[N], int lane) {
   return r;
 }
 
-// floats per wave slab: dW1 (C1, 2*C0) then dW0 (C0, 16)
+// One launch covers 64 rows of W1 per blockIdx.y ("pass"): lane n owns row 64*pass + n.  Keeping a
+// single W1 row (+ its gradient row) per lane holds the kernel at ~200 VGPRs (two waves per SIMD, no
+// scratch); the layer-0 part (dm0, dh0 -> dW0) is linear in the rows, so every pass contributes a
+// partial dW0 and the reduce kernel adds them.
+// slab per (pass, wave): dW1 rows [64*pass, 64*pass+64) x (2*C0), then the partial dW0 (C0, 16)
+constexpr int kBwdBatch = 32;  // pillars staged per block and round
+constexpr int kBwdPts = 4;     // points per pillar staged in LDS (pillars with more read global memory)
+
 template <int C0, int C1>
 __global__ __launch_bounds__(256) void dynamic_pfn_bwd_kernel(PfnArgs a, const float* __restrict__ cs_table,
                                                               const float* __restrict__ dfeat, const float* __restrict__ dcanvas,
                                                               float* __restrict__ slabs) {
-  constexpr bool TWO = C1 > 64;          // second output row per lane
   constexpr int K1 = 2 * C0;             // row length of W1
-  constexpr int SLAB = C1 * K1 + C0 * 16;
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  constexpr int SLAB = 64 * K1 + C0 * 16;
+  constexpr int NB = kBwdBatch, KP = kBwdPts;
+  // A wave working alone through vstart -> order -> point -> gradient row pays four dependent memory
+  // latencies per pillar (one wave per SIMD: nothing else to switch to).  The block therefore stages a
+  // batch of NB pillars in LDS with all 256 threads loading in parallel -- three latencies per batch --
+  // and each wave then works through its share from LDS.
+  __shared__ int m_s[NB], m_e[NB];
+  __shared__ uint32_t m_key[NB];
+  __shared__ float p_l[NB][KP][8];
+  __shared__ float d_l[NB][64];
+  const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+  const int wave = blockIdx.x * 4 + wib;
+  const int nwaves = gridDim.x * 4;
+  const int row0 = blockIdx.y * 64, row = row0 + lane;
+  const bool la = row < C1;
   const int V = min(*a.v_dev, a.v_cap);
-  const bool la = lane < C1, lb = TWO && lane + 64 < C1;
-  float w0[16], w1a[K1], w1b[TWO ? K1 : 1];
+  float w0[16], w1[K1];
 #pragma unroll
   for (int k = 0; k < 16; ++k) w0[k] = lane < C0 ? a.w0[lane * 16 + k] : 0.f;
 #pragma unroll
-  for (int k = 0; k < K1; ++k) {
-    w1a[k] = la ? a.w1[lane * K1 + k] : 0.f;
-    if (TWO) w1b[k] = lb ? a.w1[(lane + 64) * K1 + k] : 0.f;
-  }
-  float dwa[K1], dwb[TWO ? K1 : 1], dw0[16];
+  for (int k = 0; k < K1; ++k) w1[k] = la ? a.w1[row * K1 + k] : 0.f;
+  float dw1[K1], dw0[16];
 #pragma unroll
-  for (int k = 0; k < K1; ++k) { dwa[k] = 0.f; if (TWO) dwb[k] = 0.f; }
+  for (int k = 0; k < K1; ++k) dw1[k] = 0.f;
 #pragma unroll
   for (int k = 0; k < 16; ++k) dw0[k] = 0.f;
 
-  for (int v = wave; v < V; v += nwaves) {
-    const int s = a.vstart[v], e = a.vstart[v + 1];
-    uint32_t key = a.ukeys[v];
-    const int ri = key % a.R; key /= a.R;
-    const int ti = key % a.T; key /= a.T;
-    const int bi = key / a.Z;
-    long long sx = 0, sy = 0, sz = 0, sr = 0, sp = 0;
-    for (int i = s + lane; i < e; i += 64) {
-      const float* p = a.pts + (size_t)a.order[i] * a.stride;
-      sr += to_fix(p[0]); sp += to_fix(p[1]); sz += to_fix(p[2]); sx += to_fix(p[3]); sy += to_fix(p[4]);
+  for (int v0 = blockIdx.x * NB; v0 < V; v0 += gridDim.x * NB) {
+    __syncthreads();  // the previous batch has been consumed
+    if (tid < NB) {
+      const int v = v0 + tid;
+      m_s[tid] = v < V ? a.vstart[v] : 0;
+      m_e[tid] = v < V ? a.vstart[v + 1] : 0;
+      m_key[tid] = v < V ? a.ukeys[v] : 0u;
     }
-    const double inv_n = 1.0 / ((double)(e - s) * kFix);
-    const float mx = (float)((double)pn::wave_sum(sx) * inv_n), my = (float)((double)pn::wave_sum(sy) * inv_n);
-    const float mz = (float)((double)pn::wave_sum(sz) * inv_n), mr = (float)((double)pn::wave_sum(sr) * inv_n);
-    const float mp = (float)((double)pn::wave_sum(sp) * inv_n);
-    const float rc = __fadd_rn(__fmul_rn((float)ri, a.vx), a.xoff);
-    const float pc = __fadd_rn(__fmul_rn((float)ti, a.vy), a.yoff);
-    const float xc = __fmul_rn(rc, cs_table[2 * ti]), yc = __fmul_rn(rc, cs_table[2 * ti + 1]);
-    float d[16];
-    auto decorate = [&](const float* p) {
-      const float rho = p[0], phi = p[1], z = p[2], x = p[3], y = p[4];
-      const float t[16] = {rho, phi, z, x, y, p[5], p[6], x - mx, y - my, z - mz, x - xc, y - yc, rho - mr, phi - mp, rho - rc, phi - pc};
+    __syncthreads();
+    if (tid < NB * KP) {
+      const int p = tid / KP, j = tid - p * KP;
+      const int s = m_s[p], n = m_e[p] - s;
+      if (j < n && n <= KP) {
+        const float* src = a.pts + (size_t)a.order[s + j] * a.stride;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) d[k] = t[k];
-    };
-    auto layer0 = [&]() -> float {
-      float h = 0.f;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) h = fmaf(w0[k], d[k], h);
-      return h > 0.f ? h : 0.f;
-    };
-    // pass A: layer-0 maxima and the point that attains them
-    float m0 = 0.f;
-    int q0 = -1;
-    for (int i = s; i < e; ++i) {
-      decorate(a.pts + (size_t)a.order[i] * a.stride);
-      const float h = layer0();
-      if (h > m0) { m0 = h; q0 = i; }
+        for (int k = 0; k < 7; ++k) p_l[p][j][k] = src[k];
+      }
     }
-    float g0 = 0.f, g1 = 0.f;
 #pragma unroll
-    for (int c = 0; c < C0; ++c) {
-      const float m = lane_bcast(m0, c);
-      g0 = fmaf(w1a[C0 + c], m, g0);
-      if (TWO) g1 = fmaf(w1b[C0 + c], m, g1);
+    for (int k = 0; k < NB * 64 / 256; ++k) {
+      const int idx = tid + 256 * k, p = idx >> 6, r = idx & 63;
+      float g = 0.f;
+      if (v0 + p < V && row0 + r < C1) {
+        if (dcanvas) {
+          uint32_t key = m_key[p];
+          const int ri = key % a.R; key /= a.R;
+          const int ti = key % a.T; key /= a.T;
+          const int bi = key / a.Z;
+          g = dcanvas[(((size_t)bi * a.T + ti) * a.R + ri) * C1 + row0 + r];
+        } else {
+          g = dfeat[(size_t)(v0 + p) * C1 + row0 + r];
+        }
+      }
+      d_l[p][r] = g;
     }
-    // pass B: layer-1 maxima and their points
-    float f0 = 0.f, f1 = 0.f;
-    int pa = -1, pb = -1;
-    for (int i = s; i < e; ++i) {
-      decorate(a.pts + (size_t)a.order[i] * a.stride);
-      const float h = layer0();
-      float y0 = g0, y1 = g1;
+    __syncthreads();
+
+    for (int q = wib; q < NB && v0 + q < V; q += 4) {
+      const int s = m_s[q], e = m_e[q], n = e - s;
+      uint32_t key = m_key[q];
+      const int ri = key % a.R; key /= a.R;
+      const int ti = key % a.T;
+      const float rc = __fadd_rn(__fmul_rn((float)ri, a.vx), a.xoff);
+      const float pc = __fadd_rn(__fmul_rn((float)ti, a.vy), a.yoff);
+      const float xc = __fmul_rn(rc, cs_table[2 * ti]), yc = __fmul_rn(rc, cs_table[2 * ti + 1]);
+      float mx, my, mz, mr, mp;
+      float d[16];
+      auto decorate = [&](const float* p) {
+        const float rho = p[0], phi = p[1], z = p[2], x = p[3], y = p[4];
+        const float t[16] = {rho, phi, z, x, y, p[5], p[6], x - mx, y - my, z - mz, x - xc, y - yc, rho - mr, phi - mp, rho - rc, phi - pc};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = t[k];
+      };
+      auto layer0 = [&]() -> float {
+        float h = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) h = fmaf(w0[k], d[k], h);
+        return h > 0.f ? h : 0.f;
+      };
+      float u[C0];
+      if (n <= KP) {
+        // ---- everything from LDS; the layer-0 activations of the (at most KP) points stay in registers
+        long long sx = 0, sy = 0, sz = 0, sr = 0, sp = 0;
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+          if (j < n) {
+            const float* p = p_l[q][j];
+            sr += to_fix(p[0]); sp += to_fix(p[1]); sz += to_fix(p[2]); sx += to_fix(p[3]); sy += to_fix(p[4]);
+          }
+        const double inv_n = 1.0 / ((double)n * kFix);
+        mx = (float)((double)sx * inv_n); my = (float)((double)sy * inv_n); mz = (float)((double)sz * inv_n);
+        mr = (float)((double)sr * inv_n); mp = (float)((double)sp * inv_n);
+        float h[KP], m0 = 0.f;
+        int q0 = -1;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+          h[j] = 0.f;
+          if (j < n) {
+            decorate(p_l[q][j]);
+            h[j] = layer0();
+            if (h[j] > m0) { m0 = h[j]; q0 = j; }
+          }
+        }
+        float g0 = 0.f;
+#pragma unroll
+        for (int c = 0; c < C0; ++c) g0 = fmaf(w1[C0 + c], lane_bcast(m0, c), g0);
+        float f0 = 0.f;
+        int pa = -1;
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+          if (j < n) {
+            float y0 = g0;
+#pragma unroll
+            for (int c = 0; c < C0; ++c) y0 = fmaf(w1[c], lane_bcast(h[j], c), y0);
+            if (y0 > f0) { f0 = y0; pa = j; }
+          }
+        const float da = (la && pa >= 0) ? d_l[q][lane] : 0.f;
+#pragma unroll
+        for (int c = 0; c < C0; ++c) {
+          dw1[C0 + c] = fmaf(da, lane_bcast(m0, c), dw1[C0 + c]);
+          u[c] = da * w1[C0 + c];
+        }
+        const float dm0 = reduce_scatter<C0>(u, lane);
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+          if (j < n && __ballot((pa == j) || (q0 == j)) != 0ull) {
+            const float ea = pa == j ? da : 0.f;
+#pragma unroll
+            for (int c = 0; c < C0; ++c) {
+              dw1[c] = fmaf(ea, lane_bcast(h[j], c), dw1[c]);
+              u[c] = ea * w1[c];
+            }
+            float dh = reduce_scatter<C0>(u, lane);
+            if (q0 == j) dh += dm0;
+            const float dy0 = (lane < C0 && h[j] > 0.f) ? dh : 0.f;
+            decorate(p_l[q][j]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dw0[k] = fmaf(dy0, d[k], dw0[k]);
+          }
+        continue;
+      }
+      // ---- general path: points from global memory, three passes
+      long long sx = 0, sy = 0, sz = 0, sr = 0, sp = 0;
+      for (int i = s + lane; i < e; i += 64) {
+        const float* p = a.pts + (size_t)a.order[i] * a.stride;
+        sr += to_fix(p[0]); sp += to_fix(p[1]); sz += to_fix(p[2]); sx += to_fix(p[3]); sy += to_fix(p[4]);
+      }
+      const double inv_n = 1.0 / ((double)n * kFix);
+      mx = (float)((double)pn::wave_sum(sx) * inv_n); my = (float)((double)pn::wave_sum(sy) * inv_n);
+      mz = (float)((double)pn::wave_sum(sz) * inv_n); mr = (float)((double)pn::wave_sum(sr) * inv_n);
+      mp = (float)((double)pn::wave_sum(sp) * inv_n);
+      float m0 = 0.f;
+      int q0 = -1;
+      for (int i = s; i < e; ++i) {
+        decorate(a.pts + (size_t)a.order[i] * a.stride);
+        const float h = layer0();
+        if (h > m0) { m0 = h; q0 = i; }
+      }
+      float g0 = 0.f;
+#pragma unroll
+      for (int c = 0; c < C0; ++c) g0 = fmaf(w1[C0 + c], lane_bcast(m0, c), g0);
+      float f0 = 0.f;
+      int pa = -1;
+      for (int i = s; i < e; ++i) {
+        decorate(a.pts + (size_t)a.order[i] * a.stride);
+        const float h = layer0();
+        float y0 = g0;
+#pragma unroll
+        for (int c = 0; c < C0; ++c) y0 = fmaf(w1[c], lane_bcast(h, c), y0);
+        if (y0 > f0) { f0 = y0; pa = i; }
+      }
+      const float da = (la && pa >= 0) ? d_l[q][lane] : 0.f;
 #pragma unroll
       for (int c = 0; c < C0; ++c) {
-        const float hc = lane_bcast(h, c);
-        y0 = fmaf(w1a[c], hc, y0);
-        if (TWO) y1 = fmaf(w1b[c], hc, y1);
+        dw1[C0 + c] = fmaf(da, lane_bcast(m0, c), dw1[C0 + c]);
+        u[c] = da * w1[C0 + c];
       }
-      if (y0 > f0) { f0 = y0; pa = i; }
-      if (TWO && y1 > f1) { f1 = y1; pb = i; }
-    }
-    // incoming gradient of this pillar's C1 features (zero where the ReLU output is zero)
-    const float* dsrc = dcanvas ? dcanvas + (((size_t)bi * a.T + ti) * a.R + ri) * C1 : dfeat + (size_t)v * C1;
-    const float da = (la && pa >= 0) ? dsrc[lane] : 0.f;
-    const float db = (lb && pb >= 0) ? dsrc[lane + 64] : 0.f;
-    // voxel-constant half: dW1[:, C0 + c] += dy1 * m0[c];  dm0[c] = sum_n dy1[n] W1[n][C0 + c]
-    float u[C0];
+      const float dm0 = reduce_scatter<C0>(u, lane);
+      for (int i = s; i < e; ++i) {
+        if (__ballot((pa == i) || (q0 == i)) == 0ull) continue;  // this point receives no gradient
+        decorate(a.pts + (size_t)a.order[i] * a.stride);
+        const float h = layer0();
+        const float ea = pa == i ? da : 0.f;
 #pragma unroll
-    for (int c = 0; c < C0; ++c) {
-      const float m = lane_bcast(m0, c);
-      dwa[C0 + c] = fmaf(da, m, dwa[C0 + c]);
-      u[c] = da * w1a[C0 + c];
-      if (TWO) { dwb[C0 + c] = fmaf(db, m, dwb[C0 + c]); u[c] += db * w1b[C0 + c]; }
-    }
-    const float dm0 = reduce_scatter<C0>(u, lane);  // lane l: dm0[l & (C0-1)]
-    // pass C: per point, the per-point half of dW1 and dW0
-    for (int i = s; i < e; ++i) {
-      // points that receive no gradient at all (no layer-1 argmax, no layer-0 argmax) are skipped
-      const bool hit = (pa == i) || (pb == i) || (q0 == i);
-      if (__ballot(hit) == 0ull) continue;
-      decorate(a.pts + (size_t)a.order[i] * a.stride);
-      const float h = layer0();
-      const float ea = pa == i ? da : 0.f, eb = pb == i ? db : 0.f;
+        for (int c = 0; c < C0; ++c) {
+          dw1[c] = fmaf(ea, lane_bcast(h, c), dw1[c]);
+          u[c] = ea * w1[c];
+        }
+        float dh = reduce_scatter<C0>(u, lane);
+        if (q0 == i) dh += dm0;
+        const float dy0 = (lane < C0 && h > 0.f) ? dh : 0.f;
 #pragma unroll
-      for (int c = 0; c < C0; ++c) {
-        const float hc = lane_bcast(h, c);
-        dwa[c] = fmaf(ea, hc, dwa[c]);
-        u[c] = ea * w1a[c];
-        if (TWO) { dwb[c] = fmaf(eb, hc, dwb[c]); u[c] += eb * w1b[c]; }
+        for (int k = 0; k < 16; ++k) dw0[k] = fmaf(dy0, d[k], dw0[k]);
       }
-      float dh = reduce_scatter<C0>(u, lane);   // lane c: dh0[i][c]
-      if (q0 == i) dh += dm0;
-      const float dy0 = (lane < C0 && h > 0.f) ? dh : 0.f;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) dw0[k] = fmaf(dy0, d[k], dw0[k]);
     }
   }
-  float* slab = slabs + (size_t)wave * SLAB;
-  if (la) {
+  float* slab = slabs + ((size_t)blockIdx.y * nwaves + wave) * SLAB;
 #pragma unroll
-    for (int k = 0; k < K1; ++k) slab[lane * K1 + k] = dwa[k];
-  }
-  if (lb) {
-#pragma unroll
-    for (int k = 0; k < K1; ++k) slab[(lane + 64) * K1 + k] = dwb[k];
-  }
+  for (int k = 0; k < K1; ++k) slab[lane * K1 + k] = dw1[k];
   if (lane < C0) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) slab[C1 * K1 + lane * 16 + k] = dw0[k];
+    for (int k = 0; k < 16; ++k) slab[64 * K1 + lane * 16 + k] = dw0[k];
   }
 }
 
-__global__ void pfn_bwd_reduce_kernel(const float* __restrict__ slabs, int nwaves, int slab, int w1_floats, float* __restrict__ dw0,
-                                      float* __restrict__ dw1, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= slab) return;
+// one output per 4 threads: thread part p adds the slabs of the waves w = p (mod 4) in order, the four partial
+// sums are combined in a fixed order
+__global__ __launch_bounds__(256) void pfn_bwd_reduce_kernel(const float* __restrict__ slabs, int nwaves, int passes, int c0, int c1,
+                                                             float* __restrict__ dw0, float* __restrict__ dw1, int accumulate) {
+  __shared__ float red[4][64];
+  const int k1 = 2 * c0, slab = 64 * k1 + c0 * 16, w1_floats = c1 * k1;
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
   float t = 0.f;
-  for (int w = 0; w < nwaves; ++w) t += slabs[(size_t)w * slab + i];
-  float* dst = i < w1_floats ? dw1 + i : dw0 + (i - w1_floats);
-  *dst = accumulate ? *dst + t : t;
+  if (o < w1_floats + c0 * 16) {
+    if (o < w1_floats) {
+      const int row = o / k1, pass = row >> 6, local = (row & 63) * k1 + (o - row * k1);
+      for (int w = part; w < nwaves; w += 4) t += slabs[((size_t)pass * nwaves + w) * slab + local];
+    } else {
+      const int local = 64 * k1 + (o - w1_floats);
+      for (int ps = 0; ps < passes; ++ps)
+        for (int w = part; w < nwaves; w += 4) t += slabs[((size_t)ps * nwaves + w) * slab + local];
+    }
+  }
+  red[part][threadIdx.x & 63] = t;
+  __syncthreads();
+  if (part == 0 && o < w1_floats + c0 * 16) {
+    const int l = threadIdx.x;
+    const float sum = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    float* dst = o < w1_floats ? dw1 + o : dw0 + (o - w1_floats);
+    *dst = accumulate ? *dst + sum : sum;
+  }
 }
 
 // cos / sin of every pillar-centre azimuth of the grid: table[2*t] = cos(t*vy + yoff), [2*t+1] = sin(...)
@@ -675,10 +785,10 @@ int pn_scatter_canvas_fwd(const float* features, const int64_t* unq, const int32
   return pn::check_launch("scatter_canvas_kernel");
 }
 
-constexpr int kPfnBwdBlocks = 256;  // 1024 waves, one per SIMD
-constexpr int kPfnBwdSlabMax = 128 * 64 + 32 * 16;
+constexpr int kPfnBwdBlocks = 256;  // x 2 passes x 4 waves = two waves per SIMD for the (32, 128) reader
+constexpr int kPfnBwdSlabMax = 64 * 64 + 32 * 16;
 
-size_t pn_dynamic_pfn_bwd_workspace_bytes(void) { return (size_t)kPfnBwdBlocks * 4 * kPfnBwdSlabMax * sizeof(float); }
+size_t pn_dynamic_pfn_bwd_workspace_bytes(void) { return (size_t)kPfnBwdBlocks * 4 * 2 * kPfnBwdSlabMax * sizeof(float); }
 
 int pn_dynamic_pfn_bwd(const float* points, int point_stride, const int32_t* voxel_start, const int32_t* order,
                        const int32_t* num_voxels, int v_capacity, const uint32_t* unq_keys, const int32_t* grid, const float* w0,
@@ -694,13 +804,14 @@ int pn_dynamic_pfn_bwd(const float* points, int point_stride, const int32_t* vox
   PfnArgs a{points, point_stride, voxel_start, order, num_voxels, v_capacity, unq_keys, grid[0], grid[1], grid[2],
             w0, c0, w1, c1, vx, vy, x_offset, y_offset, nullptr, nullptr};
   float* slabs = static_cast<float*>(workspace);
-  const int slab = c1 * 2 * c0 + c0 * 16;
+  const int passes = pn::cdiv(c1, 64);
   if (c0 == 32)
-    hipLaunchKernelGGL((dynamic_pfn_bwd_kernel<32, 128>), dim3(kPfnBwdBlocks), dim3(256), 0, pn::S(stream), a, center_table, d_features, d_canvas, slabs);
+    hipLaunchKernelGGL((dynamic_pfn_bwd_kernel<32, 128>), dim3(kPfnBwdBlocks, passes), dim3(256), 0, pn::S(stream), a, center_table, d_features, d_canvas, slabs);
   else
-    hipLaunchKernelGGL((dynamic_pfn_bwd_kernel<16, 32>), dim3(kPfnBwdBlocks), dim3(256), 0, pn::S(stream), a, center_table, d_features, d_canvas, slabs);
-  hipLaunchKernelGGL(pfn_bwd_reduce_kernel, dim3(pn::cdiv(slab, 256)), dim3(256), 0, pn::S(stream), slabs, kPfnBwdBlocks * 4, slab,
-                     c1 * 2 * c0, dw0, dw1, accumulate);
+    hipLaunchKernelGGL((dynamic_pfn_bwd_kernel<16, 32>), dim3(kPfnBwdBlocks, passes), dim3(256), 0, pn::S(stream), a, center_table, d_features, d_canvas, slabs);
+  const int outs = c1 * 2 * c0 + c0 * 16;
+  hipLaunchKernelGGL(pfn_bwd_reduce_kernel, dim3(pn::cdiv(outs, 64)), dim3(256), 0, pn::S(stream), slabs, kPfnBwdBlocks * 4, passes, c0, c1,
+                     dw0, dw1, accumulate);
   return pn::check_launch("dynamic_pfn_bwd");
 }
 
