@@ -21,6 +21,7 @@
 // column i -- 32 consecutive floats per half, and 4 * (BM + 8) = 32 (mod 64) banks puts the two
 // halves on disjoint banks.
 #include "pn_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -36,7 +37,7 @@ struct WgradArgs {
   int in_ps, in_co, dy_ps, dy_co;
   int M;            // B * OH * OW
   int m_per_split;  // multiple of 32
-  int ci_tiles;
+  int ci_tiles, co_tiles, tiles_per_split, splits;
   int cin_pad, cout_pad;
   unsigned in_bytes, dy_bytes;
 };
@@ -55,10 +56,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const int split = blockIdx.x;
-  const int tap = blockIdx.y / a.ci_tiles, cit = blockIdx.y - tap * a.ci_tiles;
+  // Block order: all (tap, ci tile, co tile) blocks of one pixel slice are neighbours in dispatch order AND
+  // on the same XCD (blocks are dealt round-robin over the 8 XCDs): they read the same dY rows and
+  // overlapping X rows, which then come from that XCD's L2 instead of HBM (9 taps = 9x less HBM traffic).
+  const int per_split = a.tiles_per_split;                 // taps * ci_tiles * co_tiles
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int split = (kq / per_split) * 8 + xcd;
+  if (split >= a.splits) return;
+  int t = kq - (kq / per_split) * per_split;
+  const int cot = t % a.co_tiles; t /= a.co_tiles;
+  const int cit = t % a.ci_tiles;
+  const int tap = t / a.ci_tiles;
   const int kh = tap / a.KW, kw = tap - kh * a.KW;
-  const int ci0 = cit * BM, co0 = blockIdx.z * BN;
+  const int ci0 = cit * BM, co0 = cot * BN;
   const int m_begin = split * a.m_per_split;
   const int m_end = min(a.M, m_begin + a.m_per_split);
   const int nsteps = (m_end - m_begin + WK - 1) / WK;
@@ -180,8 +190,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
     const int ci = (int)(r % cin);
     const int tap = (int)(r / cin);
     const float* p = part + ((size_t)tap * cin_pad + ci) * cout_pad + co;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += p[k * slice];
+    // four independent partial sums (fixed association): the loads of one round are in flight together
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {
+      s0 += p[(size_t)k * slice]; s1 += p[(size_t)(k + 1) * slice]; s2 += p[(size_t)(k + 2) * slice]; s3 += p[(size_t)(k + 3) * slice];
+    }
+    for (; k < splits; ++k) s0 += p[(size_t)k * slice];
+    const float s = (s0 + s1) + (s2 + s3);
     float* d = dw + ((size_t)co * cin + ci) * taps + tap;
     *d = accumulate ? *d + s : s;
   }
@@ -257,6 +273,9 @@ __global__ void pack_dgrad_s2_kernel(const float* __restrict__ w, int cout, int 
   }
 }
 
+// blocks per launch the pixel range is split for (measured on MI355X at B=4: 512 -> 71 TF, 1024 -> 82, 2048 -> 86)
+static const int kWgradTargetBlocks = [] { const char* e = getenv("PN_WGRAD_BLOCKS"); return e ? atoi(e) : 2048; }();
+
 struct WgradPlan {
   int tm, tn, bm, bn, ci_tiles, co_tiles, cin_pad, cout_pad, splits, m_per_split, taps;
   long long M;
@@ -280,7 +299,7 @@ int plan_wgrad(const pn_conv_desc* d, WgradPlan& p) {
   p.cin_pad = p.ci_tiles * p.bm; p.cout_pad = p.co_tiles * p.bn;
   p.taps = d->kh * d->kw;
   const long long tiles = (long long)p.taps * p.ci_tiles * p.co_tiles;
-  long long s = std::max<long long>(1, (1024 + tiles - 1) / tiles);
+  long long s = std::max<long long>(1, (kWgradTargetBlocks + tiles - 1) / tiles);
   s = std::min<long long>(s, std::max<long long>(1, p.M / 256));
   p.m_per_split = (int)(((p.M + s - 1) / s + WK - 1) / WK * WK);
   p.splits = (int)((p.M + p.m_per_split - 1) / p.m_per_split);
@@ -295,7 +314,9 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN>), dim3(p.splits, p.taps * p.ci_tiles, p.co_tiles), dim3(256), smem, st, a);
+  const int per_split = p.taps * p.ci_tiles * p.co_tiles;
+  const int groups8 = pn::cdiv(p.splits, 8);  // splits are handed out in groups of 8, one per XCD
+  hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN>), dim3(groups8 * per_split * 8), dim3(256), smem, st, a);
   return pn::check_launch("conv_wgrad_kernel");
 }
 
@@ -331,6 +352,7 @@ int pn_conv2d_wgrad_f32(const pn_conv_desc* d, const float* in, const float* dou
   a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
   a.in_ps = d->in_pixel_stride; a.in_co = d->in_channel_offset; a.dy_ps = d->out_pixel_stride; a.dy_co = d->out_channel_offset;
   a.M = (int)p.M; a.m_per_split = p.m_per_split; a.ci_tiles = p.ci_tiles; a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;
+  a.co_tiles = p.co_tiles; a.tiles_per_split = p.taps * p.ci_tiles * p.co_tiles; a.splits = p.splits;
   a.in_bytes = (unsigned)in_bytes; a.dy_bytes = (unsigned)dy_bytes;
   hipStream_t st = pn::S(stream);
   int rc;
