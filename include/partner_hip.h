@@ -176,10 +176,10 @@ int pn_dynamic_pfn_fwd_table(const float *points, int point_stride, const int32_
 /* pointer to the uint32 key-per-voxel array inside a pn_unique_rank_bitmap workspace */
 const uint32_t *pn_unique_keys_ptr(const void *workspace, uint64_t num_cells, int n_capacity);
 
-/* Backward of the (C0, C1) = (32, 128) pillar feature net: gradients of the two Linear weights
+/* Backward of the pillar feature net, (C0, C1) = (32, 128) or (16, 32): gradients of the two Linear weights
  * (autograd through pillar_encoder.py:393-406 / 63-71; the points are data, no gradient).
  * The incoming gradient is either d_features (V,128) or the dense canvas gradient d_canvas
- * (B,T,R,128) NHWC, of which only the occupied cells are read (= backward of DynamicPPScatter,
+ * (B,T,R,C1) NHWC, of which only the occupied cells are read (= backward of DynamicPPScatter,
  * pillar_encoder.py:418-432, fused).  dw0 (32,16), dw1 (128,64) in torch layout.  The maximum's
  * gradient goes to the first point attaining it (torch_scatter.scatter_max semantics).
  * Deterministic: per-wave partial sums, added in wave order. */
