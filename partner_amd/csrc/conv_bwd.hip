@@ -28,6 +28,25 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// unsigned division by a launch-time constant without a divide or a branch (Granlund-Montgomery):
+// q = (t + ((n - t) >> s1)) >> s2 with t = umulhi(m, n)
+struct FastDiv {
+  unsigned m, s1, s2;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  FastDiv f;
+  f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l > 0 ? l - 1 : 0;
+  return f;
+}
+__device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv f) {
+  const unsigned t = __umulhi(f.m, n);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 struct WgradArgs {
   const float* in;
   const float* dy;
@@ -40,9 +59,11 @@ struct WgradArgs {
   int ci_tiles, co_tiles, tiles_per_split, splits;
   int cin_pad, cout_pad;
   unsigned in_bytes, dy_bytes;
+  FastDiv div_ohw, div_ow;
 };
 
 constexpr int WK = 32;  // pixels per K step
+
 
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
@@ -79,16 +100,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   // this thread's pixels: A rows pa + A_ROWS*j, B rows pb + B_ROWS*j of every 32-pixel step
   const int ca = tid % (BM / 4), pa = tid / (BM / 4);
   const int cb = tid % (BN / 4), pb = tid / (BN / 4);
-  int a_b[A_PER_T], a_oh[A_PER_T], a_ow[A_PER_T];  // (b, oh, ow) of the A pixels, advanced by 32 per step
-#pragma unroll
-  for (int j = 0; j < A_PER_T; ++j) {
-    const int m = m_begin + pa + A_ROWS * j;
-    const int ohw = a.OH * a.OW;
-    a_b[j] = m / ohw;
-    const int rem = m - a_b[j] * ohw;
-    a_oh[j] = rem / a.OW;
-    a_ow[j] = rem - a_oh[j] * a.OW;
-  }
   const unsigned a_chan = (unsigned)(a.in_co + ci0 + ca * 4);
   const bool a_cok = ci0 + ca * 4 < a.Cin;
   const unsigned b_chan = (unsigned)(a.dy_co + co0 + cb * 4);
@@ -99,20 +110,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   auto load_global = [&]() {
 #pragma unroll
     for (int j = 0; j < A_PER_T; ++j) {
-      const int ih = a_oh[j] * a.stride - a.pad_h + kh, iw = a_ow[j] * a.stride - a.pad_w + kw;
-      const bool ok = a_cok && (ld_m + pa + A_ROWS * j < m_end) && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-      const long long pix = ((long long)a_b[j] * a.H + ih) * a.W + iw;
-      const unsigned vo = ok ? (unsigned)((pix * a.in_ps + a_chan) * 4) : 0xffffffffu;
+      // (b, oh, ow) of output pixel m by multiply-shift division: branch-free, no per-row state
+      const unsigned m = (unsigned)(ld_m + pa + A_ROWS * j);
+      const unsigned b = fast_div(m, a.div_ohw);
+      const unsigned rem = m - b * (unsigned)(a.OH * a.OW);
+      const unsigned oh = fast_div(rem, a.div_ow);
+      const unsigned ow = rem - oh * (unsigned)a.OW;
+      const int ih = (int)oh * a.stride - a.pad_h + kh, iw = (int)ow * a.stride - a.pad_w + kw;
+      const bool ok = a_cok && ((int)m < m_end) && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      const unsigned pix = (b * (unsigned)a.H + (unsigned)ih) * (unsigned)a.W + (unsigned)iw;  // < 2^29 pixels (2 GiB map)
+      const unsigned vo = ok ? (pix * (unsigned)a.in_ps + a_chan) * 4u : 0xffffffffu;
       ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, 0, 0));
-      // advance to the same row of the next step
-      a_ow[j] += WK;
-      while (a_ow[j] >= a.OW) { a_ow[j] -= a.OW; ++a_oh[j]; }
-      while (a_oh[j] >= a.OH) { a_oh[j] -= a.OH; ++a_b[j]; }
     }
 #pragma unroll
     for (int j = 0; j < B_PER_T; ++j) {
       const int m = ld_m + pb + B_ROWS * j;
-      const unsigned vo = (b_cok && m < m_end) ? (unsigned)(((long long)m * a.dy_ps + b_chan) * 4) : 0xffffffffu;
+      const unsigned vo = (b_cok && m < m_end) ? ((unsigned)m * (unsigned)a.dy_ps + b_chan) * 4u : 0xffffffffu;
       rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vo, 0, 0));
     }
     ld_m += WK;
@@ -142,11 +155,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   for (int t = 0; t < nsteps; ++t) {
     const int buf = t & 1;
     const bool more = t + 1 < nsteps;
-    if (more) load_global();
     const float* As = smem + buf * STAGE + wm * TM * 32 + li;
     const float* Bs = smem + buf * STAGE + WK * LDA + wn * TN * 32 + li;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    auto sub_step = [&](int s) {
       float fa[4][TM], fb[4][TN];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -163,7 +174,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
-    }
+    };
+    // the address arithmetic and the issue of the next tile's loads sit in the shadow of the first
+    // sub-step's MFMAs (the matrix pipe runs them while the wave issues VALU / VMEM instructions)
+    sub_step(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) load_global();
+    __builtin_amdgcn_sched_barrier(0);
+    sub_step(1);
+    sub_step(2);
+    sub_step(3);
     if (more) store_lds(buf ^ 1);
     __syncthreads();
   }
@@ -273,8 +293,8 @@ __global__ void pack_dgrad_s2_kernel(const float* __restrict__ w, int cout, int 
   }
 }
 
-// blocks per launch the pixel range is split for (measured on MI355X at B=4: 512 -> 71 TF, 1024 -> 82, 2048 -> 86)
-static const int kWgradTargetBlocks = [] { const char* e = getenv("PN_WGRAD_BLOCKS"); return e ? atoi(e) : 2048; }();
+// blocks per launch the pixel range is split for (512 block slots per launch: 2 blocks x 256 CUs; 1536 = three full rounds measured best at B=4, 94 TFLOP/s over the model layers)
+static const int kWgradTargetBlocks = [] { const char* e = getenv("PN_WGRAD_BLOCKS"); return e ? atoi(e) : 1536; }();
 
 struct WgradPlan {
   int tm, tn, bm, bn, ci_tiles, co_tiles, cin_pad, cout_pad, splits, m_per_split, taps;
@@ -299,7 +319,7 @@ int plan_wgrad(const pn_conv_desc* d, WgradPlan& p) {
   p.cin_pad = p.ci_tiles * p.bm; p.cout_pad = p.co_tiles * p.bn;
   p.taps = d->kh * d->kw;
   const long long tiles = (long long)p.taps * p.ci_tiles * p.co_tiles;
-  long long s = std::max<long long>(1, (kWgradTargetBlocks + tiles - 1) / tiles);
+  long long s = std::max<long long>(1, kWgradTargetBlocks / tiles);  // never one block over a full round of the 512 block slots
   s = std::min<long long>(s, std::max<long long>(1, p.M / 256));
   p.m_per_split = (int)(((p.M + s - 1) / s + WK - 1) / WK * WK);
   p.splits = (int)((p.M + p.m_per_split - 1) / p.m_per_split);
@@ -354,6 +374,7 @@ int pn_conv2d_wgrad_f32(const pn_conv_desc* d, const float* in, const float* dou
   a.M = (int)p.M; a.m_per_split = p.m_per_split; a.ci_tiles = p.ci_tiles; a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;
   a.co_tiles = p.co_tiles; a.tiles_per_split = p.taps * p.ci_tiles * p.co_tiles; a.splits = p.splits;
   a.in_bytes = (unsigned)in_bytes; a.dy_bytes = (unsigned)dy_bytes;
+  a.div_ohw = make_fastdiv((unsigned)(p.OH * p.OW)); a.div_ow = make_fastdiv((unsigned)p.OW);
   hipStream_t st = pn::S(stream);
   int rc;
   if (p.tm == 2 && p.tn == 2) rc = launch_wgrad<2, 2>(a, p, st);
