@@ -398,6 +398,24 @@ int pn_setblock_sector_col_attn(const float *q, const float *kv_raw, const float
                                 pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * H3  window attention of the geometry-aware head E2ESWVoteHead
+ * (WindowAttention / SwinTransformerBlock, det3d/models/bbox_heads/swin_utils/sw2votev4_util.py:65-103,
+ * 127-188; that file cannot run in the reference -- semantics = the repaired restatement in
+ * oracle/polar_oracle.py, parity unpinned by the reference).
+ * qkv: (B,H,W,3C) token map = Linear(C,3C) (bias included) of the LayerNorm-ed tokens; qkv_bias (3C,
+ * nullable) is what the zero-padded tokens outside the map see; vote: (B,H,W,>=3) = (pred_centers, vote_cls);
+ * pos: (H,W,2) Cartesian cell centres; vote MLP 3->16->C, rpe MLP 2->16->heads (1x1 conv weights),
+ * tau (heads).  window = 7, head_dim = 64; shift = 0 or window/2.  out: (B,H,W,C) attention output
+ * before the projection.  Zero padding to window multiples, cyclic shift, window partition, the shift
+ * mask and their inverses are index arithmetic inside the kernel. */
+int pn_swv_window_attn(const float *qkv, const float *vote, int vote_pixel_stride, const float *pos,
+                       const float *qkv_bias, const float *vote_w1, const float *vote_b1,
+                       const float *vote_w2, const float *vote_b2, const float *rpe_w1,
+                       const float *rpe_b1, const float *rpe_w2, const float *rpe_b2, const float *tau,
+                       int batch, int h, int w, int c, int heads, int window, int shift, float *out,
+                       pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * L1  CenterPoint loss, forward value.
  * Replaces CenterHead.loss / _sigmoid      det3d/models/bbox_heads/center_head.py:244-288
  *          FastFocalLoss, RegLoss           det3d/models/losses/centernet_loss.py:26-54, 6-24

@@ -1,0 +1,247 @@
+"""E2ESWVoteHead: the geometry-aware head of the Waymo PARTNER config.
+
+Reference: det3d/models/bbox_heads/e2e_swv_head.py:22-201 and
+det3d/models/bbox_heads/swin_utils/sw2votev4_util.py:42-419.  The reference class cannot be
+constructed or run (unregistered, misspelled keyword arguments and function names, undefined
+variables, layers that are never appended -- SURVEY F3), so this module implements the *intended*
+computation as restated in ``oracle/polar_oracle.py::e2e_swv_head`` (parity unpinned by the
+reference) and takes the head section of ``configs/waymo/voxelnet/waymo_partner_36epoch.py``
+unchanged (its key spellings, e.g. ``kernel_size`` / ``sl_depth`` / ``weight_dict``).
+
+Forward only, eval mode, on the HIP kernels: 3x3 convolutions and the four linear layers of every
+Swin block on the MFMA kernel, LayerNorm, and ``pn_swv_window_attn`` for the shifted-window cosine
+attention with vote embedding and Cartesian relative-position bias.  Loss / target assignment
+(SetCriterion, TimeMatcher, GroundTruthProcessor) are outside this round.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import hip, ops
+from .builder import BBOX_HEADS
+from .nn_utils import PlanCache, Sequential, eval_only
+
+
+class _WindowAttention(nn.Module):
+    """parameters of WindowAttention (sw2votev4_util.py:42-63)"""
+
+    def __init__(self, dim, num_heads, qkv_bias=True):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.tau = nn.Parameter(torch.ones(1, num_heads, 1, 1))
+        self.rpe = nn.Sequential(nn.Conv2d(2, 16, kernel_size=1, bias=True), nn.ReLU(), nn.Conv2d(16, num_heads, kernel_size=1, bias=True))
+        self.vote_mlp = nn.Sequential(nn.Conv1d(3, 16, kernel_size=1, bias=True), nn.ReLU(), nn.Conv1d(16, dim, kernel_size=1, bias=True))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1, self.act, self.fc2 = nn.Linear(dim, hidden), nn.GELU(), nn.Linear(hidden, dim)
+
+
+class _SwinBlock(nn.Module):
+    def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio):
+        super().__init__()
+        self.window_size, self.shift_size = window_size, shift_size
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = _WindowAttention(dim, num_heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+
+class _BasicLayer(nn.Module):
+    def __init__(self, dim, depth, num_heads, window_size, mlp_ratio):
+        super().__init__()
+        self.blocks = nn.ModuleList([_SwinBlock(dim, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2, mlp_ratio)
+                                     for i in range(depth)])
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, in_chans, embed_dim):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=1, stride=1)
+        self.norm = nn.LayerNorm(embed_dim)
+
+
+class SwVoteHeadV4(nn.Module):
+    """SwinTransformer(embed_dim, depth=[d], num_heads=[4], window 7, mlp_ratio 1, patch embed 1x1)
+    (sw2votev4_util.py:294-388): one BasicLayer + ``norm0``"""
+
+    def __init__(self, embed_dim=256, depth=(2,), num_heads=(4,), window_size=7, mlp_ratio=1.0, in_ch=512):
+        super().__init__()
+        assert len(depth) == 1, "the PARTNER config uses a single Swin stage"
+        self.embed_dim, self.window_size, self.num_heads = embed_dim, window_size, num_heads[0]
+        self.patch_embed = _PatchEmbed(in_ch, embed_dim)
+        self.layers = nn.ModuleList([_BasicLayer(embed_dim, depth[0], num_heads[0], window_size, mlp_ratio)])
+        self.norm0 = nn.LayerNorm(embed_dim)
+
+
+def _cfg_get(cfg, *names, default=None):
+    for n in names:
+        if n in cfg:
+            return cfg[n]
+    return default
+
+
+@BBOX_HEADS.register_module
+class E2ESWVoteHead(nn.Module):
+    def __init__(self, in_channels=[128, ], tasks=[], dataset="nuscenes", weight=0.25, code_weights=[], common_heads=dict(),
+                 logger=None, init_bias=-2.19, share_conv_channel=64, num_hm_conv=2, dcn_head=False, voxel_shape="cuboid",
+                 voxel_generator=None, out_size_factor=4, npixels=0, SET_CRIT_CONFIG=dict(), MATCHER_CONFIG=dict(),
+                 USE_FOCAL_LOSS=True, GT_PROCESSOR_CONFIG=dict(), CODER_CONFIG=dict(), HEAD_CONFIG=dict()):
+        super().__init__()
+        head_conv = 64
+        self.dataset, self.voxel_shape, self.period = dataset, voxel_shape, 2 * np.pi
+        self.class_names = [t["class_names"] for t in tasks]
+        self.num_classes = [t["num_class"] for t in tasks]
+        self.code_weights, self.weight = code_weights, weight
+        ks = _cfg_get(HEAD_CONFIG, "kernel_size", "kernal_size", default=3)
+        if _cfg_get(HEAD_CONFIG, "sw_head_version", default="votev4") != "votev4":
+            raise NotImplementedError("only sw_head_version='votev4' exists in the reference")
+        self.window_size = _cfg_get(HEAD_CONFIG, "window_size", default=7)
+        self.sl_depths = list(_cfg_get(HEAD_CONFIG, "sl_depth", "sl_depths", default=[2]))
+        self.iou_loss = bool(_cfg_get(HEAD_CONFIG, "iou_loss", default=False))
+        self.iou_factor = _cfg_get(HEAD_CONFIG, "iou_factor", default=False)
+        n_cls = _cfg_get(HEAD_CONFIG, "num_classes", default=sum(self.num_classes) or 1)
+        embed = in_channels // 2
+        self.layer = SwVoteHeadV4(embed_dim=embed, depth=self.sl_depths, num_heads=(4,), window_size=self.window_size, mlp_ratio=1.0,
+                                  in_ch=in_channels)
+
+        def cbr(cin, cout):
+            return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1, bias=True), nn.BatchNorm2d(cout), nn.ReLU())
+
+        self.cls_head = nn.Sequential(cbr(embed, embed), cbr(embed, embed),
+                                      nn.Conv2d(embed, n_cls, kernel_size=ks, stride=1, padding=ks // 2))
+        code_size = _cfg_get(HEAD_CONFIG, "code_size", default=7) + (1 if _cfg_get(HEAD_CONFIG, "encode_angle_by_sincos", default=True) else 0)
+        self.code_size = code_size
+
+        def two(cin, cout):
+            return nn.Sequential(nn.Conv2d(cin, head_conv, kernel_size=ks, stride=1, padding=ks // 2), nn.ReLU(inplace=True),
+                                 nn.Conv2d(head_conv, cout, kernel_size=ks, stride=1, padding=ks // 2))
+
+        self.bbox_head = two(embed, code_size)
+        if self.iou_loss:
+            self.iou_head = two(embed, 1)
+        self.vote_head = two(in_channels, 2)
+        self.vote_cls_head = nn.Sequential(nn.Conv2d(in_channels, embed, kernel_size=3, stride=1, padding=1, bias=True), nn.BatchNorm2d(embed),
+                                           nn.ReLU(), nn.Conv2d(embed, 1, kernel_size=ks, stride=1, padding=ks // 2))
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self.cls_head[-1].bias.data.fill_(_cfg_get(HEAD_CONFIG, "init_bias", default=init_bias))
+        gp = GT_PROCESSOR_CONFIG
+        self.max_volumn_space, self.min_volumn_space = gp.get("max_volumn_space"), gp.get("min_volumn_space")
+        self.grid_size = gp.get("grid_size")
+        self.out_size_factor = out_size_factor
+        self.set_crit_config, self.matcher_config, self.coder_config = dict(SET_CRIT_CONFIG), dict(MATCHER_CONFIG), dict(CODER_CONFIG)
+        self._generate_offset_grid()
+        self._plan = PlanCache()
+        (logger or logging.getLogger("E2ESWVoteHead")).info("Finish E2ESWVoteHead Initialization")
+
+    def _generate_offset_grid(self):
+        """Cartesian cell-centre coordinates of the polar map (e2e_swv_head.py:175-192)"""
+        if self.grid_size is None:
+            self.register_buffer("offset_grid", torch.zeros(1, 2, 1, 1))
+            self.register_buffer("xy_offset", torch.zeros(1, 2, 1, 1))
+            return
+        x, y = int(self.grid_size[0]) // self.out_size_factor, int(self.grid_size[1]) // self.out_size_factor
+        xmin, ymin = float(self.min_volumn_space[0]), float(self.min_volumn_space[1])
+        xmax, ymax = float(self.max_volumn_space[0]), float(self.max_volumn_space[1])
+        xoff, yoff = (xmax - xmin) / x, (ymax - ymin) / y
+        yv, xv = torch.meshgrid(torch.arange(y), torch.arange(x), indexing="ij")
+        yv = (yv.float() + 0.5) * yoff + ymin
+        xv = (xv.float() + 0.5) * xoff + xmin
+        self.register_buffer("offset_grid", torch.stack([xv * torch.cos(yv), xv * torch.sin(yv)], 0)[None])
+        self.register_buffer("xy_offset", torch.tensor([xoff, yoff]).view(1, 2, 1, 1))
+
+    def get_proper_xy(self, pred_boxes):
+        """e2e_swv_head.py:194-198"""
+        return torch.cat([pred_boxes[:, :2] + self.offset_grid, pred_boxes[:, 2:]], dim=1)
+
+    # ---------------------------------------------------------------------------------------
+    def _build_plan(self):
+        def conv(m, act, bn=None):
+            if bn is None:
+                return ops.ConvLayer(m.weight, stride=1, pad=m.padding[0], shift=m.bias, act=act)
+            scale, shift = ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, m.bias)
+            return ops.ConvLayer(m.weight, stride=1, pad=m.padding[0], scale=scale, shift=shift, act=act)
+
+        def two(seq):
+            return conv(seq[0], ops.ACT_RELU), conv(seq[2], ops.ACT_NONE)
+
+        L = self.layer
+        plan = dict(vote=two(self.vote_head),
+                    vote_cls=(conv(self.vote_cls_head[0], ops.ACT_RELU, self.vote_cls_head[1]), conv(self.vote_cls_head[3], ops.ACT_NONE)),
+                    patch=ops.GemmLayer(L.patch_embed.proj.weight.flatten(1), L.patch_embed.proj.bias),
+                    cls=(conv(self.cls_head[0][0], ops.ACT_RELU, self.cls_head[0][1]), conv(self.cls_head[1][0], ops.ACT_RELU, self.cls_head[1][1]),
+                         conv(self.cls_head[2], ops.ACT_NONE)),
+                    bbox=two(self.bbox_head), iou=two(self.iou_head) if self.iou_loss else None, blocks=[])
+        for blk in L.layers[0].blocks:
+            a = blk.attn
+            f = lambda t: t.detach().float().contiguous()  # noqa: E731
+            plan["blocks"].append(dict(
+                qkv=ops.GemmLayer(a.qkv.weight, a.qkv.bias), proj=ops.GemmLayer(a.proj.weight, a.proj.bias),
+                fc1=ops.GemmLayer(blk.mlp.fc1.weight, blk.mlp.fc1.bias), fc2=ops.GemmLayer(blk.mlp.fc2.weight, blk.mlp.fc2.bias),
+                qkv_bias=None if a.qkv.bias is None else f(a.qkv.bias), vw1=f(a.vote_mlp[0].weight).view(16, 3), vb1=f(a.vote_mlp[0].bias),
+                vw2=f(a.vote_mlp[2].weight).view(-1, 16), vb2=f(a.vote_mlp[2].bias), rw1=f(a.rpe[0].weight).view(16, 2), rb1=f(a.rpe[0].bias),
+                rw2=f(a.rpe[2].weight).view(-1, 16), rb2=f(a.rpe[2].bias), tau=f(a.tau).view(-1), shift=blk.shift_size, mod=blk))
+        plan["pos"] = self.offset_grid[0].permute(1, 2, 0).contiguous().float()  # (H, W, 2)
+        return plan
+
+    def forward_nhwc(self, x: torch.Tensor):
+        """x: NHWC (B,H,W,Cin) -> dict of NHWC tensors"""
+        eval_only(self, "E2ESWVoteHead")
+        hip.require_device(x)
+        plan = self._plan.get(self, self._build_plan)
+        b, h, w, cin = x.shape
+        if tuple(plan["pos"].shape[:2]) != (h, w):
+            raise ValueError(f"head input map {(h, w)} does not match the configured offset grid {tuple(plan['pos'].shape[:2])}")
+        C, heads, ws = self.layer.embed_dim, self.layer.num_heads, self.window_size
+        # vote branch: (pred_centers | vote_cls | pad) in one 4-channel map read by the attention kernel
+        vote = torch.zeros((b, h, w, 4), dtype=torch.float32, device=x.device)
+        plan["vote"][1](plan["vote"][0](x), out=vote, out_channel_offset=0)
+        plan["vote_cls"][1](plan["vote_cls"][0](x), out=vote, out_channel_offset=2)
+        L = self.layer
+        n = b * h * w
+        t = plan["patch"](x.view(n, cin))
+        t = ops.layernorm(t, L.patch_embed.norm.weight, L.patch_embed.norm.bias, L.patch_embed.norm.eps)
+        for bp in plan["blocks"]:
+            blk = bp["mod"]
+            y = ops.layernorm(t, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+            qkv = bp["qkv"](y)
+            att = torch.empty((n, C), dtype=torch.float32, device=x.device)
+            hip.call("pn_swv_window_attn", qkv.data_ptr(), vote.data_ptr(), 4, plan["pos"].data_ptr(), hip.ptr(bp["qkv_bias"]),
+                     bp["vw1"].data_ptr(), bp["vb1"].data_ptr(), bp["vw2"].data_ptr(), bp["vb2"].data_ptr(), bp["rw1"].data_ptr(),
+                     bp["rb1"].data_ptr(), bp["rw2"].data_ptr(), bp["rb2"].data_ptr(), bp["tau"].data_ptr(), b, h, w, C, heads, ws,
+                     int(bp["shift"]), att.data_ptr(), hip.stream())
+            t = bp["proj"](att, residual=t)
+            z = ops.layernorm(t, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            t = bp["fc2"](bp["fc1"](z, act=ops.ACT_GELU), residual=t)
+        feat = ops.layernorm(t, L.norm0.weight, L.norm0.bias, L.norm0.eps).view(b, h, w, C)
+        hm = plan["cls"][2](plan["cls"][1](plan["cls"][0](feat)))
+        boxes = plan["bbox"][1](plan["bbox"][0](feat))
+        ret = dict(pred_centers=vote[..., 0:2], pred_vote_cls=vote[..., 2:3], hm=hm, reg=boxes[..., 0:2], height=boxes[..., 2:3],
+                   dim=boxes[..., 3:6], rot=boxes[..., 6:8])
+        if self.iou_loss:
+            ret["iou"] = plan["iou"][1](plan["iou"][0](feat))
+        ret["_feat"] = feat
+        return ret
+
+    def forward(self, x, **kwargs):
+        """logical (B,C,H,W) in; {'det_preds': [dict of logical (B,c,H,W) views]} as e2e_swv_head.py:150-173"""
+        hip.require_device(x)
+        out = self.forward_nhwc(ops.to_nhwc(x))
+        out.pop("_feat")
+        return {"det_preds": [{k: v.permute(0, 3, 1, 2) for k, v in out.items()}]}
+
+    def loss(self, example, preds_dicts, **kwargs):
+        raise NotImplementedError("E2ESWVoteHead.loss (SetCriterion / TimeMatcher / vote map targets) is not built yet (SURVEY.md 8f next-3)")
+
+    def predict(self, example, preds_dicts, test_cfg, **kwargs):
+        raise NotImplementedError("decode + NMS (SURVEY.md 8f next-2) is outside this round's hot path")

@@ -60,6 +60,31 @@ def test_reference_configs_load_unchanged():
     assert w.model.type == "VoxelNetV3" and w.model.neck.ds_num_filters == [128, 256]
     neck = P.build_neck(w.model.neck)  # set_* keys are swallowed like in the reference
     assert sum(p.numel() for p in neck.parameters()) == 4576768
+    # the whole PARTNER detector builds from the unchanged file: VFE reader, (placeholder) sparse backbone, two SetBlocks,
+    # RPN and the geometry-aware head E2ESWVoteHead with the config's own key spellings
+    det = P.build_detector(w.model, train_cfg=w.train_cfg, test_cfg=w.test_cfg)
+    head = det.bbox_head
+    assert type(det).__name__ == "VoxelNetV3" and type(head).__name__ == "E2ESWVoteHead"
+    assert tuple(head.offset_grid.shape) == (1, 2, 256, 144) and head.window_size == 7 and head.iou_loss and head.code_size == 8
+    assert len(head.layer.layers[0].blocks) == 2 and [b.shift_size for b in head.layer.layers[0].blocks] == [0, 3]
+    assert sum(p.numel() for p in head.parameters()) == 3895549
+
+
+def test_swv_oracle_window_bookkeeping():
+    """window partition / reverse are inverses, the shift mask separates exactly the wrapped regions (H3 oracle helpers)"""
+    import torch
+    from oracle import polar_oracle as O
+    x = torch.arange(2 * 14 * 21 * 3, dtype=torch.float32).view(2, 14, 21, 3)
+    win = O._window_partition(x, 7)
+    assert tuple(win.shape) == (2 * 2 * 3, 7, 7, 3) and torch.equal(O._window_reverse(win, 7, 14, 21), x)
+    m = O._swin_shift_mask(14, 21, 7, 3)
+    assert tuple(m.shape) == (6, 49, 49) and set(m.unique().tolist()) == {-100.0, 0.0}
+    assert (m[0] == 0).all()                      # the top-left window holds one region only
+    assert (m[-1] != 0).any() and (m[-1].diagonal() == 0).all()
+    og = O.swv_offset_grid([1152, 2048, 40], 8, [0.3, -3.14368, -2.0], [75.18, 3.14368, 4.0])
+    assert tuple(og.shape) == (1, 2, 256, 144)
+    r = og.pow(2).sum(1).sqrt()[0]                # radius of every cell centre grows along the range axis only
+    assert torch.allclose(r[0], r[100], atol=1e-4) and (r[0, 1:] > r[0, :-1]).all()
 
 
 def test_state_dict_matches_reference_key_for_key(golden):

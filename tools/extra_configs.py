@@ -68,3 +68,22 @@ synth.load_filled(neck, 3); neck = neck.to(dev).eval()
 xb = torch.randn((1, 256, 144, 256), device=dev)  # NHWC (B, theta, r, C)
 t = timeit(lambda: neck.forward_nhwc(xb))
 print(f"C4  RPN of the Waymo config on (256 x 144) x 256: {t:.3f} ms  ({143.14 / t:.1f} TFLOP/s on 143.14 GFLOP)")
+
+# ---- C4 geometry-aware head (H3): E2ESWVoteHead on the RPN output (B, 512, 256, 144)
+import numpy as np  # noqa: E402
+tasks = [dict(num_class=1, class_names=["VEHICLE"])]
+head = P.build_bbox_head(dict(
+    type="E2ESWVoteHead", in_channels=512, tasks=tasks, dataset="waymo", weight=2, code_weights=[1.0] * 8, out_size_factor=8,
+    common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2)}, voxel_shape="cylinder",
+    CODER_CONFIG={"code_size": 7, "encode_angle_by_sincos": True},
+    GT_PROCESSOR_CONFIG={"max_volumn_space": [75.18, 3.14368, 4.0], "min_volumn_space": [0.3, -3.14368, -2.0], "grid_size": np.array([1152, 2048, 40])},
+    HEAD_CONFIG={"kernel_size": 3, "sw_head_version": "votev4", "window_size": 7, "sl_depth": [2], "code_size": 7, "encode_angle_by_sincos": True,
+                 "iou_loss": True, "init_bias": -2.19, "num_classes": 1}))
+geo = {k: getattr(head, k).clone() for k in ("offset_grid", "xy_offset")}
+synth.load_filled(head, 4)
+for k, v in geo.items():
+    getattr(head, k).data.copy_(v)
+head = head.to(dev).eval()
+xh = torch.randn((1, 256, 144, 512), device=dev)  # NHWC
+t = timeit(lambda: head.forward_nhwc(xh))
+print(f"C4  E2ESWVoteHead (256 x 144, 512 ch, 2 Swin blocks of 777 windows x 4 heads): {t:.3f} ms")
