@@ -16,7 +16,7 @@ from partner_amd.utils import synth
 dev = torch.device("cuda:0")
 
 
-def timeit(fn, n=20, warm=3):
+def timeit(fn, n=20, warm=25):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
