@@ -244,6 +244,22 @@ int pn_pack_deconv2x2_weight_f32(const float *w_iohw, int cin, int cout, float *
 int pn_conv2d_nhwc_f32(const pn_conv_desc *desc, const float *in, const float *packed_w,
                        const float *scale, const float *shift, float *out, pn_stream_t stream);
 
+/* bf16 variant of the same kernel (BASELINE configs[3], "bf16 BEV convs on MFMA"): bf16 NHWC activations
+ * and bf16 packed weights, f32 accumulation on v_mfma_f32_32x32x16_bf16, scale / shift / activation in f32,
+ * output bf16 (out_is_f32 = 0) or f32 (1, e.g. the last layer before an fp32 consumer).  The descriptor is the
+ * same (strides / offsets in elements); cin, the input pixel stride and channel offset must be multiples of 8.
+ * A ConvTranspose2d(k=2,s=2) weight (Cin,Cout,2,2) is packed as the 1x1 convolution weight
+ * (4*Cout, Cin, 1, 1) with row (2*di+dj)*Cout + n and run with deconv2x2 = 1.  Round-to-nearest-even
+ * conversions: pn_f32_to_bf16 / pn_bf16_to_f32. */
+size_t pn_conv_packed_weight_bf16_elems(int cout, int cin, int kh, int kw, int groups);
+int pn_pack_conv_weight_bf16(const float *w_oihw, int cout_total, int cin_per_group, int kh, int kw,
+                             int groups, void *packed, pn_stream_t stream);
+int pn_conv2d_nhwc_bf16(const pn_conv_desc *desc, const void *in_bf16, const void *packed_w_bf16,
+                        const float *scale, const float *shift, void *out, int out_is_f32,
+                        pn_stream_t stream);
+int pn_f32_to_bf16(const float *x, void *y, size_t n, pn_stream_t stream);
+int pn_bf16_to_f32(const void *x, float *y, size_t n, pn_stream_t stream);
+
 /* plain direct convolution (any channel count, no MFMA): used for constant folding of the
  * position-conditioned calibration (center_head_parallel.py:243-266) and as an on-device
  * cross-check of the MFMA kernel.  Weights in torch layout (Cout, Cin/groups, KH, KW). */

@@ -29,6 +29,20 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+// element types of the kernel: DT_F32 (f32 in / f32 out), DT_BF16 (bf16 in / bf16 out, f32 accumulate) and
+// DT_BF16_F32OUT (bf16 in / f32 out: last layer before an fp32 consumer).  In bytes the LDS images and the
+// operand fetch are IDENTICAL for both input types -- a 16-byte fragment is 4 f32 (four 32x32x2 MFMAs) or
+// 8 bf16 (one 32x32x16 MFMA) -- so one kernel body serves both; only the channel <-> byte arithmetic, the MFMA
+// and the store differ.  A K step is 8 such chunks per row: 32 f32 or 64 bf16 channels.
+enum { DT_F32 = 0, DT_BF16 = 1, DT_BF16_F32OUT = 2 };
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+  unsigned u = __builtin_bit_cast(unsigned, f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
 
 enum { MODE_CONV = 0, MODE_DECONV2 = 1, MODE_STRAT = 2 };
 
@@ -59,8 +73,11 @@ struct ConvArgs {
 constexpr int BK = 32;
 constexpr int A_LD = BK + 4;
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int DT = DT_F32>
 __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
+  constexpr int ES = DT == DT_F32 ? 4 : 2;   // bytes per input element
+  constexpr int CPC = 16 / ES;               // channels per 16-byte chunk
+  constexpr int BKC = 8 * CPC;               // channels per K step
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -112,7 +129,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     const int ow = rem - oh * a.OWsub + (a.mode == MODE_STRAT ? z * a.OWsub : 0);
     const int ih0 = oh * a.stride - a.pad_h, iw0 = ow * a.stride - a.pad_w;
     const long long pix = ((long long)b * a.H + ih0) * a.W + iw0;  // may be negative by at most `back`/in_ps
-    a_off[j] = (unsigned)((pix * a.in_ps + back + a.in_co + z * a.in_group_stride + c4 * 4) * 4);
+    a_off[j] = (unsigned)((pix * a.in_ps + back + a.in_co + z * a.in_group_stride + c4 * CPC) * ES);
     unsigned mk = 0;
     for (int kh = 0, t = 0; kh < a.KH; ++kh)
       for (int kw = 0; kw < a.KW; ++kw, ++t)
@@ -127,9 +144,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     b_off[j] = (n0 + n < a.cout_pad) ? (unsigned)(((size_t)k4 * a.cout_pad + n0 + n) * 16) : 0xffffffffu;
   }
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.in) - back, 0, a.in_bytes + (unsigned)(back * 4), 0x00020000);
+      reinterpret_cast<char*>(const_cast<float*>(a.in)) - back * ES, 0, a.in_bytes + (unsigned)(back * ES), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.w) + (size_t)z * taps * (a.cin_chunks * BK) * a.cout_pad, 0, a.w_bytes, 0x00020000);
+      reinterpret_cast<char*>(const_cast<float*>(a.w)) + (size_t)z * taps * a.cin_chunks * 8 * a.cout_pad * 16, 0, a.w_bytes, 0x00020000);
   const int nsteps = taps * a.cin_chunks;
 
   f32x4 ra[A_PER_T], rb[B_PER_T];
@@ -139,11 +156,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   // (tap, chunk) of the next tile to fetch, advanced incrementally: scalar adds only
   int ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
   auto load_global = [&](bool live) {
-    const unsigned so_a = (unsigned)(((ld_kh * a.W + ld_kw) * a.in_ps + ld_chunk * BK) * 4);
+    const unsigned so_a = (unsigned)(((ld_kh * a.W + ld_kw) * a.in_ps + ld_chunk * BKC) * ES);
     const unsigned so_b = (unsigned)((ld_tap * a.cin_chunks + ld_chunk) * 8) * (unsigned)a.cout_pad * 16u;
     // `live` == false (past the last K step): every lane is redirected out of range, the loads
     // return zeros without touching memory and the loop body stays branch-free
-    const unsigned cok = (unsigned)(live && ld_chunk * BK + c4 * 4 < a.Cin);
+    const unsigned cok = (unsigned)(live && ld_chunk * BKC + c4 * CPC < a.Cin);
 #pragma unroll
     for (int j = 0; j < A_PER_T; ++j) {
       const unsigned sel = (a_mask[j] >> ld_tap) & cok;          // 1: inside the map
@@ -200,13 +217,22 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * 4);
   };
   auto mfma_sub = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
+    if constexpr (DT == DT_F32) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+    } else {  // the 16-byte fragment is A[row][k = 8h .. 8h+7] / B[k = 8h .. 8h+7][col]: one 32x32x16 MFMA
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                             acc[i][j], 0, 0, 0);
+    }
   };
 
   load_global(true);
@@ -215,7 +241,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   __syncthreads();
   read_frags(0, 0, af[0], bf[0]);
 
-  constexpr int NM = 4 * TM * TN;          // MFMAs per sub-step
+  constexpr int NM = (DT == DT_F32 ? 4 : 1) * TM * TN;  // MFMAs per sub-step
   constexpr int NF = TM + TN;              // fragment reads per sub-step
   constexpr int NS = A_PER_T + B_PER_T;    // LDS stores == buffer loads per step
   for (int t = 0; t < nsteps; ++t) {
@@ -322,7 +348,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] += rv[k];
       }
-      *reinterpret_cast<f32x4*>(a.out + pix * a.out_ps + coff) = o;
+      if constexpr (DT == DT_BF16) {
+        using u16x4 = __attribute__((ext_vector_type(4))) unsigned short;
+        u16x4 ob;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ob[k] = f32_to_bf16_rne(o[k]);
+        *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned short*>(a.out) + pix * a.out_ps + coff) = ob;
+      } else {
+        *reinterpret_cast<f32x4*>(a.out + pix * a.out_ps + coff) = o;
+      }
     }
     return;
   }
@@ -374,7 +408,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
         }
         float o = pn::apply_act(fmaf(acc[i][j][r], sc[j], sh[j]), a.act);
         if (a.res) o += a.res[rpix * a.res_ps + col_off[j]];
-        *dst = o;
+        if constexpr (DT == DT_BF16)
+          reinterpret_cast<unsigned short*>(a.out)[dst - a.out] = f32_to_bf16_rne(o);
+        else
+          *dst = o;
       }
     }
   }
@@ -457,24 +494,25 @@ __global__ void conv_direct_kernel(ConvArgs a, const float* __restrict__ w_oihw,
   }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int DT = DT_F32>
 int launch_conv(const ConvArgs& a, int zdim, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr size_t smem = 2 * (size_t)(BM * A_LD + BK * BN) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, DT>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
   ConvArgs b = a;
   b.nmt = pn::cdiv(a.M, BM);
   dim3 grid(b.nmt, pn::cdiv(a.ncols, BN), zdim);
-  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN>), grid, dim3(WM * WN * 64), smem, st, b);
+  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, DT>), grid, dim3(WM * WN * 64), smem, st, b);
   return pn::check_launch("conv_mfma_kernel");
 }
 
-int fill_args(const pn_conv_desc* d, ConvArgs& a, int& zdim) {
+// es = bytes per input element (4: f32, 2: bf16); a K step is 8 chunks of 16 bytes = 128 / es channels
+int fill_args(const pn_conv_desc* d, ConvArgs& a, int& zdim, int es = 4) {
   PN_REQUIRE(d != nullptr, "conv: null descriptor");
   PN_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0, "conv: bad sizes");
   PN_REQUIRE(d->groups >= 1 && d->kh >= 1 && d->kw >= 1 && d->stride >= 1, "conv: bad kernel params");
@@ -503,13 +541,13 @@ int fill_args(const pn_conv_desc* d, ConvArgs& a, int& zdim) {
     a.mode = MODE_STRAT; a.OWsub = a.OW / d->range_strata; zdim = d->range_strata; a.in_group_stride = 0;
   }
   a.M = d->batch * a.OH * a.OWsub;
-  a.cin_chunks = pn::cdiv(d->cin, BK);
+  a.cin_chunks = pn::cdiv(d->cin, 128 / es);
   a.cout_pad = pn::cdiv(a.ncols, 32) * 32;
-  const unsigned long long in_bytes = (unsigned long long)d->batch * d->in_h * d->in_w * d->in_pixel_stride * 4ull;
+  const unsigned long long in_bytes = (unsigned long long)d->batch * d->in_h * d->in_w * d->in_pixel_stride * (unsigned long long)es;
   PN_REQUIRE(in_bytes < (1ull << 31), "conv: input map larger than 2 GiB is not addressable by the buffer descriptor");
   PN_REQUIRE(d->kh * d->kw <= 32, "conv: at most 32 taps");
   a.in_bytes = (unsigned)in_bytes;
-  a.w_bytes = (unsigned)((size_t)d->kh * d->kw * a.cin_chunks * BK * a.cout_pad * 4);
+  a.w_bytes = (unsigned)((size_t)d->kh * d->kw * a.cin_chunks * 8 * a.cout_pad * 16);
   a.force_tile = 0;
   a.res = nullptr;
   a.res_ps = 0;
@@ -539,9 +577,107 @@ int dispatch_conv(const ConvArgs& a, int zdim, hipStream_t st) {
   }
 }
 
+template <int DT>
+int dispatch_conv_bf16(const ConvArgs& a, int zdim, hipStream_t st) {
+  static const int forced = [] { const char* e = getenv("PN_CONV_TILE_BF16"); return e ? atoi(e) : 0; }();
+  int tile = forced;
+  if (tile == 0) {
+    const long long t128 = (long long)pn::cdiv(a.M, 128) * pn::cdiv(a.ncols, 128) * zdim;
+    const long long t64x128 = (long long)pn::cdiv(a.M, 64) * pn::cdiv(a.ncols, 128) * zdim;
+    if (a.ncols > 64) tile = t128 >= 384 ? 1 : (t64x128 >= 256 ? 2 : 3);
+    else if (a.ncols > 32) tile = 3;
+    else tile = 4;
+  }
+  switch (tile) {
+    case 1: return launch_conv<2, 2, 2, 2, DT>(a, zdim, st);
+    case 2: return launch_conv<2, 2, 1, 2, DT>(a, zdim, st);
+    case 3: return launch_conv<2, 2, 1, 1, DT>(a, zdim, st);
+    case 4: return launch_conv<2, 1, 1, 1, DT>(a, zdim, st);
+    default: return pn::fail(PN_ERR_INVALID, "conv_bf16: unknown tile id %d", tile);
+  }
+}
+
+// torch (Cout_total, Cin_g, KH, KW) f32 -> bf16 [g][tap][cin_pad/8][cout_pad][8]
+__global__ void pack_conv_weight_bf16_kernel(const float* __restrict__ w, int cout_g, int cin_g, int kh, int kw, int groups, int cin_pad,
+                                             int cout_pad, unsigned short* __restrict__ packed, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int k1 = r & 7;
+    r >>= 3;
+    const int n = r % cout_pad;
+    r /= cout_pad;
+    const int k8 = r % (cin_pad / 8);
+    r /= (cin_pad / 8);
+    const int tap = r % (kh * kw);
+    const int g = (int)(r / (kh * kw));
+    const int c = k8 * 8 + k1;
+    float v = 0.f;
+    if (n < cout_g && c < cin_g) v = w[(((size_t)(g * cout_g + n) * cin_g + c) * kh + tap / kw) * kw + tap % kw];
+    packed[i] = f32_to_bf16_rne(v);
+  }
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = f32_to_bf16_rne(x[i]);
+}
+
+__global__ void bf16_to_f32_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = __builtin_bit_cast(float, (unsigned)x[i] << 16);
+}
+
 }  // namespace
 
 extern "C" {
+
+/* ---- bf16 variant (BASELINE configs[3]: "bf16 BEV convs on MFMA"): bf16 activations and weights, f32 accumulate on
+ * v_mfma_f32_32x32x16_bf16, scale / shift / activation in f32, output bf16 (or f32 for the last layer) ---- */
+size_t pn_conv_packed_weight_bf16_elems(int cout, int cin, int kh, int kw, int groups) {
+  return (size_t)groups * kh * kw * (size_t)(pn::cdiv(cin, 64) * 64) * (size_t)(pn::cdiv(cout, 32) * 32);
+}
+
+int pn_pack_conv_weight_bf16(const float* w_oihw, int cout_total, int cin_per_group, int kh, int kw, int groups, void* packed,
+                             pn_stream_t stream) {
+  PN_REQUIRE(w_oihw && packed && groups >= 1 && cout_total % groups == 0, "pack_conv_weight_bf16: bad arguments");
+  const int cout_g = cout_total / groups;
+  const int cin_pad = pn::cdiv(cin_per_group, 64) * 64, cout_pad = pn::cdiv(cout_g, 32) * 32;
+  const size_t total = pn_conv_packed_weight_bf16_elems(cout_g, cin_per_group, kh, kw, groups);
+  hipLaunchKernelGGL(pack_conv_weight_bf16_kernel, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0, pn::S(stream),
+                     w_oihw, cout_g, cin_per_group, kh, kw, groups, cin_pad, cout_pad, static_cast<unsigned short*>(packed), total);
+  return pn::check_launch("pack_conv_weight_bf16_kernel");
+}
+
+int pn_conv2d_nhwc_bf16(const pn_conv_desc* d, const void* in_bf16, const void* packed_w_bf16, const float* scale, const float* shift,
+                        void* out, int out_is_f32, pn_stream_t stream) {
+  ConvArgs a;
+  int zdim = 1;
+  if (int rc = fill_args(d, a, zdim, 2)) return rc;
+  PN_REQUIRE(in_bf16 && packed_w_bf16 && out, "conv_bf16: null pointer");
+  PN_REQUIRE(!d->deconv2x2 || (d->kh == 1 && d->kw == 1), "conv_bf16: only the ConvTranspose2d(k=2,s=2) form of deconv2x2");
+  PN_REQUIRE(d->cin % 8 == 0 && d->in_pixel_stride % 8 == 0 && d->in_channel_offset % 8 == 0,
+             "conv_bf16: cin, input pixel stride and channel offset must be multiples of 8");
+  PN_REQUIRE(!d->accumulate, "conv_bf16: accumulate is not supported");
+  PN_REQUIRE(((uintptr_t)in_bf16 & 15) == 0 && ((uintptr_t)packed_w_bf16 & 15) == 0, "conv_bf16: pointers must be 16-byte aligned");
+  a.in = static_cast<const float*>(in_bf16); a.w = static_cast<const float*>(packed_w_bf16); a.scale = scale; a.shift = shift;
+  a.out = static_cast<float*>(out);
+  return out_is_f32 ? dispatch_conv_bf16<DT_BF16_F32OUT>(a, zdim, pn::S(stream)) : dispatch_conv_bf16<DT_BF16>(a, zdim, pn::S(stream));
+}
+
+int pn_f32_to_bf16(const float* x, void* y, size_t n, pn_stream_t stream) {
+  PN_REQUIRE(x && y, "f32_to_bf16: null pointer");
+  if (n == 0) return PN_OK;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)std::min<size_t>(8192, (n + 255) / 256)), dim3(256), 0, pn::S(stream), x,
+                     static_cast<unsigned short*>(y), n);
+  return pn::check_launch("f32_to_bf16_kernel");
+}
+
+int pn_bf16_to_f32(const void* x, float* y, size_t n, pn_stream_t stream) {
+  PN_REQUIRE(x && y, "bf16_to_f32: null pointer");
+  if (n == 0) return PN_OK;
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)std::min<size_t>(8192, (n + 255) / 256)), dim3(256), 0, pn::S(stream),
+                     static_cast<const unsigned short*>(x), y, n);
+  return pn::check_launch("bf16_to_f32_kernel");
+}
 
 size_t pn_conv_packed_weight_floats(int cout, int cin, int kh, int kw, int groups) {
   return (size_t)groups * kh * kw * (size_t)(pn::cdiv(cin, BK) * BK) * (size_t)(pn::cdiv(cout, 32) * 32);

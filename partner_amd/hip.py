@@ -67,6 +67,11 @@ SIGNATURES = {
     "pn_pack_deconv2x2_weight_f32": (_I, [_P, _I, _I, _P, _P]),
     "pn_conv2d_nhwc_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "pn_conv2d_direct_nhwc_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    "pn_conv_packed_weight_bf16_elems": (_SZ, [_I, _I, _I, _I, _I]),
+    "pn_pack_conv_weight_bf16": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "pn_conv2d_nhwc_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "pn_f32_to_bf16": (_I, [_P, _P, _SZ, _P]),
+    "pn_bf16_to_f32": (_I, [_P, _P, _SZ, _P]),
     "pn_fold_bn_f32": (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "pn_conv2d_wgrad_workspace_bytes": (_SZ, [_P]),
     "pn_conv2d_wgrad_f32": (_I, [_P, _P, _P, _P, _I, _P, _SZ, _P]),

@@ -71,33 +71,52 @@ class RPN(nn.Module):
 
     # ---------------------------------------------------------------------------------------
     @staticmethod
-    def _fused(conv, bn, stride, pad, deconv=False):
+    def _fused(conv, bn, stride, pad, deconv=False, dtype="f32"):
         scale, shift = ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, conv.bias)
         return ops.ConvLayer(conv.weight, stride=stride, pad=pad, scale=scale, shift=shift, act=ops.ACT_RELU,
-                             deconv2x2=deconv)
+                             deconv2x2=deconv, dtype=dtype)
 
-    def _build_plan(self):
+    def set_compute_dtype(self, dtype: str) -> "RPN":
+        """"f32" (default, the reference's arithmetic) or "bf16": bf16 activations / weights with f32 accumulation on
+        the bf16 MFMA (BASELINE configs[3]); the concatenated output stays f32 for the head."""
+        assert dtype in ("f32", "bf16")
+        self.compute_dtype = dtype
+        return self
+
+    def _build_plan(self, dtype="f32"):
         plan = dict(blocks=[], deblocks=[])
         for blk in self.blocks:
             mods = list(blk._modules.values())
-            layers = [self._fused(mods[1], mods[2], mods[1].stride[0], 1)]  # ZeroPad2d(1) + conv == pad 1
+            layers = [self._fused(mods[1], mods[2], mods[1].stride[0], 1, dtype=dtype)]  # ZeroPad2d(1) + conv == pad 1
             for k in range(4, len(mods), 3):
-                layers.append(self._fused(mods[k], mods[k + 1], 1, 1))
+                layers.append(self._fused(mods[k], mods[k + 1], 1, 1, dtype=dtype))
             plan["blocks"].append(layers)
         for de in self.deblocks:
             up, bn = de[0], de[1]
             if isinstance(up, nn.ConvTranspose2d):
+                if up.stride[0] == 1 and up.kernel_size[0] == 1:  # ConvTranspose2d(k=1, s=1) == 1x1 convolution with the transposed weight
+                    w1 = up.weight.detach().permute(1, 0, 2, 3).contiguous()
+                    scale, shift = ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, up.bias)
+                    plan["deblocks"].append(ops.ConvLayer(w1, stride=1, pad=0, scale=scale, shift=shift, act=ops.ACT_RELU, dtype=dtype))
+                    continue
                 if up.stride[0] != 2:
-                    raise NotImplementedError("RPN deblock: only ConvTranspose2d(k=2, s=2) has a HIP kernel")
-                plan["deblocks"].append(self._fused(up, bn, 1, 0, deconv=True))
+                    raise NotImplementedError("RPN deblock: only ConvTranspose2d(k=2, s=2) / (k=1, s=1) have a HIP kernel")
+                plan["deblocks"].append(self._fused(up, bn, 1, 0, deconv=True, dtype=dtype))
             else:
-                plan["deblocks"].append(self._fused(up, bn, up.stride[0], 0))
+                plan["deblocks"].append(self._fused(up, bn, up.stride[0], 0, dtype=dtype))
         return plan
 
     def forward_nhwc(self, x: torch.Tensor, return_blocks=False):
-        """x: NHWC (B,H,W,C) -> NHWC (B,H',W',sum(us_filters))"""
+        """x: NHWC (B,H,W,C) f32 -> NHWC (B,H',W',sum(us_filters)) f32"""
         eval_only(self, "RPN")
-        plan = self._plan.get(self, self._build_plan)
+        dtype = getattr(self, "compute_dtype", "f32")
+        if dtype == "bf16":
+            if not hasattr(self, "_plan_bf16"):
+                self._plan_bf16 = PlanCache()
+            plan = self._plan_bf16.get(self, lambda: self._build_plan("bf16"))
+            x = ops.to_bf16(x)
+        else:
+            plan = self._plan.get(self, self._build_plan)
         out, off, block_outs = None, 0, []
         for i, layers in enumerate(plan["blocks"]):
             for layer in layers:

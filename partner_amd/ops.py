@@ -280,7 +280,7 @@ class ConvLayer:
     scale / shift: per-output-channel affine (folded BatchNorm, or bias as shift)."""
 
     def __init__(self, weight: torch.Tensor, stride=1, pad=0, groups=1, scale=None, shift=None, act=ACT_NONE,
-                 deconv2x2=False, range_strata=0):
+                 deconv2x2=False, range_strata=0, dtype="f32"):
         hip.require_device(weight)
         lib = hip.load()
         w = weight.detach().contiguous().float()
@@ -289,7 +289,25 @@ class ConvLayer:
         self.deconv2x2, self.range_strata, self.groups = bool(deconv2x2), int(range_strata), int(groups)
         self.stride, self.act = int(stride), int(act)
         self.pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
-        if deconv2x2:
+        assert dtype in ("f32", "bf16")
+        self.dtype = dtype
+        if dtype == "bf16":
+            # bf16 activations / weights, f32 accumulate (pn_conv2d_nhwc_bf16)
+            if deconv2x2:
+                cin, cout = w.shape[0], w.shape[1]
+                assert tuple(w.shape[2:]) == (2, 2)
+                self.cin, self.cout, self.kh, self.kw = cin, cout, 1, 1
+                wc = w.permute(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1).contiguous()  # row (2*di+dj)*Cout + n
+                self.packed = torch.empty(lib.pn_conv_packed_weight_bf16_elems(4 * cout, cin, 1, 1, 1), dtype=torch.bfloat16, device=dev)
+                hip.call("pn_pack_conv_weight_bf16", wc.data_ptr(), 4 * cout, cin, 1, 1, 1, self.packed.data_ptr(), st)
+            else:
+                pack_groups = self.range_strata if self.range_strata > 1 else self.groups
+                cout_t, cin_g, kh, kw = w.shape
+                self.cin, self.cout, self.kh, self.kw = cin_g, cout_t // pack_groups, kh, kw
+                self.packed = torch.empty(lib.pn_conv_packed_weight_bf16_elems(self.cout, cin_g, kh, kw, pack_groups), dtype=torch.bfloat16,
+                                          device=dev)
+                hip.call("pn_pack_conv_weight_bf16", w.data_ptr(), cout_t, cin_g, kh, kw, pack_groups, self.packed.data_ptr(), st)
+        elif deconv2x2:
             cin, cout = w.shape[0], w.shape[1]
             assert tuple(w.shape[2:]) == (2, 2)
             self.cin, self.cout, self.kh, self.kw = cin, cout, 1, 1
@@ -333,15 +351,32 @@ class ConvLayer:
         return ((h + 2 * self.pad[0] - self.kh) // self.stride + 1, (w + 2 * self.pad[1] - self.kw) // self.stride + 1)
 
     def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_channel_offset=0, in_channel_offset=0,
-                 in_channels: Optional[int] = None, accumulate=False) -> torch.Tensor:
+                 in_channels: Optional[int] = None, accumulate=False, out_f32=False) -> torch.Tensor:
         """x: NHWC (B,H,W,Ct).  Reads channels [in_channel_offset, +cin*groups); writes channels
-        [out_channel_offset, +out_channels) of ``out`` (allocated if None)."""
+        [out_channel_offset, +out_channels) of ``out`` (allocated if None).  bf16 layers take / return
+        torch.bfloat16 maps (``out_f32``: f32 output)."""
         hip.require_device(x)
-        assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+        in_dt = torch.bfloat16 if self.dtype == "bf16" else torch.float32
+        assert x.dim() == 4 and x.is_contiguous() and x.dtype == in_dt
         b, h, w, ct = x.shape
         oh, ow = self.out_hw(h, w)
         if out is None:
-            out = torch.empty((b, oh, ow, self.out_channels), dtype=torch.float32, device=x.device)
+            out = torch.empty((b, oh, ow, self.out_channels), dtype=torch.float32 if (out_f32 or self.dtype == "f32") else torch.bfloat16,
+                              device=x.device)
+        if self.dtype == "bf16":
+            assert out.shape[:3] == (b, oh, ow) and out.is_contiguous()
+            d = ConvDesc(b, h, w, self.cin, self.cout, self.groups, self.kh, self.kw, self.stride, self.pad[0], self.pad[1],
+                         ct, in_channel_offset, out.shape[3], out_channel_offset, self.act, int(self.deconv2x2), self.range_strata)
+            st = hip.stream()
+            prof = _PROFILER
+            if prof is not None:
+                ev = prof.begin(st)
+            hip.call("pn_conv2d_nhwc_bf16", C.byref(d), x.data_ptr(), self.packed.data_ptr(), hip.ptr(self.scale), hip.ptr(self.shift),
+                     out.data_ptr(), int(out.dtype == torch.float32), st)
+            if prof is not None:
+                macs = b * h * w * 4 * self.cout * self.cin if self.deconv2x2 else b * oh * ow * self.groups * self.cout * self.cin * self.kh * self.kw
+                prof.end(ev, 2.0 * macs, st)
+            return out
         assert out.shape[:3] == (b, oh, ow) and out.is_contiguous()
         d = ConvDesc(b, h, w, self.cin, self.cout, self.groups, self.kh, self.kw, self.stride, self.pad[0], self.pad[1],
                      ct, in_channel_offset, out.shape[3], out_channel_offset, self.act, int(self.deconv2x2),
@@ -800,3 +835,20 @@ def strat_expand(dy: torch.Tensor, strata: int, out: Optional[torch.Tensor] = No
         out = torch.empty((b, h, w, strata * c), dtype=torch.float32, device=dy.device)
     hip.call("pn_strat_expand_f32", dy.data_ptr(), b, h, w, c, strata, out.data_ptr(), hip.stream())
     return out
+
+
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    """f32 -> bf16 (round to nearest even) on the HIP kernel; same shape"""
+    hip.require_device(x)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    hip.call("pn_f32_to_bf16", x.data_ptr(), y.data_ptr(), x.numel(), hip.stream())
+    return y
+
+
+def to_f32(x: torch.Tensor) -> torch.Tensor:
+    hip.require_device(x)
+    assert x.is_contiguous() and x.dtype == torch.bfloat16
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    hip.call("pn_bf16_to_f32", x.data_ptr(), y.data_ptr(), x.numel(), hip.stream())
+    return y

@@ -465,7 +465,17 @@ class PolarPillarTrainStep:
         ops.adam_step(self.ps.flat_p, self.ps.flat_g, self.ps.flat_m, self.ps.flat_v, self.iter + 1, lr, beta1, self.beta2, self.eps,
                       self.wd, total_norm=total_norm, max_norm=self.max_norm)
         self.iter += 1
+        self.invalidate_inference_plans()
         return total_norm
+
+    def invalidate_inference_plans(self):
+        """the kernels update the parameters behind PyTorch's version counters: drop the packed-weight plans of the
+        inference path so that the next eval forward re-packs from the trained weights"""
+        for m in self.model.modules():
+            for attr in ("_plan", "_plan_bf16"):
+                pc = getattr(m, attr, None)
+                if pc is not None and hasattr(pc, "plan"):
+                    pc.plan = None
 
     def step(self, points, sample_offsets, batch, targets: ops.CenterLossTargets, grid_ind=None):
         import torch.distributed as dist

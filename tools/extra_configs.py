@@ -87,3 +87,13 @@ head = head.to(dev).eval()
 xh = torch.randn((1, 256, 144, 512), device=dev)  # NHWC
 t = timeit(lambda: head.forward_nhwc(xh))
 print(f"C4  E2ESWVoteHead (256 x 144, 512 ch, 2 Swin blocks of 777 windows x 4 heads): {t:.3f} ms")
+
+# ---- C4 RPN with bf16 convolutions (BASELINE configs[3])
+neck.set_compute_dtype("bf16")
+ref32 = None
+t = timeit(lambda: neck.forward_nhwc(xb))
+y16 = neck.forward_nhwc(xb)
+neck.set_compute_dtype("f32")
+y32 = neck.forward_nhwc(xb)
+err = float((y16 - y32).abs().max() / y32.abs().max())
+print(f"C4  RPN of the Waymo config, bf16 convs (f32 accumulate): {t:.3f} ms  ({143.14 / t:.1f} TFLOP/s on 143.14 GFLOP); max rel diff to the f32 path {err:.2e}")
