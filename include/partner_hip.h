@@ -491,6 +491,33 @@ int pn_add_f32(const float *a, const float *b, float *out, size_t n, pn_stream_t
 int pn_strat_expand_f32(const float *dy, int batch, int h, int w, int c, int strata, float *out,
                         pn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * next-2  decode + rotated NMS: head tensors -> boxes, entirely on the device and on the caller's stream.
+ * Replaces CenterHead.decode / post_processing (plain path)   det3d/models/bbox_heads/center_head.py:350-402, 462-577
+ *          rotate_nms_pcdet                                   det3d/core/bbox/box_torch_ops.py:248-277
+ *          nms_gpu: IoU bit masks + greedy reduce             det3d/ops/iou3d_nms/src/iou3d_nms_kernel.cu:104-311,
+ *                                                             iou3d_nms.cpp:90-136 (host loop after a blocking copy there)
+ * Inputs are the raw NHWC head outputs (pixel strides in floats); vel may be NULL (7-dim boxes, else 9:
+ * [x,y,z,dims(3),vel(2),rot]).  cylinder != 0: cell (y, x) has centre rho = x*step_x + origin_x,
+ * azimuth = y*step_y + origin_y (step = out_size_factor * voxel_size); otherwise Cartesian cells.
+ * post_center_range: 6 HOST floats.  Ties in the score order are broken by cell index.  At most 8192 cells
+ * above the score threshold enter the sort (first in cell order).  nms_pre_max_size <= 4096.
+ * Outputs per sample: out_count[b] boxes in out_boxes[b][:count] (post_max rows allocated), scores, labels
+ * (int64), cells (flat y*W+x).  The rotated-IoU arithmetic has no runnable reference here (CUDA only):
+ * parity is against oracle/box_nms.c, unpinned by the reference. */
+size_t pn_center_decode_nms_workspace_bytes(int batch, int cells, int box_dims, int pre_max,
+                                            int post_max);
+int pn_center_decode_nms_f32(const float *hm, int hm_pixel_stride, int classes, const float *reg,
+                             int reg_pixel_stride, const float *height, int height_pixel_stride,
+                             const float *dim, int dim_pixel_stride, const float *rot,
+                             int rot_pixel_stride, const float *vel, int vel_pixel_stride, int batch,
+                             int h, int w, int cylinder, float step_x, float step_y, float origin_x,
+                             float origin_y, int rectify, float score_threshold,
+                             const float *post_center_range, float nms_iou_threshold, int pre_max,
+                             int post_max, float *out_boxes, float *out_scores, int64_t *out_labels,
+                             int32_t *out_cells, int32_t *out_count, void *workspace,
+                             size_t workspace_bytes, pn_stream_t stream);
+
 /* layout helpers at the API boundary */
 int pn_nchw_to_nhwc_f32(const float *in, int b, int c, int h, int w, float *out, pn_stream_t stream);
 int pn_nhwc_to_nchw_f32(const float *in, int b, int c, int h, int w, int pixel_stride,

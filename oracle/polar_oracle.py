@@ -753,3 +753,72 @@ def e2e_swv_head(sd: SD, prefix: str, x: Tensor, offset_grid: Tensor, window=7, 
     if return_feat:
         ret["feat"] = feat
     return ret
+
+
+# ======================================================================================
+# next-2  decode + rotated NMS            det3d/models/bbox_heads/center_head.py:350-402 (decode),
+#                                         :462-577 (post_processing), :404-460 (predict)
+#         rotate_nms_pcdet                det3d/core/bbox/box_torch_ops.py:248-277
+#         BEV rotated IoU / greedy NMS    det3d/ops/iou3d_nms/src/iou3d_nms_kernel.cu:104-311, iou3d_nms.cpp:90-136
+# The IoU / NMS arithmetic is restated in oracle/box_nms.c (the reference's is CUDA only: PARITY UNPINNED,
+# see that file's header); this part is the numpy restatement of the decode and of the selection logic
+# for the plain path (no double flip, no stateful / per-class NMS, no panoptic, sector 0).
+# ======================================================================================
+def center_decode(preds: Dict[str, np.ndarray], voxel_shape: str, out_size_factor, voxel_size, pc_range, rectify=False):
+    """preds: NHWC numpy arrays (B,H,W,c) 'hm','reg','height','dim','rot'[,'vel'] (raw head outputs).
+    -> boxes (B, H*W, 9 or 7) [x, y, z, dims(3), (vel 2), rot], scores (B, H*W, ncls) (center_head.py:350-402)"""
+    hm = 1.0 / (1.0 + np.exp(-preds["hm"].astype(np.float32)))
+    dim = np.exp(preds["dim"].astype(np.float32))
+    rot = np.arctan2(preds["rot"][..., 0:1], preds["rot"][..., 1:2]).astype(np.float32)
+    B, H, W, ncls = hm.shape
+    reg = preds["reg"].reshape(B, H * W, 2).astype(np.float32)
+    hei = preds["height"].reshape(B, H * W, 1).astype(np.float32)
+    rot = rot.reshape(B, H * W, 1)
+    dim = dim.reshape(B, H * W, 3)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    xs, ys = xs.reshape(1, -1, 1), ys.reshape(1, -1, 1)
+    if voxel_shape == "cylinder":
+        rho = xs * np.float32(out_size_factor) * np.float32(voxel_size[0]) + np.float32(pc_range[0])
+        az = ys * np.float32(out_size_factor) * np.float32(voxel_size[1]) + np.float32(pc_range[1])
+        cx, cy = rho * np.cos(az), rho * np.sin(az)
+        x, y = cx + reg[:, :, 0:1], cy + reg[:, :, 1:2]
+        azs = None
+        if rectify:
+            azs = np.arctan2(y, x)
+            rot = rot + azs
+    else:
+        x = (xs + reg[:, :, 0:1]) * np.float32(out_size_factor) * np.float32(voxel_size[0]) + np.float32(pc_range[0])
+        y = (ys + reg[:, :, 1:2]) * np.float32(out_size_factor) * np.float32(voxel_size[1]) + np.float32(pc_range[1])
+    parts = [x, y, hei, dim]
+    if "vel" in preds:
+        vel = preds["vel"].reshape(B, H * W, 2).astype(np.float32).copy()
+        if voxel_shape == "cylinder" and rectify:
+            vr = np.linalg.norm(vel, axis=-1)
+            va = np.arctan2(vel[:, :, 1], vel[:, :, 0]) + azs[..., 0]
+            vel = np.stack([vr * np.cos(va), vr * np.sin(va)], -1)
+        parts.append(vel)
+    parts.append(rot)
+    return np.concatenate([p.astype(np.float32) for p in parts], 2), hm.reshape(B, H * W, ncls)
+
+
+def nms_boxes_pcdet(boxes: np.ndarray) -> np.ndarray:
+    """(n, >=7) [x,y,z,l,w,h,...,rot] -> (n,7) in the NMS kernel's convention (box_torch_ops.py:255-257)"""
+    b = boxes[:, [0, 1, 2, 4, 3, 5, -1]].astype(np.float32).copy()
+    b[:, -1] = -b[:, -1] - np.float32(np.pi / 2)
+    return b
+
+
+def center_post_process(boxes: np.ndarray, hm: np.ndarray, score_threshold: float, post_center_range, nms_iou_threshold: float,
+                        nms_pre_max_size: int, nms_post_max_size: int, nms_fn):
+    """one sample of post_processing (center_head.py:470-520, plain path).  nms_fn(sorted boxes (n,7), thresh) -> kept
+    indices (the C oracle's ov_nms_sorted).  Ties in the score sort are broken by cell index (torch.sort leaves them
+    unspecified).  -> dict(box3d_lidar, scores, label_preds, cells)"""
+    scores, labels = hm.max(-1), hm.argmax(-1)
+    pr = np.asarray(post_center_range, np.float32)
+    mask = (scores > np.float32(score_threshold)) & (boxes[:, :3] >= pr[:3]).all(1) & (boxes[:, :3] <= pr[3:]).all(1)
+    cells = np.nonzero(mask)[0]
+    b, s, l = boxes[cells], scores[cells], labels[cells]
+    order = np.lexsort((cells, -s))[:nms_pre_max_size]
+    keep = np.asarray(nms_fn(nms_boxes_pcdet(b[order]), nms_iou_threshold), np.int64)
+    sel = order[keep][:nms_post_max_size]
+    return dict(box3d_lidar=b[sel], scores=s[sel], label_preds=l[sel], cells=cells[sel])

@@ -561,7 +561,9 @@ int dispatch_conv(const ConvArgs& a, int zdim, hipStream_t st) {
   if (tile == 0) {
     const long long t128 = (long long)pn::cdiv(a.M, 128) * pn::cdiv(a.ncols, 128) * zdim;
     const long long t64x128 = (long long)pn::cdiv(a.M, 64) * pn::cdiv(a.ncols, 128) * zdim;
-    if (a.ncols > 64) tile = t128 >= 384 ? 1 : (t64x128 >= 256 ? 2 : 3);
+    static const int min128 = [] { const char* e = getenv("PN_CONV_MIN128"); return e ? atoi(e) : 384; }();
+    static const int min64x128 = [] { const char* e = getenv("PN_CONV_MIN64X128"); return e ? atoi(e) : 256; }();
+    if (a.ncols > 64) tile = t128 >= min128 ? 1 : (t64x128 >= min64x128 ? 2 : 3);
     else if (a.ncols > 32) tile = 3;
     else tile = 4;
   }

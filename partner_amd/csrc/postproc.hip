@@ -1,0 +1,349 @@
+// Decode + rotated NMS of the centre heads: head tensors -> boxes, on the device.
+// Reference: decode / post_processing / predict   det3d/models/bbox_heads/center_head.py:350-402, 462-577, 404-460
+//            rotate_nms_pcdet                      det3d/core/bbox/box_torch_ops.py:248-277
+//            box_overlap / iou_bev / nms_kernel    det3d/ops/iou3d_nms/src/iou3d_nms_kernel.cu:104-311
+//            nms_gpu greedy reduce (on the HOST there, after a blocking D2H copy)   iou3d_nms.cpp:90-136
+// Plain path only (no double flip, no stateful / per-class NMS, no panoptic, sector 0).
+// Pipeline per sample, all on the caller's stream, no host round trip:
+//   decode_kernel        every cell: sigmoid/max over classes, exp(dim), atan2(rot), polar cell centre -> Cartesian,
+//                        score / range mask
+//   select_sort_kernel   one block: order-preserving compaction of the valid cells into LDS (cap 8192), bitonic sort
+//                        by (score desc, cell asc) -- torch.sort leaves ties unspecified --, first pre_max survive
+//   nms_mask_kernel      64 x 64 IoU tiles -> suppression bit masks (same tiling as the reference)
+//   nms_reduce_kernel    one wave walks the sorted boxes, lane l owns word l of the "removed" bit set
+//   gather_kernel        kept[:post_max] -> box3d_lidar / scores / label_preds
+// Rotated IoU: overlap polygon = edge crossings + contained corners (1e-2 margin), ordered by angle about their mean,
+// fan-summed cross products -- the oracle's box_nms.c is the same arithmetic on the CPU.
+#include "pn_common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr float kEps = 1e-8f;
+constexpr int kCap = 8192;   // candidates per sample that enter the sort
+constexpr int kSortThreads = 1024;
+
+struct pt { float x, y; };
+
+__device__ __forceinline__ float cross3(pt p1, pt p2, pt p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
+
+__device__ __forceinline__ bool bbox_overlap(pt p1, pt p2, pt q1, pt q2) {
+  return fminf(p1.x, p2.x) <= fmaxf(q1.x, q2.x) && fminf(q1.x, q2.x) <= fmaxf(p1.x, p2.x) && fminf(p1.y, p2.y) <= fmaxf(q1.y, q2.y) &&
+         fminf(q1.y, q2.y) <= fmaxf(p1.y, p2.y);
+}
+
+__device__ bool seg_intersection(pt p1, pt p0, pt q1, pt q0, pt& ans) {
+  if (!bbox_overlap(p0, p1, q0, q1)) return false;
+  const float s1 = cross3(q0, p1, p0), s2 = cross3(p1, q1, p0), s3 = cross3(p0, q1, q0), s4 = cross3(q1, p1, q0);
+  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return false;
+  const float s5 = cross3(q1, p1, p0);
+  if (fabsf(s5 - s1) > kEps) {
+    ans.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+    ans.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+  } else {
+    const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+    const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+    const float D = a0 * b1 - a1 * b0;
+    ans.x = (b0 * c1 - b1 * c0) / D;
+    ans.y = (a1 * c0 - a0 * c1) / D;
+  }
+  return true;
+}
+
+__device__ bool inside(const float* box, pt p) {
+  const float c = cosf(-box[6]), s = sinf(-box[6]);
+  const float rx = (p.x - box[0]) * c + (p.y - box[1]) * (-s);
+  const float ry = (p.x - box[0]) * s + (p.y - box[1]) * c;
+  return fabsf(rx) < box[3] / 2 + 1e-2f && fabsf(ry) < box[4] / 2 + 1e-2f;
+}
+
+__device__ void corners(const float* b, pt* c) {
+  const float hx = b[3] / 2, hy = b[4] / 2, co = cosf(b[6]), si = sinf(b[6]);
+  const float lx[4] = {-hx, hx, hx, -hx}, ly[4] = {-hy, -hy, hy, hy};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float px = b[0] + lx[k], py = b[1] + ly[k];
+    c[k].x = (px - b[0]) * co + (py - b[1]) * (-si) + b[0];
+    c[k].y = (px - b[0]) * si + (py - b[1]) * co + b[1];
+  }
+  c[4] = c[0];
+}
+
+__device__ float iou_bev(const float* a, const float* b) {
+  pt ca[5], cb[5], poly[16], ctr = {0.f, 0.f};
+  corners(a, ca);
+  corners(b, cb);
+  int cnt = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      if (seg_intersection(ca[i + 1], ca[i], cb[j + 1], cb[j], poly[cnt])) {
+        ctr.x += poly[cnt].x; ctr.y += poly[cnt].y; ++cnt;
+      }
+  for (int k = 0; k < 4; ++k) {
+    if (inside(a, cb[k])) { ctr.x += cb[k].x; ctr.y += cb[k].y; poly[cnt++] = cb[k]; }
+    if (inside(b, ca[k])) { ctr.x += ca[k].x; ctr.y += ca[k].y; poly[cnt++] = ca[k]; }
+  }
+  ctr.x /= cnt; ctr.y /= cnt;
+  for (int j = 0; j < cnt - 1; ++j)
+    for (int i = 0; i < cnt - j - 1; ++i)
+      if (atan2f(poly[i].y - ctr.y, poly[i].x - ctr.x) > atan2f(poly[i + 1].y - ctr.y, poly[i + 1].x - ctr.x)) {
+        const pt t = poly[i]; poly[i] = poly[i + 1]; poly[i + 1] = t;
+      }
+  float area = 0.f;
+  for (int k = 0; k < cnt - 1; ++k) {
+    const float ax = poly[k].x - poly[0].x, ay = poly[k].y - poly[0].y;
+    const float bx = poly[k + 1].x - poly[0].x, by = poly[k + 1].y - poly[0].y;
+    area += ax * by - ay * bx;
+  }
+  const float so = fabsf(area) / 2.0f;
+  const float sa = a[3] * a[4], sb = b[3] * b[4];
+  return so / fmaxf(sa + sb - so, kEps);
+}
+
+struct DecodeArgs {
+  const float* hm; int hm_ps, ncls;
+  const float* reg; int reg_ps;
+  const float* hei; int hei_ps;
+  const float* dim; int dim_ps;
+  const float* rot; int rot_ps;
+  const float* vel; int vel_ps;
+  int B, H, W, cylinder, rectify, nb;
+  float sx, sy, x0, y0, thr;
+  float lo[3], hi[3];
+  float* boxes;   // (B, cells, nb)
+  float* score;   // (B, cells): score of valid cells, -1 otherwise
+  int* label;     // (B, cells)
+};
+
+__global__ void decode_kernel(DecodeArgs a) {
+  const int cells = a.H * a.W;
+  const size_t total = (size_t)a.B * cells;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cell = (int)(i % cells);
+    const int yy = cell / a.W, xx = cell - yy * a.W;
+    const float* ph = a.hm + i * a.hm_ps;
+    float best = -1.f;
+    int lab = 0;
+    for (int c = 0; c < a.ncls; ++c) {
+      const float s = 1.f / (1.f + expf(-ph[c]));
+      if (s > best) { best = s; lab = c; }   // first maximum, as torch.max
+    }
+    const float* pr = a.reg + i * a.reg_ps;
+    float x, y, r = atan2f(a.rot[i * a.rot_ps], a.rot[i * a.rot_ps + 1]), azs = 0.f;
+    if (a.cylinder) {
+      const float rho = (float)xx * a.sx + a.x0, az = (float)yy * a.sy + a.y0;
+      x = rho * cosf(az) + pr[0];
+      y = rho * sinf(az) + pr[1];
+      if (a.rectify) { azs = atan2f(y, x); r += azs; }
+    } else {
+      x = ((float)xx + pr[0]) * a.sx + a.x0;
+      y = ((float)yy + pr[1]) * a.sy + a.y0;
+    }
+    const float z = a.hei[i * a.hei_ps];
+    float* o = a.boxes + i * a.nb;
+    o[0] = x; o[1] = y; o[2] = z;
+    const float* pd = a.dim + i * a.dim_ps;
+    o[3] = expf(pd[0]); o[4] = expf(pd[1]); o[5] = expf(pd[2]);
+    if (a.vel) {
+      float vx = a.vel[i * a.vel_ps], vy = a.vel[i * a.vel_ps + 1];
+      if (a.cylinder && a.rectify) {
+        const float vr = sqrtf(vx * vx + vy * vy), va = atan2f(vy, vx) + azs;
+        vx = vr * cosf(va); vy = vr * sinf(va);
+      }
+      o[6] = vx; o[7] = vy;
+    }
+    o[a.nb - 1] = r;
+    const bool ok = best > a.thr && x >= a.lo[0] && y >= a.lo[1] && z >= a.lo[2] && x <= a.hi[0] && y <= a.hi[1] && z <= a.hi[2];
+    a.score[i] = ok ? best : -1.f;
+    a.label[i] = lab;
+  }
+}
+
+// one block per sample
+__global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* __restrict__ score, const float* __restrict__ boxes, int cells, int nb,
+                                                                   int pre_max, int* __restrict__ sel_cell, float* __restrict__ nms_boxes,
+                                                                   int* __restrict__ n_sel) {
+  __shared__ unsigned long long keys[kCap];
+  __shared__ int wave_cnt[kSortThreads / 64];
+  __shared__ int base_s;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* sc = score + (size_t)b * cells;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  // ---- order-preserving compaction (cell order) of the valid cells
+  for (int c0 = 0; c0 < cells; c0 += kSortThreads) {
+    const int c = c0 + tid;
+    const float s = c < cells ? sc[c] : -1.f;
+    const bool v = s >= 0.f;
+    const unsigned long long bal = __ballot(v);
+    if (lane == 0) wave_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base_s;
+    for (int k = 0; k < wv; ++k) off += wave_cnt[k];
+    const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+    // key: score bits (positive floats order like unsigned) then ~cell, so that a descending sort yields
+    // score descending, cell ascending
+    if (v && pos < kCap) keys[pos] = ((unsigned long long)__builtin_bit_cast(unsigned, s) << 32) | (unsigned)(0xffffffffu - (unsigned)c);
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int k = 0; k < kSortThreads / 64; ++k) t += wave_cnt[k];
+      base_s += t;
+    }
+    __syncthreads();
+  }
+  const int n = min(base_s, kCap);
+  int npad = 1;
+  while (npad < n) npad <<= 1;
+  for (int i = n + tid; i < npad; i += kSortThreads) keys[i] = 0ull;
+  __syncthreads();
+  // ---- bitonic sort, descending
+  for (int k = 2; k <= npad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npad; i += kSortThreads) {
+        const int p = i ^ j;
+        if (p > i) {
+          const unsigned long long a = keys[i], c = keys[p];
+          const bool desc = (i & k) == 0;
+          if (desc ? a < c : a > c) { keys[i] = c; keys[p] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  const int m = min(n, pre_max);
+  if (tid == 0) n_sel[b] = m;
+  for (int i = tid; i < m; i += kSortThreads) {
+    const int cell = (int)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
+    sel_cell[(size_t)b * pre_max + i] = cell;
+    const float* src = boxes + ((size_t)b * cells + cell) * nb;
+    float* d = nms_boxes + ((size_t)b * pre_max + i) * 7;
+    // rotate_nms_pcdet's convention: [x, y, z, dims[1], dims[0], dims[2], -rot - pi/2]
+    d[0] = src[0]; d[1] = src[1]; d[2] = src[2]; d[3] = src[4]; d[4] = src[3]; d[5] = src[5];
+    d[6] = -src[nb - 1] - 1.57079632679489661923f;
+  }
+}
+
+// grid (col blocks, row blocks, B), 64 threads: bit j of mask[row][col block] <=> IoU(row, 64*col block + j) > thresh, j after row
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ nms_boxes, const int* __restrict__ n_sel, int pre_max, int col_blocks,
+                                                      float thresh, unsigned long long* __restrict__ mask) {
+  __shared__ float cb[64 * 7];
+  const int b = blockIdx.z, rb = blockIdx.y, cbk = blockIdx.x;
+  const int n = n_sel[b];
+  if (cbk < rb || rb * 64 >= n || cbk * 64 >= n) return;
+  const float* bx = nms_boxes + (size_t)b * pre_max * 7;
+  const int col_size = min(64, n - cbk * 64), row_size = min(64, n - rb * 64);
+  if ((int)threadIdx.x < col_size)
+    for (int k = 0; k < 7; ++k) cb[threadIdx.x * 7 + k] = bx[(size_t)(cbk * 64 + threadIdx.x) * 7 + k];
+  __syncthreads();
+  if ((int)threadIdx.x < row_size) {
+    const int row = rb * 64 + threadIdx.x;
+    float mine[7];
+    for (int k = 0; k < 7; ++k) mine[k] = bx[(size_t)row * 7 + k];
+    unsigned long long t = 0ull;
+    for (int i = (rb == cbk ? (int)threadIdx.x + 1 : 0); i < col_size; ++i)
+      if (iou_bev(mine, cb + i * 7) > thresh) t |= 1ull << i;
+    mask[((size_t)b * pre_max + row) * col_blocks + cbk] = t;
+  }
+}
+
+// grid B, one wave: lane l owns word l of the removed set (pre_max <= 4096)
+__global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ n_sel, int pre_max,
+                                                        int col_blocks, int post_max, int* __restrict__ keep, int* __restrict__ n_keep) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int n = n_sel[b];
+  const unsigned long long* mk = mask + (size_t)b * pre_max * col_blocks;
+  unsigned long long removed = 0ull;
+  int m = 0;
+  unsigned long long next = (n > 0 && lane < col_blocks && lane >= 0) ? mk[lane] : 0ull;  // row 0
+  for (int i = 0; i < n && m < post_max; ++i) {
+    const unsigned long long row = next;
+    if (i + 1 < n) next = (lane < col_blocks && lane >= (i + 1) / 64) ? mk[(size_t)(i + 1) * col_blocks + lane] : 0ull;  // prefetch
+    const unsigned long long word = __shfl(removed, i >> 6, 64);
+    if (!((word >> (i & 63)) & 1ull)) {
+      if (lane == 0) keep[(size_t)b * post_max + m] = i;
+      ++m;
+      if (lane >= (i >> 6)) removed |= row;  // words before the row's own block were never written (upper triangle only)
+    }
+  }
+  if (lane == 0) n_keep[b] = m;
+}
+
+__global__ void gather_kernel(const int* __restrict__ keep, const int* __restrict__ n_keep, const int* __restrict__ sel_cell,
+                              const float* __restrict__ boxes, const float* __restrict__ score, const int* __restrict__ label, int cells, int nb,
+                              int pre_max, int post_max, float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                              int64_t* __restrict__ out_labels, int* __restrict__ out_cells) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_keep[b]) return;
+  const int cell = sel_cell[(size_t)b * pre_max + keep[(size_t)b * post_max + i]];
+  const size_t src = (size_t)b * cells + cell, dst = (size_t)b * post_max + i;
+  for (int k = 0; k < nb; ++k) out_boxes[dst * nb + k] = boxes[src * nb + k];
+  out_scores[dst] = score[src];
+  out_labels[dst] = label[src];
+  out_cells[dst] = cell;
+}
+
+struct Ws {
+  float* boxes; float* score; int* label; int* sel_cell; float* nms_boxes; int* n_sel; unsigned long long* mask; int* keep;
+  size_t bytes;
+};
+
+Ws carve(void* base, int batch, int cells, int nb, int pre_max, int post_max) {
+  Ws w;
+  char* p = static_cast<char*>(base);
+  auto take = [&](size_t n) { char* r = p; p += (n + 255) / 256 * 256; return r; };
+  const int cbk = (pre_max + 63) / 64;
+  w.boxes = (float*)take((size_t)batch * cells * nb * 4);
+  w.score = (float*)take((size_t)batch * cells * 4);
+  w.label = (int*)take((size_t)batch * cells * 4);
+  w.sel_cell = (int*)take((size_t)batch * pre_max * 4);
+  w.nms_boxes = (float*)take((size_t)batch * pre_max * 7 * 4);
+  w.n_sel = (int*)take((size_t)batch * 4);
+  w.mask = (unsigned long long*)take((size_t)batch * pre_max * cbk * 8);
+  w.keep = (int*)take((size_t)batch * post_max * 4);
+  w.bytes = (size_t)(p - static_cast<char*>(base));
+  return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pn_center_decode_nms_workspace_bytes(int batch, int cells, int box_dims, int pre_max, int post_max) {
+  return carve(nullptr, batch, cells, box_dims, pre_max, post_max).bytes;
+}
+
+int pn_center_decode_nms_f32(const float* hm, int hm_pixel_stride, int classes, const float* reg, int reg_pixel_stride, const float* height,
+                             int height_pixel_stride, const float* dim, int dim_pixel_stride, const float* rot, int rot_pixel_stride,
+                             const float* vel, int vel_pixel_stride, int batch, int h, int w, int cylinder, float step_x, float step_y,
+                             float origin_x, float origin_y, int rectify, float score_threshold, const float* post_center_range,
+                             float nms_iou_threshold, int pre_max, int post_max, float* out_boxes, float* out_scores, int64_t* out_labels,
+                             int32_t* out_cells, int32_t* out_count, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(hm && reg && height && dim && rot && post_center_range && out_boxes && out_scores && out_labels && out_cells && out_count && workspace,
+             "center_decode_nms: null pointer");
+  PN_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && classes >= 1, "center_decode_nms: bad sizes");
+  PN_REQUIRE(pre_max >= 1 && pre_max <= 4096 && post_max >= 1, "center_decode_nms: nms_pre_max_size must be in [1, 4096]");
+  const int nb = vel ? 9 : 7, cells = h * w;
+  Ws ws = carve(workspace, batch, cells, nb, pre_max, post_max);
+  PN_REQUIRE(workspace_bytes >= ws.bytes, "center_decode_nms: workspace too small");
+  hipStream_t st = pn::S(stream);
+  DecodeArgs a{};
+  a.hm = hm; a.hm_ps = hm_pixel_stride; a.ncls = classes; a.reg = reg; a.reg_ps = reg_pixel_stride; a.hei = height; a.hei_ps = height_pixel_stride;
+  a.dim = dim; a.dim_ps = dim_pixel_stride; a.rot = rot; a.rot_ps = rot_pixel_stride; a.vel = vel; a.vel_ps = vel_pixel_stride;
+  a.B = batch; a.H = h; a.W = w; a.cylinder = cylinder; a.rectify = rectify; a.nb = nb;
+  a.sx = step_x; a.sy = step_y; a.x0 = origin_x; a.y0 = origin_y; a.thr = score_threshold;
+  for (int k = 0; k < 3; ++k) { a.lo[k] = post_center_range[k]; a.hi[k] = post_center_range[3 + k]; }
+  a.boxes = ws.boxes; a.score = ws.score; a.label = ws.label;
+  const size_t total = (size_t)batch * cells;
+  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(select_sort_kernel, dim3(batch), dim3(kSortThreads), 0, st, ws.score, ws.boxes, cells, nb, pre_max, ws.sel_cell, ws.nms_boxes,
+                     ws.n_sel);
+  const int cbk = (pre_max + 63) / 64;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(cbk, cbk, batch), dim3(64), 0, st, ws.nms_boxes, ws.n_sel, pre_max, cbk, nms_iou_threshold, ws.mask);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(batch), dim3(64), 0, st, ws.mask, ws.n_sel, pre_max, cbk, post_max, ws.keep, out_count);
+  hipLaunchKernelGGL(gather_kernel, dim3((post_max + 127) / 128, batch), dim3(128), 0, st, ws.keep, out_count, ws.sel_cell, ws.boxes, ws.score,
+                     ws.label, cells, nb, pre_max, post_max, out_boxes, out_scores, out_labels, out_cells);
+  return pn::check_launch("center_decode_nms");
+}
+
+}  // extern "C"

@@ -157,8 +157,66 @@ class CenterHead(nn.Module):
             rets["num_positive"].append(out[3])
         return rets
 
+    @torch.no_grad()
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
-        raise NotImplementedError("decode + rotated NMS (SURVEY.md 8f next-2) is outside this round's hot path")
+        """decode + rotated NMS on the device (center_head.py:404-460, 350-402, 462-577), plain path: no double flip,
+        no stateful / per-class NMS, no panoptic, sector 0.  Returns the reference's list (one dict per sample) of
+        'box3d_lidar' (n, 9|7), 'scores', 'label_preds', 'metadata'."""
+        import ctypes as C
+        lib = hip.load()
+        get = (lambda k, d=None: test_cfg.get(k, d)) if hasattr(test_cfg, "get") else (lambda k, d=None: getattr(test_cfg, k, d))
+        for flag in ("double_flip", "stateful_nms", "panoptic", "per_class_nms"):
+            if get(flag, False):
+                raise NotImplementedError(f"predict: test_cfg.{flag} is not built (only the plain decode + rotate_nms_pcdet path)")
+        if kwargs.get("prev_dets") is not None or kwargs.get("sec_id", 0) != 0:
+            raise NotImplementedError("predict: sector streaming (prev_dets / sec_id > 0) is not built")
+        nms = get("nms")
+        nget = (lambda k: nms[k]) if isinstance(nms, dict) else (lambda k: getattr(nms, k))
+        pre_max, post_max, iou_thr = int(nget("nms_pre_max_size")), int(nget("nms_post_max_size")), float(nget("nms_iou_threshold"))
+        pcr = list(get("post_center_limit_range"))
+        assert len(pcr) == 6, "predict: post_center_limit_range must have 6 entries"
+        osf, vs, pr = get("out_size_factor"), get("voxel_size"), get("pc_range")
+        cyl = int(self.voxel_shape == "cylinder")
+        if not cyl:
+            pr = [float(v) for v in example["pc_range"][0]][:2] if "pc_range" in example else pr  # ref_pc_range of the reference
+        rets = []
+        for pd in preds_dicts["det_preds"]:
+            hm = pd["hm"]
+            hip.require_device(hm)
+            b, ncls, h, w = hm.shape
+            names = ["hm", "reg", "height", "dim", "rot"] + (["vel"] if "vel" in pd else [])
+            for k in names:
+                t = pd[k]
+                assert t.stride(1) == 1 and t.stride(2) == w * t.stride(3), "head tensors must be channels-last views"
+            nb = 9 if "vel" in pd else 7
+            dev = hm.device
+            out_boxes = torch.empty((b, post_max, nb), dtype=torch.float32, device=dev)
+            out_scores = torch.empty((b, post_max), dtype=torch.float32, device=dev)
+            out_labels = torch.empty((b, post_max), dtype=torch.int64, device=dev)
+            out_cells = torch.empty((b, post_max), dtype=torch.int32, device=dev)
+            out_count = torch.empty((b,), dtype=torch.int32, device=dev)
+            wsb = lib.pn_center_decode_nms_workspace_bytes(b, h * w, nb, pre_max, post_max)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            vel = pd.get("vel")
+            hip.call("pn_center_decode_nms_f32", hm.data_ptr(), hm.stride(3), ncls, pd["reg"].data_ptr(), pd["reg"].stride(3),
+                     pd["height"].data_ptr(), pd["height"].stride(3), pd["dim"].data_ptr(), pd["dim"].stride(3), pd["rot"].data_ptr(),
+                     pd["rot"].stride(3), hip.ptr(vel), 0 if vel is None else vel.stride(3), b, h, w, cyl, float(osf) * float(vs[0]),
+                     float(osf) * float(vs[1]), float(pr[0]), float(pr[1]), int(bool(get("rectify", False))), float(get("score_threshold")),
+                     (C.c_float * 6)(*[float(v) for v in pcr]), iou_thr, pre_max, post_max, out_boxes.data_ptr(), out_scores.data_ptr(),
+                     out_labels.data_ptr(), out_cells.data_ptr(), out_count.data_ptr(), ws.data_ptr(), wsb, hip.stream())
+            counts = out_count.cpu().tolist()  # the one host sync of the call: the API returns exact-size tensors
+            rets.append([dict(box3d_lidar=out_boxes[i, :n], scores=out_scores[i, :n], label_preds=out_labels[i, :n], cells=out_cells[i, :n])
+                         for i, n in enumerate(counts)])
+        metas = example.get("metadata", [None] * len(rets[0])) if isinstance(example, dict) else [None] * len(rets[0])
+        ret_list = []
+        for i in range(len(rets[0])):
+            flag, labels = 0, []
+            for j, ncls in enumerate(self.num_classes[:len(rets)]):
+                labels.append(rets[j][i]["label_preds"] + flag)
+                flag += ncls
+            ret_list.append(dict(box3d_lidar=torch.cat([r[i]["box3d_lidar"] for r in rets]), scores=torch.cat([r[i]["scores"] for r in rets]),
+                                 label_preds=torch.cat(labels), cells=torch.cat([r[i]["cells"] for r in rets]), metadata=metas[i]))
+        return ret_list
 
 
 @BBOX_HEADS.register_module

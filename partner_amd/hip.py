@@ -95,6 +95,9 @@ SIGNATURES = {
     "pn_setblock_range_attn": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "pn_setblock_sector_col_attn": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "pn_swv_window_attn": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "pn_center_decode_nms_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "pn_center_decode_nms_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _P, _F, _I, _I,
+                                      _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "pn_nchw_to_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "pn_nhwc_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "pn_grad_norm_workspace_bytes": (_SZ, []),
