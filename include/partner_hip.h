@@ -518,6 +518,44 @@ int pn_center_decode_nms_f32(const float *hm, int hm_pixel_stride, int classes, 
                              int32_t *out_cells, int32_t *out_count, void *workspace,
                              size_t workspace_bytes, pn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * next-1  sparse 3-D convolutions of the middle encoder SpMiddleResNetFHD
+ * (det3d/models/backbones/scn.py:17-192; the arithmetic is the third-party spconv package there: SubMConv3d /
+ * SparseConv3d / SparseConvTensor.dense -- parity unpinned, restated in oracle/polar_oracle.py).
+ * A level's active set = bitmap over its (B,D,H,W) cells + per-word ranks ("index", pn_sparse_index_bytes);
+ * features live in key order, key = ((b*D+z)*H+y)*W+x.  All counts stay on the device.
+ *   pn_sparse_index_from_coords   coords (n,4) int32 [b,z,y,x] -> index, keys (rank order), count, and the rank of
+ *                                 every input row (pn_sparse_permute_rows then puts the features in key order)
+ *   pn_sparse_index_downsample    active output sites of a strided SparseConv3d (kernel/stride/pad per axis z,y,x)
+ *   pn_sparse_neighbors           nbr[out site][tap] = input index or -1; tap = (kz*KH + ky)*KW + kx; one table
+ *                                 serves every convolution that shares an indice_key
+ *   pn_sparse_conv_f32            out = act((sum_t W_t in[nbr[.][t]]) * scale + shift + residual), on the MFMA
+ *                                 kernel in gather mode; packed_w = pn_pack_conv_weight_f32 of (Cout, Cin, taps, 1)
+ *   pn_sparse_to_dense_nhwc       (B, H, W, C*D) with channel c*D + z  ==  .dense().view(N, C*D, H, W) in NHWC
+ */
+size_t pn_sparse_index_bytes(uint64_t num_cells);
+int pn_sparse_index_from_coords(const int32_t *coords, int n_capacity, const int32_t *n_dev,
+                                const int32_t *dims, void *index_buf, uint32_t *keys, int32_t *count,
+                                int32_t *rank_of_input, pn_stream_t stream);
+int pn_sparse_index_downsample(const uint32_t *in_keys, int in_capacity, const int32_t *n_in,
+                               const int32_t *in_dims, const int32_t *kernel, const int32_t *stride,
+                               const int32_t *pad, const int32_t *out_dims, void *out_index_buf,
+                               uint32_t *out_keys, int out_capacity, int32_t *out_count,
+                               pn_stream_t stream);
+int pn_sparse_neighbors(const uint32_t *out_keys, int out_capacity, const int32_t *n_out,
+                        const int32_t *out_dims, const void *in_index_buf, const int32_t *in_dims,
+                        const int32_t *kernel, const int32_t *stride, const int32_t *pad, int32_t *nbr,
+                        pn_stream_t stream);
+int pn_sparse_permute_rows(const float *in, const int32_t *rank, int n_capacity, const int32_t *n_dev,
+                           int c, float *out, pn_stream_t stream);
+int pn_sparse_conv_f32(const float *in, int in_rows, int cin, const int32_t *nbr, const int32_t *n_out,
+                       int out_capacity, int taps, const float *packed_w, int cout, const float *scale,
+                       const float *shift, int act, const float *residual, float *out,
+                       pn_stream_t stream);
+int pn_sparse_to_dense_nhwc(const float *feats, const uint32_t *keys, int capacity,
+                            const int32_t *n_dev, const int32_t *dims, int c, float *out,
+                            pn_stream_t stream);
+
 /* layout helpers at the API boundary */
 int pn_nchw_to_nhwc_f32(const float *in, int b, int c, int h, int w, float *out, pn_stream_t stream);
 int pn_nhwc_to_nchw_f32(const float *in, int b, int c, int h, int w, int pixel_stride,

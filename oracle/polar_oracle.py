@@ -822,3 +822,70 @@ def center_post_process(boxes: np.ndarray, hm: np.ndarray, score_threshold: floa
     keep = np.asarray(nms_fn(nms_boxes_pcdet(b[order]), nms_iou_threshold), np.int64)
     sel = order[keep][:nms_post_max_size]
     return dict(box3d_lidar=b[sel], scores=s[sel], label_preds=l[sel], cells=cells[sel])
+
+
+# ======================================================================================
+# next-1  SpMiddleResNetFHD (sparse 3-D middle encoder)   det3d/models/backbones/scn.py:17-192
+# PARITY UNPINNED: the arithmetic of SubMConv3d / SparseConv3d / SparseConvTensor.dense is the third-party spconv
+# package (README.md:45 `spconv-cu114`, unpinned), which is not installed here and has no CPU path in the reference.
+# Restated from spconv's published semantics on DENSE tensors with an explicit activity mask:
+#   SubMConv3d      y = conv3d(x, W, b, padding=k//2) at the ACTIVE INPUT sites only (the active set is unchanged)
+#   SparseConv3d    y = conv3d(x, W, None, stride, padding); active outputs = sites whose receptive field holds an
+#                   active input (max-pool of the mask)
+#   BatchNorm1d / ReLU act on active features only; inactive sites stay exactly zero in .dense()
+# Weight layout of spconv 2.x: (Cout, kD, kH, kW, Cin).
+# ======================================================================================
+def _sp_w(w: Tensor) -> Tensor:
+    return w.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def _sp_bn(sd: SD, p: str, x: Tensor, mask: Tensor, eps=1e-3) -> Tensor:
+    y = (x - sd[p + "running_mean"][None, :, None, None, None]) / torch.sqrt(sd[p + "running_var"][None, :, None, None, None] + eps)
+    return (y * sd[p + "weight"][None, :, None, None, None] + sd[p + "bias"][None, :, None, None, None]) * mask
+
+
+def _sp_subm(sd: SD, p: str, x: Tensor, mask: Tensor) -> Tensor:
+    w = _sp_w(sd[p + "weight"])
+    return F.conv3d(x, w, sd.get(p + "bias"), padding=[k // 2 for k in w.shape[2:]]) * mask
+
+
+def _sp_down(sd: SD, p: str, x: Tensor, mask: Tensor, stride, padding):
+    w = _sp_w(sd[p + "weight"])
+    k = list(w.shape[2:])
+    m = (F.max_pool3d(mask, k, stride, padding) > 0).float()
+    return F.conv3d(x, w, None, stride, padding) * m, m
+
+
+def _sp_block(sd: SD, p: str, x: Tensor, mask: Tensor) -> Tensor:
+    out = F.relu(_sp_bn(sd, p + "bn1.", _sp_subm(sd, p + "conv1.", x, mask), mask))
+    out = _sp_bn(sd, p + "bn2.", _sp_subm(sd, p + "conv2.", out, mask), mask)
+    return F.relu(out + x)
+
+
+def sp_middle_resnet_fhd(sd: SD, prefix: str, voxel_features: Tensor, coors: np.ndarray, batch_size: int, input_shape,
+                         extra_sp_shape=(1, 0, 0), return_stages=False):
+    """voxel_features (V,C); coors (V,4) int [b,z,y,x]; input_shape [x,y,z] -> (B, C*D, H, W) dense BEV map (scn.py:157-192)"""
+    D, H, W = (int(v) + e for v, e in zip(list(input_shape)[::-1], extra_sp_shape))
+    C = voxel_features.shape[1]
+    x = torch.zeros((batch_size, C, D, H, W))
+    mask = torch.zeros((batch_size, 1, D, H, W))
+    c = torch.from_numpy(np.asarray(coors)).long()
+    x[c[:, 0], :, c[:, 1], c[:, 2], c[:, 3]] = voxel_features
+    mask[c[:, 0], 0, c[:, 1], c[:, 2], c[:, 3]] = 1.0
+    p = prefix
+    x = F.relu(_sp_bn(sd, p + "conv_input.1.", _sp_subm(sd, p + "conv_input.0.", x, mask), mask))
+    for i in range(2):
+        x = _sp_block(sd, f"{p}conv1.{i}.", x, mask)
+    stages = [x]
+    pad4 = 0 if extra_sp_shape[0] != 0 else 1
+    for name, pad in (("conv2", [1, 1, 1]), ("conv3", [1, 1, 1]), ("conv4", [pad4, 1, 1])):
+        x, mask = _sp_down(sd, f"{p}{name}.0.", x, mask, [2, 2, 2], pad)
+        x = F.relu(_sp_bn(sd, f"{p}{name}.1.", x, mask))
+        for i in (3, 4):
+            x = _sp_block(sd, f"{p}{name}.{i}.", x, mask)
+        stages.append(x)
+    x, mask = _sp_down(sd, p + "extra_conv.0.", x, mask, [2, 1, 1], [0, 0, 0])
+    x = F.relu(_sp_bn(sd, p + "extra_conv.1.", x, mask))
+    N, Cc, Dd, Hh, Ww = x.shape
+    ret = x.reshape(N, Cc * Dd, Hh, Ww)
+    return (ret, stages) if return_stages else ret

@@ -68,12 +68,16 @@ struct ConvArgs {
   int force_tile;        // >0: tile override (tuning / tests)
   const float* res;      // optional residual added after the activation (GEMM use)
   int res_ps;
+  // gather mode (sparse convolution): GEMM row m = output site, tap t reads input row nbr[m*taps + t] (-1: none)
+  const int* nbr;
+  const int* n_valid;    // device count of valid output sites (rows beyond it are neither computed nor written)
+  int res_pre_act;       // 1: out = act(conv*scale + shift + residual) (residual blocks); 0: act(...) + residual
 };
 
 constexpr int BK = 32;
 constexpr int A_LD = BK + 4;
 
-template <int WM, int WN, int TM, int TN, int DT = DT_F32>
+template <int WM, int WN, int TM, int TN, int DT = DT_F32, bool GATHER = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   constexpr int ES = DT == DT_F32 ? 4 : 2;   // bytes per input element
   constexpr int CPC = 16 / ES;               // channels per 16-byte chunk
@@ -104,6 +108,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   }
   const int m0 = mt * BM;
   const int n0 = blockIdx.y * BN;
+  int m_valid = a.M;
+  int* nbr_s = reinterpret_cast<int*>(smem + 2 * STAGE);  // gather mode: this block's [BM][taps] neighbour rows
+  if constexpr (GATHER) {
+    m_valid = min(a.M, *a.n_valid);
+    if (m0 >= m_valid) return;  // block uniform, before any barrier
+    const int tps = a.KH * a.KW;
+    for (int i = tid; i < BM * tps; i += NT) {
+      const int m = m0 + i / tps;
+      nbr_s[i] = m < m_valid ? a.nbr[(size_t)m0 * tps + i] : -1;
+    }
+    __syncthreads();
+  }
 
   // ---- global -> register staging through buffer loads --------------------------------------
   // Every per-step address is  descriptor base + per-thread voffset (fixed) + wave-uniform
@@ -129,7 +145,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     const int ow = rem - oh * a.OWsub + (a.mode == MODE_STRAT ? z * a.OWsub : 0);
     const int ih0 = oh * a.stride - a.pad_h, iw0 = ow * a.stride - a.pad_w;
     const long long pix = ((long long)b * a.H + ih0) * a.W + iw0;  // may be negative by at most `back`/in_ps
-    a_off[j] = (unsigned)((pix * a.in_ps + back + a.in_co + z * a.in_group_stride + c4 * CPC) * ES);
+    a_off[j] = GATHER ? (unsigned)((a.in_co + c4 * CPC) * ES)
+                      : (unsigned)((pix * a.in_ps + back + a.in_co + z * a.in_group_stride + c4 * CPC) * ES);
     unsigned mk = 0;
     for (int kh = 0, t = 0; kh < a.KH; ++kh)
       for (int kw = 0; kw < a.KW; ++kw, ++t)
@@ -156,15 +173,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   // (tap, chunk) of the next tile to fetch, advanced incrementally: scalar adds only
   int ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
   auto load_global = [&](bool live) {
-    const unsigned so_a = (unsigned)(((ld_kh * a.W + ld_kw) * a.in_ps + ld_chunk * BKC) * ES);
+    const unsigned so_a = GATHER ? (unsigned)(ld_chunk * BKC * ES) : (unsigned)(((ld_kh * a.W + ld_kw) * a.in_ps + ld_chunk * BKC) * ES);
     const unsigned so_b = (unsigned)((ld_tap * a.cin_chunks + ld_chunk) * 8) * (unsigned)a.cout_pad * 16u;
     // `live` == false (past the last K step): every lane is redirected out of range, the loads
     // return zeros without touching memory and the loop body stays branch-free
     const unsigned cok = (unsigned)(live && ld_chunk * BKC + c4 * CPC < a.Cin);
 #pragma unroll
     for (int j = 0; j < A_PER_T; ++j) {
-      const unsigned sel = (a_mask[j] >> ld_tap) & cok;          // 1: inside the map
-      const unsigned vo = a_off[j] | (0u - (1u - (sel & 1u)));   // branch-free: ~0 when outside
+      unsigned vo;
+      if constexpr (GATHER) {
+        const int idx = nbr_s[((tid >> 3) + (NT / 8) * j) * taps + ld_tap];   // input row of this (site, tap), -1: inactive
+        vo = (idx >= 0 && cok) ? (unsigned)idx * (unsigned)(a.in_ps * ES) + a_off[j] : 0xffffffffu;
+      } else {
+        const unsigned sel = (a_mask[j] >> ld_tap) & cok;          // 1: inside the map
+        vo = a_off[j] | (0u - (1u - (sel & 1u)));                  // branch-free: ~0 when outside
+      }
       ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, so_a, 0));
     }
 #pragma unroll
@@ -328,7 +351,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
       const int row = p * RPP + rr;
       const int gm = m0 + wm * TR + row;
       const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * TLD + cg * 4);
-      if (gm >= a.M || !cok) continue;
+      if (gm >= m_valid || !cok) continue;
       size_t pix;
       if (a.mode == MODE_CONV) {
         pix = (size_t)gm;
@@ -341,12 +364,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
                                      : ((size_t)b * a.OH + oh) * a.OW + ow;
       }
       f32x4 o;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = pn::apply_act(fmaf(v[k], vs[k], vh[k]), a.act);
-      if (a.res) {
+      if (a.res && a.res_pre_act) {
         const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + pix * a.res_ps + coff);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] += rv[k];
+        for (int k = 0; k < 4; ++k) o[k] = pn::apply_act(fmaf(v[k], vs[k], vh[k]) + rv[k], a.act);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pn::apply_act(fmaf(v[k], vs[k], vh[k]), a.act);
+        if (a.res) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + pix * a.res_ps + coff);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] += rv[k];
+        }
       }
       if constexpr (DT == DT_BF16) {
         using u16x4 = __attribute__((ext_vector_type(4))) unsigned short;
@@ -384,7 +413,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const int gm = m0 + row;
-      if (gm >= a.M) continue;
+      if (gm >= m_valid) continue;
       size_t pix;  // output pixel index (deconv: the top-left of the 2x2 cell)
       int b = 0, oh = 0, ow = 0;
       if (a.mode == MODE_CONV) {
@@ -406,8 +435,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
           rpix = ((size_t)b * (2 * a.OH) + 2 * oh + (col_d[j] >> 1)) * (2 * a.OW) + 2 * ow + (col_d[j] & 1);
           dst = a.out + rpix * a.out_ps + col_off[j];
         }
-        float o = pn::apply_act(fmaf(acc[i][j][r], sc[j], sh[j]), a.act);
-        if (a.res) o += a.res[rpix * a.res_ps + col_off[j]];
+        float o;
+        if (a.res && a.res_pre_act) {
+          o = pn::apply_act(fmaf(acc[i][j][r], sc[j], sh[j]) + a.res[rpix * a.res_ps + col_off[j]], a.act);
+        } else {
+          o = pn::apply_act(fmaf(acc[i][j][r], sc[j], sh[j]), a.act);
+          if (a.res) o += a.res[rpix * a.res_ps + col_off[j]];
+        }
         if constexpr (DT == DT_BF16)
           reinterpret_cast<unsigned short*>(a.out)[dst - a.out] = f32_to_bf16_rne(o);
         else
@@ -494,20 +528,21 @@ __global__ void conv_direct_kernel(ConvArgs a, const float* __restrict__ w_oihw,
   }
 }
 
-template <int WM, int WN, int TM, int TN, int DT = DT_F32>
+template <int WM, int WN, int TM, int TN, int DT = DT_F32, bool GATHER = false>
 int launch_conv(const ConvArgs& a, int zdim, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr size_t smem = 2 * (size_t)(BM * A_LD + BK * BN) * sizeof(float);
+  // gather mode keeps the block's [BM][taps <= 32] neighbour table behind the two staging buffers
+  constexpr size_t smem = 2 * (size_t)(BM * A_LD + BK * BN) * sizeof(float) + (GATHER ? (size_t)BM * 32 * sizeof(int) : 0);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, DT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, DT, GATHER>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
   ConvArgs b = a;
   b.nmt = pn::cdiv(a.M, BM);
   dim3 grid(b.nmt, pn::cdiv(a.ncols, BN), zdim);
-  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, DT>), grid, dim3(WM * WN * 64), smem, st, b);
+  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, DT, GATHER>), grid, dim3(WM * WN * 64), smem, st, b);
   return pn::check_launch("conv_mfma_kernel");
 }
 
@@ -551,6 +586,9 @@ int fill_args(const pn_conv_desc* d, ConvArgs& a, int& zdim, int es = 4) {
   a.force_tile = 0;
   a.res = nullptr;
   a.res_ps = 0;
+  a.nbr = nullptr;
+  a.n_valid = nullptr;
+  a.res_pre_act = 0;
   return PN_OK;
 }
 
@@ -631,6 +669,30 @@ __global__ void bf16_to_f32_kernel(const unsigned short* __restrict__ x, float* 
 }  // namespace
 
 extern "C" {
+
+/* ---- sparse convolution as a gathered GEMM: out[m] = act((sum_t W_t . in[nbr[m][t]]) * scale + shift) (+ residual[m]).
+ * Same kernel, MODE "gather": the A tile loader takes the input row of every (output site, tap) from the block's neighbour table
+ * (staged in LDS) instead of pixel arithmetic.  packed_w: pn_pack_conv_weight_f32 of the weight seen as (Cout, Cin, taps, 1). ---- */
+int pn_sparse_conv_f32(const float* in, int in_rows, int cin, const int32_t* nbr, const int32_t* n_out, int out_capacity, int taps,
+                       const float* packed_w, int cout, const float* scale, const float* shift, int act, const float* residual, float* out,
+                       pn_stream_t stream) {
+  PN_REQUIRE(in && nbr && n_out && packed_w && out, "sparse_conv: null pointer");
+  PN_REQUIRE(in_rows >= 1 && cin >= 4 && cin % 4 == 0 && cout >= 1 && out_capacity >= 1 && taps >= 1 && taps <= 32, "sparse_conv: bad sizes");
+  PN_REQUIRE((unsigned long long)in_rows * cin * 4ull < (1ull << 31), "sparse_conv: input feature matrix larger than 2 GiB");
+  ConvArgs a{};
+  a.in = in; a.w = packed_w; a.scale = scale; a.shift = shift; a.out = out;
+  a.B = 1; a.H = in_rows; a.W = 1; a.Cin = cin; a.Cout = cout; a.OH = out_capacity; a.OW = 1;
+  a.KH = taps; a.KW = 1; a.stride = 1; a.pad_h = 0; a.pad_w = 0;
+  a.in_ps = cin; a.in_co = 0; a.out_ps = cout; a.out_co = 0; a.act = act; a.mode = MODE_CONV;
+  a.M = out_capacity; a.OWsub = 1; a.cin_chunks = pn::cdiv(cin, BK); a.cout_pad = pn::cdiv(cout, 32) * 32; a.ncols = cout;
+  a.in_group_stride = 0; a.in_bytes = (unsigned)((size_t)in_rows * cin * 4); a.w_bytes = (unsigned)((size_t)taps * a.cin_chunks * 8 * a.cout_pad * 16);
+  a.res = residual; a.res_ps = cout; a.nbr = nbr; a.n_valid = n_out;
+  a.res_pre_act = 1;  // SparseBasicBlock: relu(bn2(conv2(.)) + identity), scn.py:84-95
+  hipStream_t st = pn::S(stream);
+  if (cout > 64) return out_capacity >= 128 * 128 ? launch_conv<2, 2, 2, 2, DT_F32, true>(a, 1, st) : launch_conv<2, 2, 1, 2, DT_F32, true>(a, 1, st);
+  if (cout > 32) return launch_conv<2, 2, 1, 1, DT_F32, true>(a, 1, st);
+  return launch_conv<2, 1, 1, 1, DT_F32, true>(a, 1, st);
+}
 
 /* ---- bf16 variant (BASELINE configs[3]: "bf16 BEV convs on MFMA"): bf16 activations and weights, f32 accumulate on
  * v_mfma_f32_32x32x16_bf16, scale / shift / activation in f32, output bf16 (or f32 for the last layer) ---- */

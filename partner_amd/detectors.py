@@ -123,25 +123,10 @@ class VoxelNet(SingleStageDetector):
         raise NotImplementedError("VoxelNet forward needs the sparse 3-D backbone (SURVEY.md 8f next-1), not built yet")
 
 
-@builder.BACKBONES.register_module
-class SpMiddleResNetFHD(nn.Module):
-    """Sparse 3-D middle encoder of the Waymo PARTNER config (det3d/models/backbones/scn.py:97-192).  Its
-    arithmetic lives in the third-party spconv package; a gfx950 sparse convolution is SURVEY.md 8f next-1.
-    Registered so that the config builds; calling it raises."""
-
-    def __init__(self, num_input_features=128, norm_cfg=None, name="SpMiddleResNetFHD", **kwargs):
-        super().__init__()
-        self.name = name
-
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("SpMiddleResNetFHD (sparse 3-D convolutions) has no gfx950 kernel yet (SURVEY.md 8f next-1)")
-
-
 @DETECTORS.register_module
 class VoxelNetV3(SingleStageDetector):
     """PARTNER detector (voxelnet.py:171-301): hard voxels -> mean VFE -> sparse 3-D backbone -> two SetBlocks
-    (global representation re-alignment) -> RPN -> head.  The re-alignment stage is built and runs on the HIP
-    kernels (``realign``); the end-to-end forward waits for the sparse backbone."""
+    (global representation re-alignment) -> RPN -> head, end to end on the HIP kernels (eval mode)."""
 
     def __init__(self, reader, backbone, neck, bbox_head, seg_head=None, part_head=None, train_cfg=None, test_cfg=None,
                  pretrained=None):
@@ -167,6 +152,44 @@ class VoxelNetV3(SingleStageDetector):
         hip.call("pn_transpose_hw_f32", y.contiguous().data_ptr(), b, r, t, c, out.data_ptr(), hip.stream())
         return ops.as_nchw(out)
 
+    def realign_nhwc(self, xh: torch.Tensor) -> torch.Tensor:
+        """NHWC (B, theta, r, C) -> same, through the two SetBlocks (token order of the reference: r-major, voxelnet.py:210-221)"""
+        b, t, r, c = xh.shape
+        tok = torch.empty((b, r, t, c), dtype=torch.float32, device=xh.device)
+        hip.call("pn_transpose_hw_f32", xh.data_ptr(), b, t, r, c, tok.data_ptr(), hip.stream())
+        y = tok.view(b, r * t, c)
+        for attn in self.attns:
+            y = attn(y)
+        out = torch.empty((b, t, r, c), dtype=torch.float32, device=xh.device)
+        hip.call("pn_transpose_hw_f32", y.contiguous().data_ptr(), b, r, t, c, out.data_ptr(), hip.stream())
+        return out
+
+    def extract_feat_hard(self, data):
+        """voxelnet.py:202-227: mean VFE -> sparse 3-D backbone -> 2 x SetBlock -> RPN; returns the NHWC neck output"""
+        feats = self.reader(data["features"], data["num_voxels"])
+        x = self.backbone.forward_nhwc(feats, data["coors"], data["batch_size"], data["input_shape"])
+        x = self.realign_nhwc(x)
+        if self.with_neck:
+            x = self.neck.forward_nhwc(x)
+        return x
+
     def forward(self, example, return_loss=True, **kwargs):
-        raise NotImplementedError("VoxelNetV3 end-to-end forward needs the sparse 3-D backbone (SURVEY.md 8f next-1); "
-                                  "reader, realign(), neck and head run stand-alone")
+        """hard-voxel branch of voxelnet.py:239-301 (the Waymo PARTNER config); example keys: voxels (V,P,F), coordinates (V,4)
+        [b,z,y,x], num_points (V,), num_voxels (B,), shape [[x,y,z]]"""
+        if "voxels" not in example:
+            raise NotImplementedError("VoxelNetV3: only the hard-voxel branch of the PARTNER config is built")
+        hip.require_device(example["voxels"], example["coordinates"])
+        data = dict(features=example["voxels"], num_voxels=example["num_points"], coors=example["coordinates"],
+                    batch_size=len(example["num_voxels"]), input_shape=[int(v) for v in example["shape"][0]])
+        x = self.extract_feat_hard(data)
+        head_out = self.bbox_head.forward_nhwc(x) if hasattr(self.bbox_head, "forward_nhwc") else None
+        if head_out is not None:
+            head_out.pop("_feat", None)
+            preds = {"det_preds": [{k: v.permute(0, 3, 1, 2) for k, v in head_out.items()}]}
+        else:
+            preds = self.bbox_head(ops.as_nchw(x))
+        if return_loss:
+            return self.bbox_head.loss(example, preds)
+        if kwargs.get("raw_preds", False) or self.test_cfg is None:
+            return preds
+        return {"det": self.bbox_head.predict(example, preds, self.test_cfg, **kwargs)}
