@@ -119,6 +119,23 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
       nbr_s[i] = m < m_valid ? a.nbr[(size_t)m0 * tps + i] : -1;
     }
     __syncthreads();
+    // Taps for which none of this tile's sites has an active neighbour are skipped altogether: sites are stored in
+    // key order, so a tile is a run of neighbouring cells and most of the 27 offsets point at empty space together.
+    // tap_list[0 .. n) = the live taps in ascending order, tap_list[32] = n.
+    int* tap_list = nbr_s + BM * 32;
+    if (tid < tps) {
+      int any = 0;
+      for (int r = 0; r < BM; ++r) any |= nbr_s[r * tps + tid] >= 0;
+      tap_list[33 + tid] = any;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int n = 0;
+      for (int t = 0; t < tps; ++t)
+        if (tap_list[33 + t]) tap_list[n++] = t;
+      tap_list[32] = n;
+    }
+    __syncthreads();
   }
 
   // ---- global -> register staging through buffer loads --------------------------------------
@@ -164,7 +181,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
       reinterpret_cast<char*>(const_cast<float*>(a.in)) - back * ES, 0, a.in_bytes + (unsigned)(back * ES), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(const_cast<float*>(a.w)) + (size_t)z * taps * a.cin_chunks * 8 * a.cout_pad * 16, 0, a.w_bytes, 0x00020000);
-  const int nsteps = taps * a.cin_chunks;
+  const int* tap_list = nbr_s + BM * 32;
+  const int taps_loop = GATHER ? tap_list[32] : taps;   // taps the K loop runs over
+  const int nsteps = taps_loop * a.cin_chunks;
 
   f32x4 ra[A_PER_T], rb[B_PER_T];
 
@@ -174,7 +193,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   int ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
   auto load_global = [&](bool live) {
     const unsigned so_a = GATHER ? (unsigned)(ld_chunk * BKC * ES) : (unsigned)(((ld_kh * a.W + ld_kw) * a.in_ps + ld_chunk * BKC) * ES);
-    const unsigned so_b = (unsigned)((ld_tap * a.cin_chunks + ld_chunk) * 8) * (unsigned)a.cout_pad * 16u;
+    const int tap = GATHER ? __builtin_amdgcn_readfirstlane(tap_list[ld_tap]) : ld_tap;
+    const unsigned so_b = (unsigned)((tap * a.cin_chunks + ld_chunk) * 8) * (unsigned)a.cout_pad * 16u;
     // `live` == false (past the last K step): every lane is redirected out of range, the loads
     // return zeros without touching memory and the loop body stays branch-free
     const unsigned cok = (unsigned)(live && ld_chunk * BKC + c4 * CPC < a.Cin);
@@ -182,7 +202,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     for (int j = 0; j < A_PER_T; ++j) {
       unsigned vo;
       if constexpr (GATHER) {
-        const int idx = nbr_s[((tid >> 3) + (NT / 8) * j) * taps + ld_tap];   // input row of this (site, tap), -1: inactive
+        const int idx = nbr_s[((tid >> 3) + (NT / 8) * j) * taps + tap];   // input row of this (site, tap), -1: inactive
         vo = (idx >= 0 && cok) ? (unsigned)idx * (unsigned)(a.in_ps * ES) + a_off[j] : 0xffffffffu;
       } else {
         const unsigned sel = (a_mask[j] >> ld_tap) & cok;          // 1: inside the map
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     for (int j = 0; j < B_PER_T; ++j)
       rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, live ? b_off[j] : 0xffffffffu, live ? so_b : 0u, 0));
     if (++ld_kw == a.KW) { ld_kw = 0; ++ld_kh; }
-    if (++ld_tap == taps) { ld_tap = 0; ld_kh = 0; ld_kw = 0; ++ld_chunk; }
+    if (++ld_tap == taps_loop) { ld_tap = 0; ld_kh = 0; ld_kw = 0; ++ld_chunk; }
   };
   auto store_lds = [&](int buf) {
     float* As = smem + buf * STAGE;
@@ -532,7 +552,7 @@ template <int WM, int WN, int TM, int TN, int DT = DT_F32, bool GATHER = false>
 int launch_conv(const ConvArgs& a, int zdim, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   // gather mode keeps the block's [BM][taps <= 32] neighbour table behind the two staging buffers
-  constexpr size_t smem = 2 * (size_t)(BM * A_LD + BK * BN) * sizeof(float) + (GATHER ? (size_t)BM * 32 * sizeof(int) : 0);
+  constexpr size_t smem = 2 * (size_t)(BM * A_LD + BK * BN) * sizeof(float) + (GATHER ? (size_t)(BM * 32 + 72) * sizeof(int) : 0);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, DT, GATHER>),

@@ -58,6 +58,33 @@ def synth_sweep_polar(n_points: int, seed: int = 0, **kw) -> np.ndarray:
     return np.ascontiguousarray(cart_to_polar_host(synth_sweep_cart(n_points, seed, **kw)))
 
 
+def synth_sweep_beams_cart(n_points: int, seed: int = 0, rho_max: float = 74.0, beams: int = 64, sensor_height: float = 1.8,
+                           elev_deg=(-17.6, 2.4), n_objects: int = 60) -> np.ndarray:
+    """(N,5) float32 [x, y, z, intensity, dt]: a spinning multi-beam lidar over a ground plane with box-shaped
+    obstacles (SURVEY.md 8d "realistic variant").  Unlike the uniform sweep, the returns lie on 2-D surfaces, so the
+    active set of a sparse 3-D backbone stays sparse through the strided stages (uniform points dilate to a dense grid)."""
+    rng = np.random.default_rng(seed)
+    elev = np.deg2rad(rng.choice(np.linspace(elev_deg[0], elev_deg[1], beams), n_points))
+    az = rng.uniform(-np.pi, np.pi, n_points)
+    ground = np.where(elev < -1e-3, sensor_height / np.tan(-np.minimum(elev, -1e-3)), np.inf)   # range of the ground hit
+    # obstacles: vertical cylinders of radius 1-3 m at random places; a ray stops at the first one in its azimuth window
+    obj_r, obj_az = rng.uniform(5.0, rho_max, n_objects), rng.uniform(-np.pi, np.pi, n_objects)
+    obj_w = rng.uniform(1.0, 3.0, n_objects) / obj_r                                              # half width in radians
+    hit = np.full(n_points, np.inf)
+    for r_, a_, w_ in zip(obj_r, obj_az, obj_w):
+        d = np.abs(np.angle(np.exp(1j * (az - a_))))
+        hit = np.where(d < w_, np.minimum(hit, r_), hit)
+    rho = np.minimum(np.minimum(ground, hit), rho_max * rng.uniform(0.6, 1.0, n_points))         # far returns drop out at random ranges
+    rho = np.clip(rho + rng.normal(0.0, 0.02, n_points), 0.5, rho_max)
+    z = np.where(rho >= ground - 0.05, -sensor_height, rho * np.tan(elev)) + rng.normal(0.0, 0.02, n_points)
+    pts = np.stack([rho * np.cos(az), rho * np.sin(az), z, rng.uniform(0.0, 1.0, n_points), np.zeros(n_points)], axis=1)
+    return pts.astype(np.float32)
+
+
+def synth_sweep_beams_polar(n_points: int, seed: int = 0, **kw) -> np.ndarray:
+    return np.ascontiguousarray(cart_to_polar_host(synth_sweep_beams_cart(n_points, seed, **kw)))
+
+
 def _rng_for(name: str, base_seed: int) -> np.random.Generator:
     return np.random.default_rng([base_seed, zlib.crc32(name.encode())])
 

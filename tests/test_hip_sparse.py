@@ -68,3 +68,30 @@ def test_sp_backbone_waymo_size_runs(dev):
     b = net.forward_nhwc(f, c, 1, shape)
     assert tuple(a.shape) == (1, 256, 144, 256) and torch.isfinite(a).all() and torch.equal(a, b)
     assert 0.0 < float((a != 0).float().mean()) < 0.9
+
+
+def test_voxelnet_v3_end_to_end_waymo_config(dev):
+    """configs/waymo/polar_partner_c4.py (same model section as the reference's Waymo PARTNER config, which also builds here:
+    tests/test_host_api.py) -> VoxelNetV3 -> forward on one synthetic 180k-point sweep:
+    hard voxelization (device) -> mean VFE -> sparse backbone -> 2 x SetBlock -> RPN -> E2ESWVoteHead"""
+    import os
+    import partner_amd as P
+    from partner_amd.voxel_generator import VoxelGenerator
+    cfg_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "waymo", "polar_partner_c4.py")
+    w = P.Config.fromfile(cfg_path)
+    m = P.build_detector(w.model, train_cfg=w.train_cfg, test_cfg=None)
+    geo = {k: getattr(m.bbox_head, k).clone() for k in ("offset_grid", "xy_offset")}
+    synth.load_filled(m, base_seed=31)
+    for k, v in geo.items():
+        getattr(m.bbox_head, k).data.copy_(v)
+    m = m.to(dev).eval()
+    sw = torch.from_numpy(synth.synth_sweep_polar(180000, seed=0, rho_max=74.0)).to(dev)
+    vg = VoxelGenerator(synth.WAYMO_VOXEL, synth.WAYMO_RANGE, 5, 150000)
+    voxels, coors, num = vg.generate(sw)
+    coords4 = torch.cat([torch.zeros((coors.shape[0], 1), dtype=coors.dtype, device=dev), coors], 1)
+    example = dict(voxels=voxels, coordinates=coords4, num_points=num, num_voxels=[int(voxels.shape[0])], shape=[np.array([1152, 2048, 40])],
+                   metadata=[dict(token="t0")])
+    out = m(example, return_loss=False)["det_preds"][0]
+    assert tuple(out["hm"].shape) == (1, 1, 256, 144) and tuple(out["reg"].shape) == (1, 2, 256, 144)
+    for k, v in out.items():
+        assert torch.isfinite(v).all(), k

@@ -108,3 +108,35 @@ out["hm"] = out["hm"] * 0 + torch.randn_like(out["hm"]) * 2.0 - 3.0          # r
 t = timeit(lambda: m.bbox_head.predict(dict(metadata=[None]), {"det_preds": [out]}, tcfg), n=20, warm=5)
 n_det = m.bbox_head.predict(dict(metadata=[None]), {"det_preds": [out]}, tcfg)[0]["scores"].numel()
 print(f"C2  decode + rotated NMS (128 x 128 x 10, pre 1000 / post 83, incl. the one host sync): {t:.3f} ms  ({n_det} boxes)")
+
+# ---- C4 end to end: Waymo PARTNER model, one 180k-point sweep (B = 1): voxelize -> VFE -> sparse backbone -> 2 x SetBlock -> RPN -> E2ESWVoteHead
+cfg4 = P.Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "waymo", "polar_partner_c4.py"))
+m4 = P.build_detector(cfg4.model, train_cfg=cfg4.train_cfg, test_cfg=None)
+geo = {k: getattr(m4.bbox_head, k).clone() for k in ("offset_grid", "xy_offset")}
+synth.load_filled(m4, 31)
+for k, v in geo.items():
+    getattr(m4.bbox_head, k).data.copy_(v)
+m4 = m4.to(dev).eval()
+
+def frame4():
+    voxels, coors, num = vg.generate(sw)
+    coords4 = torch.cat([torch.zeros((coors.shape[0], 1), dtype=coors.dtype, device=dev), coors], 1)
+    ex = dict(voxels=voxels, coordinates=coords4, num_points=num, num_voxels=[int(voxels.shape[0])], shape=[np.array([1152, 2048, 40])])
+    return m4(ex, return_loss=False)
+
+def sparse_only():
+    voxels, coors, num = vg.generate(sw)
+    coords4 = torch.cat([torch.zeros((coors.shape[0], 1), dtype=coors.dtype, device=dev), coors], 1)
+    return m4.backbone.forward_nhwc(m4.reader(voxels, num), coords4, 1, [1152, 2048, 40])
+
+t = timeit(sparse_only)
+print(f"C4  voxelize + VFE + SpMiddleResNetFHD, UNIFORM random 180k points (dilates to a nearly dense pyramid): {t:.3f} ms")
+sw_uniform = sw
+sw = torch.from_numpy(synth.synth_sweep_beams_polar(180000, seed=0)).to(dev)   # 64-beam sweep over ground + obstacles
+t = timeit(sparse_only)
+print(f"C4  voxelize + VFE + SpMiddleResNetFHD, 64-beam synthetic sweep (surfaces): {t:.3f} ms")
+t = timeit(frame4)
+print(f"C4  end to end, f32 (B=1, 180k pts): {t:.3f} ms  ({1e3 / t:.1f} frames/s)")
+m4.neck.set_compute_dtype("bf16")
+t = timeit(frame4)
+print(f"C4  end to end, bf16 RPN convs:       {t:.3f} ms  ({1e3 / t:.1f} frames/s)")
