@@ -556,6 +556,23 @@ int pn_sparse_to_dense_nhwc(const float *feats, const uint32_t *keys, int capaci
                             const int32_t *n_dev, const int32_t *dims, int c, float *out,
                             pn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * next-3  CenterPoint target assignment on the polar grid, on the device.
+ * Replaces AssignLabel.assign_heatmap_polar   det3d/datasets/pipelines/preprocess.py:253-342
+ *          gaussian_radius / draw_umich_gaussian det3d/core/utils/center_utils.py:18-64
+ * gt_boxes (B, max_gt, box_cols >= 9) f32 [x,y,z,l,w,h,vx,vy,...,rot], gt_classes (B, max_gt) 1-based within the task,
+ * num_gt (B) device counts.  Outputs as the reference's example dict: hm (B, classes, feature_a, feature_r),
+ * ind / cat int64 and mask uint8 (B, max_objs), anno_box (B, max_objs, 10) = [dx, dy, z, log l, log w, log h, vx, vy,
+ * sin rot, cos rot]; all fully overwritten.  As in the reference the footprint is rotated by COLUMN 6 of the box. */
+size_t pn_assign_heatmap_workspace_bytes(int batch, int max_objs);
+int pn_assign_heatmap_polar_f32(const float *gt_boxes, const int32_t *gt_classes, const int32_t *num_gt,
+                                int batch, int max_gt, int box_cols, int max_objs, int classes,
+                                int feature_r, int feature_a, float voxel_size_r, float voxel_size_a,
+                                float range_r0, float range_a0, int out_size_factor,
+                                float gaussian_overlap, int min_radius, int rectify, float *hm,
+                                int64_t *ind, uint8_t *mask, int64_t *cat, float *anno_box,
+                                void *workspace, size_t workspace_bytes, pn_stream_t stream);
+
 /* layout helpers at the API boundary */
 int pn_nchw_to_nhwc_f32(const float *in, int b, int c, int h, int w, float *out, pn_stream_t stream);
 int pn_nhwc_to_nchw_f32(const float *in, int b, int c, int h, int w, int pixel_stride,

@@ -889,3 +889,85 @@ def sp_middle_resnet_fhd(sd: SD, prefix: str, voxel_features: Tensor, coors: np.
     N, Cc, Dd, Hh, Ww = x.shape
     ret = x.reshape(N, Cc * Dd, Hh, Ww)
     return (ret, stages) if return_stages else ret
+
+
+# ======================================================================================
+# next-3  CenterPoint target assignment on the polar grid
+#         AssignLabel.assign_heatmap_polar   det3d/datasets/pipelines/preprocess.py:253-342
+#         gaussian_radius / gaussian2D / draw_umich_gaussian   det3d/core/utils/center_utils.py:18-64
+#         center_to_corner_box2d             det3d/core/bbox/box_np_ops.py:265-285 (corners_nd :55-85, rotation_2d :207-220)
+# Pinned by tests/golden/assign.npz (captured from the reference).  dtypes as the pipeline delivers them: float32 boxes,
+# float32 voxel_size / pc_range (VoxelGenerator), so the cell arithmetic is float32 and only the real-world cell centre
+# (int32 * float32 under NumPy's promotion rules) is float64.
+# ======================================================================================
+def gaussian_radius_f32(h: np.float32, w: np.float32, min_overlap: float) -> np.float32:
+    f = np.float32
+    b1 = h + w
+    c1 = w * h * f(1 - min_overlap) / f(1 + min_overlap)
+    r1 = (b1 + np.sqrt(b1 * b1 - f(4) * c1)) / f(2)
+    b2 = f(2) * (h + w)
+    c2 = f(1 - min_overlap) * w * h
+    r2 = (b2 + np.sqrt(b2 * b2 - f(16) * c2)) / f(2)
+    a3 = f(4 * min_overlap)
+    b3 = f(-2 * min_overlap) * (h + w)
+    c3 = f(min_overlap - 1) * w * h
+    r3 = (b3 + np.sqrt(b3 * b3 - f(4) * a3 * c3)) / f(2)
+    return min(r1, r2, r3)
+
+
+def assign_heatmap_polar(gt_boxes: np.ndarray, gt_classes: np.ndarray, ncls: int, max_objs: int, out_size_factor: int,
+                         gaussian_overlap: float, min_radius: int, rectify: bool, voxel_size, pc_range, feature_map_size):
+    """gt_boxes (n, 9) f32 [x,y,z,l,w,h,vx,vy,rot]; gt_classes (n,) 1-based.  -> hm (ncls, A, R) f32, ind / mask / cat (max_objs,),
+    anno_box (max_objs, 10) f32 [dx, dy, z, log l, log w, log h, vx, vy, sin, cos]."""
+    f = np.float32
+    vs, pr = np.asarray(voxel_size, f), np.asarray(pc_range, f)
+    R, A = int(feature_map_size[0]), int(feature_map_size[1])
+    hm = np.zeros((ncls, A, R), f)
+    ind, mask, cat = np.zeros(max_objs, np.int64), np.zeros(max_objs, np.uint8), np.zeros(max_objs, np.int64)
+    anno = np.zeros((max_objs, 10), f)
+    n = min(len(gt_boxes), max_objs)
+    unit = np.array([[-0.5, -0.5], [-0.5, 0.5], [0.5, 0.5], [0.5, -0.5]], f)     # clockwise from the minimum corner
+    for k in range(n):
+        b = gt_boxes[k].astype(f)
+        # NB the reference rotates the footprint by COLUMN 6 of the box (preprocess.py:266): the heading for 7-column Waymo
+        # boxes, but vx for the 9-column nuScenes boxes [x,y,z,l,w,h,vx,vy,rot] -- reproduced as is
+        s, c = np.sin(b[6]), np.cos(b[6])
+        loc = b[3:5][None, :] * unit                                               # (4, 2) f32
+        cx = loc[:, 0] * c + loc[:, 1] * s + b[0]                                  # rotation_2d: [x, y] @ [[c, -s], [s, c]]
+        cy = loc[:, 0] * (-s) + loc[:, 1] * c + b[1]
+        rho, az = np.sqrt(cx * cx + cy * cy), np.arctan2(cy, cx)
+        dr = (rho.max() - rho.min()) / vs[0] / f(out_size_factor)
+        da = (az.max() - az.min()) / vs[1] / f(out_size_factor)
+        if not (dr > 0 and da > 0):
+            continue
+        r, a = np.sqrt(b[0] * b[0] + b[1] * b[1]), np.arctan2(b[1], b[0])
+        radius = max(int(min_radius), int(gaussian_radius_f32(dr, da, gaussian_overlap)) - int(r > 30))
+        ct = np.array([(r - pr[0]) / vs[0] / f(out_size_factor), (a - pr[1]) / vs[1] / f(out_size_factor)], f)
+        ci = ct.astype(np.int32)
+        ci[1] = np.clip(ci[1], 0, A - 1)
+        if not (0 <= ci[0] < R):
+            continue
+        # draw_umich_gaussian(hm[cls], ct, radius): centre from the UNCLIPPED ct, clipped window, element-wise maximum
+        cls = int(gt_classes[k]) - 1
+        x, y = int(ct[0]), int(ct[1])
+        left, right = min(x, radius), min(R - x, radius + 1)
+        top, bottom = min(y, radius), min(A - y, radius + 1)
+        if right > -left and bottom > -top:
+            sigma = (2 * radius + 1) / 6
+            yy, xx = np.ogrid[-top:bottom, -left:right]
+            g = np.exp(-(xx * xx + yy * yy) / (2 * sigma * sigma))
+            win = hm[cls, y - top:y + bottom, x - left:x + right]
+            if min(win.shape) > 0 and min(g.shape) > 0:
+                np.maximum(win, g, out=win)
+        r_real = np.float64(ci[0]) * out_size_factor * np.float64(vs[0]) + np.float64(pr[0])
+        a_real = np.float64(ci[1]) * out_size_factor * np.float64(vs[1]) + np.float64(pr[1])
+        xc, yc = r_real * np.cos(a_real), r_real * np.sin(a_real)
+        vx, vy, rot = b[6], b[7], b[8]
+        if rectify:
+            rot = rot - a
+            vr, va = np.sqrt(vx * vx + vy * vy), np.arctan2(vy, vx) - a
+            vx, vy = vr * np.cos(va), vr * np.sin(va)
+        cat[k], ind[k], mask[k] = cls, int(ci[1]) * R + int(ci[0]), 1
+        anno[k] = np.array([np.float64(b[0]) - xc, np.float64(b[1]) - yc, b[2], np.log(b[3]), np.log(b[4]), np.log(b[5]), vx, vy,
+                            np.sin(rot), np.cos(rot)], np.float64).astype(f)
+    return hm, ind, mask, cat, anno

@@ -852,3 +852,31 @@ def to_f32(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     hip.call("pn_bf16_to_f32", x.data_ptr(), y.data_ptr(), x.numel(), hip.stream())
     return y
+
+
+# ------------------------------------------------------------------------------ next-3 target assignment
+def assign_heatmap_polar(gt_boxes: torch.Tensor, gt_classes: torch.Tensor, num_gt: torch.Tensor, classes: int, max_objs: int,
+                         feature_map_size, voxel_size, pc_range, out_size_factor: int, gaussian_overlap=0.1, min_radius=2,
+                         rectify=False) -> CenterLossTargets:
+    """gt_boxes (B, max_gt, 9) f32, gt_classes (B, max_gt) int32 (1-based), num_gt (B) int32, all on the device
+    -> CenterLossTargets (hm, ind, mask, cat, anno_box) ready for center_loss / PolarPillarTrainStep.step"""
+    hip.require_device(gt_boxes, gt_classes, num_gt)
+    lib = hip.load()
+    assert gt_boxes.dtype == torch.float32 and gt_classes.dtype == torch.int32 and num_gt.dtype == torch.int32
+    assert gt_boxes.is_contiguous() and gt_classes.is_contiguous()
+    b, max_gt, cols = gt_boxes.shape
+    dev = gt_boxes.device
+    fr, fa = int(feature_map_size[0]), int(feature_map_size[1])
+    t = CenterLossTargets.__new__(CenterLossTargets)
+    t.hm = torch.empty((b, classes, fa, fr), dtype=torch.float32, device=dev)
+    t.ind = torch.empty((b, max_objs), dtype=torch.int64, device=dev)
+    t.mask = torch.empty((b, max_objs), dtype=torch.uint8, device=dev)
+    t.cat = torch.empty((b, max_objs), dtype=torch.int64, device=dev)
+    t.anno = torch.empty((b, max_objs, 10), dtype=torch.float32, device=dev)
+    nbytes = lib.pn_assign_heatmap_workspace_bytes(b, max_objs)
+    ws = _workspace(nbytes, dev)
+    hip.call("pn_assign_heatmap_polar_f32", gt_boxes.data_ptr(), gt_classes.data_ptr(), num_gt.data_ptr(), b, max_gt, cols, max_objs, classes,
+             fr, fa, float(voxel_size[0]), float(voxel_size[1]), float(pc_range[0]), float(pc_range[1]), int(out_size_factor),
+             float(gaussian_overlap), int(min_radius), int(bool(rectify)), t.hm.data_ptr(), t.ind.data_ptr(), t.mask.data_ptr(), t.cat.data_ptr(),
+             t.anno.data_ptr(), ws.data_ptr(), nbytes, hip.stream())
+    return t

@@ -85,6 +85,21 @@ def synth_sweep_beams_polar(n_points: int, seed: int = 0, **kw) -> np.ndarray:
     return np.ascontiguousarray(cart_to_polar_host(synth_sweep_beams_cart(n_points, seed, **kw)))
 
 
+def synth_gt_boxes(n: int, seed: int, rho_max: float = 48.0):
+    """(n, 9) float32 [x, y, z, l, w, h, vx, vy, rot] + classes (n,) int 1..10: boxes of mixed size all over the range,
+    a few outside the feature map and a few overlapping"""
+    r = np.random.default_rng(seed)
+    rho, az = r.uniform(0.5, rho_max + 6.0, n), r.uniform(-np.pi, np.pi, n)
+    b = np.zeros((n, 9), np.float32)
+    b[:, 0], b[:, 1] = rho * np.cos(az), rho * np.sin(az)
+    b[:, 2] = r.uniform(-3, 1, n)
+    b[:, 3:6] = np.exp(r.uniform(np.log(0.4), np.log(11.0), (n, 3)))
+    b[:, 6:8] = r.standard_normal((n, 2)) * 3
+    b[:, 8] = r.uniform(-np.pi, np.pi, n)
+    b[1, :2] = b[0, :2] + 0.3            # two objects in (almost) the same cell
+    return b, r.integers(1, 11, n).astype(np.int64)
+
+
 def _rng_for(name: str, base_seed: int) -> np.random.Generator:
     return np.random.default_rng([base_seed, zlib.crc32(name.encode())])
 

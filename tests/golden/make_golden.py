@@ -530,7 +530,32 @@ def gen_optim():
     save("optim.npz", **out)
 
 
+# ----------------------------------------------------------------------------- next-3 target assignment
+def gen_assign():
+    """AssignLabel.assign_heatmap_polar (preprocess.py:253-342) on seeded boxes: hm / ind / mask / cat / anno_box, with the
+    dtypes the pipeline hands it (float32 voxel_size / pc_range arrays from VoxelGenerator)."""
+    import types
+    from det3d.datasets.pipelines.preprocess import AssignLabel
+    out = {}
+    vs, pr = np.array(synth.NUSC_VOXEL, np.float32), np.array(synth.NUSC_RANGE, np.float32)
+    fmap = np.array([512, 512, 1]) [:2] // 4
+    for tag, n, rectify, seed in (("a", 60, False, 1), ("b", 140, True, 2)):
+        boxes, classes = synth.synth_gt_boxes(n, seed)
+        me = types.SimpleNamespace(_max_objs=100, out_size_factor=4, gaussian_overlap=0.1, _min_radius=2, rectify=rectify)
+        hms = [np.zeros((10, fmap[1], fmap[0]), np.float32)]
+        inds, masks, cats = [np.zeros(100, np.int64)], [np.zeros(100, np.uint8)], [np.zeros(100, np.int64)]
+        annos = [np.zeros((100, 10), np.float32)]
+        AssignLabel.assign_heatmap_polar(me, hms, annos, inds, masks, cats, dict(gt_boxes=[boxes.copy()], gt_classes=[classes.copy()]),
+                                         [None], vs, pr, fmap, "NuScenesDataset")
+        out[f"{tag}_n"], out[f"{tag}_rectify"], out[f"{tag}_seed"] = n, rectify, seed
+        nz = np.nonzero(hms[0])
+        out[f"{tag}_hm_idx"] = np.stack(nz, 1).astype(np.int32)
+        out[f"{tag}_hm_val"] = hms[0][nz]
+        out[f"{tag}_ind"], out[f"{tag}_mask"], out[f"{tag}_cat"], out[f"{tag}_anno"] = inds[0], masks[0], cats[0], annos[0]
+    save("assign.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim"]
+    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign"]
     for w in which:
         globals()["gen_" + w]()

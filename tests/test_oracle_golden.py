@@ -416,3 +416,20 @@ def test_optimizer_step_restatement(golden):
         for n in names:
             O.adam_decoupled_step(P[n], grads[n] * np.float32(coef), M[n], V[n], k + 1, lr, mom)
             close(P[n], g[f"after{step}::" + n], 2e-6, 2e-7)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_target_assignment_restatement(golden, tag):
+    """polar CenterPoint targets (heat map, ind, mask, cat, anno_box) against AssignLabel.assign_heatmap_polar of the reference"""
+    g = golden("assign.npz")
+    boxes, classes = synth.synth_gt_boxes(int(g[f"{tag}_n"]), int(g[f"{tag}_seed"]))
+    hm, ind, mask, cat, anno = O.assign_heatmap_polar(boxes, classes, 10, 100, 4, 0.1, 2, bool(g[f"{tag}_rectify"]), synth.NUSC_VOXEL,
+                                                      synth.NUSC_RANGE, [128, 128])
+    np.testing.assert_array_equal(mask, g[f"{tag}_mask"])
+    np.testing.assert_array_equal(ind, g[f"{tag}_ind"])
+    np.testing.assert_array_equal(cat, g[f"{tag}_cat"])
+    np.testing.assert_allclose(anno, g[f"{tag}_anno"], rtol=1e-5, atol=1e-6)
+    ref = np.zeros_like(hm)
+    idx = g[f"{tag}_hm_idx"]
+    ref[idx[:, 0], idx[:, 1], idx[:, 2]] = g[f"{tag}_hm_val"]
+    np.testing.assert_allclose(hm, ref, rtol=1e-6, atol=1e-7)
