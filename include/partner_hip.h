@@ -573,6 +573,20 @@ int pn_assign_heatmap_polar_f32(const float *gt_boxes, const int32_t *gt_classes
                                 int64_t *ind, uint8_t *mask, int64_t *cat, float *anno_box,
                                 void *workspace, size_t workspace_bytes, pn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * next-4 (device half)  multi-sweep accumulation for streaming inference (BASELINE configs[4]).
+ * Replaces read_sweep / remove_close + the concatenation of LoadPointCloudFromFile
+ *          det3d/datasets/pipelines/loading.py:62-84, 216-332
+ * raw: the sweeps' points (n, in_cols >= 4) f32 [x,y,z,intensity,...] concatenated, key frame first; sweep_offsets
+ * (sweeps+1) int32; transforms (sweeps,4,4) float64 row-major (entry 0 unused); time_lags (sweeps) f32.
+ * Past sweeps lose the points with |x| < min_distance and |y| < min_distance (own frame), are moved into the key
+ * frame and tagged with their time lag.  out (n,5) [x,y,z,intensity,dt], order preserved; out_count on the device. */
+size_t pn_accumulate_sweeps_workspace_bytes(int n);
+int pn_accumulate_sweeps_f32(const float *raw, int n, int in_cols, const int32_t *sweep_offsets,
+                             int sweeps, const double *transforms, const float *time_lags,
+                             float min_distance, float *out, int32_t *out_count, void *workspace,
+                             size_t workspace_bytes, pn_stream_t stream);
+
 /* layout helpers at the API boundary */
 int pn_nchw_to_nhwc_f32(const float *in, int b, int c, int h, int w, float *out, pn_stream_t stream);
 int pn_nhwc_to_nchw_f32(const float *in, int b, int c, int h, int w, int pixel_stride,

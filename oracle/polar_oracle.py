@@ -971,3 +971,23 @@ def assign_heatmap_polar(gt_boxes: np.ndarray, gt_classes: np.ndarray, ncls: int
         anno[k] = np.array([np.float64(b[0]) - xc, np.float64(b[1]) - yc, b[2], np.log(b[3]), np.log(b[4]), np.log(b[5]), vx, vy,
                             np.sin(rot), np.cos(rot)], np.float64).astype(f)
     return hm, ind, mask, cat, anno
+
+
+# ======================================================================================
+# next-4 (device half)  multi-sweep accumulation
+#         read_file / remove_close / read_sweep     det3d/datasets/pipelines/loading.py:42-84
+#         LoadPointCloudFromFile.get_points          loading.py:216-250 (key frame first, then the sweeps; time lag column)
+# Pinned by tests/golden/sweeps.npz (captured from the reference on temporary .bin files).
+# ======================================================================================
+def accumulate_sweeps(clouds: List[np.ndarray], transforms: np.ndarray, time_lags: np.ndarray, min_distance: float = 1.0) -> np.ndarray:
+    """clouds[s]: (n_s, >=4) f32 raw points [x,y,z,intensity,...] of sweep s (s = 0 is the key frame); transforms (S,4,4) f64;
+    -> (N', 5) f32 [x, y, z, intensity, time lag]"""
+    out = [np.concatenate([clouds[0][:, :4].astype(np.float32), np.zeros((len(clouds[0]), 1), np.float32)], 1)]
+    for s in range(1, len(clouds)):
+        p = clouds[s][:, :4].astype(np.float32)
+        keep = ~((np.abs(p[:, 0]) < min_distance) & (np.abs(p[:, 1]) < min_distance))   # in the sweep's own frame
+        p = p[keep]
+        hom = np.concatenate([p[:, :3].astype(np.float64), np.ones((len(p), 1))], 1)
+        p[:, :3] = (hom @ np.asarray(transforms[s], np.float64).T)[:, :3].astype(np.float32)
+        out.append(np.concatenate([p, np.full((len(p), 1), np.float32(time_lags[s]), np.float32)], 1))
+    return np.concatenate(out, 0)

@@ -133,3 +133,137 @@ int pn_assign_heatmap_polar_f32(const float* gt_boxes, const int32_t* gt_classes
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// Multi-sweep accumulation on the device (the device half; BASELINE configs[4] "10-sweep
+// accumulation"): raw sweeps (N, 5) f32 [x, y, z, intensity, ring] concatenated key frame first -> (N', 5)
+// [x, y, z, intensity, time lag] in the key frame.
+// Reference: read_file / remove_close / read_sweep   det3d/datasets/pipelines/loading.py:42-84
+//            LoadPointCloudFromFile.get_points       loading.py:216-332 (concatenation order: key frame, then the sweeps)
+// Points of the past sweeps with |x| < 1 and |y| < 1 (in their own frame) are dropped, the rest are moved with the
+// sweep's 4x4 transform (float64 matrix, float64 product, rounded to float32 -- as numpy does) and tagged with the
+// sweep's time lag.  Order-preserving compaction: flag -> block scan (fixed order) -> scatter; the count stays on
+// the device.
+// =================================================================================================
+namespace {
+
+constexpr int kAccT = 256, kAccItems = 8;
+
+struct AccArgs {
+  const float* raw; int n; int in_cols; const int32_t* offsets; int sweeps; const double* mats; const float* lags; float radius;
+  float* out; int32_t* count; uint32_t* tile; int ntiles;
+};
+
+__device__ __forceinline__ int sweep_of(const AccArgs& a, int i) {
+  int s = 0;
+  while (s + 1 < a.sweeps && i >= a.offsets[s + 1]) ++s;   // <= 10 sweeps: linear search on a cached array
+  return s;
+}
+
+__device__ __forceinline__ bool acc_keep(const AccArgs& a, int i, int s) {
+  if (s == 0) return true;   // the key frame is taken as it is (loading.py:228-232)
+  const float* p = a.raw + (size_t)i * a.in_cols;
+  return !(fabsf(p[0]) < a.radius && fabsf(p[1]) < a.radius);
+}
+
+__device__ uint32_t acc_block_scan(uint32_t v, uint32_t* total) {
+  __shared__ uint32_t wsum[kAccT / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kAccT / 64; ++k) {
+    if (k < w) base += wsum[k];
+    tot += wsum[k];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ void acc_count_kernel(AccArgs a) {
+  const int base = (blockIdx.x * kAccT + threadIdx.x) * kAccItems;
+  uint32_t c = 0;
+  for (int k = 0; k < kAccItems; ++k) {
+    const int i = base + k;
+    if (i < a.n && acc_keep(a, i, sweep_of(a, i))) ++c;
+  }
+  uint32_t tot;
+  acc_block_scan(c, &tot);
+  if (threadIdx.x == 0) a.tile[blockIdx.x] = tot;
+}
+
+__global__ void acc_offsets_kernel(AccArgs a) {
+  uint32_t carry = 0;
+  for (int b0 = 0; b0 < a.ntiles; b0 += kAccT) {
+    const int i = b0 + threadIdx.x;
+    const uint32_t v = i < a.ntiles ? a.tile[i] : 0;
+    uint32_t tot;
+    const uint32_t ex = acc_block_scan(v, &tot);
+    if (i < a.ntiles) a.tile[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *a.count = (int32_t)carry;
+}
+
+__global__ void acc_scatter_kernel(AccArgs a) {
+  const int base = (blockIdx.x * kAccT + threadIdx.x) * kAccItems;
+  bool keep[kAccItems];
+  int sw[kAccItems];
+  uint32_t c = 0;
+  for (int k = 0; k < kAccItems; ++k) {
+    const int i = base + k;
+    sw[k] = i < a.n ? sweep_of(a, i) : 0;
+    keep[k] = i < a.n && acc_keep(a, i, sw[k]);
+    c += keep[k];
+  }
+  uint32_t tot;
+  uint32_t pos = a.tile[blockIdx.x] + acc_block_scan(c, &tot);
+  for (int k = 0; k < kAccItems; ++k) {
+    if (!keep[k]) continue;
+    const float* p = a.raw + (size_t)(base + k) * a.in_cols;
+    float* o = a.out + (size_t)pos * 5;
+    if (sw[k] == 0) {
+      o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+    } else {
+      const double* m = a.mats + (size_t)sw[k] * 16;
+      const double x = p[0], y = p[1], z = p[2];
+      o[0] = (float)(m[0] * x + m[1] * y + m[2] * z + m[3]);
+      o[1] = (float)(m[4] * x + m[5] * y + m[6] * z + m[7]);
+      o[2] = (float)(m[8] * x + m[9] * y + m[10] * z + m[11]);
+    }
+    o[3] = p[3];
+    o[4] = a.lags[sw[k]];
+    ++pos;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pn_accumulate_sweeps_workspace_bytes(int n) { return (size_t)pn::cdiv(n, kAccT * kAccItems) * sizeof(uint32_t) + 256; }
+
+int pn_accumulate_sweeps_f32(const float* raw, int n, int in_cols, const int32_t* sweep_offsets, int sweeps, const double* transforms,
+                             const float* time_lags, float min_distance, float* out, int32_t* out_count, void* workspace,
+                             size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(raw && sweep_offsets && transforms && time_lags && out && out_count && workspace, "accumulate_sweeps: null pointer");
+  PN_REQUIRE(n >= 1 && in_cols >= 4 && sweeps >= 1, "accumulate_sweeps: bad sizes");
+  PN_REQUIRE(workspace_bytes >= pn_accumulate_sweeps_workspace_bytes(n), "accumulate_sweeps: workspace too small");
+  AccArgs a{raw, n, in_cols, sweep_offsets, sweeps, transforms, time_lags, min_distance, out, out_count, static_cast<uint32_t*>(workspace),
+            pn::cdiv(n, kAccT * kAccItems)};
+  hipStream_t st = pn::S(stream);
+  hipLaunchKernelGGL(acc_count_kernel, dim3(a.ntiles), dim3(kAccT), 0, st, a);
+  hipLaunchKernelGGL(acc_offsets_kernel, dim3(1), dim3(kAccT), 0, st, a);
+  hipLaunchKernelGGL(acc_scatter_kernel, dim3(a.ntiles), dim3(kAccT), 0, st, a);
+  return pn::check_launch("accumulate_sweeps");
+}
+
+}  // extern "C"

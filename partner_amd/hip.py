@@ -107,6 +107,8 @@ SIGNATURES = {
     "pn_sparse_to_dense_nhwc": (_I, [_P, _P, _I, _P, _P, _I, _P, _P]),
     "pn_assign_heatmap_workspace_bytes": (_SZ, [_I, _I]),
     "pn_assign_heatmap_polar_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "pn_accumulate_sweeps_workspace_bytes": (_SZ, [_I]),
+    "pn_accumulate_sweeps_f32": (_I, [_P, _I, _I, _P, _I, _P, _P, _F, _P, _P, _P, _SZ, _P]),
     "pn_nchw_to_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "pn_nhwc_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "pn_grad_norm_workspace_bytes": (_SZ, []),

@@ -880,3 +880,20 @@ def assign_heatmap_polar(gt_boxes: torch.Tensor, gt_classes: torch.Tensor, num_g
              float(gaussian_overlap), int(min_radius), int(bool(rectify)), t.hm.data_ptr(), t.ind.data_ptr(), t.mask.data_ptr(), t.cat.data_ptr(),
              t.anno.data_ptr(), ws.data_ptr(), nbytes, hip.stream())
     return t
+
+
+# ------------------------------------------------------------------------------ next-4 sweep accumulation
+def accumulate_sweeps(raw: torch.Tensor, sweep_offsets: torch.Tensor, transforms: torch.Tensor, time_lags: torch.Tensor, min_distance=1.0):
+    """raw (n, >=4) f32 concatenated sweeps (key frame first), sweep_offsets (S+1) int32, transforms (S,4,4) float64, time_lags (S) f32,
+    all on the device -> (out (n,5) f32 [x,y,z,intensity,dt] of which the first count rows are valid, count (1,) int32 on the device)"""
+    hip.require_device(raw, sweep_offsets, transforms, time_lags)
+    lib = hip.load()
+    assert raw.is_contiguous() and raw.dtype == torch.float32 and transforms.dtype == torch.float64 and transforms.is_contiguous()
+    n, cols = raw.shape
+    out = torch.empty((n, 5), dtype=torch.float32, device=raw.device)
+    count = torch.empty(1, dtype=torch.int32, device=raw.device)
+    nbytes = lib.pn_accumulate_sweeps_workspace_bytes(n)
+    ws = _workspace(nbytes, raw.device)
+    hip.call("pn_accumulate_sweeps_f32", raw.data_ptr(), n, cols, sweep_offsets.data_ptr(), transforms.shape[0], transforms.data_ptr(),
+             time_lags.data_ptr(), float(min_distance), out.data_ptr(), count.data_ptr(), ws.data_ptr(), nbytes, hip.stream())
+    return out, count

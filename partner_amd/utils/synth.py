@@ -100,6 +100,25 @@ def synth_gt_boxes(n: int, seed: int, rho_max: float = 48.0):
     return b, r.integers(1, 11, n).astype(np.int64)
 
 
+def synth_raw_sweeps(n_sweeps: int, n_points: int, seed: int = 0):
+    """raw nuScenes-style sweeps for the accumulation tests: list of (n,5) f32 [x,y,z,intensity,ring] (a good share of the points
+    near the sensor so that remove_close matters), (n_sweeps,4,4) float64 rigid transforms (entry 0 = identity), time lags f32"""
+    r = np.random.default_rng(seed)
+    clouds, mats, lags = [], np.tile(np.eye(4), (n_sweeps, 1, 1)), np.zeros(n_sweeps, np.float32)
+    for s in range(n_sweeps):
+        c = synth_sweep_cart(n_points + 37 * s, seed=seed * 100 + s)
+        near = r.random(len(c)) < 0.15
+        c[near, :2] = r.uniform(-1.5, 1.5, (int(near.sum()), 2)).astype(np.float32)
+        c[:, 4] = r.integers(0, 32, len(c)).astype(np.float32)          # ring index column of the .bin layout
+        clouds.append(c)
+        if s > 0:
+            yaw, t = r.uniform(-0.2, 0.2), r.uniform(-3, 3, 3)
+            mats[s, :3, :3] = [[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]]
+            mats[s, :3, 3] = t
+            lags[s] = 0.05 * s
+    return clouds, mats, lags
+
+
 def _rng_for(name: str, base_seed: int) -> np.random.Generator:
     return np.random.default_rng([base_seed, zlib.crc32(name.encode())])
 

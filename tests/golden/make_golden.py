@@ -555,7 +555,30 @@ def gen_assign():
     save("assign.npz", **out)
 
 
+# ----------------------------------------------------------------------------- next-4 sweep accumulation
+def gen_sweeps():
+    """read_sweep (loading.py:73-84) + the key-frame concatenation of LoadPointCloudFromFile.get_points (:216-250) on temp .bin
+    files: 1 key frame + 3 past sweeps with rigid transforms and time lags; stores the accumulated (N', 5) cloud."""
+    import tempfile
+    from det3d.datasets.pipelines.loading import read_file, read_sweep
+    clouds, mats, lags = synth.synth_raw_sweeps(4, 2500, seed=5)
+    with tempfile.TemporaryDirectory() as d:
+        paths = []
+        for i, c in enumerate(clouds):
+            paths.append(os.path.join(d, f"s{i}.bin"))
+            c.astype(np.float32).tofile(paths[-1])
+        points = read_file(paths[0])
+        pts_list, t_list = [points], [np.zeros((points.shape[0], 1))]
+        for i in range(1, 4):
+            ps, ts = read_sweep(dict(lidar_path=paths[i], transform_matrix=mats[i], time_lag=float(lags[i])))
+            pts_list.append(ps); t_list.append(ts)
+        pts = np.concatenate(pts_list, 0)
+        times = np.concatenate(t_list, 0).astype(pts.dtype)
+        acc = np.hstack([pts, times])
+    save("sweeps.npz", accumulated=acc.astype(np.float32), counts=np.array([len(p) for p in pts_list]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign"]
+    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps"]
     for w in which:
         globals()["gen_" + w]()

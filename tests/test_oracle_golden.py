@@ -433,3 +433,11 @@ def test_target_assignment_restatement(golden, tag):
     idx = g[f"{tag}_hm_idx"]
     ref[idx[:, 0], idx[:, 1], idx[:, 2]] = g[f"{tag}_hm_val"]
     np.testing.assert_allclose(hm, ref, rtol=1e-6, atol=1e-7)
+
+
+def test_sweep_accumulation_restatement(golden):
+    g = golden("sweeps.npz")
+    clouds, mats, lags = synth.synth_raw_sweeps(4, 2500, seed=5)
+    acc = O.accumulate_sweeps(clouds, mats, lags)
+    assert acc.shape == g["accumulated"].shape and int(g["counts"][1]) < len(clouds[1])    # remove_close really dropped points
+    np.testing.assert_allclose(acc, g["accumulated"], rtol=0, atol=1e-6)
