@@ -161,6 +161,7 @@ __device__ __forceinline__ int sweep_of(const AccArgs& a, int i) {
 }
 
 __device__ __forceinline__ bool acc_keep(const AccArgs& a, int i, int s) {
+  if (i >= a.offsets[a.sweeps]) return false;   // rows of a capacity-sized buffer past the last sweep
   if (s == 0) return true;   // the key frame is taken as it is (loading.py:228-232)
   const float* p = a.raw + (size_t)i * a.in_cols;
   return !(fabsf(p[0]) < a.radius && fabsf(p[1]) < a.radius);

@@ -168,6 +168,8 @@ class CenterHead(nn.Module):
         for flag in ("double_flip", "stateful_nms", "panoptic", "per_class_nms"):
             if get(flag, False):
                 raise NotImplementedError(f"predict: test_cfg.{flag} is not built (only the plain decode + rotate_nms_pcdet path)")
+        if kwargs.get("device_only", False) and len(preds_dicts["det_preds"]) != 1:
+            raise NotImplementedError("predict(device_only=True) supports a single task")
         if kwargs.get("prev_dets") is not None or kwargs.get("sec_id", 0) != 0:
             raise NotImplementedError("predict: sector streaming (prev_dets / sec_id > 0) is not built")
         nms = get("nms")
@@ -204,6 +206,9 @@ class CenterHead(nn.Module):
                      float(osf) * float(vs[1]), float(pr[0]), float(pr[1]), int(bool(get("rectify", False))), float(get("score_threshold")),
                      (C.c_float * 6)(*[float(v) for v in pcr]), iou_thr, pre_max, post_max, out_boxes.data_ptr(), out_scores.data_ptr(),
                      out_labels.data_ptr(), out_cells.data_ptr(), out_count.data_ptr(), ws.data_ptr(), wsb, hip.stream())
+            if kwargs.get("device_only", False):
+                # fixed-size outputs + device counts: nothing leaves the stream (hipGraph capturable); one task only
+                return dict(box3d_lidar=out_boxes, scores=out_scores, label_preds=out_labels, cells=out_cells, count=out_count)
             counts = out_count.cpu().tolist()  # the one host sync of the call: the API returns exact-size tensors
             rets.append([dict(box3d_lidar=out_boxes[i, :n], scores=out_scores[i, :n], label_preds=out_labels[i, :n], cells=out_cells[i, :n])
                          for i, n in enumerate(counts)])

@@ -883,7 +883,8 @@ def assign_heatmap_polar(gt_boxes: torch.Tensor, gt_classes: torch.Tensor, num_g
 
 
 # ------------------------------------------------------------------------------ next-4 sweep accumulation
-def accumulate_sweeps(raw: torch.Tensor, sweep_offsets: torch.Tensor, transforms: torch.Tensor, time_lags: torch.Tensor, min_distance=1.0):
+def accumulate_sweeps(raw: torch.Tensor, sweep_offsets: torch.Tensor, transforms: torch.Tensor, time_lags: torch.Tensor, min_distance=1.0,
+                      count: Optional[torch.Tensor] = None):
     """raw (n, >=4) f32 concatenated sweeps (key frame first), sweep_offsets (S+1) int32, transforms (S,4,4) float64, time_lags (S) f32,
     all on the device -> (out (n,5) f32 [x,y,z,intensity,dt] of which the first count rows are valid, count (1,) int32 on the device)"""
     hip.require_device(raw, sweep_offsets, transforms, time_lags)
@@ -891,7 +892,8 @@ def accumulate_sweeps(raw: torch.Tensor, sweep_offsets: torch.Tensor, transforms
     assert raw.is_contiguous() and raw.dtype == torch.float32 and transforms.dtype == torch.float64 and transforms.is_contiguous()
     n, cols = raw.shape
     out = torch.empty((n, 5), dtype=torch.float32, device=raw.device)
-    count = torch.empty(1, dtype=torch.int32, device=raw.device)
+    if count is None:
+        count = torch.empty(1, dtype=torch.int32, device=raw.device)
     nbytes = lib.pn_accumulate_sweeps_workspace_bytes(n)
     ws = _workspace(nbytes, raw.device)
     hip.call("pn_accumulate_sweeps_f32", raw.data_ptr(), n, cols, sweep_offsets.data_ptr(), transforms.shape[0], transforms.data_ptr(),
