@@ -173,6 +173,30 @@ class VoxelNetV3(SingleStageDetector):
             x = self.neck.forward_nhwc(x)
         return x
 
+    def forward_points(self, points: torch.Tensor, voxel_generator=None):
+        """Fused single-sample path from polar-decorated points (N, F) on the device: hard voxelization (device, count stays on
+        the device) -> mean VFE -> sparse backbone -> 2 x SetBlock -> RPN -> head.  No host synchronisation: capturable
+        in a hipGraph (``engine.FrameEngine``).  ``voxel_generator``: dict(range, voxel_size, max_points_in_voxel,
+        max_voxel_num); default = the one the config hands to the head."""
+        eval_only(self, "VoxelNetV3")
+        vg = voxel_generator or getattr(self.bbox_head, "voxel_generator_cfg", None)
+        if vg is None:
+            raise ValueError("VoxelNetV3.forward_points needs the voxel_generator section of the config")
+        mv = vg["max_voxel_num"]
+        mv = int(mv[0] if isinstance(mv, (list, tuple)) else mv)
+        voxels, coors, num, nv = ops.hard_voxelize(points, vg["voxel_size"], vg["range"], int(vg["max_points_in_voxel"]), mv)
+        feats = self.reader(voxels, num)
+        coords4 = torch.cat([torch.zeros((mv, 1), dtype=torch.int32, device=points.device), coors], 1)
+        rg, vs = vg["range"], vg["voxel_size"]
+        grid = [int(round((rg[3 + a] - rg[a]) / vs[a])) for a in range(3)]
+        x = self.backbone.forward_nhwc(feats, coords4, 1, grid, n_voxels=nv)
+        x = self.realign_nhwc(x)
+        if self.with_neck:
+            x = self.neck.forward_nhwc(x)
+        out = self.bbox_head.forward_nhwc(x)
+        out.pop("_feat", None)
+        return {k: v.permute(0, 3, 1, 2) for k, v in out.items()}
+
     def forward(self, example, return_loss=True, **kwargs):
         """hard-voxel branch of voxelnet.py:239-301 (the Waymo PARTNER config); example keys: voxels (V,P,F), coordinates (V,4)
         [b,z,y,x], num_points (V,), num_voxels (B,), shape [[x,y,z]]"""

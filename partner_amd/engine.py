@@ -18,7 +18,7 @@ class FrameEngine:
         dev = next(model.parameters()).device
         hip.require_device(next(model.parameters()))
         self.batch, self.n = batch, points_per_sweep
-        self.spec = spec or ops.GridSpec.from_range(model.reader.pc_range, model.reader.voxel_size)
+        self.spec = spec or (ops.GridSpec.from_range(model.reader.pc_range, model.reader.voxel_size) if hasattr(model.reader, "pc_range") else None)
         # static input buffer; pre-filled with a spread-out synthetic sweep so that the capture warm-up does not
         # run the degenerate "every point in one pillar" case
         from .utils import synth
@@ -34,6 +34,9 @@ class FrameEngine:
 
     def _step(self):
         polar = ops.cart_to_polar(self.cart)
+        if hasattr(self.model, "attns"):   # VoxelNetV3 (Waymo PARTNER config): single-sample hard-voxel path
+            assert self.batch == 1, "the fused VoxelNetV3 path takes one sample per frame"
+            return self.model.forward_points(polar)
         return self.model.forward_points(polar, self.offsets, self.batch, self.spec)
 
     def capture(self, warmup: int = 3, stream: "torch.cuda.Stream" = None) -> "FrameEngine":

@@ -98,6 +98,7 @@ class E2ESWVoteHead(nn.Module):
         super().__init__()
         head_conv = 64
         self.dataset, self.voxel_shape, self.period = dataset, voxel_shape, 2 * np.pi
+        self.voxel_generator_cfg = voxel_generator  # the hard-voxelization parameters of the config (used by VoxelNetV3.forward_points)
         self.class_names = [t["class_names"] for t in tasks]
         self.num_classes = [t["num_class"] for t in tasks]
         self.code_weights, self.weight = code_weights, weight

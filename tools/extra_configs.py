@@ -159,3 +159,15 @@ for i in range(220):
 lat = np.sort(np.array(lat))
 print(f"C5  RAW 10-sweep frame (300k pts) -> boxes, one hipGraph (accumulate + model + decode/NMS): p50 {lat[len(lat)//2]:.3f} ms  p99 {lat[int(len(lat)*0.99)]:.3f} ms; "
       f"{int(seng.offsets[1])} points kept, {int(o['count'][0])} boxes")
+
+# ---- C4 as a hipGraph: one 180k-point sweep per replay (B = 1), bf16 RPN convolutions
+cart4 = torch.from_numpy(synth.synth_sweep_beams_cart(180000, seed=0)).to(dev)
+eng4 = FrameEngine(m4, 1, 180000).capture()
+lat = []
+for i in range(120):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    eng4.run(cart4); torch.cuda.synchronize()
+    if i >= 20:
+        lat.append(1e3 * (time.perf_counter() - t0))
+lat = np.sort(np.array(lat))
+print(f"C4  hipGraph replay per frame (cart points -> head tensors, bf16 RPN): p50 {lat[len(lat)//2]:.3f} ms  p99 {lat[int(len(lat)*0.99)]:.3f} ms ({1e3/lat[len(lat)//2]:.1f} frames/s)")
