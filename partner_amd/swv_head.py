@@ -166,12 +166,22 @@ class E2ESWVoteHead(nn.Module):
         return torch.cat([pred_boxes[:, :2] + self.offset_grid, pred_boxes[:, 2:]], dim=1)
 
     # ---------------------------------------------------------------------------------------
+    def set_compute_dtype(self, dtype: str) -> "E2ESWVoteHead":
+        """"f32" (default) or "bf16": the 3x3 convolution branches (vote / vote_cls / cls / bbox / iou) run with bf16
+        activations and weights and f32 accumulation (BASELINE configs[3]); the Swin stage and all outputs stay f32."""
+        assert dtype in ("f32", "bf16")
+        self.compute_dtype = dtype
+        self._plan = PlanCache()
+        return self
+
     def _build_plan(self):
+        dt = getattr(self, "compute_dtype", "f32")
+
         def conv(m, act, bn=None):
             if bn is None:
-                return ops.ConvLayer(m.weight, stride=1, pad=m.padding[0], shift=m.bias, act=act)
+                return ops.ConvLayer(m.weight, stride=1, pad=m.padding[0], shift=m.bias, act=act, dtype=dt)
             scale, shift = ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, m.bias)
-            return ops.ConvLayer(m.weight, stride=1, pad=m.padding[0], scale=scale, shift=shift, act=act)
+            return ops.ConvLayer(m.weight, stride=1, pad=m.padding[0], scale=scale, shift=shift, act=act, dtype=dt)
 
         def two(seq):
             return conv(seq[0], ops.ACT_RELU), conv(seq[2], ops.ACT_NONE)
@@ -205,9 +215,11 @@ class E2ESWVoteHead(nn.Module):
             raise ValueError(f"head input map {(h, w)} does not match the configured offset grid {tuple(plan['pos'].shape[:2])}")
         C, heads, ws = self.layer.embed_dim, self.layer.num_heads, self.window_size
         # vote branch: (pred_centers | vote_cls | pad) in one 4-channel map read by the attention kernel
+        bf16 = getattr(self, "compute_dtype", "f32") == "bf16"
+        xc = ops.to_bf16(x) if bf16 else x
         vote = torch.zeros((b, h, w, 4), dtype=torch.float32, device=x.device)
-        plan["vote"][1](plan["vote"][0](x), out=vote, out_channel_offset=0)
-        plan["vote_cls"][1](plan["vote_cls"][0](x), out=vote, out_channel_offset=2)
+        plan["vote"][1](plan["vote"][0](xc), out=vote, out_channel_offset=0)
+        plan["vote_cls"][1](plan["vote_cls"][0](xc), out=vote, out_channel_offset=2)
         L = self.layer
         n = b * h * w
         t = plan["patch"](x.view(n, cin))
@@ -225,12 +237,13 @@ class E2ESWVoteHead(nn.Module):
             z = ops.layernorm(t, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
             t = bp["fc2"](bp["fc1"](z, act=ops.ACT_GELU), residual=t)
         feat = ops.layernorm(t, L.norm0.weight, L.norm0.bias, L.norm0.eps).view(b, h, w, C)
-        hm = plan["cls"][2](plan["cls"][1](plan["cls"][0](feat)))
-        boxes = plan["bbox"][1](plan["bbox"][0](feat))
+        fc = ops.to_bf16(feat) if bf16 else feat
+        hm = plan["cls"][2](plan["cls"][1](plan["cls"][0](fc)), out_f32=True)
+        boxes = plan["bbox"][1](plan["bbox"][0](fc), out_f32=True)
         ret = dict(pred_centers=vote[..., 0:2], pred_vote_cls=vote[..., 2:3], hm=hm, reg=boxes[..., 0:2], height=boxes[..., 2:3],
                    dim=boxes[..., 3:6], rot=boxes[..., 6:8])
         if self.iou_loss:
-            ret["iou"] = plan["iou"][1](plan["iou"][0](feat))
+            ret["iou"] = plan["iou"][1](plan["iou"][0](fc), out_f32=True)
         ret["_feat"] = feat
         return ret
 
