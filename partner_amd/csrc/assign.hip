@@ -167,27 +167,6 @@ __device__ __forceinline__ bool acc_keep(const AccArgs& a, int i, int s) {
   return !(fabsf(p[0]) < a.radius && fabsf(p[1]) < a.radius);
 }
 
-__device__ uint32_t acc_block_scan(uint32_t v, uint32_t* total) {
-  __shared__ uint32_t wsum[kAccT / 64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
-  }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  uint32_t base = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < kAccT / 64; ++k) {
-    if (k < w) base += wsum[k];
-    tot += wsum[k];
-  }
-  __syncthreads();
-  *total = tot;
-  return base + inc - v;
-}
 
 __global__ void acc_count_kernel(AccArgs a) {
   const int base = (blockIdx.x * kAccT + threadIdx.x) * kAccItems;
@@ -197,7 +176,7 @@ __global__ void acc_count_kernel(AccArgs a) {
     if (i < a.n && acc_keep(a, i, sweep_of(a, i))) ++c;
   }
   uint32_t tot;
-  acc_block_scan(c, &tot);
+  pn::block_exclusive_scan<kAccT>(c, &tot);
   if (threadIdx.x == 0) a.tile[blockIdx.x] = tot;
 }
 
@@ -207,7 +186,7 @@ __global__ void acc_offsets_kernel(AccArgs a) {
     const int i = b0 + threadIdx.x;
     const uint32_t v = i < a.ntiles ? a.tile[i] : 0;
     uint32_t tot;
-    const uint32_t ex = acc_block_scan(v, &tot);
+    const uint32_t ex = pn::block_exclusive_scan<kAccT>(v, &tot);
     if (i < a.ntiles) a.tile[i] = carry + ex;
     carry += tot;
   }
@@ -226,7 +205,7 @@ __global__ void acc_scatter_kernel(AccArgs a) {
     c += keep[k];
   }
   uint32_t tot;
-  uint32_t pos = a.tile[blockIdx.x] + acc_block_scan(c, &tot);
+  uint32_t pos = a.tile[blockIdx.x] + pn::block_exclusive_scan<kAccT>(c, &tot);
   for (int k = 0; k < kAccItems; ++k) {
     if (!keep[k]) continue;
     const float* p = a.raw + (size_t)(base + k) * a.in_cols;

@@ -40,6 +40,32 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// Block-wide exclusive scan of one value per thread (THREADS = multiple of 64): returns the exclusive prefix and leaves
+// the block total in *total.  Wave-level shuffles + one LDS hop; fixed association order.  Shared by the bitmap
+// unique-rank (voxelize.hip), the sparse-convolution site index (sparse_conv.hip) and the sweep compaction (assign.hip).
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
+  __shared__ uint32_t wsum[THREADS / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < THREADS / 64; ++k) {
+    if (k < w) base += wsum[k];
+    tot += wsum[k];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == PN_ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == PN_ACT_TANH) return tanhf(v);

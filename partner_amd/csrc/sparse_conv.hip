@@ -34,27 +34,6 @@ __device__ __forceinline__ int lookup(const uint32_t* __restrict__ bitmap, const
   return (int)(word_rank[w] + __popc(bits & ((1u << bit) - 1u)));
 }
 
-__device__ uint32_t block_scan(uint32_t v, uint32_t* total) {
-  __shared__ uint32_t wsum[kT / 64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
-  }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  uint32_t base = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < kT / 64; ++k) {
-    if (k < w) base += wsum[k];
-    tot += wsum[k];
-  }
-  __syncthreads();
-  *total = tot;
-  return base + inc - v;
-}
 
 __global__ void mark_coords_kernel(const int32_t* __restrict__ coords, int n_cap, const int32_t* __restrict__ n_dev, Dims d, uint32_t* __restrict__ bitmap) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,7 +73,7 @@ __global__ void tile_totals_kernel(const uint32_t* __restrict__ bitmap, size_t n
 #pragma unroll
   for (int k = 0; k < kItems; ++k) s += base + k < nwords ? __popc(bitmap[base + k]) : 0;
   uint32_t tot;
-  block_scan(s, &tot);
+  pn::block_exclusive_scan<kT>(s, &tot);
   if (threadIdx.x == 0) tile_total[blockIdx.x] = tot;
 }
 
@@ -104,7 +83,7 @@ __global__ void tile_offsets_kernel(uint32_t* __restrict__ tile_total, int ntile
     const int i = base + threadIdx.x;
     const uint32_t v = i < ntiles ? tile_total[i] : 0;
     uint32_t tot;
-    const uint32_t ex = block_scan(v, &tot);
+    const uint32_t ex = pn::block_exclusive_scan<kT>(v, &tot);
     if (i < ntiles) tile_total[i] = carry + ex;
     carry += tot;
   }
@@ -121,7 +100,7 @@ __global__ void emit_kernel(const uint32_t* __restrict__ bitmap, size_t nwords, 
     s += __popc(words[k]);
   }
   uint32_t tot;
-  uint32_t rank = tile_offset[blockIdx.x] + block_scan(s, &tot);
+  uint32_t rank = tile_offset[blockIdx.x] + pn::block_exclusive_scan<kT>(s, &tot);
 #pragma unroll
   for (int k = 0; k < kItems; ++k) {
     if (base + k >= nwords) break;

@@ -87,29 +87,6 @@ __global__ void mark_kernel(const uint32_t* __restrict__ keys, int n_cap, const 
   atomicOr(&bitmap[k >> 5], 1u << (k & 31));
 }
 
-// block-wide exclusive scan of one value per thread (256 threads = 4 waves); returns the
-// exclusive prefix and leaves the block total in *total.
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
-  __shared__ uint32_t wsum[kScanThreads / 64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
-  }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  uint32_t base = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < kScanThreads / 64; ++k) {
-    if (k < w) base += wsum[k];
-    tot += wsum[k];
-  }
-  __syncthreads();
-  *total = tot;
-  return base + inc - v;
-}
 
 // phase 1: per-tile totals.  MODE 0: popcount of bitmap words; MODE 1: values of an int array
 // limited to the first *limit entries.
@@ -129,7 +106,7 @@ __global__ void scan_tile_totals_kernel(const uint32_t* __restrict__ src, size_t
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) s += scan_item<MODE>(src, base + k, n, limit);
   uint32_t tot;
-  block_exclusive_scan(s, &tot);
+  pn::block_exclusive_scan<kScanThreads>(s, &tot);
   if (threadIdx.x == 0) tile_total[blockIdx.x] = tot;
 }
 
@@ -141,7 +118,7 @@ __global__ void scan_tile_offsets_kernel(uint32_t* __restrict__ tile_total, int 
     const int i = base + threadIdx.x;
     const uint32_t v = i < ntiles ? tile_total[i] : 0;
     uint32_t tot;
-    const uint32_t ex = block_exclusive_scan(v, &tot);
+    const uint32_t ex = pn::block_exclusive_scan<kScanThreads>(v, &tot);
     if (i < ntiles) tile_total[i] = carry + ex;
     carry += tot;
   }
@@ -165,7 +142,7 @@ __global__ void scan_emit_voxels_kernel(const uint32_t* __restrict__ bitmap, siz
     s += __popc(words[k]);
   }
   uint32_t tot;
-  uint32_t rank = tile_offset[blockIdx.x] + block_exclusive_scan(s, &tot);
+  uint32_t rank = tile_offset[blockIdx.x] + pn::block_exclusive_scan<kScanThreads>(s, &tot);
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     if (base + k >= nwords) break;
@@ -221,7 +198,7 @@ __global__ void scan_emit_starts_kernel(const uint32_t* __restrict__ cnt, size_t
     s += vals[k];
   }
   uint32_t tot;
-  uint32_t run = tile_offset[blockIdx.x] + block_exclusive_scan(s, &tot);
+  uint32_t run = tile_offset[blockIdx.x] + pn::block_exclusive_scan<kScanThreads>(s, &tot);
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     if (base + k <= V && base + k <= n_cap) voxel_start[base + k] = (int32_t)run;
@@ -288,7 +265,7 @@ __global__ void scan_emit_flags_kernel(const uint32_t* __restrict__ flag, size_t
     s += vals[k];
   }
   uint32_t tot;
-  uint32_t run = tile_offset[blockIdx.x] + block_exclusive_scan(s, &tot);
+  uint32_t run = tile_offset[blockIdx.x] + pn::block_exclusive_scan<kScanThreads>(s, &tot);
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     if (base + k < n) vid_at[base + k] = (int32_t)run;
