@@ -176,6 +176,18 @@ int pn_dynamic_pfn_fwd_table(const float *points, int point_stride, const int32_
 /* pointer to the uint32 key-per-voxel array inside a pn_unique_rank_bitmap workspace */
 const uint32_t *pn_unique_keys_ptr(const void *workspace, uint64_t num_cells, int n_capacity);
 
+/* Static (hard-voxel) pillar feature net, eval mode: PillarFeatureNet.forward + PFNLayer.forward_static
+ * (det3d/models/readers/pillar_encoder.py:74-169, 47-60).  voxels (V,P,F), num_points (V), coors (V,4) int32 [b,z,y,x];
+ * decoration = [features, xyz - mean, xy - pillar centre (, |xyz|)], padded slots zeroed; per layer
+ * Linear(no bias) -> BatchNorm1d (folded: scale, shift) -> ReLU -> max over the P slots (padded slots included, as in
+ * the reference).  c1 = 0: single layer (features (V,c0)); else two layers with the [x, max] concatenation
+ * (features (V,c1)).  The pillar count is read from the device. */
+int pn_static_pfn_fwd(const float *voxels, const int32_t *num_points, const int32_t *coors,
+                      const int32_t *num_voxels, int v_capacity, int p, int f, int with_distance,
+                      const float *w0, const float *scale0, const float *shift0, int c0, const float *w1,
+                      const float *scale1, const float *shift1, int c1, float vx, float vy,
+                      float x_offset, float y_offset, float *features, pn_stream_t stream);
+
 /* Backward of the pillar feature net, (C0, C1) = (32, 128) or (16, 32): gradients of the two Linear weights
  * (autograd through pillar_encoder.py:393-406 / 63-71; the points are data, no gradient).
  * The incoming gradient is either d_features (V,128) or the dense canvas gradient d_canvas

@@ -991,3 +991,31 @@ def accumulate_sweeps(clouds: List[np.ndarray], transforms: np.ndarray, time_lag
         p[:, :3] = (hom @ np.asarray(transforms[s], np.float64).T)[:, :3].astype(np.float32)
         out.append(np.concatenate([p, np.full((len(p), 1), np.float32(time_lags[s]), np.float32)], 1))
     return np.concatenate(out, 0)
+
+
+# ======================================================================================
+# V4 static twin  PillarFeatureNet.forward / PFNLayer.forward_static   det3d/models/readers/pillar_encoder.py:131-169, 47-60
+# Pinned by tests/golden/pillar_static.npz (captured from the reference).
+# ======================================================================================
+def pillar_feature_net_static(sd: SD, prefix: str, voxels: Tensor, num_points: Tensor, coors: Tensor, voxel_size, pc_range,
+                              with_distance=False, eps=1e-3) -> Tensor:
+    """voxels (V,P,F), num_points (V,), coors (V,4) [b,z,y,x] -> (V, C_last); eval-mode BatchNorm1d"""
+    vx, vy = voxel_size[0], voxel_size[1]
+    xo, yo = vx / 2 + pc_range[0], vy / 2 + pc_range[1]
+    mean = voxels[:, :, :3].sum(dim=1, keepdim=True) / num_points.to(voxels.dtype).view(-1, 1, 1)
+    parts = [voxels, voxels[:, :, :3] - mean,
+             torch.stack([voxels[:, :, 0] - (coors[:, 3].to(voxels.dtype).unsqueeze(1) * vx + xo),
+                          voxels[:, :, 1] - (coors[:, 2].to(voxels.dtype).unsqueeze(1) * vy + yo)], -1)]
+    if with_distance:
+        parts.append(voxels[:, :, :3].norm(dim=2, keepdim=True))
+    x = torch.cat(parts, -1)
+    x = x * (torch.arange(voxels.shape[1])[None, :] < num_points[:, None]).to(x.dtype).unsqueeze(-1)   # padded slots -> 0
+    n_layers = len([k for k in sd if k.startswith(prefix + "pfn_layers.") and k.endswith("linear.weight")])
+    for i in range(n_layers):
+        p = f"{prefix}pfn_layers.{i}."
+        y = x @ sd[p + "linear.weight"].t()
+        y = (y - sd[p + "norm.running_mean"]) / torch.sqrt(sd[p + "norm.running_var"] + eps) * sd[p + "norm.weight"] + sd[p + "norm.bias"]
+        y = F.relu(y)
+        ymax = y.max(dim=1, keepdim=True)[0]          # padded slots take part (relu of the BatchNorm shift), as in the reference
+        x = ymax if i == n_layers - 1 else torch.cat([y, ymax.expand(-1, y.shape[1], -1)], 2)
+    return x.squeeze(1)

@@ -816,3 +816,135 @@ int pn_dynamic_pfn_bwd(const float* points, int point_stride, const int32_t* vox
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// Static (hard-voxel) pillar feature net: PillarFeatureNet.forward + PFNLayer.forward_static
+// (det3d/models/readers/pillar_encoder.py:74-169, 47-60), eval mode (BatchNorm1d folded into scale / shift).
+// voxels (V, P, F): decoration [x, y, z, ..., x - mean(x,y,z), x - pillar centre (x, y)] (+ |xyz| when with_distance),
+// padded slots zeroed (`features *= mask`), then up to two layers of Linear(no bias) -> BN -> ReLU -> max over the P
+// slots.  As in the reference the PADDED slots take part in the maximum with relu(shift) (the BatchNorm shift of a zero
+// row).  One wave per pillar, lane = output channel, weights transposed in LDS.
+// =================================================================================================
+namespace {
+
+struct StaticPfnArgs {
+  const float* vox; const int32_t* num; const int32_t* coors; const int32_t* v_dev;
+  int v_cap, P, F, nin, with_dist;
+  const float* w0; const float* s0; const float* h0; int c0;   // layer 0 weight (c0, nin), scale, shift
+  const float* w1; const float* s1; const float* h1; int c1;   // optional layer 1 (c1, 2*c0); c1 = 0: single layer
+  float vx, vy, xoff, yoff;
+  float* out;  // (V, c_last)
+};
+
+constexpr int kSpWaves = 4, kSpMaxIn = 16, kSpMaxP = 32;
+
+__global__ __launch_bounds__(kSpWaves * 64) void static_pfn_kernel(StaticPfnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* w0t = lds;                                   // [nin][c0]
+  float* w1t = w0t + a.nin * a.c0;                    // [2*c0][c1]
+  float* rows = w1t + (a.c1 ? 2 * a.c0 * a.c1 : 0);   // per wave: [P][64] layer-0 activations
+  for (int i = threadIdx.x; i < a.nin * a.c0; i += blockDim.x) {
+    const int k = i / a.c0, n = i - k * a.c0;
+    w0t[i] = a.w0[n * a.nin + k];
+  }
+  if (a.c1)
+    for (int i = threadIdx.x; i < 2 * a.c0 * a.c1; i += blockDim.x) {
+      const int k = i / a.c1, n = i - k * a.c1;
+      w1t[i] = a.w1[n * 2 * a.c0 + k];
+    }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  float* act = rows + (size_t)wib * (a.P + 1) * 64;   // P activation rows + one row for the maxima
+  const int V = min(*a.v_dev, a.v_cap);
+  const float sc0 = lane < a.c0 ? a.s0[lane] : 0.f, sh0 = lane < a.c0 ? a.h0[lane] : 0.f;
+  for (int v = blockIdx.x * kSpWaves + wib; v < V; v += gridDim.x * kSpWaves) {
+    const int n = a.num[v];
+    const float* vp = a.vox + (size_t)v * a.P * a.F;
+    // mean of x, y, z over ALL P slots divided by num (the reference sums the zero padding too)
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int p = 0; p < a.P; ++p) { sx += vp[p * a.F]; sy += vp[p * a.F + 1]; sz += vp[p * a.F + 2]; }
+    const float mx = sx / (float)n, my = sy / (float)n, mz = sz / (float)n;
+    const float cx = (float)a.coors[(size_t)v * 4 + 3] * a.vx + a.xoff, cy = (float)a.coors[(size_t)v * 4 + 2] * a.vy + a.yoff;
+    float m0 = -3.0e38f;
+    for (int p = 0; p < a.P; ++p) {
+      float d[kSpMaxIn];
+      const bool live = p < n;
+#pragma unroll
+      for (int k = 0; k < kSpMaxIn; ++k) d[k] = 0.f;
+      if (live) {
+        const float* q = vp + p * a.F;
+        for (int k = 0; k < a.F; ++k) d[k] = q[k];
+        d[a.F] = q[0] - mx; d[a.F + 1] = q[1] - my; d[a.F + 2] = q[2] - mz;
+        d[a.F + 3] = q[0] - cx; d[a.F + 4] = q[1] - cy;
+        if (a.with_dist) d[a.F + 5] = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+      }
+      float h = 0.f;
+      if (lane < a.c0)
+        for (int k = 0; k < a.nin; ++k) h = fmaf(w0t[k * a.c0 + lane], d[k], h);
+      h = fmaf(h, sc0, sh0);
+      h = h > 0.f ? h : 0.f;
+      m0 = fmaxf(m0, h);
+      act[p * 64 + lane] = h;
+    }
+    if (a.c1 == 0) {
+      if (lane < a.c0) a.out[(size_t)v * a.c0 + lane] = m0;
+      continue;
+    }
+    // layer 1 on [x_p, max]: the max half is the same for every slot
+    float g0 = 0.f, g1 = 0.f;
+    const bool two = a.c1 > 64;
+    // broadcast m0 through LDS row P
+    float* mrow = act + (size_t)a.P * 64;
+    mrow[lane] = m0;
+    for (int c = 0; c < a.c0; ++c) {
+      const float m = mrow[c];
+      if (lane < a.c1) g0 = fmaf(w1t[(a.c0 + c) * a.c1 + lane], m, g0);
+      if (two && lane + 64 < a.c1) g1 = fmaf(w1t[(a.c0 + c) * a.c1 + lane + 64], m, g1);
+    }
+    const float s1a = lane < a.c1 ? a.s1[lane] : 0.f, h1a = lane < a.c1 ? a.h1[lane] : 0.f;
+    const float s1b = (two && lane + 64 < a.c1) ? a.s1[lane + 64] : 0.f, h1b = (two && lane + 64 < a.c1) ? a.h1[lane + 64] : 0.f;
+    float f0 = -3.0e38f, f1 = -3.0e38f;
+    for (int p = 0; p < a.P; ++p) {
+      float y0 = g0, y1 = g1;
+      for (int c = 0; c < a.c0; ++c) {
+        const float hc = act[p * 64 + c];
+        if (lane < a.c1) y0 = fmaf(w1t[c * a.c1 + lane], hc, y0);
+        if (two && lane + 64 < a.c1) y1 = fmaf(w1t[c * a.c1 + lane + 64], hc, y1);
+      }
+      y0 = fmaf(y0, s1a, h1a); y1 = fmaf(y1, s1b, h1b);
+      f0 = fmaxf(f0, y0 > 0.f ? y0 : 0.f);
+      f1 = fmaxf(f1, y1 > 0.f ? y1 : 0.f);
+    }
+    if (lane < a.c1) a.out[(size_t)v * a.c1 + lane] = f0;
+    if (two && lane + 64 < a.c1) a.out[(size_t)v * a.c1 + lane + 64] = f1;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pn_static_pfn_fwd(const float* voxels, const int32_t* num_points, const int32_t* coors, const int32_t* num_voxels, int v_capacity, int p,
+                      int f, int with_distance, const float* w0, const float* scale0, const float* shift0, int c0, const float* w1,
+                      const float* scale1, const float* shift1, int c1, float vx, float vy, float x_offset, float y_offset, float* features,
+                      pn_stream_t stream) {
+  PN_REQUIRE(voxels && num_points && coors && num_voxels && w0 && scale0 && shift0 && features, "static_pfn: null pointer");
+  const int nin = f + 5 + (with_distance ? 1 : 0);
+  PN_REQUIRE(f >= 3 && nin <= kSpMaxIn && p >= 1 && p <= kSpMaxP, "static_pfn: at most 16 decorated input features and 32 points per pillar");
+  PN_REQUIRE(c0 >= 1 && c0 <= 64 && (c1 == 0 || (w1 && scale1 && shift1 && c1 <= 128)), "static_pfn: supports C0 <= 64, C1 <= 128");
+  if (v_capacity == 0) return PN_OK;
+  StaticPfnArgs a{voxels, num_points, coors, num_voxels, v_capacity, p, f, nin, with_distance, w0, scale0, shift0, c0, w1, scale1, shift1, c1,
+                  vx, vy, x_offset, y_offset, features};
+  const size_t smem = (size_t)(nin * c0 + (c1 ? 2 * c0 * c1 : 0) + kSpWaves * (p + 1) * 64) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&static_pfn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    attr_done = true;
+  }
+  PN_REQUIRE(smem <= 140 * 1024, "static_pfn: layer sizes exceed LDS");
+  const int blocks = std::max(1, std::min(2048, pn::cdiv(v_capacity, kSpWaves)));
+  hipLaunchKernelGGL(static_pfn_kernel, dim3(blocks), dim3(kSpWaves * 64), smem, pn::S(stream), a);
+  return pn::check_launch("static_pfn_kernel");
+}
+
+}  // extern "C"

@@ -88,8 +88,13 @@ class PointPillars(SingleStageDetector):
     def extract_preds(self, example) -> Dict[str, object]:
         """reference ``example`` dict (dynamic branch keys) -> {'det_preds': [...]}"""
         eval_only(self, "PointPillars")
-        if "voxels" in example:
-            raise NotImplementedError("PointPillars hard-voxel (static) branch has no HIP kernels yet")
+        if "voxels" in example:   # hard-voxel (static) branch, point_pillars.py:27-38 / 60-76
+            voxels, coords = example["voxels"], example["coordinates"]
+            hip.require_device(voxels, coords)
+            feats = self.reader(voxels, example["num_points"], coords)
+            x1 = self.backbone(feats, coords, len(example["num_voxels"]), [int(v) for v in example["shape"][0]])
+            x2 = self.neck.forward_nhwc(ops.to_nhwc(x1)) if self.with_neck else ops.to_nhwc(x1)
+            return self.bbox_head(ops.as_nchw(x2))
         points, grid_ind = example["points"], example["grid_ind"]
         hip.require_device(points, grid_ind)
         batch = len(example["num_points"])

@@ -59,6 +59,7 @@ SIGNATURES = {
     "pn_dynamic_pfn_fwd_table": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P]),
     "pn_dynamic_pfn_bwd_workspace_bytes": (_SZ, []),
     "pn_dynamic_pfn_bwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _I, _P, _SZ, _P]),
+    "pn_static_pfn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P]),
     "pn_scatter_canvas_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "pn_fill_zero": (_I, [_P, _SZ, _P]),
     "pn_conv_packed_weight_floats": (_SZ, [_I, _I, _I, _I, _I]),

@@ -9,7 +9,7 @@ from torch import nn
 
 from . import hip, ops
 from .builder import BACKBONES, READERS
-from .nn_utils import build_norm_layer, eval_only
+from .nn_utils import PlanCache, build_norm_layer, eval_only
 
 
 class PFNLayer(nn.Module):
@@ -152,9 +152,37 @@ class PillarFeatureNet(nn.Module):
         self.pfn_layers = nn.ModuleList([
             PFNLayer(filters[i], filters[i + 1], norm_cfg=norm_cfg, last_layer=(i == len(filters) - 2))
             for i in range(len(filters) - 1)])
+        self.num_input, self._with_distance = num_input_features, bool(with_distance)
+        self.vx, self.vy = voxel_size[0], voxel_size[1]
+        self.x_offset, self.y_offset = self.vx / 2 + pc_range[0], self.vy / 2 + pc_range[1]
+        self._plan = PlanCache()
+
+    def _build_plan(self):
+        if len(self.pfn_layers) > 2:
+            raise NotImplementedError("PillarFeatureNet HIP kernel: one or two PFN layers")
+        plan = []
+        for l in self.pfn_layers:
+            scale, shift = ops.fold_bn(l.norm.weight, l.norm.bias, l.norm.running_mean, l.norm.running_var, l.norm.eps)
+            plan.append((l.linear.weight.detach().float().contiguous(), scale, shift))
+        return plan
 
     def forward(self, features, num_voxels, coors):
-        raise NotImplementedError("PillarFeatureNet (static voxels) has no HIP kernel yet; use DynamicPFNet")
+        """features (V,P,F) f32, num_voxels (V,) int, coors (V,4) int [b,z,y,x] -> (V, C) as pillar_encoder.py:131-169 (eval mode)"""
+        hip.require_device(features, num_voxels, coors)
+        eval_only(self, "PillarFeatureNet")
+        plan = self._plan.get(self, self._build_plan)
+        v, p, f = features.shape
+        assert f == self.num_input
+        w0, s0, h0 = plan[0]
+        w1, s1, h1 = plan[1] if len(plan) > 1 else (None, None, None)
+        c0, c1 = w0.shape[0], (0 if w1 is None else w1.shape[0])
+        out = torch.empty((v, c1 or c0), dtype=torch.float32, device=features.device)
+        nv = torch.full((1,), v, dtype=torch.int32, device=features.device)
+        hip.call("pn_static_pfn_fwd", features.contiguous().data_ptr(), num_voxels.to(torch.int32).contiguous().data_ptr(),
+                 coors.to(torch.int32).contiguous().data_ptr(), nv.data_ptr(), v, p, f, int(self._with_distance), w0.data_ptr(), s0.data_ptr(),
+                 h0.data_ptr(), c0, hip.ptr(w1), hip.ptr(s1), hip.ptr(h1), c1, float(self.vx), float(self.vy), float(self.x_offset),
+                 float(self.y_offset), out.data_ptr(), hip.stream())
+        return out
 
 
 @BACKBONES.register_module

@@ -578,7 +578,28 @@ def gen_sweeps():
     save("sweeps.npz", accumulated=acc.astype(np.float32), counts=np.array([len(p) for p in pts_list]))
 
 
+# ----------------------------------------------------------------------------- V4 static twin: PillarFeatureNet
+def gen_pillar_static():
+    """PillarFeatureNet.forward (pillar_encoder.py:131-169) + PFNLayer.forward_static (:47-60), eval mode, on hard voxels of a
+    synthetic Cartesian sweep: one layer (64,) and two layers (64, 128) with the distance feature."""
+    from det3d.models.readers.pillar_encoder import PillarFeatureNet
+    pts = synth.synth_sweep_cart(6000, seed=3)[:, :4].copy()
+    rng_, vs = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], [0.8, 0.8, 8.0]
+    vg = VoxelGenerator(vs, rng_, 20, 1500)
+    voxels, coors, num = vg.generate(pts, 1500)[:3]
+    coors4 = np.concatenate([np.zeros((len(coors), 1), coors.dtype), coors], 1)
+    out = dict(voxels=voxels.astype(np.float32), coors=coors4.astype(np.int32), num=num.astype(np.int32))
+    for tag, filters, dist in (("one", (64,), False), ("two", (64, 128), True)):
+        net = PillarFeatureNet(num_input_features=4, num_filters=filters, with_distance=dist, voxel_size=vs, pc_range=rng_).eval()
+        synth.load_filled(net, base_seed=41)
+        with torch.no_grad():
+            y = net(torch.from_numpy(out["voxels"]), torch.from_numpy(out["num"]), torch.from_numpy(coors4.astype(np.int64)))
+        out[f"{tag}_features"] = y.numpy()
+        out[f"{tag}_keys"] = np.array(list(net.state_dict().keys()))
+    save("pillar_static.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps"]
+    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static"]
     for w in which:
         globals()["gen_" + w]()

@@ -441,3 +441,22 @@ def test_sweep_accumulation_restatement(golden):
     acc = O.accumulate_sweeps(clouds, mats, lags)
     assert acc.shape == g["accumulated"].shape and int(g["counts"][1]) < len(clouds[1])    # remove_close really dropped points
     np.testing.assert_allclose(acc, g["accumulated"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,dist", [("one", False), ("two", True)])
+def test_static_pillar_feature_net_restatement(golden, tag, dist):
+    g = golden("pillar_static.npz")
+    keys = [str(k) for k in g[f"{tag}_keys"]]
+    nin = 4 + 5 + int(dist)
+    filt = [nin, 64] if tag == "one" else [nin, 32, 128]     # PFNLayer halves the width of non-final layers
+    shapes = {}
+    for i in range(len(filt) - 1):
+        cin = filt[i] if i == 0 else 2 * filt[i]
+        p = f"pfn_layers.{i}."
+        shapes.update({p + "linear.weight": (filt[i + 1], cin), p + "norm.weight": (filt[i + 1],), p + "norm.bias": (filt[i + 1],),
+                       p + "norm.running_mean": (filt[i + 1],), p + "norm.running_var": (filt[i + 1],), p + "norm.num_batches_tracked": ()})
+    assert list(shapes) == keys
+    sd = filled_sd(shapes, 41)
+    y = O.pillar_feature_net_static(sd, "", torch.from_numpy(g["voxels"]), torch.from_numpy(g["num"]), torch.from_numpy(g["coors"]).long(),
+                                    [0.8, 0.8, 8.0], [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], with_distance=dist)
+    close(y, g[f"{tag}_features"], 1e-5, 1e-5)
