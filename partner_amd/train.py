@@ -468,6 +468,21 @@ class PolarPillarTrainStep:
         self.invalidate_inference_plans()
         return total_norm
 
+    # ---- checkpoint / resume (the reference saves model + optimizer state per epoch, det3d/torchie/trainer/trainer.py:342-372)
+    def state_dict(self) -> Dict[str, object]:
+        """optimizer-side state; the parameters themselves are in ``model.state_dict()`` (views of the flat buffer)"""
+        return dict(iter=self.iter, exp_avg=self.ps.flat_m.clone(), exp_avg_sq=self.ps.flat_v.clone(), names=list(self.ps.names),
+                    schedule=dict(self.sched))
+
+    def load_state_dict(self, state: Dict[str, object]) -> None:
+        if list(state["names"]) != list(self.ps.names):
+            raise ValueError("optimizer state belongs to a model with different parameters")
+        self.iter = int(state["iter"])
+        self.ps.flat_m.copy_(state["exp_avg"])
+        self.ps.flat_v.copy_(state["exp_avg_sq"])
+        self.sched.update(state.get("schedule", {}))
+        self.invalidate_inference_plans()
+
     def invalidate_inference_plans(self):
         """the kernels update the parameters behind PyTorch's version counters: drop the packed-weight plans of the
         inference path so that the next eval forward re-packs from the trained weights"""
