@@ -252,6 +252,21 @@ def main():
         barrier()
         eager_ms = 1e3 * (time.perf_counter() - t1) / args.steps
 
+    def committed_traffic():
+        """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/r1_final_pmc_traffic.csv: FETCH_SIZE doubled as
+        the gfx950 guide prescribes + WRITE_SIZE, separate --pmc passes of this same command with --streams 1); None if absent"""
+        import csv
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_final_pmc_traffic.csv")
+        if not os.path.exists(path):
+            return None
+        tot, n = 0.0, 0
+        for r in csv.DictReader(open(path)):
+            if r["kernel"].startswith("conv_mfma_kernel"):
+                k = int(r["launches"])
+                tot += k * (float(r["fetch_KB_corrected_x2_avg"]) + float(r["WRITE_SIZE_KB_avg"])) * 1024.0
+                n += k
+        return round(tot / n) if n else None
+
     roofline = None
     if prof is not None:
         flops, ms, launches = prof.collect()
@@ -259,7 +274,8 @@ def main():
         ach = flops / (ms * 1e-3) / 1e12
         roofline = dict(bound="mfma", kernel="conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
                         achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        traffic=None, launches=launches, flops_per_launch=round(flops / launches), avg_launch_us=round(1e3 * ms / launches, 2),
+                        traffic=committed_traffic(), traffic_unit="HBM bytes per conv launch (offline PMC passes, profiles/r1_final_pmc_traffic.csv)",
+                        launches=launches, flops_per_launch=round(flops / launches), avg_launch_us=round(1e3 * ms / launches, 2),
                         conv_ms_per_step=round(ms / args.steps, 4),
                         measured="HIP events around every conv launch over the same K steps replayed eagerly "
                                  "(events cannot be recorded inside the hipGraph of the timed region)",
