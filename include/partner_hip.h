@@ -499,6 +499,8 @@ int pn_adam_step_f32(float *params, const float *grads, float *exp_avg, float *e
  * that its weight / data gradients are those of an ordinary convolution with strata*c outputs
  * (center_head_parallel.py:45-59). */
 int pn_tanh_bwd_f32(const float *y, const float *dy, float *dx, size_t n, pn_stream_t stream);
+/* dx = dy where the ReLU OUTPUT y is positive, else 0 (plain CenterHead: conv + ReLU chains, center_head.py:65-109) */
+int pn_relu_bwd_f32(const float *y, const float *dy, float *dx, size_t n, pn_stream_t stream);
 int pn_add_f32(const float *a, const float *b, float *out, size_t n, pn_stream_t stream);
 int pn_strat_expand_f32(const float *dy, int batch, int h, int w, int c, int strata, float *out,
                         pn_stream_t stream);

@@ -78,6 +78,10 @@ __global__ void tanh_bwd_kernel(const float* __restrict__ y, const float* __rest
     dx[i] = dy[i] * (1.f - y[i] * y[i]);
 }
 
+__global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
 }
@@ -127,6 +131,13 @@ int pn_tanh_bwd_f32(const float* y, const float* dy, float* dx, size_t n, pn_str
   if (n == 0) return PN_OK;
   hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, pn::S(stream), y, dy, dx, n);
   return pn::check_launch("tanh_bwd_kernel");
+}
+
+int pn_relu_bwd_f32(const float* y, const float* dy, float* dx, size_t n, pn_stream_t stream) {
+  PN_REQUIRE(y && dy && dx, "relu_bwd: null pointer");
+  if (n == 0) return PN_OK;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, pn::S(stream), y, dy, dx, n);
+  return pn::check_launch("relu_bwd_kernel");
 }
 
 int pn_add_f32(const float* a, const float* b, float* out, size_t n, pn_stream_t stream) {

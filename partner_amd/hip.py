@@ -116,6 +116,7 @@ SIGNATURES = {
     "pn_grad_norm_f32": (_I, [_P, _SZ, _P, _P, _SZ, _P]),
     "pn_adam_step_f32": (_I, [_P, _P, _P, _P, _SZ, _I, _F, _F, _F, _F, _F, _P, _F, _P]),
     "pn_tanh_bwd_f32": (_I, [_P, _P, _P, _SZ, _P]),
+    "pn_relu_bwd_f32": (_I, [_P, _P, _P, _SZ, _P]),
     "pn_add_f32": (_I, [_P, _P, _P, _SZ, _P]),
     "pn_strat_expand_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "pn_center_loss_workspace_bytes": (_SZ, []),

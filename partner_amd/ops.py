@@ -817,6 +817,16 @@ def tanh_bwd(y: torch.Tensor, dy: torch.Tensor, dx: Optional[torch.Tensor] = Non
     return dx
 
 
+def relu_bwd(y: torch.Tensor, dy: torch.Tensor, dx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx = dy * (y > 0), y = the ReLU output; dx may be dy"""
+    hip.require_device(y, dy)
+    assert y.is_contiguous() and dy.is_contiguous() and y.numel() == dy.numel()
+    if dx is None:
+        dx = torch.empty_like(dy)
+    hip.call("pn_relu_bwd_f32", y.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.numel(), hip.stream())
+    return dx
+
+
 def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     hip.require_device(a, b)
     assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()

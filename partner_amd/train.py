@@ -153,6 +153,22 @@ class _ConvBNReLU:
         return self.conv.bwd(dy, need_dx=need_dx, dx=dx, accumulate=accumulate)
 
 
+class _ConvReLU:
+    """Conv2d(bias) + ReLU of the plain CenterHead (center_head.py:65-109, 166-242)"""
+
+    def __init__(self, ps: ParamStore, wname: str, bname: str, pad: int):
+        self.conv = _Conv(ps, wname, bname, 1, pad, act=RELU)
+        self.z = None
+
+    def fwd(self, x):
+        self.z = self.conv.fwd(x)   # ReLU fused into the epilogue; its output is also the backward mask
+        return self.z
+
+    def bwd(self, dout, dx=None, accumulate=False):
+        dy = ops.relu_bwd(self.z, dout, dx=dout)
+        return self.conv.bwd(dy, dx=dx, accumulate=accumulate)
+
+
 class _ConvGNReLU:
     """Conv2d(bias) + GroupNorm-family + ReLU (+ calibration second output) of the merged heads"""
 
@@ -246,8 +262,11 @@ class PolarPillarTrainStep:
         reader, neck, head = model.reader, model.neck, model.bbox_head
         if not isinstance(reader, DynamicPFNet):
             raise NotImplementedError("training step: the reader must be a DynamicPFNet")
-        if not isinstance(head, CenterHeadSingle):
-            raise NotImplementedError("training step: the head must be CenterHeadSingle / CenterHeadSinglePos")
+        self.plain_head = type(head).__name__ == "CenterHead"
+        if not (isinstance(head, CenterHeadSingle) or self.plain_head):
+            raise NotImplementedError("training step: the head must be CenterHead, CenterHeadSingle or CenterHeadSinglePos")
+        if self.plain_head and len(head.tasks) != 1:
+            raise NotImplementedError("training step: the plain CenterHead is supported with a single task")
         reader._check_supported()
         dev = next(model.parameters()).device
         hip.require_device(next(model.parameters()))
@@ -272,6 +291,20 @@ class PolarPillarTrainStep:
         self.up_filters = list(neck._num_upsample_filters)
         # ---- head
         hp = "bbox_head."
+        self.code_weights, self.loss_weight = list(head.code_weights), float(head.weight)
+        self.ncls = sum(head.num_classes)
+        self.has_pos = False
+        if self.plain_head:
+            self.shared = _ConvReLU(ps, hp + "shared_conv.0.weight", hp + "shared_conv.0.bias", 1)
+            self.branches = {}
+            task = head.tasks[0]
+            for name in task.heads:
+                convs = [(i, mod) for i, mod in enumerate(getattr(task, name)._modules.values()) if isinstance(mod, nn.Conv2d)]
+                bp = f"{hp}tasks.0.{name}."
+                hidden = [_ConvReLU(ps, f"{bp}{i}.weight", f"{bp}{i}.bias", mod.padding[0]) for i, mod in convs[:-1]]
+                i, mod = convs[-1]
+                self.branches[name] = ("plain", hidden, _Conv(ps, f"{bp}{i}.weight", f"{bp}{i}.bias", 1, mod.padding[0]), 1)
+            return
         rs = head.shared_conv[1]
         assert isinstance(rs, RSNorm)
         self.shared = _ConvGNReLU(ps, hp + "shared_conv.0.weight", hp + "shared_conv.0.bias", hp + "shared_conv.1.groupnorm.weight",
@@ -351,7 +384,9 @@ class PolarPillarTrainStep:
                 maps[kind] = c1.fwd(mid)
             self.cal_w, self.cal_b = maps["calibration_weight"], maps["calibration_bias"]
             mul, add = self.cal_w[0], self.cal_b[0]
-        if mul is not None:
+        if self.plain_head:
+            xs = x_hm = self.shared.fwd(out)
+        elif mul is not None:
             xs, x_hm = self.shared.fwd(out, mul=mul, add=add)
         else:
             xs = x_hm = self.shared.fwd(out)
@@ -359,6 +394,12 @@ class PolarPillarTrainStep:
         preds = {}
         self.branch_mid = {}
         for name, (kind, first, last, groups) in self.branches.items():
+            if kind == "plain":
+                z = xs
+                for layer in first:
+                    z = layer.fwd(z)
+                preds[name] = last.fwd(z)
+                continue
             z = first.fwd(x_hm if name == "hm" else xs)
             self.branch_mid[name] = z
             if kind == "conv" and groups > 1:
@@ -393,6 +434,13 @@ class PolarPillarTrainStep:
         d_xhm = None
         first_into_xs = True
         for name, (kind, first, last, groups) in self.branches.items():
+            if kind == "plain":
+                dz = last.bwd(d_pred[name], cout=ps.p[last.wname].shape[0], dx=None if first else d_xs, accumulate=(not first) and not first_into_xs)
+                for li in range(len(first) - 1, -1, -1):
+                    into_xs = li == 0
+                    dz = first[li].bwd(dz, dx=d_xs if into_xs else None, accumulate=into_xs and not first_into_xs)
+                first_into_xs = False
+                continue
             z = self.branch_mid[name]
             if kind == "conv" and groups > 1:
                 # grouped final convolution: one output tensor per merged head (e.g. rot | vel)
@@ -417,8 +465,11 @@ class PolarPillarTrainStep:
                 first.bwd(dz, dx=d_xs, accumulate=not first_into_xs)
                 first_into_xs = False
         # shared conv + RSNorm (+ calibration)
-        res = self.shared.bwd(d_xs, dout2=d_xhm)
-        d_x2 = res[0]
+        if self.plain_head:
+            d_x2 = self.shared.bwd(d_xs)
+        else:
+            res = self.shared.bwd(d_xs, dout2=d_xhm)
+            d_x2 = res[0]
         if self.has_pos:
             d_calw, d_calb = res[1], res[2]
             for kind, dmap, ymap in (("calibration_weight", d_calw, self.cal_w), ("calibration_bias", d_calb, self.cal_b)):
