@@ -548,6 +548,85 @@ __global__ void conv_direct_kernel(ConvArgs a, const float* __restrict__ w_oihw,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Convolutions with very few output channels (the last layer of every head branch: 64 -> 1 / 2 / 3 / 10).  On the MFMA
+// tile they are latency bound (a 64 x 32 tile does 16 MFMAs per K step but waits a full global round trip for each of its
+// 18 steps: 19 us for 0.2 GFLOP).  Here one block = 64 output pixels x 4 waves; wave q owns a quarter of the input
+// channels, lane = pixel, the weights of the wave's channels are wave-uniform (scalar loads feeding v_fmac), the four
+// partial sums meet in LDS.  1024 waves for a 128 x 128 map, ~2300 FMAs each.
+constexpr int kSmallN = 16;
+
+template <int NOUT, int TAPS>
+__global__ __launch_bounds__(256) void conv_small_n_kernel(ConvArgs a) {
+  __shared__ float part[4][64][NOUT + 1];
+  const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), z = blockIdx.y;
+  const int m = blockIdx.x * 64 + lane;
+  const bool live = m < a.M;
+  const int mm = live ? m : 0;
+  const int ohw = a.OH * a.OW;
+  const int b = mm / ohw, rem = mm - b * ohw, oh = rem / a.OW, ow = rem - oh * a.OW;
+  const int cq = ((a.Cin + 15) / 16) * 4;                 // channels per wave: whole quads, at most 16 (Cin <= 64)
+  const int c0 = q * cq, c1 = min(a.Cin, c0 + cq);
+  // every input value of the wave's pixel x channel-quarter is requested before the first one is used: with one
+  // wave per SIMD there is nobody else to hide the latency behind
+  f32x4 x[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    const int kh = t / a.KW, kw = t - kh * a.KW;
+    const int ih = oh * a.stride - a.pad_h + kh, iw = ow * a.stride - a.pad_w + kw;
+    const bool in = live && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+    const float* ip = a.in + ((size_t)(b * a.H + (in ? ih : 0)) * a.W + (in ? iw : 0)) * a.in_ps + a.in_co + z * a.in_group_stride;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int c = c0 + 4 * cc;
+      x[t][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (in && c < c1) x[t][cc] = *reinterpret_cast<const f32x4*>(ip + c);
+    }
+  }
+  float acc[NOUT];
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) acc[n] = 0.f;
+  // packed weights [g][tap][cin_pad/4][cout_pad][4]: the NOUT x 4 block of (n, k) for one channel quad is contiguous
+  const int quads = a.cin_chunks * 8;
+  const float* wz = a.w + ((size_t)z * TAPS * quads + (c0 >> 2)) * a.cout_pad * 4;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      if (c0 + 4 * cc < c1) {                                                   // wave-uniform
+        const float* wp = wz + ((size_t)t * quads + cc) * a.cout_pad * 4;       // wave-uniform address -> scalar loads
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {   // columns past Cout are zero in the packed weights
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[n] = fmaf(x[t][cc][k], wp[n * 4 + k], acc[n]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) part[q][lane][n] = acc[n];
+  __syncthreads();
+  // thread (pixel p = tid & 63, output group g = tid >> 6): outputs n = g, g + 4, ...
+  const int p = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int mo = blockIdx.x * 64 + p;
+  if (mo >= a.M) return;
+  for (int n = g; n < a.Cout; n += 4) {
+    const float v = (part[0][p][n] + part[1][p][n]) + (part[2][p][n] + part[3][p][n]);
+    const int sidx = z * a.Cout + n;
+    const float sc = a.scale ? a.scale[sidx] : 1.f, sh = a.shift ? a.shift[sidx] : 0.f;
+    a.out[(size_t)mo * a.out_ps + a.out_co + z * a.Cout + n] = pn::apply_act(fmaf(v, sc, sh), a.act);
+  }
+}
+
+template <int TAPS>
+void launch_small_n(const ConvArgs& a, int zdim, hipStream_t st) {
+  const dim3 grid(pn::cdiv(a.M, 64), zdim);
+  if (a.ncols <= 4) hipLaunchKernelGGL((conv_small_n_kernel<4, TAPS>), grid, dim3(256), 0, st, a);
+  else if (a.ncols <= 8) hipLaunchKernelGGL((conv_small_n_kernel<8, TAPS>), grid, dim3(256), 0, st, a);
+  else if (a.ncols <= 12) hipLaunchKernelGGL((conv_small_n_kernel<12, TAPS>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_small_n_kernel<16, TAPS>), grid, dim3(256), 0, st, a);
+}
+
 template <int WM, int WN, int TM, int TN, int DT = DT_F32, bool GATHER = false>
 int launch_conv(const ConvArgs& a, int zdim, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -621,7 +700,9 @@ int dispatch_conv(const ConvArgs& a, int zdim, hipStream_t st) {
     const long long t64x128 = (long long)pn::cdiv(a.M, 64) * pn::cdiv(a.ncols, 128) * zdim;
     static const int min128 = [] { const char* e = getenv("PN_CONV_MIN128"); return e ? atoi(e) : 384; }();
     static const int min64x128 = [] { const char* e = getenv("PN_CONV_MIN64X128"); return e ? atoi(e) : 256; }();
-    if (a.ncols > 64) tile = t128 >= min128 ? 1 : (t64x128 >= min64x128 ? 2 : 3);
+    // mid-size maps (256 .. 1023 tiles of 64 x 128): eight waves of 32 x 32 per block measured 8 % faster than four of 32 x 64
+    // on the 128 x 128 layers (103 vs 95 TFLOP/s), also on the stride-2 and 2x2 layers
+    if (a.ncols > 64) tile = t128 >= min128 ? 1 : (t64x128 >= min64x128 ? 5 : 3);
     else if (a.ncols > 32) tile = 3;
     else tile = 4;
   }
@@ -814,6 +895,15 @@ int pn_conv2d_nhwc_f32(const pn_conv_desc* d, const float* in, const float* pack
     a.res = out; a.res_ps = d->out_pixel_stride;
   }
   hipStream_t st = pn::S(stream);
+  static const int small_n = [] { const char* e = getenv("PN_CONV_SMALL_N"); return e ? atoi(e) : 1; }();
+  const int taps = a.KH * a.KW;
+  if (small_n && a.mode == MODE_CONV && a.ncols <= kSmallN && a.Cin <= 64 && (taps == 9 || taps == 1) && a.res == nullptr &&
+      a.M >= 4096) {
+    // last layer of a head branch: too few columns for an MFMA tile to hide its load latency
+    if (taps == 9) launch_small_n<9>(a, zdim, st);
+    else launch_small_n<1>(a, zdim, st);
+    return pn::check_launch("conv_small_n_kernel");
+  }
   return dispatch_conv(a, zdim, st);
 }
 

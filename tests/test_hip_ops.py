@@ -243,6 +243,14 @@ def _conv_case(dev, b, cin, cout, h, w, k, stride, pad, groups=1, act=0, seed=0,
     dict(b=1, cin=32, cout=2, h=16, w=16, k=3, stride=1, pad=1, groups=2, act=2, bn=False),
     dict(b=1, cin=20, cout=24, h=9, w=7, k=3, stride=1, pad=1, act=1),          # Cin not a multiple of 32
     dict(b=3, cin=128, cout=128, h=256, w=256, k=3, stride=1, pad=1, act=1),    # big-tile path (M=196608)
+    # last layers of the head branches on a full map (M >= 4096, <= 16 columns): the scalar-weight small-N kernel
+    dict(b=1, cin=64, cout=1, h=128, w=128, k=3, stride=1, pad=1, act=0, bn=False),
+    dict(b=1, cin=64, cout=3, h=128, w=128, k=3, stride=1, pad=1, act=0),
+    dict(b=2, cin=64, cout=10, h=72, w=100, k=3, stride=1, pad=1, act=0, bn=False),   # ragged last block
+    dict(b=1, cin=32, cout=2, h=128, w=128, k=3, stride=1, pad=1, groups=2, act=2, bn=False),
+    dict(b=1, cin=64, cout=2, h=128, w=128, k=1, stride=1, pad=0, act=0, bn=False),
+    dict(b=1, cin=20, cout=7, h=64, w=80, k=3, stride=1, pad=1, act=1),           # ragged channel quarters
+    dict(b=1, cin=64, cout=16, h=64, w=64, k=3, stride=2, pad=1, act=1),
 ])
 def test_conv_mfma(dev, case):
     import zlib

@@ -1,0 +1,19 @@
+import torch, time, os, sys
+sys.path.insert(0, '/root/repo')
+from partner_amd import ops
+import torch.nn.functional as F
+torch.manual_seed(0)
+dev='cuda'
+for (cin,cout,k,groups) in [(64,1,3,1),(64,2,3,1),(64,3,3,1),(64,10,3,1),(64,4,3,2),(64,2,1,1)]:
+    w=torch.randn(cout,cin//groups,k,k,device=dev)*0.05; b=torch.randn(cout,device=dev)
+    x=torch.randn(1,cin,128,128,device=dev)
+    layer=ops.ConvLayer(w,stride=1,pad=k//2,groups=groups,shift=b)
+    xn=ops.to_nhwc(x)
+    y=layer(xn)
+    ref=F.conv2d(x,w,b,padding=k//2,groups=groups).permute(0,2,3,1)
+    err=(y-ref).abs().max().item()
+    for _ in range(20): layer(xn)
+    torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(200): layer(xn)
+    torch.cuda.synchronize(); dt=(time.perf_counter()-t)/200*1e6
+    print(cin,cout,k,groups,'err %.2e'%err,'%.1f us'%dt)
