@@ -100,12 +100,17 @@ int pn_unique_rank_bitmap(const uint32_t *keys, int n_capacity, const int32_t *n
 /* ---------------------------------------------------------------------------------------
  * Bucket the points by voxel rank: voxel_start[v] = exclusive scan of unq_cnt (V+1 entries,
  * capacity n_capacity+1) and order[] = point indices grouped by voxel (order inside a voxel
- * is unspecified; every consumer below reduces with order-independent arithmetic).
+ * is unspecified; every forward consumer below reduces with order-independent arithmetic).
  */
 size_t pn_bucket_workspace_bytes(int n_capacity);
 int pn_bucket_points(const int32_t *unq_inv, const int32_t *unq_cnt, int n_capacity,
                      const int32_t *n_dev, const int32_t *num_voxels, int32_t *voxel_start,
                      int32_t *order, void *workspace, size_t workspace_bytes, pn_stream_t stream);
+/* order_out = order_in with every voxel run sorted by ascending point index (out of place).  Only
+ * the PFN backward (pn_dynamic_pfn_bwd) depends on the order inside a run -- through floating-point
+ * summation order -- so a training step that must be bit-reproducible sorts the runs first. */
+int pn_sort_voxel_runs(const int32_t *voxel_start, const int32_t *num_voxels, int voxel_capacity,
+                       const int32_t *order_in, int32_t *order_out, pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * V2  hard voxelization (first-come voxel ids, <= max_points points per voxel in point order,

@@ -436,6 +436,33 @@ int pn_bucket_points(const int32_t* unq_inv, const int32_t* unq_cnt, int n_capac
   return pn::check_launch("bucket_points");
 }
 
+// Optional canonical order inside every voxel run: ascending point index.  The forward consumers are order independent
+// (fixed-point means, maxima); the PFN BACKWARD sums per-point products in run order, so bit-reproducible training sorts
+// the runs once per iteration.  One wave per run, rank sort (the point indices of a run are distinct).
+__global__ __launch_bounds__(256) void sort_runs_kernel(const int32_t* __restrict__ voxel_start, const int32_t* __restrict__ v_dev,
+                                                        int v_cap, const int32_t* __restrict__ in, int32_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int V = min(*v_dev, v_cap);
+  for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < V; v += gridDim.x * 4) {
+    const int s = voxel_start[v], n = voxel_start[v + 1] - s;
+    for (int i = lane; i < n; i += 64) {
+      const int32_t e = in[s + i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += in[s + j] < e;
+      out[s + rank] = e;
+    }
+  }
+}
+
+int pn_sort_voxel_runs(const int32_t* voxel_start, const int32_t* num_voxels, int voxel_capacity, const int32_t* order_in,
+                       int32_t* order_out, pn_stream_t stream) {
+  PN_REQUIRE(voxel_start && num_voxels && order_in && order_out && order_in != order_out, "sort_voxel_runs: bad pointers");
+  if (voxel_capacity <= 0) return PN_OK;
+  hipLaunchKernelGGL(sort_runs_kernel, dim3(std::min(2048, pn::cdiv(voxel_capacity, 4))), dim3(256), 0, pn::S(stream), voxel_start,
+                     num_voxels, voxel_capacity, order_in, order_out);
+  return pn::check_launch("sort_runs_kernel");
+}
+
 
 size_t pn_hard_voxelize_workspace_bytes(uint64_t num_cells, int n, int max_points) {
   // unique workspace + inv + cnt + first + flag + vid_at + tiles + sel[max_points][n] + nv

@@ -286,7 +286,33 @@ class CenterHeadSingle(CenterHead):
                     shared_gn=(rs.num_heads, rs.num_groups, rs.groupnorm.weight.detach(), rs.groupnorm.bias.detach(),
                                rs.groupnorm.eps),
                     branches={name: self._branch_plan(getattr(self, name)) for name in self.heads})
+        plan["merged"] = self._merge_branches(plan["branches"])
         return plan
+
+    def _merge_branches(self, branches):
+        """Branches conv3x3(64->64) + per-channel GroupNorm + ReLU + conv that read the same shared map (everything but
+        'hm' and the stratified 'reg') are run pairwise as ONE 64->128 convolution + ONE 128-channel GroupNorm; the
+        final convolutions then read their half of the 128-channel map.  Same arithmetic per output channel (the
+        normalisation is per channel), half the launches and a full 128-column MFMA tile instead of two of 64."""
+        cands = []
+        for name, steps in branches.items():
+            if name == "hm" or len(steps) != 3 or steps[0][0] != "conv" or steps[1][0] != "gn" or steps[2][0] != "conv":
+                continue
+            fc = [m for m in getattr(self, name)._modules.values()]
+            conv, gn = fc[0], fc[1]
+            if not (isinstance(conv, nn.Conv2d) and conv.groups == 1 and isinstance(gn, nn.GroupNorm) and gn.num_groups == gn.num_channels):
+                continue
+            cands.append((name, conv, gn, steps[2][1]))
+        merged = []
+        for i in range(0, len(cands) - 1, 2):
+            (na, ca, ga, fa), (nb, cb, gb, fb) = cands[i], cands[i + 1]
+            if ca.weight.shape != cb.weight.shape or ga.eps != gb.eps:
+                continue
+            conv = ops.ConvLayer(torch.cat([ca.weight, cb.weight], 0), stride=1, pad=ca.padding[0],
+                                 shift=torch.cat([ca.bias, cb.bias], 0).detach(), act=ops.ACT_NONE)
+            gn = (ga.num_groups + gb.num_groups, 1, torch.cat([ga.weight, gb.weight]).detach(), torch.cat([ga.bias, gb.bias]).detach(), ga.eps)
+            merged.append(dict(names=(na, nb), conv=conv, gn=gn, finals=(fa, fb), split=ca.weight.shape[0]))
+        return merged
 
     @staticmethod
     def _run_branch(steps, x):
@@ -312,8 +338,14 @@ class CenterHeadSingle(CenterHead):
         else:
             xs = x_hm = ops.groupnorm_strat(raw, cg, st, ga, be, eps, act=ops.ACT_RELU)
         ret = {}
+        outs = {}
+        for mg in plan["merged"]:
+            cg, st, ga, be, eps = mg["gn"]
+            h = ops.groupnorm_strat(mg["conv"](xs), cg, st, ga, be, eps, act=ops.ACT_RELU)
+            for j, (name, final) in enumerate(zip(mg["names"], mg["finals"])):
+                outs[name] = final(h, in_channel_offset=j * mg["split"])
         for name, steps in plan["branches"].items():
-            y = ops.as_nchw(self._run_branch(steps, x_hm if name == "hm" else xs))
+            y = ops.as_nchw(outs[name] if name in outs else self._run_branch(steps, x_hm if name == "hm" else xs))
             if "_" in name:
                 names = name.split("_")
                 dim = y.shape[1] // len(names)

@@ -128,7 +128,9 @@ class VoxelIndex:
 
 
 def build_voxel_index(keys: torch.Tensor, spec: GridSpec, batch: int, n_dev: Optional[torch.Tensor] = None,
-                      want_unq=True) -> VoxelIndex:
+                      want_unq=True, sorted_runs=False) -> VoxelIndex:
+    """``sorted_runs``: points of a voxel in ascending index order (bit-reproducible PFN backward); otherwise the
+    order inside a voxel is unspecified, which no forward kernel depends on."""
     hip.require_device(keys)
     lib = hip.load()
     dev = keys.device
@@ -150,6 +152,9 @@ def build_voxel_index(keys: torch.Tensor, spec: GridSpec, batch: int, n_dev: Opt
     order = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
     hip.call("pn_bucket_points", inv.data_ptr(), cnt.data_ptr(), n, hip.ptr(n_dev), nv.data_ptr(), vstart.data_ptr(),
              order.data_ptr(), bws.data_ptr(), bws_bytes, st)
+    if sorted_runs and n > 0:
+        raw, order = order, torch.empty_like(order)
+        hip.call("pn_sort_voxel_runs", vstart.data_ptr(), nv.data_ptr(), n, raw.data_ptr(), order.data_ptr(), st)
     kp = lib.pn_unique_keys_ptr(ws.data_ptr(), cells, n)
     return VoxelIndex(n, cells, spec, batch, unq, inv, cnt, nv, vstart, order, ws, kp)
 

@@ -351,7 +351,7 @@ class PolarPillarTrainStep:
         else:
             keys = ops.keys_from_grid_ind(grid_ind.to(torch.int64).contiguous(), spec, batch)
             n_dev = None
-        self.vi = ops.build_voxel_index(keys, spec, batch, n_dev=n_dev, want_unq=False)
+        self.vi = ops.build_voxel_index(keys, spec, batch, n_dev=n_dev, want_unq=False, sorted_runs=True)
         self.points = points
         canvas = torch.empty((batch, spec.grid[1], spec.grid[0], self.reader.out_channels), dtype=torch.float32, device=self.dev)
         hip.call("pn_fill_zero", canvas.data_ptr(), canvas.numel() * 4, hip.stream())
