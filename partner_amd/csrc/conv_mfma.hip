@@ -554,7 +554,7 @@ __global__ void conv_direct_kernel(ConvArgs a, const float* __restrict__ w_oihw,
 // 18 steps: 19 us for 0.2 GFLOP).  Here one block = 64 output pixels x 4 waves; wave q owns a quarter of the input
 // channels, lane = pixel, the weights of the wave's channels are wave-uniform (scalar loads feeding v_fmac), the four
 // partial sums meet in LDS.  1024 waves for a 128 x 128 map, ~2300 FMAs each.
-constexpr int kSmallN = 16;
+constexpr int kSmallN = 8;    // 10 .. 16 columns measured slower than the 64 x 32 MFMA tile inside a frame (32 vs 19 us)
 
 template <int NOUT, int TAPS>
 __global__ __launch_bounds__(256) void conv_small_n_kernel(ConvArgs a) {
@@ -622,9 +622,7 @@ template <int TAPS>
 void launch_small_n(const ConvArgs& a, int zdim, hipStream_t st) {
   const dim3 grid(pn::cdiv(a.M, 64), zdim);
   if (a.ncols <= 4) hipLaunchKernelGGL((conv_small_n_kernel<4, TAPS>), grid, dim3(256), 0, st, a);
-  else if (a.ncols <= 8) hipLaunchKernelGGL((conv_small_n_kernel<8, TAPS>), grid, dim3(256), 0, st, a);
-  else if (a.ncols <= 12) hipLaunchKernelGGL((conv_small_n_kernel<12, TAPS>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_small_n_kernel<16, TAPS>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_small_n_kernel<8, TAPS>), grid, dim3(256), 0, st, a);
 }
 
 template <int WM, int WN, int TM, int TN, int DT = DT_F32, bool GATHER = false>

@@ -128,6 +128,39 @@ def test_full_c2_model(dev, golden):
     assert rel_err(ops.as_nchw(x2)[:, :, ::8, ::8], g["x2_s8"]) < REL
 
 
+def test_full_size_properties_300k_points(dev):
+    """BASELINE configs[4] size (300k-point frames), where the oracle is too slow to be the checker: properties that hold
+    for the reference's arithmetic independent of size.
+    (1) point-order invariance: pillar means are exact fixed-point sums and the pillar feature is a maximum, so any
+        permutation of the input points gives BIT-identical head tensors;
+    (2) batch independence (eval BatchNorm, per-sample GroupNorm): a frame run inside a batch of two equals the frame alone;
+    (3) every point given twice: the pillar means (2S / 2n in fixed point) and the maxima are unchanged, so are the bits."""
+    m = build(detector_cfg(synth.NUSC_RANGE, synth.NUSC_VOXEL), 0, dev)
+    n = 300000
+    a = torch.from_numpy(synth.synth_sweep_polar(n, seed=21)).to(dev)
+    b = torch.from_numpy(synth.synth_sweep_polar(n, seed=22)).to(dev)
+    offs1 = torch.tensor([0, n], dtype=torch.int32, device=dev)
+    keys = ("reg", "rot", "vel", "height", "dim", "hm")
+    pa = {k: v.clone() for k, v in m.forward_points(a, offs1, 1).items()}
+    # (1) permutation
+    perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    pp = m.forward_points(a[perm].contiguous(), offs1, 1)
+    for k in keys:
+        assert torch.equal(pa[k], pp[k]), k
+    # (2) batch of two
+    offs2 = torch.tensor([0, n, 2 * n], dtype=torch.int32, device=dev)
+    pab = m.forward_points(torch.cat([a, b]), offs2, 2)
+    pb = m.forward_points(b, offs1, 1)
+    for k in keys:
+        assert rel_err(pab[k][0:1], pa[k].cpu().numpy()) < 1e-5, k
+        assert rel_err(pab[k][1:2], pb[k].cpu().numpy()) < 1e-5, k
+    # (3) every point twice
+    dup = torch.cat([a, a])
+    pd = m.forward_points(dup, torch.tensor([0, dup.shape[0]], dtype=torch.int32, device=dev), 1)
+    for k in keys:
+        assert torch.equal(pa[k], pd[k]), k
+
+
 def test_center_head_plain_and_single(dev, golden):
     import partner_amd as P
     g = golden("heads.npz")

@@ -250,7 +250,7 @@ def _conv_case(dev, b, cin, cout, h, w, k, stride, pad, groups=1, act=0, seed=0,
     dict(b=1, cin=32, cout=2, h=128, w=128, k=3, stride=1, pad=1, groups=2, act=2, bn=False),
     dict(b=1, cin=64, cout=2, h=128, w=128, k=1, stride=1, pad=0, act=0, bn=False),
     dict(b=1, cin=20, cout=7, h=64, w=80, k=3, stride=1, pad=1, act=1),           # ragged channel quarters
-    dict(b=1, cin=64, cout=16, h=64, w=64, k=3, stride=2, pad=1, act=1),
+    dict(b=1, cin=64, cout=8, h=128, w=128, k=3, stride=2, pad=1, act=1),
 ])
 def test_conv_mfma(dev, case):
     import zlib
