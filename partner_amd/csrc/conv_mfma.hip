@@ -101,18 +101,25 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
 
   // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so give each XCD a
   // contiguous run of m tiles (neighbouring tiles share halo rows in that XCD's L2).
+  // Gather mode: the grid is sized by the site CAPACITY, the live sites are the first *n_valid rows -- deal only the live
+  // tiles over the XCDs (dealing all capacity tiles would put every live one on the first XCD or two).
   int mt;
+  int m_valid = a.M;
   {
-    const int bid = blockIdx.x, q = a.nmt >> 3, r = a.nmt & 7, x = bid & 7;
-    mt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    int nmt = a.nmt;
+    if constexpr (GATHER) {
+      m_valid = min(a.M, *a.n_valid);
+      nmt = (m_valid + BM - 1) / BM;
+    }
+    const int bid = blockIdx.x, q = nmt >> 3, r = nmt & 7, x = bid & 7, idx = bid >> 3;
+    if (GATHER && idx >= (x < r ? q + 1 : q)) return;  // block uniform, before any barrier
+    mt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
   }
   const int m0 = mt * BM;
   const int n0 = blockIdx.y * BN;
-  int m_valid = a.M;
   int* nbr_s = reinterpret_cast<int*>(smem + 2 * STAGE);  // gather mode: this block's [BM][taps] neighbour rows
   if constexpr (GATHER) {
-    m_valid = min(a.M, *a.n_valid);
-    if (m0 >= m_valid) return;  // block uniform, before any barrier
+    if (m0 >= m_valid) return;
     const int tps = a.KH * a.KW;
     for (int i = tid; i < BM * tps; i += NT) {
       const int m = m0 + i / tps;
