@@ -42,6 +42,39 @@ for i in range(220):
 lat = np.sort(np.array(lat))
 print(f"C5  300k-pt frame, hipGraph, 1 stream: latency p50 {lat[len(lat)//2]:.3f} ms  p99 {lat[int(len(lat)*0.99)]:.3f} ms  ({1e3/lat[len(lat)//2]:.0f} frames/s)")
 
+# ---- scatter stage alone (V0..V5: cart->polar, grid index, unique-rank, bucket, PFN, canvas) on the config grid and on the
+#      BASELINE.json synthetic grid (0.3125 m x 0.05 rad: R=160, Theta=126); algorithmic bytes per SURVEY 8(d):
+#      N*F*4 + V*4*8 + V*C*4 + B*C*Theta*R*4 (grid indices computed in-kernel)
+def scatter_row(tag, rng_, vs):
+    cfg = bench.c2_model_cfg()
+    cfg["reader"].update(voxel_size=list(vs), pc_range=list(rng_))
+    # (the head is not run here and keeps the config grid's position encoding)
+    ms = P.build_detector(cfg); synth.load_filled(ms, 0); ms = ms.to(dev).eval()
+    spec = ops.GridSpec.from_range(rng_, vs)
+    cart = torch.from_numpy(synth.synth_sweep_cart(30000, seed=5)).to(dev)
+    offs = torch.tensor([0, 30000], dtype=torch.int32, device=dev)
+    def run():
+        polar = ops.cart_to_polar(cart)
+        _, keys = ops.grid_index(polar, offs, 1, spec, want_grid_ind=False)
+        return ms.encode_canvas(polar, keys, spec, 1, n_dev=offs[1:])
+    g = torch.cuda.CUDAGraph()
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        run()
+    t = timeit(g.replay, n=200, warm=20)
+    polar = ops.cart_to_polar(cart)
+    _, keys = ops.grid_index(polar, offs, 1, spec, want_grid_ind=False)
+    V = ops.build_voxel_index(keys, spec, 1).count()
+    C_ = ms.reader.out_channels
+    nbytes = 30000 * 7 * 4 + V * 4 * 8 + V * C_ * 4 + C_ * spec.grid[0] * spec.grid[1] * 4
+    print(f"C2  scatter stage, {tag} grid {spec.grid[0]} x {spec.grid[1]}: {t * 1e3:.1f} us per 30k-pt sweep (hipGraph), V = {V}, "
+          f"{nbytes / 1e6:.1f} MB algorithmic -> {nbytes / t / 1e6:.0f} GB/s ({nbytes / t / 1e6 / 8000:.3f} of 8 TB/s)")
+
+scatter_row("config", synth.NUSC_RANGE, synth.NUSC_VOXEL)
+scatter_row("BASELINE synthetic", synth.COARSE_RANGE, synth.COARSE_VOXEL)
+
 # ---- C4 stages
 sw = torch.from_numpy(synth.synth_sweep_polar(180000, seed=0, rho_max=74.0)).to(dev)
 vg = VoxelGenerator(synth.WAYMO_VOXEL, synth.WAYMO_RANGE, 5, 150000)
