@@ -215,6 +215,12 @@ int pn_scatter_canvas_fwd(const float *features, const int64_t *unq, const int32
                           int v_capacity, int c, int t, int r, float *canvas, pn_stream_t stream);
 
 int pn_fill_zero(void *ptr, size_t bytes, pn_stream_t stream);
+/* Sparse clear: zero the canvas cells of the voxels in unq_keys (the cells pn_dynamic_pfn_fwd wrote).
+ * A frame engine that owns a persistent canvas (zero between frames) calls this after the first
+ * convolution has consumed the canvas instead of re-filling the whole map (134 MB for the
+ * nuScenes grid) before every frame.  grid = {R, T, Z} as for the PFN. */
+int pn_clear_canvas_cells(const uint32_t *unq_keys, const int32_t *num_voxels, int v_capacity,
+                          const int32_t *grid, int c, float *canvas, pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * B1 / H*  2-D convolution on the BEV map as an implicit GEMM on fp32 MFMA

@@ -186,10 +186,22 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
 constexpr int kHeavyPillar = 64;  // pillars with more points than this take the block-per-pillar kernel
 constexpr int kHeavyWaves = 8;
 
+constexpr int kFwdBatch = 64;    // pillars per block and round
+constexpr int kFwdPoints = 1024; // point rows staged in LDS per sub-batch (>= kHeavyPillar, so any non-heavy pillar fits)
+
+// A wave walking alone through vstart -> order -> point pays three dependent memory latencies per pillar and per point
+// (two waves per SIMD: little to switch to), which was all of this kernel's time.  The block therefore takes a batch of
+// consecutive pillars -- their points are one consecutive range of order[] -- and stages run bounds, keys and the point
+// rows in LDS with all 256 threads loading in parallel (three latencies per BATCH); each wave then works through its
+// share of the pillars from LDS.  A batch whose points exceed the LDS rows is cut into sub-batches at pillar boundaries.
 __global__ __launch_bounds__(256) void dynamic_pfn_32_128_kernel(PfnArgs a, const float* __restrict__ cs_table) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  constexpr int NB = kFwdBatch, CAP = kFwdPoints;
+  static_assert(CAP >= kHeavyPillar, "a non-heavy pillar must fit the staging rows");
+  __shared__ int m_s[NB], m_e[NB];
+  __shared__ uint32_t m_key[NB];
+  __shared__ __attribute__((aligned(16))) float m_c[NB][12];  // per pillar: mx my mz mr mp rc pc xc yc, canvas cell (int bits)
+  __shared__ __attribute__((aligned(16))) float p_l[CAP][8];
+  const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
   const int V = min(*a.v_dev, a.v_cap);
   float w0[16], w1a[64], w1b[64];
 #pragma unroll
@@ -199,80 +211,126 @@ __global__ __launch_bounds__(256) void dynamic_pfn_32_128_kernel(PfnArgs a, cons
     w1a[k] = a.w1[lane * 64 + k];
     w1b[k] = a.w1[(lane + 64) * 64 + k];
   }
-  int n_s = 0, n_e = 0;
-  uint32_t n_key = 0;
-  if (wave < V) { n_s = a.vstart[wave]; n_e = a.vstart[wave + 1]; n_key = a.ukeys[wave]; }
-  for (int v = wave; v < V; v += nwaves) {
-    const int s = n_s, e = n_e;
-    uint32_t key = n_key;
-    if (v + nwaves < V) { n_s = a.vstart[v + nwaves]; n_e = a.vstart[v + nwaves + 1]; n_key = a.ukeys[v + nwaves]; }
-    if (e - s > kHeavyPillar) continue;  // dynamic_pfn_32_128_heavy_kernel spreads those over a whole block
-    const int ri = key % a.R; key /= a.R;
-    const int ti = key % a.T; key /= a.T;
-    const int bi = key / a.Z;
-    float mx, my, mz, mr, mp;
-    if (e - s == 1) {  // single-point pillar: the fixed-point mean of one value (same rounding as the general path)
-      const float* p = a.pts + (size_t)a.order[s] * a.stride;
-      mr = (float)((double)to_fix(p[0]) / kFix); mp = (float)((double)to_fix(p[1]) / kFix); mz = (float)((double)to_fix(p[2]) / kFix);
-      mx = (float)((double)to_fix(p[3]) / kFix); my = (float)((double)to_fix(p[4]) / kFix);
-    } else {
-      long long sx = 0, sy = 0, sz = 0, sr = 0, sp = 0;
-      for (int i = s + lane; i < e; i += 64) {
-        const float* p = a.pts + (size_t)a.order[i] * a.stride;
-        sr += to_fix(p[0]); sp += to_fix(p[1]); sz += to_fix(p[2]); sx += to_fix(p[3]); sy += to_fix(p[4]);
+  for (int v0 = blockIdx.x * NB; v0 < V; v0 += gridDim.x * NB) {
+    const int nb = min(NB, V - v0);
+    __syncthreads();  // the previous batch has been consumed
+    if (tid < nb) {
+      m_s[tid] = a.vstart[v0 + tid];
+      m_e[tid] = a.vstart[v0 + tid + 1];
+      m_key[tid] = a.ukeys[v0 + tid];
+    }
+    __syncthreads();
+    int q0 = 0;
+    while (q0 < nb) {  // block-uniform
+      const int base = m_s[q0];
+      if (m_e[q0] - base > kHeavyPillar) { ++q0; continue; }  // dynamic_pfn_32_128_heavy_kernel spreads those over a whole block
+      int q1 = q0 + 1;
+      while (q1 < nb && m_e[q1] - m_s[q1] <= kHeavyPillar && m_e[q1] - base <= CAP) ++q1;
+      const int npts = m_e[q1 - 1] - base;
+      for (int t = tid; t < npts; t += 256) {
+        const float* src = a.pts + (size_t)a.order[base + t] * a.stride;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) p_l[t][k] = src[k];
       }
-      const double inv_n = 1.0 / ((double)(e - s) * kFix);
-      mx = (float)((double)pn::wave_sum(sx) * inv_n); my = (float)((double)pn::wave_sum(sy) * inv_n);
-      mz = (float)((double)pn::wave_sum(sz) * inv_n); mr = (float)((double)pn::wave_sum(sr) * inv_n);
-      mp = (float)((double)pn::wave_sum(sp) * inv_n);
-    }
-    const float rc = __fadd_rn(__fmul_rn((float)ri, a.vx), a.xoff);
-    const float pc = __fadd_rn(__fmul_rn((float)ti, a.vy), a.yoff);
-    const float xc = __fmul_rn(rc, cs_table[2 * ti]), yc = __fmul_rn(rc, cs_table[2 * ti + 1]);
-    auto layer0 = [&](const float* p) -> float {
-      const float rho = p[0], phi = p[1], z = p[2], x = p[3], y = p[4];
-      const float d[16] = {rho, phi, z, x, y, p[5], p[6], x - mx, y - my, z - mz, x - xc, y - yc,
-                           rho - mr, phi - mp, rho - rc, phi - pc};
-      float h = 0.f;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) h = fmaf(w0[k], d[k], h);
-      return h > 0.f ? h : 0.f;  // lanes >= 32 carry zeros (their w0 is zero)
-    };
-    float m0 = 0.f;
-    float h_first = 0.f;
-    for (int i = s; i < e; ++i) {
-      const float h = layer0(a.pts + (size_t)a.order[i] * a.stride);
-      if (i == s) h_first = h;
-      m0 = fmaxf(m0, h);
-    }
-    float g0 = 0.f, g1 = 0.f;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      const float m = lane_bcast(m0, c);
-      g0 = fmaf(w1a[32 + c], m, g0);
-      g1 = fmaf(w1b[32 + c], m, g1);
-    }
-    float f0 = 0.f, f1 = 0.f;
-    for (int i = s; i < e; ++i) {
-      const float h = (i == s) ? h_first : layer0(a.pts + (size_t)a.order[i] * a.stride);
-      float y0 = g0, y1 = g1;
-#pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        const float hc = lane_bcast(h, c);
-        y0 = fmaf(w1a[c], hc, y0);
-        y1 = fmaf(w1b[c], hc, y1);
+      __syncthreads();
+      // per-pillar scalars, one THREAD per pillar (the whole batch in one pass of wave instructions instead of one pass
+      // per pillar): key decode, cell centre, exact fixed-point means
+      if (q0 + tid < q1) {
+        const int q = q0 + tid;
+        uint32_t key = m_key[q];
+        const int ri = key % a.R; key /= a.R;
+        const int ti = key % a.T; key /= a.T;
+        const int bi = key / a.Z;
+        const int s = m_s[q] - base, e = m_e[q] - base;
+        long long sx = 0, sy = 0, sz = 0, sr = 0, sp = 0;
+        for (int i = s; i < e; ++i) {
+          const float* p = p_l[i];
+          sr += to_fix(p[0]); sp += to_fix(p[1]); sz += to_fix(p[2]); sx += to_fix(p[3]); sy += to_fix(p[4]);
+        }
+        const double inv_n = 1.0 / ((double)(e - s) * kFix);
+        float* c = m_c[q];
+        c[0] = (float)((double)sx * inv_n); c[1] = (float)((double)sy * inv_n); c[2] = (float)((double)sz * inv_n);
+        c[3] = (float)((double)sr * inv_n); c[4] = (float)((double)sp * inv_n);
+        const float rc = __fadd_rn(__fmul_rn((float)ri, a.vx), a.xoff);
+        c[5] = rc;
+        c[6] = __fadd_rn(__fmul_rn((float)ti, a.vy), a.yoff);
+        c[7] = __fmul_rn(rc, cs_table[2 * ti]);
+        c[8] = __fmul_rn(rc, cs_table[2 * ti + 1]);
+        c[9] = __builtin_bit_cast(float, (bi * a.T + ti) * a.R + ri);
       }
-      f0 = fmaxf(f0, y0);
-      f1 = fmaxf(f1, y1);
-    }
-    if (a.feat) {
-      a.feat[(size_t)v * 128 + lane] = f0;
-      a.feat[(size_t)v * 128 + lane + 64] = f1;
-    }
-    if (a.canvas) {
-      float* cv = a.canvas + (((size_t)bi * a.T + ti) * a.R + ri) * 128;
-      cv[lane] = f0;
-      cv[lane + 64] = f1;
+      __syncthreads();
+      for (int q = q0 + wib; q < q1; q += 4) {
+        const int v = v0 + q;
+        const int s = m_s[q] - base, e = m_e[q] - base;
+        const float* c = m_c[q];
+        const float mx = c[0], my = c[1], mz = c[2], mr = c[3], mp = c[4], rc = c[5], pc = c[6], xc = c[7], yc = c[8];
+        const int cell = __builtin_bit_cast(int, c[9]);
+        auto layer0 = [&](const float* p) -> float {
+          const float rho = p[0], phi = p[1], z = p[2], x = p[3], y = p[4];
+          const float d[16] = {rho, phi, z, x, y, p[5], p[6], x - mx, y - my, z - mz, x - xc, y - yc,
+                               rho - mr, phi - mp, rho - rc, phi - pc};
+          float h = 0.f;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) h = fmaf(w0[k], d[k], h);
+          return h > 0.f ? h : 0.f;  // lanes >= 32 carry zeros (their w0 is zero)
+        };
+        float m0 = 0.f;
+        float h_first = 0.f;
+        for (int i = s; i < e; ++i) {
+          const float h = layer0(p_l[i]);
+          if (i == s) h_first = h;
+          m0 = fmaxf(m0, h);
+        }
+        float g0 = 0.f, g1 = 0.f;
+        float f0 = 0.f, f1 = 0.f;
+        if (e - s == 1) {  // one point (most pillars of a single sweep): maximum == the point, one broadcast serves both halves
+          float hb[32];
+#pragma unroll
+          for (int k = 0; k < 32; ++k) hb[k] = lane_bcast(h_first, k);
+#pragma unroll
+          for (int k = 0; k < 32; ++k) {
+            g0 = fmaf(w1a[32 + k], hb[k], g0);
+            g1 = fmaf(w1b[32 + k], hb[k], g1);
+          }
+#pragma unroll
+          for (int k = 0; k < 32; ++k) {
+            g0 = fmaf(w1a[k], hb[k], g0);
+            g1 = fmaf(w1b[k], hb[k], g1);
+          }
+          f0 = fmaxf(0.f, g0);
+          f1 = fmaxf(0.f, g1);
+        } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          const float m = lane_bcast(m0, k);
+          g0 = fmaf(w1a[32 + k], m, g0);
+          g1 = fmaf(w1b[32 + k], m, g1);
+        }
+        for (int i = s; i < e; ++i) {
+          const float h = (i == s) ? h_first : layer0(p_l[i]);
+          float y0 = g0, y1 = g1;
+#pragma unroll
+          for (int k = 0; k < 32; ++k) {
+            const float hc = lane_bcast(h, k);
+            y0 = fmaf(w1a[k], hc, y0);
+            y1 = fmaf(w1b[k], hc, y1);
+          }
+          f0 = fmaxf(f0, y0);
+          f1 = fmaxf(f1, y1);
+        }
+        }
+        if (a.feat) {
+          a.feat[(size_t)v * 128 + lane] = f0;
+          a.feat[(size_t)v * 128 + lane + 64] = f1;
+        }
+        if (a.canvas) {
+          float* cv = a.canvas + (size_t)cell * 128;
+          cv[lane] = f0;
+          cv[lane + 64] = f1;
+        }
+      }
+      q0 = q1;
+      if (q0 < nb) __syncthreads();  // the staged rows are rewritten by the next sub-batch
     }
   }
 }
@@ -697,9 +755,35 @@ __global__ void scatter_canvas_kernel(const float* __restrict__ feat, const int6
   }
 }
 
+// zero the canvas cells of the given voxel keys: 16 bytes per thread, c / 4 threads per cell
+__global__ void clear_canvas_cells_kernel(const uint32_t* __restrict__ ukeys, const int32_t* __restrict__ v_dev, int v_cap, int c4,
+                                          int Z, int T, int R, float* __restrict__ canvas) {
+  const int V = min(*v_dev, v_cap);
+  const size_t total = (size_t)V * c4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i / c4), k = (int)(i - (size_t)v * c4);
+    uint32_t key = ukeys[v];
+    const int ri = key % R; key /= R;
+    const int ti = key % T; key /= T;
+    const int bi = key / Z;
+    reinterpret_cast<float4*>(canvas)[(((size_t)bi * T + ti) * R + ri) * c4 + k] = float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pn_clear_canvas_cells(const uint32_t* unq_keys, const int32_t* num_voxels, int v_capacity, const int32_t* grid, int c,
+                          float* canvas, pn_stream_t stream) {
+  PN_REQUIRE(unq_keys && num_voxels && grid && canvas && c >= 4 && c % 4 == 0, "clear_canvas_cells: bad arguments");
+  PN_REQUIRE(((uintptr_t)canvas & 15) == 0, "clear_canvas_cells: canvas must be 16-byte aligned");
+  if (v_capacity == 0) return PN_OK;
+  const size_t total = (size_t)v_capacity * (c / 4);
+  hipLaunchKernelGGL(clear_canvas_cells_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, pn::S(stream),
+                     unq_keys, num_voxels, v_capacity, c / 4, grid[2], grid[1], grid[0], canvas);
+  return pn::check_launch("clear_canvas_cells_kernel");
+}
 
 int pn_scatter_mean_f32(const float* points, int point_stride, int f, const int32_t* voxel_start, const int32_t* order,
                         const int32_t* num_voxels, int v_capacity, float* mean, pn_stream_t stream) {
@@ -766,7 +850,7 @@ int pn_dynamic_pfn_fwd_table(const float* points, int point_stride, const int32_
   if (v_capacity == 0) return PN_OK;
   PfnArgs a{points, point_stride, voxel_start, order, num_voxels, v_capacity, unq_keys, grid[0], grid[1], grid[2],
             w0, c0, w1, c1, vx, vy, x_offset, y_offset, features, canvas};
-  const int blocks = std::max(1, std::min(512, pn::cdiv(v_capacity, 4 * 2)));  // persistent: 2 waves per SIMD, weights loaded once per wave
+  const int blocks = std::max(1, std::min(512, pn::cdiv(v_capacity, kFwdBatch)));  // persistent: 2 waves per SIMD, weights loaded once per wave
   hipLaunchKernelGGL(dynamic_pfn_32_128_kernel, dim3(blocks), dim3(256), 0, pn::S(stream), a, center_table);
   if (int rc = pn::check_launch("dynamic_pfn_32_128_kernel")) return rc;
   // at most n / kHeavyPillar pillars can be heavy; the blocks find them by scanning voxel_start

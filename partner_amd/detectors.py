@@ -63,26 +63,45 @@ class PointPillars(SingleStageDetector):
 
     # -- fused device-side chain --------------------------------------------------------------
     def encode_canvas(self, points: torch.Tensor, keys: torch.Tensor, spec: ops.GridSpec, batch: int,
-                      n_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """points (N,7) + linear voxel keys -> NHWC canvas (B, T, R, C); no host sync"""
+                      n_dev: Optional[torch.Tensor] = None, canvas: Optional[torch.Tensor] = None, return_index=False):
+        """points (N,7) + linear voxel keys -> NHWC canvas (B, T, R, C); no host sync.
+        ``canvas``: a persistent all-zero map to write into (see ``forward_points``); otherwise a fresh zero-filled one."""
         if not isinstance(self.reader, DynamicPFNet):
             raise NotImplementedError("fused encode path needs a DynamicPFNet reader")
         vi = ops.build_voxel_index(keys, spec, batch, n_dev=n_dev, want_unq=False)
-        canvas = torch.empty((batch, spec.grid[1], spec.grid[0], self.reader.out_channels), dtype=torch.float32,
-                             device=points.device)
-        hip.call("pn_fill_zero", canvas.data_ptr(), canvas.numel() * 4, hip.stream())
+        shape = (batch, spec.grid[1], spec.grid[0], self.reader.out_channels)
+        if canvas is None:
+            canvas = torch.empty(shape, dtype=torch.float32, device=points.device)
+            hip.call("pn_fill_zero", canvas.data_ptr(), canvas.numel() * 4, hip.stream())
+        else:
+            hip.require_device(canvas)
+            assert tuple(canvas.shape) == shape and canvas.is_contiguous() and canvas.dtype == torch.float32
         self.reader.encode(points, vi, None, canvas)
-        return canvas
+        return (canvas, vi) if return_index else canvas
+
+    def new_canvas(self, batch: int, spec: Optional[ops.GridSpec] = None, device=None) -> torch.Tensor:
+        """a zeroed persistent canvas for ``forward_points(..., canvas=)``"""
+        spec = spec or ops.GridSpec.from_range(self.reader.pc_range, self.reader.voxel_size)
+        device = device or next(self.parameters()).device
+        return torch.zeros((batch, spec.grid[1], spec.grid[0], self.reader.out_channels), dtype=torch.float32, device=device)
 
     def forward_points(self, points: torch.Tensor, sample_offsets: torch.Tensor, batch: int,
-                       spec: Optional[ops.GridSpec] = None) -> Dict[str, torch.Tensor]:
+                       spec: Optional[ops.GridSpec] = None, canvas: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """Hot path from polar-decorated points: grid indices are computed on the device (V1).
-        points (N,7) [rho,phi,z,x,y,i,t]; sample_offsets int32 (batch+1).  -> head tensors."""
+        points (N,7) [rho,phi,z,x,y,i,t]; sample_offsets int32 (batch+1).  -> head tensors.
+        ``canvas``: a persistent map owned by the caller (``new_canvas``), all zero on entry; the frame's pillars are
+        written into it and their cells are cleared again once the backbone has consumed it (a sparse clear of ~28k
+        cells instead of a 134 MB fill per frame) -- all zero on exit."""
         eval_only(self, "PointPillars")
         spec = spec or ops.GridSpec.from_range(self.reader.pc_range, self.reader.voxel_size)
         _, keys = ops.grid_index(points, sample_offsets, batch, spec, want_grid_ind=False)
-        canvas = self.encode_canvas(points, keys, spec, batch, n_dev=sample_offsets[batch:])
-        x2 = self.neck.forward_nhwc(canvas)
+        if canvas is None:
+            cv = self.encode_canvas(points, keys, spec, batch, n_dev=sample_offsets[batch:])
+            x2 = self.neck.forward_nhwc(cv)
+        else:
+            cv, vi = self.encode_canvas(points, keys, spec, batch, n_dev=sample_offsets[batch:], canvas=canvas, return_index=True)
+            x2 = self.neck.forward_nhwc(cv)
+            ops.clear_canvas_cells(cv, vi)
         return self.bbox_head(ops.as_nchw(x2))["det_preds"][0]
 
     def extract_preds(self, example) -> Dict[str, object]:

@@ -31,13 +31,15 @@ class FrameEngine:
         self.offsets = torch.tensor([points_per_sweep * b for b in range(batch + 1)], dtype=torch.int32, device=dev)
         self.graph = None
         self.outputs: Dict[str, torch.Tensor] = {}
+        # persistent BEV canvas of this engine: zero between frames, the frame's cells are cleared after use
+        self.canvas = None if hasattr(model, "attns") else model.new_canvas(batch, self.spec, dev)
 
     def _step(self):
         polar = ops.cart_to_polar(self.cart)
         if hasattr(self.model, "attns"):   # VoxelNetV3 (Waymo PARTNER config): single-sample hard-voxel path
             assert self.batch == 1, "the fused VoxelNetV3 path takes one sample per frame"
             return self.model.forward_points(polar)
-        return self.model.forward_points(polar, self.offsets, self.batch, self.spec)
+        return self.model.forward_points(polar, self.offsets, self.batch, self.spec, canvas=self.canvas)
 
     def capture(self, warmup: int = 3, stream: "torch.cuda.Stream" = None) -> "FrameEngine":
         """capture the frame into a HIP graph; `stream` (optional) is the stream the graph will be
@@ -94,13 +96,14 @@ class StreamingFrameEngine:
         self.transforms = torch.from_numpy(mats).to(dev)
         self.time_lags = torch.from_numpy(lags).to(dev)
         self.offsets = torch.zeros(2, dtype=torch.int32, device=dev)   # [0, number of accumulated points]: written by the accumulation kernel
+        self.canvas = model.new_canvas(1, self.spec, dev)               # persistent, zero between frames
         self.graph = None
         self.outputs: Dict[str, torch.Tensor] = {}
 
     def _step(self):
         cart, _ = ops.accumulate_sweeps(self.raw, self.sweep_offsets, self.transforms, self.time_lags, 1.0, count=self.offsets[1:2])
         polar = ops.cart_to_polar(cart)                                   # rows past the count are ignored downstream
-        preds = self.model.forward_points(polar, self.offsets, 1, self.spec)
+        preds = self.model.forward_points(polar, self.offsets, 1, self.spec, canvas=self.canvas)
         if self.test_cfg is None:
             return dict(preds)
         return self.model.bbox_head.predict(dict(metadata=[None]), {"det_preds": [preds]}, self.test_cfg, device_only=True)

@@ -63,6 +63,7 @@ SIGNATURES = {
     "pn_static_pfn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P]),
     "pn_scatter_canvas_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "pn_fill_zero": (_I, [_P, _SZ, _P]),
+    "pn_clear_canvas_cells": (_I, [_P, _P, _I, _P, _I, _P, _P]),
     "pn_conv_packed_weight_floats": (_SZ, [_I, _I, _I, _I, _I]),
     "pn_pack_conv_weight_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "pn_deconv2x2_packed_weight_floats": (_SZ, [_I, _I]),

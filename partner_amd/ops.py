@@ -207,6 +207,15 @@ def dynamic_pfn(points: torch.Tensor, vi: VoxelIndex, w0: torch.Tensor, w1: torc
              hip.ptr(canvas), hip.stream())
 
 
+def clear_canvas_cells(canvas: torch.Tensor, vi: VoxelIndex, v_cap: Optional[int] = None) -> None:
+    """zero the cells of ``vi``'s voxels in a persistent NHWC canvas (sparse clear after the canvas has been consumed)"""
+    hip.require_device(canvas)
+    assert canvas.is_contiguous() and canvas.dtype == torch.float32
+    _, _, g = vi.spec.c_arrays()
+    hip.call("pn_clear_canvas_cells", vi.unq_keys_ptr, vi.num_voxels.data_ptr(), vi.n_cap if v_cap is None else v_cap, g,
+             canvas.shape[-1], canvas.data_ptr(), hip.stream())
+
+
 def scatter_canvas(features: torch.Tensor, unq: torch.Tensor, batch: int, t: int, r: int,
                    num_voxels: Optional[torch.Tensor] = None) -> torch.Tensor:
     """-> zero-filled NHWC canvas (batch, T, R, C) with features written at unq[:, (0,2,3)]"""

@@ -241,6 +241,27 @@ def test_frame_engine_graph_replay_matches_eager(dev):
         ref = m.forward_points(ops.cart_to_polar(cart), offs, 2, spec)
         for k in ref:
             assert torch.equal(out[k], ref[k]), (seed, k)
+        # the engine's persistent canvas is all zero again after the frame (sparse clear of the frame's cells)
+        assert int(torch.count_nonzero(eng.canvas)) == 0
+
+
+def test_persistent_canvas_full_grid(dev):
+    """nuScenes grid, 30k and (heavy pillars) clustered frames through forward_points(canvas=): same bits as the
+    fresh-canvas path, canvas all zero afterwards"""
+    from partner_amd import ops
+    m = build(detector_cfg(synth.NUSC_RANGE, synth.NUSC_VOXEL), 0, dev)
+    canvas = m.new_canvas(1)
+    offs = torch.tensor([0, 30000], dtype=torch.int32, device=dev)
+    for seed in (3, 4):
+        pts = torch.from_numpy(synth.synth_sweep_polar(30000, seed=seed)).to(dev)
+        if seed == 4:   # a wall: 5000 points in a handful of pillars (heavy-pillar kernel writes cells too)
+            pts[:5000, 0] = 10.0 + 0.2 * torch.rand(5000, device=dev)
+            pts[:5000, 1] = 0.3 + 0.02 * torch.rand(5000, device=dev)
+        ref = m.forward_points(pts, offs, 1)
+        out = m.forward_points(pts, offs, 1, canvas=canvas)
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), (seed, k)
+        assert int(torch.count_nonzero(canvas)) == 0
 
 
 def test_center_loss_forward_value(dev, golden):
