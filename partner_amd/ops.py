@@ -141,14 +141,15 @@ def build_voxel_index(keys: torch.Tensor, spec: GridSpec, batch: int, n_dev: Opt
     unq = torch.empty((max(n, 1), 4), dtype=torch.int64, device=dev) if want_unq else None
     inv = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
     cnt = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
-    nv = torch.zeros((1,), dtype=torch.int32, device=dev)
+    nv = torch.empty((1,), dtype=torch.int32, device=dev)          # always written by the rank scan
     _, _, g = spec.c_arrays()
     st = hip.stream()
     hip.call("pn_unique_rank_bitmap", keys.data_ptr(), n, hip.ptr(n_dev), cells, g, hip.ptr(unq), inv.data_ptr(),
              cnt.data_ptr(), nv.data_ptr(), ws.data_ptr(), ws_bytes, st)
     bws_bytes = lib.pn_bucket_workspace_bytes(n)
     bws = torch.empty(max(bws_bytes, 1), dtype=torch.uint8, device=dev)
-    vstart = torch.zeros((n + 1,), dtype=torch.int32, device=dev)
+    # entries [0, V] are written by the bucket scan; entries past V are never read (every consumer is bounded by num_voxels)
+    vstart = torch.empty((n + 1,), dtype=torch.int32, device=dev) if n > 0 else torch.zeros((1,), dtype=torch.int32, device=dev)
     order = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
     hip.call("pn_bucket_points", inv.data_ptr(), cnt.data_ptr(), n, hip.ptr(n_dev), nv.data_ptr(), vstart.data_ptr(),
              order.data_ptr(), bws.data_ptr(), bws_bytes, st)
