@@ -198,7 +198,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   // (nearly) the same lines, so the slab stays in this XCD's L2 while it is being used.
   // (tap, chunk) of the next tile to fetch, advanced incrementally: scalar adds only
   int ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
-  auto load_global = [&](bool live) {
+  auto load_global_to = [&](bool live, f32x4 (&ra)[A_PER_T], f32x4 (&rb)[B_PER_T]) {
     const unsigned so_a = GATHER ? (unsigned)(ld_chunk * BKC * ES) : (unsigned)(((ld_kh * a.W + ld_kw) * a.in_ps + ld_chunk * BKC) * ES);
     const int tap = GATHER ? __builtin_amdgcn_readfirstlane(tap_list[ld_tap]) : ld_tap;
     const unsigned so_b = (unsigned)((tap * a.cin_chunks + ld_chunk) * 8) * (unsigned)a.cout_pad * 16u;
@@ -223,7 +223,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     if (++ld_kw == a.KW) { ld_kw = 0; ++ld_kh; }
     if (++ld_tap == taps_loop) { ld_tap = 0; ld_kh = 0; ld_kw = 0; ++ld_chunk; }
   };
-  auto store_lds = [&](int buf) {
+  auto load_global = [&](bool live) { load_global_to(live, ra, rb); };
+  auto store_lds_from = [&](int buf, const f32x4 (&ra)[A_PER_T], const f32x4 (&rb)[B_PER_T]) {
     float* As = smem + buf * STAGE;
     float* Bs = As + A_FLOATS;
 #pragma unroll
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < B_PER_T; ++j) *reinterpret_cast<f32x4*>(Bs + (tid + NT * j) * 4) = rb[j];
   };
+  auto store_lds = [&](int buf) { store_lds_from(buf, ra, rb); };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -285,9 +287,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     }
   };
 
-  load_global(true);
-  store_lds(0);
-  load_global(nsteps > 1);
+  // prologue: the loads of the first TWO K steps are issued back to back (a second register set, dead afterwards), so the
+  // block pays one global-memory latency before its first MFMA instead of two
+  {
+    f32x4 ra0[A_PER_T], rb0[B_PER_T];
+    load_global_to(true, ra0, rb0);
+    load_global(nsteps > 1);
+    store_lds_from(0, ra0, rb0);
+  }
   __syncthreads();
   read_frags(0, 0, af[0], bf[0]);
 
