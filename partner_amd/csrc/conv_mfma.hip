@@ -223,7 +223,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     if (++ld_kw == a.KW) { ld_kw = 0; ++ld_kh; }
     if (++ld_tap == taps_loop) { ld_tap = 0; ld_kh = 0; ld_kw = 0; ++ld_chunk; }
   };
-  auto load_global = [&](bool live) { load_global_to(live, ra, rb); };
   auto store_lds_from = [&](int buf, const f32x4 (&ra)[A_PER_T], const f32x4 (&rb)[B_PER_T]) {
     float* As = smem + buf * STAGE;
     float* Bs = As + A_FLOATS;
@@ -235,7 +234,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < B_PER_T; ++j) *reinterpret_cast<f32x4*>(Bs + (tid + NT * j) * 4) = rb[j];
   };
-  auto store_lds = [&](int buf) { store_lds_from(buf, ra, rb); };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -289,10 +287,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
 
   // prologue: the loads of the first TWO K steps are issued back to back (a second register set, dead afterwards), so the
   // block pays one global-memory latency before its first MFMA instead of two
+  // Prefetch distance = two K steps (two register sets, used alternately): with one block per CU nothing else covers the
+  // L2 / HBM latency of a tile, and a distance of one step (~1 us) left ~11 % of the loop waiting on vmcnt.
+  f32x4 ra2[A_PER_T], rb2[B_PER_T];
   {
     f32x4 ra0[A_PER_T], rb0[B_PER_T];
     load_global_to(true, ra0, rb0);
-    load_global(nsteps > 1);
+    load_global_to(nsteps > 1, ra, rb);
+    load_global_to(nsteps > 2, ra2, rb2);
     store_lds_from(0, ra0, rb0);
   }
   __syncthreads();
@@ -301,8 +303,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   constexpr int NM = (DT == DT_F32 ? 4 : 1) * TM * TN;  // MFMAs per sub-step
   constexpr int NF = TM + TN;              // fragment reads per sub-step
   constexpr int NS = A_PER_T + B_PER_T;    // LDS stores == buffer loads per step
-  for (int t = 0; t < nsteps; ++t) {
-    const int buf = t & 1;
+  auto kstep = [&](int t, int buf, f32x4 (&rx)[A_PER_T], f32x4 (&ry)[B_PER_T]) {
     // sub-step 0: fragments of sub-step 1, then MFMAs
     read_frags(buf, 1, af[1], bf[1]);
     mfma_sub(af[0], bf[0]);
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     // sub-step 1: fragments of sub-step 2; the LDS stores of step t+1 are spread between the MFMAs
     read_frags(buf, 2, af[0], bf[0]);
     mfma_sub(af[1], bf[1]);
-    store_lds(buf ^ 1);  // (past the last step this writes zeros into a stage nobody reads)
+    store_lds_from(buf ^ 1, rx, ry);  // the tile of step t+1 (past the last step: zeros into a stage nobody reads)
     __builtin_amdgcn_sched_group_barrier(0x100, NF, 1);
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
@@ -321,10 +322,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     }
     __builtin_amdgcn_sched_group_barrier(0x008, NM, 1);
     __builtin_amdgcn_sched_barrier(0);
-    // sub-step 2: fragments of sub-step 3; the buffer loads of step t+2 are spread between the MFMAs
+    // sub-step 2: fragments of sub-step 3; the buffer loads of step t+3 (into the registers just stored) are spread between the MFMAs
     read_frags(buf, 3, af[1], bf[1]);
     mfma_sub(af[0], bf[0]);
-    load_global(t + 2 < nsteps);
+    load_global_to(t + 3 < nsteps, rx, ry);
     __builtin_amdgcn_sched_group_barrier(0x100, NF, 2);
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
@@ -341,6 +342,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_group_barrier(0x100, NF, 3);
     __builtin_amdgcn_sched_group_barrier(0x008, NM, 3);
     __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int t = 0; t < nsteps; t += 2) {
+    kstep(t, 0, ra, rb);
+    if (t + 1 < nsteps) kstep(t + 1, 1, ra2, rb2);
   }
 
   // ---- epilogue: per-channel affine + activation, NHWC store ----------------------------
