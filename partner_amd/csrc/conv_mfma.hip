@@ -721,7 +721,9 @@ int dispatch_conv(const ConvArgs& a, int zdim, hipStream_t st) {
     // on the 128 x 128 layers (103 vs 95 TFLOP/s), also on the stride-2 and 2x2 layers
     if (a.ncols > 64) tile = t128 >= min128 ? 1 : (t64x128 >= min64x128 ? 5 : 3);
     else if (a.ncols > 32) tile = 3;
-    else tile = 4;
+    // <= 32 columns: with few blocks (<= 2 per CU) the 4-wave 64 x 64 block hides its load latency better than the 2-wave
+    // 64 x 32 one although half of its columns are padding (17.7 vs 19.1 us for 64 -> 10, 15.9 vs 17.6 for the grouped 32 -> 32)
+    else tile = (long long)pn::cdiv(a.M, 64) * zdim <= 512 ? 3 : 4;
   }
   switch (tile) {
     case 1: return launch_conv<2, 2, 2, 2>(a, zdim, st);  // 128 x 128, 4 waves of 64x64
