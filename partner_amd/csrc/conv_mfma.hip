@@ -189,7 +189,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(const_cast<float*>(a.w)) + (size_t)z * taps * a.cin_chunks * 8 * a.cout_pad * 16, 0, a.w_bytes, 0x00020000);
   const int* tap_list = nbr_s + BM * 32;
-  const int taps_loop = GATHER ? tap_list[32] : taps;   // taps the K loop runs over
+  // Four-phase data gradient of a 3x3 stride-2 convolution (DECONV2 with 2x2 taps): output phase d = 2*ph + pw uses tap
+  // (u, v) only if (ph || !u) && (pw || !v) -- 9 of the 16 (phase, tap) weight blocks are non-zero.  A column tile that lies
+  // inside the phases [d_lo, d_hi] runs over the union of their live taps only (packed 4 bits per entry).
+  unsigned tapsel = 0;
+  int n_sel = 0;
+  if (!GATHER && a.mode == MODE_DECONV2 && taps == 4) {
+    const int d_lo = n0 / a.Cout, d_hi = min(3, (n0 + BN - 1) / a.Cout);
+    unsigned live = 0;
+    for (int d = d_lo; d <= d_hi; ++d)
+      for (int t = 0; t < 4; ++t)
+        if (((d >> 1) || !(t >> 1)) && ((d & 1) || !(t & 1))) live |= 1u << t;
+    for (int t = 0; t < 4; ++t)
+      if (live >> t & 1) tapsel |= (unsigned)t << (4 * n_sel++);
+  }
+  const int taps_loop = GATHER ? tap_list[32] : (n_sel ? n_sel : taps);   // taps the K loop runs over
   const int nsteps = taps_loop * a.cin_chunks;
 
   f32x4 ra[A_PER_T], rb[B_PER_T];
@@ -199,8 +213,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   // (tap, chunk) of the next tile to fetch, advanced incrementally: scalar adds only
   int ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
   auto load_global_to = [&](bool live, f32x4 (&ra)[A_PER_T], f32x4 (&rb)[B_PER_T]) {
-    const unsigned so_a = GATHER ? (unsigned)(ld_chunk * BKC * ES) : (unsigned)(((ld_kh * a.W + ld_kw) * a.in_ps + ld_chunk * BKC) * ES);
-    const int tap = GATHER ? __builtin_amdgcn_readfirstlane(tap_list[ld_tap]) : ld_tap;
+    int tap = GATHER ? __builtin_amdgcn_readfirstlane(tap_list[ld_tap]) : ld_tap;
+    int kh = ld_kh, kw = ld_kw;
+    if (!GATHER && n_sel) {  // block-uniform: the live 2x2 taps of this column tile
+      tap = (int)(tapsel >> (4 * ld_tap)) & 15;
+      kh = tap >> 1;
+      kw = tap & 1;
+    }
+    const unsigned so_a = GATHER ? (unsigned)(ld_chunk * BKC * ES) : (unsigned)(((kh * a.W + kw) * a.in_ps + ld_chunk * BKC) * ES);
     const unsigned so_b = (unsigned)((tap * a.cin_chunks + ld_chunk) * 8) * (unsigned)a.cout_pad * 16u;
     // `live` == false (past the last K step): every lane is redirected out of range, the loads
     // return zeros without touching memory and the loop body stays branch-free
@@ -212,7 +232,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
         const int idx = nbr_s[((tid >> 3) + (NT / 8) * j) * taps + tap];   // input row of this (site, tap), -1: inactive
         vo = (idx >= 0 && cok) ? (unsigned)idx * (unsigned)(a.in_ps * ES) + a_off[j] : 0xffffffffu;
       } else {
-        const unsigned sel = (a_mask[j] >> ld_tap) & cok;          // 1: inside the map
+        const unsigned sel = (a_mask[j] >> tap) & cok;             // 1: inside the map
         vo = a_off[j] | (0u - (1u - (sel & 1u)));                  // branch-free: ~0 when outside
       }
       ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, so_a, 0));
