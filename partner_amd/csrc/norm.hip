@@ -448,6 +448,7 @@ struct GnBwdArgs {
   int accumulate;
   double* part2;       // [B][strata][splits][C][2]
   float* coef;         // [B][strata][cgroups][2] = (m1, m2)
+  double* chan;        // [B][strata][C][2] per-sample channel sums (dbeta, dgamma contributions)
 };
 
 __device__ __forceinline__ void gn_point(const GnBwdArgs& a, const float* smean, int s, int cv, size_t pix, int y, int x,
@@ -506,40 +507,59 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_partial_kernel(GnBwdArgs a) {
   }
 }
 
-// block per stratum s, thread per channel: dgamma/dbeta (sum over batch and splits, fixed order) and
-// the per-(b, group) coefficients m1, m2
-__global__ void gn_bwd_finalize_kernel(GnBwdArgs a) {
-  extern __shared__ double sh[];  // [C][2] gamma-weighted per-channel sums of the current b
+// block per (stratum s, sample b): per-channel sums over the row splits (256 / C threads per channel, fixed order), the
+// per-(b, group) coefficients m1, m2, and the channel sums of this sample for gn_bwd_param_kernel
+__global__ __launch_bounds__(kThreads) void gn_bwd_finalize_kernel(GnBwdArgs a) {
+  extern __shared__ double sh[];  // [256][2] partial sums, then [C][2] gamma-weighted per-channel sums
   const GnArgs& f = a.f;
-  const int s = blockIdx.x;
+  const int s = blockIdx.x, b = blockIdx.y;
   const int cpg = f.C / f.cgroups;
   const double n = (double)cpg * f.H * (f.W / f.strata);
-  double tg = 0.0, tb = 0.0;
+  const int nparts = kThreads / f.C, c = threadIdx.x % f.C, part = threadIdx.x / f.C;
+  double t0 = 0.0, t1 = 0.0;
+  if (part < nparts) {
+    const double* p = a.part2 + (((size_t)b * f.strata + s) * f.splits) * f.C * 2 + (size_t)c * 2;
+    for (int k = part; k < f.splits; k += nparts) { t0 += p[(size_t)k * f.C * 2]; t1 += p[(size_t)k * f.C * 2 + 1]; }
+  }
+  sh[2 * threadIdx.x] = t0;
+  sh[2 * threadIdx.x + 1] = t1;
+  __syncthreads();
+  if (part == 0) {
+    for (int q = 1; q < nparts; ++q) { t0 += sh[2 * (q * f.C + c)]; t1 += sh[2 * (q * f.C + c) + 1]; }
+    double* cs = a.chan + (((size_t)b * f.strata + s) * f.C + c) * 2;
+    cs[0] = t0;
+    cs[1] = t1;
+  }
+  __syncthreads();
+  if (part == 0) {
+    const double ga = f.gamma ? (double)f.gamma[s * f.C + c] : 1.0;
+    sh[2 * c] = ga * t0;
+    sh[2 * c + 1] = ga * t1;
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < f.cgroups; g += blockDim.x) {
+    double m1 = 0.0, m2 = 0.0;
+    for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) { m1 += sh[2 * cc]; m2 += sh[2 * cc + 1]; }
+    float* co = a.coef + (((size_t)b * f.strata + s) * f.cgroups + g) * 2;
+    co[0] = (float)(m1 / n);
+    co[1] = (float)(m2 / n);
+  }
+}
+
+// dgamma / dbeta: thread per (stratum, channel), samples added in order
+__global__ void gn_bwd_param_kernel(GnBwdArgs a) {
+  const GnArgs& f = a.f;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= f.strata * f.C) return;
+  const int s = i / f.C, c = i - s * f.C;
+  double tb = 0.0, tg = 0.0;
   for (int b = 0; b < f.B; ++b) {
-    for (int c = threadIdx.x; c < f.C; c += blockDim.x) {
-      double t0 = 0.0, t1 = 0.0;
-      const double* p = a.part2 + (((size_t)b * f.strata + s) * f.splits) * f.C * 2 + (size_t)c * 2;
-      for (int k = 0; k < f.splits; ++k) { t0 += p[(size_t)k * f.C * 2]; t1 += p[(size_t)k * f.C * 2 + 1]; }
-      if (c == (int)threadIdx.x) { tb += t0; tg += t1; }  // blockDim.x >= C: one channel per thread
-      const double ga = f.gamma ? (double)f.gamma[s * f.C + c] : 1.0;
-      sh[2 * c] = ga * t0;
-      sh[2 * c + 1] = ga * t1;
-    }
-    __syncthreads();
-    for (int g = threadIdx.x; g < f.cgroups; g += blockDim.x) {
-      double m1 = 0.0, m2 = 0.0;
-      for (int c = g * cpg; c < (g + 1) * cpg; ++c) { m1 += sh[2 * c]; m2 += sh[2 * c + 1]; }
-      float* co = a.coef + (((size_t)b * f.strata + s) * f.cgroups + g) * 2;
-      co[0] = (float)(m1 / n);
-      co[1] = (float)(m2 / n);
-    }
-    __syncthreads();
+    const double* cs = a.chan + (((size_t)b * f.strata + s) * f.C + c) * 2;
+    tb += cs[0];
+    tg += cs[1];
   }
-  const int c = threadIdx.x;
-  if (c < f.C) {
-    if (a.dbeta) a.dbeta[s * f.C + c] = (a.accumulate ? a.dbeta[s * f.C + c] : 0.f) + (float)tb;
-    if (a.dgamma) a.dgamma[s * f.C + c] = (a.accumulate ? a.dgamma[s * f.C + c] : 0.f) + (float)tg;
-  }
+  if (a.dbeta) a.dbeta[i] = (a.accumulate ? a.dbeta[i] : 0.f) + (float)tb;
+  if (a.dgamma) a.dgamma[i] = (a.accumulate ? a.dgamma[i] : 0.f) + (float)tg;
 }
 
 __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(GnBwdArgs a) {
@@ -609,7 +629,8 @@ extern "C" {
 
 size_t pn_groupnorm_bwd_workspace_bytes(int batch, int c, int channel_groups, int range_strata) {
   return pn_groupnorm_workspace_bytes(batch, channel_groups, range_strata) +
-         (size_t)batch * range_strata * 256 * c * 2 * sizeof(double) + (size_t)batch * range_strata * channel_groups * 2 * sizeof(float);
+         (size_t)batch * range_strata * 256 * c * 2 * sizeof(double) + (size_t)batch * range_strata * c * 2 * sizeof(double) +
+         (size_t)batch * range_strata * channel_groups * 2 * sizeof(float);
 }
 
 int pn_groupnorm_strat_bwd(const float* x, const float* dout, const float* dout2, const float* mul, int batch, int h, int w, int c,
@@ -641,7 +662,8 @@ int pn_groupnorm_strat_bwd(const float* x, const float* dout, const float* dout2
   f.stat = reinterpret_cast<float*>(f.part + ngroups * 256 * 2);
   char* p = static_cast<char*>(workspace) + pn_groupnorm_workspace_bytes(batch, channel_groups, range_strata);
   a.part2 = reinterpret_cast<double*>(p);
-  a.coef = reinterpret_cast<float*>(p + (size_t)batch * range_strata * 256 * c * 2 * sizeof(double));
+  a.chan = reinterpret_cast<double*>(p + (size_t)batch * range_strata * 256 * c * 2 * sizeof(double));
+  a.coef = reinterpret_cast<float*>(a.chan + (size_t)batch * range_strata * c * 2);
   a.dout = dout; a.dps = dout_pixel_stride; a.dco = dout_channel_offset; a.dout2 = dout2;
   a.dx = dx; a.xps = dx_pixel_stride; a.xco = dx_channel_offset;
   a.dgamma = dgamma; a.dbeta = dbeta; a.dmul = dmul; a.dadd = dadd; a.accumulate = accumulate;
@@ -650,7 +672,9 @@ int pn_groupnorm_strat_bwd(const float* x, const float* dout, const float* dout2
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(kThreads), 0, st, f);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ngroups), dim3(64), 0, st, f);
   hipLaunchKernelGGL(gn_bwd_partial_kernel, grid, dim3(kThreads), 0, st, a);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(range_strata), dim3(kThreads), (size_t)c * 2 * sizeof(double), st, a);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(range_strata, batch), dim3(kThreads), (size_t)kThreads * 2 * sizeof(double), st, a);
+  if (dgamma || dbeta)
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(pn::cdiv(range_strata * c, 256)), dim3(256), 0, st, a);
   if (dout2) {
     const size_t total = (size_t)h * w * (c / 4);
     hipLaunchKernelGGL(gn_bwd_calib_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, st, a);
