@@ -40,3 +40,10 @@ def test_host_only_entry_points():
     rc = lib.pn_conv2d_nhwc_f32(None, None, None, None, None, None, None)
     assert rc == -1 and "null descriptor" in hip.last_error()
     assert C.sizeof(hip.ConvDesc) == 21 * 4
+    # the entries added for the frame engines / reproducible training validate on the host as well
+    rc = lib.pn_clear_canvas_cells(None, None, 10, None, 128, None, None)
+    assert rc == -1 and "clear_canvas_cells" in hip.last_error()
+    buf = (C.c_int32 * 4)()
+    rc = lib.pn_sort_voxel_runs(C.addressof(buf), C.addressof(buf), 4, C.addressof(buf), C.addressof(buf), None)   # in == out
+    assert rc == -1 and "sort_voxel_runs" in hip.last_error()
+    assert lib.pn_groupnorm_bwd_workspace_bytes(4, 64, 64, 1) > lib.pn_groupnorm_workspace_bytes(4, 64, 1)
