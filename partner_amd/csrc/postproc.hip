@@ -178,43 +178,37 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
   unsigned long long* keys = sort_lds;                       // [kCap]
   int* hist = reinterpret_cast<int*>(sort_lds + kCap);       // [kHistBins]
   __shared__ int wave_cnt[kSortThreads / 64];
-  __shared__ int base_s, cut_bin, n_kept;
+  __shared__ int n_valid, cut_bin, n_ge, n_kept;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float* sc = score + (size_t)b * cells;
-  if (tid == 0) base_s = 0;
+  if (tid == 0) { n_valid = 0; n_kept = 0; }
   for (int i = tid; i < kHistBins; i += kSortThreads) hist[i] = 0;
   __syncthreads();
-  // ---- order-preserving compaction (cell order) of the valid cells
-  for (int c0 = 0; c0 < cells; c0 += kSortThreads) {
-    const int c = c0 + tid;
-    const float s = c < cells ? sc[c] : -1.f;
-    const bool v = s >= 0.f;
-    const unsigned long long bal = __ballot(v);
-    if (lane == 0) wave_cnt[wv] = __popcll(bal);
-    __syncthreads();
-    int off = base_s;
-    for (int k = 0; k < wv; ++k) off += wave_cnt[k];
-    const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-    // key: score bits (positive floats order like unsigned) then ~cell, so that a descending sort yields
-    // score descending, cell ascending
-    if (v && pos < kCap) {
-      keys[pos] = ((unsigned long long)__builtin_bit_cast(unsigned, s) << 32) | (unsigned)(0xffffffffu - (unsigned)c);
-      atomicAdd(&hist[(__builtin_bit_cast(unsigned, s) >> 19) & (kHistBins - 1)], 1);   // integer counts: order independent
+  // key: score bits (positive floats order like unsigned) then ~cell, so that a descending sort yields score descending,
+  // cell ascending.  Only the first pre_max of that order are used, so:
+  // ---- pass 1: histogram of the score bits [30:19] of the valid cells (integer LDS atomics: order independent)
+  constexpr int kBatch = 16;   // scores per thread requested back to back (one memory latency per 16k cells instead of 16)
+  {
+    int mine = 0;
+    for (int c0 = 0; c0 < cells; c0 += kSortThreads * kBatch) {
+      float sv[kBatch];
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) {
+        const int c = c0 + k * kSortThreads + tid;
+        sv[k] = c < cells ? sc[c] : -1.f;
+      }
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k)
+        if (sv[k] >= 0.f) { atomicAdd(&hist[(__builtin_bit_cast(unsigned, sv[k]) >> 19) & (kHistBins - 1)], 1); ++mine; }
     }
-    __syncthreads();
-    if (tid == 0) {
-      int t = 0;
-      for (int k = 0; k < kSortThreads / 64; ++k) t += wave_cnt[k];
-      base_s += t;
-    }
-    __syncthreads();
+    mine = pn::wave_sum(mine);
+    if (lane == 0 && mine) atomicAdd(&n_valid, mine);
   }
-  int n = min(base_s, kCap);
-  // ---- only the first pre_max of the sorted order are used: drop every candidate whose score bin lies below the bin in
-  //      which the pre_max-th best falls (a superset of the top pre_max, usually a few hundred more), then sort those
-  if (n > pre_max) {
-    if (wv == 0) {  // one wave walks the histogram from the top: 64 bins per step
-      int acc = 0, found = -1;
+  __syncthreads();
+  // ---- the bin in which the pre_max-th best falls: one wave walks the histogram from the top, 64 bins per step
+  if (wv == 0) {
+    int acc = 0, found = -1, ge = n_valid;
+    if (n_valid > pre_max) {
       for (int hi = kHistBins - 64; hi >= 0 && found < 0; hi -= 64) {
         const int v = hist[hi + 63 - lane];                 // lane 0 = highest bin of the chunk
         int inc = v;
@@ -224,36 +218,66 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
           if (lane >= o) inc += t;
         }
         const unsigned long long hit = __ballot(acc + inc >= pre_max);
-        if (hit) found = hi + 63 - (__ffsll((long long)hit) - 1);
+        if (hit) {
+          const int l = __ffsll((long long)hit) - 1;
+          found = hi + 63 - l;
+          ge = acc + __shfl(inc, l, 64);
+        }
         acc += __shfl(inc, 63, 64);
       }
-      if (lane == 0) { cut_bin = found < 0 ? 0 : found; n_kept = 0; }
     }
-    __syncthreads();
-    const unsigned cut = (unsigned)cut_bin;
-    // stable compaction in place (kept position <= source position; one chunk of 1024 per round)
-    for (int c0 = 0; c0 < n; c0 += kSortThreads) {
-      const int i = c0 + tid;
-      const unsigned long long k = i < n ? keys[i] : 0ull;
-      const bool v = i < n && (((unsigned)(k >> 51)) & (kHistBins - 1)) >= cut;
+    if (lane == 0) { cut_bin = found < 0 ? 0 : found; n_ge = ge; }
+  }
+  __syncthreads();
+  const unsigned cut = (unsigned)cut_bin;
+  // ---- pass 2: the candidates at or above that bin (a superset of the top pre_max, usually a few hundred more) -> keys
+  if (n_ge <= kCap) {
+    // the sort below orders them by the full key, so the order in which they land here is irrelevant: one LDS atomic per wave
+    for (int c0 = 0; c0 < cells; c0 += kSortThreads * kBatch) {
+      float sv[kBatch];
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) {
+        const int c = c0 + k * kSortThreads + tid;
+        sv[k] = c < cells ? sc[c] : -1.f;
+      }
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) {
+        const int c = c0 + k * kSortThreads + tid;
+        const float s = sv[k];
+        const bool v = s >= 0.f && ((__builtin_bit_cast(unsigned, s) >> 19) & (kHistBins - 1)) >= cut;
+        const unsigned long long bal = __ballot(v);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&n_kept, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (v) keys[base + __popcll(bal & ((1ull << lane) - 1ull))] =
+            ((unsigned long long)__builtin_bit_cast(unsigned, s) << 32) | (unsigned)(0xffffffffu - (unsigned)c);
+      }
+    }
+  } else {
+    // more than kCap candidates in and above one bin (e.g. a constant score map): the first kCap in CELL order enter the
+    // sort -- ordered compaction, block scans
+    for (int c0 = 0; c0 < cells; c0 += kSortThreads) {
+      const int c = c0 + tid;
+      const float s = c < cells ? sc[c] : -1.f;
+      const bool v = s >= 0.f && ((__builtin_bit_cast(unsigned, s) >> 19) & (kHistBins - 1)) >= cut;
       const unsigned long long bal = __ballot(v);
       if (lane == 0) wave_cnt[wv] = __popcll(bal);
       __syncthreads();
       int off = n_kept;
-      for (int q = 0; q < wv; ++q) off += wave_cnt[q];
+      for (int k = 0; k < wv; ++k) off += wave_cnt[k];
       const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-      __syncthreads();   // every key of this chunk has been read before any is overwritten
-      if (v) keys[pos] = k;
+      if (v && pos < kCap) keys[pos] = ((unsigned long long)__builtin_bit_cast(unsigned, s) << 32) | (unsigned)(0xffffffffu - (unsigned)c);
       __syncthreads();
       if (tid == 0) {
         int t = 0;
-        for (int q = 0; q < kSortThreads / 64; ++q) t += wave_cnt[q];
+        for (int k = 0; k < kSortThreads / 64; ++k) t += wave_cnt[k];
         n_kept += t;
       }
       __syncthreads();
     }
-    n = n_kept;
   }
+  __syncthreads();
+  const int n = min(n_kept, kCap);
   int npad = 1;
   while (npad < n) npad <<= 1;
   for (int i = n + tid; i < npad; i += kSortThreads) keys[i] = 0ull;
@@ -269,8 +293,12 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
           if (desc ? a < c : a > c) { keys[i] = c; keys[p] = a; }
         }
       }
-      __syncthreads();
+      // a pass with j < 64 stays inside 64-key chunks, and a chunk belongs to one wave (i = tid + 1024 * r): between two such
+      // passes the wave's own in-order LDS traffic is all the ordering needed -- 51 of the 66 passes of a 2048-key sort
+      const bool cur_local = j < 64, next_local = j > 1 ? (j >> 1) < 64 : k < 64;
+      if (!(cur_local && next_local)) __syncthreads();
     }
+  __syncthreads();
   const int m = min(n, pre_max);
   if (tid == 0) n_sel[b] = m;
   for (int i = tid; i < m; i += kSortThreads) {
