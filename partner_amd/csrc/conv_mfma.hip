@@ -267,9 +267,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   // One barrier per K step; everything else sits in the shadow of the MFMAs:
   //   sub-step 0: read fragments of sub-step 1            | MFMAs of sub-step 0
   //   sub-step 1: read fragments of sub-step 2            | MFMAs of sub-step 1
-  //               store the (landed) tile of step t+1 into the other LDS stage,
-  //               issue the buffer loads of step t+2 into the same registers
+  //               store the (landed) tile of step t+1 into the other LDS stage
   //   sub-step 2: read fragments of sub-step 3            | MFMAs of sub-step 2
+  //               issue the buffer loads of step t+3 into the registers just stored (two register sets alternate:
+  //               the tile of step t+2 is in flight in the other one)
   //   barrier     (all LDS stores of step t+1 landed, all reads of this stage issued)
   //   sub-step 3: read fragments of step t+1, sub-step 0  | MFMAs of sub-step 3
   // The stage written in step t was last read before the barrier of step t-1 (WAR safe); it is
@@ -305,10 +306,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     }
   };
 
-  // prologue: the loads of the first TWO K steps are issued back to back (a second register set, dead afterwards), so the
-  // block pays one global-memory latency before its first MFMA instead of two
   // Prefetch distance = two K steps (two register sets, used alternately): with one block per CU nothing else covers the
   // L2 / HBM latency of a tile, and a distance of one step (~1 us) left ~11 % of the loop waiting on vmcnt.
+  // Prologue: the loads of steps 0, 1 and 2 are issued back to back (step 0 into a third set that is dead afterwards), so
+  // the block pays one global-memory latency before its first MFMA.
   f32x4 ra2[A_PER_T], rb2[B_PER_T];
   {
     f32x4 ra0[A_PER_T], rb0[B_PER_T];
