@@ -292,6 +292,24 @@ def test_conv_mfma(dev, case):
     _conv_case(dev, seed=zlib.crc32(str(sorted(case.items())).encode()) % 1000, **case)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_conv_mfma_random_shapes(dev, seed):
+    """random batch / map / channel / kernel / stride / padding / group / activation combinations (ragged tiles in every
+    dimension, channel counts that are not multiples of the 32-channel K step, 1 .. 200 output channels)"""
+    r = np.random.default_rng(9000 + seed)
+    k = int(r.choice([1, 2, 3, 3, 3, 5]))
+    stride = int(r.choice([1, 1, 2]))
+    groups = int(r.choice([1, 1, 1, 2, 4]))
+    cin = 4 * int(r.integers(1, 40 // groups + 2))                 # per group, multiple of 4
+    cout = int(r.integers(1, 200 // groups + 2))
+    if groups > 1:
+        cout = 4 * max(1, cout // 4)                                   # grouped outputs are written as aligned channel slices
+    h, w = int(r.integers(k, 70)), int(r.integers(k, 90))
+    pad = int(r.integers(0, k // 2 + 1))
+    b = int(r.integers(1, 4))
+    _conv_case(dev, b, cin, cout, h, w, k, stride, pad, groups=groups, act=int(r.integers(0, 3)), seed=seed, bn=bool(r.integers(0, 2)))
+
+
 def test_deconv2x2(dev):
     from partner_amd import ops
     rng = np.random.default_rng(5)

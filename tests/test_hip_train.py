@@ -55,6 +55,17 @@ def test_conv_wgrad_dgrad(dev, case):
     assert rel_err(dx, x.grad) < 2e-5
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_conv_wgrad_dgrad_random_shapes(dev, seed):
+    r = np.random.default_rng(7000 + seed)
+    k, stride = [(1, 1), (3, 1), (3, 2), (2, 2), (3, 1)][int(r.integers(0, 5))]
+    pad = 1 if k == 3 else 0
+    cin, cout = 4 * int(r.integers(1, 50)), 4 * int(r.integers(1, 50))
+    b = int(r.integers(1, 4))
+    h, w = 2 * int(r.integers(2, 30)), 2 * int(r.integers(2, 40))      # even maps (the four-phase stride-2 data gradient)
+    test_conv_wgrad_dgrad(dev, (b, h, w, cin, cout, k, stride, pad))
+
+
 def test_conv_wgrad_channel_slices(dev):
     """input / dout taken as channel slices of wider NHWC maps (concat buffers of rpn.py:155-157)"""
     from partner_amd import ops
