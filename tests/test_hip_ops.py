@@ -363,6 +363,28 @@ def test_groupnorm_family(dev):
         assert (ops.as_nchw(y).cpu() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_groupnorm_random_shapes(dev, seed):
+    """random batch / map / channel counts (4 .. 256, dividing 1024), channel groups (powers of two) and range strata, with and
+    without ReLU, against the oracle's RSNorm restatement (= GroupNorm over range strata stacked on channels)"""
+    from partner_amd import ops
+    r = np.random.default_rng(300 + seed)
+    c = int(r.choice([4, 8, 16, 32, 64, 128, 256]))
+    groups = int(2 ** r.integers(0, int(np.log2(min(c, 128))) + 1))
+    strata = int(r.choice([1, 1, 2, 4, 8]))
+    b, h = int(r.integers(1, 4)), int(r.integers(1, 50))
+    w = strata * int(r.integers(1, 24))
+    x = torch.from_numpy((r.standard_normal((b, c, h, w)) * r.uniform(0.1, 5.0) + r.uniform(-2, 2)).astype(np.float32))
+    g = torch.from_numpy(r.uniform(0.5, 1.5, strata * c).astype(np.float32))
+    be = torch.from_numpy(r.standard_normal(strata * c).astype(np.float32))
+    act = int(r.integers(0, 2))
+    ref = O.rs_norm(x, g, be, groups, strata) if strata > 1 else F.group_norm(x, groups, g, be, 1e-5)
+    ref = F.relu(ref) if act else ref
+    y = ops.groupnorm_strat(ops.to_nhwc(x.to(dev)), groups, strata, g.to(dev), be.to(dev), 1e-5, act=act)
+    err = (ops.as_nchw(y).cpu() - ref).abs().max().item()
+    assert err < 5e-5 * max(1.0, ref.abs().max().item()), (c, groups, strata, b, h, w, err)
+
+
 def test_layout_roundtrip(dev):
     from partner_amd import ops
     x = torch.from_numpy(np.random.default_rng(8).standard_normal((2, 37, 13, 21)).astype(np.float32)).to(dev)
