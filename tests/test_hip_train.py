@@ -122,6 +122,13 @@ def test_batchnorm_train_fwd_bwd(dev, shape):
     assert rel_err(dg2.cpu(), 2 * g.grad) < 2e-5
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_batchnorm_random_shapes(dev, seed):
+    r = np.random.default_rng(600 + seed)
+    c = 4 * int(r.integers(1, 65))
+    test_batchnorm_train_fwd_bwd(dev, (int(r.integers(1, 5)), int(r.integers(1, 60)), int(r.integers(1, 70)), c))
+
+
 def test_groupnorm_family_bwd(dev):
     """RSNorm(1,4)+ReLU with the calibration second output, GroupNorm(C,C)+ReLU, the 8-stratum
     GroupNorm of RangeStratified: dx, dgamma, dbeta (and dmul, dadd) against autograd over the oracle"""
