@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Launches the 128-column 3x3 convolution at 9 / 18 / 36 / 72 K steps (Cin = 32 .. 256) on an HW x HW map; run under
+rocprofv3 --kernel-trace: the durations against the step count give the per-step time and the fixed cost of a launch.
+  HW=256 rocprofv3 --kernel-trace --output-format csv -d out -- python3 tools/conv_fixed_cost.py"""
 import os, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from partner_amd import ops
 dev = torch.device("cuda:0")
