@@ -38,4 +38,16 @@ model = dict(
     part_head=None,
 )
 train_cfg = dict(assigner=dict(out_size_factor=get_downsample_factor(model), gaussian_overlap=0.1, max_objs=500, min_radius=2))
-test_cfg = None  # decode + NMS are not part of this hot path
+# the reference config's post-processing settings (polarstream_det_n_seg_1_sector.py:102-116): per-class rotated NMS
+rectify = True
+test_cfg = dict(
+    post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
+    max_per_img=500,
+    per_class_nms=True,
+    rectify=rectify,
+    nms=dict(nms_pre_max_size=1000, nms_post_max_size=83, nms_iou_threshold=0.1),
+    score_threshold=0.1,
+    pc_range=voxel_generator["range"],
+    out_size_factor=get_downsample_factor(model),
+    voxel_size=voxel_generator["voxel_size"],
+)

@@ -529,7 +529,11 @@ int pn_strat_expand_f32(const float *dy, int batch, int h, int w, int c, int str
  * above the score threshold enter the sort (first in cell order).  nms_pre_max_size <= 4096.
  * Outputs per sample: out_count[b] boxes in out_boxes[b][:count] (post_max rows allocated), scores, labels
  * (int64), cells (flat y*W+x).  The rotated-IoU arithmetic has no runnable reference here (CUDA only):
- * parity is against oracle/box_nms.c, unpinned by the reference. */
+ * parity is against oracle/box_nms.c, unpinned by the reference.
+ * per_class_nms != 0: test_cfg.per_class_nms of the reference's nuScenes configs (center_head.py:514-518,
+ * detectron2 layers.batched_nms_rotated, third party, absent here): one greedy pass in score order in which only
+ * boxes of the SAME class suppress each other; the reference passes every candidate, here the first pre_max
+ * (<= 4096) of the score order enter -- pass pre_max = 4096 for that mode. */
 size_t pn_center_decode_nms_workspace_bytes(int batch, int cells, int box_dims, int pre_max,
                                             int post_max);
 int pn_center_decode_nms_f32(const float *hm, int hm_pixel_stride, int classes, const float *reg,
@@ -538,8 +542,8 @@ int pn_center_decode_nms_f32(const float *hm, int hm_pixel_stride, int classes, 
                              int rot_pixel_stride, const float *vel, int vel_pixel_stride, int batch,
                              int h, int w, int cylinder, float step_x, float step_y, float origin_x,
                              float origin_y, int rectify, float score_threshold,
-                             const float *post_center_range, float nms_iou_threshold, int pre_max,
-                             int post_max, float *out_boxes, float *out_scores, int64_t *out_labels,
+                             const float *post_center_range, float nms_iou_threshold,
+                             int per_class_nms, int pre_max, int post_max, float *out_boxes, float *out_scores, int64_t *out_labels,
                              int32_t *out_cells, int32_t *out_count, void *workspace,
                              size_t workspace_bytes, pn_stream_t stream);
 

@@ -809,17 +809,31 @@ def nms_boxes_pcdet(boxes: np.ndarray) -> np.ndarray:
 
 
 def center_post_process(boxes: np.ndarray, hm: np.ndarray, score_threshold: float, post_center_range, nms_iou_threshold: float,
-                        nms_pre_max_size: int, nms_post_max_size: int, nms_fn):
+                        nms_pre_max_size: int, nms_post_max_size: int, nms_fn, per_class: bool = False):
     """one sample of post_processing (center_head.py:470-520, plain path).  nms_fn(sorted boxes (n,7), thresh) -> kept
     indices (the C oracle's ov_nms_sorted).  Ties in the score sort are broken by cell index (torch.sort leaves them
-    unspecified).  -> dict(box3d_lidar, scores, label_preds, cells)"""
+    unspecified).  -> dict(box3d_lidar, scores, label_preds, cells)
+
+    per_class (test_cfg.per_class_nms, center_head.py:514-518): detectron2's layers.batched_nms_rotated -- THIRD PARTY, absent
+    here, parity unpinned.  Its published semantics: every class is moved to its own region of the plane, one greedy rotated
+    NMS in score order runs over all boxes, the kept indices come back in score order; i.e. a greedy NMS in which only boxes
+    of the same class suppress each other.  The BEV rectangle it is given, (x, y, dims[0], dims[1], rot in degrees) in
+    detectron2's convention, is the rectangle of nms_boxes_pcdet (dims[0] along the direction -rot).  Restated with the same
+    IoU routine as the multi-class path; nms_pre_max_size bounds the candidates (the reference passes all of them)."""
     scores, labels = hm.max(-1), hm.argmax(-1)
     pr = np.asarray(post_center_range, np.float32)
     mask = (scores > np.float32(score_threshold)) & (boxes[:, :3] >= pr[:3]).all(1) & (boxes[:, :3] <= pr[3:]).all(1)
     cells = np.nonzero(mask)[0]
     b, s, l = boxes[cells], scores[cells], labels[cells]
     order = np.lexsort((cells, -s))[:nms_pre_max_size]
-    keep = np.asarray(nms_fn(nms_boxes_pcdet(b[order]), nms_iou_threshold), np.int64)
+    if per_class:
+        lab, kept = l[order], []
+        for c in np.unique(lab):
+            idx = np.nonzero(lab == c)[0]                       # positions in the score order
+            kept.append(idx[np.asarray(nms_fn(nms_boxes_pcdet(b[order[idx]]), nms_iou_threshold), np.int64)])
+        keep = np.sort(np.concatenate(kept)) if kept else np.zeros(0, np.int64)
+    else:
+        keep = np.asarray(nms_fn(nms_boxes_pcdet(b[order]), nms_iou_threshold), np.int64)
     sel = order[keep][:nms_post_max_size]
     return dict(box3d_lidar=b[sel], scores=s[sel], label_preds=l[sel], cells=cells[sel])
 

@@ -173,7 +173,8 @@ constexpr size_t kSortLds = (size_t)kCap * sizeof(unsigned long long) + (size_t)
 
 __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* __restrict__ score, const float* __restrict__ boxes, int cells, int nb,
                                                                    int pre_max, int* __restrict__ sel_cell, float* __restrict__ nms_boxes,
-                                                                   int* __restrict__ n_sel) {
+                                                                   int* __restrict__ n_sel, const int* __restrict__ label,
+                                                                   int* __restrict__ sel_label) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long sort_lds[];
   unsigned long long* keys = sort_lds;                       // [kCap]
   int* hist = reinterpret_cast<int*>(sort_lds + kCap);       // [kHistBins]
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
   for (int i = tid; i < m; i += kSortThreads) {
     const int cell = (int)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
     sel_cell[(size_t)b * pre_max + i] = cell;
+    sel_label[(size_t)b * pre_max + i] = label[(size_t)b * cells + cell];
     const float* src = boxes + ((size_t)b * cells + cell) * nb;
     float* d = nms_boxes + ((size_t)b * pre_max + i) * 7;
     // rotate_nms_pcdet's convention: [x, y, z, dims[1], dims[0], dims[2], -rot - pi/2]
@@ -323,9 +325,13 @@ __device__ __forceinline__ bool may_overlap(const float* a, const float* b) {
 // Two phases so that the expensive polygon intersection is not paid by a whole wave whenever ONE of its rows has a near
 // neighbour: (1) every row marks its candidate columns with the cheap distance test, (2) the tile's candidate pairs are
 // laid out as one list in LDS and dealt evenly over the 64 lanes; hits are OR-ed into the row masks (integer atomics).
+// per_class: boxes of different classes never suppress each other (detectron2's batched_nms_rotated moves every class to its
+// own region of the plane before one NMS; the same decision without the coordinate offsets).
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ nms_boxes, const int* __restrict__ n_sel, int pre_max, int col_blocks,
-                                                      float thresh, unsigned long long* __restrict__ mask) {
+                                                      float thresh, unsigned long long* __restrict__ mask, const int* __restrict__ sel_label,
+                                                      int per_class) {
   __shared__ float cb[64 * 7], rbx[64 * 7];
+  __shared__ int clab[64];
   __shared__ unsigned long long cand[64], hit[64];
   __shared__ unsigned short pairs[64 * 64];
   const int b = blockIdx.z, rb = blockIdx.y, cbk = blockIdx.x, lane = threadIdx.x;
@@ -337,12 +343,14 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     for (int k = 0; k < 7; ++k) cb[lane * 7 + k] = bx[(size_t)(cbk * 64 + lane) * 7 + k];
   if (lane < row_size)
     for (int k = 0; k < 7; ++k) rbx[lane * 7 + k] = bx[(size_t)(rb * 64 + lane) * 7 + k];
+  clab[lane] = (per_class && lane < col_size) ? sel_label[(size_t)b * pre_max + cbk * 64 + lane] : 0;
+  const int my_label = (per_class && lane < row_size) ? sel_label[(size_t)b * pre_max + rb * 64 + lane] : 0;
   hit[lane] = 0ull;
   __syncthreads();
   unsigned long long c = 0ull;
   if (lane < row_size)
     for (int i = (rb == cbk ? lane + 1 : 0); i < col_size; ++i)
-      if (may_overlap(rbx + lane * 7, cb + i * 7)) c |= 1ull << i;
+      if (clab[i] == my_label && may_overlap(rbx + lane * 7, cb + i * 7)) c |= 1ull << i;
   cand[lane] = c;
   // exclusive prefix of the per-row candidate counts -> each row writes its (row, col) pairs into the list
   int cnt = __popcll(c), inc = cnt;
@@ -405,7 +413,7 @@ __global__ void gather_kernel(const int* __restrict__ keep, const int* __restric
 }
 
 struct Ws {
-  float* boxes; float* score; int* label; int* sel_cell; float* nms_boxes; int* n_sel; unsigned long long* mask; int* keep;
+  float* boxes; float* score; int* label; int* sel_cell; int* sel_label; float* nms_boxes; int* n_sel; unsigned long long* mask; int* keep;
   size_t bytes;
 };
 
@@ -418,6 +426,7 @@ Ws carve(void* base, int batch, int cells, int nb, int pre_max, int post_max) {
   w.score = (float*)take((size_t)batch * cells * 4);
   w.label = (int*)take((size_t)batch * cells * 4);
   w.sel_cell = (int*)take((size_t)batch * pre_max * 4);
+  w.sel_label = (int*)take((size_t)batch * pre_max * 4);
   w.nms_boxes = (float*)take((size_t)batch * pre_max * 7 * 4);
   w.n_sel = (int*)take((size_t)batch * 4);
   w.mask = (unsigned long long*)take((size_t)batch * pre_max * cbk * 8);
@@ -438,8 +447,9 @@ int pn_center_decode_nms_f32(const float* hm, int hm_pixel_stride, int classes, 
                              int height_pixel_stride, const float* dim, int dim_pixel_stride, const float* rot, int rot_pixel_stride,
                              const float* vel, int vel_pixel_stride, int batch, int h, int w, int cylinder, float step_x, float step_y,
                              float origin_x, float origin_y, int rectify, float score_threshold, const float* post_center_range,
-                             float nms_iou_threshold, int pre_max, int post_max, float* out_boxes, float* out_scores, int64_t* out_labels,
-                             int32_t* out_cells, int32_t* out_count, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+                             float nms_iou_threshold, int per_class_nms, int pre_max, int post_max, float* out_boxes, float* out_scores,
+                             int64_t* out_labels, int32_t* out_cells, int32_t* out_count, void* workspace, size_t workspace_bytes,
+                             pn_stream_t stream) {
   PN_REQUIRE(hm && reg && height && dim && rot && post_center_range && out_boxes && out_scores && out_labels && out_cells && out_count && workspace,
              "center_decode_nms: null pointer");
   PN_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && classes >= 1, "center_decode_nms: bad sizes");
@@ -463,9 +473,10 @@ int pn_center_decode_nms_f32(const float* hm, int hm_pixel_stride, int classes, 
     sort_attr = true;
   }
   hipLaunchKernelGGL(select_sort_kernel, dim3(batch), dim3(kSortThreads), kSortLds, st, ws.score, ws.boxes, cells, nb, pre_max, ws.sel_cell,
-                     ws.nms_boxes, ws.n_sel);
+                     ws.nms_boxes, ws.n_sel, ws.label, ws.sel_label);
   const int cbk = (pre_max + 63) / 64;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(cbk, cbk, batch), dim3(64), 0, st, ws.nms_boxes, ws.n_sel, pre_max, cbk, nms_iou_threshold, ws.mask);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(cbk, cbk, batch), dim3(64), 0, st, ws.nms_boxes, ws.n_sel, pre_max, cbk, nms_iou_threshold, ws.mask,
+                     ws.sel_label, per_class_nms != 0);
   hipLaunchKernelGGL(nms_reduce_kernel, dim3(batch), dim3(64), 0, st, ws.mask, ws.n_sel, pre_max, cbk, post_max, ws.keep, out_count);
   hipLaunchKernelGGL(gather_kernel, dim3((post_max + 127) / 128, batch), dim3(128), 0, st, ws.keep, out_count, ws.sel_cell, ws.boxes, ws.score,
                      ws.label, cells, nb, pre_max, post_max, out_boxes, out_scores, out_labels, out_cells);

@@ -159,15 +159,16 @@ class CenterHead(nn.Module):
 
     @torch.no_grad()
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
-        """decode + rotated NMS on the device (center_head.py:404-460, 350-402, 462-577), plain path: no double flip,
-        no stateful / per-class NMS, no panoptic, sector 0.  Returns the reference's list (one dict per sample) of
+        """decode + rotated NMS on the device (center_head.py:404-460, 350-402, 462-577): the multi-class rotate_nms_pcdet path and
+        the per-class one (test_cfg.per_class_nms, batched_nms_rotated); no double flip, no stateful NMS, no panoptic, sector 0.  Returns the reference's list (one dict per sample) of
         'box3d_lidar' (n, 9|7), 'scores', 'label_preds', 'metadata'."""
         import ctypes as C
         lib = hip.load()
         get = (lambda k, d=None: test_cfg.get(k, d)) if hasattr(test_cfg, "get") else (lambda k, d=None: getattr(test_cfg, k, d))
-        for flag in ("double_flip", "stateful_nms", "panoptic", "per_class_nms"):
+        for flag in ("double_flip", "stateful_nms", "panoptic"):
             if get(flag, False):
-                raise NotImplementedError(f"predict: test_cfg.{flag} is not built (only the plain decode + rotate_nms_pcdet path)")
+                raise NotImplementedError(f"predict: test_cfg.{flag} is not built (only the plain decode + NMS paths)")
+        per_class = bool(get("per_class_nms", False))   # batched_nms_rotated of the nuScenes configs (center_head.py:514-518)
         if kwargs.get("device_only", False) and len(preds_dicts["det_preds"]) != 1:
             raise NotImplementedError("predict(device_only=True) supports a single task")
         if kwargs.get("prev_dets") is not None or kwargs.get("sec_id", 0) != 0:
@@ -175,6 +176,8 @@ class CenterHead(nn.Module):
         nms = get("nms")
         nget = (lambda k: nms[k]) if isinstance(nms, dict) else (lambda k: getattr(nms, k))
         pre_max, post_max, iou_thr = int(nget("nms_pre_max_size")), int(nget("nms_post_max_size")), float(nget("nms_iou_threshold"))
+        if per_class:
+            pre_max = 4096   # the reference passes every candidate to the per-class NMS; the device path takes the best 4096
         pcr = list(get("post_center_limit_range"))
         assert len(pcr) == 6, "predict: post_center_limit_range must have 6 entries"
         osf, vs, pr = get("out_size_factor"), get("voxel_size"), get("pc_range")
@@ -204,7 +207,7 @@ class CenterHead(nn.Module):
                      pd["height"].data_ptr(), pd["height"].stride(3), pd["dim"].data_ptr(), pd["dim"].stride(3), pd["rot"].data_ptr(),
                      pd["rot"].stride(3), hip.ptr(vel), 0 if vel is None else vel.stride(3), b, h, w, cyl, float(osf) * float(vs[0]),
                      float(osf) * float(vs[1]), float(pr[0]), float(pr[1]), int(bool(get("rectify", False))), float(get("score_threshold")),
-                     (C.c_float * 6)(*[float(v) for v in pcr]), iou_thr, pre_max, post_max, out_boxes.data_ptr(), out_scores.data_ptr(),
+                     (C.c_float * 6)(*[float(v) for v in pcr]), iou_thr, int(per_class), pre_max, post_max, out_boxes.data_ptr(), out_scores.data_ptr(),
                      out_labels.data_ptr(), out_cells.data_ptr(), out_count.data_ptr(), ws.data_ptr(), wsb, hip.stream())
             if kwargs.get("device_only", False):
                 # fixed-size outputs + device counts: nothing leaves the stream (hipGraph capturable); one task only
