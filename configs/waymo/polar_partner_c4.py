@@ -33,4 +33,14 @@ model = dict(
     part_head=None,
 )
 train_cfg = dict(assigner=dict(out_size_factor=get_downsample_factor(model), gaussian_overlap=0.1, max_objs=500, min_radius=2))
-test_cfg = None
+# post-processing settings of the reference config (waymo_partner_36epoch.py:142-154): multi-class rotate_nms_pcdet
+rectify = False
+test_cfg = dict(
+    post_center_limit_range=[-80, -80, -10.0, 80, 80, 10.0],
+    nms=dict(nms_pre_max_size=4096, nms_post_max_size=500, nms_iou_threshold=0.7),
+    score_threshold=0.1,
+    pc_range=voxel_generator["range"],
+    out_size_factor=get_downsample_factor(model),
+    voxel_size=voxel_generator["voxel_size"],
+    rectify=rectify,
+)

@@ -547,6 +547,21 @@ int pn_center_decode_nms_f32(const float *hm, int hm_pixel_stride, int classes, 
                              int32_t *out_cells, int32_t *out_count, void *workspace,
                              size_t workspace_bytes, pn_stream_t stream);
 
+/* Same pipeline for the geometry-aware head: E2ESWVoteHead.decode / post_processing (e2e_swv_head.py:313-366, 368-470; code that
+ * does not run in the reference, restated from its text): score = sigmoid(hm) * clamp((iou + 1) / 2, 0, 1)^iou_factor (iou may be
+ * NULL), centre = reg + offset_grid (planar (2, H, W) Cartesian cell centres), rot = atan2(rot[1], rot[0]), and with rectify the
+ * heading + atan2(y, x) wrapped into (-pi, pi].  7-dim boxes.  Workspace: pn_center_decode_nms_workspace_bytes(batch, h*w, 7, ..). */
+int pn_swv_decode_nms_f32(const float *hm, int hm_pixel_stride, int classes, const float *reg,
+                          int reg_pixel_stride, const float *height, int height_pixel_stride,
+                          const float *dim, int dim_pixel_stride, const float *rot, int rot_pixel_stride,
+                          const float *iou, int iou_pixel_stride, int iou_factor,
+                          const float *offset_grid, int batch, int h, int w, int rectify,
+                          float score_threshold, const float *post_center_range,
+                          float nms_iou_threshold, int per_class_nms, int pre_max, int post_max,
+                          float *out_boxes, float *out_scores, int64_t *out_labels, int32_t *out_cells,
+                          int32_t *out_count, void *workspace, size_t workspace_bytes,
+                          pn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * next-1  sparse 3-D convolutions of the middle encoder SpMiddleResNetFHD
  * (det3d/models/backbones/scn.py:17-192; the arithmetic is the third-party spconv package there: SubMConv3d /

@@ -801,6 +801,28 @@ def center_decode(preds: Dict[str, np.ndarray], voxel_shape: str, out_size_facto
     return np.concatenate([p.astype(np.float32) for p in parts], 2), hm.reshape(B, H * W, ncls)
 
 
+def swv_decode(preds: Dict[str, np.ndarray], offset_grid: np.ndarray, iou_factor: int = 1, rectify: bool = False):
+    """E2ESWVoteHead.decode (e2e_swv_head.py:313-366; the reference's code does not run -- restated from its text, PARITY UNPINNED).
+    preds: NHWC numpy (B,H,W,c) 'hm','reg','height','dim','rot'[,'iou']; offset_grid (2,H,W) Cartesian cell centres.
+    -> boxes (B, H*W, 7) [x, y, z, dims(3), rot], scores (B, H*W, ncls)"""
+    f = np.float32
+    hm = (1.0 / (1.0 + np.exp(-preds["hm"].astype(f)))).astype(f)
+    B, H, W, ncls = hm.shape
+    if "iou" in preds:
+        u = np.clip((preds["iou"].astype(f) + f(1.0)) * f(0.5), f(0.0), f(1.0))
+        hm = hm * (u if iou_factor == 1 else np.power(u, f(iou_factor))).astype(f)
+    dim = np.exp(preds["dim"].astype(f)).reshape(B, H * W, 3)
+    rot = np.arctan2(preds["rot"][..., 1:2], preds["rot"][..., 0:1]).astype(f).reshape(B, H * W, 1)
+    g = np.asarray(offset_grid, f).reshape(2, H * W)
+    reg = preds["reg"].reshape(B, H * W, 2).astype(f)
+    x, y = reg[:, :, 0:1] + g[0][None, :, None], reg[:, :, 1:2] + g[1][None, :, None]
+    if rectify:
+        rot = rot + np.arctan2(y, x).astype(f)
+        rot = rot + np.where(rot > f(np.pi), f(-2 * np.pi), np.where(rot < f(-np.pi), f(2 * np.pi), f(0.0))).astype(f)
+    hei = preds["height"].reshape(B, H * W, 1).astype(f)
+    return np.concatenate([x, y, hei, dim, rot], 2).astype(f), hm.reshape(B, H * W, ncls)
+
+
 def nms_boxes_pcdet(boxes: np.ndarray) -> np.ndarray:
     """(n, >=7) [x,y,z,l,w,h,...,rot] -> (n,7) in the NMS kernel's convention (box_torch_ops.py:255-257)"""
     b = boxes[:, [0, 1, 2, 4, 3, 5, -1]].astype(np.float32).copy()

@@ -121,6 +121,11 @@ struct DecodeArgs {
   float* boxes;   // (B, cells, nb)
   float* score;   // (B, cells): score of valid cells, -1 otherwise
   int* label;     // (B, cells)
+  // geometry-aware head (E2ESWVoteHead.decode, e2e_swv_head.py:313-366): Cartesian centre = reg + offset_grid, score rectified by
+  // the IoU branch, rot = atan2(rot[1], rot[0]), rectified heading wrapped into (-pi, pi]
+  int swv;
+  const float* iou; int iou_ps; int iou_factor;
+  const float* grid;   // offset_grid, planar (2, H, W)
 };
 
 __global__ void decode_kernel(DecodeArgs a) {
@@ -132,13 +137,27 @@ __global__ void decode_kernel(DecodeArgs a) {
     const float* ph = a.hm + i * a.hm_ps;
     float best = -1.f;
     int lab = 0;
+    float q = 1.f;
+    if (a.swv && a.iou) {
+      const float u = fminf(fmaxf((a.iou[i * a.iou_ps] + 1.f) * 0.5f, 0.f), 1.f);
+      q = a.iou_factor == 1 ? u : powf(u, (float)a.iou_factor);
+    }
     for (int c = 0; c < a.ncls; ++c) {
-      const float s = 1.f / (1.f + expf(-ph[c]));
+      const float s = (1.f / (1.f + expf(-ph[c]))) * q;
       if (s > best) { best = s; lab = c; }   // first maximum, as torch.max
     }
     const float* pr = a.reg + i * a.reg_ps;
     float x, y, r = atan2f(a.rot[i * a.rot_ps], a.rot[i * a.rot_ps + 1]), azs = 0.f;
-    if (a.cylinder) {
+    if (a.swv) {
+      x = pr[0] + a.grid[cell];
+      y = pr[1] + a.grid[cells + cell];
+      r = atan2f(a.rot[i * a.rot_ps + 1], a.rot[i * a.rot_ps]);
+      if (a.rectify) {
+        r += atan2f(y, x);
+        if (r > 3.14159265358979323846f) r -= 6.28318530717958647692f;
+        else if (r < -3.14159265358979323846f) r += 6.28318530717958647692f;
+      }
+    } else if (a.cylinder) {
       const float rho = (float)xx * a.sx + a.x0, az = (float)yy * a.sy + a.y0;
       x = rho * cosf(az) + pr[0];
       y = rho * sinf(az) + pr[1];
@@ -435,6 +454,34 @@ Ws carve(void* base, int batch, int cells, int nb, int pre_max, int post_max) {
   return w;
 }
 
+// decode -> select / sort -> IoU masks -> greedy reduce -> gather, shared by the CenterHead and the E2ESWVoteHead entry points
+int run_decode_nms(DecodeArgs a, const float* post_center_range, float nms_iou_threshold, int per_class_nms, int pre_max, int post_max,
+                   float* out_boxes, float* out_scores, int64_t* out_labels, int32_t* out_cells, int32_t* out_count, void* workspace,
+                   size_t workspace_bytes, pn_stream_t stream) {
+  const int nb = a.nb, cells = a.H * a.W, batch = a.B;
+  Ws ws = carve(workspace, batch, cells, nb, pre_max, post_max);
+  PN_REQUIRE(workspace_bytes >= ws.bytes, "decode_nms: workspace too small");
+  hipStream_t st = pn::S(stream);
+  for (int k = 0; k < 3; ++k) { a.lo[k] = post_center_range[k]; a.hi[k] = post_center_range[3 + k]; }
+  a.boxes = ws.boxes; a.score = ws.score; a.label = ws.label;
+  const size_t total = (size_t)batch * cells;
+  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, st, a);
+  static bool sort_attr = false;
+  if (!sort_attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortLds);
+    sort_attr = true;
+  }
+  hipLaunchKernelGGL(select_sort_kernel, dim3(batch), dim3(kSortThreads), kSortLds, st, ws.score, ws.boxes, cells, nb, pre_max, ws.sel_cell,
+                     ws.nms_boxes, ws.n_sel, ws.label, ws.sel_label);
+  const int cbk = (pre_max + 63) / 64;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(cbk, cbk, batch), dim3(64), 0, st, ws.nms_boxes, ws.n_sel, pre_max, cbk, nms_iou_threshold, ws.mask,
+                     ws.sel_label, per_class_nms != 0);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(batch), dim3(64), 0, st, ws.mask, ws.n_sel, pre_max, cbk, post_max, ws.keep, out_count);
+  hipLaunchKernelGGL(gather_kernel, dim3((post_max + 127) / 128, batch), dim3(128), 0, st, ws.keep, out_count, ws.sel_cell, ws.boxes, ws.score,
+                     ws.label, cells, nb, pre_max, post_max, out_boxes, out_scores, out_labels, out_cells);
+  return pn::check_launch("decode_nms");
+}
+
 }  // namespace
 
 extern "C" {
@@ -454,33 +501,32 @@ int pn_center_decode_nms_f32(const float* hm, int hm_pixel_stride, int classes, 
              "center_decode_nms: null pointer");
   PN_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && classes >= 1, "center_decode_nms: bad sizes");
   PN_REQUIRE(pre_max >= 1 && pre_max <= 4096 && post_max >= 1, "center_decode_nms: nms_pre_max_size must be in [1, 4096]");
-  const int nb = vel ? 9 : 7, cells = h * w;
-  Ws ws = carve(workspace, batch, cells, nb, pre_max, post_max);
-  PN_REQUIRE(workspace_bytes >= ws.bytes, "center_decode_nms: workspace too small");
-  hipStream_t st = pn::S(stream);
   DecodeArgs a{};
   a.hm = hm; a.hm_ps = hm_pixel_stride; a.ncls = classes; a.reg = reg; a.reg_ps = reg_pixel_stride; a.hei = height; a.hei_ps = height_pixel_stride;
   a.dim = dim; a.dim_ps = dim_pixel_stride; a.rot = rot; a.rot_ps = rot_pixel_stride; a.vel = vel; a.vel_ps = vel_pixel_stride;
-  a.B = batch; a.H = h; a.W = w; a.cylinder = cylinder; a.rectify = rectify; a.nb = nb;
+  a.B = batch; a.H = h; a.W = w; a.cylinder = cylinder; a.rectify = rectify; a.nb = vel ? 9 : 7;
   a.sx = step_x; a.sy = step_y; a.x0 = origin_x; a.y0 = origin_y; a.thr = score_threshold;
-  for (int k = 0; k < 3; ++k) { a.lo[k] = post_center_range[k]; a.hi[k] = post_center_range[3 + k]; }
-  a.boxes = ws.boxes; a.score = ws.score; a.label = ws.label;
-  const size_t total = (size_t)batch * cells;
-  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, st, a);
-  static bool sort_attr = false;
-  if (!sort_attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortLds);
-    sort_attr = true;
-  }
-  hipLaunchKernelGGL(select_sort_kernel, dim3(batch), dim3(kSortThreads), kSortLds, st, ws.score, ws.boxes, cells, nb, pre_max, ws.sel_cell,
-                     ws.nms_boxes, ws.n_sel, ws.label, ws.sel_label);
-  const int cbk = (pre_max + 63) / 64;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(cbk, cbk, batch), dim3(64), 0, st, ws.nms_boxes, ws.n_sel, pre_max, cbk, nms_iou_threshold, ws.mask,
-                     ws.sel_label, per_class_nms != 0);
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(batch), dim3(64), 0, st, ws.mask, ws.n_sel, pre_max, cbk, post_max, ws.keep, out_count);
-  hipLaunchKernelGGL(gather_kernel, dim3((post_max + 127) / 128, batch), dim3(128), 0, st, ws.keep, out_count, ws.sel_cell, ws.boxes, ws.score,
-                     ws.label, cells, nb, pre_max, post_max, out_boxes, out_scores, out_labels, out_cells);
-  return pn::check_launch("center_decode_nms");
+  return run_decode_nms(a, post_center_range, nms_iou_threshold, per_class_nms, pre_max, post_max, out_boxes, out_scores, out_labels, out_cells,
+                        out_count, workspace, workspace_bytes, stream);
+}
+
+int pn_swv_decode_nms_f32(const float* hm, int hm_pixel_stride, int classes, const float* reg, int reg_pixel_stride, const float* height,
+                          int height_pixel_stride, const float* dim, int dim_pixel_stride, const float* rot, int rot_pixel_stride,
+                          const float* iou, int iou_pixel_stride, int iou_factor, const float* offset_grid, int batch, int h, int w,
+                          int rectify, float score_threshold, const float* post_center_range, float nms_iou_threshold, int per_class_nms,
+                          int pre_max, int post_max, float* out_boxes, float* out_scores, int64_t* out_labels, int32_t* out_cells,
+                          int32_t* out_count, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(hm && reg && height && dim && rot && offset_grid && post_center_range && out_boxes && out_scores && out_labels && out_cells &&
+                 out_count && workspace, "swv_decode_nms: null pointer");
+  PN_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && classes >= 1 && iou_factor >= 0, "swv_decode_nms: bad sizes");
+  PN_REQUIRE(pre_max >= 1 && pre_max <= 4096 && post_max >= 1, "swv_decode_nms: nms_pre_max_size must be in [1, 4096]");
+  DecodeArgs a{};
+  a.hm = hm; a.hm_ps = hm_pixel_stride; a.ncls = classes; a.reg = reg; a.reg_ps = reg_pixel_stride; a.hei = height; a.hei_ps = height_pixel_stride;
+  a.dim = dim; a.dim_ps = dim_pixel_stride; a.rot = rot; a.rot_ps = rot_pixel_stride; a.vel = nullptr; a.vel_ps = 0;
+  a.B = batch; a.H = h; a.W = w; a.cylinder = 1; a.rectify = rectify; a.nb = 7; a.thr = score_threshold;
+  a.swv = 1; a.iou = iou; a.iou_ps = iou_pixel_stride; a.iou_factor = iou_factor; a.grid = offset_grid;
+  return run_decode_nms(a, post_center_range, nms_iou_threshold, per_class_nms, pre_max, post_max, out_boxes, out_scores, out_labels, out_cells,
+                        out_count, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -258,4 +258,54 @@ class E2ESWVoteHead(nn.Module):
         raise NotImplementedError("E2ESWVoteHead.loss (SetCriterion / TimeMatcher / vote map targets) is not built yet (SURVEY.md 8f next-3)")
 
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
-        raise NotImplementedError("decode + NMS (SURVEY.md 8f next-2) is outside this round's hot path")
+        """decode + rotated NMS on the device (e2e_swv_head.py:262-470, restated from its text: that code does not run in the
+        reference).  Score = sigmoid(hm) rectified by the IoU branch, Cartesian centre = reg + offset_grid, optional heading
+        rectification; multi-class rotate_nms_pcdet or test_cfg.per_class_nms.  ``device_only=True`` returns fixed-size device
+        tensors + a device count (hipGraph capturable); otherwise the reference's list of dicts (one host sync for the counts)."""
+        import ctypes as C
+        lib = hip.load()
+        get = (lambda k, d=None: test_cfg.get(k, d)) if hasattr(test_cfg, "get") else (lambda k, d=None: getattr(test_cfg, k, d))
+        for flag in ("double_flip", "stateful_nms", "panoptic"):
+            if get(flag, False):
+                raise NotImplementedError(f"predict: test_cfg.{flag} is not built")
+        if kwargs.get("prev_dets") is not None or kwargs.get("sec_id", 0) != 0:
+            raise NotImplementedError("predict: sector streaming (prev_dets / sec_id > 0) is not built")
+        if len(preds_dicts["det_preds"]) != 1:
+            raise NotImplementedError("E2ESWVoteHead.predict: one task (the reference's Waymo config has one)")
+        nms = get("nms")
+        nget = (lambda k: nms[k]) if isinstance(nms, dict) else (lambda k: getattr(nms, k))
+        pre_max, post_max, iou_thr = int(nget("nms_pre_max_size")), int(nget("nms_post_max_size")), float(nget("nms_iou_threshold"))
+        per_class = bool(get("per_class_nms", False))
+        if per_class:
+            pre_max = 4096
+        pcr = [float(v) for v in get("post_center_limit_range")]
+        assert len(pcr) == 6
+        pd = preds_dicts["det_preds"][0]
+        hm = pd["hm"]
+        hip.require_device(hm)
+        b, ncls, h, w = hm.shape
+        for k in ("hm", "reg", "height", "dim", "rot") + (("iou",) if "iou" in pd else ()):
+            t = pd[k]
+            assert t.stride(1) == 1 and t.stride(2) == w * t.stride(3), "head tensors must be channels-last views"
+        assert tuple(self.offset_grid.shape) == (1, 2, h, w), "head map does not match the configured offset grid"
+        dev = hm.device
+        grid = self.offset_grid[0].contiguous()
+        out_boxes = torch.empty((b, post_max, 7), dtype=torch.float32, device=dev)
+        out_scores = torch.empty((b, post_max), dtype=torch.float32, device=dev)
+        out_labels = torch.empty((b, post_max), dtype=torch.int64, device=dev)
+        out_cells = torch.empty((b, post_max), dtype=torch.int32, device=dev)
+        out_count = torch.empty((b,), dtype=torch.int32, device=dev)
+        wsb = lib.pn_center_decode_nms_workspace_bytes(b, h * w, 7, pre_max, post_max)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        iou = pd.get("iou") if self.iou_loss else None
+        hip.call("pn_swv_decode_nms_f32", hm.data_ptr(), hm.stride(3), ncls, pd["reg"].data_ptr(), pd["reg"].stride(3), pd["height"].data_ptr(),
+                 pd["height"].stride(3), pd["dim"].data_ptr(), pd["dim"].stride(3), pd["rot"].data_ptr(), pd["rot"].stride(3), hip.ptr(iou),
+                 0 if iou is None else iou.stride(3), int(getattr(self, "iou_factor", 1)), grid.data_ptr(), b, h, w, int(bool(get("rectify", False))),
+                 float(get("score_threshold")), (C.c_float * 6)(*pcr), iou_thr, int(per_class), pre_max, post_max, out_boxes.data_ptr(),
+                 out_scores.data_ptr(), out_labels.data_ptr(), out_cells.data_ptr(), out_count.data_ptr(), ws.data_ptr(), wsb, hip.stream())
+        if kwargs.get("device_only", False):
+            return dict(box3d_lidar=out_boxes, scores=out_scores, label_preds=out_labels, cells=out_cells, count=out_count)
+        counts = out_count.cpu().tolist()
+        metas = example.get("metadata", [None] * b) if isinstance(example, dict) else [None] * b
+        return [dict(box3d_lidar=out_boxes[i, :n], scores=out_scores[i, :n], label_preds=out_labels[i, :n], cells=out_cells[i, :n], metadata=metas[i])
+                for i, n in enumerate(counts)]

@@ -138,6 +138,43 @@ def test_predict_per_class_nms(dev, clib):
     assert len(got[0]["cells"]) > len(plain[0]["cells"]) or len(got[0]["cells"]) == 83
 
 
+@pytest.mark.parametrize("rectify", [False, True])
+def test_swv_head_predict_matches_oracle(dev, clib, rectify):
+    """E2ESWVoteHead.predict (the Waymo PARTNER config's head: IoU-rectified scores, Cartesian reg + offset grid, one class) with the
+    config's own test_cfg sizes (pre 4096 / post 500 / IoU 0.7) against the oracle restatement"""
+    import os
+    import partner_amd as P
+    from oracle import polar_oracle as O
+    cfg = P.Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "waymo", "polar_partner_c4.py"))
+    head = P.build_bbox_head(cfg.model["bbox_head"] if isinstance(cfg.model, dict) else cfg.model.bbox_head).to(dev).eval()
+    h, w = 256, 144
+    p = synth_head_outputs(2, h, w, 1, 120, seed=61, with_vel=False)
+    r = np.random.default_rng(9)
+    p["iou"] = r.uniform(-1.2, 1.2, (2, h, w, 1)).astype(np.float32)
+    p["reg"] = r.uniform(-0.5, 0.5, (2, h, w, 2)).astype(np.float32)
+    test_cfg = dict(post_center_limit_range=[-80.0, -80.0, -10.0, 80.0, 80.0, 10.0], score_threshold=0.1, rectify=rectify,
+                    nms=dict(nms_pre_max_size=4096, nms_post_max_size=500, nms_iou_threshold=0.7))
+    preds = {"det_preds": [{k: torch.from_numpy(v).to(dev).permute(0, 3, 1, 2) for k, v in p.items()}]}
+    got = head.predict(dict(metadata=["a", "b"]), preds, test_cfg)
+    boxes, hm = O.swv_decode(p, head.offset_grid[0].cpu().numpy(), int(head.iou_factor), rectify)
+
+    def c_nms(sorted_boxes, thr):
+        keep = np.empty(len(sorted_boxes), np.int64)
+        sb = np.ascontiguousarray(sorted_boxes, np.float32)
+        n = clib.ov_nms_sorted(sb.ctypes.data_as(C.POINTER(C.c_float)), len(sb), C.c_float(thr), keep.ctypes.data_as(C.POINTER(C.c_int64)))
+        return keep[:n]
+
+    for i in range(2):
+        ref = O.center_post_process(boxes[i], hm[i], 0.1, test_cfg["post_center_limit_range"], 0.7, 4096, 500, c_nms)
+        assert len(ref["cells"]) > 50
+        np.testing.assert_array_equal(got[i]["cells"].cpu().numpy(), ref["cells"])
+        np.testing.assert_allclose(got[i]["scores"].cpu().numpy(), ref["scores"], rtol=1e-5, atol=1e-7)
+        d = np.abs(got[i]["box3d_lidar"].cpu().numpy() - ref["box3d_lidar"])
+        d[:, -1] = np.minimum(d[:, -1], np.abs(d[:, -1] - 2 * np.pi))
+        assert d.max() < 2e-4
+    assert got[1]["metadata"] == "b"
+
+
 def test_detector_predict_with_config_test_cfg(dev):
     """the nuScenes config's own test_cfg (per_class_nms, rectify) through the detector: forward -> bbox_head.predict"""
     import os

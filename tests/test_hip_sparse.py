@@ -91,10 +91,17 @@ def test_voxelnet_v3_end_to_end_waymo_config(dev):
     coords4 = torch.cat([torch.zeros((coors.shape[0], 1), dtype=coors.dtype, device=dev), coors], 1)
     example = dict(voxels=voxels, coordinates=coords4, num_points=num, num_voxels=[int(voxels.shape[0])], shape=[np.array([1152, 2048, 40])],
                    metadata=[dict(token="t0")])
-    out = m(example, return_loss=False)["det_preds"][0]
+    preds = m(example, return_loss=False)
+    out = preds["det_preds"][0]
     assert tuple(out["hm"].shape) == (1, 1, 256, 144) and tuple(out["reg"].shape) == (1, 2, 256, 144)
     for k, v in out.items():
         assert torch.isfinite(v).all(), k
+    # ... and on to boxes with the config's own test_cfg (E2ESWVoteHead.predict: IoU-rectified scores, rotated NMS)
+    out["hm"] = out["hm"] + 3.0                          # random-init weights give no peaks: lift the logits over the threshold
+    dets = m.bbox_head.predict(example, preds, w.test_cfg)
+    assert len(dets) == 1 and dets[0]["metadata"] == dict(token="t0")
+    n = dets[0]["scores"].numel()
+    assert 0 < n <= 500 and dets[0]["box3d_lidar"].shape == (n, 7) and torch.isfinite(dets[0]["box3d_lidar"]).all()
 
 
 def test_voxelnet_v3_batch_of_two(dev):
