@@ -194,6 +194,15 @@ def test_detector_predict_with_config_test_cfg(dev):
     assert 0 < n <= 83 and out[0]["box3d_lidar"].shape == (n, 9) and torch.isfinite(out[0]["box3d_lidar"]).all()
     s = out[0]["scores"]
     assert (s[:-1] >= s[1:]).all()
+    # the detector's own forward(example, return_loss=False) ends in predict when it was built with a test_cfg (point_pillars.py:104-108)
+    spec = ops.GridSpec.from_range(synth.NUSC_RANGE, synth.NUSC_VOXEL)
+    gi, _ = ops.grid_index(pts, torch.tensor([0, 30000], dtype=torch.int32, device=dev), 1, spec)
+    example = dict(points=pts, grid_ind=gi, num_points=[30000], voxel_size=np.stack([np.float32(synth.NUSC_VOXEL)]),
+                   pc_range=np.stack([np.float32(synth.NUSC_RANGE)]), grid_size=np.stack([np.array([512, 512, 1])]), metadata=["tok"])
+    det = m(example, return_loss=False)
+    assert set(det) == {"det"} and len(det["det"]) == 1 and set(det["det"][0]) >= {"box3d_lidar", "scores", "label_preds", "metadata"}
+    raw = m(example, return_loss=False, raw_preds=True)
+    assert "det_preds" in raw
 
 
 def test_predict_large_pre_max(dev, clib):
