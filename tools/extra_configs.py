@@ -172,6 +172,12 @@ t = timeit(sparse_only)
 print(f"C4  voxelize + VFE + SpMiddleResNetFHD, 64-beam synthetic sweep (surfaces): {t:.3f} ms")
 t = timeit(frame4)
 print(f"C4  end to end, f32 (B=1, 180k pts): {t:.3f} ms  ({1e3 / t:.1f} frames/s)")
+# decode + NMS of the geometry-aware head with the config's test_cfg (pre 4096 / post 500 / IoU 0.7) on lifted logits
+_p4 = frame4()
+_p4["det_preds"][0]["hm"] = _p4["det_preds"][0]["hm"] + 3.0
+t = timeit(lambda: m4.bbox_head.predict(dict(metadata=[None]), _p4, cfg4.test_cfg, device_only=True), n=20, warm=5)
+print(f"C4  E2ESWVoteHead decode + rotated NMS (256 x 144 map, pre 4096 / post 500, device only): {t:.3f} ms "
+      f"({int(m4.bbox_head.predict(dict(metadata=[None]), _p4, cfg4.test_cfg, device_only=True)['count'][0])} boxes)")
 m4.neck.set_compute_dtype("bf16"); m4.bbox_head.set_compute_dtype("bf16")
 t = timeit(frame4)
 print(f"C4  end to end, bf16 BEV convs (RPN + head branches): {t:.3f} ms  ({1e3 / t:.1f} frames/s)")
