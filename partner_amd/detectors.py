@@ -137,14 +137,44 @@ class PointPillars(SingleStageDetector):
 
 @DETECTORS.register_module
 class VoxelNet(SingleStageDetector):
-    """VoxelNet family (voxelnet.py:27-131): needs the sparse 3-D middle encoder."""
+    """VoxelNet (voxelnet.py:27-131): reader -> sparse 3-D middle encoder -> RPN -> head, the detector of the reference's
+    CenterPoint-style voxel configs (VoxelNetV3 is this plus the re-alignment attention).  Eval mode, on the HIP kernels."""
 
     def __init__(self, reader, backbone, neck, bbox_head, seg_head=None, part_head=None, train_cfg=None, test_cfg=None,
                  pretrained=None):
         super().__init__(reader, backbone, neck, bbox_head, seg_head, part_head, train_cfg, test_cfg, pretrained)
 
+    def extract_feat_hard(self, data):
+        """voxelnet.py:47-58; returns the NHWC neck output"""
+        feats = self.reader(data["features"], data["num_voxels"])
+        x = self.backbone.forward_nhwc(feats, data["coors"], data["batch_size"], data["input_shape"])
+        return self.neck.forward_nhwc(x) if self.with_neck else x
+
+    def extract_feat_dynamic(self, data):
+        """voxelnet.py:60-70: dynamic voxel encoder (mean of the points of a voxel) -> sparse backbone on unq"""
+        feats, unq = self.reader(data)
+        x = self.backbone.forward_nhwc(feats, unq.to(torch.int32), data["batch_size"], [int(v) for v in data["grid_size"]])
+        return self.neck.forward_nhwc(x) if self.with_neck else x
+
     def forward(self, example, return_loss=True, **kwargs):
-        raise NotImplementedError("VoxelNet forward needs the sparse 3-D backbone (SURVEY.md 8f next-1), not built yet")
+        eval_only(self, "VoxelNet")
+        if "voxels" in example:
+            hip.require_device(example["voxels"], example["coordinates"])
+            data = dict(features=example["voxels"], num_voxels=example["num_points"], coors=example["coordinates"],
+                        batch_size=len(example["num_voxels"]), input_shape=[int(v) for v in example["shape"][0]])
+            x = self.extract_feat_hard(data)
+        else:
+            hip.require_device(example["points"], example["grid_ind"])
+            data = dict(points=example["points"], grid_ind=example["grid_ind"], num_points=example["num_points"],
+                        batch_size=len(example["num_points"]), voxel_size=example["voxel_size"][0], pc_range=example["pc_range"][0],
+                        grid_size=example["grid_size"][0])
+            x = self.extract_feat_dynamic(data)
+        preds = self.bbox_head(ops.as_nchw(x))
+        if return_loss:
+            return self.bbox_head.loss(example, preds)
+        if kwargs.get("raw_preds", False) or self.test_cfg is None:
+            return preds
+        return {"det": self.bbox_head.predict(example, preds, self.test_cfg, **kwargs)}
 
 
 @DETECTORS.register_module
