@@ -12,8 +12,11 @@ from . import hip, ops
 
 
 class FrameEngine:
-    def __init__(self, model, batch: int, points_per_sweep: int, spec: ops.GridSpec = None, point_features: int = 5):
+    def __init__(self, model, batch: int, points_per_sweep: int, spec: ops.GridSpec = None, point_features: int = 5, test_cfg=None):
+        """``test_cfg``: when given, the frame ends in ``bbox_head.predict(..., device_only=True)`` inside the same graph
+        (fixed-size box / score / label buffers + a device count); otherwise the outputs are the head tensors."""
         hip.load()
+        self.test_cfg = test_cfg
         self.model = model.eval()
         dev = next(model.parameters()).device
         hip.require_device(next(model.parameters()))
@@ -38,8 +41,12 @@ class FrameEngine:
         polar = ops.cart_to_polar(self.cart)
         if hasattr(self.model, "attns"):   # VoxelNetV3 (Waymo PARTNER config): single-sample hard-voxel path
             assert self.batch == 1, "the fused VoxelNetV3 path takes one sample per frame"
-            return self.model.forward_points(polar)
-        return self.model.forward_points(polar, self.offsets, self.batch, self.spec, canvas=self.canvas)
+            preds = self.model.forward_points(polar)
+        else:
+            preds = self.model.forward_points(polar, self.offsets, self.batch, self.spec, canvas=self.canvas)
+        if self.test_cfg is None:
+            return preds
+        return self.model.bbox_head.predict(dict(metadata=[None] * self.batch), {"det_preds": [preds]}, self.test_cfg, device_only=True)
 
     def capture(self, warmup: int = 3, stream: "torch.cuda.Stream" = None) -> "FrameEngine":
         """capture the frame into a HIP graph; `stream` (optional) is the stream the graph will be
