@@ -563,6 +563,18 @@ int pn_swv_decode_nms_f32(const float *hm, int hm_pixel_stride, int classes, con
                           pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Segmentation head SingleConvHead (det3d/models/seg_heads/seg_head.py:53-83, 176-195), the `seg` super-task of the
+ * reference's nuScenes polar config; secondary to the detection hot path.  The head's 1x1 convolution over
+ * cat[canvas, bilinear_up(x2)] is evaluated as conv(canvas) + bilinear_up(conv(x2)) (pn_conv2d_nhwc_f32 twice):
+ *   pn_bilinear_upsample_add_f32   out (B,H,W,C) += bilinear(low (B,h,w,C)), F.interpolate(align_corners=False) weights
+ *   pn_seg_point_labels            labels[i] = 1 + argmax_c seg[y_i, x_i, c] for one sample; grid_ind rows [z, y, x] (int64)
+ */
+int pn_bilinear_upsample_add_f32(const float *low, int batch, int h, int w, int c, int out_h, int out_w,
+                                 float *out, pn_stream_t stream);
+int pn_seg_point_labels(const float *seg_sample, int h, int w, int classes, const int64_t *grid_ind,
+                        int n, int64_t *labels, pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * next-1  sparse 3-D convolutions of the middle encoder SpMiddleResNetFHD
  * (det3d/models/backbones/scn.py:17-192; the arithmetic is the third-party spconv package there: SubMConv3d /
  * SparseConv3d / SparseConvTensor.dense -- parity unpinned, restated in oracle/polar_oracle.py).

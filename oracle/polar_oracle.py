@@ -378,6 +378,20 @@ def center_head(sd: SD, prefix: str, x: Tensor, tasks_num_classes: Sequence[int]
     return rets
 
 
+def single_conv_head(sd: SD, prefix: str, x1: Tensor, x2: Tensor) -> Tensor:
+    """SingleConvHead.forward (det3d/models/seg_heads/seg_head.py:75-83): bilinear up-sampling of the RPN output to the canvas,
+    concatenation, one convolution.  -> seg_preds (B, num_classes, H, W)"""
+    x = F.interpolate(x2, size=x1.shape[-2:], mode="bilinear")
+    w = sd[prefix + "conv.weight"]
+    return F.conv2d(torch.cat([x1, x], dim=1), w, sd[prefix + "conv.bias"], padding=w.shape[-1] // 2)
+
+
+def seg_point_labels(seg_preds: Tensor, valid_grid_ind: Sequence[np.ndarray]) -> List[np.ndarray]:
+    """SingleConvHead.predict (seg_head.py:176-195) for a 2-D prediction map: label = 1 + argmax at [theta, r] of every point"""
+    lab = torch.argmax(seg_preds, dim=1) + 1
+    return [lab[i][torch.from_numpy(np.asarray(g))[:, 1], torch.from_numpy(np.asarray(g))[:, 2]].numpy() for i, g in enumerate(valid_grid_ind)]
+
+
 # ======================================================================================
 # L1  CenterHead.loss                     det3d/models/bbox_heads/center_head.py:244-288
 #     FastFocalLoss / RegLoss             det3d/models/losses/centernet_loss.py:26-54,6-24

@@ -30,9 +30,10 @@ class SingleStageDetector(nn.Module):
         if neck is not None:
             self.neck = builder.build_neck(neck)
         self.bbox_head = builder.build_bbox_head(bbox_head) if bbox_head is not None else None
-        if seg_head is not None:
-            raise NotImplementedError("segmentation heads are outside the hot path (SURVEY.md 2.1); build with seg_head=None")
-        self.seg_head = None
+        # the `seg` super-task of the nuScenes polar config (SingleConvHead): forward + per-point prediction, eval only
+        self.seg_head = builder.build_seg_head(seg_head) if seg_head is not None else None
+        if part_head is not None:
+            raise NotImplementedError("part heads are outside the hot path (SURVEY.md 2.1); build with part_head=None")
         self.part_head = None
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
         self.init_weights(pretrained)
@@ -112,8 +113,9 @@ class PointPillars(SingleStageDetector):
             hip.require_device(voxels, coords)
             feats = self.reader(voxels, example["num_points"], coords)
             x1 = self.backbone(feats, coords, len(example["num_voxels"]), [int(v) for v in example["shape"][0]])
-            x2 = self.neck.forward_nhwc(ops.to_nhwc(x1)) if self.with_neck else ops.to_nhwc(x1)
-            return self.bbox_head(ops.as_nchw(x2))
+            x1h = ops.to_nhwc(x1)
+            x2 = self.neck.forward_nhwc(x1h) if self.with_neck else x1h
+            return self._heads(x1h, x2)
         points, grid_ind = example["points"], example["grid_ind"]
         hip.require_device(points, grid_ind)
         batch = len(example["num_points"])
@@ -124,15 +126,33 @@ class PointPillars(SingleStageDetector):
         keys = ops.keys_from_grid_ind(grid_ind.to(torch.int64).contiguous(), spec, batch)
         canvas = self.encode_canvas(points.contiguous(), keys, spec, batch)
         x2 = self.neck.forward_nhwc(canvas)
-        return self.bbox_head(ops.as_nchw(x2))
+        return self._heads(canvas, x2)
+
+    def _heads(self, x1_nhwc: torch.Tensor, x2_nhwc: torch.Tensor) -> Dict[str, object]:
+        """point_pillars.py:91-96: the detection head on the RPN output, the segmentation head (when the config has one) on the
+        canvas + the RPN output"""
+        preds = {}
+        if self.bbox_head is not None:
+            preds.update(self.bbox_head(ops.as_nchw(x2_nhwc)))
+        if self.seg_head is not None:
+            seg = self.seg_head.forward_nhwc(x1_nhwc, x2_nhwc)
+            preds["seg_preds"] = seg.permute(0, 3, 1, 2)[:, :self.seg_head.num_classes]
+        return preds
 
     def forward(self, example, return_loss=True, **kwargs):
         preds = self.extract_preds(example)
         if return_loss:
+            if self.seg_head is not None:
+                raise NotImplementedError("training with the segmentation head is out of scope (SegLoss is not built)")
             return self.bbox_head.loss(example, preds)
         if kwargs.get("raw_preds", False) or self.test_cfg is None:
             return preds
-        return {"det": self.bbox_head.predict(example, preds, self.test_cfg, **kwargs)}
+        ret = {}
+        if self.bbox_head is not None:
+            ret["det"] = self.bbox_head.predict(example, preds, self.test_cfg, **kwargs)
+        if self.seg_head is not None:
+            ret["seg"] = self.seg_head.predict(example, preds, self.test_cfg)
+        return ret
 
 
 @DETECTORS.register_module

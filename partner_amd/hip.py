@@ -103,6 +103,8 @@ SIGNATURES = {
                                       _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "pn_swv_decode_nms_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _F, _P, _F, _I, _I, _I,
                                    _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "pn_bilinear_upsample_add_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "pn_seg_point_labels": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     "pn_sparse_index_bytes": (_SZ, [_U64]),
     "pn_sparse_index_from_coords": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "pn_sparse_index_downsample": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),

@@ -599,7 +599,26 @@ def gen_pillar_static():
     save("pillar_static.npz", **out)
 
 
+# ----------------------------------------------------------------------------- segmentation head (the config's `seg` super-task)
+def gen_seg_head():
+    """SingleConvHead of the reference (seg_heads/seg_head.py:53-83, 176-195) on a small canvas + RPN map, eval: logits and the
+    per-point labels of its predict()"""
+    from det3d.models.seg_heads.seg_head import SingleConvHead
+    head = SingleConvHead(kernel=1, num_classes=6, in_channels=8 + 12, weight=2, loss=dict(type="SegLoss", ignore=-1)).eval()
+    synth.load_filled(head, base_seed=77)
+    r = np.random.default_rng(3)
+    x1 = torch.from_numpy(r.standard_normal((2, 8, 16, 24)).astype(np.float32))
+    x2 = torch.from_numpy(r.standard_normal((2, 12, 4, 6)).astype(np.float32))
+    with torch.no_grad():
+        preds = head(x1, x2)
+    gi = [np.stack([np.zeros(50, np.int64), r.integers(0, 16, 50), r.integers(0, 24, 50)], 1) for _ in range(2)]
+    example = dict(num_points=[50, 50], metadata=[dict(token="a"), dict(token="b")], valid_grid_ind=[torch.from_numpy(g) for g in gi])
+    labels = [list(d.values())[0].numpy() for d in head.predict(example, preds, None)]
+    save("seg_head.npz", x1=x1.numpy(), x2=x2.numpy(), seg_preds=preds["seg_preds"].numpy(), gi0=gi[0], gi1=gi[1], labels0=labels[0],
+         labels1=labels[1], state_keys=np.array(list(head.state_dict().keys())))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static"]
+    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static", "seg_head"]
     for w in which:
         globals()["gen_" + w]()

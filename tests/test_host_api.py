@@ -49,13 +49,12 @@ def test_config_dict_and_file():
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
 def test_reference_configs_load_unchanged():
     """configs/nusc and configs/waymo of the reference parse through our Config + det3d shim;
-    the nuScenes polar model builds (seg_head set aside: segmentation is out of scope)."""
+    the nuScenes polar model builds from the file as it is, detection AND segmentation head (super_tasks = ['det', 'seg'])."""
     cfg = P.Config.fromfile(os.path.join(REF, "configs/nusc/pp/polarstream_det_n_seg_1_sector.py"))
     assert cfg.model.reader.type == "DynamicPFNet" and cfg.assigner.out_size_factor == 4
-    model = dict(cfg.model)
-    model["seg_head"] = None
-    m = P.build_detector(model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
-    assert sum(p.numel() for p in m.parameters()) == 5618580
+    m = P.build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    assert type(m.seg_head).__name__ == "SingleConvHead" and m.test_cfg["per_class_nms"]
+    assert sum(p.numel() for p in m.parameters()) == 5618580 + 512 * 16 + 16
     w = P.Config.fromfile(os.path.join(REF, "configs/waymo/voxelnet/waymo_partner_36epoch.py"))
     assert w.model.type == "VoxelNetV3" and w.model.neck.ds_num_filters == [128, 256]
     neck = P.build_neck(w.model.neck)  # set_* keys are swallowed like in the reference

@@ -460,3 +460,15 @@ def test_static_pillar_feature_net_restatement(golden, tag, dist):
     y = O.pillar_feature_net_static(sd, "", torch.from_numpy(g["voxels"]), torch.from_numpy(g["num"]), torch.from_numpy(g["coors"]).long(),
                                     [0.8, 0.8, 8.0], [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], with_distance=dist)
     close(y, g[f"{tag}_features"], 1e-5, 1e-5)
+
+
+def test_single_conv_seg_head(golden):
+    """the config's `seg` super-task: oracle restatement of SingleConvHead.forward / predict vs the reference (seg_head.npz)"""
+    g = golden("seg_head.npz")
+    sd = filled_sd({"conv.weight": (6, 20, 1, 1), "conv.bias": (6,)}, 77)
+    assert list(g["state_keys"]) == list(sd)
+    seg = O.single_conv_head(sd, "", torch.from_numpy(g["x1"]), torch.from_numpy(g["x2"]))
+    close(seg, g["seg_preds"], rtol=1e-5, atol=1e-6)
+    lab = O.seg_point_labels(seg, [g["gi0"], g["gi1"]])
+    np.testing.assert_array_equal(lab[0], g["labels0"])
+    np.testing.assert_array_equal(lab[1], g["labels1"])
