@@ -6,6 +6,11 @@ only, fp32) on N MI355X GPUs of one node.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Launched bare with N > 1 (no RANK / WORLD_SIZE in the environment) the script starts N child
+processes of itself, one per GPU, before anything touches the GPU (the reference launches one
+process per GPU too: README.md:64, tools/train.py:103-107), waits for them and exits with their
+status; rank 0 prints the line.
+
 One step = one pass of the hot path over one batch (default: 1 sweep) that is already resident
 in HBM as Cartesian points: cart->polar (V0), grid indices (V1), bitmap unique-rank, bucketing,
 fused PFN + canvas (V4/V5), RPN (B1), CenterHeadSinglePos (H2) -- head tensors out.
@@ -13,11 +18,18 @@ Frames are independent, so ranks just process their own frames (weak scaling, no
 collective); the timed region is bracketed by barrier + device synchronise and the maximum
 over ranks is reported.
 
-Extra objects in the JSON line:
-  roofline     -- the dominant kernel (fp32-MFMA implicit-GEMM convolution): algorithmic FLOPs
-                  of every launch / its HIP-event duration, both summed over the timed region.
-  cpu_baseline -- the CPU oracle (oracle/polar_oracle.py, a port of the reference path checked
-                  against reference goldens) timed on this box's host cores, rank 0, N=1 only.
+Objects in the JSON line:
+  value / ms_per_step        the timed region: K hipGraph replays, `--streams` frames in flight (default 4)
+  single_stream_ms_per_step  the same K replays with ONE frame in flight (latency regime) -- the regime `roofline` is
+                             quoted in, so roofline.conv_ms_per_step <= single_stream_ms_per_step
+  roofline          the dominant kernel (fp32-MFMA implicit-GEMM convolution): algorithmic FLOPs of every launch / its
+                    own execution time (events attached to the dispatch, = rocprofv3's kernel duration), one stream
+  roofline_scatter  the scatter stage V0..V5 against the HBM roofline: algorithmic bytes of the variant that is run
+                    (persistent canvas + sparse clear: the dense canvas is never moved) / time of the stage's hipGraph
+  train_step        BASELINE configs[2]: the DDP training iteration at bs = 4 sweeps per GPU (fwd + loss + bwd + bucketed
+                    gradient all-reduce overlapped with backward + clip / wd / Adam)
+  cpu_baseline      the CPU oracle (oracle/polar_oracle.py, a port of the reference path checked against reference
+                    goldens) timed on this box's host cores, rank 0, N=1 only.
 """
 from __future__ import annotations
 
@@ -25,6 +37,8 @@ import argparse
 import json
 import logging
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,6 +51,7 @@ sys.path.insert(0, ROOT)
 from partner_amd.utils import synth  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_TBS = 8.0            # same guide: HBM3E ~8 TB/s
 
 TASKS = [dict(num_class=10, class_names=["car", "truck", "construction_vehicle", "bus", "trailer", "barrier",
                                          "motorcycle", "bicycle", "pedestrian", "traffic_cone"])]
@@ -62,8 +77,32 @@ def c2_model_cfg():
         seg_head=None, part_head=None)
 
 
-def cpu_baseline(n_points: int, batch: int, budget_s: float = 20.0, max_frames: int = 10):
-    """time the CPU oracle on the same workload (bounded sample)"""
+def host_cpu_info():
+    """(model name, physical cores, logical cpus) of this host from /proc/cpuinfo"""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return model, (len(cores) or logical or (os.cpu_count() or 1)), (logical or (os.cpu_count() or 1))
+
+
+def cpu_baseline(n_points: int, batch: int, budget_s: float = 30.0, min_frames: int = 20, max_frames: int = 40):
+    """time the CPU oracle on the same workload (bounded sample: >= 20 timed frames, <= ~30 s)"""
     from oracle import polar_oracle as O
 
     cfg = c2_model_cfg()
@@ -75,56 +114,124 @@ def cpu_baseline(n_points: int, batch: int, budget_s: float = 20.0, max_frames: 
     import partner_amd as P
     shapes = {k: _S(tuple(v.shape)) for k, v in P.build_detector(cfg).state_dict().items()}
     sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, 0).items()}
+    model_name, phys, logical = host_cpu_info()
     # torch CPU convolutions stop scaling (and collapse) beyond ~16 threads on the GPU box's host
-    # (measured: 8 thr 0.36 s, 16 thr 0.28 s, 32 thr 0.33 s, 64 thr 0.70 s, 256 thr 34 s per frame)
-    threads = min(16, os.cpu_count() or 1)
+    # (measured r1: 8 thr 0.36 s, 16 thr 0.28 s, 32 thr 0.33 s, 64 thr 0.70 s, 256 thr 34 s per frame)
+    threads = min(16, phys)
     torch.set_num_threads(threads)
     times = []
     t_all = time.perf_counter()
     with torch.no_grad():
-        for f in range(max_frames + 1):
+        for f in range(max_frames + 2):
             sweeps = [synth.synth_sweep_cart(n_points, seed=1000 + f * batch + b) for b in range(batch)]
             t0 = time.perf_counter()
             polar = [O.cart_to_polar(s) for s in sweeps]
             gi = O.with_batch_index([O.grid_index(p, synth.NUSC_RANGE, synth.NUSC_VOXEL) for p in polar])
             O.pointpillars_forward(sd, cfg, np.concatenate(polar, 0), gi, batch)
             dt = time.perf_counter() - t0
-            if f > 0:  # first frame is warm-up
+            if f > 1:  # two warm-up frames
                 times.append(dt)
-            if time.perf_counter() - t_all > budget_s and len(times) >= 2:
+            if len(times) >= max_frames or (time.perf_counter() - t_all > budget_s and len(times) >= min_frames):
                 break
+    ts = np.sort(np.array(times))
     fps = batch * len(times) / sum(times)
     return dict(value=round(fps, 4), unit="frames/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{len(times)} timed frames (+1 warm-up) of the same {n_points}-pt synthetic sweeps, batch {batch}, "
-                       f"oracle/polar_oracle.py (numpy + torch CPU fp32, {torch.get_num_threads()} threads)")
+                cpu_model=model_name, host_physical_cores=phys, host_logical_cpus=logical,
+                p50_s_per_frame=round(float(ts[len(ts) // 2]), 4),
+                sample=f"{len(times)} timed frames (+2 warm-up) of the same {n_points}-pt synthetic sweeps, batch {batch}, "
+                       f"oracle/polar_oracle.py (numpy + torch CPU fp32, {torch.get_num_threads()} threads: more threads are slower "
+                       f"on this host); survey-container cross-check of the actual reference: 1.05-1.3 frames/s on 8 vCPU (SURVEY 6)")
 
 
-def train_mode(args, model, dev, rank, world, red_dev):
-    """BASELINE configs[2]: the DDP training iteration, bs = --batch sweeps per GPU, fp32"""
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n: int) -> int:
+    """bare `python bench.py --gpus N`: start N children of this script (fresh interpreters -- nothing is re-exec'd and
+    this parent never touches the GPU), one rank per GPU, and return the worst exit status"""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:   # one rank failed: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ training leg
+class TrainLeg:
+    """BASELINE configs[2]: the DDP training iteration, bs = `batch` sweeps per GPU, fp32"""
+
+    def __init__(self, model, dev, rank, batch, n_points, total_steps):
+        from partner_amd import ops
+        from partner_amd.train import PolarPillarTrainStep
+        self.ops, self.B, self.N = ops, batch, n_points
+        self.ts = PolarPillarTrainStep(model, total_steps=max(100, total_steps))
+        self.ts.sync_initial_params()
+        pool = 2
+        self.frames = []
+        for f in range(pool):
+            cart = np.concatenate([synth.synth_sweep_cart(n_points, seed=(rank * pool + f) * batch + b) for b in range(batch)], 0)
+            self.frames.append(torch.from_numpy(cart).to(dev))
+        self.offs = torch.tensor([n_points * b for b in range(batch + 1)], dtype=torch.int32, device=dev)
+        # targets as SURVEY 8d prescribes for C3: K = 40 random boxes per frame through the (device) polar target assignment
+        gb = torch.zeros((batch, 64, 9), dtype=torch.float32)
+        gc = torch.zeros((batch, 64), dtype=torch.int32)
+        for b in range(batch):
+            boxes, classes = synth.synth_gt_boxes(40, seed=1000 + rank * batch + b)
+            gb[b, :40], gc[b, :40] = torch.from_numpy(boxes), torch.from_numpy(classes.astype(np.int32))
+        self.tg = ops.assign_heatmap_polar(gb.to(dev), gc.to(dev), torch.full((batch,), 40, dtype=torch.int32, device=dev), 10, 500, [128, 128],
+                                           np.float32(synth.NUSC_VOXEL), np.float32(synth.NUSC_RANGE), 4, 0.1, 2)
+
+    def step(self, i):
+        polar = self.ops.cart_to_polar(self.frames[i % len(self.frames)])
+        return self.ts.step(polar, self.offs, self.B, self.tg)
+
+    def allreduce_ms(self, reps=10):
+        """the gradient exchange alone: `reps` bucketed all-reduces of the flat gradient buffer, back to back"""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return 0.0
+        g = torch.zeros_like(self.ts.ps.flat_g)
+        for _ in range(2):
+            dist.all_reduce(g)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for lo, hi in self.ts.buckets:
+                dist.all_reduce(g[lo:hi])
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / reps
+
+
+def run_train(args, model, dev, rank, world, red_dev, steps, warmup):
     from partner_amd import dist_utils as D
-    from partner_amd import ops
-    from partner_amd.train import PolarPillarTrainStep
-    B, N = args.batch, args.points
-    ts = PolarPillarTrainStep(model, total_steps=max(100, args.steps + args.warmup))
-    ts.sync_initial_params()
-    pool = 2
-    frames = []
-    for f in range(pool):
-        cart = np.concatenate([synth.synth_sweep_cart(N, seed=(rank * pool + f) * B + b) for b in range(B)], 0)
-        frames.append(torch.from_numpy(cart).to(dev))
-    offs = torch.tensor([N * b for b in range(B + 1)], dtype=torch.int32, device=dev)
-    # targets as SURVEY 8d prescribes for C3: K = 40 random boxes per frame through the (device) polar target assignment
-    gb = torch.zeros((B, 64, 9), dtype=torch.float32)
-    gc = torch.zeros((B, 64), dtype=torch.int32)
-    for b in range(B):
-        boxes, classes = synth.synth_gt_boxes(40, seed=1000 + rank * B + b)
-        gb[b, :40], gc[b, :40] = torch.from_numpy(boxes), torch.from_numpy(classes.astype(np.int32))
-    tg = ops.assign_heatmap_polar(gb.to(dev), gc.to(dev), torch.full((B,), 40, dtype=torch.int32, device=dev), 10, 500, [128, 128],
-                                  np.float32(synth.NUSC_VOXEL), np.float32(synth.NUSC_RANGE), 4, 0.1, 2)
-
-    def step(i):
-        polar = ops.cart_to_polar(frames[i % pool])
-        return ts.step(polar, offs, B, tg)
+    leg = TrainLeg(model, dev, rank, args.train_batch, args.points, steps + warmup)
 
     def barrier():
         torch.cuda.synchronize()
@@ -132,32 +239,119 @@ def train_mode(args, model, dev, rank, world, red_dev):
         torch.cuda.synchronize()
 
     loss0 = None
-    for i in range(args.warmup):
-        loss = step(i)
+    for i in range(warmup):
+        loss = leg.step(i)
         loss0 = float(loss[0]) if loss0 is None else loss0
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(i)
+    for i in range(steps):
+        loss = leg.step(i)
     barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, red_dev)
+    ar = D.max_over_ranks(leg.allreduce_ms(), red_dev)
+    B = args.train_batch
+    return dict(ms_per_iter=round(1e3 * elapsed / steps, 3), frames_per_s=round(world * steps * B / elapsed, 3), sweeps_per_iter_per_gpu=B,
+                iters=steps, warmup=warmup, n_gpus=world,
+                all_reduce_ms=round(ar, 3), all_reduce="flat fp32 gradient buffer in reverse-layer-order buckets, issued during backward "
+                                                       f"({leg.ts.ps.total} floats, {len(leg.ts.buckets)} buckets); all_reduce_ms = the exchange alone, not overlapped",
+                approx_tflops_per_gpu=round(3 * 150.6e9 * B * steps / elapsed / 1e12, 1),  # fwd 150.6 GFLOP/frame, bwd = dgrad + wgrad
+                first_loss=loss0, last_loss=float(loss[0]))
+
+
+# ------------------------------------------------------------------------------------------------ scatter roofline
+def scatter_roofline(model, dev, n_points, spec):
+    """V0..V5 alone (cart->polar, grid index, unique-rank, bucket, PFN, canvas write, sparse clear) as one hipGraph,
+    timed with HIP events over 200 replays on the current stream"""
+    from partner_amd import ops
+    cart = torch.from_numpy(synth.synth_sweep_cart(n_points, seed=5)).to(dev)
+    offs = torch.tensor([0, n_points], dtype=torch.int32, device=dev)
+    persistent = model.new_canvas(1, spec, dev)
+
+    def run():
+        return model.scatter_stage(cart, offs, 1, spec, persistent)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            vi = run()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    v = vi.count()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        run()
+    for _ in range(20):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 200
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / reps
+    c = model.reader.out_channels
+    b_in = n_points * 5 * 4                     # Cartesian points read (x, y, z, intensity, dt)
+    b_feat = v * c * 4                          # pillar features written (into their canvas cells)
+    b_unq = v * 4 * 8                           # SURVEY 8(d) bills the unq table; the fused path keeps int32 keys (v * 4 B) instead
+    b_clear = v * c * 4                         # sparse clear of the same cells after the backbone's first layer
+    alg = n_points * 7 * 4 + b_unq + b_feat     # SURVEY 8(d) "without canvas" variant: 16.2 MB at V = 28.3k
+    pmc = committed_pmc_bytes(("cart_to_polar", "grid_index", "mark", "scan_", "rank_points", "bucket", "dynamic_pfn", "clear_canvas",
+                               "voxel_index", "fused_index"))
+    return dict(bound="hbm", stage="V0..V5 (cart->polar, grid index, bitmap unique-rank, bucketing, fused PFN + canvas cells, sparse clear)",
+                variant="persistent canvas + sparse clear: the 134 MB dense canvas is never filled or moved",
+                points=n_points, voxels=v, bytes_algorithmic=alg, bytes_algorithmic_with_clear=alg + b_clear,
+                bytes_breakdown=dict(points_in=b_in, polar_points=n_points * 7 * 4, unq=b_unq, features=b_feat, clear=b_clear),
+                bytes_pmc=pmc, us=round(us, 2), achieved=round(alg / us / 1e6, 4), peak=PEAK_HBM_TBS, unit="TB/s",
+                frac=round(alg / us / 1e6 / PEAK_HBM_TBS, 4), frac_with_clear=round((alg + b_clear) / us / 1e6 / PEAK_HBM_TBS, 4),
+                measured="HIP events around 200 replays of the stage's own hipGraph on one stream")
+
+
+def committed_pmc_bytes(kernel_prefixes, per="frame"):
+    """HBM bytes from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the gfx950 guide prescribes + WRITE_SIZE, separate
+    --pmc passes of this command with --streams 1): summed over the kernels whose name contains one of the prefixes, per frame
+    (per='frame') or averaged per launch (per='launch'); None if the summary is absent"""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.csv")
+    if not os.path.exists(path):
+        return None
+    rows = list(csv.DictReader(open(path)))
+    frames = None
+    for r in rows:
+        if "dynamic_pfn_32_128_kernel" in r["kernel"]:
+            frames = int(r["launches"])     # one launch per frame
+    tot, n = 0.0, 0
+    for r in rows:
+        if any(p in r["kernel"] for p in kernel_prefixes):
+            k = int(r["launches"])
+            tot += k * (float(r["fetch_KB_corrected_x2_avg"]) + float(r["WRITE_SIZE_KB_avg"])) * 1024.0
+            n += k
+    if not n:
+        return None
+    return round(tot / frames) if (per == "frame" and frames) else round(tot / n)
+
+
+# ------------------------------------------------------------------------------------------------ main
+def dry_run(args, rank, world):
+    """launcher / rendezvous / barrier / max-reduce on any backend without a GPU (CPU tests of the N > 1 plumbing)"""
+    from partner_amd import dist_utils as D
+    D.init(args.backend, None)
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
     if rank == 0:
-        fps = world * args.steps * B / elapsed
-        # algorithmic FLOPs of one iteration: forward 150.6 GFLOP/frame, backward = data + weight gradient
-        tf = 3 * 150.6e9 * B * args.steps / elapsed / 1e12
-        print(json.dumps({
-            "metric": "frames/sec DDP training step (fwd + loss + bwd + grad all-reduce + clip/wd/Adam), 30k-pt sweeps (whole job)",
-            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "nuScenes polar-pillar PARTNER cfg training iteration (BASELINE configs[2])", "points_per_sweep": N,
-                       "sweeps_per_step_per_gpu": B, "parallelism": f"dp{world}, one flat-gradient all-reduce per step",
-                       "flat_gradient_floats": ts.ps.total},
-            "approx_tflops_per_gpu": round(tf, 1), "first_loss": loss0, "last_loss": float(loss[0]),
-        }), flush=True)
+        print(json.dumps({"metric": "dry run of the launcher and the rank plumbing (no GPU work, no product path)", "value": round(world * args.steps / elapsed, 3),
+                          "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run",
+                          "config": {"workload": "none (--dry-run)", "parallelism": f"ranks x{world}", "backend": args.backend}}), flush=True)
     if world > 1:
         D.barrier()
         torch.distributed.destroy_process_group()
+    return 0
 
 
 def main():
@@ -165,27 +359,41 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=None, help="sweeps per step per GPU (default 1; 4 in --mode train)")
+    ap.add_argument("--batch", type=int, default=1, help="sweeps per step per GPU of the inference path")
+    ap.add_argument("--train-batch", type=int, default=4, help="sweeps per training iteration per GPU (BASELINE configs[2]: 4)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
-                    help="infer: BASELINE configs[1], the headline metric (default); train: configs[2], one DDP training "
-                         "iteration (forward, loss, backward, flat-gradient all-reduce, clip + wd + Adam) at bs=4/GPU")
+                    help="infer: BASELINE configs[1], the headline metric, with the training iteration as the `train_step` object "
+                         "(default); train: configs[2] as the headline line (K timed training iterations)")
     ap.add_argument("--points", type=int, default=30000, help="points per sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-events", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replays")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for a same-GPU dry run)")
     ap.add_argument("--streams", type=int, default=4, help="frames in flight per GPU (one hipGraph engine per HIP stream)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the launcher, the rendezvous and the reductions only")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)     # before anything touches the GPU
 
     from partner_amd import dist_utils as D
     rank, local_rank, world = D.env_rank_world()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the product path"
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch one rank per GPU, or run bare and let bench.py start them)", file=sys.stderr)
+        return 2
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X: there is no CPU fallback for the product path (use --dry-run to test the launcher)", file=sys.stderr)
+        return 3
     ndev = torch.cuda.device_count()
-    assert args.backend != "nccl" or local_rank < ndev, f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible"
+    if args.backend == "nccl" and local_rank >= ndev:
+        print(f"bench.py: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible", file=sys.stderr)
+        return 2
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
-    D.init(args.backend, dev)  # RCCL over xGMI; only the barrier and the MAX-reduce of the time use it
+    D.init(args.backend, dev)  # RCCL over xGMI: barrier, MAX-reduce of the time and the gradient buckets of the training leg
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     import partner_amd as P
@@ -196,11 +404,28 @@ def main():
     synth.load_filled(model, base_seed=0)
     model = model.to(dev).eval()
 
-    if args.batch is None:
-        args.batch = 4 if args.mode == "train" else 1
+    def barrier():
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+
     B, N = args.batch, args.points
     if args.mode == "train":
-        return train_mode(args, model, dev, rank, world, red_dev)
+        tr = run_train(args, model, dev, rank, world, red_dev, args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "frames/sec DDP training step (fwd + loss + bwd + grad all-reduce + clip/wd/Adam), 30k-pt sweeps (whole job)",
+                "value": tr["frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": tr["ms_per_iter"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "nuScenes polar-pillar PARTNER cfg training iteration (BASELINE configs[2])", "points_per_sweep": N,
+                           "sweeps_per_step_per_gpu": args.train_batch, "parallelism": f"dp{world}, bucketed flat-gradient all-reduce overlapped with backward"},
+                "train_step": tr}), flush=True)
+        if world > 1:
+            D.barrier()
+            torch.distributed.destroy_process_group()
+        return 0
+
     pool = 8  # distinct resident frames per rank
     frames = []
     for f in range(pool):
@@ -222,12 +447,7 @@ def main():
 
     def step(i):
         # consecutive frames go to alternating streams: independent frames overlap on the GPU
-        return engines[i % len(engines)].run(frames[i % pool]) if engines else step_eager(i)
-
-    def barrier():
-        torch.cuda.synchronize()
-        D.barrier()
-        torch.cuda.synchronize()
+        return engines[i % len(engines)].run(frames[i % pool], sync=False) if engines else step_eager(i)
 
     for i in range(args.warmup):
         step(i)
@@ -238,9 +458,21 @@ def main():
     barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, red_dev)
 
-    # roofline pass: HIP events cannot be recorded inside a replayed graph, so the same K steps are
-    # run again eagerly with an event pair around every conv launch (same kernels, same inputs)
-    prof, eager_ms = None, None
+    # the same K frames with ONE frame in flight (one engine, one stream): the regime the per-kernel figures are quoted in
+    single_ms = None
+    if engines:
+        for i in range(min(args.warmup, 5)):
+            engines[0].run(frames[i % pool], sync=False)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            engines[0].run(frames[i % pool], sync=False)
+        barrier()
+        single_ms = 1e3 * D.max_over_ranks(time.perf_counter() - t1, red_dev) / args.steps
+
+    # roofline pass: the same K steps launched eagerly on one stream with an event pair attached to every conv DISPATCH
+    # (hipExtLaunchKernelGGL start/stop events = the kernel's own execution time; events cannot ride inside a replayed graph)
+    roofline = None
     if not args.no_roofline_events:
         for i in range(2):
             step_eager(i)
@@ -251,35 +483,31 @@ def main():
             step_eager(i)
         barrier()
         eager_ms = 1e3 * (time.perf_counter() - t1) / args.steps
-
-    def committed_traffic():
-        """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/r1_final_pmc_traffic.csv: FETCH_SIZE doubled as
-        the gfx950 guide prescribes + WRITE_SIZE, separate --pmc passes of this same command with --streams 1); None if absent"""
-        import csv
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_final_pmc_traffic.csv")
-        if not os.path.exists(path):
-            return None
-        tot, n = 0.0, 0
-        for r in csv.DictReader(open(path)):
-            if r["kernel"].startswith("conv_mfma_kernel"):
-                k = int(r["launches"])
-                tot += k * (float(r["fetch_KB_corrected_x2_avg"]) + float(r["WRITE_SIZE_KB_avg"])) * 1024.0
-                n += k
-        return round(tot / n) if n else None
-
-    roofline = None
-    if prof is not None:
-        flops, ms, launches = prof.collect()
+        flops, ms, launches, tags = prof.collect(by_tag=True)
         ops.disable_conv_profiling()
         ach = flops / (ms * 1e-3) / 1e12
-        roofline = dict(bound="mfma", kernel="conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
+        layers = {t: dict(launches_per_step=round(n / args.steps, 2), us=round(1e3 * m / n, 2), tflops=round(f / (m * 1e-3) / 1e12, 1))
+                  for t, (f, m, n) in sorted(tags.items(), key=lambda kv: -kv[1][1])}
+        roofline = dict(bound="mfma", kernel="conv_mfma_kernel family (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
                         achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        traffic=committed_traffic(), traffic_unit="HBM bytes per conv launch (offline PMC passes, profiles/r1_final_pmc_traffic.csv)",
-                        launches=launches, flops_per_launch=round(flops / launches), avg_launch_us=round(1e3 * ms / launches, 2),
-                        conv_ms_per_step=round(ms / args.steps, 4),
-                        measured="HIP events around every conv launch over the same K steps replayed eagerly "
-                                 "(events cannot be recorded inside the hipGraph of the timed region)",
-                        eager_ms_per_step=round(eager_ms, 4))
+                        traffic=committed_pmc_bytes(("conv_mfma_kernel", "conv_small_n", "conv_multi"), per="launch"),
+                        traffic_unit="HBM bytes per conv launch (offline PMC passes of this command, profiles/r2_pmc_traffic.csv)",
+                        launches=launches, launches_per_step=round(launches / args.steps, 2), flops_per_launch=round(flops / launches),
+                        avg_launch_us=round(1e3 * ms / launches, 2), conv_ms_per_step=round(ms / args.steps, 4),
+                        paired_with="single_stream_ms_per_step (one frame in flight)",
+                        measured="start/stop events attached to every conv dispatch (hipExtLaunchKernelGGL) over the same K steps "
+                                 "launched eagerly on one stream: per-kernel execution time as in a rocprofv3 kernel trace",
+                        eager_ms_per_step=round(eager_ms, 4), by_layer=layers)
+
+    scatter = None
+    if not args.no_roofline_events and rank == 0 and B == 1:
+        scatter = scatter_roofline(model, dev, N, spec)
+
+    train = None
+    if not args.no_train_leg:
+        engines.clear()        # free the graphs' private pools before the training iteration allocates its activations
+        torch.cuda.empty_cache()
+        train = run_train(args, model, dev, rank, world, red_dev, steps=min(args.steps, 10), warmup=3)
 
     if rank == 0:
         fps = world * args.steps * B / elapsed
@@ -291,8 +519,9 @@ def main():
             "config": {"workload": "nuScenes polar-pillar PARTNER cfg (DynamicPFNet -> DynamicPPScatter -> RPN -> "
                                    "CenterHeadSinglePos), grid 512x512x1, forward only (BASELINE configs[1])",
                        "points_per_sweep": N, "sweeps_per_step_per_gpu": B, "parallelism": f"frame-replicas x{world}",
-                       "launch": "eager" if args.eager else f"hipGraph replay per frame, {len(engines)} frame(s) in flight on separate HIP streams"},
-            "roofline": roofline,
+                       "launch": "eager" if args.eager else f"hipGraph replay per frame, {max(1, args.streams)} frame(s) in flight on separate HIP streams"},
+            "single_stream_ms_per_step": None if single_ms is None else round(single_ms, 4),
+            "roofline": roofline, "roofline_scatter": scatter, "train_step": train,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, B)
@@ -301,7 +530,8 @@ def main():
     if world > 1:
         D.barrier()
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

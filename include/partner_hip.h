@@ -659,6 +659,12 @@ int pn_event_create(pn_event_t *ev);
 int pn_event_destroy(pn_event_t ev);
 int pn_event_record(pn_event_t ev, pn_stream_t stream);
 int pn_event_elapsed_ms(pn_event_t start, pn_event_t stop, float *ms); /* synchronises on stop */
+/* Arms the calling host thread: the NEXT convolution / GEMM launch of this thread (pn_conv2d_nhwc_f32,
+ * pn_conv2d_nhwc_bf16, pn_conv2d_multi_f32, pn_gemm_bias_act_f32, pn_sparse_conv_f32) attaches `start` / `stop` to the
+ * kernel dispatch itself (hipExtLaunchKernelGGL), so that pn_event_elapsed_ms(start, stop) is that kernel's execution
+ * time -- what a rocprofv3 kernel trace reports -- without the launch gaps a pair of hipEventRecord calls around an eager
+ * launch includes.  One shot; not usable while the stream is being captured into a hipGraph. */
+int pn_profile_next_launch(pn_event_t start, pn_event_t stop);
 
 #ifdef __cplusplus
 }

@@ -661,8 +661,15 @@ __global__ __launch_bounds__(256) void conv_small_n_kernel(ConvArgs a) {
 template <int TAPS>
 void launch_small_n(const ConvArgs& a, int zdim, hipStream_t st) {
   const dim3 grid(pn::cdiv(a.M, 64), zdim);
-  if (a.ncols <= 4) hipLaunchKernelGGL((conv_small_n_kernel<4, TAPS>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_small_n_kernel<8, TAPS>), grid, dim3(256), 0, st, a);
+  pn::ProfileSlot ps;
+  const bool prof = pn::take_profile_slot(ps);
+  if (a.ncols <= 4) {
+    if (prof) hipExtLaunchKernelGGL((conv_small_n_kernel<4, TAPS>), grid, dim3(256), 0, st, ps.start, ps.stop, 0, a);
+    else hipLaunchKernelGGL((conv_small_n_kernel<4, TAPS>), grid, dim3(256), 0, st, a);
+  } else {
+    if (prof) hipExtLaunchKernelGGL((conv_small_n_kernel<8, TAPS>), grid, dim3(256), 0, st, ps.start, ps.stop, 0, a);
+    else hipLaunchKernelGGL((conv_small_n_kernel<8, TAPS>), grid, dim3(256), 0, st, a);
+  }
 }
 
 template <int WM, int WN, int TM, int TN, int DT = DT_F32, bool GATHER = false>
@@ -679,7 +686,11 @@ int launch_conv(const ConvArgs& a, int zdim, hipStream_t st) {
   ConvArgs b = a;
   b.nmt = pn::cdiv(a.M, BM);
   dim3 grid(b.nmt, pn::cdiv(a.ncols, BN), zdim);
-  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, DT, GATHER>), grid, dim3(WM * WN * 64), smem, st, b);
+  pn::ProfileSlot ps;
+  if (pn::take_profile_slot(ps))
+    hipExtLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, DT, GATHER>), grid, dim3(WM * WN * 64), smem, st, ps.start, ps.stop, 0, b);
+  else
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, DT, GATHER>), grid, dim3(WM * WN * 64), smem, st, b);
   return pn::check_launch("conv_mfma_kernel");
 }
 

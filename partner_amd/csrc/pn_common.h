@@ -1,6 +1,7 @@
 // Shared helpers for libpartner_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -18,6 +19,18 @@ inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PN_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
   return PN_OK;
+}
+
+// one-shot per-thread timing slot armed by pn_profile_next_launch(): the launcher that finds it attaches the events to
+// its dispatch (hipExtLaunchKernelGGL) and clears it
+struct ProfileSlot { hipEvent_t start, stop; };
+ProfileSlot* profile_slot();
+inline bool take_profile_slot(ProfileSlot& out) {
+  ProfileSlot* s = profile_slot();
+  if (!s->start) return false;
+  out = *s;
+  s->start = s->stop = nullptr;
+  return true;
 }
 
 inline hipStream_t S(pn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

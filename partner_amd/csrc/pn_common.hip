@@ -17,6 +17,11 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+ProfileSlot* profile_slot() {
+  static thread_local ProfileSlot slot = {nullptr, nullptr};
+  return &slot;
+}
+
 namespace {
 __global__ void zero_fill_kernel(uint4* __restrict__ p16, size_t n16, unsigned char* __restrict__ tail, int ntail) {
   const uint4 z = {0u, 0u, 0u, 0u};
@@ -168,6 +173,14 @@ int pn_event_elapsed_ms(pn_event_t start, pn_event_t stop, float* ms) {
   hipError_t rc = hipEventSynchronize((hipEvent_t)stop);
   if (rc == hipSuccess) rc = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
   if (rc != hipSuccess) return pn::fail(PN_ERR_LAUNCH, "hipEventElapsedTime: %s", hipGetErrorString(rc));
+  return PN_OK;
+}
+
+int pn_profile_next_launch(pn_event_t start, pn_event_t stop) {
+  PN_REQUIRE((start && stop) || (!start && !stop), "profile_next_launch: both events or none");
+  pn::ProfileSlot* s = pn::profile_slot();
+  s->start = (hipEvent_t)start;
+  s->stop = (hipEvent_t)stop;
   return PN_OK;
 }
 

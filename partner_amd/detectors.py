@@ -105,6 +105,16 @@ class PointPillars(SingleStageDetector):
             ops.clear_canvas_cells(cv, vi)
         return self.bbox_head(ops.as_nchw(x2))["det_preds"][0]
 
+    def scatter_stage(self, cart: torch.Tensor, sample_offsets: torch.Tensor, batch: int, spec: ops.GridSpec, canvas: torch.Tensor):
+        """V0..V5 alone, exactly as a frame of ``forward_points(canvas=)`` runs them (cart->polar, grid index, unique-rank,
+        bucketing, fused PFN writing the persistent canvas, sparse clear): what bench.py's ``roofline_scatter`` times.
+        -> the VoxelIndex (voxel count on the device)"""
+        polar = ops.cart_to_polar(cart)
+        _, keys = ops.grid_index(polar, sample_offsets, batch, spec, want_grid_ind=False)
+        cv, vi = self.encode_canvas(polar, keys, spec, batch, n_dev=sample_offsets[batch:], canvas=canvas, return_index=True)
+        ops.clear_canvas_cells(cv, vi)
+        return vi
+
     def extract_preds(self, example) -> Dict[str, object]:
         """reference ``example`` dict (dynamic branch keys) -> {'det_preds': [...]}"""
         eval_only(self, "PointPillars")

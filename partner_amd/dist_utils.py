@@ -68,6 +68,33 @@ def allreduce_flat_grads(flat_g: torch.Tensor) -> None:
         dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
 
 
+class GradExchange:
+    """Bucketed gradient exchange overlapped with backward (the reference's DDP reducer buckets in reverse layer
+    order, det3d/torchie/apis/train.py:330-336).  ``buckets`` are contiguous [lo, hi) ranges of the flat gradient buffer in the
+    order backward completes them; ``ready(k)`` starts the asynchronous SUM all-reduce of bucket k (RCCL's stream waits for the
+    kernels queued so far and runs next to the rest of backward), ``finish()`` starts whatever has not been started and makes
+    the compute stream wait for all of them.  World size 1: no-ops."""
+
+    def __init__(self, flat_g: torch.Tensor, buckets):
+        self.flat_g, self.buckets = flat_g, list(buckets)
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.issued = [False] * len(self.buckets)
+        self.pending = []
+
+    def ready(self, k: int) -> None:
+        if self.active and k < len(self.buckets) and not self.issued[k]:
+            lo, hi = self.buckets[k]
+            self.issued[k] = True
+            self.pending.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self) -> None:
+        for k in range(len(self.buckets)):
+            self.ready(k)
+        for w in self.pending:
+            w.wait()   # stream-level wait on GPU backends; the host is not blocked
+        self.pending = []
+
+
 def broadcast_flat_params(flat_p: torch.Tensor, src: int = 0) -> None:
     """rank `src` -> all, once before training (what DistributedDataParallel's constructor does,
     det3d/torchie/apis/train.py:330-336)"""

@@ -33,6 +33,8 @@ class FrameEngine:
         self.cart = torch.from_numpy(np.ascontiguousarray(init)).to(dev)
         self.offsets = torch.tensor([points_per_sweep * b for b in range(batch + 1)], dtype=torch.int32, device=dev)
         self.graph = None
+        self.stream = None
+        self.done = None
         self.outputs: Dict[str, torch.Tensor] = {}
         # persistent BEV canvas of this engine: zero between frames, the frame's cells are cleared after use
         self.canvas = None if hasattr(model, "attns") else model.new_canvas(batch, self.spec, dev)
@@ -64,15 +66,28 @@ class FrameEngine:
             self.outputs = self._step()
         return self
 
-    def run(self, cart: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """cart: (batch*points, 5) on the device.  Returns the head tensors (static buffers,
-        overwritten by the next call)."""
+    def run(self, cart: torch.Tensor, sync: bool = True) -> Dict[str, torch.Tensor]:
+        """cart: (batch*points, 5) on the device.  Returns the head tensors: STATIC buffers, valid until the next ``run`` of
+        this engine overwrites them.
+
+        Stream contract (engine with a private stream): the engine's stream first waits for the caller's current stream --
+        ``cart`` may still be in flight there (an H2D copy, preprocessing) and a consumer of the previous outputs may still be
+        reading them -- and, with ``sync=True``, the caller's stream then waits for the replay, so the outputs can be consumed
+        on the caller's stream without any device-wide synchronisation.  ``sync=False`` leaves the frame in flight
+        (pipelined engines, bench.py): wait on ``self.done`` (an event recorded after the replay) before touching the outputs."""
         if self.graph is None:
             self.capture()
         if getattr(self, "stream", None) is not None:
+            cur = torch.cuda.current_stream()
+            self.stream.wait_stream(cur)
             with torch.cuda.stream(self.stream):
                 self.cart.copy_(cart, non_blocking=True)
                 self.graph.replay()
+                if self.done is None:
+                    self.done = torch.cuda.Event()
+                self.done.record(self.stream)
+            if sync:
+                cur.wait_event(self.done)
         else:
             self.cart.copy_(cart, non_blocking=True)
             self.graph.replay()

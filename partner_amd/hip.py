@@ -133,6 +133,7 @@ SIGNATURES = {
     "pn_event_destroy": (_I, [_P]),
     "pn_event_record": (_I, [_P, _P]),
     "pn_event_elapsed_ms": (_I, [_P, _P, C.POINTER(_F)]),
+    "pn_profile_next_launch": (_I, [_P, _P]),
 }
 
 

@@ -236,11 +236,13 @@ def scatter_canvas(features: torch.Tensor, unq: torch.Tensor, batch: int, t: int
 
 # ------------------------------------------------------------------------------ convolution
 class ConvProfiler:
-    """HIP-event pairs around every MFMA-conv launch on the launch stream (bench.py roofline)."""
+    """Execution time of every MFMA-conv launch (bench.py roofline): the event pair is attached to the kernel dispatch
+    itself (``pn_profile_next_launch`` -> hipExtLaunchKernelGGL), so the elapsed time is the kernel's own duration -- the
+    figure a rocprofv3 kernel trace reports -- and not the launch gap of an eager stream."""
 
     def __init__(self):
         self.lib = hip.load()
-        self.pairs = []   # (start, stop, flops)
+        self.pairs = []   # (start, stop, flops, tag)
         self.free = []
 
     def _event(self):
@@ -251,27 +253,30 @@ class ConvProfiler:
         return ev
 
     def begin(self, stream):
-        ev = self._event()
-        hip.call("pn_event_record", ev, stream)
-        return ev
+        a, b = self._event(), self._event()
+        hip.call("pn_profile_next_launch", a, b)
+        return (a, b)
 
-    def end(self, start, flops, stream):
-        ev = self._event()
-        hip.call("pn_event_record", ev, stream)
-        self.pairs.append((start, ev, flops))
+    def end(self, evs, flops, stream, tag=None):
+        self.pairs.append((evs[0], evs[1], flops, tag))
 
-    def collect(self):
-        """-> (total algorithmic FLOPs, total milliseconds, launches); synchronises"""
+    def collect(self, by_tag=False):
+        """-> (total algorithmic FLOPs, total milliseconds, launches[, {tag: (flops, ms, launches)}]); synchronises"""
         flops, ms = 0.0, 0.0
+        tags = {}
         out = C.c_float()
-        for a, b, f in self.pairs:
+        for a, b, f, tag in self.pairs:
             hip.call("pn_event_elapsed_ms", a, b, C.byref(out))
             ms += out.value
             flops += f
+            t = tags.setdefault(tag, [0.0, 0.0, 0])
+            t[0] += f
+            t[1] += out.value
+            t[2] += 1
             self.free += [a, b]
         n = len(self.pairs)
         self.pairs = []
-        return flops, ms, n
+        return (flops, ms, n, {k: tuple(v) for k, v in tags.items()}) if by_tag else (flops, ms, n)
 
 
 _PROFILER: Optional[ConvProfiler] = None
@@ -390,7 +395,7 @@ class ConvLayer:
                      out.data_ptr(), int(out.dtype == torch.float32), st)
             if prof is not None:
                 macs = b * h * w * 4 * self.cout * self.cin if self.deconv2x2 else b * oh * ow * self.groups * self.cout * self.cin * self.kh * self.kw
-                prof.end(ev, 2.0 * macs, st)
+                prof.end(ev, 2.0 * macs, st, tag=f"{oh}x{ow} {self.cin * self.groups}->{self.out_channels} k{self.kh} bf16")
             return out
         assert out.shape[:3] == (b, oh, ow) and out.is_contiguous()
         d = ConvDesc(b, h, w, self.cin, self.cout, self.groups, self.kh, self.kw, self.stride, self.pad[0], self.pad[1],
@@ -409,7 +414,7 @@ class ConvLayer:
             else:
                 z = self.groups
                 macs = b * oh * ow * z * self.cout * self.cin * self.kh * self.kw
-            prof.end(ev, 2.0 * macs, st)
+            prof.end(ev, 2.0 * macs, st, tag=f"{oh}x{ow} {self.cin * self.groups}->{self.out_channels} k{self.kh}{'t' if self.deconv2x2 else ''}{'s' if self.range_strata > 1 else ''}")
         return out
 
 

@@ -54,11 +54,17 @@ class ParamStore:
     every parameter starts on a 16-byte boundary.  The flat gradient buffer is what gets all-reduced
     (one collective per step, dist_utils.py:8-28 coalesces the same way)."""
 
-    def __init__(self, model: nn.Module, device):
+    def __init__(self, model: nn.Module, device, order_key=None):
+        """``order_key(name) -> sortable``: position of a parameter in the flat buffer (default: named_parameters order);
+        the training step orders the buffer by the time a gradient is complete in backward, so that a gradient bucket is one
+        contiguous range"""
         self.names: List[str] = []
         self.offsets: Dict[str, Tuple[int, torch.Size]] = {}
         off = 0
-        for name, p in model.named_parameters():
+        named = list(model.named_parameters())
+        if order_key is not None:
+            named.sort(key=lambda kv: order_key(kv[0]))   # stable: ties keep the module order
+        for name, p in named:
             self.names.append(name)
             self.offsets[name] = (off, p.shape)
             off += (p.numel() + 3) // 4 * 4
@@ -271,10 +277,30 @@ class PolarPillarTrainStep:
         dev = next(model.parameters()).device
         hip.require_device(next(model.parameters()))
         self.dev = dev
-        self.ps = ps = ParamStore(model, dev)
+        # flat-buffer order = reverse of the order in which backward completes the gradients: reader | block 0 (+ its deblock)
+        # | block 1 ... | head, so that the buckets of the gradient exchange (head first) are contiguous ranges
+        up0 = neck._upsample_start_idx
+
+        def order_key(name: str):
+            parts = name.split(".")
+            if parts[0] == "reader":
+                return 0
+            if parts[0] == "neck" and parts[1] == "blocks":
+                return 1 + 2 * int(parts[2])
+            if parts[0] == "neck" and parts[1] == "deblocks":
+                return 2 + 2 * (int(parts[2]) + up0)
+            return 1000 if parts[0] == "bbox_head" else 999
+
+        self.ps = ps = ParamStore(model, dev, order_key)
+        # gradient buckets [lo, hi) in the order backward completes them: the head, the last RPN block (+ deblock), the rest
+        first_head = min((ps.offsets[n][0] for n in ps.names if n.startswith("bbox_head.")), default=ps.total)
+        last_blk = len(neck.blocks) - 1
+        first_last = min((ps.offsets[n][0] for n in ps.names if order_key(n) >= 1 + 2 * last_blk), default=first_head)
+        self.buckets = [b for b in ((first_head, ps.total), (first_last, first_head), (0, first_last)) if b[1] > b[0]]
         self.sched = dict(total=total_steps, lr_max=lr_max, moms=tuple(moms), div=div_factor, pct=pct_start)
         self.wd, self.max_norm, self.beta2, self.eps = weight_decay, max_norm, beta2, eps
         self.iter = 0
+        self._exchange = None
         self.reader, self.neck, self.head = reader, neck, head
         self.spec = ops.GridSpec.from_range(reader.pc_range, reader.voxel_size)
         self.w0, self.w1 = "reader.pfn_layers.0.linear.weight", "reader.pfn_layers.1.linear.weight"
@@ -480,6 +506,7 @@ class PolarPillarTrainStep:
                 dmid = c1.bwd(d)
                 dmid = ops.tanh_bwd(self.cal_mid[kind], dmid, dx=dmid)
                 c0.bwd(dmid, need_dx=False)
+        self._bucket_ready(0)   # every head gradient is queued: its exchange overlaps the backward of the RPN
         # RPN
         nblk = len(self.blocks)
         d_block = None
@@ -495,10 +522,18 @@ class PolarPillarTrainStep:
             for layer in reversed(self.blocks[i]):
                 d = layer.bwd(d)
             d_block = d
+            if i == nblk - 1 and len(self.buckets) > 2:
+                self._bucket_ready(1)
         d_canvas = d_block
         r = self.reader
         ops.dynamic_pfn_bwd(self.points, self.vi, ps.p[self.w0], ps.p[self.w1], r.vx, r.vy, r.x_offset, r.y_offset, d_canvas=d_canvas,
                             dw0=ps.g[self.w0], dw1=ps.g[self.w1])
+
+    def _bucket_ready(self, k: int) -> None:
+        """start the SUM all-reduce of gradient bucket k (asynchronous: RCCL's stream waits for the kernels queued so far and
+        runs next to the rest of backward; the reference's DDP reducer does the same per bucket, det3d/torchie/apis/train.py:330-336)"""
+        if self._exchange is not None:
+            self._exchange.ready(k)
 
     # ------------------------------------------------------------------------------------------
     def forward_backward(self, points, sample_offsets, batch, targets: ops.CenterLossTargets, grid_ind=None, grad_scale=1.0):
@@ -545,11 +580,16 @@ class PolarPillarTrainStep:
 
     def step(self, points, sample_offsets, batch, targets: ops.CenterLossTargets, grid_ind=None):
         import torch.distributed as dist
-        from .dist_utils import allreduce_flat_grads
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        from .dist_utils import GradExchange
+        self._exchange = GradExchange(self.ps.flat_g, self.buckets) if world > 1 else None
         # the reference averages the gradients over ranks (dist_utils.py:17-28): fold 1/world into the loss gradient
-        loss = self.forward_backward(points, sample_offsets, batch, targets, grid_ind, grad_scale=1.0 / world)
-        allreduce_flat_grads(self.ps.flat_g)  # ONE collective per step over the flat buffer (RCCL on ROCm)
+        try:
+            loss = self.forward_backward(points, sample_offsets, batch, targets, grid_ind, grad_scale=1.0 / world)
+            if self._exchange is not None:
+                self._exchange.finish()   # the last bucket (reader + first blocks), then the stream waits for all of them
+        finally:
+            self._exchange = None
         self.optimizer_step()
         return loss
 

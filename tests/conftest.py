@@ -15,6 +15,12 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "reference: needs /root/reference (container-only cross-checks)")
 
 
+def load_golden(name):
+    """module-level twin of the ``golden`` fixture (for worker processes of multi-rank tests)"""
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

@@ -95,3 +95,85 @@ def test_two_rank_gloo_gradient_exchange():
     np.testing.assert_array_equal(res[0][2], res[1][2])
     np.testing.assert_array_equal(res[0][3], res[1][3])                    # ... and the same parameters after the step
     assert not np.array_equal(res[0][3], res[0][1])
+
+
+def test_bench_bare_launch_starts_one_rank_per_gpu():
+    """`python bench.py --gpus 2` without a launcher: bench.py starts the two ranks itself (before anything touches a GPU), they
+    rendezvous on 127.0.0.1, rank 0 prints ONE JSON line and the exit status is 0 (--dry-run: no GPU in this container)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "5"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["data"] == "dry-run"
+
+
+def test_bench_without_gpu_fails_loudly_not_silently():
+    """the product path has no CPU fallback: without a GPU (and without --dry-run) bench.py exits non-zero with a message, also when
+    it had to start the ranks itself"""
+    import subprocess
+    import sys
+    import torch as _t
+    if _t.cuda.is_available():
+        import pytest
+        pytest.skip("needs a GPU-less host")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    for n in ("1", "2"):
+        res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", n, "--backend", "gloo"], env=env, capture_output=True,
+                             text=True, timeout=300)
+        assert res.returncode != 0 and "no CPU fallback" in res.stderr
+
+
+def _bucket_worker(rank, world, port, q):
+    """GradExchange (what PolarPillarTrainStep.step drives): buckets become ready in backward order, the result equals one
+    all-reduce of the whole buffer"""
+    import numpy as np
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from partner_amd import dist_utils as D
+    assert D.init("gloo") is True
+    n = 1000
+    g = torch.from_numpy(np.random.default_rng(7 + rank).standard_normal(n).astype(np.float32))
+    flat = g.clone() / world
+    ex = D.GradExchange(flat, [(700, 1000), (300, 700), (0, 300)])
+    assert ex.active
+    ex.ready(0)
+    ex.ready(0)          # idempotent
+    ex.ready(1)
+    ex.finish()          # issues bucket 2, waits for all
+    q.put((rank, g.numpy(), flat.numpy().copy()))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_bucketed_exchange_equals_mean():
+    import numpy as np
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mean = res[0][1] / 2 + res[1][1] / 2
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    np.testing.assert_allclose(res[0][2], mean, rtol=1e-6, atol=1e-7)
+
+
+def test_grad_exchange_single_process_is_inert():
+    from partner_amd import dist_utils as D
+    flat = torch.ones(8)
+    ex = D.GradExchange(flat, [(4, 8), (0, 4)])
+    assert not ex.active
+    ex.ready(0)
+    ex.finish()
+    assert torch.equal(flat, torch.ones(8))
