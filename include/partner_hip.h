@@ -352,6 +352,15 @@ int pn_groupnorm_strat_fwd(const float *x, int batch, int h, int w, int c, int p
                            int out_pixel_stride, int out_channel_offset, const float *mul,
                            const float *add, float *out2, void *workspace, size_t workspace_bytes,
                            pn_stream_t stream);
+/* the normalisation pass of pn_groupnorm_strat_fwd alone: mean_rstd [batch][range_strata][channel_groups][2] comes from the
+ * producing convolution's epilogue (pn_conv2d_multi_f32 stat_mean_rstd); out2 = out*mul + add goes to its own
+ * pixel stride / channel offset (e.g. the second half of a concatenated map) */
+int pn_groupnorm_apply_f32(const float *x, int batch, int h, int w, int c, int pixel_stride,
+                           int channel_offset, int channel_groups, int range_strata,
+                           const float *mean_rstd, const float *gamma, const float *beta, int act,
+                           float *out, int out_pixel_stride, int out_channel_offset, const float *mul,
+                           const float *add, float *out2, int out2_pixel_stride,
+                           int out2_channel_offset, pn_stream_t stream);
 
 /* Backward of pn_groupnorm_strat_fwd (autograd through RSNorm / GroupNorm + ReLU and the
  * calibration x*W(pos)+b(pos), center_head_parallel.py:148-176,268).  dout: gradient of `out`;
@@ -650,6 +659,51 @@ int pn_nhwc_to_nchw_f32(const float *in, int b, int c, int h, int w, int pixel_s
 /* (B,H,W,C) -> (B,W,H,C): the (theta,r) <-> (r,theta) token order change around the attention
  * blocks, x.permute(0,1,3,2) at det3d/models/detectors/voxelnet.py:211,219 */
 int pn_transpose_hw_f32(const float *in, int b, int h, int w, int c, float *out, pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Several convolutions of one tile shape as ONE launch, with the GroupNorm-family layer between two convolutions folded
+ * into them: the producing convolution's epilogue emits per-segment statistics and the last block to finish turns them
+ * into an affine table (deterministic: fixed-order fold, no float atomics); the consuming convolution applies
+ * relu(x*A + B) while it loads its input tile, so the normalised map is never written.
+ * Replaces the head of CenterHeadSingle / CenterHeadSinglePos.forward: shared_conv + RSNorm, the five first-stage
+ * branches (RangeStratified 'reg', grouped 'rot_vel', 'height', 'dim', 'hm') and their last convolutions
+ * (det3d/models/bbox_heads/center_head_parallel.py:120-196, 262-284; det3d/models/utils/norm.py:58-75).
+ *   desc / in / packed_w / scale / shift / out: as pn_conv2d_nhwc_f32 (range_strata > 1 and groups > 1 become z slices).
+ *   stat_*: statistics of the affine-applied, pre-activation output (desc.act must be PN_ACT_NONE for them to be the
+ *     norm's input): stat_partials (pn_conv_stat_partial_floats floats of scratch), stat_tickets (one uint32 per z slice,
+ *     zero on entry, left zero), stat_strata (RSNorm on a plain convolution: strata along the output width, each a multiple
+ *     of 32 columns; 1 otherwise -- the stratified convolution's strata are its z slices), stat_channel_groups (1: one group
+ *     over all columns; cout: per channel), stat_gamma / stat_beta ([stratum][cout]), stat_eps;
+ *     outputs: stat_affine [batch][stat_affine_strata][cout][2] = (A, B) with y = x*A + B  and / or
+ *              stat_mean_rstd [batch][stat_affine_strata][groups][2] (the layout pn_groupnorm_apply_f32 reads).
+ *   norm_*: normalise-on-load: input element (b, ih, iw, c) is read as relu(x*A + B), (A, B) =
+ *     norm_affine[((b*norm_strata + iw / (in_w / norm_strata)) * norm_channels + c)]; zero padding stays zero.
+ *     Either every job of a launch has it or none.
+ *   tile: 1 = 128x128, 3 = 64x64, 4 = 64x32, 5 = 64x128 (pixels x columns per block); 3 and 4 support norm_*.
+ */
+typedef struct {
+  pn_conv_desc desc;
+  const float *in;
+  const float *packed_w;
+  const float *scale;
+  const float *shift;
+  float *out;
+  float *stat_partials;
+  uint32_t *stat_tickets;
+  int32_t stat_strata;
+  int32_t stat_channel_groups;
+  const float *stat_gamma;
+  const float *stat_beta;
+  float stat_eps;
+  int32_t stat_affine_strata;
+  float *stat_affine;
+  float *stat_mean_rstd;
+  const float *norm_affine;
+  int32_t norm_strata;
+  int32_t norm_channels;
+} pn_conv_job;
+size_t pn_conv_stat_partial_floats(const pn_conv_desc *desc, int tile);
+int pn_conv2d_multi_f32(const pn_conv_job *jobs, int njobs, int tile, pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * timing helper: HIP events on `stream`, used by bench.py for the roofline object.

@@ -23,6 +23,7 @@
 // k = 8s+4+j from lane half 1, for A and B alike (the sum is order independent up to fp32
 // rounding).
 #include "pn_common.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -72,13 +73,114 @@ struct ConvArgs {
   const int* nbr;
   const int* n_valid;    // device count of valid output sites (rows beyond it are neither computed nor written)
   int res_pre_act;       // 1: out = act(conv*scale + shift + residual) (residual blocks); 0: act(...) + residual
+  // ---- statistics of the (affine-applied, pre-activation) output for the GroupNorm-family layer that follows
+  // (st_part != null).  Every block writes per-column (sum, sum of squares) of each of its 32-row segments; the block
+  // that takes the last ticket of its (job, z) adds the partials in a fixed order and writes the affine table the consumer
+  // applies while it loads its input tile (and/or mean / rstd for the stand-alone apply kernel).
+  float* st_part;        // [z][segments][cout_pad][2]
+  unsigned* st_ticket;   // [z] counters, zero on entry, left zero
+  int st_tiles;          // blocks per z
+  int st_S;              // range strata along the OUTPUT width inside one z (RSNorm on a plain conv: S; otherwise 1)
+  int st_cg;             // channel groups of the norm: 1 (all columns) or ncols (per channel)
+  const float* st_gamma; // [z or stratum][ncols]
+  const float* st_beta;
+  float st_eps;
+  float* st_ab;          // out, optional: [B][st_ab_S][ncols][2] = (A, B): y = x*A + B
+  int st_ab_S;           // strata count of the table (slot = stratum inside z, or z itself for the stratified conv)
+  float* st_stat;        // out, optional: [B][st_ab_S][st_cg][2] = (mean, rstd)
+  // ---- normalise-on-load (NORM_IN kernels): the input element (b, ih, iw, c) is replaced by relu(x*A + B) with
+  // (A, B) = ni_ab[((b*ni_S + iw / (W / ni_S)) * ni_C + c)], zero padding stays zero
+  const float* ni_ab;
+  int ni_S, ni_C;
+  int st_segs_z;         // 32-row segments per z (rounded up to whole tiles)
+  int zdim;              // multi-job launches: number of z slices of this job
 };
 
 constexpr int BK = 32;
 constexpr int A_LD = BK + 4;
 
-template <int WM, int WN, int TM, int TN, int DT = DT_F32, bool GATHER = false>
-__global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
+// Fixed-order fold of the per-segment statistics of one (job, z) by ONE block (the last to finish) -> affine table /
+// (mean, rstd).  Groups: (sample b, stratum s) x {all columns | one column}.  Segment = 32 consecutive GEMM rows.
+template <int NT>
+__device__ __forceinline__ void finalize_stats(const ConvArgs& a, const int z, float* smem_f) {
+  double* red = reinterpret_cast<double*>(smem_f);   // [2][NT]
+  __shared__ float s_ms[2];
+  const int tid = threadIdx.x;
+  const int cp = a.cout_pad, ncols = a.ncols, S = a.st_S;
+  const int slices = NT / cp > 0 ? NT / cp : 1;       // host guarantees cp <= NT
+  const int col = tid % cp, sl = tid / cp;
+  const int pix_b = a.OH * a.OWsub;                    // GEMM rows per sample
+  const int wsub = a.OWsub / S;                        // output columns per stratum (multiple of 32 when S > 1)
+  const int spr = wsub / 32;                           // segments per (row, stratum) when S > 1
+  const int count = S == 1 ? (pix_b + 31) / 32 : a.OH * spr;
+  const float2* part = reinterpret_cast<const float2*>(a.st_part) + (size_t)z * a.st_segs_z * cp;
+  const int slot0 = a.mode == MODE_STRAT ? z : 0;
+  const bool per_channel = a.st_cg > 1;
+  for (int b = 0; b < a.B; ++b)
+    for (int s = 0; s < S; ++s) {
+      double t1 = 0.0, t2 = 0.0;
+      if (sl < slices)
+        for (int i = sl; i < count; i += slices) {
+          const int seg = S == 1 ? (b * pix_b) / 32 + i : ((b * a.OH + i / spr) * a.OWsub + s * wsub) / 32 + i % spr;
+          const float2 v = part[(size_t)seg * cp + col];
+          t1 += (double)v.x;
+          t2 += (double)v.y;
+        }
+      red[tid] = t1;
+      red[NT + tid] = t2;
+      __syncthreads();
+      const int slot = slot0 + s;
+      const size_t grp = (size_t)b * a.st_ab_S + slot;
+      if (per_channel) {
+        if (tid < ncols) {
+          double u1 = 0.0, u2 = 0.0;
+          for (int k = 0; k < slices; ++k) {
+            u1 += red[k * cp + tid];
+            u2 += red[NT + k * cp + tid];
+          }
+          const double n = (double)a.OH * wsub;
+          const double mean = u1 / n;
+          double var = u2 / n - mean * mean;
+          var = var < 0.0 ? 0.0 : var;
+          const float rstd = (float)(1.0 / sqrt(var + (double)a.st_eps));
+          const float ga = a.st_gamma ? a.st_gamma[slot * ncols + tid] : 1.f, be = a.st_beta ? a.st_beta[slot * ncols + tid] : 0.f;
+          const float A = ga * rstd;
+          if (a.st_ab) reinterpret_cast<float2*>(a.st_ab)[grp * ncols + tid] = make_float2(A, be - (float)mean * A);
+          if (a.st_stat) reinterpret_cast<float2*>(a.st_stat)[grp * ncols + tid] = make_float2((float)mean, rstd);
+        }
+      } else {
+        if (tid < 64) {   // first wave: strided fixed-order sums, then the xor butterfly
+          double u1 = 0.0, u2 = 0.0;
+          for (int k = tid; k < slices * cp; k += 64) {
+            u1 += red[k];
+            u2 += red[NT + k];
+          }
+          u1 = pn::wave_sum(u1);
+          u2 = pn::wave_sum(u2);
+          if (tid == 0) {
+            const double n = (double)a.OH * wsub * ncols;
+            const double mean = u1 / n;
+            double var = u2 / n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            s_ms[0] = (float)mean;
+            s_ms[1] = (float)(1.0 / sqrt(var + (double)a.st_eps));
+            if (a.st_stat) reinterpret_cast<float2*>(a.st_stat)[grp] = make_float2(s_ms[0], s_ms[1]);
+          }
+        }
+        __syncthreads();
+        if (a.st_ab)
+          for (int c = tid; c < ncols; c += NT) {
+            const float ga = a.st_gamma ? a.st_gamma[slot * ncols + c] : 1.f, be = a.st_beta ? a.st_beta[slot * ncols + c] : 0.f;
+            const float A = ga * s_ms[1];
+            reinterpret_cast<float2*>(a.st_ab)[grp * ncols + c] = make_float2(A, be - s_ms[0] * A);
+          }
+      }
+      __syncthreads();
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int DT, bool GATHER, bool NORM_IN>
+__device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid, const int n0, const int z) {
   constexpr int ES = DT == DT_F32 ? 4 : 2;   // bytes per input element
   constexpr int CPC = 16 / ES;               // channels per 16-byte chunk
   constexpr int BKC = 8 * CPC;               // channels per K step
@@ -97,7 +199,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int z = blockIdx.z;
 
   // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so give each XCD a
   // contiguous run of m tiles (neighbouring tiles share halo rows in that XCD's L2).
@@ -111,12 +212,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
       m_valid = min(a.M, *a.n_valid);
       nmt = (m_valid + BM - 1) / BM;
     }
-    const int bid = blockIdx.x, q = nmt >> 3, r = nmt & 7, x = bid & 7, idx = bid >> 3;
-    if (GATHER && idx >= (x < r ? q + 1 : q)) return;  // block uniform, before any barrier
-    mt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+    if constexpr (GATHER) {
+      const int q = nmt >> 3, r = nmt & 7, x = bid & 7, idx = bid >> 3;
+      if (idx >= (x < r ? q + 1 : q)) return;  // block uniform, before any barrier
+      mt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+    } else {
+      mt = bid;   // the wrappers deal the tiles over the XCDs
+    }
   }
   const int m0 = mt * BM;
-  const int n0 = blockIdx.y * BN;
   int* nbr_s = reinterpret_cast<int*>(smem + 2 * STAGE);  // gather mode: this block's [BM][taps] neighbour rows
   if constexpr (GATHER) {
     if (m0 >= m_valid) return;
@@ -157,6 +261,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   const long long back = ((long long)a.pad_h * a.W + a.pad_w) * a.in_ps;  // floats
   unsigned a_off[A_PER_T];   // byte offset of (row, tap 0, chunk 0) relative to the shifted base
   unsigned a_mask[A_PER_T];  // bit t: tap t reads inside the map
+  unsigned a_grp[NORM_IN ? A_PER_T : 1];
+  float* ntab = smem + 2 * STAGE;   // NORM_IN: the (A, B) table [B * ni_S][ni_C][2] of the producing norm, staged once
+  if constexpr (NORM_IN) {
+    static_assert(!GATHER, "normalise-on-load is not combined with the gather mode");
+    const int n = a.B * a.ni_S * a.ni_C * 2;
+    for (int i = tid; i < n; i += NT) ntab[i] = a.ni_ab[i];
+    __syncthreads();
+  }
 #pragma unroll
   for (int j = 0; j < A_PER_T; ++j) {
     const int row = (tid >> 3) + (NT / 8) * j;
@@ -176,6 +288,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
       for (int kw = 0; kw < a.KW; ++kw, ++t)
         if (ok && (unsigned)(ih0 + kh) < (unsigned)a.H && (unsigned)(iw0 + kw) < (unsigned)a.W) mk |= 1u << t;
     a_mask[j] = mk;
+    if constexpr (NORM_IN) {   // statistics group (sample, range stratum) of the input pixel under each kw, 10 bits each
+      const int wsub_in = a.W / a.ni_S;
+      unsigned g = 0;
+      for (int kw = 0; kw < a.KW; ++kw) {
+        const int s_in = min(max((iw0 + kw) / wsub_in, 0), a.ni_S - 1);
+        g |= (unsigned)(b * a.ni_S + s_in) << (10 * kw);
+      }
+      a_grp[j] = g;
+    }
   }
   unsigned b_off[B_PER_T];
 #pragma unroll
@@ -212,7 +333,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   // (nearly) the same lines, so the slab stays in this XCD's L2 while it is being used.
   // (tap, chunk) of the next tile to fetch, advanced incrementally: scalar adds only
   int ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
-  auto load_global_to = [&](bool live, f32x4 (&ra)[A_PER_T], f32x4 (&rb)[B_PER_T]) {
+  struct LdTag { int tap, kw, chunk; };   // what a register set holds (NORM_IN: needed when the set is stored to LDS)
+  auto load_global_to = [&](bool live, f32x4 (&ra)[A_PER_T], f32x4 (&rb)[B_PER_T], LdTag& tag) {
     int tap = GATHER ? __builtin_amdgcn_readfirstlane(tap_list[ld_tap]) : ld_tap;
     int kh = ld_kh, kw = ld_kw;
     if (!GATHER && n_sel) {  // block-uniform: the live 2x2 taps of this column tile
@@ -220,6 +342,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
       kh = tap >> 1;
       kw = tap & 1;
     }
+    tag.tap = live ? tap : 31;   // 31: no tap (every mask bit clear)
+    tag.kw = kw;
+    tag.chunk = ld_chunk;
     const unsigned so_a = GATHER ? (unsigned)(ld_chunk * BKC * ES) : (unsigned)(((kh * a.W + kw) * a.in_ps + ld_chunk * BKC) * ES);
     const unsigned so_b = (unsigned)((tap * a.cin_chunks + ld_chunk) * 8) * (unsigned)a.cout_pad * 16u;
     // `live` == false (past the last K step): every lane is redirected out of range, the loads
@@ -243,13 +368,26 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     if (++ld_kw == a.KW) { ld_kw = 0; ++ld_kh; }
     if (++ld_tap == taps_loop) { ld_tap = 0; ld_kh = 0; ld_kw = 0; ++ld_chunk; }
   };
-  auto store_lds_from = [&](int buf, const f32x4 (&ra)[A_PER_T], const f32x4 (&rb)[B_PER_T]) {
+  auto store_lds_from = [&](int buf, const f32x4 (&ra)[A_PER_T], const f32x4 (&rb)[B_PER_T], const LdTag& tag) {
     float* As = smem + buf * STAGE;
     float* Bs = As + A_FLOATS;
 #pragma unroll
     for (int j = 0; j < A_PER_T; ++j) {
       const int row = (tid >> 3) + (NT / 8) * j;
-      *reinterpret_cast<f32x4*>(As + row * A_LD + c4 * 4) = ra[j];
+      f32x4 v = ra[j];
+      if constexpr (NORM_IN) {
+        // the producing layer's GroupNorm + ReLU, applied on the way into LDS: y = max(x*A + B, 0); padding stays zero
+        const int ch = tag.chunk * BKC + c4 * CPC;
+        const bool sel = ((a_mask[j] >> tag.tap) & 1u) && ch < a.Cin;
+        const int gi = (int)(a_grp[j] >> (10 * tag.kw)) & 1023;
+        const float* tp = ntab + ((size_t)gi * a.ni_C + (sel ? ch + z * a.in_group_stride : 0)) * 2;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
+        v[0] = sel ? fmaxf(fmaf(v[0], t0[0], t0[1]), 0.f) : 0.f;
+        v[1] = sel ? fmaxf(fmaf(v[1], t0[2], t0[3]), 0.f) : 0.f;
+        v[2] = sel ? fmaxf(fmaf(v[2], t1[0], t1[1]), 0.f) : 0.f;
+        v[3] = sel ? fmaxf(fmaf(v[3], t1[2], t1[3]), 0.f) : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(As + row * A_LD + c4 * 4) = v;
     }
 #pragma unroll
     for (int j = 0; j < B_PER_T; ++j) *reinterpret_cast<f32x4*>(Bs + (tid + NT * j) * 4) = rb[j];
@@ -311,12 +449,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   // Prologue: the loads of steps 0, 1 and 2 are issued back to back (step 0 into a third set that is dead afterwards), so
   // the block pays one global-memory latency before its first MFMA.
   f32x4 ra2[A_PER_T], rb2[B_PER_T];
+  LdTag tag1, tag2;
   {
     f32x4 ra0[A_PER_T], rb0[B_PER_T];
-    load_global_to(true, ra0, rb0);
-    load_global_to(nsteps > 1, ra, rb);
-    load_global_to(nsteps > 2, ra2, rb2);
-    store_lds_from(0, ra0, rb0);
+    LdTag tag0;
+    load_global_to(true, ra0, rb0, tag0);
+    load_global_to(nsteps > 1, ra, rb, tag1);
+    load_global_to(nsteps > 2, ra2, rb2, tag2);
+    store_lds_from(0, ra0, rb0, tag0);
   }
   __syncthreads();
   read_frags(0, 0, af[0], bf[0]);
@@ -324,7 +464,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
   constexpr int NM = (DT == DT_F32 ? 4 : 1) * TM * TN;  // MFMAs per sub-step
   constexpr int NF = TM + TN;              // fragment reads per sub-step
   constexpr int NS = A_PER_T + B_PER_T;    // LDS stores == buffer loads per step
-  auto kstep = [&](int t, int buf, f32x4 (&rx)[A_PER_T], f32x4 (&ry)[B_PER_T]) {
+  auto kstep = [&](int t, int buf, f32x4 (&rx)[A_PER_T], f32x4 (&ry)[B_PER_T], LdTag& tag) {
     // sub-step 0: fragments of sub-step 1, then MFMAs
     read_frags(buf, 1, af[1], bf[1]);
     mfma_sub(af[0], bf[0]);
@@ -334,7 +474,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     // sub-step 1: fragments of sub-step 2; the LDS stores of step t+1 are spread between the MFMAs
     read_frags(buf, 2, af[0], bf[0]);
     mfma_sub(af[1], bf[1]);
-    store_lds_from(buf ^ 1, rx, ry);  // the tile of step t+1 (past the last step: zeros into a stage nobody reads)
+    store_lds_from(buf ^ 1, rx, ry, tag);  // the tile of step t+1 (past the last step: zeros into a stage nobody reads)
     __builtin_amdgcn_sched_group_barrier(0x100, NF, 1);
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
@@ -346,7 +486,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     // sub-step 2: fragments of sub-step 3; the buffer loads of step t+3 (into the registers just stored) are spread between the MFMAs
     read_frags(buf, 3, af[1], bf[1]);
     mfma_sub(af[0], bf[0]);
-    load_global_to(t + 3 < nsteps, rx, ry);
+    load_global_to(t + 3 < nsteps, rx, ry, tag);
     __builtin_amdgcn_sched_group_barrier(0x100, NF, 2);
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
@@ -365,8 +505,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
   for (int t = 0; t < nsteps; t += 2) {
-    kstep(t, 0, ra, rb);
-    if (t + 1 < nsteps) kstep(t + 1, 1, ra2, rb2);
+    kstep(t, 0, ra, rb, tag1);
+    if (t + 1 < nsteps) kstep(t + 1, 1, ra2, rb2, tag2);
   }
 
   // ---- epilogue: per-channel affine + activation, NHWC store ----------------------------
@@ -447,6 +587,54 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
         *reinterpret_cast<f32x4*>(a.out + pix * a.out_ps + coff) = o;
       }
     }
+    if (a.st_part) {
+      // ---- output statistics: per-column (sum, sum of squares) of the wave's 32-row segments, straight from the LDS tile
+      constexpr int LPC = 64 / TC > 0 ? 64 / TC : 1;   // lanes per column (TC = 32: two, 16 rows each; TC = 64: one, 32 rows)
+      constexpr int RPL = 32 / LPC;
+      const int col = lane % TC, part_h = lane / TC;
+      const int gcol = n0 + wn * TC + col;
+      float csc = 1.f, csh = 0.f;
+      if (gcol < a.ncols) {
+        if (a.scale) csc = a.scale[z * a.Cout + gcol];
+        if (a.shift) csh = a.shift[z * a.Cout + gcol];
+      }
+      float* part = a.st_part + (size_t)z * a.st_segs_z * a.cout_pad * 2;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < RPL; ++r) {
+          const int row = i * 32 + part_h * RPL + r;
+          const float v = fmaf(tile[row * TLD + col], csc, csh);
+          const bool live = m0 + wm * TR + row < m_valid;
+          s1 += live ? v : 0.f;
+          s2 += live ? v * v : 0.f;
+        }
+        if constexpr (LPC == 2) {
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+        }
+        if (part_h == 0 && gcol < a.cout_pad) {
+          const int seg = (m0 + wm * TR) / 32 + i;
+          float2* dst = reinterpret_cast<float2*>(part) + (size_t)seg * a.cout_pad + gcol;
+          *dst = make_float2(gcol < a.ncols ? s1 : 0.f, gcol < a.ncols ? s2 : 0.f);
+        }
+      }
+      // ---- ticket: the block that arrives last at this (job, z) folds the partials in a fixed order
+      __shared__ unsigned s_last;
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned t = atomicAdd(a.st_ticket + z, 1u);
+        s_last = (t == (unsigned)a.st_tiles - 1u) ? 1u : 0u;
+      }
+      __syncthreads();
+      if (s_last) {
+        __threadfence();
+        finalize_stats<NT>(a, z, smem);
+        if (tid == 0) a.st_ticket[z] = 0u;   // ready for the next launch (hipGraph replay)
+      }
+    }
     return;
   }
   float sc[TN], sh[TN];
@@ -509,6 +697,51 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
       }
     }
   }
+}
+
+
+// single convolution: grid (m tiles, column tiles, z)
+template <int WM, int WN, int TM, int TN, int DT = DT_F32, bool GATHER = false, bool NORM_IN = false>
+__global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
+  constexpr int BN = WN * TN * 32;
+  int bid = blockIdx.x;
+  if constexpr (!GATHER) {
+    // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so give each XCD a contiguous run of m tiles
+    // (neighbouring tiles share halo rows in that XCD's L2)
+    const int nmt = a.nmt, q = nmt >> 3, r = nmt & 7, x = bid & 7, idx = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+  }
+  conv_body<WM, WN, TM, TN, DT, GATHER, NORM_IN>(a, bid, blockIdx.y * BN, blockIdx.z);
+}
+
+// several convolutions of one tile shape as ONE launch (the branches of a detection head: same map, different weights /
+// input slices / output slices): the tiles of all jobs form one list, dealt over the XCDs in contiguous runs
+constexpr int kMaxJobs = 8;
+struct MultiArgs {
+  int njobs, total;
+  int first[kMaxJobs + 1];   // first tile of every job in the flattened list
+  ConvArgs job[kMaxJobs];
+};
+
+template <int WM, int WN, int TM, int TN, bool NORM_IN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_multi_kernel(MultiArgs m_by_value) {
+  constexpr int BN = WN * TN * 32;
+  // The job table is read through the kernarg segment pointer (scalar loads at a block-uniform offset): indexing the
+  // by-value parameter dynamically would make the compiler copy all of it to scratch.
+  const MultiArgs* mp = (const MultiArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int bid = blockIdx.x;
+  const int nt = mp->total, q = nt >> 3, r = nt & 7, x = bid & 7, idx = bid >> 3;
+  const int t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+  int j = 0;
+  for (int k = 1; k < mp->njobs; ++k)
+    if (t >= mp->first[k]) j = k;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const ConvArgs& a = mp->job[j];
+  const int local = t - mp->first[j];
+  const int ntn = (a.ncols + BN - 1) / BN, per_z = a.nmt * ntn;
+  const int z = local / per_z, rem = local - z * per_z;
+  const int ny = rem / a.nmt, mt = rem - ny * a.nmt;
+  conv_body<WM, WN, TM, TN, DT_F32, false, NORM_IN>(a, mt, ny * BN, z);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -677,11 +910,13 @@ int launch_conv(const ConvArgs& a, int zdim, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   // gather mode keeps the block's [BM][taps <= 32] neighbour table behind the two staging buffers
   constexpr size_t smem = 2 * (size_t)(BM * A_LD + BK * BN) * sizeof(float) + (GATHER ? (size_t)(BM * 32 + 72) * sizeof(int) : 0);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {false};   // per device: the attribute belongs to the device's code object
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, DT, GATHER>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
   ConvArgs b = a;
   b.nmt = pn::cdiv(a.M, BM);
@@ -697,6 +932,9 @@ int launch_conv(const ConvArgs& a, int zdim, hipStream_t st) {
 // es = bytes per input element (4: f32, 2: bf16); a K step is 8 chunks of 16 bytes = 128 / es channels
 int fill_args(const pn_conv_desc* d, ConvArgs& a, int& zdim, int es = 4) {
   PN_REQUIRE(d != nullptr, "conv: null descriptor");
+  a = ConvArgs{};
+  a.ni_S = 1;
+  a.st_S = 1;
   PN_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0, "conv: bad sizes");
   PN_REQUIRE(d->groups >= 1 && d->kh >= 1 && d->kw >= 1 && d->stride >= 1, "conv: bad kernel params");
   a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Cin = d->cin; a.Cout = d->cout;
@@ -817,6 +1055,43 @@ __global__ void bf16_to_f32_kernel(const unsigned short* __restrict__ x, float* 
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     y[i] = __builtin_bit_cast(float, (unsigned)x[i] << 16);
 }
+
+template <int WM, int WN, int TM, int TN, bool NORM_IN>
+int launch_multi(MultiArgs& m, size_t extra_smem, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t base = 2 * (size_t)(BM * A_LD + BK * BN) * sizeof(float);
+  const size_t smem = base + extra_smem;
+  PN_REQUIRE(smem <= 160 * 1024, "conv_multi: the normalisation table does not fit LDS");
+  static size_t attr_smem[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || attr_smem[dev] < smem) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_multi_kernel<WM, WN, TM, TN, NORM_IN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (dev >= 0 && dev < 64) attr_smem[dev] = smem;
+  }
+  int total = 0;
+  for (int j = 0; j < m.njobs; ++j) {
+    ConvArgs& a = m.job[j];
+    a.nmt = pn::cdiv(a.M, BM);
+    a.st_segs_z = a.nmt * (BM / 32);
+    const int tiles_z = a.nmt * pn::cdiv(a.ncols, BN);
+    a.st_tiles = tiles_z;
+    if (a.st_part) PN_REQUIRE(a.cout_pad <= WM * WN * 64 && pn::cdiv(a.ncols, BN) == 1, "conv_multi: statistics need the job's columns in one column tile");
+    m.first[j] = total;
+    total += tiles_z * a.zdim;
+  }
+  m.first[m.njobs] = total;
+  m.total = total;
+  pn::ProfileSlot ps;
+  if (pn::take_profile_slot(ps))
+    hipExtLaunchKernelGGL((conv_multi_kernel<WM, WN, TM, TN, NORM_IN>), dim3(total), dim3(WM * WN * 64), smem, st, ps.start, ps.stop, 0, m);
+  else
+    hipLaunchKernelGGL((conv_multi_kernel<WM, WN, TM, TN, NORM_IN>), dim3(total), dim3(WM * WN * 64), smem, st, m);
+  return pn::check_launch("conv_multi_kernel");
+}
+
+int tile_bm(int tile) { return tile == 1 ? 128 : 64; }
 
 }  // namespace
 
@@ -956,6 +1231,71 @@ int pn_conv2d_nhwc_f32(const pn_conv_desc* d, const float* in, const float* pack
     return pn::check_launch("conv_small_n_kernel");
   }
   return dispatch_conv(a, zdim, st);
+}
+
+size_t pn_conv_stat_partial_floats(const pn_conv_desc* d, int tile) {
+  ConvArgs a;
+  int zdim = 1;
+  if (fill_args(d, a, zdim)) return 0;
+  const int bm = tile_bm(tile);
+  return (size_t)zdim * pn::cdiv(a.M, bm) * (bm / 32) * a.cout_pad * 2;
+}
+
+int pn_conv2d_multi_f32(const pn_conv_job* jobs, int njobs, int tile, pn_stream_t stream) {
+  PN_REQUIRE(jobs && njobs >= 1 && njobs <= kMaxJobs, "conv_multi: 1 .. 8 jobs");
+  MultiArgs m;
+  memset(&m, 0, sizeof(m));
+  m.njobs = njobs;
+  bool norm_in = false;
+  size_t extra = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const pn_conv_job& jb = jobs[j];
+    ConvArgs& a = m.job[j];
+    int zdim = 1;
+    if (int rc = fill_args(&jb.desc, a, zdim)) return rc;
+    const pn_conv_desc* d = &jb.desc;
+    PN_REQUIRE(jb.in && jb.packed_w && jb.out, "conv_multi: null pointer");
+    PN_REQUIRE(d->cin % 4 == 0 && d->in_pixel_stride % 4 == 0 && d->in_channel_offset % 4 == 0,
+               "conv_multi: cin, input pixel stride and channel offset must be multiples of 4");
+    PN_REQUIRE(((uintptr_t)jb.in & 15) == 0 && ((uintptr_t)jb.packed_w & 15) == 0, "conv_multi: pointers must be 16-byte aligned");
+    PN_REQUIRE(!d->accumulate, "conv_multi: accumulate is not supported");
+    a.in = jb.in; a.w = jb.packed_w; a.scale = jb.scale; a.shift = jb.shift; a.out = jb.out;
+    a.zdim = zdim;
+    if (jb.stat_partials) {
+      PN_REQUIRE(jb.stat_tickets && (jb.stat_affine || jb.stat_mean_rstd), "conv_multi: statistics need tickets and an output table");
+      PN_REQUIRE(a.mode != MODE_DECONV2, "conv_multi: no statistics for the transposed convolution");
+      PN_REQUIRE((a.Cout % 4 == 0) && (a.out_ps % 4 == 0) && (a.out_co % 4 == 0) && (((uintptr_t)a.out & 15) == 0),
+                 "conv_multi: statistics need the vectorised epilogue (channel counts / offsets multiples of 4)");
+      PN_REQUIRE(a.mode == MODE_STRAT || zdim == 1, "conv_multi: statistics of grouped convolutions are not supported");
+      const int S = jb.stat_strata < 1 ? 1 : jb.stat_strata;
+      PN_REQUIRE(S == 1 || (a.mode == MODE_CONV && a.OWsub % S == 0 && (a.OWsub / S) % 32 == 0),
+                 "conv_multi: stat_strata needs a plain convolution whose strata are multiples of 32 columns");
+      PN_REQUIRE(a.B == 1 || (a.OH * a.OWsub) % 32 == 0, "conv_multi: with batch > 1 a sample must be a whole number of 32-row segments");
+      PN_REQUIRE(jb.stat_channel_groups == 1 || jb.stat_channel_groups == a.ncols, "conv_multi: channel groups must be 1 or the column count");
+      const int slots = a.mode == MODE_STRAT ? zdim : S;
+      PN_REQUIRE(jb.stat_affine_strata >= slots, "conv_multi: stat_affine_strata too small");
+      a.st_part = jb.stat_partials; a.st_ticket = jb.stat_tickets; a.st_S = S; a.st_cg = jb.stat_channel_groups;
+      a.st_gamma = jb.stat_gamma; a.st_beta = jb.stat_beta; a.st_eps = jb.stat_eps;
+      a.st_ab = jb.stat_affine; a.st_ab_S = jb.stat_affine_strata; a.st_stat = jb.stat_mean_rstd;
+    }
+    if (jb.norm_affine) {
+      PN_REQUIRE(jb.norm_strata >= 1 && a.W % jb.norm_strata == 0 && a.KW <= 3 && a.KH * a.KW <= 16, "conv_multi: bad normalise-on-load geometry");
+      PN_REQUIRE(jb.norm_channels >= a.Cin * (d->groups > 1 ? d->groups : 1) && a.B * jb.norm_strata < 1024, "conv_multi: normalisation table too small / too many groups");
+      a.ni_ab = jb.norm_affine; a.ni_S = jb.norm_strata; a.ni_C = jb.norm_channels;
+      norm_in = true;
+      extra = std::max(extra, (size_t)a.B * a.ni_S * a.ni_C * 2 * sizeof(float));
+    }
+  }
+  if (norm_in)
+    for (int j = 0; j < njobs; ++j) PN_REQUIRE(m.job[j].ni_ab, "conv_multi: normalise-on-load must be given for every job of the launch or for none");
+  hipStream_t st = pn::S(stream);
+  switch (tile) {
+    case 1: PN_REQUIRE(!norm_in, "conv_multi: tile 1 has no normalise-on-load variant"); return launch_multi<2, 2, 2, 2, false>(m, 0, st);
+    case 3: return norm_in ? launch_multi<2, 2, 1, 1, true>(m, extra, st) : launch_multi<2, 2, 1, 1, false>(m, 0, st);
+    case 4: return norm_in ? launch_multi<2, 1, 1, 1, true>(m, extra, st) : launch_multi<2, 1, 1, 1, false>(m, 0, st);
+    case 5: PN_REQUIRE(!norm_in, "conv_multi: tile 5 has no normalise-on-load variant"); return launch_multi<2, 4, 1, 1, false>(m, 0, st);
+    default: return pn::fail(PN_ERR_INVALID, "conv_multi: tile must be 1 (128x128), 3 (64x64), 4 (64x32) or 5 (64x128)");
+  }
 }
 
 int pn_gemm_bias_act_f32(const float* x, int m, int k, int ldx, const float* packed_w, int n, const float* bias, int act,

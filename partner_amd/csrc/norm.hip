@@ -31,6 +31,7 @@ struct GnArgs {
   const float* mul;
   const float* add;
   float* out2;
+  int o2ps, o2co;
   double* part;  // [B][strata][cgroups][splits][2]
   float* stat;   // [B][strata][cgroups][2] = (mean, rstd), written by gn_finalize_kernel
 };
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(GnArgs a) {
       f32x4 w;
 #pragma unroll
       for (int k = 0; k < 4; ++k) w[k] = v[k] * m[k] + d[k];
-      *reinterpret_cast<f32x4*>(a.out2 + pix * a.C + cv * 4) = w;
+      *reinterpret_cast<f32x4*>(a.out2 + pix * a.o2ps + a.o2co + cv * 4) = w;
     }
   }
 }
@@ -188,7 +189,7 @@ int pn_groupnorm_strat_fwd(const float* x, int batch, int h, int w, int c, int p
   a.rows_per_split = pn::cdiv(h, a.splits);
   a.gamma = gamma; a.beta = beta; a.eps = eps; a.act = act;
   a.out = out; a.ops = out_pixel_stride; a.oco = out_channel_offset;
-  a.mul = mul; a.add = add; a.out2 = out2;
+  a.mul = mul; a.add = add; a.out2 = out2; a.o2ps = c; a.o2co = 0;
   a.part = static_cast<double*>(workspace);
   const size_t ngroups = (size_t)batch * range_strata * channel_groups;
   a.stat = reinterpret_cast<float*>(a.part + ngroups * 256 * 2);
@@ -197,6 +198,36 @@ int pn_groupnorm_strat_fwd(const float* x, int batch, int h, int w, int c, int p
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ngroups), dim3(64), 0, pn::S(stream), a);
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(kThreads), 0, pn::S(stream), a);
   return pn::check_launch("groupnorm_strat");
+}
+
+/* normalisation pass alone, with the group statistics already on the device (written by the producing convolution's
+ * epilogue, pn_conv2d_multi_f32 stat_mean_rstd): one launch instead of statistics + finalize + apply */
+int pn_groupnorm_apply_f32(const float* x, int batch, int h, int w, int c, int pixel_stride, int channel_offset, int channel_groups,
+                           int range_strata, const float* mean_rstd, const float* gamma, const float* beta, int act, float* out,
+                           int out_pixel_stride, int out_channel_offset, const float* mul, const float* add, float* out2,
+                           int out2_pixel_stride, int out2_channel_offset, pn_stream_t stream) {
+  PN_REQUIRE(x && out && mean_rstd, "groupnorm_apply: null pointer");
+  PN_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && c >= 1, "groupnorm_apply: bad sizes");
+  PN_REQUIRE(c % 4 == 0 && c <= 4 * kThreads && (4 * kThreads) % c == 0, "groupnorm_apply: channel count must be a multiple of 4 dividing 1024");
+  PN_REQUIRE(pixel_stride % 4 == 0 && channel_offset % 4 == 0 && out_pixel_stride % 4 == 0 && out_channel_offset % 4 == 0,
+             "groupnorm_apply: strides / offsets must be multiples of 4 floats");
+  PN_REQUIRE(channel_groups >= 1 && c % channel_groups == 0, "groupnorm_apply: channel_groups must divide the channel count");
+  PN_REQUIRE(range_strata >= 1 && w % range_strata == 0, "groupnorm_apply: range axis not divisible by range_strata");
+  PN_REQUIRE((out2 == nullptr) || (mul && add && out2_pixel_stride % 4 == 0 && out2_channel_offset % 4 == 0), "groupnorm_apply: out2 needs mul, add and aligned strides");
+  GnArgs a;
+  a.x = x; a.B = batch; a.H = h; a.W = w; a.C = c; a.ps = pixel_stride; a.co = channel_offset;
+  a.cgroups = channel_groups; a.strata = range_strata;
+  a.splits = pick_splits(batch, h, range_strata);
+  if (a.splits > 256) a.splits = 256;
+  a.rows_per_split = pn::cdiv(h, a.splits);
+  a.gamma = gamma; a.beta = beta; a.eps = 0.f; a.act = act;
+  a.out = out; a.ops = out_pixel_stride; a.oco = out_channel_offset;
+  a.mul = mul; a.add = add; a.out2 = out2; a.o2ps = out2_pixel_stride; a.o2co = out2_channel_offset;
+  a.part = nullptr;
+  a.stat = const_cast<float*>(mean_rstd);
+  dim3 grid(a.splits, range_strata, batch);
+  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(kThreads), 0, pn::S(stream), a);
+  return pn::check_launch("groupnorm_apply");
 }
 
 }  // extern "C"

@@ -57,6 +57,20 @@ class SepHead(nn.Module):
             setattr(self, head, fc)
 
 
+def _dense_weight(conv: nn.Conv2d) -> torch.Tensor:
+    """weight of a grouped convolution as the block-diagonal dense (Cout, Cin, KH, KW) tensor (groups == 1: the weight itself)"""
+    w = conv.weight.detach()
+    g = conv.groups
+    if g == 1:
+        return w
+    cout, cin_g = w.shape[0], w.shape[1]
+    dense = torch.zeros((cout, cin_g * g) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
+    cg = cout // g
+    for k in range(g):
+        dense[k * cg:(k + 1) * cg, k * cin_g:(k + 1) * cin_g] = w[k * cg:(k + 1) * cg]
+    return dense
+
+
 def _conv_bias(conv: nn.Conv2d, act, **kw) -> ops.ConvLayer:
     return ops.ConvLayer(conv.weight, stride=conv.stride[0], pad=conv.padding[0], groups=conv.groups, shift=conv.bias,
                          act=act, **kw)
@@ -290,7 +304,108 @@ class CenterHeadSingle(CenterHead):
                                rs.groupnorm.eps),
                     branches={name: self._branch_plan(getattr(self, name)) for name in self.heads})
         plan["merged"] = self._merge_branches(plan["branches"])
+        plan["fused"] = self._build_fused()
         return plan
+
+    # ---- fused execution: 4 launches + one ticket clear instead of ~26 (convolutions + 15 GroupNorm passes) ----------
+    def _build_fused(self):
+        """Layers of the fused path, or None when the head does not have the shape the fused kernels cover: every branch
+        = [3x3 conv (or RangeStratified) -> GroupNorm-family -> ReLU -> last conv], 64 hidden channels.
+        Launch 1: shared conv, its epilogue emits the RSNorm statistics.  Launch 2: RSNorm + ReLU (+ calibration) -> [xs | x_hm].
+        Launch 3: ALL first-stage branch convolutions as one multi-job launch, each emitting its GroupNorm statistics.
+        Launch 4: ALL last convolutions as one multi-job launch that applies GroupNorm + ReLU while loading its input."""
+        rs = self.shared_conv[1]
+        if not isinstance(rs, RSNorm) or rs.num_heads != 1:
+            return None
+        c_sh = self.shared_conv[0].out_channels
+        if c_sh % 32 != 0 or c_sh > 128:
+            return None
+        first, last = [], []
+        for name in self.heads:
+            mods = list(getattr(self, name)._modules.values())
+            if isinstance(mods[0], RangeStratified):
+                if len(mods) != 2 or mods[0].nheads != 1:
+                    return None
+                conv, gn, fin = mods[0].conv[0], mods[0].conv[1], mods[1]
+                cmid = mods[0].outchannels
+                lay = ops.ConvLayer(conv.weight, stride=1, pad=1, range_strata=mods[0].ngroups, shift=conv.bias, act=ops.ACT_NONE)
+                st = dict(strata=1, channel_groups=1, gamma=gn.weight.detach().float().contiguous(), beta=gn.bias.detach().float().contiguous(), eps=gn.eps,
+                          affine_strata=mods[0].ngroups)
+            else:
+                if len(mods) != 4 or not (isinstance(mods[0], nn.Conv2d) and isinstance(mods[1], nn.GroupNorm) and isinstance(mods[3], nn.Conv2d)):
+                    return None
+                conv, gn, fin = mods[0], mods[1], mods[3]
+                cmid = conv.out_channels
+                if gn.num_groups != gn.num_channels or conv.kernel_size != (3, 3) or conv.padding != (1, 1):
+                    return None
+                lay = ops.ConvLayer(_dense_weight(conv), stride=1, pad=1, shift=conv.bias, act=ops.ACT_NONE)
+                st = dict(strata=1, channel_groups=cmid, gamma=gn.weight.detach().float().contiguous(), beta=gn.bias.detach().float().contiguous(), eps=gn.eps,
+                          affine_strata=1)
+            if cmid % 32 != 0 or cmid > 128 or fin.kernel_size[0] != fin.kernel_size[1]:
+                return None
+            first.append((name, lay, st, cmid))
+            last.append((name, ops.ConvLayer(_dense_weight(fin), stride=1, pad=fin.padding[0], shift=fin.bias, act=ops.ACT_NONE), fin.out_channels))
+        return dict(shared=_conv_bias(self.shared_conv[0], ops.ACT_NONE), first=first, last=last, c_sh=c_sh,
+                    rs=(rs.num_groups, rs.groupnorm.weight.detach().float().contiguous(), rs.groupnorm.bias.detach().float().contiguous(), rs.groupnorm.eps))
+
+    def _fused_ok(self, fz, b, h, w) -> bool:
+        if fz is None:
+            return False
+        s = fz["rs"][0]
+        if w % s != 0 or (w // s) % 32 != 0 or b * max(s, 8) >= 1024:
+            return False
+        for name, lay, st, cmid in fz["first"]:
+            if lay.range_strata > 1 and (w % lay.range_strata != 0 or (b > 1 and (h * (w // lay.range_strata)) % 32 != 0)):
+                return False
+        return b == 1 or (h * w) % 32 == 0
+
+    def _forward_fused(self, plan, x: torch.Tensor):
+        fz = plan["fused"]
+        b, h, w, _ = x.shape
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        c_sh = fz["c_sh"]
+        mul, add = self._calibration(plan, x[..., :c_sh])
+        n_first = len(fz["first"])
+        n_tick = 1 + sum(max(lay.range_strata, 1) for _, lay, _, _ in fz["first"])
+        tickets = torch.empty((n_tick,), dtype=torch.int32, device=dev)
+        hip.call("pn_fill_zero", tickets.data_ptr(), tickets.numel() * 4, hip.stream())
+        # launch 1: shared convolution + RSNorm statistics
+        s_rs, g_rs, b_rs, eps_rs = fz["rs"]
+        raw = torch.empty((b, h, w, c_sh), **f32)
+        stat0 = torch.empty((b, s_rs, 1, 2), **f32)
+        j0 = ops.ConvJob(fz["shared"], x, raw)
+        j0.stats = dict(strata=s_rs, channel_groups=1, gamma=None, beta=None, eps=eps_rs, affine_strata=s_rs, mean_rstd=stat0,
+                        partials=torch.empty((j0.partial_floats(3),), **f32), tickets=tickets[0:1])
+        ops.conv_multi([j0], 3)
+        # launch 2: RSNorm + ReLU -> xs, and the position-calibrated copy for the heat-map branch
+        xcat = torch.empty((b, h, w, c_sh * (2 if mul is not None else 1)), **f32)
+        ops.groupnorm_apply(raw, 1, s_rs, stat0, g_rs, b_rs, ops.ACT_RELU, xcat, 0, mul=mul, add=add, out2=xcat if mul is not None else None,
+                            out2_channel_offset=c_sh)
+        # launch 3: every first-stage branch, statistics of its GroupNorm in the epilogue
+        cm_tot = sum(cm for *_, cm in fz["first"])
+        mid = torch.empty((b, h, w, cm_tot), **f32)
+        jobs, tabs, off, tk = [], [], 0, 1
+        for name, lay, st, cmid in fz["first"]:
+            nz = max(lay.range_strata, 1)
+            jb = ops.ConvJob(lay, xcat, mid, in_channel_offset=(c_sh if (name == "hm" and mul is not None) else 0), out_channel_offset=off)
+            tab = torch.empty((b, st["affine_strata"], cmid, 2), **f32)
+            jb.stats = dict(st, affine=tab, partials=torch.empty((jb.partial_floats(3),), **f32), tickets=tickets[tk:tk + nz])
+            jobs.append(jb)
+            tabs.append((tab, st["affine_strata"], cmid, off))
+            off += cmid
+            tk += nz
+        ops.conv_multi(jobs, 3)
+        # launch 4: every last convolution, GroupNorm + ReLU applied while the input tile is loaded
+        widths = [(co + 3) // 4 * 4 for *_, co in fz["last"]]
+        out = torch.empty((b, h, w, sum(widths)), **f32)
+        jobs, off, outs = [], 0, {}
+        for (name, lay, co), (tab, strata, cmid, in_off), wd in zip(fz["last"], tabs, widths):
+            jobs.append(ops.ConvJob(lay, mid, out, in_channel_offset=in_off, out_channel_offset=off, norm=(tab, strata, cmid)))
+            outs[name] = out[..., off:off + co]
+            off += wd
+        ops.conv_multi(jobs, 4)
+        return outs
 
     def _merge_branches(self, branches):
         """Branches conv3x3(64->64) + per-channel GroupNorm + ReLU + conv that read the same shared map (everything but
@@ -333,7 +448,21 @@ class CenterHeadSingle(CenterHead):
         hip.require_device(x)
         eval_only(self, type(self).__name__)
         plan = self._plan.get(self, self._build_plan)
-        raw = plan["shared"](ops.to_nhwc(x))
+        xh = ops.to_nhwc(x)
+        if self._fused_ok(plan["fused"], xh.shape[0], xh.shape[1], xh.shape[2]) and not getattr(self, "force_unfused", False):
+            outs = self._forward_fused(plan, xh)
+            ret = {}
+            for name in plan["branches"]:
+                y = ops.as_nchw(outs[name])
+                if "_" in name:
+                    names = name.split("_")
+                    dim = y.shape[1] // len(names)
+                    for j, nm in enumerate(names):
+                        ret[nm] = y[:, j * dim:(j + 1) * dim]
+                else:
+                    ret[name] = y
+            return {"det_preds": [ret]}
+        raw = plan["shared"](xh)
         cg, st, ga, be, eps = plan["shared_gn"]
         mul, add = self._calibration(plan, raw)
         if mul is not None:

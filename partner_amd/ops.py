@@ -418,6 +418,73 @@ class ConvLayer:
         return out
 
 
+class ConvJob:
+    """One convolution of a multi-job launch (``conv_multi``): a packed ``ConvLayer`` applied to a channel slice of ``x``,
+    writing a channel slice of ``out``; optionally emitting the statistics of the GroupNorm-family layer that follows it
+    (``stats=dict(strata, channel_groups, gamma, beta, eps, affine=, affine_strata=, mean_rstd=)``) and / or reading its input
+    through the affine table of the norm that precedes it (``norm=(table, strata, channels)``: relu(x*A + B) on load)."""
+
+    def __init__(self, layer: "ConvLayer", x: torch.Tensor, out: torch.Tensor, in_channel_offset=0, out_channel_offset=0, stats=None,
+                 norm=None):
+        assert layer.dtype == "f32" and not layer.deconv2x2
+        hip.require_device(x, out)
+        assert x.dim() == 4 and x.is_contiguous() and out.is_contiguous() and x.dtype == torch.float32
+        self.layer, self.x, self.out, self.in_co, self.out_co, self.stats, self.norm = layer, x, out, in_channel_offset, out_channel_offset, stats, norm
+        b, h, w, ct = x.shape
+        oh, ow = layer.out_hw(h, w)
+        assert out.shape[:3] == (b, oh, ow)
+        self.desc = ConvDesc(b, h, w, layer.cin, layer.cout, layer.groups, layer.kh, layer.kw, layer.stride, layer.pad[0], layer.pad[1],
+                             ct, in_channel_offset, out.shape[3], out_channel_offset, layer.act, 0, layer.range_strata, 0, 0, 0)
+        self.macs = b * oh * ow * layer.groups * layer.cout * layer.cin * layer.kh * layer.kw
+
+    def partial_floats(self, tile: int) -> int:
+        return int(hip.load().pn_conv_stat_partial_floats(C.byref(self.desc), tile))
+
+
+def conv_multi(jobs: Sequence[ConvJob], tile: int, scratch: Optional[dict] = None) -> None:
+    """run the jobs as ONE launch of the MFMA kernel (tile: 1 = 128x128, 3 = 64x64, 4 = 64x32, 5 = 64x128).
+    Statistics jobs need ``stats['partials']`` (float scratch of ``job.partial_floats(tile)``) and ``stats['tickets']`` (uint32,
+    one per z slice, zero on entry -- left zero)."""
+    arr = (hip.ConvJob * len(jobs))()
+    keep = []
+    for k, jb in enumerate(jobs):
+        c = arr[k]
+        c.desc = jb.desc
+        c.in_, c.packed_w, c.out = jb.x.data_ptr(), jb.layer.packed.data_ptr(), jb.out.data_ptr()
+        c.scale, c.shift = hip.ptr(jb.layer.scale), hip.ptr(jb.layer.shift)
+        if jb.stats is not None:
+            st = jb.stats
+            c.stat_partials, c.stat_tickets = st["partials"].data_ptr(), st["tickets"].data_ptr()
+            c.stat_strata, c.stat_channel_groups = int(st.get("strata", 1)), int(st["channel_groups"])
+            c.stat_gamma, c.stat_beta, c.stat_eps = hip.ptr(st.get("gamma")), hip.ptr(st.get("beta")), float(st["eps"])
+            c.stat_affine_strata = int(st["affine_strata"])
+            c.stat_affine, c.stat_mean_rstd = hip.ptr(st.get("affine")), hip.ptr(st.get("mean_rstd"))
+        if jb.norm is not None:
+            tab, strata, channels = jb.norm
+            c.norm_affine, c.norm_strata, c.norm_channels = tab.data_ptr(), int(strata), int(channels)
+    st = hip.stream()
+    prof = _PROFILER
+    if prof is not None:
+        ev = prof.begin(st)
+    hip.call("pn_conv2d_multi_f32", arr, len(jobs), int(tile), st)
+    if prof is not None:
+        j0 = jobs[0]
+        prof.end(ev, 2.0 * sum(j.macs for j in jobs), st,
+                 tag=f"multi x{len(jobs)} {j0.out.shape[1]}x{j0.out.shape[2]} {sum(j.layer.cin * j.layer.groups for j in jobs)}->{sum(j.layer.out_channels for j in jobs)} k{j0.layer.kh}")
+
+
+def groupnorm_apply(x: torch.Tensor, channel_groups: int, range_strata: int, mean_rstd: torch.Tensor, gamma, beta, act, out: torch.Tensor,
+                    out_channel_offset=0, mul=None, add=None, out2: Optional[torch.Tensor] = None, out2_channel_offset=0,
+                    channels: Optional[int] = None, channel_offset=0) -> None:
+    """normalisation pass with the statistics already on the device (from a convolution's epilogue)"""
+    hip.require_device(x, out, mean_rstd)
+    b, h, w, ct = x.shape
+    c = ct - channel_offset if channels is None else channels
+    hip.call("pn_groupnorm_apply_f32", x.data_ptr(), b, h, w, c, ct, channel_offset, channel_groups, range_strata, mean_rstd.data_ptr(),
+             hip.ptr(gamma), hip.ptr(beta), int(act), out.data_ptr(), out.shape[3], out_channel_offset, hip.ptr(mul), hip.ptr(add), hip.ptr(out2),
+             0 if out2 is None else out2.shape[3], out2_channel_offset, hip.stream())
+
+
 def conv2d_direct(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=0, groups=1,
                   act=ACT_NONE) -> torch.Tensor:
     """plain direct convolution (any channel counts); NHWC in / NHWC out"""
