@@ -662,7 +662,7 @@ int pn_transpose_hw_f32(const float *in, int b, int h, int w, int c, float *out,
 
 /* ---------------------------------------------------------------------------------------
  * Several convolutions of one tile shape as ONE launch, with the GroupNorm-family layer between two convolutions folded
- * into them: the producing convolution's epilogue emits per-segment statistics and the last block to finish turns them
+ * into them: the producing convolution's epilogue emits per-tile statistics partials, a small second launch folds them
  * into an affine table (deterministic: fixed-order fold, no float atomics); the consuming convolution applies
  * relu(x*A + B) while it loads its input tile, so the normalised map is never written.
  * Replaces the head of CenterHeadSingle / CenterHeadSinglePos.forward: shared_conv + RSNorm, the five first-stage
@@ -670,11 +670,10 @@ int pn_transpose_hw_f32(const float *in, int b, int h, int w, int c, float *out,
  * (det3d/models/bbox_heads/center_head_parallel.py:120-196, 262-284; det3d/models/utils/norm.py:58-75).
  *   desc / in / packed_w / scale / shift / out: as pn_conv2d_nhwc_f32 (range_strata > 1 and groups > 1 become z slices).
  *   stat_*: statistics of the affine-applied, pre-activation output (desc.act must be PN_ACT_NONE for them to be the
- *     norm's input): stat_partials (pn_conv_stat_partial_floats floats of scratch), stat_tickets (one uint32 per z slice,
- *     zero on entry, left zero), stat_strata (RSNorm on a plain convolution: strata along the output width, each a multiple
+ *     norm's input): stat_partials (pn_conv_stat_partial_floats floats of scratch), stat_strata (RSNorm on a plain convolution: strata along the output width, each a multiple
  *     of 32 columns; 1 otherwise -- the stratified convolution's strata are its z slices), stat_channel_groups (1: one group
  *     over all columns; cout: per channel), stat_gamma / stat_beta ([stratum][cout]), stat_eps;
- *     outputs: stat_affine [batch][stat_affine_strata][cout][2] = (A, B) with y = x*A + B  and / or
+ *     outputs (written by pn_conv_stats_finalize_f32): stat_affine [batch][stat_affine_strata][cout][2] = (A, B) with y = x*A + B  and / or
  *              stat_mean_rstd [batch][stat_affine_strata][groups][2] (the layout pn_groupnorm_apply_f32 reads).
  *   norm_*: normalise-on-load: input element (b, ih, iw, c) is read as relu(x*A + B), (A, B) =
  *     norm_affine[((b*norm_strata + iw / (in_w / norm_strata)) * norm_channels + c)]; zero padding stays zero.
@@ -689,7 +688,6 @@ typedef struct {
   const float *shift;
   float *out;
   float *stat_partials;
-  uint32_t *stat_tickets;
   int32_t stat_strata;
   int32_t stat_channel_groups;
   const float *stat_gamma;
@@ -704,6 +702,16 @@ typedef struct {
 } pn_conv_job;
 size_t pn_conv_stat_partial_floats(const pn_conv_desc *desc, int tile);
 int pn_conv2d_multi_f32(const pn_conv_job *jobs, int njobs, int tile, pn_stream_t stream);
+/* folds the partials the jobs' epilogues wrote (same job array and tile as the pn_conv2d_multi_f32 call; jobs without
+ * stat_partials are skipped) into stat_affine / stat_mean_rstd: one small launch, fixed association order */
+int pn_conv_stats_finalize_f32(const pn_conv_job *jobs, int njobs, int tile, pn_stream_t stream);
+/* RSNorm + activation of `producer->out` (a plain convolution launched with all-channel statistics, stat_strata = the norm's
+ * range strata) WITHOUT a finalize launch: every block folds the partials of its own (sample, stratum) group first.
+ * gamma / beta [stratum][cout]; out2 = out*mul + add with (H, W, cout) maps (CenterHeadSinglePos calibration), optional. */
+int pn_conv_stats_apply_f32(const pn_conv_job *producer, int tile, const float *gamma, const float *beta, int act,
+                            float *out, int out_pixel_stride, int out_channel_offset, const float *mul,
+                            const float *add, float *out2, int out2_pixel_stride, int out2_channel_offset,
+                            pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * timing helper: HIP events on `stream`, used by bench.py for the roofline object.

@@ -74,12 +74,11 @@ struct ConvArgs {
   const int* n_valid;    // device count of valid output sites (rows beyond it are neither computed nor written)
   int res_pre_act;       // 1: out = act(conv*scale + shift + residual) (residual blocks); 0: act(...) + residual
   // ---- statistics of the (affine-applied, pre-activation) output for the GroupNorm-family layer that follows
-  // (st_part != null).  Every block writes per-column (sum, sum of squares) of each of its 32-row segments; the block
-  // that takes the last ticket of its (job, z) adds the partials in a fixed order and writes the affine table the consumer
-  // applies while it loads its input tile (and/or mean / rstd for the stand-alone apply kernel).
-  float* st_part;        // [z][segments][cout_pad][2]
-  unsigned* st_ticket;   // [z] counters, zero on entry, left zero
-  int st_tiles;          // blocks per z
+  // (st_part != null).  Every block writes ONE partial (sum, sum of squares) per column and tile (per-channel groups) or per
+  // 32-row segment and wave column (all-channel groups); conv_stats_finalize_kernel (a separate small launch: folding them
+  // inside this kernel costs registers, i.e. occupancy, in every variant) adds them in a fixed order and writes the affine
+  // table the consumer applies while it loads its input tile.
+  float* st_part;        // per-channel: [z][tile][cout_pad][2]; all-channel: [z][segment][WN][2]
   int st_S;              // range strata along the OUTPUT width inside one z (RSNorm on a plain conv: S; otherwise 1)
   int st_cg;             // channel groups of the norm: 1 (all columns) or ncols (per channel)
   const float* st_gamma; // [z or stratum][ncols]
@@ -98,86 +97,6 @@ struct ConvArgs {
 
 constexpr int BK = 32;
 constexpr int A_LD = BK + 4;
-
-// Fixed-order fold of the per-segment statistics of one (job, z) by ONE block (the last to finish) -> affine table /
-// (mean, rstd).  Groups: (sample b, stratum s) x {all columns | one column}.  Segment = 32 consecutive GEMM rows.
-template <int NT>
-__device__ __forceinline__ void finalize_stats(const ConvArgs& a, const int z, float* smem_f) {
-  double* red = reinterpret_cast<double*>(smem_f);   // [2][NT]
-  __shared__ float s_ms[2];
-  const int tid = threadIdx.x;
-  const int cp = a.cout_pad, ncols = a.ncols, S = a.st_S;
-  const int slices = NT / cp > 0 ? NT / cp : 1;       // host guarantees cp <= NT
-  const int col = tid % cp, sl = tid / cp;
-  const int pix_b = a.OH * a.OWsub;                    // GEMM rows per sample
-  const int wsub = a.OWsub / S;                        // output columns per stratum (multiple of 32 when S > 1)
-  const int spr = wsub / 32;                           // segments per (row, stratum) when S > 1
-  const int count = S == 1 ? (pix_b + 31) / 32 : a.OH * spr;
-  const float2* part = reinterpret_cast<const float2*>(a.st_part) + (size_t)z * a.st_segs_z * cp;
-  const int slot0 = a.mode == MODE_STRAT ? z : 0;
-  const bool per_channel = a.st_cg > 1;
-  for (int b = 0; b < a.B; ++b)
-    for (int s = 0; s < S; ++s) {
-      double t1 = 0.0, t2 = 0.0;
-      if (sl < slices)
-        for (int i = sl; i < count; i += slices) {
-          const int seg = S == 1 ? (b * pix_b) / 32 + i : ((b * a.OH + i / spr) * a.OWsub + s * wsub) / 32 + i % spr;
-          const float2 v = part[(size_t)seg * cp + col];
-          t1 += (double)v.x;
-          t2 += (double)v.y;
-        }
-      red[tid] = t1;
-      red[NT + tid] = t2;
-      __syncthreads();
-      const int slot = slot0 + s;
-      const size_t grp = (size_t)b * a.st_ab_S + slot;
-      if (per_channel) {
-        if (tid < ncols) {
-          double u1 = 0.0, u2 = 0.0;
-          for (int k = 0; k < slices; ++k) {
-            u1 += red[k * cp + tid];
-            u2 += red[NT + k * cp + tid];
-          }
-          const double n = (double)a.OH * wsub;
-          const double mean = u1 / n;
-          double var = u2 / n - mean * mean;
-          var = var < 0.0 ? 0.0 : var;
-          const float rstd = (float)(1.0 / sqrt(var + (double)a.st_eps));
-          const float ga = a.st_gamma ? a.st_gamma[slot * ncols + tid] : 1.f, be = a.st_beta ? a.st_beta[slot * ncols + tid] : 0.f;
-          const float A = ga * rstd;
-          if (a.st_ab) reinterpret_cast<float2*>(a.st_ab)[grp * ncols + tid] = make_float2(A, be - (float)mean * A);
-          if (a.st_stat) reinterpret_cast<float2*>(a.st_stat)[grp * ncols + tid] = make_float2((float)mean, rstd);
-        }
-      } else {
-        if (tid < 64) {   // first wave: strided fixed-order sums, then the xor butterfly
-          double u1 = 0.0, u2 = 0.0;
-          for (int k = tid; k < slices * cp; k += 64) {
-            u1 += red[k];
-            u2 += red[NT + k];
-          }
-          u1 = pn::wave_sum(u1);
-          u2 = pn::wave_sum(u2);
-          if (tid == 0) {
-            const double n = (double)a.OH * wsub * ncols;
-            const double mean = u1 / n;
-            double var = u2 / n - mean * mean;
-            var = var < 0.0 ? 0.0 : var;
-            s_ms[0] = (float)mean;
-            s_ms[1] = (float)(1.0 / sqrt(var + (double)a.st_eps));
-            if (a.st_stat) reinterpret_cast<float2*>(a.st_stat)[grp] = make_float2(s_ms[0], s_ms[1]);
-          }
-        }
-        __syncthreads();
-        if (a.st_ab)
-          for (int c = tid; c < ncols; c += NT) {
-            const float ga = a.st_gamma ? a.st_gamma[slot * ncols + c] : 1.f, be = a.st_beta ? a.st_beta[slot * ncols + c] : 0.f;
-            const float A = ga * s_ms[1];
-            reinterpret_cast<float2*>(a.st_ab)[grp * ncols + c] = make_float2(A, be - s_ms[0] * A);
-          }
-      }
-      __syncthreads();
-    }
-}
 
 template <int WM, int WN, int TM, int TN, int DT, bool GATHER, bool NORM_IN>
 __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid, const int n0, const int z) {
@@ -588,9 +507,14 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid, cons
       }
     }
     if (a.st_part) {
-      // ---- output statistics: per-column (sum, sum of squares) of the wave's 32-row segments, straight from the LDS tile
+      // ---- output statistics, reduced inside the block before they leave it:
+      //   per-channel groups: ONE (sum, sum of squares) per column for the whole tile (the host guarantees a tile never
+      //                       straddles two samples)              -> part[z][tile][cout_pad]
+      //   all-channel groups: one pair per 32-row segment and wave column (lanes reduced by the xor butterfly)
+      //                                                            -> part[z][segment][WN]
       constexpr int LPC = 64 / TC > 0 ? 64 / TC : 1;   // lanes per column (TC = 32: two, 16 rows each; TC = 64: one, 32 rows)
       constexpr int RPL = 32 / LPC;
+      __shared__ float s_red[WM][BN][2];
       const int col = lane % TC, part_h = lane / TC;
       const int gcol = n0 + wn * TC + col;
       float csc = 1.f, csh = 0.f;
@@ -598,7 +522,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid, cons
         if (a.scale) csc = a.scale[z * a.Cout + gcol];
         if (a.shift) csh = a.shift[z * a.Cout + gcol];
       }
-      float* part = a.st_part + (size_t)z * a.st_segs_z * a.cout_pad * 2;
+      const bool per_channel = a.st_cg > 1;
+      float2* part = reinterpret_cast<float2*>(a.st_part);
+      float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         float s1 = 0.f, s2 = 0.f;
@@ -606,33 +532,41 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid, cons
         for (int r = 0; r < RPL; ++r) {
           const int row = i * 32 + part_h * RPL + r;
           const float v = fmaf(tile[row * TLD + col], csc, csh);
-          const bool live = m0 + wm * TR + row < m_valid;
+          const bool live = (m0 + wm * TR + row < m_valid) && gcol < a.ncols;
           s1 += live ? v : 0.f;
           s2 += live ? v * v : 0.f;
         }
+        if (per_channel) {
+          t1 += s1;
+          t2 += s2;
+        } else {
+          s1 = pn::wave_sum(s1);
+          s2 = pn::wave_sum(s2);
+          if (lane == 0) {
+            const int seg = (m0 + wm * TR) / 32 + i;
+            part[((size_t)z * a.st_segs_z + seg) * WN + wn] = make_float2(s1, s2);
+          }
+        }
+      }
+      if (per_channel) {
         if constexpr (LPC == 2) {
-          s1 += __shfl_xor(s1, 32, 64);
-          s2 += __shfl_xor(s2, 32, 64);
+          t1 += __shfl_xor(t1, 32, 64);
+          t2 += __shfl_xor(t2, 32, 64);
         }
-        if (part_h == 0 && gcol < a.cout_pad) {
-          const int seg = (m0 + wm * TR) / 32 + i;
-          float2* dst = reinterpret_cast<float2*>(part) + (size_t)seg * a.cout_pad + gcol;
-          *dst = make_float2(gcol < a.ncols ? s1 : 0.f, gcol < a.ncols ? s2 : 0.f);
+        if (part_h == 0) {
+          s_red[wm][wn * TC + col][0] = t1;
+          s_red[wm][wn * TC + col][1] = t2;
         }
-      }
-      // ---- ticket: the block that arrives last at this (job, z) folds the partials in a fixed order
-      __shared__ unsigned s_last;
-      __threadfence();
-      __syncthreads();
-      if (tid == 0) {
-        const unsigned t = atomicAdd(a.st_ticket + z, 1u);
-        s_last = (t == (unsigned)a.st_tiles - 1u) ? 1u : 0u;
-      }
-      __syncthreads();
-      if (s_last) {
-        __threadfence();
-        finalize_stats<NT>(a, z, smem);
-        if (tid == 0) a.st_ticket[z] = 0u;   // ready for the next launch (hipGraph replay)
+        __syncthreads();
+        if (tid < BN && tid < a.cout_pad) {
+          float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+          for (int k = 0; k < WM; ++k) {
+            u1 += s_red[k][tid][0];
+            u2 += s_red[k][tid][1];
+          }
+          part[((size_t)z * a.nmt + mt) * a.cout_pad + tid] = make_float2(u1, u2);
+        }
       }
     }
     return;
@@ -726,22 +660,228 @@ struct MultiArgs {
 template <int WM, int WN, int TM, int TN, bool NORM_IN>
 __global__ __launch_bounds__(WM* WN * 64) void conv_multi_kernel(MultiArgs m_by_value) {
   constexpr int BN = WN * TN * 32;
-  // The job table is read through the kernarg segment pointer (scalar loads at a block-uniform offset): indexing the
-  // by-value parameter dynamically would make the compiler copy all of it to scratch.
-  const MultiArgs* mp = (const MultiArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  // The job table is read through the kernarg segment pointer, in the CONSTANT address space and at a block-uniform offset
+  // (scalar loads into SGPRs, once): indexing the by-value parameter dynamically would make the compiler copy all of it to
+  // scratch, and reading it through a generic pointer reloads every field inside the K loop.
+  typedef const __attribute__((address_space(4))) int* kptr_t;
+  const kptr_t base = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const int njobs = base[offsetof(MultiArgs, njobs) / 4], nt = base[offsetof(MultiArgs, total) / 4];
   const int bid = blockIdx.x;
-  const int nt = mp->total, q = nt >> 3, r = nt & 7, x = bid & 7, idx = bid >> 3;
+  const int q = nt >> 3, r = nt & 7, x = bid & 7, idx = bid >> 3;
   const int t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
   int j = 0;
-  for (int k = 1; k < mp->njobs; ++k)
-    if (t >= mp->first[k]) j = k;
+  for (int k = 1; k < njobs; ++k)
+    if (t >= base[offsetof(MultiArgs, first) / 4 + k]) j = k;
   j = __builtin_amdgcn_readfirstlane(j);
-  const ConvArgs& a = mp->job[j];
-  const int local = t - mp->first[j];
+  const int local = t - base[offsetof(MultiArgs, first) / 4 + j];
+  static_assert(sizeof(ConvArgs) % 4 == 0 && offsetof(MultiArgs, job) % 4 == 0, "job table must be dword aligned");
+  constexpr int JW = sizeof(ConvArgs) / 4;
+  union { ConvArgs a; int w[JW]; } u;
+  const kptr_t src = base + offsetof(MultiArgs, job) / 4 + j * JW;
+#pragma unroll
+  for (int i = 0; i < JW; ++i) u.w[i] = src[i];
+  const ConvArgs& a = u.a;
   const int ntn = (a.ncols + BN - 1) / BN, per_z = a.nmt * ntn;
   const int z = local / per_z, rem = local - z * per_z;
   const int ny = rem / a.nmt, mt = rem - ny * a.nmt;
   conv_body<WM, WN, TM, TN, DT_F32, false, NORM_IN>(a, mt, ny * BN, z);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Fold of the statistics partials a convolution's epilogue wrote (fixed order, fp64) -> affine table (A, B) / (mean, rstd).
+// One block per (job, z, sample, 16-column chunk) for per-channel groups, per (job, z, sample, stratum) for all-channel ones.
+struct FinArgs {
+  int njobs, total;
+  int first[kMaxJobs + 1];
+  int bm, wn;
+  ConvArgs job[kMaxJobs];
+};
+
+__device__ __forceinline__ void group_geometry(const ConvArgs& a, int& pix_b, int& wsub, int& spr) {
+  pix_b = a.OH * a.OWsub;
+  wsub = a.OWsub / a.st_S;
+  spr = a.st_S > 1 ? wsub / 32 : 1;
+}
+
+// (sum, sum of squares) of the all-channel group (z, b, s) from part[z][segment][wn]: every thread of the block calls this;
+// the result is the same on all of them (fixed association order)
+template <int NT>
+__device__ __forceinline__ void fold_allch_group(const ConvArgs& a, const float2* part, int wn_count, int z, int b, int s, double* red,
+                                                 double& o1, double& o2) {
+  int pix_b, wsub, spr;
+  group_geometry(a, pix_b, wsub, spr);
+  const int tid = threadIdx.x;
+  const int count = (a.st_S == 1 ? (pix_b + 31) / 32 : a.OH * spr) * wn_count;
+  double t1 = 0.0, t2 = 0.0;
+  for (int e = tid; e < count; e += NT) {
+    const int i = e / wn_count, w = e - i * wn_count;
+    const int seg = a.st_S == 1 ? (b * pix_b) / 32 + i : ((b * a.OH + i / spr) * a.OWsub + s * wsub) / 32 + i % spr;
+    const float2 v = part[((size_t)z * a.st_segs_z + seg) * wn_count + w];
+    t1 += (double)v.x;
+    t2 += (double)v.y;
+  }
+  t1 = pn::wave_sum(t1);   // xor butterfly: the same association order on every run
+  t2 = pn::wave_sum(t2);
+  __syncthreads();
+  if ((tid & 63) == 0) {
+    red[tid >> 6] = t1;
+    red[NT / 64 + (tid >> 6)] = t2;
+  }
+  __syncthreads();
+  o1 = 0.0;
+  o2 = 0.0;
+  for (int k = 0; k < NT / 64; ++k) {
+    o1 += red[k];
+    o2 += red[NT / 64 + k];
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_stats_finalize_kernel(FinArgs by_value) {
+  constexpr int NT = 256;
+  typedef const __attribute__((address_space(4))) int* kptr_t;
+  const kptr_t base = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const int njobs = base[offsetof(FinArgs, njobs) / 4];
+  const int BM = base[offsetof(FinArgs, bm) / 4], WNc = base[offsetof(FinArgs, wn) / 4];
+  const int t = blockIdx.x;
+  int j = 0;
+  for (int k = 1; k < njobs; ++k)
+    if (t >= base[offsetof(FinArgs, first) / 4 + k]) j = k;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const int local = t - base[offsetof(FinArgs, first) / 4 + j];
+  constexpr int JW = sizeof(ConvArgs) / 4;
+  union { ConvArgs a; int w[JW]; } u;
+  const kptr_t src = base + offsetof(FinArgs, job) / 4 + j * JW;
+#pragma unroll
+  for (int i = 0; i < JW; ++i) u.w[i] = src[i];
+  const ConvArgs& a = u.a;
+
+  __shared__ double red[2 * NT];
+  const int tid = threadIdx.x;
+  const int cp = a.cout_pad, ncols = a.ncols;
+  int pix_b, wsub, spr;
+  group_geometry(a, pix_b, wsub, spr);
+  const float2* part = reinterpret_cast<const float2*>(a.st_part);
+  if (a.st_cg > 1) {
+    // per-channel groups: part[z][tile][cp]
+    const int chunks = (cp + 15) / 16;
+    const int z = local / (a.B * chunks), rem = local - z * (a.B * chunks), b = rem / chunks, chunk = rem - b * chunks;
+    const int c = chunk * 16 + (tid & 15), sl = tid >> 4;   // 16 slices of the sample's tiles
+    const int tiles_b = a.B == 1 ? a.nmt : pix_b / BM;
+    const float2* pb = part + ((size_t)z * a.nmt + (size_t)b * tiles_b) * cp + c;
+    double t1 = 0.0, t2 = 0.0;
+    if (c < cp) {
+#pragma unroll 8
+      for (int i = sl; i < tiles_b; i += 16) {
+        const float2 v = pb[(size_t)i * cp];
+        t1 += (double)v.x;
+        t2 += (double)v.y;
+      }
+    }
+    red[tid] = t1;
+    red[NT + tid] = t2;
+    __syncthreads();
+    if (tid < 16 && c < ncols) {
+      double u1 = 0.0, u2 = 0.0;
+      for (int k = 0; k < 16; ++k) {
+        u1 += red[k * 16 + tid];
+        u2 += red[NT + k * 16 + tid];
+      }
+      const double n = (double)pix_b;
+      const double mean = u1 / n;
+      double var = u2 / n - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      const float rstd = (float)(1.0 / sqrt(var + (double)a.st_eps));
+      const int slot = a.mode == MODE_STRAT ? z : 0;
+      const size_t grp = (size_t)b * a.st_ab_S + slot;
+      const float ga = a.st_gamma ? a.st_gamma[slot * ncols + c] : 1.f, be = a.st_beta ? a.st_beta[slot * ncols + c] : 0.f;
+      const float A = ga * rstd;
+      if (a.st_ab) reinterpret_cast<float2*>(a.st_ab)[grp * ncols + c] = make_float2(A, be - (float)mean * A);
+      if (a.st_stat) reinterpret_cast<float2*>(a.st_stat)[grp * ncols + c] = make_float2((float)mean, rstd);
+    }
+    return;
+  }
+  // all-channel groups: part[z][segment][WN]
+  const int S = a.st_S;
+  const int z = local / (a.B * S), rem = local - z * (a.B * S), b = rem / S, s = rem - b * S;
+  double u1, u2;
+  fold_allch_group<NT>(a, part, WNc, z, b, s, red, u1, u2);
+  const double n = (double)a.OH * wsub * ncols;
+  const double mean = u1 / n;
+  double var = u2 / n - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  const float fmean = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)a.st_eps));
+  const int slot = (a.mode == MODE_STRAT ? z : 0) + s;
+  const size_t grp = (size_t)b * a.st_ab_S + slot;
+  if (tid == 0 && a.st_stat) reinterpret_cast<float2*>(a.st_stat)[grp] = make_float2(fmean, rstd);
+  if (a.st_ab)
+    for (int c = tid; c < ncols; c += NT) {
+      const float ga = a.st_gamma ? a.st_gamma[slot * ncols + c] : 1.f, be = a.st_beta ? a.st_beta[slot * ncols + c] : 0.f;
+      const float A = ga * rstd;
+      reinterpret_cast<float2*>(a.st_ab)[grp * ncols + c] = make_float2(A, be - fmean * A);
+    }
+}
+
+// RSNorm / GroupNorm(1 group per stratum) + activation (+ calibrated copy) of a convolution output whose all-channel statistics
+// partials were written by its epilogue: every block first folds the partials of ITS (sample, stratum) group (a few hundred
+// entries), then normalises its rows -- no statistics pass over the map, no finalize launch.
+struct ApplyArgs {
+  ConvArgs conv;     // the producing convolution (geometry + st_part); its `out` is the input here
+  int wn;            // wave columns of the producing tile
+  int splits, rows_per_split;
+  const float* gamma;  // [stratum][C]
+  const float* beta;
+  int act;
+  float* out;
+  int ops, oco;
+  const float* mul;    // (H, W, C) maps, optional: out2 = out * mul + add
+  const float* add;
+  float* out2;
+  int o2ps, o2co;
+};
+
+__global__ __launch_bounds__(256) void conv_stats_apply_kernel(ApplyArgs g) {
+  constexpr int NT = 256;
+  __shared__ double red[2 * (NT / 64)];
+  const ConvArgs& a = g.conv;
+  const int split = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+  double u1, u2;
+  fold_allch_group<NT>(a, reinterpret_cast<const float2*>(a.st_part), g.wn, 0, b, s, red, u1, u2);
+  const int H = a.OH, W = a.OW, C = a.ncols;
+  const int wsub = W / a.st_S;
+  const double n = (double)H * wsub * C;
+  const double dmean = u1 / n;
+  double var = u2 / n - dmean * dmean;
+  var = var < 0.0 ? 0.0 : var;
+  const float mean = (float)dmean, rstd = (float)(1.0 / sqrt(var + (double)a.st_eps));
+  const int vpc = C / 4;
+  const int cv = threadIdx.x % vpc, pl = threadIdx.x / vpc, ppb = NT / vpc;
+  float ga[4], be[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = cv * 4 + k;
+    ga[k] = g.gamma ? g.gamma[s * C + c] : 1.f;
+    be[k] = g.beta ? g.beta[s * C + c] : 0.f;
+  }
+  const int y0 = split * g.rows_per_split, y1 = min(H, y0 + g.rows_per_split);
+  const int npix = (y1 - y0) * wsub;
+  for (int p = pl; p < npix; p += ppb) {
+    const int y = y0 + p / wsub, x = s * wsub + p % wsub;
+    const size_t pix = (size_t)(b * H + y) * W + x;
+    f32x4 v = *reinterpret_cast<const f32x4*>(a.out + pix * a.out_ps + a.out_co + cv * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = pn::apply_act((v[k] - mean) * rstd * ga[k] + be[k], g.act);
+    *reinterpret_cast<f32x4*>(g.out + pix * g.ops + g.oco + cv * 4) = v;
+    if (g.out2) {
+      const size_t q = ((size_t)y * W + x) * C + cv * 4;
+      const f32x4 m = *reinterpret_cast<const f32x4*>(g.mul + q);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(g.add + q);
+      f32x4 w;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = v[k] * m[k] + d[k];
+      *reinterpret_cast<f32x4*>(g.out2 + pix * g.o2ps + g.o2co + cv * 4) = w;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1074,10 +1214,7 @@ int launch_multi(MultiArgs& m, size_t extra_smem, hipStream_t st) {
   for (int j = 0; j < m.njobs; ++j) {
     ConvArgs& a = m.job[j];
     a.nmt = pn::cdiv(a.M, BM);
-    a.st_segs_z = a.nmt * (BM / 32);
     const int tiles_z = a.nmt * pn::cdiv(a.ncols, BN);
-    a.st_tiles = tiles_z;
-    if (a.st_part) PN_REQUIRE(a.cout_pad <= WM * WN * 64 && pn::cdiv(a.ncols, BN) == 1, "conv_multi: statistics need the job's columns in one column tile");
     m.first[j] = total;
     total += tiles_z * a.zdim;
   }
@@ -1241,50 +1378,61 @@ size_t pn_conv_stat_partial_floats(const pn_conv_desc* d, int tile) {
   return (size_t)zdim * pn::cdiv(a.M, bm) * (bm / 32) * a.cout_pad * 2;
 }
 
+static int tile_wn(int tile) { return tile == 5 ? 4 : (tile == 4 ? 1 : 2); }
+
+// pn_conv_job -> ConvArgs (validation included); `extra` = LDS bytes of the normalise-on-load table
+static int job_to_args(const pn_conv_job& jb, int tile, ConvArgs& a, size_t& extra) {
+  int zdim = 1;
+  if (int rc = fill_args(&jb.desc, a, zdim)) return rc;
+  const pn_conv_desc* d = &jb.desc;
+  PN_REQUIRE(jb.in && jb.packed_w && jb.out, "conv_multi: null pointer");
+  PN_REQUIRE(d->cin % 4 == 0 && d->in_pixel_stride % 4 == 0 && d->in_channel_offset % 4 == 0,
+             "conv_multi: cin, input pixel stride and channel offset must be multiples of 4");
+  PN_REQUIRE(((uintptr_t)jb.in & 15) == 0 && ((uintptr_t)jb.packed_w & 15) == 0, "conv_multi: pointers must be 16-byte aligned");
+  PN_REQUIRE(!d->accumulate, "conv_multi: accumulate is not supported");
+  a.in = jb.in; a.w = jb.packed_w; a.scale = jb.scale; a.shift = jb.shift; a.out = jb.out;
+  a.zdim = zdim;
+  const int bm = tile_bm(tile), bn = tile_wn(tile) * (tile == 1 ? 64 : 32);
+  a.nmt = pn::cdiv(a.M, bm);
+  a.st_segs_z = a.nmt * (bm / 32);
+  if (jb.stat_partials) {
+    PN_REQUIRE(a.mode != MODE_DECONV2, "conv_multi: no statistics for the transposed convolution");
+    PN_REQUIRE((a.Cout % 4 == 0) && (a.out_ps % 4 == 0) && (a.out_co % 4 == 0) && (((uintptr_t)a.out & 15) == 0),
+               "conv_multi: statistics need the vectorised epilogue (channel counts / offsets multiples of 4)");
+    PN_REQUIRE(a.mode == MODE_STRAT || zdim == 1, "conv_multi: statistics of grouped convolutions are not supported");
+    PN_REQUIRE(a.ncols <= bn, "conv_multi: statistics need the job's columns in one column tile");
+    const int S = jb.stat_strata < 1 ? 1 : jb.stat_strata;
+    PN_REQUIRE(S == 1 || (a.mode == MODE_CONV && a.OWsub % S == 0 && (a.OWsub / S) % 32 == 0),
+               "conv_multi: stat_strata needs a plain convolution whose strata are multiples of 32 columns");
+    PN_REQUIRE(a.B == 1 || (a.OH * a.OWsub) % (jb.stat_channel_groups > 1 ? bm : 32) == 0,
+               "conv_multi: with batch > 1 a sample must be a whole number of tiles (per-channel statistics) / 32-row segments");
+    PN_REQUIRE(jb.stat_channel_groups == 1 || jb.stat_channel_groups == a.ncols, "conv_multi: channel groups must be 1 or the column count");
+    const int slots = a.mode == MODE_STRAT ? zdim : S;
+    PN_REQUIRE(jb.stat_affine_strata >= slots, "conv_multi: stat_affine_strata too small");
+    a.st_part = jb.stat_partials; a.st_S = S; a.st_cg = jb.stat_channel_groups;
+    a.st_gamma = jb.stat_gamma; a.st_beta = jb.stat_beta; a.st_eps = jb.stat_eps;
+    a.st_ab = jb.stat_affine; a.st_ab_S = jb.stat_affine_strata; a.st_stat = jb.stat_mean_rstd;
+  }
+  if (jb.norm_affine) {
+    PN_REQUIRE(jb.norm_strata >= 1 && a.W % jb.norm_strata == 0 && a.KW <= 3 && a.KH * a.KW <= 16, "conv_multi: bad normalise-on-load geometry");
+    PN_REQUIRE(jb.norm_channels >= a.Cin * (d->groups > 1 ? d->groups : 1) && a.B * jb.norm_strata < 1024, "conv_multi: normalisation table too small / too many groups");
+    a.ni_ab = jb.norm_affine; a.ni_S = jb.norm_strata; a.ni_C = jb.norm_channels;
+    extra = std::max(extra, (size_t)a.B * a.ni_S * a.ni_C * 2 * sizeof(float));
+  }
+  return PN_OK;
+}
+
 int pn_conv2d_multi_f32(const pn_conv_job* jobs, int njobs, int tile, pn_stream_t stream) {
   PN_REQUIRE(jobs && njobs >= 1 && njobs <= kMaxJobs, "conv_multi: 1 .. 8 jobs");
+  PN_REQUIRE(tile == 1 || tile == 3 || tile == 4 || tile == 5, "conv_multi: tile must be 1 (128x128), 3 (64x64), 4 (64x32) or 5 (64x128)");
   MultiArgs m;
   memset(&m, 0, sizeof(m));
   m.njobs = njobs;
   bool norm_in = false;
   size_t extra = 0;
   for (int j = 0; j < njobs; ++j) {
-    const pn_conv_job& jb = jobs[j];
-    ConvArgs& a = m.job[j];
-    int zdim = 1;
-    if (int rc = fill_args(&jb.desc, a, zdim)) return rc;
-    const pn_conv_desc* d = &jb.desc;
-    PN_REQUIRE(jb.in && jb.packed_w && jb.out, "conv_multi: null pointer");
-    PN_REQUIRE(d->cin % 4 == 0 && d->in_pixel_stride % 4 == 0 && d->in_channel_offset % 4 == 0,
-               "conv_multi: cin, input pixel stride and channel offset must be multiples of 4");
-    PN_REQUIRE(((uintptr_t)jb.in & 15) == 0 && ((uintptr_t)jb.packed_w & 15) == 0, "conv_multi: pointers must be 16-byte aligned");
-    PN_REQUIRE(!d->accumulate, "conv_multi: accumulate is not supported");
-    a.in = jb.in; a.w = jb.packed_w; a.scale = jb.scale; a.shift = jb.shift; a.out = jb.out;
-    a.zdim = zdim;
-    if (jb.stat_partials) {
-      PN_REQUIRE(jb.stat_tickets && (jb.stat_affine || jb.stat_mean_rstd), "conv_multi: statistics need tickets and an output table");
-      PN_REQUIRE(a.mode != MODE_DECONV2, "conv_multi: no statistics for the transposed convolution");
-      PN_REQUIRE((a.Cout % 4 == 0) && (a.out_ps % 4 == 0) && (a.out_co % 4 == 0) && (((uintptr_t)a.out & 15) == 0),
-                 "conv_multi: statistics need the vectorised epilogue (channel counts / offsets multiples of 4)");
-      PN_REQUIRE(a.mode == MODE_STRAT || zdim == 1, "conv_multi: statistics of grouped convolutions are not supported");
-      const int S = jb.stat_strata < 1 ? 1 : jb.stat_strata;
-      PN_REQUIRE(S == 1 || (a.mode == MODE_CONV && a.OWsub % S == 0 && (a.OWsub / S) % 32 == 0),
-                 "conv_multi: stat_strata needs a plain convolution whose strata are multiples of 32 columns");
-      PN_REQUIRE(a.B == 1 || (a.OH * a.OWsub) % 32 == 0, "conv_multi: with batch > 1 a sample must be a whole number of 32-row segments");
-      PN_REQUIRE(jb.stat_channel_groups == 1 || jb.stat_channel_groups == a.ncols, "conv_multi: channel groups must be 1 or the column count");
-      const int slots = a.mode == MODE_STRAT ? zdim : S;
-      PN_REQUIRE(jb.stat_affine_strata >= slots, "conv_multi: stat_affine_strata too small");
-      a.st_part = jb.stat_partials; a.st_ticket = jb.stat_tickets; a.st_S = S; a.st_cg = jb.stat_channel_groups;
-      a.st_gamma = jb.stat_gamma; a.st_beta = jb.stat_beta; a.st_eps = jb.stat_eps;
-      a.st_ab = jb.stat_affine; a.st_ab_S = jb.stat_affine_strata; a.st_stat = jb.stat_mean_rstd;
-    }
-    if (jb.norm_affine) {
-      PN_REQUIRE(jb.norm_strata >= 1 && a.W % jb.norm_strata == 0 && a.KW <= 3 && a.KH * a.KW <= 16, "conv_multi: bad normalise-on-load geometry");
-      PN_REQUIRE(jb.norm_channels >= a.Cin * (d->groups > 1 ? d->groups : 1) && a.B * jb.norm_strata < 1024, "conv_multi: normalisation table too small / too many groups");
-      a.ni_ab = jb.norm_affine; a.ni_S = jb.norm_strata; a.ni_C = jb.norm_channels;
-      norm_in = true;
-      extra = std::max(extra, (size_t)a.B * a.ni_S * a.ni_C * 2 * sizeof(float));
-    }
+    if (int rc = job_to_args(jobs[j], tile, m.job[j], extra)) return rc;
+    norm_in = norm_in || m.job[j].ni_ab != nullptr;
   }
   if (norm_in)
     for (int j = 0; j < njobs; ++j) PN_REQUIRE(m.job[j].ni_ab, "conv_multi: normalise-on-load must be given for every job of the launch or for none");
@@ -1293,9 +1441,61 @@ int pn_conv2d_multi_f32(const pn_conv_job* jobs, int njobs, int tile, pn_stream_
     case 1: PN_REQUIRE(!norm_in, "conv_multi: tile 1 has no normalise-on-load variant"); return launch_multi<2, 2, 2, 2, false>(m, 0, st);
     case 3: return norm_in ? launch_multi<2, 2, 1, 1, true>(m, extra, st) : launch_multi<2, 2, 1, 1, false>(m, 0, st);
     case 4: return norm_in ? launch_multi<2, 1, 1, 1, true>(m, extra, st) : launch_multi<2, 1, 1, 1, false>(m, 0, st);
-    case 5: PN_REQUIRE(!norm_in, "conv_multi: tile 5 has no normalise-on-load variant"); return launch_multi<2, 4, 1, 1, false>(m, 0, st);
-    default: return pn::fail(PN_ERR_INVALID, "conv_multi: tile must be 1 (128x128), 3 (64x64), 4 (64x32) or 5 (64x128)");
+    default: PN_REQUIRE(!norm_in, "conv_multi: tile 5 has no normalise-on-load variant"); return launch_multi<2, 4, 1, 1, false>(m, 0, st);
   }
+}
+
+int pn_conv_stats_finalize_f32(const pn_conv_job* jobs, int njobs, int tile, pn_stream_t stream) {
+  PN_REQUIRE(jobs && njobs >= 1 && njobs <= kMaxJobs, "conv_stats_finalize: 1 .. 8 jobs");
+  PN_REQUIRE(tile == 1 || tile == 3 || tile == 4 || tile == 5, "conv_stats_finalize: bad tile");
+  FinArgs f;
+  memset(&f, 0, sizeof(f));
+  f.bm = tile_bm(tile);
+  f.wn = tile_wn(tile);
+  int n = 0, total = 0;
+  for (int j = 0; j < njobs; ++j) {
+    if (!jobs[j].stat_partials) continue;
+    PN_REQUIRE(jobs[j].stat_affine || jobs[j].stat_mean_rstd, "conv_stats_finalize: no output table");
+    ConvArgs& a = f.job[n];
+    size_t extra = 0;
+    if (int rc = job_to_args(jobs[j], tile, a, extra)) return rc;
+    f.first[n] = total;
+    total += a.st_cg > 1 ? a.zdim * a.B * pn::cdiv(a.cout_pad, 16) : a.zdim * a.B * a.st_S;
+    ++n;
+  }
+  PN_REQUIRE(n > 0, "conv_stats_finalize: no job carries statistics");
+  f.njobs = n;
+  f.first[n] = total;
+  f.total = total;
+  hipLaunchKernelGGL(conv_stats_finalize_kernel, dim3(total), dim3(256), 0, pn::S(stream), f);
+  return pn::check_launch("conv_stats_finalize_kernel");
+}
+
+int pn_conv_stats_apply_f32(const pn_conv_job* producer, int tile, const float* gamma, const float* beta, int act, float* out,
+                            int out_pixel_stride, int out_channel_offset, const float* mul, const float* add, float* out2,
+                            int out2_pixel_stride, int out2_channel_offset, pn_stream_t stream) {
+  PN_REQUIRE(producer && producer->stat_partials && out, "conv_stats_apply: null pointer");
+  PN_REQUIRE(tile == 1 || tile == 3 || tile == 4 || tile == 5, "conv_stats_apply: bad tile");
+  ApplyArgs g;
+  memset(&g, 0, sizeof(g));
+  size_t extra = 0;
+  if (int rc = job_to_args(*producer, tile, g.conv, extra)) return rc;
+  const ConvArgs& a = g.conv;
+  PN_REQUIRE(a.mode == MODE_CONV && a.zdim == 1 && a.st_cg == 1, "conv_stats_apply: the producer must be a plain convolution with all-channel statistics");
+  const int c = a.ncols;
+  PN_REQUIRE(c % 4 == 0 && c <= 1024 && 1024 % c == 0, "conv_stats_apply: channel count must be a multiple of 4 dividing 1024");
+  PN_REQUIRE(out_pixel_stride % 4 == 0 && out_channel_offset % 4 == 0, "conv_stats_apply: output stride / offset must be multiples of 4");
+  PN_REQUIRE(out2 == nullptr || (mul && add && out2_pixel_stride % 4 == 0 && out2_channel_offset % 4 == 0), "conv_stats_apply: out2 needs mul, add and aligned strides");
+  g.wn = tile_wn(tile);
+  int splits = 1;
+  while (splits < a.OH && (long long)a.B * a.st_S * splits < 512) splits *= 2;
+  g.splits = splits;
+  g.rows_per_split = pn::cdiv(a.OH, splits);
+  g.gamma = gamma; g.beta = beta; g.act = act;
+  g.out = out; g.ops = out_pixel_stride; g.oco = out_channel_offset;
+  g.mul = mul; g.add = add; g.out2 = out2; g.o2ps = out2_pixel_stride; g.o2co = out2_channel_offset;
+  hipLaunchKernelGGL(conv_stats_apply_kernel, dim3(splits, a.st_S, a.B), dim3(256), 0, pn::S(stream), g);
+  return pn::check_launch("conv_stats_apply_kernel");
 }
 
 int pn_gemm_bias_act_f32(const float* x, int m, int k, int ldx, const float* packed_w, int n, const float* bias, int act,

@@ -307,13 +307,14 @@ class CenterHeadSingle(CenterHead):
         plan["fused"] = self._build_fused()
         return plan
 
-    # ---- fused execution: 4 launches + one ticket clear instead of ~26 (convolutions + 15 GroupNorm passes) ----------
+    # ---- fused execution: 5 launches instead of ~26 (convolutions + 15 GroupNorm passes) ----------
     def _build_fused(self):
         """Layers of the fused path, or None when the head does not have the shape the fused kernels cover: every branch
         = [3x3 conv (or RangeStratified) -> GroupNorm-family -> ReLU -> last conv], 64 hidden channels.
-        Launch 1: shared conv, its epilogue emits the RSNorm statistics.  Launch 2: RSNorm + ReLU (+ calibration) -> [xs | x_hm].
-        Launch 3: ALL first-stage branch convolutions as one multi-job launch, each emitting its GroupNorm statistics.
-        Launch 4: ALL last convolutions as one multi-job launch that applies GroupNorm + ReLU while loading its input."""
+        Launch 1: shared conv, its epilogue emits the RSNorm statistics partials.  Launch 2: RSNorm + ReLU (+ calibration) ->
+        [xs | x_hm], folding the partials in its prologue.  Launch 3: ALL first-stage branch convolutions as one multi-job launch,
+        each emitting its GroupNorm statistics partials; 3b: one small launch folds them into affine tables.  Launch 4: ALL last
+        convolutions as one multi-job launch that applies GroupNorm + ReLU while loading its input."""
         rs = self.shared_conv[1]
         if not isinstance(rs, RSNorm) or rs.num_heads != 1:
             return None
@@ -357,7 +358,7 @@ class CenterHeadSingle(CenterHead):
         for name, lay, st, cmid in fz["first"]:
             if lay.range_strata > 1 and (w % lay.range_strata != 0 or (b > 1 and (h * (w // lay.range_strata)) % 32 != 0)):
                 return False
-        return b == 1 or (h * w) % 32 == 0
+        return b == 1 or (h * w) % 64 == 0
 
     def _forward_fused(self, plan, x: torch.Tensor):
         fz = plan["fused"]
@@ -366,36 +367,33 @@ class CenterHeadSingle(CenterHead):
         f32 = dict(dtype=torch.float32, device=dev)
         c_sh = fz["c_sh"]
         mul, add = self._calibration(plan, x[..., :c_sh])
-        n_first = len(fz["first"])
-        n_tick = 1 + sum(max(lay.range_strata, 1) for _, lay, _, _ in fz["first"])
-        tickets = torch.empty((n_tick,), dtype=torch.int32, device=dev)
-        hip.call("pn_fill_zero", tickets.data_ptr(), tickets.numel() * 4, hip.stream())
-        # launch 1: shared convolution + RSNorm statistics
         s_rs, g_rs, b_rs, eps_rs = fz["rs"]
         raw = torch.empty((b, h, w, c_sh), **f32)
-        stat0 = torch.empty((b, s_rs, 1, 2), **f32)
         j0 = ops.ConvJob(fz["shared"], x, raw)
-        j0.stats = dict(strata=s_rs, channel_groups=1, gamma=None, beta=None, eps=eps_rs, affine_strata=s_rs, mean_rstd=stat0,
-                        partials=torch.empty((j0.partial_floats(3),), **f32), tickets=tickets[0:1])
-        ops.conv_multi([j0], 3)
-        # launch 2: RSNorm + ReLU -> xs, and the position-calibrated copy for the heat-map branch
         xcat = torch.empty((b, h, w, c_sh * (2 if mul is not None else 1)), **f32)
-        ops.groupnorm_apply(raw, 1, s_rs, stat0, g_rs, b_rs, ops.ACT_RELU, xcat, 0, mul=mul, add=add, out2=xcat if mul is not None else None,
-                            out2_channel_offset=c_sh)
-        # launch 3: every first-stage branch, statistics of its GroupNorm in the epilogue
         cm_tot = sum(cm for *_, cm in fz["first"])
         mid = torch.empty((b, h, w, cm_tot), **f32)
-        jobs, tabs, off, tk = [], [], 0, 1
+        jobs1, off = [], 0
         for name, lay, st, cmid in fz["first"]:
-            nz = max(lay.range_strata, 1)
-            jb = ops.ConvJob(lay, xcat, mid, in_channel_offset=(c_sh if (name == "hm" and mul is not None) else 0), out_channel_offset=off)
+            jobs1.append(ops.ConvJob(lay, xcat, mid, in_channel_offset=(c_sh if (name == "hm" and mul is not None) else 0), out_channel_offset=off))
+            off += cmid
+        # launch 1: shared convolution, RSNorm statistics partials in its epilogue
+        j0.stats = dict(strata=s_rs, channel_groups=1, gamma=None, beta=None, eps=eps_rs, affine_strata=s_rs,
+                        partials=torch.empty((j0.partial_floats(3),), **f32))
+        ops.conv_multi([j0], 3)
+        # launch 2: RSNorm + ReLU -> xs, and the position-calibrated copy for the heat-map branch (each block folds the partials of
+        # its own stratum first: no statistics pass, no finalize launch)
+        ops.conv_stats_apply(j0, 3, g_rs, b_rs, ops.ACT_RELU, xcat, 0, mul=mul, add=add, out2=xcat if mul is not None else None,
+                             out2_channel_offset=c_sh)
+        # launch 3: every first-stage branch, GroupNorm statistics partials in the epilogue; launch 3b folds them
+        tabs, off = [], 0
+        for jb, (name, lay, st, cmid) in zip(jobs1, fz["first"]):
             tab = torch.empty((b, st["affine_strata"], cmid, 2), **f32)
-            jb.stats = dict(st, affine=tab, partials=torch.empty((jb.partial_floats(3),), **f32), tickets=tickets[tk:tk + nz])
-            jobs.append(jb)
+            jb.stats = dict(st, affine=tab, partials=torch.empty((jb.partial_floats(3),), **f32))
             tabs.append((tab, st["affine_strata"], cmid, off))
             off += cmid
-            tk += nz
-        ops.conv_multi(jobs, 3)
+        ops.conv_multi(jobs1, 3)
+        ops.conv_stats_finalize(jobs1, 3)
         # launch 4: every last convolution, GroupNorm + ReLU applied while the input tile is loaded
         widths = [(co + 3) // 4 * 4 for *_, co in fz["last"]]
         out = torch.empty((b, h, w, sum(widths)), **f32)

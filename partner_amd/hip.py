@@ -34,7 +34,7 @@ class ConvJob(C.Structure):
     """mirror of ``pn_conv_job``"""
 
     _fields_ = [("desc", ConvDesc), ("in_", C.c_void_p), ("packed_w", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
-                ("out", C.c_void_p), ("stat_partials", C.c_void_p), ("stat_tickets", C.c_void_p), ("stat_strata", C.c_int32),
+                ("out", C.c_void_p), ("stat_partials", C.c_void_p), ("stat_strata", C.c_int32),
                 ("stat_channel_groups", C.c_int32), ("stat_gamma", C.c_void_p), ("stat_beta", C.c_void_p), ("stat_eps", C.c_float),
                 ("stat_affine_strata", C.c_int32), ("stat_affine", C.c_void_p), ("stat_mean_rstd", C.c_void_p),
                 ("norm_affine", C.c_void_p), ("norm_strata", C.c_int32), ("norm_channels", C.c_int32)]
@@ -81,6 +81,8 @@ SIGNATURES = {
     "pn_conv2d_nhwc_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "pn_conv_stat_partial_floats": (_SZ, [C.POINTER(ConvDesc), _I]),
     "pn_conv2d_multi_f32": (_I, [C.POINTER(ConvJob), _I, _I, _P]),
+    "pn_conv_stats_finalize_f32": (_I, [C.POINTER(ConvJob), _I, _I, _P]),
+    "pn_conv_stats_apply_f32": (_I, [C.POINTER(ConvJob), _I, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
     "pn_groupnorm_apply_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
     "pn_conv2d_direct_nhwc_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "pn_conv_packed_weight_bf16_elems": (_SZ, [_I, _I, _I, _I, _I]),

@@ -441,12 +441,9 @@ class ConvJob:
         return int(hip.load().pn_conv_stat_partial_floats(C.byref(self.desc), tile))
 
 
-def conv_multi(jobs: Sequence[ConvJob], tile: int, scratch: Optional[dict] = None) -> None:
-    """run the jobs as ONE launch of the MFMA kernel (tile: 1 = 128x128, 3 = 64x64, 4 = 64x32, 5 = 64x128).
-    Statistics jobs need ``stats['partials']`` (float scratch of ``job.partial_floats(tile)``) and ``stats['tickets']`` (uint32,
-    one per z slice, zero on entry -- left zero)."""
+
+def _job_array(jobs: Sequence[ConvJob]):
     arr = (hip.ConvJob * len(jobs))()
-    keep = []
     for k, jb in enumerate(jobs):
         c = arr[k]
         c.desc = jb.desc
@@ -454,7 +451,7 @@ def conv_multi(jobs: Sequence[ConvJob], tile: int, scratch: Optional[dict] = Non
         c.scale, c.shift = hip.ptr(jb.layer.scale), hip.ptr(jb.layer.shift)
         if jb.stats is not None:
             st = jb.stats
-            c.stat_partials, c.stat_tickets = st["partials"].data_ptr(), st["tickets"].data_ptr()
+            c.stat_partials = st["partials"].data_ptr()
             c.stat_strata, c.stat_channel_groups = int(st.get("strata", 1)), int(st["channel_groups"])
             c.stat_gamma, c.stat_beta, c.stat_eps = hip.ptr(st.get("gamma")), hip.ptr(st.get("beta")), float(st["eps"])
             c.stat_affine_strata = int(st["affine_strata"])
@@ -462,6 +459,14 @@ def conv_multi(jobs: Sequence[ConvJob], tile: int, scratch: Optional[dict] = Non
         if jb.norm is not None:
             tab, strata, channels = jb.norm
             c.norm_affine, c.norm_strata, c.norm_channels = tab.data_ptr(), int(strata), int(channels)
+    return arr
+
+
+def conv_multi(jobs: Sequence[ConvJob], tile: int) -> None:
+    """run the jobs as ONE launch of the MFMA kernel (tile: 1 = 128x128, 3 = 64x64, 4 = 64x32, 5 = 64x128).
+    Statistics jobs need ``stats['partials']`` (float scratch of ``job.partial_floats(tile)``); ``conv_stats_finalize`` /
+    ``conv_stats_apply`` turn the partials into the norm's affine table / apply the norm."""
+    arr = _job_array(jobs)
     st = hip.stream()
     prof = _PROFILER
     if prof is not None:
@@ -471,6 +476,19 @@ def conv_multi(jobs: Sequence[ConvJob], tile: int, scratch: Optional[dict] = Non
         j0 = jobs[0]
         prof.end(ev, 2.0 * sum(j.macs for j in jobs), st,
                  tag=f"multi x{len(jobs)} {j0.out.shape[1]}x{j0.out.shape[2]} {sum(j.layer.cin * j.layer.groups for j in jobs)}->{sum(j.layer.out_channels for j in jobs)} k{j0.layer.kh}")
+
+
+def conv_stats_finalize(jobs: Sequence[ConvJob], tile: int) -> None:
+    """fold the statistics partials of the jobs (same list / tile as the ``conv_multi`` call) into their affine tables"""
+    hip.call("pn_conv_stats_finalize_f32", _job_array(jobs), len(jobs), int(tile), hip.stream())
+
+
+def conv_stats_apply(producer: ConvJob, tile: int, gamma, beta, act, out: torch.Tensor, out_channel_offset=0, mul=None, add=None,
+                     out2: Optional[torch.Tensor] = None, out2_channel_offset=0) -> None:
+    """RSNorm + activation (+ calibrated copy) of ``producer.out`` from the partials its epilogue wrote; no finalize launch"""
+    hip.require_device(out)
+    hip.call("pn_conv_stats_apply_f32", _job_array([producer]), int(tile), hip.ptr(gamma), hip.ptr(beta), int(act), out.data_ptr(), out.shape[3],
+             out_channel_offset, hip.ptr(mul), hip.ptr(add), hip.ptr(out2), 0 if out2 is None else out2.shape[3], out2_channel_offset, hip.stream())
 
 
 def groupnorm_apply(x: torch.Tensor, channel_groups: int, range_strata: int, mean_rstd: torch.Tensor, gamma, beta, act, out: torch.Tensor,
