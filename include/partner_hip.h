@@ -106,6 +106,29 @@ size_t pn_bucket_workspace_bytes(int n_capacity);
 int pn_bucket_points(const int32_t *unq_inv, const int32_t *unq_cnt, int n_capacity,
                      const int32_t *n_dev, const int32_t *num_voxels, int32_t *voxel_start,
                      int32_t *order, void *workspace, size_t workspace_bytes, pn_stream_t stream);
+/* ---------------------------------------------------------------------------------------
+ * The per-frame index of the dynamic path in THREE launches (V0 + V1 + unique + bucketing): cart -> polar rows and grid
+ * index as pn_cart_to_polar_f32 / pn_polar_grid_index_f32, voxel ranks in the row order of torch.unique(grid_ind, dim=0)
+ * (det3d/models/readers/pillar_encoder.py:398) by ONE single-pass scan over per-cell point counts, points bucketed by voxel.
+ * Same unq_keys / voxel_start / num_voxels / point sets per voxel as pn_unique_rank_bitmap + pn_bucket_points.
+ *   cell_count: one uint32 per grid cell (batch*Z*T*R), ALL ZERO on entry; left holding the voxels' first point slots --
+ *     pn_clear_frame_cells zeroes those entries again (sparse), so a persistent buffer never needs a dense fill.
+ *   scan_state: pn_voxel_index_fused_state_bytes bytes, all zero on entry, left all zero.
+ *   polar (n, f_in+2), keys (n) uint32, pos (n) int32 (slot of the point inside its cell), unq_keys (n), voxel_start (n+1),
+ *   order (n), num_voxels (1): outputs; rows / entries past the counts are not written.
+ */
+size_t pn_voxel_index_fused_state_bytes(uint64_t num_cells);
+int pn_voxel_index_fused_f32(const float *cart, int n_capacity, int f_in, const int32_t *sample_offsets,
+                             int batch, const float *range_lo, const float *voxel_size,
+                             const int32_t *grid, float *polar, uint32_t *keys, int32_t *pos,
+                             uint32_t *cell_count, void *scan_state, size_t scan_state_bytes,
+                             uint32_t *unq_keys, int32_t *voxel_start, int32_t *order,
+                             int32_t *num_voxels, pn_stream_t stream);
+/* end of frame: zero the canvas cells (nullable) and the cell_count entries (nullable) of the frame's voxels */
+int pn_clear_frame_cells(const uint32_t *unq_keys, const int32_t *num_voxels, int v_capacity,
+                         const int32_t *grid, int c, float *canvas, uint32_t *cell_count,
+                         pn_stream_t stream);
+
 /* order_out = order_in with every voxel run sorted by ascending point index (out of place).  Only
  * the PFN backward (pn_dynamic_pfn_bwd) depends on the order inside a run -- through floating-point
  * summation order -- so a training step that must be bit-reproducible sorts the runs first. */

@@ -11,6 +11,7 @@
 // banks), the layer-0 activations of the current point go through a per-wave LDS row and are
 // read back as broadcasts.
 #include "pn_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -184,7 +185,7 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
 }
 
 constexpr int kHeavyPillar = 64;  // pillars with more points than this take the block-per-pillar kernel
-constexpr int kHeavyWaves = 8;
+constexpr int kHeavyWaves = 4;   // = the waves of the batched path: both run as blocks of ONE launch
 
 constexpr int kFwdBatch = 64;    // pillars per block and round
 constexpr int kFwdPoints = 1024; // point rows staged in LDS per sub-batch (>= kHeavyPillar, so any non-heavy pillar fits)
@@ -194,7 +195,7 @@ constexpr int kFwdPoints = 1024; // point rows staged in LDS per sub-batch (>= k
 // consecutive pillars -- their points are one consecutive range of order[] -- and stages run bounds, keys and the point
 // rows in LDS with all 256 threads loading in parallel (three latencies per BATCH); each wave then works through its
 // share of the pillars from LDS.  A batch whose points exceed the LDS rows is cut into sub-batches at pillar boundaries.
-__global__ __launch_bounds__(256) void dynamic_pfn_32_128_kernel(PfnArgs a, const float* __restrict__ cs_table) {
+__device__ __forceinline__ void pfn_32_128_main(const PfnArgs& a, const float* __restrict__ cs_table, const int bid, const int nblk) {
   constexpr int NB = kFwdBatch, CAP = kFwdPoints;
   static_assert(CAP >= kHeavyPillar, "a non-heavy pillar must fit the staging rows");
   __shared__ int m_s[NB], m_e[NB];
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void dynamic_pfn_32_128_kernel(PfnArgs a, cons
     w1a[k] = a.w1[lane * 64 + k];
     w1b[k] = a.w1[(lane + 64) * 64 + k];
   }
-  for (int v0 = blockIdx.x * NB; v0 < V; v0 += gridDim.x * NB) {
+  for (int v0 = bid * NB; v0 < V; v0 += nblk * NB) {
     const int nb = min(NB, V - v0);
     __syncthreads();  // the previous batch has been consumed
     if (tid < nb) {
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void dynamic_pfn_32_128_kernel(PfnArgs a, cons
     int q0 = 0;
     while (q0 < nb) {  // block-uniform
       const int base = m_s[q0];
-      if (m_e[q0] - base > kHeavyPillar) { ++q0; continue; }  // dynamic_pfn_32_128_heavy_kernel spreads those over a whole block
+      if (m_e[q0] - base > kHeavyPillar) { ++q0; continue; }  // the heavy-pillar blocks of the same launch spreads those over a whole block
       int q1 = q0 + 1;
       while (q1 < nb && m_e[q1] - m_s[q1] <= kHeavyPillar && m_e[q1] - base <= CAP) ++q1;
       const int npts = m_e[q1 - 1] - base;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) void dynamic_pfn_32_128_kernel(PfnArgs a, cons
 // sweep): one 8-wave block per pillar, the three phases (means, layer-0 maxima, layer-1 maxima)
 // meet in LDS.  Sums are exact int64 and maxima order independent, so the values are bit-identical
 // to what the one-wave path would have produced.
-__global__ __launch_bounds__(kHeavyWaves * 64) void dynamic_pfn_32_128_heavy_kernel(PfnArgs a, const float* __restrict__ cs_table) {
+__device__ __forceinline__ void pfn_32_128_heavy(const PfnArgs& a, const float* __restrict__ cs_table, const int bid, const int nblk) {
   __shared__ long long part_sum[kHeavyWaves][5];
   __shared__ float part_max[kHeavyWaves][128];
   __shared__ int heavy_list[kHeavyWaves * 64];
@@ -350,10 +351,10 @@ __global__ __launch_bounds__(kHeavyWaves * 64) void dynamic_pfn_32_128_heavy_ker
   bool loaded = false;
   // block b owns the pillars v == b (mod gridDim.x) -- neighbouring heavy pillars land on different
   // blocks; every thread tests one of them, the hits are compacted into an LDS list
-  for (int base = 0; base < V; base += gridDim.x * blockDim.x) {
+  for (int base = 0; base < V; base += nblk * (kHeavyWaves * 64)) {
     if (threadIdx.x == 0) heavy_n = 0;
     __syncthreads();
-    const int cand = base + blockIdx.x + gridDim.x * threadIdx.x;
+    const int cand = base + bid + nblk * threadIdx.x;
     if (cand < V && a.vstart[cand + 1] - a.vstart[cand] > kHeavyPillar) heavy_list[atomicAdd(&heavy_n, 1)] = cand;
     __syncthreads();
     const int n_heavy = heavy_n;
@@ -446,6 +447,27 @@ __global__ __launch_bounds__(kHeavyWaves * 64) void dynamic_pfn_32_128_heavy_ker
   }
   }
 }
+
+// ONE launch for both populations of pillars: blocks [0, main_blocks) run the batched one-wave-per-pillar path, the remaining
+// blocks look for pillars of more than kHeavyPillar points.  (Two launches cost ~5 us of dependent-dispatch latency inside a
+// replayed graph, more than the heavy path's own work on a sweep that has no such pillar.  Both bodies are 4-wave blocks: an
+// 8-wave heavy block made the merged kernel's register budget 128 and the batched path, whose weights alone are 144 registers,
+// lost 6 us to it.)
+static_assert(kHeavyWaves * 64 == 256, "both bodies of dynamic_pfn_32_128_kernel are 256-thread blocks");
+__global__ __launch_bounds__(256) void dynamic_pfn_32_128_main_kernel(PfnArgs a, const float* __restrict__ cs_table) {
+  pfn_32_128_main(a, cs_table, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256) void dynamic_pfn_32_128_heavy_kernel(PfnArgs a, const float* __restrict__ cs_table) {
+  pfn_32_128_heavy(a, cs_table, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256) void dynamic_pfn_32_128_kernel(PfnArgs a, const float* __restrict__ cs_table, int main_blocks) {
+  if ((int)blockIdx.x < main_blocks) {
+    pfn_32_128_main(a, cs_table, blockIdx.x, main_blocks);
+  } else {
+    pfn_32_128_heavy(a, cs_table, blockIdx.x - main_blocks, gridDim.x - main_blocks);
+  }
+}
+
 
 // ---- backward of the (32, 128) pillar feature net: weight gradients only (the points are data) -----
 // Forward per pillar:  h0[p] = relu(W0 d16[p]);  m0 = max_p h0[p];  y1[p] = W1a h0[p] + W1b m0;
@@ -851,12 +873,18 @@ int pn_dynamic_pfn_fwd_table(const float* points, int point_stride, const int32_
   PfnArgs a{points, point_stride, voxel_start, order, num_voxels, v_capacity, unq_keys, grid[0], grid[1], grid[2],
             w0, c0, w1, c1, vx, vy, x_offset, y_offset, features, canvas};
   const int blocks = std::max(1, std::min(512, pn::cdiv(v_capacity, kFwdBatch)));  // persistent: 2 waves per SIMD, weights loaded once per wave
-  hipLaunchKernelGGL(dynamic_pfn_32_128_kernel, dim3(blocks), dim3(256), 0, pn::S(stream), a, center_table);
-  if (int rc = pn::check_launch("dynamic_pfn_32_128_kernel")) return rc;
   // at most n / kHeavyPillar pillars can be heavy; the blocks find them by scanning voxel_start
   const int hblocks = std::max(1, std::min(256, pn::cdiv(v_capacity, kHeavyPillar)));
-  hipLaunchKernelGGL(dynamic_pfn_32_128_heavy_kernel, dim3(hblocks), dim3(kHeavyWaves * 64), 0, pn::S(stream), a, center_table);
-  return pn::check_launch("dynamic_pfn_32_128_heavy_kernel");
+  // two launches by default: the merged kernel (PN_PFN_SPLIT=0) was measured 7 us SLOWER than main + heavy back to back
+  // (45.3 vs 33.3 + 4.8 us inside a frame) although its register count and LDS are those of the batched path alone
+  static const int split = [] { const char* e = getenv("PN_PFN_SPLIT"); return e ? atoi(e) : 1; }();
+  if (split) {
+    hipLaunchKernelGGL(dynamic_pfn_32_128_main_kernel, dim3(blocks), dim3(256), 0, pn::S(stream), a, center_table);
+    hipLaunchKernelGGL(dynamic_pfn_32_128_heavy_kernel, dim3(hblocks), dim3(256), 0, pn::S(stream), a, center_table);
+    return pn::check_launch("dynamic_pfn_32_128_kernel (split)");
+  }
+  hipLaunchKernelGGL(dynamic_pfn_32_128_kernel, dim3(blocks + hblocks), dim3(kHeavyWaves * 64), 0, pn::S(stream), a, center_table, blocks);
+  return pn::check_launch("dynamic_pfn_32_128_kernel");
 }
 
 int pn_scatter_canvas_fwd(const float* features, const int64_t* unq, const int32_t* num_voxels, int v_capacity, int c,

@@ -225,6 +225,159 @@ __global__ void bucket_fill_kernel(const int32_t* __restrict__ inv, int n_cap, c
 }
 
 
+// ---------------------------------------------------------------------------- fused frame index (V0 + V1 + unique + bucketing)
+// Three launches instead of thirteen for the per-frame index of the dynamic path (the stage is bound by the ~5 us a dependent
+// launch costs inside a replayed graph, not by bandwidth):
+//   1. cart -> polar, grid index, key, and pos = atomicAdd(cell_count[key], 1): the point's slot inside its cell
+//   2. ONE single-pass scan (decoupled look-back) over the cell counts: an occupied cell's voxel rank = number of occupied
+//      cells with a smaller key (= row order of torch.unique(dim=0)) and its first point slot = number of points in smaller
+//      cells; emits unq_keys / voxel_start, leaves the start in cell_count[key]
+//   3. order[cell_count[key] + pos] = point
+// cell_count (one uint32 per grid cell) must be all zero on entry; pn_clear_frame_cells zeroes the frame's cells again (a
+// sparse clear next to the canvas clear), so a persistent buffer never needs a dense fill.  Same outputs as
+// pn_polar_grid_index_f32 + pn_unique_rank_bitmap + pn_bucket_points (order inside a voxel is unspecified in both).
+__global__ void fused_polar_index_kernel(const float* __restrict__ cart, int n_cap, int f_in, const int32_t* __restrict__ offs, int batch,
+                                         GridParams gp, float* __restrict__ polar, uint32_t* __restrict__ keys, int32_t* __restrict__ pos,
+                                         uint32_t* __restrict__ cell_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = min(offs[batch], n_cap);
+  if (i >= n) return;
+  int b = 0;
+  while (b + 1 < batch && i >= offs[b + 1]) ++b;
+  const float* p = cart + (size_t)i * f_in;
+  float* o = polar + (size_t)i * (f_in + 2);
+  const float x = p[0], y = p[1], zc = p[2];
+  const float rho = (float)sqrt((double)__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)));   // as cart_to_polar_kernel
+  const float phi = (float)atan2((double)y, (double)x);
+  o[0] = rho; o[1] = phi; o[2] = zc; o[3] = x; o[4] = y;
+  for (int k = 3; k < f_in; ++k) o[k + 2] = p[k];
+  const int r = cell_index(rho, gp.lo[0], gp.vs[0], gp.g[0]);
+  const int t = cell_index(phi, gp.lo[1], gp.vs[1], gp.g[1]);
+  const int z = cell_index(zc, gp.lo[2], gp.vs[2], gp.g[2]);
+  const uint32_t key = (uint32_t)((((size_t)b * gp.g[2] + z) * gp.g[1] + t) * gp.g[0] + r);
+  keys[i] = key;
+  pos[i] = (int32_t)atomicAdd(&cell_count[key], 1u);
+}
+
+// tile state of the look-back scan: status (2 bits: 0 = nothing yet, 1 = tile aggregate, 2 = inclusive prefix) | occupied
+// cells (30 bits) | points (32 bits).  Written / read with agent-scope relaxed atomics: the tiles of one launch sit on different
+// XCDs whose L2s are not coherent with each other.
+__device__ __forceinline__ unsigned long long pack_state(unsigned status, uint32_t nz, uint32_t pts) {
+  return ((unsigned long long)status << 62) | ((unsigned long long)nz << 32) | pts;
+}
+
+__global__ __launch_bounds__(kScanThreads) void cell_scan_kernel(uint32_t* __restrict__ cell_count, size_t ncells, int ntiles,
+                                                                 unsigned long long* __restrict__ tile_state, uint32_t* __restrict__ counters,
+                                                                 uint32_t* __restrict__ unq_keys, int32_t* __restrict__ voxel_start,
+                                                                 int32_t* __restrict__ num_voxels, int v_cap) {
+  __shared__ uint32_t s_tile, s_pre_nz, s_pre_pts;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_tile = __hip_atomic_fetch_add(&counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tiles in start order
+  __syncthreads();
+  const int tile = (int)s_tile;
+  const size_t base = (size_t)tile * kScanTile + (size_t)tid * kScanItems;
+  uint32_t c[kScanItems];
+  uint32_t nz = 0, pts = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    c[k] = base + k < ncells ? cell_count[base + k] : 0u;
+    nz += c[k] != 0u;
+    pts += c[k];
+  }
+  uint32_t tot_nz, tot_pts;
+  const uint32_t ex_nz = pn::block_exclusive_scan<kScanThreads>(nz, &tot_nz);
+  const uint32_t ex_pts = pn::block_exclusive_scan<kScanThreads>(pts, &tot_pts);
+  if (tid < 64) {   // wave 0: publish the aggregate, then look back 64 tiles at a time
+    uint32_t pre_nz = 0, pre_pts = 0;
+    if (tile > 0) {
+      if (tid == 0) __hip_atomic_store(&tile_state[tile], pack_state(1u, tot_nz, tot_pts), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int hi = tile - 1;   // nearest predecessor not yet accounted for
+      while (hi >= 0) {
+        const int j = hi - tid;
+        unsigned long long st = pack_state(2u, 0u, 0u);   // lanes past tile 0 behave like an (empty) inclusive prefix
+        if (j >= 0) st = __hip_atomic_load(&tile_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned status = (unsigned)(st >> 62);
+        const unsigned long long none = __ballot(status == 0u), pref = __ballot(status == 2u);
+        // usable run: lanes 0 .. first lane that is a prefix, provided no lane before it is still empty
+        const int first_pref = pref ? __ffsll((long long)pref) - 1 : 64;
+        const int first_none = none ? __ffsll((long long)none) - 1 : 64;
+        if (first_none < first_pref) {   // a predecessor in the window has not published yet: wait for it
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        const bool use = tid <= first_pref;   // first_pref == 64: all 64 are aggregates
+        uint32_t a_nz = use ? (uint32_t)(st >> 32) & 0x3fffffffu : 0u, a_pts = use ? (uint32_t)st : 0u;
+        pre_nz += pn::wave_sum(a_nz);
+        pre_pts += pn::wave_sum(a_pts);
+        if (first_pref < 64) break;
+        hi -= 64;
+      }
+    }
+    if (tid == 0) {
+      __hip_atomic_store(&tile_state[tile], pack_state(2u, pre_nz + tot_nz, pre_pts + tot_pts), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_pre_nz = pre_nz;
+      s_pre_pts = pre_pts;
+      if (tile == ntiles - 1) {   // grand totals
+        const uint32_t V = min(pre_nz + tot_nz, (uint32_t)v_cap);
+        *num_voxels = (int32_t)V;
+        voxel_start[V] = (int32_t)(pre_pts + tot_pts);
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t rank = s_pre_nz + ex_nz, start = s_pre_pts + ex_pts;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (c[k] != 0u) {
+      if ((int)rank < v_cap) {
+        unq_keys[rank] = (uint32_t)(base + k);
+        voxel_start[rank] = (int32_t)start;
+      }
+      cell_count[base + k] = start;   // the first point slot of the cell, read by order_fill_kernel
+      ++rank;
+      start += c[k];
+    }
+  }
+  // self-cleaning: the block that finishes last resets the scan state for the next launch (a replayed graph has no memset node
+  // to rely on); every other block is past its look-back by the time it takes its ticket
+  __syncthreads();
+  if (tid == 0) s_tile = __hip_atomic_fetch_add(&counters[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if ((int)s_tile == ntiles - 1) {
+    for (int j = tid; j < ntiles; j += kScanThreads) tile_state[j] = 0ull;
+    if (tid < 2) counters[tid] = 0u;
+  }
+}
+
+__global__ void order_fill_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ pos, int n_cap, const int32_t* __restrict__ n_dev,
+                                  const uint32_t* __restrict__ cell_count, int32_t* __restrict__ order) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = min(*n_dev, n_cap);
+  if (i >= n) return;
+  order[cell_count[keys[i]] + (uint32_t)pos[i]] = i;
+}
+
+// sparse clear at the end of a frame: the canvas cells of the frame's voxels (16 bytes per thread, c / 4 threads per cell) and
+// their cell_count entries
+__global__ void clear_frame_cells_kernel(const uint32_t* __restrict__ ukeys, const int32_t* __restrict__ v_dev, int v_cap, int c4, int Z, int T,
+                                         int R, float* __restrict__ canvas, uint32_t* __restrict__ cell_count) {
+  const int V = min(*v_dev, v_cap);
+  const int per = c4 > 0 ? c4 : 1;
+  const size_t total = (size_t)V * per;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i / per), k = (int)(i - (size_t)v * per);
+    const uint32_t key0 = ukeys[v];
+    if (canvas) {
+      uint32_t key = key0;
+      const int ri = key % R; key /= R;
+      const int ti = key % T; key /= T;
+      const int bi = key / Z;
+      reinterpret_cast<float4*>(canvas)[(((size_t)bi * T + ti) * R + ri) * c4 + k] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (k == 0 && cell_count) cell_count[key0] = 0u;
+  }
+}
+
 // ---------------------------------------------------------------------------- V2 hard voxelization
 // Reference semantics (point_cloud_ops.py:7-72): points are visited in order; a point outside the
 // grid is dropped; a voxel's id is its order of first appearance; at most max_voxels voxels are
@@ -416,6 +569,55 @@ int pn_unique_rank_bitmap(const uint32_t* keys, int n_capacity, const int32_t* n
     hipLaunchKernelGGL(rank_points_kernel, dim3(pblocks), dim3(256), 0, st, keys, n_capacity, n_dev, bitmap, rank, unq_inv,
                        unq_cnt);
   return pn::check_launch("unique_rank_bitmap");
+}
+
+size_t pn_voxel_index_fused_state_bytes(uint64_t num_cells) {
+  const size_t ntiles = (size_t)((num_cells + kScanTile - 1) / kScanTile);
+  return align256(ntiles * 8) + 256;
+}
+
+int pn_voxel_index_fused_f32(const float* cart, int n_capacity, int f_in, const int32_t* sample_offsets, int batch, const float* range_lo,
+                             const float* voxel_size, const int32_t* grid, float* polar, uint32_t* keys, int32_t* pos, uint32_t* cell_count,
+                             void* scan_state, size_t scan_state_bytes, uint32_t* unq_keys, int32_t* voxel_start, int32_t* order,
+                             int32_t* num_voxels, pn_stream_t stream) {
+  PN_REQUIRE(sample_offsets && range_lo && voxel_size && grid && keys && pos && cell_count && scan_state && unq_keys && voxel_start && order &&
+                 num_voxels && (n_capacity == 0 || (cart && polar)), "voxel_index_fused: null pointer");
+  PN_REQUIRE(f_in >= 3 && n_capacity >= 0 && batch >= 1, "voxel_index_fused: bad sizes");
+  const uint64_t cells = (uint64_t)batch * grid[0] * grid[1] * grid[2];
+  PN_REQUIRE(cells > 0 && cells < (1ull << 32), "voxel_index_fused: more than 2^32 cells");
+  PN_REQUIRE((uint64_t)n_capacity < (1ull << 30), "voxel_index_fused: too many points");
+  if (scan_state_bytes < pn_voxel_index_fused_state_bytes(cells)) return pn::fail(PN_ERR_WORKSPACE, "voxel_index_fused: scan state too small");
+  GridParams gp;
+  for (int k = 0; k < 3; ++k) {
+    gp.lo[k] = range_lo[k];
+    gp.vs[k] = voxel_size[k];
+    gp.g[k] = grid[k];
+  }
+  hipStream_t st = pn::S(stream);
+  const int ntiles = (int)((cells + kScanTile - 1) / kScanTile);
+  unsigned long long* tile_state = static_cast<unsigned long long*>(scan_state);
+  uint32_t* counters = reinterpret_cast<uint32_t*>(static_cast<char*>(scan_state) + align256((size_t)ntiles * 8));
+  const int pblocks = pn::cdiv(n_capacity > 0 ? n_capacity : 1, 256);
+  if (n_capacity > 0)
+    hipLaunchKernelGGL(fused_polar_index_kernel, dim3(pblocks), dim3(256), 0, st, cart, n_capacity, f_in, sample_offsets, batch, gp, polar, keys,
+                       pos, cell_count);
+  hipLaunchKernelGGL(cell_scan_kernel, dim3(ntiles), dim3(kScanThreads), 0, st, cell_count, (size_t)cells, ntiles, tile_state, counters, unq_keys,
+                     voxel_start, num_voxels, n_capacity);
+  if (n_capacity > 0)
+    hipLaunchKernelGGL(order_fill_kernel, dim3(pblocks), dim3(256), 0, st, keys, pos, n_capacity, sample_offsets + batch, cell_count, order);
+  return pn::check_launch("voxel_index_fused");
+}
+
+int pn_clear_frame_cells(const uint32_t* unq_keys, const int32_t* num_voxels, int v_capacity, const int32_t* grid, int c, float* canvas,
+                         uint32_t* cell_count, pn_stream_t stream) {
+  PN_REQUIRE(unq_keys && num_voxels && grid && (canvas || cell_count), "clear_frame_cells: bad arguments");
+  PN_REQUIRE(!canvas || (c >= 4 && c % 4 == 0 && ((uintptr_t)canvas & 15) == 0), "clear_frame_cells: canvas needs c % 4 == 0 and 16-byte alignment");
+  if (v_capacity == 0) return PN_OK;
+  const int c4 = canvas ? c / 4 : 0;
+  const size_t total = (size_t)v_capacity * (c4 > 0 ? c4 : 1);
+  hipLaunchKernelGGL(clear_frame_cells_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, pn::S(stream), unq_keys,
+                     num_voxels, v_capacity, c4, grid[2], grid[1], grid[0], canvas, cell_count);
+  return pn::check_launch("clear_frame_cells_kernel");
 }
 
 size_t pn_bucket_workspace_bytes(int n_capacity) {

@@ -105,15 +105,55 @@ class PointPillars(SingleStageDetector):
             ops.clear_canvas_cells(cv, vi)
         return self.bbox_head(ops.as_nchw(x2))["det_preds"][0]
 
-    def scatter_stage(self, cart: torch.Tensor, sample_offsets: torch.Tensor, batch: int, spec: ops.GridSpec, canvas: torch.Tensor):
-        """V0..V5 alone, exactly as a frame of ``forward_points(canvas=)`` runs them (cart->polar, grid index, unique-rank,
-        bucketing, fused PFN writing the persistent canvas, sparse clear): what bench.py's ``roofline_scatter`` times.
+    def new_index_state(self, batch: int, spec: Optional[ops.GridSpec] = None, device=None):
+        """persistent scratch of the fused frame index for ``forward_cart(..., index_state=)``; None when the grid is too large"""
+        spec = spec or ops.GridSpec.from_range(self.reader.pc_range, self.reader.voxel_size)
+        device = device or next(self.parameters()).device
+        return ops.FrameIndexState(spec, batch, device) if ops.FrameIndexState.supported(spec, batch) else None
+
+    def encode_cart(self, cart: torch.Tensor, sample_offsets: torch.Tensor, batch: int, spec: ops.GridSpec,
+                    canvas: Optional[torch.Tensor] = None, index_state=None):
+        """V0..V5 from Cartesian points: fused frame index (3 launches) + fused PFN writing the canvas cells (1 launch).
+        -> (canvas, VoxelIndex, polar points)"""
+        if not isinstance(self.reader, DynamicPFNet):
+            raise NotImplementedError("fused encode path needs a DynamicPFNet reader")
+        shape = (batch, spec.grid[1], spec.grid[0], self.reader.out_channels)
+        if index_state is None and not ops.FrameIndexState.supported(spec, batch):
+            polar = ops.cart_to_polar(cart)
+            _, keys = ops.grid_index(polar, sample_offsets, batch, spec, want_grid_ind=False)
+            cv, vi = self.encode_canvas(polar, keys, spec, batch, n_dev=sample_offsets[batch:], canvas=canvas, return_index=True)
+            return cv, vi, polar
+        polar, vi = ops.fused_voxel_index(cart, sample_offsets, batch, spec, index_state)
+        if canvas is None:
+            canvas = torch.empty(shape, dtype=torch.float32, device=cart.device)
+            hip.call("pn_fill_zero", canvas.data_ptr(), canvas.numel() * 4, hip.stream())
+        else:
+            hip.require_device(canvas)
+            assert tuple(canvas.shape) == shape and canvas.is_contiguous() and canvas.dtype == torch.float32
+        self.reader.encode(polar, vi, None, canvas)
+        return canvas, vi, polar
+
+    def scatter_stage(self, cart: torch.Tensor, sample_offsets: torch.Tensor, batch: int, spec: ops.GridSpec, canvas: torch.Tensor,
+                      index_state=None):
+        """V0..V5 alone, exactly as a frame of ``forward_cart(canvas=, index_state=)`` runs them (fused frame index, fused PFN
+        writing the persistent canvas, sparse clear): what bench.py's ``roofline_scatter`` times.
         -> the VoxelIndex (voxel count on the device)"""
-        polar = ops.cart_to_polar(cart)
-        _, keys = ops.grid_index(polar, sample_offsets, batch, spec, want_grid_ind=False)
-        cv, vi = self.encode_canvas(polar, keys, spec, batch, n_dev=sample_offsets[batch:], canvas=canvas, return_index=True)
-        ops.clear_canvas_cells(cv, vi)
+        cv, vi, _ = self.encode_cart(cart, sample_offsets, batch, spec, canvas=canvas, index_state=index_state)
+        ops.clear_frame_cells(cv, vi, getattr(vi, "state", None) if index_state is not None else None)
         return vi
+
+    def forward_cart(self, cart: torch.Tensor, sample_offsets: torch.Tensor, batch: int, spec: Optional[ops.GridSpec] = None,
+                     canvas: Optional[torch.Tensor] = None, index_state=None) -> Dict[str, torch.Tensor]:
+        """The hot path from CARTESIAN points (N, 5) [x, y, z, intensity, dt] resident on the device: V0 .. H2, head tensors out.
+        ``canvas`` / ``index_state``: persistent buffers owned by the caller (``new_canvas`` / ``new_index_state``), all zero on
+        entry and on exit (the frame's cells are cleared once the backbone's first layer has consumed the canvas)."""
+        eval_only(self, "PointPillars")
+        spec = spec or ops.GridSpec.from_range(self.reader.pc_range, self.reader.voxel_size)
+        cv, vi, _ = self.encode_cart(cart, sample_offsets, batch, spec, canvas=canvas, index_state=index_state)
+        x2 = self.neck.forward_nhwc(cv)
+        if canvas is not None or index_state is not None:
+            ops.clear_frame_cells(cv if canvas is not None else None, vi, index_state)
+        return self.bbox_head(ops.as_nchw(x2))["det_preds"][0]
 
     def extract_preds(self, example) -> Dict[str, object]:
         """reference ``example`` dict (dynamic branch keys) -> {'det_preds': [...]}"""

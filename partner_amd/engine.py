@@ -38,14 +38,17 @@ class FrameEngine:
         self.outputs: Dict[str, torch.Tensor] = {}
         # persistent BEV canvas of this engine: zero between frames, the frame's cells are cleared after use
         self.canvas = None if hasattr(model, "attns") else model.new_canvas(batch, self.spec, dev)
+        # persistent per-cell counters + scan state of the fused frame index (zero between frames)
+        self.index_state = None if hasattr(model, "attns") else model.new_index_state(batch, self.spec, dev)
 
     def _step(self):
-        polar = ops.cart_to_polar(self.cart)
         if hasattr(self.model, "attns"):   # VoxelNetV3 (Waymo PARTNER config): single-sample hard-voxel path
             assert self.batch == 1, "the fused VoxelNetV3 path takes one sample per frame"
-            preds = self.model.forward_points(polar)
+            preds = self.model.forward_points(ops.cart_to_polar(self.cart))
+        elif self.index_state is not None:
+            preds = self.model.forward_cart(self.cart, self.offsets, self.batch, self.spec, canvas=self.canvas, index_state=self.index_state)
         else:
-            preds = self.model.forward_points(polar, self.offsets, self.batch, self.spec, canvas=self.canvas)
+            preds = self.model.forward_points(ops.cart_to_polar(self.cart), self.offsets, self.batch, self.spec, canvas=self.canvas)
         if self.test_cfg is None:
             return preds
         return self.model.bbox_head.predict(dict(metadata=[None] * self.batch), {"det_preds": [preds]}, self.test_cfg, device_only=True)
@@ -119,13 +122,14 @@ class StreamingFrameEngine:
         self.time_lags = torch.from_numpy(lags).to(dev)
         self.offsets = torch.zeros(2, dtype=torch.int32, device=dev)   # [0, number of accumulated points]: written by the accumulation kernel
         self.canvas = model.new_canvas(1, self.spec, dev)               # persistent, zero between frames
+        self.index_state = model.new_index_state(1, self.spec, dev)
         self.graph = None
         self.outputs: Dict[str, torch.Tensor] = {}
 
     def _step(self):
         cart, _ = ops.accumulate_sweeps(self.raw, self.sweep_offsets, self.transforms, self.time_lags, 1.0, count=self.offsets[1:2])
-        polar = ops.cart_to_polar(cart)                                   # rows past the count are ignored downstream
-        preds = self.model.forward_points(polar, self.offsets, 1, self.spec, canvas=self.canvas)
+        # rows past the count are ignored downstream
+        preds = self.model.forward_cart(cart, self.offsets, 1, self.spec, canvas=self.canvas, index_state=self.index_state)
         if self.test_cfg is None:
             return dict(preds)
         return self.model.bbox_head.predict(dict(metadata=[None]), {"det_preds": [preds]}, self.test_cfg, device_only=True)

@@ -59,6 +59,9 @@ SIGNATURES = {
     "pn_unique_keys_ptr": (_P, [_P, _U64, _I]),
     "pn_bucket_workspace_bytes": (_SZ, [_I]),
     "pn_bucket_points": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "pn_voxel_index_fused_state_bytes": (_SZ, [_U64]),
+    "pn_voxel_index_fused_f32": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _P, _P]),
+    "pn_clear_frame_cells": (_I, [_P, _P, _I, _P, _I, _P, _P, _P]),
     "pn_sort_voxel_runs": (_I, [_P, _P, _I, _P, _P, _P]),
     "pn_hard_voxelize_workspace_bytes": (_SZ, [_U64, _I, _I]),
     "pn_hard_voxelize_f32": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),

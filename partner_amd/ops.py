@@ -114,8 +114,8 @@ class VoxelIndex:
     spec: GridSpec
     batch: int
     unq: Optional[torch.Tensor]       # (n_cap,4) int64, first V rows valid
-    unq_inv: torch.Tensor             # (n_cap,) int32
-    unq_cnt: torch.Tensor             # (n_cap,) int32, first V valid
+    unq_inv: Optional[torch.Tensor]   # (n_cap,) int32 (None on the fused frame-index path)
+    unq_cnt: Optional[torch.Tensor]   # (n_cap,) int32, first V valid (None on the fused frame-index path)
     num_voxels: torch.Tensor          # (1,) int32 on device
     voxel_start: torch.Tensor         # (n_cap+1,) int32
     order: torch.Tensor               # (n_cap,) int32
@@ -158,6 +158,59 @@ def build_voxel_index(keys: torch.Tensor, spec: GridSpec, batch: int, n_dev: Opt
         hip.call("pn_sort_voxel_runs", vstart.data_ptr(), nv.data_ptr(), n, raw.data_ptr(), order.data_ptr(), st)
     kp = lib.pn_unique_keys_ptr(ws.data_ptr(), cells, n)
     return VoxelIndex(n, cells, spec, batch, unq, inv, cnt, nv, vstart, order, ws, kp)
+
+
+class FrameIndexState:
+    """persistent scratch of the fused frame index (``fused_voxel_index``): one uint32 per grid cell and the scan state, all zero
+    between frames (the frame's cells are cleared again by ``clear_frame_cells``) -- owned by whoever replays frames (an engine),
+    one per stream in flight"""
+
+    MAX_CELLS = 1 << 24   # 64 MB of counters; larger grids (the Waymo 3-D grid) take the bitmap path
+
+    def __init__(self, spec: GridSpec, batch: int, device):
+        lib = hip.load()
+        self.cells = spec.num_cells(batch)
+        self.spec, self.batch = spec, batch
+        self.cell_count = torch.zeros((self.cells,), dtype=torch.int32, device=device)
+        self.scan_state = torch.zeros((int(lib.pn_voxel_index_fused_state_bytes(self.cells)),), dtype=torch.uint8, device=device)
+
+    @staticmethod
+    def supported(spec: GridSpec, batch: int) -> bool:
+        return spec.num_cells(batch) <= FrameIndexState.MAX_CELLS
+
+
+def fused_voxel_index(cart: torch.Tensor, sample_offsets: torch.Tensor, batch: int, spec: GridSpec, state: Optional[FrameIndexState] = None):
+    """cart (N, F>=3) Cartesian points -> (polar (N, F+2), VoxelIndex) in three launches (V0 + V1 + unique + bucketing).
+    ``state``: persistent zeroed scratch (see FrameIndexState); without it a fresh zero-filled one is used (two extra fills)."""
+    hip.require_device(cart, sample_offsets)
+    assert cart.dtype == torch.float32 and cart.is_contiguous() and sample_offsets.dtype == torch.int32
+    if state is None:
+        state = FrameIndexState(spec, batch, cart.device)
+    assert state.cells == spec.num_cells(batch)
+    n, f = cart.shape
+    dev = cart.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    polar = torch.empty((n, f + 2), dtype=torch.float32, device=dev)
+    keys = torch.empty((max(n, 1),), **i32)
+    pos = torch.empty((max(n, 1),), **i32)
+    ukeys = torch.empty((max(n, 1),), **i32)
+    vstart = torch.empty((n + 1,), **i32)
+    order = torch.empty((max(n, 1),), **i32)
+    nv = torch.empty((1,), **i32)
+    lo, vs, g = spec.c_arrays()
+    hip.call("pn_voxel_index_fused_f32", cart.data_ptr(), n, f, sample_offsets.data_ptr(), batch, lo, vs, g, polar.data_ptr(), keys.data_ptr(),
+             pos.data_ptr(), state.cell_count.data_ptr(), state.scan_state.data_ptr(), state.scan_state.numel(), ukeys.data_ptr(), vstart.data_ptr(),
+             order.data_ptr(), nv.data_ptr(), hip.stream())
+    vi = VoxelIndex(n, state.cells, spec, batch, None, None, None, nv, vstart, order, ukeys, ukeys.data_ptr())
+    vi.keys, vi.state = keys, state
+    return polar, vi
+
+
+def clear_frame_cells(canvas: Optional[torch.Tensor], vi: VoxelIndex, state: Optional[FrameIndexState] = None, v_cap: Optional[int] = None) -> None:
+    """sparse clear at the end of a frame: the canvas cells of the frame's voxels and their ``cell_count`` entries"""
+    _, _, g = vi.spec.c_arrays()
+    hip.call("pn_clear_frame_cells", vi.unq_keys_ptr, vi.num_voxels.data_ptr(), vi.n_cap if v_cap is None else v_cap, g,
+             0 if canvas is None else canvas.shape[-1], hip.ptr(canvas), None if state is None else state.cell_count.data_ptr(), hip.stream())
 
 
 def scatter_mean(points: torch.Tensor, vi: VoxelIndex, v_cap: Optional[int] = None) -> torch.Tensor:
