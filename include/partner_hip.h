@@ -725,6 +725,10 @@ typedef struct {
 } pn_conv_job;
 size_t pn_conv_stat_partial_floats(const pn_conv_desc *desc, int tile);
 int pn_conv2d_multi_f32(const pn_conv_job *jobs, int njobs, int tile, pn_stream_t stream);
+/* the same job list on the VALU kernel for convolutions with very few output columns (1x1 / 3x3, <= 64 input channels,
+ * <= 12 columns: the last convolutions of the head branches, center_head_parallel.py:140-175), norm_* supported (a
+ * range-stratified table only for 1x1 kernels); one launch for all jobs */
+int pn_conv2d_small_n_multi_f32(const pn_conv_job *jobs, int njobs, pn_stream_t stream);
 /* folds the partials the jobs' epilogues wrote (same job array and tile as the pn_conv2d_multi_f32 call; jobs without
  * stat_partials are skipped) into stat_affine / stat_mean_rstd: one small launch, fixed association order */
 int pn_conv_stats_finalize_f32(const pn_conv_job *jobs, int njobs, int tile, pn_stream_t stream);

@@ -1031,6 +1031,155 @@ __global__ __launch_bounds__(256) void conv_small_n_kernel(ConvArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The LAST convolutions of a detection head as one launch: a handful of output columns each (64 -> 1 .. 10), input read through
+// the affine table of the GroupNorm that precedes it (relu(x*A + B), padding stays zero).  An MFMA tile is 3 % used at these
+// widths (49 us for the five of CenterHeadSinglePos on 64 x 32 tiles); here block = 64 pixels x 4 waves of ONE job, wave q
+// owns a quarter of the job's input channels, lane = pixel: all 9 x 4 float4 of the lane are requested before the first is used,
+// the weights and (for per-channel norms) the affine pairs are wave-uniform scalar loads feeding v_fma, the four partial sums
+// meet in LDS.  Jobs with range-stratified norm tables (ni_S > 1) are supported for 1x1 kernels (per-lane table rows).
+template <int NOUT, int TAPS>
+__device__ __forceinline__ void small_n_body(const ConvArgs& a, const int mtile, float (*part)[64][13], float* w_lds) {
+  const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  {  // stage the job's weights: packed global [tap][cin_pad/4][cout_pad][4] -> LDS [tap][16 quads][NOUT][4]
+    const int quads = a.cin_chunks * 8;
+    for (int i = threadIdx.x; i < TAPS * 16 * NOUT; i += 256) {
+      const int n = i % NOUT, qd = (i / NOUT) % 16, t = i / (NOUT * 16);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (qd < quads && n < a.cout_pad) v = *reinterpret_cast<const f32x4*>(a.w + (((size_t)t * quads + qd) * a.cout_pad + n) * 4);
+      *reinterpret_cast<f32x4*>(w_lds + (size_t)i * 4) = v;
+    }
+  }
+  const int m = mtile * 64 + lane;
+  const bool live = m < a.M;
+  const int mm = live ? m : 0;
+  const int ohw = a.OH * a.OW;
+  const int b = mm / ohw, rem = mm - b * ohw, oh = rem / a.OW, ow = rem - oh * a.OW;
+  const int cq = ((a.Cin + 15) / 16) * 4;                 // channels per wave: whole quads, at most 16 (Cin <= 64)
+  const int c0 = q * cq, c1 = min(a.Cin, c0 + cq);
+  f32x4 x[TAPS][4];
+  unsigned inmask = 0;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    const int kh = t / a.KW, kw = t - kh * a.KW;
+    const int ih = oh * a.stride - a.pad_h + kh, iw = ow * a.stride - a.pad_w + kw;
+    const bool in = live && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+    inmask |= (unsigned)in << t;
+    const float* ip = a.in + ((size_t)(b * a.H + (in ? ih : 0)) * a.W + (in ? iw : 0)) * a.in_ps + a.in_co;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int c = c0 + 4 * cc;
+      x[t][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (in && c < c1) x[t][cc] = *reinterpret_cast<const f32x4*>(ip + c);
+    }
+  }
+  if (a.ni_ab) {
+    if (a.ni_S == 1) {
+      // per-channel norm: the (A, B) pairs of the wave's channels are wave-uniform -> scalar operands
+      const float* tab = a.ni_ab + ((size_t)b * a.ni_C + c0) * 2;   // b is wave-uniform when a sample is a whole number of 64-pixel tiles
+      const float* tb = (const float*)__builtin_assume_aligned(tab, 8);
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        if (c0 + 4 * cc < c1) {
+          float A[4], Bv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            A[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tb[(cc * 4 + k) * 2])));
+            Bv[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tb[(cc * 4 + k) * 2 + 1])));
+          }
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t) {
+            const bool in = (inmask >> t) & 1u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[t][cc][k] = in ? fmaxf(fmaf(x[t][cc][k], A[k], Bv[k]), 0.f) : 0.f;
+          }
+        }
+      }
+    } else {
+      // range-stratified norm (TAPS == 1): the lane's table row depends on its input column
+      const int wsub_in = a.W / a.ni_S;
+      const int iw = ow * a.stride - a.pad_w;
+      const int s_in = min(max(iw / wsub_in, 0), a.ni_S - 1);
+      const float* tab = a.ni_ab + ((size_t)(b * a.ni_S + s_in) * a.ni_C + c0) * 2;
+      const bool in = inmask & 1u;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        if (c0 + 4 * cc < c1) {
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(tab + cc * 8), t1 = *reinterpret_cast<const f32x4*>(tab + cc * 8 + 4);
+          x[0][cc][0] = in ? fmaxf(fmaf(x[0][cc][0], t0[0], t0[1]), 0.f) : 0.f;
+          x[0][cc][1] = in ? fmaxf(fmaf(x[0][cc][1], t0[2], t0[3]), 0.f) : 0.f;
+          x[0][cc][2] = in ? fmaxf(fmaf(x[0][cc][2], t1[0], t1[1]), 0.f) : 0.f;
+          x[0][cc][3] = in ? fmaxf(fmaf(x[0][cc][3], t1[2], t1[3]), 0.f) : 0.f;
+        }
+      }
+    }
+  }
+  float acc[NOUT];
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) acc[n] = 0.f;
+  __syncthreads();   // the staged weights are complete
+  // weights of the job from LDS (staged by the block, layout [tap][quad][NOUT][4]): a wave-uniform ds_read_b128 is a broadcast
+  // and pipelines 16 deep; the same values as wave-uniform SCALAR loads made every (tap, quad) group wait for the scalar
+  // cache (the whole launch took 61 us instead of ~15)
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      if (c0 + 4 * cc < c1) {                                                   // wave-uniform
+        const float* wp = w_lds + ((t * 16 + (c0 >> 2) + cc) * NOUT) * 4;
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {   // columns past Cout are zero in the packed weights
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + n * 4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[n] = fmaf(x[t][cc][k], wv[k], acc[n]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) part[q][lane][n] = acc[n];
+  __syncthreads();
+  // thread (pixel p = tid & 63, output group g = tid >> 6): outputs n = g, g + 4, ...
+  const int p = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int mo = mtile * 64 + p;
+  if (mo >= a.M) return;
+  for (int n = g; n < a.Cout; n += 4) {
+    const float v = (part[0][p][n] + part[1][p][n]) + (part[2][p][n] + part[3][p][n]);
+    const float sc = a.scale ? a.scale[n] : 1.f, sh = a.shift ? a.shift[n] : 0.f;
+    a.out[(size_t)mo * a.out_ps + a.out_co + n] = pn::apply_act(fmaf(v, sc, sh), a.act);
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_small_n_multi_kernel(MultiArgs m_by_value) {
+  __shared__ float part[4][64][13];
+  __shared__ __attribute__((aligned(16))) float w_lds[9 * 16 * 12 * 4];
+  typedef const __attribute__((address_space(4))) int* kptr_t;
+  const kptr_t base = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const int njobs = base[offsetof(MultiArgs, njobs) / 4];
+  const int t = blockIdx.x;
+  int j = 0;
+  for (int k = 1; k < njobs; ++k)
+    if (t >= base[offsetof(MultiArgs, first) / 4 + k]) j = k;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const int local = t - base[offsetof(MultiArgs, first) / 4 + j];
+  constexpr int JW = sizeof(ConvArgs) / 4;
+  union { ConvArgs a; int w[JW]; } u;
+  const kptr_t src = base + offsetof(MultiArgs, job) / 4 + j * JW;
+#pragma unroll
+  for (int i = 0; i < JW; ++i) u.w[i] = src[i];
+  const ConvArgs& a = u.a;
+  const int taps = a.KH * a.KW;
+  if (taps == 1) {
+    if (a.ncols <= 4) small_n_body<4, 1>(a, local, part, w_lds);
+    else small_n_body<12, 1>(a, local, part, w_lds);
+  } else {
+    if (a.ncols <= 4) small_n_body<4, 9>(a, local, part, w_lds);
+    else if (a.ncols <= 8) small_n_body<8, 9>(a, local, part, w_lds);
+    else small_n_body<12, 9>(a, local, part, w_lds);
+  }
+}
+
 template <int TAPS>
 void launch_small_n(const ConvArgs& a, int zdim, hipStream_t st) {
   const dim3 grid(pn::cdiv(a.M, 64), zdim);
@@ -1443,6 +1592,33 @@ int pn_conv2d_multi_f32(const pn_conv_job* jobs, int njobs, int tile, pn_stream_
     case 4: return norm_in ? launch_multi<2, 1, 1, 1, true>(m, extra, st) : launch_multi<2, 1, 1, 1, false>(m, 0, st);
     default: PN_REQUIRE(!norm_in, "conv_multi: tile 5 has no normalise-on-load variant"); return launch_multi<2, 4, 1, 1, false>(m, 0, st);
   }
+}
+
+int pn_conv2d_small_n_multi_f32(const pn_conv_job* jobs, int njobs, pn_stream_t stream) {
+  PN_REQUIRE(jobs && njobs >= 1 && njobs <= kMaxJobs, "conv_small_n_multi: 1 .. 8 jobs");
+  MultiArgs m;
+  memset(&m, 0, sizeof(m));
+  m.njobs = njobs;
+  int total = 0;
+  for (int j = 0; j < njobs; ++j) {
+    ConvArgs& a = m.job[j];
+    size_t extra = 0;
+    if (int rc = job_to_args(jobs[j], 3, a, extra)) return rc;
+    const int taps = a.KH * a.KW;
+    PN_REQUIRE(a.mode == MODE_CONV && a.zdim == 1 && a.ncols <= 12 && a.Cin <= 64 && (taps == 9 || taps == 1) && !jobs[j].stat_partials,
+               "conv_small_n_multi: plain 1x1 / 3x3 convolutions with <= 64 input channels and <= 12 output columns, no statistics");
+    PN_REQUIRE(!a.ni_ab || a.ni_S == 1 || taps == 1, "conv_small_n_multi: a range-stratified norm table needs a 1x1 kernel");
+    PN_REQUIRE(!a.ni_ab || a.ni_S > 1 || a.B == 1 || (a.OH * a.OW) % 64 == 0, "conv_small_n_multi: with batch > 1 a sample must be a whole number of 64-pixel tiles");
+    m.first[j] = total;
+    total += pn::cdiv(a.M, 64);
+  }
+  m.first[njobs] = total;
+  m.total = total;
+  hipStream_t st = pn::S(stream);
+  pn::ProfileSlot ps;
+  if (pn::take_profile_slot(ps)) hipExtLaunchKernelGGL(conv_small_n_multi_kernel, dim3(total), dim3(256), 0, st, ps.start, ps.stop, 0, m);
+  else hipLaunchKernelGGL(conv_small_n_multi_kernel, dim3(total), dim3(256), 0, st, m);
+  return pn::check_launch("conv_small_n_multi_kernel");
 }
 
 int pn_conv_stats_finalize_f32(const pn_conv_job* jobs, int njobs, int tile, pn_stream_t stream) {

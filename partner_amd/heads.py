@@ -402,7 +402,12 @@ class CenterHeadSingle(CenterHead):
             jobs.append(ops.ConvJob(lay, mid, out, in_channel_offset=in_off, out_channel_offset=off, norm=(tab, strata, cmid)))
             outs[name] = out[..., off:off + co]
             off += wd
-        ops.conv_multi(jobs, 4)
+        small = all(j.layer.cin <= 64 and j.layer.out_channels <= 12 and (j.layer.kh, j.layer.kw) in ((1, 1), (3, 3)) and j.layer.stride == 1
+                    and (strata == 1 or j.layer.kh == 1) for j, (_, strata, _, _) in zip(jobs, tabs))
+        if small and not getattr(self, "force_mfma_last", False):
+            ops.conv_small_n_multi(jobs)     # few output columns: the VALU kernel (an MFMA tile would be 3 % used)
+        else:
+            ops.conv_multi(jobs, 4)
         return outs
 
     def _merge_branches(self, branches):

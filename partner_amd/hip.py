@@ -84,6 +84,7 @@ SIGNATURES = {
     "pn_conv2d_nhwc_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "pn_conv_stat_partial_floats": (_SZ, [C.POINTER(ConvDesc), _I]),
     "pn_conv2d_multi_f32": (_I, [C.POINTER(ConvJob), _I, _I, _P]),
+    "pn_conv2d_small_n_multi_f32": (_I, [C.POINTER(ConvJob), _I, _P]),
     "pn_conv_stats_finalize_f32": (_I, [C.POINTER(ConvJob), _I, _I, _P]),
     "pn_conv_stats_apply_f32": (_I, [C.POINTER(ConvJob), _I, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
     "pn_groupnorm_apply_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),

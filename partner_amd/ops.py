@@ -531,6 +531,19 @@ def conv_multi(jobs: Sequence[ConvJob], tile: int) -> None:
                  tag=f"multi x{len(jobs)} {j0.out.shape[1]}x{j0.out.shape[2]} {sum(j.layer.cin * j.layer.groups for j in jobs)}->{sum(j.layer.out_channels for j in jobs)} k{j0.layer.kh}")
 
 
+def conv_small_n_multi(jobs: Sequence[ConvJob]) -> None:
+    """the jobs (1x1 / 3x3, <= 64 input channels, <= 12 output columns each) as ONE launch of the VALU kernel"""
+    st = hip.stream()
+    prof = _PROFILER
+    if prof is not None:
+        ev = prof.begin(st)
+    hip.call("pn_conv2d_small_n_multi_f32", _job_array(jobs), len(jobs), st)
+    if prof is not None:
+        j0 = jobs[0]
+        prof.end(ev, 2.0 * sum(j.macs for j in jobs), st,
+                 tag=f"small-n x{len(jobs)} {j0.out.shape[1]}x{j0.out.shape[2]} {sum(j.layer.cin * j.layer.groups for j in jobs)}->{sum(j.layer.out_channels for j in jobs)}")
+
+
 def conv_stats_finalize(jobs: Sequence[ConvJob], tile: int) -> None:
     """fold the statistics partials of the jobs (same list / tile as the ``conv_multi`` call) into their affine tables"""
     hip.call("pn_conv_stats_finalize_f32", _job_array(jobs), len(jobs), int(tile), hip.stream())

@@ -494,6 +494,11 @@ def test_fused_head_vs_oracle_and_unfused(dev, case):
     un = h(x.to(dev))["det_preds"][0]
     for k in out:
         assert rel_err(out[k], un[k].cpu().numpy()) < 2e-5, k
+    # the last convolutions on the MFMA multi-job kernel (normalise-on-load in the tile loader) instead of the VALU kernel
+    h.force_unfused, h.force_mfma_last = False, True
+    mf = h(x.to(dev))["det_preds"][0]
+    for k in out:
+        assert rel_err(out[k], mf[k].cpu().numpy()) < 2e-5, k
 
 
 def test_fused_head_small_maps_take_the_layer_path(dev):
