@@ -1,0 +1,323 @@
+"""CPU restatement of the TRAINING side of the geometry-aware head: TEST INFRASTRUCTURE ONLY.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; partner_amd never does.
+
+What it restates (reference root = /root/reference):
+  GroundTruthProcessor.process / draw_votemap      det3d/models/bbox_heads/e2e_modules.py:31-148
+  draw_center_to_votemap, gaussian_radius, gaussian2D   det3d/models/e2e_utils/centernet_utils.py:5-44, 68-88
+  CenterCoder.encode / get_delta / decode_torch    det3d/models/e2e_utils/box_coder_utils.py:64-244
+  TimeMatcher                                      det3d/models/e2e_utils/matcher.py:8-154
+  SetCriterion                                     det3d/models/e2e_utils/set_crit.py:30-206
+  E2ESigmoidFocalClassificationLoss, SmoothL1Loss, IOULoss   det3d/models/e2e_utils/loss_utils.py:447-535, 583-594
+  boxes_iou3d_gpu (target of the IoU branch)       det3d/ops/iou3d_nms/iou3d_nms_utils.py:38-72
+  E2ESWVoteHead.loss                               det3d/models/bbox_heads/e2e_swv_head.py:203-260
+
+Pinning.  GroundTruthProcessor, CenterCoder and TimeMatcher import and run in the survey container: their outputs are captured
+in tests/golden/e2e_loss.npz (tests/golden/make_golden.py::gen_e2e) and this file is checked against them
+(tests/test_oracle_e2e.py): PINNED.  SetCriterion cannot be imported as published (loss_utils.py:7 imports names that do not
+exist); with placeholder names injected by the harness it runs, and its loss_ce / loss_bbox / loss_vote /
+loss_vote_cls values are captured too: PINNED for those four terms.  loss_iou calls a CUDA-only extension
+(boxes_iou3d_gpu): its target is restated here on the BEV polygon clipping of oracle/box_nms.c -- PARITY UNPINNED for that term.
+E2ESWVoteHead.loss itself cannot run in the reference (the class cannot even be constructed); how each defect on the way
+was read:
+  * e2e_swv_head.py:125,131 `matcher_settings['weights_dict']` -> the config's key `weight_dict`;  :120 `box_coder_conifg`,
+    :139 `gt_processor_settings` -> the variables defined one line above them;
+  * `example['global_box']` (:206) is produced nowhere in the reference: taken to be (B, M, 7 [+ 2 velocity] + 1) rows
+    [x, y, z, dx, dy, dz, (vx, vy,) heading, class] padded with all-zero rows, which is what :207 and
+    GroundTruthProcessor.process (:50-58: padding removal by `sum() == 0`) expect;
+  * SetCriterion / TimeMatcher receive `use_focal_loss`, `box_pred_metric`, `use_heatmap` through **kwargs and ignore the
+    last two (as the reference's signatures do).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+
+# ------------------------------------------------------------------------------------------------ vote map
+def gaussian_radius_t(height: Tensor, width: Tensor, min_overlap: float) -> Tensor:
+    """centernet_utils.py:5-32 (torch scalars, fp32)"""
+    a1 = 1
+    b1 = height + width
+    c1 = width * height * (1 - min_overlap) / (1 + min_overlap)
+    r1 = (b1 + (b1 ** 2 - 4 * a1 * c1).sqrt()) / 2
+    a2 = 4
+    b2 = 2 * (height + width)
+    c2 = (1 - min_overlap) * width * height
+    r2 = (b2 + (b2 ** 2 - 4 * a2 * c2).sqrt()) / 2
+    a3 = 4 * min_overlap
+    b3 = -2 * min_overlap * (height + width)
+    c3 = (min_overlap - 1) * width * height
+    r3 = (b3 + (b3 ** 2 - 4 * a3 * c3).sqrt()) / 2
+    return torch.min(torch.min(r1, r2), r3)
+
+
+def gaussian2d(shape, sigma) -> np.ndarray:
+    """centernet_utils.py:35-41 (float64 numpy)"""
+    m, n = [(ss - 1.) / 2. for ss in shape]
+    y, x = np.ogrid[-m:m + 1, -n:n + 1]
+    h = np.exp(-(x * x + y * y) / (2 * sigma * sigma))
+    h[h < np.finfo(h.dtype).eps * h.max()] = 0
+    return h
+
+
+def box_corners_bev(boxes: Tensor) -> Tensor:
+    """center_to_corner_box2d(xy, dims[3:5], heading) (box_torch_ops.py:184-203, 24-60, 145-158) -> (N, 4, 2)"""
+    dims = boxes[:, 3:5]
+    norm = torch.tensor([[0, 0], [0, 1], [1, 1], [1, 0]], dtype=boxes.dtype) - 0.5       # clockwise from the minimum point
+    corners = dims[:, None, :] * norm[None]
+    s, c = torch.sin(boxes[:, 6]), torch.cos(boxes[:, 6])
+    rot_t = torch.stack([torch.stack([c, -s]), torch.stack([s, c])])                      # (2, 2, N)
+    return torch.einsum("aij,jka->aik", corners, rot_t) + boxes[:, None, :2]
+
+
+def draw_votemap(task_boxes: Tensor, task_classes: Tensor, num_class: int, max_space, min_space, grid_size, stride: int,
+                 num_max_objs: int = 500, gaussian_overlap: float = 0.1, return_objects: bool = False):
+    """GroundTruthProcessor.draw_votemap (e2e_modules.py:92-148) + draw_center_to_votemap (centernet_utils.py:68-88).
+    -> votemap (H = phi cells, W = rho cells, 4 + num_class): [cx, cy, c_rho, c_phi] of the LAST object whose window covers the
+    cell, and per class the maximum of the objects' Gaussians"""
+    fms = np.array(grid_size)[::-1] / stride            # [z, phi, rho] cells
+    H, W = int(fms[1]), int(fms[2])
+    votemap = task_boxes.new_zeros(H, W, 4 + num_class)
+    objs = []
+    if task_boxes.shape[0] == 0:
+        return (votemap, objs) if return_objects else votemap
+    corners = box_corners_bev(task_boxes)
+    rhos, phis = torch.norm(corners, 2, 2), torch.atan2(corners[:, :, 1], corners[:, :, 0])
+    max_bound = torch.from_numpy(np.asarray(max_space))
+    min_bound = torch.from_numpy(np.asarray(min_space))
+    gs = torch.from_numpy(np.asarray(grid_size))
+    vsz = [(max_bound[i] - min_bound[i]) / gs[i] for i in range(3)]
+    drho = (rhos.max(1)[0] - rhos.min(1)[0]) / vsz[0] / stride
+    dphi = (phis.max(1)[0] - phis.min(1)[0]) / vsz[1] / stride
+    c_rho = torch.norm(task_boxes[:, :2], 2, 1)
+    c_phi = torch.atan2(task_boxes[:, 1], task_boxes[:, 0])
+    centers = torch.stack([task_boxes[:, 0], task_boxes[:, 1], c_rho, c_phi], -1)
+    ind = torch.stack([(c_rho - min_bound[0]) / vsz[0] / stride, (c_phi - min_bound[1]) / vsz[1] / stride], -1).int()
+    for k in range(min(num_max_objs, task_boxes.shape[0])):
+        if drho[k] <= 0 or dphi[k] <= 0:
+            continue
+        if not (0 <= ind[k][0] < fms[2] and 0 <= ind[k][1] < fms[1]):
+            continue
+        if dphi[k] > (fms[1] / 4):                       # the box straddles the +-pi seam
+            spec = phis[k]
+            if torch.atan2(task_boxes[k, 1], task_boxes[k, 0]) > 0:
+                trunc = math.pi - torch.min(spec[spec > 0])
+            else:
+                trunc = torch.max(spec[spec <= 0]) + math.pi
+            dphi[k] = trunc / vsz[1] / stride
+        rho_i, phi_i = int(ind[k][0]), int(ind[k][1])
+        r_rho = int(gaussian_radius_t(drho[k], drho[k], gaussian_overlap))
+        r_phi = int(gaussian_radius_t(dphi[k], dphi[k], gaussian_overlap))
+        left, right = min(rho_i, r_rho), min(W - rho_i, r_rho + 1)
+        top, bottom = min(phi_i, r_phi), min(H - phi_i, r_phi + 1)
+        votemap[phi_i - top:phi_i + bottom, rho_i - left:rho_i + right, :4] = centers[k]
+        diameter = max(2 * r_rho + 1, 2 * r_phi + 1)
+        g = gaussian2d((2 * r_phi + 1, 2 * r_rho + 1), sigma=diameter / 6)
+        cls = int(task_classes[k])
+        cur = votemap[phi_i - top:phi_i + bottom, rho_i - left:rho_i + right, 4 + cls]
+        mg = torch.from_numpy(g[r_phi - top:r_phi + bottom, r_rho - left:r_rho + right]).to(cur.dtype)
+        torch.max(cur, mg, out=cur)
+        objs.append((k, rho_i, phi_i, r_rho, r_phi))
+    return (votemap, objs) if return_objects else votemap
+
+
+def gt_process(global_box: Tensor, class_names: Sequence[str], mapping: Dict[str, int], **votemap_kw):
+    """GroundTruthProcessor.process (e2e_modules.py:31-90), one task.  global_box (B, M, 7 + 1): [..., heading, class] with
+    all-zero padding rows -> dict(gt_boxes [B x (n, 7)], gt_classes [B x (n,)], votemap (B, H, W, 4 + ncls))"""
+    boxes_l, classes_l, maps = [], [], []
+    for k in range(global_box.shape[0]):
+        rows = global_box[k, :, :-1]
+        cls = global_box[k, :, -1]
+        count = rows.shape[0] - 1
+        while count > 0 and rows[count].sum() == 0:
+            count -= 1
+        rows, cls = rows[:count + 1], cls[:count + 1].int()
+        bs, cs = [], []
+        for off, name in enumerate(class_names):
+            m = cls == mapping[name]
+            bs.append(rows[m])
+            cs.append(torch.full((int(m.sum()),), off, dtype=torch.long))
+        tb, tc = torch.cat(bs, 0), torch.cat(cs, 0)
+        boxes_l.append(tb)
+        classes_l.append(tc)
+        maps.append(draw_votemap(tb, tc, len(class_names), **votemap_kw))
+    return dict(gt_boxes=boxes_l, gt_classes=classes_l, votemap=torch.stack(maps, 0), gt_cls_num=len(class_names))
+
+
+# ------------------------------------------------------------------------------------------------ box coder
+def _prep(b: Tensor) -> Tensor:
+    return torch.cat([b[..., :3], torch.clamp_min(b[..., 3:6], 1e-5), b[..., 6:]], -1)
+
+
+def coder_encode(gt: Tensor) -> Tensor:
+    """CenterCoder.encode with encode_angle_by_sincos (box_coder_utils.py:107-138): (n, 7) -> (n, 8)"""
+    t = _prep(gt)
+    return torch.cat([t[:, :3], torch.log(t[:, 3:6]), torch.cos(t[:, 6:7]), torch.sin(t[:, 6:7])], -1)
+
+
+def coder_delta(gt: Tensor, preds: Tensor) -> Tensor:
+    """CenterCoder.get_delta (box_coder_utils.py:172-216): gt (n, 7) raw boxes, preds (n, 8) [x, y, z, log d, cos, sin]"""
+    g = _prep(gt)
+    return torch.cat([g[:, :3] - preds[:, :3], torch.log(g[:, 3:6]) - preds[:, 3:6], torch.cos(g[:, 6:7]) - preds[:, 6:7],
+                      torch.sin(g[:, 6:7]) - preds[:, 7:8]], -1)
+
+
+def coder_decode(preds: Tensor) -> Tensor:
+    """CenterCoder.decode_torch (box_coder_utils.py:218-244): (n, 8) -> (n, 7)"""
+    return torch.cat([preds[..., :3], torch.exp(preds[..., 3:6]), torch.atan2(preds[..., 7:8], preds[..., 6:7])], -1)
+
+
+# ------------------------------------------------------------------------------------------------ matcher
+def matcher_cost(pred_logits: Tensor, pred_boxes: Tensor, gt_classes: Tensor, gt_boxes: Tensor, w_ce=0.25, w_bbox=0.75,
+                 code_weights=None) -> Tensor:
+    """cost matrix of one scene (matcher.py:78-93, 136-147): -(sigmoid(logit)[:, cls] ** w_ce) * (exp(-L1 cdist) ** w_bbox)"""
+    cw = torch.ones(pred_boxes.shape[-1]) if code_weights is None else torch.as_tensor(code_weights, dtype=torch.float32)
+    ce = pred_logits.sigmoid()[:, gt_classes]
+    bb = torch.exp(-torch.cdist(pred_boxes * cw, coder_encode(gt_boxes) * cw, p=1))
+    return -1.0 * (ce ** w_ce) * (bb ** w_bbox)
+
+
+def time_matcher(pred_logits: Tensor, pred_boxes: Tensor, gt_classes: List[Tensor], gt_boxes: List[Tensor], **kw):
+    """TimeMatcher.forward (matcher.py:122-154) -> [(query indices, gt indices)] per scene (scipy's linear_sum_assignment)"""
+    from scipy.optimize import linear_sum_assignment
+    out = []
+    with torch.no_grad():
+        for i in range(pred_boxes.shape[0]):
+            if gt_classes[i].shape[0] == 0:
+                out.append((torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64)))
+                continue
+            r, c = linear_sum_assignment(matcher_cost(pred_logits[i], pred_boxes[i], gt_classes[i], gt_boxes[i], **kw).numpy())
+            out.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(c, dtype=torch.int64)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def focal_sum(logits: Tensor, target: Tensor, gamma=2.0, alpha=0.25) -> Tensor:
+    """E2ESigmoidFocalClassificationLoss(reduction='sum') (loss_utils.py:447-503)"""
+    p = torch.sigmoid(logits)
+    aw = target * alpha + (1.0 - target) * (1.0 - alpha)
+    pt = target * (1.0 - p) + (1.0 - target) * p
+    bce = torch.clamp(logits, min=0) - logits * target + torch.log1p(torch.exp(-torch.abs(logits)))
+    return (aw * torch.pow(pt, gamma) * bce).sum()
+
+
+def smooth_l1_sigma(x: Tensor, sigma: float) -> Tensor:
+    """SmoothL1Loss.smooth_l1_loss (loss_utils.py:512-524), elementwise"""
+    s2 = sigma ** 2
+    ax = torch.abs(x)
+    inside = (ax < 1 / s2).type_as(x)
+    return 0.5 * (sigma * x) ** 2 * inside + (ax - 0.5 / s2) * (1.0 - inside)
+
+
+def iou3d_pairs(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """boxes_iou3d_gpu(a, b) diagonal (iou3d_nms_utils.py:38-72): a[i] vs b[i], boxes (n, 7) [x, y, z, dx, dy, dz, heading].
+    BEV overlap by float64 polygon clipping (the reference's is a CUDA kernel: UNPINNED)."""
+    def to_pcdet(x):
+        y = x[:, [0, 1, 2, 4, 3, 5, 6]].astype(np.float64).copy()
+        y[:, 6] = -y[:, 6] - np.pi / 2
+        return y
+
+    def corners(bx):
+        x, y, dx, dy, ang = bx[0], bx[1], bx[3], bx[4], bx[6]
+        c, s = np.cos(ang), np.sin(ang)
+        pts = np.array([[dx / 2, dy / 2], [-dx / 2, dy / 2], [-dx / 2, -dy / 2], [dx / 2, -dy / 2]])
+        return np.stack([x + pts[:, 0] * c - pts[:, 1] * s, y + pts[:, 0] * s + pts[:, 1] * c], 1)
+
+    def clip(poly, p0, p1):
+        out = []
+        for i in range(len(poly)):
+            cur, nxt = poly[i], poly[(i + 1) % len(poly)]
+            sc = (p1[0] - p0[0]) * (cur[1] - p0[1]) - (p1[1] - p0[1]) * (cur[0] - p0[0])
+            sn = (p1[0] - p0[0]) * (nxt[1] - p0[1]) - (p1[1] - p0[1]) * (nxt[0] - p0[0])
+            if sc >= 0:
+                out.append(cur)
+            if sc * sn < 0:
+                t = sc / (sc - sn)
+                out.append(cur + t * (nxt - cur))
+        return out
+
+    pa, pb = to_pcdet(a), to_pcdet(b)
+    res = np.zeros(len(a))
+    for i in range(len(a)):
+        ca, cb = corners(pa[i]), corners(pb[i])
+        poly = [p for p in ca]
+        for k in range(4):
+            if not poly:
+                break
+            poly = clip(poly, cb[k], cb[(k + 1) % 4])
+        area = 0.0
+        for k in range(len(poly)):
+            x0, y0 = poly[k]
+            x1, y1 = poly[(k + 1) % len(poly)]
+            area += x0 * y1 - x1 * y0
+        bev = abs(area) / 2
+        hmax = min(pa[i, 2] + pa[i, 5] / 2, pb[i, 2] + pb[i, 5] / 2)
+        hmin = max(pa[i, 2] - pa[i, 5] / 2, pb[i, 2] - pb[i, 5] / 2)
+        ov = bev * max(hmax - hmin, 0.0)
+        va, vb = pa[i, 3] * pa[i, 4] * pa[i, 5], pb[i, 3] * pb[i, 4] * pb[i, 5]
+        res[i] = ov / max(va + vb - ov, 1e-6)
+    return res
+
+
+def set_criterion(pred: Dict[str, Tensor], gt: Dict[str, object], indices=None, weight_dict=None, sigma=3.0, gamma=2.0, alpha=0.25,
+                  matcher_weights=(0.25, 0.75), code_weights=None, world_size=1, iou_fn=None) -> Dict[str, Tensor]:
+    """SetCriterion.forward (set_crit.py:68-206).  pred: pred_logits (B, Q, C), pred_boxes (B, Q, 8), pred_centers (B, Q, 2),
+    pred_vote_cls (B, Q, C), [pred_ious (B, Q, 1)]; gt: gt_boxes / gt_classes (lists), votemap (B, H, W, 4 + C).
+    Differentiable in the predictions (torch autograd)."""
+    wd = weight_dict or {"loss_ce": 1, "loss_bbox": 2, "loss_vote": 0.25, "loss_vote_cls": 1, "loss_iou": 2}
+    logits, boxes = pred["pred_logits"], pred["pred_boxes"]
+    if indices is None:
+        indices = time_matcher(logits.detach(), boxes.detach(), gt["gt_classes"], gt["gt_boxes"], w_ce=matcher_weights[0],
+                               w_bbox=matcher_weights[1], code_weights=code_weights)
+    bidx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
+    sidx = torch.cat([src for src, _ in indices])
+    mboxes = boxes[bidx, sidx]
+    gboxes = torch.cat([g[j] for g, (_, j) in zip(gt["gt_boxes"], indices)], 0)
+    cw = torch.ones(boxes.shape[-1]) if code_weights is None else torch.as_tensor(code_weights, dtype=torch.float32)
+    delta = coder_delta(gboxes, mboxes) * cw
+    num_boxes = max(sum(len(c) for c in gt["gt_classes"]) / world_size, 1.0)
+    gcls = torch.zeros(logits.shape[:2], dtype=torch.int64)
+    gcls[bidx, sidx] = torch.cat([t[j] for t, (_, j) in zip(gt["gt_classes"], indices)]) + 1
+    onehot = torch.zeros(logits.shape[:2] + (logits.shape[2] + 1,))
+    onehot.scatter_(-1, gcls.unsqueeze(-1), 1.0)
+    out = {}
+    out["loss_ce"] = focal_sum(logits, onehot[..., 1:], gamma, alpha) / num_boxes
+    lb = smooth_l1_sigma(delta, sigma).sum(0)
+    out["loss_bbox"] = lb.sum() / num_boxes
+    out["loc_loss_elem"] = lb.detach() / num_boxes
+    b, q, c = pred["pred_centers"].shape
+    votemap = gt["votemap"].reshape(b, q, -1)
+    mask = votemap[:, :, 0] != 0
+    vote_num = max(float(mask.sum()), 1.0)
+    out["loss_vote"] = smooth_l1_sigma(pred["pred_centers"][mask] - votemap[:, :, :c][mask], sigma).sum(0).sum() / vote_num
+    out["loss_vote_cls"] = focal_sum(pred["pred_vote_cls"], votemap[:, :, 4:], gamma, alpha) / vote_num
+    if "pred_ious" in pred:
+        dec = coder_decode(mboxes)[:, :7].detach()
+        tgt = (iou_fn or iou3d_pairs)(dec.numpy(), gboxes[:, :7].numpy())
+        tgt = torch.from_numpy(np.nan_to_num(np.asarray(tgt, np.float64)).astype(np.float32)) * 2 - 1
+        out["loss_iou"] = torch.nn.functional.smooth_l1_loss(pred["pred_ious"][bidx, sidx].squeeze(-1), tgt, reduction="none").sum() / num_boxes
+        out["iou_target"] = tgt
+    out["loss"] = sum(out[k] * wd[k] for k in ("loss_ce", "loss_bbox", "loss_vote", "loss_vote_cls", "loss_iou") if k in out and k in wd)
+    out["indices"] = indices
+    return out
+
+
+def e2e_swv_loss(preds: Dict[str, Tensor], global_box: Tensor, offset_grid: Tensor, class_names, mapping, votemap_kw, iou=True, **crit_kw):
+    """E2ESWVoteHead.loss (e2e_swv_head.py:203-260), one task.  preds: logical (B, c, H, W) head tensors; global_box (B, M, 9 | 10):
+    the velocity columns are dropped (:207).  -> the SetCriterion dict (loss = det_loss)"""
+    tb = global_box[..., [0, 1, 2, 3, 4, 5, -2, -1]]
+    gt = gt_process(tb, class_names, mapping, **votemap_kw)
+    anno = torch.cat([preds["reg"], preds["height"], preds["dim"], preds["rot"]], 1)
+    og = offset_grid.to(anno.dtype)
+    pb = torch.cat([anno[:, :2] + og, anno[:, 2:]], 1)
+    pc = preds["pred_centers"] + og
+    B, code, H, W = pb.shape
+    flat = lambda t: t.permute(0, 2, 3, 1).reshape(B, H * W, -1)  # noqa: E731
+    pd = dict(pred_logits=flat(preds["hm"]), pred_boxes=flat(pb), pred_centers=flat(pc), pred_vote_cls=flat(preds["pred_vote_cls"]))
+    if iou:
+        pd["pred_ious"] = flat(preds["iou"])
+    return set_criterion(pd, gt, **crit_kw), gt

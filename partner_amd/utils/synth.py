@@ -100,6 +100,54 @@ def synth_gt_boxes(n: int, seed: int, rho_max: float = 48.0):
     return b, r.integers(1, 11, n).astype(np.int64)
 
 
+def synth_vehicle_boxes(batch: int, max_boxes: int, seed: int, rho_max: float = 72.0):
+    """example['global_box'] of the Waymo PARTNER head: (batch, max_boxes, 8) f32 rows [x, y, z, dx, dy, dz, heading, class = 1],
+    zero rows as padding; a few boxes on the +-pi azimuth seam, one right at the sensor, one long truck"""
+    r = np.random.default_rng(seed)
+    out = np.zeros((batch, max_boxes, 8), np.float32)
+    for b in range(batch):
+        n = int(r.integers(max_boxes // 3, max_boxes - 2)) if b else max_boxes - 5
+        rho, az = r.uniform(3.0, rho_max, n), r.uniform(-np.pi, np.pi, n)
+        az[:3] = np.array([np.pi - 0.004, -np.pi + 0.006, np.pi - 0.02])[:min(3, n)]      # across / next to the seam
+        rho[3 % n] = 1.2
+        out[b, :n, 0], out[b, :n, 1] = rho * np.cos(az), rho * np.sin(az)
+        out[b, :n, 2] = r.uniform(-1.0, 2.0, n)
+        out[b, :n, 3] = r.uniform(3.5, 5.5, n)
+        out[b, :n, 4] = r.uniform(1.6, 2.3, n)
+        out[b, :n, 5] = r.uniform(1.4, 2.2, n)
+        out[b, 4 % n, 3] = 14.0
+        out[b, :n, 6] = r.uniform(-np.pi, np.pi, n)
+        out[b, :n, 7] = 1.0
+    return out
+
+
+def synth_swv_preds(batch: int, h: int, w: int, seed: int, boxes: np.ndarray = None, offset_grid: np.ndarray = None):
+    """head tensors of the geometry-aware head, logical (B, c, H, W) f32: hm (1), reg (2), height (1), dim (3, log), rot (2: cos, sin),
+    iou (1), pred_centers (2), pred_vote_cls (1).  With ``boxes`` / ``offset_grid`` given, the cells next to ground-truth centres
+    get predictions close to the truth (a trained head), so that the matching is decided by more than noise."""
+    r = np.random.default_rng(seed)
+    f = np.float32
+    p = dict(hm=(r.standard_normal((batch, 1, h, w)) * 1.2 - 3.0).astype(f), reg=(r.standard_normal((batch, 2, h, w)) * 0.6).astype(f),
+             height=(r.standard_normal((batch, 1, h, w)) * 0.5 + 0.5).astype(f), dim=(r.standard_normal((batch, 3, h, w)) * 0.2 + np.log(2.5)).astype(f),
+             rot=r.standard_normal((batch, 2, h, w)).astype(f), iou=(r.standard_normal((batch, 1, h, w)) * 0.5).astype(f),
+             pred_centers=(r.standard_normal((batch, 2, h, w)) * 0.8).astype(f), pred_vote_cls=(r.standard_normal((batch, 1, h, w)) - 2.0).astype(f))
+    if boxes is not None and offset_grid is not None:
+        g = np.asarray(offset_grid, f).reshape(2, h * w)
+        for b in range(batch):
+            for row in boxes[b]:
+                if row[3] == 0:
+                    continue
+                d = (g[0] - row[0]) ** 2 + (g[1] - row[1]) ** 2
+                for cell in np.argsort(d)[:3]:
+                    y, x = divmod(int(cell), w)
+                    p["hm"][b, 0, y, x] = f(r.normal(1.5, 0.7))
+                    p["reg"][b, :, y, x] = (row[:2] - g[:, cell]) + r.normal(0, 0.15, 2)
+                    p["height"][b, 0, y, x] = row[2] + r.normal(0, 0.1)
+                    p["dim"][b, :, y, x] = np.log(row[3:6]) + r.normal(0, 0.05, 3)
+                    p["rot"][b, :, y, x] = [np.cos(row[6]) + r.normal(0, 0.05), np.sin(row[6]) + r.normal(0, 0.05)]
+    return p
+
+
 def synth_raw_sweeps(n_sweeps: int, n_points: int, seed: int = 0):
     """raw nuScenes-style sweeps for the accumulation tests: list of (n,5) f32 [x,y,z,intensity,ring] (a good share of the points
     near the sensor so that remove_close matters), (n_sweeps,4,4) float64 rigid transforms (entry 0 = identity), time lags f32"""

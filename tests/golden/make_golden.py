@@ -618,7 +618,77 @@ def gen_seg_head():
          labels1=labels[1], state_keys=np.array(list(head.state_dict().keys())))
 
 
+WAYMO_HEAD_GT = dict(max_volumn_space=[75.18, 3.14368, 4.0], min_volumn_space=[0.3, -3.14368, -2.0], grid_size=[1152, 2048, 40])
+
+
+def gen_e2e():
+    """training side of the geometry-aware head: GroundTruthProcessor (vote map), CenterCoder, TimeMatcher and -- with the names
+    loss_utils.py:7 fails to import injected as placeholders -- SetCriterion, all run from the reference on synthetic Waymo-size
+    inputs (B = 2, 256 x 144 map).  The IoU term needs a CUDA-only extension and is not captured."""
+    import importlib
+    from det3d.models.bbox_heads.e2e_modules import GroundTruthProcessor
+    from det3d.models.e2e_utils.box_coder_utils import CenterCoder
+    from det3d.models.e2e_utils.matcher import TimeMatcher
+    import det3d.core.utils.center_utils as cu
+    for nm in ("bbox3d_overlaps_iou", "bbox3d_overlaps_giou", "bbox3d_overlaps_diou"):   # names loss_utils.py:7 expects (unused by the config's losses)
+        if not hasattr(cu, nm):
+            setattr(cu, nm, None)
+    set_crit = importlib.import_module("det3d.models.e2e_utils.set_crit")
+    from oracle import polar_oracle as O
+    tasks = [ADict(num_class=1, class_names=["Vehicle"])]
+    cfg = ADict(tasks=tasks, generate_votemap=True, feature_map_stride=8, gaussian_overlap=0.1, min_radius=4, num_max_objs=500, scale_factor=2,
+                mapping={"Vehicle": 1}, **WAYMO_HEAD_GT)
+    gtp = GroundTruthProcessor(gt_processor_cfg=cfg)
+    B, H, W = 2, 256, 144
+    gbox = synth.synth_vehicle_boxes(B, 48, seed=5)
+    gt = gtp.process(torch.from_numpy(gbox))[0]
+    vm = gt["votemap"].numpy()
+    nz = np.argwhere(np.abs(vm).sum(-1) != 0)
+    out = dict(global_box_seed=np.int64(5), vm_idx=nz.astype(np.int32), vm_val=vm[nz[:, 0], nz[:, 1], nz[:, 2]], vm_shape=np.array(vm.shape),
+               gt_counts=np.array([len(x) for x in gt["gt_classes"]]))
+    for b in range(B):
+        out[f"gt_boxes{b}"] = gt["gt_boxes"][b].numpy()
+    coder = CenterCoder(code_size=7, encode_angle_by_sincos=True, period=2 * np.pi)
+    og = O.swv_offset_grid(WAYMO_HEAD_GT["grid_size"], 8, WAYMO_HEAD_GT["min_volumn_space"], WAYMO_HEAD_GT["max_volumn_space"])
+    preds = {k: torch.from_numpy(v) for k, v in synth.synth_swv_preds(B, H, W, seed=9, boxes=gbox, offset_grid=og[0].numpy()).items()}
+    anno = torch.cat([preds["reg"], preds["height"], preds["dim"], preds["rot"]], 1)
+    pb = torch.cat([anno[:, :2] + og, anno[:, 2:]], 1).permute(0, 2, 3, 1).reshape(B, H * W, 8)
+    pc = (preds["pred_centers"] + og).permute(0, 2, 3, 1).reshape(B, H * W, 2)
+    flat = lambda t: t.permute(0, 2, 3, 1).reshape(B, H * W, -1)  # noqa: E731
+    out["enc0"] = coder.encode(gt["gt_boxes"])[0].numpy()
+    n0 = len(gt["gt_boxes"][0])
+    out["delta0"] = coder.get_delta(gt_boxes=gt["gt_boxes"][0], preds=pb[0, :n0]).numpy()
+    out["dec0"] = coder.decode_torch(pb[0, :64]).numpy()
+    mcfg = dict(weight_dict={"loss_ce": 0.25, "loss_bbox": 0.75}, losses=["loss_ce", "loss_bbox"], code_weights=[1.0] * 8, use_focal_loss=True,
+                box_pred_metric="loss_bbox", use_heatmap=False, box_coder=coder, period=2 * np.pi)
+    matcher = TimeMatcher(**mcfg)
+    pd = dict(pred_logits=flat(preds["hm"]), pred_boxes=pb, pred_centers=pc, pred_vote_cls=flat(preds["pred_vote_cls"]))
+    inds = matcher(pd, gt)["inds"]
+    for b in range(B):
+        out[f"match_src{b}"], out[f"match_tgt{b}"] = inds[b][0].numpy(), inds[b][1].numpy()
+    crit = set_crit.SetCriterion(matcher=matcher, weight_dict={"loss_ce": 1, "loss_bbox": 2, "loss_vote": 0.25, "loss_vote_cls": 1, "loss_iou": 2},
+                                 losses=["loss_ce", "loss_bbox", "loss_vote", "loss_vote_cls"], sigma=3.0, box_coder=coder, code_weights=[1.0] * 8,
+                                 gamma=2.0, alpha=0.25, use_focal_loss=True)
+    for k in pd:
+        pd[k] = pd[k].clone().requires_grad_(True)
+    ls = crit(pd, gt)
+    for k in ("loss_ce", "loss_bbox", "loss_vote", "loss_vote_cls", "loc_loss_elem", "loss"):
+        out["crit_" + k] = ls[k].detach().numpy()
+    ls["loss"].backward()
+    # gradients of the four pinned terms w.r.t. the predictions (sparse where they are sparse)
+    out["g_logits_sum"] = np.array([float(pd["pred_logits"].grad.double().sum()), float(pd["pred_logits"].grad.double().abs().sum())])
+    gb = pd["pred_boxes"].grad
+    gnz = np.argwhere(gb.abs().sum(-1).numpy() != 0)
+    out["g_boxes_idx"], out["g_boxes_val"] = gnz.astype(np.int32), gb.numpy()[gnz[:, 0], gnz[:, 1]]
+    gc = pd["pred_centers"].grad
+    cnz = np.argwhere(gc.abs().sum(-1).numpy() != 0)
+    out["g_centers_idx"], out["g_centers_val"] = cnz.astype(np.int32), gc.numpy()[cnz[:, 0], cnz[:, 1]]
+    out["g_vote_cls_sum"] = np.array([float(pd["pred_vote_cls"].grad.double().sum()), float(pd["pred_vote_cls"].grad.double().abs().sum())])
+    out["g_logits_at_matches"] = np.concatenate([pd["pred_logits"].grad[b, inds[b][0], 0].numpy() for b in range(B)])
+    save("e2e_loss.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static", "seg_head"]
+    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static", "seg_head", "e2e"]
     for w in which:
         globals()["gen_" + w]()
