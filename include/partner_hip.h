@@ -675,6 +675,52 @@ int pn_accumulate_sweeps_f32(const float *raw, int n, int in_cols, const int32_t
                              float min_distance, float *out, int32_t *out_count, void *workspace,
                              size_t workspace_bytes, pn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Training side of the geometry-aware head E2ESWVoteHead (Waymo PARTNER config): targets, matcher cost, set criterion.
+ * Replaces GroundTruthProcessor.process / draw_votemap (det3d/models/bbox_heads/e2e_modules.py:31-148, centernet_utils.py:68-88),
+ * TimeMatcher's cost (det3d/models/e2e_utils/matcher.py:78-93, 136-147; the assignment itself is scipy on the host there,
+ * pn_lsap_f32 here) and SetCriterion (det3d/models/e2e_utils/set_crit.py:68-206 with loss_utils.py:447-535, 583-594 and
+ * iou3d_nms_utils.py:38-72).  Head tensors are NHWC views given as pointer + pixel stride; offset_grid is planar (2, H, W).
+ */
+/* example['global_box'] (batch, max_boxes, cols >= 8) rows [x, y, z, dx, dy, dz, heading, class], all-zero rows as padding ->
+ * per sample the rows of the task's classes (class_ids, in that order): gt_boxes (batch, max_boxes, 7), gt_classes = position in
+ * class_ids, gt_counts (batch) */
+int pn_swv_gt_compact(const float *global_box, int batch, int max_boxes, int cols, const int32_t *class_ids,
+                      int n_classes, float *gt_boxes, int32_t *gt_classes, int32_t *gt_counts,
+                      pn_stream_t stream);
+size_t pn_swv_votemap_workspace_bytes(int batch, int max_boxes, int h, int w);
+/* votemap (batch, H = grid[1]/stride, W = grid[0]/stride, 4 + n_classes): [cx, cy, c_rho, c_phi] of the last object whose window
+ * covers the cell + per class the maximum of the objects' Gaussians; vote_count (1): cells with a centre (votemap[..., 0] != 0) */
+int pn_swv_draw_votemap_f32(const float *gt_boxes, const int32_t *gt_classes, const int32_t *gt_counts, int batch,
+                            int max_boxes, int n_classes, const float *max_space, const float *min_space,
+                            const int32_t *grid, int stride, int num_max_objs, double gaussian_overlap,
+                            float *votemap, int32_t *vote_count, void *workspace, size_t workspace_bytes,
+                            pn_stream_t stream);
+/* cost (batch, rows, H*W): row g of sample b = -(sigmoid(hm[q, cls_g])^w_ce * exp(-L1(code_weights*(pred_q - encode(gt_g))))^w_bbox)
+ * for g < gt_counts[b] (rows >= the largest count; other rows are not written) */
+int pn_swv_match_cost_f32(const float *hm, int hm_ps, int ncls, const float *reg, int reg_ps, const float *height,
+                          int height_ps, const float *dim, int dim_ps, const float *rot, int rot_ps,
+                          const float *offset_grid, int batch, int h, int w, const float *gt_boxes,
+                          const int32_t *gt_classes, const int32_t *gt_counts, int max_boxes, int rows, float w_ce,
+                          float w_bbox, const float *code_weights, float *cost, pn_stream_t stream);
+/* HOST function on host memory: rectangular linear sum assignment, cost (nr, nc) row major with nr <= nc; col_of_row[nr] */
+int pn_lsap_f32(const float *cost, int nr, int nc, int32_t *col_of_row);
+size_t pn_swv_criterion_workspace_bytes(int batch, int h, int w);
+/* out[14] = [det_loss, loss_ce, loss_bbox, loss_vote, loss_vote_cls, loss_iou, loc_loss_elem x 8] (device);
+ * loss_weights = [ce, bbox, vote, vote_cls, iou]; iou nullable (no IoU branch).  Gradients of det_loss w.r.t. the head tensors,
+ * dense NHWC (all or none): d_hm (B,H,W,ncls), d_boxes (B,H,W,8: reg 2, height 1, dim 3, rot 2), d_centers (B,H,W,2),
+ * d_vote_cls (B,H,W,ncls), d_iou (B,H,W,1). */
+int pn_swv_set_criterion_f32(const float *hm, int hm_ps, int ncls, const float *reg, int reg_ps, const float *height,
+                             int height_ps, const float *dim, int dim_ps, const float *rot, int rot_ps,
+                             const float *iou, int iou_ps, const float *pred_centers, int centers_ps,
+                             const float *pred_vote_cls, int vote_cls_ps, const float *offset_grid, int batch, int h,
+                             int w, const float *votemap, const int32_t *vote_count, const int32_t *match_sample,
+                             const int32_t *match_query, const int32_t *match_gt, int n_match, const float *gt_boxes,
+                             const int32_t *gt_classes, int max_boxes, float num_boxes, const float *loss_weights,
+                             float sigma, float gamma, float alpha, const float *code_weights, float *out, float *d_hm,
+                             float *d_boxes, float *d_centers, float *d_vote_cls, float *d_iou, void *workspace,
+                             size_t workspace_bytes, pn_stream_t stream);
+
 /* layout helpers at the API boundary */
 int pn_nchw_to_nhwc_f32(const float *in, int b, int c, int h, int w, float *out, pn_stream_t stream);
 int pn_nhwc_to_nchw_f32(const float *in, int b, int c, int h, int w, int pixel_stride,

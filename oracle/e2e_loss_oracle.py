@@ -214,8 +214,36 @@ def smooth_l1_sigma(x: Tensor, sigma: float) -> Tensor:
 
 
 def iou3d_pairs(a: np.ndarray, b: np.ndarray) -> np.ndarray:
-    """boxes_iou3d_gpu(a, b) diagonal (iou3d_nms_utils.py:38-72): a[i] vs b[i], boxes (n, 7) [x, y, z, dx, dy, dz, heading].
-    BEV overlap by float64 polygon clipping (the reference's is a CUDA kernel: UNPINNED)."""
+    """boxes_iou3d_gpu(a, b) diagonal (iou3d_nms_utils.py:38-72), fp32, with the BEV overlap of the CUDA kernel's arithmetic as
+    restated in oracle/box_nms.c::ov_box_overlap (edge crossings + corners inside within a 1e-2 margin, iou3d_nms_kernel.cu:104-215):
+    what the reference's extension computes up to rounding -- UNPINNED (the extension cannot be built here).  ``iou3d_pairs_exact``
+    is the float64 exact-clipping cross-check; the two differ by the kernel's containment margin (a few 1e-3 in IoU)."""
+    import ctypes as C
+    import os
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "liboracle.so"))
+    lib.ov_box_overlap.restype = C.c_float
+    lib.ov_box_overlap.argtypes = [C.c_void_p, C.c_void_p]
+    f = np.float32
+
+    def to_pcdet(x):
+        y = np.ascontiguousarray(x[:, [0, 1, 2, 4, 3, 5, 6]].astype(f))
+        y[:, 6] = -y[:, 6] - f(np.pi / 2)
+        return y
+
+    pa, pb = to_pcdet(np.asarray(a)), to_pcdet(np.asarray(b))
+    res = np.zeros(len(pa), f)
+    for i in range(len(pa)):
+        bev = f(lib.ov_box_overlap(pa[i].ctypes.data_as(C.c_void_p), pb[i].ctypes.data_as(C.c_void_p)))
+        hmax = min(pa[i, 2] + pa[i, 5] / f(2), pb[i, 2] + pb[i, 5] / f(2))
+        hmin = max(pa[i, 2] - pa[i, 5] / f(2), pb[i, 2] - pb[i, 5] / f(2))
+        ov = f(bev * max(f(hmax - hmin), f(0)))
+        va, vb = f(pa[i, 3] * pa[i, 4] * pa[i, 5]), f(pb[i, 3] * pb[i, 4] * pb[i, 5])
+        res[i] = ov / max(f(va + vb - ov), f(1e-6))
+    return res
+
+
+def iou3d_pairs_exact(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """the same quantity by exact float64 polygon clipping (no containment margin): cross-check of ``iou3d_pairs``"""
     def to_pcdet(x):
         y = x[:, [0, 1, 2, 4, 3, 5, 6]].astype(np.float64).copy()
         y[:, 6] = -y[:, 6] - np.pi / 2

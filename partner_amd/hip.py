@@ -135,6 +135,14 @@ SIGNATURES = {
     "pn_assign_heatmap_polar_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "pn_accumulate_sweeps_workspace_bytes": (_SZ, [_I]),
     "pn_accumulate_sweeps_f32": (_I, [_P, _I, _I, _P, _I, _P, _P, _F, _P, _P, _P, _SZ, _P]),
+    "pn_swv_gt_compact": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
+    "pn_swv_votemap_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "pn_swv_draw_votemap_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, C.c_double, _P, _P, _P, _SZ, _P]),
+    "pn_swv_match_cost_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P]),
+    "pn_lsap_f32": (_I, [_P, _I, _I, _P]),
+    "pn_swv_criterion_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "pn_swv_set_criterion_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I,
+                                      _F, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "pn_nchw_to_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "pn_nhwc_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "pn_grad_norm_workspace_bytes": (_SZ, []),

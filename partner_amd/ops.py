@@ -40,6 +40,16 @@ def as_nchw(x_nhwc: torch.Tensor) -> torch.Tensor:
     return x_nhwc.permute(0, 3, 1, 2)
 
 
+def pixel_stride(t: torch.Tensor) -> int:
+    """pixel stride (floats) of a logical (B, c, H, W) tensor that is a channels-last view (possibly a channel slice of a wider NHWC
+    map); raises if it is not one.  A size-1 channel dimension may carry any stride."""
+    b, c, h, w = t.shape
+    ok = (c == 1 or t.stride(1) == 1) and t.stride(2) == w * t.stride(3) and (b == 1 or t.stride(0) == h * t.stride(2)) and t.stride(3) >= c
+    if not ok:
+        raise hip.PartnerHipError("head tensors must be channels-last (NHWC-backed) views")
+    return t.stride(3)
+
+
 def nhwc_slice_to_nchw(x_nhwc: torch.Tensor, c0: int, c: int) -> torch.Tensor:
     """contiguous NCHW copy of channels [c0, c0+c) of an NHWC tensor"""
     b, h, w, ct = x_nhwc.shape

@@ -10,8 +10,10 @@ unchanged (its key spellings, e.g. ``kernel_size`` / ``sl_depth`` / ``weight_dic
 
 Forward only, eval mode, on the HIP kernels: 3x3 convolutions and the four linear layers of every
 Swin block on the MFMA kernel, LayerNorm, and ``pn_swv_window_attn`` for the shifted-window cosine
-attention with vote embedding and Cartesian relative-position bias.  Loss / target assignment
-(SetCriterion, TimeMatcher, GroundTruthProcessor) are outside this round.
+attention with vote embedding and Cartesian relative-position bias.  The training side -- vote-map
+targets (GroundTruthProcessor), the matcher's cost matrix + Hungarian assignment (TimeMatcher) and the
+set criterion with its gradients w.r.t. the head tensors (SetCriterion) -- is ``assign_targets`` /
+``match`` / ``loss`` on the kernels of ``e2e_loss.hip``.
 """
 from __future__ import annotations
 
@@ -141,6 +143,7 @@ class E2ESWVoteHead(nn.Module):
         self.grid_size = gp.get("grid_size")
         self.out_size_factor = out_size_factor
         self.set_crit_config, self.matcher_config, self.coder_config = dict(SET_CRIT_CONFIG), dict(MATCHER_CONFIG), dict(CODER_CONFIG)
+        self.gt_processor_config = dict(GT_PROCESSOR_CONFIG)
         self._generate_offset_grid()
         self._plan = PlanCache()
         (logger or logging.getLogger("E2ESWVoteHead")).info("Finish E2ESWVoteHead Initialization")
@@ -254,8 +257,158 @@ class E2ESWVoteHead(nn.Module):
         out.pop("_feat")
         return {"det_preds": [{k: v.permute(0, 3, 1, 2) for k, v in out.items()}]}
 
+    # ---- training side: vote-map targets, Hungarian matching, set criterion -------------------------------------------
+    def _gt_cfg(self):
+        gp = self.gt_processor_config
+        names = [n for t in gp.get("tasks", []) for n in (t["class_names"] if isinstance(t, dict) else t.class_names)] or \
+                [n for t in self.class_names for n in t]
+        mapping = dict(gp.get("mapping", {n: i + 1 for i, n in enumerate(names)}))
+        ids = []
+        for n in names:
+            hit = [v for k, v in mapping.items() if k.lower() == n.lower()]
+            if not hit:
+                raise KeyError(f"GT_PROCESSOR_CONFIG.mapping has no entry for class {n!r}")
+            ids.append(int(hit[0]))
+        return names, ids
+
+    def assign_targets(self, global_box: torch.Tensor):
+        """GroundTruthProcessor.process (e2e_modules.py:31-90) on the device: example['global_box'] (B, M, 7 [+ 2 velocity] + 1) rows
+        [x, y, z, dx, dy, dz, (vx, vy,) heading, class], all-zero rows as padding -> dict(gt_boxes (B, M, 7), gt_classes (B, M),
+        gt_counts (B), votemap (B, H, W, 4 + C), vote_count (1)), all device tensors"""
+        hip.require_device(global_box)
+        import ctypes as C
+        lib = hip.load()
+        gb = global_box.float().contiguous()
+        b, m, cols = gb.shape
+        dev = gb.device
+        names, ids = self._gt_cfg()
+        gp = self.gt_processor_config
+        i32 = dict(dtype=torch.int32, device=dev)
+        gt_boxes = torch.empty((b, m, 7), dtype=torch.float32, device=dev)
+        gt_cls, gt_cnt = torch.empty((b, m), **i32), torch.empty((b,), **i32)
+        cid = torch.tensor(ids, **i32)
+        st = hip.stream()
+        hip.call("pn_swv_gt_compact", gb.data_ptr(), b, m, cols, cid.data_ptr(), len(ids), gt_boxes.data_ptr(), gt_cls.data_ptr(), gt_cnt.data_ptr(), st)
+        stride = int(gp.get("feature_map_stride", self.out_size_factor))
+        grid = [int(v) for v in self.grid_size]
+        h, w = grid[1] // stride, grid[0] // stride
+        votemap = torch.empty((b, h, w, 4 + len(ids)), dtype=torch.float32, device=dev)
+        vote_count = torch.empty((1,), **i32)
+        wsb = lib.pn_swv_votemap_workspace_bytes(b, m, h, w)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        hip.call("pn_swv_draw_votemap_f32", gt_boxes.data_ptr(), gt_cls.data_ptr(), gt_cnt.data_ptr(), b, m, len(ids),
+                 (C.c_float * 3)(*[float(v) for v in self.max_volumn_space]), (C.c_float * 3)(*[float(v) for v in self.min_volumn_space]),
+                 (C.c_int32 * 3)(*grid), stride, int(gp.get("num_max_objs", 500)), float(0.1), votemap.data_ptr(), vote_count.data_ptr(),
+                 ws.data_ptr(), wsb, st)   # draw_center_to_votemap's own default overlap (the config's value is not passed down, centernet_utils.py:68)
+        return dict(gt_boxes=gt_boxes, gt_classes=gt_cls, gt_counts=gt_cnt, votemap=votemap, vote_count=vote_count)
+
+    def _head_ptrs(self, pd):
+        """(pointer, pixel stride) of the logical (B, c, H, W) channels-last views the head returns"""
+        b, _, h, w = pd["hm"].shape
+        args = []
+        for k in ("hm", "reg", "height", "dim", "rot"):
+            t = pd[k]
+            hip.require_device(t)
+            assert t.dtype == torch.float32
+            args.append((t.data_ptr(), ops.pixel_stride(t)))
+        return b, h, w, args
+
+    def match(self, pd, tg):
+        """TimeMatcher.forward (matcher.py:122-154): cost matrix on the device, the assignment on the host (as the reference: scipy
+        there, pn_lsap_f32 here).  -> [(query indices ascending, gt indices)] per sample, int64 CPU tensors"""
+        import numpy as np
+        import ctypes as C
+        b, h, w, ptrs = self._head_ptrs(pd)
+        counts = tg["gt_counts"].cpu().tolist()                 # host sync: the assignment is a host algorithm
+        rows = max(counts) if counts else 0
+        if rows == 0:
+            return [(torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64)) for _ in range(b)]
+        mw = self.matcher_config.get("weight_dict", self.matcher_config.get("weights_dict", {"loss_ce": 0.25, "loss_bbox": 0.75}))
+        cw = torch.tensor([float(v) for v in self.matcher_config.get("code_weights", [1.0] * 8)][:8], dtype=torch.float32, device=pd["hm"].device)
+        q = h * w
+        cost = torch.empty((b, rows, q), dtype=torch.float32, device=pd["hm"].device)
+        grid = self.offset_grid[0].contiguous()
+        (hm, hm_ps), (reg, reg_ps), (hei, hei_ps), (dim, dim_ps), (rot, rot_ps) = ptrs
+        hip.call("pn_swv_match_cost_f32", hm, hm_ps, pd["hm"].shape[1], reg, reg_ps, hei, hei_ps, dim, dim_ps, rot, rot_ps, grid.data_ptr(), b, h, w,
+                 tg["gt_boxes"].data_ptr(), tg["gt_classes"].data_ptr(), tg["gt_counts"].data_ptr(), tg["gt_boxes"].shape[1], rows,
+                 float(mw["loss_ce"]), float(mw["loss_bbox"]), cw.data_ptr(), cost.data_ptr(), hip.stream())
+        host = cost.cpu().numpy()
+        out = []
+        for i, n in enumerate(counts):
+            if n == 0:
+                out.append((torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64)))
+                continue
+            mat = np.ascontiguousarray(host[i, :n])
+            col = np.empty(n, np.int32)
+            hip.call("pn_lsap_f32", mat.ctypes.data_as(C.c_void_p), n, q, col.ctypes.data_as(C.c_void_p))
+            order = np.argsort(col, kind="stable")              # scipy returns the pairs sorted by row (= query) index
+            out.append((torch.from_numpy(col[order].astype(np.int64)), torch.from_numpy(order.astype(np.int64))))
+        return out
+
     def loss(self, example, preds_dicts, **kwargs):
-        raise NotImplementedError("E2ESWVoteHead.loss (SetCriterion / TimeMatcher / vote map targets) is not built yet (SURVEY.md 8f next-3)")
+        """E2ESWVoteHead.loss (e2e_swv_head.py:203-260; that code cannot run in the reference -- this follows its text and the
+        config, see oracle/e2e_loss_oracle.py for how each defect was read).  example['global_box']: (B, M, 7 [+ 2] + 1) ground-truth
+        rows.  Returns the reference's dict of per-task lists: det_loss (device scalar), ce_loss, bbox_loss, vote_reg_loss,
+        vote_cls_loss[, iou_loss] (CPU scalars).  The gradients of det_loss w.r.t. the head tensors are kept in ``self.last_loss``
+        (dense NHWC maps: d_hm, d_boxes (reg|height|dim|rot), d_centers, d_vote_cls, d_iou) for a training step."""
+        import ctypes as C
+        import torch.distributed as dist
+        lib = hip.load()
+        if len(preds_dicts["det_preds"]) != 1:
+            raise NotImplementedError("E2ESWVoteHead.loss: one task (the reference's Waymo config has one)")
+        pd = preds_dicts["det_preds"][0]
+        gbox = example["global_box"]
+        if not torch.is_tensor(gbox):
+            gbox = torch.as_tensor(gbox)
+        dev = pd["hm"].device
+        tg = self.assign_targets(gbox.to(dev))
+        inds = self.match(pd, tg)
+        b, h, w, ptrs = self._head_ptrs(pd)
+        assert tuple(tg["votemap"].shape[1:3]) == (h, w), "vote map and head map sizes differ"
+        ncls = pd["hm"].shape[1]
+        i32 = dict(dtype=torch.int32, device=dev)
+        mb = torch.cat([torch.full((len(s),), i, dtype=torch.int32) for i, (s, _) in enumerate(inds)]).to(dev) if inds else torch.zeros(0, **i32)
+        mq = torch.cat([s for s, _ in inds]).to(torch.int32).to(dev)
+        mg = torch.cat([t for _, t in inds]).to(torch.int32).to(dev)
+        n_match = int(mq.numel())
+        total = torch.tensor([float(n_match)], dtype=torch.float32)
+        world = 1
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size()
+            t = total.to(dev) if dist.get_backend() == "nccl" else total
+            dist.all_reduce(t)
+            total = t.cpu()
+        num_boxes = max(float(total) / world, 1.0)
+        sc = self.set_crit_config
+        wd = sc.get("weight_dict", {"loss_ce": 1, "loss_bbox": 2, "loss_vote": 0.25, "loss_vote_cls": 1, "loss_iou": 2})
+        losses = list(sc.get("losses", ["loss_ce", "loss_bbox", "loss_vote", "loss_vote_cls", "loss_iou"]))
+        weights = [float(wd.get(k, 0.0)) if k in losses else 0.0 for k in ("loss_ce", "loss_bbox", "loss_vote", "loss_vote_cls", "loss_iou")]
+        use_iou = self.iou_loss and "iou" in pd and "loss_iou" in losses
+        for k in ("pred_centers", "pred_vote_cls") + (("iou",) if use_iou else ()):
+            ops.pixel_stride(pd[k])
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = torch.empty((14,), **f32)
+        grads = dict(d_hm=torch.empty((b, h, w, ncls), **f32), d_boxes=torch.empty((b, h, w, 8), **f32), d_centers=torch.empty((b, h, w, 2), **f32),
+                     d_vote_cls=torch.empty((b, h, w, ncls), **f32), d_iou=torch.empty((b, h, w, 1), **f32) if use_iou else None)
+        wsb = lib.pn_swv_criterion_workspace_bytes(b, h, w)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        grid = self.offset_grid[0].contiguous()
+        cw = [float(v) for v in sc.get("code_weights", [1.0] * 8)][:8]
+        (hm, hm_ps), (reg, reg_ps), (hei, hei_ps), (dim, dim_ps), (rot, rot_ps) = ptrs
+        iou = pd["iou"] if use_iou else None
+        hip.call("pn_swv_set_criterion_f32", hm, hm_ps, ncls, reg, reg_ps, hei, hei_ps, dim, dim_ps, rot, rot_ps, hip.ptr(iou),
+                 0 if iou is None else iou.stride(3), pd["pred_centers"].data_ptr(), pd["pred_centers"].stride(3), pd["pred_vote_cls"].data_ptr(),
+                 pd["pred_vote_cls"].stride(3), grid.data_ptr(), b, h, w, tg["votemap"].data_ptr(), tg["vote_count"].data_ptr(), hip.ptr(mb) if n_match else None,
+                 hip.ptr(mq) if n_match else None, hip.ptr(mg) if n_match else None, n_match, tg["gt_boxes"].data_ptr(), tg["gt_classes"].data_ptr(),
+                 tg["gt_boxes"].shape[1], float(num_boxes), (C.c_float * 5)(*weights), float(sc.get("sigma", 3.0)), float(sc.get("gamma", 2.0)),
+                 float(sc.get("alpha", 0.25)), (C.c_float * 8)(*cw), out.data_ptr(), grads["d_hm"].data_ptr(), grads["d_boxes"].data_ptr(),
+                 grads["d_centers"].data_ptr(), grads["d_vote_cls"].data_ptr(), hip.ptr(grads["d_iou"]), ws.data_ptr(), wsb, hip.stream())
+        self.last_loss = dict(out=out, grads=grads, indices=inds, targets=tg, num_boxes=num_boxes)
+        host = out.detach().cpu()
+        ret = dict(det_loss=[out[0]], ce_loss=[host[1]], bbox_loss=[host[2]], vote_reg_loss=[host[3]], vote_cls_loss=[host[4]])
+        if use_iou:
+            ret["iou_loss"] = [host[5]]
+        return ret
 
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
         """decode + rotated NMS on the device (e2e_swv_head.py:262-470, restated from its text: that code does not run in the

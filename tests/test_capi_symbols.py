@@ -47,3 +47,31 @@ def test_host_only_entry_points():
     rc = lib.pn_sort_voxel_runs(C.addressof(buf), C.addressof(buf), 4, C.addressof(buf), C.addressof(buf), None)   # in == out
     assert rc == -1 and "sort_voxel_runs" in hip.last_error()
     assert lib.pn_groupnorm_bwd_workspace_bytes(4, 64, 64, 1) > lib.pn_groupnorm_workspace_bytes(4, 64, 1)
+
+
+def test_lsap_host_function_matches_scipy():
+    """pn_lsap_f32 (host code, no GPU): rectangular assignment against scipy.optimize.linear_sum_assignment -- what the
+    reference's TimeMatcher calls (matcher.py:149) -- on random, tie-heavy and degenerate matrices"""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    from partner_amd import hip
+    lib = hip.load()
+    rng = np.random.default_rng(0)
+    for nr, nc, kind in [(1, 1, "rand"), (5, 5, "rand"), (7, 40, "rand"), (40, 3000, "rand"), (12, 60, "ties"), (6, 9, "const"), (30, 31, "neg")]:
+        if kind == "rand":
+            c = rng.standard_normal((nr, nc)).astype(np.float32)
+        elif kind == "ties":
+            c = rng.integers(0, 4, (nr, nc)).astype(np.float32)
+        elif kind == "const":
+            c = np.full((nr, nc), 2.5, np.float32)
+        else:
+            c = -np.exp(-rng.uniform(0, 30, (nr, nc))).astype(np.float32)        # the matcher's cost range: (-1, 0], many ~0
+        col = np.empty(nr, np.int32)
+        rc = lib.pn_lsap_f32(c.ctypes.data_as(C.c_void_p), nr, nc, col.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        assert len(set(col.tolist())) == nr and col.min() >= 0 and col.max() < nc
+        r, cc = linear_sum_assignment(c.astype(np.float64))
+        assert abs(float(c[np.arange(nr), col].astype(np.float64).sum()) - float(c[r, cc].astype(np.float64).sum())) < 1e-9
+        if kind in ("rand", "neg"):   # unique optimum: the same assignment
+            np.testing.assert_array_equal(col, cc)
+    assert lib.pn_lsap_f32(None, 3, 2, None) == -1

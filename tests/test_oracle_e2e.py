@@ -80,9 +80,16 @@ def test_iou3d_target_restatement_against_closed_forms():
     half overlap and a rotated square against hand-computed values"""
     a = np.array([[0, 0, 0, 4, 2, 2, 0.3], [0, 0, 0, 4, 2, 2, 0.0], [0, 0, 0, 4, 2, 2, 0.0], [0, 0, 0, 2, 2, 2, 0.0]], np.float32)
     b = np.array([[0, 0, 0, 4, 2, 2, 0.3], [10, 0, 0, 4, 2, 2, 0.0], [2, 0, 0.5, 4, 2, 2, 0.0], [0, 0, 0, 2, 2, 2, np.pi / 4]], np.float32)
-    got = E.iou3d_pairs(a, b)
+    got = E.iou3d_pairs_exact(a, b)
     inter = 2 * 2 * 1.5
     exp3 = inter / (16 + 16 - inter)
     oct_area = 8 * (np.sqrt(2) - 1)          # square and its 45-degree copy: regular octagon, side 2(sqrt2 - 1), apothem 1
     exp4 = oct_area * 2 / (8 + 8 - oct_area * 2)
     np.testing.assert_allclose(got, [1.0, 0.0, exp3, exp4], rtol=1e-6, atol=1e-9)
+    # the kernel-arithmetic restatement (fp32, 1e-2 containment margin) agrees with the exact one up to that margin
+    np.testing.assert_allclose(E.iou3d_pairs(a, b), got, atol=2e-2)
+    r = np.random.default_rng(2)
+    ra = np.concatenate([r.uniform(-3, 3, (200, 3)), r.uniform(1.5, 5, (200, 3)), r.uniform(-3.2, 3.2, (200, 1))], 1).astype(np.float32)
+    rb = ra + np.concatenate([r.normal(0, 0.6, (200, 3)), r.normal(0, 0.3, (200, 3)), r.normal(0, 0.4, (200, 1))], 1).astype(np.float32)
+    rb[:, 3:6] = np.maximum(rb[:, 3:6], 0.5)
+    np.testing.assert_allclose(E.iou3d_pairs(ra, rb), E.iou3d_pairs_exact(ra, rb), atol=2e-2)
