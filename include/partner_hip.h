@@ -721,6 +721,36 @@ int pn_swv_set_criterion_f32(const float *hm, int hm_ps, int ncls, const float *
                              float *d_boxes, float *d_centers, float *d_vote_cls, float *d_iou, void *workspace,
                              size_t workspace_bytes, pn_stream_t stream);
 
+/* boxes of sector `sec_id` back into the sweep's frame after the per-sector NMS (center_head.py:533-545): centre (and velocity)
+ * rotated by +angle, heading -= angle; boxes (batch, capacity, box_dims) with counts (batch) valid rows each */
+int pn_rotate_boxes_f32(float *boxes, const int32_t *counts, int batch, int capacity, int box_dims, double angle,
+                        pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Sector streaming (a sweep processed as azimuth sectors, one after the other).
+ */
+size_t pn_split_polar_sectors_workspace_bytes(int n_capacity, int nsectors, int batch);
+/* Voxelization.voxelize_streaming_polar (det3d/datasets/pipelines/voxelization.py:305-393): polar points (n, f >= 5)
+ * [rho, phi, z, x, y, ...] of `batch` samples -> the same rows grouped by (sector, sample) in their original order
+ * (out_offsets: nsectors*batch + 1 entries), phi shifted into the first sector's range, x / y recomputed from (rho, phi), and the
+ * [b, z, theta, r] grid indices / linear keys against the SECTOR grid (theta cells = grid[1] / nsectors), both nullable.
+ * pc_range (6) / voxel_size (3) / grid (3) are those of the full sweep. */
+int pn_split_polar_sectors_f32(const float *points, int n_capacity, int f, const int32_t *sample_offsets, int batch,
+                               int nsectors, const float *pc_range, const float *voxel_size, const int32_t *grid,
+                               float *out_points, int64_t *grid_ind, uint32_t *keys, int32_t *out_offsets,
+                               void *workspace, size_t workspace_bytes, pn_stream_t stream);
+/* The row concatenations of the context-padding convolutions (ConvContext / ConvBDCP, det3d/models/necks/rpn_context.py:10-44,
+ * 98-158: torch.cat / F.pad along the azimuth axis of NCHW maps = whole-row pieces of NHWC maps): output sample k (of n_out <= 64,
+ * out_rows rows of w pixels x c channels) = pieces[3k], pieces[3k+1], pieces[3k+2] stacked; a piece is `rows` rows starting at
+ * `src` (already offset to its sample / first row / channel, pixel stride in floats) or zeros when src is NULL. */
+typedef struct {
+  const float *src;
+  int32_t pixel_stride;
+  int32_t rows;
+} pn_row_piece;
+int pn_assemble_rows_f32(const pn_row_piece *pieces, int n_out, int out_rows, int w, int c, float *out,
+                         int out_pixel_stride, int out_channel_offset, pn_stream_t stream);
+
 /* layout helpers at the API boundary */
 int pn_nchw_to_nhwc_f32(const float *in, int b, int c, int h, int w, float *out, pn_stream_t stream);
 int pn_nhwc_to_nchw_f32(const float *in, int b, int c, int h, int w, int pixel_stride,

@@ -5,6 +5,6 @@ from .builder import (BACKBONES, BBOX_HEADS, DETECTORS, LOSSES, NECKS, READERS, 
                       build_backbone, build_bbox_head, build_detector, build_loss, build_neck, build_reader, build_seg_head)
 from .config import Config, ConfigDict, get_downsample_factor  # noqa: F401
 from .registry import Registry, build_from_cfg  # noqa: F401
-from . import readers, necks, heads, swv_head, sparse_backbone, seg_heads, detectors  # noqa: F401,E402  (registers the modules)
+from . import readers, necks, necks_context, heads, swv_head, sparse_backbone, seg_heads, detectors  # noqa: F401,E402  (registers the modules)
 
 __version__ = "0.1.0"

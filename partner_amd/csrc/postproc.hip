@@ -404,6 +404,38 @@ int run_decode_nms(DecodeArgs a, const float* post_center_range, float nms_iou_t
 
 extern "C" {
 
+}  // extern "C"
+
+namespace {
+// boxes of a sector back into the sweep's frame (center_head.py:533-545): [x y] @ [[c, s], [-s, c]] with c = cos(angle), s = sin(angle)
+// rounded to fp32 as torch.tensor(..., dtype=float) does, heading -= angle, velocity rotated like the centre
+__global__ void rotate_boxes_kernel(float* __restrict__ boxes, const int32_t* __restrict__ counts, int cap, int nb, float c, float s, float angle, int batch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch * cap) return;
+  const int b = i / cap, k = i - b * cap;
+  if (k >= counts[b]) return;
+  float* bx = boxes + (size_t)i * nb;
+  const float x = bx[0], y = bx[1];
+  bx[0] = __fadd_rn(__fmul_rn(x, c), __fmul_rn(y, -s));
+  bx[1] = __fadd_rn(__fmul_rn(x, s), __fmul_rn(y, c));
+  bx[nb - 1] = bx[nb - 1] - angle;
+  if (nb > 7) {
+    const float vx = bx[6], vy = bx[7];
+    bx[6] = __fadd_rn(__fmul_rn(vx, c), __fmul_rn(vy, -s));
+    bx[7] = __fadd_rn(__fmul_rn(vx, s), __fmul_rn(vy, c));
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int pn_rotate_boxes_f32(float* boxes, const int32_t* counts, int batch, int capacity, int box_dims, double angle, pn_stream_t stream) {
+  PN_REQUIRE(boxes && counts && batch >= 1 && capacity >= 1 && box_dims >= 7, "rotate_boxes: bad arguments");
+  hipLaunchKernelGGL(rotate_boxes_kernel, dim3(pn::cdiv(batch * capacity, 256)), dim3(256), 0, pn::S(stream), boxes, counts, capacity, box_dims,
+                     (float)cos(angle), (float)sin(angle), (float)angle, batch);
+  return pn::check_launch("rotate_boxes_kernel");
+}
+
 size_t pn_center_decode_nms_workspace_bytes(int batch, int cells, int box_dims, int pre_max, int post_max) {
   return carve(nullptr, batch, cells, box_dims, pre_max, post_max).bytes;
 }

@@ -206,6 +206,77 @@ class PointPillars(SingleStageDetector):
 
 
 @DETECTORS.register_module
+class PolarStream(PointPillars):
+    """PolarStream (det3d/models/detectors/polarstream.py:7-180): a sweep given as a LIST of azimuth-sector examples is processed
+    sector by sector, the neck (RPNTECP / RPNBDCP) pads every sector with the context rows the previous sector left behind, and the
+    per-sector detections are rotated back into the sweep's frame and concatenated (single_stage.py:83-165).  A single example (dict)
+    is the full-sweep case.  Eval mode; detection super-task; no stateful NMS / panoptic fusion."""
+
+    def forward_one_sector(self, example, return_loss=True, **kwargs):
+        eval_only(self, "PolarStream")
+        points, grid_ind = example["points"], example["grid_ind"]
+        hip.require_device(points, grid_ind)
+        batch = len(example["num_points"])
+        g = [int(v) for v in example["grid_size"][0]]
+        # the sector grid: the reader's range with the azimuth axis cut to the sector (voxelization.py:318-323)
+        spec = ops.GridSpec(tuple(float(v) for v in self.reader.pc_range[:3]), tuple(float(v) for v in self.reader.voxel_size), (g[0], g[1], g[2]))
+        keys = ops.keys_from_grid_ind(grid_ind.to(torch.int64).contiguous(), spec, batch)
+        canvas = self.encode_canvas(points.contiguous(), keys, spec, batch)
+        nxt = []
+        if hasattr(self.neck, "_pad_feature_only") or not hasattr(self.neck, "forward_nhwc"):
+            raise NotImplementedError("PolarStream drives the trailing-edge neck (RPNTECP) or the plain RPN; RPNBDCP is driven by PolarStreamBDCP's two-sweep loop")
+        try:
+            x2, nxt = self.neck.forward_nhwc(canvas, kwargs.get("prev_context", []), kwargs.get("sec_id", 0))
+        except TypeError:
+            x2 = self.neck.forward_nhwc(canvas)
+        preds = self.bbox_head(ops.as_nchw(x2))
+        ret = {}
+        if return_loss:
+            ret.update(self.bbox_head.loss(example, preds))
+        elif kwargs.get("raw_preds", False) or self.test_cfg is None:
+            ret.update(preds)
+        else:
+            ret["det"] = self.bbox_head.predict(example, preds, self.test_cfg, sec_id=kwargs.get("sec_id", 0))
+        if len(nxt):
+            ret["next_context"] = nxt
+        return ret
+
+    def forward(self, example, return_loss=True, **kwargs):
+        if isinstance(example, dict):
+            return self.forward_one_sector(example, return_loss, **kwargs)
+        get = (lambda k, d=None: self.test_cfg.get(k, d)) if hasattr(self.test_cfg, "get") else (lambda k, d=None: getattr(self.test_cfg, k, d))
+        if self.test_cfg is not None and (get("stateful_nms", False) or get("panoptic", False)):
+            raise NotImplementedError("PolarStream: stateful NMS / panoptic fusion across sectors are not built")
+        rets, prev = [], []
+        for i, ex in enumerate(example):
+            r = self.forward_one_sector(ex, return_loss, **dict(kwargs, prev_context=prev, sec_id=i))
+            prev = r.pop("next_context", []) if i < len(example) - 1 else []
+            r.pop("next_context", None)
+            rets.append(r)
+        return self.merge_sectors(rets, len(example[-1]["num_points"]))
+
+    def merge_sectors(self, sectors, batch_size):
+        """single_stage.py:83-165 for the keys this build produces: losses are lists concatenated over sectors, detections are
+        concatenated per sample"""
+        out = {}
+        for k in sectors[0]:
+            vals = [s[k] for s in sectors]
+            if "loss" in k:
+                out[k] = [v for lst in vals for v in lst]
+            elif k == "det":
+                merged = []
+                for i in range(len(vals[0])):
+                    d = {}
+                    for f in vals[0][0]:
+                        d[f] = vals[0][i][f] if f == "metadata" else torch.cat([v[i][f] for v in vals])
+                    merged.append(d)
+                out[k] = merged
+            elif k == "det_preds":
+                out[k] = vals
+        return out
+
+
+@DETECTORS.register_module
 class VoxelNet(SingleStageDetector):
     """VoxelNet (voxelnet.py:27-131): reader -> sparse 3-D middle encoder -> RPN -> head, the detector of the reference's
     CenterPoint-style voxel configs (VoxelNetV3 is this plus the re-alignment attention).  Eval mode, on the HIP kernels."""

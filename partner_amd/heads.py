@@ -185,8 +185,9 @@ class CenterHead(nn.Module):
         per_class = bool(get("per_class_nms", False))   # batched_nms_rotated of the nuScenes configs (center_head.py:514-518)
         if kwargs.get("device_only", False) and len(preds_dicts["det_preds"]) != 1:
             raise NotImplementedError("predict(device_only=True) supports a single task")
-        if kwargs.get("prev_dets") is not None or kwargs.get("sec_id", 0) != 0:
-            raise NotImplementedError("predict: sector streaming (prev_dets / sec_id > 0) is not built")
+        if kwargs.get("prev_dets") is not None:
+            raise NotImplementedError("predict: stateful NMS across sectors (prev_dets) is not built")
+        sec_id = int(kwargs.get("sec_id", 0))
         nms = get("nms")
         nget = (lambda k: nms[k]) if isinstance(nms, dict) else (lambda k: getattr(nms, k))
         pre_max, post_max, iou_thr = int(nget("nms_pre_max_size")), int(nget("nms_post_max_size")), float(nget("nms_iou_threshold"))
@@ -223,6 +224,11 @@ class CenterHead(nn.Module):
                      float(osf) * float(vs[1]), float(pr[0]), float(pr[1]), int(bool(get("rectify", False))), float(get("score_threshold")),
                      (C.c_float * 6)(*[float(v) for v in pcr]), iou_thr, int(per_class), pre_max, post_max, out_boxes.data_ptr(), out_scores.data_ptr(),
                      out_labels.data_ptr(), out_cells.data_ptr(), out_count.data_ptr(), ws.data_ptr(), wsb, hip.stream())
+            if sec_id > 0:
+                # sector streaming: the sector's boxes back into the sweep's frame (center_head.py:533-545)
+                interval = float(get("interval"))
+                angle = interval * sec_id if cyl else 2 * 3.141592653589793 / interval * sec_id
+                hip.call("pn_rotate_boxes_f32", out_boxes.data_ptr(), out_count.data_ptr(), b, post_max, nb, float(angle), hip.stream())
             if kwargs.get("device_only", False):
                 # fixed-size outputs + device counts: nothing leaves the stream (hipGraph capturable); one task only
                 return dict(box3d_lidar=out_boxes, scores=out_scores, label_preds=out_labels, cells=out_cells, count=out_count)

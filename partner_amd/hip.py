@@ -30,6 +30,12 @@ class ConvDesc(C.Structure):
         "range_strata", "pad_h_end", "pad_w_end", "accumulate")]
 
 
+class RowPiece(C.Structure):
+    """mirror of ``pn_row_piece``"""
+
+    _fields_ = [("src", C.c_void_p), ("pixel_stride", C.c_int32), ("rows", C.c_int32)]
+
+
 class ConvJob(C.Structure):
     """mirror of ``pn_conv_job``"""
 
@@ -143,6 +149,10 @@ SIGNATURES = {
     "pn_swv_criterion_workspace_bytes": (_SZ, [_I, _I, _I]),
     "pn_swv_set_criterion_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I,
                                       _F, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "pn_rotate_boxes_f32": (_I, [_P, _P, _I, _I, _I, C.c_double, _P]),
+    "pn_split_polar_sectors_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "pn_split_polar_sectors_f32": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "pn_assemble_rows_f32": (_I, [C.POINTER(RowPiece), _I, _I, _I, _I, _P, _I, _I, _P]),
     "pn_nchw_to_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "pn_nhwc_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "pn_grad_norm_workspace_bytes": (_SZ, []),

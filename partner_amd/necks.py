@@ -36,12 +36,7 @@ class RPN(nn.Module):
         cin = [num_input_features, *ds_num_filters[:-1]]
         blocks, deblocks = [], []
         for i, n in enumerate(layer_nums):
-            blk = Sequential(nn.ZeroPad2d(1), nn.Conv2d(cin[i], ds_num_filters[i], 3, stride=ds_layer_strides[i], bias=False),
-                             build_norm_layer(self._norm_cfg, ds_num_filters[i])[1], nn.ReLU())
-            for _ in range(n):
-                blk.add(nn.Conv2d(ds_num_filters[i], ds_num_filters[i], 3, padding=1, bias=False))
-                blk.add(build_norm_layer(self._norm_cfg, ds_num_filters[i])[1])
-                blk.add(nn.ReLU())
+            blk, _ = self._make_layer(cin[i], ds_num_filters[i], n, stride=ds_layer_strides[i])
             blocks.append(blk)
             j = i - self._upsample_start_idx
             if j >= 0:
@@ -56,6 +51,16 @@ class RPN(nn.Module):
         self.deblocks = nn.ModuleList(deblocks)
         self._plan = PlanCache()
         (logger or logging.getLogger("RPN")).info("Finish RPN Initialization")
+
+    def _make_layer(self, inplanes, planes, num_blocks, stride=1):
+        """rpn.py:124-142: ZeroPad2d(1) + Conv3x3(stride) + norm + ReLU, then num_blocks x (Conv3x3(pad 1) + norm + ReLU)"""
+        blk = Sequential(nn.ZeroPad2d(1), nn.Conv2d(inplanes, planes, 3, stride=stride, bias=False),
+                         build_norm_layer(self._norm_cfg, planes)[1], nn.ReLU())
+        for _ in range(num_blocks):
+            blk.add(nn.Conv2d(planes, planes, 3, padding=1, bias=False))
+            blk.add(build_norm_layer(self._norm_cfg, planes)[1])
+            blk.add(nn.ReLU())
+        return blk, planes
 
     @property
     def downsample_factor(self):

@@ -688,7 +688,61 @@ def gen_e2e():
     save("e2e_loss.npz", **out)
 
 
+STREAM_NECK = dict(layer_nums=[1, 2], ds_layer_strides=[2, 2], ds_num_filters=[16, 32], us_layer_strides=[1, 2], us_num_filters=[16, 16],
+                   num_input_features=8)
+
+
+def gen_stream():
+    """sector streaming: the reference's Voxelization.voxelize_streaming_polar on a 4-sector split of a synthetic sweep, and its
+    context-padding necks RPNTECP (two chained sectors) and RPNBDCP (feature_only with 1 and 4 stacked sectors; streaming mode
+    with a previous sweep for the first / a middle / the last sector) on small maps"""
+    from det3d.models.necks.rpn_context import RPNTECP, RPNBDCP
+    out = {}
+    # ---- streaming voxelization
+    cfg = ADict(vox_cfg(synth.NUSC_RANGE, synth.NUSC_VOXEL), nsectors=4)
+    vx = Voxelization(cfg=cfg, super_tasks=["det"])
+    pts = synth.synth_sweep_polar(6000, seed=77, rho_max=55.0)
+    res = {"mode": "val", "lidar": {"points": pts.copy()}}
+    secs, _ = vx.voxelize_streaming_polar(res, {})
+    for i, sec in enumerate(secs["sectors"]):
+        out[f"sec{i}_points"] = sec["lidar"]["points"].astype(np.float32)
+        out[f"sec{i}_grid_ind"] = np.ascontiguousarray(sec["lidar"]["voxels"]["grid_ind"]).astype(np.int32)
+    out["sec_shape"] = np.asarray(secs["sectors"][0]["lidar"]["voxels"]["shape"])
+    # ---- necks
+    logger = logging.getLogger("RPN")
+    rng = np.random.default_rng(3)
+    for name, cls, kw in (("tecp", RPNTECP, {}), ("bdcp", RPNBDCP, dict(nsectors=4))):
+        torch.manual_seed(0)
+        neck = cls(logger=logger, **STREAM_NECK, **kw).eval()
+        sd = synth.fill_state_dict(neck.state_dict(), 21)
+        neck.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        out[f"{name}_state_keys"] = np.array(list(neck.state_dict().keys()))
+        xs = [torch.from_numpy(rng.standard_normal((2, 8, 16, 24)).astype(np.float32)) for _ in range(4)]
+        with torch.no_grad():
+            if name == "tecp":
+                y0, ctx = neck(xs[0])
+                y1, ctx1 = neck(xs[1], prev_context=[c.clone() for c in ctx], sec_id=1)
+                out["tecp_y0"], out["tecp_y1"] = y0.numpy(), y1.numpy()
+                out["tecp_ctx_shapes"] = np.array([list(c.shape) for c in ctx])
+                out["tecp_ctx1_last"] = ctx1[-1].numpy()
+            else:
+                full = torch.cat(xs, 2)                                     # a full sweep: 64 azimuth rows
+                y, cur_full = neck(full, nsectors=1, mode="feature_only")
+                out["bdcp_full"] = y.numpy()
+                stacked = torch.cat(xs, 0)                                  # 4 sectors x batch 2, sector-major
+                ys, _ = neck(stacked, nsectors=4, mode="feature_only")
+                out["bdcp_stacked"] = ys.numpy()
+                # streaming over the sectors of a NEW sweep with the previous sweep's per-layer inputs as leading-edge context
+                xn = [torch.from_numpy(rng.standard_normal((2, 8, 16, 24)).astype(np.float32)) for _ in range(4)]
+                prev_ctx = []
+                for sec in range(4):
+                    yy, cur = neck(xn[sec], prev_sweep=cur_full, prev_context=[c for c in prev_ctx], sec_id=sec, nsectors=4, mode="eval")
+                    out[f"bdcp_stream{sec}"] = yy.numpy()
+                    prev_ctx = cur
+    save("stream.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static", "seg_head", "e2e"]
+    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static", "seg_head", "e2e", "stream"]
     for w in which:
         globals()["gen_" + w]()
