@@ -1073,6 +1073,59 @@ def assign_heatmap_polar(gt_boxes: torch.Tensor, gt_classes: torch.Tensor, num_g
     return t
 
 
+# ------------------------------------------------------------------------------ next-4 sector streaming
+def split_polar_sectors(points: torch.Tensor, sample_offsets: torch.Tensor, batch: int, nsectors: int, pc_range, voxel_size,
+                        want_grid_ind=True, want_keys=False):
+    """Voxelization.voxelize_streaming_polar (voxelization.py:305-393) on the device: polar points (N, F >= 5) of ``batch`` samples
+    -> (points grouped by (sector, sample) in their original order, with phi shifted into the first sector and x / y recomputed;
+    part offsets (nsectors * batch + 1,) int32 on the device; grid_ind (N, 4) int64 [b, z, theta, r] against the sector grid; keys)"""
+    import numpy as np
+    hip.require_device(points, sample_offsets)
+    lib = hip.load()
+    assert points.dtype == torch.float32 and points.is_contiguous() and sample_offsets.dtype == torch.int32
+    n, f = points.shape
+    rg, vs = np.asarray(pc_range, dtype=np.float32), np.asarray(voxel_size, dtype=np.float32)
+    grid = np.round((rg[3:] - rg[:3]) / vs).astype(np.int64)
+    dev = points.device
+    out = torch.empty_like(points)
+    offs = torch.empty((nsectors * batch + 1,), dtype=torch.int32, device=dev)
+    gi = torch.empty((max(n, 1), 4), dtype=torch.int64, device=dev) if want_grid_ind else None
+    keys = torch.empty((max(n, 1),), dtype=torch.int32, device=dev) if want_keys else None
+    nbytes = lib.pn_split_polar_sectors_workspace_bytes(n, nsectors, batch)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    hip.call("pn_split_polar_sectors_f32", points.data_ptr(), n, f, sample_offsets.data_ptr(), batch, nsectors, (C.c_float * 6)(*rg.tolist()),
+             (C.c_float * 3)(*vs.tolist()), (C.c_int32 * 3)(*[int(g) for g in grid]), out.data_ptr(), hip.ptr(gi), hip.ptr(keys), offs.data_ptr(),
+             ws.data_ptr(), nbytes, hip.stream())
+    return out, offs, gi, keys
+
+
+def assemble_rows(samples, w: int, c: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``samples``: per output sample a list of up to three row pieces, each ``(None, rows)`` (zeros) or ``(tensor, sample, row0, rows)``
+    taken from an NHWC map (B, H, W, C') with C' >= c -- the torch.cat / F.pad along the azimuth axis of rpn_context.py's
+    convolutions.  -> NHWC (len(samples), sum(rows), w, c)"""
+    n = len(samples)
+    rows_out = sum(p[-1] for p in samples[0])
+    arr = (hip.RowPiece * (3 * n))()
+    dev = None
+    for k, pieces in enumerate(samples):
+        assert len(pieces) <= 3 and sum(p[-1] for p in pieces) == rows_out
+        for j in range(3):
+            e = arr[3 * k + j]
+            if j >= len(pieces) or pieces[j][0] is None:
+                e.src, e.pixel_stride, e.rows = None, 0, (pieces[j][-1] if j < len(pieces) else 0)
+                continue
+            t, smp, r0, rows = pieces[j]
+            hip.require_device(t)
+            assert t.dim() == 4 and t.is_contiguous() and t.shape[2] == w and t.shape[3] >= c and 0 <= r0 and r0 + rows <= t.shape[1]
+            dev = t.device
+            e.src = t.data_ptr() + 4 * ((smp * t.shape[1] + r0) * t.shape[2] * t.shape[3])
+            e.pixel_stride, e.rows = t.shape[3], rows
+    if out is None:
+        out = torch.empty((n, rows_out, w, c), dtype=torch.float32, device=dev)
+    hip.call("pn_assemble_rows_f32", arr, n, rows_out, w, c, out.data_ptr(), out.shape[3], 0, hip.stream())
+    return out
+
+
 # ------------------------------------------------------------------------------ next-4 sweep accumulation
 def accumulate_sweeps(raw: torch.Tensor, sweep_offsets: torch.Tensor, transforms: torch.Tensor, time_lags: torch.Tensor, min_distance=1.0,
                       count: Optional[torch.Tensor] = None):
