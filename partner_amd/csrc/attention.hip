@@ -389,11 +389,10 @@ int pn_setblock_range_attn(const float* qkv, const float* kpos, const float* pos
   const int n = k * win_w, hd = c / heads;
   const size_t smem = (size_t)heads * (3 * n * hd + n * n) * sizeof(float);
   PN_REQUIRE(smem <= 160 * 1024, "range_attn: window too large for LDS");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {false};
+  if (pn::first_use_on_device(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&range_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    attr_done = true;
   }
   PosMlp pm{pos_mlp, heads};
   hipLaunchKernelGGL(range_attn_kernel, dim3(batch * (w / win_w)), dim3(256), smem, pn::S(stream), qkv, kpos, pm, batch, w, c, k,

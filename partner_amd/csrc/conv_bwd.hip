@@ -329,10 +329,9 @@ int plan_wgrad(const pn_conv_desc* d, WgradPlan& p) {
 template <int TM, int TN>
 int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
   constexpr size_t smem = 2 * (size_t)WK * (TM * 64 + 8 + TN * 64 + 8) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {false};
+  if (pn::first_use_on_device(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   const int per_split = p.taps * p.ci_tiles * p.co_tiles;
   const int groups8 = pn::cdiv(p.splits, 8);  // splits are handed out in groups of 8, one per XCD

@@ -839,11 +839,10 @@ int pn_dynamic_pfn_fwd(const float* points, int point_stride, const int32_t* vox
   PfnArgs a{points, point_stride, voxel_start, order, num_voxels, v_capacity, unq_keys, grid[0], grid[1], grid[2],
             w0, c0, w1, c1, vx, vy, x_offset, y_offset, features, canvas};
   const size_t smem = (size_t)(16 * c0 + 2 * c0 * c1 + kPfnWaves * 64) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {false};
+  if (pn::first_use_on_device(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dynamic_pfn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)((16 * 64 + 2 * 64 * 128 + kPfnWaves * 64) * sizeof(float)));
-    attr_done = true;
   }
   const int blocks = std::max(1, std::min(1024, pn::cdiv(v_capacity, kPfnWaves * 2)));
   hipLaunchKernelGGL(dynamic_pfn_kernel, dim3(blocks), dim3(kPfnWaves * 64), smem, pn::S(stream), a);
@@ -1048,10 +1047,9 @@ int pn_static_pfn_fwd(const float* voxels, const int32_t* num_points, const int3
   StaticPfnArgs a{voxels, num_points, coors, num_voxels, v_capacity, p, f, nin, with_distance, w0, scale0, shift0, c0, w1, scale1, shift1, c1,
                   vx, vy, x_offset, y_offset, features};
   const size_t smem = (size_t)(nin * c0 + (c1 ? 2 * c0 * c1 : 0) + kSpWaves * (p + 1) * 64) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {false};
+  if (pn::first_use_on_device(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&static_pfn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-    attr_done = true;
   }
   PN_REQUIRE(smem <= 140 * 1024, "static_pfn: layer sizes exceed LDS");
   const int blocks = std::max(1, std::min(2048, pn::cdiv(v_capacity, kSpWaves)));

@@ -33,6 +33,16 @@ inline bool take_profile_slot(ProfileSlot& out) {
   return true;
 }
 
+// hipFuncSetAttribute belongs to the CURRENT device's copy of the kernel: true the first time the calling site runs on a device
+// (one-shot statics would leave the second GPU of a process with the default dynamic-LDS limit).  `flags` = a static array of 64.
+inline bool first_use_on_device(bool* flags) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  if (flags[dev]) return false;
+  flags[dev] = true;
+  return true;
+}
+
 inline hipStream_t S(pn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

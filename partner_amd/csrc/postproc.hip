@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
   unsigned long long* keys = sort_lds;                       // [kCap]
   int* hist = reinterpret_cast<int*>(sort_lds + kCap);       // [kHistBins]
   __shared__ int wave_cnt[kSortThreads / 64];
-  __shared__ int n_valid, cut_bin, n_ge, n_kept;
+  __shared__ int n_valid, cut_bin, n_ge, n_kept, sub_cut;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float* sc = score + (size_t)b * cells;
   if (tid == 0) { n_valid = 0; n_kept = 0; }
@@ -143,10 +143,11 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
     if (lane == 0 && mine) atomicAdd(&n_valid, mine);
   }
   __syncthreads();
-  // ---- the bin in which the pre_max-th best falls: one wave walks the histogram from the top, 64 bins per step
-  if (wv == 0) {
-    int acc = 0, found = -1, ge = n_valid;
-    if (n_valid > pre_max) {
+  // ---- the bin in which the `need`-th best falls: one wave walks the histogram from the top, 64 bins per step
+  //      -> (bin, number of entries at or above it); bin 0 / total when fewer than `need` entries exist
+  auto find_cut = [&](int need, int total, int& bin_out, int& ge_out) {
+    int acc = 0, found = -1, ge = total;
+    if (total > need) {
       for (int hi = kHistBins - 64; hi >= 0 && found < 0; hi -= 64) {
         const int v = hist[hi + 63 - lane];                 // lane 0 = highest bin of the chunk
         int inc = v;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
           const int t = __shfl_up(inc, o, 64);
           if (lane >= o) inc += t;
         }
-        const unsigned long long hit = __ballot(acc + inc >= pre_max);
+        const unsigned long long hit = __ballot(acc + inc >= need);
         if (hit) {
           const int l = __ffsll((long long)hit) - 1;
           found = hi + 63 - l;
@@ -164,11 +165,43 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
         acc += __shfl(inc, 63, 64);
       }
     }
-    if (lane == 0) { cut_bin = found < 0 ? 0 : found; n_ge = ge; }
+    bin_out = found < 0 ? 0 : found;
+    ge_out = ge;
+  };
+  if (wv == 0) {
+    int cb, ge;
+    find_cut(pre_max, n_valid, cb, ge);
+    if (lane == 0) { cut_bin = cb; n_ge = ge; sub_cut = 0; }
   }
   __syncthreads();
   const unsigned cut = (unsigned)cut_bin;
-  // ---- pass 2: the candidates at or above that bin (a superset of the top pre_max, usually a few hundred more) -> keys
+  // More candidates at or above the cut bin than the sort buffer holds (a near-constant score map: an untrained head puts a whole
+  // map into one bin of the top 12 score bits): refine INSIDE the cut bin with a second histogram on the next 12 bits, so that the
+  // candidates are still the best by score and not the first in cell order.
+  if (n_ge > kCap) {
+    const int n_above = n_ge - hist[cut];    // entries in the bins above the cut: fewer than pre_max by construction
+    __syncthreads();
+    for (int i = tid; i < kHistBins; i += kSortThreads) hist[i] = 0;
+    __syncthreads();
+    for (int c = tid; c < cells; c += kSortThreads) {
+      const float s = sc[c];
+      const unsigned u = __builtin_bit_cast(unsigned, s);
+      if (s >= 0.f && ((u >> 19) & (kHistBins - 1)) == cut) atomicAdd(&hist[(u >> 7) & (kHistBins - 1)], 1);
+    }
+    __syncthreads();
+    if (wv == 0) {
+      int sb, ge;
+      find_cut(pre_max - n_above, n_ge - n_above, sb, ge);
+      if (lane == 0) { sub_cut = sb; n_ge = n_above + ge; }
+    }
+    __syncthreads();
+  }
+  const unsigned scut = (unsigned)sub_cut;
+  auto at_or_above = [&](float s) {
+    const unsigned u = __builtin_bit_cast(unsigned, s), bin = (u >> 19) & (kHistBins - 1);
+    return s >= 0.f && (bin > cut || (bin == cut && ((u >> 7) & (kHistBins - 1)) >= scut));
+  };
+  // ---- pass 2: the candidates at or above the cut (a superset of the top pre_max, usually a few hundred more) -> keys
   if (n_ge <= kCap) {
     // the sort below orders them by the full key, so the order in which they land here is irrelevant: one LDS atomic per wave
     for (int c0 = 0; c0 < cells; c0 += kSortThreads * kBatch) {
@@ -182,7 +215,7 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
       for (int k = 0; k < kBatch; ++k) {
         const int c = c0 + k * kSortThreads + tid;
         const float s = sv[k];
-        const bool v = s >= 0.f && ((__builtin_bit_cast(unsigned, s) >> 19) & (kHistBins - 1)) >= cut;
+        const bool v = at_or_above(s);
         const unsigned long long bal = __ballot(v);
         int base = 0;
         if (lane == 0 && bal) base = atomicAdd(&n_kept, __popcll(bal));
@@ -192,27 +225,30 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
       }
     }
   } else {
-    // more than kCap candidates in and above one bin (e.g. a constant score map): the first kCap in CELL order enter the
-    // sort -- ordered compaction, block scans
-    for (int c0 = 0; c0 < cells; c0 += kSortThreads) {
-      const int c = c0 + tid;
-      const float s = c < cells ? sc[c] : -1.f;
-      const bool v = s >= 0.f && ((__builtin_bit_cast(unsigned, s) >> 19) & (kHistBins - 1)) >= cut;
-      const unsigned long long bal = __ballot(v);
-      if (lane == 0) wave_cnt[wv] = __popcll(bal);
-      __syncthreads();
-      int off = n_kept;
-      for (int k = 0; k < wv; ++k) off += wave_cnt[k];
-      const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-      if (v && pos < kCap) keys[pos] = ((unsigned long long)__builtin_bit_cast(unsigned, s) << 32) | (unsigned)(0xffffffffu - (unsigned)c);
-      __syncthreads();
-      if (tid == 0) {
-        int t = 0;
-        for (int k = 0; k < kSortThreads / 64; ++k) t += wave_cnt[k];
-        n_kept += t;
+    // still too many: more than kCap scores agree in their top 24 bits.  First everything strictly above the refined cut, then
+    // the refined cut bin itself in cell order until the sort buffer is full (ordered compaction, block scans).
+    for (int phase = 0; phase < 2; ++phase)
+      for (int c0 = 0; c0 < cells; c0 += kSortThreads) {
+        const int c = c0 + tid;
+        const float s = c < cells ? sc[c] : -1.f;
+        const unsigned u = __builtin_bit_cast(unsigned, s), bin = (u >> 19) & (kHistBins - 1), sub = (u >> 7) & (kHistBins - 1);
+        const bool above = bin > cut || (bin == cut && sub > scut), equal = bin == cut && sub == scut;
+        const bool v = s >= 0.f && (phase == 0 ? above : equal);
+        const unsigned long long bal = __ballot(v);
+        if (lane == 0) wave_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = n_kept;
+        for (int k = 0; k < wv; ++k) off += wave_cnt[k];
+        const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+        if (v && pos < kCap) keys[pos] = ((unsigned long long)__builtin_bit_cast(unsigned, s) << 32) | (unsigned)(0xffffffffu - (unsigned)c);
+        __syncthreads();
+        if (tid == 0) {
+          int t = 0;
+          for (int k = 0; k < kSortThreads / 64; ++k) t += wave_cnt[k];
+          n_kept += t;
+        }
+        __syncthreads();
       }
-      __syncthreads();
-    }
   }
   __syncthreads();
   const int n = min(n_kept, kCap);
@@ -384,10 +420,9 @@ int run_decode_nms(DecodeArgs a, const float* post_center_range, float nms_iou_t
   a.boxes = ws.boxes; a.score = ws.score; a.label = ws.label;
   const size_t total = (size_t)batch * cells;
   hipLaunchKernelGGL(decode_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, st, a);
-  static bool sort_attr = false;
-  if (!sort_attr) {
+  static bool sort_attr[64] = {false};
+  if (pn::first_use_on_device(sort_attr)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortLds);
-    sort_attr = true;
   }
   hipLaunchKernelGGL(select_sort_kernel, dim3(batch), dim3(kSortThreads), kSortLds, st, ws.score, ws.boxes, cells, nb, pre_max, ws.sel_cell,
                      ws.nms_boxes, ws.n_sel, ws.label, ws.sel_label);

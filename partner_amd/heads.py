@@ -193,6 +193,9 @@ class CenterHead(nn.Module):
         pre_max, post_max, iou_thr = int(nget("nms_pre_max_size")), int(nget("nms_post_max_size")), float(nget("nms_iou_threshold"))
         if per_class:
             pre_max = 4096   # the reference passes every candidate to the per-class NMS; the device path takes the best 4096
+        if pre_max > 4096:
+            raise ValueError(f"predict: nms_pre_max_size = {pre_max} exceeds the device NMS capacity of 4096 candidates per sample "
+                             "(INTEGRATION.md, limits)")
         pcr = list(get("post_center_limit_range"))
         assert len(pcr) == 6, "predict: post_center_limit_range must have 6 entries"
         osf, vs, pr = get("out_size_factor"), get("voxel_size"), get("pc_range")

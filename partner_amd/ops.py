@@ -720,6 +720,11 @@ _WS = {}
 def _workspace(nbytes: int, dev) -> torch.Tensor:
     """grow-only scratch buffer per (device, stream): the backward kernels need their workspace only
     until the launch that consumes it has been queued on the same stream"""
+    if torch.cuda.is_current_stream_capturing():
+        # every hipGraph capture runs on torch's shared capture stream: a cached buffer keyed by the stream would be shared by all
+        # captured engines (and owned by the first graph's pool) -- a race once the engines replay concurrently.  Inside a capture
+        # the scratch is a plain allocation of that graph's private pool.
+        return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     key = (str(dev), hip.stream())
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
