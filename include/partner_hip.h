@@ -817,6 +817,46 @@ int pn_conv_stats_apply_f32(const pn_conv_job *producer, int tile, const float *
                             pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Differentiable primitives for the TRAINING forms of the attention blocks (det3d/models/utils/set_transformer.py:118-166,
+ * 216-259, 307-354, 392-440 under torch autograd; the inference kernels above keep no intermediates).
+ * pn_contract_f32: C[g0,g1,g2, m0,m1, n0,n1] (+)= alpha * sum_{k0,k1} A[g.., m0,m1, k0,k1] * B[g.., n0,n1, k0,k1]; strides in
+ * elements, stride_a = {g0,g1,g2,m0,m1,k0,k1}, stride_b = {g0,g1,g2,n0,n1,k0,k1}, stride_c = {g0,g1,g2,m0,m1,n0,n1},
+ * dims = {G0,G1,G2,M0,M1,N0,N1,K0,K1}.  The head / window / raw-view permutations of the reference are strides here.
+ */
+int pn_contract_f32(const float *a, const int64_t *stride_a, const float *b, const int64_t *stride_b, float *c,
+                    const int64_t *stride_c, const int32_t *dims, float alpha, int accumulate, pn_stream_t stream);
+/* softmax over the middle axis of a contiguous (outer, n, inner) array and its backward (dx = y * (dy - sum(y * dy))) */
+int pn_softmax_f32(const float *x, float *y, long long outer, int n, int inner, pn_stream_t stream);
+int pn_softmax_bwd_f32(const float *y, const float *dy, float *dx, long long outer, int n, int inner, pn_stream_t stream);
+/* backward of pn_layernorm_f32 over rows of c <= 1024 values: dx, and dgamma / dbeta (+= when accumulate) */
+size_t pn_layernorm_bwd_workspace_bytes(long long rows, int c);
+int pn_layernorm_bwd_f32(const float *x, const float *dy, const float *gamma, float eps, long long rows, int c, float *dx,
+                         float *dgamma, float *dbeta, int accumulate, void *workspace, size_t workspace_bytes,
+                         pn_stream_t stream);
+/* exact (erf) GELU and its backward */
+int pn_gelu_f32(const float *x, float *y, size_t n, pn_stream_t stream);
+int pn_gelu_bwd_f32(const float *x, const float *dy, float *dx, size_t n, pn_stream_t stream);
+/* rel[g0,g1, m0,m1, n0,n1][0..1] = a[g.., m0,m1][0..1] - b[g.., n0,n1][0..1], columns 2..cols-1 zero, output contiguous:
+ * the Cartesian offsets the relative-position MLPs take (set_transformer.py:230-236, 321-326).  Strides in floats,
+ * stride_a = {g0,g1,m0,m1}, stride_b = {g0,g1,n0,n1}, dims = {G0,G1,M0,M1,N0,N1}. */
+int pn_pair_diff_f32(const float *a, const int64_t *stride_a, const float *b, const int64_t *stride_b,
+                     const int32_t *dims, int cols, float *rel, pn_stream_t stream);
+/* nn.Dropout (row_len = 1) / DropPath (row_len = elements of one sample): y = x * mask, mask in {0, 1/(1-p)} from a
+ * counter-based generator keyed by (seed, element / row_len); the mask is kept for the backward (dx = dy * mask) */
+int pn_dropout_f32(const float *x, size_t n, size_t row_len, float p, uint64_t seed, float *y, float *mask,
+                   pn_stream_t stream);
+int pn_mul_f32(const float *a, const float *b, float *y, size_t n, pn_stream_t stream);
+/* dst[b, index[b,k,w], w, :] += src[b, k, w, :]: backward of the key-point row gather (set_transformer.py:144-147) */
+int pn_scatter_rows_f32(const float *src, const int32_t *index, int batch, int k, int h, int w, int c, float *dst,
+                        pn_stream_t stream);
+/* torch.roll(x, shift, dims=2) of a (batch, h, w, c) map (set_transformer.py:121-124, 160-163) */
+int pn_roll_w_f32(const float *x, int batch, int h, int w, int c, int shift, float *y, pn_stream_t stream);
+/* F.normalize over rows of c values (cosine attention, swin_transformer_v2.py:156-158) and its backward; inv_norm[rows] */
+int pn_l2_normalize_f32(const float *x, long long rows, int c, float eps, float *y, float *inv_norm, pn_stream_t stream);
+int pn_l2_normalize_bwd_f32(const float *y, const float *dy, const float *inv_norm, long long rows, int c, float *dx,
+                            pn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * timing helper: HIP events on `stream`, used by bench.py for the roofline object.
  */
 typedef void *pn_event_t;

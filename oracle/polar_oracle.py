@@ -450,10 +450,14 @@ def _ln(sd: SD, p: str, x: Tensor) -> Tensor:
     return F.layer_norm(x, (x.shape[-1],), sd[p + "weight"], sd[p + "bias"], 1e-5)
 
 
-def _pos_bias(sd: SD, p: str, rel: Tensor) -> Tensor:
-    """rel (G,2,L) -> (G,heads,L): Conv1d(2->16) + BN1d(eval) + ReLU + Conv1d(16->heads)."""
+def _pos_bias(sd: SD, p: str, rel: Tensor, train=False) -> Tensor:
+    """rel (G,2,L) -> (G,heads,L): Conv1d(2->16) + BN1d + ReLU + Conv1d(16->heads); BN1d with the running statistics, or
+    (train: module.train() semantics) the batch statistics -- the running buffers are left untouched."""
     y = F.conv1d(rel, sd[p + "0.weight"], sd[p + "0.bias"])
-    y = F.batch_norm(y, sd[p + "1.running_mean"], sd[p + "1.running_var"], sd[p + "1.weight"], sd[p + "1.bias"], False, 0.1, 1e-5)
+    if train:
+        y = F.batch_norm(y, None, None, sd[p + "1.weight"], sd[p + "1.bias"], True, 0.1, 1e-5)
+    else:
+        y = F.batch_norm(y, sd[p + "1.running_mean"], sd[p + "1.running_var"], sd[p + "1.weight"], sd[p + "1.bias"], False, 0.1, 1e-5)
     return F.conv1d(F.relu(y), sd[p + "3.weight"], sd[p + "3.bias"])
 
 
@@ -473,8 +477,9 @@ def _raw_view_keypoints(t: Tensor, B: int, K: int, W: int, heads: int) -> Tensor
 
 
 def set_attention(sd: SD, p: str, x: Tensor, pos_cart: Tensor, reso, heads: int, K=4, win_w=8, shift=False,
-                  return_topidx=False, top_override=None, return_scores=False):
-    """SetAttention.forward for H_sp=H (full range column), W_sp=1.  x (B,L,C); pos_cart (B,H,W,2)."""
+                  return_topidx=False, top_override=None, return_scores=False, train=False):
+    """SetAttention.forward for H_sp=H (full range column), W_sp=1.  x (B,L,C); pos_cart (B,H,W,2).
+    train: BatchNorm1d of the position MLPs in training mode (dropout / drop-path rates are taken as 0)."""
     H, W = reso
     B, L, C = x.shape
     hd = C // heads
@@ -510,7 +515,7 @@ def set_attention(sd: SD, p: str, x: Tensor, pos_cart: Tensor, reso, heads: int,
     # ---- sector attention 1: key points <- their column ------------------------------------
     q = "sector_attn1."
     rel = (sp[:, :, :, None] - xp[:, :, None, :]).reshape(B * W, 2, K * H)
-    bias = _pos_bias(sd, p + q + "pos_embedding_cart.", rel).view(B * W, heads, K, H)
+    bias = _pos_bias(sd, p + q + "pos_embedding_cart.", rel, train).view(B * W, heads, K, H)
     qq = _raw_view_keypoints(_lin(sd, p + q + "proj_q.", kp), B, K, W, heads) * scale
     kk = _cols(_lin(sd, p + q + "proj_k.", xt), B, H, W, heads)
     vv = _cols(_lin(sd, p + q + "proj_v.", xt), B, H, W, heads)
@@ -526,7 +531,7 @@ def set_attention(sd: SD, p: str, x: Tensor, pos_cart: Tensor, reso, heads: int,
     sn = _ln(sd, p + q + "norm1.", s1)
     wp = kpos.view(B, 1, K, nw, win_w, 2).permute(0, 1, 3, 5, 2, 4).reshape(B * nw, 2, n)
     rel = (wp[:, :, :, None] - wp[:, :, None, :]).reshape(B * nw, 2, n * n)
-    bias = _pos_bias(sd, p + q + "pos_embedding_cart.", rel).view(B * nw, heads, n, n)
+    bias = _pos_bias(sd, p + q + "pos_embedding_cart.", rel, train).view(B * nw, heads, n, n)
 
     def win(t):
         return t.view(B, K, nw, win_w, heads, hd).permute(0, 2, 4, 1, 3, 5).reshape(B * nw, heads, n, hd)
@@ -542,7 +547,7 @@ def set_attention(sd: SD, p: str, x: Tensor, pos_cart: Tensor, reso, heads: int,
     # ---- sector attention 2: column <- key points (no proj / mlp inside) --------------------
     q = "sector_attn2."
     rel = (xp[:, :, :, None] - sp[:, :, None, :]).reshape(B * W, 2, H * K)
-    bias = _pos_bias(sd, p + q + "pos_embedding_cart.", rel).view(B * W, heads, H, K)
+    bias = _pos_bias(sd, p + q + "pos_embedding_cart.", rel, train).view(B * W, heads, H, K)
     qq = _cols(_lin(sd, p + q + "proj_q.", xt), B, H, W, heads) * scale
     kk = _raw_view_keypoints(_lin(sd, p + q + "proj_k.", s2), B, K, W, heads)
     vv = _raw_view_keypoints(_lin(sd, p + q + "proj_v.", s2), B, K, W, heads)

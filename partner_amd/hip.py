@@ -153,6 +153,20 @@ SIGNATURES = {
     "pn_split_polar_sectors_workspace_bytes": (_SZ, [_I, _I, _I]),
     "pn_split_polar_sectors_f32": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "pn_assemble_rows_f32": (_I, [C.POINTER(RowPiece), _I, _I, _I, _I, _P, _I, _I, _P]),
+    "pn_contract_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
+    "pn_softmax_f32": (_I, [_P, _P, C.c_longlong, _I, _I, _P]),
+    "pn_softmax_bwd_f32": (_I, [_P, _P, _P, C.c_longlong, _I, _I, _P]),
+    "pn_layernorm_bwd_workspace_bytes": (_SZ, [C.c_longlong, _I]),
+    "pn_layernorm_bwd_f32": (_I, [_P, _P, _P, _F, C.c_longlong, _I, _P, _P, _P, _I, _P, _SZ, _P]),
+    "pn_gelu_f32": (_I, [_P, _P, _SZ, _P]),
+    "pn_gelu_bwd_f32": (_I, [_P, _P, _P, _SZ, _P]),
+    "pn_pair_diff_f32": (_I, [_P, _P, _P, _P, _P, _I, _P, _P]),
+    "pn_dropout_f32": (_I, [_P, _SZ, _SZ, _F, C.c_uint64, _P, _P, _P]),
+    "pn_mul_f32": (_I, [_P, _P, _P, _SZ, _P]),
+    "pn_scatter_rows_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "pn_roll_w_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "pn_l2_normalize_f32": (_I, [_P, C.c_longlong, _I, _F, _P, _P, _P]),
+    "pn_l2_normalize_bwd_f32": (_I, [_P, _P, _P, C.c_longlong, _I, _P, _P]),
     "pn_nchw_to_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "pn_nhwc_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "pn_grad_norm_workspace_bytes": (_SZ, []),
