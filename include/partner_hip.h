@@ -644,6 +644,26 @@ int pn_sparse_to_dense_nhwc(const float *feats, const uint32_t *keys, int capaci
                             const int32_t *n_dev, const int32_t *dims, int c, float *out,
                             pn_stream_t stream);
 
+/* Backward side of the sparse convolutions (scn.py:97-192 under autograd; spconv's own backward in the reference).
+ *   pn_sparse_neighbors_transpose  inv[in row][tap] = the output row that reads it through that tap, or -1 (at most one
+ *                                  exists): the data gradient is then pn_sparse_conv_f32 over `inv` with the (Cin, Cout)
+ *                                  transposed weights -- a gather, no atomics
+ *   pn_sparse_conv_wgrad_f32       dw[co][tap][ci] (+)= sum_i dout[i][co] * in[nbr[i][tap]][ci]  (spconv weight layout
+ *                                  (Cout, kD, kH, kW, Cin)); `cin` = row width of `in`, cin_real <= cin the channels kept;
+ *                                  channels <= 128; partials per 2048-row chunk folded in chunk order
+ *   pn_sparse_from_dense_nhwc      gradient of pn_sparse_to_dense_nhwc: gathers (B, H, W, C*D) back to the active rows
+ *   pn_add_relu_f32                out = max(a + b, 0)  (SparseBasicBlock's residual join, scn.py:84-95)
+ */
+int pn_sparse_neighbors_transpose(const int32_t *nbr, const int32_t *n_out, int out_capacity, int taps, int in_rows,
+                                  int32_t *inv, pn_stream_t stream);
+size_t pn_sparse_conv_wgrad_workspace_bytes(int out_capacity, int taps, int cout, int cin);
+int pn_sparse_conv_wgrad_f32(const float *in, int cin, int cin_real, const float *dout, int cout, const int32_t *nbr,
+                             const int32_t *n_out, int out_capacity, int taps, float *dw, int accumulate,
+                             void *workspace, size_t workspace_bytes, pn_stream_t stream);
+int pn_sparse_from_dense_nhwc(const float *dense, const uint32_t *keys, int capacity, const int32_t *n_dev,
+                              const int32_t *dims, int c, float *feats, pn_stream_t stream);
+int pn_add_relu_f32(const float *a, const float *b, float *out, size_t n, pn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * next-3  CenterPoint target assignment on the polar grid, on the device.
  * Replaces AssignLabel.assign_heatmap_polar   det3d/datasets/pipelines/preprocess.py:253-342

@@ -894,7 +894,15 @@ def _sp_w(w: Tensor) -> Tensor:
     return w.permute(0, 4, 1, 2, 3).contiguous()
 
 
-def _sp_bn(sd: SD, p: str, x: Tensor, mask: Tensor, eps=1e-3) -> Tensor:
+def _sp_bn(sd: SD, p: str, x: Tensor, mask: Tensor, eps=1e-3, train=False) -> Tensor:
+    """BatchNorm1d over the ACTIVE sites' feature rows; train: batch statistics (biased variance) of those rows, running buffers
+    untouched"""
+    if train:
+        n = mask.sum()
+        mean = (x * mask).sum(dim=(0, 2, 3, 4)) / n
+        var = (((x - mean[None, :, None, None, None]) ** 2) * mask).sum(dim=(0, 2, 3, 4)) / n
+        y = (x - mean[None, :, None, None, None]) / torch.sqrt(var[None, :, None, None, None] + eps)
+        return (y * sd[p + "weight"][None, :, None, None, None] + sd[p + "bias"][None, :, None, None, None]) * mask
     y = (x - sd[p + "running_mean"][None, :, None, None, None]) / torch.sqrt(sd[p + "running_var"][None, :, None, None, None] + eps)
     return (y * sd[p + "weight"][None, :, None, None, None] + sd[p + "bias"][None, :, None, None, None]) * mask
 
@@ -907,40 +915,41 @@ def _sp_subm(sd: SD, p: str, x: Tensor, mask: Tensor) -> Tensor:
 def _sp_down(sd: SD, p: str, x: Tensor, mask: Tensor, stride, padding):
     w = _sp_w(sd[p + "weight"])
     k = list(w.shape[2:])
-    m = (F.max_pool3d(mask, k, stride, padding) > 0).float()
+    m = (F.max_pool3d(mask, k, stride, padding) > 0).to(x.dtype)
     return F.conv3d(x, w, None, stride, padding) * m, m
 
 
-def _sp_block(sd: SD, p: str, x: Tensor, mask: Tensor) -> Tensor:
-    out = F.relu(_sp_bn(sd, p + "bn1.", _sp_subm(sd, p + "conv1.", x, mask), mask))
-    out = _sp_bn(sd, p + "bn2.", _sp_subm(sd, p + "conv2.", out, mask), mask)
+def _sp_block(sd: SD, p: str, x: Tensor, mask: Tensor, train=False) -> Tensor:
+    out = F.relu(_sp_bn(sd, p + "bn1.", _sp_subm(sd, p + "conv1.", x, mask), mask, train=train))
+    out = _sp_bn(sd, p + "bn2.", _sp_subm(sd, p + "conv2.", out, mask), mask, train=train)
     return F.relu(out + x)
 
 
 def sp_middle_resnet_fhd(sd: SD, prefix: str, voxel_features: Tensor, coors: np.ndarray, batch_size: int, input_shape,
-                         extra_sp_shape=(1, 0, 0), return_stages=False):
-    """voxel_features (V,C); coors (V,4) int [b,z,y,x]; input_shape [x,y,z] -> (B, C*D, H, W) dense BEV map (scn.py:157-192)"""
+                         extra_sp_shape=(1, 0, 0), return_stages=False, train=False):
+    """voxel_features (V,C); coors (V,4) int [b,z,y,x]; input_shape [x,y,z] -> (B, C*D, H, W) dense BEV map (scn.py:157-192);
+    train: every BatchNorm1d uses the batch statistics of the active rows (module.train())"""
     D, H, W = (int(v) + e for v, e in zip(list(input_shape)[::-1], extra_sp_shape))
     C = voxel_features.shape[1]
-    x = torch.zeros((batch_size, C, D, H, W))
-    mask = torch.zeros((batch_size, 1, D, H, W))
+    x = torch.zeros((batch_size, C, D, H, W), dtype=voxel_features.dtype)
+    mask = torch.zeros((batch_size, 1, D, H, W), dtype=voxel_features.dtype)
     c = torch.from_numpy(np.asarray(coors)).long()
     x[c[:, 0], :, c[:, 1], c[:, 2], c[:, 3]] = voxel_features
     mask[c[:, 0], 0, c[:, 1], c[:, 2], c[:, 3]] = 1.0
     p = prefix
-    x = F.relu(_sp_bn(sd, p + "conv_input.1.", _sp_subm(sd, p + "conv_input.0.", x, mask), mask))
+    x = F.relu(_sp_bn(sd, p + "conv_input.1.", _sp_subm(sd, p + "conv_input.0.", x, mask), mask, train=train))
     for i in range(2):
-        x = _sp_block(sd, f"{p}conv1.{i}.", x, mask)
+        x = _sp_block(sd, f"{p}conv1.{i}.", x, mask, train)
     stages = [x]
     pad4 = 0 if extra_sp_shape[0] != 0 else 1
     for name, pad in (("conv2", [1, 1, 1]), ("conv3", [1, 1, 1]), ("conv4", [pad4, 1, 1])):
         x, mask = _sp_down(sd, f"{p}{name}.0.", x, mask, [2, 2, 2], pad)
-        x = F.relu(_sp_bn(sd, f"{p}{name}.1.", x, mask))
+        x = F.relu(_sp_bn(sd, f"{p}{name}.1.", x, mask, train=train))
         for i in (3, 4):
-            x = _sp_block(sd, f"{p}{name}.{i}.", x, mask)
+            x = _sp_block(sd, f"{p}{name}.{i}.", x, mask, train)
         stages.append(x)
     x, mask = _sp_down(sd, p + "extra_conv.0.", x, mask, [2, 1, 1], [0, 0, 0])
-    x = F.relu(_sp_bn(sd, p + "extra_conv.1.", x, mask))
+    x = F.relu(_sp_bn(sd, p + "extra_conv.1.", x, mask, train=train))
     N, Cc, Dd, Hh, Ww = x.shape
     ret = x.reshape(N, Cc * Dd, Hh, Ww)
     return (ret, stages) if return_stages else ret

@@ -153,6 +153,11 @@ SIGNATURES = {
     "pn_split_polar_sectors_workspace_bytes": (_SZ, [_I, _I, _I]),
     "pn_split_polar_sectors_f32": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "pn_assemble_rows_f32": (_I, [C.POINTER(RowPiece), _I, _I, _I, _I, _P, _I, _I, _P]),
+    "pn_sparse_neighbors_transpose": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "pn_sparse_conv_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "pn_sparse_conv_wgrad_f32": (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P, _SZ, _P]),
+    "pn_sparse_from_dense_nhwc": (_I, [_P, _P, _I, _P, _P, _I, _P, _P]),
+    "pn_add_relu_f32": (_I, [_P, _P, _P, _SZ, _P]),
     "pn_contract_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "pn_softmax_f32": (_I, [_P, _P, C.c_longlong, _I, _I, _P]),
     "pn_softmax_bwd_f32": (_I, [_P, _P, _P, C.c_longlong, _I, _I, _P]),

@@ -1,0 +1,220 @@
+"""Training form of SpMiddleResNetFHD (det3d/models/backbones/scn.py:97-192 under autograd; the convolution arithmetic and its
+backward are spconv's in the reference -- third party, absent: PARITY UNPINNED, checked against fp64 autograd over the dense
+restatement ``oracle/polar_oracle.py::sp_middle_resnet_fhd(train=True)``).
+
+Forward: the inference path's index / neighbour tables (sparse_backbone.py), but every convolution is followed by a
+training-mode BatchNorm1d over the active rows (batch statistics, running-stat update) instead of the folded affine, recorded
+on the tape of autodiff.py.  Backward per convolution: data gradient = the same gathered MFMA GEMM over the transposed
+neighbour table with (Cin, Cout)-transposed weights; weight gradient = pn_sparse_conv_wgrad_f32 (csrc/sparse_bwd.hip).
+The active-site counts are read back to the host once per resolution level (five small synchronisations per step): training
+is throughput- not latency-bound, and exact row counts let BatchNorm and the element-wise kernels run on the live rows only."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import autodiff as ad
+from . import hip, ops
+from .sparse_backbone import SparseBasicBlock, SpMiddleResNetFHD
+
+
+def _pack(w_oit: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, taps) -> MFMA-packed weights of a (taps x 1) gathered convolution"""
+    lib = hip.load()
+    cout, cin, taps = w_oit.shape
+    packed = torch.empty(lib.pn_conv_packed_weight_floats(cout, cin, taps, 1, 1), dtype=torch.float32, device=w_oit.device)
+    hip.call("pn_pack_conv_weight_f32", w_oit.data_ptr(), cout, cin, taps, 1, 1, packed.data_ptr(), hip.stream())
+    return packed
+
+
+class _Level:
+    """active set of one resolution level: keys (n,), count (device int32), dims [B, D, H, W], index buffer"""
+
+    def __init__(self, index, keys, count, n, dims):
+        self.index, self.keys, self.count, self.n, self.dims = index, keys, count, n, dims
+        self.subm_nbr: Optional[torch.Tensor] = None
+        self.subm_inv: Optional[torch.Tensor] = None
+
+
+def _transpose_table(nbr: torch.Tensor, count_out: torch.Tensor, n_out: int, taps: int, in_rows: int) -> torch.Tensor:
+    inv = torch.empty((in_rows, taps), dtype=torch.int32, device=nbr.device)
+    hip.call("pn_sparse_neighbors_transpose", nbr.data_ptr(), count_out.data_ptr(), n_out, taps, in_rows, inv.data_ptr(), hip.stream())
+    return inv
+
+
+def sparse_conv(t: ad.Tape, x: ad.Node, w: ad.Node, bias: Optional[ad.Node], nbr: torch.Tensor, inv_fn, count_in: torch.Tensor, n_in: int,
+                count_out: torch.Tensor, n_out: int, cin_real: Optional[int] = None) -> ad.Node:
+    """x (n_in, cin_rows) -> (n_out, cout); w in spconv layout (Cout, kD, kH, kW, Cin); ``inv_fn()`` -> transposed table (lazy,
+    shared by the convolutions of one indice_key)"""
+    wv = w.v
+    cout, cin = wv.shape[0], wv.shape[4]
+    taps = wv.shape[1] * wv.shape[2] * wv.shape[3]
+    rows_c = x.v.shape[1]
+    w_oit = wv.reshape(cout, taps, cin).permute(0, 2, 1)
+    if rows_c != cin:   # zero-padded input channels (the MFMA loader reads 4 at a time)
+        w_oit = torch.cat([w_oit, torch.zeros((cout, rows_c - cin, taps), dtype=torch.float32, device=wv.device)], 1)
+    packed = _pack(w_oit.contiguous())
+    y = torch.zeros((n_out, cout), dtype=torch.float32, device=x.v.device)
+    hip.call("pn_sparse_conv_f32", x.v.data_ptr(), n_in, rows_c, nbr.data_ptr(), count_out.data_ptr(), n_out, taps, packed.data_ptr(), cout, None,
+             hip.ptr(None if bias is None else bias.v), ops.ACT_NONE, None, y.data_ptr(), hip.stream())
+
+    def bw(dy):
+        lib = hip.load()
+        if x.needs_grad:
+            packed_t = _pack(wv.reshape(cout, taps, cin).permute(2, 0, 1).contiguous())   # (Cin, Cout, taps)
+            dx = torch.zeros((n_in, cin), dtype=torch.float32, device=dy.device)
+            hip.call("pn_sparse_conv_f32", dy.data_ptr(), n_out, cout, inv_fn().data_ptr(), count_in.data_ptr(), n_in, taps, packed_t.data_ptr(), cin,
+                     None, None, ops.ACT_NONE, None, dx.data_ptr(), hip.stream())
+            ad.accumulate(x, dx, own=True)
+        dw = torch.empty_like(wv)
+        nbytes = lib.pn_sparse_conv_wgrad_workspace_bytes(n_out, taps, cout, rows_c)
+        ws = ops._workspace(nbytes, dy.device)
+        hip.call("pn_sparse_conv_wgrad_f32", x.v.data_ptr(), rows_c, cin, dy.data_ptr(), cout, nbr.data_ptr(), count_out.data_ptr(), n_out, taps,
+                 dw.data_ptr(), 0, ws.data_ptr(), nbytes, hip.stream())
+        ad.accumulate(w, dw, own=True)
+        if bias is not None:
+            ad.accumulate(bias, ops.channel_sum(dy.view(1, n_out, 1, cout)), own=True)
+
+    return t.new(y, bw)
+
+
+def batchnorm_rows(t: ad.Tape, x: ad.Node, bn: torch.nn.Module, gamma: ad.Node, beta: ad.Node, act: int) -> ad.Node:
+    """training-mode BatchNorm1d (+ ReLU) over the rows of x (scn.py builds BN1d(eps 1e-3, momentum 0.01))"""
+    rows, c = x.v.shape
+    y, stat = ops.batchnorm_train(x.v.view(1, rows, 1, c), gamma.v, beta.v, bn.eps, bn.momentum, bn.running_mean, bn.running_var, act=act)
+
+    def bw(dy):
+        dx, dg, db = ops.batchnorm_bwd(x.v.view(1, rows, 1, c), dy.view(1, rows, 1, c), gamma.v, beta.v, stat, act=act)
+        ad.accumulate(x, dx.view(rows, c), own=True)
+        ad.accumulate(gamma, dg, own=True)
+        ad.accumulate(beta, db, own=True)
+
+    return t.new(y.view(rows, c), bw)
+
+
+def add_relu(t: ad.Tape, a: ad.Node, b: ad.Node) -> ad.Node:
+    y = torch.empty_like(a.v)
+    hip.call("pn_add_relu_f32", a.v.data_ptr(), b.v.data_ptr(), y.data_ptr(), y.numel(), hip.stream())
+
+    def bw(dy):
+        g = ops.relu_bwd(y, dy)
+        ad.accumulate(a, g)
+        ad.accumulate(b, g)
+
+    return t.new(y, bw)
+
+
+def sp_middle_resnet_fhd_train(t: ad.Tape, net: SpMiddleResNetFHD, voxel_features: torch.Tensor, coors: torch.Tensor, batch_size: int, input_shape,
+                               prefix="") -> ad.Node:
+    """-> node holding the dense NHWC BEV map (B, H', W', 128*D'); gradients of every parameter are recorded on ``t``
+    (leaf names = prefix + state-dict names)"""
+    hip.require_device(voxel_features, coors)
+    lib = hip.load()
+    dev, st = voxel_features.device, hip.stream()
+    P: Dict[str, ad.Node] = {name: t.param(p.data, prefix + name) for name, p in net.named_parameters()}
+    V, cin = voxel_features.shape
+    D, H, W = (int(v) + e for v, e in zip(list(input_shape)[::-1], net.extra_sp_shape))
+    dims = [int(batch_size), D, H, W]
+    i4 = lambda v: (C.c_int32 * 4)(*[int(q) for q in v])   # noqa: E731
+    i3 = lambda v: (C.c_int32 * 3)(*[int(q) for q in v])   # noqa: E731
+
+    def new_index(d):
+        return torch.empty(lib.pn_sparse_index_bytes(d[0] * d[1] * d[2] * d[3]), dtype=torch.uint8, device=dev)
+
+    def neighbors(out: _Level, src: _Level, geo):
+        taps = geo[0][0] * geo[0][1] * geo[0][2]
+        nbr = torch.empty((out.n, taps), dtype=torch.int32, device=dev)
+        hip.call("pn_sparse_neighbors", out.keys.data_ptr(), out.n, out.count.data_ptr(), i4(out.dims), src.index.data_ptr(), i4(src.dims), i3(geo[0]),
+                 i3(geo[1]), i3(geo[2]), nbr.data_ptr(), st)
+        return nbr
+
+    # ---- level 0
+    coors = coors.to(torch.int32).contiguous()
+    n_dev = torch.full((1,), V, dtype=torch.int32, device=dev)
+    index = new_index(dims)
+    keys = torch.empty(V, dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    rank = torch.empty(V, dtype=torch.int32, device=dev)
+    hip.call("pn_sparse_index_from_coords", coors.data_ptr(), V, n_dev.data_ptr(), i4(dims), index.data_ptr(), keys.data_ptr(), count.data_ptr(),
+             rank.data_ptr(), st)
+    lvl = _Level(index, keys, count, int(count.item()), dims)
+    c0 = (cin + 3) // 4 * 4
+    src = voxel_features.contiguous().float()
+    if c0 != cin:
+        src = torch.cat([src, torch.zeros((V, c0 - cin), dtype=torch.float32, device=dev)], 1).contiguous()
+    feats = torch.zeros((max(lvl.n, 1), c0), dtype=torch.float32, device=dev)
+    hip.call("pn_sparse_permute_rows", src.data_ptr(), rank.data_ptr(), V, n_dev.data_ptr(), c0, feats.data_ptr(), st)
+    subm_geo = ((3, 3, 3), (1, 1, 1), (1, 1, 1))
+
+    def subm_tables(level: _Level):
+        if level.subm_nbr is None:
+            level.subm_nbr = neighbors(level, level, subm_geo)
+
+        def inv():
+            if level.subm_inv is None:
+                level.subm_inv = _transpose_table(level.subm_nbr, level.count, level.n, 27, level.n)
+            return level.subm_inv
+
+        return level.subm_nbr, inv
+
+    def subm(x, level, name, bias=True):
+        nbr, inv = subm_tables(level)
+        return sparse_conv(t, x, P[name + ".weight"], P.get(name + ".bias") if bias else None, nbr, inv, level.count, level.n, level.count, level.n)
+
+    def bn(x, mod, name, act):
+        return batchnorm_rows(t, x, mod, P[name + ".weight"], P[name + ".bias"], act)
+
+    def block(x, level, blk: SparseBasicBlock, name):
+        y = bn(subm(x, level, name + ".conv1"), blk.bn1, name + ".bn1", ops.ACT_RELU)
+        y = bn(subm(y, level, name + ".conv2"), blk.bn2, name + ".bn2", ops.ACT_NONE)
+        return add_relu(t, y, x)
+
+    def down(x, level: _Level, conv, bnm, name):
+        geo = (conv.kernel_size, conv.stride, conv.padding)
+        odims = net._out_dims(level.dims, geo)
+        ocells = odims[0] * odims[1] * odims[2] * odims[3]
+        ocap = int(min(ocells, 8 * level.n))
+        oindex = new_index(odims)
+        okeys = torch.empty(ocap, dtype=torch.int32, device=dev)
+        ocount = torch.empty(1, dtype=torch.int32, device=dev)
+        hip.call("pn_sparse_index_downsample", level.keys.data_ptr(), level.n, level.count.data_ptr(), i4(level.dims), i3(geo[0]), i3(geo[1]), i3(geo[2]),
+                 i4(odims), oindex.data_ptr(), okeys.data_ptr(), ocap, ocount.data_ptr(), st)
+        out = _Level(oindex, okeys, ocount, int(ocount.item()), odims)
+        taps = geo[0][0] * geo[0][1] * geo[0][2]
+        nbr = neighbors(out, level, geo)
+        cache = {}
+
+        def inv():
+            if "t" not in cache:
+                cache["t"] = _transpose_table(nbr, out.count, out.n, taps, level.n)
+            return cache["t"]
+
+        y = sparse_conv(t, x, P[name + ".0.weight"], None, nbr, inv, level.count, level.n, out.count, out.n)
+        return bn(y, bnm, name + ".1", ops.ACT_RELU), out
+
+    x = t.const(feats)
+    nbr0, inv0 = subm_tables(lvl)
+    x = sparse_conv(t, x, P["conv_input.0.weight"], None, nbr0, inv0, lvl.count, lvl.n, lvl.count, lvl.n)
+    x = bn(x, net.conv_input[1], "conv_input.1", ops.ACT_RELU)
+    for i, blk in enumerate(net.conv1):
+        x = block(x, lvl, blk, f"conv1.{i}")
+    for sname in ("conv2", "conv3", "conv4"):
+        seq = getattr(net, sname)
+        x, lvl = down(x, lvl, seq[0], seq[1], sname)
+        for i in (3, 4):
+            x = block(x, lvl, seq[i], f"{sname}.{i}")
+    x, lvl = down(x, lvl, net.extra_conv[0], net.extra_conv[1], "extra_conv")
+    cch = x.v.shape[1]
+    od = lvl.dims
+    dense = torch.empty((od[0], od[2], od[3], cch * od[1]), dtype=torch.float32, device=dev)
+    hip.call("pn_sparse_to_dense_nhwc", x.v.data_ptr(), lvl.keys.data_ptr(), lvl.n, lvl.count.data_ptr(), i4(od), cch, dense.data_ptr(), st)
+    last, xin = lvl, x
+
+    def bw(dy):
+        g = torch.empty((last.n, cch), dtype=torch.float32, device=dev)
+        hip.call("pn_sparse_from_dense_nhwc", dy.data_ptr(), last.keys.data_ptr(), last.n, last.count.data_ptr(), i4(od), cch, g.data_ptr(), st)
+        ad.accumulate(xin, g, own=True)
+
+    return t.new(dense, bw)
