@@ -871,6 +871,15 @@ int pn_scatter_rows_f32(const float *src, const int32_t *index, int batch, int k
                         pn_stream_t stream);
 /* torch.roll(x, shift, dims=2) of a (batch, h, w, c) map (set_transformer.py:121-124, 160-163) */
 int pn_roll_w_f32(const float *x, int batch, int h, int w, int c, int shift, float *y, pn_stream_t stream);
+/* shifted-window plumbing (sw2votev4_util.py:140-176): zero-pad (batch, h, w, c) to (batch, hp, wp, c) and roll by
+ * (-shift, -shift); pn_crop_roll_f32 is its adjoint (roll back by +shift, crop) and the forward's way back to the map */
+int pn_pad_roll_f32(const float *x, int batch, int h, int w, int hp, int wp, int c, int shift, float *y, pn_stream_t stream);
+int pn_crop_roll_f32(const float *y, int batch, int h, int w, int hp, int wp, int c, int shift, float *x, pn_stream_t stream);
+/* y[r, ch] = x[r, ch] * scale[ch] over n = rows*c elements; y = 1/max(x, lo) and its backward (the clamped per-head
+ * temperature tau of the cosine attention, sw2votev4_util.py:84) */
+int pn_scale_channels_f32(const float *x, const float *scale, size_t n, int c, float *y, pn_stream_t stream);
+int pn_recip_clamp_f32(const float *x, float lo, int n, float *y, pn_stream_t stream);
+int pn_recip_clamp_bwd_f32(const float *x, const float *dy, float lo, int n, float *dx, pn_stream_t stream);
 /* F.normalize over rows of c values (cosine attention, swin_transformer_v2.py:156-158) and its backward; inv_norm[rows] */
 int pn_l2_normalize_f32(const float *x, long long rows, int c, float eps, float *y, float *inv_norm, pn_stream_t stream);
 int pn_l2_normalize_bwd_f32(const float *y, const float *dy, const float *inv_norm, long long rows, int c, float *dx,

@@ -738,15 +738,15 @@ def swv_swin_block(sd: SD, p: str, x: Tensor, H: int, W: int, pos: Tensor, vote:
 
 
 def e2e_swv_head(sd: SD, prefix: str, x: Tensor, offset_grid: Tensor, window=7, depth=2, heads=4, iou=True,
-                 return_feat=False) -> Dict[str, Tensor]:
-    """E2ESWVoteHead.forward (e2e_swv_head.py:150-173), eval mode (BatchNorm running statistics)."""
+                 return_feat=False, train=False) -> Dict[str, Tensor]:
+    """E2ESWVoteHead.forward (e2e_swv_head.py:150-173); BatchNorm2d with the running statistics, or (train) the batch statistics"""
     p = prefix
 
     def conv(name, t, pad=1):
         return F.conv2d(t, sd[p + name + ".weight"], sd.get(p + name + ".bias"), padding=pad)
 
     def bn(name, t):
-        return _bn(sd, p + name + ".", t, False, eps=1e-5)
+        return _bn(sd, p + name + ".", t, train, eps=1e-5, momentum=0.1)
 
     centers = conv("vote_head.2", F.relu(conv("vote_head.0", x)))
     vote_cls = conv("vote_cls_head.3", F.relu(bn("vote_cls_head.1", conv("vote_cls_head.0", x))))

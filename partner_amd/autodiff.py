@@ -31,6 +31,7 @@ class Tape:
         self.nodes: List[Node] = []
         self.params: List[Node] = []
         self._views = []   # (leaf, reshaped alias) pairs
+        self._slices = []  # (leaf, row-slice alias, lo, hi)
 
     def param(self, v: torch.Tensor, name: str) -> Node:
         n = Node(v, None, name)
@@ -41,6 +42,12 @@ class Tape:
         """alias of a leaf under another shape (a Conv1d(k=1) weight used as a matrix); its gradient is routed back to the leaf"""
         alias = Node(leaf.v.view(shape), None, leaf.name)
         self._views.append((leaf, alias))
+        return alias
+
+    def sliced(self, leaf: Node, lo: int, hi: int) -> Node:
+        """alias of rows [lo, hi) of a leaf (the q / k / v thirds of a fused qkv weight); gradient routed into the leaf's rows"""
+        alias = Node(leaf.v[lo:hi], None, leaf.name)
+        self._slices.append((leaf, alias, lo, hi))
         return alias
 
     def const(self, v: torch.Tensor) -> Node:
@@ -64,6 +71,16 @@ class Tape:
             if alias.g is not None:
                 accumulate(leaf, alias.g.view(leaf.v.shape), own=alias.owned)
                 alias.g = None
+        touched = {}
+        for leaf, alias, lo, hi in self._slices:
+            if alias.g is None:
+                continue
+            if id(leaf) not in touched:
+                touched[id(leaf)] = (leaf, torch.zeros_like(leaf.v))
+            touched[id(leaf)][1][lo:hi].copy_(alias.g)
+            alias.g = None
+        for leaf, full in touched.values():
+            accumulate(leaf, full, own=True)
 
 
 def accumulate(node: Node, g: torch.Tensor, own=False) -> None:
@@ -87,9 +104,9 @@ def _i32(vals: Sequence[int]):
 
 
 # ------------------------------------------------------------------------------------------------ primitives
-def linear(t: Tape, x: Node, w: Node, b: Optional[Node], k_pad: Optional[int] = None) -> Node:
-    """y = x @ w^T + b; x (M, K) contiguous.  ``k_pad``: x already carries k_pad >= K columns (zeros past K), the weight is
-    padded to match (the MFMA loader reads 4 input channels at a time)."""
+def linear(t: Tape, x: Node, w: Node, b: Optional[Node], k_pad: Optional[int] = None, relu=False) -> Node:
+    """y = [relu](x @ w^T + b); x (M, K) contiguous.  ``k_pad``: x already carries k_pad >= K columns (zeros past K), the weight
+    is padded to match (the MFMA loader reads 4 input channels at a time)."""
     wv = w.v
     n_out, k = wv.shape
     if k_pad is not None and k_pad != k:
@@ -98,9 +115,11 @@ def linear(t: Tape, x: Node, w: Node, b: Optional[Node], k_pad: Optional[int] = 
         wv = wp
     kk = wv.shape[1]
     m = x.v.shape[0]
-    y = ops.GemmLayer(wv, None if b is None else b.v)(x.v)
+    y = ops.GemmLayer(wv, None if b is None else b.v)(x.v, act=ops.ACT_RELU if relu else ops.ACT_NONE)
 
     def bw(dy):
+        if relu:
+            dy = ops.relu_bwd(y, dy)
         dy4 = dy.view(1, m, 1, n_out)
         if x.needs_grad:
             dx = ops.ConvDgrad(wv.view(n_out, kk, 1, 1), 1, 0)(dy4).view(m, kk)
@@ -153,6 +172,35 @@ def add(t: Tape, a: Node, b: Node) -> Node:
     def bw(dy):
         accumulate(a, dy)
         accumulate(b, dy)
+
+    return t.new(y, bw)
+
+
+def view(t: Tape, x: Node, shape) -> Node:
+    """reshape of a contiguous value (no copy); the gradient is viewed back"""
+    shp = x.v.shape
+
+    def bw(dy):
+        accumulate(x, dy.view(shp))
+
+    return t.new(x.v.view(shape), bw)
+
+
+def add_broadcast(t: Tape, x: Node, b: Node, batch: int) -> Node:
+    """y[i] = x[i] + b for the ``batch`` equal leading slices of x (a per-window bias shared by every sample)"""
+    y = torch.empty_like(x.v)
+    xs, ys = x.v.view(batch, -1), y.view(batch, -1)
+    bf = b.v.view(-1)
+    for i in range(batch):
+        ops.add(xs[i], bf, out=ys[i])
+
+    def bw(dy):
+        accumulate(x, dy)
+        d = dy.view(batch, -1)
+        db = d[0].clone() if batch == 1 else ops.add(d[0], d[1])
+        for i in range(2, batch):
+            ops.add(db, d[i], out=db)
+        accumulate(b, db.view(b.v.shape), own=True)
 
     return t.new(y, bw)
 
@@ -290,6 +338,142 @@ def l2_normalize(t: Tape, x: Node, eps=1e-12) -> Node:
     def bw(dy):
         dx = torch.empty_like(dy)
         hip.call("pn_l2_normalize_bwd_f32", y.data_ptr(), dy.data_ptr(), inv.data_ptr(), rows, c, dx.data_ptr(), hip.stream())
+        accumulate(x, dx, own=True)
+
+    return t.new(y, bw)
+
+
+# ------------------------------------------------------------------------------------------------ dense NHWC maps
+def _pad4(dy: torch.Tensor) -> torch.Tensor:
+    """zero pad channels up to a multiple of 4 (the MFMA loader of the data-gradient GEMM reads 4 at a time)"""
+    c = dy.shape[-1]
+    if c % 4 == 0:
+        return dy
+    out = torch.zeros(dy.shape[:-1] + ((c + 3) // 4 * 4,), dtype=torch.float32, device=dy.device)
+    out[..., :c].copy_(dy)
+    return out
+
+
+def conv2d(t: Tape, x: Node, w: Node, b: Optional[Node], stride=1, pad=0, relu=False) -> Node:
+    """Conv2d(+bias)(+ReLU) on an NHWC map; w (Cout, Cin, k, k).  x may carry zero pad channels past Cin."""
+    wv = w.v
+    cout, cin, k, _ = wv.shape
+    layer = ops.ConvLayer(wv, stride=stride, pad=pad, shift=None if b is None else b.v, act=ops.ACT_RELU if relu else ops.ACT_NONE)
+    ct = x.v.shape[3]
+    if ct != cin:
+        layer.pad_input_channels(ct)
+    y = layer(x.v)
+
+    def bw(dy):
+        if relu:
+            dy = ops.relu_bwd(y, dy)
+        dy4 = _pad4(dy)
+        dw = ops.conv_wgrad(x.v, dy4, k, k, stride, pad, cin=cin, cout=cout)
+        accumulate(w, dw, own=True)
+        if b is not None:
+            accumulate(b, ops.channel_sum(dy4, c=cout), own=True)
+        if x.needs_grad:
+            dx = ops.ConvDgrad(wv, stride, pad)(dy4)
+            if ct != cin:
+                full = torch.zeros_like(x.v)
+                full[..., :cin].copy_(dx)
+                dx = full
+            accumulate(x, dx, own=True)
+
+    return t.new(y, bw)
+
+
+def batchnorm2d(t: Tape, x: Node, bn: torch.nn.Module, gamma: Node, beta: Node, relu=True) -> Node:
+    """training-mode BatchNorm2d (+ReLU) on an NHWC map (batch statistics; running statistics updated)"""
+    act = ops.ACT_RELU if relu else ops.ACT_NONE
+    y, stat = ops.batchnorm_train(x.v, gamma.v, beta.v, bn.eps, bn.momentum, bn.running_mean, bn.running_var, act=act)
+
+    def bw(dy):
+        dx, dg, db = ops.batchnorm_bwd(x.v, dy, gamma.v, beta.v, stat, act=act)
+        accumulate(x, dx, own=True)
+        accumulate(gamma, dg, own=True)
+        accumulate(beta, db, own=True)
+
+    return t.new(y, bw)
+
+
+def concat_channels(t: Tape, parts: Sequence[Node], width: int) -> Node:
+    """channel concatenation of NHWC maps into a ``width``-channel map (zero filled past the parts)"""
+    shp = parts[0].v.shape[:-1]
+    y = torch.zeros(shp + (width,), dtype=torch.float32, device=parts[0].v.device)
+    offs, o = [], 0
+    for p in parts:
+        c = p.v.shape[-1]
+        y[..., o:o + c].copy_(p.v)
+        offs.append((o, c))
+        o += c
+
+    def bw(dy):
+        for p, (o, c) in zip(parts, offs):
+            accumulate(p, dy[..., o:o + c].contiguous(), own=True)
+
+    return t.new(y, bw)
+
+
+def pad_roll(t: Tape, x: Node, b: int, h: int, w: int, hp: int, wp: int, c: int, shift: int) -> Node:
+    """(b*h*w, c) map -> zero-padded to hp x wp and rolled by (-shift, -shift): (b*hp*wp, c)"""
+    y = torch.empty((b * hp * wp, c), dtype=torch.float32, device=x.v.device)
+    hip.call("pn_pad_roll_f32", x.v.data_ptr(), b, h, w, hp, wp, c, shift, y.data_ptr(), hip.stream())
+
+    def bw(dy):
+        dx = torch.empty_like(x.v)
+        hip.call("pn_crop_roll_f32", dy.data_ptr(), b, h, w, hp, wp, c, shift, dx.data_ptr(), hip.stream())
+        accumulate(x, dx, own=True)
+
+    return t.new(y, bw)
+
+
+def pad_roll_raw(x: torch.Tensor, b: int, h: int, w: int, hp: int, wp: int, c: int, shift: int) -> torch.Tensor:
+    y = torch.empty((b * hp * wp, c), dtype=torch.float32, device=x.device)
+    hip.call("pn_pad_roll_f32", x.data_ptr(), b, h, w, hp, wp, c, shift, y.data_ptr(), hip.stream())
+    return y
+
+
+def crop_roll(t: Tape, y: Node, b: int, h: int, w: int, hp: int, wp: int, c: int, shift: int) -> Node:
+    """inverse plumbing: roll back by (+shift, +shift) and crop to h x w"""
+    x = torch.empty((b * h * w, c), dtype=torch.float32, device=y.v.device)
+    hip.call("pn_crop_roll_f32", y.v.data_ptr(), b, h, w, hp, wp, c, shift, x.data_ptr(), hip.stream())
+
+    def bw(dx):
+        dy = torch.empty_like(y.v)
+        hip.call("pn_pad_roll_f32", dx.data_ptr(), b, h, w, hp, wp, c, shift, dy.data_ptr(), hip.stream())
+        accumulate(y, dy, own=True)
+
+    return t.new(x, bw)
+
+
+def scale_channels(t: Tape, x: Node, s: Node) -> Node:
+    """y[r, c] = x[r, c] * s[c]"""
+    c = s.v.numel()
+    y = torch.empty_like(x.v)
+    hip.call("pn_scale_channels_f32", x.v.data_ptr(), s.v.data_ptr(), x.v.numel(), c, y.data_ptr(), hip.stream())
+
+    def bw(dy):
+        if x.needs_grad:
+            dx = torch.empty_like(dy)
+            hip.call("pn_scale_channels_f32", dy.data_ptr(), s.v.data_ptr(), dy.numel(), c, dx.data_ptr(), hip.stream())
+            accumulate(x, dx, own=True)
+        prod = torch.empty_like(dy)
+        hip.call("pn_mul_f32", dy.data_ptr(), x.v.data_ptr(), prod.data_ptr(), dy.numel(), hip.stream())
+        accumulate(s, ops.channel_sum(prod.view(1, -1, 1, c)).view(s.v.shape), own=True)
+
+    return t.new(y, bw)
+
+
+def recip_clamp(t: Tape, x: Node, lo: float) -> Node:
+    """y = 1 / max(x, lo) on a small parameter vector"""
+    n = x.v.numel()
+    y = torch.empty_like(x.v)
+    hip.call("pn_recip_clamp_f32", x.v.data_ptr(), float(lo), n, y.data_ptr(), hip.stream())
+
+    def bw(dy):
+        dx = torch.empty_like(x.v)
+        hip.call("pn_recip_clamp_bwd_f32", x.v.data_ptr(), dy.contiguous().data_ptr(), float(lo), n, dx.data_ptr(), hip.stream())
         accumulate(x, dx, own=True)
 
     return t.new(y, bw)

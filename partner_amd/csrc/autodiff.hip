@@ -273,6 +273,47 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
   for (int k = lane; k < c; k += 64) dx[row * c + k] = inv * (dy[row * c + k] - y[row * c + k] * d);   // norm above eps (clamped rows: dx = dy / eps, not handled)
 }
 
+
+// window-attention plumbing of the shifted-window stage (sw2votev4_util.py:140-176): zero-pad a (B, H, W, C) map to (B, Hp, Wp, C) and
+// roll it by (-shift, -shift); crop_roll is the adjoint (roll by (+shift, +shift), crop to H x W) and also the forward's way back
+__global__ void pad_roll_kernel(const float* __restrict__ x, int B, int H, int W, int Hp, int Wp, int c, int shift, float* __restrict__ y) {
+  const long long total = (long long)B * Hp * Wp * c;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    long long r = i / c;
+    const int j = (int)(r % Wp); r /= Wp;
+    const int ii = (int)(r % Hp);
+    const int b = (int)(r / Hp);
+    const int h = (ii + shift) % Hp, w = (j + shift) % Wp;
+    y[i] = (h < H && w < W) ? x[(((size_t)b * H + h) * W + w) * c + ch] : 0.f;
+  }
+}
+__global__ void crop_roll_kernel(const float* __restrict__ y, int B, int H, int W, int Hp, int Wp, int c, int shift, float* __restrict__ x) {
+  const long long total = (long long)B * H * W * c;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    long long r = i / c;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int b = (int)(r / H);
+    const int ii = ((h - shift) % Hp + Hp) % Hp, j = ((w - shift) % Wp + Wp) % Wp;
+    x[i] = y[(((size_t)b * Hp + ii) * Wp + j) * c + ch];
+  }
+}
+// y[r, c] = x[r, c] * s[c]
+__global__ void scale_channels_kernel(const float* __restrict__ x, const float* __restrict__ s, size_t n, int c, float* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = x[i] * s[i % c];
+}
+// y = 1 / max(x, lo);  dx = x > lo ? -dy / x^2 : 0   (the clamped temperature of the cosine attention, sw2votev4_util.py:84)
+__global__ void recip_clamp_kernel(const float* __restrict__ x, float lo, int n, float* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = 1.f / fmaxf(x[i], lo);
+}
+__global__ void recip_clamp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float lo, int n, float* __restrict__ dx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = x[i] > lo ? -dy[i] / (x[i] * x[i]) : 0.f;
+}
+
 unsigned grid_for(long long total, int threads = 256) { return (unsigned)std::min<long long>(65535, (total + threads - 1) / threads); }
 
 }  // namespace
@@ -394,6 +435,37 @@ int pn_l2_normalize_bwd_f32(const float* y, const float* dy, const float* inv_no
   PN_REQUIRE(y && dy && inv_norm && dx && rows >= 1 && c >= 1, "l2_normalize_bwd: bad arguments");
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, pn::S(stream), y, dy, inv_norm, rows, c, dx);
   return pn::check_launch("l2norm_bwd_kernel");
+}
+
+int pn_pad_roll_f32(const float* x, int batch, int h, int w, int hp, int wp, int c, int shift, float* y, pn_stream_t stream) {
+  PN_REQUIRE(x && y && batch >= 1 && h >= 1 && w >= 1 && hp >= h && wp >= w && c >= 1 && shift >= 0, "pad_roll: bad arguments");
+  hipLaunchKernelGGL(pad_roll_kernel, dim3(grid_for((long long)batch * hp * wp * c)), dim3(256), 0, pn::S(stream), x, batch, h, w, hp, wp, c, shift, y);
+  return pn::check_launch("pad_roll_kernel");
+}
+
+int pn_crop_roll_f32(const float* y, int batch, int h, int w, int hp, int wp, int c, int shift, float* x, pn_stream_t stream) {
+  PN_REQUIRE(x && y && batch >= 1 && h >= 1 && w >= 1 && hp >= h && wp >= w && c >= 1 && shift >= 0, "crop_roll: bad arguments");
+  hipLaunchKernelGGL(crop_roll_kernel, dim3(grid_for((long long)batch * h * w * c)), dim3(256), 0, pn::S(stream), y, batch, h, w, hp, wp, c, shift, x);
+  return pn::check_launch("crop_roll_kernel");
+}
+
+int pn_scale_channels_f32(const float* x, const float* scale, size_t n, int c, float* y, pn_stream_t stream) {
+  PN_REQUIRE(x && scale && y && c >= 1, "scale_channels: bad arguments");
+  if (n == 0) return PN_OK;
+  hipLaunchKernelGGL(scale_channels_kernel, dim3(grid_for((long long)n)), dim3(256), 0, pn::S(stream), x, scale, n, c, y);
+  return pn::check_launch("scale_channels_kernel");
+}
+
+int pn_recip_clamp_f32(const float* x, float lo, int n, float* y, pn_stream_t stream) {
+  PN_REQUIRE(x && y && n >= 1, "recip_clamp: bad arguments");
+  hipLaunchKernelGGL(recip_clamp_kernel, dim3(pn::cdiv(n, 256)), dim3(256), 0, pn::S(stream), x, lo, n, y);
+  return pn::check_launch("recip_clamp_kernel");
+}
+
+int pn_recip_clamp_bwd_f32(const float* x, const float* dy, float lo, int n, float* dx, pn_stream_t stream) {
+  PN_REQUIRE(x && dy && dx && n >= 1, "recip_clamp_bwd: bad arguments");
+  hipLaunchKernelGGL(recip_clamp_bwd_kernel, dim3(pn::cdiv(n, 256)), dim3(256), 0, pn::S(stream), x, dy, lo, n, dx);
+  return pn::check_launch("recip_clamp_bwd_kernel");
 }
 
 }  // extern "C"

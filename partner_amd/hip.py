@@ -158,6 +158,11 @@ SIGNATURES = {
     "pn_sparse_conv_wgrad_f32": (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P, _SZ, _P]),
     "pn_sparse_from_dense_nhwc": (_I, [_P, _P, _I, _P, _P, _I, _P, _P]),
     "pn_add_relu_f32": (_I, [_P, _P, _P, _SZ, _P]),
+    "pn_pad_roll_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "pn_crop_roll_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "pn_scale_channels_f32": (_I, [_P, _P, _SZ, _I, _P, _P]),
+    "pn_recip_clamp_f32": (_I, [_P, _F, _I, _P, _P]),
+    "pn_recip_clamp_bwd_f32": (_I, [_P, _P, _F, _I, _P, _P]),
     "pn_contract_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "pn_softmax_f32": (_I, [_P, _P, C.c_longlong, _I, _I, _P]),
     "pn_softmax_bwd_f32": (_I, [_P, _P, _P, C.c_longlong, _I, _I, _P]),

@@ -195,3 +195,60 @@ def test_setblock_training_step_matches_fp64_autograd(dev, golden, shift):
     assert not bad, bad
     # training-mode BatchNorm1d updated its running statistics
     assert not torch.equal(blk.attns.range_attn.pos_embedding_cart[1].running_mean.cpu(), rm0)
+
+
+def test_e2e_swv_head_training_forward_backward_matches_fp64_autograd(dev):
+    """reduced E2ESWVoteHead (32 input channels, 12 x 10 map -> 2 x 2 windows of 7 x 7 after padding, one plain and one shifted
+    block): every output, the input gradient and the gradient of every parameter against fp64 autograd over the oracle (parity
+    unpinned by the reference).  Outputs 2e-4, gradients 2e-3 of each tensor's max (floored for vanishing ones)."""
+    import partner_amd as P
+    from oracle import polar_oracle as O
+    from partner_amd import autodiff as ad
+    from partner_amd.swv_head_train import e2e_swv_head_train
+    from tools.extra_configs_cfg import waymo_head_cfg
+    cfg = waymo_head_cfg()
+    cfg["in_channels"] = 32
+    cfg["GT_PROCESSOR_CONFIG"]["grid_size"] = [80, 96, 40]
+    head = P.build_bbox_head(cfg)
+    grid = head.offset_grid.clone()
+    synth.load_filled(head, base_seed=77)
+    with torch.no_grad():
+        head.offset_grid.copy_(grid)
+        for blk in head.layer.layers[0].blocks:      # temperatures on both sides of the 0.01 clamp
+            blk.attn.tau.copy_(torch.tensor([0.5, 0.005, 1.5, 0.2]).view(1, 4, 1, 1))
+    sd64 = {k: v.detach().double().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "num_batches" not in k
+                                                          and k not in ("offset_grid", "xy_offset"))
+            for k, v in head.state_dict().items()}
+    B, H, W, cin = 2, 12, 10, 32
+    rng = np.random.default_rng(9)
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    x64 = x.double().requires_grad_()
+    ref = O.e2e_swv_head(sd64, "", x64, grid.double(), window=7, depth=2, heads=4, iou=True, train=True)
+    ref["boxes"] = torch.cat([ref["reg"], ref["height"], ref["dim"], ref["rot"]], 1)
+    names = ["pred_centers", "pred_vote_cls", "hm", "boxes", "iou"]
+    gys = {k: torch.from_numpy(rng.standard_normal(tuple(ref[k].shape)).astype(np.float32)) for k in names}
+    torch.autograd.backward([ref[k] for k in names], [gys[k].double() for k in names])
+
+    head = head.to(dev).train()
+    t = ad.Tape()
+    xn = t.input(x.permute(0, 2, 3, 1).contiguous().to(dev))
+    out = e2e_swv_head_train(t, head, xn, prefix="")
+    for k in names:
+        assert rel(out[k].v.permute(0, 3, 1, 2), ref[k]) < 2e-4, k
+    for k in names:   # one backward sweep over the shared tape: seed every output, then run
+        ad.accumulate(out[k], gys[k].permute(0, 2, 3, 1).contiguous().to(dev))
+    t.backward(out["hm"], torch.zeros_like(out["hm"].v))
+    assert rel(xn.g.permute(0, 3, 1, 2), x64.grad) < 2e-3
+    got = {n.name: n.g for n in t.params}
+    scale = float(np.median([float(p.grad.abs().max()) for p in sd64.values() if p.requires_grad and p.grad is not None]))
+    worst = {}
+    for name, p64 in sd64.items():
+        if not p64.requires_grad:
+            continue
+        assert p64.grad is not None and got[name] is not None, name
+        worst[name] = float((got[name].double().cpu() - p64.grad).abs().max() / max(float(p64.grad.abs().max()), 5e-3 * scale))
+    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    assert not bad, bad
+    # the clamped temperature (tau = 0.005 < 0.01) gets no gradient, the others do
+    gt = got["layer.layers.0.blocks.0.attn.tau"].view(-1).cpu()
+    assert float(gt[1]) == 0.0 and float(gt[0].abs()) > 0
