@@ -61,8 +61,10 @@ class Tape:
         self.nodes.append(n)
         return n
 
-    def backward(self, root: Node, grad: torch.Tensor) -> None:
-        accumulate(root, grad)
+    def backward(self, root: Optional[Node] = None, grad: Optional[torch.Tensor] = None) -> None:
+        """reverse sweep; ``root`` / ``grad`` seed one output (further outputs may have been seeded with ``accumulate``)"""
+        if root is not None:
+            accumulate(root, grad)
         for n in reversed(self.nodes):
             if n.g is not None:
                 n.bw(n.g)
@@ -477,3 +479,46 @@ def recip_clamp(t: Tape, x: Node, lo: float) -> Node:
         accumulate(x, dx, own=True)
 
     return t.new(y, bw)
+
+
+def transpose_hw(t: Tape, x: Node, b: int, h: int, w: int, c: int) -> Node:
+    """(b, h, w, c) -> (b, w, h, c) (the reference's permute between the azimuth-major BEV map and the range-major token order,
+    voxelnet.py:210-221)"""
+    y = torch.empty((b, w, h, c), dtype=torch.float32, device=x.v.device)
+    hip.call("pn_transpose_hw_f32", x.v.data_ptr(), b, h, w, c, y.data_ptr(), hip.stream())
+
+    def bw(dy):
+        dx = torch.empty(x.v.shape, dtype=torch.float32, device=dy.device)
+        hip.call("pn_transpose_hw_f32", dy.data_ptr(), b, w, h, c, dx.data_ptr(), hip.stream())
+        accumulate(x, dx, own=True)
+
+    return t.new(y, bw)
+
+
+def conv_transpose2d(t: Tape, x: Node, w: Node) -> Node:
+    """ConvTranspose2d(kernel = stride, no bias) of the RPN deblocks (rpn.py:80-110): weight (Cin, Cout, k, k), k in {1, 2}"""
+    wv = w.v
+    cin, cout, k, _ = wv.shape
+    if k == 1:   # a 1x1 convolution with the transposed weight
+        wt = wv.permute(1, 0, 2, 3).contiguous()
+        y = ops.ConvLayer(wt, stride=1, pad=0)(x.v)
+
+        def bw1(dy):
+            dw = ops.conv_wgrad(x.v, dy, 1, 1, 1, 0)                      # (Cout, Cin, 1, 1)
+            accumulate(w, dw.permute(1, 0, 2, 3).contiguous(), own=True)
+            if x.needs_grad:
+                accumulate(x, ops.ConvDgrad(wt, 1, 0)(dy), own=True)
+
+        return t.new(y, bw1)
+    if k != 2:
+        raise hip.PartnerHipError("conv_transpose2d: only kernel = stride in {1, 2} has a HIP kernel")
+    y = ops.ConvLayer(wv, deconv2x2=True)(x.v)
+
+    def bw2(dy):
+        # the transposed convolution's weight gradient is the gradient of the stride-2 convolution dy -> x with the same tensor
+        dw = ops.conv_wgrad(dy, x.v, 2, 2, 2, 0)                          # (Cin, Cout, 2, 2)
+        accumulate(w, dw, own=True)
+        if x.needs_grad:
+            accumulate(x, ops.ConvLayer(wv, stride=2, pad=0)(dy), own=True)
+
+    return t.new(y, bw2)
