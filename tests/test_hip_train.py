@@ -440,9 +440,11 @@ def test_train_step_bitwise_reproducible(dev, golden):
                 assert torch.equal(ref[k], cur[k]), k
 
 
-def test_full_c2_train_step_grads_vs_fp64_autograd(dev):
-    """BASELINE size: the full nuScenes polar-pillar model (5.6 M parameters, 512 x 512 grid), one 30k-point sweep, targets from 40
-    boxes -- loss and EVERY parameter gradient of the HIP training step.
+@pytest.mark.parametrize("batch", [1, 4])
+def test_full_c2_train_step_grads_vs_fp64_autograd(dev, batch):
+    """BASELINE size: the full nuScenes polar-pillar model (5.6 M parameters, 512 x 512 grid), 30k-point sweeps, targets from 40
+    boxes per sample -- loss and EVERY parameter gradient of the HIP training step, at one sample and at the config's own
+    per-GPU batch of 4 (BASELINE configs[2]; BatchNorm statistics then span the four samples).
 
     At this depth fp32 gradients are ill-conditioned (BatchNorm backward subtracts the large uniform part of the focal-loss
     gradient; a ReLU whose pre-activation is ~1e-7 flips between implementations and, under a sparse box-loss gradient, moves a
@@ -460,12 +462,16 @@ def test_full_c2_train_step_grads_vs_fp64_autograd(dev):
     synth.load_filled(m, base_seed=0)
     m = m.to(dev).eval()
     base = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
-    sw = synth.synth_sweep_polar(30000, seed=3)
-    boxes, classes = synth.synth_gt_boxes(40, seed=78)
-    hm, ind, mask, cat, anno = O.assign_heatmap_polar(boxes, classes, 10, 500, 4, 0.1, 2, False, synth.NUSC_VOXEL, synth.NUSC_RANGE, [128, 128])
+    sws = [synth.synth_sweep_polar(30000, seed=3 + b) for b in range(batch)]
+    sw = np.concatenate(sws, 0)
+    tgs = []
+    for b in range(batch):
+        boxes, classes = synth.synth_gt_boxes(40, seed=78 + b)
+        tgs.append(O.assign_heatmap_polar(boxes, classes, 10, 500, 4, 0.1, 2, False, synth.NUSC_VOXEL, synth.NUSC_RANGE, [128, 128]))
+    hm, ind, mask, cat, anno = (np.stack([t[i] for t in tgs], 0) for i in range(5))
     torch.set_num_threads(16)
     cfg = model_cfg(synth.NUSC_RANGE, synth.NUSC_VOXEL)
-    gi = O.with_batch_index([O.grid_index(sw, synth.NUSC_RANGE, synth.NUSC_VOXEL)])
+    gi = O.with_batch_index([O.grid_index(s_, synth.NUSC_RANGE, synth.NUSC_VOXEL) for s_ in sws])
     gsz = O.grid_size_of(synth.NUSC_RANGE, synth.NUSC_VOXEL)
     rd = cfg["reader"]
 
@@ -473,21 +479,22 @@ def test_full_c2_train_step_grads_vs_fp64_autograd(dev):
         sd = {k: (v.to(dtype).requires_grad_("running" not in k) if v.dtype == torch.float32 else v.clone()) for k, v in base.items()}
         feats, unq, _ = O.dynamic_pfn(sd, "reader.", sw.astype(np.float64 if dtype == torch.float64 else np.float32), gi, gsz, rd["voxel_size"],
                                       rd["pc_range"])
-        x1 = O.scatter_canvas(feats, unq, 1, gsz)
+        x1 = O.scatter_canvas(feats, unq, batch, gsz)
         x2 = O.rpn(sd, "neck.", x1, training=True, **{k: v for k, v in cfg["neck"].items() if k != "type"})
         pos = O.polar_pos_encoding(cfg["bbox_head"]["voxel_generator"], 4).to(dtype)
         preds = O.center_head_single(sd, "bbox_head.", x2, cfg["bbox_head"]["common_heads"], pos_encoding=pos)
-        tgt = [torch.from_numpy(hm[None]).to(dtype), torch.from_numpy(ind[None]), torch.from_numpy(mask[None]), torch.from_numpy(cat[None]),
-               torch.from_numpy(anno[None]).to(dtype)]
+        tgt = [torch.from_numpy(hm).to(dtype), torch.from_numpy(ind), torch.from_numpy(mask), torch.from_numpy(cat),
+               torch.from_numpy(anno).to(dtype)]
         loss = O.center_loss(preds, *tgt, code_weights=[1.5, 1.5, 1.0, 1.0, 1.0, 1.0, 0.5, 0.5, 1.0, 1.0], weight=0.5)
         loss["det_loss"].backward()
         return float(loss["det_loss"].detach()), {k: v.grad for k, v in sd.items() if getattr(v, "grad", None) is not None}
 
     loss64, g64 = oracle_grads(torch.float64)
-    loss32, g32 = oracle_grads(torch.float32)
+    loss32, g32 = oracle_grads(torch.float32) if batch == 1 else (None, None)   # the fp32-oracle accuracy class is established at one sample
     ts = PolarPillarTrainStep(m, total_steps=100)
-    tg = ops.CenterLossTargets(*(torch.from_numpy(a[None]) for a in (hm, ind, mask, cat, anno)), dev)
-    out = ts.forward_backward(torch.from_numpy(sw).to(dev), torch.tensor([0, 30000], dtype=torch.int32, device=dev), 1, tg)
+    tg = ops.CenterLossTargets(*(torch.from_numpy(a) for a in (hm, ind, mask, cat, anno)), dev)
+    offs = torch.tensor([30000 * b for b in range(batch + 1)], dtype=torch.int32, device=dev)
+    out = ts.forward_backward(torch.from_numpy(sw).to(dev), offs, batch, tg)
     assert abs(float(out[0]) - loss64) < 1e-5 * abs(loss64)
     gscale = max(float(v.abs().max()) for v in g64.values())
     e_hip, e_o32 = [], []
@@ -501,11 +508,13 @@ def test_full_c2_train_step_grads_vs_fp64_autograd(dev):
             assert float(g.abs().max()) < 1e-4 * gscale, name
             continue
         e_hip.append(float((g.cpu().double() - t).abs().max() / sc))
-        e_o32.append(float((g32[name].double() - t).abs().max() / sc))
+        if g32 is not None:
+            e_o32.append(float((g32[name].double() - t).abs().max() / sc))
     e_hip, e_o32 = np.array(e_hip), np.array(e_o32)
     assert len(e_hip) > 90
     assert np.median(e_hip) < 5e-3 and np.quantile(e_hip, 0.95) < 2e-2 and e_hip.max() < 6e-2, (np.median(e_hip), np.quantile(e_hip, 0.95), e_hip.max())
-    assert np.median(e_hip) < 3 * np.median(e_o32) + 1e-3, (np.median(e_hip), np.median(e_o32))
+    if g32 is not None:
+        assert np.median(e_hip) < 3 * np.median(e_o32) + 1e-3, (np.median(e_hip), np.median(e_o32))
 
 
 def test_train_step_plain_center_head_vs_oracle_autograd(dev, golden):
