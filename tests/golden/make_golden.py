@@ -455,10 +455,28 @@ def gen_setblock():
                        H_sp=H, W_sp=1, H=4, W=8, drop=0.1, attn_drop=0.1, drop_path=0.1, norm_layer=torch.nn.LayerNorm,
                        pos=pos, shift=shift).eval()
         synth.load_filled(blk, base_seed=60 + int(shift))
+        # the key-point rows the reference picked: SectorAttention receives the gathered key-point positions (s_pos) next to the
+        # full position map (x_pos, rolled for the shifted block); every BEV cell has its own position, so matching them back gives
+        # the reference's top_idx, including its resolution of the ties among zero scores (unstable argsort, set_transformer.py:143)
+        seen = {}
+        hook = blk.attns.sector_attn1.register_forward_pre_hook(lambda mod, args: seen.update(s_pos=args[2].clone(), x_pos=args[3].clone()))
         with torch.no_grad():
             y = blk(x)
+            xn = blk.attns.norm1(x).view(2, H, W, C)
+        hook.remove()
         tag = "shift" if shift else "noshift"
         out[f"y_{tag}"] = y.numpy()
+        s_pos, x_pos = seen["s_pos"], seen["x_pos"].expand(2, -1, -1, -1)                 # (B, K, W, 2), (B, H, W, 2)
+        match = (s_pos[:, :, None, :, :] == x_pos[:, None, :, :, :]).all(-1)             # (B, K, H, W)
+        assert bool((match.sum(2) == 1).all())
+        out[f"top_{tag}"] = match.float().argmax(2).numpy().astype(np.int16)             # (B, K, W) rows in the (rolled) frame
+        # how tie-heavy the case is: columns with fewer than K positive strict-interior local maxima have to fill up from the zeros
+        if shift:
+            xn = torch.roll(xn, -4, 2)
+        sc = xn.mean(3)                                                                   # (B, H, W)
+        inner = sc[:, 1:-1]
+        lm = (inner >= sc[:, :-2]) & (inner >= sc[:, 2:]) & (inner > 0)
+        out[f"tie_cols_{tag}"] = np.array(int((lm.sum(1) < 4).sum()))
         out[f"state_keys_{tag}"] = np.array(list(blk.state_dict().keys()))
     save("setblock_small.npz", **out)
     # full-size Waymo-shape block pair (voxelnet.py:192-199): probes + checksums only

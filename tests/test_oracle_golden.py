@@ -377,6 +377,12 @@ def test_setblock_small(golden, shift):
     sd = filled_sd(shapes, 60 + int(shift))
     y = O.set_block(sd, "", torch.from_numpy(g["x"]), torch.from_numpy(g["pos"]), (16, 32), heads=4, shift=shift)
     close(y, g[f"y_{tag}"], 1e-4, 1e-4)
+    # the key-point rows the reference's CPU run selected, including how it resolved the ties among zero scores (the fixture is
+    # tie-heavy: tie_cols of its 64 columns hold fewer than 4 positive local maxima)
+    pos = torch.from_numpy(g["pos"])[..., :2].repeat(2, 1, 1, 1)
+    _, top = O.set_attention(sd, "attns.", torch.from_numpy(g["x"]), pos, (16, 32), 4, 4, 8, shift, return_topidx=True)
+    assert int(g[f"tie_cols_{tag}"]) >= 10
+    np.testing.assert_array_equal(top.numpy(), g[f"top_{tag}"].astype(np.int64))
 
 
 def test_setblock_full_size(golden):
