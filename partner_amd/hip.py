@@ -163,6 +163,7 @@ SIGNATURES = {
     "pn_scale_channels_f32": (_I, [_P, _P, _SZ, _I, _P, _P]),
     "pn_recip_clamp_f32": (_I, [_P, _F, _I, _P, _P]),
     "pn_recip_clamp_bwd_f32": (_I, [_P, _P, _F, _I, _P, _P]),
+    "pn_global_augment_f32": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _P, _P]),
     "pn_contract_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "pn_softmax_f32": (_I, [_P, _P, C.c_longlong, _I, _I, _P]),
     "pn_softmax_bwd_f32": (_I, [_P, _P, _P, C.c_longlong, _I, _I, _P]),

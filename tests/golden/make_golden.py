@@ -760,7 +760,32 @@ def gen_stream():
     save("stream.npz", **out)
 
 
+# ----------------------------------------------------------------------------- next-4 global augmentation
+def gen_augment():
+    """the reference's own augmentation functions under seeded np.random: inputs, outputs, and the seeds (the host side of the
+    port re-draws from the same seed in the same order)"""
+    from det3d.core.sampler import preprocess as prep
+    out = {}
+    rng = np.random.default_rng(7)
+    for case, (cols, std) in enumerate(((9, 0.0), (7, [0.5, 0.5, 0.2]), (9, 0.3), (7, 0.0))):
+        pts = (rng.standard_normal((1200, 5)) * np.array([20, 20, 2, 1, 0.1])).astype(np.float32)
+        boxes = rng.standard_normal((37, cols)).astype(np.float32)
+        boxes[:, :2] *= 25
+        boxes[:, 3:6] = np.abs(boxes[:, 3:6]) + 0.5
+        out[f"pts_{case}"], out[f"boxes_{case}"] = pts.copy(), boxes.copy()
+        seed = 100 + case
+        np.random.seed(seed)
+        b, p = prep.random_flip_both(boxes.copy(), pts.copy())
+        b, p = prep.global_rotation(b, p, rotation=[-0.78539816, 0.78539816])
+        b, p = prep.global_scaling_v2(b, p, 0.95, 1.05)
+        b, p = prep.global_translate_(b, p, noise_translate_std=std)
+        out[f"pts_out_{case}"], out[f"boxes_out_{case}"] = p, b
+        out[f"seed_{case}"] = np.array(seed)
+        out[f"std_{case}"] = np.asarray(std, np.float64).reshape(-1)
+    save("augment.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static", "seg_head", "e2e", "stream"]
+    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static", "seg_head", "e2e", "stream", "augment"]
     for w in which:
         globals()["gen_" + w]()
