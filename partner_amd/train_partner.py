@@ -144,6 +144,15 @@ class PartnerTrainStep:
                 pc.plan = None
         return total_norm
 
+    def sync_initial_params(self):
+        """rank 0's parameters (and floating-point buffers: BatchNorm running statistics) to every rank, once before the first step
+        -- what DistributedDataParallel's constructor does in the reference (det3d/torchie/apis/train.py:330-336)"""
+        from .dist_utils import broadcast_flat_params
+        broadcast_flat_params(self.ps.flat_p)
+        for b in self.model.buffers():
+            if b.dtype.is_floating_point:
+                broadcast_flat_params(b)
+
     def step(self, example):
         import torch.distributed as dist
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1

@@ -182,3 +182,67 @@ def test_partner_training_step_full_size_waymo_config(dev):
     ms = (time.perf_counter() - t0) / 3 * 1e3
     print(f"PARTNER bs=2 training iteration: {ms:.1f} ms")
     assert float(l1["det_loss"][0]) < float(l0["det_loss"][0])
+
+
+def _ddp_rank(rank, world, port, q):
+    """one rank of a 2-rank PartnerTrainStep.step (both ranks on cuda:0, gloo transport): rank-specific start, rank-specific clouds"""
+    import os
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from partner_amd import dist_utils as D
+    from partner_amd.train_partner import PartnerTrainStep
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    assert D.init("gloo") is True
+    m, _, _ = build(dev)
+    m = m.to(dev).train()
+    step = PartnerTrainStep(m, total_steps=100, drop=0.0, attn_drop=0.0, drop_path=0.0)
+    if rank == 1:
+        with torch.no_grad():
+            step.ps.flat_p.mul_(1.5)
+    step.sync_initial_params()
+    start = step.ps.flat_p.clone()
+    ex = make_example(dev, seed=3 + 10 * rank)[0]
+    ex["global_box"] = make_example(dev, seed=3)[0]["global_box"]     # the same boxes: the ranks' matched counts (num_boxes) agree
+    losses = step.step(ex)
+    q.put((rank, start.cpu().numpy(), step.ps.flat_p.cpu().numpy(), float(losses["det_loss"][0])))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_partner_two_rank_step_matches_single_process_mean(dev):
+    """world size 2: equal parameters on both ranks after sync_initial_params and after the step, equal to ONE process applying
+    the mean of the two ranks' gradients with the same optimizer step (the reference averages gradients over ranks, dist_utils.py:17-28)"""
+    import socket
+    import torch.multiprocessing as mp
+    from partner_amd.train_partner import PartnerTrainStep
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    assert res[0][3] != res[1][3]                                       # the ranks really saw different clouds
+    m, _, _ = build(dev)
+    m = m.to(dev).train()
+    step = PartnerTrainStep(m, total_steps=100, drop=0.0, attn_drop=0.0, drop_path=0.0)
+    np.testing.assert_array_equal(step.ps.flat_p.cpu().numpy(), res[0][1])
+    gb = make_example(dev, seed=3)[0]["global_box"]
+    total = None
+    for rank in range(2):
+        ex = make_example(dev, seed=3 + 10 * rank)[0]
+        ex["global_box"] = gb
+        step.forward_backward(ex, grad_scale=0.5)
+        total = step.ps.flat_g.clone() if total is None else total + step.ps.flat_g
+    step.ps.flat_g.copy_(total)
+    step.optimizer_step()
+    np.testing.assert_allclose(step.ps.flat_p.cpu().numpy(), res[0][2], rtol=2e-5, atol=2e-7)
