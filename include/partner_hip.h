@@ -650,8 +650,8 @@ int pn_sparse_to_dense_nhwc(const float *feats, const uint32_t *keys, int capaci
  *                                  transposed weights -- a gather, no atomics
  *   pn_sparse_conv_wgrad_f32       dw[co][tap][ci] (+)= sum_i dout[i][co] * in[nbr[i][tap]][ci]  (spconv weight layout
  *                                  (Cout, kD, kH, kW, Cin)); `cin` = row width of `in` (a multiple of 4), cin_real <= cin the
- *                                  channels kept; gathered im2col matrix + one MFMA wgrad GEMM, fixed reduction order.  Rows of
- *                                  `dout` past *n_out must be finite (they meet zero rows of the gathered matrix)
+ *                                  channels kept; the MFMA weight-gradient kernel of pn_conv2d_wgrad_f32 with the neighbour
+ *                                  table in its loader, row slices reduced in slice order (no atomics)
  *   pn_sparse_from_dense_nhwc      gradient of pn_sparse_to_dense_nhwc: gathers (B, H, W, C*D) back to the active rows
  *   pn_add_relu_f32                out = max(a + b, 0)  (SparseBasicBlock's residual join, scn.py:84-95)
  */

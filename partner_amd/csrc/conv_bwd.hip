@@ -60,12 +60,16 @@ struct WgradArgs {
   int cin_pad, cout_pad;
   unsigned in_bytes, dy_bytes;
   FastDiv div_ohw, div_ow;
+  // gather mode (sparse convolution, scn.py:97-192 under autograd): GEMM k index m = output site, tap t reads input row
+  // nbr[m * taps + t] (-1: inactive); n_valid = device count of live output sites
+  const int* nbr;
+  const int* n_valid;
 };
 
 constexpr int WK = 32;  // pixels per K step
 
 
-template <int TM, int TN>
+template <int TM, int TN, bool GATHER>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int BM = TM * 64, BN = TN * 64;
   constexpr int LDA = BM + 8, LDB = BN + 8;
@@ -91,8 +95,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int kh = tap / a.KW, kw = tap - kh * a.KW;
   const int ci0 = cit * BM, co0 = cot * BN;
   const int m_begin = split * a.m_per_split;
-  const int m_end = min(a.M, m_begin + a.m_per_split);
-  const int nsteps = (m_end - m_begin + WK - 1) / WK;
+  int m_end = min(a.M, m_begin + a.m_per_split);
+  if constexpr (GATHER) m_end = min(m_end, *a.n_valid);
+  const int nsteps = m_end > m_begin ? (m_end - m_begin + WK - 1) / WK : 0;
 
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.dy_bytes, 0x00020000);
@@ -112,6 +117,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     for (int j = 0; j < A_PER_T; ++j) {
       // (b, oh, ow) of output pixel m by multiply-shift division: branch-free, no per-row state
       const unsigned m = (unsigned)(ld_m + pa + A_ROWS * j);
+      if constexpr (GATHER) {
+        const int idx = ((int)m < m_end) ? a.nbr[(size_t)m * (a.KH * a.KW) + tap] : -1;
+        const unsigned vo = (a_cok && idx >= 0) ? ((unsigned)idx * (unsigned)a.in_ps + a_chan) * 4u : 0xffffffffu;
+        ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, 0, 0));
+        continue;
+      }
       const unsigned b = fast_div(m, a.div_ohw);
       const unsigned rem = m - b * (unsigned)(a.OH * a.OW);
       const unsigned oh = fast_div(rem, a.div_ow);
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
 // sum the pixel slices in slice order, write torch layout (Cout, Cin, KH, KW)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int taps, int cin, int cout, int cin_pad,
-                                    int cout_pad, float* __restrict__ dw, int accumulate) {
+                                    int cout_pad, float* __restrict__ dw, int accumulate, int tap_major = 0) {
   const size_t total = (size_t)taps * cin * cout;
   const size_t slice = (size_t)taps * cin_pad * cout_pad;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -218,7 +229,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
     }
     for (; k < splits; ++k) s0 += p[(size_t)k * slice];
     const float s = (s0 + s1) + (s2 + s3);
-    float* d = dw + ((size_t)co * cin + ci) * taps + tap;
+    // torch (Cout, Cin, KH, KW) or spconv (Cout, taps, Cin)
+    float* d = tap_major ? dw + ((size_t)co * taps + tap) * cin + ci : dw + ((size_t)co * cin + ci) * taps + tap;
     *d = accumulate ? *d + s : s;
   }
 }
@@ -326,17 +338,36 @@ int plan_wgrad(const pn_conv_desc* d, WgradPlan& p) {
   return PN_OK;
 }
 
-template <int TM, int TN>
+template <int TM, int TN, bool GATHER = false>
 int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
   constexpr size_t smem = 2 * (size_t)WK * (TM * 64 + 8 + TN * 64 + 8) * sizeof(float);
   static bool attr_done[64] = {false};
   if (pn::first_use_on_device(attr_done)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TM, TN, GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   const int per_split = p.taps * p.ci_tiles * p.co_tiles;
   const int groups8 = pn::cdiv(p.splits, 8);  // splits are handed out in groups of 8, one per XCD
-  hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN>), dim3(groups8 * per_split * 8), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, GATHER>), dim3(groups8 * per_split * 8), dim3(256), smem, st, a);
   return pn::check_launch("conv_wgrad_kernel");
+}
+
+// plan of the gathered (sparse) weight gradient: rows = output sites, `taps` neighbour columns
+int plan_sparse_wgrad(int out_capacity, int taps, int cout, int cin, WgradPlan& p) {
+  PN_REQUIRE(out_capacity >= 1 && taps >= 1 && taps <= 64 && cout >= 1 && cin >= 4 && cin % 4 == 0, "sparse_conv_wgrad: bad sizes (row width a multiple of 4)");
+  p.OH = out_capacity; p.OW = 1;
+  p.M = out_capacity;
+  p.tm = cin > 64 ? 2 : 1;
+  p.tn = cout > 64 ? 2 : 1;
+  p.bm = p.tm * 64; p.bn = p.tn * 64;
+  p.ci_tiles = pn::cdiv(cin, p.bm); p.co_tiles = pn::cdiv(cout, p.bn);
+  p.cin_pad = p.ci_tiles * p.bm; p.cout_pad = p.co_tiles * p.bn;
+  p.taps = taps;
+  const long long tiles = (long long)p.taps * p.ci_tiles * p.co_tiles;
+  long long s = std::max<long long>(1, kWgradTargetBlocks / tiles);
+  s = std::min<long long>(s, std::max<long long>(1, p.M / 256));
+  p.m_per_split = (int)(((p.M + s - 1) / s + WK - 1) / WK * WK);
+  p.splits = (int)((p.M + p.m_per_split - 1) / p.m_per_split);
+  return PN_OK;
 }
 
 constexpr int kSumSlices = 2048;
@@ -384,6 +415,45 @@ int pn_conv2d_wgrad_f32(const pn_conv_desc* d, const float* in, const float* dou
   const size_t total = (size_t)p.taps * d->cin * d->cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, st,
                      a.part, p.splits, p.taps, d->cin, d->cout, p.cin_pad, p.cout_pad, dweight, accumulate);
+  return pn::check_launch("wgrad_reduce_kernel");
+}
+
+size_t pn_sparse_conv_wgrad_workspace_bytes(int out_capacity, int taps, int cout, int cin) {
+  WgradPlan p;
+  if (plan_sparse_wgrad(out_capacity, taps, cout, cin, p)) return 0;
+  return (size_t)p.splits * p.taps * p.cin_pad * p.cout_pad * sizeof(float);
+}
+
+int pn_sparse_conv_wgrad_f32(const float* in, int cin, int cin_real, const float* dout, int cout, const int32_t* nbr, const int32_t* n_out,
+                             int out_capacity, int taps, float* dw, int accumulate, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  WgradPlan p;
+  if (int rc = plan_sparse_wgrad(out_capacity, taps, cout, cin, p)) return rc;
+  PN_REQUIRE(in && dout && nbr && n_out && dw && workspace, "sparse_conv_wgrad: null pointer");
+  PN_REQUIRE(cin_real >= 1 && cin_real <= cin, "sparse_conv_wgrad: cin_real out of range");
+  if (workspace_bytes < pn_sparse_conv_wgrad_workspace_bytes(out_capacity, taps, cout, cin)) return pn::fail(PN_ERR_WORKSPACE, "sparse_conv_wgrad: workspace too small");
+  const unsigned long long dy_bytes = (unsigned long long)out_capacity * cout * 4ull;
+  PN_REQUIRE(dy_bytes < (1ull << 31), "sparse_conv_wgrad: gradient matrix larger than 2 GiB");
+  WgradArgs a{};
+  a.in = in; a.dy = dout; a.part = static_cast<float*>(workspace);
+  a.B = 1; a.H = out_capacity; a.W = 1; a.Cin = cin; a.Cout = cout; a.OH = out_capacity; a.OW = 1;
+  a.KH = taps; a.KW = 1; a.stride = 1; a.pad_h = 0; a.pad_w = 0;
+  a.in_ps = cin; a.in_co = 0; a.dy_ps = cout; a.dy_co = 0;
+  a.M = out_capacity; a.m_per_split = p.m_per_split; a.ci_tiles = p.ci_tiles; a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;
+  a.co_tiles = p.co_tiles; a.tiles_per_split = p.taps * p.ci_tiles * p.co_tiles; a.splits = p.splits;
+  a.in_bytes = 0x7fffffffu;   // the gathered rows are range-checked through the neighbour table, not the descriptor
+  a.dy_bytes = (unsigned)dy_bytes;
+  a.div_ohw = make_fastdiv((unsigned)out_capacity); a.div_ow = make_fastdiv(1u);
+  a.nbr = nbr; a.n_valid = n_out;
+  hipStream_t st = pn::S(stream);
+  int rc;
+  if (p.tm == 2 && p.tn == 2) rc = launch_wgrad<2, 2, true>(a, p, st);
+  else if (p.tm == 2) rc = launch_wgrad<2, 1, true>(a, p, st);
+  else if (p.tn == 2) rc = launch_wgrad<1, 2, true>(a, p, st);
+  else rc = launch_wgrad<1, 1, true>(a, p, st);
+  if (rc) return rc;
+  const size_t total = (size_t)p.taps * cin_real * cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, st, a.part, p.splits, p.taps, cin_real, cout,
+                     p.cin_pad, p.cout_pad, dw, accumulate, 1);
   return pn::check_launch("wgrad_reduce_kernel");
 }
 
