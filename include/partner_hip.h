@@ -579,6 +579,27 @@ int pn_center_decode_nms_f32(const float *hm, int hm_pixel_stride, int classes, 
                              int32_t *out_cells, int32_t *out_count, void *workspace,
                              size_t workspace_bytes, pn_stream_t stream);
 
+/* Double-flip test-time augmentation (CenterHead.double_flip_decode, center_head.py:289-346): the input batch is 4 * merged_batch
+ * samples in groups [original, y -> -y, x -> -x, both]; copies 1..3 are flipped back along H / W / both, reg / rot (sin, cos) /
+ * vel take the mirrored frame's signs, and the four are averaged: out_hm = mean sigmoid(hm) (probabilities), out_dim = mean
+ * exp(dim) (sizes), the others plain means.  Outputs are contiguous (merged_batch, h, w, c).  The decode that follows is
+ * pn_center_decode_nms_merged_f32 = pn_center_decode_nms_f32 without the sigmoid / exp (center_head.py:350-353 `if not
+ * double_flip`). */
+int pn_double_flip_merge_f32(const float *hm, int hm_pixel_stride, int classes, const float *reg, int reg_pixel_stride,
+                             const float *height, int height_pixel_stride, const float *dim, int dim_pixel_stride,
+                             const float *rot, int rot_pixel_stride, const float *vel, int vel_pixel_stride,
+                             int merged_batch, int h, int w, float *out_hm, float *out_reg, float *out_height,
+                             float *out_dim, float *out_rot, float *out_vel, pn_stream_t stream);
+int pn_center_decode_nms_merged_f32(const float *hm_prob, int hm_pixel_stride, int classes, const float *reg,
+                                    int reg_pixel_stride, const float *height, int height_pixel_stride,
+                                    const float *dim_size, int dim_pixel_stride, const float *rot, int rot_pixel_stride,
+                                    const float *vel, int vel_pixel_stride, int batch, int h, int w, int cylinder,
+                                    float step_x, float step_y, float origin_x, float origin_y, int rectify,
+                                    float score_threshold, const float *post_center_range, float nms_iou_threshold,
+                                    int per_class_nms, int pre_max, int post_max, float *out_boxes, float *out_scores,
+                                    int64_t *out_labels, int32_t *out_cells, int32_t *out_count, void *workspace,
+                                    size_t workspace_bytes, pn_stream_t stream);
+
 /* Same pipeline for the geometry-aware head: E2ESWVoteHead.decode / post_processing (e2e_swv_head.py:313-366, 368-470; code that
  * does not run in the reference, restated from its text): score = sigmoid(hm) * clamp((iou + 1) / 2, 0, 1)^iou_factor (iou may be
  * NULL), centre = reg + offset_grid (planar (2, H, W) Cartesian cell centres), rot = atan2(rot[1], rot[0]), and with rectify the

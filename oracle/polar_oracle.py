@@ -783,11 +783,48 @@ def e2e_swv_head(sd: SD, prefix: str, x: Tensor, offset_grid: Tensor, window=7, 
 # see that file's header); this part is the numpy restatement of the decode and of the selection logic
 # for the plain path (no double flip, no stateful / per-class NMS, no panoptic, sector 0).
 # ======================================================================================
-def center_decode(preds: Dict[str, np.ndarray], voxel_shape: str, out_size_factor, voxel_size, pc_range, rectify=False):
-    """preds: NHWC numpy arrays (B,H,W,c) 'hm','reg','height','dim','rot'[,'vel'] (raw head outputs).
+def double_flip_merge(preds: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """CenterHead.double_flip_decode (center_head.py:289-346): NHWC arrays (4B, H, W, c) in groups [original, y -> -y, x -> -x, both]
+    -> merged (B, H, W, c); 'hm' comes out as averaged probabilities, 'dim' as averaged sizes.  Pinned by tests/golden/double_flip.npz."""
+    out = {}
+    g = {}
+    for k, v in preds.items():
+        n, H, W, C = v.shape
+        t = torch.from_numpy(np.ascontiguousarray(v)).float().reshape(n // 4, 4, H, W, C).clone()
+        t[:, 1] = torch.flip(t[:, 1], dims=[1])
+        t[:, 2] = torch.flip(t[:, 2], dims=[2])
+        t[:, 3] = torch.flip(t[:, 3], dims=[1, 2])
+        g[k] = t
+    out["hm"] = torch.sigmoid(g["hm"]).mean(dim=1)
+    out["dim"] = torch.exp(g["dim"]).mean(dim=1)
+    out["height"] = g["height"].mean(dim=1)
+    reg = g["reg"]
+    reg[:, 1, ..., 1] = 1 - reg[:, 1, ..., 1]
+    reg[:, 2, ..., 0] = 1 - reg[:, 2, ..., 0]
+    reg[:, 3, ..., 0] = 1 - reg[:, 3, ..., 0]
+    reg[:, 3, ..., 1] = 1 - reg[:, 3, ..., 1]
+    out["reg"] = reg.mean(dim=1)
+    rots, rotc = g["rot"][..., 0:1], g["rot"][..., 1:2]
+    rotc[:, 1] *= -1
+    rots[:, 2] *= -1
+    rots[:, 3] *= -1
+    rotc[:, 3] *= -1
+    out["rot"] = torch.cat([rots.mean(dim=1), rotc.mean(dim=1)], -1)
+    if "vel" in g:
+        vel = g["vel"]
+        vel[:, 1, ..., 1] *= -1
+        vel[:, 2, ..., 0] *= -1
+        vel[:, 3] *= -1
+        out["vel"] = vel.mean(dim=1)
+    return {k: v.numpy() for k, v in out.items()}
+
+
+def center_decode(preds: Dict[str, np.ndarray], voxel_shape: str, out_size_factor, voxel_size, pc_range, rectify=False, activated=False):
+    """preds: NHWC numpy arrays (B,H,W,c) 'hm','reg','height','dim','rot'[,'vel'] (raw head outputs; activated: the merged maps of
+    double_flip_merge, whose hm / dim are probabilities / sizes already, center_head.py:350-353).
     -> boxes (B, H*W, 9 or 7) [x, y, z, dims(3), (vel 2), rot], scores (B, H*W, ncls) (center_head.py:350-402)"""
-    hm = 1.0 / (1.0 + np.exp(-preds["hm"].astype(np.float32)))
-    dim = np.exp(preds["dim"].astype(np.float32))
+    hm = preds["hm"].astype(np.float32) if activated else 1.0 / (1.0 + np.exp(-preds["hm"].astype(np.float32)))
+    dim = preds["dim"].astype(np.float32) if activated else np.exp(preds["dim"].astype(np.float32))
     rot = np.arctan2(preds["rot"][..., 0:1], preds["rot"][..., 1:2]).astype(np.float32)
     B, H, W, ncls = hm.shape
     reg = preds["reg"].reshape(B, H * W, 2).astype(np.float32)

@@ -42,6 +42,7 @@ struct DecodeArgs {
   // geometry-aware head (E2ESWVoteHead.decode, e2e_swv_head.py:313-366): Cartesian centre = reg + offset_grid, score rectified by
   // the IoU branch, rot = atan2(rot[1], rot[0]), rectified heading wrapped into (-pi, pi]
   int swv;
+  int activated;   // double-flip path: hm already holds (averaged) probabilities and dim (averaged) sizes -- no sigmoid / exp here
   const float* iou; int iou_ps; int iou_factor;
   const float* grid;   // offset_grid, planar (2, H, W)
 };
@@ -61,7 +62,7 @@ __global__ void decode_kernel(DecodeArgs a) {
       q = a.iou_factor == 1 ? u : powf(u, (float)a.iou_factor);
     }
     for (int c = 0; c < a.ncls; ++c) {
-      const float s = (1.f / (1.f + expf(-ph[c]))) * q;
+      const float s = (a.activated ? ph[c] : 1.f / (1.f + expf(-ph[c]))) * q;
       if (s > best) { best = s; lab = c; }   // first maximum, as torch.max
     }
     const float* pr = a.reg + i * a.reg_ps;
@@ -88,7 +89,8 @@ __global__ void decode_kernel(DecodeArgs a) {
     float* o = a.boxes + i * a.nb;
     o[0] = x; o[1] = y; o[2] = z;
     const float* pd = a.dim + i * a.dim_ps;
-    o[3] = expf(pd[0]); o[4] = expf(pd[1]); o[5] = expf(pd[2]);
+    if (a.activated) { o[3] = pd[0]; o[4] = pd[1]; o[5] = pd[2]; }
+    else { o[3] = expf(pd[0]); o[4] = expf(pd[1]); o[5] = expf(pd[2]); }
     if (a.vel) {
       float vx = a.vel[i * a.vel_ps], vy = a.vel[i * a.vel_ps + 1];
       if (a.cylinder && a.rectify) {
@@ -101,6 +103,72 @@ __global__ void decode_kernel(DecodeArgs a) {
     const bool ok = best > a.thr && x >= a.lo[0] && y >= a.lo[1] && z >= a.lo[2] && x <= a.hi[0] && y <= a.hi[1] && z <= a.hi[2];
     a.score[i] = ok ? best : -1.f;
     a.label[i] = lab;
+  }
+}
+
+// double-flip test-time augmentation (CenterHead.double_flip_decode, center_head.py:289-346): the batch holds groups of four
+// clouds [original, y -> -y, x -> -x, both]; the maps of copies 1..3 are flipped back along H / W / both, regression offsets,
+// heading (sin, cos) and velocity get the signs of the mirrored frame, and the four are averaged -- probabilities (sigmoid) for the
+// heat map and sizes (exp) for dim, so the decode that follows must not apply them again.
+struct FlipArgs {
+  const float* hm; int hm_ps, ncls;
+  const float* reg; int reg_ps;
+  const float* hei; int hei_ps;
+  const float* dim; int dim_ps;
+  const float* rot; int rot_ps;
+  const float* vel; int vel_ps;
+  int B, H, W;   // B = merged samples (input batch = 4 B)
+  float *o_hm, *o_reg, *o_hei, *o_dim, *o_rot, *o_vel;
+};
+__global__ void double_flip_merge_kernel(FlipArgs a) {
+  const int cells = a.H * a.W;
+  const size_t total = (size_t)a.B * cells;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / cells), cell = (int)(i % cells);
+    const int y = cell / a.W, x = cell - y * a.W;
+    size_t src[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = (k & 1) ? a.H - 1 - y : y, xx = (k & 2) ? a.W - 1 - x : x;
+      src[k] = ((size_t)(4 * b + k) * a.H + yy) * a.W + xx;
+    }
+    // torch.mean over the copy axis: running sum in copy order, then / 4
+    for (int c = 0; c < a.ncls; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += 1.f / (1.f + expf(-a.hm[src[k] * a.hm_ps + c]));
+      a.o_hm[i * a.ncls + c] = s * 0.25f;
+    }
+    for (int c = 0; c < 3; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += expf(a.dim[src[k] * a.dim_ps + c]);
+      a.o_dim[i * 3 + c] = s * 0.25f;
+    }
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += a.hei[src[k] * a.hei_ps];
+      a.o_hei[i] = s * 0.25f;
+    }
+    float rx = 0.f, ry = 0.f, rs = 0.f, rc = 0.f, vx = 0.f, vy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float* pr = a.reg + src[k] * a.reg_ps;
+      rx += (k & 2) ? 1.f - pr[0] : pr[0];          // x -> -x: reg_x -> 1 - reg_x
+      ry += (k & 1) ? 1.f - pr[1] : pr[1];          // y -> -y: reg_y -> 1 - reg_y
+      const float* pt = a.rot + src[k] * a.rot_ps;  // [sin, cos]
+      rs += (k & 2) ? -pt[0] : pt[0];
+      rc += (k & 1) ? -pt[1] : pt[1];
+      if (a.vel) {
+        const float* pv = a.vel + src[k] * a.vel_ps;
+        vx += (k & 2) ? -pv[0] : pv[0];
+        vy += (k & 1) ? -pv[1] : pv[1];
+      }
+    }
+    a.o_reg[i * 2] = rx * 0.25f; a.o_reg[i * 2 + 1] = ry * 0.25f;
+    a.o_rot[i * 2] = rs * 0.25f; a.o_rot[i * 2 + 1] = rc * 0.25f;
+    if (a.vel) { a.o_vel[i * 2] = vx * 0.25f; a.o_vel[i * 2 + 1] = vy * 0.25f; }
   }
 }
 
@@ -493,6 +561,44 @@ int pn_center_decode_nms_f32(const float* hm, int hm_pixel_stride, int classes, 
   a.sx = step_x; a.sy = step_y; a.x0 = origin_x; a.y0 = origin_y; a.thr = score_threshold;
   return run_decode_nms(a, post_center_range, nms_iou_threshold, per_class_nms, pre_max, post_max, out_boxes, out_scores, out_labels, out_cells,
                         out_count, workspace, workspace_bytes, stream);
+}
+
+int pn_center_decode_nms_merged_f32(const float* hm_prob, int hm_pixel_stride, int classes, const float* reg, int reg_pixel_stride,
+                                    const float* height, int height_pixel_stride, const float* dim_size, int dim_pixel_stride, const float* rot,
+                                    int rot_pixel_stride, const float* vel, int vel_pixel_stride, int batch, int h, int w, int cylinder,
+                                    float step_x, float step_y, float origin_x, float origin_y, int rectify, float score_threshold,
+                                    const float* post_center_range, float nms_iou_threshold, int per_class_nms, int pre_max, int post_max,
+                                    float* out_boxes, float* out_scores, int64_t* out_labels, int32_t* out_cells, int32_t* out_count,
+                                    void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(hm_prob && reg && height && dim_size && rot && post_center_range && out_boxes && out_scores && out_labels && out_cells && out_count &&
+                 workspace, "center_decode_nms_merged: null pointer");
+  PN_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && classes >= 1, "center_decode_nms_merged: bad sizes");
+  PN_REQUIRE(pre_max >= 1 && pre_max <= 4096 && post_max >= 1, "center_decode_nms_merged: nms_pre_max_size must be in [1, 4096]");
+  DecodeArgs a{};
+  a.hm = hm_prob; a.hm_ps = hm_pixel_stride; a.ncls = classes; a.reg = reg; a.reg_ps = reg_pixel_stride; a.hei = height; a.hei_ps = height_pixel_stride;
+  a.dim = dim_size; a.dim_ps = dim_pixel_stride; a.rot = rot; a.rot_ps = rot_pixel_stride; a.vel = vel; a.vel_ps = vel_pixel_stride;
+  a.B = batch; a.H = h; a.W = w; a.cylinder = cylinder; a.rectify = rectify; a.nb = vel ? 9 : 7;
+  a.sx = step_x; a.sy = step_y; a.x0 = origin_x; a.y0 = origin_y; a.thr = score_threshold;
+  a.activated = 1;
+  return run_decode_nms(a, post_center_range, nms_iou_threshold, per_class_nms, pre_max, post_max, out_boxes, out_scores, out_labels, out_cells,
+                        out_count, workspace, workspace_bytes, stream);
+}
+
+int pn_double_flip_merge_f32(const float* hm, int hm_pixel_stride, int classes, const float* reg, int reg_pixel_stride, const float* height,
+                             int height_pixel_stride, const float* dim, int dim_pixel_stride, const float* rot, int rot_pixel_stride,
+                             const float* vel, int vel_pixel_stride, int merged_batch, int h, int w, float* out_hm, float* out_reg,
+                             float* out_height, float* out_dim, float* out_rot, float* out_vel, pn_stream_t stream) {
+  PN_REQUIRE(hm && reg && height && dim && rot && out_hm && out_reg && out_height && out_dim && out_rot && (!vel || out_vel),
+             "double_flip_merge: null pointer");
+  PN_REQUIRE(merged_batch >= 1 && h >= 1 && w >= 1 && classes >= 1, "double_flip_merge: bad sizes");
+  FlipArgs a{};
+  a.hm = hm; a.hm_ps = hm_pixel_stride; a.ncls = classes; a.reg = reg; a.reg_ps = reg_pixel_stride; a.hei = height; a.hei_ps = height_pixel_stride;
+  a.dim = dim; a.dim_ps = dim_pixel_stride; a.rot = rot; a.rot_ps = rot_pixel_stride; a.vel = vel; a.vel_ps = vel_pixel_stride;
+  a.B = merged_batch; a.H = h; a.W = w;
+  a.o_hm = out_hm; a.o_reg = out_reg; a.o_hei = out_height; a.o_dim = out_dim; a.o_rot = out_rot; a.o_vel = out_vel;
+  const size_t total = (size_t)merged_batch * h * w;
+  hipLaunchKernelGGL(double_flip_merge_kernel, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0, pn::S(stream), a);
+  return pn::check_launch("double_flip_merge_kernel");
 }
 
 int pn_swv_decode_nms_f32(const float* hm, int hm_pixel_stride, int classes, const float* reg, int reg_pixel_stride, const float* height,

@@ -179,9 +179,10 @@ class CenterHead(nn.Module):
         import ctypes as C
         lib = hip.load()
         get = (lambda k, d=None: test_cfg.get(k, d)) if hasattr(test_cfg, "get") else (lambda k, d=None: getattr(test_cfg, k, d))
-        for flag in ("double_flip", "stateful_nms", "panoptic"):
+        for flag in ("stateful_nms", "panoptic"):
             if get(flag, False):
-                raise NotImplementedError(f"predict: test_cfg.{flag} is not built (only the plain decode + NMS paths)")
+                raise NotImplementedError(f"predict: test_cfg.{flag} is not built (only the plain and double-flip decode + NMS paths)")
+        double_flip = bool(get("double_flip", False))   # center_head.py:412, 425-427
         per_class = bool(get("per_class_nms", False))   # batched_nms_rotated of the nuScenes configs (center_head.py:514-518)
         if kwargs.get("device_only", False) and len(preds_dicts["det_preds"]) != 1:
             raise NotImplementedError("predict(device_only=True) supports a single task")
@@ -213,6 +214,26 @@ class CenterHead(nn.Module):
                 assert t.stride(1) == 1 and t.stride(2) == w * t.stride(3), "head tensors must be channels-last views"
             nb = 9 if "vel" in pd else 7
             dev = hm.device
+            vel = pd.get("vel")
+            decode_fn = "pn_center_decode_nms_f32"
+            if double_flip:
+                # the batch holds groups of four clouds [original, y-flip, x-flip, both]: flip the maps back, fix the signs, average
+                # (double_flip_decode, center_head.py:289-346); the merged hm / dim are probabilities / sizes already
+                if b % 4 != 0:
+                    raise ValueError(f"predict(double_flip): the batch ({b}) must hold groups of four flipped copies")
+                b //= 4
+                f32 = dict(dtype=torch.float32, device=dev)
+                mg = dict(hm=torch.empty((b, h, w, ncls), **f32), reg=torch.empty((b, h, w, 2), **f32), height=torch.empty((b, h, w, 1), **f32),
+                          dim=torch.empty((b, h, w, 3), **f32), rot=torch.empty((b, h, w, 2), **f32))
+                if vel is not None:
+                    mg["vel"] = torch.empty((b, h, w, 2), **f32)
+                hip.call("pn_double_flip_merge_f32", hm.data_ptr(), hm.stride(3), ncls, pd["reg"].data_ptr(), pd["reg"].stride(3),
+                         pd["height"].data_ptr(), pd["height"].stride(3), pd["dim"].data_ptr(), pd["dim"].stride(3), pd["rot"].data_ptr(),
+                         pd["rot"].stride(3), hip.ptr(vel), 0 if vel is None else vel.stride(3), b, h, w, mg["hm"].data_ptr(), mg["reg"].data_ptr(),
+                         mg["height"].data_ptr(), mg["dim"].data_ptr(), mg["rot"].data_ptr(), hip.ptr(mg.get("vel")), hip.stream())
+                pd = {k: v.permute(0, 3, 1, 2) for k, v in mg.items()}
+                hm, vel = pd["hm"], pd.get("vel")
+                decode_fn = "pn_center_decode_nms_merged_f32"
             out_boxes = torch.empty((b, post_max, nb), dtype=torch.float32, device=dev)
             out_scores = torch.empty((b, post_max), dtype=torch.float32, device=dev)
             out_labels = torch.empty((b, post_max), dtype=torch.int64, device=dev)
@@ -220,8 +241,7 @@ class CenterHead(nn.Module):
             out_count = torch.empty((b,), dtype=torch.int32, device=dev)
             wsb = lib.pn_center_decode_nms_workspace_bytes(b, h * w, nb, pre_max, post_max)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            vel = pd.get("vel")
-            hip.call("pn_center_decode_nms_f32", hm.data_ptr(), hm.stride(3), ncls, pd["reg"].data_ptr(), pd["reg"].stride(3),
+            hip.call(decode_fn, hm.data_ptr(), hm.stride(3), ncls, pd["reg"].data_ptr(), pd["reg"].stride(3),
                      pd["height"].data_ptr(), pd["height"].stride(3), pd["dim"].data_ptr(), pd["dim"].stride(3), pd["rot"].data_ptr(),
                      pd["rot"].stride(3), hip.ptr(vel), 0 if vel is None else vel.stride(3), b, h, w, cyl, float(osf) * float(vs[0]),
                      float(osf) * float(vs[1]), float(pr[0]), float(pr[1]), int(bool(get("rectify", False))), float(get("score_threshold")),
@@ -239,6 +259,8 @@ class CenterHead(nn.Module):
             rets.append([dict(box3d_lidar=out_boxes[i, :n], scores=out_scores[i, :n], label_preds=out_labels[i, :n], cells=out_cells[i, :n])
                          for i, n in enumerate(counts)])
         metas = example.get("metadata", [None] * len(rets[0])) if isinstance(example, dict) else [None] * len(rets[0])
+        if double_flip:
+            metas = list(metas)[::4] if len(metas) >= 4 * len(rets[0]) else metas   # meta_list[:4 * batch:4]
         ret_list = []
         for i in range(len(rets[0])):
             flag, labels = 0, []

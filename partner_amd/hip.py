@@ -126,6 +126,9 @@ SIGNATURES = {
     "pn_center_decode_nms_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "pn_center_decode_nms_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _P, _F, _I, _I, _I,
                                       _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "pn_center_decode_nms_merged_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _P, _F, _I, _I, _I,
+                                             _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "pn_double_flip_merge_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "pn_swv_decode_nms_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _F, _P, _F, _I, _I, _I,
                                    _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "pn_bilinear_upsample_add_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),

@@ -785,7 +785,23 @@ def gen_augment():
     save("augment.npz", **out)
 
 
+# ----------------------------------------------------------------------------- next-2 double-flip test-time augmentation
+def gen_double_flip():
+    """CenterHead.double_flip_decode of the reference on random head maps (two groups of four flipped copies)"""
+    from det3d.models.bbox_heads.center_head import CenterHead
+    rng = np.random.default_rng(17)
+    shapes = dict(hm=3, reg=2, height=1, dim=3, rot=2, vel=2)
+    inp = {k: rng.standard_normal((8, 6, 5, c)).astype(np.float32) for k, c in shapes.items()}
+    out = {f"in_{k}": v for k, v in inp.items()}
+    pd = {k: torch.from_numpy(v.copy()) for k, v in inp.items()}
+    metas = CenterHead.double_flip_decode(None, pd, [f"m{i}" for i in range(8)])
+    for k, v in pd.items():
+        out[f"out_{k}"] = v.numpy()
+    out["metas"] = np.array(metas)
+    save("double_flip.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static", "seg_head", "e2e", "stream", "augment"]
+    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static", "seg_head", "e2e", "stream", "augment", "double_flip"]
     for w in which:
         globals()["gen_" + w]()

@@ -478,3 +478,13 @@ def test_single_conv_seg_head(golden):
     lab = O.seg_point_labels(seg, [g["gi0"], g["gi1"]])
     np.testing.assert_array_equal(lab[0], g["labels0"])
     np.testing.assert_array_equal(lab[1], g["labels1"])
+
+
+def test_double_flip_merge_matches_reference(golden):
+    """CenterHead.double_flip_decode (center_head.py:289-346) captured from the reference: the oracle's merge, bit for bit"""
+    g = golden("double_flip.npz")
+    names = ["hm", "reg", "height", "dim", "rot", "vel"]
+    got = O.double_flip_merge({k: g[f"in_{k}"] for k in names})
+    for k in names:
+        np.testing.assert_array_equal(got[k], g[f"out_{k}"], err_msg=k)
+    assert list(g["metas"]) == ["m0", "m4"]
