@@ -611,7 +611,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "nuScenes polar-pillar PARTNER cfg (DynamicPFNet -> DynamicPPScatter -> RPN -> "
                                    "CenterHeadSinglePos), grid 512x512x1, forward only (BASELINE configs[1])",
-                       "points_per_sweep": N, "sweeps_per_step_per_gpu": B, "parallelism": f"frame-replicas x{world}",
+                       "points_per_sweep": N, "sweeps_per_step_per_gpu": B, "parallelism": f"frame-replicas x{world}", "device": hip.device_info(dev.index or 0),
                        "launch": "eager" if args.eager else f"hipGraph replay per frame, {max(1, args.streams)} frame(s) in flight on separate HIP streams"},
             "single_stream_ms_per_step": None if single_ms is None else round(single_ms, 4),
             "batched": batched, "roofline": roofline, "roofline_scatter": scatter, "train_step": train,

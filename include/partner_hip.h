@@ -48,6 +48,15 @@ int pn_version(void);
 int pn_last_error(char *buf, size_t buf_len);
 /* number of HIP devices visible, -1 if the runtime is unusable */
 int pn_device_count(void);
+/* Opaque per-device handle: the only object the library keeps for a caller.  Creation queries the device and FAILS LOUDLY when it
+ * is not a gfx950 part (the library holds gfx950 code objects only); pn_handle_info reports what the roofline figures are priced
+ * against (compute units, LDS per CU, HBM bytes, architecture string).  The compute entry points do not need a handle: they take
+ * device pointers and a stream and keep no state between calls. */
+typedef struct pn_handle_s *pn_handle_t;
+int pn_handle_create(int device, pn_handle_t *out);
+int pn_handle_destroy(pn_handle_t handle);
+int pn_handle_info(pn_handle_t handle, int *device, int *compute_units, int *lds_bytes_per_cu, unsigned long long *hbm_bytes,
+                   char *arch, size_t arch_len);
 
 /* ---------------------------------------------------------------------------------------
  * V0  cart -> polar point decoration.

@@ -1,6 +1,7 @@
 // Error reporting, device query, HIP-event helpers and small layout kernels of libpartner_hip.
 #include "pn_common.h"
 #include <algorithm>
+#include <cstring>
 
 namespace pn {
 
@@ -49,6 +50,49 @@ int zero_async(void* ptr, size_t bytes, hipStream_t st) {
 }
 
 }  // namespace pn
+
+// ---- opaque per-device handle: device properties + the one loud check that the code objects match the GPU -------
+struct pn_handle_s {
+  int device;
+  int compute_units;
+  int lds_bytes;
+  size_t hbm_bytes;
+  char arch[64];
+};
+
+extern "C" int pn_handle_create(int device, pn_handle_t* out) {
+  PN_REQUIRE(out != nullptr, "handle_create: null output");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return pn::fail(PN_ERR_INVALID, "handle_create: no HIP device %d (%d visible)", device, n);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return pn::fail(PN_ERR_LAUNCH, "handle_create: hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return pn::fail(PN_ERR_INVALID, "handle_create: device %d is %s; libpartner_hip holds gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+  pn_handle_s* h = new pn_handle_s();
+  h->device = device;
+  h->compute_units = prop.multiProcessorCount;
+  h->lds_bytes = (int)prop.maxSharedMemoryPerMultiProcessor;
+  h->hbm_bytes = prop.totalGlobalMem;
+  snprintf(h->arch, sizeof(h->arch), "%s", prop.gcnArchName);
+  *out = h;
+  return PN_OK;
+}
+
+extern "C" int pn_handle_destroy(pn_handle_t h) {
+  delete h;
+  return PN_OK;
+}
+
+extern "C" int pn_handle_info(pn_handle_t h, int* device, int* compute_units, int* lds_bytes_per_cu, unsigned long long* hbm_bytes, char* arch,
+                              size_t arch_len) {
+  PN_REQUIRE(h != nullptr, "handle_info: null handle");
+  if (device) *device = h->device;
+  if (compute_units) *compute_units = h->compute_units;
+  if (lds_bytes_per_cu) *lds_bytes_per_cu = h->lds_bytes;
+  if (hbm_bytes) *hbm_bytes = (unsigned long long)h->hbm_bytes;
+  if (arch && arch_len) snprintf(arch, arch_len, "%s", h->arch);
+  return PN_OK;
+}
 
 namespace {
 

@@ -167,6 +167,9 @@ SIGNATURES = {
     "pn_recip_clamp_f32": (_I, [_P, _F, _I, _P, _P]),
     "pn_recip_clamp_bwd_f32": (_I, [_P, _P, _F, _I, _P, _P]),
     "pn_global_augment_f32": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _P, _P]),
+    "pn_handle_create": (_I, [_I, _P]),
+    "pn_handle_destroy": (_I, [_P]),
+    "pn_handle_info": (_I, [_P, _P, _P, _P, _P, _P, _SZ]),
     "pn_contract_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "pn_softmax_f32": (_I, [_P, _P, C.c_longlong, _I, _I, _P]),
     "pn_softmax_bwd_f32": (_I, [_P, _P, _P, C.c_longlong, _I, _I, _P]),
@@ -249,6 +252,20 @@ def require_device(*tensors: torch.Tensor) -> None:
             raise PartnerHipError(
                 "partner_amd operators run only on a gfx950 (MI355X) device through libpartner_hip.so; "
                 "got a CPU tensor and there is deliberately no CPU fallback")
+
+
+def device_info(device: int = 0) -> dict:
+    """what the library sees on HIP device ``device`` through its per-device handle (pn_handle_create fails loudly on a non-gfx950 part)"""
+    h = C.c_void_p()
+    call("pn_handle_create", int(device), C.byref(h))
+    try:
+        dev, cus, lds = C.c_int(), C.c_int(), C.c_int()
+        hbm = C.c_ulonglong()
+        arch = C.create_string_buffer(64)
+        call("pn_handle_info", h, C.byref(dev), C.byref(cus), C.byref(lds), C.byref(hbm), arch, 64)
+        return dict(device=dev.value, arch=arch.value.decode(), compute_units=cus.value, lds_bytes_per_cu=lds.value, hbm_bytes=hbm.value)
+    finally:
+        load().pn_handle_destroy(h)
 
 
 def call(name: str, *args) -> None:
