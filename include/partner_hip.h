@@ -588,6 +588,22 @@ int pn_center_decode_nms_f32(const float *hm, int hm_pixel_stride, int classes, 
                              int32_t *out_cells, int32_t *out_count, void *workspace,
                              size_t workspace_bytes, pn_stream_t stream);
 
+/* Stateful NMS across azimuth sectors (test_cfg.stateful_nms, center_head.py:486-501, 507-509): the sector's thresholded candidates
+ * are rotated by sector_angle into the sweep's frame BEFORE the NMS, the detections of the previous sectors (prev_* : (batch,
+ * prev_capacity, box_dims) boxes / (batch, prev_capacity) scores, int64 labels / (batch) int32 counts; prev_capacity may be 0)
+ * compete in the same NMS, and post_max is the caller's nms_post_max_size * (sec_id + 1).  out_cells >= h*w marks a carried-over
+ * detection (row h*w + k of the previous list).  Workspace: pn_center_decode_nms_workspace_bytes(batch, h*w + prev_capacity, ...). */
+int pn_center_decode_nms_stateful_f32(const float *hm, int hm_pixel_stride, int classes, const float *reg,
+                                      int reg_pixel_stride, const float *height, int height_pixel_stride,
+                                      const float *dim, int dim_pixel_stride, const float *rot, int rot_pixel_stride,
+                                      const float *vel, int vel_pixel_stride, int batch, int h, int w, int cylinder,
+                                      float step_x, float step_y, float origin_x, float origin_y, int rectify,
+                                      float score_threshold, const float *post_center_range, float nms_iou_threshold,
+                                      int per_class_nms, int pre_max, int post_max, double sector_angle,
+                                      const float *prev_boxes, const float *prev_scores, const int64_t *prev_labels,
+                                      const int32_t *prev_count, int prev_capacity, float *out_boxes, float *out_scores,
+                                      int64_t *out_labels, int32_t *out_cells, int32_t *out_count, void *workspace,
+                                      size_t workspace_bytes, pn_stream_t stream);
 /* Double-flip test-time augmentation (CenterHead.double_flip_decode, center_head.py:289-346): the input batch is 4 * merged_batch
  * samples in groups [original, y -> -y, x -> -x, both]; copies 1..3 are flipped back along H / W / both, reg / rot (sin, cos) /
  * vel take the mirrored frame's signs, and the four are averaged: out_hm = mean sigmoid(hm) (probabilities), out_dim = mean

@@ -916,6 +916,42 @@ def center_post_process(boxes: np.ndarray, hm: np.ndarray, score_threshold: floa
     return dict(box3d_lidar=b[sel], scores=s[sel], label_preds=l[sel], cells=cells[sel])
 
 
+def center_post_process_stateful(boxes: np.ndarray, hm: np.ndarray, score_threshold: float, post_center_range, nms_iou_threshold: float,
+                                 nms_pre_max_size: int, nms_post_max_size: int, nms_fn, prev, sector_angle: float, sec_id: int):
+    """one sample of post_processing with test_cfg.stateful_nms (center_head.py:470-531): threshold / range mask, the sector's candidates
+    rotated into the sweep's frame, the previous sectors' detections (prev: dict(box3d_lidar, scores, label_preds) or None) put in front,
+    ONE rotated NMS over the union, at most nms_post_max_size * (sec_id + 1) boxes.  Ties in the score sort: the sector's own cells
+    first (by cell index), carried-over detections after (index H*W + k) -- torch leaves them unspecified.
+    -> dict(box3d_lidar, scores, label_preds, cells)"""
+    scores, labels = hm.max(-1), hm.argmax(-1)
+    pr = np.asarray(post_center_range, np.float32)
+    mask = (scores > np.float32(score_threshold)) & (boxes[:, :3] >= pr[:3]).all(1) & (boxes[:, :3] <= pr[3:]).all(1)
+    cells = np.nonzero(mask)[0]
+    b, s, l = boxes[cells].copy(), scores[cells], labels[cells]
+    if prev is not None:
+        c, sn = np.float32(np.cos(sector_angle)), np.float32(np.sin(-sector_angle))
+        m = np.array([[c, -sn], [sn, c]], np.float32)           # rot_mat_T of the reference: [[cos, -sin(-a)], [sin(-a), cos]]
+        xy = b[:, :2].copy()
+        b[:, 0] = xy[:, 0] * m[0, 0] + xy[:, 1] * m[1, 0]
+        b[:, 1] = xy[:, 0] * m[0, 1] + xy[:, 1] * m[1, 1]
+        b[:, -1] -= np.float32(sector_angle)
+        if b.shape[1] > 7:
+            v = b[:, 6:8].copy()
+            b[:, 6] = v[:, 0] * m[0, 0] + v[:, 1] * m[1, 0]
+            b[:, 7] = v[:, 0] * m[0, 1] + v[:, 1] * m[1, 1]
+        npv = len(prev["scores"])
+        idx = np.concatenate([cells, len(scores) + np.arange(npv)])
+        b = np.concatenate([b, np.asarray(prev["box3d_lidar"], np.float32)], 0)
+        s = np.concatenate([s, np.asarray(prev["scores"], np.float32)])
+        l = np.concatenate([l, np.asarray(prev["label_preds"], np.int64)])
+    else:
+        idx = cells
+    order = np.lexsort((idx, -s))[:nms_pre_max_size]
+    keep = np.asarray(nms_fn(nms_boxes_pcdet(b[order]), nms_iou_threshold), np.int64)
+    sel = order[keep][:nms_post_max_size * (sec_id + 1)]
+    return dict(box3d_lidar=b[sel], scores=s[sel], label_preds=l[sel], cells=idx[sel])
+
+
 # ======================================================================================
 # next-1  SpMiddleResNetFHD (sparse 3-D middle encoder)   det3d/models/backbones/scn.py:17-192
 # PARITY UNPINNED: the arithmetic of SubMConv3d / SparseConv3d / SparseConvTensor.dense is the third-party spconv

@@ -43,6 +43,11 @@ struct DecodeArgs {
   // the IoU branch, rot = atan2(rot[1], rot[0]), rectified heading wrapped into (-pi, pi]
   int swv;
   int activated;   // double-flip path: hm already holds (averaged) probabilities and dim (averaged) sizes -- no sigmoid / exp here
+  // stateful NMS across azimuth sectors (center_head.py:486-501): the sector's candidates are rotated into the sweep's frame BEFORE the
+  // NMS and the previous sectors' detections are appended as `extra` further candidates per sample (rows cells .. cells + extra - 1)
+  int extra;
+  int pre_rot;
+  float rot_c, rot_s, rot_angle;
   const float* iou; int iou_ps; int iou_factor;
   const float* grid;   // offset_grid, planar (2, H, W)
 };
@@ -86,7 +91,8 @@ __global__ void decode_kernel(DecodeArgs a) {
       y = ((float)yy + pr[1]) * a.sy + a.y0;
     }
     const float z = a.hei[i * a.hei_ps];
-    float* o = a.boxes + i * a.nb;
+    const size_t oi = (size_t)(i / cells) * (cells + a.extra) + cell;   // row of this cell in the candidate arrays
+    float* o = a.boxes + oi * a.nb;
     o[0] = x; o[1] = y; o[2] = z;
     const float* pd = a.dim + i * a.dim_ps;
     if (a.activated) { o[3] = pd[0]; o[4] = pd[1]; o[5] = pd[2]; }
@@ -101,9 +107,32 @@ __global__ void decode_kernel(DecodeArgs a) {
     }
     o[a.nb - 1] = r;
     const bool ok = best > a.thr && x >= a.lo[0] && y >= a.lo[1] && z >= a.lo[2] && x <= a.hi[0] && y <= a.hi[1] && z <= a.hi[2];
-    a.score[i] = ok ? best : -1.f;
-    a.label[i] = lab;
+    if (a.pre_rot) {   // after the range mask, as the reference: [x y] @ [[c, s], [-s, c]], heading -= angle, velocity like the centre
+      o[0] = __fadd_rn(__fmul_rn(x, a.rot_c), __fmul_rn(y, -a.rot_s));
+      o[1] = __fadd_rn(__fmul_rn(x, a.rot_s), __fmul_rn(y, a.rot_c));
+      o[a.nb - 1] = r - a.rot_angle;
+      if (a.vel) {
+        const float vx = o[6], vy = o[7];
+        o[6] = __fadd_rn(__fmul_rn(vx, a.rot_c), __fmul_rn(vy, -a.rot_s));
+        o[7] = __fadd_rn(__fmul_rn(vx, a.rot_s), __fmul_rn(vy, a.rot_c));
+      }
+    }
+    a.score[oi] = ok ? best : -1.f;
+    a.label[oi] = lab;
   }
+}
+
+// rows cells .. cells + extra - 1 of every sample's candidate arrays = the detections of the previous sectors (score -1 past the count)
+__global__ void append_prev_kernel(const float* __restrict__ pb, const float* __restrict__ ps, const int64_t* __restrict__ pl, const int32_t* __restrict__ pc,
+                                   int batch, int cells, int extra, int nb, float* __restrict__ boxes, float* __restrict__ score, int* __restrict__ label) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch * extra) return;
+  const int b = i / extra, k = i - b * extra;
+  const size_t row = (size_t)b * (cells + extra) + cells + k;
+  const bool live = k < pc[b];
+  score[row] = live ? ps[i] : -1.f;
+  label[row] = live ? (int)pl[i] : 0;
+  for (int c = 0; c < nb; ++c) boxes[row * nb + c] = live ? pb[(size_t)i * nb + c] : 0.f;
 }
 
 // double-flip test-time augmentation (CenterHead.double_flip_decode, center_head.py:289-346): the batch holds groups of four
@@ -477,17 +506,22 @@ Ws carve(void* base, int batch, int cells, int nb, int pre_max, int post_max) {
 }
 
 // decode -> select / sort -> IoU masks -> greedy reduce -> gather, shared by the CenterHead and the E2ESWVoteHead entry points
+struct PrevDets { const float* boxes; const float* scores; const int64_t* labels; const int32_t* count; };
+
 int run_decode_nms(DecodeArgs a, const float* post_center_range, float nms_iou_threshold, int per_class_nms, int pre_max, int post_max,
                    float* out_boxes, float* out_scores, int64_t* out_labels, int32_t* out_cells, int32_t* out_count, void* workspace,
-                   size_t workspace_bytes, pn_stream_t stream) {
-  const int nb = a.nb, cells = a.H * a.W, batch = a.B;
+                   size_t workspace_bytes, pn_stream_t stream, PrevDets prev = PrevDets{nullptr, nullptr, nullptr, nullptr}) {
+  const int nb = a.nb, grid_cells = a.H * a.W, cells = grid_cells + a.extra, batch = a.B;
   Ws ws = carve(workspace, batch, cells, nb, pre_max, post_max);
   PN_REQUIRE(workspace_bytes >= ws.bytes, "decode_nms: workspace too small");
   hipStream_t st = pn::S(stream);
   for (int k = 0; k < 3; ++k) { a.lo[k] = post_center_range[k]; a.hi[k] = post_center_range[3 + k]; }
   a.boxes = ws.boxes; a.score = ws.score; a.label = ws.label;
-  const size_t total = (size_t)batch * cells;
+  const size_t total = (size_t)batch * grid_cells;
   hipLaunchKernelGGL(decode_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, st, a);
+  if (a.extra > 0)
+    hipLaunchKernelGGL(append_prev_kernel, dim3(pn::cdiv(batch * a.extra, 256)), dim3(256), 0, st, prev.boxes, prev.scores, prev.labels, prev.count, batch,
+                       grid_cells, a.extra, nb, ws.boxes, ws.score, ws.label);
   static bool sort_attr[64] = {false};
   if (pn::first_use_on_device(sort_attr)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortLds);
@@ -582,6 +616,31 @@ int pn_center_decode_nms_merged_f32(const float* hm_prob, int hm_pixel_stride, i
   a.activated = 1;
   return run_decode_nms(a, post_center_range, nms_iou_threshold, per_class_nms, pre_max, post_max, out_boxes, out_scores, out_labels, out_cells,
                         out_count, workspace, workspace_bytes, stream);
+}
+
+int pn_center_decode_nms_stateful_f32(const float* hm, int hm_pixel_stride, int classes, const float* reg, int reg_pixel_stride, const float* height,
+                                      int height_pixel_stride, const float* dim, int dim_pixel_stride, const float* rot, int rot_pixel_stride,
+                                      const float* vel, int vel_pixel_stride, int batch, int h, int w, int cylinder, float step_x, float step_y,
+                                      float origin_x, float origin_y, int rectify, float score_threshold, const float* post_center_range,
+                                      float nms_iou_threshold, int per_class_nms, int pre_max, int post_max, double sector_angle,
+                                      const float* prev_boxes, const float* prev_scores, const int64_t* prev_labels, const int32_t* prev_count,
+                                      int prev_capacity, float* out_boxes, float* out_scores, int64_t* out_labels, int32_t* out_cells,
+                                      int32_t* out_count, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(hm && reg && height && dim && rot && post_center_range && out_boxes && out_scores && out_labels && out_cells && out_count && workspace,
+             "center_decode_nms_stateful: null pointer");
+  PN_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && classes >= 1 && prev_capacity >= 0, "center_decode_nms_stateful: bad sizes");
+  PN_REQUIRE(prev_capacity == 0 || (prev_boxes && prev_scores && prev_labels && prev_count), "center_decode_nms_stateful: previous detections missing");
+  PN_REQUIRE(pre_max >= 1 && pre_max <= 4096 && post_max >= 1, "center_decode_nms_stateful: nms_pre_max_size must be in [1, 4096]");
+  DecodeArgs a{};
+  a.hm = hm; a.hm_ps = hm_pixel_stride; a.ncls = classes; a.reg = reg; a.reg_ps = reg_pixel_stride; a.hei = height; a.hei_ps = height_pixel_stride;
+  a.dim = dim; a.dim_ps = dim_pixel_stride; a.rot = rot; a.rot_ps = rot_pixel_stride; a.vel = vel; a.vel_ps = vel_pixel_stride;
+  a.B = batch; a.H = h; a.W = w; a.cylinder = cylinder; a.rectify = rectify; a.nb = vel ? 9 : 7;
+  a.sx = step_x; a.sy = step_y; a.x0 = origin_x; a.y0 = origin_y; a.thr = score_threshold;
+  a.extra = prev_capacity;
+  a.pre_rot = sector_angle != 0.0;
+  a.rot_c = (float)cos(sector_angle); a.rot_s = (float)sin(sector_angle); a.rot_angle = (float)sector_angle;
+  return run_decode_nms(a, post_center_range, nms_iou_threshold, per_class_nms, pre_max, post_max, out_boxes, out_scores, out_labels, out_cells,
+                        out_count, workspace, workspace_bytes, stream, PrevDets{prev_boxes, prev_scores, prev_labels, prev_count});
 }
 
 int pn_double_flip_merge_f32(const float* hm, int hm_pixel_stride, int classes, const float* reg, int reg_pixel_stride, const float* height,

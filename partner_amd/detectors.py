@@ -210,7 +210,8 @@ class PolarStream(PointPillars):
     """PolarStream (det3d/models/detectors/polarstream.py:7-180): a sweep given as a LIST of azimuth-sector examples is processed
     sector by sector, the neck (RPNTECP / RPNBDCP) pads every sector with the context rows the previous sector left behind, and the
     per-sector detections are rotated back into the sweep's frame and concatenated (single_stage.py:83-165).  A single example (dict)
-    is the full-sweep case.  Eval mode; detection super-task; no stateful NMS / panoptic fusion."""
+    is the full-sweep case.  Eval mode; detection super-task; stateful NMS across sectors (test_cfg.stateful_nms, the default of the
+    reference's 4-sector configs) is supported, panoptic fusion is not."""
 
     def forward_one_sector(self, example, return_loss=True, **kwargs):
         eval_only(self, "PolarStream")
@@ -236,7 +237,7 @@ class PolarStream(PointPillars):
         elif kwargs.get("raw_preds", False) or self.test_cfg is None:
             ret.update(preds)
         else:
-            ret["det"] = self.bbox_head.predict(example, preds, self.test_cfg, sec_id=kwargs.get("sec_id", 0))
+            ret["det"] = self.bbox_head.predict(example, preds, self.test_cfg, sec_id=kwargs.get("sec_id", 0), prev_dets=kwargs.get("prev_dets"))
         if len(nxt):
             ret["next_context"] = nxt
         return ret
@@ -245,24 +246,44 @@ class PolarStream(PointPillars):
         if isinstance(example, dict):
             return self.forward_one_sector(example, return_loss, **kwargs)
         get = (lambda k, d=None: self.test_cfg.get(k, d)) if hasattr(self.test_cfg, "get") else (lambda k, d=None: getattr(self.test_cfg, k, d))
-        if self.test_cfg is not None and (get("stateful_nms", False) or get("panoptic", False)):
-            raise NotImplementedError("PolarStream: stateful NMS / panoptic fusion across sectors are not built")
+        if self.test_cfg is not None and get("panoptic", False):
+            raise NotImplementedError("PolarStream: panoptic fusion across sectors is not built")
+        stateful = self.test_cfg is not None and bool(get("stateful_nms", False))
         rets, prev = [], []
         for i, ex in enumerate(example):
-            r = self.forward_one_sector(ex, return_loss, **dict(kwargs, prev_context=prev, sec_id=i))
+            kw = dict(kwargs, prev_context=prev, sec_id=i)
+            if stateful and i > 0 and "det" in rets[-1]:
+                kw["prev_dets"] = rets[-1]["det"]     # polarstream.py:91-92
+            r = self.forward_one_sector(ex, return_loss, **kw)
             prev = r.pop("next_context", []) if i < len(example) - 1 else []
             r.pop("next_context", None)
             rets.append(r)
-        return self.merge_sectors(rets, len(example[-1]["num_points"]))
+        out = self.merge_sectors(rets, len(example[-1]["num_points"]), stateful)
+        if stateful and "det" in out:
+            for det, meta in zip(out["det"], example[-1].get("metadata", [None] * len(out["det"]))):
+                det["metadata"] = meta
+        return out
 
-    def merge_sectors(self, sectors, batch_size):
+    def merge_sectors(self, sectors, batch_size, stateful=False):
         """single_stage.py:83-165 for the keys this build produces: losses are lists concatenated over sectors, detections are
-        concatenated per sample"""
+        concatenated per sample; with stateful NMS the LAST sector's per-task lists already hold the whole sweep (merge_dets
+        :137-153: tasks concatenated, labels offset by the preceding tasks' class counts)"""
         out = {}
         for k in sectors[0]:
             vals = [s[k] for s in sectors]
             if "loss" in k:
                 out[k] = [v for lst in vals for v in lst]
+            elif k == "det" and stateful:
+                tasks = vals[-1]
+                merged = []
+                for i in range(len(tasks[0])):
+                    flag, labels = 0, []
+                    for j, ncls in enumerate(self.bbox_head.num_classes[:len(tasks)]):
+                        labels.append(tasks[j][i]["label_preds"] + flag)
+                        flag += ncls
+                    merged.append(dict(box3d_lidar=torch.cat([t[i]["box3d_lidar"] for t in tasks]), scores=torch.cat([t[i]["scores"] for t in tasks]),
+                                       label_preds=torch.cat(labels)))
+                out[k] = merged
             elif k == "det":
                 merged = []
                 for i in range(len(vals[0])):

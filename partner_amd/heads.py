@@ -179,15 +179,16 @@ class CenterHead(nn.Module):
         import ctypes as C
         lib = hip.load()
         get = (lambda k, d=None: test_cfg.get(k, d)) if hasattr(test_cfg, "get") else (lambda k, d=None: getattr(test_cfg, k, d))
-        for flag in ("stateful_nms", "panoptic"):
-            if get(flag, False):
-                raise NotImplementedError(f"predict: test_cfg.{flag} is not built (only the plain and double-flip decode + NMS paths)")
+        if get("panoptic", False):
+            raise NotImplementedError("predict: test_cfg.panoptic (instance ids for the segmentation super-task) is not built")
         double_flip = bool(get("double_flip", False))   # center_head.py:412, 425-427
+        stateful = bool(get("stateful_nms", False))     # center_head.py:466, 486-501, 507-509
+        if stateful and (double_flip or kwargs.get("device_only", False)):
+            raise NotImplementedError("predict: stateful NMS is not combined with double flip / device_only outputs")
         per_class = bool(get("per_class_nms", False))   # batched_nms_rotated of the nuScenes configs (center_head.py:514-518)
         if kwargs.get("device_only", False) and len(preds_dicts["det_preds"]) != 1:
             raise NotImplementedError("predict(device_only=True) supports a single task")
-        if kwargs.get("prev_dets") is not None:
-            raise NotImplementedError("predict: stateful NMS across sectors (prev_dets) is not built")
+        prev_dets = kwargs.get("prev_dets") if stateful else None
         sec_id = int(kwargs.get("sec_id", 0))
         nms = get("nms")
         nget = (lambda k: nms[k]) if isinstance(nms, dict) else (lambda k: getattr(nms, k))
@@ -204,7 +205,7 @@ class CenterHead(nn.Module):
         if not cyl:
             pr = [float(v) for v in example["pc_range"][0]][:2] if "pc_range" in example else pr  # ref_pc_range of the reference
         rets = []
-        for pd in preds_dicts["det_preds"]:
+        for task_id, pd in enumerate(preds_dicts["det_preds"]):
             hm = pd["hm"]
             hip.require_device(hm)
             b, ncls, h, w = hm.shape
@@ -241,6 +242,43 @@ class CenterHead(nn.Module):
             out_count = torch.empty((b,), dtype=torch.int32, device=dev)
             wsb = lib.pn_center_decode_nms_workspace_bytes(b, h * w, nb, pre_max, post_max)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            if stateful:
+                # the previous sectors' detections compete in this sector's NMS; this sector's candidates are rotated into the sweep's
+                # frame first; the output may hold nms_post_max_size * (sec_id + 1) boxes
+                interval = float(get("interval")) if sec_id > 0 else 0.0
+                angle = (interval * sec_id if cyl else 2 * 3.141592653589793 / interval * sec_id) if sec_id > 0 else 0.0
+                prev = None if prev_dets is None else prev_dets[task_id]
+                pcap = 0 if prev is None else max([int(d["scores"].numel()) for d in prev] + [0])
+                pmax = post_max * (sec_id + 1)
+                f32 = dict(dtype=torch.float32, device=dev)
+                pb = torch.zeros((b, max(pcap, 1), nb), **f32)
+                ps = torch.zeros((b, max(pcap, 1)), **f32)
+                pl = torch.zeros((b, max(pcap, 1)), dtype=torch.int64, device=dev)
+                pc = torch.zeros((b,), dtype=torch.int32, device=dev)
+                if pcap:
+                    for i, d in enumerate(prev):
+                        n = int(d["scores"].numel())
+                        pb[i, :n].copy_(d["box3d_lidar"])
+                        ps[i, :n].copy_(d["scores"])
+                        pl[i, :n].copy_(d["label_preds"])
+                        pc[i] = n
+                out_boxes = torch.empty((b, pmax, nb), **f32)
+                out_scores = torch.empty((b, pmax), **f32)
+                out_labels = torch.empty((b, pmax), dtype=torch.int64, device=dev)
+                out_cells = torch.empty((b, pmax), dtype=torch.int32, device=dev)
+                wsb = lib.pn_center_decode_nms_workspace_bytes(b, h * w + pcap, nb, pre_max, pmax)
+                ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                hip.call("pn_center_decode_nms_stateful_f32", hm.data_ptr(), hm.stride(3), ncls, pd["reg"].data_ptr(), pd["reg"].stride(3),
+                         pd["height"].data_ptr(), pd["height"].stride(3), pd["dim"].data_ptr(), pd["dim"].stride(3), pd["rot"].data_ptr(),
+                         pd["rot"].stride(3), hip.ptr(vel), 0 if vel is None else vel.stride(3), b, h, w, cyl, float(osf) * float(vs[0]),
+                         float(osf) * float(vs[1]), float(pr[0]), float(pr[1]), int(bool(get("rectify", False))), float(get("score_threshold")),
+                         (C.c_float * 6)(*[float(v) for v in pcr]), iou_thr, int(per_class), pre_max, pmax, float(angle), pb.data_ptr(), ps.data_ptr(),
+                         pl.data_ptr(), pc.data_ptr(), pcap, out_boxes.data_ptr(), out_scores.data_ptr(), out_labels.data_ptr(), out_cells.data_ptr(),
+                         out_count.data_ptr(), ws.data_ptr(), wsb, hip.stream())
+                counts = out_count.cpu().tolist()
+                rets.append([dict(box3d_lidar=out_boxes[i, :n], scores=out_scores[i, :n], label_preds=out_labels[i, :n], cells=out_cells[i, :n])
+                             for i, n in enumerate(counts)])
+                continue
             hip.call(decode_fn, hm.data_ptr(), hm.stride(3), ncls, pd["reg"].data_ptr(), pd["reg"].stride(3),
                      pd["height"].data_ptr(), pd["height"].stride(3), pd["dim"].data_ptr(), pd["dim"].stride(3), pd["rot"].data_ptr(),
                      pd["rot"].stride(3), hip.ptr(vel), 0 if vel is None else vel.stride(3), b, h, w, cyl, float(osf) * float(vs[0]),
@@ -258,6 +296,8 @@ class CenterHead(nn.Module):
             counts = out_count.cpu().tolist()  # the one host sync of the call: the API returns exact-size tensors
             rets.append([dict(box3d_lidar=out_boxes[i, :n], scores=out_scores[i, :n], label_preds=out_labels[i, :n], cells=out_cells[i, :n])
                          for i, n in enumerate(counts)])
+        if stateful:
+            return rets   # per task, per sample, unmerged: the next sector's prev_dets (center_head.py:439-440)
         metas = example.get("metadata", [None] * len(rets[0])) if isinstance(example, dict) else [None] * len(rets[0])
         if double_flip:
             metas = list(metas)[::4] if len(metas) >= 4 * len(rets[0]) else metas   # meta_list[:4 * batch:4]

@@ -128,6 +128,8 @@ SIGNATURES = {
                                       _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "pn_center_decode_nms_merged_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _P, _F, _I, _I, _I,
                                              _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "pn_center_decode_nms_stateful_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _P, _F, _I, _I, _I,
+                                               C.c_double, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "pn_double_flip_merge_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "pn_swv_decode_nms_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _F, _P, _F, _I, _I, _I,
                                    _P, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -168,3 +168,14 @@ def test_polarstream_detector_streams_sectors(dev):
         ref_boxes = S.rotate_sector_boxes(alone[b]["box3d_lidar"].cpu().numpy(), interval * sec)
         np.testing.assert_allclose(rot[b]["box3d_lidar"].cpu().numpy(), ref_boxes, rtol=1e-6, atol=1e-6)
         assert torch.equal(rot[b]["scores"], alone[b]["scores"])
+    # ---- the reference's 4-sector configs run with stateful NMS (polarstream_det_n_seg_4_sector_*.py:104): one NMS over the
+    # detections carried from sector to sector; the sweep's list = the LAST sector's output in score order, at most
+    # post_max * nsectors boxes (the kernel-level parity of the chain is tests/test_hip_postproc.py::test_stateful_nms_across_sectors)
+    model.test_cfg = dict(test_cfg, stateful_nms=True)
+    sdets = model(examples, return_loss=False)["det"]
+    assert len(sdets) == batch
+    for b in range(batch):
+        n = sdets[b]["scores"].numel()
+        assert 0 < n <= 40 * nsec and sdets[b]["box3d_lidar"].shape == (n, 9) and sdets[b]["metadata"] is None
+        assert torch.isfinite(sdets[b]["box3d_lidar"]).all() and bool((sdets[b]["scores"][:-1] >= sdets[b]["scores"][1:]).all())
+    model.test_cfg = test_cfg
