@@ -69,6 +69,17 @@ def test_reference_configs_load_unchanged():
     assert sum(p.numel() for p in head.parameters()) == 3895549
 
 
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_reference_streaming_config_builds_unchanged():
+    """the reference's 4-sector trailing-edge streaming config (PolarStream + RPNTECP, stateful + per-class NMS) builds from the file as it is"""
+    cfg = P.Config.fromfile(os.path.join(REF, "configs/nusc/pp/polarstream/polarstream_det_n_seg_4_sector_trailing_edge.py"))
+    m = P.build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    assert (type(m).__name__, type(m.neck).__name__, type(m.bbox_head).__name__) == ("PolarStream", "RPNTECP", "CenterHeadSinglePos")
+    assert m.test_cfg["stateful_nms"] and m.test_cfg["per_class_nms"] and not m.test_cfg["panoptic"]
+    assert abs(m.test_cfg["interval"] - 2 * 3.1488 / 4) < 1e-3
+    assert [type(d[0]).__name__ for d in m.neck.deblocks] == ["Conv2d", "Conv2d", "ConvTranspose2d"]   # us strides 0.5, 1, 2 (rpn.py:80-110: ConvTranspose2d only above 1)
+
+
 def test_swv_oracle_window_bookkeeping():
     """window partition / reverse are inverses, the shift mask separates exactly the wrapped regions (H3 oracle helpers)"""
     import torch
