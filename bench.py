@@ -277,7 +277,7 @@ def run_train_partner(args, dev, rank, world, red_dev, steps, warmup):
     vg = VoxelGenerator(synth.WAYMO_VOXEL, synth.WAYMO_RANGE, 5, 150000)
     vs, cs, ns, counts = [], [], [], []
     for b in range(B):
-        sw = torch.from_numpy(synth.synth_sweep_polar(180000, seed=rank * B + b, rho_max=74.0)).to(dev)
+        sw = torch.from_numpy(synth.synth_sweep_beams_polar(180000, seed=rank * B + b)).to(dev)
         voxels, coors, num = vg.generate(sw)
         vs.append(voxels)
         ns.append(num)

@@ -203,14 +203,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int i = threadIdx.x; i < 2 * c; i += 256) part[(size_t)blockIdx.x * 2 * c + i] = acc[i];
 }
 
-__global__ void layernorm_bwd_fold_kernel(const double* __restrict__ part, int nblocks, int c, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                          int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * c) return;
+// one block per output value (dgamma[c] or dbeta[c]): lane-strided partial sums over the row blocks, then a fixed-shape tree in LDS
+__global__ __launch_bounds__(256) void layernorm_bwd_fold_kernel(const double* __restrict__ part, int nblocks, int c, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, int accumulate) {
+  __shared__ double red[256];
+  const int i = blockIdx.x;   // 0 .. 2c-1
   double t = 0.0;
-  for (int b = 0; b < nblocks; ++b) t += part[(size_t)b * 2 * c + i];
-  float* dst = i < c ? dgamma + i : dbeta + (i - c);
-  *dst = accumulate ? *dst + (float)t : (float)t;
+  for (int b = threadIdx.x; b < nblocks; b += 256) t += part[(size_t)b * 2 * c + i];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float* dst = i < c ? dgamma + i : dbeta + (i - c);
+    *dst = accumulate ? *dst + (float)red[0] : (float)red[0];
+  }
 }
 
 __global__ void gelu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
@@ -429,8 +438,8 @@ int pn_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, fl
   const int nb = (int)((rows + kLnRowsPerBlock - 1) / kLnRowsPerBlock);
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), (size_t)2 * c * sizeof(double), pn::S(stream), x, dy, gamma, eps, rows, c, dx,
                      static_cast<double*>(workspace));
-  hipLaunchKernelGGL(layernorm_bwd_fold_kernel, dim3(pn::cdiv(2 * c, 256)), dim3(256), 0, pn::S(stream), static_cast<const double*>(workspace), nb, c,
-                     dgamma, dbeta, accumulate);
+  hipLaunchKernelGGL(layernorm_bwd_fold_kernel, dim3(2 * c), dim3(256), 0, pn::S(stream), static_cast<const double*>(workspace), nb, c, dgamma, dbeta,
+                     accumulate);
   return pn::check_launch("layernorm_bwd");
 }
 

@@ -151,7 +151,7 @@ def test_partner_training_step_full_size_waymo_config(dev):
     vg = VoxelGenerator(synth.WAYMO_VOXEL, synth.WAYMO_RANGE, 5, 150000)
     vs, cs, ns, counts = [], [], [], []
     for b in range(2):
-        sw = torch.from_numpy(synth.synth_sweep_polar(180000, seed=b, rho_max=74.0)).to(dev)
+        sw = torch.from_numpy(synth.synth_sweep_beams_polar(180000, seed=b)).to(dev)
         voxels, coors, num = vg.generate(sw)
         vs.append(voxels)
         ns.append(num)
