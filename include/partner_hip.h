@@ -866,6 +866,15 @@ typedef struct {
   int32_t norm_strata;
   int32_t norm_channels;
 } pn_conv_job;
+/* A plain 3x3 / stride 1 / pad 1 / groups 1 layer (map width even; BatchNorm folded into scale / shift, activation in the epilogue)
+ * with a one-dimensional Winograd transform F(2, 3) along the width: four GEMMs over pairs of adjacent output pixels, 6 instead of 9
+ * MFMA-equivalents per output.  The transformed operands are formed in registers (inputs) / at pack time (weights:
+ * pn_pack_conv_weight_wino_f32 from torch layout (Cout, Cin, 3, 3)); results agree with pn_conv2d_nhwc_f32 to ~1e-6 relative.
+ * rpn.py:124-142 (the stride-1 convolutions of every block). */
+size_t pn_conv_wino_packed_weight_floats(int cout, int cin);
+int pn_pack_conv_weight_wino_f32(const float *w_oihw, int cout, int cin, float *packed, pn_stream_t stream);
+int pn_conv2d_wino_nhwc_f32(const pn_conv_desc *desc, const float *in, const float *packed_w, const float *scale,
+                            const float *shift, float *out, pn_stream_t stream);
 size_t pn_conv_stat_partial_floats(const pn_conv_desc *desc, int tile);
 int pn_conv2d_multi_f32(const pn_conv_job *jobs, int njobs, int tile, pn_stream_t stream);
 /* the same job list on the VALU kernel for convolutions with very few output columns (1x1 / 3x3, <= 64 input channels,

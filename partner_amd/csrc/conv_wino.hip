@@ -1,0 +1,361 @@
+// 3x3 / stride-1 / pad-1 convolution with a one-dimensional Winograd transform F(2, 3) along the image width, on the fp32 MFMA.
+// Replaces (arithmetic) the same Conv2d + folded BatchNorm + ReLU layers of the RPN as conv_mfma.hip does
+// (det3d/models/necks/rpn.py:124-142) -- those layers are MFMA-bound, and F(2, 3) needs 4 products for 2 outputs of a 3-tap
+// filter: 6 instead of 9 MFMA-equivalents per output (1.5x fewer matrix cycles) at unchanged accumulator and staging budgets.
+//
+//   For a PAIR of horizontally adjacent outputs (x = 2p, 2p + 1) of one row and the four input pixels d0..d3 at x = 2p-1 .. 2p+2
+//   of input row y + kh - 1:   m0 = (d0 - d2) g0     m1 = (d1 + d2) (g0 + g1 + g2) / 2     m2 = (d2 - d1) (g0 - g1 + g2) / 2     m3 = (d1 - d3) g2
+//   out[2p] = sum_kh sum_ci (m0 + m1 + m2),   out[2p + 1] = sum_kh sum_ci (m1 - m2 - m3)        (g = the three kw taps of row kh).
+//   So the layer is FOUR independent GEMMs (one per Winograd position q) with M = pairs, N = Cout, K = 3 * Cin, whose A operands are
+//   sums / differences of two input pixels (formed in registers on the way into LDS: no transformed tensor is ever materialised)
+//   and whose B operands are the transformed weights (packed once).  A block = 64 pairs (128 output pixels) x 64 columns; wave q
+//   runs GEMM q on a 64 x 64 wave tile (the 2 x 2 MFMA tiling of the 128 x 128 direct tile); the output transform joins the four
+//   waves' tiles through LDS in the epilogue, where the per-channel affine and the activation are applied as in the direct kernel.
+//
+// K step = 32 input channels of one kernel row kh: A stage [4 q][64 pairs][32 + 4], B stage [4 q][8 k4][64 cols][4] floats
+// (69.6 KB; two stages).  MFMA operand layouts are those of conv_mfma.hip.
+// Numerics: every product differs from the direct form by the rounding of one extra add on each operand (|error| ~ 1e-7 relative
+// per term); the parity tests hold the same 1e-4 bound as the direct kernel.
+#include "pn_common.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int WP = 64;                          // pairs per block tile
+constexpr int WBN = 64;                         // output columns per block tile
+constexpr int WA_LD = 36;                       // floats per A row (32 channels + pad)
+constexpr int WA_FLOATS = 4 * WP * WA_LD;       // 9216
+constexpr int WB_FLOATS = 4 * 8 * WBN * 4;      // 8192
+constexpr int WSTAGE = WA_FLOATS + WB_FLOATS;   // 17408 floats
+constexpr size_t kWinoSmem = 2 * (size_t)WSTAGE * sizeof(float);
+
+struct WinoArgs {
+  const float* in;
+  const float* w;
+  const float* scale;
+  const float* shift;
+  float* out;
+  int B, H, W, Cin, Cout;
+  int in_ps, in_co, out_ps, out_co;
+  int act;
+  int pairs_per_row, total_pairs, ptiles;
+  int chunks, cout_pad;
+  unsigned in_bytes, w_bytes;
+};
+
+// NW = 4: wave q = position q on a 64 x 64 wave tile; NW = 8: waves q and q + 4 share position q and take 32 columns each
+// (64 x 32 wave tiles, two waves per SIMD: the second wave fills the first one's barrier / staging bubbles)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
+  constexpr int NT = NW * 64;
+  constexpr int PPT = (WP * 8) / NT;       // pairs per thread in the loader (2 or 1)
+  constexpr int BPT = (4 * 8 * WBN) / NT;  // weight float4 per thread (8 or 4)
+  constexpr int TN = NW == 4 ? 2 : 1;      // 32-column MFMA tiles per wave
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wq = wave & 3, wc = wave >> 2;   // position, column half (NW == 8)
+  // XCD-aware order: blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of pair tiles
+  int pt;
+  {
+    const int bid = blockIdx.x, q = a.ptiles >> 3, r = a.ptiles & 7, x = bid & 7, idx = bid >> 3;
+    pt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+    if (idx >= (x < r ? q + 1 : q)) return;
+  }
+  const int n0 = blockIdx.y * WBN;
+  const int pl = tid >> 3, c4 = tid & 7;
+
+  // ---- loader state: PPT pairs per thread, four input pixels each
+  const long long back = ((long long)a.W + 1) * a.in_ps;   // floats: the descriptor base is moved back so that every voffset >= 0
+  unsigned a_off[PPT];     // byte offset of pixel (b, oh - 1, 2 owp - 1), channel in_co + 4 c4, relative to the shifted base
+  unsigned a_rmask[PPT];   // bit kh: input row oh + kh - 1 inside the map
+  unsigned a_cmask[PPT];   // bit j: input column 2 owp - 1 + j inside the map
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int p = pt * WP + pl + (NT / 8) * k;
+    const bool ok = p < a.total_pairs;
+    const int pp = ok ? p : 0;
+    const int rowi = pp / a.pairs_per_row, owp = pp - rowi * a.pairs_per_row;
+    const int b = rowi / a.H, oh = rowi - b * a.H;
+    const long long pix = ((long long)b * a.H + (oh - 1)) * a.W + (2 * owp - 1);
+    a_off[k] = (unsigned)((pix * a.in_ps + back + a.in_co + c4 * 4) * 4);
+    unsigned rm = 0, cm = 0;
+    for (int kh = 0; kh < 3; ++kh)
+      if (ok && (unsigned)(oh + kh - 1) < (unsigned)a.H) rm |= 1u << kh;
+    for (int j = 0; j < 4; ++j)
+      if ((unsigned)(2 * owp - 1 + j) < (unsigned)a.W) cm |= 1u << j;
+    a_rmask[k] = rm;
+    a_cmask[k] = cm;
+  }
+  unsigned b_off[BPT];
+#pragma unroll
+  for (int j = 0; j < BPT; ++j) {
+    const int idx = tid + NT * j;                 // (q, k4, col)
+    const int col = idx & (WBN - 1), k4 = (idx >> 6) & 7, q = idx >> 9;
+    b_off[j] = (n0 + col < a.cout_pad) ? (unsigned)((((size_t)q * 8 + k4) * a.cout_pad + n0 + col) * 16) : 0xffffffffu;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<float*>(a.in)) - back * 4, 0,
+                                                                         a.in_bytes + (unsigned)(back * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+
+  const int nsteps = 3 * a.chunks;
+  int ld_kh = 0, ld_chunk = 0;   // K order: channel chunk outermost, kernel rows innermost
+  f32x4 ra[PPT][4], rb[BPT], ra2[PPT][4], rb2[BPT];
+  auto load_global = [&](bool live, f32x4 (&ra)[PPT][4], f32x4 (&rb)[BPT]) {
+    const unsigned so_a = (unsigned)((ld_kh * a.W * a.in_ps + ld_chunk * 32) * 4);
+    const unsigned so_b = (unsigned)((ld_chunk * 3 + ld_kh) * 32) * (unsigned)a.cout_pad * 16u;   // [chunk][kh][q][k4][col][4]
+    const bool cok = live && ld_chunk * 32 + c4 * 4 < a.Cin;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const bool rok = cok && ((a_rmask[k] >> ld_kh) & 1u);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned vo = (rok && ((a_cmask[k] >> j) & 1u)) ? a_off[k] + (unsigned)(j * a.in_ps * 4) : 0xffffffffu;
+        ra[k][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, so_a, 0));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BPT; ++j)
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, live ? b_off[j] : 0xffffffffu, live ? so_b : 0u, 0));
+    if (++ld_kh == 3) { ld_kh = 0; ++ld_chunk; }
+  };
+  auto store_lds = [&](int buf, const f32x4 (&ra)[PPT][4], const f32x4 (&rb)[BPT]) {
+    float* As = smem + buf * WSTAGE;
+    float* Bs = As + WA_FLOATS;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int pair = pl + (NT / 8) * k;
+      const f32x4 d0 = ra[k][0], d1 = ra[k][1], d2 = ra[k][2], d3 = ra[k][3];
+      *reinterpret_cast<f32x4*>(As + (0 * WP + pair) * WA_LD + c4 * 4) = d0 - d2;
+      *reinterpret_cast<f32x4*>(As + (1 * WP + pair) * WA_LD + c4 * 4) = d1 + d2;
+      *reinterpret_cast<f32x4*>(As + (2 * WP + pair) * WA_LD + c4 * 4) = d2 - d1;
+      *reinterpret_cast<f32x4*>(As + (3 * WP + pair) * WA_LD + c4 * 4) = d1 - d3;
+    }
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) *reinterpret_cast<f32x4*>(Bs + (size_t)(tid + NT * j) * 4) = rb[j];
+  };
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int a_frag = (wq * WP + li) * WA_LD + lh * 4;
+  const int b_frag = WA_FLOATS + ((wq * 8 + lh) * WBN + wc * 32 + li) * 4;
+  f32x4 af[2][2], bf[2][TN];
+  auto read_frags = [&](int buf, int sub, f32x4 (&fa)[2], f32x4 (&fb)[TN]) {
+    const float* As = smem + buf * WSTAGE + a_frag + sub * 8;
+    const float* Bs = smem + buf * WSTAGE + b_frag + sub * 2 * WBN * 4;
+    fa[0] = *reinterpret_cast<const f32x4*>(As);
+    fa[1] = *reinterpret_cast<const f32x4*>(As + 32 * WA_LD);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * 4);
+  };
+  auto mfma_sub = [&](const f32x4 (&fa)[2], const f32x4 (&fb)[TN]) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+  };
+
+  // ---- software pipeline (the schedule of conv_mfma.hip): one barrier per K step, everything else in the shadow of the MFMAs
+  //   sub-step 0: fragments of sub-step 1                                   | MFMAs of sub-step 0
+  //   sub-step 1: fragments of sub-step 2; Winograd input transform + LDS stores of step t+1 into the other stage
+  //   sub-step 2: fragments of sub-step 3; buffer loads of step t+3 into the registers just stored (two sets alternate)
+  //   barrier;  sub-step 3: first fragments of step t+1                     | MFMAs of sub-step 3
+  {
+    f32x4 ra0[PPT][4], rb0[BPT];
+    load_global(true, ra0, rb0);
+    load_global(nsteps > 1, ra, rb);
+    load_global(nsteps > 2, ra2, rb2);
+    store_lds(0, ra0, rb0);
+  }
+  __syncthreads();
+  read_frags(0, 0, af[0], bf[0]);
+  constexpr int NM = 4 * 2 * TN;           // MFMAs per sub-step
+  constexpr int NF = 2 + TN;               // fragment reads per sub-step
+  constexpr int NSA = PPT * 4, NSB = BPT;  // LDS stores per step (A rows, B quads) == buffer loads per step
+  constexpr int NS = NSA + NSB;
+  auto kstep = [&](int t, int buf, f32x4 (&rx)[PPT][4], f32x4 (&ry)[BPT]) {
+    read_frags(buf, 1, af[1], bf[1]);
+    mfma_sub(af[0], bf[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(buf, 2, af[0], bf[0]);
+    mfma_sub(af[1], bf[1]);
+    store_lds(buf ^ 1, rx, ry);
+    __builtin_amdgcn_sched_group_barrier(0x100, NF, 1);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, NM / NS > 0 ? NM / NS : 1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 1);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 1);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(buf, 3, af[1], bf[1]);
+    mfma_sub(af[0], bf[0]);
+    load_global(t + 3 < nsteps, rx, ry);
+    __builtin_amdgcn_sched_group_barrier(0x100, NF, 2);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, NM / NS > 0 ? NM / NS : 1, 2);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 2);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 2);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    read_frags(buf ^ 1, 0, af[0], bf[0]);
+    mfma_sub(af[1], bf[1]);
+    __builtin_amdgcn_sched_group_barrier(0x100, NF, 3);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 3);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int t = 0; t < nsteps; t += 2) {
+    kstep(t, 0, ra, rb);
+    if (t + 1 < nsteps) kstep(t + 1, 1, ra2, rb2);
+  }
+  __syncthreads();   // every wave is done with the last stage before the epilogue reuses the LDS
+
+  // ---- epilogue: the four positions' tiles through LDS, output transform, affine + activation, two pixels per pair
+  constexpr int TLD = WBN + 4;
+  float* T = smem;   // [4 q][64 pairs][TLD]: 69.6 KB, the staging buffers are free (the loop ended with a barrier)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        T[(wq * WP + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + wc * 32 + j * 32 + li] = acc[i][j][r];
+  __syncthreads();
+  const bool vec_cols = (a.out_ps % 4 == 0) && (a.out_co % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
+#pragma unroll
+  for (int k = 0; k < 1024 / NT; ++k) {
+    const int item = tid + NT * k;
+    const int cq = item & 15, pair = item >> 4;
+    const int p = pt * WP + pair;
+    const int col = n0 + cq * 4;
+    if (p >= a.total_pairs || col >= a.Cout) continue;
+    const f32x4 m0 = *reinterpret_cast<const f32x4*>(T + (0 * WP + pair) * TLD + cq * 4);
+    const f32x4 m1 = *reinterpret_cast<const f32x4*>(T + (1 * WP + pair) * TLD + cq * 4);
+    const f32x4 m2 = *reinterpret_cast<const f32x4*>(T + (2 * WP + pair) * TLD + cq * 4);
+    const f32x4 m3 = *reinterpret_cast<const f32x4*>(T + (3 * WP + pair) * TLD + cq * 4);
+    f32x4 y0 = (m0 + m1) + m2, y1 = (m1 - m2) - m3;
+    const int rowi = p / a.pairs_per_row, owp = p - rowi * a.pairs_per_row;
+    float* o = a.out + ((size_t)rowi * a.W + 2 * owp) * a.out_ps + a.out_co + col;
+    const int nvalid = min(4, a.Cout - col);
+    if (vec_cols && nvalid == 4) {
+      f32x4 vs = {1.f, 1.f, 1.f, 1.f}, vh = {0.f, 0.f, 0.f, 0.f};
+      if (a.scale) vs = *reinterpret_cast<const f32x4*>(a.scale + col);
+      if (a.shift) vh = *reinterpret_cast<const f32x4*>(a.shift + col);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        y0[c] = pn::apply_act(fmaf(y0[c], vs[c], vh[c]), a.act);
+        y1[c] = pn::apply_act(fmaf(y1[c], vs[c], vh[c]), a.act);
+      }
+      *reinterpret_cast<f32x4*>(o) = y0;
+      *reinterpret_cast<f32x4*>(o + a.out_ps) = y1;
+    } else {
+      for (int c = 0; c < nvalid; ++c) {
+        const float sc = a.scale ? a.scale[col + c] : 1.f, sh = a.shift ? a.shift[col + c] : 0.f;
+        o[c] = pn::apply_act(fmaf(y0[c], sc, sh), a.act);
+        o[a.out_ps + c] = pn::apply_act(fmaf(y1[c], sc, sh), a.act);
+      }
+    }
+  }
+}
+
+// torch (Cout, Cin, 3, 3) -> [chunk][kh][q][k4 (8)][cout_pad][4]: U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2
+__global__ void pack_wino_weight_kernel(const float* __restrict__ w, int cout, int cin, int chunks, int cout_pad, float* __restrict__ packed, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int k1 = r & 3; r >>= 2;
+    const int n = (int)(r % cout_pad); r /= cout_pad;
+    const int k4 = r & 7; r >>= 3;
+    const int q = r & 3; r >>= 2;
+    const int kh = (int)(r % 3);
+    const int chunk = (int)(r / 3);
+    const int c = chunk * 32 + k4 * 4 + k1;
+    float v = 0.f;
+    if (n < cout && c < cin) {
+      const float* g = w + (((size_t)n * cin + c) * 3 + kh) * 3;
+      v = q == 0 ? g[0] : q == 1 ? (g[0] + g[1] + g[2]) * 0.5f : q == 2 ? (g[0] - g[1] + g[2]) * 0.5f : g[2];
+    }
+    packed[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pn_conv_wino_packed_weight_floats(int cout, int cin) {
+  return (size_t)pn::cdiv(cin, 32) * 3 * 4 * 8 * (size_t)(pn::cdiv(cout, WBN) * WBN) * 4;
+}
+
+int pn_pack_conv_weight_wino_f32(const float* w_oihw, int cout, int cin, float* packed, pn_stream_t stream) {
+  PN_REQUIRE(w_oihw && packed && cout >= 1 && cin >= 1, "pack_conv_weight_wino: bad arguments");
+  const int chunks = pn::cdiv(cin, 32), cout_pad = pn::cdiv(cout, WBN) * WBN;
+  const size_t total = pn_conv_wino_packed_weight_floats(cout, cin);
+  hipLaunchKernelGGL(pack_wino_weight_kernel, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0, pn::S(stream), w_oihw, cout, cin, chunks,
+                     cout_pad, packed, total);
+  return pn::check_launch("pack_wino_weight_kernel");
+}
+
+int pn_conv2d_wino_nhwc_f32(const pn_conv_desc* d, const float* in, const float* packed_w, const float* scale, const float* shift, float* out,
+                            pn_stream_t stream) {
+  PN_REQUIRE(d && in && packed_w && out, "conv_wino: null pointer");
+  PN_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->groups == 1 && !d->deconv2x2 && d->range_strata <= 1 &&
+                 !d->accumulate,
+             "conv_wino: plain 3x3 / stride 1 / pad 1 convolutions only");
+  PN_REQUIRE(d->batch >= 1 && d->in_h >= 1 && d->in_w >= 2 && d->in_w % 2 == 0, "conv_wino: the map width must be even");
+  PN_REQUIRE(d->cin >= 4 && d->cin % 4 == 0 && d->in_pixel_stride % 4 == 0 && d->in_channel_offset % 4 == 0 && d->cout >= 1,
+             "conv_wino: cin, input pixel stride and channel offset must be multiples of 4");
+  PN_REQUIRE(d->in_pixel_stride >= d->in_channel_offset + d->cin && d->out_pixel_stride >= d->out_channel_offset + d->cout,
+             "conv_wino: channel slice does not fit the pixel stride");
+  PN_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "conv_wino: pointers must be 16-byte aligned");
+  const unsigned long long in_bytes = (unsigned long long)d->batch * d->in_h * d->in_w * d->in_pixel_stride * 4ull;
+  PN_REQUIRE(in_bytes + ((unsigned long long)d->in_w + 1) * d->in_pixel_stride * 4ull < (1ull << 32), "conv_wino: input map too large for the buffer descriptor");
+  WinoArgs a{};
+  a.in = in; a.w = packed_w; a.scale = scale; a.shift = shift; a.out = out;
+  a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Cin = d->cin; a.Cout = d->cout;
+  a.in_ps = d->in_pixel_stride; a.in_co = d->in_channel_offset; a.out_ps = d->out_pixel_stride; a.out_co = d->out_channel_offset;
+  a.act = d->act;
+  a.pairs_per_row = d->in_w / 2;
+  a.total_pairs = d->batch * d->in_h * a.pairs_per_row;
+  a.ptiles = pn::cdiv(a.total_pairs, WP);
+  a.chunks = pn::cdiv(d->cin, 32);
+  a.cout_pad = pn::cdiv(d->cout, WBN) * WBN;
+  a.in_bytes = (unsigned)in_bytes;
+  a.w_bytes = (unsigned)(pn_conv_wino_packed_weight_floats(d->cout, d->cin) * 4);
+  static bool attr_done[64] = {false};
+  if (pn::first_use_on_device(attr_done)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoSmem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoSmem);
+  }
+  static const int waves = [] { const char* e = getenv("PN_WINO_WAVES"); return e ? atoi(e) : 8; }();
+  const dim3 grid(pn::cdiv(a.ptiles, 8) * 8, a.cout_pad / WBN);
+  pn::ProfileSlot ps;
+  const bool prof = pn::take_profile_slot(ps);
+  if (waves == 4) {
+    if (prof) hipExtLaunchKernelGGL(conv_wino_kernel<4>, grid, dim3(256), kWinoSmem, pn::S(stream), ps.start, ps.stop, 0, a);
+    else hipLaunchKernelGGL(conv_wino_kernel<4>, grid, dim3(256), kWinoSmem, pn::S(stream), a);
+  } else {
+    if (prof) hipExtLaunchKernelGGL(conv_wino_kernel<8>, grid, dim3(512), kWinoSmem, pn::S(stream), ps.start, ps.stop, 0, a);
+    else hipLaunchKernelGGL(conv_wino_kernel<8>, grid, dim3(512), kWinoSmem, pn::S(stream), a);
+  }
+  return pn::check_launch("conv_wino_kernel");
+}
+
+}  // extern "C"

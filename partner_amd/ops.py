@@ -7,6 +7,7 @@ nothing falls back to PyTorch arithmetic.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 
@@ -356,6 +357,10 @@ def disable_conv_profiling() -> None:
     _PROFILER = None
 
 
+_WINO_ON = os.environ.get("PN_CONV_WINO", "1") != "0"
+_WINO_MIN_TILES = int(os.environ.get("PN_CONV_WINO_MIN_TILES", "256"))
+
+
 class ConvLayer:
     """One packed convolution (+ per-channel affine + activation) on NHWC maps.
 
@@ -406,6 +411,13 @@ class ConvLayer:
         self.shift = None if shift is None else shift.detach().contiguous().float()
         self.out_channels = self.cout * (self.groups if not deconv2x2 else 1)
         self._pack_cin = self.cin
+        # plain 3x3 / stride 1 / pad 1 layers also keep the width-Winograd F(2, 3) weights (conv_wino.hip: 6 instead of 9 MFMA
+        # equivalents per output); used when the map is large enough to fill the chip with its 64-pair x 64-column tiles
+        self.wino_packed = None
+        if (dtype == "f32" and not deconv2x2 and self.range_strata <= 1 and self.groups == 1 and (self.kh, self.kw) == (3, 3)
+                and self.stride == 1 and self.pad == (1, 1) and self.cin % 4 == 0 and _WINO_ON):
+            self.wino_packed = _f32(lib.pn_conv_wino_packed_weight_floats(self.cout, self.cin), dev)
+            hip.call("pn_pack_conv_weight_wino_f32", w.data_ptr(), self.cout, self.cin, self.wino_packed.data_ptr(), st)
 
     def repack(self, weight: torch.Tensor, shift: Optional[torch.Tensor] = None) -> None:
         """refresh the packed copy from an updated weight of the same shape (training: once per step)"""
@@ -418,8 +430,16 @@ class ConvLayer:
             pack_groups = self.range_strata if self.range_strata > 1 else self.groups
             hip.call("pn_pack_conv_weight_f32", w.data_ptr(), w.shape[0], self._pack_cin, self.kh, self.kw, pack_groups,
                      self.packed.data_ptr(), st)
+            if self.wino_packed is not None:
+                hip.call("pn_pack_conv_weight_wino_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino_packed.data_ptr(), st)
         if shift is not None:
             self.shift = shift
+
+    def _use_wino(self, b: int, h: int, w: int, accumulate: bool) -> bool:
+        if self.wino_packed is None or accumulate or w % 2 or self.cin != self._pack_cin:
+            return False
+        tiles = ((b * h * (w // 2) + 63) // 64) * ((self.cout + 63) // 64)
+        return tiles >= _WINO_MIN_TILES
 
     def pad_input_channels(self, cin_padded: int) -> "ConvLayer":
         """declare that the input map carries zero pad channels up to a multiple of 4 (e.g. the 5-channel
@@ -468,8 +488,13 @@ class ConvLayer:
         prof = _PROFILER
         if prof is not None:
             ev = prof.begin(st)
-        hip.call("pn_conv2d_nhwc_f32", C.byref(d), x.data_ptr(), self.packed.data_ptr(), hip.ptr(self.scale),
-                 hip.ptr(self.shift), out.data_ptr(), st)
+        use_wino = self._use_wino(b, h, w, accumulate)
+        if use_wino:
+            hip.call("pn_conv2d_wino_nhwc_f32", C.byref(d), x.data_ptr(), self.wino_packed.data_ptr(), hip.ptr(self.scale), hip.ptr(self.shift),
+                     out.data_ptr(), st)
+        else:
+            hip.call("pn_conv2d_nhwc_f32", C.byref(d), x.data_ptr(), self.packed.data_ptr(), hip.ptr(self.scale),
+                     hip.ptr(self.shift), out.data_ptr(), st)
         if prof is not None:
             # algorithmic FLOPs = 2 * output pixels * Cout * Cin * KH * KW (per group), dense-conv count
             if self.deconv2x2:
@@ -477,7 +502,7 @@ class ConvLayer:
             else:
                 z = self.groups
                 macs = b * oh * ow * z * self.cout * self.cin * self.kh * self.kw
-            prof.end(ev, 2.0 * macs, st, tag=f"{oh}x{ow} {self.cin * self.groups}->{self.out_channels} k{self.kh}{'t' if self.deconv2x2 else ''}{'s' if self.range_strata > 1 else ''}")
+            prof.end(ev, 2.0 * macs, st, tag=f"{oh}x{ow} {self.cin * self.groups}->{self.out_channels} k{self.kh}{'t' if self.deconv2x2 else ''}{'s' if self.range_strata > 1 else ''}{' F(2,3)' if use_wino else ''}")
         return out
 
 

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Parity (vs the direct MFMA convolution and vs torch f64) and kernel time of the width-Winograd F(2,3) convolution on the RPN's
+stride-1 3x3 layers.  python tools/wino_bench.py"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from partner_amd import hip, ops
+
+torch.manual_seed(0)
+dev = torch.device("cuda:0")
+lib = hip.load()
+
+
+def wino(x, w, scale, shift, act):
+    b, h, wd, cin = x.shape
+    cout = w.shape[0]
+    packed = torch.empty(lib.pn_conv_wino_packed_weight_floats(cout, cin), dtype=torch.float32, device=dev)
+    hip.call("pn_pack_conv_weight_wino_f32", w.contiguous().data_ptr(), cout, cin, packed.data_ptr(), hip.stream())
+    d = ops.ConvDesc(b, h, wd, cin, cout, 1, 3, 3, 1, 1, 1, cin, 0, cout, 0, act, 0, 0)
+    out = torch.empty((b, h, wd, cout), dtype=torch.float32, device=dev)
+
+    def run():
+        hip.call("pn_conv2d_wino_nhwc_f32", C.byref(d), x.data_ptr(), packed.data_ptr(), hip.ptr(scale), hip.ptr(shift), out.data_ptr(), hip.stream())
+        return out
+    return run
+
+
+def timeit(fn, n=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+for (b, h, wd, cin, cout) in [(1, 256, 256, 128, 128), (1, 128, 128, 128, 128), (1, 64, 64, 256, 256), (2, 30, 22, 36, 70), (1, 7, 6, 8, 5)]:
+    x = torch.randn((b, h, wd, cin), device=dev)
+    w = torch.randn((cout, cin, 3, 3), device=dev) * 0.05
+    scale = torch.rand(cout, device=dev) + 0.5
+    shift = torch.randn(cout, device=dev)
+    direct = ops.ConvLayer(w, stride=1, pad=1, scale=scale, shift=shift, act=ops.ACT_RELU)
+    run = wino(x, w, scale, shift, ops.ACT_RELU)
+    yd, yw = direct(x), run()
+    ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1) * scale.double()[None, :, None, None]
+                     + shift.double()[None, :, None, None]).permute(0, 2, 3, 1)
+    sc = float(ref.abs().max())
+    ed, ew = float((yd.double() - ref).abs().max()) / sc, float((yw.double() - ref).abs().max()) / sc
+    td, tw = timeit(lambda: direct(x)), timeit(run)
+    gf = 2.0 * b * h * wd * cin * cout * 9 / 1e9
+    print(f"{b}x{h}x{wd} {cin}->{cout}: err direct {ed:.2e} wino {ew:.2e} | direct {td:.1f} us ({gf / td * 1e-3:.1f} TF)  wino {tw:.1f} us ({gf / tw * 1e-3:.1f} TF-equivalent)  x{td / tw:.2f}")
