@@ -1,0 +1,109 @@
+"""GPU parity of the width-Winograd F(2,3) convolution (csrc/conv_wino.hip, the stride-1 3x3 layers of the RPN, rpn.py:124-142)
+against torch's float64 convolution and against the direct MFMA kernel it replaces.  Tolerance: 2e-5 of the output's maximum
+(fp32 MFMA accumulation over up to 9 * 256 terms; the direct kernel meets the same bound), far inside the model-level 1e-4."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from partner_amd import hip
+    hip.load()
+    return torch.device("cuda:0")
+
+
+def run_wino(x, w, scale, shift, act, in_co=0, cin=None, out=None, out_co=0):
+    from partner_amd import hip, ops
+    lib = hip.load()
+    b, h, wd, ct = x.shape
+    cout = w.shape[0]
+    cin = w.shape[1] if cin is None else cin
+    packed = torch.empty(lib.pn_conv_wino_packed_weight_floats(cout, cin), dtype=torch.float32, device=x.device)
+    hip.call("pn_pack_conv_weight_wino_f32", w.contiguous().data_ptr(), cout, cin, packed.data_ptr(), hip.stream())
+    if out is None:
+        out = torch.empty((b, h, wd, cout), dtype=torch.float32, device=x.device)
+    d = ops.ConvDesc(b, h, wd, cin, cout, 1, 3, 3, 1, 1, 1, ct, in_co, out.shape[3], out_co, act, 0, 0)
+    hip.call("pn_conv2d_wino_nhwc_f32", C.byref(d), x.data_ptr(), packed.data_ptr(), hip.ptr(scale), hip.ptr(shift), out.data_ptr(), hip.stream())
+    return out
+
+
+def ref64(x, w, scale, shift, relu):
+    y = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1)
+    if scale is not None:
+        y = y * scale.double()[None, :, None, None]
+    if shift is not None:
+        y = y + shift.double()[None, :, None, None]
+    return (torch.relu(y) if relu else y).permute(0, 2, 3, 1)
+
+
+CASES = [(1, 128, 128, 128, 128), (1, 64, 64, 256, 256), (2, 30, 22, 36, 70), (1, 7, 6, 8, 5), (3, 5, 2, 4, 1), (1, 9, 130, 64, 64), (1, 1, 2, 32, 33)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=str)
+def test_wino_matches_float64_and_direct(dev, case):
+    from partner_amd import ops
+    b, h, wd, cin, cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn((b, h, wd, cin), generator=g).to(dev)
+    w = (torch.randn((cout, cin, 3, 3), generator=g) * 0.1).to(dev)
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(dev), torch.randn(cout, generator=g).to(dev)
+    for sc, sh, act in ((scale, shift, ops.ACT_RELU), (None, None, ops.ACT_NONE), (None, shift, ops.ACT_NONE)):
+        y = run_wino(x, w, sc, sh, act)
+        r = ref64(x, w, sc, sh, act == ops.ACT_RELU)
+        err = float((y.double() - r).abs().max() / (r.abs().max() + 1e-30))
+        assert err < 2e-5, (case, err)
+    direct = ops.ConvLayer(w, stride=1, pad=1, scale=scale, shift=shift, act=ops.ACT_RELU)
+    if direct.wino_packed is not None:          # ConvLayer takes the Winograd kernel by itself on large maps: compare against the forced direct kernel
+        direct.wino_packed = None
+    yd = direct(x)
+    yw = run_wino(x, w, scale, shift, ops.ACT_RELU)
+    assert float((yd - yw).abs().max() / (yd.abs().max() + 1e-30)) < 2e-5
+    assert torch.equal(run_wino(x, w, scale, shift, ops.ACT_RELU), yw)     # bitwise reproducible
+
+
+def test_wino_channel_slices_and_zero_padding(dev):
+    """reads a channel slice of a wider map, writes a slice of a wider output (the RPN's concatenated deblock output), leaves the other
+    channels alone; exact zeros in -> shift out (the zero padding of the borders is exact)"""
+    from partner_amd import ops
+    g = torch.Generator().manual_seed(5)
+    b, h, wd, cin, cout = 1, 12, 20, 16, 24
+    wide = torch.randn((b, h, wd, 40), generator=g).to(dev)
+    w = (torch.randn((cout, cin, 3, 3), generator=g) * 0.1).to(dev)
+    shift = torch.randn(cout, generator=g).to(dev)
+    out = torch.full((b, h, wd, 64), 7.0, device=dev)
+    run_wino(wide, w, None, shift, ops.ACT_NONE, in_co=8, cin=cin, out=out, out_co=32)
+    r = ref64(wide[..., 8:24].contiguous(), w, None, shift, False)
+    assert float((out[..., 32:56].double() - r).abs().max() / r.abs().max()) < 2e-5
+    assert bool((out[..., :32] == 7.0).all()) and bool((out[..., 56:] == 7.0).all())
+    z = run_wino(torch.zeros((1, 6, 8, 16), device=dev), w, None, shift, ops.ACT_NONE)
+    assert torch.equal(z, shift.expand(1, 6, 8, cout).contiguous())
+
+
+def test_wino_rejects_unsupported_geometry(dev):
+    from partner_amd import hip, ops
+    x = torch.randn((1, 8, 7, 16), device=dev)             # odd width
+    w = torch.randn((8, 16, 3, 3), device=dev)
+    with pytest.raises(hip.PartnerHipError):
+        run_wino(x, w, None, None, ops.ACT_NONE)
+
+
+def test_conv_layer_picks_wino_only_on_large_maps(dev):
+    from partner_amd import ops
+    w = torch.randn((128, 128, 3, 3), device=dev) * 0.05
+    layer = ops.ConvLayer(w, stride=1, pad=1, act=ops.ACT_RELU)
+    assert layer.wino_packed is not None
+    assert layer._use_wino(1, 128, 128, False) and layer._use_wino(1, 256, 256, False)
+    assert not layer._use_wino(1, 32, 32, False) and not layer._use_wino(1, 128, 127, False) and not layer._use_wino(1, 128, 128, True)
+    assert ops.ConvLayer(w, stride=2, pad=1).wino_packed is None
+    # both kernels behind the same layer agree on a map above the threshold
+    x = torch.randn((1, 128, 128, 128), device=dev)
+    y1 = layer(x)
+    layer.wino_packed = None
+    y0 = layer(x)
+    assert float((y1 - y0).abs().max() / y0.abs().max()) < 2e-5
