@@ -25,13 +25,10 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int WP = 64;                          // pairs per block tile
 constexpr int WBN = 64;                         // output columns per block tile
 constexpr int WA_LD = 36;                       // floats per A row (32 channels + pad)
-constexpr int WA_FLOATS = 4 * WP * WA_LD;       // 9216
 constexpr int WB_FLOATS = 4 * 8 * WBN * 4;      // 8192
-constexpr int WSTAGE = WA_FLOATS + WB_FLOATS;   // 17408 floats
-constexpr size_t kWinoSmem = 2 * (size_t)WSTAGE * sizeof(float);
+constexpr size_t wino_smem(int wp) { return 2 * (size_t)(4 * wp * WA_LD + WB_FLOATS) * sizeof(float); }   // 64 pairs: 139 KB, 32 pairs: 102 KB
 
 struct WinoArgs {
   const float* in;
@@ -47,14 +44,19 @@ struct WinoArgs {
   unsigned in_bytes, w_bytes;
 };
 
-// NW = 4: wave q = position q on a 64 x 64 wave tile; NW = 8: waves q and q + 4 share position q and take 32 columns each
-// (64 x 32 wave tiles, two waves per SIMD: the second wave fills the first one's barrier / staging bubbles)
-template <int NW>
+// NW = 4: wave q = position q on a WP x 64 wave tile; NW = 8: waves q and q + 4 share position q and take 32 columns each
+// (two waves per SIMD: the second wave fills the first one's barrier / staging bubbles).  WP = pairs per block tile: 64, or 32 for
+// maps whose 64-pair tiles would not fill the chip (the 64 x 64 layers).
+template <int NW, int WP>
 __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
   constexpr int NT = NW * 64;
-  constexpr int PPT = (WP * 8) / NT;       // pairs per thread in the loader (2 or 1)
+  constexpr int WA_FLOATS = 4 * WP * WA_LD;
+  constexpr int WSTAGE = WA_FLOATS + WB_FLOATS;
+  constexpr int PPT = (WP * 8) / NT > 0 ? (WP * 8) / NT : 1;   // pairs per thread in the loader
+  constexpr bool A_ALL = (WP * 8) >= NT;   // false: only the first WP * 8 threads load activations
   constexpr int BPT = (4 * 8 * WBN) / NT;  // weight float4 per thread (8 or 4)
   constexpr int TN = NW == 4 ? 2 : 1;      // 32-column MFMA tiles per wave
+  constexpr int TM = WP / 32;              // 32-pair MFMA tiles per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int p = pt * WP + pl + (NT / 8) * k;
-    const bool ok = p < a.total_pairs;
+    const bool ok = p < a.total_pairs && (A_ALL || tid < WP * 8);
     const int pp = ok ? p : 0;
     const int rowi = pp / a.pairs_per_row, owp = pp - rowi * a.pairs_per_row;
     const int b = rowi / a.H, oh = rowi - b * a.H;
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
       const int pair = pl + (NT / 8) * k;
+      if (!A_ALL && tid >= WP * 8) break;
       const f32x4 d0 = ra[k][0], d1 = ra[k][1], d2 = ra[k][2], d3 = ra[k][3];
       *reinterpret_cast<f32x4*>(As + (0 * WP + pair) * WA_LD + c4 * 4) = d0 - d2;
       *reinterpret_cast<f32x4*>(As + (1 * WP + pair) * WA_LD + c4 * 4) = d1 + d2;
@@ -139,9 +142,9 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
     for (int j = 0; j < BPT; ++j) *reinterpret_cast<f32x4*>(Bs + (size_t)(tid + NT * j) * 4) = rb[j];
   };
 
-  f32x16 acc[2][TN];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -149,20 +152,20 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
 
   const int a_frag = (wq * WP + li) * WA_LD + lh * 4;
   const int b_frag = WA_FLOATS + ((wq * 8 + lh) * WBN + wc * 32 + li) * 4;
-  f32x4 af[2][2], bf[2][TN];
-  auto read_frags = [&](int buf, int sub, f32x4 (&fa)[2], f32x4 (&fb)[TN]) {
+  f32x4 af[2][TM], bf[2][TN];
+  auto read_frags = [&](int buf, int sub, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
     const float* As = smem + buf * WSTAGE + a_frag + sub * 8;
     const float* Bs = smem + buf * WSTAGE + b_frag + sub * 2 * WBN * 4;
-    fa[0] = *reinterpret_cast<const f32x4*>(As);
-    fa[1] = *reinterpret_cast<const f32x4*>(As + 32 * WA_LD);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * WA_LD);
 #pragma unroll
     for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * 4);
   };
-  auto mfma_sub = [&](const f32x4 (&fa)[2], const f32x4 (&fb)[TN]) {
+  auto mfma_sub = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
   };
@@ -181,8 +184,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
   }
   __syncthreads();
   read_frags(0, 0, af[0], bf[0]);
-  constexpr int NM = 4 * 2 * TN;           // MFMAs per sub-step
-  constexpr int NF = 2 + TN;               // fragment reads per sub-step
+  constexpr int NM = 4 * TM * TN;          // MFMAs per sub-step
+  constexpr int NF = TM + TN;              // fragment reads per sub-step
   constexpr int NSA = PPT * 4, NSB = BPT;  // LDS stores per step (A rows, B quads) == buffer loads per step
   constexpr int NS = NSA + NSB;
   auto kstep = [&](int t, int buf, f32x4 (&rx)[PPT][4], f32x4 (&ry)[BPT]) {
@@ -230,9 +233,9 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
 
   // ---- epilogue: the four positions' tiles through LDS, output transform, affine + activation, two pixels per pair
   constexpr int TLD = WBN + 4;
-  float* T = smem;   // [4 q][64 pairs][TLD]: 69.6 KB, the staging buffers are free (the loop ended with a barrier)
+  float* T = smem;   // [4 q][WP pairs][TLD] (69.6 KB at 64 pairs): the staging buffers are free (the loop ended with a barrier)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
   __syncthreads();
   const bool vec_cols = (a.out_ps % 4 == 0) && (a.out_co % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
 #pragma unroll
-  for (int k = 0; k < 1024 / NT; ++k) {
+  for (int k = 0; k < (WP * 16) / NT; ++k) {
     const int item = tid + NT * k;
     const int cq = item & 15, pair = item >> 4;
     const int p = pt * WP + pair;
@@ -334,27 +337,37 @@ int pn_conv2d_wino_nhwc_f32(const pn_conv_desc* d, const float* in, const float*
   a.act = d->act;
   a.pairs_per_row = d->in_w / 2;
   a.total_pairs = d->batch * d->in_h * a.pairs_per_row;
-  a.ptiles = pn::cdiv(a.total_pairs, WP);
   a.chunks = pn::cdiv(d->cin, 32);
   a.cout_pad = pn::cdiv(d->cout, WBN) * WBN;
   a.in_bytes = (unsigned)in_bytes;
   a.w_bytes = (unsigned)(pn_conv_wino_packed_weight_floats(d->cout, d->cin) * 4);
   static bool attr_done[64] = {false};
   if (pn::first_use_on_device(attr_done)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoSmem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoSmem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_smem(64));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_smem(64));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<8, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_smem(32));
   }
   static const int waves = [] { const char* e = getenv("PN_WINO_WAVES"); return e ? atoi(e) : 8; }();
-  const dim3 grid(pn::cdiv(a.ptiles, 8) * 8, a.cout_pad / WBN);
+  static const int force_wp = [] { const char* e = getenv("PN_WINO_PAIRS"); return e ? atoi(e) : 0; }();
+  // 64-pair tiles when they fill the chip (>= 256 blocks), 32-pair tiles otherwise
+  const int ncol = a.cout_pad / WBN;
+  int wp = (long long)pn::cdiv(a.total_pairs, 64) * ncol >= 256 ? 64 : 32;
+  if (force_wp == 32 || force_wp == 64) wp = force_wp;
+  if (waves == 4) wp = 64;
+  a.ptiles = pn::cdiv(a.total_pairs, wp);
+  const dim3 grid(pn::cdiv(a.ptiles, 8) * 8, ncol);
   pn::ProfileSlot ps;
   const bool prof = pn::take_profile_slot(ps);
-  if (waves == 4) {
-    if (prof) hipExtLaunchKernelGGL(conv_wino_kernel<4>, grid, dim3(256), kWinoSmem, pn::S(stream), ps.start, ps.stop, 0, a);
-    else hipLaunchKernelGGL(conv_wino_kernel<4>, grid, dim3(256), kWinoSmem, pn::S(stream), a);
-  } else {
-    if (prof) hipExtLaunchKernelGGL(conv_wino_kernel<8>, grid, dim3(512), kWinoSmem, pn::S(stream), ps.start, ps.stop, 0, a);
-    else hipLaunchKernelGGL(conv_wino_kernel<8>, grid, dim3(512), kWinoSmem, pn::S(stream), a);
-  }
+  hipStream_t st = pn::S(stream);
+#define PN_WINO_LAUNCH(NW, WPT)                                                                                                         \
+  do {                                                                                                                                  \
+    if (prof) hipExtLaunchKernelGGL((conv_wino_kernel<NW, WPT>), grid, dim3(NW * 64), wino_smem(WPT), st, ps.start, ps.stop, 0, a);     \
+    else hipLaunchKernelGGL((conv_wino_kernel<NW, WPT>), grid, dim3(NW * 64), wino_smem(WPT), st, a);                                   \
+  } while (0)
+  if (waves == 4) PN_WINO_LAUNCH(4, 64);
+  else if (wp == 64) PN_WINO_LAUNCH(8, 64);
+  else PN_WINO_LAUNCH(8, 32);
+#undef PN_WINO_LAUNCH
   return pn::check_launch("conv_wino_kernel");
 }
 

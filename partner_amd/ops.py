@@ -438,7 +438,7 @@ class ConvLayer:
     def _use_wino(self, b: int, h: int, w: int, accumulate: bool) -> bool:
         if self.wino_packed is None or accumulate or w % 2 or self.cin != self._pack_cin:
             return False
-        tiles = ((b * h * (w // 2) + 63) // 64) * ((self.cout + 63) // 64)
+        tiles = ((b * h * (w // 2) + 31) // 32) * ((self.cout + 63) // 64)   # 32-pair x 64-column tiles (the kernel takes 64-pair ones when they fill the chip)
         return tiles >= _WINO_MIN_TILES
 
     def pad_input_channels(self, cin_padded: int) -> "ConvLayer":

@@ -99,7 +99,7 @@ def test_conv_layer_picks_wino_only_on_large_maps(dev):
     layer = ops.ConvLayer(w, stride=1, pad=1, act=ops.ACT_RELU)
     assert layer.wino_packed is not None
     assert layer._use_wino(1, 128, 128, False) and layer._use_wino(1, 256, 256, False)
-    assert not layer._use_wino(1, 32, 32, False) and not layer._use_wino(1, 128, 127, False) and not layer._use_wino(1, 128, 128, True)
+    assert layer._use_wino(1, 64, 128, False) and not layer._use_wino(1, 32, 32, False) and not layer._use_wino(1, 128, 127, False) and not layer._use_wino(1, 128, 128, True)
     assert ops.ConvLayer(w, stride=2, pad=1).wino_packed is None
     # both kernels behind the same layer agree on a map above the threshold
     x = torch.randn((1, 128, 128, 128), device=dev)
