@@ -26,9 +26,14 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int WBN = 64;                         // output columns per block tile
-constexpr int WA_LD = 36;                       // floats per A row (32 channels + pad)
-constexpr int WB_FLOATS = 4 * 8 * WBN * 4;      // 8192
-constexpr size_t wino_smem(int wp) { return 2 * (size_t)(4 * wp * WA_LD + WB_FLOATS) * sizeof(float); }   // 64 pairs: 139 KB, 32 pairs: 102 KB
+// LDS of a block: two stages of A [4 q][wp pairs][bkc + 4] and B [4 q][bkc / 4][64 cols][4] floats, reused by the epilogue's
+// [4 q][wp][68] tile.  64 pairs x 32 channels: 139 KB (one block per CU); 64 pairs x 16 channels: 74 KB (two blocks per CU: one
+// block's prologue / epilogue runs behind the other's MFMAs); 32 pairs x 32 channels: 102 KB.
+constexpr size_t wino_smem(int wp, int bkc) {
+  const size_t stage = 2 * (size_t)(4 * wp * (bkc + 4) + 4 * (bkc / 4) * WBN * 4) * sizeof(float);
+  const size_t epi = (size_t)4 * wp * (WBN + 4) * sizeof(float);
+  return stage > epi ? stage : epi;
+}
 
 struct WinoArgs {
   const float* in;
@@ -46,17 +51,24 @@ struct WinoArgs {
 
 // NW = 4: wave q = position q on a WP x 64 wave tile; NW = 8: waves q and q + 4 share position q and take 32 columns each
 // (two waves per SIMD: the second wave fills the first one's barrier / staging bubbles).  WP = pairs per block tile: 64, or 32 for
-// maps whose 64-pair tiles would not fill the chip (the 64 x 64 layers).
-template <int NW, int WP>
+// maps whose 64-pair tiles would not fill the chip (the 64 x 64 layers).  BKC = input channels per K step (32 or 16).
+template <int NW, int WP, int BKC>
 __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
   constexpr int NT = NW * 64;
+  constexpr int KQ = BKC / 4;              // 16-byte channel quads per row and K step
+  constexpr int NH = 32 / BKC;             // K steps per 32-channel chunk of the packed weights
+  constexpr int NSUB = BKC / 8;            // 8-channel MFMA sub-steps per K step
+  constexpr int WA_LD = BKC + 4;
   constexpr int WA_FLOATS = 4 * WP * WA_LD;
+  constexpr int WB_FLOATS = 4 * KQ * WBN * 4;
   constexpr int WSTAGE = WA_FLOATS + WB_FLOATS;
-  constexpr int PPT = (WP * 8) / NT > 0 ? (WP * 8) / NT : 1;   // pairs per thread in the loader
-  constexpr bool A_ALL = (WP * 8) >= NT;   // false: only the first WP * 8 threads load activations
-  constexpr int BPT = (4 * 8 * WBN) / NT;  // weight float4 per thread (8 or 4)
+  constexpr int APASS = NT / KQ;           // pairs covered by one pass of the block's threads
+  constexpr int PPT = WP / APASS > 0 ? WP / APASS : 1;   // pairs per thread in the loader
+  constexpr bool A_ALL = WP >= APASS;      // false: only the first WP * KQ threads load activations
+  constexpr int BPT = (4 * KQ * WBN) / NT; // weight float4 per thread
   constexpr int TN = NW == 4 ? 2 : 1;      // 32-column MFMA tiles per wave
   constexpr int TM = WP / 32;              // 32-pair MFMA tiles per wave
+  static_assert(BPT >= 1 && (4 * KQ * WBN) % NT == 0, "weight tile / threads mismatch");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -69,7 +81,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
     if (idx >= (x < r ? q + 1 : q)) return;
   }
   const int n0 = blockIdx.y * WBN;
-  const int pl = tid >> 3, c4 = tid & 7;
+  const int pl = tid / KQ, c4 = tid % KQ;
 
   // ---- loader state: PPT pairs per thread, four input pixels each
   const long long back = ((long long)a.W + 1) * a.in_ps;   // floats: the descriptor base is moved back so that every voffset >= 0
@@ -78,8 +90,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
   unsigned a_cmask[PPT];   // bit j: input column 2 owp - 1 + j inside the map
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
-    const int p = pt * WP + pl + (NT / 8) * k;
-    const bool ok = p < a.total_pairs && (A_ALL || tid < WP * 8);
+    const int p = pt * WP + pl + APASS * k;
+    const bool ok = p < a.total_pairs && (A_ALL || tid < WP * KQ);
     const int pp = ok ? p : 0;
     const int rowi = pp / a.pairs_per_row, owp = pp - rowi * a.pairs_per_row;
     const int b = rowi / a.H, oh = rowi - b * a.H;
@@ -96,21 +108,23 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
   unsigned b_off[BPT];
 #pragma unroll
   for (int j = 0; j < BPT; ++j) {
-    const int idx = tid + NT * j;                 // (q, k4, col)
-    const int col = idx & (WBN - 1), k4 = (idx >> 6) & 7, q = idx >> 9;
+    const int idx = tid + NT * j;                 // (q, k4, col) of this K step's weight tile
+    const int col = idx & (WBN - 1), k4 = (idx >> 6) % KQ, q = idx / (WBN * KQ);
     b_off[j] = (n0 + col < a.cout_pad) ? (unsigned)((((size_t)q * 8 + k4) * a.cout_pad + n0 + col) * 16) : 0xffffffffu;
   }
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<float*>(a.in)) - back * 4, 0,
                                                                          a.in_bytes + (unsigned)(back * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
 
-  const int nsteps = 3 * a.chunks;
-  int ld_kh = 0, ld_chunk = 0;   // K order: channel chunk outermost, kernel rows innermost
+  const int nsteps = 3 * NH * a.chunks;
+  int ld_kh = 0, ld_half = 0, ld_chunk = 0;   // K order: 32-channel chunk outermost, then its BKC-channel parts, kernel rows innermost
   f32x4 ra[PPT][4], rb[BPT], ra2[PPT][4], rb2[BPT];
   auto load_global = [&](bool live, f32x4 (&ra)[PPT][4], f32x4 (&rb)[BPT]) {
-    const unsigned so_a = (unsigned)((ld_kh * a.W * a.in_ps + ld_chunk * 32) * 4);
-    const unsigned so_b = (unsigned)((ld_chunk * 3 + ld_kh) * 32) * (unsigned)a.cout_pad * 16u;   // [chunk][kh][q][k4][col][4]
-    const bool cok = live && ld_chunk * 32 + c4 * 4 < a.Cin;
+    const int ch0 = ld_chunk * 32 + ld_half * BKC;
+    const unsigned so_a = (unsigned)((ld_kh * a.W * a.in_ps + ch0) * 4);
+    // packed weights [chunk][kh][q][k4 (8)][col][4]: the part's quads are k4 = half * KQ ..
+    const unsigned so_b = ((unsigned)((ld_chunk * 3 + ld_kh) * 32) + (unsigned)(ld_half * KQ)) * (unsigned)a.cout_pad * 16u;
+    const bool cok = live && ch0 + c4 * 4 < a.Cin;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
       const bool rok = cok && ((a_rmask[k] >> ld_kh) & 1u);
@@ -123,20 +137,24 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
 #pragma unroll
     for (int j = 0; j < BPT; ++j)
       rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, live ? b_off[j] : 0xffffffffu, live ? so_b : 0u, 0));
-    if (++ld_kh == 3) { ld_kh = 0; ++ld_chunk; }
+    if (++ld_kh == 3) {
+      ld_kh = 0;
+      if (++ld_half == NH) { ld_half = 0; ++ld_chunk; }
+    }
   };
   auto store_lds = [&](int buf, const f32x4 (&ra)[PPT][4], const f32x4 (&rb)[BPT]) {
     float* As = smem + buf * WSTAGE;
     float* Bs = As + WA_FLOATS;
+    if (A_ALL || tid < WP * KQ) {
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      const int pair = pl + (NT / 8) * k;
-      if (!A_ALL && tid >= WP * 8) break;
-      const f32x4 d0 = ra[k][0], d1 = ra[k][1], d2 = ra[k][2], d3 = ra[k][3];
-      *reinterpret_cast<f32x4*>(As + (0 * WP + pair) * WA_LD + c4 * 4) = d0 - d2;
-      *reinterpret_cast<f32x4*>(As + (1 * WP + pair) * WA_LD + c4 * 4) = d1 + d2;
-      *reinterpret_cast<f32x4*>(As + (2 * WP + pair) * WA_LD + c4 * 4) = d2 - d1;
-      *reinterpret_cast<f32x4*>(As + (3 * WP + pair) * WA_LD + c4 * 4) = d1 - d3;
+      for (int k = 0; k < PPT; ++k) {
+        const int pair = pl + APASS * k;
+        const f32x4 d0 = ra[k][0], d1 = ra[k][1], d2 = ra[k][2], d3 = ra[k][3];
+        *reinterpret_cast<f32x4*>(As + (0 * WP + pair) * WA_LD + c4 * 4) = d0 - d2;
+        *reinterpret_cast<f32x4*>(As + (1 * WP + pair) * WA_LD + c4 * 4) = d1 + d2;
+        *reinterpret_cast<f32x4*>(As + (2 * WP + pair) * WA_LD + c4 * 4) = d2 - d1;
+        *reinterpret_cast<f32x4*>(As + (3 * WP + pair) * WA_LD + c4 * 4) = d1 - d3;
+      }
     }
 #pragma unroll
     for (int j = 0; j < BPT; ++j) *reinterpret_cast<f32x4*>(Bs + (size_t)(tid + NT * j) * 4) = rb[j];
@@ -151,7 +169,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int a_frag = (wq * WP + li) * WA_LD + lh * 4;
-  const int b_frag = WA_FLOATS + ((wq * 8 + lh) * WBN + wc * 32 + li) * 4;
+  const int b_frag = WA_FLOATS + ((wq * KQ + lh) * WBN + wc * 32 + li) * 4;
   f32x4 af[2][TM], bf[2][TN];
   auto read_frags = [&](int buf, int sub, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
     const float* As = smem + buf * WSTAGE + a_frag + sub * 8;
@@ -170,11 +188,10 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
   };
 
-  // ---- software pipeline (the schedule of conv_mfma.hip): one barrier per K step, everything else in the shadow of the MFMAs
-  //   sub-step 0: fragments of sub-step 1                                   | MFMAs of sub-step 0
-  //   sub-step 1: fragments of sub-step 2; Winograd input transform + LDS stores of step t+1 into the other stage
-  //   sub-step 2: fragments of sub-step 3; buffer loads of step t+3 into the registers just stored (two sets alternate)
-  //   barrier;  sub-step 3: first fragments of step t+1                     | MFMAs of sub-step 3
+  // ---- software pipeline (the schedule of conv_mfma.hip): one barrier per K step, everything else in the shadow of the MFMAs.
+  // Every sub-step reads the next sub-step's fragments, then issues its MFMAs; the Winograd input transform + LDS stores of step
+  // t+1 (into the other stage) ride on sub-step STORE_SUB, the buffer loads of step t+3 (into the registers just stored; two sets
+  // alternate) on sub-step LOAD_SUB, the barrier sits before the last sub-step, which reads the first fragments of step t+1.
   {
     f32x4 ra0[PPT][4], rb0[BPT];
     load_global(true, ra0, rb0);
@@ -186,44 +203,44 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
   read_frags(0, 0, af[0], bf[0]);
   constexpr int NM = 4 * TM * TN;          // MFMAs per sub-step
   constexpr int NF = TM + TN;              // fragment reads per sub-step
-  constexpr int NSA = PPT * 4, NSB = BPT;  // LDS stores per step (A rows, B quads) == buffer loads per step
-  constexpr int NS = NSA + NSB;
+  constexpr int NS = PPT * 4 + BPT;        // LDS stores per step == buffer loads per step
+  constexpr int STORE_SUB = NSUB == 4 ? 1 : 0, LOAD_SUB = NSUB == 4 ? 2 : 0;
   auto kstep = [&](int t, int buf, f32x4 (&rx)[PPT][4], f32x4 (&ry)[BPT]) {
-    read_frags(buf, 1, af[1], bf[1]);
-    mfma_sub(af[0], bf[0]);
-    __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(buf, 2, af[0], bf[0]);
-    mfma_sub(af[1], bf[1]);
-    store_lds(buf ^ 1, rx, ry);
-    __builtin_amdgcn_sched_group_barrier(0x100, NF, 1);
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, NM / NS > 0 ? NM / NS : 1, 1);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 1);
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 1);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, NM, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(buf, 3, af[1], bf[1]);
-    mfma_sub(af[0], bf[0]);
-    load_global(t + 3 < nsteps, rx, ry);
-    __builtin_amdgcn_sched_group_barrier(0x100, NF, 2);
+    for (int sub = 0; sub < NSUB; ++sub) {
+      f32x4 (&ca)[TM] = af[sub & 1];
+      f32x4 (&cb)[TN] = bf[sub & 1];
+      f32x4 (&na)[TM] = af[(sub + 1) & 1];
+      f32x4 (&nb)[TN] = bf[(sub + 1) & 1];
+      if (sub == NSUB - 1) {
+        __syncthreads();
+        read_frags(buf ^ 1, 0, na, nb);
+      } else {
+        read_frags(buf, sub + 1, na, nb);
+      }
+      mfma_sub(ca, cb);
+      if (sub == STORE_SUB) store_lds(buf ^ 1, rx, ry);
+      if (sub == LOAD_SUB) load_global(t + 3 < nsteps, rx, ry);
+      __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
+      if (sub == STORE_SUB) {
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, NM / NS > 0 ? NM / NS : 1, 2);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 2);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 2);
+        for (int k = 0; k < NS; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, NM / (2 * NS) > 0 ? NM / (2 * NS) : 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
+      if (sub == LOAD_SUB) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, NM / (2 * NS) > 0 ? NM / (2 * NS) : 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, NM, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    read_frags(buf ^ 1, 0, af[0], bf[0]);
-    mfma_sub(af[1], bf[1]);
-    __builtin_amdgcn_sched_group_barrier(0x100, NF, 3);
-    __builtin_amdgcn_sched_group_barrier(0x008, NM, 3);
-    __builtin_amdgcn_sched_barrier(0);
   };
   for (int t = 0; t < nsteps; t += 2) {
     kstep(t, 0, ra, rb);
@@ -343,30 +360,28 @@ int pn_conv2d_wino_nhwc_f32(const pn_conv_desc* d, const float* in, const float*
   a.w_bytes = (unsigned)(pn_conv_wino_packed_weight_floats(d->cout, d->cin) * 4);
   static bool attr_done[64] = {false};
   if (pn::first_use_on_device(attr_done)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_smem(64));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_smem(64));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<8, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_smem(32));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<8, 64, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_smem(64, 32));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<8, 32, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_smem(32, 32));
   }
-  static const int waves = [] { const char* e = getenv("PN_WINO_WAVES"); return e ? atoi(e) : 8; }();
   static const int force_wp = [] { const char* e = getenv("PN_WINO_PAIRS"); return e ? atoi(e) : 0; }();
-  // 64-pair tiles when they fill the chip (>= 256 blocks), 32-pair tiles otherwise
+  // 64-pair tiles when they fill the chip (>= 256 blocks), 32-pair tiles otherwise.  K steps of 32 channels: 16-channel steps fit two
+  // blocks per CU (74 KB each) but measured 9 % slower (128 vs 117 us on the 256 x 256 layers): half the MFMAs per barrier costs more
+  // than the second block's overlap gives.
   const int ncol = a.cout_pad / WBN;
   int wp = (long long)pn::cdiv(a.total_pairs, 64) * ncol >= 256 ? 64 : 32;
   if (force_wp == 32 || force_wp == 64) wp = force_wp;
-  if (waves == 4) wp = 64;
   a.ptiles = pn::cdiv(a.total_pairs, wp);
   const dim3 grid(pn::cdiv(a.ptiles, 8) * 8, ncol);
   pn::ProfileSlot ps;
   const bool prof = pn::take_profile_slot(ps);
   hipStream_t st = pn::S(stream);
-#define PN_WINO_LAUNCH(NW, WPT)                                                                                                         \
-  do {                                                                                                                                  \
-    if (prof) hipExtLaunchKernelGGL((conv_wino_kernel<NW, WPT>), grid, dim3(NW * 64), wino_smem(WPT), st, ps.start, ps.stop, 0, a);     \
-    else hipLaunchKernelGGL((conv_wino_kernel<NW, WPT>), grid, dim3(NW * 64), wino_smem(WPT), st, a);                                   \
+#define PN_WINO_LAUNCH(WPT)                                                                                                              \
+  do {                                                                                                                                   \
+    if (prof) hipExtLaunchKernelGGL((conv_wino_kernel<8, WPT, 32>), grid, dim3(512), wino_smem(WPT, 32), st, ps.start, ps.stop, 0, a);   \
+    else hipLaunchKernelGGL((conv_wino_kernel<8, WPT, 32>), grid, dim3(512), wino_smem(WPT, 32), st, a);                                 \
   } while (0)
-  if (waves == 4) PN_WINO_LAUNCH(4, 64);
-  else if (wp == 64) PN_WINO_LAUNCH(8, 64);
-  else PN_WINO_LAUNCH(8, 32);
+  if (wp == 64) PN_WINO_LAUNCH(64);
+  else PN_WINO_LAUNCH(32);
 #undef PN_WINO_LAUNCH
   return pn::check_launch("conv_wino_kernel");
 }
