@@ -45,6 +45,7 @@ struct WinoArgs {
   int in_ps, in_co, out_ps, out_co;
   int act;
   int pairs_per_row, total_pairs, ptiles;
+  int ncol;                // 64-column tiles
   int chunks, cout_pad;
   unsigned in_bytes, w_bytes;
 };
@@ -73,14 +74,15 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wq = wave & 3, wc = wave >> 2;   // position, column half (NW == 8)
-  // XCD-aware order: blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of pair tiles
-  int pt;
-  {
-    const int bid = blockIdx.x, q = a.ptiles >> 3, r = a.ptiles & 7, x = bid & 7, idx = bid >> 3;
-    pt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
-    if (idx >= (x < r ? q + 1 : q)) return;
-  }
-  const int n0 = blockIdx.y * WBN;
+  // PERSISTENT blocks: gridDim.x blocks (one per CU), dealt round-robin over the 8 XCDs by the hardware; every XCD owns a contiguous
+  // run of pair tiles (neighbouring tiles share halo rows in that XCD's L2), its blocks walk the run's (pair tile, column tile) list
+  // with the column tile fastest.  The next tile's first three K steps are requested BEFORE the previous tile's epilogue runs, so
+  // the prologue's memory latency hides behind the output transform and stores.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int xq = a.ptiles >> 3, xr = a.ptiles & 7;
+  const int px0 = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+  const int xtiles = (xcd < xr ? xq + 1 : xq) * a.ncol;
+  int pt = 0, n0 = 0;
   const int pl = tid / KQ, c4 = tid % KQ;
 
   // ---- loader state: PPT pairs per thread, four input pixels each
@@ -88,37 +90,42 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
   unsigned a_off[PPT];     // byte offset of pixel (b, oh - 1, 2 owp - 1), channel in_co + 4 c4, relative to the shifted base
   unsigned a_rmask[PPT];   // bit kh: input row oh + kh - 1 inside the map
   unsigned a_cmask[PPT];   // bit j: input column 2 owp - 1 + j inside the map
-#pragma unroll
-  for (int k = 0; k < PPT; ++k) {
-    const int p = pt * WP + pl + APASS * k;
-    const bool ok = p < a.total_pairs && (A_ALL || tid < WP * KQ);
-    const int pp = ok ? p : 0;
-    const int rowi = pp / a.pairs_per_row, owp = pp - rowi * a.pairs_per_row;
-    const int b = rowi / a.H, oh = rowi - b * a.H;
-    const long long pix = ((long long)b * a.H + (oh - 1)) * a.W + (2 * owp - 1);
-    a_off[k] = (unsigned)((pix * a.in_ps + back + a.in_co + c4 * 4) * 4);
-    unsigned rm = 0, cm = 0;
-    for (int kh = 0; kh < 3; ++kh)
-      if (ok && (unsigned)(oh + kh - 1) < (unsigned)a.H) rm |= 1u << kh;
-    for (int j = 0; j < 4; ++j)
-      if ((unsigned)(2 * owp - 1 + j) < (unsigned)a.W) cm |= 1u << j;
-    a_rmask[k] = rm;
-    a_cmask[k] = cm;
-  }
   unsigned b_off[BPT];
+  int ld_kh = 0, ld_half = 0, ld_chunk = 0;   // K order: 32-channel chunk outermost, then its BKC-channel parts, kernel rows innermost
+  auto setup_tile = [&](int tl) {
+    pt = px0 + tl / a.ncol;
+    n0 = (tl - (tl / a.ncol) * a.ncol) * WBN;
+    ld_kh = 0; ld_half = 0; ld_chunk = 0;
 #pragma unroll
-  for (int j = 0; j < BPT; ++j) {
-    const int idx = tid + NT * j;                 // (q, k4, col) of this K step's weight tile
-    const int col = idx & (WBN - 1), k4 = (idx >> 6) % KQ, q = idx / (WBN * KQ);
-    b_off[j] = (n0 + col < a.cout_pad) ? (unsigned)((((size_t)q * 8 + k4) * a.cout_pad + n0 + col) * 16) : 0xffffffffu;
-  }
+    for (int k = 0; k < PPT; ++k) {
+      const int p = pt * WP + pl + APASS * k;
+      const bool ok = p < a.total_pairs && (A_ALL || tid < WP * KQ);
+      const int pp = ok ? p : 0;
+      const int rowi = pp / a.pairs_per_row, owp = pp - rowi * a.pairs_per_row;
+      const int b = rowi / a.H, oh = rowi - b * a.H;
+      const long long pix = ((long long)b * a.H + (oh - 1)) * a.W + (2 * owp - 1);
+      a_off[k] = (unsigned)((pix * a.in_ps + back + a.in_co + c4 * 4) * 4);
+      unsigned rm = 0, cm = 0;
+      for (int kh = 0; kh < 3; ++kh)
+        if (ok && (unsigned)(oh + kh - 1) < (unsigned)a.H) rm |= 1u << kh;
+      for (int j = 0; j < 4; ++j)
+        if ((unsigned)(2 * owp - 1 + j) < (unsigned)a.W) cm |= 1u << j;
+      a_rmask[k] = rm;
+      a_cmask[k] = cm;
+    }
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      const int idx = tid + NT * j;                 // (q, k4, col) of this K step's weight tile
+      const int col = idx & (WBN - 1), k4 = (idx >> 6) % KQ, q = idx / (WBN * KQ);
+      b_off[j] = (n0 + col < a.cout_pad) ? (unsigned)((((size_t)q * 8 + k4) * a.cout_pad + n0 + col) * 16) : 0xffffffffu;
+    }
+  };
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<float*>(a.in)) - back * 4, 0,
                                                                          a.in_bytes + (unsigned)(back * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
 
   const int nsteps = 3 * NH * a.chunks;
-  int ld_kh = 0, ld_half = 0, ld_chunk = 0;   // K order: 32-channel chunk outermost, then its BKC-channel parts, kernel rows innermost
-  f32x4 ra[PPT][4], rb[BPT], ra2[PPT][4], rb2[BPT];
+  f32x4 ra[PPT][4], rb[BPT], ra2[PPT][4], rb2[BPT], ra0[PPT][4], rb0[BPT];
   auto load_global = [&](bool live, f32x4 (&ra)[PPT][4], f32x4 (&rb)[BPT]) {
     const int ch0 = ld_chunk * 32 + ld_half * BKC;
     const unsigned so_a = (unsigned)((ld_kh * a.W * a.in_ps + ch0) * 4);
@@ -161,12 +168,6 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
   };
 
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int a_frag = (wq * WP + li) * WA_LD + lh * 4;
   const int b_frag = WA_FLOATS + ((wq * KQ + lh) * WBN + wc * 32 + li) * 4;
@@ -192,15 +193,6 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
   // Every sub-step reads the next sub-step's fragments, then issues its MFMAs; the Winograd input transform + LDS stores of step
   // t+1 (into the other stage) ride on sub-step STORE_SUB, the buffer loads of step t+3 (into the registers just stored; two sets
   // alternate) on sub-step LOAD_SUB, the barrier sits before the last sub-step, which reads the first fragments of step t+1.
-  {
-    f32x4 ra0[PPT][4], rb0[BPT];
-    load_global(true, ra0, rb0);
-    load_global(nsteps > 1, ra, rb);
-    load_global(nsteps > 2, ra2, rb2);
-    store_lds(0, ra0, rb0);
-  }
-  __syncthreads();
-  read_frags(0, 0, af[0], bf[0]);
   constexpr int NM = 4 * TM * TN;          // MFMAs per sub-step
   constexpr int NF = TM + TN;              // fragment reads per sub-step
   constexpr int NS = PPT * 4 + BPT;        // LDS stores per step == buffer loads per step
@@ -242,58 +234,81 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  for (int t = 0; t < nsteps; t += 2) {
-    kstep(t, 0, ra, rb);
-    if (t + 1 < nsteps) kstep(t + 1, 1, ra2, rb2);
-  }
-  __syncthreads();   // every wave is done with the last stage before the epilogue reuses the LDS
-
-  // ---- epilogue: the four positions' tiles through LDS, output transform, affine + activation, two pixels per pair
+  // ---- epilogue of a finished tile: the four positions' tiles through LDS, output transform, affine + activation, two pixels per pair
   constexpr int TLD = WBN + 4;
-  float* T = smem;   // [4 q][WP pairs][TLD] (69.6 KB at 64 pairs): the staging buffers are free (the loop ended with a barrier)
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        T[(wq * WP + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + wc * 32 + j * 32 + li] = acc[i][j][r];
-  __syncthreads();
   const bool vec_cols = (a.out_ps % 4 == 0) && (a.out_co % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
+  auto epilogue = [&](int ept, int en0) {
+    float* T = smem;   // [4 q][WP pairs][TLD] (69.6 KB at 64 pairs): the staging buffers are free (the K loop ended with a barrier)
 #pragma unroll
-  for (int k = 0; k < (WP * 16) / NT; ++k) {
-    const int item = tid + NT * k;
-    const int cq = item & 15, pair = item >> 4;
-    const int p = pt * WP + pair;
-    const int col = n0 + cq * 4;
-    if (p >= a.total_pairs || col >= a.Cout) continue;
-    const f32x4 m0 = *reinterpret_cast<const f32x4*>(T + (0 * WP + pair) * TLD + cq * 4);
-    const f32x4 m1 = *reinterpret_cast<const f32x4*>(T + (1 * WP + pair) * TLD + cq * 4);
-    const f32x4 m2 = *reinterpret_cast<const f32x4*>(T + (2 * WP + pair) * TLD + cq * 4);
-    const f32x4 m3 = *reinterpret_cast<const f32x4*>(T + (3 * WP + pair) * TLD + cq * 4);
-    f32x4 y0 = (m0 + m1) + m2, y1 = (m1 - m2) - m3;
-    const int rowi = p / a.pairs_per_row, owp = p - rowi * a.pairs_per_row;
-    float* o = a.out + ((size_t)rowi * a.W + 2 * owp) * a.out_ps + a.out_co + col;
-    const int nvalid = min(4, a.Cout - col);
-    if (vec_cols && nvalid == 4) {
-      f32x4 vs = {1.f, 1.f, 1.f, 1.f}, vh = {0.f, 0.f, 0.f, 0.f};
-      if (a.scale) vs = *reinterpret_cast<const f32x4*>(a.scale + col);
-      if (a.shift) vh = *reinterpret_cast<const f32x4*>(a.shift + col);
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        y0[c] = pn::apply_act(fmaf(y0[c], vs[c], vh[c]), a.act);
-        y1[c] = pn::apply_act(fmaf(y1[c], vs[c], vh[c]), a.act);
-      }
-      *reinterpret_cast<f32x4*>(o) = y0;
-      *reinterpret_cast<f32x4*>(o + a.out_ps) = y1;
-    } else {
-      for (int c = 0; c < nvalid; ++c) {
-        const float sc = a.scale ? a.scale[col + c] : 1.f, sh = a.shift ? a.shift[col + c] : 0.f;
-        o[c] = pn::apply_act(fmaf(y0[c], sc, sh), a.act);
-        o[a.out_ps + c] = pn::apply_act(fmaf(y1[c], sc, sh), a.act);
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          T[(wq * WP + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + wc * 32 + j * 32 + li] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (WP * 16) / NT; ++k) {
+      const int item = tid + NT * k;
+      const int cq = item & 15, pair = item >> 4;
+      const int p = ept * WP + pair;
+      const int col = en0 + cq * 4;
+      if (p >= a.total_pairs || col >= a.Cout) continue;
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(T + (0 * WP + pair) * TLD + cq * 4);
+      const f32x4 m1 = *reinterpret_cast<const f32x4*>(T + (1 * WP + pair) * TLD + cq * 4);
+      const f32x4 m2 = *reinterpret_cast<const f32x4*>(T + (2 * WP + pair) * TLD + cq * 4);
+      const f32x4 m3 = *reinterpret_cast<const f32x4*>(T + (3 * WP + pair) * TLD + cq * 4);
+      f32x4 y0 = (m0 + m1) + m2, y1 = (m1 - m2) - m3;
+      const int rowi = p / a.pairs_per_row, owp = p - rowi * a.pairs_per_row;
+      float* o = a.out + ((size_t)rowi * a.W + 2 * owp) * a.out_ps + a.out_co + col;
+      const int nvalid = min(4, a.Cout - col);
+      if (vec_cols && nvalid == 4) {
+        f32x4 vs = {1.f, 1.f, 1.f, 1.f}, vh = {0.f, 0.f, 0.f, 0.f};
+        if (a.scale) vs = *reinterpret_cast<const f32x4*>(a.scale + col);
+        if (a.shift) vh = *reinterpret_cast<const f32x4*>(a.shift + col);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          y0[c] = pn::apply_act(fmaf(y0[c], vs[c], vh[c]), a.act);
+          y1[c] = pn::apply_act(fmaf(y1[c], vs[c], vh[c]), a.act);
+        }
+        *reinterpret_cast<f32x4*>(o) = y0;
+        *reinterpret_cast<f32x4*>(o + a.out_ps) = y1;
+      } else {
+        for (int c = 0; c < nvalid; ++c) {
+          const float sc = a.scale ? a.scale[col + c] : 1.f, sh = a.shift ? a.shift[col + c] : 0.f;
+          o[c] = pn::apply_act(fmaf(y0[c], sc, sh), a.act);
+          o[a.out_ps + c] = pn::apply_act(fmaf(y1[c], sc, sh), a.act);
+        }
       }
     }
+    __syncthreads();   // the tile in LDS has been consumed: the next tile's first stage may be stored
+  };
+
+  int prev_pt = -1, prev_n0 = 0;
+  for (int tl = slot; tl < xtiles; tl += per_xcd) {
+    setup_tile(tl);
+    load_global(true, ra0, rb0);
+    load_global(nsteps > 1, ra, rb);
+    load_global(nsteps > 2, ra2, rb2);
+    if (prev_pt >= 0) epilogue(prev_pt, prev_n0);   // runs while the three tiles just requested are in flight
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    store_lds(0, ra0, rb0);
+    __syncthreads();
+    read_frags(0, 0, af[0], bf[0]);
+    for (int t = 0; t < nsteps; t += 2) {
+      kstep(t, 0, ra, rb);
+      if (t + 1 < nsteps) kstep(t + 1, 1, ra2, rb2);
+    }
+    __syncthreads();   // every wave is done with the last stage before the epilogue reuses the LDS
+    prev_pt = pt;
+    prev_n0 = n0;
   }
+  if (prev_pt >= 0) epilogue(prev_pt, prev_n0);
 }
 
 // torch (Cout, Cin, 3, 3) -> [chunk][kh][q][k4 (8)][cout_pad][4]: U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2
@@ -371,7 +386,18 @@ int pn_conv2d_wino_nhwc_f32(const pn_conv_desc* d, const float* in, const float*
   int wp = (long long)pn::cdiv(a.total_pairs, 64) * ncol >= 256 ? 64 : 32;
   if (force_wp == 32 || force_wp == 64) wp = force_wp;
   a.ptiles = pn::cdiv(a.total_pairs, wp);
-  const dim3 grid(pn::cdiv(a.ptiles, 8) * 8, ncol);
+  a.ncol = ncol;
+  // one persistent block per CU (a multiple of 8: the XCD count), fewer when there are fewer tiles
+  static int cus[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && cus[dev] == 0) {
+    int n = 0;
+    cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) ? n / 8 * 8 : 256;
+  }
+  const int ncu = (dev >= 0 && dev < 64) ? cus[dev] : 256;
+  const long long tiles = (long long)a.ptiles * ncol;
+  const dim3 grid((unsigned)std::min<long long>(ncu, (tiles + 7) / 8 * 8));
   pn::ProfileSlot ps;
   const bool prof = pn::take_profile_slot(ps);
   hipStream_t st = pn::S(stream);
