@@ -369,7 +369,7 @@ def committed_pmc_bytes(kernel_prefixes, per="frame"):
     rows = list(csv.DictReader(open(path)))
     frames = None
     for r in rows:
-        if "dynamic_pfn_32_128_kernel" in r["kernel"]:
+        if "dynamic_pfn_32_128_kernel" in r["kernel"] or "dynamic_pfn_32_128_main_kernel" in r["kernel"]:
             frames = int(r["launches"])     # one launch per frame
     tot, n = 0.0, 0
     for r in rows:
@@ -581,9 +581,11 @@ def main():
         ach = flops / (ms * 1e-3) / 1e12
         layers = {t: dict(launches_per_step=round(n / args.steps, 2), us=round(1e3 * m / n, 2), tflops=round(f / (m * 1e-3) / 1e12, 1))
                   for t, (f, m, n) in sorted(tags.items(), key=lambda kv: -kv[1][1])}
-        roofline = dict(bound="mfma", kernel="conv_mfma_kernel family (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
+        roofline = dict(bound="mfma", kernel="conv_mfma_kernel / conv_wino_kernel family (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; the stride-1 3x3 "
+                                             "layers through a width-Winograd F(2,3) transform: 6 of the 9 algorithmic MACs reach the MFMA, so `achieved` "
+                                             "counts algorithmic FLOPs and can exceed the MFMA issue rate of a layer)",
                         achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        traffic=committed_pmc_bytes(("conv_mfma_kernel", "conv_small_n", "conv_multi"), per="launch"),
+                        traffic=committed_pmc_bytes(("conv_mfma_kernel", "conv_wino_kernel", "conv_small_n", "conv_multi"), per="launch"),
                         traffic_unit="HBM bytes per conv launch (offline PMC passes of this command, profiles/r2_pmc_traffic.csv)",
                         launches=launches, launches_per_step=round(launches / args.steps, 2), flops_per_launch=round(flops / launches),
                         avg_launch_us=round(1e3 * ms / launches, 2), conv_ms_per_step=round(ms / args.steps, 4),
