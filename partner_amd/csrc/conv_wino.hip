@@ -380,8 +380,8 @@ int pn_conv2d_wino_nhwc_f32(const pn_conv_desc* d, const float* in, const float*
   }
   static const int force_wp = [] { const char* e = getenv("PN_WINO_PAIRS"); return e ? atoi(e) : 0; }();
   // 64-pair tiles when they fill the chip (>= 256 blocks), 32-pair tiles otherwise.  K steps of 32 channels: 16-channel steps fit two
-  // blocks per CU (74 KB each) but measured 9 % slower (128 vs 117 us on the 256 x 256 layers): half the MFMAs per barrier costs more
-  // than the second block's overlap gives.
+  // blocks per CU (74 KB each) but measured slower on the 256 x 256 layers (8 waves of 64 x 32: 128 us, 4 waves of 64 x 64: 143 us,
+  // against 114-117 us): half the MFMAs per barrier costs more than the second block's overlap gives.
   const int ncol = a.cout_pad / WBN;
   int wp = (long long)pn::cdiv(a.total_pairs, 64) * ncol >= 256 ? 64 : 32;
   if (force_wp == 32 || force_wp == 64) wp = force_wp;
