@@ -311,6 +311,242 @@ __global__ __launch_bounds__(NW * 64) void conv_wino_kernel(WinoArgs a) {
   if (prev_pt >= 0) epilogue(prev_pt, prev_n0);
 }
 
+// ---- variant for layers with >= 128 output columns: a block covers WP pairs x 128 columns with EIGHT 64-wide wave tiles (wave = position
+// q x column half), the transformed INPUT goes through LDS as above, the transformed WEIGHTS do not: every wave's B operand is private
+// to it (its position, its 64 columns), and the packed layout is the MFMA fragment layout, so each lane fetches its own 16-byte
+// fragments straight from L2 one K step ahead.  LDS is the A image only (74 KB at 64 pairs), a barrier covers 64 MFMAs per wave as in
+// the direct 128 x 128 tile, and the input transform is done once per 128 columns instead of once per 64.
+constexpr int WBN2 = 128;
+constexpr size_t wino_bd_smem(int wp) {
+  const size_t stage = 2 * (size_t)(4 * wp * 36) * sizeof(float);
+  const size_t epi = (size_t)4 * wp * (64 + 4) * sizeof(float);   // the epilogue handles the two column halves one after the other
+  return stage > epi ? stage : epi;
+}
+
+template <int WP>
+__global__ __launch_bounds__(512) void conv_wino_bd_kernel(WinoArgs a) {
+  constexpr int NT = 512, WA_LD = 36, WA_FLOATS = 4 * WP * WA_LD;
+  constexpr int TM = WP / 32;
+  constexpr bool A_ALL = WP * 8 >= NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wq = wave & 3, wc = wave >> 2;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int xq = a.ptiles >> 3, xr = a.ptiles & 7;
+  const int px0 = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+  const int xtiles = (xcd < xr ? xq + 1 : xq) * a.ncol;   // a.ncol = 128-column tiles here
+  int pt = 0, n0 = 0;
+  const int pl = tid >> 3, c4 = tid & 7;
+
+  const long long back = ((long long)a.W + 1) * a.in_ps;
+  unsigned a_off, a_rmask, a_cmask;
+  unsigned b_base;   // byte offset of this lane's fragment for (k4 = lh, column j = 0) inside one (chunk, kh) block of the packed weights
+  int ld_kh = 0, ld_chunk = 0;     // A loader position
+  int lb_kh = 0, lb_chunk = 0;     // B loader position
+  auto setup_tile = [&](int tl) {
+    pt = px0 + tl / a.ncol;
+    n0 = (tl - (tl / a.ncol) * a.ncol) * WBN2;
+    ld_kh = ld_chunk = lb_kh = lb_chunk = 0;
+    const int p = pt * WP + pl;
+    const bool ok = p < a.total_pairs && (A_ALL || tid < WP * 8);
+    const int pp = ok ? p : 0;
+    const int rowi = pp / a.pairs_per_row, owp = pp - rowi * a.pairs_per_row;
+    const int b = rowi / a.H, oh = rowi - b * a.H;
+    const long long pix = ((long long)b * a.H + (oh - 1)) * a.W + (2 * owp - 1);
+    a_off = (unsigned)((pix * a.in_ps + back + a.in_co + c4 * 4) * 4);
+    unsigned rm = 0, cm = 0;
+    for (int kh = 0; kh < 3; ++kh)
+      if (ok && (unsigned)(oh + kh - 1) < (unsigned)a.H) rm |= 1u << kh;
+    for (int j = 0; j < 4; ++j)
+      if ((unsigned)(2 * owp - 1 + j) < (unsigned)a.W) cm |= 1u << j;
+    a_rmask = rm;
+    a_cmask = cm;
+    const int col = n0 + wc * 64 + li;
+    b_base = (unsigned)((((size_t)wq * 8 + lh) * a.cout_pad + col) * 16);
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<float*>(a.in)) - back * 4, 0,
+                                                                         a.in_bytes + (unsigned)(back * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const int nsteps = 3 * a.chunks;
+
+  f32x4 ra[4], ra2[4], ra0[4];
+  auto load_a = [&](bool live, f32x4 (&r)[4]) {
+    const unsigned so_a = (unsigned)((ld_kh * a.W * a.in_ps + ld_chunk * 32) * 4);
+    const bool rok = live && ld_chunk * 32 + c4 * 4 < a.Cin && ((a_rmask >> ld_kh) & 1u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned vo = (rok && ((a_cmask >> j) & 1u)) ? a_off + (unsigned)(j * a.in_ps * 4) : 0xffffffffu;
+      r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, so_a, 0));
+    }
+    if (++ld_kh == 3) { ld_kh = 0; ++ld_chunk; }
+  };
+  auto store_a = [&](int buf, const f32x4 (&r)[4]) {
+    if (A_ALL || tid < WP * 8) {
+      float* As = smem + buf * WA_FLOATS;
+      *reinterpret_cast<f32x4*>(As + (0 * WP + pl) * WA_LD + c4 * 4) = r[0] - r[2];
+      *reinterpret_cast<f32x4*>(As + (1 * WP + pl) * WA_LD + c4 * 4) = r[1] + r[2];
+      *reinterpret_cast<f32x4*>(As + (2 * WP + pl) * WA_LD + c4 * 4) = r[2] - r[1];
+      *reinterpret_cast<f32x4*>(As + (3 * WP + pl) * WA_LD + c4 * 4) = r[1] - r[3];
+    }
+  };
+  // this lane's B fragments of one K step: [sub-step][32-column tile]
+  f32x4 fb0[4][2], fb1[4][2];
+  auto load_b = [&](bool live, f32x4 (&f)[4][2]) {
+    const unsigned so_b = (unsigned)((lb_chunk * 3 + lb_kh) * 32) * (unsigned)a.cout_pad * 16u;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned vo = live ? b_base + (unsigned)(((size_t)2 * sub * a.cout_pad + j * 32) * 16) : 0xffffffffu;
+        f[sub][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vo, live ? so_b : 0u, 0));
+      }
+    if (++lb_kh == 3) { lb_kh = 0; ++lb_chunk; }
+  };
+
+  f32x16 acc[TM][2];
+  const int a_frag = (wq * WP + li) * WA_LD + lh * 4;
+  f32x4 af[2][TM];
+  auto read_a = [&](int buf, int sub, f32x4 (&fa)[TM]) {
+    const float* As = smem + buf * WA_FLOATS + a_frag + sub * 8;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * WA_LD);
+  };
+  auto mfma_sub = [&](const f32x4 (&fa)[TM], const f32x4 (&fbv)[2]) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fbv[j][kk], acc[i][j], 0, 0, 0);
+  };
+  constexpr int NM = 4 * TM * 2;
+  auto kstep = [&](int t, int buf, f32x4 (&rx)[4], f32x4 (&bc)[4][2], f32x4 (&bn)[4][2]) {
+    // sub-step 0: A fragments of sub-step 1; the weight fragments of step t+1 are requested (a whole step ahead of their use)
+    read_a(buf, 1, af[1]);
+    load_b(t + 1 < nsteps, bn);
+    mfma_sub(af[0], bc[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, NM / 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // sub-step 1: A fragments of sub-step 2; input transform + LDS stores of step t+1
+    read_a(buf, 2, af[0]);
+    mfma_sub(af[1], bc[1]);
+    store_a(buf ^ 1, rx);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, NM / 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // sub-step 2: A fragments of sub-step 3; input loads of step t+3 into the registers just stored
+    read_a(buf, 3, af[1]);
+    mfma_sub(af[0], bc[2]);
+    load_a(t + 3 < nsteps, rx);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, NM / 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    read_a(buf ^ 1, 0, af[0]);
+    mfma_sub(af[1], bc[3]);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  constexpr int TLD = 64 + 4;
+  const bool vec_cols = (a.out_ps % 4 == 0) && (a.out_co % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
+  auto epilogue = [&](int ept, int en0) {
+    float* T = smem;   // [4 q][WP][TLD]: one 64-column half at a time
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (wc == half) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[(wq * WP + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + j * 32 + li] = acc[i][j][r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < (WP * 16) / NT; ++k) {
+        const int item = tid + NT * k;
+        const int cq = item & 15, pair = item >> 4;
+        const int p = ept * WP + pair;
+        const int col = en0 + half * 64 + cq * 4;
+        if (p >= a.total_pairs || col >= a.Cout) continue;
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(T + (0 * WP + pair) * TLD + cq * 4);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(T + (1 * WP + pair) * TLD + cq * 4);
+        const f32x4 m2 = *reinterpret_cast<const f32x4*>(T + (2 * WP + pair) * TLD + cq * 4);
+        const f32x4 m3 = *reinterpret_cast<const f32x4*>(T + (3 * WP + pair) * TLD + cq * 4);
+        f32x4 y0 = (m0 + m1) + m2, y1 = (m1 - m2) - m3;
+        const int rowi = p / a.pairs_per_row, owp = p - rowi * a.pairs_per_row;
+        float* o = a.out + ((size_t)rowi * a.W + 2 * owp) * a.out_ps + a.out_co + col;
+        const int nvalid = min(4, a.Cout - col);
+        if (vec_cols && nvalid == 4) {
+          f32x4 vs = {1.f, 1.f, 1.f, 1.f}, vh = {0.f, 0.f, 0.f, 0.f};
+          if (a.scale) vs = *reinterpret_cast<const f32x4*>(a.scale + col);
+          if (a.shift) vh = *reinterpret_cast<const f32x4*>(a.shift + col);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            y0[c] = pn::apply_act(fmaf(y0[c], vs[c], vh[c]), a.act);
+            y1[c] = pn::apply_act(fmaf(y1[c], vs[c], vh[c]), a.act);
+          }
+          *reinterpret_cast<f32x4*>(o) = y0;
+          *reinterpret_cast<f32x4*>(o + a.out_ps) = y1;
+        } else {
+          for (int c = 0; c < nvalid; ++c) {
+            const float sc = a.scale ? a.scale[col + c] : 1.f, sh = a.shift ? a.shift[col + c] : 0.f;
+            o[c] = pn::apply_act(fmaf(y0[c], sc, sh), a.act);
+            o[a.out_ps + c] = pn::apply_act(fmaf(y1[c], sc, sh), a.act);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  };
+
+  int prev_pt = -1, prev_n0 = 0;
+  for (int tl = slot; tl < xtiles; tl += per_xcd) {
+    setup_tile(tl);
+    load_a(true, ra0);
+    load_b(true, fb0);
+    load_a(nsteps > 1, ra);
+    load_a(nsteps > 2, ra2);
+    if (prev_pt >= 0) epilogue(prev_pt, prev_n0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    store_a(0, ra0);
+    __syncthreads();
+    read_a(0, 0, af[0]);
+    for (int t = 0; t < nsteps; t += 2) {
+      kstep(t, 0, ra, fb0, fb1);
+      if (t + 1 < nsteps) kstep(t + 1, 1, ra2, fb1, fb0);
+    }
+    __syncthreads();
+    prev_pt = pt;
+    prev_n0 = n0;
+  }
+  if (prev_pt >= 0) epilogue(prev_pt, prev_n0);
+}
+
 // torch (Cout, Cin, 3, 3) -> [chunk][kh][q][k4 (8)][cout_pad][4]: U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2
 __global__ void pack_wino_weight_kernel(const float* __restrict__ w, int cout, int cin, int chunks, int cout_pad, float* __restrict__ packed, size_t total) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -406,6 +642,32 @@ int pn_conv2d_wino_nhwc_f32(const pn_conv_desc* d, const float* in, const float*
     if (prof) hipExtLaunchKernelGGL((conv_wino_kernel<8, WPT, 32>), grid, dim3(512), wino_smem(WPT, 32), st, ps.start, ps.stop, 0, a);   \
     else hipLaunchKernelGGL((conv_wino_kernel<8, WPT, 32>), grid, dim3(512), wino_smem(WPT, 32), st, a);                                 \
   } while (0)
+  static const int bd_on = [] { const char* e = getenv("PN_WINO_BDIRECT"); return e ? atoi(e) : 1; }();
+  if (bd_on && a.cout_pad % WBN2 == 0) {
+    // 128-column tiles with the weights fetched straight into the MFMA operands: when they fill the chip
+    const int ncol2 = a.cout_pad / WBN2;
+    // (the 32-pair form of this kernel measured slower than the LDS-weights kernel on the 128 x 128 layers: 33 vs 31 us)
+    const int wp2 = (long long)pn::cdiv(a.total_pairs, 64) * ncol2 >= ncu ? 64 : 0;
+    if (wp2) {
+      static bool done_bd[64] = {false};
+      if (pn::first_use_on_device(done_bd)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_bd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_bd_smem(64));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_bd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_bd_smem(32));
+      }
+      a.ptiles = pn::cdiv(a.total_pairs, wp2);
+      a.ncol = ncol2;
+      const long long tiles2 = (long long)a.ptiles * ncol2;
+      const dim3 grid2((unsigned)std::min<long long>(ncu, (tiles2 + 7) / 8 * 8));
+      if (wp2 == 64) {
+        if (prof) hipExtLaunchKernelGGL((conv_wino_bd_kernel<64>), grid2, dim3(512), wino_bd_smem(64), st, ps.start, ps.stop, 0, a);
+        else hipLaunchKernelGGL((conv_wino_bd_kernel<64>), grid2, dim3(512), wino_bd_smem(64), st, a);
+      } else {
+        if (prof) hipExtLaunchKernelGGL((conv_wino_bd_kernel<32>), grid2, dim3(512), wino_bd_smem(32), st, ps.start, ps.stop, 0, a);
+        else hipLaunchKernelGGL((conv_wino_bd_kernel<32>), grid2, dim3(512), wino_bd_smem(32), st, a);
+      }
+      return pn::check_launch("conv_wino_bd_kernel");
+    }
+  }
   if (wp == 64) PN_WINO_LAUNCH(64);
   else PN_WINO_LAUNCH(32);
 #undef PN_WINO_LAUNCH
