@@ -585,7 +585,7 @@ def main():
                                              "layers through a width-Winograd F(2,3) transform: 6 of the 9 algorithmic MACs reach the MFMA, so `achieved` "
                                              "counts algorithmic FLOPs and can exceed the MFMA issue rate of a layer)",
                         achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        traffic=committed_pmc_bytes(("conv_mfma_kernel", "conv_wino_kernel", "conv_small_n", "conv_multi"), per="launch"),
+                        traffic=committed_pmc_bytes(("conv_mfma_kernel", "conv_wino", "conv_small_n", "conv_multi"), per="launch"),
                         traffic_unit="HBM bytes per conv launch (offline PMC passes of this command, profiles/r2_pmc_traffic.csv)",
                         launches=launches, launches_per_step=round(launches / args.steps, 2), flops_per_launch=round(flops / launches),
                         avg_launch_us=round(1e3 * ms / launches, 2), conv_ms_per_step=round(ms / args.steps, 4),
