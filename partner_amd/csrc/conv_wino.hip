@@ -588,7 +588,7 @@ int pn_conv2d_wino_nhwc_f32(const pn_conv_desc* d, const float* in, const float*
                             pn_stream_t stream) {
   PN_REQUIRE(d && in && packed_w && out, "conv_wino: null pointer");
   PN_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->groups == 1 && !d->deconv2x2 && d->range_strata <= 1 &&
-                 !d->accumulate,
+                 !d->accumulate && d->pad_h_end == 0 && d->pad_w_end == 0,
              "conv_wino: plain 3x3 / stride 1 / pad 1 convolutions only");
   PN_REQUIRE(d->batch >= 1 && d->in_h >= 1 && d->in_w >= 2 && d->in_w % 2 == 0, "conv_wino: the map width must be even");
   PN_REQUIRE(d->cin >= 4 && d->cin % 4 == 0 && d->in_pixel_stride % 4 == 0 && d->in_channel_offset % 4 == 0 && d->cout >= 1,
