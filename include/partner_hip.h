@@ -941,6 +941,16 @@ int pn_l2_normalize_f32(const float *x, long long rows, int c, float eps, float 
 int pn_l2_normalize_bwd_f32(const float *y, const float *dy, const float *inv_norm, long long rows, int c, float *dx,
                             pn_stream_t stream);
 
+/* next-4  ego-motion warp of the previous sweep's feature maps for the bidirectional context padding
+ * (PolarStreamBDCP.forward_one_sweep `feature_only`, det3d/models/detectors/polarstream.py:318-372 with get_grids :223-238 and
+ * get_center :239-247): the previous sweep's map, given as its nsectors sector maps stacked sector-major in the batch axis
+ * (nsectors * batch, h / nsectors, w, c) NHWC (h = azimuth rows of the whole sweep, w = range columns; nsectors = 1: a plain
+ * (batch, h, w, c) map) -> out (batch, h, w, c): the whole-sweep map resampled at the rotated cell positions (the torch.cat of
+ * polarstream.py:343-349 is folded into the read).  rot2x2: (batch, 2, 2) row-major `transform_matrix[:2, :2]`
+ * (voxelization.py:447); bilinear, zero padding, align_corners = False (torch.nn.functional.grid_sample defaults). */
+int pn_polar_warp_f32(const float *in, const float *rot2x2, int batch, int nsectors, int h, int w, int c, float range_lo,
+                      float range_hi, float azimuth_lo, float azimuth_hi, float *out, pn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * next-4  global augmentation of one training sample, in place on the device: points (n, point_stride >= 3) [x, y, z, ...]
  * and boxes (m, box_cols = 7 | 9) [x, y, z, w, l, h, (vx, vy,) heading].  Order and arithmetic of

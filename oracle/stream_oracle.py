@@ -145,3 +145,30 @@ def rotate_sector_boxes(boxes: np.ndarray, angle: float) -> np.ndarray:
     if b.shape[1] > 7:
         b[:, 6:8] = b[:, 6:8] @ m
     return b.numpy()
+
+
+def warp_prev_sweep(cur_sweep: List[Tensor], transform: Tensor, nsectors: int, pc_range) -> List[Tensor]:
+    """the `feature_only` tail of PolarStreamBDCP.forward_one_sweep (polarstream.py:318-372, get_grids :223-238, get_center :239-247):
+    per-layer inputs of the stacked sectors (nsectors * bs, C, h, W) -> whole-sweep maps (bs, C, nsectors * h, W) resampled at the
+    rotated cell positions with torch's own grid_sample (bilinear, zeros, align_corners=False).  transform: (bs, 2, 2)."""
+    out = []
+    center = [(pc_range[3] + pc_range[0]) / 2, (pc_range[4] + pc_range[1]) / 2]
+    half_a, half_r = (pc_range[4] - pc_range[1]) / 2, (pc_range[3] - pc_range[0]) / 2
+    bs = transform.shape[0]
+    for x in cur_sweep:
+        if nsectors > 1:
+            x = x.reshape((nsectors, bs, -1, x.shape[-2], x.shape[-1]))
+            x = torch.cat([x[j] for j in range(nsectors)], -2)
+        H, W = x.shape[-2], x.shape[-1]
+        ga, gr = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        ga = (pc_range[4] - pc_range[1]) / H * ga + pc_range[1]
+        gr = (pc_range[3] - pc_range[0]) / W * gr + pc_range[0]
+        grid = torch.stack([gr * torch.cos(ga), gr * torch.sin(ga)], -1)
+        grid = torch.einsum("bjk,mnk->bmnj", transform.float(), grid)
+        rho = torch.norm(grid, dim=-1, keepdim=True)
+        az = torch.atan2(grid[:, :, :, 1], grid[:, :, :, 0]).unsqueeze(-1)
+        rho = (rho - center[0]) / half_r
+        az = (az - center[1]) / half_a
+        out.append(F.grid_sample(x, torch.cat([rho, az], -1), align_corners=False))
+    return out
+

@@ -141,6 +141,59 @@ __global__ __launch_bounds__(kT) void assemble_rows_kernel(AsmArgs a) {
   }
 }
 
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// ---- ego-motion warp of the previous sweep's per-layer feature maps (PolarStreamBDCP.forward_one_sweep, polarstream.py:318-372):
+// every cell (m = azimuth row, n = range column) of the polar map is taken to Cartesian coordinates at its LOWER edge
+// (az = lo_a + m * span_a / H, r = lo_r + n * span_r / W: get_grids :223-238), rotated by the sample's 2x2 matrix, turned back into
+// (rho, azimuth), normalised to [-1, 1] with the map's centre / half-span (get_center :239-247) and sampled bilinearly with zero padding
+// (torch.nn.functional.grid_sample defaults: bilinear, zeros, align_corners = False).  NHWC maps (B, H, W, C); one thread per
+// (cell, 4 channels).
+struct WarpArgs {
+  const float* in; const float* rot; float* out;
+  int B, H, W, C;
+  float lo_r, hi_r, lo_a, hi_a;
+  int nsec, hs;   // input stacked sector-major: sample (sector * B + b), hs = H / nsec rows each
+};
+__global__ void polar_warp_kernel(WarpArgs a) {
+  const int c4 = a.C >> 2;
+  const long long total = (long long)a.B * a.H * a.W * c4;
+  const float span_r = a.hi_r - a.lo_r, span_a = a.hi_a - a.lo_a;
+  const float cen_r = (a.hi_r + a.lo_r) * 0.5f, cen_a = (a.hi_a + a.lo_a) * 0.5f, half_r = span_r * 0.5f, half_a = span_a * 0.5f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % c4);
+    long long r = i / c4;
+    const int n = (int)(r % a.W); r /= a.W;
+    const int m = (int)(r % a.H);
+    const int b = (int)(r / a.H);
+    const float az = span_a / (float)a.H * (float)m + a.lo_a;
+    const float rr = span_r / (float)a.W * (float)n + a.lo_r;
+    const float x = rr * cosf(az), y = rr * sinf(az);
+    const float* t = a.rot + (size_t)b * 4;
+    const float xs = t[0] * x + t[1] * y, ys = t[2] * x + t[3] * y;
+    const float rho = sqrtf(xs * xs + ys * ys), phi = atan2f(ys, xs);
+    const float gx = (rho - cen_r) / half_r, gy = (phi - cen_a) / half_a;
+    const float ix = ((gx + 1.f) * (float)a.W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)a.H - 1.f) * 0.5f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* base = a.in + q * 4;
+    auto tap = [&](int yy, int xx, float wgt) {
+      if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) {
+        const int sec = yy / a.hs, ys_ = yy - sec * a.hs;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + ((((size_t)sec * a.B + b) * a.hs + ys_) * a.W + xx) * a.C);
+        acc += v * wgt;
+      }
+    };
+    tap(y0, x0, wy0 * wx0);
+    tap(y0, x0 + 1, wy0 * wx1);
+    tap(y0 + 1, x0, wy1 * wx0);
+    tap(y0 + 1, x0 + 1, wy1 * wx1);
+    *reinterpret_cast<f32x4*>(a.out + i * 4) = acc;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -196,6 +249,17 @@ int pn_assemble_rows_f32(const pn_row_piece* pieces, int n_out, int out_rows, in
   const size_t total = (size_t)n_out * out_rows * w * (c / 4);
   hipLaunchKernelGGL(assemble_rows_kernel, dim3((unsigned)std::min<size_t>(4096, (total + kT - 1) / kT)), dim3(kT), 0, pn::S(stream), a);
   return pn::check_launch("assemble_rows_kernel");
+}
+
+int pn_polar_warp_f32(const float* in, const float* rot2x2, int batch, int nsectors, int h, int w, int c, float range_lo, float range_hi,
+                      float azimuth_lo, float azimuth_hi, float* out, pn_stream_t stream) {
+  PN_REQUIRE(in && rot2x2 && out && in != out && batch >= 1 && h >= 1 && w >= 1 && c >= 4 && c % 4 == 0, "polar_warp: bad arguments (channels a multiple of 4)");
+  PN_REQUIRE(nsectors >= 1 && h % nsectors == 0, "polar_warp: the azimuth rows must divide into the sectors");
+  PN_REQUIRE(range_hi > range_lo && azimuth_hi > azimuth_lo, "polar_warp: empty range");
+  WarpArgs a{in, rot2x2, out, batch, h, w, c, range_lo, range_hi, azimuth_lo, azimuth_hi, nsectors, h / nsectors};
+  const long long total = (long long)batch * h * w * (c / 4);
+  hipLaunchKernelGGL(polar_warp_kernel, dim3((unsigned)std::min<long long>(65535, (total + 255) / 256)), dim3(256), 0, pn::S(stream), a);
+  return pn::check_launch("polar_warp_kernel");
 }
 
 }  // extern "C"

@@ -298,6 +298,100 @@ class PolarStream(PointPillars):
 
 
 @DETECTORS.register_module
+class PolarStreamBDCP(PolarStream):
+    """PolarStream with bidirectional context padding (det3d/models/detectors/polarstream.py:180-470): ``forward`` takes TWO sweeps.
+    The previous sweep runs in ``feature_only`` mode (all its sectors stacked in the batch axis, sector-major); the per-layer inputs
+    of the neck (RPNBDCP) are glued back into whole-sweep maps and warped into the current sweep's frame by the ego rotation
+    (``transform_matrix`` (bs, 2, 2); `pn_polar_warp_f32`).  The current sweep is then streamed sector by sector: trailing-edge context
+    from the sector before, leading-edge context from the warped previous sweep.  Eval mode, detection super-task."""
+
+    def __init__(self, reader, backbone, neck, bbox_head, seg_head=None, part_head=None, train_cfg=None, test_cfg=None, pretrained=None,
+                 nsectors=1):
+        neck = dict(neck)
+        neck["nsectors"] = nsectors          # polarstream.py:205
+        super().__init__(reader, backbone, neck, bbox_head, seg_head, part_head, train_cfg, test_cfg, pretrained)
+        self.nsectors = int(nsectors)
+
+    def _canvas(self, example):
+        points, grid_ind = example["points"], example["grid_ind"]
+        hip.require_device(points, grid_ind)
+        batch = len(example["num_points"])
+        g = [int(v) for v in example["grid_size"][0]]
+        spec = ops.GridSpec(tuple(float(v) for v in self.reader.pc_range[:3]), tuple(float(v) for v in self.reader.voxel_size), (g[0], g[1], g[2]))
+        keys = ops.keys_from_grid_ind(grid_ind.to(torch.int64).contiguous(), spec, batch)
+        return self.encode_canvas(points.contiguous(), keys, spec, batch), batch
+
+    def _get(self, k, d=None):
+        return self.test_cfg.get(k, d) if hasattr(self.test_cfg, "get") else getattr(self.test_cfg, k, d)
+
+    def warp_prev_sweep(self, cur_sweep, transform, bs):
+        """per-layer inputs of the stacked sectors (nsectors * bs, h, w, c) -> whole-sweep maps (bs, nsectors * h, w, c) warped by the
+        (bs, 2, 2) rotation (polarstream.py:340-358)"""
+        pr = self._get("pc_range")
+        rot = transform.to(cur_sweep[0].device).float().contiguous()
+        out = []
+        for x in cur_sweep:
+            n, h, w, c = x.shape
+            assert n == self.nsectors * bs and x.is_contiguous()
+            warped = torch.empty((bs, self.nsectors * h, w, c), dtype=torch.float32, device=x.device)
+            hip.call("pn_polar_warp_f32", x.data_ptr(), rot.data_ptr(), bs, self.nsectors, self.nsectors * h, w, c, float(pr[0]), float(pr[3]), float(pr[1]),
+                     float(pr[4]), warped.data_ptr(), hip.stream())
+            out.append(warped)
+        return out
+
+    def forward_one_sweep(self, example, mode="feature_only", return_loss=False, **kwargs):
+        eval_only(self, "PolarStreamBDCP")
+        if return_loss:
+            raise NotImplementedError("PolarStreamBDCP: training (the two-sweep loss path) is not built")
+        canvas, batch = self._canvas(example)
+        nsec = self.nsectors
+        bs = batch // nsec
+        if mode == "feature_only":
+            _, cur = self.neck.forward_nhwc(canvas, nsectors=nsec, mode="feature_only")
+            return self.warp_prev_sweep(cur, torch.as_tensor(example["transform_matrix"])[:bs], bs)
+        prev_sweep = kwargs["prev_sweep"]
+        if nsec == 1:
+            x2, _ = self.neck.forward_nhwc(canvas, prev_sweep=prev_sweep, nsectors=1, mode=mode)
+        else:
+            outs, ctx = [], []
+            for j in range(nsec):
+                y, ctx = self.neck.forward_nhwc(canvas[j * bs:(j + 1) * bs].contiguous(), prev_sweep=prev_sweep, prev_context=ctx, sec_id=j, nsectors=nsec,
+                                                mode=mode)
+                outs.append(y)
+            x2 = torch.cat(outs, 0)
+        preds = self.bbox_head(ops.as_nchw(x2))
+        if kwargs.get("raw_preds", False) or self.test_cfg is None:
+            return [dict(det_preds=[{k: v[i * bs:(i + 1) * bs] for k, v in t.items()} for t in preds["det_preds"]]) for i in range(nsec)]
+        stateful = bool(self._get("stateful_nms", False))
+        rets, prev_dets = [], None
+        metas = example.get("metadata", [None] * batch)
+        for i in range(nsec):
+            pr = {"det_preds": [{k: v[i * bs:(i + 1) * bs] for k, v in t.items()} for t in preds["det_preds"]]}
+            ex = dict(metadata=metas[i * bs:(i + 1) * bs])
+            if "pc_range" in example:
+                ex["pc_range"] = example["pc_range"][i * bs:(i + 1) * bs]
+            det = self.bbox_head.predict(ex, pr, self.test_cfg, sec_id=i, prev_dets=prev_dets)
+            rets.append({"det": det})
+            prev_dets = det if stateful and i < nsec - 1 else None
+        return rets
+
+    def forward(self, example, return_loss=True, **kwargs):
+        """example: [previous sweep, current sweep] (polarstream.py:266-290)"""
+        if isinstance(example, dict) or len(example) != 2:
+            raise ValueError("PolarStreamBDCP.forward takes a list of two sweeps [previous, current]")
+        prev_sweep = self.forward_one_sweep(example[0], "feature_only", False, **kwargs)
+        rets = self.forward_one_sweep(example[1], "train" if return_loss else "eval", return_loss, prev_sweep=prev_sweep, **kwargs)
+        ex = example[1]
+        bs = len(ex["num_points"]) // self.nsectors
+        stateful = self.test_cfg is not None and bool(self._get("stateful_nms", False))
+        out = self.merge_sectors(rets, bs, stateful)
+        if stateful and "det" in out:
+            for det, meta in zip(out["det"], ex.get("metadata", [None] * bs)[:bs]):
+                det["metadata"] = meta
+        return out
+
+
+@DETECTORS.register_module
 class VoxelNet(SingleStageDetector):
     """VoxelNet (voxelnet.py:27-131): reader -> sparse 3-D middle encoder -> RPN -> head, the detector of the reference's
     CenterPoint-style voxel configs (VoxelNetV3 is this plus the re-alignment attention).  Eval mode, on the HIP kernels."""

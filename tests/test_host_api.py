@@ -80,6 +80,18 @@ def test_reference_streaming_config_builds_unchanged():
     assert [type(d[0]).__name__ for d in m.neck.deblocks] == ["Conv2d", "Conv2d", "ConvTranspose2d"]   # us strides 0.5, 1, 2 (rpn.py:80-110: ConvTranspose2d only above 1)
 
 
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_reference_bidirectional_config_builds_unchanged():
+    """the reference's 4-sector bidirectional config (PolarStreamBDCP + RPNBDCP) builds from the file as it is; the detector hands its
+    sector count to the neck (polarstream.py:205)"""
+    cfg = P.Config.fromfile(os.path.join(REF, "configs/nusc/pp/polarstream/polarstream_det_n_seg_4_sector_bidirectional.py"))
+    m = P.build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    assert (type(m).__name__, type(m.neck).__name__, type(m.bbox_head).__name__) == ("PolarStreamBDCP", "RPNBDCP", "CenterHeadSinglePos")
+    assert m.nsectors == 4 and m.neck.nsectors == 4 and m.test_cfg["stateful_nms"]
+    with pytest.raises(ValueError):
+        m({"points": None}, return_loss=False)          # one sweep is not enough: forward takes [previous, current]
+
+
 def test_swv_oracle_window_bookkeeping():
     """window partition / reverse are inverses, the shift mask separates exactly the wrapped regions (H3 oracle helpers)"""
     import torch
