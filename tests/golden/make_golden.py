@@ -760,6 +760,82 @@ def gen_stream():
     save("stream.npz", **out)
 
 
+# ----------------------------------------------------------------------------- next-4 PolarStreamBDCP (two sweeps, ego-rotation warp)
+BDCP_VOXEL = (0.784, 0.0984 / 2, 8.0)
+BDCP_ANGLES = (0.04, -0.06)
+
+
+def gen_stream_bdcp():
+    """the reference's PolarStreamBDCP on CPU (torch.cuda.current_device patched to name the CPU for its mesh grids): two synthetic
+    sweeps of batch 2 split into 4 sectors by the reference's own voxelize_streaming_polar + collate; stored: the warped per-layer
+    maps of the previous sweep (what forward_one_sweep('feature_only') returns) and the raw head tensors of the current sweep
+    (a forward hook on the head; the hook ends the call before the reference's CUDA NMS)"""
+    nsec, batch = 4, 2
+    rng_ = list(synth.NUSC_RANGE)
+    heads = {"reg": (2, 2), "rot_vel": (2, 2), "height": (1, 2), "dim": (3, 2)}
+    cfg = dict(type="PolarStreamBDCP", nsectors=nsec, pretrained=None,
+               reader=dict(type="DynamicPFNet", num_filters=[32, 32], num_input_features=7, voxel_shape="cylinder", xyz_cluster=True, raz_cluster=True,
+                           xy_center=True, ra_center=True, voxel_size=list(BDCP_VOXEL), pc_range=rng_),
+               backbone=dict(type="DynamicPPScatter", ds_factor=1),
+               neck=dict(type="RPNBDCP", layer_nums=[1, 1], ds_layer_strides=[2, 2], ds_num_filters=[32, 64], us_layer_strides=[1, 2], us_num_filters=[32, 32],
+                         num_input_features=32, logger=logging.getLogger("RPN")),
+               bbox_head=dict(type="CenterHeadSingle", in_channels=64, tasks=NUSC_TASKS, dataset="nuscenes", weight=0.5, code_weights=[1.0] * 10,
+                              common_heads=heads, voxel_shape="cylinder"),
+               seg_head=None, part_head=None)
+    test_cfg = ADict(pc_range=rng_, stateful_nms=True)
+    model = build_detector(cfg, train_cfg=None, test_cfg=test_cfg).eval()
+    synth.load_filled(model, base_seed=23)
+    vx = Voxelization(cfg=ADict(vox_cfg(synth.NUSC_RANGE, BDCP_VOXEL), nsectors=nsec), super_tasks=["det"])
+    tm = np.stack([np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]], np.float32) for a in BDCP_ANGLES])
+
+    def example(seed):
+        per_sample = []
+        for b in range(batch):
+            pts = synth.synth_sweep_polar(2500 + 100 * b, seed=seed + b)
+            secs, _ = vx.voxelize_streaming_polar({"mode": "val", "lidar": {"points": pts.copy()}}, {})
+            per_sample.append(secs["sectors"])
+        pts, gis, num = [], [], []
+        for sec in range(nsec):
+            for b in range(batch):
+                sd = per_sample[b][sec]["lidar"]
+                gi = np.ascontiguousarray(sd["voxels"]["grid_ind"]).astype(np.int64)
+                pts.append(sd["points"].astype(np.float32))
+                gis.append(np.pad(gi, ((0, 0), (1, 0)), constant_values=sec * batch + b))
+                num.append(len(gi))
+        shape = np.asarray(per_sample[0][0]["lidar"]["voxels"]["shape"])
+        n = nsec * batch
+        return dict(points=torch.from_numpy(np.concatenate(pts)), grid_ind=torch.from_numpy(np.concatenate(gis)), num_points=torch.tensor(num),
+                    voxel_size=np.stack([np.asarray(BDCP_VOXEL)] * n), pc_range=np.stack([np.asarray(rng_)] * n), grid_size=np.stack([shape] * n),
+                    metadata=[None] * n, transform_matrix=torch.from_numpy(np.concatenate([tm] * nsec)))
+
+    class _Done(Exception):
+        pass
+    grabbed = {}
+
+    def hook(mod, inp, outp):
+        grabbed["preds"] = outp
+        raise _Done
+    out = {"angles": np.asarray(BDCP_ANGLES)}
+    real = torch.cuda.current_device
+    torch.cuda.current_device = lambda: "cpu"
+    try:
+        with torch.no_grad():
+            prev = model.forward_one_sweep(example(70), "feature_only", False)
+            h = model.bbox_head.register_forward_hook(hook)
+            try:
+                model.forward_one_sweep(example(80), "eval", False, prev_sweep=prev)
+            except _Done:
+                pass
+            h.remove()
+    finally:
+        torch.cuda.current_device = real
+    for i, p in enumerate(prev):
+        out[f"warped{i}"] = p.numpy() if i == len(prev) - 1 else p[:, ::4].numpy()      # every fourth channel of the larger maps
+    for k, v in grabbed["preds"]["det_preds"][0].items():
+        out[f"pred_{k}"] = v.numpy()
+    save("stream_bdcp.npz", **out)
+
+
 # ----------------------------------------------------------------------------- next-4 global augmentation
 def gen_augment():
     """the reference's own augmentation functions under seeded np.random: inputs, outputs, and the seeds (the host side of the
@@ -802,6 +878,6 @@ def gen_double_flip():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static", "seg_head", "e2e", "stream", "augment", "double_flip"]
+    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static", "seg_head", "e2e", "stream", "stream_bdcp", "augment", "double_flip"]
     for w in which:
         globals()["gen_" + w]()
