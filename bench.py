@@ -579,16 +579,17 @@ def main():
         flops, ms, launches, tags = prof.collect(by_tag=True)
         ops.disable_conv_profiling()
         ach = flops / (ms * 1e-3) / 1e12
-        # MFMA work actually ISSUED: the Winograd launches issue 6 of their 9 algorithmic MACs
-        issued = sum(f * (2.0 / 3.0 if "F(2,3)" in t else 1.0) for t, (f, m, n) in tags.items()) / (ms * 1e-3) / 1e12
+        # MFMA work actually ISSUED: the Winograd launches issue 6 (F(2,3)) or 4.5 (F(4,3)) of their 9 algorithmic MACs
+        issued = sum(f * (2.0 / 3.0 if "F(2,3)" in t else 0.5 if "F(4,3)" in t else 1.0) for t, (f, m, n) in tags.items()) / (ms * 1e-3) / 1e12
         layers = {t: dict(launches_per_step=round(n / args.steps, 2), us=round(1e3 * m / n, 2), tflops=round(f / (m * 1e-3) / 1e12, 1))
                   for t, (f, m, n) in sorted(tags.items(), key=lambda kv: -kv[1][1])}
         roofline = dict(bound="mfma", kernel="conv_mfma_kernel / conv_wino_kernel family (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; the stride-1 3x3 "
-                                             "layers through a width-Winograd F(2,3) transform: 6 of the 9 algorithmic MACs reach the MFMA, so `achieved` "
-                                             "counts algorithmic FLOPs and can exceed the MFMA issue rate of a layer)",
+                                             "layers through a width-Winograd transform -- F(4,3) on the 256 x 256 maps, F(2,3) on the smaller ones: 4.5 / 6 of "
+                                             "the 9 algorithmic MACs reach the MFMA, so `achieved` counts algorithmic FLOPs and can exceed the MFMA issue "
+                                             "rate of a layer)",
                         achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                         issued=dict(tflops=round(issued, 3), frac=round(issued / PEAK_F32_MFMA_TFLOPS, 4),
-                                    note="MFMA FLOPs the kernels issue (Winograd launches: 2/3 of their algorithmic FLOPs): the matrix-pipe utilisation"),
+                                    note="MFMA FLOPs the kernels issue (Winograd launches: 2/3 resp. 1/2 of their algorithmic FLOPs): the matrix-pipe utilisation"),
                         traffic=committed_pmc_bytes(("conv_mfma_kernel", "conv_wino", "conv_small_n", "conv_multi"), per="launch"),
                         traffic_unit="HBM bytes per conv launch (offline PMC passes of this command, profiles/r2_pmc_traffic.csv)",
                         launches=launches, launches_per_step=round(launches / args.steps, 2), flops_per_launch=round(flops / launches),

@@ -875,6 +875,16 @@ size_t pn_conv_wino_packed_weight_floats(int cout, int cin);
 int pn_pack_conv_weight_wino_f32(const float *w_oihw, int cout, int cin, float *packed, pn_stream_t stream);
 int pn_conv2d_wino_nhwc_f32(const pn_conv_desc *desc, const float *in, const float *packed_w, const float *scale,
                             const float *shift, float *out, pn_stream_t stream);
+/* The same layers with F(4, 3) along the width (map width a multiple of 4; activation none or ReLU): six GEMMs over quads of
+ * adjacent output pixels, 4.5 MFMA-equivalents per output; a wave owns all six positions of its 32 quads x 32 columns, so the output
+ * transform is wave-local.  Block tile 32 quads x 128 columns, two blocks per CU; pn_conv_wino4_tiles = the number of block tiles
+ * of a launch (the caller takes this kernel when they fill the chip).  Weights: pn_pack_conv_weight_wino4_f32 from torch layout
+ * (transformed in double, rounded once); results agree with pn_conv2d_nhwc_f32 to ~4e-6 of the map's range.  rpn.py:124-142. */
+size_t pn_conv_wino4_packed_weight_floats(int cout, int cin);
+int pn_pack_conv_weight_wino4_f32(const float *w_oihw, int cout, int cin, float *packed, pn_stream_t stream);
+int pn_conv_wino4_tiles(const pn_conv_desc *desc);
+int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc *desc, const float *in, const float *packed_w, const float *scale,
+                             const float *shift, float *out, pn_stream_t stream);
 size_t pn_conv_stat_partial_floats(const pn_conv_desc *desc, int tile);
 int pn_conv2d_multi_f32(const pn_conv_job *jobs, int njobs, int tile, pn_stream_t stream);
 /* the same job list on the VALU kernel for convolutions with very few output columns (1x1 / 3x3, <= 64 input channels,

@@ -360,7 +360,7 @@ def conv2d(t: Tape, x: Node, w: Node, b: Optional[Node], stride=1, pad=0, relu=F
     """Conv2d(+bias)(+ReLU) on an NHWC map; w (Cout, Cin, k, k).  x may carry zero pad channels past Cin."""
     wv = w.v
     cout, cin, k, _ = wv.shape
-    layer = ops.ConvLayer(wv, stride=stride, pad=pad, shift=None if b is None else b.v, act=ops.ACT_RELU if relu else ops.ACT_NONE)
+    layer = ops.ConvLayer(wv, stride=stride, pad=pad, shift=None if b is None else b.v, act=ops.ACT_RELU if relu else ops.ACT_NONE, wino4=False)
     ct = x.v.shape[3]
     if ct != cin:
         layer.pad_input_channels(ct)

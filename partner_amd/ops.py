@@ -359,6 +359,10 @@ def disable_conv_profiling() -> None:
 
 _WINO_ON = os.environ.get("PN_CONV_WINO", "1") != "0"
 _WINO_MIN_TILES = int(os.environ.get("PN_CONV_WINO_MIN_TILES", "256"))
+# F(4, 3) (conv_wino4.hip): PN_CONV_WINO4=0 keeps F(2, 3); taken from this many 32-quad x 128-column block tiles on (measured: 144
+# tiles of the Waymo RPN's 128 x 72 x 256 -> 256 layer 78 us against 104 with F(2, 3); 128 tiles of the 128 x 128 x 128 layer 42 against 31)
+_WINO4_ON = os.environ.get("PN_CONV_WINO4", "1") != "0"
+_WINO4_MIN_TILES = int(os.environ.get("PN_CONV_WINO4_MIN_TILES", "140"))
 
 
 class ConvLayer:
@@ -368,7 +372,7 @@ class ConvLayer:
     scale / shift: per-output-channel affine (folded BatchNorm, or bias as shift)."""
 
     def __init__(self, weight: torch.Tensor, stride=1, pad=0, groups=1, scale=None, shift=None, act=ACT_NONE,
-                 deconv2x2=False, range_strata=0, dtype="f32"):
+                 deconv2x2=False, range_strata=0, dtype="f32", wino4=True):
         hip.require_device(weight)
         lib = hip.load()
         w = weight.detach().contiguous().float()
@@ -418,6 +422,11 @@ class ConvLayer:
                 and self.stride == 1 and self.pad == (1, 1) and self.cin % 4 == 0 and _WINO_ON):
             self.wino_packed = _f32(lib.pn_conv_wino_packed_weight_floats(self.cout, self.cin), dev)
             hip.call("pn_pack_conv_weight_wino_f32", w.data_ptr(), self.cout, self.cin, self.wino_packed.data_ptr(), st)
+        # ... and the F(4, 3) weights (4.5 MFMA equivalents per output) when the kernel's 128-column tiles fit the layer
+        self.wino4_packed = None
+        if self.wino_packed is not None and _WINO4_ON and wino4 and self.cout % 128 == 0 and self.act in (ACT_NONE, ACT_RELU):
+            self.wino4_packed = _f32(lib.pn_conv_wino4_packed_weight_floats(self.cout, self.cin), dev)
+            hip.call("pn_pack_conv_weight_wino4_f32", w.data_ptr(), self.cout, self.cin, self.wino4_packed.data_ptr(), st)
 
     def repack(self, weight: torch.Tensor, shift: Optional[torch.Tensor] = None) -> None:
         """refresh the packed copy from an updated weight of the same shape (training: once per step)"""
@@ -432,6 +441,8 @@ class ConvLayer:
                      self.packed.data_ptr(), st)
             if self.wino_packed is not None:
                 hip.call("pn_pack_conv_weight_wino_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino_packed.data_ptr(), st)
+            if self.wino4_packed is not None:
+                hip.call("pn_pack_conv_weight_wino4_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino4_packed.data_ptr(), st)
         if shift is not None:
             self.shift = shift
 
@@ -440,6 +451,11 @@ class ConvLayer:
             return False
         tiles = ((b * h * (w // 2) + 31) // 32) * ((self.cout + 63) // 64)   # 32-pair x 64-column tiles (the kernel takes 64-pair ones when they fill the chip)
         return tiles >= _WINO_MIN_TILES
+
+    def _use_wino4(self, b: int, h: int, w: int, accumulate: bool) -> bool:
+        if self.wino4_packed is None or accumulate or w % 4 or self.cin != self._pack_cin:
+            return False
+        return ((b * h * (w // 4) + 31) // 32) * (self.cout // 128) >= _WINO4_MIN_TILES
 
     def pad_input_channels(self, cin_padded: int) -> "ConvLayer":
         """declare that the input map carries zero pad channels up to a multiple of 4 (e.g. the 5-channel
@@ -488,8 +504,12 @@ class ConvLayer:
         prof = _PROFILER
         if prof is not None:
             ev = prof.begin(st)
-        use_wino = self._use_wino(b, h, w, accumulate)
-        if use_wino:
+        use_wino4 = self._use_wino4(b, h, w, accumulate)
+        use_wino = not use_wino4 and self._use_wino(b, h, w, accumulate)
+        if use_wino4:
+            hip.call("pn_conv2d_wino4_nhwc_f32", C.byref(d), x.data_ptr(), self.wino4_packed.data_ptr(), hip.ptr(self.scale), hip.ptr(self.shift),
+                     out.data_ptr(), st)
+        elif use_wino:
             hip.call("pn_conv2d_wino_nhwc_f32", C.byref(d), x.data_ptr(), self.wino_packed.data_ptr(), hip.ptr(self.scale), hip.ptr(self.shift),
                      out.data_ptr(), st)
         else:
@@ -502,7 +522,7 @@ class ConvLayer:
             else:
                 z = self.groups
                 macs = b * oh * ow * z * self.cout * self.cin * self.kh * self.kw
-            prof.end(ev, 2.0 * macs, st, tag=f"{oh}x{ow} {self.cin * self.groups}->{self.out_channels} k{self.kh}{'t' if self.deconv2x2 else ''}{'s' if self.range_strata > 1 else ''}{' F(2,3)' if use_wino else ''}")
+            prof.end(ev, 2.0 * macs, st, tag=f"{oh}x{ow} {self.cin * self.groups}->{self.out_channels} k{self.kh}{'t' if self.deconv2x2 else ''}{'s' if self.range_strata > 1 else ''}{' F(2,3)' if use_wino else ' F(4,3)' if use_wino4 else ''}")
         return out
 
 

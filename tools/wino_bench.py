@@ -29,6 +29,20 @@ def wino(x, w, scale, shift, act):
     return run
 
 
+def wino4(x, w, scale, shift, act):
+    b, h, wd, cin = x.shape
+    cout = w.shape[0]
+    packed = torch.empty(lib.pn_conv_wino4_packed_weight_floats(cout, cin), dtype=torch.float32, device=dev)
+    hip.call("pn_pack_conv_weight_wino4_f32", w.contiguous().data_ptr(), cout, cin, packed.data_ptr(), hip.stream())
+    d = ops.ConvDesc(b, h, wd, cin, cout, 1, 3, 3, 1, 1, 1, cin, 0, cout, 0, act, 0, 0)
+    out = torch.empty((b, h, wd, cout), dtype=torch.float32, device=dev)
+
+    def run():
+        hip.call("pn_conv2d_wino4_nhwc_f32", C.byref(d), x.data_ptr(), packed.data_ptr(), hip.ptr(scale), hip.ptr(shift), out.data_ptr(), hip.stream())
+        return out
+    return run
+
+
 def timeit(fn, n=30):
     for _ in range(5):
         fn()
@@ -42,7 +56,8 @@ def timeit(fn, n=30):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for (b, h, wd, cin, cout) in [(1, 256, 256, 128, 128), (1, 128, 128, 128, 128), (1, 64, 64, 256, 256), (2, 30, 22, 36, 70), (1, 7, 6, 8, 5)]:
+for (b, h, wd, cin, cout) in [(1, 256, 256, 128, 128), (1, 128, 128, 128, 128), (1, 64, 64, 256, 256), (1, 256, 144, 128, 128), (1, 128, 72, 256, 256),
+                              (2, 30, 24, 36, 70), (2, 30, 22, 36, 70), (1, 7, 8, 8, 5)]:
     x = torch.randn((b, h, wd, cin), device=dev)
     w = torch.randn((cout, cin, 3, 3), device=dev) * 0.05
     scale = torch.rand(cout, device=dev) + 0.5
@@ -57,4 +72,9 @@ for (b, h, wd, cin, cout) in [(1, 256, 256, 128, 128), (1, 128, 128, 128, 128), 
     ed, ew = float((yd.double() - ref).abs().max()) / sc, float((yw.double() - ref).abs().max()) / sc
     td, tw = timeit(lambda: direct(x)), timeit(run)
     gf = 2.0 * b * h * wd * cin * cout * 9 / 1e9
+    if wd % 4 == 0:
+        r4 = wino4(x, w, scale, shift, ops.ACT_RELU)
+        e4 = float((r4().double() - ref).abs().max()) / sc
+        t4 = timeit(r4)
+        print(f"    F(4,3): err {e4:.2e}  {t4:.1f} us ({gf / t4 * 1e-3:.1f} TF-equivalent)")
     print(f"{b}x{h}x{wd} {cin}->{cout}: err direct {ed:.2e} wino {ew:.2e} | direct {td:.1f} us ({gf / td * 1e-3:.1f} TF)  wino {tw:.1f} us ({gf / tw * 1e-3:.1f} TF-equivalent)  x{td / tw:.2f}")
