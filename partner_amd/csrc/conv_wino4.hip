@@ -316,6 +316,214 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
   if (prev_pt >= 0) epilogue(prev_pt, prev_n0, prev_sc, prev_sh);
 }
 
+// ---- K-split form for maps whose 32-quad x 128-column tiles would not fill the chip (the 128 x 128 and 64 x 64 maps of the nuScenes
+// RPN: 128 resp. 64 such tiles on 512 block slots).  Block tile = 32 quads x 32 columns, FOUR times as many blocks; the four waves of a
+// block share the tile and split K: wave ks multiplies sub-step ks (8 of the 32 channels) of every K step, one barrier per K step.
+// The four partial accumulator sets are joined through LDS all-to-all -- wave d receives rows 8 d .. 8 d + 7 (accumulator registers
+// 4 d .. 4 d + 3 of all six positions) from the other three -- so every wave transforms and stores a quarter of the tile.
+constexpr int W4K_N = 32;
+constexpr size_t wino4_ks_smem() {
+  const size_t stage = (2 * (size_t)(6 * 32 * W4_LD) + 2 * W4K_N) * sizeof(float);
+  const size_t join = (size_t)4 * 3 * 6 * 4 * 64 * sizeof(float);      // [dst wave][src slot][q][rr][lane]
+  return stage > join ? stage : join;
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wino4_ks_kernel(Wino4Args a) {
+  constexpr int WQ = 32;
+  constexpr int WA_FLOATS = 6 * WQ * W4_LD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, ks = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int xq = a.qtiles >> 3, xr = a.qtiles & 7;
+  const int px0 = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+  const int xtiles = (xcd < xr ? xq + 1 : xq) * a.ncol;      // a.ncol = 32-column tiles here
+  int pt = 0, n0 = 0;
+  const int pl = tid >> 3, c4 = tid & 7;
+
+  const long long back = ((long long)a.W + 1) * a.in_ps;
+  unsigned a_off = 0, a_off0 = 0, a_off5 = 0, a_rmask = 0;
+  unsigned b_base = 0;
+  int ld_kh = 0, ld_chunk = 0, lb_kh = 0, lb_chunk = 0;
+  float sc = 1.f, sh = 0.f;
+  auto setup_tile = [&](int tl) {
+    pt = px0 + tl / a.ncol;
+    n0 = (tl - (tl / a.ncol) * a.ncol) * W4K_N;
+    ld_kh = ld_chunk = lb_kh = lb_chunk = 0;
+    const int p = pt * WQ + pl;
+    const bool ok = p < a.total_quads;
+    const int pp = ok ? p : 0;
+    const int rowi = pp / a.quads_per_row, oq = pp - rowi * a.quads_per_row;
+    const int b = rowi / a.H, oh = rowi - b * a.H;
+    const long long pix = ((long long)b * a.H + (oh - 1)) * a.W + (4 * oq - 1);
+    const unsigned off = (unsigned)((pix * a.in_ps + back + a.in_co + c4 * 4) * 4);
+    a_off = off;
+    a_off0 = oq > 0 ? off : 0xffffffffu;
+    a_off5 = oq + 1 < a.quads_per_row ? off : 0xffffffffu;
+    unsigned rm = 0;
+    for (int kh = 0; kh < 3; ++kh)
+      if (ok && (unsigned)(oh + kh - 1) < (unsigned)a.H) rm |= 1u << kh;
+    a_rmask = rm;
+    b_base = (unsigned)((((size_t)2 * ks + lh) * a.cout_pad + n0 + li) * 16);
+    // the column's affine: requested here, a whole K loop before the epilogue uses it
+    const int c = n0 + li;
+    sc = (a.scale && c < a.Cout) ? a.scale[c] : 1.f;
+    sh = (a.shift && c < a.Cout) ? a.shift[c] : 0.f;
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<float*>(a.in)) - back * 4, 0,
+                                                                         a.in_bytes + (unsigned)(back * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const int nsteps = 3 * a.chunks;
+  const unsigned cp16 = (unsigned)a.cout_pad * 16u;
+  const unsigned ps4 = (unsigned)a.in_ps * 4u;
+
+  f32x4 ra[6];
+  auto load_a = [&](bool live) {
+    const unsigned so_a = (unsigned)((ld_kh * a.W * a.in_ps + ld_chunk * 32) * 4);
+    const bool rok = live & (ld_chunk * 32 + c4 * 4 < a.Cin) & (((a_rmask >> ld_kh) & 1u) != 0);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const unsigned base = j == 0 ? a_off0 : j == 5 ? a_off5 : a_off;
+      ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, rok ? base : 0xffffffffu, so_a + (unsigned)j * ps4, 0));
+    }
+    if (++ld_kh == 3) { ld_kh = 0; ++ld_chunk; }
+  };
+  auto store_a = [&](int buf) {
+    float* As = smem + buf * WA_FLOATS + pl * W4_LD + c4 * 4;
+    const f32x4 d0 = ra[0], d1 = ra[1], d2 = ra[2], d3 = ra[3], d4 = ra[4], d5 = ra[5];
+    const f32x4 e = d4 - 4.f * d2, o = d3 - 4.f * d1;
+    const f32x4 f = d4 - d2, g = 2.f * (d3 - d1);
+    *reinterpret_cast<f32x4*>(As + 0 * WQ * W4_LD) = (4.f * d0 - 5.f * d2) + d4;
+    *reinterpret_cast<f32x4*>(As + 1 * WQ * W4_LD) = e + o;
+    *reinterpret_cast<f32x4*>(As + 2 * WQ * W4_LD) = e - o;
+    *reinterpret_cast<f32x4*>(As + 3 * WQ * W4_LD) = f + g;
+    *reinterpret_cast<f32x4*>(As + 4 * WQ * W4_LD) = f - g;
+    *reinterpret_cast<f32x4*>(As + 5 * WQ * W4_LD) = (4.f * d1 - 5.f * d3) + d5;
+  };
+  unsigned so_b = 0;
+  auto b_step_offset = [&]() { return (unsigned)((lb_chunk * 3 + lb_kh) * 48) * cp16; };
+  f32x16 acc[6];
+  const int a_frag = li * W4_LD + lh * 4 + ks * 8;
+  f32x4 af[6], bf[2][6];
+  auto read_a = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) af[q] = *reinterpret_cast<const f32x4*>(smem + buf * WA_FLOATS + a_frag + q * WQ * W4_LD);
+  };
+  auto load_b = [&](bool live, f32x4 (&f)[6]) {      // this wave's sub-step of the K step at (lb_chunk, lb_kh), then advance
+    const unsigned vo = live ? b_base : 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) f[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vo, so_b + (unsigned)(q * 8) * cp16, 0));
+    if (++lb_kh == 3) { lb_kh = 0; ++lb_chunk; }
+    so_b = b_step_offset();
+  };
+  // one K step: barrier (tile t is in LDS, tile t-1 has been read by everyone), this wave's six A fragments, 24 MFMAs; in their shadow
+  // the weight fragments of step t+1, the transform + LDS stores of step t+1's tile and the input loads of step t+2
+  auto kstep = [&](auto par_c, int t) __attribute__((always_inline)) {
+    constexpr int buf = decltype(par_c)::value;
+    __syncthreads();
+    read_a(buf);
+    load_b(t + 1 < nsteps, bf[buf ^ 1]);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][kk], bf[buf][q][kk], acc[q], 0, 0, 0);
+    store_a(buf ^ 1);
+    load_a(t + 2 < nsteps);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 20, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  // join + epilogue of wave D (compile-time: the accumulator registers are indexed statically)
+  auto finish = [&](auto d_c, int ept, int en0) __attribute__((always_inline)) {
+    constexpr int D = decltype(d_c)::value;
+    float* J = smem + lane;
+    // send: to every other wave its quarter of this wave's partial sums
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      if (d == D) continue;
+      const int sl = D < d ? D : D - 1;
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) J[((((d * 3 + sl) * 6 + q) * 4 + rr)) * 64] = acc[q][4 * d + rr];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[q][4 * D + rr] += J[((((D * 3 + sl) * 6 + q) * 4 + rr)) * 64];
+    const int col = en0 + li;
+    if (col < a.Cout) {
+      const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int r = 4 * D + rr;
+        const int p = ept * WQ + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (p >= a.total_quads) continue;
+        const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+        const float y0 = (m0 + s12) + s34;
+        const float y1 = d12 + 2.f * d34;
+        const float y2 = s12 + 4.f * s34;
+        const float y3 = (d12 + 8.f * d34) + m5;
+        const int rowi = p / a.quads_per_row, oq = p - rowi * a.quads_per_row;
+        float* o = a.out + ((size_t)rowi * a.W + 4 * oq) * a.out_ps + a.out_co + col;
+        o[0] = fmaxf(fmaf(y0, sc, sh), lo);
+        o[a.out_ps] = fmaxf(fmaf(y1, sc, sh), lo);
+        o[2 * (size_t)a.out_ps] = fmaxf(fmaf(y2, sc, sh), lo);
+        o[3 * (size_t)a.out_ps] = fmaxf(fmaf(y3, sc, sh), lo);
+      }
+    }
+    __syncthreads();   // the join buffer overlaps the next tile's stages
+  };
+
+  for (int tl = slot; tl < xtiles; tl += per_xcd) {
+    setup_tile(tl);
+    so_b = b_step_offset();
+    load_a(true);
+    load_b(true, bf[0]);
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    store_a(0);
+    load_a(nsteps > 1);
+    for (int t = 0; t < nsteps; t += 2) {
+      kstep(I0{}, t);
+      if (t + 1 < nsteps) kstep(I1{}, t + 1);
+    }
+    __syncthreads();   // every wave is done reading the last stage: the join may overwrite it
+    if (ks == 0) finish(I0{}, pt, n0);
+    else if (ks == 1) finish(I1{}, pt, n0);
+    else if (ks == 2) finish(I2{}, pt, n0);
+    else finish(I3{}, pt, n0);
+  }
+}
+
 // torch (Cout, Cin, 3, 3) -> [chunk][kh][q 6][k4 8][cout_pad][4], transformed in double, rounded once
 __global__ void pack_wino4_weight_kernel(const float* __restrict__ w, int cout, int cin, int chunks, int cout_pad, float* __restrict__ packed, size_t total) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -361,6 +569,15 @@ int pn_conv_wino4_tiles(const pn_conv_desc* d) {
   return (int)std::min<long long>(1 << 30, ((quads + 31) / 32) * pn::cdiv(d->cout, W4N));
 }
 
+// the form a launch takes: 1 = 32 quads x 128 columns per block (every wave on the whole K range), 2 = 32 quads x 32 columns per block
+// with K split over the block's four waves (maps with fewer than ~3/4 of the 2-per-CU block slots in tiles of the first form)
+static int wino4_form(long long tiles128, int ncu) {
+  static const int force = [] { const char* e = getenv("PN_WINO4_KSPLIT"); return e ? atoi(e) : -1; }();
+  if (force == 0) return 1;
+  if (force == 1) return 2;
+  return tiles128 * 4 >= 3LL * 2 * ncu ? 1 : 2;
+}
+
 int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc* d, const float* in, const float* packed_w, const float* scale, const float* shift, float* out,
                              pn_stream_t stream) {
   PN_REQUIRE(d && in && packed_w && out, "conv_wino4: null pointer");
@@ -400,12 +617,23 @@ int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc* d, const float* in, const float
   }
   const int ncu = (dev >= 0 && dev < 64) ? cus[dev] : 256;
   a.qtiles = pn::cdiv(a.total_quads, 32);
-  const long long tiles = (long long)a.qtiles * a.ncol;
-  // persistent blocks, two per CU (a multiple of 8: the XCD count), fewer when there are fewer tiles
-  const dim3 grid((unsigned)std::min<long long>(2 * ncu, (tiles + 7) / 8 * 8));
   pn::ProfileSlot ps;
   const bool prof = pn::take_profile_slot(ps);
   hipStream_t st = pn::S(stream);
+  if (wino4_form((long long)a.qtiles * a.ncol, ncu) == 2) {
+    static bool ks_done[64] = {false};
+    if (pn::first_use_on_device(ks_done))
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_ks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino4_ks_smem());
+    a.ncol = a.cout_pad / W4K_N;
+    const long long tiles = (long long)a.qtiles * a.ncol;
+    const dim3 grid((unsigned)std::min<long long>(2 * ncu, (tiles + 7) / 8 * 8));
+    if (prof) hipExtLaunchKernelGGL(conv_wino4_ks_kernel, grid, dim3(256), wino4_ks_smem(), st, ps.start, ps.stop, 0, a);
+    else hipLaunchKernelGGL(conv_wino4_ks_kernel, grid, dim3(256), wino4_ks_smem(), st, a);
+    return pn::check_launch("conv_wino4_ks_kernel");
+  }
+  const long long tiles = (long long)a.qtiles * a.ncol;
+  // persistent blocks, two per CU (a multiple of 8: the XCD count), fewer when there are fewer tiles
+  const dim3 grid((unsigned)std::min<long long>(2 * ncu, (tiles + 7) / 8 * 8));
   if (prof) hipExtLaunchKernelGGL(conv_wino4_kernel, grid, dim3(256), wino4_smem(32), st, ps.start, ps.stop, 0, a);
   else hipLaunchKernelGGL(conv_wino4_kernel, grid, dim3(256), wino4_smem(32), st, a);
   return pn::check_launch("conv_wino4_kernel");

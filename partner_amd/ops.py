@@ -359,10 +359,12 @@ def disable_conv_profiling() -> None:
 
 _WINO_ON = os.environ.get("PN_CONV_WINO", "1") != "0"
 _WINO_MIN_TILES = int(os.environ.get("PN_CONV_WINO_MIN_TILES", "256"))
-# F(4, 3) (conv_wino4.hip): PN_CONV_WINO4=0 keeps F(2, 3); taken from this many 32-quad x 128-column block tiles on (measured: 144
-# tiles of the Waymo RPN's 128 x 72 x 256 -> 256 layer 78 us against 104 with F(2, 3); 128 tiles of the 128 x 128 x 128 layer 42 against 31)
+# F(4, 3) (conv_wino4.hip): PN_CONV_WINO4=0 keeps F(2, 3); taken from this many 32-quad x 32-column tiles on (the kernel's K-split form
+# runs one block per such tile, the plain form one per 32 quads x 128 columns when those fill the chip).  Measured against F(2, 3):
+# 256 x 256 x 128 -> 128: 79 us / 112; 128 x 128 x 128 -> 128 (512 tiles): 27 / 31; 64 x 64 x 256 -> 256 (256 tiles): 31 / 37;
+# Waymo RPN 256 x 144 x 128 -> 128: 61 / 105, 128 x 72 x 256 -> 256: 71 / 104
 _WINO4_ON = os.environ.get("PN_CONV_WINO4", "1") != "0"
-_WINO4_MIN_TILES = int(os.environ.get("PN_CONV_WINO4_MIN_TILES", "140"))
+_WINO4_MIN_TILES = int(os.environ.get("PN_CONV_WINO4_MIN_TILES", "256"))
 
 
 class ConvLayer:
@@ -455,7 +457,7 @@ class ConvLayer:
     def _use_wino4(self, b: int, h: int, w: int, accumulate: bool) -> bool:
         if self.wino4_packed is None or accumulate or w % 4 or self.cin != self._pack_cin:
             return False
-        return ((b * h * (w // 4) + 31) // 32) * (self.cout // 128) >= _WINO4_MIN_TILES
+        return ((b * h * (w // 4) + 31) // 32) * (self.cout // 32) >= _WINO4_MIN_TILES
 
     def pad_input_channels(self, cin_padded: int) -> "ConvLayer":
         """declare that the input map carries zero pad channels up to a multiple of 4 (e.g. the 5-channel

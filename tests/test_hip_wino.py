@@ -59,8 +59,7 @@ def test_wino_matches_float64_and_direct(dev, case):
         err = float((y.double() - r).abs().max() / (r.abs().max() + 1e-30))
         assert err < 2e-5, (case, err)
     direct = ops.ConvLayer(w, stride=1, pad=1, scale=scale, shift=shift, act=ops.ACT_RELU)
-    if direct.wino_packed is not None:          # ConvLayer takes the Winograd kernel by itself on large maps: compare against the forced direct kernel
-        direct.wino_packed = None
+    direct.wino_packed = direct.wino4_packed = None    # ConvLayer takes the Winograd kernels by itself on large maps: compare against the forced direct kernel
     yd = direct(x)
     yw = run_wino(x, w, scale, shift, ops.ACT_RELU)
     assert float((yd - yw).abs().max() / (yd.abs().max() + 1e-30)) < 2e-5
@@ -103,19 +102,25 @@ def test_conv_layer_picks_wino_only_on_large_maps(dev):
     assert ops.ConvLayer(w, stride=2, pad=1).wino_packed is None
     # both kernels behind the same layer agree on a map above the threshold
     x = torch.randn((1, 128, 128, 128), device=dev)
-    y1 = layer(x)
-    layer.wino_packed = None
-    y0 = layer(x)
+    keep4, layer.wino4_packed = layer.wino4_packed, None
+    y1 = layer(x)                                   # F(2, 3)
+    keep2, layer.wino_packed = layer.wino_packed, None
+    y0 = layer(x)                                   # direct
     assert float((y1 - y0).abs().max() / y0.abs().max()) < 2e-5
-    # F(4, 3) from 140 block tiles (32 quads x 128 columns) on: the 256 x 256 maps of the nuScenes RPN, every stride-1 layer of the Waymo RPN
-    assert layer.wino4_packed is not None and layer._use_wino4(1, 256, 256, False) and layer._use_wino4(1, 256, 144, False)
-    assert not layer._use_wino4(1, 128, 128, False) and not layer._use_wino4(1, 256, 254, False) and not layer._use_wino4(1, 256, 256, True)
+    layer.wino_packed, layer.wino4_packed = keep2, keep4
+    # F(4, 3) from 256 tiles of 32 quads x 32 columns on: every stride-1 layer of the nuScenes and of the Waymo RPN
+    assert layer.wino4_packed is not None and layer._use_wino4(1, 256, 256, False) and layer._use_wino4(1, 256, 144, False) and layer._use_wino4(1, 128, 128, False)
+    assert not layer._use_wino4(1, 32, 64, False) and not layer._use_wino4(1, 256, 254, False) and not layer._use_wino4(1, 256, 256, True)
     assert ops.ConvLayer(torch.randn((64, 128, 3, 3), device=dev), stride=1, pad=1).wino4_packed is None        # 128-column tiles only
     x = torch.randn((1, 256, 144, 128), device=dev)
-    y4 = layer(x)
-    layer.wino4_packed = None
-    y0 = layer(x)
-    assert float((y4 - y0).abs().max() / y0.abs().max()) < 2e-5
+    for shape in ((1, 256, 144, 128), (1, 128, 128, 128), (1, 256, 256, 128)):     # K-split form, K-split form, plain form
+        x = torch.randn(shape, device=dev)
+        y4 = layer(x)
+        k4, k2 = layer.wino4_packed, layer.wino_packed
+        layer.wino4_packed = layer.wino_packed = None
+        y0 = layer(x)
+        layer.wino4_packed, layer.wino_packed = k4, k2
+        assert float((y4 - y0).abs().max() / y0.abs().max()) < 2e-5, shape
 
 
 def test_c2_model_runs_its_stride1_layers_on_the_winograd_kernels(dev):
@@ -141,7 +146,7 @@ def test_c2_model_runs_its_stride1_layers_on_the_winograd_kernels(dev):
         ops.disable_conv_profiling()
     wino = {t: v[2] for t, v in tags.items() if "F(2,3)" in t or "F(4,3)" in t}
     assert sum(wino.values()) == 13, wino
-    assert any(t.startswith("256x256") and "F(4,3)" in t for t in wino) and any(t.startswith("64x64") and "F(2,3)" in t for t in wino)
+    assert any(t.startswith("256x256") and "F(4,3)" in t for t in wino) and any(t.startswith("64x64") and "F(4,3)" in t for t in wino)
 
 
 # ------------------------------------------------------------------------------------------ F(4, 3)  (csrc/conv_wino4.hip)
@@ -161,7 +166,7 @@ def run_wino4(x, w, scale, shift, act, in_co=0, cin=None, out=None, out_co=0):
 
 
 CASES4 = [(1, 256, 256, 128, 128), (1, 256, 144, 128, 128), (1, 128, 72, 256, 256), (2, 30, 24, 36, 70), (1, 7, 8, 8, 5), (3, 5, 4, 4, 1), (1, 9, 132, 64, 130),
-          (1, 1, 4, 32, 33), (2, 3, 260, 20, 129)]
+          (1, 1, 4, 32, 33), (2, 3, 260, 20, 129), (1, 100, 512, 8, 130), (3, 67, 100, 12, 128)]   # the last two: plain form with ragged channels / tiles
 
 
 @pytest.mark.parametrize("case", CASES4, ids=str)

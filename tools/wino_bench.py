@@ -63,7 +63,7 @@ for (b, h, wd, cin, cout) in [(1, 256, 256, 128, 128), (1, 128, 128, 128, 128), 
     scale = torch.rand(cout, device=dev) + 0.5
     shift = torch.randn(cout, device=dev)
     direct = ops.ConvLayer(w, stride=1, pad=1, scale=scale, shift=shift, act=ops.ACT_RELU)
-    direct.wino_packed = None      # ConvLayer would take the Winograd kernel by itself on the large maps: force the direct kernel here
+    direct.wino_packed = direct.wino4_packed = None      # ConvLayer would take the Winograd kernels by itself on the large maps: force the direct kernel here
     run = wino(x, w, scale, shift, ops.ACT_RELU)
     yd, yw = direct(x), run()
     ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1) * scale.double()[None, :, None, None]
