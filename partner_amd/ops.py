@@ -424,9 +424,9 @@ class ConvLayer:
                 and self.stride == 1 and self.pad == (1, 1) and self.cin % 4 == 0 and _WINO_ON):
             self.wino_packed = _f32(lib.pn_conv_wino_packed_weight_floats(self.cout, self.cin), dev)
             hip.call("pn_pack_conv_weight_wino_f32", w.data_ptr(), self.cout, self.cin, self.wino_packed.data_ptr(), st)
-        # ... and the F(4, 3) weights (4.5 MFMA equivalents per output) when the kernel's 128-column tiles fit the layer
+        # ... and the F(4, 3) weights (4.5 MFMA equivalents per output) when the kernel's 32-column wave tiles fit the layer
         self.wino4_packed = None
-        if self.wino_packed is not None and _WINO4_ON and wino4 and self.cout % 128 == 0 and self.act in (ACT_NONE, ACT_RELU):
+        if self.wino_packed is not None and _WINO4_ON and wino4 and self.cout % 32 == 0 and self.act in (ACT_NONE, ACT_RELU):
             self.wino4_packed = _f32(lib.pn_conv_wino4_packed_weight_floats(self.cout, self.cin), dev)
             hip.call("pn_pack_conv_weight_wino4_f32", w.data_ptr(), self.cout, self.cin, self.wino4_packed.data_ptr(), st)
 

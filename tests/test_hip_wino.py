@@ -111,7 +111,7 @@ def test_conv_layer_picks_wino_only_on_large_maps(dev):
     # F(4, 3) from 256 tiles of 32 quads x 32 columns on: every stride-1 layer of the nuScenes and of the Waymo RPN
     assert layer.wino4_packed is not None and layer._use_wino4(1, 256, 256, False) and layer._use_wino4(1, 256, 144, False) and layer._use_wino4(1, 128, 128, False)
     assert not layer._use_wino4(1, 32, 64, False) and not layer._use_wino4(1, 256, 254, False) and not layer._use_wino4(1, 256, 256, True)
-    assert ops.ConvLayer(torch.randn((64, 128, 3, 3), device=dev), stride=1, pad=1).wino4_packed is None        # 128-column tiles only
+    assert ops.ConvLayer(torch.randn((64, 128, 3, 3), device=dev), stride=1, pad=1).wino4_packed is not None and ops.ConvLayer(torch.randn((72, 128, 3, 3), device=dev), stride=1, pad=1).wino4_packed is None        # whole 32-column wave tiles only
     x = torch.randn((1, 256, 144, 128), device=dev)
     for shape in ((1, 256, 144, 128), (1, 128, 128, 128), (1, 256, 256, 128)):     # K-split form, K-split form, plain form
         x = torch.randn(shape, device=dev)
