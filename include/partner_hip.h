@@ -885,6 +885,21 @@ int pn_pack_conv_weight_wino4_f32(const float *w_oihw, int cout, int cin, float 
 int pn_conv_wino4_tiles(const pn_conv_desc *desc);
 int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc *desc, const float *in, const float *packed_w, const float *scale,
                              const float *shift, float *out, pn_stream_t stream);
+/* The FIRST 3x3 convolution of the backbone (ZeroPad2d(1) + Conv2d(3, stride 1 | 2) + folded BatchNorm + activation, rpn.py:124-142) on
+ * the pillar canvas of DynamicPPScatter (pillar_encoder.py:393-432), exploiting its sparsity: only (pillar, tap) pairs are multiplied
+ * -- per tap one gathered MFMA GEMM over the pairs whose parity reaches an output, then a fixed-order reduction over the nine taps with
+ * the affine + activation (outputs no pillar reaches get act(shift)).  unq_keys / num_voxels: the frame's sorted cell keys
+ * ((b * H + y) * W + x) and their count on the device (pn_unique_voxels / the fused frame index); the caller promises that every
+ * non-zero pixel of the canvas is among them.  cin 32, 64 or 128.  Weights: pn_pack_pillar_conv_weight_f32 from torch
+ * layout (Cout, Cin, 3, 3).  Deterministic; agrees with pn_conv2d_nhwc_f32 to ~1e-6 of the map's range. */
+size_t pn_pillar_conv_packed_weight_floats(int cout, int cin);
+int pn_pack_pillar_conv_weight_f32(const float *w_oihw, int cout, int cin, float *packed, pn_stream_t stream);
+size_t pn_pillar_conv_workspace_bytes(int v_capacity, int batch, int oh, int ow, int cout);
+int pn_pillar_conv3x3_f32(const float *canvas, int batch, int h, int w, int cin, int in_pixel_stride, int in_channel_offset,
+                          const uint32_t *unq_keys, const int32_t *num_voxels, int v_capacity, int stride,
+                          const float *packed_w, int cout, const float *scale, const float *shift, int act, float *out,
+                          int out_pixel_stride, int out_channel_offset, void *workspace, size_t workspace_bytes,
+                          pn_stream_t stream);
 size_t pn_conv_stat_partial_floats(const pn_conv_desc *desc, int tile);
 int pn_conv2d_multi_f32(const pn_conv_job *jobs, int njobs, int tile, pn_stream_t stream);
 /* the same job list on the VALU kernel for convolutions with very few output columns (1x1 / 3x3, <= 64 input channels,

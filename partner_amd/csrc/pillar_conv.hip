@@ -1,0 +1,326 @@
+// The FIRST 3x3 convolution of the BEV backbone on the pillar canvas, exploiting that the canvas is sparse.
+// Replaces (arithmetic) ZeroPad2d(1) + Conv2d(3, stride s) + folded BatchNorm + ReLU of RPN block 0 (det3d/models/necks/rpn.py:124-142)
+// applied to DynamicPPScatter's canvas (det3d/models/readers/pillar_encoder.py:393-432), whose non-zero pixels are exactly the frame's
+// V pillars (~11 % of the 512 x 512 map at 30k points).  The dense kernel spends 9 taps x Cin x Cout MACs on every output pixel;
+// only (active input pixel, tap) PAIRS contribute: 2.25 V of them at stride 2 (a pixel reaches one output per compatible tap parity)
+// against 9 * OH * OW dense (output, tap) pairs -- 9.4x fewer at 28k pillars.
+//
+//   1. pair_kernel      one thread per pillar: for every tap (kh, kw) with (y + 1 - kh) % s == 0 and (x + 1 - kw) % s == 0 the pair
+//                       (input pixel -> output pixel (y + 1 - kh) / s, (x + 1 - kw) / s) is appended to the tap's list (slot =
+//                       atomicAdd on the tap's counter) and the slot is recorded at slots[output][tap].  An output has at most one
+//                       pair per tap, so the ORDER inside a list never reaches the arithmetic.
+//   2. pair_gemm_kernel per tap t one dense GEMM  partial[t][slot][:] = canvas[pair.input][:] . W_t  over the tap's list (MFMA,
+//                       128 gathered rows x Cout per block, the whole K = Cin staged in LDS once, weights straight into the MFMA
+//                       operands from L2).
+//   3. pair_reduce_kernel  out[o][:] = act(scale * sum_{t = 0..8, slots[o][t] >= 0} partial[t][slots[o][t]][:] + shift) in FIXED tap
+//                       order (deterministic, replay == eager bit for bit); outputs no pillar reaches get act(shift).
+// Same terms as the dense convolution, summed per tap first (128-term dot products) and then over taps: agreement with the dense
+// kernel ~1e-6 of the map's range.  The caller promises that every non-zero pixel of the canvas is in the key list.
+#include "pn_common.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int PC_ROWS = 128;      // gathered rows per GEMM block
+
+struct PairArgs {
+  const uint32_t* keys;
+  const int32_t* v_dev;
+  int v_cap;
+  int B, H, W, OH, OW, stride;
+  int cap;                  // rows per tap list (multiple of PC_ROWS)
+  int32_t* cnt;             // [9] (+ padding)
+  int32_t* pair_in;         // [9][cap] input pixel index
+  int32_t* slots;           // [B * OH * OW][9], -1 = no pair
+};
+
+// the nine counters to 0 and every slot to -1, as an ordinary kernel (memset nodes of a captured hipGraph are not re-executed reliably
+// between replays on ROCm 7.2, see pn_common.h)
+__global__ void pair_init_kernel(int32_t* __restrict__ cnt, int4* __restrict__ slots4, size_t n4, int32_t* __restrict__ slots, size_t n) {
+  if (blockIdx.x == 0 && threadIdx.x < 16) cnt[threadIdx.x] = 0;
+  const int4 m = {-1, -1, -1, -1};
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) slots4[i] = m;
+  for (size_t i = n4 * 4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) slots[i] = -1;
+}
+
+// blocks of 1024 threads: the pairs of a block's 1024 pillars are counted per tap with wave ballots, ONE atomic per (block, tap)
+// reserves the block's slots (same-address atomics serialise at L2: one per (wave, tap) took 47 us for 28k pillars)
+__global__ __launch_bounds__(1024) void pair_kernel(PairArgs a) {
+  __shared__ int wcnt[16][9];
+  __shared__ int bbase[9];
+  const int V = min(*a.v_dev, a.v_cap);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = blockIdx.x * 1024; base < V; base += gridDim.x * 1024) {
+    const int i = base + threadIdx.x;
+    int x = 0, y = 0, b = 0;
+    bool live = i < V;
+    if (live) {
+      uint32_t key = a.keys[i];
+      x = key % a.W; key /= a.W;
+      y = key % a.H;
+      b = key / a.H;
+      live = b < a.B;
+    }
+    const int pix = (b * a.H + y) * a.W + x;
+    unsigned okbits = 0;
+    int rank[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ny = y + 1 - kh;
+      const bool oky = live && ny >= 0 && ny % a.stride == 0 && ny / a.stride < a.OH;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int nx = x + 1 - kw;
+        const bool ok = oky && nx >= 0 && nx % a.stride == 0 && nx / a.stride < a.OW;
+        const int t = kh * 3 + kw;
+        const unsigned long long mask = __ballot(ok);
+        rank[t] = __popcll(mask & ((1ull << lane) - 1ull));
+        if (ok) okbits |= 1u << t;
+        if (lane == 0) wcnt[wave][t] = __popcll(mask);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) { const int c = wcnt[w][threadIdx.x]; wcnt[w][threadIdx.x] = tot; tot += c; }   // exclusive over the waves
+      bbase[threadIdx.x] = tot ? atomicAdd(&a.cnt[threadIdx.x], tot) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (!((okbits >> t) & 1u)) continue;
+      const int slot = bbase[t] + wcnt[wave][t] + rank[t];
+      if (slot < a.cap) {
+        const int kh = t / 3, kw = t - kh * 3;
+        const int oy = (y + 1 - kh) / a.stride, ox = (x + 1 - kw) / a.stride;
+        a.pair_in[(size_t)t * a.cap + slot] = pix;
+        a.slots[((size_t)(b * a.OH + oy) * a.OW + ox) * 9 + t] = slot;
+      }
+    }
+    __syncthreads();   // wcnt / bbase are rewritten by the next chunk
+  }
+}
+
+struct GemmArgs {
+  const float* canvas;
+  const float* w;           // packed [9][cin / 4][cout_pad][4]
+  const int32_t* cnt;
+  const int32_t* pair_in;
+  float* partial;           // [9][cap][cout]
+  int cap, cin, in_ps, in_co, cout, cout_pad;
+};
+
+// block = 8 waves: wave (wm = 0..1, wn = 0..3) computes rows 64 wm .. 64 wm + 63 x columns 32 wn .. 32 wn + 31 of the block's
+// 128 rows x 128 columns (blockIdx.z walks further 128-column groups).  A: the block's 128 gathered rows x Cin (<= 128) in LDS,
+// row stride Cin + 4; B: this lane's fragments from L2.
+// NSUB = Cin / 8 (compile-time: a run-time bound put a branch -- and a full vmcnt(0) wait -- between the sub-steps)
+template <int NSUB>
+__global__ __launch_bounds__(512, 4) void pair_gemm_kernel(GemmArgs a) {      // 4 waves per SIMD = two blocks per CU (<= 128 registers)
+  const int t = blockIdx.y;
+  const int row0 = blockIdx.x * PC_ROWS;
+  const int n = min(a.cnt[t], a.cap);
+  if (row0 >= n) return;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ld = a.cin + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int c4n = a.cin >> 2;                               // 16-byte channel quads per row
+  const int col0 = blockIdx.z * 128 + wn * 32;
+  const bool colok = col0 < a.cout_pad;
+  // this lane's weight fragments of the first eight sub-steps, requested before the rows are gathered (they do not depend on the
+  // tile); the second eight are requested into the same registers as the first are consumed -- 64 MFMAs ahead.  (A fragment per
+  // sub-step requested one sub-step = 8 MFMAs ahead left the wave waiting on L2 sixteen times.)
+  constexpr int NB = NSUB < 8 ? NSUB : 8;
+  f32x4 bq[NB];
+  const float* wt = a.w + ((size_t)t * c4n * a.cout_pad + (colok ? col0 : 0) + li) * 4;     // + k4 * cout_pad * 4
+#pragma unroll
+  for (int s = 0; s < NB; ++s) bq[s] = *reinterpret_cast<const f32x4*>(wt + (size_t)(2 * s + lh) * a.cout_pad * 4);
+  // ---- stage the gathered rows (rows past the list's end: zeros): all of a thread's row indices first, then all its row loads, then
+  // the LDS stores -- one index / row / store at a time serialised 2 x NSUB / 2 memory latencies per tile (24 of the launch's 41 us)
+  constexpr int C4N = 2 * NSUB, ITEMS = PC_ROWS * C4N / 512;
+  int pixv[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int r = (tid + 512 * k) / C4N;
+    pixv[k] = row0 + r < n ? a.pair_in[(size_t)t * a.cap + row0 + r] : -1;
+  }
+  f32x4 rowv[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int c4 = (tid + 512 * k) % C4N;
+    rowv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (pixv[k] >= 0) rowv[k] = *reinterpret_cast<const f32x4*>(a.canvas + (size_t)pixv[k] * a.in_ps + a.in_co + c4 * 4);
+  }
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int item = tid + 512 * k;
+    *reinterpret_cast<f32x4*>(smem + (item / C4N) * ld + (item % C4N) * 4) = rowv[k];
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  __syncthreads();
+  if (colok) {
+    const float* Ab = smem + (wm * 64 + li) * ld + lh * 4;
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + s * 8);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + 32 * ld + s * 8);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], bq[s % NB][kk], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], bq[s % NB][kk], acc[1], 0, 0, 0);
+      }
+      if (s + NB < NSUB) bq[s % NB] = *reinterpret_cast<const f32x4*>(wt + (size_t)(2 * (s + NB) + lh) * a.cout_pad * 4);
+    }
+    const int col = col0 + li;
+    if (col < a.cout) {
+      float* P = a.partial + ((size_t)t * a.cap + row0 + wm * 64) * a.cout + col;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          P[(size_t)row * a.cout] = acc[i][r];
+        }
+    }
+  }
+}
+
+struct ReduceArgs {
+  const float* partial;
+  const int32_t* slots;
+  const float* scale;
+  const float* shift;
+  float* out;
+  int cap, cout, out_ps, out_co, act;
+  long long npix;
+};
+
+__global__ void pair_reduce_kernel(ReduceArgs a) {
+  const int c4n = a.cout >> 2;
+  const long long total = a.npix * c4n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long o = i / c4n;
+    const int c4 = (int)(i - o * c4n);
+    const int32_t* sl = a.slots + o * 9;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int slot = sl[t];
+      if (slot >= 0) s += *reinterpret_cast<const f32x4*>(a.partial + ((size_t)t * a.cap + slot) * a.cout + c4 * 4);
+    }
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + c4 * 4);
+    if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + c4 * 4);
+    f32x4 y;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) y[c] = pn::apply_act(fmaf(s[c], sc[c], sh[c]), a.act);
+    *reinterpret_cast<f32x4*>(a.out + o * a.out_ps + a.out_co + c4 * 4) = y;
+  }
+}
+
+// torch (Cout, Cin, 3, 3) -> [tap][cin / 4][cout_pad][4]
+__global__ void pack_pillar_weight_kernel(const float* __restrict__ w, int cout, int cin, int cout_pad, float* __restrict__ packed, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int k1 = r & 3; r >>= 2;
+    const int n = (int)(r % cout_pad); r /= cout_pad;
+    const int k4 = (int)(r % (cin / 4));
+    const int t = (int)(r / (cin / 4));
+    const int c = k4 * 4 + k1;
+    packed[i] = n < cout ? w[((size_t)n * cin + c) * 9 + t] : 0.f;
+  }
+}
+
+inline int cap_rows(int v_capacity) { return pn::cdiv(std::max(v_capacity, 1), PC_ROWS) * PC_ROWS; }
+inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+struct Layout { size_t pairs, slots, partial, total; };
+inline Layout layout(int v_capacity, int batch, int oh, int ow, int cout) {
+  const size_t cap = (size_t)cap_rows(v_capacity);
+  Layout l;
+  l.pairs = 256;                                                  // [0, 256): the nine tap counters
+  l.slots = l.pairs + up256(9 * cap * 4);
+  l.partial = l.slots + up256((size_t)batch * oh * ow * 9 * 4);
+  l.total = l.partial + up256(9 * cap * (size_t)cout * 4);
+  return l;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pn_pillar_conv_packed_weight_floats(int cout, int cin) { return (size_t)9 * cin * (size_t)(pn::cdiv(cout, 32) * 32); }
+
+int pn_pack_pillar_conv_weight_f32(const float* w_oihw, int cout, int cin, float* packed, pn_stream_t stream) {
+  PN_REQUIRE(w_oihw && packed && cout >= 1 && cin >= 4 && cin % 4 == 0, "pack_pillar_conv_weight: bad arguments");
+  const size_t total = pn_pillar_conv_packed_weight_floats(cout, cin);
+  hipLaunchKernelGGL(pack_pillar_weight_kernel, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0, pn::S(stream), w_oihw, cout, cin,
+                     pn::cdiv(cout, 32) * 32, packed, total);
+  return pn::check_launch("pack_pillar_weight_kernel");
+}
+
+size_t pn_pillar_conv_workspace_bytes(int v_capacity, int batch, int oh, int ow, int cout) { return layout(v_capacity, batch, oh, ow, cout).total; }
+
+int pn_pillar_conv3x3_f32(const float* canvas, int batch, int h, int w, int cin, int in_pixel_stride, int in_channel_offset, const uint32_t* unq_keys,
+                          const int32_t* num_voxels, int v_capacity, int stride, const float* packed_w, int cout, const float* scale, const float* shift,
+                          int act, float* out, int out_pixel_stride, int out_channel_offset, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(canvas && unq_keys && num_voxels && packed_w && out && workspace, "pillar_conv: null pointer");
+  PN_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && (stride == 1 || stride == 2) && v_capacity >= 1, "pillar_conv: bad sizes (stride 1 or 2)");
+  PN_REQUIRE((cin == 32 || cin == 64 || cin == 128) && in_pixel_stride % 4 == 0 && in_channel_offset % 4 == 0 && in_pixel_stride >= in_channel_offset + cin,
+             "pillar_conv: cin 32, 64 or 128, 16-byte aligned channel slice");
+  PN_REQUIRE(cout >= 4 && cout % 4 == 0 && out_pixel_stride % 4 == 0 && out_channel_offset % 4 == 0 && out_pixel_stride >= out_channel_offset + cout,
+             "pillar_conv: cout a multiple of 4, 16-byte aligned output slice");
+  PN_REQUIRE(((uintptr_t)canvas & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "pillar_conv: pointers must be 16-byte aligned");
+  const int oh = (h + 2 - 3) / stride + 1, ow = (w + 2 - 3) / stride + 1;
+  PN_REQUIRE((long long)batch * h * w < (1ll << 31), "pillar_conv: map too large");
+  if (workspace_bytes < pn_pillar_conv_workspace_bytes(v_capacity, batch, oh, ow, cout)) return pn::fail(PN_ERR_WORKSPACE, "pillar_conv: workspace too small");
+  PN_REQUIRE(((uintptr_t)workspace & 15) == 0, "pillar_conv: workspace must be 16-byte aligned");
+  const int cap = cap_rows(v_capacity);
+  const Layout lo = layout(v_capacity, batch, oh, ow, cout);
+  char* ws = static_cast<char*>(workspace);
+  int32_t* cnt = reinterpret_cast<int32_t*>(ws);
+  int32_t* pair_in = reinterpret_cast<int32_t*>(ws + lo.pairs);
+  int32_t* slots = reinterpret_cast<int32_t*>(ws + lo.slots);
+  const size_t slot_bytes = (size_t)batch * oh * ow * 9 * 4;
+  float* partial = reinterpret_cast<float*>(ws + lo.partial);
+  hipStream_t st = pn::S(stream);
+  const size_t nslots = slot_bytes / 4;
+  hipLaunchKernelGGL(pair_init_kernel, dim3((unsigned)std::min<size_t>(2048, (nslots / 4 + 255) / 256 + 1)), dim3(256), 0, st, cnt, reinterpret_cast<int4*>(slots),
+                     nslots / 4, slots, nslots);
+  PairArgs pa{unq_keys, num_voxels, v_capacity, batch, h, w, oh, ow, stride, cap, cnt, pair_in, slots};
+  // a profile slot (bench.py's per-launch events) brackets all three kernels: start on the first, stop on the last
+  pn::ProfileSlot ps;
+  const bool prof = pn::take_profile_slot(ps);
+  const dim3 pgrid((unsigned)std::min(256, pn::cdiv(v_capacity, 1024)));
+  if (prof) hipExtLaunchKernelGGL(pair_kernel, pgrid, dim3(1024), 0, st, ps.start, nullptr, 0, pa);
+  else hipLaunchKernelGGL(pair_kernel, pgrid, dim3(1024), 0, st, pa);
+  const int cout_pad = pn::cdiv(cout, 32) * 32;
+  GemmArgs ga{canvas, packed_w, cnt, pair_in, partial, cap, cin, in_pixel_stride, in_channel_offset, cout, cout_pad};
+  const size_t smem = (size_t)PC_ROWS * (cin + 4) * sizeof(float);
+  static bool attr_done[64] = {false};
+  if (pn::first_use_on_device(attr_done)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)PC_ROWS * 132 * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)PC_ROWS * 68 * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)PC_ROWS * 36 * sizeof(float)));
+  }
+  const dim3 grid(cap / PC_ROWS, 9, pn::cdiv(cout_pad, 128));
+  if (cin == 128) hipLaunchKernelGGL(pair_gemm_kernel<16>, grid, dim3(512), smem, st, ga);
+  else if (cin == 64) hipLaunchKernelGGL(pair_gemm_kernel<8>, grid, dim3(512), smem, st, ga);
+  else hipLaunchKernelGGL(pair_gemm_kernel<4>, grid, dim3(512), smem, st, ga);
+  ReduceArgs ra{partial, slots, scale, shift, out, cap, cout, out_pixel_stride, out_channel_offset, act, (long long)batch * oh * ow};
+  const long long total = ra.npix * (cout / 4);
+  const dim3 rgrid((unsigned)std::min<long long>(65535, (total + 255) / 256));
+  if (prof) hipExtLaunchKernelGGL(pair_reduce_kernel, rgrid, dim3(256), 0, st, nullptr, ps.stop, 0, ra);
+  else hipLaunchKernelGGL(pair_reduce_kernel, rgrid, dim3(256), 0, st, ra);
+  return pn::check_launch("pillar_conv kernels");
+}
+
+}  // extern "C"

@@ -26,6 +26,10 @@ __global__ void transpose_nbr_kernel(const int32_t* __restrict__ nbr, const int3
   }
 }
 
+__global__ void fill_minus_one_kernel(int32_t* __restrict__ p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = -1;
+}
+
 struct Dims4 { int B, D, H, W; };
 __global__ void from_dense_kernel(const float* __restrict__ dense, const uint32_t* __restrict__ keys, int cap, const int32_t* __restrict__ n_dev, Dims4 d,
                                   int c, float* __restrict__ feats) {
@@ -53,7 +57,8 @@ int pn_sparse_neighbors_transpose(const int32_t* nbr, const int32_t* n_out, int 
                                   pn_stream_t stream) {
   PN_REQUIRE(nbr && n_out && inv && out_capacity >= 1 && taps >= 1 && in_rows >= 1, "sparse_neighbors_transpose: bad arguments");
   hipStream_t st = pn::S(stream);
-  if (hipMemsetAsync(inv, 0xFF, (size_t)in_rows * taps * sizeof(int32_t), st) != hipSuccess) return pn::fail(PN_ERR_LAUNCH, "sparse_neighbors_transpose: memset");
+  // (a fill kernel, not hipMemsetAsync: memset nodes of a captured hipGraph are not re-executed reliably, pn_common.h)
+  hipLaunchKernelGGL(fill_minus_one_kernel, dim3((unsigned)std::min<size_t>(2048, ((size_t)in_rows * taps + 255) / 256)), dim3(256), 0, st, inv, (size_t)in_rows * taps);
   const long long total = (long long)out_capacity * taps;
   hipLaunchKernelGGL(transpose_nbr_kernel, dim3((unsigned)std::min<long long>(65535, (total + 255) / 256)), dim3(256), 0, st, nbr, n_out, out_capacity,
                      taps, in_rows, inv);

@@ -80,6 +80,13 @@ class PointPillars(SingleStageDetector):
         self.reader.encode(points, vi, None, canvas)
         return (canvas, vi) if return_index else canvas
 
+    def _neck_on_canvas(self, canvas: torch.Tensor, vi) -> torch.Tensor:
+        """the backbone on a freshly encoded canvas: plain RPNs take the voxel index with it (sparse first convolution)"""
+        from .necks import RPN
+        if type(self.neck) is RPN:
+            return self.neck.forward_nhwc(canvas, pillars=vi)
+        return self.neck.forward_nhwc(canvas)
+
     def new_canvas(self, batch: int, spec: Optional[ops.GridSpec] = None, device=None) -> torch.Tensor:
         """a zeroed persistent canvas for ``forward_points(..., canvas=)``"""
         spec = spec or ops.GridSpec.from_range(self.reader.pc_range, self.reader.voxel_size)
@@ -97,11 +104,11 @@ class PointPillars(SingleStageDetector):
         spec = spec or ops.GridSpec.from_range(self.reader.pc_range, self.reader.voxel_size)
         _, keys = ops.grid_index(points, sample_offsets, batch, spec, want_grid_ind=False)
         if canvas is None:
-            cv = self.encode_canvas(points, keys, spec, batch, n_dev=sample_offsets[batch:])
-            x2 = self.neck.forward_nhwc(cv)
+            cv, vi = self.encode_canvas(points, keys, spec, batch, n_dev=sample_offsets[batch:], return_index=True)
+            x2 = self._neck_on_canvas(cv, vi)
         else:
             cv, vi = self.encode_canvas(points, keys, spec, batch, n_dev=sample_offsets[batch:], canvas=canvas, return_index=True)
-            x2 = self.neck.forward_nhwc(cv)
+            x2 = self._neck_on_canvas(cv, vi)
             ops.clear_canvas_cells(cv, vi)
         return self.bbox_head(ops.as_nchw(x2))["det_preds"][0]
 
@@ -150,7 +157,7 @@ class PointPillars(SingleStageDetector):
         eval_only(self, "PointPillars")
         spec = spec or ops.GridSpec.from_range(self.reader.pc_range, self.reader.voxel_size)
         cv, vi, _ = self.encode_cart(cart, sample_offsets, batch, spec, canvas=canvas, index_state=index_state)
-        x2 = self.neck.forward_nhwc(cv)
+        x2 = self._neck_on_canvas(cv, vi)
         if canvas is not None or index_state is not None:
             ops.clear_frame_cells(cv if canvas is not None else None, vi, index_state)
         return self.bbox_head(ops.as_nchw(x2))["det_preds"][0]
@@ -174,8 +181,8 @@ class PointPillars(SingleStageDetector):
         if list(spec.grid) != g:
             raise ValueError(f"example grid_size {g} does not match the reader's voxel grid {list(spec.grid)}")
         keys = ops.keys_from_grid_ind(grid_ind.to(torch.int64).contiguous(), spec, batch)
-        canvas = self.encode_canvas(points.contiguous(), keys, spec, batch)
-        x2 = self.neck.forward_nhwc(canvas)
+        canvas, vi = self.encode_canvas(points.contiguous(), keys, spec, batch, return_index=True)
+        x2 = self._neck_on_canvas(canvas, vi)
         return self._heads(canvas, x2)
 
     def _heads(self, x1_nhwc: torch.Tensor, x2_nhwc: torch.Tensor) -> Dict[str, object]:

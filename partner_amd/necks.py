@@ -89,7 +89,12 @@ class RPN(nn.Module):
         return self
 
     def _build_plan(self, dtype="f32"):
-        plan = dict(blocks=[], deblocks=[])
+        plan = dict(blocks=[], deblocks=[], pillar0=None)
+        if dtype == "f32" and len(self.blocks):
+            c0, b0 = list(self.blocks[0]._modules.values())[1:3]
+            if ops.PillarConvLayer.supports(c0.weight, c0.stride[0], c0.groups):
+                scale, shift = ops.fold_bn(b0.weight, b0.bias, b0.running_mean, b0.running_var, b0.eps, c0.bias)
+                plan["pillar0"] = ops.PillarConvLayer(c0.weight, c0.stride[0], scale=scale, shift=shift, act=ops.ACT_RELU)
         for blk in self.blocks:
             mods = list(blk._modules.values())
             layers = [self._fused(mods[1], mods[2], mods[1].stride[0], 1, dtype=dtype)]  # ZeroPad2d(1) + conv == pad 1
@@ -111,8 +116,9 @@ class RPN(nn.Module):
                 plan["deblocks"].append(self._fused(up, bn, up.stride[0], 0, dtype=dtype))
         return plan
 
-    def forward_nhwc(self, x: torch.Tensor, return_blocks=False):
-        """x: NHWC (B,H,W,C) f32 -> NHWC (B,H',W',sum(us_filters)) f32"""
+    def forward_nhwc(self, x: torch.Tensor, return_blocks=False, pillars=None):
+        """x: NHWC (B,H,W,C) f32 -> NHWC (B,H',W',sum(us_filters)) f32.  ``pillars``: the frame's ops.VoxelIndex when x is the
+        pillar canvas (its cells are the only non-zero pixels): the first convolution then multiplies (pillar, tap) pairs only"""
         eval_only(self, "RPN")
         dtype = getattr(self, "compute_dtype", "f32")
         if dtype == "bf16":
@@ -124,8 +130,12 @@ class RPN(nn.Module):
             plan = self._plan.get(self, self._build_plan)
         out, off, block_outs = None, 0, []
         for i, layers in enumerate(plan["blocks"]):
-            for layer in layers:
-                x = layer(x)
+            for k, layer in enumerate(layers):
+                p0 = plan.get("pillar0") if (i == 0 and k == 0 and pillars is not None and dtype == "f32") else None
+                if p0 is not None and p0.worth_it(pillars, x.shape[0], x.shape[1], x.shape[2]):
+                    x = p0(x, pillars)
+                else:
+                    x = layer(x)
             block_outs.append(x)
             j = i - self._upsample_start_idx
             if j >= 0:

@@ -528,6 +528,65 @@ class ConvLayer:
         return out
 
 
+_PILLAR_CONV_ON = os.environ.get("PN_PILLAR_CONV", "1") != "0"
+# taken when the pillar capacity bounds the (pillar, tap) pairs to this fraction of the dense (output, tap) pairs
+_PILLAR_CONV_MAX_FILL = float(os.environ.get("PN_PILLAR_CONV_MAX_FILL", "0.35"))
+
+
+class PillarConvLayer:
+    """The backbone's first 3x3 convolution on the SPARSE pillar canvas (csrc/pillar_conv.hip; rpn.py:124-142 on the canvas of
+    pillar_encoder.py:393-432): (pillar, tap) pairs -> one gathered MFMA GEMM per tap -> fixed-order reduction over the taps with the
+    folded BatchNorm + activation.  ``__call__(canvas, vi)``: ``vi`` = the frame's VoxelIndex; every non-zero pixel of ``canvas``
+    must be one of its cells."""
+
+    def __init__(self, weight: torch.Tensor, stride: int, scale=None, shift=None, act=ACT_NONE):
+        hip.require_device(weight)
+        lib = hip.load()
+        w = weight.detach().contiguous().float()
+        self.cout, self.cin = int(w.shape[0]), int(w.shape[1])
+        assert tuple(w.shape[2:]) == (3, 3) and stride in (1, 2) and self.cin in (32, 64, 128) and self.cout % 4 == 0
+        self.stride, self.act = int(stride), int(act)
+        self.packed = _f32(lib.pn_pillar_conv_packed_weight_floats(self.cout, self.cin), w.device)
+        hip.call("pn_pack_pillar_conv_weight_f32", w.data_ptr(), self.cout, self.cin, self.packed.data_ptr(), hip.stream())
+        self.scale = None if scale is None else scale.detach().contiguous().float()
+        self.shift = None if shift is None else shift.detach().contiguous().float()
+
+    @staticmethod
+    def supports(conv_weight: torch.Tensor, stride: int, groups: int) -> bool:
+        co, ci, kh, kw = conv_weight.shape
+        return _PILLAR_CONV_ON and (kh, kw) == (3, 3) and stride in (1, 2) and groups == 1 and ci in (32, 64, 128) and co % 4 == 0
+
+    def worth_it(self, vi: "VoxelIndex", b: int, h: int, w: int) -> bool:
+        """the pillar capacity (known on the host: no sync) bounds the pairs: 9 / stride^2 per pillar"""
+        oh, ow = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
+        return vi.n_cap * 9.0 / (self.stride * self.stride) <= _PILLAR_CONV_MAX_FILL * 9.0 * b * oh * ow
+
+    def __call__(self, canvas: torch.Tensor, vi: "VoxelIndex", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        hip.require_device(canvas)
+        lib = hip.load()
+        assert canvas.dim() == 4 and canvas.is_contiguous() and canvas.dtype == torch.float32 and canvas.shape[3] >= self.cin
+        b, h, w, ct = canvas.shape
+        assert (w, h) == (vi.spec.grid[0], vi.spec.grid[1]) and b == vi.batch and vi.spec.grid[2] == 1, "the voxel index does not describe this canvas"
+        oh, ow = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
+        if out is None:
+            out = torch.empty((b, oh, ow, self.cout), dtype=torch.float32, device=canvas.device)
+        nbytes = lib.pn_pillar_conv_workspace_bytes(vi.n_cap, b, oh, ow, self.cout)
+        ws = _workspace(nbytes, canvas.device)
+        st = hip.stream()
+        prof = _PROFILER
+        if prof is not None:
+            ev = prof.begin(st)
+        hip.call("pn_pillar_conv3x3_f32", canvas.data_ptr(), b, h, w, self.cin, ct, 0, vi.unq_keys_ptr, vi.num_voxels.data_ptr(), vi.n_cap, self.stride,
+                 self.packed.data_ptr(), self.cout, hip.ptr(self.scale), hip.ptr(self.shift), self.act, out.data_ptr(), out.shape[3], 0,
+                 ws.data_ptr(), nbytes, st)
+        if prof is not None:
+            # FLOPs actually multiplied: the (pillar, tap) pairs of THIS frame (the nine counters head the workspace; reading them
+            # synchronises -- profiling runs only); the events bracket the pair, GEMM and reduce kernels
+            pairs = int(ws[:36].view(torch.int32).sum().item())
+            prof.end(ev, 2.0 * pairs * self.cout * self.cin, st, tag=f"{oh}x{ow} {self.cin}->{self.cout} k3 pillars")
+        return out
+
+
 class ConvJob:
     """One convolution of a multi-job launch (``conv_multi``): a packed ``ConvLayer`` applied to a channel slice of ``x``,
     writing a channel slice of ``out``; optionally emitting the statistics of the GroupNorm-family layer that follows it
