@@ -586,11 +586,12 @@ def main():
         roofline = dict(bound="mfma", kernel="conv_mfma_kernel / conv_wino_kernel family (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; the stride-1 3x3 "
                                              "layers through a width-Winograd transform -- F(4,3) on the 256 x 256 maps, F(2,3) on the smaller ones: 4.5 / 6 of "
                                              "the 9 algorithmic MACs reach the MFMA, so `achieved` counts algorithmic FLOPs and can exceed the MFMA issue "
-                                             "rate of a layer)",
+                                             "rate of a layer; block 0's first layer multiplies (pillar, tap) pairs only -- pillar_conv.hip -- and is counted "
+                                             "with the FLOPs it actually multiplies)",
                         achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                         issued=dict(tflops=round(issued, 3), frac=round(issued / PEAK_F32_MFMA_TFLOPS, 4),
                                     note="MFMA FLOPs the kernels issue (Winograd launches: 2/3 resp. 1/2 of their algorithmic FLOPs): the matrix-pipe utilisation"),
-                        traffic=committed_pmc_bytes(("conv_mfma_kernel", "conv_wino", "conv_small_n", "conv_multi"), per="launch"),
+                        traffic=committed_pmc_bytes(("conv_mfma_kernel", "conv_wino", "conv_small_n", "conv_multi", "pair_gemm", "pair_reduce"), per="launch"),
                         traffic_unit="HBM bytes per conv launch (offline PMC passes of this command, profiles/r2_pmc_traffic.csv)",
                         launches=launches, launches_per_step=round(launches / args.steps, 2), flops_per_launch=round(flops / launches),
                         avg_launch_us=round(1e3 * ms / launches, 2), conv_ms_per_step=round(ms / args.steps, 4),

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(512, 4) void pair_gemm_kernel(GemmArgs a) {      //
   const int n = min(a.cnt[t], a.cap);
   if (row0 >= n) return;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int ld = a.cin + 4;
+  constexpr int ld = 8 * NSUB + 4;                           // row stride in floats (16-byte multiple: the LDS accesses stay 128-bit)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 2, wn = wave & 3;
