@@ -120,10 +120,20 @@ struct GemmArgs {
 // NSUB = Cin / 8 (compile-time: a run-time bound put a branch -- and a full vmcnt(0) wait -- between the sub-steps)
 template <int NSUB>
 __global__ __launch_bounds__(512, 4) void pair_gemm_kernel(GemmArgs a) {      // 4 waves per SIMD = two blocks per CU (<= 128 registers)
-  const int t = blockIdx.y;
-  const int row0 = blockIdx.x * PC_ROWS;
-  const int n = min(a.cnt[t], a.cap);
-  if (row0 >= n) return;
+  // work item w = blockIdx.x -> (tap, 128-row tile) through the nine list lengths: the live blocks come first in the grid (a
+  // (tile, tap) grid interleaved ~1600 blocks that exit at once with the ~500 live ones)
+  int t = 0, row0 = 0, n = 0;
+  {
+    int w = blockIdx.x;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int nk = min(a.cnt[k], a.cap), tk = (nk + PC_ROWS - 1) / PC_ROWS;
+      if (!found && w < tk) { t = k; row0 = w * PC_ROWS; n = nk; found = true; }
+      if (!found) w -= tk;
+    }
+    if (!found) return;
+  }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int ld = 8 * NSUB + 4;                           // row stride in floats (16-byte multiple: the LDS accesses stay 128-bit)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -311,7 +321,7 @@ int pn_pillar_conv3x3_f32(const float* canvas, int batch, int h, int w, int cin,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)PC_ROWS * 68 * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)PC_ROWS * 36 * sizeof(float)));
   }
-  const dim3 grid(cap / PC_ROWS, 9, pn::cdiv(cout_pad, 128));
+  const dim3 grid(9 * (cap / PC_ROWS), 1, pn::cdiv(cout_pad, 128));
   if (cin == 128) hipLaunchKernelGGL(pair_gemm_kernel<16>, grid, dim3(512), smem, st, ga);
   else if (cin == 64) hipLaunchKernelGGL(pair_gemm_kernel<8>, grid, dim3(512), smem, st, ga);
   else hipLaunchKernelGGL(pair_gemm_kernel<4>, grid, dim3(512), smem, st, ga);
