@@ -221,11 +221,19 @@ __global__ void pair_reduce_kernel(ReduceArgs a) {
     const long long o = i / c4n;
     const int c4 = (int)(i - o * c4n);
     const int32_t* sl = a.slots + o * 9;
+    int slot[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) slot[t] = sl[t];
+    // all nine rows are requested at once (an absent pair reads row 0 of its tap's list and is dropped by the select below: a
+    // branch per tap serialised up to nine dependent latencies); the sum keeps the tap order
+    f32x4 v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = *reinterpret_cast<const f32x4*>(a.partial + ((size_t)t * a.cap + max(slot[t], 0)) * a.cout + c4 * 4);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int slot = sl[t];
-      if (slot >= 0) s += *reinterpret_cast<const f32x4*>(a.partial + ((size_t)t * a.cap + slot) * a.cout + c4 * 4);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      s += slot[t] >= 0 ? v[t] : z;
     }
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + c4 * 4);
