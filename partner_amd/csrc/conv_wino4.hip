@@ -482,8 +482,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_ks_kernel(Wino4Args a) {
       const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int r = 4 * D + rr;
         const int p = ept * WQ + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (p >= a.total_quads) continue;

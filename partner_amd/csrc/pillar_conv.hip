@@ -12,13 +12,13 @@
 //   2. pair_gemm_kernel per tap t one dense GEMM  partial[t][slot][:] = canvas[pair.input][:] . W_t  over the tap's list (MFMA,
 //                       128 gathered rows x Cout per block, the whole K = Cin staged in LDS once, weights straight into the MFMA
 //                       operands from L2).
+//   (pair_init_kernel first: the nine counters to 0, every slot to -1.)
 //   3. pair_reduce_kernel  out[o][:] = act(scale * sum_{t = 0..8, slots[o][t] >= 0} partial[t][slots[o][t]][:] + shift) in FIXED tap
 //                       order (deterministic, replay == eager bit for bit); outputs no pillar reaches get act(shift).
 // Same terms as the dense convolution, summed per tap first (128-term dot products) and then over taps: agreement with the dense
 // kernel ~1e-6 of the map's range.  The caller promises that every non-zero pixel of the canvas is in the key list.
 #include "pn_common.h"
 #include <algorithm>
-#include <cstdlib>
 
 namespace {
 
