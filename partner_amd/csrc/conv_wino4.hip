@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
 constexpr int W4K_N = 32;
 constexpr size_t wino4_ks_smem() {
   const size_t stage = (2 * (size_t)(6 * 32 * W4_LD) + 2 * W4K_N) * sizeof(float);
-  const size_t join = (size_t)4 * 3 * 6 * 4 * 64 * sizeof(float);      // [dst wave][src slot][q][rr][lane]
+  const size_t join = (size_t)4 * 3 * 6 * 64 * 4 * sizeof(float);      // [dst wave][src slot][q][lane][4 registers]
   return stage > join ? stage : join;
 }
 
@@ -459,24 +459,27 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_ks_kernel(Wino4Args a) {
   // join + epilogue of wave D (compile-time: the accumulator registers are indexed statically)
   auto finish = [&](auto d_c, int ept, int en0) __attribute__((always_inline)) {
     constexpr int D = decltype(d_c)::value;
-    float* J = smem + lane;
+    f32x4* J = reinterpret_cast<f32x4*>(smem) + lane;      // [dst wave][src slot][q][lane] x 4 registers: 128-bit LDS accesses
     // send: to every other wave its quarter of this wave's partial sums
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       if (d == D) continue;
       const int sl = D < d ? D : D - 1;
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) J[((((d * 3 + sl) * 6 + q) * 4 + rr)) * 64] = acc[q][4 * d + rr];
+      for (int q = 0; q < 6; ++q) {
+        const f32x4 v = {acc[q][4 * d], acc[q][4 * d + 1], acc[q][4 * d + 2], acc[q][4 * d + 3]};
+        J[((d * 3 + sl) * 6 + q) * 64] = v;
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl)
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
+      for (int q = 0; q < 6; ++q) {
+        const f32x4 v = J[((D * 3 + sl) * 6 + q) * 64];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) acc[q][4 * D + rr] += J[((((D * 3 + sl) * 6 + q) * 4 + rr)) * 64];
+        for (int rr = 0; rr < 4; ++rr) acc[q][4 * D + rr] += v[rr];
+      }
     const int col = en0 + li;
     if (col < a.Cout) {
       const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
