@@ -365,6 +365,7 @@ _WINO_MIN_TILES = int(os.environ.get("PN_CONV_WINO_MIN_TILES", "256"))
 # Waymo RPN 256 x 144 x 128 -> 128: 61 / 105, 128 x 72 x 256 -> 256: 71 / 104
 _WINO4_ON = os.environ.get("PN_CONV_WINO4", "1") != "0"
 _WINO4_MIN_TILES = int(os.environ.get("PN_CONV_WINO4_MIN_TILES", "256"))
+_WINO4_DGRAD = os.environ.get("PN_CONV_WINO4_DGRAD", "1") != "0"     # F(4, 3) for the training data gradients (the forward stays on F(2, 3), see train.py)
 
 
 class ConvLayer:
@@ -882,9 +883,11 @@ class ConvDgrad:
             raise hip.PartnerHipError(f"ConvDgrad: unsupported geometry k={kh}x{kw} stride={stride} pad={pad}")
         # the data gradient of a 3x3 / stride-1 / pad-1 convolution is itself one (taps mirrored, channels swapped): it takes the
         # width-Winograd kernel on large maps, like the forward layer (conv_wino.hip)
-        self.wino_packed = None
+        self.wino_packed = self.wino4_packed = None
         if self.kind == "s1" and (kh, kw, self.pad) == (3, 3, 1) and cout % 4 == 0 and _WINO_ON:
             self.wino_packed = _f32(lib.pn_conv_wino_packed_weight_floats(cin, cout), dev)
+            if _WINO4_ON and _WINO4_DGRAD and cin % 32 == 0:
+                self.wino4_packed = _f32(lib.pn_conv_wino4_packed_weight_floats(cin, cout), dev)
         self.repack(weight)
 
     def repack(self, weight: torch.Tensor) -> None:
@@ -895,6 +898,8 @@ class ConvDgrad:
             if self.wino_packed is not None:
                 wd = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()     # (Cin, Cout, 3, 3): the equivalent forward weight of the gradient conv
                 hip.call("pn_pack_conv_weight_wino_f32", wd.data_ptr(), self.cin, self.cout, self.wino_packed.data_ptr(), st)
+                if self.wino4_packed is not None:
+                    hip.call("pn_pack_conv_weight_wino4_f32", wd.data_ptr(), self.cin, self.cout, self.wino4_packed.data_ptr(), st)
         elif self.kind == "s2k3":
             hip.call("pn_pack_conv_dgrad_s2_weight_f32", w.data_ptr(), self.cout, self.cin, self.packed.data_ptr(), st)
         else:
@@ -927,6 +932,10 @@ class ConvDgrad:
         assert out.shape[:3] == (b, h, w) and out.is_contiguous()
         d.out_pixel_stride = out.shape[3]
         d.accumulate = int(accumulate)
+        if (self.wino4_packed is not None and not accumulate and ow % 4 == 0 and cin_eff == self.cout
+                and ((b * oh * (ow // 4) + 31) // 32) * (self.cin // 32) >= _WINO4_MIN_TILES):
+            hip.call("pn_conv2d_wino4_nhwc_f32", C.byref(d), dout.data_ptr(), self.wino4_packed.data_ptr(), None, None, out.data_ptr(), hip.stream())
+            return out
         if (self.wino_packed is not None and not accumulate and ow % 2 == 0 and cin_eff == self.cout
                 and ((b * oh * (ow // 2) + 31) // 32) * ((self.cin + 63) // 64) >= _WINO_MIN_TILES):
             hip.call("pn_conv2d_wino_nhwc_f32", C.byref(d), dout.data_ptr(), self.wino_packed.data_ptr(), None, None, out.data_ptr(), hip.stream())
