@@ -456,7 +456,7 @@ class ConvLayer:
         return tiles >= _WINO_MIN_TILES
 
     def _use_wino4(self, b: int, h: int, w: int, accumulate: bool) -> bool:
-        if self.wino4_packed is None or accumulate or w % 4 or self.cin != self._pack_cin:
+        if self.wino4_packed is None or accumulate or w % 4 or self.cin != self._pack_cin or h * w > getattr(self, "wino4_max_pixels", 1 << 62):
             return False
         return ((b * h * (w // 4) + 31) // 32) * (self.cout // 32) >= _WINO4_MIN_TILES
 

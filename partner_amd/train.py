@@ -84,6 +84,13 @@ class ParamStore:
             self.g[name] = self.flat_g[o:o + p.numel()].view(shape)
 
 
+import os as _os
+# F(4, 3) in the training FORWARD only on maps of at most this many pixels (the 128 x 128 and 64 x 64 layers): with it on the 256 x 256
+# layers too the full-size gradient test misses its 2e-2 bound on the 95th percentile (2.2e-2: the forward's rounding is amplified
+# through the batch statistics); the data gradients take F(4, 3) everywhere (ops.ConvDgrad)
+_TRAIN_WINO4_MAX_PIXELS = int(_os.environ.get("PN_TRAIN_WINO4_MAX_PIXELS", "16384"))
+
+
 class _Conv:
     """plain convolution (optional bias, optional fused activation) with explicit backward"""
 
@@ -98,9 +105,8 @@ class _Conv:
             # its data gradient is the stride-2 convolution with the same tensor read as (Cout_conv, Cin_conv, 2, 2)
             self.dgrad = ops.ConvLayer(w, stride=2, pad=0)
         else:
-            # (F(2, 3) at most in the training forward: the full-size gradients amplify the forward's rounding, and the accuracy class of
-            # tests/test_hip_train.py was established with it; F(4, 3) carries ~3x the fp32 error of the direct kernel)
-            self.layer = ops.ConvLayer(w, stride=stride, pad=pad, shift=None if bname is None else ps.p[bname], act=act, wino4=False)
+            self.layer = ops.ConvLayer(w, stride=stride, pad=pad, shift=None if bname is None else ps.p[bname], act=act, wino4=_TRAIN_WINO4_MAX_PIXELS > 0)
+            self.layer.wino4_max_pixels = _TRAIN_WINO4_MAX_PIXELS
             if cin_pad is not None:
                 self.layer.pad_input_channels(cin_pad)
             self.dgrad = ops.ConvDgrad(w, stride, pad)
