@@ -885,6 +885,13 @@ int pn_pack_conv_weight_wino4_f32(const float *w_oihw, int cout, int cin, float 
 int pn_conv_wino4_tiles(const pn_conv_desc *desc);
 int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc *desc, const float *in, const float *packed_w, const float *scale,
                              const float *shift, float *out, pn_stream_t stream);
+/* Weight gradient of a plain 3x3 / stride 1 / pad 1 convolution in the F(4, 3) domain (map width a multiple of 4): six GEMMs per kernel
+ * row over the quads, dW = G^T [ (B^T d) (A dy)^T ], half the MFMA work of pn_conv2d_wgrad_f32; desc as for pn_conv2d_wgrad_f32 (in_* = the
+ * layer's input x, out_* = dout); slices summed in fixed order (deterministic).  Autograd of the RPN's Conv2d layers, rpn.py:124-142 under
+ * trainer.py:275-300. */
+size_t pn_conv2d_wgrad_wino4_workspace_bytes(const pn_conv_desc *desc);
+int pn_conv2d_wgrad_wino4_f32(const pn_conv_desc *desc, const float *x, const float *dout, float *dw_oihw, int accumulate,
+                              void *workspace, size_t workspace_bytes, pn_stream_t stream);
 /* The FIRST 3x3 convolution of the backbone (ZeroPad2d(1) + Conv2d(3, stride 1 | 2) + folded BatchNorm + activation, rpn.py:124-142) on
  * the pillar canvas of DynamicPPScatter (pillar_encoder.py:393-432), exploiting its sparsity: only (pillar, tap) pairs are multiplied
  * -- per tap one gathered MFMA GEMM over the pairs whose parity reaches an output, then a fixed-order reduction over the nine taps with

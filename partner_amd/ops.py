@@ -814,6 +814,14 @@ def conv_wgrad(x: torch.Tensor, dout: torch.Tensor, kh: int, kw: int, stride=1, 
     assert dout.shape[:3] == (b, oh, ow), (dout.shape, (b, oh, ow))
     if out is None:
         out = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device)
+    if (_WGRAD_WINO4 and (kh, kw, stride, ph, pw) == (3, 3, 1, 1, 1) and w % 4 == 0 and cin % 4 == 0 and cout % 4 == 0 and in_channel_offset % 4 == 0
+            and dout_channel_offset % 4 == 0 and ct % 4 == 0 and dout.shape[3] % 4 == 0 and b * h * (w // 4) >= _WGRAD_WINO4_MIN_QUADS
+            and cin * cout >= 0.75 * (-(-cin // 128) * 128) * (-(-cout // 128) * 128)):      # its 128 x 128 (ci, co) tiles mostly full
+        # F(4, 3) weight gradient (conv_wgrad_wino4.hip): half the MFMA work on the maps large enough to fill the chip with its slices
+        nbytes = lib.pn_conv2d_wgrad_wino4_workspace_bytes(C.byref(d))
+        ws = _workspace(nbytes, x.device)
+        hip.call("pn_conv2d_wgrad_wino4_f32", C.byref(d), x.data_ptr(), dout.data_ptr(), out.data_ptr(), int(accumulate), ws.data_ptr(), nbytes, hip.stream())
+        return out
     nbytes = lib.pn_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = _workspace(nbytes, x.device)
     hip.call("pn_conv2d_wgrad_f32", C.byref(d), x.data_ptr(), dout.data_ptr(), out.data_ptr(), int(accumulate), ws.data_ptr(),
@@ -822,6 +830,8 @@ def conv_wgrad(x: torch.Tensor, dout: torch.Tensor, kh: int, kw: int, stride=1, 
 
 
 _WS = {}
+_WGRAD_WINO4 = os.environ.get("PN_CONV_WGRAD_WINO4", "1") != "0"
+_WGRAD_WINO4_MIN_QUADS = int(os.environ.get("PN_CONV_WGRAD_WINO4_MIN_QUADS", "4096"))
 
 
 def _workspace(nbytes: int, dev) -> torch.Tensor:
