@@ -52,12 +52,17 @@ __global__ __launch_bounds__(512) void wgrad_wino4_kernel(WgArgs a) {
   const int ql = tid >> 5, c4 = tid & 31;        // loader item: quad of the step, 16-byte channel group
 
   f32x4 rx[6], rd[4];
-  auto load_step = [&](int t) {
-    const int g = q_begin + t * WG_KQ + ql;
-    const bool ok = g < q_end;
-    const int gg = ok ? g : 0;
-    const int rowi = gg / a.qpr, tq = gg - rowi * a.qpr;
-    const int b = rowi / a.H, oy = rowi - b * a.H;
+  // this thread's quad of the step being loaded, as (sample, row, quad of the row): advanced by 16 quads per step without divisions
+  int lg = q_begin + ql, ltq, lrow;
+  {
+    const int rowi = lg / a.qpr;
+    ltq = lg - rowi * a.qpr;
+    lrow = rowi;                 // b * H + oy
+  }
+  auto load_step = [&](int) {
+    const bool ok = lg < q_end;
+    const int tq = ltq;
+    const int b = lrow / a.H, oy = lrow - b * a.H;
     const int iy = oy + kh - 1;
     const bool xok = ok && (unsigned)iy < (unsigned)a.H && ci0 + c4 * 4 < a.Cin;
     const float* xp = a.x + ((size_t)(b * a.H + (xok ? iy : 0)) * a.W + 4 * tq - 1) * a.x_ps + a.x_co + ci0 + c4 * 4;
@@ -70,6 +75,9 @@ __global__ __launch_bounds__(512) void wgrad_wino4_kernel(WgArgs a) {
     const float* dp = a.dy + ((size_t)(b * a.H + oy) * a.W + 4 * tq) * a.dy_ps + a.dy_co + co0 + c4 * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) rd[j] = dok ? *reinterpret_cast<const f32x4*>(dp + (size_t)j * a.dy_ps) : f32x4{0.f, 0.f, 0.f, 0.f};
+    lg += WG_KQ;
+    ltq += WG_KQ;
+    while (ltq >= a.qpr) { ltq -= a.qpr; ++lrow; }
   };
   auto store_step = [&](int buf) {
     float* Vs = smem + buf * ST + ql * WG_LD + c4 * 4;
@@ -114,21 +122,28 @@ __global__ __launch_bounds__(512) void wgrad_wino4_kernel(WgArgs a) {
     const int buf = t & 1;
     if (t + 1 < nsteps) load_step(t + 1);                 // in flight during this step's MFMAs
     const float* S = smem + buf * ST;
+    auto mfma_range = [&](int k0, int k1) __attribute__((always_inline)) {
 #pragma unroll
-    for (int kp = 0; kp < WG_KQ / 2; ++kp) {
-      float av[3], bv[3][2];
+      for (int kp = k0; kp < k1; ++kp) {
+        float av[3], bv[3][2];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        av[p] = S[a_off + (p * WG_KQ + 2 * kp) * WG_LD];
-        bv[p][0] = S[b_off + (p * WG_KQ + 2 * kp) * WG_LD];
-        bv[p][1] = S[b_off + (p * WG_KQ + 2 * kp) * WG_LD + 32];
+        for (int p = 0; p < 3; ++p) {
+          av[p] = S[a_off + (p * WG_KQ + 2 * kp) * WG_LD];
+          bv[p][0] = S[b_off + (p * WG_KQ + 2 * kp) * WG_LD];
+          bv[p][1] = S[b_off + (p * WG_KQ + 2 * kp) * WG_LD + 32];
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p][j], acc[p][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p][j], acc[p][j], 0, 0, 0);
-    }
+    };
+    // the transform + LDS stores of the next step sit between the two halves of this step's MFMAs: issued behind the first 24, they run
+    // while the matrix pipe works those off.  (PMC on the 256 x 256 layer: MFMA busy 0.62, no LDS bank conflicts; the loop is bound by
+    // its barrier per 48 MFMAs -- with the loads switched off 398 of 490 us remain -- not by the staging VALU work or the divisions.)
+    mfma_range(0, WG_KQ / 4);
     if (t + 1 < nsteps) store_step(buf ^ 1);
+    mfma_range(WG_KQ / 4, WG_KQ / 2);
     __syncthreads();
   }
   // partial sums of this slice: [slice][kh][q][ci][co]
