@@ -432,22 +432,34 @@ class ConvLayer:
             hip.call("pn_pack_conv_weight_wino4_f32", w.data_ptr(), self.cout, self.cin, self.wino4_packed.data_ptr(), st)
 
     def repack(self, weight: torch.Tensor, shift: Optional[torch.Tensor] = None) -> None:
-        """refresh the packed copy from an updated weight of the same shape (training: once per step)"""
+        """refresh the packed copies from an updated weight of the same shape (training: once per step).  LAZY: a layout (direct,
+        F(2, 3), F(4, 3)) is packed when the next call takes it -- a layer keeps up to three and uses one per map size, and the
+        tiny pack launches were 0.8 ms of an 18.8 ms training iteration.  ``weight`` must stay valid (and unchanged) until then: the
+        training steps hand in views of their flat parameter buffer, which the optimizer rewrites only after the backward."""
         w = weight.detach()
         assert w.is_contiguous() and w.dtype == torch.float32
-        st = hip.stream()
-        if self.deconv2x2:
-            hip.call("pn_pack_deconv2x2_weight_f32", w.data_ptr(), self._pack_cin, self.cout, self.packed.data_ptr(), st)
-        else:
-            pack_groups = self.range_strata if self.range_strata > 1 else self.groups
-            hip.call("pn_pack_conv_weight_f32", w.data_ptr(), w.shape[0], self._pack_cin, self.kh, self.kw, pack_groups,
-                     self.packed.data_ptr(), st)
-            if self.wino_packed is not None:
-                hip.call("pn_pack_conv_weight_wino_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino_packed.data_ptr(), st)
-            if self.wino4_packed is not None:
-                hip.call("pn_pack_conv_weight_wino4_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino4_packed.data_ptr(), st)
+        self._stale_w = w
+        self._stale = {"direct"} | ({"wino"} if self.wino_packed is not None else set()) | ({"wino4"} if self.wino4_packed is not None else set())
         if shift is not None:
             self.shift = shift
+
+    def _ensure(self, layout: str) -> None:
+        stale = getattr(self, "_stale", None)
+        if not stale or layout not in stale:
+            return
+        stale.discard(layout)
+        w, st = self._stale_w, hip.stream()
+        if layout == "direct":
+            if self.deconv2x2:
+                hip.call("pn_pack_deconv2x2_weight_f32", w.data_ptr(), self._pack_cin, self.cout, self.packed.data_ptr(), st)
+            else:
+                pack_groups = self.range_strata if self.range_strata > 1 else self.groups
+                hip.call("pn_pack_conv_weight_f32", w.data_ptr(), w.shape[0], self._pack_cin, self.kh, self.kw, pack_groups,
+                         self.packed.data_ptr(), st)
+        elif layout == "wino":
+            hip.call("pn_pack_conv_weight_wino_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino_packed.data_ptr(), st)
+        else:
+            hip.call("pn_pack_conv_weight_wino4_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino4_packed.data_ptr(), st)
 
     def _use_wino(self, b: int, h: int, w: int, accumulate: bool) -> bool:
         if self.wino_packed is None or accumulate or w % 2 or self.cin != self._pack_cin:
@@ -509,6 +521,7 @@ class ConvLayer:
             ev = prof.begin(st)
         use_wino4 = self._use_wino4(b, h, w, accumulate)
         use_wino = not use_wino4 and self._use_wino(b, h, w, accumulate)
+        self._ensure("wino4" if use_wino4 else "wino" if use_wino else "direct")
         if use_wino4:
             hip.call("pn_conv2d_wino4_nhwc_f32", C.byref(d), x.data_ptr(), self.wino4_packed.data_ptr(), hip.ptr(self.scale), hip.ptr(self.shift),
                      out.data_ptr(), st)
@@ -617,6 +630,7 @@ def _job_array(jobs: Sequence[ConvJob]):
     for k, jb in enumerate(jobs):
         c = arr[k]
         c.desc = jb.desc
+        jb.layer._ensure("direct")
         c.in_, c.packed_w, c.out = jb.x.data_ptr(), jb.layer.packed.data_ptr(), jb.out.data_ptr()
         c.scale, c.shift = hip.ptr(jb.layer.scale), hip.ptr(jb.layer.shift)
         if jb.stats is not None:
@@ -901,19 +915,28 @@ class ConvDgrad:
         self.repack(weight)
 
     def repack(self, weight: torch.Tensor) -> None:
-        w = weight.detach().contiguous().float()
-        st = hip.stream()
-        if self.kind == "s1":
-            hip.call("pn_pack_conv_dgrad_weight_f32", w.data_ptr(), self.cout, self.cin, self.kh, self.kw, self.packed.data_ptr(), st)
-            if self.wino_packed is not None:
-                wd = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()     # (Cin, Cout, 3, 3): the equivalent forward weight of the gradient conv
-                hip.call("pn_pack_conv_weight_wino_f32", wd.data_ptr(), self.cin, self.cout, self.wino_packed.data_ptr(), st)
-                if self.wino4_packed is not None:
-                    hip.call("pn_pack_conv_weight_wino4_f32", wd.data_ptr(), self.cin, self.cout, self.wino4_packed.data_ptr(), st)
-        elif self.kind == "s2k3":
-            hip.call("pn_pack_conv_dgrad_s2_weight_f32", w.data_ptr(), self.cout, self.cin, self.packed.data_ptr(), st)
+        """lazy, as ConvLayer.repack: the layout a call takes is packed on first use"""
+        self._stale_w = weight.detach().contiguous().float()
+        self._stale = {"direct"} | ({"wino"} if self.wino_packed is not None else set()) | ({"wino4"} if self.wino4_packed is not None else set())
+
+    def _ensure(self, layout: str) -> None:
+        if layout not in self._stale:
+            return
+        self._stale.discard(layout)
+        w, st = self._stale_w, hip.stream()
+        if layout == "direct":
+            if self.kind == "s1":
+                hip.call("pn_pack_conv_dgrad_weight_f32", w.data_ptr(), self.cout, self.cin, self.kh, self.kw, self.packed.data_ptr(), st)
+            elif self.kind == "s2k3":
+                hip.call("pn_pack_conv_dgrad_s2_weight_f32", w.data_ptr(), self.cout, self.cin, self.packed.data_ptr(), st)
+            else:
+                hip.call("pn_pack_deconv2x2_weight_f32", w.data_ptr(), self.cout, self.cin, self.packed.data_ptr(), st)
+            return
+        wd = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()     # (Cin, Cout, 3, 3): the equivalent forward weight of the gradient conv
+        if layout == "wino":
+            hip.call("pn_pack_conv_weight_wino_f32", wd.data_ptr(), self.cin, self.cout, self.wino_packed.data_ptr(), st)
         else:
-            hip.call("pn_pack_deconv2x2_weight_f32", w.data_ptr(), self.cout, self.cin, self.packed.data_ptr(), st)
+            hip.call("pn_pack_conv_weight_wino4_f32", wd.data_ptr(), self.cin, self.cout, self.wino4_packed.data_ptr(), st)
 
     def __call__(self, dout: torch.Tensor, out: Optional[torch.Tensor] = None, dout_channel_offset=0,
                  out_channel_offset=0, accumulate=False) -> torch.Tensor:
@@ -944,12 +967,15 @@ class ConvDgrad:
         d.accumulate = int(accumulate)
         if (self.wino4_packed is not None and not accumulate and ow % 4 == 0 and cin_eff == self.cout
                 and ((b * oh * (ow // 4) + 31) // 32) * (self.cin // 32) >= _WINO4_MIN_TILES):
+            self._ensure("wino4")
             hip.call("pn_conv2d_wino4_nhwc_f32", C.byref(d), dout.data_ptr(), self.wino4_packed.data_ptr(), None, None, out.data_ptr(), hip.stream())
             return out
         if (self.wino_packed is not None and not accumulate and ow % 2 == 0 and cin_eff == self.cout
                 and ((b * oh * (ow // 2) + 31) // 32) * ((self.cin + 63) // 64) >= _WINO_MIN_TILES):
+            self._ensure("wino")
             hip.call("pn_conv2d_wino_nhwc_f32", C.byref(d), dout.data_ptr(), self.wino_packed.data_ptr(), None, None, out.data_ptr(), hip.stream())
             return out
+        self._ensure("direct")
         hip.call("pn_conv2d_nhwc_f32", C.byref(d), dout.data_ptr(), self.packed.data_ptr(), None, None, out.data_ptr(), hip.stream())
         return out
 
