@@ -907,6 +907,33 @@ int pn_pillar_conv3x3_f32(const float *canvas, int batch, int h, int w, int cin,
                           const float *packed_w, int cout, const float *scale, const float *shift, int act, float *out,
                           int out_pixel_stride, int out_channel_offset, void *workspace, size_t workspace_bytes,
                           pn_stream_t stream);
+/* The same convolution in TRAINING: the pair tables are built once per iteration (pn_pillar_pairs_build; pn_pillar_pairs_bytes of
+ * caller-owned memory that lives from the forward to the backward) and shared by
+ *   forward          pn_pillar_conv3x3_tables_f32        (oh, ow = the output map; workspace 9 * cap * cout floats, cap = v_capacity
+ *                                                         rounded up to 128)
+ *   data gradient    pn_pillar_conv3x3_dgrad_f32         d(pillar features) [v_capacity][cin], rows in the order of unq_keys -- what
+ *                                                         pn_dynamic_pfn_bwd takes as d_features; packed_wt = pn_pack_pillar_conv_weight_f32
+ *                                                         of the weight with its first two axes swapped; workspace 9 * cap * cin floats
+ *   weight gradient  pn_pillar_conv3x3_wgrad_f32         dW (Cout, Cin, 3, 3) = sum over the pairs of dout[out]^T x[in], blocks summed in
+ *                                                         fixed order (deterministic); cin, cout <= 128
+ * Autograd of Conv2d in RPN block 0, rpn.py:124-142 under trainer.py:275-300. */
+size_t pn_pillar_pairs_bytes(int v_capacity, int batch, int oh, int ow);
+int pn_pillar_pairs_build(const uint32_t *unq_keys, const int32_t *num_voxels, int v_capacity, int batch, int h, int w,
+                          int stride, void *pair_tables, size_t table_bytes, pn_stream_t stream);
+int pn_pillar_conv3x3_tables_f32(const float *canvas, int batch, int oh, int ow, int cin, int in_pixel_stride,
+                                 int in_channel_offset, const void *pair_tables, int v_capacity, const float *packed_w,
+                                 int cout, const float *scale, const float *shift, int act, float *out,
+                                 int out_pixel_stride, int out_channel_offset, void *workspace, size_t workspace_bytes,
+                                 pn_stream_t stream);
+int pn_pillar_conv3x3_dgrad_f32(const float *dout, int batch, int oh, int ow, int cout, int dout_pixel_stride,
+                                int dout_channel_offset, const void *pair_tables, const int32_t *num_voxels,
+                                int v_capacity, const float *packed_wt, int cin, float *dfeat, void *workspace,
+                                size_t workspace_bytes, pn_stream_t stream);
+size_t pn_pillar_conv_wgrad_workspace_bytes(int v_capacity, int cin, int cout);
+int pn_pillar_conv3x3_wgrad_f32(const float *canvas, int in_pixel_stride, int in_channel_offset, int cin, const float *dout,
+                                int dout_pixel_stride, int dout_channel_offset, int cout, const void *pair_tables,
+                                int v_capacity, int batch, int oh, int ow, float *dw_oihw, int accumulate, void *workspace,
+                                size_t workspace_bytes, pn_stream_t stream);
 size_t pn_conv_stat_partial_floats(const pn_conv_desc *desc, int tile);
 int pn_conv2d_multi_f32(const pn_conv_job *jobs, int njobs, int tile, pn_stream_t stream);
 /* the same job list on the VALU kernel for convolutions with very few output columns (1x1 / 3x3, <= 64 input channels,

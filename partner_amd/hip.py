@@ -185,6 +185,12 @@ SIGNATURES = {
     "pn_pack_pillar_conv_weight_f32": (_I, [_P, _I, _I, _P, _P]),
     "pn_pillar_conv_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "pn_pillar_conv3x3_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _SZ, _P]),
+    "pn_pillar_pairs_bytes": (_SZ, [_I, _I, _I, _I]),
+    "pn_pillar_pairs_build": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "pn_pillar_conv3x3_tables_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _SZ, _P]),
+    "pn_pillar_conv3x3_dgrad_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _SZ, _P]),
+    "pn_pillar_conv_wgrad_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "pn_pillar_conv3x3_wgrad_f32": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _SZ, _P]),
     "pn_polar_warp_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _P, _P]),
     "pn_contract_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "pn_softmax_f32": (_I, [_P, _P, C.c_longlong, _I, _I, _P]),

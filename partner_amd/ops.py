@@ -600,6 +600,58 @@ class PillarConvLayer:
             prof.end(ev, 2.0 * pairs * self.cout * self.cin, st, tag=f"{oh}x{ow} {self.cin}->{self.cout} k3 pillars")
         return out
 
+    # ---- training: pair tables built once per iteration, shared by forward, data gradient and weight gradient
+    def repack(self, weight: torch.Tensor) -> None:
+        w = weight.detach().contiguous().float()
+        hip.call("pn_pack_pillar_conv_weight_f32", w.data_ptr(), self.cout, self.cin, self.packed.data_ptr(), hip.stream())
+        if getattr(self, "packed_t", None) is None:
+            self.packed_t = _f32(hip.load().pn_pillar_conv_packed_weight_floats(self.cin, self.cout), w.device)
+        wt = w.permute(1, 0, 2, 3).contiguous()          # (Cin, Cout, 3, 3): the data gradient multiplies by W_tap^T, same tap
+        hip.call("pn_pack_pillar_conv_weight_f32", wt.data_ptr(), self.cin, self.cout, self.packed_t.data_ptr(), hip.stream())
+
+    def build_tables(self, vi: "VoxelIndex", b: int, h: int, w: int) -> torch.Tensor:
+        lib = hip.load()
+        oh, ow = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
+        nbytes = lib.pn_pillar_pairs_bytes(vi.n_cap, b, oh, ow)
+        tables = torch.empty(nbytes, dtype=torch.uint8, device=vi.num_voxels.device)
+        hip.call("pn_pillar_pairs_build", vi.unq_keys_ptr, vi.num_voxels.data_ptr(), vi.n_cap, b, h, w, self.stride, tables.data_ptr(), nbytes, hip.stream())
+        return tables
+
+    def forward_tables(self, canvas: torch.Tensor, vi: "VoxelIndex", tables: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        b, h, w, ct = canvas.shape
+        oh, ow = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
+        if out is None:
+            out = torch.empty((b, oh, ow, self.cout), dtype=torch.float32, device=canvas.device)
+        cap = (vi.n_cap + 127) // 128 * 128
+        ws = _workspace(9 * cap * self.cout * 4, canvas.device)
+        hip.call("pn_pillar_conv3x3_tables_f32", canvas.data_ptr(), b, oh, ow, self.cin, ct, 0, tables.data_ptr(), vi.n_cap, self.packed.data_ptr(), self.cout,
+                 hip.ptr(self.scale), hip.ptr(self.shift), self.act, out.data_ptr(), out.shape[3], 0, ws.data_ptr(), ws.numel(), hip.stream())
+        return out
+
+    def dgrad_features(self, dout: torch.Tensor, vi: "VoxelIndex", tables: torch.Tensor) -> torch.Tensor:
+        """d(pillar features) (n_cap, Cin), rows in the order of the index's cells (what ``dynamic_pfn_bwd`` takes as d_features)"""
+        hip.require_device(dout)
+        assert dout.is_contiguous() and dout.shape[3] >= self.cout
+        b, oh, ow, ct = dout.shape
+        dfeat = torch.empty((max(vi.n_cap, 1), self.cin), dtype=torch.float32, device=dout.device)
+        cap = (vi.n_cap + 127) // 128 * 128
+        ws = _workspace(9 * cap * self.cin * 4, dout.device)
+        hip.call("pn_pillar_conv3x3_dgrad_f32", dout.data_ptr(), b, oh, ow, self.cout, ct, 0, tables.data_ptr(), vi.num_voxels.data_ptr(), vi.n_cap,
+                 self.packed_t.data_ptr(), self.cin, dfeat.data_ptr(), ws.data_ptr(), ws.numel(), hip.stream())
+        return dfeat
+
+    def wgrad(self, canvas: torch.Tensor, dout: torch.Tensor, vi: "VoxelIndex", tables: torch.Tensor, out: Optional[torch.Tensor] = None,
+              accumulate=False) -> torch.Tensor:
+        lib = hip.load()
+        b, oh, ow, ct = dout.shape
+        if out is None:
+            out = torch.empty((self.cout, self.cin, 3, 3), dtype=torch.float32, device=dout.device)
+        nbytes = lib.pn_pillar_conv_wgrad_workspace_bytes(vi.n_cap, self.cin, self.cout)
+        ws = _workspace(nbytes, dout.device)
+        hip.call("pn_pillar_conv3x3_wgrad_f32", canvas.data_ptr(), canvas.shape[3], 0, self.cin, dout.data_ptr(), ct, 0, self.cout, tables.data_ptr(), vi.n_cap,
+                 b, oh, ow, out.data_ptr(), int(accumulate), ws.data_ptr(), nbytes, hip.stream())
+        return out
+
 
 class ConvJob:
     """One convolution of a multi-job launch (``conv_multi``): a packed ``ConvLayer`` applied to a channel slice of ``x``,
