@@ -308,7 +308,8 @@ __global__ void pillar_reduce_kernel(PillarReduceArgs a) {
 // ---- training: weight gradient over the pairs.  dW_t[co][ci] = sum_{pairs of tap t} dy[out][co] x[in][ci]: block (j, t) contracts
 // the pairs [j * range, (j + 1) * range) of tap t in steps of 64 (both operands gathered into LDS, the MFMA's contraction index is the
 // pair: 32-bit column reads as in conv_wgrad_wino4.hip) into a 128 x 128 tile; pair_wgrad_reduce_kernel sums the blocks in order.
-constexpr int PW_K = 64, PW_LD = 160;
+constexpr int PW_K = 32, PW_LD = 160;      // 41 KB of LDS per block: three blocks per CU overlap their gather latencies (64 pairs per step, one block per CU: 400 us)
+constexpr int PW_BLOCKS_PER_TAP = 336;      // blocks per tap over the CAPACITY of a list; at stride 2 a list holds about a quarter of it: ~84 live, three per CU
 struct PairWgArgs {
   const float* x;
   const float* dy;
@@ -334,30 +335,42 @@ __global__ __launch_bounds__(512) void pair_wgrad_kernel(PairWgArgs a) {
   for (int k = 0; k < 2; ++k)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-  const int c4 = tid & 31, r0 = tid >> 5;       // loader: rows r0, r0 + 16, r0 + 32, r0 + 48, 16-byte channel group c4
-  for (int p = p0; p < p1; p += PW_K) {
-    int pin[4], pout[4];
+  constexpr int NI = PW_K / 16;                 // loader items per thread
+  const int c4 = tid & 31, r0 = tid >> 5;       // loader: rows r0, r0 + 16, ..., 16-byte channel group c4
+  // software pipeline: the pair indices run two steps ahead, the gathered rows one step ahead of the MFMAs (index -> row are two
+  // dependent memory latencies; loaded inside the step they serialised with the 32 MFMAs: 315 us per bs = 4 launch)
+  int pin[NI], pout[NI];
+  f32x4 xv[NI], dv[NI];
+  auto load_idx = [&](int p) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NI; ++k) {
       const int q = p + r0 + 16 * k;
       pin[k] = q < p1 ? a.pair_in[(size_t)t * a.cap + q] : -1;
       pout[k] = q < p1 ? a.pair_out[(size_t)t * a.cap + q] : -1;
     }
-    f32x4 xv[4], dv[4];
+  };
+  auto load_rows = [&]() {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NI; ++k) {
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       xv[k] = (pin[k] >= 0 && c4 * 4 < a.cin) ? *reinterpret_cast<const f32x4*>(a.x + (size_t)pin[k] * a.x_ps + a.x_co + c4 * 4) : z;
       dv[k] = (pout[k] >= 0 && c4 * 4 < a.cout) ? *reinterpret_cast<const f32x4*>(a.dy + (size_t)pout[k] * a.dy_ps + a.dy_co + c4 * 4) : z;
     }
+  };
+  load_idx(p0);
+  load_rows();
+  load_idx(p0 + PW_K);
+  for (int p = p0; p < p1; p += PW_K) {
     __syncthreads();          // the previous step's tiles have been read
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NI; ++k) {
       *reinterpret_cast<f32x4*>(Xs + (r0 + 16 * k) * PW_LD + c4 * 4) = xv[k];
       *reinterpret_cast<f32x4*>(Ds + (r0 + 16 * k) * PW_LD + c4 * 4) = dv[k];
     }
     __syncthreads();
-#pragma unroll 8
+    load_rows();                 // step p + PW_K (indices already here); in flight during the MFMAs below
+    load_idx(p + 2 * PW_K);
+#pragma unroll
     for (int kp = 0; kp < PW_K / 2; ++kp) {
       const float av = Ds[(2 * kp + lh) * PW_LD + 32 * wm + li];
       const float b0 = Xs[(2 * kp + lh) * PW_LD + 64 * wn + li];
@@ -567,7 +580,7 @@ int pn_pillar_conv3x3_dgrad_f32(const float* dout, int batch, int oh, int ow, in
 // training: dW (Cout, Cin, 3, 3) over the pairs.  cin, cout <= 128.
 size_t pn_pillar_conv_wgrad_workspace_bytes(int v_capacity, int cin, int cout) {
   const int cap = cap_rows(v_capacity);
-  const int range = std::max(PW_K, pn::cdiv(pn::cdiv(cap, 28), PW_K) * PW_K);     // ~28 blocks per tap (9 taps: one round of 256 CUs)
+  const int range = std::max(PW_K, pn::cdiv(pn::cdiv(cap, PW_BLOCKS_PER_TAP), PW_K) * PW_K);
   return (size_t)9 * pn::cdiv(cap, range) * cin * cout * 4 + 256;
 }
 
@@ -579,7 +592,7 @@ int pn_pillar_conv3x3_wgrad_f32(const float* canvas, int in_pixel_stride, int in
   PN_REQUIRE(in_pixel_stride % 4 == 0 && in_channel_offset % 4 == 0 && dout_pixel_stride % 4 == 0 && dout_channel_offset % 4 == 0, "pillar_conv_wgrad: aligned slices");
   if (workspace_bytes < pn_pillar_conv_wgrad_workspace_bytes(v_capacity, cin, cout)) return pn::fail(PN_ERR_WORKSPACE, "pillar_conv_wgrad: workspace too small");
   const int cap = cap_rows(v_capacity);
-  const int range = std::max(PW_K, pn::cdiv(pn::cdiv(cap, 28), PW_K) * PW_K);
+  const int range = std::max(PW_K, pn::cdiv(pn::cdiv(cap, PW_BLOCKS_PER_TAP), PW_K) * PW_K);
   const int nblk = pn::cdiv(cap, range);
   const Tables tb = tables(v_capacity, batch, oh, ow);
   const char* base = static_cast<const char*>(pair_tables);
