@@ -265,12 +265,24 @@ __global__ void pair_reduce_kernel(ReduceArgs a) {
   }
 }
 
+// exclusive scan of the per-block counts over the blocks, one wave per tap (64 blocks per pass, running carry)
 __global__ void pair_scan_kernel(int32_t* __restrict__ blk, int nblocks, int32_t* __restrict__ cnt) {
-  const int t = threadIdx.x;
+  const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (t >= 9) return;
-  int run = 0;
-  for (int b = 0; b < nblocks; ++b) { const int c = blk[b * 16 + t]; blk[b * 16 + t] = run; run += c; }
-  cnt[t] = run;
+  int carry = 0;
+  for (int b0 = 0; b0 < nblocks; b0 += 64) {
+    const int b = b0 + lane;
+    const int c = b < nblocks ? blk[b * 16 + t] : 0;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    if (b < nblocks) blk[b * 16 + t] = carry + incl - c;
+    carry += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) cnt[t] = carry;
 }
 
 // ---- training: data gradient at the pillars.  dfeat[i][:] = sum over the pillar's pairs of partial[tap][slot][:], the rows
@@ -491,7 +503,7 @@ static int pairs_build(const uint32_t* unq_keys, const int32_t* num_voxels, int 
   if (ordered) {
     const int nblocks = pn::cdiv(v_capacity, 1024);          // one block per 1024 pillars, in pillar order
     hipLaunchKernelGGL(pair_kernel<1>, dim3(nblocks), dim3(1024), 0, st, pa);
-    hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(64), 0, st, pa.blk, nblocks, cnt);
+    hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(576), 0, st, pa.blk, nblocks, cnt);
     hipLaunchKernelGGL(pair_kernel<2>, dim3(nblocks), dim3(1024), 0, st, pa);
   } else {
     hipLaunchKernelGGL(pair_kernel<0>, dim3((unsigned)std::min(256, pn::cdiv(v_capacity, 1024))), dim3(1024), 0, st, pa);
