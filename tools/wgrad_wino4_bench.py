@@ -1,8 +1,12 @@
-import sys; sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""F(4,3) weight gradient (csrc/conv_wgrad_wino4.hip) against the direct weight-gradient kernel and float64 autograd on the training
+shapes (bs = 4): errors and event-timed launches.  python tools/wgrad_wino4_bench.py"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from partner_amd import ops, hip
 dev = torch.device("cuda:0")
-import os
 for (b, h, w, cin, cout) in [(1, 8, 16, 8, 12), (2, 33, 64, 36, 20), (4, 256, 256, 128, 128), (4, 128, 128, 128, 128), (4, 64, 64, 256, 256), (4, 128, 128, 384, 64)]:
     torch.manual_seed(0)
     x = torch.randn((b, h, w, cin), device=dev)
