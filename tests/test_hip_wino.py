@@ -331,3 +331,33 @@ def test_pillar_conv_training_path_matches_dense_autograd(dev, case):
     dw2 = layer.wgrad(canvas, dy, vi, tables, out=dw.clone(), accumulate=True)
     assert float((dw2 - 2 * dw).abs().max()) < 1e-5 * float(dw.abs().max())
     assert torch.equal(layer.wgrad(canvas, dy, vi, tables), dw)          # fixed block order: bitwise reproducible
+
+
+def test_winograd_family_random_shapes(dev):
+    """forty random small geometries (width a multiple of 4, ragged channel counts, batch 1-3, single rows / columns of quads) through
+    F(4, 3) forward (both forms by tile count), F(2, 3) and the F(4, 3) weight gradient against float64"""
+    from partner_amd import hip, ops
+    lib = hip.load()
+    rng = np.random.default_rng(1234)
+    for it in range(40):
+        b, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 40)), 4 * int(rng.integers(1, 40))
+        cin, cout = 4 * int(rng.integers(1, 40)), int(rng.integers(1, 150))
+        g = torch.Generator().manual_seed(it)
+        x = torch.randn((b, h, w, cin), generator=g).to(dev)
+        wt = (torch.randn((cout, cin, 3, 3), generator=g) * 0.1).to(dev)
+        shift = torch.randn(cout, generator=g).to(dev)
+        r = ref64(x, wt, None, shift, True)
+        sc = float(r.abs().max()) + 1e-30
+        for fn in (run_wino4, run_wino):
+            y = fn(x, wt, None, shift, ops.ACT_RELU)
+            assert float((y.double() - r).abs().max()) / sc < 2e-5, (it, fn.__name__, b, h, w, cin, cout)
+        if cout % 4 == 0:
+            dy = torch.randn((b, h, w, cout), generator=g).to(dev)
+            d = ops.ConvDesc(b, h, w, cin, cout, 1, 3, 3, 1, 1, 1, cin, 0, cout, 0, 0, 0, 0)
+            nbytes = lib.pn_conv2d_wgrad_wino4_workspace_bytes(C.byref(d))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            dw = torch.empty((cout, cin, 3, 3), device=dev)
+            hip.call("pn_conv2d_wgrad_wino4_f32", C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 0, ws.data_ptr(), nbytes, hip.stream())
+            w64 = torch.zeros((cout, cin, 3, 3), dtype=torch.float64, device=dev, requires_grad=True)
+            (torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w64, padding=1) * dy.permute(0, 3, 1, 2).double()).sum().backward()
+            assert float((dw.double() - w64.grad).abs().max() / (w64.grad.abs().max() + 1e-30)) < 2e-5, (it, "wgrad", b, h, w, cin, cout)
