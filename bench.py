@@ -30,6 +30,15 @@ Objects in the JSON line:
                     gradient all-reduce overlapped with backward + clip / wd / Adam)
   cpu_baseline      the CPU oracle (oracle/polar_oracle.py, a port of the reference path checked against reference
                     goldens) timed on this box's host cores, rank 0, N=1 only.
+  c4                BASELINE configs[3] (N=1): the Waymo PARTNER detector at bs = 2, f32 and with bf16 BEV convolutions: ms per
+                    step, per-stage ms, issued-MFMA roofline fraction per MFMA stage (partner_amd/utils/legs.py)
+  c5                BASELINE configs[4] (N=1): 300k-point streaming frames, one hipGraph replay per frame, latency p50 / p99
+  roofline_scatter_coarse   SURVEY 8(d)'s secondary row: the scatter stage on the 0.3125 m x 0.05 rad synthetic grid
+  ranks             N > 1: what every rank saw (world size after init, device ordinal, PCI bus id, host)
+
+roofline.frac is the matrix work ISSUED (MFMA FLOPs the kernels execute: Winograd launches issue 2/3 resp. 1/2 of the direct
+algorithm's FLOPs) / kernel time / 157.3 TFLOP/s, so it cannot exceed 1; the direct algorithm's FLOPs over the same time are
+reported next to it as `algorithmic_equiv` (first layer billed dense there, with the pairs it multiplies in `frac`).
 """
 from __future__ import annotations
 
@@ -101,7 +110,7 @@ def host_cpu_info():
     return model, (len(cores) or logical or (os.cpu_count() or 1)), (logical or (os.cpu_count() or 1))
 
 
-def cpu_baseline(n_points: int, batch: int, budget_s: float = 30.0, min_frames: int = 20, max_frames: int = 40):
+def cpu_baseline(n_points: int, batch: int, budget_s: float = 30.0, min_frames: int = 20, max_frames: int = 40, warmups: int = 5):
     """time the CPU oracle on the same workload (bounded sample: >= 20 timed frames, <= ~30 s)"""
     from oracle import polar_oracle as O
 
@@ -122,14 +131,14 @@ def cpu_baseline(n_points: int, batch: int, budget_s: float = 30.0, min_frames: 
     times = []
     t_all = time.perf_counter()
     with torch.no_grad():
-        for f in range(max_frames + 2):
+        for f in range(max_frames + warmups):
             sweeps = [synth.synth_sweep_cart(n_points, seed=1000 + f * batch + b) for b in range(batch)]
             t0 = time.perf_counter()
             polar = [O.cart_to_polar(s) for s in sweeps]
             gi = O.with_batch_index([O.grid_index(p, synth.NUSC_RANGE, synth.NUSC_VOXEL) for p in polar])
             O.pointpillars_forward(sd, cfg, np.concatenate(polar, 0), gi, batch)
             dt = time.perf_counter() - t0
-            if f > 1:  # two warm-up frames
+            if f >= warmups:
                 times.append(dt)
             if len(times) >= max_frames or (time.perf_counter() - t_all > budget_s and len(times) >= min_frames):
                 break
@@ -138,7 +147,7 @@ def cpu_baseline(n_points: int, batch: int, budget_s: float = 30.0, min_frames: 
     return dict(value=round(fps, 4), unit="frames/s", cores=torch.get_num_threads(), kind="port",
                 cpu_model=model_name, host_physical_cores=phys, host_logical_cpus=logical,
                 p50_s_per_frame=round(float(ts[len(ts) // 2]), 4),
-                sample=f"{len(times)} timed frames (+2 warm-up) of the same {n_points}-pt synthetic sweeps, batch {batch}, "
+                sample=f"{len(times)} timed frames (+{warmups} warm-up) of the same {n_points}-pt synthetic sweeps, batch {batch}, "
                        f"oracle/polar_oracle.py (numpy + torch CPU fp32, {torch.get_num_threads()} threads: more threads are slower "
                        f"on this host); survey-container cross-check of the actual reference: 1.05-1.3 frames/s on 8 vCPU (SURVEY 6)")
 
@@ -248,14 +257,33 @@ def run_train(args, model, dev, rank, world, red_dev, steps, warmup):
         loss = leg.step(i)
     barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, red_dev)
+    last_loss = float(loss[0])
     ar = D.max_over_ranks(leg.allreduce_ms(), red_dev)
+    # the same iterations with the exchange switched off (timing only; the ranks' parameters diverge from here on, nothing
+    # follows): exposed communication = ms_per_iter - ms_per_iter_no_exchange
+    no_ex = None
+    if world > 1:
+        leg.ts.exchange_enabled = False
+        for i in range(2):
+            leg.step(i)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            leg.step(i)
+        barrier()
+        no_ex = 1e3 * D.max_over_ranks(time.perf_counter() - t1, red_dev) / steps
+        leg.ts.exchange_enabled = True
     B = args.train_batch
     return dict(ms_per_iter=round(1e3 * elapsed / steps, 3), frames_per_s=round(world * steps * B / elapsed, 3), sweeps_per_iter_per_gpu=B,
                 iters=steps, warmup=warmup, n_gpus=world,
+                ms_per_iter_no_exchange=None if no_ex is None else round(no_ex, 3),
+                exposed_exchange_ms=None if no_ex is None else round(1e3 * elapsed / steps - no_ex, 3),
                 all_reduce_ms=round(ar, 3), all_reduce="flat fp32 gradient buffer in reverse-layer-order buckets, issued during backward "
-                                                       f"({leg.ts.ps.total} floats, {len(leg.ts.buckets)} buckets); all_reduce_ms = the exchange alone, not overlapped",
+                                                       f"({leg.ts.ps.total} floats, {len(leg.ts.buckets)} buckets); all_reduce_ms = the exchange alone, back to back, "
+                                                       "not overlapped; exposed_exchange_ms = ms_per_iter - ms_per_iter_no_exchange (the same iterations with the "
+                                                       "collectives switched off)",
                 approx_tflops_per_gpu=round(3 * 150.6e9 * B * steps / elapsed / 1e12, 1),  # fwd 150.6 GFLOP/frame, bwd = dgrad + wgrad
-                first_loss=loss0, last_loss=float(loss[0]))
+                first_loss=loss0, last_loss=last_loss)
 
 
 def run_train_partner(args, dev, rank, world, red_dev, steps, warmup):
@@ -358,13 +386,22 @@ def scatter_roofline(model, dev, n_points, spec):
                 measured="HIP events around 200 replays of the stage's own hipGraph on one stream")
 
 
+def pmc_traffic_path():
+    """the newest committed PMC traffic summary (profiles/rN_pmc_traffic.csv)"""
+    for r in ("r3", "r2"):
+        path = os.path.join(ROOT, "profiles", f"{r}_pmc_traffic.csv")
+        if os.path.exists(path):
+            return path
+    return None
+
+
 def committed_pmc_bytes(kernel_prefixes, per="frame"):
     """HBM bytes from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the gfx950 guide prescribes + WRITE_SIZE, separate
     --pmc passes of this command with --streams 1): summed over the kernels whose name contains one of the prefixes, per frame
     (per='frame') or averaged per launch (per='launch'); None if the summary is absent"""
     import csv
-    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.csv")
-    if not os.path.exists(path):
+    path = pmc_traffic_path()
+    if path is None:
         return None
     rows = list(csv.DictReader(open(path)))
     frames = None
@@ -383,21 +420,45 @@ def committed_pmc_bytes(kernel_prefixes, per="frame"):
 
 
 # ------------------------------------------------------------------------------------------------ main
+def rank_table(rank, world, dev_index=None):
+    """what every rank saw after the rendezvous: -> (ranks_seen, [per-rank dict]) on every rank.  ranks_seen is
+    dist.get_world_size() AFTER init (1 without a process group): the line is self-verifying when the driver runs N > 1"""
+    import torch.distributed as dist
+    me = dict(rank=rank, pid=os.getpid(), host=socket.gethostname(), world_size_seen=1, device=dev_index, pci_bus_id=None)
+    if dev_index is not None:
+        try:
+            from partner_amd import hip
+            me["pci_bus_id"] = hip.device_info(dev_index).get("pci_bus_id")
+        except Exception as e:  # noqa: BLE001 -- the identity of the device is a report, never a reason to lose the line
+            me["pci_bus_id"] = f"unavailable: {e}"
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, [me]
+    me["world_size_seen"] = dist.get_world_size()
+    table = [None] * dist.get_world_size()
+    dist.all_gather_object(table, me)
+    return dist.get_world_size(), sorted(table, key=lambda r: r["rank"])
+
+
 def dry_run(args, rank, world):
     """launcher / rendezvous / barrier / max-reduce on any backend without a GPU (CPU tests of the N > 1 plumbing)"""
     from partner_amd import dist_utils as D
-    D.init(args.backend, None)
+    D.init(args.backend, None, timeout_s=args.collective_timeout)
     D.barrier()
+    seen, ranks = rank_table(rank, world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001)
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0)
+    # the two timings of the training leg's exchange accounting, on sleeps: same fields as the GPU line
+    train = dict(ms_per_iter=round(1e3 * elapsed / args.steps, 3), ms_per_iter_no_exchange=round(1e3 * elapsed / args.steps, 3) if world > 1 else None,
+                 exposed_exchange_ms=0.0 if world > 1 else None, n_gpus=world)
     if rank == 0:
         print(json.dumps({"metric": "dry run of the launcher and the rank plumbing (no GPU work, no product path)", "value": round(world * args.steps / elapsed, 3),
                           "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run",
-                          "config": {"workload": "none (--dry-run)", "parallelism": f"ranks x{world}", "backend": args.backend}}), flush=True)
+                          "config": {"workload": "none (--dry-run)", "parallelism": f"ranks x{world}", "backend": args.backend},
+                          "ranks_seen": seen, "ranks": ranks, "train_step": train}), flush=True)
     if world > 1:
         D.barrier()
         torch.distributed.destroy_process_group()
@@ -424,6 +485,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for a same-GPU dry run)")
     ap.add_argument("--streams", type=int, default=4, help="frames in flight per GPU (one hipGraph engine per HIP stream)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the launcher, the rendezvous and the reductions only")
+    ap.add_argument("--collective-timeout", type=float, default=300.0, help="seconds a rank waits in a collective before it gives up (N > 1)")
+    ap.add_argument("--no-c4", action="store_true", help="skip the Waymo PARTNER leg (BASELINE configs[3], N = 1 only)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the 300k-point streaming leg (BASELINE configs[4], N = 1 only)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -445,7 +509,9 @@ def main():
         return 2
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
-    D.init(args.backend, dev)  # RCCL over xGMI: barrier, MAX-reduce of the time and the gradient buckets of the training leg
+    # RCCL over xGMI: barrier, MAX-reduce of the time and the gradient buckets of the training leg; every wait is bounded
+    D.init(args.backend, dev, timeout_s=args.collective_timeout)
+    ranks_seen, ranks = rank_table(rank, world, dev.index)
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     import partner_amd as P
@@ -473,7 +539,7 @@ def main():
                 "config": {"workload": "Waymo polar PARTNER cfg (VoxelNetV3: mean VFE -> SpMiddleResNetFHD -> 2 x SetBlock -> RPN -> E2ESWVoteHead), "
                                        "training iteration (BASELINE configs[3])", "points_per_sweep": 180000, "sweeps_per_step_per_gpu": 2,
                            "parallelism": f"dp{world}, flat-gradient all-reduce"},
-                "train_step": tr}), flush=True)
+                "train_step": tr, "ranks_seen": ranks_seen, "ranks": ranks}), flush=True)
         if world > 1:
             D.barrier()
             torch.distributed.destroy_process_group()
@@ -488,7 +554,7 @@ def main():
                 "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "nuScenes polar-pillar PARTNER cfg training iteration (BASELINE configs[2])", "points_per_sweep": N,
                            "sweeps_per_step_per_gpu": args.train_batch, "parallelism": f"dp{world}, bucketed flat-gradient all-reduce overlapped with backward"},
-                "train_step": tr}), flush=True)
+                "train_step": tr, "ranks_seen": ranks_seen, "ranks": ranks}), flush=True)
         if world > 1:
             D.barrier()
             torch.distributed.destroy_process_group()
@@ -576,39 +642,72 @@ def main():
             step_eager(i)
         barrier()
         eager_ms = 1e3 * (time.perf_counter() - t1) / args.steps
-        flops, ms, launches, tags = prof.collect(by_tag=True)
+        flops, ms, launches, tags = prof.collect(by_tag=True, full=True)
         ops.disable_conv_profiling()
-        ach = flops / (ms * 1e-3) / 1e12
-        # MFMA work actually ISSUED: the Winograd launches issue 6 (F(2,3)) or 4.5 (F(4,3)) of their 9 algorithmic MACs
-        issued = sum(f * (2.0 / 3.0 if "F(2,3)" in t else 0.5 if "F(4,3)" in t else 1.0) for t, (f, m, n) in tags.items()) / (ms * 1e-3) / 1e12
-        layers = {t: dict(launches_per_step=round(n / args.steps, 2), us=round(1e3 * m / n, 2), tflops=round(f / (m * 1e-3) / 1e12, 1))
-                  for t, (f, m, n) in sorted(tags.items(), key=lambda kv: -kv[1][1])}
-        roofline = dict(bound="mfma", kernel="conv_mfma_kernel / conv_wino_kernel family (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; the stride-1 3x3 "
-                                             "layers through a width-Winograd transform -- F(4,3) on the 256 x 256 maps, F(2,3) on the smaller ones: 4.5 / 6 of "
-                                             "the 9 algorithmic MACs reach the MFMA, so `achieved` counts algorithmic FLOPs and can exceed the MFMA issue "
-                                             "rate of a layer; block 0's first layer multiplies (pillar, tap) pairs only -- pillar_conv.hip -- and is counted "
-                                             "with the FLOPs it actually multiplies)",
-                        achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        issued=dict(tflops=round(issued, 3), frac=round(issued / PEAK_F32_MFMA_TFLOPS, 4),
-                                    note="MFMA FLOPs the kernels issue (Winograd launches: 2/3 resp. 1/2 of their algorithmic FLOPs): the matrix-pipe utilisation"),
+        # roofline.frac: the matrix work ISSUED / kernel time / peak.  Winograd launches issue 6 (F(2,3)) or 4.5
+        # (F(4,3)) of the direct algorithm's 9 MACs per output; block 0's first layer multiplies its (pillar, tap) pairs only.
+        issued_f = sum(t[3] for t in tags.values())
+        dense_f = sum(t[4] for t in tags.values())
+        issued = issued_f / (ms * 1e-3) / 1e12
+        dense = dense_f / (ms * 1e-3) / 1e12
+        layers = {t: dict(launches_per_step=round(n / args.steps, 2), us=round(1e3 * m / n, 2), tflops_issued=round(iss / (m * 1e-3) / 1e12, 1),
+                          frac=round(iss / (m * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3), tflops_algorithmic_equiv=round(den / (m * 1e-3) / 1e12, 1))
+                  for t, (f, m, n, iss, den) in sorted(tags.items(), key=lambda kv: -kv[1][1])}
+        roofline = dict(bound="mfma", kernel="conv_mfma_kernel / conv_wino_kernel / conv_wino4_kernel family (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; the "
+                                             "stride-1 3x3 layers through a width-Winograd transform, F(4,3) or F(2,3); block 0's first layer on (pillar, tap) "
+                                             "pairs -- pillar_conv.hip)",
+                        achieved=round(issued, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(issued / PEAK_F32_MFMA_TFLOPS, 4),
+                        counts="FLOPs the kernels ISSUE to the matrix pipes (Winograd launches: 2/3 resp. 1/2 of the direct algorithm's; first layer: "
+                               "the pairs it multiplies) / the kernels' own execution time",
+                        algorithmic_equiv=dict(tflops=round(dense, 3), over_peak=round(dense / PEAK_F32_MFMA_TFLOPS, 4),
+                                               note="the direct dense algorithm's FLOPs (every layer 2*pixels*Cout*Cin*KH*KW, first layer included) over the "
+                                                    "same kernel time: what the FLOP-reducing forms buy; not a roofline fraction, may exceed 1"),
                         traffic=committed_pmc_bytes(("conv_mfma_kernel", "conv_wino", "conv_small_n", "conv_multi", "pair_gemm", "pair_reduce"), per="launch"),
-                        traffic_unit="HBM bytes per conv launch (offline PMC passes of this command, profiles/r2_pmc_traffic.csv)",
-                        launches=launches, launches_per_step=round(launches / args.steps, 2), flops_per_launch=round(flops / launches),
+                        traffic_unit="HBM bytes per conv launch (offline PMC passes of this command, profiles/%s)" % os.path.basename(pmc_traffic_path() or "none"),
+                        launches=launches, launches_per_step=round(launches / args.steps, 2), flops_issued_per_launch=round(issued_f / launches),
                         avg_launch_us=round(1e3 * ms / launches, 2), conv_ms_per_step=round(ms / args.steps, 4),
                         paired_with="single_stream_ms_per_step (one frame in flight)",
                         measured="start/stop events attached to every conv dispatch (hipExtLaunchKernelGGL) over the same K steps "
                                  "launched eagerly on one stream: per-kernel execution time as in a rocprofv3 kernel trace",
                         eager_ms_per_step=round(eager_ms, 4), by_layer=layers)
 
-    scatter = None
-    if not args.no_roofline_events and rank == 0 and B == 1:
+    # every rank runs the stage measurement (rank 0's is reported): no rank waits in a collective while another measures alone
+    scatter = coarse = None
+    if not args.no_roofline_events and B == 1:
         scatter = scatter_roofline(model, dev, N, spec)
+        from partner_amd.utils import legs
+        try:
+            coarse = legs.coarse_scatter_row(c2_model_cfg(), dev, N)
+        except Exception as e:  # noqa: BLE001 -- a secondary row never costs the headline line
+            coarse = dict(error=f"{type(e).__name__}: {e}")
+
+    # BASELINE configs[4] and configs[3] on this GPU (N = 1 only: secondary objects of the default line)
+    c5 = c4 = None
+    if world == 1 and B == 1 and not args.eager:
+        from partner_amd.utils import legs
+        if not args.no_c5:
+            try:
+                tcfg = dict(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], score_threshold=0.1, out_size_factor=4,
+                            voxel_size=synth.NUSC_VOXEL, pc_range=synth.NUSC_RANGE,
+                            nms=dict(nms_pre_max_size=1000, nms_post_max_size=83, nms_iou_threshold=0.2))
+                c5 = legs.c5_leg(model, dev, tcfg)
+            except Exception as e:  # noqa: BLE001
+                c5 = dict(error=f"{type(e).__name__}: {e}")
 
     train = None
     if not args.no_train_leg:
         engines.clear()        # free the graphs' private pools before the training iteration allocates its activations
         torch.cuda.empty_cache()
         train = run_train(args, model, dev, rank, world, red_dev, steps=min(args.steps, 10), warmup=3)
+
+    if world == 1 and B == 1 and not args.eager and not args.no_c4:
+        from partner_amd.utils import legs
+        engines.clear()
+        torch.cuda.empty_cache()
+        try:
+            c4 = legs.c4_leg(dev)
+        except Exception as e:  # noqa: BLE001
+            c4 = dict(error=f"{type(e).__name__}: {e}")
 
     if rank == 0:
         fps = world * args.steps * B / elapsed
@@ -622,7 +721,8 @@ def main():
                        "points_per_sweep": N, "sweeps_per_step_per_gpu": B, "parallelism": f"frame-replicas x{world}", "device": hip.device_info(dev.index or 0),
                        "launch": "eager" if args.eager else f"hipGraph replay per frame, {max(1, args.streams)} frame(s) in flight on separate HIP streams"},
             "single_stream_ms_per_step": None if single_ms is None else round(single_ms, 4),
-            "batched": batched, "roofline": roofline, "roofline_scatter": scatter, "train_step": train,
+            "batched": batched, "roofline": roofline, "roofline_scatter": scatter, "roofline_scatter_coarse": coarse, "train_step": train,
+            "c4": c4, "c5": c5, "ranks_seen": ranks_seen, "ranks": ranks,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, B)

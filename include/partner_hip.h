@@ -57,6 +57,9 @@ int pn_handle_create(int device, pn_handle_t *out);
 int pn_handle_destroy(pn_handle_t handle);
 int pn_handle_info(pn_handle_t handle, int *device, int *compute_units, int *lds_bytes_per_cu, unsigned long long *hbm_bytes,
                    char *arch, size_t arch_len);
+/* PCI bus id of the handle's device ("0000:05:00.0"), NUL terminated: identifies the physical GPU behind a rank in the
+ * multi-GPU bench line (one process per GPU, as tools/train.py:103-107 launches the reference). */
+int pn_handle_pci_bus_id(pn_handle_t handle, char *buf, size_t buf_len);
 
 /* ---------------------------------------------------------------------------------------
  * V0  cart -> polar point decoration.
@@ -695,8 +698,8 @@ int pn_sparse_to_dense_nhwc(const float *feats, const uint32_t *keys, int capaci
  *                                  exists): the data gradient is then pn_sparse_conv_f32 over `inv` with the (Cin, Cout)
  *                                  transposed weights -- a gather, no atomics
  *   pn_sparse_conv_wgrad_f32       dw[co][tap][ci] (+)= sum_i dout[i][co] * in[nbr[i][tap]][ci]  (spconv weight layout
- *                                  (Cout, kD, kH, kW, Cin)); `cin` = row width of `in` (a multiple of 4), cin_real <= cin the
- *                                  channels kept; the MFMA weight-gradient kernel of pn_conv2d_wgrad_f32 with the neighbour
+ *                                  (Cout, kD, kH, kW, Cin)); `in_rows` x `cin` = the feature matrix `in` (cin a multiple of 4;
+ *                                  in_rows * cin * 4 < 2 GiB: row offsets are 32-bit), cin_real <= cin the channels kept; the MFMA weight-gradient kernel of pn_conv2d_wgrad_f32 with the neighbour
  *                                  table in its loader, row slices reduced in slice order (no atomics)
  *   pn_sparse_from_dense_nhwc      gradient of pn_sparse_to_dense_nhwc: gathers (B, H, W, C*D) back to the active rows
  *   pn_add_relu_f32                out = max(a + b, 0)  (SparseBasicBlock's residual join, scn.py:84-95)
@@ -704,7 +707,7 @@ int pn_sparse_to_dense_nhwc(const float *feats, const uint32_t *keys, int capaci
 int pn_sparse_neighbors_transpose(const int32_t *nbr, const int32_t *n_out, int out_capacity, int taps, int in_rows,
                                   int32_t *inv, pn_stream_t stream);
 size_t pn_sparse_conv_wgrad_workspace_bytes(int out_capacity, int taps, int cout, int cin);
-int pn_sparse_conv_wgrad_f32(const float *in, int cin, int cin_real, const float *dout, int cout, const int32_t *nbr,
+int pn_sparse_conv_wgrad_f32(const float *in, int in_rows, int cin, int cin_real, const float *dout, int cout, const int32_t *nbr,
                              const int32_t *n_out, int out_capacity, int taps, float *dw, int accumulate,
                              void *workspace, size_t workspace_bytes, pn_stream_t stream);
 int pn_sparse_from_dense_nhwc(const float *dense, const uint32_t *keys, int capacity, const int32_t *n_dev,

@@ -424,7 +424,7 @@ size_t pn_sparse_conv_wgrad_workspace_bytes(int out_capacity, int taps, int cout
   return (size_t)p.splits * p.taps * p.cin_pad * p.cout_pad * sizeof(float);
 }
 
-int pn_sparse_conv_wgrad_f32(const float* in, int cin, int cin_real, const float* dout, int cout, const int32_t* nbr, const int32_t* n_out,
+int pn_sparse_conv_wgrad_f32(const float* in, int in_rows, int cin, int cin_real, const float* dout, int cout, const int32_t* nbr, const int32_t* n_out,
                              int out_capacity, int taps, float* dw, int accumulate, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
   WgradPlan p;
   if (int rc = plan_sparse_wgrad(out_capacity, taps, cout, cin, p)) return rc;
@@ -433,6 +433,8 @@ int pn_sparse_conv_wgrad_f32(const float* in, int cin, int cin_real, const float
   if (workspace_bytes < pn_sparse_conv_wgrad_workspace_bytes(out_capacity, taps, cout, cin)) return pn::fail(PN_ERR_WORKSPACE, "sparse_conv_wgrad: workspace too small");
   const unsigned long long dy_bytes = (unsigned long long)out_capacity * cout * 4ull;
   PN_REQUIRE(dy_bytes < (1ull << 31), "sparse_conv_wgrad: gradient matrix larger than 2 GiB");
+  // the loader forms 32-bit byte offsets idx * cin * 4 into `in`: a feature matrix of 2 GiB or more would wrap / fall outside the descriptor
+  PN_REQUIRE(in_rows > 0 && (unsigned long long)in_rows * cin * 4ull < (1ull << 31), "sparse_conv_wgrad: feature matrix (in_rows x cin) must be under 2 GiB");
   WgradArgs a{};
   a.in = in; a.dy = dout; a.part = static_cast<float*>(workspace);
   a.B = 1; a.H = out_capacity; a.W = 1; a.Cin = cin; a.Cout = cout; a.OH = out_capacity; a.OW = 1;
@@ -440,7 +442,7 @@ int pn_sparse_conv_wgrad_f32(const float* in, int cin, int cin_real, const float
   a.in_ps = cin; a.in_co = 0; a.dy_ps = cout; a.dy_co = 0;
   a.M = out_capacity; a.m_per_split = p.m_per_split; a.ci_tiles = p.ci_tiles; a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;
   a.co_tiles = p.co_tiles; a.tiles_per_split = p.taps * p.ci_tiles * p.co_tiles; a.splits = p.splits;
-  a.in_bytes = 0x7fffffffu;   // the gathered rows are range-checked through the neighbour table, not the descriptor
+  a.in_bytes = (unsigned)((unsigned long long)in_rows * cin * 4ull);   // rows past the matrix read as zero (hardware bounds check)
   a.dy_bytes = (unsigned)dy_bytes;
   a.div_ohw = make_fastdiv((unsigned)out_capacity); a.div_ow = make_fastdiv(1u);
   a.nbr = nbr; a.n_valid = n_out;

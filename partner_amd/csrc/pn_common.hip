@@ -94,6 +94,13 @@ extern "C" int pn_handle_info(pn_handle_t h, int* device, int* compute_units, in
   return PN_OK;
 }
 
+extern "C" int pn_handle_pci_bus_id(pn_handle_t h, char* buf, size_t buf_len) {
+  PN_REQUIRE(h != nullptr && buf && buf_len >= 13, "handle_pci_bus_id: null handle or a buffer under 13 bytes");
+  hipError_t rc = hipDeviceGetPCIBusId(buf, (int)buf_len, h->device);
+  if (rc != hipSuccess) return pn::fail(PN_ERR_LAUNCH, "hipDeviceGetPCIBusId: %s", hipGetErrorString(rc));
+  return PN_OK;
+}
+
 namespace {
 
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int c, int hw, float* __restrict__ out, size_t total) {

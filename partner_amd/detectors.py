@@ -233,9 +233,10 @@ class PolarStream(PointPillars):
         nxt = []
         if hasattr(self.neck, "_pad_feature_only") or not hasattr(self.neck, "forward_nhwc"):
             raise NotImplementedError("PolarStream drives the trailing-edge neck (RPNTECP) or the plain RPN; RPNBDCP is driven by PolarStreamBDCP's two-sweep loop")
-        try:
+        from .necks_context import RPNTECP
+        if isinstance(self.neck, RPNTECP):      # the trailing-edge neck takes (and returns) the context rows
             x2, nxt = self.neck.forward_nhwc(canvas, kwargs.get("prev_context", []), kwargs.get("sec_id", 0))
-        except TypeError:
+        else:                                   # plain RPN: no context, its own signature (return_blocks, pillars)
             x2 = self.neck.forward_nhwc(canvas)
         preds = self.bbox_head(ops.as_nchw(x2))
         ret = {}

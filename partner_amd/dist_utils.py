@@ -18,14 +18,18 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend: str, device: Optional[torch.device] = None) -> bool:
-    """initialise the default process group from the torchrun environment; False when world size is 1"""
+def init(backend: str, device: Optional[torch.device] = None, timeout_s: Optional[float] = None) -> bool:
+    """initialise the default process group from the torchrun environment; False when world size is 1.
+    ``timeout_s`` bounds every collective wait (a rank that faults leaves the others with an error, not a hang)."""
     _, _, world = env_rank_world()
     if world <= 1:
         return False
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     kw = {}
+    if timeout_s is not None:
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
     if backend == "nccl" and device is not None:
         kw["device_id"] = device
     dist.init_process_group(backend, **kw)

@@ -160,7 +160,7 @@ SIGNATURES = {
     "pn_assemble_rows_f32": (_I, [C.POINTER(RowPiece), _I, _I, _I, _I, _P, _I, _I, _P]),
     "pn_sparse_neighbors_transpose": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "pn_sparse_conv_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
-    "pn_sparse_conv_wgrad_f32": (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P, _SZ, _P]),
+    "pn_sparse_conv_wgrad_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P, _SZ, _P]),
     "pn_sparse_from_dense_nhwc": (_I, [_P, _P, _I, _P, _P, _I, _P, _P]),
     "pn_add_relu_f32": (_I, [_P, _P, _P, _SZ, _P]),
     "pn_pad_roll_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
@@ -172,6 +172,7 @@ SIGNATURES = {
     "pn_handle_create": (_I, [_I, _P]),
     "pn_handle_destroy": (_I, [_P]),
     "pn_handle_info": (_I, [_P, _P, _P, _P, _P, _P, _SZ]),
+    "pn_handle_pci_bus_id": (_I, [_P, _P, _SZ]),
     "pn_conv_wino_packed_weight_floats": (_SZ, [_I, _I]),
     "pn_pack_conv_weight_wino_f32": (_I, [_P, _I, _I, _P, _P]),
     "pn_conv2d_wino_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P]),
@@ -285,7 +286,10 @@ def device_info(device: int = 0) -> dict:
         hbm = C.c_ulonglong()
         arch = C.create_string_buffer(64)
         call("pn_handle_info", h, C.byref(dev), C.byref(cus), C.byref(lds), C.byref(hbm), arch, 64)
-        return dict(device=dev.value, arch=arch.value.decode(), compute_units=cus.value, lds_bytes_per_cu=lds.value, hbm_bytes=hbm.value)
+        bus = C.create_string_buffer(32)
+        call("pn_handle_pci_bus_id", h, bus, 32)
+        return dict(device=dev.value, arch=arch.value.decode(), compute_units=cus.value, lds_bytes_per_cu=lds.value, hbm_bytes=hbm.value,
+                    pci_bus_id=bus.value.decode())
     finally:
         load().pn_handle_destroy(h)
 

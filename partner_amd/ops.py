@@ -321,26 +321,36 @@ class ConvProfiler:
         hip.call("pn_profile_next_launch", a, b)
         return (a, b)
 
-    def end(self, evs, flops, stream, tag=None):
-        self.pairs.append((evs[0], evs[1], flops, tag))
+    def end(self, evs, flops, stream, tag=None, issued=None, dense=None):
+        """flops: what the launch is billed (dense-convolution count; the sparse first layer: the pairs it multiplies);
+        issued: FLOPs that reach the MFMA (default: by the Winograd form named in the tag); dense: the direct dense algorithm's
+        count (default = flops)"""
+        if issued is None:
+            issued = flops * (2.0 / 3.0 if tag and "F(2,3)" in tag else 0.5 if tag and "F(4,3)" in tag else 1.0)
+        self.pairs.append((evs[0], evs[1], flops, tag, issued, flops if dense is None else dense))
 
-    def collect(self, by_tag=False):
-        """-> (total algorithmic FLOPs, total milliseconds, launches[, {tag: (flops, ms, launches)}]); synchronises"""
+    def collect(self, by_tag=False, full=False):
+        """-> (total billed FLOPs, total milliseconds, launches[, {tag: (flops, ms, launches)}]); synchronises.
+        full=True: the per-tag tuples are (flops, ms, launches, issued FLOPs, dense-algorithm FLOPs)"""
         flops, ms = 0.0, 0.0
         tags = {}
         out = C.c_float()
-        for a, b, f, tag in self.pairs:
+        for a, b, f, tag, iss, den in self.pairs:
             hip.call("pn_event_elapsed_ms", a, b, C.byref(out))
             ms += out.value
             flops += f
-            t = tags.setdefault(tag, [0.0, 0.0, 0])
+            t = tags.setdefault(tag, [0.0, 0.0, 0, 0.0, 0.0])
             t[0] += f
             t[1] += out.value
             t[2] += 1
+            t[3] += iss
+            t[4] += den
             self.free += [a, b]
         n = len(self.pairs)
         self.pairs = []
-        return (flops, ms, n, {k: tuple(v) for k, v in tags.items()}) if by_tag else (flops, ms, n)
+        if not by_tag:
+            return (flops, ms, n)
+        return (flops, ms, n, {k: (tuple(v) if full else tuple(v[:3])) for k, v in tags.items()})
 
 
 _PROFILER: Optional[ConvProfiler] = None
@@ -597,7 +607,8 @@ class PillarConvLayer:
             # FLOPs actually multiplied: the (pillar, tap) pairs of THIS frame (the nine counters head the workspace; reading them
             # synchronises -- profiling runs only); the events bracket the pair, GEMM and reduce kernels
             pairs = int(ws[:36].view(torch.int32).sum().item())
-            prof.end(ev, 2.0 * pairs * self.cout * self.cin, st, tag=f"{oh}x{ow} {self.cin}->{self.cout} k3 pillars")
+            prof.end(ev, 2.0 * pairs * self.cout * self.cin, st, tag=f"{oh}x{ow} {self.cin}->{self.cout} k3 pillars",
+                     dense=2.0 * b * oh * ow * 9 * self.cout * self.cin)
         return out
 
     # ---- training: pair tables built once per iteration, shared by forward, data gradient and weight gradient
@@ -847,8 +858,14 @@ class GemmLayer:
         assert x.dim() == 2 and x.is_contiguous() and x.shape[1] == self.k
         m = x.shape[0]
         out = torch.empty((m, self.n), dtype=torch.float32, device=x.device)
+        st = hip.stream()
+        prof = _PROFILER
+        if prof is not None:
+            ev = prof.begin(st)
         hip.call("pn_gemm_bias_act_f32", x.data_ptr(), m, self.k, self.k, self.packed.data_ptr(), self.n, hip.ptr(self.bias),
-                 int(act), hip.ptr(residual), self.n, out.data_ptr(), self.n, hip.stream())
+                 int(act), hip.ptr(residual), self.n, out.data_ptr(), self.n, st)
+        if prof is not None:
+            prof.end(ev, 2.0 * m * self.n * self.k, st, tag=f"gemm {m}x{self.k}->{self.n}")
         return out
 
 

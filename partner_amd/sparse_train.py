@@ -71,7 +71,7 @@ def sparse_conv(t: ad.Tape, x: ad.Node, w: ad.Node, bias: Optional[ad.Node], nbr
         dw = torch.empty_like(wv)
         nbytes = lib.pn_sparse_conv_wgrad_workspace_bytes(n_out, taps, cout, rows_c)
         ws = ops._workspace(nbytes, dy.device)
-        hip.call("pn_sparse_conv_wgrad_f32", x.v.data_ptr(), rows_c, cin, dy.data_ptr(), cout, nbr.data_ptr(), count_out.data_ptr(), n_out, taps,
+        hip.call("pn_sparse_conv_wgrad_f32", x.v.data_ptr(), n_in, rows_c, cin, dy.data_ptr(), cout, nbr.data_ptr(), count_out.data_ptr(), n_out, taps,
                  dw.data_ptr(), 0, ws.data_ptr(), nbytes, hip.stream())
         ad.accumulate(w, dw, own=True)
         if bias is not None:

@@ -84,6 +84,52 @@ class ParamStore:
             self.g[name] = self.flat_g[o:o + p.numel()].view(shape)
 
 
+def invalidate_inference_plans(model: nn.Module) -> None:
+    """the kernels update the parameters behind PyTorch's version counters: drop the packed-weight plans of the
+    inference path (f32 and bf16) so that the next eval forward re-packs from the trained weights"""
+    for m in model.modules():
+        for attr in ("_plan", "_plan_bf16"):
+            pc = getattr(m, attr, None)
+            if pc is not None and hasattr(pc, "plan"):
+                pc.plan = None
+
+
+def optimizer_state(ps: ParamStore, it: int, sched: dict) -> Dict[str, object]:
+    """Adam moments of the flat buffer + where every parameter lives in it (names, offsets, sizes): a checkpoint is independent
+    of the ORDER of the buffer (the reference keeps optimizer state per parameter, det3d/torchie/trainer/trainer.py:342-372)"""
+    return dict(iter=it, exp_avg=ps.flat_m.clone(), exp_avg_sq=ps.flat_v.clone(), names=list(ps.names),
+                offsets=[int(ps.offsets[n][0]) for n in ps.names], numels=[int(ps.offsets[n][1].numel()) for n in ps.names],
+                schedule=dict(sched))
+
+
+def load_optimizer_state(ps: ParamStore, state: Dict[str, object]) -> int:
+    """restore the moments BY NAME: a checkpoint written with another layout of the flat buffer (e.g. before the buffer was
+    ordered by backward completion) loads as long as it holds the same parameters; returns the iteration count"""
+    names = list(state["names"])
+    if sorted(names) != sorted(ps.names):
+        raise ValueError("optimizer state belongs to a model with different parameters")
+    if names == list(ps.names) and state["exp_avg"].numel() == ps.total and "offsets" not in state:
+        ps.flat_m.copy_(state["exp_avg"])       # same order, legacy checkpoint without the offset table
+        ps.flat_v.copy_(state["exp_avg_sq"])
+        return int(state["iter"])
+    if "offsets" in state:
+        offs, nums = list(state["offsets"]), list(state["numels"])
+    else:   # legacy checkpoint (names only): parameters were laid out in the saved order, each on a 4-float boundary
+        nums = [int(ps.offsets[n][1].numel()) for n in names]
+        offs, o = [], 0
+        for k in nums:
+            offs.append(o)
+            o += (k + 3) // 4 * 4
+    m_src, v_src = state["exp_avg"], state["exp_avg_sq"]
+    for n, o, k in zip(names, offs, nums):
+        dst, shape = ps.offsets[n]
+        if shape.numel() != k:
+            raise ValueError(f"optimizer state: parameter {n} has {k} elements in the checkpoint, {shape.numel()} in the model")
+        ps.flat_m[dst:dst + k].copy_(m_src[o:o + k])
+        ps.flat_v[dst:dst + k].copy_(v_src[o:o + k])
+    return int(state["iter"])
+
+
 import os as _os
 # F(4, 3) in the training FORWARD only on maps of at most this many pixels (the 128 x 128 and 64 x 64 layers): with it on the 256 x 256
 # layers too the full-size gradient test misses its 2e-2 bound on the 95th percentile (2.2e-2: the forward's rounding is amplified
@@ -596,32 +642,22 @@ class PolarPillarTrainStep:
     # ---- checkpoint / resume (the reference saves model + optimizer state per epoch, det3d/torchie/trainer/trainer.py:342-372)
     def state_dict(self) -> Dict[str, object]:
         """optimizer-side state; the parameters themselves are in ``model.state_dict()`` (views of the flat buffer)"""
-        return dict(iter=self.iter, exp_avg=self.ps.flat_m.clone(), exp_avg_sq=self.ps.flat_v.clone(), names=list(self.ps.names),
-                    schedule=dict(self.sched))
+        return optimizer_state(self.ps, self.iter, self.sched)
 
     def load_state_dict(self, state: Dict[str, object]) -> None:
-        if list(state["names"]) != list(self.ps.names):
-            raise ValueError("optimizer state belongs to a model with different parameters")
-        self.iter = int(state["iter"])
-        self.ps.flat_m.copy_(state["exp_avg"])
-        self.ps.flat_v.copy_(state["exp_avg_sq"])
+        self.iter = load_optimizer_state(self.ps, state)
         self.sched.update(state.get("schedule", {}))
         self.invalidate_inference_plans()
 
     def invalidate_inference_plans(self):
-        """the kernels update the parameters behind PyTorch's version counters: drop the packed-weight plans of the
-        inference path so that the next eval forward re-packs from the trained weights"""
-        for m in self.model.modules():
-            for attr in ("_plan", "_plan_bf16"):
-                pc = getattr(m, attr, None)
-                if pc is not None and hasattr(pc, "plan"):
-                    pc.plan = None
+        invalidate_inference_plans(self.model)
 
     def step(self, points, sample_offsets, batch, targets: ops.CenterLossTargets, grid_ind=None):
         import torch.distributed as dist
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         from .dist_utils import GradExchange
-        self._exchange = GradExchange(self.ps.flat_g, self.buckets) if world > 1 else None
+        # exchange_enabled = False: a timing-only mode of bench.py (the same iteration without the collectives; ranks then diverge)
+        self._exchange = GradExchange(self.ps.flat_g, self.buckets) if world > 1 and getattr(self, "exchange_enabled", True) else None
         # the reference averages the gradients over ranks (dist_utils.py:17-28): fold 1/world into the loss gradient
         try:
             loss = self.forward_backward(points, sample_offsets, batch, targets, grid_ind, grad_scale=1.0 / world)

@@ -24,7 +24,7 @@ from . import hip, ops
 from .attention_train import set_block_train
 from .sparse_train import sp_middle_resnet_fhd_train
 from .swv_head_train import e2e_swv_head_train
-from .train import ParamStore, one_cycle
+from .train import ParamStore, invalidate_inference_plans, one_cycle
 
 
 def rpn_train(t: ad.Tape, neck: nn.Module, x: ad.Node, prefix="neck.") -> ad.Node:
@@ -138,10 +138,7 @@ class PartnerTrainStep:
         ops.adam_step(self.ps.flat_p, self.ps.flat_g, self.ps.flat_m, self.ps.flat_v, self.iter + 1, lr, beta1, self.beta2, self.eps, self.wd,
                       total_norm=total_norm, max_norm=self.max_norm)
         self.iter += 1
-        for mod in self.model.modules():   # the kernels updated the parameters behind the inference plans' packed copies
-            pc = getattr(mod, "_plan", None)
-            if pc is not None and hasattr(pc, "plan"):
-                pc.plan = None
+        invalidate_inference_plans(self.model)   # the kernels updated the parameters behind the plans' packed copies (f32 and bf16)
         return total_norm
 
     def sync_initial_params(self):

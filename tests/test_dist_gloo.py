@@ -112,6 +112,48 @@ def test_bench_bare_launch_starts_one_rank_per_gpu():
     assert len(lines) == 1, res.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 5 and line["data"] == "dry-run"
+    # the line verifies itself: the world size every rank saw after the rendezvous, one row per rank (distinct processes),
+    # and the two timings the exposed gradient exchange is the difference of
+    assert line["ranks_seen"] == 2 and [r["rank"] for r in line["ranks"]] == [0, 1]
+    assert all(r["world_size_seen"] == 2 for r in line["ranks"]) and len({r["pid"] for r in line["ranks"]}) == 2
+    assert {"device", "pci_bus_id", "host"} <= set(line["ranks"][0])
+    tr = line["train_step"]
+    assert tr["ms_per_iter_no_exchange"] is not None and abs(tr["exposed_exchange_ms"] - (tr["ms_per_iter"] - tr["ms_per_iter_no_exchange"])) < 1e-6
+
+
+def test_collective_wait_is_bounded():
+    """a rank that never arrives costs the others `timeout_s`, not a hang: rank 1 skips the barrier, rank 0's wait ends in an error"""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    code = textwrap.dedent("""
+        import os, sys, time
+        sys.path.insert(0, %r)
+        from partner_amd import dist_utils as D
+        import torch.distributed as dist
+        D.init("gloo", None, timeout_s=3.0)
+        D.barrier()
+        if int(os.environ["RANK"]) == 1:
+            time.sleep(8.0)          # the faulting rank: alive, but never enters the second barrier
+            os._exit(0)
+        t0 = time.time()
+        try:
+            D.barrier()
+        except Exception as e:
+            print("bounded", round(time.time() - t0, 1), flush=True)
+            os._exit(0)
+        print("barrier returned", flush=True)
+        os._exit(1)
+    """ % root)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    out0, err0 = procs[0].communicate(timeout=120)
+    procs[1].communicate(timeout=120)
+    assert procs[0].returncode == 0 and "bounded" in out0, (out0, err0[-1500:])
 
 
 def test_bench_without_gpu_fails_loudly_not_silently():

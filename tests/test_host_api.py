@@ -190,6 +190,33 @@ def test_param_store_layout_and_schedule():
         assert np.allclose(one_cycle(step, 100, 0.005, (0.95, 0.85), 10.0, 0.4), O.one_cycle(step, 100, 0.005, [0.95, 0.85], 10.0, 0.4), rtol=0, atol=1e-15)
 
 
+def test_optimizer_state_loads_across_flat_buffer_orders():
+    """the Adam moments are restored BY NAME, so a checkpoint written with another order of the flat buffer (or the
+    older names-only format) resumes; a checkpoint of a different model still fails loudly"""
+    from partner_amd.train import ParamStore, load_optimizer_state, optimizer_state
+    torch.manual_seed(0)
+    mk = lambda: torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3, bias=False), torch.nn.BatchNorm2d(5), torch.nn.Conv2d(5, 2, 1))   # noqa: E731
+    a = ParamStore(mk(), torch.device("cpu"))                                             # module order
+    b = ParamStore(mk(), torch.device("cpu"), order_key=lambda n: -len(n))                # another order of the same parameters
+    assert a.names != b.names and sorted(a.names) == sorted(b.names)
+    a.flat_m.copy_(torch.arange(a.total, dtype=torch.float32))
+    a.flat_v.copy_(torch.arange(a.total, dtype=torch.float32) * 2)
+    st = optimizer_state(a, 7, dict(total=100))
+    assert load_optimizer_state(b, st) == 7
+    for n in a.names:
+        (oa, sh), (ob, _) = a.offsets[n], b.offsets[n]
+        k = sh.numel()
+        assert torch.equal(a.flat_m[oa:oa + k], b.flat_m[ob:ob + k]) and torch.equal(a.flat_v[oa:oa + k], b.flat_v[ob:ob + k]), n
+    # the older format: names only, parameters in that order
+    legacy = {k: v for k, v in st.items() if k not in ("offsets", "numels")}
+    c = ParamStore(mk(), torch.device("cpu"), order_key=lambda n: -len(n))
+    load_optimizer_state(c, legacy)
+    assert torch.equal(c.flat_m, b.flat_m) and torch.equal(c.flat_v, b.flat_v)
+    other = ParamStore(torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3)), torch.device("cpu"))
+    with pytest.raises(ValueError):
+        load_optimizer_state(other, st)
+
+
 def test_sparse_first_convolution_policy():
     """host-side policy of the (pillar, tap) convolution (ops.PillarConvLayer): which first layers qualify, and when the pillar capacity makes
     the pair count small enough against the dense (output, tap) pairs -- no device needed"""
