@@ -447,6 +447,23 @@ int pn_gemm_bias_act_f32(const float *x, int m, int k, int ldx, const float *pac
                          int ldo, pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * The token GEMM of r3 (csrc/linear.hip): the same contract as pn_gemm_bias_act_f32 on a kernel built for the token matrices of
+ * the attention block and the geometry-aware head (K = 256..1024, 1k..74k rows): persistent XCD-local tiles, the weight operand
+ * straight from L2 in MFMA fragment layout, tile shape picked per problem, a K-split form for the 1k-row key-point chains.
+ * Replaces nn.Linear of SetBlock / SetAttention / Mlp  det3d/models/utils/set_transformer.py:37-53,118-166,216-259 and of the Swin
+ * stage  det3d/models/bbox_heads/swin_utils/sw2votev4_util.py (qkv / proj / Mlp / PatchEmbed.proj).
+ *   packed_w: pn_pack_linear_weight_f32 of the (n, k) torch weight -> [ceil(k/32)*8][ceil(n/128)*128][4] floats, zero padded
+ *   n, ldo, ldr multiples of 4; x / out / residual / bias 16-byte aligned; act: PN_ACT_NONE | RELU | GELU (exact erf)
+ */
+size_t pn_linear_packed_weight_floats(int n, int k);
+int pn_pack_linear_weight_f32(const float *w_nk, int n, int k, float *packed, pn_stream_t stream);
+int pn_linear_f32(const float *x, int m, int k, int ldx, const float *packed_w, int n, const float *bias, int act,
+                  const float *residual, int ldr, float *out, int ldo, pn_stream_t stream);
+/* tuning hook (tools/linear_bench.py): pins the tile form of every following pn_linear_f32 of the process -- 22 / 21 / 12 / 11 =
+ * (64 TM) x (64 TN) block tiles, 1 = the K-split form, 0 = automatic (default; also PN_LINEAR_TILE in the environment) */
+int pn_linear_set_tile(int form);
+
+/* ---------------------------------------------------------------------------------------
  * A1  global representation re-alignment (SetBlock / SetAttention), non-GEMM parts.
  * Tokens are (B, H, W, C) fp32 in physical column order; `shift` (0 or win_w/2) is the azimuth
  * roll of the odd blocks, applied as an index mapping.  pos: (H, W, 2) Cartesian cell centres
@@ -1035,7 +1052,7 @@ int pn_event_destroy(pn_event_t ev);
 int pn_event_record(pn_event_t ev, pn_stream_t stream);
 int pn_event_elapsed_ms(pn_event_t start, pn_event_t stop, float *ms); /* synchronises on stop */
 /* Arms the calling host thread: the NEXT convolution / GEMM launch of this thread (pn_conv2d_nhwc_f32,
- * pn_conv2d_nhwc_bf16, pn_conv2d_multi_f32, pn_gemm_bias_act_f32, pn_sparse_conv_f32) attaches `start` / `stop` to the
+ * pn_conv2d_nhwc_bf16, pn_conv2d_multi_f32, pn_gemm_bias_act_f32, pn_linear_f32, pn_sparse_conv_f32) attaches `start` / `stop` to the
  * kernel dispatch itself (hipExtLaunchKernelGGL), so that pn_event_elapsed_ms(start, stop) is that kernel's execution
  * time -- what a rocprofv3 kernel trace reports -- without the launch gaps a pair of hipEventRecord calls around an eager
  * launch includes.  One shot; not usable while the stream is being captured into a hipGraph. */

@@ -1,0 +1,531 @@
+// Token GEMMs (nn.Linear) of PARTNER's re-alignment attention and geometry-aware head on the gfx950 fp32 matrix pipe:
+//   out[m][:N] = act(x[m][:K] @ W^T + bias) (+ residual[m][:N])
+// Replaces every nn.Linear of SetBlock / SetAttention / Mlp (det3d/models/utils/set_transformer.py:37-53, 118-166, 216-259) and of
+// the Swin stage of E2ESWVoteHead (det3d/models/bbox_heads/swin_utils/sw2votev4_util.py: qkv / proj / Mlp / PatchEmbed).
+//
+// Why not the convolution kernel (r2 ran these as 1x1 convolutions): the token matrices are [36 864 B x 256..1024] with K = 256 for
+// most of the work, i.e. a 128 x 128 tile has only EIGHT K steps, and the 9.2 k .. 73 k rows meet 512 block slots in awkward
+// ratios (576 tiles on 512 slots = two rounds, the second 12 % full).  This kernel is built for that regime:
+//   * persistent blocks, XCD-local tile runs (N fastest: an M tile's x rows are fetched from HBM once per XCD, the <= 1 MB of
+//     weights stay in every L2), and a tile shape picked per problem so that the last round is not mostly empty;
+//   * the next tile's first two K steps of x are requested BEFORE the current tile's epilogue, which hides both the global
+//     latency of the prologue and the store tail of the epilogue behind each other;
+//   * the weight operand never touches LDS: the packed layout [K/4][Npad][4] IS the MFMA B-fragment layout, every lane fetches
+//     its own 16 bytes from L2 one sub-step ahead; only x goes through LDS (register staged, [BM][32 + 4], double buffered);
+//   * epilogue: accumulators -> wave-private LDS transpose -> 16-byte rows: bias, exact-erf GELU, residual and the store are
+//     all float4 wide.
+// Block = 4 waves as 2 x 2, wave tile (32 TM) x (32 TN), v_mfma_f32_32x32x2_f32: bit-exact fp32 FMA chains; k order inside a
+// group of 8: MFMA j takes k = 8s + j from lane half 0 and k = 8s + 4 + j from lane half 1, for x and W alike.
+#include "pn_common.h"
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int LK = 32;       // K step
+constexpr int LA_LD = 36;    // floats per x row in LDS: 32 + 4 (conflict-free ds_read_b128 over 16 rows)
+constexpr int LNPAD = 128;   // packed columns are padded to this
+
+struct LinArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  const float* res;
+  float* out;
+  int M, K, N, ldx, ldr, ldo, act;
+  int npad, nsteps;
+  int mtiles, ntiles;      // small-M form only
+  int M1;                  // rows of the first phase
+  unsigned x_bytes, w_bytes, r_bytes, o_bytes;
+#ifdef PN_LINEAR_STAMP
+  unsigned long long* stamps;   // diagnostic build only (tools/micro/linear_stamps.hip): [block][tile < 4][8] shader-clock stamps of wave 0
+#endif
+};
+
+#ifdef PN_LINEAR_STAMP
+#define LIN_STAMP(k)                                                                                              \
+  do {                                                                                                            \
+    if (tid == 0 && tcount < 4) a.stamps[((size_t)blockIdx.x * 4 + tcount) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define LIN_STAMP(k) do { } while (0)
+#endif
+
+// exact-erf GELU, 0.5 x (1 + erf(x / sqrt 2)), in ~20 VALU instructions (the library erff is ~2x that, and on this chip VALU work is
+// NOT hidden behind another wave's fp32 MFMAs: v_mfma_f32_32x32x2_f32 occupies the SIMD's fp32 lanes -- tools/micro/mfma_valu_coexec.hip
+// measures the two as strictly additive -- so an epilogue instruction costs its full issue time).  erfc(z) = t exp(-z^2 + P(t)),
+// t = 1 / (1 + z / 2), Chebyshev fit with fractional error < 1.2e-7 for all z >= 0 (Numerical Recipes, erfcc); 1 + erf(x / sqrt 2) is
+// 2 - erfc for x >= 0 and erfc(|x| / sqrt 2) for x < 0, so nothing cancels: |gelu - exact| < 3e-7 max(|x|, 1).
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.5f, z, 1.f));
+  float p = fmaf(t, 0.17087277f, -0.82215223f);
+  p = fmaf(t, p, 1.48851587f);
+  p = fmaf(t, p, -1.13520398f);
+  p = fmaf(t, p, 0.27886807f);
+  p = fmaf(t, p, -0.18628806f);
+  p = fmaf(t, p, 0.09678418f);
+  p = fmaf(t, p, 0.37409196f);
+  p = fmaf(t, p, 1.00002368f);
+  p = fmaf(t, p, -1.26551223f);
+  const float e = t * __builtin_amdgcn_exp2f(fmaf(-z, z, p) * 1.44269504088896341f);
+  return 0.5f * x * (x >= 0.f ? 2.f - e : e);
+}
+
+// One PHASE of a launch: the rows [row_lo, row_hi) of the output in (64 TM) x (64 TN) tiles, persistent blocks, XCD-local tile runs.
+template <int TM, int TN, bool GELU>
+__device__ __forceinline__ void linear_phase(const LinArgs& a, const int row_lo, const int row_hi, float* smem) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int STAGE = BM * LA_LD;
+  constexpr int APT = BM * 8 / 256;          // 16-byte chunks of x per thread and K step
+  constexpr int TC = TN * 32, TLD = TC + 4;  // epilogue: one 32-row slab of the wave tile, row stride in floats
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv >> 1, wn = wv & 1, li = lane & 31, lh = lane >> 5;
+
+  // persistent blocks; XCD x owns a contiguous run of M tiles and walks it N-fastest
+  const int mtiles = (row_hi - row_lo + BM - 1) / BM, ntiles = (a.N + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int mq = mtiles >> 3, mr = mtiles & 7;
+  const int mt0 = xcd < mr ? xcd * (mq + 1) : mr * (mq + 1) + (xcd - mr) * mq;
+  const int xtiles = (xcd < mr ? mq + 1 : mq) * ntiles;
+
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const unsigned np16 = (unsigned)a.npad * 16u;
+  const int c4 = tid & 7, r0 = tid >> 3;       // loader: thread -> (row r0 + 32 j, 16-byte chunk c4)
+
+  unsigned x_off[APT];     // byte offset of (row, chunk) or 0xffffffff past M
+  unsigned b_off;          // byte offset of this lane's B fragment column block (sub-step 0 of K step 0)
+  int m0 = 0, n0 = 0;
+  auto setup = [&](int tl) {
+    const int mt = mt0 + tl / ntiles;
+    m0 = row_lo + mt * BM;
+    n0 = (tl - (tl / ntiles) * ntiles) * BN;
+#pragma unroll
+    for (int j = 0; j < APT; ++j) {
+      const int row = m0 + r0 + 32 * j;
+      x_off[j] = row < row_hi ? (unsigned)row * (unsigned)a.ldx * 4u + (unsigned)c4 * 16u : 0xffffffffu;
+    }
+    b_off = (unsigned)(lh * a.npad + n0 + wn * TC + li) * 16u;
+  };
+
+  f32x4 ra[2][APT];
+  auto load_x = [&](int step, f32x4 (&r)[APT]) {
+    const bool live = step < a.nsteps && step * LK + c4 * 4 < a.K;
+    const unsigned so = (unsigned)step * LK * 4u;
+#pragma unroll
+    for (int j = 0; j < APT; ++j) r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, live ? x_off[j] : 0xffffffffu, so, 0));
+  };
+  auto store_x = [&](int buf, const f32x4 (&r)[APT]) {
+    float* As = smem + buf * STAGE + r0 * LA_LD + c4 * 4;
+#pragma unroll
+    for (int j = 0; j < APT; ++j) *reinterpret_cast<f32x4*>(As + 32 * j * LA_LD) = r[j];
+  };
+  // Operand fragments.  x: from LDS, one sub-step ahead.  W: straight from L2, a whole K STEP ahead (two sets of 4 sub-steps x TN
+  // fragments, alternating by K step): the vector-memory counter returns in issue order, so a fragment requested AFTER the x loads of
+  // step t+3 could not be used before those (HBM-latency) loads have landed -- the fragments of step t+1 are therefore requested in
+  // sub-steps 0 / 1 of step t, BEFORE that step's x loads (sub-step 2), and what a wait on them drains is older than a K step.
+  f32x4 af[2][TM], bf[2][4][TN];
+  const int a_frag = (wm * TM * 32 + li) * LA_LD + lh * 4;
+  auto read_a = [&](int buf, int s, f32x4 (&f)[TM]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) f[i] = *reinterpret_cast<const f32x4*>(smem + buf * STAGE + a_frag + i * 32 * LA_LD + s * 8);
+  };
+  auto load_b = [&](int step, int s, f32x4 (&f)[TN]) {      // sub-step s of K step `step` (past the end: zeros)
+    const unsigned vo = step < a.nsteps ? b_off : 0xffffffffu;
+    const unsigned so = (unsigned)(step * 8 + 2 * s) * np16;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) f[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vo, so + (unsigned)j * 512u, 0));
+  };
+  f32x16 acc[TM][TN];
+  auto mfma = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+  };
+  constexpr int NM = 4 * TM * TN;   // MFMAs per sub-step
+  // one K step (compile-time parity P: LDS stage and W fragment set): x of step t+1 (registers rx) goes to the other stage under
+  // sub-step 1, x of step t+3 is requested under sub-step 2, the barrier sits before sub-step 3
+  auto kstep = [&](auto par_c, int t, f32x4 (&rx)[APT]) __attribute__((always_inline)) {
+    constexpr int P = decltype(par_c)::value;
+    load_b(t + 1, 0, bf[P ^ 1][0]);
+    load_b(t + 1, 1, bf[P ^ 1][1]);
+    read_a(P, 1, af[1]);
+    mfma(af[0], bf[P][0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+    for (int k = 0; k < 2 * TN; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(t + 1, 2, bf[P ^ 1][2]);
+    load_b(t + 1, 3, bf[P ^ 1][3]);
+    read_a(P, 2, af[0]);
+    mfma(af[1], bf[P][1]);
+    store_x(P ^ 1, rx);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM, 1);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+#pragma unroll
+    for (int k = 0; k < 2 * TN; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+    }
+#pragma unroll
+    for (int k = 0; k < APT; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, (NM - 1 - 2 * TN) / APT > 0 ? (NM - 1 - 2 * TN) / APT : 1, 1);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(P, 3, af[1]);
+    mfma(af[0], bf[P][2]);
+    load_x(t + 3, rx);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM, 2);
+#pragma unroll
+    for (int k = 0; k < APT; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, NM / APT > 0 ? NM / APT : 1, 2);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 2);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    read_a(P ^ 1, 0, af[0]);
+    mfma(af[1], bf[P][3]);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM, 3);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 3);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // epilogue of the tile at (em0, en0): 32-row slabs through this wave's private LDS region, then float4 rows.  The vector-memory
+  // counter is shared by loads and stores and returns in order: a residual load issued after a store would have to wait for that
+  // store's acknowledgement, so the residual of pass p+1 is requested BEFORE the store of pass p, and the bias (one float4 per lane
+  // and tile: the lane's column group is the same in every pass) comes in with the tile's setup.  Everything is an unconditional
+  // buffer access (rows past M / columns past N: offset 0xffffffff = dropped store, zero load): a load or store under a branch
+  // makes the compiler fall back to s_waitcnt vmcnt(0) -- i.e. to one store round trip per pass (measured: 21 k cycles per tile).
+  const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res), 0, a.res ? a.r_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.o_bytes, 0x00020000);
+  auto epilogue = [&](int em0, int en0, f32x4 bias4) {
+    float* slab = smem + wv * (32 * TLD);
+    constexpr int TC4 = TC / 4, NP = 32 * TC4 / 64, RPP = 64 / TC4;     // float4 per row, passes per slab, rows per pass
+    const int q = lane % TC4, rrow = lane / TC4;
+    const int n = en0 + wn * TC + q * 4;
+    const bool nok = n < a.N;
+    const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + j * 32 + li] = acc[i][j][r];
+      const int mb = em0 + wm * TM * 32 + i * 32 + rrow;
+      // (no short-circuit: a && here becomes a divergent branch around the access)
+      auto roff = [&](int p) { const bool ok = nok & (mb + p * RPP < row_hi); return ok ? ((unsigned)(mb + p * RPP) * (unsigned)a.ldr + (unsigned)n) * 4u : 0xffffffffu; };
+      auto ooff = [&](int p) { const bool ok = nok & (mb + p * RPP < row_hi); return ok ? ((unsigned)(mb + p * RPP) * (unsigned)a.ldo + (unsigned)n) * 4u : 0xffffffffu; };
+      f32x4 rcur = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, roff(0), 0, 0));
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        f32x4 rnext = {0.f, 0.f, 0.f, 0.f};
+        if (p + 1 < NP) rnext = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, roff(p + 1), 0, 0));
+        f32x4 v = *reinterpret_cast<const f32x4*>(slab + (p * RPP + rrow) * TLD + q * 4) + bias4;
+        if constexpr (GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
+        }
+        v += rcur;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsrc_o, ooff(p), 0, 0);
+        rcur = rnext;
+      }
+    }
+  };
+
+  int pm0 = -1, pn0 = 0;
+  f32x4 pbias = {0.f, 0.f, 0.f, 0.f};
+  int tcount = 0;
+  (void)tcount;
+  for (int tl = slot; tl < xtiles; tl += per_xcd, ++tcount) {
+    LIN_STAMP(0);
+    setup(tl);
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    {
+      const int n = n0 + wn * TC + (lane % (TC / 4)) * 4;
+      if (a.bias && n < a.N) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) load_b(0, s4, bf[0][s4]);
+    load_x(0, ra[0]);
+    load_x(1, ra[1]);
+    LIN_STAMP(1);
+    if (pm0 >= 0) {
+      epilogue(pm0, pn0, pbias);     // while this tile's first loads are in flight
+      LIN_STAMP(2);
+      __syncthreads();               // every wave's slab is read back before the stages are refilled
+    }
+    LIN_STAMP(3);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    store_x(0, ra[0]);
+    load_x(2, ra[0]);
+    __syncthreads();
+    LIN_STAMP(4);
+    read_a(0, 0, af[0]);
+    for (int t = 0; t < a.nsteps; t += 2) {
+      kstep(std::integral_constant<int, 0>{}, t, ra[1]);
+      if (t + 1 < a.nsteps) kstep(std::integral_constant<int, 1>{}, t + 1, ra[0]);
+    }
+    LIN_STAMP(5);
+    pm0 = m0;
+    pn0 = n0;
+    pbias = bias4;
+  }
+  if (pm0 >= 0) epilogue(pm0, pn0, pbias);
+}
+
+// A launch = the rows [0, M1) in (64 TM) x (64 TN) tiles -- a whole number of rounds of the persistent grid -- and, when the row count
+// does not divide that way, the REST [M1, M) in smaller (64 TM2) x (64 TN2) tiles, so that the last round is not a handful of big
+// tiles on an otherwise idle chip (73 728 x 256: 1152 big tiles on 512 slots were three rounds for 2.25 rounds of work).
+template <int TM, int TN, int TM2, int TN2, int OCC, bool GELU>
+__global__ __launch_bounds__(256, OCC) void linear_kernel(LinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  linear_phase<TM, TN, GELU>(a, 0, a.M1, smem);
+  if constexpr (TM2 > 0) {
+    if (a.M1 < a.M) {
+      __syncthreads();      // the first phase's last epilogue slabs are read back before the stages are refilled
+      linear_phase<TM2, TN2, GELU>(a, a.M1, a.M, smem);
+    }
+  }
+}
+
+// ---- small-M form: M x N split into 32 x 64 tiles, the block's four waves = 2 column halves x 2 K halves ... (see below)
+// (the key-point chains of the SetBlock: 1024 B rows) -- 32 x 32 per wave, K split over the four waves of a block, partial sums
+// joined through LDS in a fixed order (wave 0 + wave 1 + wave 2 + wave 3).  Both operands straight from global memory: the x
+// fragment of lane (i, h) is 16 contiguous bytes of row i, and with 32 rows per block nothing is shared between waves.
+__global__ __launch_bounds__(256, 2) void linear_small_kernel(LinArgs a) {
+  __shared__ __attribute__((aligned(16))) float part[3][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, ks = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int nt = blockIdx.x % a.ntiles, mt = blockIdx.x / a.ntiles;
+  const int m0 = mt * 32, n0 = nt * 32;
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const unsigned np16 = (unsigned)a.npad * 16u;
+  // wave ks takes the 8-wide k groups g = ks, ks + 4, ks + 8, ... (interleaved: every wave streams through the same cache lines)
+  const int groups = a.nsteps * 4;
+  const unsigned xo = m0 + li < a.M ? (unsigned)(m0 + li) * (unsigned)a.ldx * 4u + (unsigned)lh * 16u : 0xffffffffu;
+  const unsigned bo = (unsigned)(lh * a.npad + n0 + li) * 16u;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int PF = 4;     // k groups in flight per wave
+  f32x4 xa[PF], xb[PF];
+  auto issue = [&](int g, f32x4& fa, f32x4& fb) {
+    const bool live = g < groups && g * 8 + lh * 4 < a.K;
+    fa = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, live ? xo : 0xffffffffu, (unsigned)g * 32u, 0));
+    fb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, g < groups ? bo : 0xffffffffu, (unsigned)(2 * g) * np16, 0));
+  };
+#pragma unroll
+  for (int p = 0; p < PF; ++p) issue(ks + 4 * p, xa[p], xb[p]);
+  for (int g = ks; g < groups; g += 4 * PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const f32x4 fa = xa[p], fb = xb[p];
+      issue(g + 4 * (p + PF), xa[p], xb[p]);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb[kk], acc, 0, 0, 0);
+    }
+  }
+  if (ks > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[ks - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (ks == 0) {
+    const int n = n0 + li;
+    const float b = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = ((acc[r] + part[0][r][lane]) + part[1][r][lane]) + part[2][r][lane];
+      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < a.M && n < a.N) {
+        v = pn::apply_act(v + b, a.act);
+        if (a.res) v += a.res[(size_t)m * a.ldr + n];
+        a.out[(size_t)m * a.ldo + n] = v;
+      }
+    }
+  }
+}
+
+// torch (N, K) -> [Kpad / 4][Npad][4], zero padded
+__global__ void pack_linear_weight_kernel(const float* __restrict__ w, int n, int k, int npad, float* __restrict__ packed, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k1 = (int)(i & 3);
+    const size_t r = i >> 2;
+    const int col = (int)(r % npad);
+    const int kk = (int)(r / npad) * 4 + k1;
+    packed[i] = (col < n && kk < k) ? w[(size_t)col * k + kk] : 0.f;
+  }
+}
+
+template <int TM, int TN, int TM2, int TN2, bool GELU>
+int launch_linear_t(const LinArgs& a, int ncu, hipStream_t st, const pn::ProfileSlot* ps) {
+  constexpr int OCC = 2;
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  auto floats = [](int tm, int tn) { return std::max<size_t>(2 * (size_t)64 * tm * LA_LD, 4 * 32 * (size_t)(tn * 32 + 4)); };   // two x stages; the epilogue's slabs reuse them
+  const size_t smem = std::max(floats(TM, TN), TM2 > 0 ? floats(TM2, TN2) : (size_t)0) * sizeof(float);
+  static bool done[64] = {false};
+  if (pn::first_use_on_device(done))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<TM, TN, TM2, TN2, OCC, GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  long long tiles = (long long)pn::cdiv(a.M1, BM) * pn::cdiv(a.N, BN);
+  if (TM2 > 0 && a.M1 < a.M) tiles = std::max(tiles, (long long)pn::cdiv(a.M - a.M1, 64 * std::max(TM2, 1)) * pn::cdiv(a.N, 64 * std::max(TN2, 1)));
+  const dim3 grid((unsigned)std::min<long long>((long long)OCC * ncu, (tiles + 7) / 8 * 8));
+  if (ps) hipExtLaunchKernelGGL((linear_kernel<TM, TN, TM2, TN2, OCC, GELU>), grid, dim3(256), smem, st, ps->start, ps->stop, 0, a);
+  else hipLaunchKernelGGL((linear_kernel<TM, TN, TM2, TN2, OCC, GELU>), grid, dim3(256), smem, st, a);
+  return pn::check_launch("linear_kernel");
+}
+
+template <int TM, int TN, int TM2, int TN2>
+int launch_linear(const LinArgs& a, int ncu, hipStream_t st, const pn::ProfileSlot* ps) {
+  return a.act == PN_ACT_GELU ? launch_linear_t<TM, TN, TM2, TN2, true>(a, ncu, st, ps) : launch_linear_t<TM, TN, TM2, TN2, false>(a, ncu, st, ps);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pn_linear_packed_weight_floats(int n, int k) {
+  return (size_t)pn::cdiv(k, LK) * LK * (size_t)(pn::cdiv(n, LNPAD) * LNPAD);
+}
+
+int pn_pack_linear_weight_f32(const float* w_nk, int n, int k, float* packed, pn_stream_t stream) {
+  PN_REQUIRE(w_nk && packed && n >= 1 && k >= 1, "pack_linear_weight: bad arguments");
+  const size_t total = pn_linear_packed_weight_floats(n, k);
+  hipLaunchKernelGGL(pack_linear_weight_kernel, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0, pn::S(stream), w_nk, n, k,
+                     pn::cdiv(n, LNPAD) * LNPAD, packed, total);
+  return pn::check_launch("pack_linear_weight_kernel");
+}
+
+// The plan of a launch: form = 10 TM + TN of the main tiles (22 | 21 | 12 | 11), 1 = the K-split small-M form; rest = form of the second
+// phase (0: none) and m1 = rows of the first.  Main tiles 128 x 128 whenever they fill at least one whole round of the 2-per-CU
+// persistent grid: the rows of the whole rounds go to them, the remaining rows to the shape that needs the least time for them.
+// PN_LINEAR_TILE / pn_linear_set_tile pin the main form (single phase).
+struct LinPlan { int form, rest, m1; };
+#ifdef PN_LINEAR_STAMP
+unsigned long long* pn_linear_stamp_buffer = nullptr;    // set by the diagnostic tool before a launch
+#endif
+static int g_linear_tile = -1;     // -1: not read yet; 0: automatic
+static double tile_cost(int tm, int tn, int k) {   // cycles of one round (two co-resident blocks, one tile each): MFMA time of both + the fixed part
+  return 2.0 * (64.0 * tm * 64.0 * tn * k / 2048.0 * 64.0 / 4.0) * 1.06 + 5000.0 + (tm * tn < 4 ? 1500.0 : 0.0);
+}
+static LinPlan linear_plan(int m, int n, int k, int ncu) {
+  if (g_linear_tile < 0) { const char* e = getenv("PN_LINEAR_TILE"); g_linear_tile = e ? atoi(e) : 0; }
+  if (g_linear_tile) return {g_linear_tile, 0, m};
+  // under half a round of big tiles (the 1k-row key-point chains): 64 x 64 tiles (measured 7-14 us on 2048 rows against 9-21 for the
+  // K-split form).  The K-split form is never picked automatically: its summation order differs from the tiled forms', and a result
+  // must not depend on how many samples share a launch (the key-point selection downstream is discontinuous:
+  // test_voxelnet_v3_batch_of_two); all tiled forms add in the same order, so the plan may depend on the row count.
+  if ((long long)pn::cdiv(m, 128) * pn::cdiv(n, 128) * 2 <= ncu) return {11, 0, m};
+  const long long slots = 2LL * ncu;
+  auto rounds_cost = [&](int rows, int tm, int tn) {
+    const long long tiles = (long long)pn::cdiv(rows, 64 * tm) * pn::cdiv(n, 64 * tn);
+    return (double)((tiles + slots - 1) / slots) * tile_cost(tm, tn, k);
+  };
+  const int nt = pn::cdiv(n, 128), mt = pn::cdiv(m, 128);
+  const long long full = (long long)mt * nt / slots;             // whole rounds of 128 x 128 tiles
+  LinPlan best{22, 0, m};
+  double best_cost = rounds_cost(m, 2, 2);
+  const int single[3][2] = {{2, 1}, {1, 2}, {1, 1}};
+  for (auto& c : single) {
+    const double v = rounds_cost(m, c[0], c[1]);
+    if (v < best_cost) { best_cost = v; best = {c[0] * 10 + c[1], 0, m}; }
+  }
+  if (full >= 1) {
+    const int m1 = (int)std::min<long long>(m, full * slots / nt * 128);
+    if (m1 < m) {
+      const int rest[2][2] = {{2, 1}, {1, 1}};
+      for (auto& c : rest) {
+        const double v = (double)full * tile_cost(2, 2, k) + rounds_cost(m - m1, c[0], c[1]);
+        if (v < best_cost) { best_cost = v; best = {22, c[0] * 10 + c[1], m1}; }
+      }
+    }
+  }
+  return best;
+}
+
+int pn_linear_set_tile(int form) {
+  PN_REQUIRE(form == 0 || form == 1 || form == 11 || form == 12 || form == 21 || form == 22, "linear_set_tile: 0 (automatic), 1, 11, 12, 21 or 22");
+  g_linear_tile = form;
+  return PN_OK;
+}
+
+int pn_linear_f32(const float* x, int m, int k, int ldx, const float* packed_w, int n, const float* bias, int act, const float* residual, int ldr,
+                  float* out, int ldo, pn_stream_t stream) {
+  PN_REQUIRE(x && packed_w && out && m > 0 && k > 0 && n > 0, "linear: bad arguments");
+  PN_REQUIRE(k % 4 == 0 && ldx % 4 == 0 && ldx >= k && ldo >= n, "linear: k and the row strides must be multiples of 4");
+  PN_REQUIRE(n % 4 == 0 && ldo % 4 == 0 && (residual == nullptr || (ldr >= n && ldr % 4 == 0)), "linear: n and the output / residual strides must be multiples of 4");
+  PN_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)packed_w & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)residual & 15) == 0 &&
+                 ((uintptr_t)bias & 15) == 0, "linear: pointers must be 16-byte aligned");
+  PN_REQUIRE(act == PN_ACT_NONE || act == PN_ACT_RELU || act == PN_ACT_GELU, "linear: activation none, ReLU or GELU");
+  const unsigned long long xb = (unsigned long long)m * ldx * 4ull;
+  const unsigned long long ob = (unsigned long long)m * ldo * 4ull, rb = residual ? (unsigned long long)m * ldr * 4ull : 0ull;
+  PN_REQUIRE(xb < (1ull << 32) && ob < (1ull << 32) && rb < (1ull << 32), "linear: matrices of 4 GiB or more are not addressable by the buffer descriptors");
+  LinArgs a{};
+  a.x = x; a.w = packed_w; a.bias = bias; a.res = residual; a.out = out;
+  a.M = m; a.K = k; a.N = n; a.ldx = ldx; a.ldr = ldr; a.ldo = ldo; a.act = act;
+  a.npad = pn::cdiv(n, LNPAD) * LNPAD;
+  a.nsteps = pn::cdiv(k, LK);
+  a.x_bytes = (unsigned)xb;
+  a.o_bytes = (unsigned)ob;
+  a.r_bytes = (unsigned)rb;
+#ifdef PN_LINEAR_STAMP
+  a.stamps = pn_linear_stamp_buffer;
+#endif
+  a.w_bytes = (unsigned)(pn_linear_packed_weight_floats(n, k) * 4);
+  static int cus[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && cus[dev] == 0) {
+    int c = 0;
+    cus[dev] = (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c >= 8) ? c / 8 * 8 : 256;
+  }
+  const int ncu = (dev >= 0 && dev < 64) ? cus[dev] : 256;
+  pn::ProfileSlot slot;
+  const bool prof = pn::take_profile_slot(slot);
+  const pn::ProfileSlot* ps = prof ? &slot : nullptr;
+  hipStream_t st = pn::S(stream);
+  const LinPlan plan = linear_plan(m, n, k, ncu);
+  a.M1 = plan.m1;
+  if (plan.form == 1) {
+    a.mtiles = pn::cdiv(m, 32);
+    a.ntiles = pn::cdiv(n, 32);
+    const dim3 grid((unsigned)(a.mtiles * a.ntiles));
+    if (ps) hipExtLaunchKernelGGL(linear_small_kernel, grid, dim3(256), 0, st, ps->start, ps->stop, 0, a);
+    else hipLaunchKernelGGL(linear_small_kernel, grid, dim3(256), 0, st, a);
+    return pn::check_launch("linear_small_kernel");
+  }
+  switch (plan.form * 100 + plan.rest) {
+    case 2221: return launch_linear<2, 2, 2, 1>(a, ncu, st, ps);
+    case 2211: return launch_linear<2, 2, 1, 1>(a, ncu, st, ps);
+    case 2100: return launch_linear<2, 1, 0, 0>(a, ncu, st, ps);
+    case 1200: return launch_linear<1, 2, 0, 0>(a, ncu, st, ps);
+    case 1100: return launch_linear<1, 1, 0, 0>(a, ncu, st, ps);
+    default: return launch_linear<2, 2, 0, 0>(a, ncu, st, ps);
+  }
+}
+
+}  // extern "C"

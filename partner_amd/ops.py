@@ -842,28 +842,38 @@ def hard_voxelize(points: torch.Tensor, voxel_size, pc_range, max_points: int, m
 ACT_GELU = hip.ACT_GELU
 
 
+_LINEAR_ON = os.environ.get("PN_LINEAR", "1") != "0"     # 0: the r2 route (1x1 convolution on conv_mfma_kernel)
+
+
 class GemmLayer:
-    """packed nn.Linear: y = act(x @ W^T + b) (+ residual), on the MFMA conv kernel (1x1 convolution)"""
+    """packed nn.Linear: y = act(x @ W^T + b) (+ residual) on the token-GEMM kernel (csrc/linear.hip: pn_linear_f32);
+    ``PN_LINEAR=0`` keeps the r2 route through the MFMA convolution kernel (a 1x1 convolution)"""
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
         hip.require_device(weight)
         lib = hip.load()
         w = weight.detach().contiguous().float()
         self.n, self.k = w.shape
-        self.packed = _f32(lib.pn_conv_packed_weight_floats(self.n, self.k, 1, 1, 1), w.device)
-        hip.call("pn_pack_conv_weight_f32", w.data_ptr(), self.n, self.k, 1, 1, 1, self.packed.data_ptr(), hip.stream())
+        self.linear = _LINEAR_ON and self.n % 4 == 0 and self.k % 4 == 0
+        if self.linear:
+            self.packed = _f32(lib.pn_linear_packed_weight_floats(self.n, self.k), w.device)
+            hip.call("pn_pack_linear_weight_f32", w.data_ptr(), self.n, self.k, self.packed.data_ptr(), hip.stream())
+        else:
+            self.packed = _f32(lib.pn_conv_packed_weight_floats(self.n, self.k, 1, 1, 1), w.device)
+            hip.call("pn_pack_conv_weight_f32", w.data_ptr(), self.n, self.k, 1, 1, 1, self.packed.data_ptr(), hip.stream())
         self.bias = None if bias is None else bias.detach().contiguous().float()
 
-    def __call__(self, x: torch.Tensor, act=ACT_NONE, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, act=ACT_NONE, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert x.dim() == 2 and x.is_contiguous() and x.shape[1] == self.k
         m = x.shape[0]
-        out = torch.empty((m, self.n), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty((m, self.n), dtype=torch.float32, device=x.device)
         st = hip.stream()
         prof = _PROFILER
         if prof is not None:
             ev = prof.begin(st)
-        hip.call("pn_gemm_bias_act_f32", x.data_ptr(), m, self.k, self.k, self.packed.data_ptr(), self.n, hip.ptr(self.bias),
-                 int(act), hip.ptr(residual), self.n, out.data_ptr(), self.n, st)
+        hip.call("pn_linear_f32" if self.linear else "pn_gemm_bias_act_f32", x.data_ptr(), m, self.k, self.k, self.packed.data_ptr(), self.n,
+                 hip.ptr(self.bias), int(act), hip.ptr(residual), self.n, out.data_ptr(), self.n, st)
         if prof is not None:
             prof.end(ev, 2.0 * m * self.n * self.k, st, tag=f"gemm {m}x{self.k}->{self.n}")
         return out

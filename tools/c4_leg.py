@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""The `c4` object of the bench line alone (BASELINE configs[3]: Waymo PARTNER detector, bs = 2): python tools/c4_leg.py [batch]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from partner_amd import hip
+from partner_amd.utils import legs
+
+hip.load()
+out = legs.c4_leg(torch.device("cuda:0"), batch=int(sys.argv[1]) if len(sys.argv) > 1 else 2)
+for prec in ("f32", "bf16_bev_convs"):
+    o = out[prec]
+    print(f"{prec}: {o['ms_per_step']} ms per step, {o['frames_per_s']} frames/s")
+    for k, v in o["stages"].items():
+        print(f"   {k:16s} {v['ms']:8.3f} ms" + (f"   issued {v['gflop_issued']:7.1f} GFLOP  {v['tflops_issued']:6.1f} TF  frac {v['frac']:.3f}  (mfma kernels {v['mfma_kernel_ms']:.3f} ms, {v['mfma_launches']} launches)" if "frac" in v else ""))
+if "--json" in sys.argv:
+    print(json.dumps(out))

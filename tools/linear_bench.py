@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Token-GEMM microbenchmark: pn_linear_f32 (csrc/linear.hip) against the r2 route (1x1 convolution on conv_mfma_kernel) on the
+shapes of the SetBlock / E2ESWVoteHead, with a float64 check of a row sample.   python tools/linear_bench.py [rows_big] [rows_small]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from partner_amd import hip, ops
+
+dev = torch.device("cuda:0")
+big = int(sys.argv[1]) if len(sys.argv) > 1 else 73728
+small = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+shapes = [(big, 256, 256, 0, True), (big, 256, 256, 0, False), (big, 256, 512, 0, False), (big, 256, 768, 0, False), (big, 256, 1024, ops.ACT_GELU, False),
+          (big, 1024, 256, 0, True), (big, 512, 256, 0, False),
+          (small, 256, 256, 0, True), (small, 256, 512, 0, False), (small, 256, 768, 0, False), (small, 256, 1024, ops.ACT_GELU, False), (small, 1024, 256, 0, True)]
+hip.load()
+
+
+def timeit(fn, n=10, warm=3):
+    """kernel execution time (events attached to the dispatch), not the eager launch cadence"""
+    for _ in range(warm):
+        fn()
+    prof = ops.enable_conv_profiling()
+    torch.cuda.synchronize()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    _, ms, k = prof.collect()
+    ops.disable_conv_profiling()
+    return 1e3 * ms / k
+
+
+g = torch.Generator(device="cpu").manual_seed(0)
+for (m, k, n, act, res) in shapes:
+    x = torch.randn((m, k), generator=g).to(dev)
+    w = (torch.randn((n, k), generator=g) / np.sqrt(k)).to(dev)
+    b = torch.randn((n,), generator=g).to(dev)
+    r = torch.randn((m, n), generator=g).to(dev) if res else None
+    new = ops.GemmLayer(w, b)
+    assert new.linear
+    ops._LINEAR_ON = False
+    old = ops.GemmLayer(w, b)
+    ops._LINEAR_ON = True
+    y_new, y_old = new(x, act=act, residual=r), old(x, act=act, residual=r)
+    rows = torch.randint(0, m, (256,), generator=g)
+    ref = x[rows].double().cpu() @ w.double().cpu().T + b.double().cpu()
+    if act == ops.ACT_GELU:
+        ref = torch.nn.functional.gelu(ref)
+    if res:
+        ref = ref + r[rows].double().cpu()
+    e_new = float((y_new[rows].double().cpu() - ref).abs().max() / ref.abs().max())
+    e_old = float((y_old[rows].double().cpu() - ref).abs().max() / ref.abs().max())
+    line = f"{m:6d} x {k:4d} -> {n:4d} act {act} res {int(res)}: "
+    t_old = timeit(lambda: old(x, act=act, residual=r))
+    line += f"r2 {t_old:7.1f} us ({2e-6 * m * n * k / t_old:6.1f} TF)  "
+    for form in (0, 22, 21, 12, 11, 1):
+        if form == 1 and m > 4096:
+            continue
+        hip.call("pn_linear_set_tile", form)
+        y = new(x, act=act, residual=r)
+        e = float((y[rows].double().cpu() - ref).abs().max() / ref.abs().max())
+        t = timeit(lambda: new(x, act=act, residual=r))
+        line += f"| {'auto' if form == 0 else form} {t:7.1f} us ({2e-6 * m * n * k / t:6.1f} TF){'' if e < 1e-5 else ' ERR %.1e' % e} "
+    hip.call("pn_linear_set_tile", 0)
+    print(line + f"| err new {e_new:.1e} old {e_old:.1e} maxdiff {float((y_new - y_old).abs().max()):.1e}", flush=True)

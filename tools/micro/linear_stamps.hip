@@ -1,0 +1,65 @@
+// Where does a tile of pn_linear_f32 spend its time?  Diagnostic build of csrc/linear.hip with shader-clock stamps (s_memtime) of
+// wave 0 at the phase boundaries of the first four tiles of every block; the product build has no stamps.
+//   cd tools/micro && hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DPN_LINEAR_STAMP linear_stamps.hip -o /tmp/linear_stamps && /tmp/linear_stamps
+// phases: 0 tile start | 1 first loads issued | 2 previous tile's epilogue done | 3 barrier passed | 4 first stage stored + barrier | 5 K loop done
+#define PN_LINEAR_STAMP 1
+#include "../../partner_amd/csrc/pn_common.hip"
+#include "../../partner_amd/csrc/linear.hip"
+#include <vector>
+#include <algorithm>
+
+static unsigned long long* g_stamps = nullptr;
+
+int main(int argc, char** argv) {
+  struct Shape { int m, k, n, act, res, form; };
+  std::vector<Shape> shapes = {{73728, 256, 256, 0, 0, 22}, {73728, 256, 256, 0, 1, 21}, {73728, 256, 1024, PN_ACT_GELU, 0, 22}, {73728, 1024, 256, 0, 1, 22},
+                               {73728, 256, 512, 0, 0, 22}};
+  hipMalloc(&g_stamps, 1024 * 4 * 8 * sizeof(unsigned long long));
+  pn_linear_stamp_buffer = g_stamps;
+  for (auto sh : shapes) {
+    float *x, *w, *pw, *b, *r, *o;
+    hipMalloc(&x, (size_t)sh.m * sh.k * 4); hipMalloc(&w, (size_t)sh.n * sh.k * 4); hipMalloc(&b, sh.n * 4);
+    hipMalloc(&r, (size_t)sh.m * sh.n * 4); hipMalloc(&o, (size_t)sh.m * sh.n * 4);
+    hipMalloc(&pw, pn_linear_packed_weight_floats(sh.n, sh.k) * 4);
+    std::vector<float> h((size_t)sh.m * std::max(sh.k, sh.n));
+    for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+    hipMemcpy(x, h.data(), (size_t)sh.m * sh.k * 4, hipMemcpyHostToDevice);
+    hipMemcpy(r, h.data(), (size_t)sh.m * sh.n * 4, hipMemcpyHostToDevice);
+    hipMemcpy(w, h.data(), (size_t)sh.n * sh.k * 4, hipMemcpyHostToDevice);
+    hipMemcpy(b, h.data(), sh.n * 4, hipMemcpyHostToDevice);
+    pn_pack_linear_weight_f32(w, sh.n, sh.k, pw, nullptr);
+    pn_linear_set_tile(sh.form);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 4; ++rep) {
+      hipMemset(g_stamps, 0, 1024 * 4 * 8 * 8);
+      hipEventRecord(e0);
+      int rc = pn_linear_f32(x, sh.m, sh.k, sh.k, pw, sh.n, b, sh.act, sh.res ? r : nullptr, sh.n, o, sh.n, nullptr);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      if (rc) { char buf[256]; pn_last_error(buf, 256); printf("error: %s\n", buf); return 1; }
+      hipEventElapsedTime(&ms, e0, e1);
+    }
+    std::vector<unsigned long long> st(1024 * 4 * 8);
+    hipMemcpy(st.data(), g_stamps, st.size() * 8, hipMemcpyDeviceToHost);
+    printf("%d x %d -> %d act %d res %d form %d: %.1f us (%.1f TFLOP/s)\n", sh.m, sh.k, sh.n, sh.act, sh.res, sh.form, ms * 1e3, 2e-9 * sh.m * sh.k * sh.n / ms);
+    // medians over blocks of the phase durations (shader cycles) for tiles 0..3
+    for (int t = 0; t < 4; ++t) {
+      std::vector<double> d[6];
+      for (int blk = 0; blk < 512; ++blk) {
+        const unsigned long long* s = &st[((size_t)blk * 4 + t) * 8];
+        if (!s[0] || !s[5]) continue;
+        d[0].push_back((double)(s[1] - s[0]));
+        d[1].push_back(s[2] ? (double)(s[2] - s[1]) : 0.0);
+        d[2].push_back((double)(s[3] - (s[2] ? s[2] : s[1])));
+        d[3].push_back((double)(s[4] - s[3]));
+        d[4].push_back((double)(s[5] - s[4]));
+        if (t < 3) { const unsigned long long* nx = &st[((size_t)blk * 4 + t + 1) * 8]; if (nx[0]) d[5].push_back((double)(nx[0] - s[0])); }
+      }
+      auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+      printf("  tile %d (%zu blocks): setup+issue %6.0f | epilogue(prev) %6.0f | barrier %6.0f | stage0 %6.0f | K loop %6.0f | tile period %6.0f cycles\n", t, d[0].size(),
+             med(d[0]), med(d[1]), med(d[2]), med(d[3]), med(d[4]), med(d[5]));
+    }
+    hipFree(x); hipFree(w); hipFree(pw); hipFree(b); hipFree(r); hipFree(o);
+  }
+  return 0;
+}
