@@ -474,16 +474,19 @@ int pn_linear_set_tile(int form);
 /* nn.LayerNorm over C; chan_mean (rows) optional = mean_C(out)  (set_transformer.py:121,135) */
 int pn_layernorm_f32(const float *x, size_t rows, int c, const float *gamma, const float *beta,
                      float eps, float *out, float *chan_mean, pn_stream_t stream);
+/* Token order of the three column-wise entries below: col_major = 0: range-major (B, H, W) tokens, the reference's order
+ * (set_transformer.py:118-131); col_major = 1: azimuth-major (B, W, H) tokens -- the order the dense BEV map arrives in (NHWC, theta
+ * outermost), every azimuth column one contiguous slab, no transpose around the blocks (voxelnet.py:211,219 permute instead). */
 /* key-point selection: top-k local maxima of chan_mean along range per azimuth column
  * (set_transformer.py:134-147) -> top_idx int32 (B,k,W), kp (B, k*W, C), kpos (B,k,W,2) */
 int pn_setblock_keypoints(const float *chan_mean, const float *xn, const float *pos, int batch, int h,
-                          int w, int c, int k, int shift, int32_t *top_idx, float *kp, float *kpos,
-                          pn_stream_t stream);
+                          int w, int c, int k, int shift, int col_major, int32_t *top_idx, float *kp,
+                          float *kpos, pn_stream_t stream);
 /* SectorAttention core: key points attend to their column (set_transformer.py:307-354).
- * q_raw: proj_q(kp) (B, k*W, C) read through the reference's raw (B,C,k,W) view; kv: (B,H,W,2C) */
+ * q_raw: proj_q(kp) (B, k*W, C) read through the reference's raw (B,C,k,W) view; kv: (tokens, 2C) */
 int pn_setblock_sector_kp_attn(const float *q_raw, const float *kv, const float *xpos,
                                const float *kpos, const float *pos_mlp, int batch, int h, int w, int c,
-                               int heads, int k, int shift, float scale, float *out,
+                               int heads, int k, int shift, int col_major, float scale, float *out,
                                pn_stream_t stream);
 /* RangeAttention core among key points, windows k x win_w (set_transformer.py:216-259);
  * qkv: (B, k*W, 3C) -> out (B, k*W, C) */
@@ -491,10 +494,10 @@ int pn_setblock_range_attn(const float *qkv, const float *kpos, const float *pos
                            int c, int heads, int k, int win_w, float scale, float *out,
                            pn_stream_t stream);
 /* SectorAttentionV2 core: every column token attends to its k key points
- * (set_transformer.py:392-440); q: (B,H,W,C), kv_raw: (B, k*W, 2C) -> out (B,H,W,C) */
+ * (set_transformer.py:392-440); q: (tokens, C), kv_raw: (B, k*W, 2C) -> out (tokens, C) */
 int pn_setblock_sector_col_attn(const float *q, const float *kv_raw, const float *xpos,
                                 const float *kpos, const float *pos_mlp, int batch, int h, int w, int c,
-                                int heads, int k, int shift, float scale, float *out,
+                                int heads, int k, int shift, int col_major, float scale, float *out,
                                 pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -122,7 +122,17 @@ class SetBlock(nn.Module):
             proj=G(a.proj.weight, a.proj.bias), mlp=mlp(a.mlp))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """x: (B, H*W, C) tokens (range-major) -> same shape"""
+        """x: (B, H*W, C) tokens (range-major, the reference's order) -> same shape"""
+        return self._run(x, col_major=False)
+
+    def forward_cols(self, x: torch.Tensor) -> torch.Tensor:
+        """x: (B, W*H, C) tokens in AZIMUTH-major order -- the dense BEV map as it stands in NHWC memory, (B, theta, r, C) -- -> same
+        shape and order.  Every op of the block is per token, per azimuth column or per key-point window, so the token order in
+        memory is free: with the columns contiguous the two sector attentions stream their slab and the permutes of
+        voxelnet.py:211,219 disappear.  Element for element the result equals ``forward`` on the transposed tokens."""
+        return self._run(x, col_major=True)
+
+    def _run(self, x: torch.Tensor, col_major: bool) -> torch.Tensor:
         eval_only(self, "SetBlock")
         hip.require_device(x)
         a = self.attns
@@ -131,21 +141,22 @@ class SetBlock(nn.Module):
         B, L, C = x.shape
         assert L == H * W, "flatten img_tokens has wrong size"
         K, heads, sh, st = a.H, a.num_heads, a.shift_size, hip.stream()
+        cm = int(col_major)
         ln = lambda t, n: ops.layernorm(t, n.weight.detach(), n.bias.detach(), n.eps)  # noqa: E731
         x2 = x.contiguous().view(B * L, C).float()
-        xn, cm = ops.layernorm(x2, a.norm1.weight.detach(), a.norm1.bias.detach(), a.norm1.eps, want_chan_mean=True)
+        xn, cmean = ops.layernorm(x2, a.norm1.weight.detach(), a.norm1.bias.detach(), a.norm1.eps, want_chan_mean=True)
         dev = x.device
         top = torch.empty((B, K, W), dtype=torch.int32, device=dev)
         kp = torch.empty((B * K * W, C), dtype=torch.float32, device=dev)
         kpos = torch.empty((B, K, W, 2), dtype=torch.float32, device=dev)
-        hip.call("pn_setblock_keypoints", cm.data_ptr(), xn.data_ptr(), p["pos"].data_ptr(), B, H, W, C, K, sh, top.data_ptr(),
+        hip.call("pn_setblock_keypoints", cmean.data_ptr(), xn.data_ptr(), p["pos"].data_ptr(), B, H, W, C, K, sh, cm, top.data_ptr(),
                  kp.data_ptr(), kpos.data_ptr(), st)
         self.last_top_idx = top
         # sector attention 1: key points <- column
         q1, kv1 = p["s1_q"](kp), p["s1_kv"](xn)
         o1 = torch.empty_like(kp)
         hip.call("pn_setblock_sector_kp_attn", q1.data_ptr(), kv1.data_ptr(), p["pos"].data_ptr(), kpos.data_ptr(),
-                 p["s1_pe"].data_ptr(), B, H, W, C, heads, K, sh, float(a.scale), o1.data_ptr(), st)
+                 p["s1_pe"].data_ptr(), B, H, W, C, heads, K, sh, cm, float(a.scale), o1.data_ptr(), st)
         s1 = p["s1_proj"](o1, residual=kp)
         s1 = p["s1_mlp"][1](p["s1_mlp"][0](ln(s1, a.sector_attn1.norm2), act=ops.ACT_GELU), residual=s1)
         # range attention among key points
@@ -159,7 +170,7 @@ class SetBlock(nn.Module):
         q3, kv3 = p["s2_q"](xn), p["s2_kv"](s2)
         o3 = torch.empty_like(x2)
         hip.call("pn_setblock_sector_col_attn", q3.data_ptr(), kv3.data_ptr(), p["pos"].data_ptr(), kpos.data_ptr(),
-                 p["s2_pe"].data_ptr(), B, H, W, C, heads, K, sh, float(a.scale), o3.data_ptr(), st)
+                 p["s2_pe"].data_ptr(), B, H, W, C, heads, K, sh, cm, float(a.scale), o3.data_ptr(), st)
         y = p["proj"](o3, residual=x2)
         y = p["mlp"][1](p["mlp"][0](ln(y, a.norm2), act=ops.ACT_GELU), residual=y)
         return y.view(B, L, C)

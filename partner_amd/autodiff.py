@@ -322,7 +322,7 @@ def gather_keypoints(t: Tape, xn: Node, cm: torch.Tensor, pos: torch.Tensor, b: 
     top = torch.empty((b, k, w), dtype=torch.int32, device=dev)
     kp = torch.empty((b * k * w, c), dtype=torch.float32, device=dev)
     kpos = torch.empty((b, k, w, 2), dtype=torch.float32, device=dev)
-    hip.call("pn_setblock_keypoints", cm.data_ptr(), xn.v.data_ptr(), pos.data_ptr(), b, h, w, c, k, 0, top.data_ptr(), kp.data_ptr(),
+    hip.call("pn_setblock_keypoints", cm.data_ptr(), xn.v.data_ptr(), pos.data_ptr(), b, h, w, c, k, 0, 0, top.data_ptr(), kp.data_ptr(),
              kpos.data_ptr(), hip.stream())
 
     def bw(dy):

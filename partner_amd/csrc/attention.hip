@@ -15,33 +15,70 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// token (b, h, w) of a (B, H, W) range-major map (the reference's order, set_transformer.py:118-131) or of the azimuth-major
+// (B, W, H) map the dense BEV tensor arrives in (NHWC with theta outermost): with col_major every azimuth column -- the unit the two
+// sector attentions and the key-point selection work on -- is ONE contiguous slab and no transpose surrounds the blocks
+__device__ __forceinline__ size_t tok(int b, int h, int w, int H, int W, int cm) {
+  return cm ? ((size_t)b * W + w) * H + h : ((size_t)b * H + h) * W + w;
+}
+
 // ---------------------------------------------------------------------------------------------
-// LayerNorm over the channel axis, one wavefront per token row.
-__global__ void layernorm_kernel(const float* __restrict__ x, size_t rows, int c, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float eps, float* __restrict__ out,
-                                 float* __restrict__ chan_mean) {
+// LayerNorm over the channel axis, one wavefront per token row.  NPL > 0: the row (c = 64 NPL values) stays in registers -- one pass
+// over memory, NPL loads in flight per lane; element -> lane assignment and summation order are those of the generic loop (NPL = 0),
+// so both give the same bits.
+template <int NPL>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, size_t rows, int c, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, float* __restrict__ out,
+                                                        float* __restrict__ chan_mean) {
   const int lane = threadIdx.x & 63;
   const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + row * c;
-  float s = 0.f;
-  for (int k = lane; k < c; k += 64) s += xr[k];
-  const float mean = pn::wave_sum(s) / (float)c;
-  float v = 0.f;
-  for (int k = lane; k < c; k += 64) {
-    const float d = xr[k] - mean;
-    v += d * d;
-  }
-  const float rstd = 1.f / sqrtf(pn::wave_sum(v) / (float)c + eps);
-  float acc = 0.f;
-  for (int k = lane; k < c; k += 64) {
-    const float y = (xr[k] - mean) * rstd * gamma[k] + beta[k];
-    out[row * c + k] = y;
-    acc += y;
-  }
-  if (chan_mean) {
-    acc = pn::wave_sum(acc);
-    if (lane == 0) chan_mean[row] = acc / (float)c;
+  if constexpr (NPL > 0) {
+    float v[NPL], g[NPL], be[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) v[j] = xr[lane + 64 * j];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) { g[j] = gamma[lane + 64 * j]; be[j] = beta[lane + 64 * j]; }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) s += v[j];
+    const float mean = pn::wave_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) { const float d = v[j] - mean; q += d * d; }
+    const float rstd = 1.f / sqrtf(pn::wave_sum(q) / (float)c + eps);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const float y = (v[j] - mean) * rstd * g[j] + be[j];
+      out[row * c + lane + 64 * j] = y;
+      acc += y;
+    }
+    if (chan_mean) {
+      acc = pn::wave_sum(acc);
+      if (lane == 0) chan_mean[row] = acc / (float)c;
+    }
+  } else {
+    float s = 0.f;
+    for (int k = lane; k < c; k += 64) s += xr[k];
+    const float mean = pn::wave_sum(s) / (float)c;
+    float v = 0.f;
+    for (int k = lane; k < c; k += 64) {
+      const float d = xr[k] - mean;
+      v += d * d;
+    }
+    const float rstd = 1.f / sqrtf(pn::wave_sum(v) / (float)c + eps);
+    float acc = 0.f;
+    for (int k = lane; k < c; k += 64) {
+      const float y = (xr[k] - mean) * rstd * gamma[k] + beta[k];
+      out[row * c + k] = y;
+      acc += y;
+    }
+    if (chan_mean) {
+      acc = pn::wave_sum(acc);
+      if (lane == 0) chan_mean[row] = acc / (float)c;
+    }
   }
 }
 
@@ -52,17 +89,17 @@ __global__ void layernorm_kernel(const float* __restrict__ x, size_t rows, int c
 // One wavefront per column.  Outputs: top_idx (B,K,W), kp (B, K*W, C) gathered rows of xn,
 // kpos (B,K,W,2) gathered Cartesian positions.
 __global__ void keypoints_kernel(const float* __restrict__ s, const float* __restrict__ xn, const float* __restrict__ pos,
-                                 int B, int H, int W, int C, int K, int shift, int32_t* __restrict__ top_idx,
+                                 int B, int H, int W, int C, int K, int shift, int cm, int32_t* __restrict__ top_idx,
                                  float* __restrict__ kp, float* __restrict__ kpos) {
   extern __shared__ float sc[];  // H scores
   const int lane = threadIdx.x;
   const int b = blockIdx.x / W, wr = blockIdx.x % W;
   const int wp = (wr + shift) % W;
   for (int h = lane; h < H; h += 64) {
-    const float v = s[((size_t)b * H + h) * W + wp];
+    const float v = s[tok(b, h, wp, H, W, cm)];
     float lm = 0.f;
     if (h >= 1 && h <= H - 2) {
-      const float a = s[((size_t)b * H + h - 1) * W + wp], c = s[((size_t)b * H + h + 1) * W + wp];
+      const float a = s[tok(b, h - 1, wp, H, W, cm)], c = s[tok(b, h + 1, wp, H, W, cm)];
       lm = fmaxf(fmaxf(a, v), c);
     }
     sc[h] = (lm == v) ? v : 0.f * v;
@@ -94,7 +131,7 @@ __global__ void keypoints_kernel(const float* __restrict__ s, const float* __res
       kpos[(((size_t)b * K + k) * W + wr) * 2 + 1] = pos[((size_t)bi * W + wp) * 2 + 1];
     }
     __syncthreads();
-    const float* src = xn + (((size_t)b * H + bi) * W + wp) * C;
+    const float* src = xn + tok(b, bi, wp, H, W, cm) * C;
     float* dst = kp + ((size_t)b * K * W + (size_t)k * W + wr) * C;
     for (int c = lane; c < C; c += 64) dst[c] = src[c];
   }
@@ -121,15 +158,28 @@ struct PosMlp {
   }
 };
 
+__device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+// sum over the 16 lanes of a row group (lanes 16 g .. 16 g + 15): every lane ends with the total
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // SectorAttention core (key points <- their azimuth column).  Block = (batch, rolled column),
 // wave = head.  q comes from the (B, K*W, C) buffer read through the reference's raw
-// reinterpretation as (B, C, K, W) (set_transformer.py:331-334); k|v is the (B,H,W,2C) projection
+// reinterpretation as (B, C, K, W) (set_transformer.py:331-334); k|v is the (tokens, 2C) projection
 // of the normalised tokens.  out: (B, K*W, C).
+// r3: the column is streamed in 16-byte pieces, FOUR rows per wave instruction (lane = (row mod 4, 4-channel group): 256 contiguous
+// bytes per row), partial dot products are reduced over the 16 lanes of a row; the relative-position bias of every (key point, row)
+// is formed once per head, up front, straight into the logit table.  (r2: one lane per row, 64-byte requests from 64 rows.)
 template <int KT>
 __global__ __launch_bounds__(256) void sector_kp_attn_kernel(const float* __restrict__ qraw, const float* __restrict__ kv,
                                                              const float* __restrict__ xpos, const float* __restrict__ kpos,
-                                                             PosMlp pm, int B, int H, int W, int C, int K, int shift,
+                                                             PosMlp pm, int B, int H, int W, int C, int K, int shift, int cm,
                                                              float scale, float* __restrict__ out) {
   extern __shared__ float lds[];
   const int heads = pm.heads, hd = C / heads;
@@ -143,28 +193,33 @@ __global__ __launch_bounds__(256) void sector_kp_attn_kernel(const float* __rest
     const int k = i / hd, d = i - k * hd;
     qs[i] = qb[((size_t)(head * hd + d) * K + k) * W + wr] * scale;
   }
-  __syncthreads();
-  // logits: lanes over range rows
-  for (int h = lane; h < H; h += 64) {
-    const float* kr = kv + (((size_t)b * H + h) * W + wp) * (2 * C) + head * hd;
-    float acc[KT];
-#pragma unroll
-    for (int k = 0; k < KT; ++k) acc[k] = 0.f;
-    for (int d = 0; d < hd; d += 4) {
-      const f32x4 kk = *reinterpret_cast<const f32x4*>(kr + d);
-#pragma unroll
-      for (int k = 0; k < KT; ++k)
-        if (k < K)
-          acc[k] += qs[k * hd + d] * kk[0] + qs[k * hd + d + 1] * kk[1] + qs[k * hd + d + 2] * kk[2] + qs[k * hd + d + 3] * kk[3];
-    }
+  // relative-position bias of (key point k, row h) for this head
+  for (int i = lane; i < K * H; i += 64) {
+    const int k = i / H, h = i - k * H;
     const float px = xpos[((size_t)h * W + wp) * 2], py = xpos[((size_t)h * W + wp) * 2 + 1];
+    const float* kp2 = kpos + (((size_t)b * K + k) * W + wr) * 2;
+    float hid[16];
+    pm.hidden(kp2[0] - px, kp2[1] - py, hid);
+    ps[i] = pm.out(hid, head);
+  }
+  __syncthreads();
+  const int rs = lane >> 4, d4 = lane & 15;
+  const bool dok = d4 * 4 < hd;
+  const size_t tstride = cm ? 1 : (size_t)W;        // token step between consecutive rows of the column
+  const size_t t0 = tok(b, 0, wp, H, W, cm);
+  f32x4 qv[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) qv[k] = (k < K && dok) ? *reinterpret_cast<const f32x4*>(qs + k * hd + d4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // logits: four rows per step
+  for (int h0 = 0; h0 < H; h0 += 4) {
+    const int h = h0 + rs;
+    f32x4 kk = {0.f, 0.f, 0.f, 0.f};
+    if (h < H && dok) kk = *reinterpret_cast<const f32x4*>(kv + (t0 + (size_t)h * tstride) * (2 * C) + head * hd + d4 * 4);
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       if (k >= K) continue;
-      const float* kp2 = kpos + (((size_t)b * K + k) * W + wr) * 2;
-      float hid[16];
-      pm.hidden(kp2[0] - px, kp2[1] - py, hid);
-      ps[k * H + h] = acc[k] + pm.out(hid, head);
+      const float sum = group16_sum(dot4(qv[k], kk));
+      if (d4 == 0 && h < H) ps[k * H + h] += sum;
     }
   }
   __syncthreads();
@@ -185,101 +240,127 @@ __global__ __launch_bounds__(256) void sector_kp_attn_kernel(const float* __rest
     for (int h = lane; h < H; h += 64) ps[k * H + h] *= inv;
   }
   __syncthreads();
-  // out[k][d] = sum_h p[k][h] * v[h][d]: lanes over d
-  for (int d = lane; d < hd; d += 64) {
-    float acc[KT];
+  // out[k][d] = sum_h p[k][h] * v[h][d]: lane (rs, d4) adds the rows h = rs (mod 4), then the four row groups are joined
+  f32x4 acc[KT];
 #pragma unroll
-    for (int k = 0; k < KT; ++k) acc[k] = 0.f;
-    for (int h = 0; h < H; ++h) {
-      const float vv = kv[(((size_t)b * H + h) * W + wp) * (2 * C) + C + head * hd + d];
+  for (int k = 0; k < KT; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int h0 = 0; h0 < H; h0 += 4) {
+    const int h = h0 + rs;
+    if (h < H && dok) {
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(kv + (t0 + (size_t)h * tstride) * (2 * C) + C + head * hd + d4 * 4);
 #pragma unroll
       for (int k = 0; k < KT; ++k)
         if (k < K) acc[k] += ps[k * H + h] * vv;
     }
+  }
 #pragma unroll
-    for (int k = 0; k < KT; ++k)
-      if (k < K) out[((size_t)b * K * W + (size_t)k * W + wr) * C + head * hd + d] = acc[k];
+  for (int k = 0; k < KT; ++k) {
+    if (k >= K) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = acc[k][e];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      acc[k][e] = v;
+    }
+    if (rs == 0 && dok) *reinterpret_cast<f32x4*>(out + ((size_t)b * K * W + (size_t)k * W + wr) * C + head * hd + d4 * 4) = acc[k];
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// RangeAttention core among key points: windows of K x win_w tokens.  qkv: (B, K*W, 3C) projection
-// of the normalised key points (q | k | v).  Block = (batch, window), wave = head.
+// RangeAttention core among key points: windows of n = K x win_w tokens.  qkv: (B, K*W, 3C) projection
+// of the normalised key points (q | k | v).
+// r3: block = (batch, window, HEAD) (r2: one block per window with a wave per head -- 32 blocks for the Waymo map, and a K image whose
+// row stride put every lane of a logit row on one LDS bank: 160 us).  q / k rows padded to hd + 1 floats (the lanes of a logit row
+// walk k: bank = (kj + d) mod 32), the window's token positions staged once, softmax with eight threads per row, P V with float4 rows.
 __global__ __launch_bounds__(256) void range_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ kpos,
                                                          PosMlp pm, int B, int W, int C, int K, int win_w, float scale,
                                                          float* __restrict__ out) {
   extern __shared__ float lds[];
   const int heads = pm.heads, hd = C / heads;
-  const int head = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tid = threadIdx.x;
   const int nw = W / win_w, n = K * win_w;
-  const int b = blockIdx.x / nw, j = blockIdx.x % nw;
-  if (head >= heads) return;
-  float* qs = lds + head * (3 * n * hd + n * n);  // q, k, v [n][hd], p [n][n]
-  float* ks = qs + n * hd;
-  float* vs = ks + n * hd;
-  float* ps = vs + n * hd;
-  for (int i = lane; i < n * hd; i += 64) {
+  const int head = blockIdx.x % heads, bj = blockIdx.x / heads;
+  const int b = bj / nw, j = bj % nw;
+  const int qld = hd + 1, pld = n + 1;
+  float* qs = lds;                    // [n][hd + 1]
+  float* ks = qs + n * qld;           // [n][hd + 1]
+  float* vs = ks + n * qld;           // [n][hd]    (16-byte aligned: n * qld * 2 is a multiple of 4 when n is)
+  float* ps = vs + n * hd;            // [n][n + 1]
+  float* tp = ps + n * pld;           // [n][2] token positions
+  auto trow = [&](int t) { const int k = t / win_w, ww = t - k * win_w; return (size_t)b * K * W + (size_t)k * W + j * win_w + ww; };
+  for (int i = tid; i < n * hd; i += 256) {
     const int t = i / hd, d = i - t * hd;
-    const int k = t / win_w, ww = t - k * win_w;
-    const float* row = qkv + ((size_t)b * K * W + (size_t)k * W + j * win_w + ww) * (3 * C) + head * hd + d;
-    qs[i] = row[0] * scale;
-    ks[i] = row[C];
-    vs[i] = row[2 * C];
+    const float* row = qkv + trow(t) * (3 * C) + head * hd + d;
+    qs[t * qld + d] = row[0] * scale;
+    ks[t * qld + d] = row[C];
+    vs[t * hd + d] = row[2 * C];
+  }
+  for (int i = tid; i < 2 * n; i += 256) {
+    const int t = i >> 1, k = t / win_w, ww = t - k * win_w;
+    tp[i] = kpos[(((size_t)b * K + k) * W + j * win_w + ww) * 2 + (i & 1)];
   }
   __syncthreads();
-  for (int e = lane; e < n * n; e += 64) {
+  for (int e = tid; e < n * n; e += 256) {
     const int qi = e / n, kj = e - qi * n;
     float acc = 0.f;
-    for (int d = 0; d < hd; ++d) acc += qs[qi * hd + d] * ks[kj * hd + d];
-    const int k1 = qi / win_w, w1 = qi - k1 * win_w, k2 = kj / win_w, w2 = kj - k2 * win_w;
-    const float* p1 = kpos + (((size_t)b * K + k1) * W + j * win_w + w1) * 2;
-    const float* p2 = kpos + (((size_t)b * K + k2) * W + j * win_w + w2) * 2;
+    for (int d = 0; d < hd; ++d) acc += qs[qi * qld + d] * ks[kj * qld + d];
     float hid[16];
-    pm.hidden(p1[0] - p2[0], p1[1] - p2[1], hid);
-    ps[e] = acc + pm.out(hid, head);
+    pm.hidden(tp[2 * qi] - tp[2 * kj], tp[2 * qi + 1] - tp[2 * kj + 1], hid);
+    ps[qi * pld + kj] = acc + pm.out(hid, head);
   }
   __syncthreads();
-  for (int qi = lane; qi < n; qi += 64) {
+  // softmax: eight consecutive lanes per row
+  for (int r = tid >> 3; r < n; r += 32) {
+    const int sub = tid & 7;
     float m = -FLT_MAX;
-    for (int kj = 0; kj < n; ++kj) m = fmaxf(m, ps[qi * n + kj]);
+    for (int kj = sub; kj < n; kj += 8) m = fmaxf(m, ps[r * pld + kj]);
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    m = fmaxf(m, __shfl_xor(m, 2, 64));
+    m = fmaxf(m, __shfl_xor(m, 4, 64));
     float sum = 0.f;
-    for (int kj = 0; kj < n; ++kj) {
-      const float e = expf(ps[qi * n + kj] - m);
-      ps[qi * n + kj] = e;
+    for (int kj = sub; kj < n; kj += 8) {
+      const float e = expf(ps[r * pld + kj] - m);
+      ps[r * pld + kj] = e;
       sum += e;
     }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64);
     const float inv = 1.f / sum;
-    for (int kj = 0; kj < n; ++kj) ps[qi * n + kj] *= inv;
+    for (int kj = sub; kj < n; kj += 8) ps[r * pld + kj] *= inv;
   }
   __syncthreads();
-  for (int i = lane; i < n * hd; i += 64) {
-    const int t = i / hd, d = i - t * hd;
-    float acc = 0.f;
-    for (int kj = 0; kj < n; ++kj) acc += ps[t * n + kj] * vs[kj * hd + d];
-    const int k = t / win_w, ww = t - k * win_w;
-    out[((size_t)b * K * W + (size_t)k * W + j * win_w + ww) * C + head * hd + d] = acc;
+  const int hd4 = hd >> 2;
+  for (int i = tid; i < n * hd4; i += 256) {
+    const int t = i / hd4, q4 = i - t * hd4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kj = 0; kj < n; ++kj) acc += ps[t * pld + kj] * *reinterpret_cast<const f32x4*>(vs + kj * hd + q4 * 4);
+    *reinterpret_cast<f32x4*>(out + trow(t) * C + head * hd + q4 * 4) = acc;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// SectorAttentionV2 core (azimuth column <- its key points).  q: (B,H,W,C) projection of the tokens;
+// SectorAttentionV2 core (azimuth column <- its key points).  q: (tokens, C) projection of the tokens;
 // k|v: (B, K*W, 2C) projection of the key points, each half read through the raw (B,C,K,W)
-// reinterpretation (set_transformer.py:417-425).  Block = (batch, rolled column), lanes over rows.
-// out: (B,H,W,C) written at the PHYSICAL column (the roll-back of set_transformer.py:157-160).
+// reinterpretation (set_transformer.py:417-425).  Block = (batch, rolled column).
+// out: (tokens, C) written at the PHYSICAL column (the roll-back of set_transformer.py:157-160).
+// r3: four rows per wave instruction (lane = (row mod 4, 4-channel group), one head per step: 256 contiguous bytes per row in and out),
+// 16-lane reductions for the four logits of a (row, head), the relative-position bias of every (row, key point, head) formed once up front.
 template <int KT>
 __global__ __launch_bounds__(256) void sector_col_attn_kernel(const float* __restrict__ q, const float* __restrict__ kvraw,
                                                               const float* __restrict__ xpos, const float* __restrict__ kpos,
-                                                              PosMlp pm, int B, int H, int W, int C, int K, int shift,
+                                                              PosMlp pm, int B, int H, int W, int C, int K, int shift, int cm,
                                                               float scale, float* __restrict__ out) {
-  extern __shared__ float lds[];  // kk[K][C], vv[K][C]
+  extern __shared__ float lds[];  // kk[K][C], vv[K][C], bias[H][K][heads]
   const int heads = pm.heads, hd = C / heads;
   const int b = blockIdx.x / W, wr = blockIdx.x % W, wp = (wr + shift) % W;
   float* kk = lds;
   float* vv = lds + K * C;
+  float* bt = vv + K * C;
   const float* kvb = kvraw + (size_t)b * K * W * (2 * C);
-  // raw view of the (K*W, 2C) buffer?  No: proj_k and proj_v outputs are separate (K*W, C) tensors in
-  // the reference; here they are the two column halves of one (K*W, 2C) GEMM output, so element
-  // [row][c] of proj_k is kvb[row*2C + c].  The reinterpretation (B, C, K, W) addresses the FLAT
+  // proj_k and proj_v outputs are separate (K*W, C) tensors in the reference; here they are the two column halves of one
+  // (K*W, 2C) GEMM output, so element [row][c] of proj_k is kvb[row*2C + c].  The reinterpretation (B, C, K, W) addresses the FLAT
   // (K*W*C) proj_k buffer: flat = ((c*K + k)*W + w)  ->  row = flat / C, col = flat % C.
   for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
     const int k = i / C, c = i - k * C;
@@ -288,36 +369,35 @@ __global__ __launch_bounds__(256) void sector_col_attn_kernel(const float* __res
     kk[i] = kvb[row * (2 * C) + col];
     vv[i] = kvb[row * (2 * C) + C + col];
   }
-  __syncthreads();
-  for (int h = threadIdx.x; h < H; h += blockDim.x) {
-    const float* qr = q + (((size_t)b * H + h) * W + wp) * C;
-    float* orow = out + (((size_t)b * H + h) * W + wp) * C;
+  for (int i = threadIdx.x; i < H * K; i += blockDim.x) {
+    const int h = i / K, k = i - h * K;
     const float px = xpos[((size_t)h * W + wp) * 2], py = xpos[((size_t)h * W + wp) * 2 + 1];
-    float hid[KT][16];
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      if (k >= K) continue;
-      const float* kp2 = kpos + (((size_t)b * K + k) * W + wr) * 2;
-      pm.hidden(px - kp2[0], py - kp2[1], hid[k]);
-    }
+    const float* kp2 = kpos + (((size_t)b * K + k) * W + wr) * 2;
+    float hid[16];
+    pm.hidden(px - kp2[0], py - kp2[1], hid);
+    for (int head = 0; head < heads; ++head) bt[(h * K + k) * heads + head] = pm.out(hid, head);
+  }
+  __syncthreads();
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, rs = lane >> 4, d4 = lane & 15;
+  const bool dok = d4 * 4 < hd;
+  const size_t tstride = cm ? 1 : (size_t)W;
+  const size_t t0 = tok(b, 0, wp, H, W, cm);
+  for (int h0 = 4 * wv; h0 < H; h0 += 16) {
+    const int h = h0 + rs;
+    const bool ok = h < H && dok;
+    const float* qr = q + (t0 + (size_t)h * tstride) * C;
+    float* orow = out + (t0 + (size_t)h * tstride) * C;
     for (int head = 0; head < heads; ++head) {
+      const int co = head * hd + d4 * 4;
+      f32x4 qq = {0.f, 0.f, 0.f, 0.f};
+      if (ok) qq = *reinterpret_cast<const f32x4*>(qr + co);
       float lg[KT];
-#pragma unroll
-      for (int k = 0; k < KT; ++k) lg[k] = 0.f;
-      for (int d = 0; d < hd; d += 4) {
-        const f32x4 qq = *reinterpret_cast<const f32x4*>(qr + head * hd + d);
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-          if (k >= K) continue;
-          const float* kr = kk + k * C + head * hd + d;
-          lg[k] += qq[0] * kr[0] + qq[1] * kr[1] + qq[2] * kr[2] + qq[3] * kr[3];
-        }
-      }
       float m = -FLT_MAX;
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         if (k >= K) continue;
-        lg[k] = lg[k] * scale + pm.out(hid[k], head);
+        const float sum = group16_sum(dok ? dot4(qq, *reinterpret_cast<const f32x4*>(kk + k * C + co)) : 0.f);
+        lg[k] = sum * scale + (h < H ? bt[(h * K + k) * heads + head] : 0.f);
         m = fmaxf(m, lg[k]);
       }
       float sum = 0.f;
@@ -328,17 +408,13 @@ __global__ __launch_bounds__(256) void sector_col_attn_kernel(const float* __res
         sum += lg[k];
       }
       const float inv = 1.f / sum;
-      for (int d = 0; d < hd; d += 4) {
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < KT; ++k) {
-          if (k >= K) continue;
-          const float p = lg[k] * inv;
-          const float* vr = vv + k * C + head * hd + d;
-          o[0] += p * vr[0]; o[1] += p * vr[1]; o[2] += p * vr[2]; o[3] += p * vr[3];
-        }
-        *reinterpret_cast<f32x4*>(orow + head * hd + d) = o;
+      for (int k = 0; k < KT; ++k) {
+        if (k >= K) continue;
+        if (dok) o += (lg[k] * inv) * *reinterpret_cast<const f32x4*>(vv + k * C + co);
       }
+      if (ok) *reinterpret_cast<f32x4*>(orow + co) = o;
     }
   }
 }
@@ -351,43 +427,53 @@ int pn_layernorm_f32(const float* x, size_t rows, int c, const float* gamma, con
                      float* chan_mean, pn_stream_t stream) {
   PN_REQUIRE(x && gamma && beta && out && c >= 1, "layernorm: bad arguments");
   if (rows == 0) return PN_OK;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, pn::S(stream), x, rows, c, gamma, beta,
-                     eps, out, chan_mean);
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t st = pn::S(stream);
+  switch (c % 64 == 0 ? c / 64 : 0) {      // register-resident rows for the channel counts of the model (64 .. 1024)
+    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean); break;
+    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean); break;
+    case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean); break;
+    case 8: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean); break;
+    case 16: hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean); break;
+    default: hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean); break;
+  }
   return pn::check_launch("layernorm_kernel");
 }
 
 int pn_setblock_keypoints(const float* chan_mean, const float* xn, const float* pos, int batch, int h, int w, int c, int k,
-                          int shift, int32_t* top_idx, float* kp, float* kpos, pn_stream_t stream) {
+                          int shift, int col_major, int32_t* top_idx, float* kp, float* kpos, pn_stream_t stream) {
   PN_REQUIRE(chan_mean && xn && pos && top_idx && kp && kpos, "keypoints: null pointer");
   PN_REQUIRE(batch >= 1 && h >= 3 && w >= 1 && c >= 1 && k >= 1 && k <= h && k <= 8, "keypoints: bad sizes");
   hipLaunchKernelGGL(keypoints_kernel, dim3(batch * w), dim3(64), h * sizeof(float), pn::S(stream), chan_mean, xn, pos, batch,
-                     h, w, c, k, shift, top_idx, kp, kpos);
+                     h, w, c, k, shift, col_major != 0, top_idx, kp, kpos);
   return pn::check_launch("keypoints_kernel");
 }
 
 int pn_setblock_sector_kp_attn(const float* q_raw, const float* kv, const float* xpos, const float* kpos, const float* pos_mlp,
-                               int batch, int h, int w, int c, int heads, int k, int shift, float scale, float* out,
+                               int batch, int h, int w, int c, int heads, int k, int shift, int col_major, float scale, float* out,
                                pn_stream_t stream) {
   PN_REQUIRE(q_raw && kv && xpos && kpos && pos_mlp && out, "sector_kp_attn: null pointer");
-  PN_REQUIRE(heads >= 1 && heads <= 4 && c % heads == 0 && (c / heads) % 4 == 0 && k <= 8, "sector_kp_attn: bad sizes");
+  PN_REQUIRE(heads >= 1 && heads <= 4 && c % heads == 0 && (c / heads) % 4 == 0 && c / heads <= 64 && k <= 8, "sector_kp_attn: bad sizes (head width <= 64)");
+  PN_REQUIRE(((uintptr_t)kv & 15) == 0 && ((uintptr_t)out & 15) == 0 && c % 4 == 0, "sector_kp_attn: 16-byte aligned buffers");
   const size_t smem = (size_t)heads * (k * (c / heads) + k * h) * sizeof(float);
   PN_REQUIRE(smem <= 64 * 1024, "sector_kp_attn: column too long for LDS");
   PosMlp pm{pos_mlp, heads};
   if (k <= 4)
     hipLaunchKernelGGL(sector_kp_attn_kernel<4>, dim3(batch * w), dim3(256), smem, pn::S(stream), q_raw, kv, xpos, kpos, pm, batch,
-                       h, w, c, k, shift, scale, out);
+                       h, w, c, k, shift, col_major != 0, scale, out);
   else
     hipLaunchKernelGGL(sector_kp_attn_kernel<8>, dim3(batch * w), dim3(256), smem, pn::S(stream), q_raw, kv, xpos, kpos, pm, batch,
-                       h, w, c, k, shift, scale, out);
+                       h, w, c, k, shift, col_major != 0, scale, out);
   return pn::check_launch("sector_kp_attn_kernel");
 }
 
 int pn_setblock_range_attn(const float* qkv, const float* kpos, const float* pos_mlp, int batch, int w, int c, int heads, int k,
                            int win_w, float scale, float* out, pn_stream_t stream) {
   PN_REQUIRE(qkv && kpos && pos_mlp && out, "range_attn: null pointer");
-  PN_REQUIRE(heads >= 1 && heads <= 4 && c % heads == 0 && w % win_w == 0, "range_attn: bad sizes");
+  PN_REQUIRE(heads >= 1 && heads <= 4 && c % heads == 0 && w % win_w == 0 && (c / heads) % 4 == 0 && (k * win_w) % 4 == 0, "range_attn: bad sizes");
+  PN_REQUIRE(((uintptr_t)out & 15) == 0 && c % 4 == 0, "range_attn: 16-byte aligned output");
   const int n = k * win_w, hd = c / heads;
-  const size_t smem = (size_t)heads * (3 * n * hd + n * n) * sizeof(float);
+  const size_t smem = ((size_t)2 * n * (hd + 1) + (size_t)n * hd + (size_t)n * (n + 1) + 2 * n) * sizeof(float);
   PN_REQUIRE(smem <= 160 * 1024, "range_attn: window too large for LDS");
   static bool attr_done[64] = {false};
   if (pn::first_use_on_device(attr_done)) {
@@ -395,24 +481,26 @@ int pn_setblock_range_attn(const float* qkv, const float* kpos, const float* pos
                               160 * 1024);
   }
   PosMlp pm{pos_mlp, heads};
-  hipLaunchKernelGGL(range_attn_kernel, dim3(batch * (w / win_w)), dim3(256), smem, pn::S(stream), qkv, kpos, pm, batch, w, c, k,
+  hipLaunchKernelGGL(range_attn_kernel, dim3(batch * (w / win_w) * heads), dim3(256), smem, pn::S(stream), qkv, kpos, pm, batch, w, c, k,
                      win_w, scale, out);
   return pn::check_launch("range_attn_kernel");
 }
 
 int pn_setblock_sector_col_attn(const float* q, const float* kv_raw, const float* xpos, const float* kpos, const float* pos_mlp,
-                                int batch, int h, int w, int c, int heads, int k, int shift, float scale, float* out,
+                                int batch, int h, int w, int c, int heads, int k, int shift, int col_major, float scale, float* out,
                                 pn_stream_t stream) {
   PN_REQUIRE(q && kv_raw && xpos && kpos && pos_mlp && out, "sector_col_attn: null pointer");
-  PN_REQUIRE(heads >= 1 && c % heads == 0 && (c / heads) % 4 == 0 && k <= 8 && c % 4 == 0, "sector_col_attn: bad sizes");
-  const size_t smem = (size_t)2 * k * c * sizeof(float);
+  PN_REQUIRE(heads >= 1 && c % heads == 0 && (c / heads) % 4 == 0 && c / heads <= 64 && k <= 8 && c % 4 == 0, "sector_col_attn: bad sizes (head width <= 64)");
+  PN_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)out & 15) == 0, "sector_col_attn: 16-byte aligned buffers");
+  const size_t smem = ((size_t)2 * k * c + (size_t)h * k * heads) * sizeof(float);
+  PN_REQUIRE(smem <= 64 * 1024, "sector_col_attn: column too long for LDS");
   PosMlp pm{pos_mlp, heads};
   if (k <= 4)
     hipLaunchKernelGGL(sector_col_attn_kernel<4>, dim3(batch * w), dim3(256), smem, pn::S(stream), q, kv_raw, xpos, kpos, pm, batch,
-                       h, w, c, k, shift, scale, out);
+                       h, w, c, k, shift, col_major != 0, scale, out);
   else
     hipLaunchKernelGGL(sector_col_attn_kernel<8>, dim3(batch * w), dim3(256), smem, pn::S(stream), q, kv_raw, xpos, kpos, pm, batch,
-                       h, w, c, k, shift, scale, out);
+                       h, w, c, k, shift, col_major != 0, scale, out);
   return pn::check_launch("sector_col_attn_kernel");
 }
 

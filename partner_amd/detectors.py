@@ -459,28 +459,17 @@ class VoxelNetV3(SingleStageDetector):
     def realign(self, x: torch.Tensor) -> torch.Tensor:
         """x: logical (B, C=256, theta=256, r=144) dense BEV map -> same shape (voxelnet.py:210-221)"""
         hip.require_device(x)
-        xh = ops.to_nhwc(x)                      # (B, theta, r, C)
-        b, t, r, c = xh.shape
-        tok = torch.empty((b, r, t, c), dtype=torch.float32, device=x.device)
-        hip.call("pn_transpose_hw_f32", xh.data_ptr(), b, t, r, c, tok.data_ptr(), hip.stream())   # (B, r, theta, C)
-        y = tok.view(b, r * t, c)
-        for attn in self.attns:
-            y = attn(y)
-        out = torch.empty((b, t, r, c), dtype=torch.float32, device=x.device)
-        hip.call("pn_transpose_hw_f32", y.contiguous().data_ptr(), b, r, t, c, out.data_ptr(), hip.stream())
-        return ops.as_nchw(out)
+        return ops.as_nchw(self.realign_nhwc(ops.to_nhwc(x)))
 
     def realign_nhwc(self, xh: torch.Tensor) -> torch.Tensor:
-        """NHWC (B, theta, r, C) -> same, through the two SetBlocks (token order of the reference: r-major, voxelnet.py:210-221)"""
+        """NHWC (B, theta, r, C) -> same, through the two SetBlocks.  The reference permutes the map to range-major tokens and back
+        (voxelnet.py:211,219); the blocks here take the tokens in the map's own azimuth-major order (``SetBlock.forward_cols``), so
+        nothing is transposed -- element for element the same result (``test_setblock_column_major_equals_range_major``)."""
         b, t, r, c = xh.shape
-        tok = torch.empty((b, r, t, c), dtype=torch.float32, device=xh.device)
-        hip.call("pn_transpose_hw_f32", xh.data_ptr(), b, t, r, c, tok.data_ptr(), hip.stream())
-        y = tok.view(b, r * t, c)
+        y = xh.contiguous().view(b, t * r, c)
         for attn in self.attns:
-            y = attn(y)
-        out = torch.empty((b, t, r, c), dtype=torch.float32, device=xh.device)
-        hip.call("pn_transpose_hw_f32", y.contiguous().data_ptr(), b, r, t, c, out.data_ptr(), hip.stream())
-        return out
+            y = attn.forward_cols(y)
+        return y.view(b, t, r, c)
 
     def extract_feat_hard(self, data):
         """voxelnet.py:202-227: mean VFE -> sparse 3-D backbone -> 2 x SetBlock -> RPN; returns the NHWC neck output"""

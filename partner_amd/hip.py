@@ -118,10 +118,10 @@ SIGNATURES = {
     "pn_groupnorm_strat_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "pn_gemm_bias_act_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),
     "pn_layernorm_f32": (_I, [_P, _SZ, _I, _P, _P, _F, _P, _P, _P]),
-    "pn_setblock_keypoints": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
-    "pn_setblock_sector_kp_attn": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "pn_setblock_keypoints": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "pn_setblock_sector_kp_attn": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "pn_setblock_range_attn": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
-    "pn_setblock_sector_col_attn": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "pn_setblock_sector_col_attn": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "pn_swv_window_attn": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "pn_center_decode_nms_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "pn_center_decode_nms_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _P, _F, _I, _I, _I,
