@@ -459,6 +459,13 @@ size_t pn_linear_packed_weight_floats(int n, int k);
 int pn_pack_linear_weight_f32(const float *w_nk, int n, int k, float *packed, pn_stream_t stream);
 int pn_linear_f32(const float *x, int m, int k, int ldx, const float *packed_w, int n, const float *bias, int act,
                   const float *residual, int ldr, float *out, int ldo, pn_stream_t stream);
+/* The same contract on the K-split form (32 x 32 tiles, the block's four waves split K, partial tiles joined in LDS in a fixed order):
+ * for matrices of a few thousand rows -- the key-point chains of the SetBlock, set_transformer.py:307-354 on 4 x 256 key points per
+ * sample -- where tiles would leave most of the chip idle on a serial walk over K.  Its fp32 summation order differs from
+ * pn_linear_f32's (which adds in the order of the r2 convolution route, bit for bit), hence the separate entry: a caller's results
+ * never depend on a form picked behind its back. */
+int pn_linear_ksplit_f32(const float *x, int m, int k, int ldx, const float *packed_w, int n, const float *bias, int act,
+                         const float *residual, int ldr, float *out, int ldo, pn_stream_t stream);
 /* tuning hook (tools/linear_bench.py): pins the tile form of every following pn_linear_f32 of the process -- 22 / 21 / 12 / 11 =
  * (64 TM) x (64 TN) block tiles, 1 = the K-split form, 0 = automatic (default; also PN_LINEAR_TILE in the environment) */
 int pn_linear_set_tile(int form);
@@ -1055,7 +1062,7 @@ int pn_event_destroy(pn_event_t ev);
 int pn_event_record(pn_event_t ev, pn_stream_t stream);
 int pn_event_elapsed_ms(pn_event_t start, pn_event_t stop, float *ms); /* synchronises on stop */
 /* Arms the calling host thread: the NEXT convolution / GEMM launch of this thread (pn_conv2d_nhwc_f32,
- * pn_conv2d_nhwc_bf16, pn_conv2d_multi_f32, pn_gemm_bias_act_f32, pn_linear_f32, pn_sparse_conv_f32) attaches `start` / `stop` to the
+ * pn_conv2d_nhwc_bf16, pn_conv2d_multi_f32, pn_gemm_bias_act_f32, pn_linear_f32, pn_linear_ksplit_f32, pn_sparse_conv_f32) attaches `start` / `stop` to the
  * kernel dispatch itself (hipExtLaunchKernelGGL), so that pn_event_elapsed_ms(start, stop) is that kernel's execution
  * time -- what a rocprofv3 kernel trace reports -- without the launch gaps a pair of hipEventRecord calls around an eager
  * launch includes.  One shot; not usable while the stream is being captured into a hipGraph. */

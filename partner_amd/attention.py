@@ -106,20 +106,26 @@ class SetBlock(nn.Module):
     def _build_plan(self):
         a = self.attns
         G = ops.GemmLayer
+        S = lambda w, b: ops.GemmLayer(w, b, ksplit=True)   # noqa: E731 -- layers of the key-point chain: K x W = 1024 rows per sample
         dev = a.norm1.weight.device
 
-        def mlp(m):
-            return G(m.fc1.weight, m.fc1.bias), G(m.fc2.weight, m.fc2.bias)
+        def mlp(m, g):
+            return g(m.fc1.weight, m.fc1.bias), g(m.fc2.weight, m.fc2.bias)
+
+        def cat(*lins, ksplit=False):
+            w = torch.cat([l.weight.detach() for l in lins], 0)
+            b = torch.cat([l.bias.detach() for l in lins], 0) if lins[0].bias is not None else None
+            return ops.GemmLayer(w, b, ksplit=ksplit)
 
         s1, ra, s2 = a.sector_attn1, a.range_attn, a.sector_attn2
         return dict(
             pos=self.pos_cart.reshape(self.patches_resolution[0], self.patches_resolution[1], 2).to(dev).float().contiguous(),
-            s1_q=G(s1.proj_q.weight, s1.proj_q.bias), s1_kv=_cat_linear(s1.proj_k, s1.proj_v), s1_proj=G(s1.proj.weight, s1.proj.bias),
-            s1_mlp=mlp(s1.mlp), s1_pe=_fold_pos_mlp(s1.pos_embedding_cart),
-            ra_qkv=_cat_linear(ra.proj_q, ra.proj_k, ra.proj_v), ra_proj=G(ra.proj.weight, ra.proj.bias), ra_mlp=mlp(ra.mlp),
+            s1_q=S(s1.proj_q.weight, s1.proj_q.bias), s1_kv=cat(s1.proj_k, s1.proj_v), s1_proj=S(s1.proj.weight, s1.proj.bias),
+            s1_mlp=mlp(s1.mlp, S), s1_pe=_fold_pos_mlp(s1.pos_embedding_cart),
+            ra_qkv=cat(ra.proj_q, ra.proj_k, ra.proj_v, ksplit=True), ra_proj=S(ra.proj.weight, ra.proj.bias), ra_mlp=mlp(ra.mlp, S),
             ra_pe=_fold_pos_mlp(ra.pos_embedding_cart),
-            s2_q=G(s2.proj_q.weight, s2.proj_q.bias), s2_kv=_cat_linear(s2.proj_k, s2.proj_v), s2_pe=_fold_pos_mlp(s2.pos_embedding_cart),
-            proj=G(a.proj.weight, a.proj.bias), mlp=mlp(a.mlp))
+            s2_q=G(s2.proj_q.weight, s2.proj_q.bias), s2_kv=cat(s2.proj_k, s2.proj_v, ksplit=True), s2_pe=_fold_pos_mlp(s2.pos_embedding_cart),
+            proj=G(a.proj.weight, a.proj.bias), mlp=mlp(a.mlp, G))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (B, H*W, C) tokens (range-major, the reference's order) -> same shape"""

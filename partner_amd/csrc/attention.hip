@@ -169,101 +169,137 @@ __device__ __forceinline__ float group16_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// SectorAttention core (key points <- their azimuth column).  Block = (batch, rolled column),
-// wave = head.  q comes from the (B, K*W, C) buffer read through the reference's raw
-// reinterpretation as (B, C, K, W) (set_transformer.py:331-334); k|v is the (tokens, 2C) projection
+// SectorAttention core (key points <- their azimuth column).  Block = (batch, rolled column).  q comes from the (B, K*W, C) buffer
+// read through the reference's raw reinterpretation as (B, C, K, W) (set_transformer.py:331-334); k|v is the (tokens, 2C) projection
 // of the normalised tokens.  out: (B, K*W, C).
-// r3: the column is streamed in 16-byte pieces, FOUR rows per wave instruction (lane = (row mod 4, 4-channel group): 256 contiguous
-// bytes per row), partial dot products are reduced over the 16 lanes of a row; the relative-position bias of every (key point, row)
-// is formed once per head, up front, straight into the logit table.  (r2: one lane per row, 64-byte requests from 64 rows.)
+// r3: SIXTEEN waves per column -- wave = (head, quarter of the rows) -- because the kernel is a chain of latencies, not of bytes: one
+// block per column, and (r2) one wave per head walked the 144 rows in dependent steps (84 us for 75 MB).  The column is streamed in
+// 16-byte pieces, four rows per wave instruction (lane = (row mod 4, 4-channel group): 256 contiguous bytes per row), all of a wave's
+// loads of a phase in flight at once; partial dot products are reduced over the 16 lanes of a row; the relative-position bias of
+// every (key point, row) is formed once up front, straight into the logit table; the four row quarters of P V are joined in LDS in
+// a fixed order.
+constexpr int SKP_CH = 4;        // row chunks per column
+constexpr int SKP_UNR = 5;       // row groups (of 4) whose loads a wave keeps in flight
 template <int KT>
-__global__ __launch_bounds__(256) void sector_kp_attn_kernel(const float* __restrict__ qraw, const float* __restrict__ kv,
-                                                             const float* __restrict__ xpos, const float* __restrict__ kpos,
-                                                             PosMlp pm, int B, int H, int W, int C, int K, int shift, int cm,
-                                                             float scale, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void sector_kp_attn_kernel(const float* __restrict__ qraw, const float* __restrict__ kv,
+                                                              const float* __restrict__ xpos, const float* __restrict__ kpos,
+                                                              PosMlp pm, int B, int H, int W, int C, int K, int shift, int cm,
+                                                              float scale, float* __restrict__ out) {
   extern __shared__ float lds[];
   const int heads = pm.heads, hd = C / heads;
-  const int head = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int head = wv & 3, chunk = wv >> 2;
   const int b = blockIdx.x / W, wr = blockIdx.x % W, wp = (wr + shift) % W;
-  float* qs = lds + head * (K * hd + K * H);  // q[K][hd], p[K][H]
-  float* ps = qs + K * hd;
-  if (head >= heads) return;
+  float* qs = lds;                         // [heads][K][hd]
+  float* ps = qs + heads * K * hd;         // [heads][K][H]
+  float* part = ps + heads * K * H;        // [SKP_CH][heads][K][hd]
   const float* qb = qraw + (size_t)b * K * W * C;
-  for (int i = lane; i < K * hd; i += 64) {
-    const int k = i / hd, d = i - k * hd;
-    qs[i] = qb[((size_t)(head * hd + d) * K + k) * W + wr] * scale;
+  for (int i = tid; i < heads * K * hd; i += 1024) {
+    const int hh = i / (K * hd), r = i - hh * (K * hd), k = r / hd, d = r - k * hd;
+    qs[i] = qb[((size_t)(hh * hd + d) * K + k) * W + wr] * scale;
   }
-  // relative-position bias of (key point k, row h) for this head
-  for (int i = lane; i < K * H; i += 64) {
+  for (int i = tid; i < K * H; i += 1024) {
     const int k = i / H, h = i - k * H;
     const float px = xpos[((size_t)h * W + wp) * 2], py = xpos[((size_t)h * W + wp) * 2 + 1];
     const float* kp2 = kpos + (((size_t)b * K + k) * W + wr) * 2;
     float hid[16];
     pm.hidden(kp2[0] - px, kp2[1] - py, hid);
-    ps[i] = pm.out(hid, head);
+    for (int hh = 0; hh < heads; ++hh) ps[(hh * K + k) * H + h] = pm.out(hid, hh);
   }
   __syncthreads();
   const int rs = lane >> 4, d4 = lane & 15;
-  const bool dok = d4 * 4 < hd;
+  const bool dok = d4 * 4 < hd, live = head < heads;
   const size_t tstride = cm ? 1 : (size_t)W;        // token step between consecutive rows of the column
   const size_t t0 = tok(b, 0, wp, H, W, cm);
-  f32x4 qv[KT];
+  const int groups = (H + 3) >> 2, gpc = (groups + SKP_CH - 1) / SKP_CH;      // row groups, groups per chunk
+  const int g0 = chunk * gpc;
+  const float* kbase = kv + t0 * (2 * C) + (live ? head : 0) * hd + (dok ? d4 * 4 : 0);
+  const size_t rstep = tstride * (size_t)(2 * C);
+  float* psh = ps + (live ? head : 0) * K * H;
+  {
+    f32x4 qv[KT];
 #pragma unroll
-  for (int k = 0; k < KT; ++k) qv[k] = (k < K && dok) ? *reinterpret_cast<const f32x4*>(qs + k * hd + d4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-  // logits: four rows per step
-  for (int h0 = 0; h0 < H; h0 += 4) {
-    const int h = h0 + rs;
-    f32x4 kk = {0.f, 0.f, 0.f, 0.f};
-    if (h < H && dok) kk = *reinterpret_cast<const f32x4*>(kv + (t0 + (size_t)h * tstride) * (2 * C) + head * hd + d4 * 4);
+    for (int k = 0; k < KT; ++k) qv[k] = (k < K && dok && live) ? *reinterpret_cast<const f32x4*>(qs + (head * K + k) * hd + d4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u0 = 0; u0 < gpc; u0 += SKP_UNR) {
+      f32x4 kk[SKP_UNR];
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      if (k >= K) continue;
-      const float sum = group16_sum(dot4(qv[k], kk));
-      if (d4 == 0 && h < H) ps[k * H + h] += sum;
+      for (int u = 0; u < SKP_UNR; ++u) {
+        const int h = min(4 * (g0 + u0 + u) + rs, H - 1);
+        kk[u] = *reinterpret_cast<const f32x4*>(kbase + (size_t)h * rstep);
+      }
+#pragma unroll
+      for (int u = 0; u < SKP_UNR; ++u) {
+        const int g = g0 + u0 + u, h = 4 * g + rs;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          if (k >= K) continue;
+          const float sum = group16_sum(dok ? dot4(qv[k], kk[u]) : 0.f);
+          if (d4 == 0 && h < H && u0 + u < gpc && live) psh[k * H + h] += sum;
+        }
+      }
     }
   }
   __syncthreads();
-  // softmax over the rows, per key point
-  for (int k = 0; k < K; ++k) {
+  // softmax over the rows: one wave per (head, key point)
+  for (int pr = wv; pr < heads * K; pr += 16) {
+    float* row = ps + pr * H;
     float m = -FLT_MAX;
-    for (int h = lane; h < H; h += 64) m = fmaxf(m, ps[k * H + h]);
+    for (int h = lane; h < H; h += 64) m = fmaxf(m, row[h]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     float sum = 0.f;
     for (int h = lane; h < H; h += 64) {
-      const float e = expf(ps[k * H + h] - m);
-      ps[k * H + h] = e;
+      const float e = expf(row[h] - m);
+      row[h] = e;
       sum += e;
     }
     sum = pn::wave_sum(sum);
     const float inv = 1.f / sum;
-    for (int h = lane; h < H; h += 64) ps[k * H + h] *= inv;
+    for (int h = lane; h < H; h += 64) row[h] *= inv;
   }
   __syncthreads();
-  // out[k][d] = sum_h p[k][h] * v[h][d]: lane (rs, d4) adds the rows h = rs (mod 4), then the four row groups are joined
-  f32x4 acc[KT];
+  // partial out[k][d] over this wave's rows: lane (rs, d4) adds the rows h = rs (mod 4), then the four row residues are joined
+  {
+    f32x4 acc[KT];
 #pragma unroll
-  for (int k = 0; k < KT; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int h0 = 0; h0 < H; h0 += 4) {
-    const int h = h0 + rs;
-    if (h < H && dok) {
-      const f32x4 vv = *reinterpret_cast<const f32x4*>(kv + (t0 + (size_t)h * tstride) * (2 * C) + C + head * hd + d4 * 4);
+    for (int k = 0; k < KT; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u0 = 0; u0 < gpc; u0 += SKP_UNR) {
+      f32x4 vv[SKP_UNR];
 #pragma unroll
-      for (int k = 0; k < KT; ++k)
-        if (k < K) acc[k] += ps[k * H + h] * vv;
+      for (int u = 0; u < SKP_UNR; ++u) {
+        const int h = min(4 * (g0 + u0 + u) + rs, H - 1);
+        vv[u] = *reinterpret_cast<const f32x4*>(kbase + C + (size_t)h * rstep);
+      }
+#pragma unroll
+      for (int u = 0; u < SKP_UNR; ++u) {
+        const int h = 4 * (g0 + u0 + u) + rs;
+        const bool ok = h < H && u0 + u < gpc;
+        const int hc = min(h, H - 1);
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+          if (k < K) acc[k] += (ok ? psh[k * H + hc] : 0.f) * vv[u];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      if (k >= K) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[k][e];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        acc[k][e] = v;
+      }
+      if (rs == 0 && dok && live) *reinterpret_cast<f32x4*>(part + ((chunk * heads + head) * K + k) * hd + d4 * 4) = acc[k];
     }
   }
+  __syncthreads();
+  for (int i = tid; i < heads * K * hd; i += 1024) {
+    const int hh = i / (K * hd), r = i - hh * (K * hd), k = r / hd, d = r - k * hd;
+    float v = part[i];
 #pragma unroll
-  for (int k = 0; k < KT; ++k) {
-    if (k >= K) continue;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = acc[k][e];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      acc[k][e] = v;
-    }
-    if (rs == 0 && dok) *reinterpret_cast<f32x4*>(out + ((size_t)b * K * W + (size_t)k * W + wr) * C + head * hd + d4 * 4) = acc[k];
+    for (int c = 1; c < SKP_CH; ++c) v += part[c * heads * K * hd + i];
+    out[((size_t)b * K * W + (size_t)k * W + wr) * C + hh * hd + d] = v;
   }
 }
 
@@ -348,10 +384,10 @@ __global__ __launch_bounds__(256) void range_attn_kernel(const float* __restrict
 // r3: four rows per wave instruction (lane = (row mod 4, 4-channel group), one head per step: 256 contiguous bytes per row in and out),
 // 16-lane reductions for the four logits of a (row, head), the relative-position bias of every (row, key point, head) formed once up front.
 template <int KT>
-__global__ __launch_bounds__(256) void sector_col_attn_kernel(const float* __restrict__ q, const float* __restrict__ kvraw,
-                                                              const float* __restrict__ xpos, const float* __restrict__ kpos,
-                                                              PosMlp pm, int B, int H, int W, int C, int K, int shift, int cm,
-                                                              float scale, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void sector_col_attn_kernel(const float* __restrict__ q, const float* __restrict__ kvraw,
+                                                               const float* __restrict__ xpos, const float* __restrict__ kpos,
+                                                               PosMlp pm, int B, int H, int W, int C, int K, int shift, int cm,
+                                                               float scale, float* __restrict__ out) {
   extern __shared__ float lds[];  // kk[K][C], vv[K][C], bias[H][K][heads]
   const int heads = pm.heads, hd = C / heads;
   const int b = blockIdx.x / W, wr = blockIdx.x % W, wp = (wr + shift) % W;
@@ -364,10 +400,10 @@ __global__ __launch_bounds__(256) void sector_col_attn_kernel(const float* __res
   // (K*W*C) proj_k buffer: flat = ((c*K + k)*W + w)  ->  row = flat / C, col = flat % C.
   for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
     const int k = i / C, c = i - k * C;
-    const size_t flat = ((size_t)c * K + k) * W + wr;
-    const size_t row = flat / C, col = flat - row * C;
-    kk[i] = kvb[row * (2 * C) + col];
-    vv[i] = kvb[row * (2 * C) + C + col];
+    const unsigned flat = ((unsigned)c * K + k) * W + wr;
+    const unsigned row = flat / (unsigned)C, col = flat - row * C;
+    kk[i] = kvb[(size_t)row * (2 * C) + col];
+    vv[i] = kvb[(size_t)row * (2 * C) + C + col];
   }
   for (int i = threadIdx.x; i < H * K; i += blockDim.x) {
     const int h = i / K, k = i - h * K;
@@ -378,43 +414,55 @@ __global__ __launch_bounds__(256) void sector_col_attn_kernel(const float* __res
     for (int head = 0; head < heads; ++head) bt[(h * K + k) * heads + head] = pm.out(hid, head);
   }
   __syncthreads();
+  // sixteen waves per column (the kernel is latency-, not byte-bound: r2's one lane per row took 52 us for 75 MB): every wave takes the
+  // row groups g = wv, wv + 16, ... (4 rows each: lane = (row mod 4, 4-channel group), 256 contiguous bytes per row and head) with the
+  // q pieces of all heads (HT = 4 per pass) in flight before the first is used
+  const int nwv = blockDim.x >> 6;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, rs = lane >> 4, d4 = lane & 15;
   const bool dok = d4 * 4 < hd;
   const size_t tstride = cm ? 1 : (size_t)W;
   const size_t t0 = tok(b, 0, wp, H, W, cm);
-  for (int h0 = 4 * wv; h0 < H; h0 += 16) {
-    const int h = h0 + rs;
-    const bool ok = h < H && dok;
-    const float* qr = q + (t0 + (size_t)h * tstride) * C;
-    float* orow = out + (t0 + (size_t)h * tstride) * C;
-    for (int head = 0; head < heads; ++head) {
-      const int co = head * hd + d4 * 4;
-      f32x4 qq = {0.f, 0.f, 0.f, 0.f};
-      if (ok) qq = *reinterpret_cast<const f32x4*>(qr + co);
-      float lg[KT];
-      float m = -FLT_MAX;
+  constexpr int HT = 4;
+  for (int hp = 0; hp < heads; hp += HT) {
+    for (int h0 = 4 * wv; h0 < H; h0 += 4 * nwv) {
+      const int h = h0 + rs;
+      const int hc = min(h, H - 1);
+      const bool ok = h < H && dok;
+      const float* qr = q + (t0 + (size_t)hc * tstride) * C + (dok ? d4 * 4 : 0);
+      float* orow = out + (t0 + (size_t)hc * tstride) * C;
+      f32x4 qq[HT];
 #pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        if (k >= K) continue;
-        const float sum = group16_sum(dok ? dot4(qq, *reinterpret_cast<const f32x4*>(kk + k * C + co)) : 0.f);
-        lg[k] = sum * scale + (h < H ? bt[(h * K + k) * heads + head] : 0.f);
-        m = fmaxf(m, lg[k]);
-      }
-      float sum = 0.f;
+      for (int hh = 0; hh < HT; ++hh) qq[hh] = *reinterpret_cast<const f32x4*>(qr + min(hp + hh, heads - 1) * hd);
 #pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        if (k >= K) continue;
-        lg[k] = expf(lg[k] - m);
-        sum += lg[k];
-      }
-      const float inv = 1.f / sum;
-      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      for (int hh = 0; hh < HT; ++hh) {
+        const int head = hp + hh;
+        if (head >= heads) continue;
+        const int co = head * hd + (dok ? d4 * 4 : 0);
+        float lg[KT];
+        float m = -FLT_MAX;
 #pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        if (k >= K) continue;
-        if (dok) o += (lg[k] * inv) * *reinterpret_cast<const f32x4*>(vv + k * C + co);
+        for (int k = 0; k < KT; ++k) {
+          if (k >= K) continue;
+          const float sum = group16_sum(dok ? dot4(qq[hh], *reinterpret_cast<const f32x4*>(kk + k * C + co)) : 0.f);
+          lg[k] = sum * scale + bt[(hc * K + k) * heads + head];
+          m = fmaxf(m, lg[k]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          if (k >= K) continue;
+          lg[k] = expf(lg[k] - m);
+          sum += lg[k];
+        }
+        const float inv = 1.f / sum;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          if (k >= K) continue;
+          o += (lg[k] * inv) * *reinterpret_cast<const f32x4*>(vv + k * C + co);
+        }
+        if (ok) *reinterpret_cast<f32x4*>(orow + co) = o;
       }
-      if (ok) *reinterpret_cast<f32x4*>(orow + co) = o;
     }
   }
 }
@@ -455,14 +503,14 @@ int pn_setblock_sector_kp_attn(const float* q_raw, const float* kv, const float*
   PN_REQUIRE(q_raw && kv && xpos && kpos && pos_mlp && out, "sector_kp_attn: null pointer");
   PN_REQUIRE(heads >= 1 && heads <= 4 && c % heads == 0 && (c / heads) % 4 == 0 && c / heads <= 64 && k <= 8, "sector_kp_attn: bad sizes (head width <= 64)");
   PN_REQUIRE(((uintptr_t)kv & 15) == 0 && ((uintptr_t)out & 15) == 0 && c % 4 == 0, "sector_kp_attn: 16-byte aligned buffers");
-  const size_t smem = (size_t)heads * (k * (c / heads) + k * h) * sizeof(float);
+  const size_t smem = ((size_t)heads * k * (c / heads) * (1 + SKP_CH) + (size_t)heads * k * h) * sizeof(float);
   PN_REQUIRE(smem <= 64 * 1024, "sector_kp_attn: column too long for LDS");
   PosMlp pm{pos_mlp, heads};
   if (k <= 4)
-    hipLaunchKernelGGL(sector_kp_attn_kernel<4>, dim3(batch * w), dim3(256), smem, pn::S(stream), q_raw, kv, xpos, kpos, pm, batch,
+    hipLaunchKernelGGL(sector_kp_attn_kernel<4>, dim3(batch * w), dim3(1024), smem, pn::S(stream), q_raw, kv, xpos, kpos, pm, batch,
                        h, w, c, k, shift, col_major != 0, scale, out);
   else
-    hipLaunchKernelGGL(sector_kp_attn_kernel<8>, dim3(batch * w), dim3(256), smem, pn::S(stream), q_raw, kv, xpos, kpos, pm, batch,
+    hipLaunchKernelGGL(sector_kp_attn_kernel<8>, dim3(batch * w), dim3(1024), smem, pn::S(stream), q_raw, kv, xpos, kpos, pm, batch,
                        h, w, c, k, shift, col_major != 0, scale, out);
   return pn::check_launch("sector_kp_attn_kernel");
 }
@@ -496,10 +544,10 @@ int pn_setblock_sector_col_attn(const float* q, const float* kv_raw, const float
   PN_REQUIRE(smem <= 64 * 1024, "sector_col_attn: column too long for LDS");
   PosMlp pm{pos_mlp, heads};
   if (k <= 4)
-    hipLaunchKernelGGL(sector_col_attn_kernel<4>, dim3(batch * w), dim3(256), smem, pn::S(stream), q, kv_raw, xpos, kpos, pm, batch,
+    hipLaunchKernelGGL(sector_col_attn_kernel<4>, dim3(batch * w), dim3(1024), smem, pn::S(stream), q, kv_raw, xpos, kpos, pm, batch,
                        h, w, c, k, shift, col_major != 0, scale, out);
   else
-    hipLaunchKernelGGL(sector_col_attn_kernel<8>, dim3(batch * w), dim3(256), smem, pn::S(stream), q, kv_raw, xpos, kpos, pm, batch,
+    hipLaunchKernelGGL(sector_col_attn_kernel<8>, dim3(batch * w), dim3(1024), smem, pn::S(stream), q, kv_raw, xpos, kpos, pm, batch,
                        h, w, c, k, shift, col_major != 0, scale, out);
   return pn::check_launch("sector_col_attn_kernel");
 }

@@ -312,12 +312,17 @@ __global__ __launch_bounds__(256, OCC) void linear_kernel(LinArgs a) {
   }
 }
 
-// ---- small-M form: M x N split into 32 x 64 tiles, the block's four waves = 2 column halves x 2 K halves ... (see below)
-// (the key-point chains of the SetBlock: 1024 B rows) -- 32 x 32 per wave, K split over the four waves of a block, partial sums
-// joined through LDS in a fixed order (wave 0 + wave 1 + wave 2 + wave 3).  Both operands straight from global memory: the x
-// fragment of lane (i, h) is 16 contiguous bytes of row i, and with 32 rows per block nothing is shared between waves.
+// ---- small-M form (the key-point chains of the SetBlock: 1024 B rows, 2.5 % of the block's FLOPs but, launched as tiles, a third of
+// its time: 64 tiles on 256 CUs, each a serial walk over K).  Block tile 32 x 32, the four waves split K: per 256-wide K chunk the
+// block stages its 32 x rows through LDS with whole-row (1 KB) loads, wave ks multiplies k = 64 ks .. 64 ks + 63 of the chunk with
+// its W fragments straight from L2 (all eight requested before the first is used), and the four partial tiles are joined through
+// LDS in a fixed order (wave 0 + 1 + 2 + 3), every wave finishing a quarter of the rows.  The summation order differs from the
+// tiled forms', so this form has its own entry point (pn_linear_ksplit_f32) and is never picked behind the caller's back.
+constexpr int LS_CH = 256;              // K chunk
+constexpr int LS_LD = LS_CH + 4;        // floats per x row in LDS (16-byte slots of 16 rows distinct: 65 i mod 16)
+template <bool GELU>
 __global__ __launch_bounds__(256, 2) void linear_small_kernel(LinArgs a) {
-  __shared__ __attribute__((aligned(16))) float part[3][16][64];
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // two stages [32][LS_LD]; the join [4][16][64] reuses them
   const int tid = threadIdx.x, lane = tid & 63, ks = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int nt = blockIdx.x % a.ntiles, mt = blockIdx.x / a.ntiles;
@@ -325,48 +330,75 @@ __global__ __launch_bounds__(256, 2) void linear_small_kernel(LinArgs a) {
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
   const unsigned np16 = (unsigned)a.npad * 16u;
-  // wave ks takes the 8-wide k groups g = ks, ks + 4, ks + 8, ... (interleaved: every wave streams through the same cache lines)
-  const int groups = a.nsteps * 4;
-  const unsigned xo = m0 + li < a.M ? (unsigned)(m0 + li) * (unsigned)a.ldx * 4u + (unsigned)lh * 16u : 0xffffffffu;
+  const int nchunks = (a.K + LS_CH - 1) / LS_CH;
+  // loader: wave w, step j -> row w + 4 j, lane -> 16 bytes at k = 4 lane of the chunk (one whole 1 KB row piece per wave instruction)
+  unsigned xo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = m0 + ks + 4 * j;
+    xo[j] = row < a.M ? (unsigned)row * (unsigned)a.ldx * 4u + (unsigned)lane * 16u : 0xffffffffu;
+  }
   const unsigned bo = (unsigned)(lh * a.npad + n0 + li) * 16u;
+  f32x4 rx[8], bf[8];
+  auto load_x = [&](int c) {
+    const bool live = c < nchunks && c * LS_CH + lane * 4 < a.K;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, live ? xo[j] : 0xffffffffu, (unsigned)c * LS_CH * 4u, 0));
+  };
+  auto load_b = [&](int c) {      // this wave's eight k groups of chunk c: k4 index = 64 c + 16 ks + 2 g + lh (past the packed rows: zeros)
+#pragma unroll
+    for (int g = 0; g < 8; ++g) bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, c < nchunks ? bo : 0xffffffffu, (unsigned)(64 * c + 16 * ks + 2 * g) * np16, 0));
+  };
+  auto store_x = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(smem + buf * 32 * LS_LD + (ks + 4 * j) * LS_LD + lane * 4) = rx[j];
+  };
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  constexpr int PF = 4;     // k groups in flight per wave
-  f32x4 xa[PF], xb[PF];
-  auto issue = [&](int g, f32x4& fa, f32x4& fb) {
-    const bool live = g < groups && g * 8 + lh * 4 < a.K;
-    fa = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, live ? xo : 0xffffffffu, (unsigned)g * 32u, 0));
-    fb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, g < groups ? bo : 0xffffffffu, (unsigned)(2 * g) * np16, 0));
-  };
-#pragma unroll
-  for (int p = 0; p < PF; ++p) issue(ks + 4 * p, xa[p], xb[p]);
-  for (int g = ks; g < groups; g += 4 * PF) {
-#pragma unroll
-    for (int p = 0; p < PF; ++p) {
-      const f32x4 fa = xa[p], fb = xb[p];
-      issue(g + 4 * (p + PF), xa[p], xb[p]);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb[kk], acc, 0, 0, 0);
-    }
-  }
-  if (ks > 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part[ks - 1][r][lane] = acc[r];
-  }
+  load_b(0);
+  load_x(0);
+  store_x(0);
+  load_x(1);
   __syncthreads();
-  if (ks == 0) {
-    const int n = n0 + li;
-    const float b = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    f32x4 af[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = ((acc[r] + part[0][r][lane]) + part[1][r][lane]) + part[2][r][lane];
-      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m < a.M && n < a.N) {
-        v = pn::apply_act(v + b, a.act);
-        if (a.res) v += a.res[(size_t)m * a.ldr + n];
-        a.out[(size_t)m * a.ldo + n] = v;
-      }
+    for (int g = 0; g < 8; ++g) af[g] = *reinterpret_cast<const f32x4*>(smem + buf * 32 * LS_LD + li * LS_LD + 64 * ks + 8 * g + 4 * lh);
+    f32x4 cb[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) cb[g] = bf[g];
+    if (c + 1 < nchunks) {
+      load_b(c + 1);
+      store_x(buf ^ 1);       // chunk c + 1 (the other stage was last read in iteration c - 1, before that iteration's barrier)
+      load_x(c + 2);
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][kk], cb[g][kk], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  // join: every wave leaves its partial tile in LDS, wave d finishes accumulator registers 4 d .. 4 d + 3 (rows 8 d .. 8 d + 7)
+  float* part = smem;      // [4][16][64]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[(ks * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  const int n = n0 + li;
+  const float b = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+  const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = 4 * ks + rr;
+    float v = ((part[(0 * 16 + r) * 64 + lane] + part[(1 * 16 + r) * 64 + lane]) + part[(2 * 16 + r) * 64 + lane]) + part[(3 * 16 + r) * 64 + lane];
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    v += b;
+    if constexpr (GELU) v = gelu_erf(v);
+    else v = fmaxf(v, lo);
+    if (m < a.M && n < a.N) {
+      if (a.res) v += a.res[(size_t)m * a.ldr + n];
+      a.out[(size_t)m * a.ldo + n] = v;
     }
   }
 }
@@ -435,10 +467,8 @@ static double tile_cost(int tm, int tn, int k) {   // cycles of one round (two c
 static LinPlan linear_plan(int m, int n, int k, int ncu) {
   if (g_linear_tile < 0) { const char* e = getenv("PN_LINEAR_TILE"); g_linear_tile = e ? atoi(e) : 0; }
   if (g_linear_tile) return {g_linear_tile, 0, m};
-  // under half a round of big tiles (the 1k-row key-point chains): 64 x 64 tiles (measured 7-14 us on 2048 rows against 9-21 for the
-  // K-split form).  The K-split form is never picked automatically: its summation order differs from the tiled forms', and a result
-  // must not depend on how many samples share a launch (the key-point selection downstream is discontinuous:
-  // test_voxelnet_v3_batch_of_two); all tiled forms add in the same order, so the plan may depend on the row count.
+  // under half a round of big tiles: 64 x 64 tiles.  (The K-split form is never picked here: pn_linear_f32 keeps ONE summation order
+  // -- the tiled forms all add in the order of the r2 convolution route -- and pn_linear_ksplit_f32 is the explicit other one.)
   if ((long long)pn::cdiv(m, 128) * pn::cdiv(n, 128) * 2 <= ncu) return {11, 0, m};
   const long long slots = 2LL * ncu;
   auto rounds_cost = [&](int rows, int tm, int tn) {
@@ -473,8 +503,8 @@ int pn_linear_set_tile(int form) {
   return PN_OK;
 }
 
-int pn_linear_f32(const float* x, int m, int k, int ldx, const float* packed_w, int n, const float* bias, int act, const float* residual, int ldr,
-                  float* out, int ldo, pn_stream_t stream) {
+static int linear_launch(const float* x, int m, int k, int ldx, const float* packed_w, int n, const float* bias, int act, const float* residual, int ldr,
+                         float* out, int ldo, pn_stream_t stream, bool ksplit) {
   PN_REQUIRE(x && packed_w && out && m > 0 && k > 0 && n > 0, "linear: bad arguments");
   PN_REQUIRE(k % 4 == 0 && ldx % 4 == 0 && ldx >= k && ldo >= n, "linear: k and the row strides must be multiples of 4");
   PN_REQUIRE(n % 4 == 0 && ldo % 4 == 0 && (residual == nullptr || (ldr >= n && ldr % 4 == 0)), "linear: n and the output / residual strides must be multiples of 4");
@@ -508,14 +538,25 @@ int pn_linear_f32(const float* x, int m, int k, int ldx, const float* packed_w, 
   const bool prof = pn::take_profile_slot(slot);
   const pn::ProfileSlot* ps = prof ? &slot : nullptr;
   hipStream_t st = pn::S(stream);
-  const LinPlan plan = linear_plan(m, n, k, ncu);
+  const LinPlan plan = (ksplit && !g_linear_tile) ? LinPlan{1, 0, m} : linear_plan(m, n, k, ncu);
   a.M1 = plan.m1;
   if (plan.form == 1) {
     a.mtiles = pn::cdiv(m, 32);
     a.ntiles = pn::cdiv(n, 32);
     const dim3 grid((unsigned)(a.mtiles * a.ntiles));
-    if (ps) hipExtLaunchKernelGGL(linear_small_kernel, grid, dim3(256), 0, st, ps->start, ps->stop, 0, a);
-    else hipLaunchKernelGGL(linear_small_kernel, grid, dim3(256), 0, st, a);
+    const size_t smem = 2 * (size_t)32 * LS_LD * sizeof(float);
+    static bool done[64] = {false};
+    if (pn::first_use_on_device(done)) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_small_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_small_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    }
+    if (act == PN_ACT_GELU) {
+      if (ps) hipExtLaunchKernelGGL(linear_small_kernel<true>, grid, dim3(256), smem, st, ps->start, ps->stop, 0, a);
+      else hipLaunchKernelGGL(linear_small_kernel<true>, grid, dim3(256), smem, st, a);
+    } else {
+      if (ps) hipExtLaunchKernelGGL(linear_small_kernel<false>, grid, dim3(256), smem, st, ps->start, ps->stop, 0, a);
+      else hipLaunchKernelGGL(linear_small_kernel<false>, grid, dim3(256), smem, st, a);
+    }
     return pn::check_launch("linear_small_kernel");
   }
   switch (plan.form * 100 + plan.rest) {
@@ -526,6 +567,16 @@ int pn_linear_f32(const float* x, int m, int k, int ldx, const float* packed_w, 
     case 1100: return launch_linear<1, 1, 0, 0>(a, ncu, st, ps);
     default: return launch_linear<2, 2, 0, 0>(a, ncu, st, ps);
   }
+}
+
+int pn_linear_f32(const float* x, int m, int k, int ldx, const float* packed_w, int n, const float* bias, int act, const float* residual, int ldr,
+                  float* out, int ldo, pn_stream_t stream) {
+  return linear_launch(x, m, k, ldx, packed_w, n, bias, act, residual, ldr, out, ldo, stream, false);
+}
+
+int pn_linear_ksplit_f32(const float* x, int m, int k, int ldx, const float* packed_w, int n, const float* bias, int act, const float* residual,
+                         int ldr, float* out, int ldo, pn_stream_t stream) {
+  return linear_launch(x, m, k, ldx, packed_w, n, bias, act, residual, ldr, out, ldo, stream, true);
 }
 
 }  // extern "C"

@@ -849,12 +849,15 @@ class GemmLayer:
     """packed nn.Linear: y = act(x @ W^T + b) (+ residual) on the token-GEMM kernel (csrc/linear.hip: pn_linear_f32);
     ``PN_LINEAR=0`` keeps the r2 route through the MFMA convolution kernel (a 1x1 convolution)"""
 
-    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, ksplit: bool = False):
+        """``ksplit``: the layer runs on a few thousand rows at most (the key-point chains of the SetBlock): pn_linear_ksplit_f32, the
+        K-split form with its own fp32 summation order, for every call of this layer"""
         hip.require_device(weight)
         lib = hip.load()
         w = weight.detach().contiguous().float()
         self.n, self.k = w.shape
         self.linear = _LINEAR_ON and self.n % 4 == 0 and self.k % 4 == 0
+        self.entry = "pn_linear_ksplit_f32" if (ksplit and self.linear) else "pn_linear_f32" if self.linear else "pn_gemm_bias_act_f32"
         if self.linear:
             self.packed = _f32(lib.pn_linear_packed_weight_floats(self.n, self.k), w.device)
             hip.call("pn_pack_linear_weight_f32", w.data_ptr(), self.n, self.k, self.packed.data_ptr(), hip.stream())
@@ -872,7 +875,7 @@ class GemmLayer:
         prof = _PROFILER
         if prof is not None:
             ev = prof.begin(st)
-        hip.call("pn_linear_f32" if self.linear else "pn_gemm_bias_act_f32", x.data_ptr(), m, self.k, self.k, self.packed.data_ptr(), self.n,
+        hip.call(self.entry, x.data_ptr(), m, self.k, self.k, self.packed.data_ptr(), self.n,
                  hip.ptr(self.bias), int(act), hip.ptr(residual), self.n, out.data_ptr(), self.n, st)
         if prof is not None:
             prof.end(ev, 2.0 * m * self.n * self.k, st, tag=f"gemm {m}x{self.k}->{self.n}")

@@ -65,10 +65,11 @@ def test_linear_two_phase_plans(dev):
 
 
 def test_linear_matches_the_convolution_route_bitwise_on_plain_sums(dev):
-    """same fp32 FMA order as the r2 route (1x1 convolution on conv_mfma_kernel): identical bits where the epilogue is plain"""
+    """pn_linear_f32 adds in the same fp32 FMA order as the r2 route (1x1 convolution on conv_mfma_kernel) whatever tiles it picks:
+    identical bits where the epilogue is plain"""
     from partner_amd import ops
     g = torch.Generator().manual_seed(5)
-    x, w, b = torch.randn((4096, 256), generator=g).to(dev), (torch.randn((512, 256), generator=g) / 16).to(dev), torch.randn((512,), generator=g).to(dev)
+    x, w, b = torch.randn((16384, 256), generator=g).to(dev), (torch.randn((512, 256), generator=g) / 16).to(dev), torch.randn((512,), generator=g).to(dev)
     new = ops.GemmLayer(w, b)
     ops._LINEAR_ON = False
     try:
@@ -77,6 +78,25 @@ def test_linear_matches_the_convolution_route_bitwise_on_plain_sums(dev):
         ops._LINEAR_ON = True
     assert new.linear and not old.linear
     assert torch.equal(new(x), old(x))
+
+
+def test_linear_ksplit_entry(dev):
+    """pn_linear_ksplit_f32 (GemmLayer(ksplit=True)): the key-point chain shapes and ragged ones against float64; on more than one K chunk,
+    with and without bias / GELU / residual"""
+    from partner_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for (m, k, n, act, bias, res) in [(1024, 256, 256, "none", True, True), (2048, 256, 1024, "gelu", True, False), (2048, 1024, 256, "none", True, True),
+                                      (1024, 256, 768, "none", True, False), (77, 520, 36, "relu", False, True), (4096, 64, 512, "gelu", True, True)]:
+        x = torch.randn((m, k), generator=g)
+        w = torch.randn((n, k), generator=g) / np.sqrt(k)
+        b = torch.randn((n,), generator=g) if bias else None
+        r = torch.randn((m, n), generator=g) if res else None
+        layer = ops.GemmLayer(w.to(dev), None if b is None else b.to(dev), ksplit=True)
+        assert layer.entry == "pn_linear_ksplit_f32"
+        y = layer(x.to(dev), act={"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "gelu": ops.ACT_GELU}[act], residual=None if r is None else r.to(dev))
+        ref = reference(x, w, b, act, r)
+        err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (m, k, n, act, err)
 
 
 def test_linear_rejects_bad_arguments(dev):
