@@ -173,6 +173,8 @@ class SetBlock(nn.Module):
         s2 = p["ra_proj"](o2, residual=s1)
         s2 = p["ra_mlp"][1](p["ra_mlp"][0](ln(s2, a.range_attn.norm2), act=ops.ACT_GELU), residual=s2)
         # sector attention 2: column <- key points
+        # (measured and dropped, r3: the query projection on a second stream beside the key-point chain -- one block per CU so that the
+        # chain's kernels still get dispatched -- 1.442 against 1.423 ms for the two blocks in one hipGraph: nothing to win)
         q3, kv3 = p["s2_q"](xn), p["s2_kv"](s2)
         o3 = torch.empty_like(x2)
         hip.call("pn_setblock_sector_col_attn", q3.data_ptr(), kv3.data_ptr(), p["pos"].data_ptr(), kpos.data_ptr(),

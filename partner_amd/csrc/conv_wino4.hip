@@ -44,6 +44,23 @@ constexpr int W4_LD = 36;       // floats per (position, quad) row of the A imag
 // have to wait -- the counter returns in order -- for every output store issued before it)
 constexpr size_t wino4_smem(int quads) { return (2 * (size_t)(6 * quads * W4_LD) + 2 * W4N) * sizeof(float); }
 
+// B^T d for four channels at once, in 13 fused multiply-adds / adds per channel (r2: 18 separate multiplies and adds -- the build runs
+// with -ffp-contract=off -- and on this chip a VALU instruction is not hidden behind another wave's fp32 MFMAs: the two share the SIMD's
+// fp32 lanes, tools/micro/mfma_valu_coexec.hip).  Vector-wide fma: the compiler emits v_pk_fma_f32 / v_pk_add_f32, two channels each.
+//   v0 = 4 d0 - 5 d2 + d4,  v1 = e + o,  v2 = e - o  (e = d4 - 4 d2, o = d3 - 4 d1),  v3 = f + g,  v4 = f - g  (f = d4 - d2,
+//   g = 2 (d3 - d1)),  v5 = 4 d1 - 5 d3 + d5
+__device__ __forceinline__ void wino4_input_transform(const f32x4 (&d)[6], f32x4 (&v)[6]) {
+  const f32x4 c4 = {4.f, 4.f, 4.f, 4.f}, m4 = {-4.f, -4.f, -4.f, -4.f}, m5 = {-5.f, -5.f, -5.f, -5.f}, c2 = {2.f, 2.f, 2.f, 2.f}, m2 = {-2.f, -2.f, -2.f, -2.f};
+  const f32x4 e = __builtin_elementwise_fma(m4, d[2], d[4]), o = __builtin_elementwise_fma(m4, d[1], d[3]);
+  const f32x4 f = d[4] - d[2], t = d[3] - d[1];
+  v[0] = __builtin_elementwise_fma(c4, d[0], __builtin_elementwise_fma(m5, d[2], d[4]));
+  v[1] = e + o;
+  v[2] = e - o;
+  v[3] = __builtin_elementwise_fma(c2, t, f);
+  v[4] = __builtin_elementwise_fma(m2, t, f);
+  v[5] = __builtin_elementwise_fma(c4, d[1], __builtin_elementwise_fma(m5, d[3], d[5]));
+}
+
 struct Wino4Args {
   const float* in;
   const float* w;
@@ -138,15 +155,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
       float* As = smem + buf * WA_FLOATS + (pl + PSTEP * k) * W4_LD + c4 * 4;
-      const f32x4 d0 = ra[k][0], d1 = ra[k][1], d2 = ra[k][2], d3 = ra[k][3], d4 = ra[k][4], d5 = ra[k][5];
-      const f32x4 e = d4 - 4.f * d2, o = d3 - 4.f * d1;          // v1 = e + o, v2 = e - o
-      const f32x4 f = d4 - d2, g = 2.f * (d3 - d1);               // v3 = f + g, v4 = f - g
-      *reinterpret_cast<f32x4*>(As + 0 * WQ * W4_LD) = (4.f * d0 - 5.f * d2) + d4;
-      *reinterpret_cast<f32x4*>(As + 1 * WQ * W4_LD) = e + o;
-      *reinterpret_cast<f32x4*>(As + 2 * WQ * W4_LD) = e - o;
-      *reinterpret_cast<f32x4*>(As + 3 * WQ * W4_LD) = f + g;
-      *reinterpret_cast<f32x4*>(As + 4 * WQ * W4_LD) = f - g;
-      *reinterpret_cast<f32x4*>(As + 5 * WQ * W4_LD) = (4.f * d1 - 5.f * d3) + d5;
+      f32x4 v[6];
+      wino4_input_transform(ra[k], v);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(As + q * WQ * W4_LD) = v[q];
     }
   };
   // this lane's weight fragments of one sub-step: one per position.  packed [chunk][kh][q 6][k4 8][cout_pad][4]
@@ -390,15 +402,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_ks_kernel(Wino4Args a) {
   };
   auto store_a = [&](int buf) {
     float* As = smem + buf * WA_FLOATS + pl * W4_LD + c4 * 4;
-    const f32x4 d0 = ra[0], d1 = ra[1], d2 = ra[2], d3 = ra[3], d4 = ra[4], d5 = ra[5];
-    const f32x4 e = d4 - 4.f * d2, o = d3 - 4.f * d1;
-    const f32x4 f = d4 - d2, g = 2.f * (d3 - d1);
-    *reinterpret_cast<f32x4*>(As + 0 * WQ * W4_LD) = (4.f * d0 - 5.f * d2) + d4;
-    *reinterpret_cast<f32x4*>(As + 1 * WQ * W4_LD) = e + o;
-    *reinterpret_cast<f32x4*>(As + 2 * WQ * W4_LD) = e - o;
-    *reinterpret_cast<f32x4*>(As + 3 * WQ * W4_LD) = f + g;
-    *reinterpret_cast<f32x4*>(As + 4 * WQ * W4_LD) = f - g;
-    *reinterpret_cast<f32x4*>(As + 5 * WQ * W4_LD) = (4.f * d1 - 5.f * d3) + d5;
+    f32x4 v[6];
+    wino4_input_transform(ra, v);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(As + q * WQ * W4_LD) = v[q];
   };
   unsigned so_b = 0;
   auto b_step_offset = [&]() { return (unsigned)((lb_chunk * 3 + lb_kh) * 48) * cp16; };

@@ -77,6 +77,29 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 // One PHASE of a launch: the rows [row_lo, row_hi) of the output in (64 TM) x (64 TN) tiles, persistent blocks, XCD-local tile runs.
+// four values at once: the polynomial and the products as vector-wide fma (v_pk_fma_f32: two values per instruction)
+__device__ __forceinline__ f32x4 gelu_erf4(const f32x4 x) {
+  auto splat = [](float c) { return f32x4{c, c, c, c}; };
+  const f32x4 z = __builtin_elementwise_abs(x) * splat(0.70710678118654752f);
+  const f32x4 u = __builtin_elementwise_fma(splat(0.5f), z, splat(1.f));
+  const f32x4 t = {__builtin_amdgcn_rcpf(u[0]), __builtin_amdgcn_rcpf(u[1]), __builtin_amdgcn_rcpf(u[2]), __builtin_amdgcn_rcpf(u[3])};
+  f32x4 p = __builtin_elementwise_fma(t, splat(0.17087277f), splat(-0.82215223f));
+  p = __builtin_elementwise_fma(t, p, splat(1.48851587f));
+  p = __builtin_elementwise_fma(t, p, splat(-1.13520398f));
+  p = __builtin_elementwise_fma(t, p, splat(0.27886807f));
+  p = __builtin_elementwise_fma(t, p, splat(-0.18628806f));
+  p = __builtin_elementwise_fma(t, p, splat(0.09678418f));
+  p = __builtin_elementwise_fma(t, p, splat(0.37409196f));
+  p = __builtin_elementwise_fma(t, p, splat(1.00002368f));
+  p = __builtin_elementwise_fma(t, p, splat(-1.26551223f));
+  const f32x4 a = __builtin_elementwise_fma(-z, z, p) * splat(1.44269504088896341f);
+  const f32x4 e = t * f32x4{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1]), __builtin_amdgcn_exp2f(a[2]), __builtin_amdgcn_exp2f(a[3])};
+  f32x4 w;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = x[i] >= 0.f ? 2.f - e[i] : e[i];
+  return splat(0.5f) * x * w;
+}
+
 template <int TM, int TN, bool GELU>
 __device__ __forceinline__ void linear_phase(const LinArgs& a, const int row_lo, const int row_hi, float* smem) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -238,8 +261,7 @@ __device__ __forceinline__ void linear_phase(const LinArgs& a, const int row_lo,
         if (p + 1 < NP) rnext = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, roff(p + 1), 0, 0));
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + (p * RPP + rrow) * TLD + q * 4) + bias4;
         if constexpr (GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          v = gelu_erf4(v);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
@@ -415,7 +437,7 @@ __global__ void pack_linear_weight_kernel(const float* __restrict__ w, int n, in
 }
 
 template <int TM, int TN, int TM2, int TN2, bool GELU>
-int launch_linear_t(const LinArgs& a, int ncu, hipStream_t st, const pn::ProfileSlot* ps) {
+int launch_linear_t(const LinArgs& a, int ncu, hipStream_t st, const pn::ProfileSlot* ps, int blocks_per_cu) {
   constexpr int OCC = 2;
   constexpr int BM = 64 * TM, BN = 64 * TN;
   auto floats = [](int tm, int tn) { return std::max<size_t>(2 * (size_t)64 * tm * LA_LD, 4 * 32 * (size_t)(tn * 32 + 4)); };   // two x stages; the epilogue's slabs reuse them
@@ -425,15 +447,16 @@ int launch_linear_t(const LinArgs& a, int ncu, hipStream_t st, const pn::Profile
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<TM, TN, TM2, TN2, OCC, GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   long long tiles = (long long)pn::cdiv(a.M1, BM) * pn::cdiv(a.N, BN);
   if (TM2 > 0 && a.M1 < a.M) tiles = std::max(tiles, (long long)pn::cdiv(a.M - a.M1, 64 * std::max(TM2, 1)) * pn::cdiv(a.N, 64 * std::max(TN2, 1)));
-  const dim3 grid((unsigned)std::min<long long>((long long)OCC * ncu, (tiles + 7) / 8 * 8));
+  const dim3 grid((unsigned)std::min<long long>((long long)blocks_per_cu * ncu, (tiles + 7) / 8 * 8));
   if (ps) hipExtLaunchKernelGGL((linear_kernel<TM, TN, TM2, TN2, OCC, GELU>), grid, dim3(256), smem, st, ps->start, ps->stop, 0, a);
   else hipLaunchKernelGGL((linear_kernel<TM, TN, TM2, TN2, OCC, GELU>), grid, dim3(256), smem, st, a);
   return pn::check_launch("linear_kernel");
 }
 
 template <int TM, int TN, int TM2, int TN2>
-int launch_linear(const LinArgs& a, int ncu, hipStream_t st, const pn::ProfileSlot* ps) {
-  return a.act == PN_ACT_GELU ? launch_linear_t<TM, TN, TM2, TN2, true>(a, ncu, st, ps) : launch_linear_t<TM, TN, TM2, TN2, false>(a, ncu, st, ps);
+int launch_linear(const LinArgs& a, int ncu, hipStream_t st, const pn::ProfileSlot* ps, int blocks_per_cu = 2) {
+  return a.act == PN_ACT_GELU ? launch_linear_t<TM, TN, TM2, TN2, true>(a, ncu, st, ps, blocks_per_cu)
+                              : launch_linear_t<TM, TN, TM2, TN2, false>(a, ncu, st, ps, blocks_per_cu);
 }
 
 }  // namespace
@@ -503,8 +526,10 @@ int pn_linear_set_tile(int form) {
   return PN_OK;
 }
 
+enum { LIN_TILED = 0, LIN_KSPLIT = 1 };
 static int linear_launch(const float* x, int m, int k, int ldx, const float* packed_w, int n, const float* bias, int act, const float* residual, int ldr,
-                         float* out, int ldo, pn_stream_t stream, bool ksplit) {
+                         float* out, int ldo, pn_stream_t stream, int mode) {
+  const bool ksplit = mode == LIN_KSPLIT;
   PN_REQUIRE(x && packed_w && out && m > 0 && k > 0 && n > 0, "linear: bad arguments");
   PN_REQUIRE(k % 4 == 0 && ldx % 4 == 0 && ldx >= k && ldo >= n, "linear: k and the row strides must be multiples of 4");
   PN_REQUIRE(n % 4 == 0 && ldo % 4 == 0 && (residual == nullptr || (ldr >= n && ldr % 4 == 0)), "linear: n and the output / residual strides must be multiples of 4");
@@ -571,12 +596,12 @@ static int linear_launch(const float* x, int m, int k, int ldx, const float* pac
 
 int pn_linear_f32(const float* x, int m, int k, int ldx, const float* packed_w, int n, const float* bias, int act, const float* residual, int ldr,
                   float* out, int ldo, pn_stream_t stream) {
-  return linear_launch(x, m, k, ldx, packed_w, n, bias, act, residual, ldr, out, ldo, stream, false);
+  return linear_launch(x, m, k, ldx, packed_w, n, bias, act, residual, ldr, out, ldo, stream, LIN_TILED);
 }
 
 int pn_linear_ksplit_f32(const float* x, int m, int k, int ldx, const float* packed_w, int n, const float* bias, int act, const float* residual,
                          int ldr, float* out, int ldo, pn_stream_t stream) {
-  return linear_launch(x, m, k, ldx, packed_w, n, bias, act, residual, ldr, out, ldo, stream, true);
+  return linear_launch(x, m, k, ldx, packed_w, n, bias, act, residual, ldr, out, ldo, stream, LIN_KSPLIT);
 }
 
 }  // extern "C"

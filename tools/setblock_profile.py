@@ -29,4 +29,16 @@ for i in range(iters + 3):
         y = b.forward_cols(y)
 e1.record()
 torch.cuda.synchronize()
-print(f"2 x SetBlock, B = {B}: {e0.elapsed_time(e1) / iters:.3f} ms per pass ({iters} iterations after 3 warm-ups)")
+print(f"2 x SetBlock, B = {B}: {e0.elapsed_time(e1) / iters:.3f} ms per pass, eager ({iters} iterations after 3 warm-ups)")
+from partner_amd.utils import legs
+
+
+def run():
+    y = x
+    for b in blks:
+        y = b.forward_cols(y)
+    return y
+
+
+ms, how = legs.graph_time_ms(run, iters, 3)
+print(f"2 x SetBlock, B = {B}: {ms:.3f} ms per pass, {how}  ({123.2 * B / ms:.1f} TFLOP/s on 123.2 GFLOP per sample = {123.2 * B / ms / 157.3:.3f} of the fp32 MFMA peak)")
