@@ -634,9 +634,26 @@ def adam_decoupled_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, t: int, lr: 
 # H3  E2ESWVoteHead (geometry-aware head)   det3d/models/bbox_heads/e2e_swv_head.py:22-201
 #     SwinTransformer / BasicLayer / SwinTransformerBlock / WindowAttention / PatchEmbed
 #                                           det3d/models/bbox_heads/swin_utils/sw2votev4_util.py:42-419
-# PARITY UNPINNED BY THE REFERENCE: the head cannot be constructed or run there (SURVEY F3:
+# PARITY PARTLY PINNED: the head as a whole cannot be constructed or run in the reference (SURVEY F3:
 # unregistered, typos such as `kernal_size`, `.contiuous()`, `torch.maixmum`, undefined names,
-# layers never appended).  This is the build's repaired reading of the intended computation:
+# layers never appended), but these parts of sw2votev4_util.py DO execute and are pinned by
+# tests/golden/swv_fragments.npz (generated from the reference by make_golden.py::gen_swv_fragments,
+# checked by tests/test_oracle_swv_fragments.py and, for the HIP path, tests/test_hip_swv.py):
+#   PINNED to reference outputs
+#     window_partition / window_reverse  :28-39    -> _window_partition / _window_reverse
+#     MLP.forward                        :19-25    -> swv_mlp
+#     PatchEmbed.forward (1 x 1 + LN)    :405-419  -> swv_patch_embed
+#     SwinTransformerBlock.forward       :125-188  -> swv_swin_block: norm1, zero padding to window multiples (padded tokens
+#                                                     are KEYS), cyclic shift, partition, reverse, shift back, crop, residual,
+#                                                     norm2 + MLP + residual -- run in the reference around a stand-in
+#                                                     attention (masked uniform average = the real attention at q = k = 0,
+#                                                     v = x, proj = I, vote / position MLPs zero)
+#   REPAIRS (the build's reading; not executable in the reference, HIP-vs-oracle only)
+#     WindowAttention.__init__ / forward :42-103   -> swv_window_attention (cosine attention / clamp(tau), rpe MLP, vote embedding)
+#     BasicLayer.forward's shift mask    :262-276  -> _swin_shift_mask (the reference fills a BOOL image and subtracts bool tensors)
+#     SwinTransformer wiring             :331-353  -> e2e_swv_head (one BasicLayer + norm0), E2ESWVoteHead.__init__ / forward
+#                                                     (e2e_swv_head.py:22-201: head branches, offset grid)
+# The repaired reading of the intended computation:
 #   * key names follow the config file (`kernel_size`, `sl_depth`, `weight_dict`);
 #   * SwinTransformer = PatchEmbed(1x1 conv + LayerNorm) + ONE BasicLayer(depth 2, shift 0 / 3)
 #     + LayerNorm `norm0` (sw2votev4_util.py:331-353 builds the layer but never appends it);
@@ -681,6 +698,18 @@ def _window_reverse(win: Tensor, ws: int, H: int, W: int) -> Tensor:
     B = int(win.shape[0] / (H * W / ws / ws))
     x = win.view(B, H // ws, W // ws, ws, ws, -1)
     return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(B, H, W, -1)
+
+
+def swv_mlp(sd: SD, p: str, x: Tensor) -> Tensor:
+    """MLP.forward (sw2votev4_util.py:19-25), dropout off; pinned by swv_fragments.npz"""
+    return F.linear(F.gelu(F.linear(x, sd[p + "fc1.weight"], sd[p + "fc1.bias"])), sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+
+
+def swv_patch_embed(sd: SD, p: str, x: Tensor) -> Tensor:
+    """PatchEmbed.forward with patch_size 1 and LayerNorm (sw2votev4_util.py:405-419): (B, Cin, H, W) -> tokens (B, H*W, C);
+    pinned by swv_fragments.npz"""
+    t = F.conv2d(x, sd[p + "proj.weight"], sd[p + "proj.bias"]).flatten(2).transpose(1, 2)
+    return F.layer_norm(t, (t.shape[-1],), sd[p + "norm.weight"], sd[p + "norm.bias"])
 
 
 def swv_window_attention(sd: SD, p: str, x: Tensor, mask, pos: Tensor, vote: Tensor, heads: int) -> Tensor:
@@ -733,8 +762,7 @@ def swv_swin_block(sd: SD, p: str, x: Tensor, H: int, W: int, pos: Tensor, vote:
     y = y[:, :H, :W, :].contiguous().view(B, H * W, C)
     x = shortcut + y
     z = F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"])
-    z = F.linear(F.gelu(F.linear(z, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])), sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
-    return x + z
+    return x + swv_mlp(sd, p + "mlp.", z)
 
 
 def e2e_swv_head(sd: SD, prefix: str, x: Tensor, offset_grid: Tensor, window=7, depth=2, heads=4, iou=True,
@@ -754,9 +782,8 @@ def e2e_swv_head(sd: SD, prefix: str, x: Tensor, offset_grid: Tensor, window=7, 
     pos = offset_grid.expand(B, -1, -1, -1).flatten(2).transpose(1, 2)                  # (B, HW, 2)
     vote = torch.cat([centers, vote_cls], 1).flatten(2).transpose(1, 2)                 # (B, HW, 3)
     lp = p + "layer."
-    t = F.conv2d(x, sd[lp + "patch_embed.proj.weight"], sd[lp + "patch_embed.proj.bias"]).flatten(2).transpose(1, 2)
+    t = swv_patch_embed(sd, lp + "patch_embed.", x)
     C = t.shape[-1]
-    t = F.layer_norm(t, (C,), sd[lp + "patch_embed.norm.weight"], sd[lp + "patch_embed.norm.bias"])
     for i in range(depth):
         t = swv_swin_block(sd, f"{lp}layers.0.blocks.{i}.", t, H, W, pos, vote, window, 0 if i % 2 == 0 else window // 2, heads)
     t = F.layer_norm(t, (C,), sd[lp + "norm0.weight"], sd[lp + "norm0.bias"])

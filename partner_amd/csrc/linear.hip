@@ -77,29 +77,6 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 // One PHASE of a launch: the rows [row_lo, row_hi) of the output in (64 TM) x (64 TN) tiles, persistent blocks, XCD-local tile runs.
-// four values at once: the polynomial and the products as vector-wide fma (v_pk_fma_f32: two values per instruction)
-__device__ __forceinline__ f32x4 gelu_erf4(const f32x4 x) {
-  auto splat = [](float c) { return f32x4{c, c, c, c}; };
-  const f32x4 z = __builtin_elementwise_abs(x) * splat(0.70710678118654752f);
-  const f32x4 u = __builtin_elementwise_fma(splat(0.5f), z, splat(1.f));
-  const f32x4 t = {__builtin_amdgcn_rcpf(u[0]), __builtin_amdgcn_rcpf(u[1]), __builtin_amdgcn_rcpf(u[2]), __builtin_amdgcn_rcpf(u[3])};
-  f32x4 p = __builtin_elementwise_fma(t, splat(0.17087277f), splat(-0.82215223f));
-  p = __builtin_elementwise_fma(t, p, splat(1.48851587f));
-  p = __builtin_elementwise_fma(t, p, splat(-1.13520398f));
-  p = __builtin_elementwise_fma(t, p, splat(0.27886807f));
-  p = __builtin_elementwise_fma(t, p, splat(-0.18628806f));
-  p = __builtin_elementwise_fma(t, p, splat(0.09678418f));
-  p = __builtin_elementwise_fma(t, p, splat(0.37409196f));
-  p = __builtin_elementwise_fma(t, p, splat(1.00002368f));
-  p = __builtin_elementwise_fma(t, p, splat(-1.26551223f));
-  const f32x4 a = __builtin_elementwise_fma(-z, z, p) * splat(1.44269504088896341f);
-  const f32x4 e = t * f32x4{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1]), __builtin_amdgcn_exp2f(a[2]), __builtin_amdgcn_exp2f(a[3])};
-  f32x4 w;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = x[i] >= 0.f ? 2.f - e[i] : e[i];
-  return splat(0.5f) * x * w;
-}
-
 template <int TM, int TN, bool GELU>
 __device__ __forceinline__ void linear_phase(const LinArgs& a, const int row_lo, const int row_hi, float* smem) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -261,7 +238,8 @@ __device__ __forceinline__ void linear_phase(const LinArgs& a, const int row_lo,
         if (p + 1 < NP) rnext = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, roff(p + 1), 0, 0));
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + (p * RPP + rrow) * TLD + q * 4) + bias4;
         if constexpr (GELU) {
-          v = gelu_erf4(v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);      // (a vector-wide v_pk_fma form of the polynomial measured the same)
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);

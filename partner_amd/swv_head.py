@@ -224,21 +224,9 @@ class E2ESWVoteHead(nn.Module):
         plan["vote"][1](plan["vote"][0](xc), out=vote, out_channel_offset=0)
         plan["vote_cls"][1](plan["vote_cls"][0](xc), out=vote, out_channel_offset=2)
         L = self.layer
-        n = b * h * w
-        t = plan["patch"](x.view(n, cin))
-        t = ops.layernorm(t, L.patch_embed.norm.weight, L.patch_embed.norm.bias, L.patch_embed.norm.eps)
-        for bp in plan["blocks"]:
-            blk = bp["mod"]
-            y = ops.layernorm(t, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
-            qkv = bp["qkv"](y)
-            att = torch.empty((n, C), dtype=torch.float32, device=x.device)
-            hip.call("pn_swv_window_attn", qkv.data_ptr(), vote.data_ptr(), 4, plan["pos"].data_ptr(), hip.ptr(bp["qkv_bias"]),
-                     bp["vw1"].data_ptr(), bp["vb1"].data_ptr(), bp["vw2"].data_ptr(), bp["vb2"].data_ptr(), bp["rw1"].data_ptr(),
-                     bp["rb1"].data_ptr(), bp["rw2"].data_ptr(), bp["rb2"].data_ptr(), bp["tau"].data_ptr(), b, h, w, C, heads, ws,
-                     int(bp["shift"]), att.data_ptr(), hip.stream())
-            t = bp["proj"](att, residual=t)
-            z = ops.layernorm(t, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-            t = bp["fc2"](bp["fc1"](z, act=ops.ACT_GELU), residual=t)
+        t = self.patch_embed_tokens(x)
+        for i in range(len(plan["blocks"])):
+            t = self.swin_block_tokens(i, t, vote, b, h, w)
         feat = ops.layernorm(t, L.norm0.weight, L.norm0.bias, L.norm0.eps).view(b, h, w, C)
         fc = ops.to_bf16(feat) if bf16 else feat
         hm = plan["cls"][2](plan["cls"][1](plan["cls"][0](fc)), out_f32=True)
@@ -249,6 +237,36 @@ class E2ESWVoteHead(nn.Module):
             ret["iou"] = plan["iou"][1](plan["iou"][0](fc), out_f32=True)
         ret["_feat"] = feat
         return ret
+
+    def patch_embed_tokens(self, x: torch.Tensor) -> torch.Tensor:
+        """PatchEmbed with 1 x 1 patches + LayerNorm (sw2votev4_util.py:405-419; pinned to the reference by swv_fragments.npz):
+        NHWC (B, H, W, Cin) -> tokens (B*H*W, C)"""
+        plan = self._plan.get(self, self._build_plan)
+        L = self.layer
+        b, h, w, cin = x.shape
+        t = plan["patch"](x.contiguous().view(b * h * w, cin))
+        return ops.layernorm(t, L.patch_embed.norm.weight, L.patch_embed.norm.bias, L.patch_embed.norm.eps)
+
+    def swin_block_tokens(self, i: int, t: torch.Tensor, vote: torch.Tensor, b: int, h: int, w: int) -> torch.Tensor:
+        """block i of the Swin stage (SwinTransformerBlock.forward, sw2votev4_util.py:125-188) on tokens (B*H*W, C); ``vote``: the
+        (B, H, W, 4) map [pred_centers | vote_cls | pad] the attention kernel reads.  Zero padding to window multiples, the cyclic
+        shift, the window partition and their inverses are index arithmetic inside pn_swv_window_attn; the plumbing is pinned to
+        the reference's block by swv_fragments.npz (test_hip_swv.py::test_swin_stage_pieces_match_the_reference_fragments)."""
+        plan = self._plan.get(self, self._build_plan)
+        bp = plan["blocks"][i]
+        blk = bp["mod"]
+        C, heads, ws = self.layer.embed_dim, self.layer.num_heads, self.window_size
+        n = b * h * w
+        y = ops.layernorm(t, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+        qkv = bp["qkv"](y)
+        att = torch.empty((n, C), dtype=torch.float32, device=t.device)
+        hip.call("pn_swv_window_attn", qkv.data_ptr(), vote.data_ptr(), 4, plan["pos"].data_ptr(), hip.ptr(bp["qkv_bias"]),
+                 bp["vw1"].data_ptr(), bp["vb1"].data_ptr(), bp["vw2"].data_ptr(), bp["vb2"].data_ptr(), bp["rw1"].data_ptr(),
+                 bp["rb1"].data_ptr(), bp["rw2"].data_ptr(), bp["rb2"].data_ptr(), bp["tau"].data_ptr(), b, h, w, C, heads, ws,
+                 int(bp["shift"]), att.data_ptr(), hip.stream())
+        t = bp["proj"](att, residual=t)
+        z = ops.layernorm(t, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        return bp["fc2"](bp["fc1"](z, act=ops.ACT_GELU), residual=t)
 
     def forward(self, x, **kwargs):
         """logical (B,C,H,W) in; {'det_preds': [dict of logical (B,c,H,W) views]} as e2e_swv_head.py:150-173"""

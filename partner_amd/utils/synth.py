@@ -171,6 +171,18 @@ def _rng_for(name: str, base_seed: int) -> np.random.Generator:
     return np.random.default_rng([base_seed, zlib.crc32(name.encode())])
 
 
+def seeded_normal(name: str, shape, base_seed: int = 0, scale: float = 1.0) -> np.ndarray:
+    """deterministic N(0, scale) float32 array keyed by a name: test inputs that fixtures need not store"""
+    return (scale * _rng_for(name, base_seed).standard_normal(tuple(shape))).astype(np.float32)
+
+
+class Shape:
+    """stand-in with a ``.shape`` for ``fill_state_dict`` (weights of a module that is not built here)"""
+
+    def __init__(self, *shape):
+        self.shape = tuple(shape)
+
+
 def fill_state_dict(state: "OrderedDict[str, object]", base_seed: int = 0) -> "OrderedDict[str, np.ndarray]":
     """Deterministic, name-keyed values for every entry of a ``state_dict``.
 

@@ -877,7 +877,70 @@ def gen_double_flip():
     save("double_flip.npz", **out)
 
 
+def gen_swv_fragments():
+    """The pieces of the geometry-aware head's Swin stage that DO execute in the reference (sw2votev4_util.py): ``window_partition`` /
+    ``window_reverse`` (:28-39), ``MLP`` (:9-25), ``PatchEmbed`` (:390-419) and the whole of ``SwinTransformerBlock.forward`` (:125-188:
+    norm1 -> zero padding to window multiples -> cyclic shift -> window partition -> attention -> reverse -> shift back -> crop ->
+    residual -> norm2 -> MLP -> residual) -- the latter run as it stands in the reference with ONE substitution: its ``self.attn``
+    (``WindowAttention``, whose constructor and forward cannot run: ``kernal_size``, ``.contiuous()``, ``torch.maixmum``, undefined ``B``)
+    is replaced by the stand-in below, a masked uniform average over the window.  That is exactly what the real attention computes when
+    q = k = 0, v = x, proj = identity and the vote / position MLPs are zero, so the oracle and the HIP kernels can be driven to the same
+    function through their weights and everything AROUND the attention is pinned to reference code.  The shift mask handed to the
+    block is ``oracle._swin_shift_mask`` (``BasicLayer.forward`` :262-276 builds it in a bool tensor and then subtracts bool tensors,
+    which torch refuses -- another piece that cannot run).
+    Inputs and weights are name-keyed seeded arrays (synth.seeded_normal / synth.load_filled, seed 77): the fixture holds OUTPUTS only.
+    Channel count 256 / 4 heads as in the PARTNER head (the HIP window attention is built for head width 64)."""
+    from det3d.models.bbox_heads.swin_utils import sw2votev4_util as U
+    from oracle import polar_oracle as O
+    SEED = 77
+    B, H, W, C, ws = 2, 9, 11, 256, 7
+    Hp = Wp = 14
+    T = lambda name, *shape: torch.from_numpy(synth.seeded_normal("swv_frag." + name, shape, SEED))  # noqa: E731
+    out = dict(dims=np.array([B, H, W, C, ws, Hp, Wp]), seed=np.int64(SEED))
+    # ---- window_partition / window_reverse on a padded map (8 channels)
+    xp = T("part_in", B, Hp, Wp, 8)
+    win = U.window_partition(xp, ws)
+    assert torch.equal(U.window_reverse(win, ws, Hp, Wp), xp)
+    out["part_out"] = win.numpy()
+    # ---- MLP (mlp_ratio 1, as the head builds it)
+    m = U.MLP(in_features=C, hidden_features=C).eval()
+    synth.load_filled(m, SEED)
+    with torch.no_grad():
+        out["mlp_out"] = m(T("mlp_in", 40, C)).numpy()
+    # ---- PatchEmbed: 1 x 1 patches + LayerNorm, as SwinTransformer builds it for the head (:316-320)
+    pe = U.PatchEmbed(patch_size=1, in_chans=2 * C, embed_dim=C, norm_layer=torch.nn.LayerNorm).eval()
+    synth.load_filled(pe, SEED)
+    with torch.no_grad():
+        out["pe_out"] = pe(T("pe_in", B, 2 * C, H, W)).numpy()
+
+    # ---- SwinTransformerBlock.forward around a stand-in attention
+    class MaskedMeanAttention(torch.nn.Module):      # OURS (not reference code): softmax(mask) @ x, the real attention at q = k = 0, v = x
+        def forward(self, x, mask=None, pos_embed=None, vote_embed=None):
+            B_, N, _ = x.shape
+            a = torch.zeros((B_, N, N))
+            if mask is not None:
+                nW = mask.shape[0]
+                a = (a.view(B_ // nW, nW, N, N) + mask.unsqueeze(0)).view(-1, N, N)
+            return a.softmax(dim=-1) @ x
+
+    x, pos, vote = T("blk_x", B, H * W, C), T("blk_pos", B, H * W, 2), T("blk_vote", B, H * W, 3)
+    for shift in (0, ws // 2):
+        blk = U.SwinTransformerBlock.__new__(U.SwinTransformerBlock)      # the constructor builds WindowAttention and fails there
+        torch.nn.Module.__init__(blk)
+        blk.dim, blk.num_heads, blk.window_size, blk.shift_size, blk.mlp_ratio = C, 4, ws, shift, 1.0
+        blk.norm1, blk.norm2 = torch.nn.LayerNorm(C), torch.nn.LayerNorm(C)
+        blk.attn, blk.drop_path = MaskedMeanAttention(), torch.nn.Identity()
+        blk.mlp = U.MLP(in_features=C, hidden_features=C)
+        blk.H, blk.W = H, W
+        blk.eval()
+        synth.load_filled(blk, SEED + 1 + shift)
+        mask = O._swin_shift_mask(Hp, Wp, ws, shift) if shift else None
+        with torch.no_grad():
+            out[f"blk_y_shift{shift}"] = blk(x, mask, pos, vote).numpy()
+    save("swv_fragments.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static", "seg_head", "e2e", "stream", "stream_bdcp", "augment", "double_flip"]
+    which = sys.argv[1:] or ["index", "hard", "reader", "full", "small", "heads", "setblock", "optim", "assign", "sweeps", "pillar_static", "seg_head", "e2e", "stream", "stream_bdcp", "augment", "double_flip", "swv_fragments"]
     for w in which:
         globals()["gen_" + w]()
