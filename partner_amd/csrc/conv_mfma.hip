@@ -1151,9 +1151,119 @@ __device__ __forceinline__ void small_n_body(const ConvArgs& a, const int mtile,
   }
 }
 
+// r3: the 3x3 / stride 1 / pad 1 jobs on a TILE of 4 rows x 16 columns (lane = pixel, wave q = a quarter of the input channels as above).
+// r2 had every lane fetch its own nine 64-byte pieces: each input element crossed the L1 nine times, from 64 different lines per
+// wave instruction (41.7 us for the five branches of CenterHeadSinglePos, 55 MB fetched for 21 MB of input).  Here wave q stages the
+// 6 x 18 halo tile of its 16 channels through LDS once -- four lanes per pixel piece, 16 pieces per instruction, the producing
+// GroupNorm's relu(x A + B) applied on the way in (once per element, not once per tap; out-of-map pixels stay zero) -- and the nine
+// taps of a lane are ds_read_b128 at a pixel stride of 20 floats (16-byte slot 5 p mod 16: conflict-free over 16 consecutive pixels).
+constexpr int SNT_W = 16, SNT_H = 4, SNT_HW = SNT_W + 2, SNT_PX = (SNT_H + 2) * SNT_HW, SNT_LD = 20;
+template <int NOUT>
+__device__ __forceinline__ void small_n_tiled_body(const ConvArgs& a, const int tile, float (*part)[64][13], float* w_lds, float* xt_all) {
+  const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tx_n = a.OW / SNT_W, ty_n = a.OH / SNT_H;
+  const int b = tile / (tx_n * ty_n), tr = tile - b * (tx_n * ty_n), ty = tr / tx_n, tx = tr - ty * tx_n;
+  const int oh0 = ty * SNT_H, ow0 = tx * SNT_W;
+  const int cq = ((a.Cin + 15) / 16) * 4;                 // channels per wave: whole quads, at most 16 (Cin <= 64)
+  const int c0 = q * cq, c1 = min(a.Cin, c0 + cq);
+  float* xt = xt_all + q * (SNT_PX * SNT_LD);
+  // Both staging loops are branch-free (clamped addresses, values selected afterwards): every load of a thread is in flight before the
+  // first is used -- under a branch the compiler serialises them, one L2 round trip per iteration.
+  constexpr int XI = (SNT_PX * 4 + 63) / 64;      // tile items per lane: (halo pixel, channel quad of the wave's 16)
+  f32x4 xv[XI], t0[XI], t1[XI];
+  bool xin[XI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int idx = lane + 64 * i;
+    const int px = min(idx >> 2, SNT_PX - 1), cc = idx & 3;
+    const int hr = px / SNT_HW, hc = px - hr * SNT_HW;
+    const int ih = oh0 - 1 + hr, iw = ow0 - 1 + hc;
+    const int c = c0 + 4 * cc;
+    xin[i] = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W && c < c1;
+    const int ihc = min(max(ih, 0), a.H - 1), iwc = min(max(iw, 0), a.W - 1), ccl = min(c, a.Cin - 4);
+    xv[i] = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.H + ihc) * a.W + iwc) * a.in_ps + a.in_co + ccl);
+    if (a.ni_ab) {      // wave-uniform: the producing norm's (A, B) pairs of the four channels
+      const float* tab = a.ni_ab + ((size_t)b * a.ni_C + ccl) * 2;
+      t0[i] = *reinterpret_cast<const f32x4*>(tab);
+      t1[i] = *reinterpret_cast<const f32x4*>(tab + 4);
+    }
+  }
+  {  // the job's weights: packed global [tap][cin_pad/4][cout_pad][4] -> LDS [tap][16 quads][NOUT][4]
+    const int quads = a.cin_chunks * 8;
+    constexpr int WI = (9 * 16 * NOUT + 255) / 256;
+    f32x4 wv[WI];
+#pragma unroll
+    for (int k = 0; k < WI; ++k) {
+      const int i = min((int)threadIdx.x + 256 * k, 9 * 16 * NOUT - 1);
+      const int n = i % NOUT, qd = (i / NOUT) % 16, t = i / (NOUT * 16);
+      const bool ok = qd < quads && n < a.cout_pad;
+      wv[k] = *reinterpret_cast<const f32x4*>(a.w + (((size_t)t * quads + min(qd, quads - 1)) * a.cout_pad + min(n, a.cout_pad - 1)) * 4);
+      if (!ok) wv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < WI; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < 9 * 16 * NOUT) *reinterpret_cast<f32x4*>(w_lds + (size_t)i * 4) = wv[k];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int idx = lane + 64 * i;
+    f32x4 v = xv[i];
+    if (a.ni_ab) {
+      v[0] = fmaxf(fmaf(v[0], t0[i][0], t0[i][1]), 0.f);
+      v[1] = fmaxf(fmaf(v[1], t0[i][2], t0[i][3]), 0.f);
+      v[2] = fmaxf(fmaf(v[2], t1[i][0], t1[i][1]), 0.f);
+      v[3] = fmaxf(fmaf(v[3], t1[i][2], t1[i][3]), 0.f);
+    }
+    if (!xin[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (idx < SNT_PX * 4) *reinterpret_cast<f32x4*>(xt + (idx >> 2) * SNT_LD + (idx & 3) * 4) = v;
+  }
+  float acc[NOUT];
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) acc[n] = 0.f;
+  __syncthreads();   // the staged weights and tiles are complete
+  const int r = lane >> 4, cl = lane & 15;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int kh = t / 3, kw = t - kh * 3;
+    const float* xp = xt + ((r + kh) * SNT_HW + cl + kw) * SNT_LD;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      if (c0 + 4 * cc < c1) {                                                   // wave-uniform
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + cc * 4);
+        const float* wp = w_lds + ((t * 16 + (c0 >> 2) + cc) * NOUT) * 4;
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {   // columns past Cout are zero in the packed weights
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + n * 4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[n] = fmaf(xv[k], wv[k], acc[n]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) part[q][lane][n] = acc[n];
+  __syncthreads();
+  // thread (pixel p = tid & 63, output group g = tid >> 6): outputs n = g, g + 4, ...
+  const int p = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const size_t mo = ((size_t)(b * a.OH + oh0 + (p >> 4)) * a.OW + ow0 + (p & 15));
+  for (int n = g; n < a.Cout; n += 4) {
+    const float v = (part[0][p][n] + part[1][p][n]) + (part[2][p][n] + part[3][p][n]);
+    const float sc = a.scale ? a.scale[n] : 1.f, sh = a.shift ? a.shift[n] : 0.f;
+    a.out[mo * a.out_ps + a.out_co + n] = pn::apply_act(fmaf(v, sc, sh), a.act);
+  }
+}
+
+__device__ __forceinline__ bool small_n_tiled_ok(const ConvArgs& a) {
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_h == 1 && a.pad_w == 1 && a.OW % SNT_W == 0 && a.OH % SNT_H == 0 && a.OH == a.H && a.OW == a.W &&
+         (a.ni_ab == nullptr || a.ni_S == 1) && (a.in_ps % 4) == 0 && (a.in_co % 4) == 0;
+}
+
 __global__ __launch_bounds__(256) void conv_small_n_multi_kernel(MultiArgs m_by_value) {
   __shared__ float part[4][64][13];
   __shared__ __attribute__((aligned(16))) float w_lds[9 * 16 * 12 * 4];
+  __shared__ __attribute__((aligned(16))) float xt_lds[4 * SNT_PX * SNT_LD];
   typedef const __attribute__((address_space(4))) int* kptr_t;
   const kptr_t base = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   const int njobs = base[offsetof(MultiArgs, njobs) / 4];
@@ -1173,6 +1283,10 @@ __global__ __launch_bounds__(256) void conv_small_n_multi_kernel(MultiArgs m_by_
   if (taps == 1) {
     if (a.ncols <= 4) small_n_body<4, 1>(a, local, part, w_lds);
     else small_n_body<12, 1>(a, local, part, w_lds);
+  } else if (small_n_tiled_ok(a)) {
+    if (a.ncols <= 4) small_n_tiled_body<4>(a, local, part, w_lds, xt_lds);
+    else if (a.ncols <= 8) small_n_tiled_body<8>(a, local, part, w_lds, xt_lds);
+    else small_n_tiled_body<12>(a, local, part, w_lds, xt_lds);
   } else {
     if (a.ncols <= 4) small_n_body<4, 9>(a, local, part, w_lds);
     else if (a.ncols <= 8) small_n_body<8, 9>(a, local, part, w_lds);
