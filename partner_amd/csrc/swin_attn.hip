@@ -4,10 +4,10 @@
 //   WindowAttention.forward        det3d/models/bbox_heads/swin_utils/sw2votev4_util.py:65-103
 //   SwinTransformerBlock.forward   sw2votev4_util.py:127-188  (zero padding to window multiples, cyclic
 //                                  shift, window partition / reverse, shift mask of BasicLayer :259-276)
-// One wave per (window, head): the 49 tokens' q, k, v head slices (+ the vote embedding, a 3->16->C
-// MLP of (pred_centers, vote_cls) added to all three) are staged in LDS; lane i owns query i:
-//   s[j] = <q_i, k_j> / max(|q_i||k_j|, 1e-6) / max(tau, 0.01) + rpe(pos_i - pos_j) + mask(i, j)
-// softmax over j in registers, out_i = sum_j p_j v_j, written back through LDS as contiguous rows.
+// Per (window, head): q, k, v head slices of the 49 tokens (+ the vote embedding, a 3->16->C MLP of (pred_centers, vote_cls) added
+// to all three),
+//   s[i][j] = <q_i, k_j> / max(|q_i||k_j|, 1e-6) / max(tau, 0.01) + rpe(pos_i - pos_j) + mask(i, j)
+// softmax over j, out_i = sum_j p_j v_j -- the products on the fp32 MFMA, see the kernel.
 // Padding, cyclic shift, partition and their inverses are index arithmetic on the token map: nothing is
 // copied.  Padded tokens take part as keys exactly as in Swin (LayerNorm output zero => q = k = v = bias
 // + vote_mlp(0)).
@@ -28,123 +28,217 @@ struct SwvParams {
   const float* tau;       // (heads)
 };
 
-constexpr int WS = 7, NT = WS * WS, HD = 64, LD = HD + 1;
+constexpr int WS = 7, NT = WS * WS, HD = 64;
 
-__global__ __launch_bounds__(64) void swv_window_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ vote, int vote_ps,
-                                                             const float* __restrict__ pos, SwvParams P, int H, int W, int C, int shift,
-                                                             float* __restrict__ out) {
-  __shared__ float Q[NT][LD], K[NT][LD], V[NT][LD];
-  __shared__ float nk[NT], px[NT], py[NT];
-  __shared__ int region[NT], tok[NT];
-  __shared__ float vhid[NT][16];
-  const int lane = threadIdx.x;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// r3: the attention of one window on the fp32 MFMA.  Block = one window, wave = head (r2: one 64-thread block per (window, head), lane =
+// query, everything on the VALU with 64-long dot products against LDS rows: 632 us per block of the Waymo map, 1.26 ms of the frame).
+// The 49 tokens are padded to 64 rows (two 32-row MFMA tiles); every product is an exact-fp32 MFMA chain:
+//   vote embedding   ve = vhid (64 x 16) W2^T (16 x 64), computed in BOTH orientations (lane = token / lane = channel: the same two
+//                    operand fragments, swapped) so that it can be added to operands of either layout without a transpose
+//   S^T = K Q^T      the TRANSPOSED logits: accumulator lane = query, registers = keys, so the softmax over the keys is a reduction
+//                    over a lane's own registers plus ONE exchange with the lane holding the other half of the keys
+//   out^T = V^T P^T  P^T is S^T's accumulator as it stands (B operand: lane = query, k = key); V^T comes from global memory with
+//                    lane = channel; the accumulator (lane = query, registers = 4 consecutive channels x 4) is stored as float4
+// k order inside every MFMA: step (register r) multiplies index rowmap(r, 0) from lane half 0 and rowmap(r, 1) from lane half 1, the
+// same for both operands (rowmap(r, h) = (r & 3) + 8 (r >> 2) + 4 h, the accumulator's row map: what makes P^T usable in place).
+// The relative-position MLP (2 -> 16 -> heads, per (query, key) pair) and the softmax stay on the VALU: ~3.5 k instructions per lane.
+__device__ __forceinline__ int rowmap(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+__global__ __launch_bounds__(256) void swv_window_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ vote, int vote_ps,
+                                                              const float* __restrict__ pos, SwvParams P, int H, int W, int C, int heads, int shift,
+                                                              float* __restrict__ out) {
+  __shared__ int tok[64];
+  __shared__ __attribute__((aligned(16))) float tinfo[64][4];      // px, py, region, key-valid (1 / 0)
+  __shared__ __attribute__((aligned(16))) float vhid[64][20];      // hidden layer of the vote MLP per token (16 + pad)
+  __shared__ float nkw[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, head = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
   const int Hp = (H + WS - 1) / WS * WS, Wp = (W + WS - 1) / WS * WS;
   const int nww = Wp / WS;
   const int wy = blockIdx.x / nww, wx = blockIdx.x - wy * nww;
-  const int head = blockIdx.y, b = blockIdx.z;
-  // ---- token bookkeeping: lane t < 49
-  if (lane < NT) {
-    const int r = lane / WS, c = lane - r * WS;
+  const int b = blockIdx.y;
+  // ---- token bookkeeping: thread t < 64 (rows >= 49 are MFMA padding: never keys, never written)
+  if (tid < 64) {
+    const int t = tid;
+    const bool row = t < NT;
+    const int r = t / WS, c = t - r * WS;
     const int hs = wy * WS + r, wsx = wx * WS + c;                 // coordinates in the (shifted) window frame
     const int hp = (hs + shift) % Hp, wp = (wsx + shift) % Wp;     // padded-map coordinates of this token
-    const bool valid = hp < H && wp < W;
-    tok[lane] = valid ? (b * H + hp) * W + wp : -1;
-    px[lane] = valid ? pos[(hp * W + wp) * 2] : 0.f;
-    py[lane] = valid ? pos[(hp * W + wp) * 2 + 1] : 0.f;
+    const bool valid = row && hp < H && wp < W;
+    const int tk = valid ? (b * H + hp) * W + wp : -1;
+    tok[t] = tk;
     const int ih = hs < Hp - WS ? 0 : (hs < Hp - shift ? 1 : 2), iw = wsx < Wp - WS ? 0 : (wsx < Wp - shift ? 1 : 2);
-    region[lane] = shift > 0 ? ih * 3 + iw : 0;
-    // hidden layer of the vote MLP for this token (zeros for padded tokens)
+    tinfo[t][0] = valid ? pos[(hp * W + wp) * 2] : 0.f;
+    tinfo[t][1] = valid ? pos[(hp * W + wp) * 2 + 1] : 0.f;
+    tinfo[t][2] = (float)((row && shift > 0) ? ih * 3 + iw : 0);
+    tinfo[t][3] = row ? 1.f : 0.f;
     float v0 = 0.f, v1 = 0.f, v2 = 0.f;
     if (valid) {
-      const float* vp = vote + (size_t)tok[lane] * vote_ps;
+      const float* vp = vote + (size_t)tk * vote_ps;
       v0 = vp[0]; v1 = vp[1]; v2 = vp[2];
     }
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       const float hsum = P.vm_b1[m] + P.vm_w1[m * 3] * v0 + P.vm_w1[m * 3 + 1] * v1 + P.vm_w1[m * 3 + 2] * v2;
-      vhid[lane][m] = hsum > 0.f ? hsum : 0.f;
+      vhid[t][m] = hsum > 0.f ? hsum : 0.f;
     }
   }
   __syncthreads();
-  // ---- stage q, k, v (+ vote embedding): lane = channel of the head
-  {
-    const int ch = head * HD + lane;
-    float w2[16];
+  if (head >= heads) return;
+  const int hc = head * HD;
+  // ---- operand fragments of the vote MLP's second layer: k = m (16): step s multiplies m = 2 s + lh
+  float w2f[2][8], vhf[2][8];       // [channel tile / token tile][step]
 #pragma unroll
-    for (int m = 0; m < 16; ++m) w2[m] = P.vm_w2[ch * 16 + m];
-    const float b2 = P.vm_b2[ch];
-    const float bq = P.qkv_bias ? P.qkv_bias[ch] : 0.f, bk = P.qkv_bias ? P.qkv_bias[C + ch] : 0.f, bv = P.qkv_bias ? P.qkv_bias[2 * C + ch] : 0.f;
-    for (int t = 0; t < NT; ++t) {
-      float ve = b2;
+  for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int m = 0; m < 16; ++m) ve = fmaf(w2[m], vhid[t][m], ve);
-      const int tk = tok[t];
-      float q = bq, k = bk, v = bv;
-      if (tk >= 0) {
-        const float* row = qkv + (size_t)tk * 3 * C;
-        q = row[ch]; k = row[C + ch]; v = row[2 * C + ch];
+    for (int s8 = 0; s8 < 8; ++s8) {
+      w2f[tt][s8] = P.vm_w2[(hc + tt * 32 + li) * 16 + 2 * s8 + lh];
+      vhf[tt][s8] = vhid[tt * 32 + li][2 * s8 + lh];
+    }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // ---- K and Q operands: lane = token (tile tt), registers = channels rowmap(r, lh) of channel tile ct.  x + bias + ve.
+  f32x16 kreg[2][2], qreg[2][2];
+  float nq[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int tk = tok[tt * 32 + li];
+    const float* row = qkv + (size_t)(tk >= 0 ? tk : 0) * 3 * C + hc;
+    float sq = 0.f, sk = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      f32x16 ve = zero16;                // ve^T tile: rows = channels of tile ct, columns = tokens of tile tt
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) ve = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[ct][s8], vhf[tt][s8], ve, 0, 0, 0);
+      f32x16 q, k;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ch = ct * 32 + 8 * g + 4 * lh;
+        f32x4 qv = {0.f, 0.f, 0.f, 0.f}, kv = {0.f, 0.f, 0.f, 0.f};
+        if (tk >= 0) {
+          qv = *reinterpret_cast<const f32x4*>(row + ch);
+          kv = *reinterpret_cast<const f32x4*>(row + C + ch);
+        }
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(P.vm_b2 + hc + ch);
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f}, bk = {0.f, 0.f, 0.f, 0.f};
+        if (P.qkv_bias) {
+          bq = *reinterpret_cast<const f32x4*>(P.qkv_bias + hc + ch);
+          bk = *reinterpret_cast<const f32x4*>(P.qkv_bias + C + hc + ch);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float e = ve[4 * g + j] + b2[j];
+          const float qq = (tk >= 0 ? qv[j] : bq[j]) + e, kk = (tk >= 0 ? kv[j] : bk[j]) + e;
+          q[4 * g + j] = qq;
+          k[4 * g + j] = kk;
+          sq = fmaf(qq, qq, sq);
+          sk = fmaf(kk, kk, sk);
+        }
       }
-      Q[t][lane] = q + ve; K[t][lane] = k + ve; V[t][lane] = v + ve;
+      qreg[tt][ct] = q;
+      kreg[tt][ct] = k;
     }
+    sq += __shfl_xor(sq, 32, 64);
+    sk += __shfl_xor(sk, 32, 64);
+    nq[tt] = sqrtf(sq);
+    if (lh == 0) nkw[head][tt * 32 + li] = sqrtf(sk);
   }
-  __syncthreads();
-  float qi[HD], nq = 0.f;
-  if (lane < NT) {
-    float s = 0.f;
+  // ---- V^T operand: lane = channel (tile ct), registers = tokens rowmap(r, lh) of token tile tj.  v + bias + ve.
+  f32x16 vreg[2][2];     // [token tile][channel tile]
 #pragma unroll
-    for (int d = 0; d < HD; ++d) { qi[d] = Q[lane][d]; nq = fmaf(qi[d], qi[d], nq); const float kv = K[lane][d]; s = fmaf(kv, kv, s); }
-    nk[lane] = sqrtf(s);
-    nq = sqrtf(nq);
-  }
-  __syncthreads();
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      f32x16 ve = zero16;                // ve tile: rows = tokens of tile tj, columns = channels of tile ct
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) ve = __builtin_amdgcn_mfma_f32_32x32x2f32(vhf[tj][s8], w2f[ct][s8], ve, 0, 0, 0);
+      const int ch = hc + ct * 32 + li;
+      const float b2 = P.vm_b2[ch], bv = P.qkv_bias ? P.qkv_bias[2 * C + ch] : 0.f;
+      f32x16 v;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tk = tok[tj * 32 + rowmap(r, lh)];
+        const float x = tk >= 0 ? qkv[(size_t)tk * 3 * C + 2 * C + ch] : bv;
+        v[r] = x + ve[r] + b2;
+      }
+      vreg[tj][ct] = v;
+    }
+  // relative-position MLP and temperature
   float rw1x[16], rw1y[16], rb1[16], rw2[16];
 #pragma unroll
   for (int m = 0; m < 16; ++m) { rw1x[m] = P.rp_w1[m * 2]; rw1y[m] = P.rp_w1[m * 2 + 1]; rb1[m] = P.rp_b1[m]; rw2[m] = P.rp_w2[head * 16 + m]; }
   const float rb2 = P.rp_b2[head];
   const float inv_tau = 1.f / fmaxf(P.tau[head], 0.01f);
-  float s[NT];
-  float smax = -3.0e38f;
-  if (lane < NT) {
-    const float xi = px[lane], yi = py[lane];
-    const int ri = region[lane];
+  // ---- per query tile: S^T = K Q^T (lane = query), logits, softmax over the keys, out^T = V^T P^T
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float dot = 0.f;
+  for (int ti = 0; ti < 2; ++ti) {
+    const int qi = ti * 32 + li;
+    f32x16 st[2] = {zero16, zero16};
 #pragma unroll
-      for (int d = 0; d < HD; ++d) dot = fmaf(qi[d], K[j][d], dot);
-      float a = dot / fmaxf(nq * nk[j], 1e-6f) * inv_tau;
-      const float dx = xi - px[j], dy = yi - py[j];
-      float rp = rb2;
+    for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const float hdn = fmaf(rw1x[m], dx, fmaf(rw1y[m], dy, rb1[m]));
-        rp = fmaf(rw2[m], hdn > 0.f ? hdn : 0.f, rp);
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[tj][ct][r], qreg[ti][ct][r], st[tj], 0, 0, 0);
+    const f32x4 me = *reinterpret_cast<const f32x4*>(tinfo[qi]);
+    const float nqi = nq[ti];
+    float smax = -3.0e38f;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = tj * 32 + rowmap(r, lh);
+        if (tj == 1 && (r >> 2) > 2) { st[tj][r] = -3.0e38f; continue; }     // keys >= 56: MFMA padding (compile-time skip)
+        const f32x4 oj = *reinterpret_cast<const f32x4*>(tinfo[j]);
+        float a = st[tj][r] / fmaxf(nqi * nkw[head][j], 1e-6f) * inv_tau;
+        const float dx = me[0] - oj[0], dy = me[1] - oj[1];
+        float rp = rb2;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          const float hdn = fmaf(rw1x[m], dx, fmaf(rw1y[m], dy, rb1[m]));
+          rp = fmaf(rw2[m], hdn > 0.f ? hdn : 0.f, rp);
+        }
+        a += rp;
+        if (oj[2] != me[2]) a += -100.f;
+        if (oj[3] == 0.f) a = -3.0e38f;            // rows 49 .. 55: not a token
+        st[tj][r] = a;
+        smax = fmaxf(smax, a);
       }
-      a += rp;
-      if (region[j] != ri) a += -100.f;
-      s[j] = a;
-      smax = fmaxf(smax, a);
-    }
+    smax = fmaxf(smax, __shfl_xor(smax, 32, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) { s[j] = expf(s[j] - smax); sum += s[j]; }
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = (tj == 1 && (r >> 2) > 2) ? 0.f : expf(st[tj][r] - smax);
+        st[tj][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.f / sum;
-    float o[HD];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const float p = s[j] * inv;
+      for (int r = 0; r < 16; ++r) st[tj][r] *= inv;
+    const int tk = tok[qi];
 #pragma unroll
-      for (int d = 0; d < HD; ++d) o[d] = fmaf(p, V[j][d], o[d]);
+    for (int ct = 0; ct < 2; ++ct) {
+      f32x16 o = zero16;
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (tj == 1 && (r >> 2) > 2) continue;      // P is zero there
+          o = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[tj][ct][r], st[tj][r], o, 0, 0, 0);
+        }
+      if (tk >= 0) {
+        float* op = out + (size_t)tk * C + hc + ct * 32 + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(op + 8 * g) = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+      }
     }
-#pragma unroll
-    for (int d = 0; d < HD; ++d) Q[lane][d] = o[d];  // row `lane` of Q is only read by this lane: safe to overwrite
-  }
-  __syncthreads();
-  for (int t = 0; t < NT; ++t) {
-    const int tk = tok[t];
-    if (tk >= 0) out[(size_t)tk * C + head * HD + lane] = Q[t][lane];
   }
 }
 
@@ -158,12 +252,14 @@ int pn_swv_window_attn(const float* qkv, const float* vote, int vote_pixel_strid
                        int heads, int window, int shift, float* out, pn_stream_t stream) {
   PN_REQUIRE(qkv && vote && pos && vote_w1 && vote_b1 && vote_w2 && vote_b2 && rpe_w1 && rpe_b1 && rpe_w2 && rpe_b2 && tau && out,
              "swv_window_attn: null pointer");
-  PN_REQUIRE(window == WS && heads >= 1 && c == heads * HD, "swv_window_attn: built for window 7 and head_dim 64");
+  PN_REQUIRE(window == WS && heads >= 1 && heads <= 4 && c == heads * HD, "swv_window_attn: built for window 7, head_dim 64 and at most 4 heads");
   PN_REQUIRE(shift >= 0 && shift < WS && batch >= 1 && h >= 1 && w >= 1 && vote_pixel_stride >= 3, "swv_window_attn: bad sizes");
+  PN_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)vote_b2 & 15) == 0 && ((uintptr_t)qkv_bias & 15) == 0,
+             "swv_window_attn: qkv, out, the vote bias and the qkv bias must be 16-byte aligned");
   SwvParams p{qkv_bias, vote_w1, vote_b1, vote_w2, vote_b2, rpe_w1, rpe_b1, rpe_w2, rpe_b2, tau};
   const int nwh = (h + WS - 1) / WS, nww = (w + WS - 1) / WS;
-  hipLaunchKernelGGL(swv_window_attn_kernel, dim3(nwh * nww, heads, batch), dim3(64), 0, pn::S(stream), qkv, vote, vote_pixel_stride, pos,
-                     p, h, w, c, shift, out);
+  hipLaunchKernelGGL(swv_window_attn_kernel, dim3(nwh * nww, batch), dim3(256), 0, pn::S(stream), qkv, vote, vote_pixel_stride, pos,
+                     p, h, w, c, heads, shift, out);
   return pn::check_launch("swv_window_attn_kernel");
 }
 
