@@ -340,11 +340,15 @@ __global__ __launch_bounds__(kScanThreads) void cell_scan_kernel(uint32_t* __res
   }
   // self-cleaning: the block that finishes last resets the scan state for the next launch (a replayed graph has no memset node
   // to rely on); every other block is past its look-back by the time it takes its ticket
-  // The ticket is an acquire-release at agent scope: every block's tile_state stores (made by this same thread 0) are ordered
-  // before its ticket, and the cleaner's plain zeroing stores after all of them -- a prefix store that lands late can not
-  // survive the reset and reach the next replay.
+  // Every block's tile_state stores (write-through agent-scope stores made by this same thread 0) are DRAINED before its ticket
+  // (s_waitcnt vmcnt(0): the store has been acknowledged), so the block that draws the last ticket zeroes the state after all of
+  // them have landed -- a prefix store that lands late cannot survive the reset and reach the next replay.  (An acquire-release
+  // ticket does the same with an L2 write-back per block: +3.6 us on the 64-block scan of a nuScenes sweep.)
   __syncthreads();
-  if (tid == 0) s_tile = __hip_atomic_fetch_add(&counters[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_tile = __hip_atomic_fetch_add(&counters[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
   if ((int)s_tile == ntiles - 1) {
     for (int j = tid; j < ntiles; j += kScanThreads) tile_state[j] = 0ull;
