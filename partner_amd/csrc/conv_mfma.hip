@@ -1500,6 +1500,86 @@ extern "C" {
 /* ---- sparse convolution as a gathered GEMM: out[m] = act((sum_t W_t . in[nbr[m][t]]) * scale + shift) (+ residual[m]).
  * Same kernel, MODE "gather": the A tile loader takes the input row of every (output site, tap) from the block's neighbour table
  * (staged in LDS) instead of pixel arithmetic.  packed_w: pn_pack_conv_weight_f32 of the weight seen as (Cout, Cin, taps, 1). ---- */
+}  // extern "C"
+
+namespace {
+
+// ---- the 16-channel level of the sparse encoder (conv_input and the two residual blocks of conv1, scn.py:112-123: 8 / 16 -> 16 channels
+// on the finest grid) on the VALU.  On the gathered MFMA kernel a tap is one K step whose second half is zero padding, three quarters of
+// the (site, tap) pairs do not exist (6.1 of 27 neighbours on a 64-beam sweep) and every step waits for a dependent gather: 160 us per
+// layer at 100 k sites, which is 0.3 GFLOP and 30 MB.  Here four lanes share an output site: lane (site, q) fetches channel quad q of
+// ALL 27 neighbour rows up front (one buffer load each, absent neighbours redirected out of range -> zeros, nothing waits on anything),
+// then walks the taps that any of the wave's 16 sites has: the other three quads of the row come from the neighbouring lanes as DPP
+// quad broadcasts folded into the FMAs, the tap's 16 x 4 weights of output quad q are read from LDS (staged once per block).
+// Summation order: taps ascending, input channels ascending (the MFMA kernel adds the two k halves of a step pairwise: last-bit
+// differences between the two routes).
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void sparse_conv_c16_kernel(const float* __restrict__ in, unsigned in_bytes, const int32_t* __restrict__ nbr,
+                                                              const int32_t* __restrict__ n_out, int cap, int taps, const float* __restrict__ packed_w,
+                                                              int quads, int cout_pad, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              int act, const float* __restrict__ residual, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float wl[27 * 256];      // [tap][ci 16][co 16]
+  __shared__ int nb_s[64 * 27];                                     // this group's neighbour rows, [site][tap]
+  const int tid = threadIdx.x, q = tid & 3, sl = tid >> 2;
+  for (int i = tid; i < taps * 256; i += 256) {
+    const int t = i >> 8, ci = (i >> 4) & 15, co = i & 15;
+    wl[i] = ci < CIN ? packed_w[(((size_t)t * quads + (ci >> 2)) * cout_pad + co) * 4 + (ci & 3)] : 0.f;
+  }
+  const int n = min(*n_out, cap);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, in_bytes, 0x00020000);
+  const f32x4 sc = scale ? *reinterpret_cast<const f32x4*>(scale + 4 * q) : f32x4{1.f, 1.f, 1.f, 1.f};
+  const f32x4 sh = shift ? *reinterpret_cast<const f32x4*>(shift + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int g = blockIdx.x; g * 64 < n; g += gridDim.x) {
+    __syncthreads();
+    for (int i = tid; i < 64 * taps; i += 256) nb_s[i] = g * 64 + i / taps < n ? nbr[(size_t)g * 64 * taps + i] : -1;
+    __syncthreads();
+    const int site = g * 64 + sl;
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (residual && site < n) r = *reinterpret_cast<const f32x4*>(residual + (size_t)site * 16 + 4 * q);
+    f32x4 x[27];
+    unsigned live = 0;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const int idx = t < taps ? nb_s[sl * taps + t] : -1;
+      live |= (__builtin_amdgcn_ballot_w64(idx >= 0) != 0ull ? 1u : 0u) << t;
+      const unsigned vo = (idx >= 0 && 4 * q < CIN) ? (unsigned)idx * (unsigned)(CIN * 4) + 16u * q : 0xffffffffu;
+      x[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0));
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      if (live >> t & 1) {                                                  // wave-uniform
+        const float* wt = wl + t * 256 + 4 * q;
+#pragma unroll
+        for (int c4 = 0; c4 < CIN / 4; ++c4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float xv = c4 == 0 ? quad_bcast<0>(x[t][k]) : c4 == 1 ? quad_bcast<1>(x[t][k]) : c4 == 2 ? quad_bcast<2>(x[t][k]) : quad_bcast<3>(x[t][k]);
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wt + (4 * c4 + k) * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv, w4[j], acc[j]);
+          }
+        }
+      }
+    }
+    if (site < n) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = pn::apply_act(fmaf(acc[j], sc[j], sh[j]) + r[j], act);
+      *reinterpret_cast<f32x4*>(out + (size_t)site * 16 + 4 * q) = v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
 int pn_sparse_conv_f32(const float* in, int in_rows, int cin, const int32_t* nbr, const int32_t* n_out, int out_capacity, int taps,
                        const float* packed_w, int cout, const float* scale, const float* shift, int act, const float* residual, float* out,
                        pn_stream_t stream) {
@@ -1516,6 +1596,20 @@ int pn_sparse_conv_f32(const float* in, int in_rows, int cin, const int32_t* nbr
   a.res = residual; a.res_ps = cout; a.nbr = nbr; a.n_valid = n_out;
   a.res_pre_act = 1;  // SparseBasicBlock: relu(bn2(conv2(.)) + identity), scn.py:84-95
   hipStream_t st = pn::S(stream);
+  static const int c16 = [] { const char* e = getenv("PN_SPARSE_C16"); return e ? atoi(e) : 1; }();
+  if (c16 && cout == 16 && (cin == 8 || cin == 16) && taps <= 27 && (size_t)in_rows * cin * 4 < 0xffffffffull && ((uintptr_t)in & 15) == 0 &&
+      ((uintptr_t)out & 15) == 0 && ((uintptr_t)residual & 15) == 0 && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0) {
+    pn::ProfileSlot ps;
+    const bool prof = pn::take_profile_slot(ps);
+    const dim3 grid((unsigned)std::min(2048, pn::cdiv(out_capacity, 64)));
+    const unsigned in_bytes = (unsigned)((size_t)in_rows * cin * 4);
+    auto kern = cin == 8 ? &sparse_conv_c16_kernel<8> : &sparse_conv_c16_kernel<16>;
+    if (prof) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, st, ps.start, ps.stop, 0, in, in_bytes, nbr, n_out, out_capacity, taps, packed_w,
+                                    a.cin_chunks * 8, a.cout_pad, scale, shift, act, residual, out);
+    else hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, in, in_bytes, nbr, n_out, out_capacity, taps, packed_w, a.cin_chunks * 8, a.cout_pad,
+                            scale, shift, act, residual, out);
+    return pn::check_launch("sparse_conv_c16_kernel");
+  }
   if (cout > 64) return out_capacity >= 128 * 128 ? launch_conv<2, 2, 2, 2, DT_F32, true>(a, 1, st) : launch_conv<2, 2, 1, 2, DT_F32, true>(a, 1, st);
   if (cout > 32) return launch_conv<2, 2, 1, 1, DT_F32, true>(a, 1, st);
   return launch_conv<2, 1, 1, 1, DT_F32, true>(a, 1, st);
