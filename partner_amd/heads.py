@@ -174,7 +174,9 @@ class CenterHead(nn.Module):
     @torch.no_grad()
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
         """decode + rotated NMS on the device (center_head.py:404-460, 350-402, 462-577): the multi-class rotate_nms_pcdet path and
-        the per-class one (test_cfg.per_class_nms, batched_nms_rotated); no double flip, no stateful NMS, no panoptic, sector 0.  Returns the reference's list (one dict per sample) of
+        the per-class one (test_cfg.per_class_nms, batched_nms_rotated); test_cfg.double_flip merges groups of four flipped copies first
+        (center_head.py:289-346, 425-427), test_cfg.stateful_nms lets the previous sectors' detections (kwargs prev_dets / sec_id) compete
+        (center_head.py:466, 486-509); panoptic fusion raises NotImplementedError (segmentation is out of scope).  Returns the reference's list (one dict per sample) of
         'box3d_lidar' (n, 9|7), 'scores', 'label_preds', 'metadata'."""
         import ctypes as C
         lib = hip.load()
