@@ -695,6 +695,10 @@ int pn_seg_point_labels(const float *seg_sample, int h, int w, int classes, cons
  *                                 serves every convolution that shares an indice_key
  *   pn_sparse_conv_f32            out = act((sum_t W_t in[nbr[.][t]]) * scale + shift + residual), on the MFMA
  *                                 kernel in gather mode; packed_w = pn_pack_conv_weight_f32 of (Cout, Cin, taps, 1)
+ *   pn_sparse_conv_c16_f32        the same for the 16-channel level (conv_input and conv1's SparseBasicBlocks, scn.py:112-123: cin 8 or
+ *                                 16, cout 16) on a VALU kernel: four lanes per site, every neighbour row fetched up front; same packed
+ *                                 weights; summation order taps ascending, channels ascending (last-bit differences to the MFMA form,
+ *                                 hence a separate entry: the caller names the form)
  *   pn_sparse_to_dense_nhwc       (B, H, W, C*D) with channel c*D + z  ==  .dense().view(N, C*D, H, W) in NHWC
  */
 size_t pn_sparse_index_bytes(uint64_t num_cells);
@@ -716,6 +720,10 @@ int pn_sparse_conv_f32(const float *in, int in_rows, int cin, const int32_t *nbr
                        int out_capacity, int taps, const float *packed_w, int cout, const float *scale,
                        const float *shift, int act, const float *residual, float *out,
                        pn_stream_t stream);
+int pn_sparse_conv_c16_f32(const float *in, int in_rows, int cin, const int32_t *nbr, const int32_t *n_out,
+                           int out_capacity, int taps, const float *packed_w, const float *scale,
+                           const float *shift, int act, const float *residual, float *out,
+                           pn_stream_t stream);
 int pn_sparse_to_dense_nhwc(const float *feats, const uint32_t *keys, int capacity,
                             const int32_t *n_dev, const int32_t *dims, int c, float *out,
                             pn_stream_t stream);

@@ -1596,23 +1596,32 @@ int pn_sparse_conv_f32(const float* in, int in_rows, int cin, const int32_t* nbr
   a.res = residual; a.res_ps = cout; a.nbr = nbr; a.n_valid = n_out;
   a.res_pre_act = 1;  // SparseBasicBlock: relu(bn2(conv2(.)) + identity), scn.py:84-95
   hipStream_t st = pn::S(stream);
-  static const int c16 = [] { const char* e = getenv("PN_SPARSE_C16"); return e ? atoi(e) : 1; }();
-  if (c16 && cout == 16 && (cin == 8 || cin == 16) && taps <= 27 && (size_t)in_rows * cin * 4 < 0xffffffffull && ((uintptr_t)in & 15) == 0 &&
-      ((uintptr_t)out & 15) == 0 && ((uintptr_t)residual & 15) == 0 && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0) {
-    pn::ProfileSlot ps;
-    const bool prof = pn::take_profile_slot(ps);
-    const dim3 grid((unsigned)std::min(2048, pn::cdiv(out_capacity, 64)));
-    const unsigned in_bytes = (unsigned)((size_t)in_rows * cin * 4);
-    auto kern = cin == 8 ? &sparse_conv_c16_kernel<8> : &sparse_conv_c16_kernel<16>;
-    if (prof) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, st, ps.start, ps.stop, 0, in, in_bytes, nbr, n_out, out_capacity, taps, packed_w,
-                                    a.cin_chunks * 8, a.cout_pad, scale, shift, act, residual, out);
-    else hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, in, in_bytes, nbr, n_out, out_capacity, taps, packed_w, a.cin_chunks * 8, a.cout_pad,
-                            scale, shift, act, residual, out);
-    return pn::check_launch("sparse_conv_c16_kernel");
-  }
   if (cout > 64) return out_capacity >= 128 * 128 ? launch_conv<2, 2, 2, 2, DT_F32, true>(a, 1, st) : launch_conv<2, 2, 1, 2, DT_F32, true>(a, 1, st);
   if (cout > 32) return launch_conv<2, 2, 1, 1, DT_F32, true>(a, 1, st);
   return launch_conv<2, 1, 1, 1, DT_F32, true>(a, 1, st);
+}
+
+// The 16-channel level (cout == 16, cin 8 or 16) on the VALU kernel above.  Same arguments and result as pn_sparse_conv_f32 up to the
+// summation order (taps ascending, channels ascending) -- a separate entry so that a caller names the form it runs.
+int pn_sparse_conv_c16_f32(const float* in, int in_rows, int cin, const int32_t* nbr, const int32_t* n_out, int out_capacity, int taps,
+                           const float* packed_w, const float* scale, const float* shift, int act, const float* residual, float* out, pn_stream_t stream) {
+  PN_REQUIRE(in && nbr && n_out && packed_w && out, "sparse_conv_c16: null pointer");
+  PN_REQUIRE((cin == 8 || cin == 16) && taps >= 1 && taps <= 27 && in_rows >= 1 && out_capacity >= 1, "sparse_conv_c16: cin must be 8 or 16, taps <= 27");
+  PN_REQUIRE((size_t)in_rows * cin * 4 < 0xffffffffull, "sparse_conv_c16: input table too large for the buffer descriptor");
+  PN_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)residual & 15) == 0 && ((uintptr_t)scale & 15) == 0 &&
+                 ((uintptr_t)shift & 15) == 0, "sparse_conv_c16: pointers must be 16-byte aligned");
+  PN_REQUIRE(act == PN_ACT_NONE || act == PN_ACT_RELU, "sparse_conv_c16: activation none or ReLU");
+  hipStream_t st = pn::S(stream);
+  pn::ProfileSlot ps;
+  const bool prof = pn::take_profile_slot(ps);
+  const dim3 grid((unsigned)std::min(2048, pn::cdiv(out_capacity, 64)));
+  const unsigned in_bytes = (unsigned)((size_t)in_rows * cin * 4);
+  const int quads = pn::cdiv(cin, 32) * 8, cout_pad = 32;          // the layout pn_pack_conv_weight_f32 gives (16, cin, taps, 1)
+  auto kern = cin == 8 ? &sparse_conv_c16_kernel<8> : &sparse_conv_c16_kernel<16>;
+  if (prof) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, st, ps.start, ps.stop, 0, in, in_bytes, nbr, n_out, out_capacity, taps, packed_w, quads, cout_pad,
+                                  scale, shift, act, residual, out);
+  else hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, in, in_bytes, nbr, n_out, out_capacity, taps, packed_w, quads, cout_pad, scale, shift, act, residual, out);
+  return pn::check_launch("sparse_conv_c16_kernel");
 }
 
 /* ---- bf16 variant (BASELINE configs[3]: "bf16 BEV convs on MFMA"): bf16 activations and weights, f32 accumulate on

@@ -74,7 +74,20 @@ struct Wino4Args {
   int ncol;                // 128-column tiles
   int chunks, cout_pad;
   unsigned in_bytes, w_bytes;
+#ifdef PN_WINO4_STAMP
+  unsigned long long* stamps;   // diagnostic build only (tools/micro/wino4_stamps.hip): [block][8] shader-clock stamps of wave 0, first tile
+#endif
 };
+
+#ifdef PN_WINO4_STAMP
+unsigned long long* pn_wino4_stamp_buffer = nullptr;
+#define W4_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    if (tid == 0 && tl == slot) a.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define W4_STAMP(k) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
   constexpr int TM = 1;                       // 32-quad MFMA tiles per wave
@@ -513,6 +526,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_ks_kernel(Wino4Args a) {
   };
 
   for (int tl = slot; tl < xtiles; tl += per_xcd) {
+    W4_STAMP(0);
     setup_tile(tl);
     so_b = b_step_offset();
     load_a(true);
@@ -521,17 +535,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_ks_kernel(Wino4Args a) {
     for (int q = 0; q < 6; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    W4_STAMP(1);
     store_a(0);
     load_a(nsteps > 1);
+    W4_STAMP(2);
     for (int t = 0; t < nsteps; t += 2) {
       kstep(I0{}, t);
+      if (t == 0) W4_STAMP(3);
       if (t + 1 < nsteps) kstep(I1{}, t + 1);
     }
+    W4_STAMP(4);
     __syncthreads();   // every wave is done reading the last stage: the join may overwrite it
+    W4_STAMP(5);
     if (ks == 0) finish(I0{}, pt, n0);
     else if (ks == 1) finish(I1{}, pt, n0);
     else if (ks == 2) finish(I2{}, pt, n0);
     else finish(I3{}, pt, n0);
+    W4_STAMP(6);
   }
 }
 
@@ -616,6 +636,9 @@ int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc* d, const float* in, const float
   a.ncol = a.cout_pad / W4N;
   a.in_bytes = (unsigned)in_bytes;
   a.w_bytes = (unsigned)(pn_conv_wino4_packed_weight_floats(d->cout, d->cin) * 4);
+#ifdef PN_WINO4_STAMP
+  a.stamps = pn_wino4_stamp_buffer;
+#endif
   static bool attr_done[64] = {false};
   if (pn::first_use_on_device(attr_done))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino4_smem(32));

@@ -13,6 +13,7 @@ gathered GEMM on the MFMA kernel with BatchNorm folded and ReLU / residual fused
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List
 
 import numpy as np
@@ -22,6 +23,8 @@ from torch import nn
 from . import hip, ops
 from .builder import BACKBONES
 from .nn_utils import PlanCache, build_norm_layer, eval_only
+
+_C16 = os.environ.get("PN_SPARSE_C16", "1") != "0"     # 0: the 16-channel level on the gathered MFMA kernel as well
 
 
 class SubMConv3d(nn.Module):
@@ -118,6 +121,12 @@ class SpMiddleResNetFHD(nn.Module):
     @staticmethod
     def _conv(feats, n_rows, nbr, count, cap, layer, act, residual=None):
         out = torch.empty((cap, layer["cout"]), dtype=torch.float32, device=feats.device)
+        if _C16 and layer["cout"] == 16 and layer["cin"] in (8, 16) and layer["taps"] <= 27:
+            # conv_input / conv1 (scn.py:112-123): the 16-channel level has its own kernel (inference; the training tape keeps one form)
+            hip.call("pn_sparse_conv_c16_f32", feats.data_ptr(), n_rows, layer["cin"], nbr.data_ptr(), count.data_ptr(), cap, layer["taps"],
+                     layer["packed"].data_ptr(), layer["scale"].data_ptr(), layer["shift"].data_ptr(), int(act), hip.ptr(residual), out.data_ptr(),
+                     hip.stream())
+            return out
         hip.call("pn_sparse_conv_f32", feats.data_ptr(), n_rows, layer["cin"], nbr.data_ptr(), count.data_ptr(), cap, layer["taps"],
                  layer["packed"].data_ptr(), layer["cout"], layer["scale"].data_ptr(), layer["shift"].data_ptr(), int(act), hip.ptr(residual),
                  out.data_ptr(), hip.stream())

@@ -372,3 +372,56 @@ def test_sp_middle_resnet_fhd_training_gradients_match_fp64_autograd(dev, cin):
     bad = {k: v for k, v in worst.items() if v > 2e-3}
     assert not bad, bad
     assert not torch.equal(net.conv_input[1].running_mean.cpu(), rm0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,taps,n,cap,res,act", [(16, 27, 5000, 6000, True, 1), (8, 27, 777, 777, False, 1), (16, 27, 64, 64, True, 0), (16, 3, 1500, 2048, False, 1),
+                                                    (16, 27, 0, 256, True, 1), (8, 27, 1, 64, False, 0)])
+def test_sparse_conv_c16_matches_the_gathered_mfma_form_and_fp64(dev, cin, taps, n, cap, res, act):
+    """pn_sparse_conv_c16_f32 (VALU, four lanes per site) against pn_sparse_conv_f32 (gathered MFMA) and against an fp64 gather-sum:
+    ragged counts (n < capacity, n = 0, a single site), missing neighbours, 8 and 16 input channels, with and without residual;
+    rows past the count stay untouched."""
+    import ctypes as C
+    from partner_amd import hip
+    g = torch.Generator().manual_seed(100 * cin + taps + n)
+    rows = max(n, 1) + 17
+    x = torch.randn((rows, cin), generator=g).to(dev)
+    w = (torch.randn((16, cin, taps), generator=g) * 0.2).to(dev)
+    nbr = torch.randint(0, rows, (cap, taps), generator=g, dtype=torch.int32)
+    nbr[torch.rand((cap, taps), generator=g) < 0.7] = -1
+    if n > 3:
+        nbr[2] = -1                                     # a site without neighbours
+        nbr[3] = torch.arange(taps, dtype=torch.int32)  # a site with all of them
+    nbr = nbr.to(dev)
+    count = torch.tensor([n], dtype=torch.int32, device=dev)
+    scale, shift = (torch.rand(16, generator=g) + 0.5).to(dev), torch.randn(16, generator=g).to(dev)
+    resid = torch.randn((cap, 16), generator=g).to(dev) if res else None
+    lib = hip.load()
+    packed = torch.empty(lib.pn_conv_packed_weight_floats(16, cin, taps, 1, 1), dtype=torch.float32, device=dev)
+    hip.call("pn_pack_conv_weight_f32", w.contiguous().data_ptr(), 16, cin, taps, 1, 1, packed.data_ptr(), hip.stream())
+    out_a = torch.full((cap, 16), 7.0, device=dev)
+    out_b = torch.full((cap, 16), 7.0, device=dev)
+    hip.call("pn_sparse_conv_c16_f32", x.data_ptr(), rows, cin, nbr.data_ptr(), count.data_ptr(), cap, taps, packed.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+             act, hip.ptr(resid), out_a.data_ptr(), hip.stream())
+    hip.call("pn_sparse_conv_f32", x.data_ptr(), rows, cin, nbr.data_ptr(), count.data_ptr(), cap, taps, packed.data_ptr(), 16, scale.data_ptr(), shift.data_ptr(),
+             act, hip.ptr(resid), out_b.data_ptr(), hip.stream())
+    torch.cuda.synchronize()
+    assert torch.all(out_a[n:] == 7.0)
+    xd, wd = x.double().cpu(), w.double().cpu()
+    nb = nbr.cpu().long()[:n]
+    ref = torch.zeros((n, 16), dtype=torch.float64)
+    for t in range(taps):
+        has = nb[:, t] >= 0
+        ref[has] += xd[nb[has, t]] @ wd[:, :, t].T
+    ref = ref * scale.double().cpu() + shift.double().cpu()
+    if res:
+        ref = ref + resid.double().cpu()[:n]
+    if act:
+        ref = ref.clamp_min(0)
+    if n:
+        bound = 2e-6 * float(ref.abs().max()) + 1e-6
+        assert float((out_a[:n].double().cpu() - ref).abs().max()) < bound
+        assert float((out_a[:n] - out_b[:n]).abs().max()) < bound
+    with pytest.raises(hip.PartnerHipError):
+        hip.call("pn_sparse_conv_c16_f32", x.data_ptr(), rows, 12, nbr.data_ptr(), count.data_ptr(), cap, taps, packed.data_ptr(), None, None, 0, None,
+                 out_a.data_ptr(), hip.stream())
