@@ -88,6 +88,9 @@ unsigned long long* pn_wino4_stamp_buffer = nullptr;
 #else
 #define W4_STAMP(k) do { } while (0)
 #endif
+#ifndef PN_WINO4_EXP
+#define PN_WINO4_EXP 0   // diagnostic build only: bit 0 no input transform, 1 no per-step barrier, 2 no fragment reads, 3 no LDS stores, 4 no loads, 5 no weight loads, 6 no input loads
+#endif
 
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
   constexpr int TM = 1;                       // 32-quad MFMA tiles per wave
@@ -353,6 +356,11 @@ constexpr size_t wino4_ks_smem() {
   return stage > join ? stage : join;
 }
 
+// Where a step's time goes (tools/micro/wino4_stamps.hip, 64 x 64 x 256 -> 256, one wave per SIMD): 2560 cycles per step for 1536 cycles
+// of MFMA.  Without the six input loads 1730, without the six weight loads 1980, without both 1656: the costs ADD, so they are not
+// latencies (a second register set that issues the input loads two steps ahead, and a third LDS stage that reads the next step's
+// fragments under the MFMAs, both changed nothing and were dropped) -- a 32 x 32 tile moves 48 KB per step and CU through the vector
+// L1 for 96 MFMAs (31 B per clock, the plain form 20), and a wave that issues in order stands behind its own loads.
 __global__ __launch_bounds__(256, 2) void conv_wino4_ks_kernel(Wino4Args a) {
   constexpr int WQ = 32;
   constexpr int WA_FLOATS = 6 * WQ * W4_LD;
@@ -413,21 +421,30 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_ks_kernel(Wino4Args a) {
     }
     if (++ld_kh == 3) { ld_kh = 0; ++ld_chunk; }
   };
-  auto store_a = [&](int buf) {
-    float* As = smem + buf * WA_FLOATS + pl * W4_LD + c4 * 4;
+  auto store_a = [&](int stage) {
+    float* As = smem + stage * WA_FLOATS + pl * W4_LD + c4 * 4;
     f32x4 v[6];
-    wino4_input_transform(ra, v);
+    if constexpr (PN_WINO4_EXP & 1) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(As + q * WQ * W4_LD) = v[q];
+      for (int q = 0; q < 6; ++q) v[q] = ra[q];
+    } else {
+      wino4_input_transform(ra, v);
+    }
+    if constexpr (!(PN_WINO4_EXP & 8)) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(As + q * WQ * W4_LD) = v[q];
+    } else {
+      if (v[0][0] == 12345.f) *reinterpret_cast<f32x4*>(As) = v[1] + v[2] + v[3] + v[4] + v[5];
+    }
   };
   unsigned so_b = 0;
   auto b_step_offset = [&]() { return (unsigned)((lb_chunk * 3 + lb_kh) * 48) * cp16; };
   f32x16 acc[6];
   const int a_frag = li * W4_LD + lh * 4 + ks * 8;
   f32x4 af[6], bf[2][6];
-  auto read_a = [&](int buf) {
+  auto read_a = [&](int stage, f32x4 (&f)[6]) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) af[q] = *reinterpret_cast<const f32x4*>(smem + buf * WA_FLOATS + a_frag + q * WQ * W4_LD);
+    for (int q = 0; q < 6; ++q) f[q] = *reinterpret_cast<const f32x4*>(smem + stage * WA_FLOATS + a_frag + q * WQ * W4_LD);
   };
   auto load_b = [&](bool live, f32x4 (&f)[6]) {      // this wave's sub-step of the K step at (lb_chunk, lb_kh), then advance
     const unsigned vo = live ? b_base : 0xffffffffu;
@@ -440,26 +457,28 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_ks_kernel(Wino4Args a) {
   // the weight fragments of step t+1, the transform + LDS stores of step t+1's tile and the input loads of step t+2
   auto kstep = [&](auto par_c, int t) __attribute__((always_inline)) {
     constexpr int buf = decltype(par_c)::value;
-    __syncthreads();
-    read_a(buf);
-    load_b(t + 1 < nsteps, bf[buf ^ 1]);
+    if constexpr (!(PN_WINO4_EXP & 2)) __syncthreads();
+    if constexpr (!(PN_WINO4_EXP & 4)) {
+      read_a(buf, af);
+    }
+    if constexpr (!(PN_WINO4_EXP & (16 | 32))) load_b(t + 1 < nsteps, bf[buf ^ 1]);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
       for (int q = 0; q < 6; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][kk], bf[buf][q][kk], acc[q], 0, 0, 0);
     store_a(buf ^ 1);
-    load_a(t + 2 < nsteps);
-    // schedule: the six LDS reads and six weight loads first, then the transform + LDS stores under the first half of the MFMAs and
-    // the input loads under the second (a finer interleave -- one MFMA per five VALU -- measured slower: 34 against 31 us on the
-    // 64 x 64 x 256 layer, where a SIMD holds a single wave)
+    if constexpr (!(PN_WINO4_EXP & (16 | 64))) load_a(t + 2 < nsteps);
+    // schedule: the six LDS reads first; every vector-memory load behind a pair of MFMAs (a wave issues in order: twelve loads in a
+    // row wait for the CU's one texture-address path, shared with the three other waves that pass the barrier at the same moment, and
+    // the MFMAs behind them wait too -- with the loads removed a step of the lone-wave layers takes 1656 cycles instead of 2730,
+    // tools/micro/wino4_stamps.hip); the transform + LDS stores under the first half of the MFMAs, the input loads
+    // under the second (a finer interleave -- one MFMA per five VALU -- measured slower: 34 against 31 us on the 64 x 64 x 256 layer)
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
+    for (int k = 0; k < 6; ++k) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, 20, 0);
       __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
     }
@@ -656,11 +675,11 @@ int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc* d, const float* in, const float
   hipStream_t st = pn::S(stream);
   // layers whose column count is not a multiple of 128 (64-column layers) would waste the plain form's tile: K-split form
   if (a.Cout % W4N != 0 || wino4_form((long long)a.qtiles * a.ncol, ncu) == 2) {
+    a.ncol = pn::cdiv(a.Cout, W4K_N);
+    const long long tiles = (long long)a.qtiles * a.ncol;
     static bool ks_done[64] = {false};
     if (pn::first_use_on_device(ks_done))
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_ks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino4_ks_smem());
-    a.ncol = pn::cdiv(a.Cout, W4K_N);
-    const long long tiles = (long long)a.qtiles * a.ncol;
     const dim3 grid((unsigned)std::min<long long>(2 * ncu, (tiles + 7) / 8 * 8));
     if (prof) hipExtLaunchKernelGGL(conv_wino4_ks_kernel, grid, dim3(256), wino4_ks_smem(), st, ps.start, ps.stop, 0, a);
     else hipLaunchKernelGGL(conv_wino4_ks_kernel, grid, dim3(256), wino4_ks_smem(), st, a);

@@ -11,7 +11,7 @@
 
 int main() {
   struct Shape { int b, h, w, cin, cout; };
-  std::vector<Shape> shapes = {{1, 128, 128, 128, 128}, {1, 64, 64, 256, 256}, {1, 128, 128, 384, 64}};
+  std::vector<Shape> shapes = {{1, 128, 128, 128, 128}, {1, 64, 64, 256, 256}};
   unsigned long long* stamps;
   hipMalloc(&stamps, 1024 * 8 * 8);
   pn_wino4_stamp_buffer = stamps;
