@@ -22,3 +22,4 @@ python3 tools/kernel_stats_summary.py "$OUT/c4_bf16" "$OUT/sum/${PFX}_c4_bf16_ke
 python3 tools/kernel_stats_summary.py --mfma "$OUT/c4_sq" "$OUT/sum/${PFX}_c4_pmc_mfma.csv" | head -40
 python3 tools/kernel_stats_summary.py "$OUT/c5" "$OUT/sum/${PFX}_c5_kernel_stats.csv" 13 "tools/c5_profile.py: nuScenes 10-sweep frame (300k raw points) -> boxes, eager launches of the StreamingFrameEngine step (13 frames)" | head -30
 ls "$OUT/sum"
+[ -n "$KEEP_RAW" ] || rm -rf "$OUT/c4_f32" "$OUT/c4_bf16" "$OUT/c4_sq" "$OUT/c5"   # gpurun copies back at most 64 MiB

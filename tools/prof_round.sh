@@ -34,3 +34,4 @@ with open(f"{out}/sum/{pfx}_4streams_kernel_stats.csv", "w") as o:
 print("summaries in", out + "/sum")
 PY
 ls "$OUT/sum"
+[ -n "$KEEP_RAW" ] || rm -rf "$OUT/stats1" "$OUT/stats4" "$OUT/fetch" "$OUT/write" "$OUT/sq"   # gpurun copies back at most 64 MiB
