@@ -978,6 +978,14 @@ int pn_conv2d_multi_f32(const pn_conv_job *jobs, int njobs, int tile, pn_stream_
  * <= 12 columns: the last convolutions of the head branches, center_head_parallel.py:140-175), norm_* supported (a
  * range-stratified table only for 1x1 kernels); one launch for all jobs */
 int pn_conv2d_small_n_multi_f32(const pn_conv_job *jobs, int njobs, pn_stream_t stream);
+
+/* 3x3 / stride 1 / pad 1 convolutions with one to three output channels over many input channels (E2ESWVoteHead's 256 -> 1 heat-map
+ * and vote-class layers, e2e_swv_head.py:88-97) as GEMM + tap sum: g = pn_linear_ksplit_f32(x, W9) with W9[(t * cout + co)][ci] =
+ * w[co][ci][t / 3][t % 3] (rows padded to a multiple of 4) reads the input once; this entry adds the nine shifted columns:
+ * out[b,y,x,co] = act(scale[co] * sum_t g[b, y + t/3 - 1, x + t%3 - 1][t * cout + co] + shift[co]), taps ascending, zero padding. */
+int pn_conv3x3_tap_sum_f32(const float *g, int ldg, int batch, int h, int w, int cout, const float *scale,
+                           const float *shift, int act, float *out, int out_pixel_stride,
+                           int out_channel_offset, pn_stream_t stream);
 /* folds the partials the jobs' epilogues wrote (same job array and tile as the pn_conv2d_multi_f32 call; jobs without
  * stat_partials are skipped) into stat_affine / stat_mean_rstd: one small launch, fixed association order */
 int pn_conv_stats_finalize_f32(const pn_conv_job *jobs, int njobs, int tile, pn_stream_t stream);

@@ -1294,6 +1294,22 @@ __global__ __launch_bounds__(256) void conv_small_n_multi_kernel(MultiArgs m_by_
   }
 }
 
+__global__ __launch_bounds__(256) void conv_tap_sum_kernel(const float* __restrict__ g, int ldg, int B, int H, int W, int cout, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int act, float* __restrict__ out, int out_ps, int out_co) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * H * W * cout) return;
+  const int co = i % cout, pix = i / cout;
+  const int x = pix % W, y = (pix / W) % H;
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) s += g[(size_t)(pix + (t / 3 - 1) * W + (t % 3 - 1)) * ldg + t * cout + co];
+  }
+  const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+  out[(size_t)pix * out_ps + out_co + co] = pn::apply_act(fmaf(s, sc, sh), act);
+}
+
 template <int TAPS>
 void launch_small_n(const ConvArgs& a, int zdim, hipStream_t st) {
   const dim3 grid(pn::cdiv(a.M, 64), zdim);
@@ -1596,8 +1612,13 @@ int pn_sparse_conv_f32(const float* in, int in_rows, int cin, const int32_t* nbr
   a.res = residual; a.res_ps = cout; a.nbr = nbr; a.n_valid = n_out;
   a.res_pre_act = 1;  // SparseBasicBlock: relu(bn2(conv2(.)) + identity), scn.py:84-95
   hipStream_t st = pn::S(stream);
-  if (cout > 64) return out_capacity >= 128 * 128 ? launch_conv<2, 2, 2, 2, DT_F32, true>(a, 1, st) : launch_conv<2, 2, 1, 2, DT_F32, true>(a, 1, st);
-  if (cout > 32) return launch_conv<2, 2, 1, 1, DT_F32, true>(a, 1, st);
+  static const int tile_exp = [] { const char* e = getenv("PN_SPARSE_TILE"); return e ? atoi(e) : 0; }();
+  if (cout > 64) {
+    if (tile_exp & 1) return launch_conv<2, 2, 1, 2, DT_F32, true>(a, 1, st);
+    if (tile_exp & 4) return launch_conv<2, 2, 1, 1, DT_F32, true>(a, 1, st);
+    return out_capacity >= 128 * 128 ? launch_conv<2, 2, 2, 2, DT_F32, true>(a, 1, st) : launch_conv<2, 2, 1, 2, DT_F32, true>(a, 1, st);
+  }
+  if (cout > 32) return (tile_exp & 2) ? launch_conv<2, 2, 2, 1, DT_F32, true>(a, 1, st) : launch_conv<2, 2, 1, 1, DT_F32, true>(a, 1, st);
   return launch_conv<2, 1, 1, 1, DT_F32, true>(a, 1, st);
 }
 
@@ -1809,6 +1830,22 @@ int pn_conv2d_multi_f32(const pn_conv_job* jobs, int njobs, int tile, pn_stream_
     case 4: return norm_in ? launch_multi<2, 1, 1, 1, true>(m, extra, st) : launch_multi<2, 1, 1, 1, false>(m, 0, st);
     default: PN_REQUIRE(!norm_in, "conv_multi: tile 5 has no normalise-on-load variant"); return launch_multi<2, 4, 1, 1, false>(m, 0, st);
   }
+}
+
+// second half of a 3x3 / stride 1 / pad 1 convolution with one to three output channels computed as a GEMM over the pixels
+// (g[pixel][tap * cout + co] = x[pixel] . w[co][:][tap], pn_linear_ksplit_f32 with the (9 cout, cin) tap matrix -- the input is read
+// once) : out[b, y, x, co] = act(scale * sum_t g[b, y + kh - 1, x + kw - 1][t cout + co] + shift), taps in ascending order, pixels
+// outside the map contribute nothing.  (The E2ESWVoteHead's 256 -> 1 heat-map / vote-class convolutions, e2e_swv_head.py:88-97, took
+// 156 us each on a 32-column MFMA tile.)
+int pn_conv3x3_tap_sum_f32(const float* g, int ldg, int batch, int h, int w, int cout, const float* scale, const float* shift, int act, float* out,
+                           int out_pixel_stride, int out_channel_offset, pn_stream_t stream) {
+  PN_REQUIRE(g && out && batch >= 1 && h >= 1 && w >= 1 && cout >= 1 && cout <= 3 && ldg >= 9 * cout, "conv3x3_tap_sum: bad arguments (cout 1 .. 3, ldg >= 9 cout)");
+  PN_REQUIRE(out_pixel_stride >= out_channel_offset + cout && out_channel_offset >= 0, "conv3x3_tap_sum: channel slice does not fit the pixel stride");
+  PN_REQUIRE((long long)batch * h * w * cout < (1ll << 31), "conv3x3_tap_sum: map too large");
+  const int total = batch * h * w * cout;
+  hipLaunchKernelGGL(conv_tap_sum_kernel, dim3(pn::cdiv(total, 256)), dim3(256), 0, pn::S(stream), g, ldg, batch, h, w, cout, scale, shift, act, out,
+                     out_pixel_stride, out_channel_offset);
+  return pn::check_launch("conv_tap_sum_kernel");
 }
 
 int pn_conv2d_small_n_multi_f32(const pn_conv_job* jobs, int njobs, pn_stream_t stream) {

@@ -374,6 +374,7 @@ _WINO_MIN_TILES = int(os.environ.get("PN_CONV_WINO_MIN_TILES", "256"))
 # 256 x 256 x 128 -> 128: 79 us / 112; 128 x 128 x 128 -> 128 (512 tiles): 27 / 31; 64 x 64 x 256 -> 256 (256 tiles): 31 / 37;
 # Waymo RPN 256 x 144 x 128 -> 128: 61 / 105, 128 x 72 x 256 -> 256: 71 / 104
 _WINO4_ON = os.environ.get("PN_CONV_WINO4", "1") != "0"
+_TAPSUM_ON = os.environ.get("PN_CONV_TAPSUM", "1") != "0"   # 3x3 layers with <= 3 output channels over >= 128 input channels as GEMM + tap sum
 _WINO4_MIN_TILES = int(os.environ.get("PN_CONV_WINO4_MIN_TILES", "256"))
 _WINO4_DGRAD = os.environ.get("PN_CONV_WINO4_DGRAD", "1") != "0"     # F(4, 3) for the training data gradients (the forward stays on F(2, 3), see train.py)
 
@@ -441,6 +442,21 @@ class ConvLayer:
             self.wino4_packed = _f32(lib.pn_conv_wino4_packed_weight_floats(self.cout, self.cin), dev)
             hip.call("pn_pack_conv_weight_wino4_f32", w.data_ptr(), self.cout, self.cin, self.wino4_packed.data_ptr(), st)
 
+        # ... and 3x3 layers with one to three output channels over many input channels (the geometry-aware head's 256 -> 1 heat-map and
+        # vote-class convolutions): a GEMM over the pixels against the (9 cout, cin) tap matrix + a nine-term shifted sum
+        # (pn_conv3x3_tap_sum_f32) -- the input is read once; on a 32-column MFMA tile these layers ran at 1.4 TFLOP/s
+        self.tap_packed = None
+        if (dtype == "f32" and not deconv2x2 and self.range_strata <= 1 and self.groups == 1 and (self.kh, self.kw) == (3, 3) and self.stride == 1
+                and self.pad == (1, 1) and self.cout <= 3 and self.cin >= 128 and self.cin % 4 == 0 and _TAPSUM_ON and _LINEAR_ON):
+            self.tap_n = (9 * self.cout + 3) // 4 * 4
+            self.tap_packed = _f32(lib.pn_linear_packed_weight_floats(self.tap_n, self.cin), dev)
+            self._pack_taps(w)
+
+    def _pack_taps(self, w: torch.Tensor) -> None:
+        w9 = torch.zeros((self.tap_n, self.cin), dtype=torch.float32, device=w.device)
+        w9[:9 * self.cout] = w.reshape(self.cout, -1, 9)[:, :self.cin].permute(2, 0, 1).reshape(9 * self.cout, -1)   # row t * cout + co
+        hip.call("pn_pack_linear_weight_f32", w9.data_ptr(), self.tap_n, self.cin, self.tap_packed.data_ptr(), hip.stream())
+
     def repack(self, weight: torch.Tensor, shift: Optional[torch.Tensor] = None) -> None:
         """refresh the packed copies from an updated weight of the same shape (training: once per step).  LAZY: a layout (direct,
         F(2, 3), F(4, 3)) is packed when the next call takes it -- a layer keeps up to three and uses one per map size, and the
@@ -450,6 +466,8 @@ class ConvLayer:
         assert w.is_contiguous() and w.dtype == torch.float32
         self._stale_w = w
         self._stale = {"direct"} | ({"wino"} if self.wino_packed is not None else set()) | ({"wino4"} if self.wino4_packed is not None else set())
+        if self.tap_packed is not None:
+            self._stale.add("tap")
         if shift is not None:
             self.shift = shift
 
@@ -466,6 +484,8 @@ class ConvLayer:
                 pack_groups = self.range_strata if self.range_strata > 1 else self.groups
                 hip.call("pn_pack_conv_weight_f32", w.data_ptr(), w.shape[0], self._pack_cin, self.kh, self.kw, pack_groups,
                          self.packed.data_ptr(), st)
+        elif layout == "tap":
+            self._pack_taps(w)
         elif layout == "wino":
             hip.call("pn_pack_conv_weight_wino_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino_packed.data_ptr(), st)
         else:
@@ -529,9 +549,20 @@ class ConvLayer:
         prof = _PROFILER
         if prof is not None:
             ev = prof.begin(st)
-        use_wino4 = self._use_wino4(b, h, w, accumulate)
-        use_wino = not use_wino4 and self._use_wino(b, h, w, accumulate)
-        self._ensure("wino4" if use_wino4 else "wino" if use_wino else "direct")
+        use_tap = self.tap_packed is not None and not accumulate and self.cin == self._pack_cin and in_channel_offset % 4 == 0 and ct % 4 == 0
+        use_wino4 = not use_tap and self._use_wino4(b, h, w, accumulate)
+        use_wino = not use_tap and not use_wino4 and self._use_wino(b, h, w, accumulate)
+        self._ensure("tap" if use_tap else "wino4" if use_wino4 else "wino" if use_wino else "direct")
+        if use_tap:
+            m = b * h * w
+            g = torch.empty((m, self.tap_n), dtype=torch.float32, device=x.device)
+            hip.call("pn_linear_ksplit_f32", x.data_ptr() + 4 * in_channel_offset, m, self.cin, ct, self.tap_packed.data_ptr(), self.tap_n, None, ACT_NONE,
+                     None, self.tap_n, g.data_ptr(), self.tap_n, st)
+            hip.call("pn_conv3x3_tap_sum_f32", g.data_ptr(), self.tap_n, b, h, w, self.cout, hip.ptr(self.scale), hip.ptr(self.shift), self.act,
+                     out.data_ptr(), out.shape[3], out_channel_offset, st)
+            if prof is not None:
+                prof.end(ev, 2.0 * m * self.cout * self.cin * 9, st, tag=f"{oh}x{ow} {self.cin}->{self.out_channels} k3 gemm+taps", issued=2.0 * m * self.cin * 32)
+            return out
         if use_wino4:
             hip.call("pn_conv2d_wino4_nhwc_f32", C.byref(d), x.data_ptr(), self.wino4_packed.data_ptr(), hip.ptr(self.scale), hip.ptr(self.shift),
                      out.data_ptr(), st)

@@ -343,6 +343,10 @@ def _conv_case(dev, b, cin, cout, h, w, k, stride, pad, groups=1, act=0, seed=0,
     dict(b=1, cin=64, cout=2, h=128, w=128, k=1, stride=1, pad=0, act=0, bn=False),
     dict(b=1, cin=20, cout=7, h=64, w=80, k=3, stride=1, pad=1, act=1),           # ragged channel quarters
     dict(b=1, cin=64, cout=8, h=128, w=128, k=3, stride=2, pad=1, act=1),
+    # one to three output channels over >= 128 input channels: GEMM over the pixels + nine-term shifted sum (pn_conv3x3_tap_sum_f32)
+    dict(b=2, cin=256, cout=1, h=48, w=36, k=3, stride=1, pad=1, act=0),
+    dict(b=1, cin=128, cout=3, h=17, w=9, k=3, stride=1, pad=1, act=1),          # ragged map: last 32-row tile, borders
+    dict(b=1, cin=256, cout=2, h=1, w=5, k=3, stride=1, pad=1, act=0, bn=False),  # a single row
 ])
 def test_conv_mfma(dev, case):
     import zlib
@@ -650,3 +654,27 @@ def test_forward_cart_equals_forward_points(dev):
         for k in ref:
             assert torch.equal(a[k], ref[k]) and torch.equal(b[k], ref[k]), (seed, k)
         assert int(torch.count_nonzero(canvas)) == 0 and int(torch.count_nonzero(state.cell_count)) == 0
+
+
+@pytest.mark.gpu
+def test_conv_tap_sum_route_is_taken_and_honours_channel_offsets(dev):
+    """ConvLayer sends 3x3 layers with <= 3 output channels over >= 128 input channels through pn_linear_ksplit_f32 +
+    pn_conv3x3_tap_sum_f32; channel slices of wider maps on both sides; checked against fp64."""
+    from partner_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 20, 24, 264), generator=g).to(dev)          # the layer reads channels 8 .. 263
+    w = (torch.randn((1, 256, 3, 3), generator=g) * 0.05).to(dev)
+    shift = torch.randn(1, generator=g).to(dev)
+    layer = ops.ConvLayer(w, stride=1, pad=1, shift=shift, act=0)
+    assert layer.tap_packed is not None
+    out = torch.full((2, 20, 24, 5), 3.0, device=dev)
+    layer(x, out=out, out_channel_offset=2, in_channel_offset=8)
+    ref = F.conv2d(x[..., 8:].permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), padding=1) + shift.double().cpu()[None, :, None, None]
+    assert float((out[..., 2].double().cpu() - ref[:, 0]).abs().max()) < 2e-5 * float(ref.abs().max())
+    assert torch.all(out[..., :2] == 3.0) and torch.all(out[..., 3:] == 3.0)
+    # refreshed weights (training: once per step) reach the tap matrix as well
+    w2 = (w * 2).contiguous()
+    layer.repack(w2)
+    out2 = layer(x, in_channel_offset=8)
+    ref2 = 2 * (ref - shift.double().cpu()[None, :, None, None]) + shift.double().cpu()[None, :, None, None]
+    assert float((out2[..., 0].double().cpu() - ref2[:, 0]).abs().max()) < 4e-5 * float(ref2.abs().max())
