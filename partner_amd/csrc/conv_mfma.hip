@@ -97,6 +97,9 @@ struct ConvArgs {
 
 constexpr int BK = 32;
 constexpr int A_LD = BK + 4;
+#ifndef PN_GATHER_EXP
+#define PN_GATHER_EXP 0   // diagnostic build only (tools/micro/gather_ablate.hip): bit 0 neighbour = own row, 1 no input loads, 2 no weight loads, 3 no LDS stores
+#endif
 
 template <int WM, int WN, int TM, int TN, int DT, bool GATHER, bool NORM_IN>
 __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid, const int n0, const int z) {
@@ -273,8 +276,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid, cons
     for (int j = 0; j < A_PER_T; ++j) {
       unsigned vo;
       if constexpr (GATHER) {
-        const int idx = nbr_s[((tid >> 3) + (NT / 8) * j) * taps + tap];   // input row of this (site, tap), -1: inactive
+        int idx = nbr_s[((tid >> 3) + (NT / 8) * j) * taps + tap];   // input row of this (site, tap), -1: inactive
+        if constexpr (PN_GATHER_EXP & 1) idx = min(m0 + (tid >> 3) + (NT / 8) * j, m_valid - 1);
         vo = (idx >= 0 && cok) ? (unsigned)idx * (unsigned)(a.in_ps * ES) + a_off[j] : 0xffffffffu;
+        if constexpr (PN_GATHER_EXP & 2) vo = 0xffffffffu;
       } else {
         const unsigned sel = (a_mask[j] >> tap) & cok;             // 1: inside the map
         vo = a_off[j] | (0u - (1u - (sel & 1u)));                  // branch-free: ~0 when outside
@@ -283,7 +288,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid, cons
     }
 #pragma unroll
     for (int j = 0; j < B_PER_T; ++j)
-      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, live ? b_off[j] : 0xffffffffu, live ? so_b : 0u, 0));
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (live && !(GATHER && (PN_GATHER_EXP & 4))) ? b_off[j] : 0xffffffffu, live ? so_b : 0u, 0));
     if (++ld_kw == a.KW) { ld_kw = 0; ++ld_kh; }
     if (++ld_tap == taps_loop) { ld_tap = 0; ld_kh = 0; ld_kw = 0; ++ld_chunk; }
   };
@@ -1619,7 +1624,10 @@ int pn_sparse_conv_f32(const float* in, int in_rows, int cin, const int32_t* nbr
     return out_capacity >= 128 * 128 ? launch_conv<2, 2, 2, 2, DT_F32, true>(a, 1, st) : launch_conv<2, 2, 1, 2, DT_F32, true>(a, 1, st);
   }
   if (cout > 32) return (tile_exp & 2) ? launch_conv<2, 2, 2, 1, DT_F32, true>(a, 1, st) : launch_conv<2, 2, 1, 1, DT_F32, true>(a, 1, st);
-  return launch_conv<2, 1, 1, 1, DT_F32, true>(a, 1, st);
+  // 32 columns: four waves on 128 rows share the weight tile (64 x 32 tiles, two waves: 237 us for the 32 -> 32 layers of the bench frame,
+  // 300 k sites; this form 207; two row tiles per wave 350)
+  if (tile_exp & 16) return launch_conv<2, 1, 1, 1, DT_F32, true>(a, 1, st);
+  return launch_conv<4, 1, 1, 1, DT_F32, true>(a, 1, st);
 }
 
 // The 16-channel level (cout == 16, cin 8 or 16) on the VALU kernel above.  Same arguments and result as pn_sparse_conv_f32 up to the

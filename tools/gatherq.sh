@@ -1,0 +1,4 @@
+cd tools/micro
+for e in ${EXPS:-0 1 2 4 6}; do
+  hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DPN_GATHER_EXP=$e -I../../include gather_ablate.hip -o /tmp/ga_$e 2>/dev/null && echo "EXP $e" && /tmp/ga_$e
+done
