@@ -911,6 +911,10 @@ typedef struct {
  * rpn.py:124-142 (the stride-1 convolutions of every block). */
 size_t pn_conv_wino_packed_weight_floats(int cout, int cin);
 int pn_pack_conv_weight_wino_f32(const float *w_oihw, int cout, int cin, float *packed, pn_stream_t stream);
+/* the same layout for the DATA GRADIENT of that layer (grad_input of Conv2d, rpn.py:124-142 under autograd): a 3x3 / stride 1 / pad 1
+ * convolution of dout with w'[n][c][kh][kw] = w[c][n][2-kh][2-kw]; packed straight from the forward (Cout, Cin, 3, 3) tensor, no
+ * flipped / transposed copy in between.  The packed size is pn_conv_wino_packed_weight_floats(cin_fwd, cout_fwd). */
+int pn_pack_conv_dgrad_weight_wino_f32(const float *w_fwd_oihw, int cout_fwd, int cin_fwd, float *packed, pn_stream_t stream);
 int pn_conv2d_wino_nhwc_f32(const pn_conv_desc *desc, const float *in, const float *packed_w, const float *scale,
                             const float *shift, float *out, pn_stream_t stream);
 /* The same layers with F(4, 3) along the width (map width a multiple of 4; activation none or ReLU): six GEMMs over quads of
@@ -920,6 +924,8 @@ int pn_conv2d_wino_nhwc_f32(const pn_conv_desc *desc, const float *in, const flo
  * (transformed in double, rounded once); results agree with pn_conv2d_nhwc_f32 to ~4e-6 of the map's range.  rpn.py:124-142. */
 size_t pn_conv_wino4_packed_weight_floats(int cout, int cin);
 int pn_pack_conv_weight_wino4_f32(const float *w_oihw, int cout, int cin, float *packed, pn_stream_t stream);
+/* F(4,3) weights of the layer's DATA GRADIENT from the forward tensor (see pn_pack_conv_dgrad_weight_wino_f32) */
+int pn_pack_conv_dgrad_weight_wino4_f32(const float *w_fwd_oihw, int cout_fwd, int cin_fwd, float *packed, pn_stream_t stream);
 int pn_conv_wino4_tiles(const pn_conv_desc *desc);
 int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc *desc, const float *in, const float *packed_w, const float *scale,
                              const float *shift, float *out, pn_stream_t stream);

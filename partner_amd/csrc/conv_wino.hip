@@ -548,7 +548,9 @@ __global__ __launch_bounds__(512) void conv_wino_bd_kernel(WinoArgs a) {
 }
 
 // torch (Cout, Cin, 3, 3) -> [chunk][kh][q][k4 (8)][cout_pad][4]: U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2
-__global__ void pack_wino_weight_kernel(const float* __restrict__ w, int cout, int cin, int chunks, int cout_pad, float* __restrict__ packed, size_t total) {
+// dgrad: w is the FORWARD weight (cin, cout, 3, 3) of the layer whose data gradient this convolution is -- taps mirrored, channels swapped
+__global__ void pack_wino_weight_kernel(const float* __restrict__ w, int cout, int cin, int chunks, int cout_pad, float* __restrict__ packed, size_t total,
+                                        int dgrad) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     size_t r = i;
     const int k1 = r & 3; r >>= 2;
@@ -560,8 +562,9 @@ __global__ void pack_wino_weight_kernel(const float* __restrict__ w, int cout, i
     const int c = chunk * 32 + k4 * 4 + k1;
     float v = 0.f;
     if (n < cout && c < cin) {
-      const float* g = w + (((size_t)n * cin + c) * 3 + kh) * 3;
-      v = q == 0 ? g[0] : q == 1 ? (g[0] + g[1] + g[2]) * 0.5f : q == 2 ? (g[0] - g[1] + g[2]) * 0.5f : g[2];
+      const float* g = dgrad ? w + (((size_t)c * cout + n) * 3 + (2 - kh)) * 3 : w + (((size_t)n * cin + c) * 3 + kh) * 3;
+      const float g0 = dgrad ? g[2] : g[0], g1 = g[1], g2 = dgrad ? g[0] : g[2];
+      v = q == 0 ? g0 : q == 1 ? (g0 + g1 + g2) * 0.5f : q == 2 ? (g0 - g1 + g2) * 0.5f : g2;
     }
     packed[i] = v;
   }
@@ -575,13 +578,23 @@ size_t pn_conv_wino_packed_weight_floats(int cout, int cin) {
   return (size_t)pn::cdiv(cin, 32) * 3 * 4 * 8 * (size_t)(pn::cdiv(cout, WBN) * WBN) * 4;
 }
 
-int pn_pack_conv_weight_wino_f32(const float* w_oihw, int cout, int cin, float* packed, pn_stream_t stream) {
-  PN_REQUIRE(w_oihw && packed && cout >= 1 && cin >= 1, "pack_conv_weight_wino: bad arguments");
+static int pack_wino(const float* w, int cout, int cin, float* packed, pn_stream_t stream, int dgrad) {
+  PN_REQUIRE(w && packed && cout >= 1 && cin >= 1, "pack_conv_weight_wino: bad arguments");
   const int chunks = pn::cdiv(cin, 32), cout_pad = pn::cdiv(cout, WBN) * WBN;
   const size_t total = pn_conv_wino_packed_weight_floats(cout, cin);
-  hipLaunchKernelGGL(pack_wino_weight_kernel, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0, pn::S(stream), w_oihw, cout, cin, chunks,
-                     cout_pad, packed, total);
+  hipLaunchKernelGGL(pack_wino_weight_kernel, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0, pn::S(stream), w, cout, cin, chunks,
+                     cout_pad, packed, total, dgrad);
   return pn::check_launch("pack_wino_weight_kernel");
+}
+
+int pn_pack_conv_weight_wino_f32(const float* w_oihw, int cout, int cin, float* packed, pn_stream_t stream) {
+  return pack_wino(w_oihw, cout, cin, packed, stream, 0);
+}
+
+// the weights of the DATA-GRADIENT convolution straight from the forward layer's (Cout_fwd, Cin_fwd, 3, 3) tensor: the gradient conv has
+// cout = Cin_fwd output and cin = Cout_fwd input channels, w'[n][c][kh][kw] = w[c][n][2 - kh][2 - kw]
+int pn_pack_conv_dgrad_weight_wino_f32(const float* w_fwd_oihw, int cout_fwd, int cin_fwd, float* packed, pn_stream_t stream) {
+  return pack_wino(w_fwd_oihw, cin_fwd, cout_fwd, packed, stream, 1);
 }
 
 int pn_conv2d_wino_nhwc_f32(const pn_conv_desc* d, const float* in, const float* packed_w, const float* scale, const float* shift, float* out,

@@ -575,7 +575,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_ks_kernel(Wino4Args a) {
 }
 
 // torch (Cout, Cin, 3, 3) -> [chunk][kh][q 6][k4 8][cout_pad][4], transformed in double, rounded once
-__global__ void pack_wino4_weight_kernel(const float* __restrict__ w, int cout, int cin, int chunks, int cout_pad, float* __restrict__ packed, size_t total) {
+// dgrad: w is the FORWARD weight (cin, cout, 3, 3) of the layer whose data gradient this convolution is -- taps mirrored, channels swapped
+__global__ void pack_wino4_weight_kernel(const float* __restrict__ w, int cout, int cin, int chunks, int cout_pad, float* __restrict__ packed, size_t total,
+                                         int dgrad) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     size_t r = i;
     const int k1 = r & 3; r >>= 2;
@@ -587,8 +589,8 @@ __global__ void pack_wino4_weight_kernel(const float* __restrict__ w, int cout, 
     const int c = chunk * 32 + k4 * 4 + k1;
     double v = 0.0;
     if (n < cout && c < cin) {
-      const float* g = w + (((size_t)n * cin + c) * 3 + kh) * 3;
-      const double g0 = g[0], g1 = g[1], g2 = g[2];
+      const float* g = dgrad ? w + (((size_t)c * cout + n) * 3 + (2 - kh)) * 3 : w + (((size_t)n * cin + c) * 3 + kh) * 3;
+      const double g0 = dgrad ? g[2] : g[0], g1 = g[1], g2 = dgrad ? g[0] : g[2];
       v = q == 0 ? g0 / 4.0 : q == 1 ? -(g0 + g1 + g2) / 6.0 : q == 2 ? -(g0 - g1 + g2) / 6.0 : q == 3 ? g0 / 24.0 + g1 / 12.0 + g2 / 6.0
           : q == 4 ? g0 / 24.0 - g1 / 12.0 + g2 / 6.0 : g2;
     }
@@ -604,13 +606,22 @@ size_t pn_conv_wino4_packed_weight_floats(int cout, int cin) {
   return (size_t)pn::cdiv(cin, 32) * 3 * 6 * 8 * (size_t)(pn::cdiv(cout, W4N) * W4N) * 4;
 }
 
-int pn_pack_conv_weight_wino4_f32(const float* w_oihw, int cout, int cin, float* packed, pn_stream_t stream) {
-  PN_REQUIRE(w_oihw && packed && cout >= 1 && cin >= 1, "pack_conv_weight_wino4: bad arguments");
+static int pack_wino4(const float* w, int cout, int cin, float* packed, pn_stream_t stream, int dgrad) {
+  PN_REQUIRE(w && packed && cout >= 1 && cin >= 1, "pack_conv_weight_wino4: bad arguments");
   const int chunks = pn::cdiv(cin, 32), cout_pad = pn::cdiv(cout, W4N) * W4N;
   const size_t total = pn_conv_wino4_packed_weight_floats(cout, cin);
-  hipLaunchKernelGGL(pack_wino4_weight_kernel, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0, pn::S(stream), w_oihw, cout, cin,
-                     chunks, cout_pad, packed, total);
+  hipLaunchKernelGGL(pack_wino4_weight_kernel, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0, pn::S(stream), w, cout, cin,
+                     chunks, cout_pad, packed, total, dgrad);
   return pn::check_launch("pack_wino4_weight_kernel");
+}
+
+int pn_pack_conv_weight_wino4_f32(const float* w_oihw, int cout, int cin, float* packed, pn_stream_t stream) {
+  return pack_wino4(w_oihw, cout, cin, packed, stream, 0);
+}
+
+// the weights of the DATA-GRADIENT convolution straight from the forward layer's (Cout_fwd, Cin_fwd, 3, 3) tensor (see conv_wino.hip)
+int pn_pack_conv_dgrad_weight_wino4_f32(const float* w_fwd_oihw, int cout_fwd, int cin_fwd, float* packed, pn_stream_t stream) {
+  return pack_wino4(w_fwd_oihw, cin_fwd, cout_fwd, packed, stream, 1);
 }
 
 int pn_conv_wino4_tiles(const pn_conv_desc* d) {

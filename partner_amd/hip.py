@@ -182,6 +182,8 @@ SIGNATURES = {
     "pn_linear_ksplit_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),
     "pn_conv_wino_packed_weight_floats": (_SZ, [_I, _I]),
     "pn_pack_conv_weight_wino_f32": (_I, [_P, _I, _I, _P, _P]),
+    "pn_pack_conv_dgrad_weight_wino_f32": (_I, [_P, _I, _I, _P, _P]),
+    "pn_pack_conv_dgrad_weight_wino4_f32": (_I, [_P, _I, _I, _P, _P]),
     "pn_conv2d_wino_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "pn_conv_wino4_packed_weight_floats": (_SZ, [_I, _I]),
     "pn_pack_conv_weight_wino4_f32": (_I, [_P, _I, _I, _P, _P]),

@@ -1045,11 +1045,12 @@ class ConvDgrad:
             else:
                 hip.call("pn_pack_deconv2x2_weight_f32", w.data_ptr(), self.cout, self.cin, self.packed.data_ptr(), st)
             return
-        wd = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()     # (Cin, Cout, 3, 3): the equivalent forward weight of the gradient conv
+        # the gradient convolution's weight is the forward one with the taps mirrored and the channels swapped: the pack kernels read it so
+        # (r2 made a flipped + transposed copy first: two more launches per layer and iteration)
         if layout == "wino":
-            hip.call("pn_pack_conv_weight_wino_f32", wd.data_ptr(), self.cin, self.cout, self.wino_packed.data_ptr(), st)
+            hip.call("pn_pack_conv_dgrad_weight_wino_f32", w.data_ptr(), self.cout, self.cin, self.wino_packed.data_ptr(), st)
         else:
-            hip.call("pn_pack_conv_weight_wino4_f32", wd.data_ptr(), self.cin, self.cout, self.wino4_packed.data_ptr(), st)
+            hip.call("pn_pack_conv_dgrad_weight_wino4_f32", w.data_ptr(), self.cout, self.cin, self.wino4_packed.data_ptr(), st)
 
     def __call__(self, dout: torch.Tensor, out: Optional[torch.Tensor] = None, dout_channel_offset=0,
                  out_channel_offset=0, accumulate=False) -> torch.Tensor:
