@@ -84,9 +84,12 @@ __global__ __launch_bounds__(512) void wgrad_wino4_kernel(WgArgs a) {
     float* Zs = Vs + 3 * WG_KQ * WG_LD;
     const f32x4 d0 = rx[0], d1 = rx[1], d2 = rx[2], d3 = rx[3], d4 = rx[4], d5 = rx[5];
     const f32x4 y0 = rd[0], y1 = rd[1], y2 = rd[2], y3 = rd[3];
+    // fused multiply-adds on whole vectors (v_pk_fma_f32): the build runs with -ffp-contract=off, and on this chip a VALU instruction is
+    // paid in MFMA time (r2: separate multiplies and adds, ~2.5x the instructions)
+    const f32x4 c4v = {4.f, 4.f, 4.f, 4.f}, m4v = {-4.f, -4.f, -4.f, -4.f}, m5v = {-5.f, -5.f, -5.f, -5.f}, c2v = {2.f, 2.f, 2.f, 2.f}, c8v = {8.f, 8.f, 8.f, 8.f};
     if (half == 0) {
-      const f32x4 e = d4 - 4.f * d2, o = d3 - 4.f * d1;
-      *reinterpret_cast<f32x4*>(Vs + 0 * WG_KQ * WG_LD) = (4.f * d0 - 5.f * d2) + d4;
+      const f32x4 e = __builtin_elementwise_fma(m4v, d2, d4), o = __builtin_elementwise_fma(m4v, d1, d3);
+      *reinterpret_cast<f32x4*>(Vs + 0 * WG_KQ * WG_LD) = __builtin_elementwise_fma(c4v, d0, __builtin_elementwise_fma(m5v, d2, d4));
       *reinterpret_cast<f32x4*>(Vs + 1 * WG_KQ * WG_LD) = e + o;
       *reinterpret_cast<f32x4*>(Vs + 2 * WG_KQ * WG_LD) = e - o;
       const f32x4 se = y0 + y2, so = y1 + y3;
@@ -94,11 +97,11 @@ __global__ __launch_bounds__(512) void wgrad_wino4_kernel(WgArgs a) {
       *reinterpret_cast<f32x4*>(Zs + 1 * WG_KQ * WG_LD) = se + so;
       *reinterpret_cast<f32x4*>(Zs + 2 * WG_KQ * WG_LD) = se - so;
     } else {
-      const f32x4 f = d4 - d2, g = 2.f * (d3 - d1);
-      *reinterpret_cast<f32x4*>(Vs + 0 * WG_KQ * WG_LD) = f + g;
-      *reinterpret_cast<f32x4*>(Vs + 1 * WG_KQ * WG_LD) = f - g;
-      *reinterpret_cast<f32x4*>(Vs + 2 * WG_KQ * WG_LD) = (4.f * d1 - 5.f * d3) + d5;
-      const f32x4 se = y0 + 4.f * y2, so = 2.f * y1 + 8.f * y3;
+      const f32x4 f = d4 - d2, t = d3 - d1;
+      *reinterpret_cast<f32x4*>(Vs + 0 * WG_KQ * WG_LD) = __builtin_elementwise_fma(c2v, t, f);
+      *reinterpret_cast<f32x4*>(Vs + 1 * WG_KQ * WG_LD) = __builtin_elementwise_fma(-c2v, t, f);
+      *reinterpret_cast<f32x4*>(Vs + 2 * WG_KQ * WG_LD) = __builtin_elementwise_fma(c4v, d1, __builtin_elementwise_fma(m5v, d3, d5));
+      const f32x4 se = __builtin_elementwise_fma(c4v, y2, y0), so = __builtin_elementwise_fma(c8v, y3, y1 + y1);
       *reinterpret_cast<f32x4*>(Zs + 0 * WG_KQ * WG_LD) = se + so;
       *reinterpret_cast<f32x4*>(Zs + 1 * WG_KQ * WG_LD) = se - so;
       *reinterpret_cast<f32x4*>(Zs + 2 * WG_KQ * WG_LD) = y3;
