@@ -19,6 +19,7 @@ reference's keys and the inference path (after ``PlanCache`` invalidation) sees 
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -49,6 +50,40 @@ def one_cycle(step: int, total_step: int, lr_max: float, moms: Sequence[float], 
     return cos(low, lr_max, pct), cos(moms[0], moms[1], pct)
 
 
+_WGRAD_STREAM = os.environ.get("PN_TRAIN_WGRAD_STREAM", "1") != "0"
+
+
+class _SideStream:
+    """Weight gradients off the critical path of backward: dW of a layer is needed by nobody before the gradient exchange / the optimizer,
+    while the chain  d(out) -> BatchNorm backward -> data gradient -> previous layer  is serial.  ``run`` queues a layer's weight-gradient
+    launches (kernel + slice reduction + bias sums) on a second HIP stream behind the work queued so far; the data gradient goes on on the
+    main stream and the two overlap -- the 64 x 64 / 128 x 128 layers do not fill the chip on their own.  ``join`` makes the main stream
+    wait (before a gradient bucket is handed to the exchange, and at the end of backward).  Same kernels, same results: nothing here
+    depends on the order two independent kernels finish in.  ``PN_TRAIN_WGRAD_STREAM=0`` keeps everything on one stream."""
+
+    def __init__(self, device):
+        on = _WGRAD_STREAM and torch.device(device).type == "cuda" and torch.cuda.is_available()
+        self.stream = torch.cuda.Stream(device=device) if on else None
+        self.dirty = False
+
+    def run(self, fn, *reads):
+        if self.stream is None:
+            fn()
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            fn()
+        for t in reads:          # blocks the caching allocator from handing these buffers out again before the side stream has read them
+            if t is not None:
+                t.record_stream(self.stream)
+        self.dirty = True
+
+    def join(self):
+        if self.stream is not None and self.dirty:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.dirty = False
+
+
 class ParamStore:
     """All trainable parameters of a module in ONE flat fp32 buffer (+ flat grad / Adam moments);
     every parameter starts on a 16-byte boundary.  The flat gradient buffer is what gets all-reduced
@@ -73,6 +108,7 @@ class ParamStore:
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat_m = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat_v = torch.zeros(off, dtype=torch.float32, device=device)
+        self.side = _SideStream(device)
         self.p: Dict[str, torch.Tensor] = {}
         self.g: Dict[str, torch.Tensor] = {}
         for name, p in model.named_parameters():
@@ -172,16 +208,20 @@ class _Conv:
         w = self.ps.p[self.wname]
         gw = self.ps.g[self.wname]
         if self.transposed:
-            ops.conv_wgrad(dout, self.x, 2, 2, 2, 0, cout=w.shape[0], dout_channel_offset=self.in_co, out=gw)
+            self.ps.side.run(lambda: ops.conv_wgrad(dout, self.x, 2, 2, 2, 0, cout=w.shape[0], dout_channel_offset=self.in_co, out=gw), dout, self.x)
             if need_dx:
                 self.dgrad.repack(w)
                 return self.dgrad(dout, out=dx, out_channel_offset=dx_co, accumulate=accumulate)
             return None
         cout = w.shape[0] if cout is None else cout
-        ops.conv_wgrad(self.x, dout, self.k, self.k, self.stride, self.pad, cin=self.cin_real, in_channel_offset=self.in_co,
-                       cout=cout, out=gw)
-        if self.bname is not None:
-            ops.channel_sum(dout, c=cout, out=self.ps.g[self.bname])
+
+        def weight_grads():
+            ops.conv_wgrad(self.x, dout, self.k, self.k, self.stride, self.pad, cin=self.cin_real, in_channel_offset=self.in_co,
+                           cout=cout, out=gw)
+            if self.bname is not None:
+                ops.channel_sum(dout, c=cout, out=self.ps.g[self.bname])
+
+        self.ps.side.run(weight_grads, dout, self.x)
         if need_dx:
             self.dgrad.repack(w)
             return self.dgrad(dout, out=dx, out_channel_offset=dx_co, accumulate=accumulate)
@@ -207,7 +247,7 @@ class _PillarConv:
 
     def bwd(self, dout, cout=None, need_dx=True, dx=None, dx_co=0, accumulate=False):
         """-> d(pillar features) (n_cap, Cin) instead of a dense canvas gradient (dynamic_pfn_bwd takes either)"""
-        self.layer.wgrad(self.x, dout, self.vi, self.tables, out=self.ps.g[self.wname])
+        self.ps.side.run(lambda: self.layer.wgrad(self.x, dout, self.vi, self.tables, out=self.ps.g[self.wname]), dout, self.x, self.tables)
         return self.layer.dgrad_features(dout, self.vi, self.tables) if need_dx else None
 
 
@@ -613,11 +653,13 @@ class PolarPillarTrainStep:
         sparse = isinstance(self.blocks[0][0].conv, _PillarConv)      # then d_block is d(pillar features) (n_cap, C), not a canvas gradient
         ops.dynamic_pfn_bwd(self.points, self.vi, ps.p[self.w0], ps.p[self.w1], r.vx, r.vy, r.x_offset, r.y_offset,
                             d_features=d_block if sparse else None, d_canvas=None if sparse else d_block, dw0=ps.g[self.w0], dw1=ps.g[self.w1])
+        ps.side.join()
 
     def _bucket_ready(self, k: int) -> None:
         """start the SUM all-reduce of gradient bucket k (asynchronous: RCCL's stream waits for the kernels queued so far and
         runs next to the rest of backward; the reference's DDP reducer does the same per bucket, det3d/torchie/apis/train.py:330-336)"""
         if self._exchange is not None:
+            self.ps.side.join()      # the bucket's weight gradients are computed on the side stream
             self._exchange.ready(k)
 
     # ------------------------------------------------------------------------------------------
