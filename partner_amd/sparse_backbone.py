@@ -25,6 +25,7 @@ from .builder import BACKBONES
 from .nn_utils import PlanCache, build_norm_layer, eval_only
 
 _C16 = os.environ.get("PN_SPARSE_C16", "1") != "0"     # 0: the 16-channel level on the gathered MFMA kernel as well
+_STRUCT_STREAM = os.environ.get("PN_SPARSE_STRUCT_STREAM", "1") != "0"   # 0: index builds / neighbour tables on the calling stream
 
 
 class SubMConv3d(nn.Module):
@@ -136,9 +137,9 @@ class SpMiddleResNetFHD(nn.Module):
     def _i3(v):
         return (C.c_int32 * 3)(*[int(x) for x in v])
 
-    def _neighbors(self, keys, cap, count, out_dims, in_index, in_dims, geo):
+    def _neighbors(self, keys, cap, count, out_dims, in_index, in_dims, geo, out=None):
         taps = geo[0][0] * geo[0][1] * geo[0][2]
-        nbr = torch.empty((cap, taps), dtype=torch.int32, device=keys.device)
+        nbr = out if out is not None else torch.empty((cap, taps), dtype=torch.int32, device=keys.device)
         hip.call("pn_sparse_neighbors", keys.data_ptr(), cap, count.data_ptr(), (C.c_int32 * 4)(*out_dims), in_index.data_ptr(),
                  (C.c_int32 * 4)(*in_dims), self._i3(geo[0]), self._i3(geo[1]), self._i3(geo[2]), nbr.data_ptr(), hip.stream())
         return nbr
@@ -163,55 +164,111 @@ class SpMiddleResNetFHD(nn.Module):
             cells = d[0] * d[1] * d[2] * d[3]
             return torch.empty(lib.pn_sparse_index_bytes(cells), dtype=torch.uint8, device=dev)
 
-        # ---- level 0: index from the voxel coordinates, features into key order (zero padded to a multiple of 4 channels)
-        index = new_index(dims)
+        # ---- the STRUCTURE of every level (active sets of the strided stages, neighbour tables) depends on the voxel coordinates only, not on
+        # the features: it is built on a second stream beside the convolutions of the earlier levels (r3; 0.8 ms of small latency-bound
+        # launches left the critical path of the frame).  Every buffer is allocated here, on the calling stream, before the fork; a level's
+        # convolutions wait for that level's event.  Inside a hipGraph capture the fork / joins become graph dependencies.
+        subm_geo = ((3, 3, 3), (1, 1, 1), (1, 1, 1))
+        main = torch.cuda.current_stream()
+        side = self._structure_stream(dev) if _STRUCT_STREAM else None
+
+        def tbl(rows, geo):
+            return torch.empty((rows, geo[0][0] * geo[0][1] * geo[0][2]), dtype=torch.int32, device=dev)
+
+        levels = []          # per level: dict(index, keys, count, cap, dims, nbr, down=(dnbr) or None)
         cap = V
-        keys = torch.empty(cap, dtype=torch.int32, device=dev)
-        count = torch.empty(1, dtype=torch.int32, device=dev)
+        lv = dict(index=new_index(dims), keys=torch.empty(cap, dtype=torch.int32, device=dev), count=torch.empty(1, dtype=torch.int32, device=dev),
+                  cap=cap, dims=dims, dnbr=None)
+        lv["nbr"] = tbl(cap, subm_geo)
         rank = torch.empty(cap, dtype=torch.int32, device=dev)
-        hip.call("pn_sparse_index_from_coords", coors.data_ptr(), V, n_voxels.data_ptr(), (C.c_int32 * 4)(*dims), index.data_ptr(), keys.data_ptr(),
-                 count.data_ptr(), rank.data_ptr(), st)
+        levels.append(lv)
+        geos = [stage["down"]["geo"] for stage in plan["stages"] if stage["down"] is not None] + [plan["extra"]["geo"]]
+        for gi, geo in enumerate(geos):
+            prev = levels[-1]
+            odims = self._out_dims(prev["dims"], geo)
+            ocap = int(min(odims[0] * odims[1] * odims[2] * odims[3], 8 * prev["cap"]))
+            nl = dict(index=new_index(odims), keys=torch.empty(ocap, dtype=torch.int32, device=dev), count=torch.empty(1, dtype=torch.int32, device=dev),
+                      cap=ocap, dims=odims, geo=geo, dnbr=tbl(ocap, geo))
+            nl["nbr"] = tbl(ocap, subm_geo) if gi + 1 < len(geos) else None      # the last level (extra_conv) has no submanifold layers
+            levels.append(nl)
+
+        def build_structure():
+            st = hip.stream()
+            l0 = levels[0]
+            hip.call("pn_sparse_index_from_coords", coors.data_ptr(), V, n_voxels.data_ptr(), (C.c_int32 * 4)(*dims), l0["index"].data_ptr(),
+                     l0["keys"].data_ptr(), l0["count"].data_ptr(), rank.data_ptr(), st)
+            self._neighbors(l0["keys"], l0["cap"], l0["count"], l0["dims"], l0["index"], l0["dims"], subm_geo, out=l0["nbr"])
+            l0["ready"] = self._mark(side)
+            for prev, cur in zip(levels[:-1], levels[1:]):
+                geo = cur["geo"]
+                hip.call("pn_sparse_index_downsample", prev["keys"].data_ptr(), prev["cap"], prev["count"].data_ptr(), (C.c_int32 * 4)(*prev["dims"]),
+                         self._i3(geo[0]), self._i3(geo[1]), self._i3(geo[2]), (C.c_int32 * 4)(*cur["dims"]), cur["index"].data_ptr(),
+                         cur["keys"].data_ptr(), cur["cap"], cur["count"].data_ptr(), st)
+                self._neighbors(cur["keys"], cur["cap"], cur["count"], cur["dims"], prev["index"], prev["dims"], geo, out=cur["dnbr"])
+                if cur["nbr"] is not None:
+                    self._neighbors(cur["keys"], cur["cap"], cur["count"], cur["dims"], cur["index"], cur["dims"], subm_geo, out=cur["nbr"])
+                cur["ready"] = self._mark(side)
+
+        if side is None:
+            build_structure()
+        else:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                build_structure()
+
+        def wait(level):
+            ev = level.get("ready")
+            if ev is not None:
+                main.wait_event(ev)
+
+        # ---- features: into key order (zero padded to a multiple of 4 channels), then the convolutions level by level
+        st = hip.stream()
         c0 = plan["cin0"]
         src = voxel_features.contiguous().float()
         if c0 != cin:
             src = torch.cat([src, torch.zeros((V, c0 - cin), dtype=torch.float32, device=dev)], 1).contiguous()
         feats = torch.zeros((cap, c0), dtype=torch.float32, device=dev)
+        cur = levels[0]
+        wait(cur)
         hip.call("pn_sparse_permute_rows", src.data_ptr(), rank.data_ptr(), V, n_voxels.data_ptr(), c0, feats.data_ptr(), st)
-        subm_geo = ((3, 3, 3), (1, 1, 1), (1, 1, 1))
-        nbr = self._neighbors(keys, cap, count, dims, index, dims, subm_geo)
-        x = self._conv(feats, cap, nbr, count, cap, plan["input"], ops.ACT_RELU)
+        x = self._conv(feats, cur["cap"], cur["nbr"], cur["count"], cur["cap"], plan["input"], ops.ACT_RELU)
+        li = 0
         for stage in plan["stages"]:
             if stage["down"] is not None:
-                geo = stage["down"]["geo"]
-                odims = self._out_dims(dims, geo)
-                ocells = odims[0] * odims[1] * odims[2] * odims[3]
-                ocap = int(min(ocells, 8 * cap))
-                oindex = new_index(odims)
-                okeys = torch.empty(ocap, dtype=torch.int32, device=dev)
-                ocount = torch.empty(1, dtype=torch.int32, device=dev)
-                hip.call("pn_sparse_index_downsample", keys.data_ptr(), cap, count.data_ptr(), (C.c_int32 * 4)(*dims), self._i3(geo[0]),
-                         self._i3(geo[1]), self._i3(geo[2]), (C.c_int32 * 4)(*odims), oindex.data_ptr(), okeys.data_ptr(), ocap, ocount.data_ptr(), st)
-                dnbr = self._neighbors(okeys, ocap, ocount, odims, index, dims, geo)
-                x = self._conv(x, cap, dnbr, ocount, ocap, stage["down"], ops.ACT_RELU)
-                index, keys, count, cap, dims = oindex, okeys, ocount, ocap, odims
-                nbr = self._neighbors(keys, cap, count, dims, index, dims, subm_geo)
+                li += 1
+                nxt = levels[li]
+                wait(nxt)
+                x = self._conv(x, cur["cap"], nxt["dnbr"], nxt["count"], nxt["cap"], stage["down"], ops.ACT_RELU)
+                cur = nxt
             for c1, c2 in stage["blocks"]:
-                y = self._conv(x, cap, nbr, count, cap, c1, ops.ACT_RELU)
-                x = self._conv(y, cap, nbr, count, cap, c2, ops.ACT_RELU, residual=x)
-        geo = plan["extra"]["geo"]
-        odims = self._out_dims(dims, geo)
-        ocap = int(min(odims[0] * odims[1] * odims[2] * odims[3], 8 * cap))
-        oindex = new_index(odims)
-        okeys = torch.empty(ocap, dtype=torch.int32, device=dev)
-        ocount = torch.empty(1, dtype=torch.int32, device=dev)
-        hip.call("pn_sparse_index_downsample", keys.data_ptr(), cap, count.data_ptr(), (C.c_int32 * 4)(*dims), self._i3(geo[0]), self._i3(geo[1]),
-                 self._i3(geo[2]), (C.c_int32 * 4)(*odims), oindex.data_ptr(), okeys.data_ptr(), ocap, ocount.data_ptr(), st)
-        dnbr = self._neighbors(okeys, ocap, ocount, odims, index, dims, geo)
-        x = self._conv(x, cap, dnbr, ocount, ocap, plan["extra"], ops.ACT_RELU)
+                y = self._conv(x, cur["cap"], cur["nbr"], cur["count"], cur["cap"], c1, ops.ACT_RELU)
+                x = self._conv(y, cur["cap"], cur["nbr"], cur["count"], cur["cap"], c2, ops.ACT_RELU, residual=x)
+        last = levels[li + 1]
+        wait(last)
+        x = self._conv(x, cur["cap"], last["dnbr"], last["count"], last["cap"], plan["extra"], ops.ACT_RELU)
         cch = plan["extra"]["cout"]
+        odims = last["dims"]
         out = torch.empty((odims[0], odims[2], odims[3], cch * odims[1]), dtype=torch.float32, device=dev)
-        hip.call("pn_sparse_to_dense_nhwc", x.data_ptr(), okeys.data_ptr(), ocap, ocount.data_ptr(), (C.c_int32 * 4)(*odims), cch, out.data_ptr(), st)
+        hip.call("pn_sparse_to_dense_nhwc", x.data_ptr(), last["keys"].data_ptr(), last["cap"], last["count"].data_ptr(), (C.c_int32 * 4)(*odims), cch,
+                 out.data_ptr(), st)
         return out
+
+    _streams: dict = {}
+
+    @classmethod
+    def _structure_stream(cls, dev):
+        key = str(dev)
+        if key not in cls._streams:
+            cls._streams[key] = torch.cuda.Stream(device=dev)
+        return cls._streams[key]
+
+    @staticmethod
+    def _mark(side):
+        if side is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(side)
+        return ev
 
     def forward(self, voxel_features, coors, batch_size, input_shape):
         """(ret (B, C*D, H, W) logical NCHW view, multi_scale_voxel_features) as scn.py:157-192; the multi-scale sparse tensors are
