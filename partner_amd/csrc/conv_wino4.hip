@@ -71,6 +71,7 @@ struct Wino4Args {
   int in_ps, in_co, out_ps, out_co;
   int act;
   int quads_per_row, total_quads, qtiles;
+  int qt0;                 // first 32-quad tile of this launch (two-phase launches: the tail of a map goes to a second launch)
   int ncol;                // 128-column tiles
   int chunks, cout_pad;
   unsigned in_bytes, w_bytes;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
   int ld_kh = 0, ld_chunk = 0;     // A loader position
   int lb_kh = 0, lb_chunk = 0;     // B loader position: the K step whose fragments are requested next
   auto setup_tile = [&](int tl) {
-    pt = px0 + tl / a.ncol;
+    pt = a.qt0 + px0 + tl / a.ncol;
     n0 = (tl - (tl / a.ncol) * a.ncol) * W4N;
     ld_kh = ld_chunk = lb_kh = lb_chunk = 0;
 #pragma unroll
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_ks_kernel(Wino4Args a) {
   int ld_kh = 0, ld_chunk = 0, lb_kh = 0, lb_chunk = 0;
   float sc = 1.f, sh = 0.f;
   auto setup_tile = [&](int tl) {
-    pt = px0 + tl / a.ncol;
+    pt = a.qt0 + px0 + tl / a.ncol;
     n0 = (tl - (tl / a.ncol) * a.ncol) * W4K_N;
     ld_kh = ld_chunk = lb_kh = lb_chunk = 0;
     const int p = pt * WQ + pl;
@@ -681,26 +682,46 @@ int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc* d, const float* in, const float
   }
   const int ncu = (dev >= 0 && dev < 64) ? cus[dev] : 256;
   a.qtiles = pn::cdiv(a.total_quads, 32);
-  pn::ProfileSlot ps;
-  const bool prof = pn::take_profile_slot(ps);
+  a.qt0 = 0;
   hipStream_t st = pn::S(stream);
-  // layers whose column count is not a multiple of 128 (64-column layers) would waste the plain form's tile: K-split form
-  if (a.Cout % W4N != 0 || wino4_form((long long)a.qtiles * a.ncol, ncu) == 2) {
-    a.ncol = pn::cdiv(a.Cout, W4K_N);
-    const long long tiles = (long long)a.qtiles * a.ncol;
+  auto launch_ks = [&](Wino4Args k, bool prof) {
     static bool ks_done[64] = {false};
     if (pn::first_use_on_device(ks_done))
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_ks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino4_ks_smem());
+    k.ncol = pn::cdiv(k.Cout, W4K_N);
+    const long long tiles = (long long)k.qtiles * k.ncol;
     const dim3 grid((unsigned)std::min<long long>(2 * ncu, (tiles + 7) / 8 * 8));
-    if (prof) hipExtLaunchKernelGGL(conv_wino4_ks_kernel, grid, dim3(256), wino4_ks_smem(), st, ps.start, ps.stop, 0, a);
-    else hipLaunchKernelGGL(conv_wino4_ks_kernel, grid, dim3(256), wino4_ks_smem(), st, a);
+    pn::ProfileSlot ps;
+    if (prof && pn::take_profile_slot(ps)) hipExtLaunchKernelGGL(conv_wino4_ks_kernel, grid, dim3(256), wino4_ks_smem(), st, ps.start, ps.stop, 0, k);
+    else hipLaunchKernelGGL(conv_wino4_ks_kernel, grid, dim3(256), wino4_ks_smem(), st, k);
+  };
+  // layers whose column count is not a multiple of 128 (64-column layers) would waste the plain form's tile: K-split form
+  if (a.Cout % W4N != 0 || wino4_form((long long)a.qtiles * a.ncol, ncu) == 2) {
+    launch_ks(a, true);
     return pn::check_launch("conv_wino4_ks_kernel");
   }
-  const long long tiles = (long long)a.qtiles * a.ncol;
-  // persistent blocks, two per CU (a multiple of 8: the XCD count), fewer when there are fewer tiles
-  const dim3 grid((unsigned)std::min<long long>(2 * ncu, (tiles + 7) / 8 * 8));
+  // persistent blocks, two per CU (a multiple of 8: the XCD count), fewer when there are fewer tiles.
+  // Two phases (r3): the plain form runs the WHOLE rounds of its 2-per-CU block slots; a last round that would be less than ~60 % full
+  // (the Waymo maps: 576 tiles = 1.125 rounds, 1152 = 2.25) goes to a second launch in the K-split form, whose tiles are a quarter
+  // as wide.  (The tail rows add their K slices in the K-split form's order: last-bit differences to the rows before them.)
+  static const int two_phase = [] { const char* e = getenv("PN_WINO4_TWO_PHASE"); return e ? atoi(e) : 1; }();
+  const long long slots = 2LL * ncu;
+  long long tiles = (long long)a.qtiles * a.ncol;
+  Wino4Args tail = a;
+  tail.qtiles = 0;
+  if (two_phase && tiles > slots && tiles % slots != 0 && (tiles % slots) * 10 < slots * 6 && slots % a.ncol == 0) {
+    const int q1 = (int)((tiles / slots) * slots / a.ncol);      // quad tiles of the full rounds
+    tail.qt0 = q1;
+    tail.qtiles = a.qtiles - q1;
+    a.qtiles = q1;
+    tiles = (long long)a.qtiles * a.ncol;
+  }
+  pn::ProfileSlot ps;
+  const bool prof = pn::take_profile_slot(ps);
+  const dim3 grid((unsigned)std::min<long long>(slots, (tiles + 7) / 8 * 8));
   if (prof) hipExtLaunchKernelGGL(conv_wino4_kernel, grid, dim3(256), wino4_smem(32), st, ps.start, ps.stop, 0, a);
   else hipLaunchKernelGGL(conv_wino4_kernel, grid, dim3(256), wino4_smem(32), st, a);
+  if (tail.qtiles > 0) launch_ks(tail, false);
   return pn::check_launch("conv_wino4_kernel");
 }
 

@@ -166,7 +166,10 @@ def run_wino4(x, w, scale, shift, act, in_co=0, cin=None, out=None, out_co=0):
 
 
 CASES4 = [(1, 256, 256, 128, 128), (1, 256, 144, 128, 128), (1, 128, 72, 256, 256), (2, 30, 24, 36, 70), (1, 7, 8, 8, 5), (3, 5, 4, 4, 1), (1, 9, 132, 64, 130),
-          (1, 1, 4, 32, 33), (2, 3, 260, 20, 129), (1, 100, 512, 8, 130), (3, 67, 100, 12, 128)]   # the last two: plain form with ragged channels / tiles
+          (1, 1, 4, 32, 33), (2, 3, 260, 20, 129), (1, 100, 512, 8, 130), (3, 67, 100, 12, 128),   # the last two: plain form with ragged channels / tiles
+          # two-phase launches: whole rounds of the plain form + the tail rows in the K-split form (576 tiles = 1.125 rounds; 1152 = 2.25, two
+          # column tiles; a ragged last quad tile in the tail)
+          (2, 256, 144, 32, 128), (2, 256, 144, 16, 256), (1, 577, 128, 8, 128)]
 
 
 @pytest.mark.parametrize("case", CASES4, ids=str)
