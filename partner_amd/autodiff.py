@@ -71,6 +71,7 @@ class Tape:
             if n.g is not None:
                 n.bw(n.g)
                 n.g = None   # interior gradients are dead after use
+        side_join(self.nodes[-1].v.device if self.nodes else None)      # every parameter gradient is complete before it is routed / read
         for leaf, alias in self._views:
             if alias.g is not None:
                 accumulate(leaf, alias.g.view(leaf.v.shape), own=alias.owned)
@@ -85,6 +86,20 @@ class Tape:
             alias.g = None
         for leaf, full in touched.values():
             accumulate(leaf, full, own=True)
+
+
+def side_run(fn, *reads) -> None:
+    """queue a layer's weight-gradient launches (and the accumulation into the parameter's gradient) on the device's second stream: weight
+    gradients run beside the data-gradient chain (ops.SideStream).  A module-level function on purpose: a backward closure that
+    held its Tape would close a reference cycle (tape -> node -> closure -> tape) and keep a whole iteration's activations alive until the
+    cyclic collector runs -- 12.7 GB more per iteration when it was tried."""
+    dev = next((r.device for r in reads if r is not None), None)
+    ops.shared_side_stream(dev if dev is not None else "cpu").run(fn, *reads)
+
+
+def side_join(device) -> None:
+    if device is not None:
+        ops.shared_side_stream(device).join()
 
 
 def accumulate(node: Node, g: torch.Tensor, own=False) -> None:
@@ -128,10 +143,13 @@ def linear(t: Tape, x: Node, w: Node, b: Optional[Node], k_pad: Optional[int] = 
         if x.needs_grad:
             dx = ops.ConvDgrad(wv.view(n_out, kk, 1, 1), 1, 0)(dy4).view(m, kk)
             accumulate(x, dx, own=True)
-        dw = ops.conv_wgrad(x.v.view(1, m, 1, kk), dy4, 1, 1).view(n_out, kk)
-        accumulate(w, dw[:, :k].contiguous() if kk != k else dw, own=True)
-        if b is not None:
-            accumulate(b, ops.channel_sum(dy4), own=True)
+        def weight_grads():
+            dw = ops.conv_wgrad(x.v.view(1, m, 1, kk), dy4, 1, 1).view(n_out, kk)
+            accumulate(w, dw[:, :k].contiguous() if kk != k else dw, own=True)
+            if b is not None:
+                accumulate(b, ops.channel_sum(dy4), own=True)
+
+        side_run(weight_grads, dy, x.v)
 
     return t.new(y, bw)
 
@@ -376,10 +394,13 @@ def conv2d(t: Tape, x: Node, w: Node, b: Optional[Node], stride=1, pad=0, relu=F
         if relu:
             dy = ops.relu_bwd(y, dy)
         dy4 = _pad4(dy)
-        dw = ops.conv_wgrad(x.v, dy4, k, k, stride, pad, cin=cin, cout=cout)
-        accumulate(w, dw, own=True)
-        if b is not None:
-            accumulate(b, ops.channel_sum(dy4, c=cout), own=True)
+        def weight_grads():
+            dw = ops.conv_wgrad(x.v, dy4, k, k, stride, pad, cin=cin, cout=cout)
+            accumulate(w, dw, own=True)
+            if b is not None:
+                accumulate(b, ops.channel_sum(dy4, c=cout), own=True)
+
+        side_run(weight_grads, dy4, x.v)
         if x.needs_grad:
             dx = ops.ConvDgrad(wv, stride, pad)(dy4)
             if ct != cin:
@@ -510,8 +531,7 @@ def conv_transpose2d(t: Tape, x: Node, w: Node) -> Node:
         y = ops.ConvLayer(wt, stride=1, pad=0)(x.v)
 
         def bw1(dy):
-            dw = ops.conv_wgrad(x.v, dy, 1, 1, 1, 0)                      # (Cout, Cin, 1, 1)
-            accumulate(w, dw.permute(1, 0, 2, 3).contiguous(), own=True)
+            side_run(lambda: accumulate(w, ops.conv_wgrad(x.v, dy, 1, 1, 1, 0).permute(1, 0, 2, 3).contiguous(), own=True), dy, x.v)   # (Cout, Cin, 1, 1) -> weight layout
             if x.needs_grad:
                 accumulate(x, ops.ConvDgrad(wt, 1, 0)(dy), own=True)
 
@@ -522,8 +542,7 @@ def conv_transpose2d(t: Tape, x: Node, w: Node) -> Node:
 
     def bw2(dy):
         # the transposed convolution's weight gradient is the gradient of the stride-2 convolution dy -> x with the same tensor
-        dw = ops.conv_wgrad(dy, x.v, 2, 2, 2, 0)                          # (Cin, Cout, 2, 2)
-        accumulate(w, dw, own=True)
+        side_run(lambda: accumulate(w, ops.conv_wgrad(dy, x.v, 2, 2, 2, 0), own=True), dy, x.v)                          # (Cin, Cout, 2, 2)
         if x.needs_grad:
             accumulate(x, ops.ConvLayer(wv, stride=2, pad=0)(dy), own=True)
 

@@ -925,6 +925,56 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 # ------------------------------------------------------------------------------ conv backward (T1)
+_WGRAD_STREAM = os.environ.get("PN_TRAIN_WGRAD_STREAM", "1") != "0"
+
+
+class SideStream:
+    """Weight gradients off the critical path of backward: dW of a layer is needed by nobody before the gradient exchange / the optimizer,
+    while the chain  d(out) -> BatchNorm backward -> data gradient -> previous layer  is serial.  ``run`` queues a layer's weight-gradient
+    launches (kernel + slice reduction + bias sums) on a second HIP stream behind the work queued so far; the data gradient goes on on the
+    main stream and the two overlap -- the 64 x 64 / 128 x 128 layers do not fill the chip on their own.  ``join`` makes the main stream
+    wait (before a gradient bucket is handed to the exchange, and at the end of backward).  Same kernels, same results: nothing here
+    depends on the order two independent kernels finish in.  ``PN_TRAIN_WGRAD_STREAM=0`` keeps everything on one stream."""
+
+    def __init__(self, device):
+        on = _WGRAD_STREAM and torch.device(device).type == "cuda" and torch.cuda.is_available()
+        self.stream = torch.cuda.Stream(device=device) if on else None
+        self.dirty = False
+        self.keep: list = []
+
+    def run(self, fn, *reads):
+        if self.stream is None:
+            fn()
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            fn()
+        # the buffers the side stream reads stay referenced until the join: freed earlier, the caching allocator would hand them to the
+        # main stream again while the side stream still reads them.  (Tensor.record_stream does the same bookkeeping inside the allocator,
+        # but with hundreds of large cross-stream blocks per iteration it kept the allocator from reusing memory: the PARTNER detector's
+        # training iteration went from 103 to 184 ms.)
+        self.keep.extend(t for t in reads if t is not None)
+        self.dirty = True
+
+    def join(self):
+        if self.stream is not None and self.dirty:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.dirty = False
+            self.keep.clear()
+
+
+_SHARED_SIDE: dict = {}
+
+
+def shared_side_stream(device) -> SideStream:
+    """ONE side stream per device for the tapes (a tape lives for one iteration; a HIP stream made per iteration would also get a fresh
+    pool in the caching allocator, i.e. a hipMalloc for every buffer it ever allocates)"""
+    key = str(torch.device(device))
+    if key not in _SHARED_SIDE:
+        _SHARED_SIDE[key] = SideStream(device)
+    return _SHARED_SIDE[key]
+
+
 def conv_wgrad(x: torch.Tensor, dout: torch.Tensor, kh: int, kw: int, stride=1, pad=0, cin: Optional[int] = None,
                in_channel_offset=0, cout: Optional[int] = None, dout_channel_offset=0, out: Optional[torch.Tensor] = None,
                accumulate=False) -> torch.Tensor:

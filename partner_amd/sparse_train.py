@@ -68,14 +68,17 @@ def sparse_conv(t: ad.Tape, x: ad.Node, w: ad.Node, bias: Optional[ad.Node], nbr
             hip.call("pn_sparse_conv_f32", dy.data_ptr(), n_out, cout, inv_fn().data_ptr(), count_in.data_ptr(), n_in, taps, packed_t.data_ptr(), cin,
                      None, None, ops.ACT_NONE, None, dx.data_ptr(), hip.stream())
             ad.accumulate(x, dx, own=True)
-        dw = torch.empty_like(wv)
-        nbytes = lib.pn_sparse_conv_wgrad_workspace_bytes(n_out, taps, cout, rows_c)
-        ws = ops._workspace(nbytes, dy.device)
-        hip.call("pn_sparse_conv_wgrad_f32", x.v.data_ptr(), n_in, rows_c, cin, dy.data_ptr(), cout, nbr.data_ptr(), count_out.data_ptr(), n_out, taps,
-                 dw.data_ptr(), 0, ws.data_ptr(), nbytes, hip.stream())
-        ad.accumulate(w, dw, own=True)
-        if bias is not None:
-            ad.accumulate(bias, ops.channel_sum(dy.view(1, n_out, 1, cout)), own=True)
+        def weight_grads():       # on the tape's second stream, beside the data-gradient chain
+            dw = torch.empty_like(wv)
+            nbytes = lib.pn_sparse_conv_wgrad_workspace_bytes(n_out, taps, cout, rows_c)
+            ws = ops._workspace(nbytes, dy.device)
+            hip.call("pn_sparse_conv_wgrad_f32", x.v.data_ptr(), n_in, rows_c, cin, dy.data_ptr(), cout, nbr.data_ptr(), count_out.data_ptr(), n_out, taps,
+                     dw.data_ptr(), 0, ws.data_ptr(), nbytes, hip.stream())
+            ad.accumulate(w, dw, own=True)
+            if bias is not None:
+                ad.accumulate(bias, ops.channel_sum(dy.view(1, n_out, 1, cout)), own=True)
+
+        ad.side_run(weight_grads, dy, x.v, nbr)
 
     return t.new(y, bw)
 

@@ -50,38 +50,7 @@ def one_cycle(step: int, total_step: int, lr_max: float, moms: Sequence[float], 
     return cos(low, lr_max, pct), cos(moms[0], moms[1], pct)
 
 
-_WGRAD_STREAM = os.environ.get("PN_TRAIN_WGRAD_STREAM", "1") != "0"
-
-
-class _SideStream:
-    """Weight gradients off the critical path of backward: dW of a layer is needed by nobody before the gradient exchange / the optimizer,
-    while the chain  d(out) -> BatchNorm backward -> data gradient -> previous layer  is serial.  ``run`` queues a layer's weight-gradient
-    launches (kernel + slice reduction + bias sums) on a second HIP stream behind the work queued so far; the data gradient goes on on the
-    main stream and the two overlap -- the 64 x 64 / 128 x 128 layers do not fill the chip on their own.  ``join`` makes the main stream
-    wait (before a gradient bucket is handed to the exchange, and at the end of backward).  Same kernels, same results: nothing here
-    depends on the order two independent kernels finish in.  ``PN_TRAIN_WGRAD_STREAM=0`` keeps everything on one stream."""
-
-    def __init__(self, device):
-        on = _WGRAD_STREAM and torch.device(device).type == "cuda" and torch.cuda.is_available()
-        self.stream = torch.cuda.Stream(device=device) if on else None
-        self.dirty = False
-
-    def run(self, fn, *reads):
-        if self.stream is None:
-            fn()
-            return
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            fn()
-        for t in reads:          # blocks the caching allocator from handing these buffers out again before the side stream has read them
-            if t is not None:
-                t.record_stream(self.stream)
-        self.dirty = True
-
-    def join(self):
-        if self.stream is not None and self.dirty:
-            torch.cuda.current_stream().wait_stream(self.stream)
-            self.dirty = False
+_SideStream = ops.SideStream
 
 
 class ParamStore:
