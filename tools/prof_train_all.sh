@@ -14,5 +14,5 @@ tail -1 "$OUT/train.log" | cut -c1-300
 cat "$OUT/partner.log"
 cd "$ROOT"
 python3 tools/kernel_stats_summary.py "$OUT/train" "$OUT/sum/${PFX}_train_kernel_stats.csv" 8 "python3 bench.py --mode train --steps 6 --warmup 2: nuScenes polar-pillar model, bs = 4 sweeps of 30k points, 8 iterations (2 warm-up + 6); NOTE: weight gradients run on a second stream beside the data-gradient chain -- the durations of overlapping kernels add up to more than the wall time of an iteration"
-python3 tools/kernel_stats_summary.py "$OUT/partner" "$OUT/sum/${PFX}_train_partner_kernel_stats.csv" 4 "python3 tools/train_partner_profile.py --steps 3: Waymo PARTNER detector, bs = 2 sweeps of 180k points, 4 iterations (1 warm-up + 3)" | head -30
+python3 tools/kernel_stats_summary.py "$OUT/partner" "$OUT/sum/${PFX}_train_partner_kernel_stats.csv" 4 "python3 tools/train_partner_profile.py --steps 3: Waymo PARTNER detector, bs = 2 sweeps of 180k points, 4 iterations (1 warm-up + 3); NOTE: weight gradients run on a second stream -- the durations of overlapping kernels add up to more than the wall time of an iteration" | head -30
 [ -n "$KEEP_RAW" ] || rm -rf "$OUT/train" "$OUT/partner"
