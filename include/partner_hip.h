@@ -181,6 +181,14 @@ int pn_scatter_mean_f32(const float *points, int point_stride, int f, const int3
 int pn_hard_voxel_mean_f32(const float *voxels, const int32_t *num_points, int v, int p, int f,
                            float *mean, pn_stream_t stream);
 
+/* The collate of several samples' hard voxels (torch.cat of the per-sample lists, F.pad(coordinates, ((0, 0), (1, 0)), value = b),
+ * det3d/torchie/parallel/collate.py:107-125) on the device, counts included: feats [batch][seg_rows][c] and coors [batch][seg_rows][3]
+ * hold every sample's list at its capacity, counts[batch] the live rows of each; the live rows are packed in sample order into
+ * feats_out / coords4_out ([b, z, y, x] rows), *total = their sum.  Rows past *total are left untouched. */
+int pn_concat_voxel_segments_f32(const float *feats, const int32_t *coors, const int32_t *counts, int batch,
+                                 int seg_rows, int c, float *feats_out, int32_t *coords4_out,
+                                 int32_t *total, pn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * V4 (+V5)  DynamicPFNet forward, cylinder grid, full decoration (16 channels):
  *   [points(7) | xyz-mean_voxel(3) | x-xc, y-yc | (rho,phi)-mean_voxel(2) | rho-rc, phi-pc]

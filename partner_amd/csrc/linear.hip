@@ -465,9 +465,12 @@ static int g_linear_tile = -1;     // -1: not read yet; 0: automatic
 static double tile_cost(int tm, int tn, int k) {   // cycles of one round (two co-resident blocks, one tile each): MFMA time of both + the fixed part
   return 2.0 * (64.0 * tm * 64.0 * tn * k / 2048.0 * 64.0 / 4.0) * 1.06 + 5000.0 + (tm * tn < 4 ? 1500.0 : 0.0);
 }
-static LinPlan linear_plan(int m, int n, int k, int ncu) {
+static int linear_tile_pin() {       // the pinned main form (0: automatic); reads PN_LINEAR_TILE once
   if (g_linear_tile < 0) { const char* e = getenv("PN_LINEAR_TILE"); g_linear_tile = e ? atoi(e) : 0; }
-  if (g_linear_tile) return {g_linear_tile, 0, m};
+  return g_linear_tile;
+}
+static LinPlan linear_plan(int m, int n, int k, int ncu) {
+  if (linear_tile_pin()) return {g_linear_tile, 0, m};
   // under half a round of big tiles: 64 x 64 tiles.  (The K-split form is never picked here: pn_linear_f32 keeps ONE summation order
   // -- the tiled forms all add in the order of the r2 convolution route -- and pn_linear_ksplit_f32 is the explicit other one.)
   if ((long long)pn::cdiv(m, 128) * pn::cdiv(n, 128) * 2 <= ncu) return {11, 0, m};
@@ -541,7 +544,9 @@ static int linear_launch(const float* x, int m, int k, int ldx, const float* pac
   const bool prof = pn::take_profile_slot(slot);
   const pn::ProfileSlot* ps = prof ? &slot : nullptr;
   hipStream_t st = pn::S(stream);
-  const LinPlan plan = (ksplit && !g_linear_tile) ? LinPlan{1, 0, m} : linear_plan(m, n, k, ncu);
+  // (r3 fix: the pin used to be read inside linear_plan only, so the process's FIRST K-split call saw the "not read yet" marker as a pin
+  // and ran a tiled form -- one call with the other summation order, enough to flip key points in the first frame of a process)
+  const LinPlan plan = (ksplit && !linear_tile_pin()) ? LinPlan{1, 0, m} : linear_plan(m, n, k, ncu);
   a.M1 = plan.m1;
   if (plan.form == 1) {
     a.mtiles = pn::cdiv(m, 32);

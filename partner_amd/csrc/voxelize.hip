@@ -499,6 +499,29 @@ struct UniqueWs {
   }
 };
 
+// feats [batch][seg_rows][c], coors [batch][seg_rows][3], counts[batch] (clamped to seg_rows) -> rows of sample b at prefix(b) + r
+__global__ __launch_bounds__(256) void concat_segments_kernel(const float* __restrict__ feats, const int32_t* __restrict__ coors,
+                                                              const int32_t* __restrict__ counts, int batch, int seg_rows, int c,
+                                                              float* __restrict__ feats_out, int32_t* __restrict__ coords4_out, int32_t* __restrict__ total) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  const int b = (int)(i / seg_rows), r = (int)(i - (long long)b * seg_rows);
+  int prefix = 0, mine = 0, all = 0;
+  for (int k = 0; k < batch; ++k) {
+    const int n = min(max(counts[k], 0), seg_rows);
+    if (k < b) prefix += n;
+    if (k == b) mine = n;
+    all += n;
+  }
+  if (i == 0) *total = all;
+  if (b >= batch || r >= mine) return;
+  const size_t src = (size_t)b * seg_rows + r, dst = (size_t)prefix + r;
+  for (int k = 0; k < c; ++k) feats_out[dst * c + k] = feats[src * c + k];
+  coords4_out[dst * 4] = b;
+  coords4_out[dst * 4 + 1] = coors[src * 3];
+  coords4_out[dst * 4 + 2] = coors[src * 3 + 1];
+  coords4_out[dst * 4 + 3] = coors[src * 3 + 2];
+}
+
 }  // namespace
 
 extern "C" {
@@ -684,6 +707,19 @@ int pn_sort_voxel_runs(const int32_t* voxel_start, const int32_t* num_voxels, in
   return pn::check_launch("sort_runs_kernel");
 }
 
+
+// Several samples' voxel lists -- each at its capacity, with its count on the device -- into ONE list with the batch index in front of the
+// coordinates: what the collate of the reference does on the host (torch.cat of the per-sample voxels and F.pad of the coordinates,
+// det3d/torchie/parallel/collate.py:107-125) without the counts ever leaving the device.  Sample b's rows follow sample b-1's.
+int pn_concat_voxel_segments_f32(const float* feats, const int32_t* coors, const int32_t* counts, int batch, int seg_rows, int c, float* feats_out,
+                                 int32_t* coords4_out, int32_t* total, pn_stream_t stream) {
+  PN_REQUIRE(feats && coors && counts && feats_out && coords4_out && total, "concat_voxel_segments: null pointer");
+  PN_REQUIRE(batch >= 1 && batch <= 64 && seg_rows >= 1 && c >= 1 && (long long)batch * seg_rows < (1ll << 31), "concat_voxel_segments: bad sizes (1 .. 64 samples)");
+  const long long rows = (long long)batch * seg_rows;
+  hipLaunchKernelGGL(concat_segments_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, pn::S(stream), feats, coors, counts, batch, seg_rows, c,
+                     feats_out, coords4_out, total);
+  return pn::check_launch("concat_segments_kernel");
+}
 
 size_t pn_hard_voxelize_workspace_bytes(uint64_t num_cells, int n, int max_points) {
   // unique workspace + inv + cnt + first + flag + vid_at + tiles + sel[max_points][n] + nv

@@ -480,23 +480,40 @@ class VoxelNetV3(SingleStageDetector):
             x = self.neck.forward_nhwc(x)
         return x
 
-    def forward_points(self, points: torch.Tensor, voxel_generator=None):
-        """Fused single-sample path from polar-decorated points (N, F) on the device: hard voxelization (device, count stays on
-        the device) -> mean VFE -> sparse backbone -> 2 x SetBlock -> RPN -> head.  No host synchronisation: capturable
-        in a hipGraph (``engine.FrameEngine``).  ``voxel_generator``: dict(range, voxel_size, max_points_in_voxel,
-        max_voxel_num); default = the one the config hands to the head."""
+    def forward_points(self, points: torch.Tensor, voxel_generator=None, sample_offsets=None):
+        """Fused path from polar-decorated points (N, F) on the device: hard voxelization (device, count stays on the device) -> mean VFE
+        -> sparse backbone -> 2 x SetBlock -> RPN -> head.  No host synchronisation: capturable in a hipGraph (``engine.FrameEngine``).
+        ``voxel_generator``: dict(range, voxel_size, max_points_in_voxel, max_voxel_num); default = the one the config hands to the head.
+        ``sample_offsets``: python ints [0, n_0, n_0 + n_1, ...] for a batch of several sweeps (r3): every sample is voxelized on its own
+        and the lists are joined on the device (pn_concat_voxel_segments_f32 = the reference's collate, counts included)."""
         eval_only(self, "VoxelNetV3")
         vg = voxel_generator or getattr(self.bbox_head, "voxel_generator_cfg", None)
         if vg is None:
             raise ValueError("VoxelNetV3.forward_points needs the voxel_generator section of the config")
         mv = vg["max_voxel_num"]
         mv = int(mv[0] if isinstance(mv, (list, tuple)) else mv)
-        voxels, coors, num, nv = ops.hard_voxelize(points, vg["voxel_size"], vg["range"], int(vg["max_points_in_voxel"]), mv)
-        feats = self.reader(voxels, num)
-        coords4 = torch.cat([torch.zeros((mv, 1), dtype=torch.int32, device=points.device), coors], 1)
         rg, vs = vg["range"], vg["voxel_size"]
         grid = [int(round((rg[3 + a] - rg[a]) / vs[a])) for a in range(3)]
-        x = self.backbone.forward_nhwc(feats, coords4, 1, grid, n_voxels=nv)
+        offs = [0, int(points.shape[0])] if sample_offsets is None else [int(v) for v in sample_offsets]
+        batch = len(offs) - 1
+        if batch == 1:
+            voxels, coors, num, nv = ops.hard_voxelize(points, vg["voxel_size"], vg["range"], int(vg["max_points_in_voxel"]), mv)
+            feats = self.reader(voxels, num)
+            coords4 = torch.cat([torch.zeros((mv, 1), dtype=torch.int32, device=points.device), coors], 1)
+        else:
+            fs, cs, nvs = [], [], []
+            for b in range(batch):
+                voxels, coors, num, nv = ops.hard_voxelize(points[offs[b]:offs[b + 1]], vg["voxel_size"], vg["range"], int(vg["max_points_in_voxel"]), mv)
+                fs.append(self.reader(voxels, num))
+                cs.append(coors)
+                nvs.append(nv)
+            seg_f, seg_c, counts = torch.stack(fs).contiguous(), torch.stack(cs).contiguous(), torch.cat(nvs).contiguous()
+            feats = torch.zeros((batch * mv, seg_f.shape[2]), dtype=torch.float32, device=points.device)
+            coords4 = torch.zeros((batch * mv, 4), dtype=torch.int32, device=points.device)
+            nv = torch.empty((1,), dtype=torch.int32, device=points.device)
+            hip.call("pn_concat_voxel_segments_f32", seg_f.data_ptr(), seg_c.data_ptr(), counts.data_ptr(), batch, mv, int(seg_f.shape[2]),
+                     feats.data_ptr(), coords4.data_ptr(), nv.data_ptr(), hip.stream())
+        x = self.backbone.forward_nhwc(feats, coords4, batch, grid, n_voxels=nv)
         x = self.realign_nhwc(x)
         if self.with_neck:
             x = self.neck.forward_nhwc(x)

@@ -42,9 +42,8 @@ class FrameEngine:
         self.index_state = None if hasattr(model, "attns") else model.new_index_state(batch, self.spec, dev)
 
     def _step(self):
-        if hasattr(self.model, "attns"):   # VoxelNetV3 (Waymo PARTNER config): single-sample hard-voxel path
-            assert self.batch == 1, "the fused VoxelNetV3 path takes one sample per frame"
-            preds = self.model.forward_points(ops.cart_to_polar(self.cart))
+        if hasattr(self.model, "attns"):   # VoxelNetV3 (Waymo PARTNER config): hard-voxel path, every sample voxelized on its own
+            preds = self.model.forward_points(ops.cart_to_polar(self.cart), sample_offsets=[self.n * b for b in range(self.batch + 1)])
         elif self.index_state is not None:
             preds = self.model.forward_cart(self.cart, self.offsets, self.batch, self.spec, canvas=self.canvas, index_state=self.index_state)
         else:

@@ -73,6 +73,7 @@ SIGNATURES = {
     "pn_hard_voxelize_f32": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "pn_scatter_mean_f32": (_I, [_P, _I, _I, _P, _P, _P, _I, _P, _P]),
     "pn_hard_voxel_mean_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "pn_concat_voxel_segments_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "pn_dynamic_pfn_fwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _F, _F, _F, _F, _P, _P, _P]),
     "pn_pfn_center_table_floats": (_SZ, [_I]),
     "pn_pfn_center_table_f32": (_I, [_I, _F, _F, _P, _P]),

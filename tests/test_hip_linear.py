@@ -106,3 +106,26 @@ def test_linear_rejects_bad_arguments(dev):
     assert lib.pn_linear_f32(x.data_ptr(), 8, 6, 6, x.data_ptr(), 8, None, 0, None, 0, x.data_ptr(), 8, None) == -1      # k % 4
     assert "multiples of 4" in hip.last_error()
     assert lib.pn_linear_set_tile(13) == -1
+
+
+@pytest.mark.gpu
+def test_first_ksplit_call_of_a_process_uses_the_ksplit_form():
+    """r3 regression: in a FRESH process the very first pn_linear_ksplit_f32 call must add in the same order as every later one (the pin
+    of the tile form used to be initialised lazily by the tiled path only: the first K-split call ran a tiled form and the first frame of
+    a process picked other key points than all later frames)"""
+    import subprocess
+    import sys
+    code = (
+        "import torch\n"
+        "from partner_amd import hip, ops\n"
+        "hip.load(); dev = torch.device('cuda:0')\n"
+        "g = torch.Generator().manual_seed(0)\n"
+        "x = torch.randn((1024, 256), generator=g).to(dev); w = (torch.randn((256, 256), generator=g) * 0.05).to(dev)\n"
+        "layer = ops.GemmLayer(w, None, ksplit=True)\n"
+        "a = layer(x).clone(); b = layer(x).clone(); c = layer(x).clone()\n"
+        "assert torch.equal(a, b) and torch.equal(b, c), float((a - b).abs().max())\n"
+        "print('ok')\n")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -275,6 +275,59 @@ def test_voxelnet_v3_fused_path_and_graph(dev):
         assert torch.equal(out[k], ref[k]), k
 
 
+def test_voxelnet_v3_fused_path_batch_of_two_and_graph(dev):
+    """r3: the fused path with two sweeps per frame -- every sample voxelized on its own, the lists joined on the device
+    (pn_concat_voxel_segments_f32) -- equals the example-dict forward of the same two sweeps bit for bit, eagerly and as ONE hipGraph
+    replay; the join itself against torch.cat on ragged counts (an empty sample included)"""
+    import os
+    import partner_amd as P
+    from partner_amd import hip, ops
+    from partner_amd.engine import FrameEngine
+    from partner_amd.voxel_generator import VoxelGenerator
+    # the join alone: three samples, counts 5 / 0 / 3 of capacity 7
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn((3, 7, 5), generator=g).to(dev)
+    coors = torch.randint(0, 100, (3, 7, 3), generator=g, dtype=torch.int32).to(dev)
+    counts = torch.tensor([5, 0, 3], dtype=torch.int32, device=dev)
+    fo = torch.full((21, 5), -1.0, device=dev)
+    co = torch.full((21, 4), -1, dtype=torch.int32, device=dev)
+    tot = torch.zeros(1, dtype=torch.int32, device=dev)
+    hip.call("pn_concat_voxel_segments_f32", feats.data_ptr(), coors.data_ptr(), counts.data_ptr(), 3, 7, 5, fo.data_ptr(), co.data_ptr(), tot.data_ptr(),
+             hip.stream())
+    assert int(tot) == 8
+    assert torch.equal(fo[:8], torch.cat([feats[0, :5], feats[2, :3]])) and torch.all(fo[8:] == -1.0)
+    exp_c = torch.cat([torch.cat([torch.zeros((5, 1), dtype=torch.int32, device=dev), coors[0, :5]], 1),
+                       torch.cat([torch.full((3, 1), 2, dtype=torch.int32, device=dev), coors[2, :3]], 1)])
+    assert torch.equal(co[:8], exp_c) and torch.all(co[8:] == -1)
+
+    cfg_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "waymo", "polar_partner_c4.py")
+    w = P.Config.fromfile(cfg_path)
+    m = P.build_detector(w.model, train_cfg=w.train_cfg, test_cfg=None)
+    geo = {k: getattr(m.bbox_head, k).clone() for k in ("offset_grid", "xy_offset")}
+    synth.load_filled(m, base_seed=31)
+    for k, v in geo.items():
+        getattr(m.bbox_head, k).data.copy_(v)
+    m = m.to(dev).eval()
+    n = 40000
+    cart = torch.cat([torch.from_numpy(synth.synth_sweep_beams_cart(n, seed=s)).to(dev) for s in (2, 5)])
+    polar = ops.cart_to_polar(cart)
+    fused = m.forward_points(polar, sample_offsets=[0, n, 2 * n])
+    vg = VoxelGenerator(synth.WAYMO_VOXEL, synth.WAYMO_RANGE, 5, 150000)
+    vs, cs, ns, nv = [], [], [], []
+    for b in range(2):
+        voxels, coors, num = vg.generate(polar[b * n:(b + 1) * n])
+        vs.append(voxels); ns.append(num); nv.append(int(voxels.shape[0]))
+        cs.append(torch.cat([torch.full((coors.shape[0], 1), b, dtype=coors.dtype, device=dev), coors], 1))
+    ref = m(dict(voxels=torch.cat(vs), coordinates=torch.cat(cs), num_points=torch.cat(ns), num_voxels=nv, shape=[np.array([1152, 2048, 40])] * 2),
+            return_loss=False)["det_preds"][0]
+    for k in ref:
+        assert fused[k].shape[0] == 2 and torch.equal(fused[k], ref[k]), k
+    eng = FrameEngine(m, 2, n).capture()
+    out = eng.run(cart)
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
+
+
 def test_waymo_frame_engine_to_boxes(dev):
     """the Waymo PARTNER frame as ONE hipGraph from Cartesian points to boxes (FrameEngine with the config's test_cfg): replay ==
     eager forward_points + predict, for two different sweeps"""
