@@ -182,7 +182,7 @@ int pn_hard_voxel_mean_f32(const float *voxels, const int32_t *num_points, int v
                            float *mean, pn_stream_t stream);
 
 /* The collate of several samples' hard voxels (torch.cat of the per-sample lists, F.pad(coordinates, ((0, 0), (1, 0)), value = b),
- * det3d/torchie/parallel/collate.py:107-125) on the device, counts included: feats [batch][seg_rows][c] and coors [batch][seg_rows][3]
+ * det3d/torchie/parallel/collate.py:126-128, 157-164) on the device, counts included: feats [batch][seg_rows][c] and coors [batch][seg_rows][3]
  * hold every sample's list at its capacity, counts[batch] the live rows of each; the live rows are packed in sample order into
  * feats_out / coords4_out ([b, z, y, x] rows), *total = their sum.  Rows past *total are left untouched. */
 int pn_concat_voxel_segments_f32(const float *feats, const int32_t *coors, const int32_t *counts, int batch,

@@ -710,7 +710,7 @@ int pn_sort_voxel_runs(const int32_t* voxel_start, const int32_t* num_voxels, in
 
 // Several samples' voxel lists -- each at its capacity, with its count on the device -- into ONE list with the batch index in front of the
 // coordinates: what the collate of the reference does on the host (torch.cat of the per-sample voxels and F.pad of the coordinates,
-// det3d/torchie/parallel/collate.py:107-125) without the counts ever leaving the device.  Sample b's rows follow sample b-1's.
+// det3d/torchie/parallel/collate.py:126-128, 157-164) without the counts ever leaving the device.  Sample b's rows follow sample b-1's.
 int pn_concat_voxel_segments_f32(const float* feats, const int32_t* coors, const int32_t* counts, int batch, int seg_rows, int c, float* feats_out,
                                  int32_t* coords4_out, int32_t* total, pn_stream_t stream) {
   PN_REQUIRE(feats && coors && counts && feats_out && coords4_out && total, "concat_voxel_segments: null pointer");

@@ -12,7 +12,8 @@ from partner_amd.utils import legs
 
 hip.load()
 out = legs.c4_leg(torch.device("cuda:0"), batch=int(sys.argv[1]) if len(sys.argv) > 1 else 2)
-print("one graph replay per frame, bs = 1:", out.get("one_graph_bs1"))
+for k in sorted(k for k in out if k.startswith("one_graph")):
+    print(k, out[k])
 for prec in ("f32", "bf16_bev_convs"):
     o = out[prec]
     print(f"{prec}: {o['ms_per_step']} ms per step, {o['frames_per_s']} frames/s")
