@@ -301,12 +301,16 @@ class _ConvGNReLU:
             return (dxr,) + tuple(extra)
         w, gw = self.ps.p[self.wname], self.ps.g[self.wname]
         cg, cin_g = self.cout // self.groups, w.shape[1]
-        ops.channel_sum(dy, out=self.ps.g[self.bname])
+        def weight_grads():
+            ops.channel_sum(dy, out=self.ps.g[self.bname])
+            for g in range(self.groups):
+                ops.conv_wgrad(self.x, dy, 3, 3, 1, 1, cin=cin_g, in_channel_offset=g * cin_g, cout=cg, dout_channel_offset=g * cg,
+                               out=gw[g * cg:(g + 1) * cg])
+
+        self.ps.side.run(weight_grads, dy, self.x)
         if dx is None:
             dx = torch.empty_like(self.x)
         for g in range(self.groups):
-            ops.conv_wgrad(self.x, dy, 3, 3, 1, 1, cin=cin_g, in_channel_offset=g * cin_g, cout=cg, dout_channel_offset=g * cg,
-                           out=gw[g * cg:(g + 1) * cg])
             self.dgrads[g].repack(w[g * cg:(g + 1) * cg])
             self.dgrads[g](dy, out=dx, dout_channel_offset=g * cg, out_channel_offset=g * cin_g, accumulate=accumulate)
         return (dx,) + tuple(extra)
@@ -336,8 +340,11 @@ class _StratConvGNReLU:
                                            RELU, dx=dout, dgamma=self.ps.g[self.gname], dbeta=self.ps.g[self.bename])
         full = ops.strat_expand(dy, self.strata)  # zeros outside the pixel's stratum: an ordinary conv gradient
         w = self.ps.p[self.wname]
-        ops.conv_wgrad(self.x, full, 3, 3, 1, 1, out=self.ps.g[self.wname])
-        ops.channel_sum(full, out=self.ps.g[self.bname])
+        def weight_grads():
+            ops.conv_wgrad(self.x, full, 3, 3, 1, 1, out=self.ps.g[self.wname])
+            ops.channel_sum(full, out=self.ps.g[self.bname])
+
+        self.ps.side.run(weight_grads, full, self.x)
         self.dgrad.repack(w)
         return self.dgrad(full, out=dx, accumulate=accumulate)
 
@@ -570,8 +577,11 @@ class PolarPillarTrainStep:
                 dz = torch.empty_like(z)
                 for g_, nm in enumerate(names):
                     dy = d_pred[nm]
-                    ops.conv_wgrad(z, dy, 3, 3, 1, 1, cin=ci, in_channel_offset=g_ * ci, cout=co, out=gw[g_ * co:(g_ + 1) * co])
-                    ops.channel_sum(dy, c=co, out=gb[g_ * co:(g_ + 1) * co])
+                    def weight_grads(dy=dy, g_=g_):
+                        ops.conv_wgrad(z, dy, 3, 3, 1, 1, cin=ci, in_channel_offset=g_ * ci, cout=co, out=gw[g_ * co:(g_ + 1) * co])
+                        ops.channel_sum(dy, c=co, out=gb[g_ * co:(g_ + 1) * co])
+
+                    ps.side.run(weight_grads, dy, z)
                     ops.ConvDgrad(w[g_ * co:(g_ + 1) * co], 1, 1)(dy, out=dz, out_channel_offset=g_ * ci)
             else:
                 cout = ps.p[last.wname].shape[0]
