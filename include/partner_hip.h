@@ -297,6 +297,11 @@ typedef struct pn_conv_desc {
                                    (asymmetric nn.ZeroPad2d); 0 = symmetric padding */
   int32_t accumulate;           /* 1: out += result (after scale/shift/act); used to sum the data
                                    gradients of branches that share an input */
+  int32_t frames_in_flight;     /* hint, 0 / 1 = none: this launch belongs to one of N independent frames that run at the
+                                   same time on other streams (several hipGraph engines).  A kernel may then take a form
+                                   that does not fill the chip on its own but wastes less work (pn_conv2d_wino4_nhwc_f32:
+                                   the plain F(4,3) form from ~96 tiles on instead of the K-split form).  Results differ
+                                   from the unhinted launch only in the summation order of the form. */
 } pn_conv_desc;
 
 size_t pn_conv_packed_weight_floats(int cout, int cin, int kh, int kw, int groups);

@@ -633,11 +633,17 @@ int pn_conv_wino4_tiles(const pn_conv_desc* d) {
 
 // the form a launch takes: 1 = 32 quads x 128 columns per block (every wave on the whole K range), 2 = 32 quads x 32 columns per block
 // with K split over the block's four waves (maps with fewer than ~3/4 of the 2-per-CU block slots in tiles of the first form)
-static int wino4_form(long long tiles128, int ncu) {
+static int wino4_form(long long tiles128, int ncu, int frames_in_flight) {
   static const int force = [] { const char* e = getenv("PN_WINO4_KSPLIT"); return e ? atoi(e) : -1; }();
   if (force == 0) return 1;
   if (force == 1) return 2;
-  return tiles128 * 4 >= 3LL * 2 * ncu ? 1 : 2;
+  static const int min_tiles = [] { const char* e = getenv("PN_WINO4_PLAIN_MIN_TILES"); return e ? atoi(e) : 0; }();
+  if (min_tiles > 0) return tiles128 >= min_tiles ? 1 : 2;
+  // other frames run beside this launch (several engines on their own streams): they fill the CUs a plain-form launch of ~100-380 tiles
+  // leaves idle, and the plain form issues less non-MFMA work per FLOP than the K-split form (four frames in flight, 128 x 128 layers in
+  // the plain form: 1308 -> 1340 frames/s; one frame in flight the same choice costs 8 % latency, so it is taken on the hint only)
+  const long long weight = frames_in_flight > 1 ? (frames_in_flight < 4 ? frames_in_flight : 4) : 1;
+  return tiles128 * 4 * weight >= 3LL * 2 * ncu ? 1 : 2;
 }
 
 int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc* d, const float* in, const float* packed_w, const float* scale, const float* shift, float* out,
@@ -696,7 +702,7 @@ int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc* d, const float* in, const float
     else hipLaunchKernelGGL(conv_wino4_ks_kernel, grid, dim3(256), wino4_ks_smem(), st, k);
   };
   // layers whose column count is not a multiple of 128 (64-column layers) would waste the plain form's tile: K-split form
-  if (a.Cout % W4N != 0 || wino4_form((long long)a.qtiles * a.ncol, ncu) == 2) {
+  if (a.Cout % W4N != 0 || wino4_form((long long)a.qtiles * a.ncol, ncu, d->frames_in_flight) == 2) {
     launch_ks(a, true);
     return pn::check_launch("conv_wino4_ks_kernel");
   }

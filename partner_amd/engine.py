@@ -12,9 +12,13 @@ from . import hip, ops
 
 
 class FrameEngine:
-    def __init__(self, model, batch: int, points_per_sweep: int, spec: ops.GridSpec = None, point_features: int = 5, test_cfg=None):
+    def __init__(self, model, batch: int, points_per_sweep: int, spec: ops.GridSpec = None, point_features: int = 5, test_cfg=None,
+                 frames_in_flight: int = 1):
         """``test_cfg``: when given, the frame ends in ``bbox_head.predict(..., device_only=True)`` inside the same graph
-        (fixed-size box / score / label buffers + a device count); otherwise the outputs are the head tensors."""
+        (fixed-size box / score / label buffers + a device count); otherwise the outputs are the head tensors.
+        ``frames_in_flight``: how many engines replay at the same time on their own streams (throughput serving); the captured
+        kernels may then take forms that leave CUs to the other frames (ops.frames_in_flight).  1 = a frame has the chip to itself."""
+        self.frames_in_flight = max(1, int(frames_in_flight))
         hip.load()
         self.test_cfg = test_cfg
         self.model = model.eval()
@@ -58,13 +62,13 @@ class FrameEngine:
         self.stream = stream
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), ops.frames_in_flight(self.frames_in_flight):
             for _ in range(warmup):  # builds plans / packs weights / sets kernel attributes outside the capture
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph), ops.frames_in_flight(self.frames_in_flight):
             self.outputs = self._step()
         return self
 

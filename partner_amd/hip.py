@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "batch", "in_h", "in_w", "cin", "cout", "groups", "kh", "kw", "stride", "pad_h", "pad_w",
         "in_pixel_stride", "in_channel_offset", "out_pixel_stride", "out_channel_offset", "act", "deconv2x2",
-        "range_strata", "pad_h_end", "pad_w_end", "accumulate")]
+        "range_strata", "pad_h_end", "pad_w_end", "accumulate", "frames_in_flight")]
 
 
 class RowPiece(C.Structure):

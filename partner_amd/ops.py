@@ -299,6 +299,27 @@ def scatter_canvas(features: torch.Tensor, unq: torch.Tensor, batch: int, t: int
 
 
 # ------------------------------------------------------------------------------ convolution
+_FRAMES_IN_FLIGHT = 1
+
+
+class frames_in_flight:
+    """``with ops.frames_in_flight(n):`` -- the convolutions launched (or captured into a hipGraph) inside the block carry the hint that n
+    independent frames run at the same time on other streams (pn_conv_desc.frames_in_flight); engine.FrameEngine wraps its capture in it"""
+
+    def __init__(self, n: int):
+        self.n, self.prev = max(1, int(n)), 1
+
+    def __enter__(self):
+        global _FRAMES_IN_FLIGHT
+        self.prev, _FRAMES_IN_FLIGHT = _FRAMES_IN_FLIGHT, self.n
+        return self
+
+    def __exit__(self, *exc):
+        global _FRAMES_IN_FLIGHT
+        _FRAMES_IN_FLIGHT = self.prev
+        return False
+
+
 class ConvProfiler:
     """Execution time of every MFMA-conv launch (bench.py roofline): the event pair is attached to the kernel dispatch
     itself (``pn_profile_next_launch`` -> hipExtLaunchKernelGGL), so the elapsed time is the kernel's own duration -- the
@@ -497,7 +518,7 @@ class ConvLayer:
         tiles = ((b * h * (w // 2) + 31) // 32) * ((self.cout + 63) // 64)   # 32-pair x 64-column tiles (the kernel takes 64-pair ones when they fill the chip)
         return tiles >= _WINO_MIN_TILES
 
-    def _use_wino4(self, b: int, h: int, w: int, accumulate: bool) -> bool:
+    def _use_wino4(self, b: int, h: int, w: int, accumulate: bool) -> bool:   # (the tile-count gate below is about leaving the direct kernel, not about the form)
         if self.wino4_packed is None or accumulate or w % 4 or self.cin != self._pack_cin or h * w > getattr(self, "wino4_max_pixels", 1 << 62):
             return False
         return ((b * h * (w // 4) + 31) // 32) * (self.cout // 32) >= _WINO4_MIN_TILES
@@ -545,6 +566,7 @@ class ConvLayer:
         d = ConvDesc(b, h, w, self.cin, self.cout, self.groups, self.kh, self.kw, self.stride, self.pad[0], self.pad[1],
                      ct, in_channel_offset, out.shape[3], out_channel_offset, self.act, int(self.deconv2x2),
                      self.range_strata, 0, 0, int(accumulate))
+        d.frames_in_flight = _FRAMES_IN_FLIGHT
         st = hip.stream()
         prof = _PROFILER
         if prof is not None:
