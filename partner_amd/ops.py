@@ -1253,12 +1253,20 @@ class CenterLossTargets:
         self.anno = anno_box.to(device).float().contiguous()
 
 
+_CODE_WEIGHTS: dict = {}
+
+
 def _loss_common(hm: torch.Tensor, ncls: int, boxes, tg: CenterLossTargets, code_weights, with_vel: bool):
     b, h, w, _ = hm.shape
     ndim = sum(n for _, n in boxes)
     ad = tg.anno.shape[-1]
     sel = list(range(ndim)) if with_vel else [0, 1, 2, 3, 4, 5, ad - 2, ad - 1]
-    cw = torch.tensor(list(code_weights)[:ndim], dtype=torch.float32, device=hm.device)
+    # cached on the device: a fresh torch.tensor(..., device=) is a pageable host-to-device copy, which makes the host wait for the stream
+    # -- twice per training iteration, in the middle of it (forward loss, backward loss): the GPU then idles while the host catches up
+    key = (tuple(float(v) for v in list(code_weights)[:ndim]), str(hm.device))
+    cw = _CODE_WEIGHTS.get(key)
+    if cw is None:
+        cw = _CODE_WEIGHTS[key] = torch.tensor(list(key[0]), dtype=torch.float32, device=hm.device)
     n = len(boxes)
     # pixel strides come from the tensors' strides, so channel-slice views of wider NHWC maps work
     args = (hm.data_ptr(), hm.stride(2), tg.hm.data_ptr(), b, ncls, h, w, (C.c_void_p * n)(*[t.data_ptr() for t, _ in boxes]),
