@@ -88,7 +88,10 @@ def set_block_train(t: ad.Tape, block: SetBlock, x: ad.Node, batch: int, prefix=
     seeds = _Seeds(seed)
     sample = L * C
     dev = x.v.device
-    pos = block.pos_cart.reshape(H, W, 2).to(dev).float().contiguous()
+    pos = block.__dict__.get("_pos_dev")          # the cells' Cartesian positions: a constant, copied to the device once
+    if pos is None or pos.device != dev or pos.shape[:2] != (H, W):
+        pos = block.pos_cart.reshape(H, W, 2).to(dev).float().contiguous()
+        block.__dict__["_pos_dev"] = pos
 
     xn, cm = ad.layernorm(t, x, P("norm1.weight"), P("norm1.bias"), a.norm1.eps, want_chan_mean=True)
     if sh:   # work in the rolled frame (set_transformer.py:121-124); rolled back before the output projection

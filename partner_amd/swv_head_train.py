@@ -23,8 +23,19 @@ from . import hip
 from .swv_head import E2ESWVoteHead
 
 
+_SHIFT_MASKS: dict = {}
+
+
 def _shift_mask(hp: int, wp: int, ws: int, shift: int, heads: int, dev) -> torch.Tensor:
-    """(nW * N * N, heads) additive mask of BasicLayer.forward (sw2votev4_util.py:259-276): 0 inside a region, -100 across"""
+    """(nW * N * N, heads) additive mask of BasicLayer.forward (sw2votev4_util.py:259-276): 0 inside a region, -100 across.  A constant of
+    the geometry: built once per (map, window, shift, heads, device) -- a numpy build + host-to-device copy per iteration is a host sync"""
+    key = (hp, wp, ws, shift, heads, str(dev))
+    if key not in _SHIFT_MASKS:
+        _SHIFT_MASKS[key] = _build_shift_mask(hp, wp, ws, shift, heads, dev)
+    return _SHIFT_MASKS[key]
+
+
+def _build_shift_mask(hp: int, wp: int, ws: int, shift: int, heads: int, dev) -> torch.Tensor:
     img = np.zeros((hp, wp), np.int32)
     cnt = 0
     for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
