@@ -705,7 +705,7 @@ def main():
     if not args.no_train_leg:
         engines.clear()        # free the graphs' private pools before the training iteration allocates its activations
         torch.cuda.empty_cache()
-        train = run_train(args, model, dev, rank, world, red_dev, steps=min(args.steps, 10), warmup=3)
+        train = run_train(args, model, dev, rank, world, red_dev, steps=min(args.steps, 20), warmup=5)
 
     if world == 1 and B == 1 and not args.eager and not args.no_c4:
         from partner_amd.utils import legs

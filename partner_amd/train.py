@@ -51,6 +51,7 @@ def one_cycle(step: int, total_step: int, lr_max: float, moms: Sequence[float], 
 
 
 _SideStream = ops.SideStream
+_OWN_STREAM = os.environ.get("PN_TRAIN_OWN_STREAM", "1") != "0"
 
 
 class ParamStore:
@@ -674,6 +675,20 @@ class PolarPillarTrainStep:
         invalidate_inference_plans(self.model)
 
     def step(self, points, sample_offsets, batch, targets: ops.CenterLossTargets, grid_ind=None):
+        if _OWN_STREAM and self.ps.side.stream is not None and torch.cuda.current_stream() == torch.cuda.default_stream():
+            # not on the legacy default stream: once a hipGraph has been launched on it, work queued there no longer overlaps with the
+            # second stream (the iteration fell back from 13.9 to the one-stream 15.3 ms inside bench.py, whose latency engine replays on
+            # the default stream) -- the iteration runs on a stream of its own, fenced against the caller's stream on both sides
+            own = self.__dict__.setdefault("_own_stream", torch.cuda.Stream(device=self.ps.flat_p.device))
+            cur = torch.cuda.current_stream()
+            own.wait_stream(cur)
+            with torch.cuda.stream(own):
+                loss = self._step(points, sample_offsets, batch, targets, grid_ind)
+            cur.wait_stream(own)
+            return loss
+        return self._step(points, sample_offsets, batch, targets, grid_ind)
+
+    def _step(self, points, sample_offsets, batch, targets: ops.CenterLossTargets, grid_ind=None):
         import torch.distributed as dist
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         from .dist_utils import GradExchange
