@@ -153,7 +153,9 @@ class PartnerTrainStep:
     def step(self, example):
         # on a stream of its own, not the legacy default stream (train.PolarPillarTrainStep.step: after a hipGraph launch on the default
         # stream the work queued there no longer overlaps with the weight-gradient stream)
-        if torch.cuda.is_available() and self.ps.flat_p.is_cuda and torch.cuda.current_stream() == torch.cuda.default_stream():
+        import torch.distributed as dist
+        single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)   # see PolarPillarTrainStep.step
+        if single and torch.cuda.is_available() and self.ps.flat_p.is_cuda and torch.cuda.current_stream() == torch.cuda.default_stream():
             own = self.__dict__.setdefault("_own_stream", torch.cuda.Stream(device=self.ps.flat_p.device))
             cur = torch.cuda.current_stream()
             own.wait_stream(cur)
