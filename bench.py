@@ -593,9 +593,8 @@ def main():
     barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, red_dev)
 
-    # every secondary leg that replays a hipGraph runs on an auxiliary stream: once a graph has been launched on the legacy default stream,
-    # work queued there no longer overlaps with other streams (the training leg, which stays on the default stream when there is a process
-    # group, lost the overlap with its weight-gradient stream: 15.3 instead of 14.0 ms per iteration)
+    # the secondary legs run on an auxiliary stream and leave the default stream to the training leg (which picks a second stream that
+    # really overlaps with it: ops.concurrent_stream)
     aux_stream = torch.cuda.Stream(device=dev)
     aux_stream.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(aux_stream)

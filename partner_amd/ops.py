@@ -950,37 +950,106 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 _WGRAD_STREAM = os.environ.get("PN_TRAIN_WGRAD_STREAM", "1") != "0"
 
 
+_CONCURRENT: dict = {}
+
+
+def concurrent_stream(device=None) -> "torch.cuda.Stream":
+    """A stream whose work really overlaps with the CURRENT stream's.  The HIP runtime multiplexes streams onto a handful of hardware queues
+    (four by default) in creation order; two streams that land on the same queue run one after the other.  Which stream collides with
+    which depends on how many streams the process made before -- measured with the training step: default + second stream 13.9 ms per
+    iteration, 15.3 ms (the one-stream time) when exactly six other streams had been created earlier, and with GPU_MAX_HW_QUEUES=8 the
+    collision just moves (tools/hwq.py).  So the choice is measured: candidates are probed with two spin kernels of ~0.3 ms, one on the
+    current stream and one on the candidate, and the first candidate that finishes the pair in about the time of one is kept (cached per
+    current stream).  Inside a hipGraph capture nothing is probed: a graph's branches are scheduled by the graph, not by these streams."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    main = torch.cuda.current_stream(dev)
+    key = (str(dev), main.cuda_stream)
+    got = _CONCURRENT.get(key)
+    if got is not None:
+        return got
+    if torch.cuda.is_current_stream_capturing():
+        any_key = (str(dev), "capture")
+        if any_key not in _CONCURRENT:
+            _CONCURRENT[any_key] = next((v for k, v in _CONCURRENT.items() if k[0] == str(dev)), None) or torch.cuda.Stream(device=dev)
+        return _CONCURRENT[any_key]
+    cycles = 600000
+
+    def pair_ms(cand):
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        if cand is not None:
+            cand.wait_stream(main)
+            with torch.cuda.stream(cand):
+                torch.cuda._sleep(cycles)
+        torch.cuda._sleep(cycles)
+        if cand is not None:
+            main.wait_stream(cand)
+        e1.record(main)
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1)
+
+    pair_ms(None)
+    one = min(pair_ms(None) for _ in range(2))
+    best, best_t = None, float("inf")
+    for _ in range(12):
+        cand = torch.cuda.Stream(device=dev)
+        t = min(pair_ms(cand) for _ in range(2))
+        if t < best_t:
+            best, best_t = cand, t
+        if t < 1.4 * one:
+            break
+    _CONCURRENT[key] = best
+    return best
+
+
 class SideStream:
     """Weight gradients off the critical path of backward: dW of a layer is needed by nobody before the gradient exchange / the optimizer,
     while the chain  d(out) -> BatchNorm backward -> data gradient -> previous layer  is serial.  ``run`` queues a layer's weight-gradient
     launches (kernel + slice reduction + bias sums) on a second HIP stream behind the work queued so far; the data gradient goes on on the
     main stream and the two overlap -- the 64 x 64 / 128 x 128 layers do not fill the chip on their own.  ``join`` makes the main stream
     wait (before a gradient bucket is handed to the exchange, and at the end of backward).  Same kernels, same results: nothing here
-    depends on the order two independent kernels finish in.  ``PN_TRAIN_WGRAD_STREAM=0`` keeps everything on one stream."""
+    depends on the order two independent kernels finish in.  The second stream is picked on first use so that it really overlaps with the
+    caller's stream (``concurrent_stream``).  ``PN_TRAIN_WGRAD_STREAM=0`` keeps everything on one stream."""
 
     def __init__(self, device):
-        on = _WGRAD_STREAM and torch.device(device).type == "cuda" and torch.cuda.is_available()
-        self.stream = torch.cuda.Stream(device=device) if on else None
+        self.on = _WGRAD_STREAM and torch.device(device).type == "cuda" and torch.cuda.is_available()
+        self.device = device
+        self._stream = None
         self.dirty = False
         self.keep: list = []
 
+    @property
+    def stream(self):
+        """the second stream for the CURRENT stream (None when switched off)"""
+        if not self.on:
+            return None
+        return concurrent_stream(self.device)
+
+    @stream.setter
+    def stream(self, value):
+        if value is None:
+            self.on = False
+
     def run(self, fn, *reads):
-        if self.stream is None:
+        side = self.stream
+        if side is None:
             fn()
             return
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
             fn()
         # the buffers the side stream reads stay referenced until the join: freed earlier, the caching allocator would hand them to the
         # main stream again while the side stream still reads them.  (Tensor.record_stream does the same bookkeeping inside the allocator,
         # but with hundreds of large cross-stream blocks per iteration it kept the allocator from reusing memory: the PARTNER detector's
         # training iteration went from 103 to 184 ms.)
         self.keep.extend(t for t in reads if t is not None)
+        self._stream = side
         self.dirty = True
 
     def join(self):
-        if self.stream is not None and self.dirty:
-            torch.cuda.current_stream().wait_stream(self.stream)
+        if self.dirty and self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
             self.dirty = False
             self.keep.clear()
 

@@ -170,7 +170,7 @@ class SpMiddleResNetFHD(nn.Module):
         # convolutions wait for that level's event.  Inside a hipGraph capture the fork / joins become graph dependencies.
         subm_geo = ((3, 3, 3), (1, 1, 1), (1, 1, 1))
         main = torch.cuda.current_stream()
-        side = self._structure_stream(dev) if _STRUCT_STREAM else None
+        side = ops.concurrent_stream(dev) if _STRUCT_STREAM else None     # a stream that really overlaps with this one (hardware-queue mapping)
 
         def tbl(rows, geo):
             return torch.empty((rows, geo[0][0] * geo[0][1] * geo[0][2]), dtype=torch.int32, device=dev)
@@ -252,15 +252,6 @@ class SpMiddleResNetFHD(nn.Module):
         hip.call("pn_sparse_to_dense_nhwc", x.data_ptr(), last["keys"].data_ptr(), last["cap"], last["count"].data_ptr(), (C.c_int32 * 4)(*odims), cch,
                  out.data_ptr(), st)
         return out
-
-    _streams: dict = {}
-
-    @classmethod
-    def _structure_stream(cls, dev):
-        key = str(dev)
-        if key not in cls._streams:
-            cls._streams[key] = torch.cuda.Stream(device=dev)
-        return cls._streams[key]
 
     @staticmethod
     def _mark(side):

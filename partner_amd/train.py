@@ -51,7 +51,6 @@ def one_cycle(step: int, total_step: int, lr_max: float, moms: Sequence[float], 
 
 
 _SideStream = ops.SideStream
-_OWN_STREAM = os.environ.get("PN_TRAIN_OWN_STREAM", "1") != "0"
 
 
 class ParamStore:
@@ -676,26 +675,12 @@ class PolarPillarTrainStep:
 
     def step(self, points, sample_offsets, batch, targets: ops.CenterLossTargets, grid_ind=None):
         import torch.distributed as dist
-        single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-        if not single and self.ps.side.stream is not None and dist.get_backend() == "gloo":
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if multi and self.ps.side.on and dist.get_backend() == "gloo":
             # gloo is the transport of the same-GPU dry runs (several ranks on ONE device, tests / bench.py --backend gloo): with the ranks'
             # extra streams the device's hardware queues are oversubscribed across processes and every collective waits for a time slice
             # (1585 against 42 ms per iteration, two ranks on one GPU) -- one stream per rank there
-            self.ps.side.stream = None
-        # (with a process group the step stays on the caller's stream: the collectives are issued from it, and at least the gloo backend
-        # is pathologically slow when they come from a non-default stream -- 487 against 39 ms per iteration, two ranks on one GPU;
-        # callers then keep hipGraph launches off the default stream themselves, as bench.py does)
-        if single and _OWN_STREAM and self.ps.side.stream is not None and torch.cuda.current_stream() == torch.cuda.default_stream():
-            # not on the legacy default stream: once a hipGraph has been launched on it, work queued there no longer overlaps with the
-            # second stream (the iteration fell back from 13.9 to the one-stream 15.3 ms inside bench.py, whose latency engine replays on
-            # the default stream) -- the iteration runs on a stream of its own, fenced against the caller's stream on both sides
-            own = self.__dict__.setdefault("_own_stream", torch.cuda.Stream(device=self.ps.flat_p.device))
-            cur = torch.cuda.current_stream()
-            own.wait_stream(cur)
-            with torch.cuda.stream(own):
-                loss = self._step(points, sample_offsets, batch, targets, grid_ind)
-            cur.wait_stream(own)
-            return loss
+            self.ps.side.on = False
         return self._step(points, sample_offsets, batch, targets, grid_ind)
 
     def _step(self, points, sample_offsets, batch, targets: ops.CenterLossTargets, grid_ind=None):

@@ -151,21 +151,6 @@ class PartnerTrainStep:
                 broadcast_flat_params(b)
 
     def step(self, example):
-        # on a stream of its own, not the legacy default stream (train.PolarPillarTrainStep.step: after a hipGraph launch on the default
-        # stream the work queued there no longer overlaps with the weight-gradient stream)
-        import torch.distributed as dist
-        single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)   # see PolarPillarTrainStep.step
-        if single and torch.cuda.is_available() and self.ps.flat_p.is_cuda and torch.cuda.current_stream() == torch.cuda.default_stream():
-            own = self.__dict__.setdefault("_own_stream", torch.cuda.Stream(device=self.ps.flat_p.device))
-            cur = torch.cuda.current_stream()
-            own.wait_stream(cur)
-            with torch.cuda.stream(own):
-                losses = self._step(example)
-            cur.wait_stream(own)
-            return losses
-        return self._step(example)
-
-    def _step(self, example):
         import torch.distributed as dist
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         losses = self.forward_backward(example, grad_scale=1.0 / world)

@@ -168,14 +168,8 @@ def c4_leg(dev, batch: int = 2, points: int = 180000, reps: int = 10, warm: int 
                points_per_sweep=points, sweeps_per_step=batch, voxels_per_step=int(sum(ex["num_voxels"])), data="synthetic 64-beam sweeps",
                launch="ms_per_step: eager launches of the whole step (the example-dict route reads the voxel counts on the host), HIP events around "
                       "%d steps after %d warm-ups; stages: one hipGraph replay each where the stage is capturable (`timed_as`)" % (reps, warm))
-    # the eager step on a stream of its own: once a hipGraph has been launched on the legacy default stream (the legs before this one did),
-    # work queued there no longer overlaps with other streams -- here the sparse encoder's structure stream
-    own = torch.cuda.Stream(device=dev)
-    own.wait_stream(torch.cuda.current_stream())
     f32 = dict()
-    with torch.cuda.stream(own):
-        t = time_ms(frame, reps, warm)
-    torch.cuda.current_stream().wait_stream(own)
+    t = time_ms(frame, reps, warm)
     f32["ms_per_step"], f32["frames_per_s"] = round(t, 4), round(1e3 * batch / t, 2)
     stages = dict()
     stages["voxelize_vfe"] = _stage(time_ms(st_vox, reps, warm))         # ends in a host read of the voxel count (the example dict carries python ints)
@@ -214,10 +208,7 @@ def c4_leg(dev, batch: int = 2, points: int = 180000, reps: int = 10, warm: int 
     m.neck.set_compute_dtype("bf16")
     m.bbox_head.set_compute_dtype("bf16")
     b16 = dict()
-    own.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(own):
-        t = time_ms(frame, reps, warm)
-    torch.cuda.current_stream().wait_stream(own)
+    t = time_ms(frame, reps, warm)
     b16["ms_per_step"], b16["frames_per_s"] = round(t, 4), round(1e3 * batch / t, 2)
     x_rpn16 = m.neck.forward_nhwc(x_at)
     st_head16 = lambda: m.bbox_head.forward_nhwc(x_rpn16)                                 # noqa: E731
