@@ -580,6 +580,11 @@ def main():
             st = torch.cuda.Stream() if args.streams > 1 else None
             engines.append(FrameEngine(model, B, N, spec, frames_in_flight=max(1, args.streams)).capture(stream=st))
 
+    stream_tuning = None
+    if len(engines) > 1:
+        from partner_amd.engine import tune_replay_streams
+        stream_tuning = tune_replay_streams(engines, frames[0])      # which streams the engines replay on is measured, see there
+
     def step(i):
         # consecutive frames go to alternating streams: independent frames overlap on the GPU
         return engines[i % len(engines)].run(frames[i % pool], sync=False) if engines else step_eager(i)
@@ -629,6 +634,8 @@ def main():
         for k in range(GS):
             st = torch.cuda.Stream() if GS > 1 else None
             eng2.append(FrameEngine(model, GB, N, spec, frames_in_flight=GS).capture(stream=st))
+        if len(eng2) > 1:
+            tune_replay_streams(eng2, groups[0], trials=6, frames=12)
         k2 = max(4, args.steps // 2)
         for i in range(max(2, args.warmup // GB)):
             eng2[i % len(eng2)].run(groups[i % len(groups)], sync=False)
@@ -739,6 +746,7 @@ def main():
                        "points_per_sweep": N, "sweeps_per_step_per_gpu": B, "parallelism": f"frame-replicas x{world}", "device": hip.device_info(dev.index or 0),
                        "launch": "eager" if args.eager else f"hipGraph replay per frame, {max(1, args.streams)} frame(s) in flight on separate HIP streams"},
             "single_stream_ms_per_step": None if single_ms is None else round(single_ms, 4),
+            "replay_stream_tuning": stream_tuning,
             "batched": batched, "roofline": roofline, "roofline_scatter": scatter, "roofline_scatter_coarse": coarse, "train_step": train,
             "c4": c4, "c5": c5, "ranks_seen": ranks_seen, "ranks": ranks,
         }

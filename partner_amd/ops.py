@@ -1003,6 +1003,51 @@ def concurrent_stream(device=None) -> "torch.cuda.Stream":
     return best
 
 
+def concurrent_streams(k: int, device=None, candidates: int = 16):
+    """k streams that overlap with EACH OTHER (several hipGraph engines replaying at once: engines whose streams share a hardware queue run
+    their frames one after the other).  Greedy: a candidate joins the set when a spin kernel on it and one on every member finish in about
+    the time of one; if the runtime has fewer independent queues than k, the best candidates found fill the set."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    main = torch.cuda.current_stream(dev)
+    cycles = 600000
+
+    def pair_ms(a, b):
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        for st in (a, b):
+            if st is not None:
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(cycles)
+        for st in (a, b):
+            if st is not None:
+                main.wait_stream(st)
+        e1.record(main)
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1)
+
+    first = torch.cuda.Stream(device=dev)
+    pair_ms(first, None)
+    one = min(pair_ms(first, None) for _ in range(2))
+    chosen, spare = [first], []
+    for _ in range(candidates):
+        if len(chosen) >= k:
+            break
+        cand = torch.cuda.Stream(device=dev)
+        worst = max(min(pair_ms(cand, m) for _ in range(2)) for m in chosen)
+        if worst < 1.4 * one:
+            chosen.append(cand)
+        else:
+            spare.append((worst, cand))
+    spare.sort(key=lambda wc: wc[0])
+    while len(chosen) < k and spare:
+        chosen.append(spare.pop(0)[1])
+    while len(chosen) < k:
+        chosen.append(torch.cuda.Stream(device=dev))
+    return chosen[:k]
+
+
 class SideStream:
     """Weight gradients off the critical path of backward: dW of a layer is needed by nobody before the gradient exchange / the optimizer,
     while the chain  d(out) -> BatchNorm backward -> data gradient -> previous layer  is serial.  ``run`` queues a layer's weight-gradient
