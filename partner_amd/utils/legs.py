@@ -205,6 +205,27 @@ def c4_leg(dev, batch: int = 2, points: int = 180000, reps: int = 10, warm: int 
         except Exception as e:   # noqa: BLE001 -- a secondary figure must not take the line down
             out[key] = dict(error=repr(e)[:200])
 
+    # throughput with TWO such frames in flight (two engines of bs = `batch` on their own streams, streams picked by measurement)
+    try:
+        from ..engine import tune_replay_streams
+        cart = torch.cat([torch.from_numpy(synth.synth_sweep_beams_cart(points, seed=rank * batch + b)).to(dev) for b in range(batch)])
+        engs = [FrameEngine(m, batch, points, frames_in_flight=2).capture(stream=torch.cuda.Stream()) for _ in range(2)]
+        tune_replay_streams(engs, cart, trials=4, frames=6)
+        for i in range(4):
+            engs[i % 2].run(cart, sync=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nrun = 24
+        for i in range(nrun):
+            engs[i % 2].run(cart, sync=False)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out["two_graphs_in_flight_bs%d" % batch] = dict(frames_per_s=round(nrun * batch / el, 2), ms_per_step=round(1e3 * el / nrun, 4), steps=nrun,
+                                                         measured="two hipGraph engines replaying alternately on two streams, host clock over %d replays" % nrun)
+        del engs
+    except Exception as e:   # noqa: BLE001
+        out["two_graphs_in_flight_bs%d" % batch] = dict(error=repr(e)[:200])
+
     m.neck.set_compute_dtype("bf16")
     m.bbox_head.set_compute_dtype("bf16")
     b16 = dict()

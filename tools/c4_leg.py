@@ -12,7 +12,7 @@ from partner_amd.utils import legs
 
 hip.load()
 out = legs.c4_leg(torch.device("cuda:0"), batch=int(sys.argv[1]) if len(sys.argv) > 1 else 2)
-for k in sorted(k for k in out if k.startswith("one_graph")):
+for k in sorted(k for k in out if k.startswith("one_graph") or k.startswith("two_graphs")):
     print(k, out[k])
 for prec in ("f32", "bf16_bev_convs"):
     o = out[prec]
