@@ -942,6 +942,22 @@ int pn_pack_conv_dgrad_weight_wino4_f32(const float *w_fwd_oihw, int cout_fwd, i
 int pn_conv_wino4_tiles(const pn_conv_desc *desc);
 int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc *desc, const float *in, const float *packed_w, const float *scale,
                              const float *shift, float *out, pn_stream_t stream);
+/* CHAINS of such layers kept in the F(4, 3) domain between layers (r4; the `layer_nums` same-shape Conv2d + BatchNorm + ReLU layers of an
+ * RPN block, rpn.py:124-142, replacing pn_conv2d_wino4_nhwc_f32 launch by launch): a layer reads its input as six PLANES
+ *   V[p 6][cg C/8][h 2][b][y H+2][xq W/4][j 4]     (channel 8 cg + 4 h + j; rows y = 0 and y = H + 1 of every image are zero padding)
+ * = the transformed quads in the MFMA fragment layout, and its epilogue writes the next layer's planes (output transform, scale / shift /
+ * activation, input transform) and / or the NHWC map.  pn_wino4_planes_floats = size of such a buffer (0: shape not representable);
+ * pn_wino4_planes_from_nhwc_f32 forms the planes of an NHWC channel slice (head of a chain); the writers also write the padding rows, so
+ * the buffers need no initialisation.  Weights: pn_pack_conv_weight_wino4_f32 unchanged.  pn_conv_wino4_chain_supported: 3x3 / stride 1 /
+ * pad 1, cin and cout multiples of 32, activation none or ReLU, whole map rows per 32- or 64-quad tile (W / 4 divides 64).  planes_out or
+ * out_nhwc may be NULL (not both); desc->out_* address out_nhwc, desc->in_pixel_stride / in_channel_offset are not used.  Results agree
+ * with pn_conv2d_wino4_nhwc_f32 up to the summation order over K. */
+size_t pn_wino4_planes_floats(int batch, int h, int w, int c);
+int pn_wino4_planes_from_nhwc_f32(const float *in, int batch, int h, int w, int c, int in_pixel_stride, int in_channel_offset,
+                                  float *planes, pn_stream_t stream);
+int pn_conv_wino4_chain_supported(const pn_conv_desc *desc);
+int pn_conv2d_wino4_chain_f32(const pn_conv_desc *desc, const float *planes_in, const float *packed_w, const float *scale,
+                              const float *shift, float *planes_out, float *out_nhwc, pn_stream_t stream);
 /* Weight gradient of a plain 3x3 / stride 1 / pad 1 convolution in the F(4, 3) domain (map width a multiple of 4): six GEMMs per kernel
  * row over the quads, dW = G^T [ (B^T d) (A dy)^T ], half the MFMA work of pn_conv2d_wgrad_f32; desc as for pn_conv2d_wgrad_f32 (in_* = the
  * layer's input x, out_* = dout); slices summed in fixed order (deterministic).  Autograd of the RPN's Conv2d layers, rpn.py:124-142 under

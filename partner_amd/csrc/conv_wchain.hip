@@ -1,0 +1,415 @@
+// Chains of 3x3 / stride-1 / pad-1 convolutions (Conv2d + folded BatchNorm + ReLU, det3d/models/necks/rpn.py:124-142: the
+// `layer_nums` same-shape layers of an RPN block) kept in the WINOGRAD DOMAIN between layers -- r4, the successor of
+// conv_wino4_ks_kernel on the 128 x 128 and 64 x 64 maps of the nuScenes RPN.
+//
+// conv_wino4.hip's F(4, 3) takes an NHWC map, forms the six transformed inputs v0..v5 of every quad (four adjacent pixels of a row)
+// in registers, moves them through LDS into the MFMA operand layout (one barrier per 24 MFMAs) and keeps all six positions in one
+// wave.  On the small maps that form sits at 0.44 MFMA busy: ~110 transform VALU per 24 MFMAs (fp32 MFMA and VALU share the SIMD's
+// fp32 lanes, tools/micro/mfma_valu_coexec.hip), twelve 16-byte loads per 24 MFMAs with no register reuse, one or two waves per SIMD.
+//
+// Here a layer's EPILOGUE writes what the NEXT layer multiplies: the output quad (after scale / shift / ReLU) is transformed at once
+// (d0 and d5, the neighbours' edge pixels, come from the adjacent lanes) and stored as six planes V_p in the MFMA fragment layout.  The
+// consumer then needs no transform, no LDS and no barrier in its K loop: every wave streams 16-byte fragments of ONE position p
+// (weights U_p as the A operand, inputs V_p as the B operand) straight from L2 into v_mfma_f32_32x32x2_f32.  The six positions of a
+// tile are six waves; K may additionally be split in two (KS) and the block may hold several column tiles (CT): 6 KS CT = 12 waves per
+// block, THREE per SIMD, independent of each other until the join -- while one wave waits for its fragments the other two multiply.
+//
+//   V[p 6][cg C/8][h 2][b][y H+2][xq W/4][j 4]   channel c = 8 cg + 4 h + j; rows y = 0 and y = H + 1 of every image are zero (the
+//   vertical padding: the three kernel rows are three row shifts of the same plane, no masks in the loop), written by whoever writes
+//   the first / last image row.
+//   Lane l = (h = l >> 5, i = l & 31) of a wave reads 16 bytes = four k-pairs of quad i: every half-wave 512 contiguous bytes.
+//   U: conv_wino4.hip's packing unchanged ([chunk][kh][q 6][k4 8][cout_pad][4], k4 = 2 (cg & 3) + h).
+//   D[cout][quad]: column (lane & 31) = quad, row = cout = (r & 3) + 8 (r >> 2) + 4 h -- registers 4 g .. 4 g + 3 of a lane are the four
+//   channels j of (cg = g, h) of its quad: the layout of V, so the epilogue stores whole 16-byte fragments.
+//
+// Join: all waves leave their accumulators in LDS, the tile is then finished by (column tile, g) "virtual waves": sum the K slices,
+// output transform, affine + activation, neighbour exchange by lane shuffles, input transform of the next layer, stores (V planes
+// and / or NHWC).  Block tiles are whole rows (32 NB quads a multiple of W / 4), so no neighbour is in another block.
+// Numerics: the same products and the same two transforms as conv_wino4.hip; only the summation order over K differs (per position,
+// two halves).
+#include "pn_common.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct WChainArgs {
+  const float* vin;
+  const float* w;
+  const float* scale;
+  const float* shift;
+  float* vout;     // next layer's planes (may be null)
+  float* out;      // NHWC output (may be null)
+  int B, H, W, Wq, Cin, Cout;
+  int out_ps, out_co;
+  int act;
+  int total_quads;
+  int qtiles, ctiles;     // block tiles: quads / columns
+  int cg_in, cg_out;      // Cin / 8, Cout / 8
+  int cout_pad;
+  unsigned plane_bytes;   // B (H + 2) Wq 16: one (p, cg, h) plane, the same for input and output (same map)
+  unsigned vin_bytes, w_bytes;
+#ifdef PN_WCHAIN_STAMP
+  unsigned long long* stamps;   // diagnostic build only (tools/micro/wchain_check.hip): [block][wave][4] shader-clock stamps
+#endif
+};
+
+#ifdef PN_WCHAIN_STAMP
+unsigned long long* pn_wchain_stamp_buffer = nullptr;
+#define WC_STAMP(k)                                                                                                      \
+  do {                                                                                                                   \
+    if (lane == 0) a.stamps[((size_t)blockIdx.x * 16 + w) * 4 + (k)] = __builtin_amdgcn_s_memtime();                       \
+  } while (0)
+#else
+#define WC_STAMP(k) do { } while (0)
+#endif
+
+// B^T d for four channels at once (the same expression tree as conv_wino4.hip's wino4_input_transform: bit-identical values)
+__device__ __forceinline__ void wchain_input_transform(const f32x4 (&d)[6], f32x4 (&v)[6]) {
+  const f32x4 c4 = {4.f, 4.f, 4.f, 4.f}, m4 = {-4.f, -4.f, -4.f, -4.f}, m5 = {-5.f, -5.f, -5.f, -5.f}, c2 = {2.f, 2.f, 2.f, 2.f}, m2 = {-2.f, -2.f, -2.f, -2.f};
+  const f32x4 e = __builtin_elementwise_fma(m4, d[2], d[4]), o = __builtin_elementwise_fma(m4, d[1], d[3]);
+  const f32x4 f = d[4] - d[2], t = d[3] - d[1];
+  v[0] = __builtin_elementwise_fma(c4, d[0], __builtin_elementwise_fma(m5, d[2], d[4]));
+  v[1] = e + o;
+  v[2] = e - o;
+  v[3] = __builtin_elementwise_fma(c2, t, f);
+  v[4] = __builtin_elementwise_fma(m2, t, f);
+  v[5] = __builtin_elementwise_fma(c4, d[1], __builtin_elementwise_fma(m5, d[3], d[5]));
+}
+
+template <int NA, int NB, int KS, int CT>
+__global__ __launch_bounds__(64 * 6 * KS * CT) void conv_wchain_kernel(WChainArgs a) {
+  constexpr int NW = 6 * KS * CT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = w % 6, ks = (w / 6) % KS, ct = w / (6 * KS);
+  const int li = lane & 31, lh = lane >> 5;
+
+  // block -> (quad tile, column tile): the column tiles of a quad tile and runs of adjacent quad tiles share an XCD (its L2 then holds
+  // the tile's planes once and the layer's weights once)
+  int qt, ctile;
+  {
+    const int bid = blockIdx.x;
+    if ((a.qtiles & 7) == 0) {
+      const int xcd = bid & 7, slot = bid >> 3;
+      qt = xcd * (a.qtiles >> 3) + slot / a.ctiles;
+      ctile = slot - (slot / a.ctiles) * a.ctiles;
+    } else {
+      qt = bid / a.ctiles;
+      ctile = bid - qt * a.ctiles;
+    }
+  }
+  WC_STAMP(0);
+  const int n0 = (ctile * CT + ct) * 32 * NA;      // this wave's first output column
+  const int q0 = qt * 32 * NB;
+
+  // this lane's quads: byte offset of (image, row r - 1 + 1 = padded row r, xq) inside a plane, plus the lane half's plane
+  unsigned voff[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int Q = q0 + 32 * b + li;
+    const bool ok = Q < a.total_quads;
+    const int QQ = ok ? Q : 0;
+    const int rowi = QQ / a.Wq, xq = QQ - rowi * a.Wq;
+    const int img = rowi / a.H, r = rowi - img * a.H;
+    voff[b] = ok ? (unsigned)(((img * (a.H + 2) + r) * a.Wq + xq) * 16) + (unsigned)lh * a.plane_bytes : 0xffffffffu;
+  }
+  unsigned uoff[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) uoff[i] = (unsigned)(((size_t)lh * a.cout_pad + n0 + 32 * i + li) * 16);
+
+  const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.vin), 0, a.vin_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const unsigned cp16 = (unsigned)a.cout_pad * 16u;
+  const unsigned row16 = (unsigned)a.Wq * 16u;
+  const int cg_per = a.cg_in / KS, cg0 = ks * cg_per, cg_last = cg0 + cg_per - 1;
+
+  f32x16 acc[NA][NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.f;
+
+  // operand ring: slot = kernel row kh; while (cg, kh) multiplies, (cg, kh + 1), (cg, kh + 2) and (cg + 1, kh) .. are in flight
+  f32x4 u[3][NA], v[3][NB];
+  auto load_step = [&](int cg, int kh) __attribute__((always_inline)) {
+    const unsigned so_u = (unsigned)((((cg >> 2) * 3 + kh) * 6 + p) * 8 + (cg & 3) * 2) * cp16;
+    const unsigned so_v = (unsigned)((p * a.cg_in + cg) * 2) * a.plane_bytes + (unsigned)kh * row16;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) u[kh][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, uoff[i], so_u, 0));
+#pragma unroll
+    for (int b = 0; b < NB; ++b) v[kh][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, voff[b], so_v, 0));
+  };
+  // the issue order is pinned (sched_barrier): prologue and loop body then request the slots in the same order, and the compiler's
+  // counted waits stay exact across the back edge -- vmcnt(2 (NA + NB)) before each step instead of vmcnt(0) at the loop head
+  load_step(cg0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  load_step(cg0, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  load_step(cg0, 2);
+  __builtin_amdgcn_sched_barrier(0);
+  WC_STAMP(1);
+  for (int cg = cg0; cg <= cg_last; ++cg) {
+    const int nx = cg < cg_last ? cg + 1 : cg_last;     // the last group's refill re-reads itself (stays inside the buffers)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[kh][i][j], v[kh][b][j], acc[i][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_step(nx, kh);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  WC_STAMP(2);
+  // ---- join + epilogue, one pass per column sub-tile i of the waves
+  f32x4* J = reinterpret_cast<f32x4*>(smem);      // [wave][b][g][lane] x 4 registers
+  const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    if (i > 0) __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 t = {acc[i][b][4 * g], acc[i][b][4 * g + 1], acc[i][b][4 * g + 2], acc[i][b][4 * g + 3]};
+        J[((w * NB + b) * 4 + g) * 64 + lane] = t;
+      }
+    __syncthreads();
+    for (int vw = w; vw < CT * 4; vw += NW) {
+      const int ect = vw >> 2, g = vw & 3;
+      const int c0 = ((ctile * CT + ect) * NA + i) * 32 + 8 * g + 4 * lh;     // four consecutive output channels
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + c0);
+      if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + c0);
+      f32x4 y[NB][4];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        f32x4 m[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          m[q] = J[((((ect * KS) * 6 + q) * NB + b) * 4 + g) * 64 + lane];
+#pragma unroll
+          for (int k = 1; k < KS; ++k) m[q] += J[((((ect * KS + k) * 6 + q) * NB + b) * 4 + g) * 64 + lane];
+        }
+        const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+        const f32x4 y0 = (m[0] + s12) + s34;
+        const f32x4 y1 = d12 + 2.f * d34;
+        const f32x4 y2 = s12 + 4.f * s34;
+        const f32x4 y3 = (d12 + 8.f * d34) + m[5];
+        const f32x4 lo4 = {lo, lo, lo, lo};
+        y[b][0] = __builtin_elementwise_max(__builtin_elementwise_fma(y0, sc, sh), lo4);
+        y[b][1] = __builtin_elementwise_max(__builtin_elementwise_fma(y1, sc, sh), lo4);
+        y[b][2] = __builtin_elementwise_max(__builtin_elementwise_fma(y2, sc, sh), lo4);
+        y[b][3] = __builtin_elementwise_max(__builtin_elementwise_fma(y3, sc, sh), lo4);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int Q = q0 + 32 * b + li;
+        const bool ok = Q < a.total_quads;
+        const int QQ = ok ? Q : 0;
+        const int rowi = QQ / a.Wq, xq = QQ - rowi * a.Wq;
+        const int img = rowi / a.H, r = rowi - img * a.H;
+        if (a.vout) {
+          f32x4 d[6];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float l = __shfl_up(y[b][3][j], 1, 32), rr = __shfl_down(y[b][0][j], 1, 32);
+            if (b > 0) {
+              const float t = __shfl(y[b > 0 ? b - 1 : 0][3][j], 31, 32);
+              l = li == 0 ? t : l;
+            }
+            if (b + 1 < NB) {
+              const float t = __shfl(y[b + 1 < NB ? b + 1 : b][0][j], 0, 32);
+              rr = li == 31 ? t : rr;
+            }
+            d[0][j] = xq > 0 ? l : 0.f;
+            d[5][j] = xq + 1 < a.Wq ? rr : 0.f;
+          }
+          d[1] = y[b][0]; d[2] = y[b][1]; d[3] = y[b][2]; d[4] = y[b][3];
+          f32x4 vv[6];
+          wchain_input_transform(d, vv);
+          if (ok) {
+            float* o = a.vout + ((size_t)(c0 >> 3) * 2 + lh) * (a.plane_bytes >> 2) + ((size_t)(img * (a.H + 2) + r + 1) * a.Wq + xq) * 4;
+            const size_t pstride = (size_t)a.cg_out * 2 * (a.plane_bytes >> 2);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride) = vv[q];
+            // the padding rows above the first and below the last image row belong to the tiles that hold those rows: the planes need
+            // no separate clear (they may be uninitialised memory)
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            if (r == 0) {
+#pragma unroll
+              for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride - (size_t)a.Wq * 4) = z4;
+            }
+            if (r == a.H - 1) {
+#pragma unroll
+              for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride + (size_t)a.Wq * 4) = z4;
+            }
+          }
+        }
+        if (a.out && ok) {
+          float* o = a.out + ((size_t)(img * a.H + r) * a.W + 4 * xq) * a.out_ps + a.out_co + c0;
+#pragma unroll
+          for (int px = 0; px < 4; ++px) *reinterpret_cast<f32x4*>(o + (size_t)px * a.out_ps) = y[b][px];
+        }
+      }
+    }
+  }
+  WC_STAMP(3);
+}
+
+// NHWC map -> the six planes (head of a chain).  One thread = one (quad, four channels): lanes along quads, so the plane stores are
+// whole 16-byte fragments in quad order.
+__global__ __launch_bounds__(256) void wchain_v_from_nhwc_kernel(const float* __restrict__ in, float* __restrict__ vout, int B, int H, int W, int Wq, int C,
+                                                                 int in_ps, int in_co, int total_quads, unsigned plane_floats) {
+  const int c4n = C >> 2;
+  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < (long long)total_quads * c4n; it += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(it / total_quads);
+    const int Q = (int)(it - (long long)c4 * total_quads);
+    const int rowi = Q / Wq, xq = Q - rowi * Wq;
+    const int img = rowi / H, r = rowi - img * H;
+    const float* px = in + ((size_t)(img * H + r) * W + 4 * xq) * in_ps + in_co + c4 * 4;
+    f32x4 d[6], v[6];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    d[0] = xq > 0 ? *reinterpret_cast<const f32x4*>(px - in_ps) : z;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[1 + k] = *reinterpret_cast<const f32x4*>(px + (size_t)k * in_ps);
+    d[5] = xq + 1 < Wq ? *reinterpret_cast<const f32x4*>(px + (size_t)4 * in_ps) : z;
+    wchain_input_transform(d, v);
+    float* o = vout + (size_t)c4 * plane_floats + ((size_t)(img * (H + 2) + r + 1) * Wq + xq) * 4;      // plane (cg = c4 >> 1, h = c4 & 1)
+    const size_t pstride = (size_t)c4n * plane_floats;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride) = v[q];
+    if (r == 0) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride - (size_t)Wq * 4) = z;
+    }
+    if (r == H - 1) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride + (size_t)Wq * 4) = z;
+    }
+  }
+}
+
+struct ChainForm { int na, nb, ks, ct; };
+
+// the form a layer takes: wave tile 32 NA columns x 32 NB quads, K split KS ways, CT column tiles per block (always 12 waves)
+static bool chain_form(const pn_conv_desc* d, ChainForm& f) {
+  if (d->in_w % 4) return false;
+  const int wq = d->in_w / 4;
+  const long long quads = (long long)d->batch * d->in_h * wq;
+  static const int force = [] { const char* e = getenv("PN_WCHAIN_FORM"); return e ? atoi(e) : 0; }();
+  // candidates, widest register tile first; a form fits when its block tile is whole rows and the grid covers the chip about once
+  const ChainForm cands[] = {{2, 2, 1, 2}, {1, 2, 2, 1}, {1, 1, 2, 1}};
+  int idx = 0;
+  for (const ChainForm& c : cands) {
+    ++idx;
+    if (force && force != idx) continue;
+    const int tq = 32 * c.nb, tc = 32 * c.na * c.ct;
+    if (tq % wq != 0 || quads % tq != 0 || d->cout % tc != 0 || (d->cin / 8) % c.ks != 0) continue;
+    const long long blocks = quads / tq * (d->cout / tc);
+    if (!force && blocks < 192 && idx < 3) continue;      // a narrower form fills the chip better
+    f = c;
+    return true;
+  }
+  return false;
+}
+
+template <int NA, int NB, int KS, int CT>
+static void launch_chain(const WChainArgs& a, hipStream_t st, bool prof, const pn::ProfileSlot& ps) {
+  constexpr int NW = 6 * KS * CT;
+  constexpr size_t smem = (size_t)NW * NB * 4 * 64 * 16;
+  static bool done[64] = {false};
+  if (pn::first_use_on_device(done))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wchain_kernel<NA, NB, KS, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const dim3 grid((unsigned)(a.qtiles * a.ctiles));
+  if (prof) hipExtLaunchKernelGGL((conv_wchain_kernel<NA, NB, KS, CT>), grid, dim3(64 * NW), smem, st, ps.start, ps.stop, 0, a);
+  else hipLaunchKernelGGL((conv_wchain_kernel<NA, NB, KS, CT>), grid, dim3(64 * NW), smem, st, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pn_wino4_planes_floats(int batch, int h, int w, int c) {
+  if (batch < 1 || h < 1 || w < 4 || w % 4 || c < 8 || c % 8) return 0;
+  return (size_t)6 * c * batch * (h + 2) * (w / 4);
+}
+
+int pn_conv_wino4_chain_supported(const pn_conv_desc* d) {
+  if (!d) return 0;
+  if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->groups == 1 && !d->deconv2x2 && d->range_strata <= 1 &&
+        !d->accumulate && d->pad_h_end == 0 && d->pad_w_end == 0))
+    return 0;
+  if (d->batch < 1 || d->in_h < 1 || d->in_w < 4 || d->cin % 32 || d->cout % 32 || d->cin < 32) return 0;
+  if (!(d->act == PN_ACT_NONE || d->act == PN_ACT_RELU)) return 0;
+  if ((unsigned long long)pn_wino4_planes_floats(d->batch, d->in_h, d->in_w, std::max(d->cin, d->cout)) * 4ull >= (1ull << 32)) return 0;
+  ChainForm f;
+  return chain_form(d, f) ? 1 : 0;
+}
+
+int pn_wino4_planes_from_nhwc_f32(const float* in, int batch, int h, int w, int c, int in_pixel_stride, int in_channel_offset, float* planes,
+                                  pn_stream_t stream) {
+  PN_REQUIRE(in && planes && pn_wino4_planes_floats(batch, h, w, c) > 0, "wino4_planes_from_nhwc: bad arguments");
+  PN_REQUIRE(in_pixel_stride % 4 == 0 && in_channel_offset % 4 == 0 && in_pixel_stride >= in_channel_offset + c && ((uintptr_t)in & 15) == 0 &&
+                 ((uintptr_t)planes & 15) == 0,
+             "wino4_planes_from_nhwc: strides / offsets must be multiples of 4 floats, pointers 16-byte aligned");
+  const int wq = w / 4;
+  const long long quads = (long long)batch * h * wq;
+  PN_REQUIRE(quads < (1ll << 30), "wino4_planes_from_nhwc: map too large");
+  const unsigned plane_floats = (unsigned)((size_t)batch * (h + 2) * wq * 4);
+  const long long items = quads * (c / 4);
+  hipLaunchKernelGGL(wchain_v_from_nhwc_kernel, dim3((unsigned)std::min<long long>(8192, (items + 255) / 256)), dim3(256), 0, pn::S(stream), in, planes, batch, h,
+                     w, wq, c, in_pixel_stride, in_channel_offset, (int)quads, plane_floats);
+  return pn::check_launch("wchain_v_from_nhwc_kernel");
+}
+
+int pn_conv2d_wino4_chain_f32(const pn_conv_desc* d, const float* planes_in, const float* packed_w, const float* scale, const float* shift,
+                              float* planes_out, float* out_nhwc, pn_stream_t stream) {
+  PN_REQUIRE(d && planes_in && packed_w && (planes_out || out_nhwc), "conv_wino4_chain: null pointer");
+  PN_REQUIRE(pn_conv_wino4_chain_supported(d), "conv_wino4_chain: layer shape not supported (3x3 / stride 1 / pad 1, cin and cout multiples of 32, "
+                                               "row-aligned tiles)");
+  PN_REQUIRE(((uintptr_t)planes_in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0 && ((uintptr_t)planes_out & 15) == 0 && ((uintptr_t)out_nhwc & 15) == 0 &&
+                 ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
+             "conv_wino4_chain: pointers must be 16-byte aligned");
+  if (out_nhwc)
+    PN_REQUIRE(d->out_pixel_stride >= d->out_channel_offset + d->cout && d->out_pixel_stride % 4 == 0 && d->out_channel_offset % 4 == 0,
+               "conv_wino4_chain: output channel slice must fit the pixel stride, in multiples of 4 floats");
+  ChainForm f;
+  chain_form(d, f);
+  WChainArgs a{};
+  a.vin = planes_in; a.w = packed_w; a.scale = scale; a.shift = shift; a.vout = planes_out; a.out = out_nhwc;
+  a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Wq = d->in_w / 4; a.Cin = d->cin; a.Cout = d->cout;
+  a.out_ps = d->out_pixel_stride; a.out_co = d->out_channel_offset;
+  a.act = d->act;
+  a.total_quads = d->batch * d->in_h * a.Wq;
+  a.qtiles = a.total_quads / (32 * f.nb);
+  a.ctiles = d->cout / (32 * f.na * f.ct);
+  a.cg_in = d->cin / 8; a.cg_out = d->cout / 8;
+  a.cout_pad = pn::cdiv(d->cout, 128) * 128;
+  a.plane_bytes = (unsigned)((size_t)d->batch * (d->in_h + 2) * a.Wq * 16);
+  a.vin_bytes = (unsigned)(pn_wino4_planes_floats(d->batch, d->in_h, d->in_w, d->cin) * 4);
+  a.w_bytes = (unsigned)(pn_conv_wino4_packed_weight_floats(d->cout, d->cin) * 4);
+#ifdef PN_WCHAIN_STAMP
+  a.stamps = pn_wchain_stamp_buffer;
+#endif
+  pn::ProfileSlot ps{};
+  const bool prof = pn::take_profile_slot(ps);
+  hipStream_t st = pn::S(stream);
+  if (f.na == 2 && f.nb == 2 && f.ks == 1 && f.ct == 2) launch_chain<2, 2, 1, 2>(a, st, prof, ps);
+  else if (f.na == 1 && f.nb == 2 && f.ks == 2 && f.ct == 1) launch_chain<1, 2, 2, 1>(a, st, prof, ps);
+  else launch_chain<1, 1, 2, 1>(a, st, prof, ps);
+  return pn::check_launch("conv_wchain_kernel");
+}
+
+}  // extern "C"

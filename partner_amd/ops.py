@@ -605,6 +605,60 @@ class ConvLayer:
         return out
 
 
+# Runs of same-map 3x3 / stride-1 layers kept in the F(4, 3) domain between layers (csrc/conv_wchain.hip): PN_CONV_CHAIN=0 runs them one
+# pn_conv2d_wino4_nhwc_f32 launch each, as r3 did
+_CHAIN_ON = os.environ.get("PN_CONV_CHAIN", "1") != "0"
+
+
+def _chain_desc(layer: "ConvLayer", b: int, h: int, w: int, out_ps: int = 0, out_co: int = 0):
+    d = ConvDesc(b, h, w, layer.cin, layer.cout, 1, 3, 3, 1, 1, 1, layer.cin, 0, out_ps or layer.cout, out_co, layer.act, 0, 0, 0, 0, 0)
+    d.frames_in_flight = _FRAMES_IN_FLIGHT
+    return d
+
+
+def conv_chain_supported(layers, b: int, h: int, w: int) -> bool:
+    """can ``layers`` (consecutive ConvLayers, each feeding the next) run as one Winograd-domain chain on a (b, h, w) map?"""
+    if not _CHAIN_ON or not layers:
+        return False
+    lib = hip.load()
+    for k, l in enumerate(layers):
+        if l.dtype != "f32" or l.wino4_packed is None or l.cin != l._pack_cin or (k and l.cin != layers[k - 1].cout):
+            return False
+        if not lib.pn_conv_wino4_chain_supported(C.byref(_chain_desc(l, b, h, w))):
+            return False
+    return True
+
+
+def conv_chain(layers, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_channel_offset=0, in_channel_offset=0) -> torch.Tensor:
+    """x NHWC (B, H, W, Ct) -> the NHWC output of the last layer.  One launch forms the six F(4, 3) planes of x, then every layer reads
+    planes and writes planes (two buffers, alternating); the last one writes the map.  Same arithmetic as the layers one by one
+    (ConvLayer.__call__ on pn_conv2d_wino4_nhwc_f32) up to the summation order over the input channels."""
+    hip.require_device(x)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    b, h, w, ct = x.shape
+    lib, st, dev = hip.load(), hip.stream(), x.device
+    cmax = max([layers[0].cin] + [l.cout for l in layers[:-1]])
+    n = lib.pn_wino4_planes_floats(b, h, w, cmax)
+    bufs = [torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev) if len(layers) > 1 else None]
+    hip.call("pn_wino4_planes_from_nhwc_f32", x.data_ptr(), b, h, w, layers[0].cin, ct, in_channel_offset, bufs[0].data_ptr(), st)
+    last = layers[-1]
+    if out is None:
+        out = torch.empty((b, h, w, last.cout), dtype=torch.float32, device=dev)
+    assert out.shape[:3] == (b, h, w) and out.is_contiguous()
+    prof = _PROFILER
+    for k, l in enumerate(layers):
+        l._ensure("wino4")
+        is_last = k == len(layers) - 1
+        d = _chain_desc(l, b, h, w, out.shape[3], out_channel_offset) if is_last else _chain_desc(l, b, h, w)
+        if prof is not None:
+            ev = prof.begin(st)
+        hip.call("pn_conv2d_wino4_chain_f32", C.byref(d), bufs[k & 1].data_ptr(), l.wino4_packed.data_ptr(), hip.ptr(l.scale), hip.ptr(l.shift),
+                 None if is_last else bufs[(k + 1) & 1].data_ptr(), out.data_ptr() if is_last else None, st)
+        if prof is not None:
+            prof.end(ev, 2.0 * b * h * w * l.cout * l.cin * 9, st, tag=f"{h}x{w} {l.cin}->{l.cout} k3 F(4,3) chain")
+    return out
+
+
 _PILLAR_CONV_ON = os.environ.get("PN_PILLAR_CONV", "1") != "0"
 # taken when the pillar capacity bounds the (pillar, tap) pairs to this fraction of the dense (output, tap) pairs
 _PILLAR_CONV_MAX_FILL = float(os.environ.get("PN_PILLAR_CONV_MAX_FILL", "0.35"))

@@ -1,0 +1,108 @@
+// conv_wchain.hip against conv_wino4.hip on the nuScenes RPN's stride-1 layer shapes: the chained form's NHWC output and its next-layer
+// planes (compared with planes formed from the reference kernel's output), and both kernels' times, launches back to back.
+//   cd tools/micro && hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I../../include wchain_check.hip -o /tmp/wchain_check && /tmp/wchain_check
+#define PN_WCHAIN_STAMP 1
+#include "../../partner_amd/csrc/pn_common.hip"
+#include "../../partner_amd/csrc/conv_wino4.hip"
+#include "../../partner_amd/csrc/conv_wchain.hip"
+#include <vector>
+#include <algorithm>
+#include <cmath>
+
+static double max_rel(const std::vector<float>& a, const std::vector<float>& b) {
+  double mx = 0, ref = 0;
+  for (size_t i = 0; i < a.size(); ++i) { mx = std::max(mx, (double)std::fabs(a[i] - b[i])); ref = std::max(ref, (double)std::fabs(b[i])); }
+  return mx / (ref + 1e-30);
+}
+
+int main(int argc, char** argv) {
+  struct Shape { int b, h, w, cin, cout; };
+  std::vector<Shape> shapes = {{1, 128, 128, 128, 128}, {1, 64, 64, 256, 256}, {1, 256, 256, 128, 128}, {2, 128, 128, 128, 128}};
+  const int reps = argc > 1 ? atoi(argv[1]) : 20;
+  unsigned long long* stamps;
+  hipMalloc(&stamps, 2048 * 16 * 4 * 8);
+  pn_wchain_stamp_buffer = stamps;
+  for (auto sh : shapes) {
+    const size_t nin = (size_t)sh.b * sh.h * sh.w * sh.cin, nout = (size_t)sh.b * sh.h * sh.w * sh.cout;
+    const size_t nvi = pn_wino4_planes_floats(sh.b, sh.h, sh.w, sh.cin), nvo = pn_wino4_planes_floats(sh.b, sh.h, sh.w, sh.cout);
+    float *x, *w, *pw, *o_ref, *o_ch, *sc, *shf, *vin, *vout, *vref;
+    hipMalloc(&x, nin * 4); hipMalloc(&o_ref, nout * 4); hipMalloc(&o_ch, nout * 4); hipMalloc(&w, (size_t)sh.cout * sh.cin * 9 * 4);
+    hipMalloc(&sc, sh.cout * 4); hipMalloc(&shf, sh.cout * 4);
+    hipMalloc(&pw, pn_conv_wino4_packed_weight_floats(sh.cout, sh.cin) * 4);
+    hipMalloc(&vin, nvi * 4); hipMalloc(&vout, nvo * 4); hipMalloc(&vref, nvo * 4);
+    hipMemset(vin, 0xff, nvi * 4); hipMemset(vout, 0xff, nvo * 4); hipMemset(vref, 0xff, nvo * 4);   // NaN patterns: the kernels own the padding rows
+    std::vector<float> h(std::max(nin, (size_t)sh.cout * sh.cin * 9));
+    for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+    hipMemcpy(x, h.data(), nin * 4, hipMemcpyHostToDevice);
+    for (auto& v : h) v = ((float)rand() / RAND_MAX - 0.5f) * 0.1f;
+    hipMemcpy(w, h.data(), (size_t)sh.cout * sh.cin * 9 * 4, hipMemcpyHostToDevice);
+    for (int i = 0; i < sh.cout; ++i) h[i] = 0.5f + (float)rand() / RAND_MAX;
+    hipMemcpy(sc, h.data(), sh.cout * 4, hipMemcpyHostToDevice);
+    for (int i = 0; i < sh.cout; ++i) h[i] = (float)rand() / RAND_MAX - 0.5f;
+    hipMemcpy(shf, h.data(), sh.cout * 4, hipMemcpyHostToDevice);
+    pn_pack_conv_weight_wino4_f32(w, sh.cout, sh.cin, pw, nullptr);
+    pn_conv_desc d{};
+    d.batch = sh.b; d.in_h = sh.h; d.in_w = sh.w; d.cin = sh.cin; d.cout = sh.cout; d.kh = d.kw = 3; d.stride = 1; d.pad_h = d.pad_w = 1; d.groups = 1;
+    d.in_pixel_stride = sh.cin; d.out_pixel_stride = sh.cout; d.act = PN_ACT_RELU;
+    char buf[256];
+    if (!pn_conv_wino4_chain_supported(&d)) { printf("%dx%dx%d %d->%d: chain form not supported\n", sh.b, sh.h, sh.w, sh.cin, sh.cout); continue; }
+    int rc = pn_conv2d_wino4_nhwc_f32(&d, x, pw, sc, shf, o_ref, nullptr);
+    rc |= pn_wino4_planes_from_nhwc_f32(x, sh.b, sh.h, sh.w, sh.cin, sh.cin, 0, vin, nullptr);
+    rc |= pn_conv2d_wino4_chain_f32(&d, vin, pw, sc, shf, vout, o_ch, nullptr);
+    rc |= pn_wino4_planes_from_nhwc_f32(o_ref, sh.b, sh.h, sh.w, sh.cout, sh.cout, 0, vref, nullptr);
+    if (rc) { pn_last_error(buf, 256); printf("error: %s\n", buf); return 1; }
+    hipDeviceSynchronize();
+    std::vector<float> a(nout), b(nout), va(nvo), vb(nvo);
+    hipMemcpy(a.data(), o_ch, nout * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), o_ref, nout * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(va.data(), vout, nvo * 4, hipMemcpyDeviceToHost); hipMemcpy(vb.data(), vref, nvo * 4, hipMemcpyDeviceToHost);
+    printf("%dx%dx%d %d->%d: nhwc max|d|/max|ref| %.3g, planes %.3g\n", sh.b, sh.h, sh.w, sh.cin, sh.cout, max_rel(a, b), max_rel(va, vb));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const double issued = 2.0 * sh.b * sh.h * sh.w * sh.cout * sh.cin * 4.5;
+    auto timeit = [&](const char* name, auto fn) {
+      for (int i = 0; i < 3; ++i) fn();
+      float best = 1e9f, tot = 0;
+      for (int r = 0; r < 5; ++r) {
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int i = 0; i < reps; ++i) fn();
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        best = std::min(best, ms / reps); tot += ms / reps;
+      }
+      printf("  %-28s %7.1f us best, %7.1f mean (%.1f TFLOP/s issued, %.3f of 157.3)\n", name, best * 1e3, tot / 5 * 1e3, issued / best * 1e-9, issued / best * 1e-9 / 157.3);
+    };
+    timeit("wino4 (plain / K-split)", [&] { pn_conv2d_wino4_nhwc_f32(&d, x, pw, sc, shf, o_ref, nullptr); });
+    timeit("chain -> planes", [&] { pn_conv2d_wino4_chain_f32(&d, vin, pw, sc, shf, vout, nullptr, nullptr); });
+    timeit("chain -> planes + nhwc", [&] { pn_conv2d_wino4_chain_f32(&d, vin, pw, sc, shf, vout, o_ch, nullptr); });
+    timeit("chain -> nhwc", [&] { pn_conv2d_wino4_chain_f32(&d, vin, pw, sc, shf, nullptr, o_ch, nullptr); });
+    timeit("planes from nhwc", [&] { pn_wino4_planes_from_nhwc_f32(x, sh.b, sh.h, sh.w, sh.cin, sh.cin, 0, vin, nullptr); });
+    // ping-pong chain of 5 layers, as the block runs them
+    timeit("5 chained layers (per layer)", [&] {
+      for (int l = 0; l < 5; ++l) pn_conv2d_wino4_chain_f32(&d, (l & 1) ? vout : vin, pw, sc, shf, (l & 1) ? vin : vout, nullptr, nullptr);
+    });
+    pn_wino4_planes_from_nhwc_f32(x, sh.b, sh.h, sh.w, sh.cin, sh.cin, 0, vin, nullptr);
+    {  // stamps of one launch (every wave): prologue | K loop | join + epilogue, and the spread of block starts / ends
+      hipMemset(stamps, 0, 2048 * 16 * 4 * 8);
+      hipDeviceSynchronize();
+      pn_conv2d_wino4_chain_f32(&d, vin, pw, sc, shf, vout, nullptr, nullptr);
+      hipDeviceSynchronize();
+      std::vector<unsigned long long> st(2048 * 16 * 4);
+      hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost);
+      std::vector<double> pro, loop, epi, tot;
+      unsigned long long t0 = ~0ull, t1 = 0, ls = 0;
+      for (int blk = 0; blk < 2048; ++blk)
+        for (int wv = 0; wv < 16; ++wv) {
+          const unsigned long long* s4 = &st[((size_t)blk * 16 + wv) * 4];
+          if (!s4[0] || !s4[3]) continue;
+          t0 = std::min(t0, s4[0]); t1 = std::max(t1, s4[3]); ls = std::max(ls, s4[0]);
+          pro.push_back((double)(s4[1] - s4[0])); loop.push_back((double)(s4[2] - s4[1])); epi.push_back((double)(s4[3] - s4[2])); tot.push_back((double)(s4[3] - s4[0]));
+        }
+      auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+      auto mx = [](std::vector<double>& v) { return v.empty() ? 0.0 : *std::max_element(v.begin(), v.end()); };
+      printf("  stamps (%zu waves, 100 MHz ticks?): prologue med %.0f | K loop med %.0f max %.0f | join+epilogue med %.0f max %.0f | wave med %.0f ; first start -> last start %.0f, -> last end %.0f\n",
+             pro.size(), med(pro), med(loop), mx(loop), med(epi), mx(epi), med(tot), (double)(ls - t0), (double)(t1 - t0));
+    }
+    hipFree(x); hipFree(w); hipFree(pw); hipFree(o_ref); hipFree(o_ch); hipFree(sc); hipFree(shf); hipFree(vin); hipFree(vout); hipFree(vref);
+  }
+  return 0;
+}
