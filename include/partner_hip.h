@@ -958,6 +958,15 @@ int pn_wino4_planes_from_nhwc_f32(const float *in, int batch, int h, int w, int 
 int pn_conv_wino4_chain_supported(const pn_conv_desc *desc);
 int pn_conv2d_wino4_chain_f32(const pn_conv_desc *desc, const float *planes_in, const float *packed_w, const float *scale,
                               const float *shift, float *planes_out, float *out_nhwc, pn_stream_t stream);
+/* The same chain step with F(2, 3) along the map height on top of F(4, 3) along the width (even map height): 24 products per OCTET
+ * (two rows x four pixels) and channel pair, 3 per output against 4.5.  Planes in / out unchanged -- the consumer forms the height
+ * transform from four rows of a plane while it loads them -- only the weights differ: pn_pack_conv_weight_wino24_f32 from torch layout
+ * ([chunk][s 4][p 6][k4 8][cout_pad][4] = Gh g Gw^T in double, rounded once).  Agrees with the direct kernel to ~5e-6 of the map's range. */
+size_t pn_conv_wino24_packed_weight_floats(int cout, int cin);
+int pn_pack_conv_weight_wino24_f32(const float *w_oihw, int cout, int cin, float *packed, pn_stream_t stream);
+int pn_conv_wino24_chain_supported(const pn_conv_desc *desc);
+int pn_conv2d_wino24_chain_f32(const pn_conv_desc *desc, const float *planes_in, const float *packed_w24, const float *scale,
+                               const float *shift, float *planes_out, float *out_nhwc, pn_stream_t stream);
 /* Weight gradient of a plain 3x3 / stride 1 / pad 1 convolution in the F(4, 3) domain (map width a multiple of 4): six GEMMs per kernel
  * row over the quads, dW = G^T [ (B^T d) (A dy)^T ], half the MFMA work of pn_conv2d_wgrad_f32; desc as for pn_conv2d_wgrad_f32 (in_* = the
  * layer's input x, out_* = dout); slices summed in fixed order (deterministic).  Autograd of the RPN's Conv2d layers, rpn.py:124-142 under

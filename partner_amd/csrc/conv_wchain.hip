@@ -80,6 +80,82 @@ __device__ __forceinline__ void wchain_input_transform(const f32x4 (&d)[6], f32x
   v[5] = __builtin_elementwise_fma(c4, d[1], __builtin_elementwise_fma(m5, d[3], d[5]));
 }
 
+// The tail of a tile for one lane: NT 32-quad tiles that follow each other along the map rows (NT 32 quads = whole rows), four output
+// channels c0 .. c0 + 3.  get_m(q, b) = the lane's four channels of position q of tile b (K slices already summed); quad_of(b, ...) = where
+// the lane's quad of tile b lies.  Output transform, affine + activation, the neighbours' edge pixels by lane shuffles, the next layer's
+// input transform, stores: six plane fragments (+ the zero padding rows next to the first / last image row) and / or four NHWC pixels.
+template <int NT, typename GetM, typename QuadOf>
+__device__ __forceinline__ void wchain_finish(const WChainArgs& a, int c0, int li, int lh, float lo, GetM get_m, QuadOf quad_of) {
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + c0);
+  if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + c0);
+  f32x4 y[NT][4];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    f32x4 m[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) m[q] = get_m(q, b);
+    const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    const f32x4 y0 = (m[0] + s12) + s34;
+    const f32x4 y1 = d12 + 2.f * d34;
+    const f32x4 y2 = s12 + 4.f * s34;
+    const f32x4 y3 = (d12 + 8.f * d34) + m[5];
+    const f32x4 lo4 = {lo, lo, lo, lo};
+    y[b][0] = __builtin_elementwise_max(__builtin_elementwise_fma(y0, sc, sh), lo4);
+    y[b][1] = __builtin_elementwise_max(__builtin_elementwise_fma(y1, sc, sh), lo4);
+    y[b][2] = __builtin_elementwise_max(__builtin_elementwise_fma(y2, sc, sh), lo4);
+    y[b][3] = __builtin_elementwise_max(__builtin_elementwise_fma(y3, sc, sh), lo4);
+  }
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    bool ok;
+    int img, r, xq;
+    quad_of(b, ok, img, r, xq);
+    if (a.vout) {
+      f32x4 d[6];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float l = __shfl_up(y[b][3][j], 1, 32), rr = __shfl_down(y[b][0][j], 1, 32);
+        if (b > 0) {
+          const float t = __shfl(y[b > 0 ? b - 1 : 0][3][j], 31, 32);
+          l = li == 0 ? t : l;
+        }
+        if (b + 1 < NT) {
+          const float t = __shfl(y[b + 1 < NT ? b + 1 : b][0][j], 0, 32);
+          rr = li == 31 ? t : rr;
+        }
+        d[0][j] = xq > 0 ? l : 0.f;
+        d[5][j] = xq + 1 < a.Wq ? rr : 0.f;
+      }
+      d[1] = y[b][0]; d[2] = y[b][1]; d[3] = y[b][2]; d[4] = y[b][3];
+      f32x4 vv[6];
+      wchain_input_transform(d, vv);
+      if (ok) {
+        float* o = a.vout + ((size_t)(c0 >> 3) * 2 + lh) * (a.plane_bytes >> 2) + ((size_t)(img * (a.H + 2) + r + 1) * a.Wq + xq) * 4;
+        const size_t pstride = (size_t)a.cg_out * 2 * (a.plane_bytes >> 2);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride) = vv[q];
+        // the padding rows above the first and below the last image row belong to the tiles that hold those rows: the planes need
+        // no separate clear (they may be uninitialised memory)
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        if (r == 0) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride - (size_t)a.Wq * 4) = z4;
+        }
+        if (r == a.H - 1) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride + (size_t)a.Wq * 4) = z4;
+        }
+      }
+    }
+    if (a.out && ok) {
+      float* o = a.out + ((size_t)(img * a.H + r) * a.W + 4 * xq) * a.out_ps + a.out_co + c0;
+#pragma unroll
+      for (int px = 0; px < 4; ++px) *reinterpret_cast<f32x4*>(o + (size_t)px * a.out_ps) = y[b][px];
+    }
+  }
+}
+
 template <int NA, int NB, int KS, int CT>
 __global__ __launch_bounds__(64 * 6 * KS * CT) void conv_wchain_kernel(WChainArgs a) {
   constexpr int NW = 6 * KS * CT;
@@ -189,83 +265,183 @@ __global__ __launch_bounds__(64 * 6 * KS * CT) void conv_wchain_kernel(WChainArg
     for (int vw = w; vw < CT * 4; vw += NW) {
       const int ect = vw >> 2, g = vw & 3;
       const int c0 = ((ctile * CT + ect) * NA + i) * 32 + 8 * g + 4 * lh;     // four consecutive output channels
-      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + c0);
-      if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + c0);
-      f32x4 y[NB][4];
+      wchain_finish<NB>(
+          a, c0, li, lh, lo,
+          [&](int q, int b) {
+            f32x4 m = J[((((ect * KS) * 6 + q) * NB + b) * 4 + g) * 64 + lane];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        f32x4 m[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          m[q] = J[((((ect * KS) * 6 + q) * NB + b) * 4 + g) * 64 + lane];
-#pragma unroll
-          for (int k = 1; k < KS; ++k) m[q] += J[((((ect * KS + k) * 6 + q) * NB + b) * 4 + g) * 64 + lane];
-        }
-        const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-        const f32x4 y0 = (m[0] + s12) + s34;
-        const f32x4 y1 = d12 + 2.f * d34;
-        const f32x4 y2 = s12 + 4.f * s34;
-        const f32x4 y3 = (d12 + 8.f * d34) + m[5];
-        const f32x4 lo4 = {lo, lo, lo, lo};
-        y[b][0] = __builtin_elementwise_max(__builtin_elementwise_fma(y0, sc, sh), lo4);
-        y[b][1] = __builtin_elementwise_max(__builtin_elementwise_fma(y1, sc, sh), lo4);
-        y[b][2] = __builtin_elementwise_max(__builtin_elementwise_fma(y2, sc, sh), lo4);
-        y[b][3] = __builtin_elementwise_max(__builtin_elementwise_fma(y3, sc, sh), lo4);
-      }
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int Q = q0 + 32 * b + li;
-        const bool ok = Q < a.total_quads;
-        const int QQ = ok ? Q : 0;
-        const int rowi = QQ / a.Wq, xq = QQ - rowi * a.Wq;
-        const int img = rowi / a.H, r = rowi - img * a.H;
-        if (a.vout) {
-          f32x4 d[6];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float l = __shfl_up(y[b][3][j], 1, 32), rr = __shfl_down(y[b][0][j], 1, 32);
-            if (b > 0) {
-              const float t = __shfl(y[b > 0 ? b - 1 : 0][3][j], 31, 32);
-              l = li == 0 ? t : l;
-            }
-            if (b + 1 < NB) {
-              const float t = __shfl(y[b + 1 < NB ? b + 1 : b][0][j], 0, 32);
-              rr = li == 31 ? t : rr;
-            }
-            d[0][j] = xq > 0 ? l : 0.f;
-            d[5][j] = xq + 1 < a.Wq ? rr : 0.f;
-          }
-          d[1] = y[b][0]; d[2] = y[b][1]; d[3] = y[b][2]; d[4] = y[b][3];
-          f32x4 vv[6];
-          wchain_input_transform(d, vv);
-          if (ok) {
-            float* o = a.vout + ((size_t)(c0 >> 3) * 2 + lh) * (a.plane_bytes >> 2) + ((size_t)(img * (a.H + 2) + r + 1) * a.Wq + xq) * 4;
-            const size_t pstride = (size_t)a.cg_out * 2 * (a.plane_bytes >> 2);
-#pragma unroll
-            for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride) = vv[q];
-            // the padding rows above the first and below the last image row belong to the tiles that hold those rows: the planes need
-            // no separate clear (they may be uninitialised memory)
-            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            if (r == 0) {
-#pragma unroll
-              for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride - (size_t)a.Wq * 4) = z4;
-            }
-            if (r == a.H - 1) {
-#pragma unroll
-              for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride + (size_t)a.Wq * 4) = z4;
-            }
-          }
-        }
-        if (a.out && ok) {
-          float* o = a.out + ((size_t)(img * a.H + r) * a.W + 4 * xq) * a.out_ps + a.out_co + c0;
-#pragma unroll
-          for (int px = 0; px < 4; ++px) *reinterpret_cast<f32x4*>(o + (size_t)px * a.out_ps) = y[b][px];
-        }
-      }
+            for (int k = 1; k < KS; ++k) m += J[((((ect * KS + k) * 6 + q) * NB + b) * 4 + g) * 64 + lane];
+            return m;
+          },
+          [&](int b, bool& ok, int& img, int& r, int& xq) {
+            const int Q = q0 + 32 * b + li;
+            ok = Q < a.total_quads;
+            const int QQ = ok ? Q : 0;
+            const int rowi = QQ / a.Wq;
+            xq = QQ - rowi * a.Wq;
+            img = rowi / a.H;
+            r = rowi - img * a.H;
+          });
     }
   }
   WC_STAMP(3);
+}
+
+// ---- the same chain step with F(2, 3) along the map HEIGHT on top of F(4, 3) along the width: an OCTET (two rows x four pixels) from
+// 4 x 6 = 24 products per input / output channel pair -- 3 per output against 4.5 -- with the planes format unchanged.  The height
+// transform is linear in the rows and the planes hold every row already width-transformed, so the CONSUMER forms it while loading:
+// a lane reads its octet's four input rows 2 t - 1 .. 2 t + 2 of position p (four fragments d0..d3, the padding rows give the zeros)
+// and multiplies b0 = d0 - d2, b1 = d1 + d2, b2 = d2 - d1, b3 = d1 - d3 (four vector subtractions per 16 MFMAs) against the four
+// height positions s of the weights U[s][p] = Gh g Gw^T; no sum over kernel rows is left, K = Cin.  A wave = one width position p of
+// 32 columns x 32 octets with four accumulators (s); before the join it folds them to the two output rows (r0 = m0 + m1 + m2,
+// r1 = m1 - m2 - m3), the tail is wchain_finish per output row.  Block = 6 KS CT QT waves: K halves, column tiles, and QT octet tiles
+// that follow each other along a row pair (QT 32 octets = whole row pairs).
+template <int KS, int CT, int QT>
+__global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WChainArgs a) {
+  constexpr int NW = 6 * KS * CT * QT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = w % 6, ks = (w / 6) % KS, ct = (w / (6 * KS)) % CT, qw = w / (6 * KS * CT);
+  const int li = lane & 31, lh = lane >> 5;
+  int qt, ctile;       // block's octet-tile group / column-tile group (a.qtiles / a.ctiles of them)
+  {
+    const int bid = blockIdx.x;
+    if ((a.qtiles & 7) == 0) {
+      const int xcd = bid & 7, slot = bid >> 3;
+      qt = xcd * (a.qtiles >> 3) + slot / a.ctiles;
+      ctile = slot - (slot / a.ctiles) * a.ctiles;
+    } else {
+      qt = bid / a.ctiles;
+      ctile = bid - qt * a.ctiles;
+    }
+  }
+  WC_STAMP(0);
+  const int n0 = (ctile * CT + ct) * 32;
+  const int o0 = qt * 32 * QT;          // first octet of the block
+  const int Hh = a.H >> 1;
+  const int total_oct = a.total_quads >> 1;
+  unsigned voff;
+  {
+    const int O = o0 + 32 * qw + li;
+    const bool ok = O < total_oct;
+    const int OO = ok ? O : 0;
+    const int orow = OO / a.Wq, xq = OO - orow * a.Wq;
+    const int img = orow / Hh, t = orow - img * Hh;
+    // padded row index of image row 2 t - 1 is 2 t
+    voff = ok ? (unsigned)(((img * (a.H + 2) + 2 * t) * a.Wq + xq) * 16) + (unsigned)lh * a.plane_bytes : 0xffffffffu;
+  }
+  const unsigned uoff = (unsigned)(((size_t)lh * a.cout_pad + n0 + li) * 16);
+  const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.vin), 0, a.vin_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const unsigned cp16 = (unsigned)a.cout_pad * 16u;
+  const unsigned row16 = (unsigned)a.Wq * 16u;
+  const int cg_per = a.cg_in / KS, cg0 = ks * cg_per, cg_last = cg0 + cg_per - 1;     // cg_per is even (Cin a multiple of 32)
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+  f32x4 d[2][4], u[2][4];
+  auto load_step = [&](int cg, int slot) __attribute__((always_inline)) {
+    const unsigned so_v = (unsigned)((p * a.cg_in + cg) * 2) * a.plane_bytes;
+    const unsigned so_u = (unsigned)((((cg >> 2) * 4) * 6 + p) * 8 + (cg & 3) * 2) * cp16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[slot][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, voff, so_v + (unsigned)r * row16, 0));
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) u[slot][s2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, uoff, so_u + (unsigned)(s2 * 48) * cp16, 0));
+  };
+  load_step(cg0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  load_step(cg0 + 1, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  WC_STAMP(1);
+  for (int cg = cg0; cg <= cg_last; cg += 2) {
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      const int nx = cg + 2 + slot <= cg_last ? cg + 2 + slot : cg_last;      // the last refills re-read a live group (stay inside the buffers)
+      f32x4 b[4];
+      b[0] = d[slot][0] - d[slot][2];
+      b[1] = d[slot][1] + d[slot][2];
+      b[2] = d[slot][2] - d[slot][1];
+      b[3] = d[slot][1] - d[slot][3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) acc[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[slot][s2][j], b[s2][j], acc[s2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_step(nx, slot);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  WC_STAMP(2);
+  // fold the four height positions to the two output rows, leave them in LDS: [wave][row][g][lane] x 4 registers
+  f32x4* J = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 r0, r1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = 4 * g + k;
+      r0[k] = (acc[0][r] + acc[1][r]) + acc[2][r];
+      r1[k] = (acc[1][r] - acc[2][r]) - acc[3][r];
+    }
+    J[((w * 2 + 0) * 4 + g) * 64 + lane] = r0;
+    J[((w * 2 + 1) * 4 + g) * 64 + lane] = r1;
+  }
+  __syncthreads();
+  const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
+  for (int vw = w; vw < CT * 8; vw += NW) {
+    const int ect = vw >> 3, g = (vw >> 1) & 3, row = vw & 1;
+    const int c0 = (ctile * CT + ect) * 32 + 8 * g + 4 * lh;
+    wchain_finish<QT>(
+        a, c0, li, lh, lo,
+        [&](int q, int b) {
+          f32x4 m = J[(((q + 6 * (KS * (ect + CT * b))) * 2 + row) * 4 + g) * 64 + lane];
+#pragma unroll
+          for (int k = 1; k < KS; ++k) m += J[(((q + 6 * (k + KS * (ect + CT * b))) * 2 + row) * 4 + g) * 64 + lane];
+          return m;
+        },
+        [&](int b, bool& ok, int& img, int& r, int& xq) {
+          const int O = o0 + 32 * b + li;
+          ok = O < total_oct;
+          const int OO = ok ? O : 0;
+          const int orow = OO / a.Wq;
+          xq = OO - orow * a.Wq;
+          img = orow / Hh;
+          r = 2 * (orow - img * Hh) + row;
+        });
+  }
+  WC_STAMP(3);
+}
+
+// torch (Cout, Cin, 3, 3) -> [chunk][s 4][p 6][k4 8][cout_pad][4] = Gh g Gw^T in double, rounded once (Gw: conv_wino4.hip's F(4, 3) rows,
+// Gh: F(2, 3): g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2 over the kernel rows)
+__global__ void pack_wino24_weight_kernel(const float* __restrict__ w, int cout, int cin, int cout_pad, float* __restrict__ packed, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int k1 = r & 3; r >>= 2;
+    const int n = (int)(r % cout_pad); r /= cout_pad;
+    const int k4 = r & 7; r >>= 3;
+    const int q = (int)(r % 6); r /= 6;
+    const int s = (int)(r & 3);
+    const int chunk = (int)(r >> 2);
+    const int c = chunk * 32 + k4 * 4 + k1;
+    double v = 0.0;
+    if (n < cout && c < cin) {
+      const float* g = w + ((size_t)n * cin + c) * 9;
+      double row[3];      // the kernel rows folded by Gh[s]
+      for (int kw = 0; kw < 3; ++kw) {
+        const double g0 = g[kw], g1 = g[3 + kw], g2 = g[6 + kw];
+        row[kw] = s == 0 ? g0 : s == 1 ? (g0 + g1 + g2) * 0.5 : s == 2 ? (g0 - g1 + g2) * 0.5 : g2;
+      }
+      const double g0 = row[0], g1 = row[1], g2 = row[2];
+      v = q == 0 ? g0 / 4.0 : q == 1 ? -(g0 + g1 + g2) / 6.0 : q == 2 ? -(g0 - g1 + g2) / 6.0 : q == 3 ? g0 / 24.0 + g1 / 12.0 + g2 / 6.0
+          : q == 4 ? g0 / 24.0 - g1 / 12.0 + g2 / 6.0 : g2;
+    }
+    packed[i] = (float)v;
+  }
 }
 
 // NHWC map -> the six planes (head of a chain).  One thread = one (quad, four channels): lanes along quads, so the plane stores are
@@ -335,6 +511,35 @@ static void launch_chain(const WChainArgs& a, hipStream_t st, bool prof, const p
   const dim3 grid((unsigned)(a.qtiles * a.ctiles));
   if (prof) hipExtLaunchKernelGGL((conv_wchain_kernel<NA, NB, KS, CT>), grid, dim3(64 * NW), smem, st, ps.start, ps.stop, 0, a);
   else hipLaunchKernelGGL((conv_wchain_kernel<NA, NB, KS, CT>), grid, dim3(64 * NW), smem, st, a);
+}
+
+struct Chain2Form { int ks, ct, qt; };
+
+// F(2,3) x F(4,3) form: octet tiles of 32 QT octets = whole row pairs; 12 waves per block
+static bool chain2_form(const pn_conv_desc* d, Chain2Form& f) {
+  if (d->in_w % 4 || d->in_h % 2) return false;
+  const int wq = d->in_w / 4;
+  const long long octs = (long long)d->batch * (d->in_h / 2) * wq;
+  const Chain2Form cands[] = {{2, 1, 1}, {1, 1, 2}};
+  for (const Chain2Form& c : cands) {
+    const int tq = 32 * c.qt, tc = 32 * c.ct;
+    if (tq % wq != 0 || octs % tq != 0 || d->cout % tc != 0 || (d->cin / 8) % (2 * c.ks) != 0) continue;
+    f = c;
+    return true;
+  }
+  return false;
+}
+
+template <int KS, int CT, int QT>
+static void launch_chain2(const WChainArgs& a, hipStream_t st, bool prof, const pn::ProfileSlot& ps) {
+  constexpr int NW = 6 * KS * CT * QT;
+  constexpr size_t smem = (size_t)NW * 2 * 4 * 64 * 16;
+  static bool done[64] = {false};
+  if (pn::first_use_on_device(done))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wchain2_kernel<KS, CT, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const dim3 grid((unsigned)(a.qtiles * a.ctiles));
+  if (prof) hipExtLaunchKernelGGL((conv_wchain2_kernel<KS, CT, QT>), grid, dim3(64 * NW), smem, st, ps.start, ps.stop, 0, a);
+  else hipLaunchKernelGGL((conv_wchain2_kernel<KS, CT, QT>), grid, dim3(64 * NW), smem, st, a);
 }
 
 }  // namespace
@@ -410,6 +615,61 @@ int pn_conv2d_wino4_chain_f32(const pn_conv_desc* d, const float* planes_in, con
   else if (f.na == 1 && f.nb == 2 && f.ks == 2 && f.ct == 1) launch_chain<1, 2, 2, 1>(a, st, prof, ps);
   else launch_chain<1, 1, 2, 1>(a, st, prof, ps);
   return pn::check_launch("conv_wchain_kernel");
+}
+
+size_t pn_conv_wino24_packed_weight_floats(int cout, int cin) {
+  return (size_t)pn::cdiv(cin, 32) * 4 * 6 * 8 * (size_t)(pn::cdiv(cout, 128) * 128) * 4;
+}
+
+int pn_pack_conv_weight_wino24_f32(const float* w_oihw, int cout, int cin, float* packed, pn_stream_t stream) {
+  PN_REQUIRE(w_oihw && packed && cout >= 1 && cin >= 1, "pack_conv_weight_wino24: bad arguments");
+  const size_t total = pn_conv_wino24_packed_weight_floats(cout, cin);
+  hipLaunchKernelGGL(pack_wino24_weight_kernel, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0, pn::S(stream), w_oihw, cout, cin,
+                     pn::cdiv(cout, 128) * 128, packed, total);
+  return pn::check_launch("pack_wino24_weight_kernel");
+}
+
+int pn_conv_wino24_chain_supported(const pn_conv_desc* d) {
+  if (!pn_conv_wino4_chain_supported(d)) return 0;
+  Chain2Form f;
+  return chain2_form(d, f) ? 1 : 0;
+}
+
+int pn_conv2d_wino24_chain_f32(const pn_conv_desc* d, const float* planes_in, const float* packed_w24, const float* scale, const float* shift,
+                               float* planes_out, float* out_nhwc, pn_stream_t stream) {
+  PN_REQUIRE(d && planes_in && packed_w24 && (planes_out || out_nhwc), "conv_wino24_chain: null pointer");
+  PN_REQUIRE(pn_conv_wino24_chain_supported(d), "conv_wino24_chain: layer shape not supported (3x3 / stride 1 / pad 1, even height, cin and cout "
+                                                "multiples of 32, row-pair-aligned tiles)");
+  PN_REQUIRE(((uintptr_t)planes_in & 15) == 0 && ((uintptr_t)packed_w24 & 15) == 0 && ((uintptr_t)planes_out & 15) == 0 && ((uintptr_t)out_nhwc & 15) == 0 &&
+                 ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
+             "conv_wino24_chain: pointers must be 16-byte aligned");
+  if (out_nhwc)
+    PN_REQUIRE(d->out_pixel_stride >= d->out_channel_offset + d->cout && d->out_pixel_stride % 4 == 0 && d->out_channel_offset % 4 == 0,
+               "conv_wino24_chain: output channel slice must fit the pixel stride, in multiples of 4 floats");
+  Chain2Form f;
+  chain2_form(d, f);
+  WChainArgs a{};
+  a.vin = planes_in; a.w = packed_w24; a.scale = scale; a.shift = shift; a.vout = planes_out; a.out = out_nhwc;
+  a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Wq = d->in_w / 4; a.Cin = d->cin; a.Cout = d->cout;
+  a.out_ps = d->out_pixel_stride; a.out_co = d->out_channel_offset;
+  a.act = d->act;
+  a.total_quads = d->batch * d->in_h * a.Wq;
+  a.qtiles = (a.total_quads / 2) / (32 * f.qt);
+  a.ctiles = d->cout / (32 * f.ct);
+  a.cg_in = d->cin / 8; a.cg_out = d->cout / 8;
+  a.cout_pad = pn::cdiv(d->cout, 128) * 128;
+  a.plane_bytes = (unsigned)((size_t)d->batch * (d->in_h + 2) * a.Wq * 16);
+  a.vin_bytes = (unsigned)(pn_wino4_planes_floats(d->batch, d->in_h, d->in_w, d->cin) * 4);
+  a.w_bytes = (unsigned)(pn_conv_wino24_packed_weight_floats(d->cout, d->cin) * 4);
+#ifdef PN_WCHAIN_STAMP
+  a.stamps = pn_wchain_stamp_buffer;
+#endif
+  pn::ProfileSlot ps{};
+  const bool prof = pn::take_profile_slot(ps);
+  hipStream_t st = pn::S(stream);
+  if (f.ks == 2) launch_chain2<2, 1, 1>(a, st, prof, ps);
+  else launch_chain2<1, 1, 2>(a, st, prof, ps);
+  return pn::check_launch("conv_wchain2_kernel");
 }
 
 }  // extern "C"

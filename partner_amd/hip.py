@@ -194,6 +194,10 @@ SIGNATURES = {
     "pn_wino4_planes_from_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "pn_conv_wino4_chain_supported": (_I, [_P]),
     "pn_conv2d_wino4_chain_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "pn_conv_wino24_packed_weight_floats": (_SZ, [_I, _I]),
+    "pn_pack_conv_weight_wino24_f32": (_I, [_P, _I, _I, _P, _P]),
+    "pn_conv_wino24_chain_supported": (_I, [_P]),
+    "pn_conv2d_wino24_chain_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "pn_conv2d_wgrad_wino4_workspace_bytes": (_SZ, [_P]),
     "pn_conv2d_wgrad_wino4_f32": (_I, [_P, _P, _P, _P, _I, _P, _SZ, _P]),
     "pn_pillar_conv_packed_weight_floats": (_SZ, [_I, _I]),

@@ -398,6 +398,7 @@ _WINO4_ON = os.environ.get("PN_CONV_WINO4", "1") != "0"
 _TAPSUM_ON = os.environ.get("PN_CONV_TAPSUM", "1") != "0"   # 3x3 layers with <= 3 output channels over >= 128 input channels as GEMM + tap sum
 _WINO4_MIN_TILES = int(os.environ.get("PN_CONV_WINO4_MIN_TILES", "256"))
 _WINO4_DGRAD = os.environ.get("PN_CONV_WINO4_DGRAD", "1") != "0"     # F(4, 3) for the training data gradients (the forward stays on F(2, 3), see train.py)
+_CHAIN2D_ON = os.environ.get("PN_CONV_CHAIN2D", "1") != "0"           # chained layers: F(2, 3) along the height on top of F(4, 3) along the width
 
 
 class ConvLayer:
@@ -462,6 +463,11 @@ class ConvLayer:
         if self.wino_packed is not None and _WINO4_ON and wino4 and self.cout % 32 == 0 and self.act in (ACT_NONE, ACT_RELU):
             self.wino4_packed = _f32(lib.pn_conv_wino4_packed_weight_floats(self.cout, self.cin), dev)
             hip.call("pn_pack_conv_weight_wino4_f32", w.data_ptr(), self.cout, self.cin, self.wino4_packed.data_ptr(), st)
+        # ... and the F(2, 3) x F(4, 3) weights of the chained form (conv_wchain.hip, ops.conv_chain: 3 MFMA equivalents per output)
+        self.wino24_packed = None
+        if self.wino4_packed is not None and _CHAIN2D_ON and self.cin % 32 == 0:
+            self.wino24_packed = _f32(lib.pn_conv_wino24_packed_weight_floats(self.cout, self.cin), dev)
+            hip.call("pn_pack_conv_weight_wino24_f32", w.data_ptr(), self.cout, self.cin, self.wino24_packed.data_ptr(), st)
 
         # ... and 3x3 layers with one to three output channels over many input channels (the geometry-aware head's 256 -> 1 heat-map and
         # vote-class convolutions): a GEMM over the pixels against the (9 cout, cin) tap matrix + a nine-term shifted sum
@@ -489,6 +495,8 @@ class ConvLayer:
         self._stale = {"direct"} | ({"wino"} if self.wino_packed is not None else set()) | ({"wino4"} if self.wino4_packed is not None else set())
         if self.tap_packed is not None:
             self._stale.add("tap")
+        if getattr(self, "wino24_packed", None) is not None:
+            self._stale.add("wino24")
         if shift is not None:
             self.shift = shift
 
@@ -509,6 +517,8 @@ class ConvLayer:
             self._pack_taps(w)
         elif layout == "wino":
             hip.call("pn_pack_conv_weight_wino_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino_packed.data_ptr(), st)
+        elif layout == "wino24":
+            hip.call("pn_pack_conv_weight_wino24_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino24_packed.data_ptr(), st)
         else:
             hip.call("pn_pack_conv_weight_wino4_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino4_packed.data_ptr(), st)
 
@@ -647,16 +657,31 @@ def conv_chain(layers, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_
     assert out.shape[:3] == (b, h, w) and out.is_contiguous()
     prof = _PROFILER
     for k, l in enumerate(layers):
-        l._ensure("wino4")
         is_last = k == len(layers) - 1
         d = _chain_desc(l, b, h, w, out.shape[3], out_channel_offset) if is_last else _chain_desc(l, b, h, w)
+        two_d = l.wino24_packed is not None and _chain_two_d(lib, d)
+        l._ensure("wino24" if two_d else "wino4")
         if prof is not None:
             ev = prof.begin(st)
-        hip.call("pn_conv2d_wino4_chain_f32", C.byref(d), bufs[k & 1].data_ptr(), l.wino4_packed.data_ptr(), hip.ptr(l.scale), hip.ptr(l.shift),
+        hip.call("pn_conv2d_wino24_chain_f32" if two_d else "pn_conv2d_wino4_chain_f32", C.byref(d), bufs[k & 1].data_ptr(),
+                 (l.wino24_packed if two_d else l.wino4_packed).data_ptr(), hip.ptr(l.scale), hip.ptr(l.shift),
                  None if is_last else bufs[(k + 1) & 1].data_ptr(), out.data_ptr() if is_last else None, st)
         if prof is not None:
-            prof.end(ev, 2.0 * b * h * w * l.cout * l.cin * 9, st, tag=f"{h}x{w} {l.cin}->{l.cout} k3 F(4,3) chain")
+            flops = 2.0 * b * h * w * l.cout * l.cin * 9
+            prof.end(ev, flops, st, tag=f"{h}x{w} {l.cin}->{l.cout} k3 F(2,3)xF(4,3) chain" if two_d else f"{h}x{w} {l.cin}->{l.cout} k3 F(4,3) chain",
+                     issued=flops / 3.0 if two_d else None)
     return out
+
+
+def _chain_two_d(lib, d) -> bool:
+    """the chained layer's form: F(2,3) x F(4,3) where the kernel has a 12-wave form for the map; on maps whose 2-D tiles cover less than
+    3/4 of the CUs (64 x 64 x 256: 128 blocks) only when other frames run beside this one (they take the free CUs, and the 2-D form
+    issues 1.5x fewer MFMAs); alone on the chip the 1-D form's 256 blocks finish sooner"""
+    if not _CHAIN2D_ON or not lib.pn_conv_wino24_chain_supported(C.byref(d)):
+        return False
+    octs, wq = d.batch * (d.in_h // 2) * (d.in_w // 4), d.in_w // 4
+    blocks = (octs // (64 if wq > 32 else 32)) * (d.cout // 32)
+    return blocks >= 192 or d.frames_in_flight > 1
 
 
 _PILLAR_CONV_ON = os.environ.get("PN_PILLAR_CONV", "1") != "0"

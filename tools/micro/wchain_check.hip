@@ -25,10 +25,11 @@ int main(int argc, char** argv) {
   for (auto sh : shapes) {
     const size_t nin = (size_t)sh.b * sh.h * sh.w * sh.cin, nout = (size_t)sh.b * sh.h * sh.w * sh.cout;
     const size_t nvi = pn_wino4_planes_floats(sh.b, sh.h, sh.w, sh.cin), nvo = pn_wino4_planes_floats(sh.b, sh.h, sh.w, sh.cout);
-    float *x, *w, *pw, *o_ref, *o_ch, *sc, *shf, *vin, *vout, *vref;
+    float *x, *w, *pw, *pw24, *o_ref, *o_ch, *sc, *shf, *vin, *vout, *vref;
     hipMalloc(&x, nin * 4); hipMalloc(&o_ref, nout * 4); hipMalloc(&o_ch, nout * 4); hipMalloc(&w, (size_t)sh.cout * sh.cin * 9 * 4);
     hipMalloc(&sc, sh.cout * 4); hipMalloc(&shf, sh.cout * 4);
     hipMalloc(&pw, pn_conv_wino4_packed_weight_floats(sh.cout, sh.cin) * 4);
+    hipMalloc(&pw24, pn_conv_wino24_packed_weight_floats(sh.cout, sh.cin) * 4);
     hipMalloc(&vin, nvi * 4); hipMalloc(&vout, nvo * 4); hipMalloc(&vref, nvo * 4);
     hipMemset(vin, 0xff, nvi * 4); hipMemset(vout, 0xff, nvo * 4); hipMemset(vref, 0xff, nvo * 4);   // NaN patterns: the kernels own the padding rows
     std::vector<float> h(std::max(nin, (size_t)sh.cout * sh.cin * 9));
@@ -41,6 +42,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < sh.cout; ++i) h[i] = (float)rand() / RAND_MAX - 0.5f;
     hipMemcpy(shf, h.data(), sh.cout * 4, hipMemcpyHostToDevice);
     pn_pack_conv_weight_wino4_f32(w, sh.cout, sh.cin, pw, nullptr);
+    pn_pack_conv_weight_wino24_f32(w, sh.cout, sh.cin, pw24, nullptr);
     pn_conv_desc d{};
     d.batch = sh.b; d.in_h = sh.h; d.in_w = sh.w; d.cin = sh.cin; d.cout = sh.cout; d.kh = d.kw = 3; d.stride = 1; d.pad_h = d.pad_w = 1; d.groups = 1;
     d.in_pixel_stride = sh.cin; d.out_pixel_stride = sh.cout; d.act = PN_ACT_RELU;
@@ -56,6 +58,16 @@ int main(int argc, char** argv) {
     hipMemcpy(a.data(), o_ch, nout * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), o_ref, nout * 4, hipMemcpyDeviceToHost);
     hipMemcpy(va.data(), vout, nvo * 4, hipMemcpyDeviceToHost); hipMemcpy(vb.data(), vref, nvo * 4, hipMemcpyDeviceToHost);
     printf("%dx%dx%d %d->%d: nhwc max|d|/max|ref| %.3g, planes %.3g\n", sh.b, sh.h, sh.w, sh.cin, sh.cout, max_rel(a, b), max_rel(va, vb));
+    const bool two_d = pn_conv_wino24_chain_supported(&d);
+    if (two_d) {
+      hipMemset(vout, 0xff, nvo * 4); hipMemset(o_ch, 0xff, nout * 4);
+      rc = pn_conv2d_wino24_chain_f32(&d, vin, pw24, sc, shf, vout, o_ch, nullptr);
+      if (rc) { pn_last_error(buf, 256); printf("error: %s\n", buf); return 1; }
+      hipDeviceSynchronize();
+      hipMemcpy(a.data(), o_ch, nout * 4, hipMemcpyDeviceToHost);
+      hipMemcpy(va.data(), vout, nvo * 4, hipMemcpyDeviceToHost);
+      printf("  2-D form: nhwc max|d|/max|ref| %.3g, planes %.3g\n", max_rel(a, b), max_rel(va, vb));
+    }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const double issued = 2.0 * sh.b * sh.h * sh.w * sh.cout * sh.cin * 4.5;
     auto timeit = [&](const char* name, auto fn) {
@@ -75,6 +87,14 @@ int main(int argc, char** argv) {
     timeit("chain -> planes", [&] { pn_conv2d_wino4_chain_f32(&d, vin, pw, sc, shf, vout, nullptr, nullptr); });
     timeit("chain -> planes + nhwc", [&] { pn_conv2d_wino4_chain_f32(&d, vin, pw, sc, shf, vout, o_ch, nullptr); });
     timeit("chain -> nhwc", [&] { pn_conv2d_wino4_chain_f32(&d, vin, pw, sc, shf, nullptr, o_ch, nullptr); });
+    if (two_d) {
+      timeit("2-D chain -> planes", [&] { pn_conv2d_wino24_chain_f32(&d, vin, pw24, sc, shf, vout, nullptr, nullptr); });
+      timeit("2-D chain -> nhwc", [&] { pn_conv2d_wino24_chain_f32(&d, vin, pw24, sc, shf, nullptr, o_ch, nullptr); });
+      timeit("2-D: 5 chained layers (x5)", [&] {
+        for (int l = 0; l < 5; ++l) pn_conv2d_wino24_chain_f32(&d, (l & 1) ? vout : vin, pw24, sc, shf, (l & 1) ? vin : vout, nullptr, nullptr);
+      });
+      pn_wino4_planes_from_nhwc_f32(x, sh.b, sh.h, sh.w, sh.cin, sh.cin, 0, vin, nullptr);
+    }
     timeit("planes from nhwc", [&] { pn_wino4_planes_from_nhwc_f32(x, sh.b, sh.h, sh.w, sh.cin, sh.cin, 0, vin, nullptr); });
     // ping-pong chain of 5 layers, as the block runs them
     timeit("5 chained layers (per layer)", [&] {
@@ -84,7 +104,8 @@ int main(int argc, char** argv) {
     {  // stamps of one launch (every wave): prologue | K loop | join + epilogue, and the spread of block starts / ends
       hipMemset(stamps, 0, 2048 * 16 * 4 * 8);
       hipDeviceSynchronize();
-      pn_conv2d_wino4_chain_f32(&d, vin, pw, sc, shf, vout, nullptr, nullptr);
+      if (two_d) pn_conv2d_wino24_chain_f32(&d, vin, pw24, sc, shf, vout, nullptr, nullptr);
+      else pn_conv2d_wino4_chain_f32(&d, vin, pw, sc, shf, vout, nullptr, nullptr);
       hipDeviceSynchronize();
       std::vector<unsigned long long> st(2048 * 16 * 4);
       hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost);
@@ -99,10 +120,10 @@ int main(int argc, char** argv) {
         }
       auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
       auto mx = [](std::vector<double>& v) { return v.empty() ? 0.0 : *std::max_element(v.begin(), v.end()); };
-      printf("  stamps (%zu waves, 100 MHz ticks?): prologue med %.0f | K loop med %.0f max %.0f | join+epilogue med %.0f max %.0f | wave med %.0f ; first start -> last start %.0f, -> last end %.0f\n",
-             pro.size(), med(pro), med(loop), mx(loop), med(epi), mx(epi), med(tot), (double)(ls - t0), (double)(t1 - t0));
+      printf("  stamps of the last form (%zu waves, shader clocks): prologue med %.0f | K loop med %.0f max %.0f | join+epilogue med %.0f max %.0f | wave med %.0f ; last start -> last end %.0f\n",
+             pro.size(), med(pro), med(loop), mx(loop), med(epi), mx(epi), med(tot), (double)(t1 - ls));
     }
-    hipFree(x); hipFree(w); hipFree(pw); hipFree(o_ref); hipFree(o_ch); hipFree(sc); hipFree(shf); hipFree(vin); hipFree(vout); hipFree(vref);
+    hipFree(x); hipFree(w); hipFree(pw); hipFree(pw24); hipFree(o_ref); hipFree(o_ch); hipFree(sc); hipFree(shf); hipFree(vin); hipFree(vout); hipFree(vref);
   }
   return 0;
 }
