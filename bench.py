@@ -445,6 +445,15 @@ def dry_run(args, rank, world):
     D.init(args.backend, None, timeout_s=args.collective_timeout)
     D.barrier()
     seen, ranks = rank_table(rank, world)
+    # the frame shard of the inference path (frame i -> rank i mod world, dist_utils.frame_shard) over world x 8 frame ids: every rank
+    # reports its own, rank 0 checks that the union covers every frame exactly once
+    frame_ids = list(range(world * 8))
+    mine = D.frame_shard(frame_ids, rank, world)
+    shards = [mine]
+    if world > 1:
+        shards = [None] * world
+        torch.distributed.all_gather_object(shards, mine)
+    flat = sorted(f for sh in shards for f in sh)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001)
@@ -458,7 +467,8 @@ def dry_run(args, rank, world):
                           "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run",
                           "config": {"workload": "none (--dry-run)", "parallelism": f"ranks x{world}", "backend": args.backend},
-                          "ranks_seen": seen, "ranks": ranks, "train_step": train}), flush=True)
+                          "ranks_seen": seen, "ranks": ranks, "train_step": train,
+                          "frame_shard": {"frames": len(frame_ids), "per_rank": [len(sh) for sh in shards], "covered_exactly_once": flat == frame_ids}}), flush=True)
     if world > 1:
         D.barrier()
         torch.distributed.destroy_process_group()

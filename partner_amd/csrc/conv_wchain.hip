@@ -44,6 +44,7 @@ struct WChainArgs {
   float* vout;     // next layer's planes (may be null)
   float* out;      // NHWC output (may be null)
   int B, H, W, Wq, Cin, Cout;
+  int wq_log2;            // Wq is a power of two (it divides a 32- or 64-quad tile)
   int out_ps, out_co;
   int act;
   int total_quads;
@@ -66,6 +67,9 @@ unsigned long long* pn_wchain_stamp_buffer = nullptr;
 #else
 #define WC_STAMP(k) do { } while (0)
 #endif
+#ifndef PN_WCHAIN_EXP
+#define PN_WCHAIN_EXP 0   // diagnostic builds only (tools/micro/wchain_check.hip), 2-D kernel's K loop: bit 0 no height transform, 1 no plane loads, 2 no weight loads
+#endif
 
 // B^T d for four channels at once (the same expression tree as conv_wino4.hip's wino4_input_transform: bit-identical values)
 __device__ __forceinline__ void wchain_input_transform(const f32x4 (&d)[6], f32x4 (&v)[6]) {
@@ -80,8 +84,20 @@ __device__ __forceinline__ void wchain_input_transform(const f32x4 (&d)[6], f32x
   v[5] = __builtin_elementwise_fma(c4, d[1], __builtin_elementwise_fma(m5, d[3], d[5]));
 }
 
+// Where element k (0 .. 63) of a tile lies, from the tile's block-uniform first row (image img0, row r0 of `rows` per image): tiles are
+// whole rows of Wq = 1 << lg quads and never taller than an image, so no vector division
+__device__ __forceinline__ void wchain_coords(int img0, int r0, int rows, int lg, int k, int& img, int& r, int& xq) {
+  xq = k & ((1 << lg) - 1);
+  r = r0 + (k >> lg);
+  img = img0;
+  if (r >= rows) {
+    r -= rows;
+    img += 1;
+  }
+}
+
 // The tail of a tile for one lane: NT 32-quad tiles that follow each other along the map rows (NT 32 quads = whole rows), four output
-// channels c0 .. c0 + 3.  get_m(q, b) = the lane's four channels of position q of tile b (K slices already summed); quad_of(b, ...) = where
+// channels c0 .. c0 + 3 (tiles are always whole).  get_m(q, b) = the lane's four channels of position q of tile b (K slices summed); quad_of(b, ...) = where
 // the lane's quad of tile b lies.  Output transform, affine + activation, the neighbours' edge pixels by lane shuffles, the next layer's
 // input transform, stores: six plane fragments (+ the zero padding rows next to the first / last image row) and / or four NHWC pixels.
 template <int NT, typename GetM, typename QuadOf>
@@ -108,9 +124,8 @@ __device__ __forceinline__ void wchain_finish(const WChainArgs& a, int c0, int l
   }
 #pragma unroll
   for (int b = 0; b < NT; ++b) {
-    bool ok;
     int img, r, xq;
-    quad_of(b, ok, img, r, xq);
+    quad_of(b, img, r, xq);
     if (a.vout) {
       f32x4 d[6];
 #pragma unroll
@@ -130,7 +145,7 @@ __device__ __forceinline__ void wchain_finish(const WChainArgs& a, int c0, int l
       d[1] = y[b][0]; d[2] = y[b][1]; d[3] = y[b][2]; d[4] = y[b][3];
       f32x4 vv[6];
       wchain_input_transform(d, vv);
-      if (ok) {
+      {
         float* o = a.vout + ((size_t)(c0 >> 3) * 2 + lh) * (a.plane_bytes >> 2) + ((size_t)(img * (a.H + 2) + r + 1) * a.Wq + xq) * 4;
         const size_t pstride = (size_t)a.cg_out * 2 * (a.plane_bytes >> 2);
 #pragma unroll
@@ -148,7 +163,7 @@ __device__ __forceinline__ void wchain_finish(const WChainArgs& a, int c0, int l
         }
       }
     }
-    if (a.out && ok) {
+    if (a.out) {
       float* o = a.out + ((size_t)(img * a.H + r) * a.W + 4 * xq) * a.out_ps + a.out_co + c0;
 #pragma unroll
       for (int px = 0; px < 4; ++px) *reinterpret_cast<f32x4*>(o + (size_t)px * a.out_ps) = y[b][px];
@@ -165,11 +180,20 @@ __global__ __launch_bounds__(64 * 6 * KS * CT) void conv_wchain_kernel(WChainArg
   const int p = w % 6, ks = (w / 6) % KS, ct = w / (6 * KS);
   const int li = lane & 31, lh = lane >> 5;
 
-  // block -> (quad tile, column tile): the column tiles of a quad tile and runs of adjacent quad tiles share an XCD (its L2 then holds
+  const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.vin), 0, a.vin_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const unsigned cp16 = (unsigned)a.cout_pad * 16u;
+  const unsigned row16 = (unsigned)a.Wq * 16u;
+  const int cg_per = a.cg_in / KS, cg0 = ks * cg_per, cg_last = cg0 + cg_per - 1;
+  f32x4* J = reinterpret_cast<f32x4*>(smem);      // [wave][b][g][lane] x 4 registers
+  const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
+  // persistent blocks: a block takes tiles bid, bid + grid, ...  The waves that finish no tile (the join's virtual waves are the first
+  // 4 CT of the block) are already in the next tile's K loop while the others store the previous one.
+  for (int bid = blockIdx.x; bid < a.qtiles * a.ctiles; bid += gridDim.x) {
+  // tile -> (quad tile, column tile): the column tiles of a quad tile and runs of adjacent quad tiles share an XCD (its L2 then holds
   // the tile's planes once and the layer's weights once)
   int qt, ctile;
   {
-    const int bid = blockIdx.x;
     if ((a.qtiles & 7) == 0) {
       const int xcd = bid & 7, slot = bid >> 3;
       qt = xcd * (a.qtiles >> 3) + slot / a.ctiles;
@@ -184,25 +208,17 @@ __global__ __launch_bounds__(64 * 6 * KS * CT) void conv_wchain_kernel(WChainArg
   const int q0 = qt * 32 * NB;
 
   // this lane's quads: byte offset of (image, row r - 1 + 1 = padded row r, xq) inside a plane, plus the lane half's plane
+  const int row0 = q0 >> a.wq_log2, img0 = row0 / a.H, r0 = row0 - img0 * a.H;      // block-uniform (scalar) division
   unsigned voff[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const int Q = q0 + 32 * b + li;
-    const bool ok = Q < a.total_quads;
-    const int QQ = ok ? Q : 0;
-    const int rowi = QQ / a.Wq, xq = QQ - rowi * a.Wq;
-    const int img = rowi / a.H, r = rowi - img * a.H;
-    voff[b] = ok ? (unsigned)(((img * (a.H + 2) + r) * a.Wq + xq) * 16) + (unsigned)lh * a.plane_bytes : 0xffffffffu;
+    int img, r, xq;
+    wchain_coords(img0, r0, a.H, a.wq_log2, 32 * b + li, img, r, xq);
+    voff[b] = (unsigned)(((img * (a.H + 2) + r) * a.Wq + xq) * 16) + (unsigned)lh * a.plane_bytes;
   }
   unsigned uoff[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) uoff[i] = (unsigned)(((size_t)lh * a.cout_pad + n0 + 32 * i + li) * 16);
-
-  const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.vin), 0, a.vin_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
-  const unsigned cp16 = (unsigned)a.cout_pad * 16u;
-  const unsigned row16 = (unsigned)a.Wq * 16u;
-  const int cg_per = a.cg_in / KS, cg0 = ks * cg_per, cg_last = cg0 + cg_per - 1;
 
   f32x16 acc[NA][NB];
 #pragma unroll
@@ -249,11 +265,9 @@ __global__ __launch_bounds__(64 * 6 * KS * CT) void conv_wchain_kernel(WChainArg
 
   WC_STAMP(2);
   // ---- join + epilogue, one pass per column sub-tile i of the waves
-  f32x4* J = reinterpret_cast<f32x4*>(smem);      // [wave][b][g][lane] x 4 registers
-  const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    if (i > 0) __syncthreads();
+    if (i > 0 || bid != (int)blockIdx.x) __syncthreads();      // the previous pass / tile has been read by its virtual waves
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -273,18 +287,11 @@ __global__ __launch_bounds__(64 * 6 * KS * CT) void conv_wchain_kernel(WChainArg
             for (int k = 1; k < KS; ++k) m += J[((((ect * KS + k) * 6 + q) * NB + b) * 4 + g) * 64 + lane];
             return m;
           },
-          [&](int b, bool& ok, int& img, int& r, int& xq) {
-            const int Q = q0 + 32 * b + li;
-            ok = Q < a.total_quads;
-            const int QQ = ok ? Q : 0;
-            const int rowi = QQ / a.Wq;
-            xq = QQ - rowi * a.Wq;
-            img = rowi / a.H;
-            r = rowi - img * a.H;
-          });
+          [&](int b, int& img, int& r, int& xq) { wchain_coords(img0, r0, a.H, a.wq_log2, 32 * b + li, img, r, xq); });
     }
   }
   WC_STAMP(3);
+  }
 }
 
 // ---- the same chain step with F(2, 3) along the map HEIGHT on top of F(4, 3) along the width: an OCTET (two rows x four pixels) from
@@ -304,9 +311,18 @@ __global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WCh
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w % 6, ks = (w / 6) % KS, ct = (w / (6 * KS)) % CT, qw = w / (6 * KS * CT);
   const int li = lane & 31, lh = lane >> 5;
-  int qt, ctile;       // block's octet-tile group / column-tile group (a.qtiles / a.ctiles of them)
+  const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.vin), 0, a.vin_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const unsigned cp16 = (unsigned)a.cout_pad * 16u;
+  const unsigned row16 = (unsigned)a.Wq * 16u;
+  const int cg_per = a.cg_in / KS, cg0 = ks * cg_per, cg_last = cg0 + cg_per - 1;     // cg_per is even (Cin a multiple of 32)
+  const int Hh = a.H >> 1;
+  f32x4* J = reinterpret_cast<f32x4*>(smem);
+  const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
+  // persistent blocks (see conv_wchain_kernel): tiles bid, bid + grid, ...
+  for (int bid = blockIdx.x; bid < a.qtiles * a.ctiles; bid += gridDim.x) {
+  int qt, ctile;       // the tile's octet-tile group / column-tile group (a.qtiles / a.ctiles of them)
   {
-    const int bid = blockIdx.x;
     if ((a.qtiles & 7) == 0) {
       const int xcd = bid & 7, slot = bid >> 3;
       qt = xcd * (a.qtiles >> 3) + slot / a.ctiles;
@@ -319,24 +335,15 @@ __global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WCh
   WC_STAMP(0);
   const int n0 = (ctile * CT + ct) * 32;
   const int o0 = qt * 32 * QT;          // first octet of the block
-  const int Hh = a.H >> 1;
-  const int total_oct = a.total_quads >> 1;
+  const int row0 = o0 >> a.wq_log2, img0 = row0 / Hh, t0 = row0 - img0 * Hh;      // block-uniform (scalar) division; rows = row pairs
   unsigned voff;
   {
-    const int O = o0 + 32 * qw + li;
-    const bool ok = O < total_oct;
-    const int OO = ok ? O : 0;
-    const int orow = OO / a.Wq, xq = OO - orow * a.Wq;
-    const int img = orow / Hh, t = orow - img * Hh;
+    int img, t, xq;
+    wchain_coords(img0, t0, Hh, a.wq_log2, 32 * qw + li, img, t, xq);
     // padded row index of image row 2 t - 1 is 2 t
-    voff = ok ? (unsigned)(((img * (a.H + 2) + 2 * t) * a.Wq + xq) * 16) + (unsigned)lh * a.plane_bytes : 0xffffffffu;
+    voff = (unsigned)(((img * (a.H + 2) + 2 * t) * a.Wq + xq) * 16) + (unsigned)lh * a.plane_bytes;
   }
   const unsigned uoff = (unsigned)(((size_t)lh * a.cout_pad + n0 + li) * 16);
-  const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.vin), 0, a.vin_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
-  const unsigned cp16 = (unsigned)a.cout_pad * 16u;
-  const unsigned row16 = (unsigned)a.Wq * 16u;
-  const int cg_per = a.cg_in / KS, cg0 = ks * cg_per, cg_last = cg0 + cg_per - 1;     // cg_per is even (Cin a multiple of 32)
 
   f32x16 acc[4];
 #pragma unroll
@@ -344,28 +351,39 @@ __global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WCh
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
   f32x4 d[2][4], u[2][4];
+  bool first = false;      // (diagnostic builds only)
   auto load_step = [&](int cg, int slot) __attribute__((always_inline)) {
     const unsigned so_v = (unsigned)((p * a.cg_in + cg) * 2) * a.plane_bytes;
     const unsigned so_u = (unsigned)((((cg >> 2) * 4) * 6 + p) * 8 + (cg & 3) * 2) * cp16;
+    if (!(PN_WCHAIN_EXP & 2) || first) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) d[slot][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, voff, so_v + (unsigned)r * row16, 0));
+      for (int r = 0; r < 4; ++r) d[slot][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, voff, so_v + (unsigned)r * row16, 0));
+    }
+    if (!(PN_WCHAIN_EXP & 4) || first) {
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) u[slot][s2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, uoff, so_u + (unsigned)(s2 * 48) * cp16, 0));
+      for (int s2 = 0; s2 < 4; ++s2) u[slot][s2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, uoff, so_u + (unsigned)(s2 * 48) * cp16, 0));
+    }
   };
+  first = true;
   load_step(cg0, 0);
   __builtin_amdgcn_sched_barrier(0);
   load_step(cg0 + 1, 1);
   __builtin_amdgcn_sched_barrier(0);
+  first = false;
   WC_STAMP(1);
   for (int cg = cg0; cg <= cg_last; cg += 2) {
 #pragma unroll
     for (int slot = 0; slot < 2; ++slot) {
       const int nx = cg + 2 + slot <= cg_last ? cg + 2 + slot : cg_last;      // the last refills re-read a live group (stay inside the buffers)
       f32x4 b[4];
-      b[0] = d[slot][0] - d[slot][2];
-      b[1] = d[slot][1] + d[slot][2];
-      b[2] = d[slot][2] - d[slot][1];
-      b[3] = d[slot][1] - d[slot][3];
+      if constexpr (PN_WCHAIN_EXP & 1) {
+        b[0] = d[slot][0]; b[1] = d[slot][1]; b[2] = d[slot][2]; b[3] = d[slot][3];
+      } else {
+        b[0] = d[slot][0] - d[slot][2];
+        b[1] = d[slot][1] + d[slot][2];
+        b[2] = d[slot][2] - d[slot][1];
+        b[3] = d[slot][1] - d[slot][3];
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -377,7 +395,7 @@ __global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WCh
   }
   WC_STAMP(2);
   // fold the four height positions to the two output rows, leave them in LDS: [wave][row][g][lane] x 4 registers
-  f32x4* J = reinterpret_cast<f32x4*>(smem);
+  if (bid != (int)blockIdx.x) __syncthreads();      // the previous tile has been read by its virtual waves
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     f32x4 r0, r1;
@@ -391,7 +409,6 @@ __global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WCh
     J[((w * 2 + 1) * 4 + g) * 64 + lane] = r1;
   }
   __syncthreads();
-  const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
   for (int vw = w; vw < CT * 8; vw += NW) {
     const int ect = vw >> 3, g = (vw >> 1) & 3, row = vw & 1;
     const int c0 = (ctile * CT + ect) * 32 + 8 * g + 4 * lh;
@@ -403,17 +420,14 @@ __global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WCh
           for (int k = 1; k < KS; ++k) m += J[(((q + 6 * (k + KS * (ect + CT * b))) * 2 + row) * 4 + g) * 64 + lane];
           return m;
         },
-        [&](int b, bool& ok, int& img, int& r, int& xq) {
-          const int O = o0 + 32 * b + li;
-          ok = O < total_oct;
-          const int OO = ok ? O : 0;
-          const int orow = OO / a.Wq;
-          xq = OO - orow * a.Wq;
-          img = orow / Hh;
-          r = 2 * (orow - img * Hh) + row;
+        [&](int b, int& img, int& r, int& xq) {
+          int t;
+          wchain_coords(img0, t0, Hh, a.wq_log2, 32 * b + li, img, t, xq);
+          r = 2 * t + row;
         });
   }
   WC_STAMP(3);
+  }
 }
 
 // torch (Cout, Cin, 3, 3) -> [chunk][s 4][p 6][k4 8][cout_pad][4] = Gh g Gw^T in double, rounded once (Gw: conv_wino4.hip's F(4, 3) rows,
@@ -477,6 +491,22 @@ __global__ __launch_bounds__(256) void wchain_v_from_nhwc_kernel(const float* __
   }
 }
 
+// one 12-wave block per CU (a multiple of 8: tiles bid and bid + grid then share an XCD); PN_WCHAIN_GRID overrides (0: one block per tile)
+static int chain_grid_limit() {
+  static const int force = [] { const char* e = getenv("PN_WCHAIN_GRID"); return e ? atoi(e) : -1; }();
+  if (force == 0) return 1 << 30;
+  if (force > 0) return force;
+  static int cus[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) ? n / 8 * 8 : 256;
+  }
+  return cus[dev];
+}
+
 struct ChainForm { int na, nb, ks, ct; };
 
 // the form a layer takes: wave tile 32 NA columns x 32 NB quads, K split KS ways, CT column tiles per block (always 12 waves)
@@ -492,7 +522,7 @@ static bool chain_form(const pn_conv_desc* d, ChainForm& f) {
     ++idx;
     if (force && force != idx) continue;
     const int tq = 32 * c.nb, tc = 32 * c.na * c.ct;
-    if (tq % wq != 0 || quads % tq != 0 || d->cout % tc != 0 || (d->cin / 8) % c.ks != 0) continue;
+    if (tq % wq != 0 || quads % tq != 0 || d->cout % tc != 0 || (d->cin / 8) % c.ks != 0 || tq / wq > d->in_h) continue;
     const long long blocks = quads / tq * (d->cout / tc);
     if (!force && blocks < 192 && idx < 3) continue;      // a narrower form fills the chip better
     f = c;
@@ -508,7 +538,7 @@ static void launch_chain(const WChainArgs& a, hipStream_t st, bool prof, const p
   static bool done[64] = {false};
   if (pn::first_use_on_device(done))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wchain_kernel<NA, NB, KS, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  const dim3 grid((unsigned)(a.qtiles * a.ctiles));
+  const dim3 grid((unsigned)std::min(a.qtiles * a.ctiles, chain_grid_limit()));
   if (prof) hipExtLaunchKernelGGL((conv_wchain_kernel<NA, NB, KS, CT>), grid, dim3(64 * NW), smem, st, ps.start, ps.stop, 0, a);
   else hipLaunchKernelGGL((conv_wchain_kernel<NA, NB, KS, CT>), grid, dim3(64 * NW), smem, st, a);
 }
@@ -523,7 +553,7 @@ static bool chain2_form(const pn_conv_desc* d, Chain2Form& f) {
   const Chain2Form cands[] = {{2, 1, 1}, {1, 1, 2}};
   for (const Chain2Form& c : cands) {
     const int tq = 32 * c.qt, tc = 32 * c.ct;
-    if (tq % wq != 0 || octs % tq != 0 || d->cout % tc != 0 || (d->cin / 8) % (2 * c.ks) != 0) continue;
+    if (tq % wq != 0 || octs % tq != 0 || d->cout % tc != 0 || (d->cin / 8) % (2 * c.ks) != 0 || tq / wq > d->in_h / 2) continue;
     f = c;
     return true;
   }
@@ -537,7 +567,7 @@ static void launch_chain2(const WChainArgs& a, hipStream_t st, bool prof, const 
   static bool done[64] = {false};
   if (pn::first_use_on_device(done))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wchain2_kernel<KS, CT, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  const dim3 grid((unsigned)(a.qtiles * a.ctiles));
+  const dim3 grid((unsigned)std::min(a.qtiles * a.ctiles, chain_grid_limit()));
   if (prof) hipExtLaunchKernelGGL((conv_wchain2_kernel<KS, CT, QT>), grid, dim3(64 * NW), smem, st, ps.start, ps.stop, 0, a);
   else hipLaunchKernelGGL((conv_wchain2_kernel<KS, CT, QT>), grid, dim3(64 * NW), smem, st, a);
 }
@@ -596,6 +626,7 @@ int pn_conv2d_wino4_chain_f32(const pn_conv_desc* d, const float* planes_in, con
   a.vin = planes_in; a.w = packed_w; a.scale = scale; a.shift = shift; a.vout = planes_out; a.out = out_nhwc;
   a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Wq = d->in_w / 4; a.Cin = d->cin; a.Cout = d->cout;
   a.out_ps = d->out_pixel_stride; a.out_co = d->out_channel_offset;
+  a.wq_log2 = __builtin_ctz((unsigned)a.Wq);
   a.act = d->act;
   a.total_quads = d->batch * d->in_h * a.Wq;
   a.qtiles = a.total_quads / (32 * f.nb);
@@ -652,6 +683,7 @@ int pn_conv2d_wino24_chain_f32(const pn_conv_desc* d, const float* planes_in, co
   a.vin = planes_in; a.w = packed_w24; a.scale = scale; a.shift = shift; a.vout = planes_out; a.out = out_nhwc;
   a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Wq = d->in_w / 4; a.Cin = d->cin; a.Cout = d->cout;
   a.out_ps = d->out_pixel_stride; a.out_co = d->out_channel_offset;
+  a.wq_log2 = __builtin_ctz((unsigned)a.Wq);
   a.act = d->act;
   a.total_quads = d->batch * d->in_h * a.Wq;
   a.qtiles = (a.total_quads / 2) / (32 * f.qt);

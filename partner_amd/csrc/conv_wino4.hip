@@ -690,7 +690,9 @@ int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc* d, const float* in, const float
   a.qtiles = pn::cdiv(a.total_quads, 32);
   a.qt0 = 0;
   hipStream_t st = pn::S(stream);
-  auto launch_ks = [&](Wino4Args k, bool prof) {
+  // stop_only: the second launch of a two-phase layer carries the STOP event of the pair whose start rides on the first launch, so the
+  // profiler's interval (and the FLOPs billed to it) covers both
+  auto launch_ks = [&](Wino4Args k, bool prof, hipEvent_t stop_only) {
     static bool ks_done[64] = {false};
     if (pn::first_use_on_device(ks_done))
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_ks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino4_ks_smem());
@@ -698,12 +700,13 @@ int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc* d, const float* in, const float
     const long long tiles = (long long)k.qtiles * k.ncol;
     const dim3 grid((unsigned)std::min<long long>(2 * ncu, (tiles + 7) / 8 * 8));
     pn::ProfileSlot ps;
-    if (prof && pn::take_profile_slot(ps)) hipExtLaunchKernelGGL(conv_wino4_ks_kernel, grid, dim3(256), wino4_ks_smem(), st, ps.start, ps.stop, 0, k);
+    if (stop_only) hipExtLaunchKernelGGL(conv_wino4_ks_kernel, grid, dim3(256), wino4_ks_smem(), st, nullptr, stop_only, 0, k);
+    else if (prof && pn::take_profile_slot(ps)) hipExtLaunchKernelGGL(conv_wino4_ks_kernel, grid, dim3(256), wino4_ks_smem(), st, ps.start, ps.stop, 0, k);
     else hipLaunchKernelGGL(conv_wino4_ks_kernel, grid, dim3(256), wino4_ks_smem(), st, k);
   };
   // layers whose column count is not a multiple of 128 (64-column layers) would waste the plain form's tile: K-split form
   if (a.Cout % W4N != 0 || wino4_form((long long)a.qtiles * a.ncol, ncu, d->frames_in_flight) == 2) {
-    launch_ks(a, true);
+    launch_ks(a, true, nullptr);
     return pn::check_launch("conv_wino4_ks_kernel");
   }
   // persistent blocks, two per CU (a multiple of 8: the XCD count), fewer when there are fewer tiles.
@@ -725,9 +728,10 @@ int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc* d, const float* in, const float
   pn::ProfileSlot ps;
   const bool prof = pn::take_profile_slot(ps);
   const dim3 grid((unsigned)std::min<long long>(slots, (tiles + 7) / 8 * 8));
-  if (prof) hipExtLaunchKernelGGL(conv_wino4_kernel, grid, dim3(256), wino4_smem(32), st, ps.start, ps.stop, 0, a);
+  const bool two = tail.qtiles > 0;
+  if (prof) hipExtLaunchKernelGGL(conv_wino4_kernel, grid, dim3(256), wino4_smem(32), st, ps.start, two ? nullptr : ps.stop, 0, a);
   else hipLaunchKernelGGL(conv_wino4_kernel, grid, dim3(256), wino4_smem(32), st, a);
-  if (tail.qtiles > 0) launch_ks(tail, false);
+  if (two) launch_ks(tail, false, prof ? ps.stop : nullptr);
   return pn::check_launch("conv_wino4_kernel");
 }
 

@@ -220,7 +220,7 @@ __device__ __forceinline__ void linear_phase(const LinArgs& a, const int row_lo,
     const int q = lane % TC4, rrow = lane / TC4;
     const int n = en0 + wn * TC + q * 4;
     const bool nok = n < a.N;
-    const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
+    const bool relu = a.act == PN_ACT_RELU;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -242,7 +242,7 @@ __device__ __forceinline__ void linear_phase(const LinArgs& a, const int row_lo,
           for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);      // (a vector-wide v_pk_fma form of the polynomial measured the same)
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
+          for (int e = 0; e < 4; ++e) v[e] = relu ? fmaxf(v[e], 0.f) : v[e];      // NaN stays NaN when there is no activation
         }
         v += rcur;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsrc_o, ooff(p), 0, 0);
@@ -345,9 +345,16 @@ __global__ __launch_bounds__(256, 2) void linear_small_kernel(LinArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, live ? xo[j] : 0xffffffffu, (unsigned)c * LS_CH * 4u, 0));
   };
-  auto load_b = [&](int c) {      // this wave's eight k groups of chunk c: k4 index = 64 c + 16 ks + 2 g + lh (past the packed rows: zeros)
+  // this wave's eight k groups of chunk c: k4 index = 64 c + 16 ks + 2 g + lh.  The packed buffer holds ceil(K / 32) * 8 such rows and the
+  // scalar offset is NOT part of the descriptor's range check, so groups past them are redirected by the vector offset (they read zeros;
+  // r3 read whatever followed the buffer for K not a multiple of 256 -- harmless only while x is zero there and the bytes are finite)
+  const int krows = (a.K + LK - 1) / LK * 8;
+  auto load_b = [&](int c) {
 #pragma unroll
-    for (int g = 0; g < 8; ++g) bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, c < nchunks ? bo : 0xffffffffu, (unsigned)(64 * c + 16 * ks + 2 * g) * np16, 0));
+    for (int g = 0; g < 8; ++g) {
+      const int k4 = 64 * c + 16 * ks + 2 * g;
+      bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, k4 + lh < krows ? bo : 0xffffffffu, (unsigned)k4 * np16, 0));
+    }
   };
   auto store_x = [&](int buf) {
 #pragma unroll
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void linear_small_kernel(LinArgs a) {
   __syncthreads();
   const int n = n0 + li;
   const float b = (a.bias && n < a.N) ? a.bias[n] : 0.f;
-  const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
+  const bool relu = a.act == PN_ACT_RELU;
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int r = 4 * ks + rr;
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void linear_small_kernel(LinArgs a) {
     const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
     v += b;
     if constexpr (GELU) v = gelu_erf(v);
-    else v = fmaxf(v, lo);
+    else v = relu ? fmaxf(v, 0.f) : v;      // (a select, not fmaxf(v, -inf): that would turn a NaN accumulator into -inf)
     if (m < a.M && n < a.N) {
       if (a.res) v += a.res[(size_t)m * a.ldr + n];
       a.out[(size_t)m * a.ldo + n] = v;

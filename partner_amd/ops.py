@@ -1139,8 +1139,7 @@ class SideStream:
     def __init__(self, device):
         self.on = _WGRAD_STREAM and torch.device(device).type == "cuda" and torch.cuda.is_available()
         self.device = device
-        self._stream = None
-        self.dirty = False
+        self._dirty: list = []        # every side stream that has run something since the last join
         self.keep: list = []
 
     @property
@@ -1168,13 +1167,22 @@ class SideStream:
         # but with hundreds of large cross-stream blocks per iteration it kept the allocator from reusing memory: the PARTNER detector's
         # training iteration went from 103 to 184 ms.)
         self.keep.extend(t for t in reads if t is not None)
-        self._stream = side
-        self.dirty = True
+        if not any(side is x for x in self._dirty):
+            self._dirty.append(side)
+
+    @property
+    def dirty(self) -> bool:
+        return bool(self._dirty)
 
     def join(self):
-        if self.dirty and self._stream is not None:
-            torch.cuda.current_stream().wait_stream(self._stream)
-            self.dirty = False
+        """the current stream waits for EVERY side stream used since the last join (the instance is shared per device and the side stream
+        depends on the caller's current stream: run() from two different streams between joins leaves two of them dirty), then the
+        read buffers are released"""
+        if self._dirty:
+            cur = torch.cuda.current_stream()
+            for side in self._dirty:
+                cur.wait_stream(side)
+            self._dirty.clear()
             self.keep.clear()
 
 

@@ -121,6 +121,28 @@ def test_bench_bare_launch_starts_one_rank_per_gpu():
     assert tr["ms_per_iter_no_exchange"] is not None and abs(tr["exposed_exchange_ms"] - (tr["ms_per_iter"] - tr["ms_per_iter_no_exchange"])) < 1e-6
 
 
+def test_bench_world_8_dry_run():
+    """the first 8-GPU run must not also be the first 8-rank run: `bench.py --gpus 8 --backend gloo --dry-run` starts eight fresh
+    processes (before anything could touch a GPU), they rendezvous on 127.0.0.1, every rank sees world size 8, the frame shard
+    (frame i -> rank i mod 8) covers every frame exactly once, rank 0 prints ONE line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--dry-run", "--steps", "3"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and [r["rank"] for r in line["ranks"]] == list(range(8))
+    assert all(r["world_size_seen"] == 8 for r in line["ranks"]) and len({r["pid"] for r in line["ranks"]}) == 8
+    assert line["frame_shard"] == {"frames": 64, "per_rank": [8] * 8, "covered_exactly_once": True}
+    assert line["scaling"] == "weak" and line["train_step"]["n_gpus"] == 8
+
+
 def test_collective_wait_is_bounded():
     """a rank that never arrives costs the others `timeout_s`, not a hang: rank 1 skips the barrier, rank 0's wait ends in an error"""
     import subprocess

@@ -99,6 +99,33 @@ def test_linear_ksplit_entry(dev):
         assert err < 2e-6, (m, k, n, act, err)
 
 
+def test_linear_ksplit_never_reads_past_the_packed_weights(dev):
+    """r3 advisor finding: for K not a multiple of 256 the K-split form addressed weight rows past the packed buffer through the scalar
+    offset (outside the descriptor's range check).  The packed weights sit between NaN blocks here; the result must be finite and right.
+    Also: with no activation a NaN in x reaches the output (the epilogue no longer clamps with fmaxf(v, -inf))"""
+    from partner_amd import hip, ops
+    lib = hip.load()
+    g = torch.Generator().manual_seed(3)
+    for (m, k, n) in [(64, 64, 32), (96, 128, 64), (33, 384, 36), (40, 520, 128)]:
+        x = torch.randn((m, k), generator=g).to(dev)
+        w = (torch.randn((n, k), generator=g) / np.sqrt(k)).to(dev)
+        nf = lib.pn_linear_packed_weight_floats(n, k)
+        guard = 4 * nf + 4096
+        arena = torch.full((guard + nf + guard,), float("nan"), dtype=torch.float32, device=dev)
+        packed = arena[guard:guard + nf]
+        hip.call("pn_pack_linear_weight_f32", w.data_ptr(), n, k, packed.data_ptr(), hip.stream())
+        y = torch.empty((m, n), dtype=torch.float32, device=dev)
+        hip.call("pn_linear_ksplit_f32", x.data_ptr(), m, k, k, packed.data_ptr(), n, None, ops.ACT_NONE, None, n, y.data_ptr(), n, hip.stream())
+        ref = x.double() @ w.double().t()
+        assert torch.isfinite(y).all(), (m, k, n)
+        assert float((y.double() - ref).abs().max() / ref.abs().max()) < 2e-6, (m, k, n)
+        x[3, 5] = float("nan")
+        hip.call("pn_linear_ksplit_f32", x.data_ptr(), m, k, k, packed.data_ptr(), n, None, ops.ACT_NONE, None, n, y.data_ptr(), n, hip.stream())
+        assert torch.isnan(y[3]).all() and torch.isfinite(y[4]).all()
+        hip.call("pn_linear_f32", x.data_ptr(), m, k, k, packed.data_ptr(), n, None, ops.ACT_NONE, None, n, y.data_ptr(), n, hip.stream())
+        assert torch.isnan(y[3]).all() and torch.isfinite(y[4]).all()
+
+
 def test_linear_rejects_bad_arguments(dev):
     from partner_amd import hip
     lib = hip.load()

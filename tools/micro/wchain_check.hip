@@ -118,6 +118,18 @@ int main(int argc, char** argv) {
           t0 = std::min(t0, s4[0]); t1 = std::max(t1, s4[3]); ls = std::max(ls, s4[0]);
           pro.push_back((double)(s4[1] - s4[0])); loop.push_back((double)(s4[2] - s4[1])); epi.push_back((double)(s4[3] - s4[2])); tot.push_back((double)(s4[3] - s4[0]));
         }
+      if (getenv("WC_TIMELINE")) {
+        for (int blk : {0, 100}) {
+          unsigned long long b0 = ~0ull;
+          for (int wv = 0; wv < 16; ++wv) if (st[((size_t)blk * 16 + wv) * 4]) b0 = std::min(b0, st[((size_t)blk * 16 + wv) * 4]);
+          printf("    block %d:", blk);
+          for (int wv = 0; wv < 16; ++wv) {
+            const unsigned long long* s4 = &st[((size_t)blk * 16 + wv) * 4];
+            if (s4[0]) printf(" w%d[%llu %llu %llu %llu]", wv, s4[0] - b0, s4[1] - b0, s4[2] - b0, s4[3] - b0);
+          }
+          printf("\n");
+        }
+      }
       auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
       auto mx = [](std::vector<double>& v) { return v.empty() ? 0.0 : *std::max_element(v.begin(), v.end()); };
       printf("  stamps of the last form (%zu waves, shader clocks): prologue med %.0f | K loop med %.0f max %.0f | join+epilogue med %.0f max %.0f | wave med %.0f ; last start -> last end %.0f\n",
