@@ -737,6 +737,18 @@ int pn_sparse_conv_c16_f32(const float *in, int in_rows, int cin, const int32_t 
                            int out_capacity, int taps, const float *packed_w, const float *scale,
                            const float *shift, int act, const float *residual, float *out,
                            pn_stream_t stream);
+/* The same convolution over GROUPS of 32 output sites with similar neighbourhoods (r4, the 32 / 64 / 128-channel levels and the strided
+ * stages): pn_sparse_group_rows sorts every window of 4096 sites of a neighbour table by its neighbour mask and returns perm[out_capacity]
+ * (the site of every slot, -1 past the live sites) and group_mask[ceil(out_capacity / 32)] (the union of the masks of slots 32 g .. 32 g + 31);
+ * one table's groups serve every convolution that shares it (indice_key).  pn_sparse_conv_grouped_f32 then runs one wave per group over
+ * the group's taps only (no tile-wide tap union: 0.73 x the MFMA work of pn_sparse_conv_f32 on a 64-beam sweep) and writes the rows to their
+ * own places: same arguments and layout as pn_sparse_conv_f32, cin a multiple of 16; results equal up to the summation order (taps
+ * ascending, channels ascending within a tap; ~2e-6 of the output's range).  scn.py:25-48,112-181. */
+int pn_sparse_group_rows(const int32_t *nbr, const int32_t *n_out, int out_capacity, int taps, int32_t *perm, uint32_t *group_mask,
+                         pn_stream_t stream);
+int pn_sparse_conv_grouped_f32(const float *in, int in_rows, int cin, const int32_t *nbr, const int32_t *n_out, int out_capacity, int taps,
+                               const int32_t *perm, const uint32_t *group_mask, const float *packed_w, int cout, const float *scale,
+                               const float *shift, int act, const float *residual, float *out, pn_stream_t stream);
 int pn_sparse_to_dense_nhwc(const float *feats, const uint32_t *keys, int capacity,
                             const int32_t *n_dev, const int32_t *dims, int c, float *out,
                             pn_stream_t stream);

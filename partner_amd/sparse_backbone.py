@@ -25,6 +25,7 @@ from .builder import BACKBONES
 from .nn_utils import PlanCache, build_norm_layer, eval_only
 
 _C16 = os.environ.get("PN_SPARSE_C16", "1") != "0"     # 0: the 16-channel level on the gathered MFMA kernel as well
+_GROUPED = os.environ.get("PN_SPARSE_GROUPED", "1") != "0"     # 0: every level >= 32 channels on the gathered tile kernel (r3) instead of sparse_group.hip
 _STRUCT_STREAM = os.environ.get("PN_SPARSE_STRUCT_STREAM", "1") != "0"   # 0: index builds / neighbour tables on the calling stream
 
 
@@ -120,8 +121,14 @@ class SpMiddleResNetFHD(nn.Module):
         return [dims[0]] + [(dims[1 + a] + 2 * p[a] - k[a]) // s[a] + 1 for a in range(3)]
 
     @staticmethod
-    def _conv(feats, n_rows, nbr, count, cap, layer, act, residual=None):
+    def _conv(feats, n_rows, nbr, count, cap, layer, act, residual=None, groups=None):
         out = torch.empty((cap, layer["cout"]), dtype=torch.float32, device=feats.device)
+        if groups is not None and layer["cin"] % 16 == 0 and layer["cout"] >= 32 and layer["taps"] <= 27:
+            # 32 / 64 / 128-channel levels and the strided stages: one wave per group of 32 similar sites, the group's taps only (sparse_group.hip)
+            hip.call("pn_sparse_conv_grouped_f32", feats.data_ptr(), n_rows, layer["cin"], nbr.data_ptr(), count.data_ptr(), cap, layer["taps"],
+                     groups[0].data_ptr(), groups[1].data_ptr(), layer["packed"].data_ptr(), layer["cout"], layer["scale"].data_ptr(),
+                     layer["shift"].data_ptr(), int(act), hip.ptr(residual), out.data_ptr(), hip.stream())
+            return out
         if _C16 and layer["cout"] == 16 and layer["cin"] in (8, 16) and layer["taps"] <= 27:
             # conv_input / conv1 (scn.py:112-123): the 16-channel level has its own kernel (inference; the training tape keeps one form)
             hip.call("pn_sparse_conv_c16_f32", feats.data_ptr(), n_rows, layer["cin"], nbr.data_ptr(), count.data_ptr(), cap, layer["taps"],
@@ -175,11 +182,22 @@ class SpMiddleResNetFHD(nn.Module):
         def tbl(rows, geo):
             return torch.empty((rows, geo[0][0] * geo[0][1] * geo[0][2]), dtype=torch.int32, device=dev)
 
+        def grp(rows):      # (perm, group masks) of a neighbour table: the sites sorted by neighbourhood, pn_sparse_group_rows
+            if not _GROUPED:
+                return None
+            return (torch.empty(rows, dtype=torch.int32, device=dev), torch.empty((rows + 31) // 32, dtype=torch.int32, device=dev))
+
+        def group(table, g, level):
+            if g is not None:
+                hip.call("pn_sparse_group_rows", table.data_ptr(), level["count"].data_ptr(), level["cap"], table.shape[1], g[0].data_ptr(), g[1].data_ptr(),
+                         hip.stream())
+
         levels = []          # per level: dict(index, keys, count, cap, dims, nbr, down=(dnbr) or None)
         cap = V
         lv = dict(index=new_index(dims), keys=torch.empty(cap, dtype=torch.int32, device=dev), count=torch.empty(1, dtype=torch.int32, device=dev),
                   cap=cap, dims=dims, dnbr=None)
         lv["nbr"] = tbl(cap, subm_geo)
+        lv["grp"], lv["dgrp"] = None, None      # level 0 is the 16-channel level (its own kernel)
         rank = torch.empty(cap, dtype=torch.int32, device=dev)
         levels.append(lv)
         geos = [stage["down"]["geo"] for stage in plan["stages"] if stage["down"] is not None] + [plan["extra"]["geo"]]
@@ -190,6 +208,8 @@ class SpMiddleResNetFHD(nn.Module):
             nl = dict(index=new_index(odims), keys=torch.empty(ocap, dtype=torch.int32, device=dev), count=torch.empty(1, dtype=torch.int32, device=dev),
                       cap=ocap, dims=odims, geo=geo, dnbr=tbl(ocap, geo))
             nl["nbr"] = tbl(ocap, subm_geo) if gi + 1 < len(geos) else None      # the last level (extra_conv) has no submanifold layers
+            nl["dgrp"] = grp(ocap)
+            nl["grp"] = grp(ocap) if nl["nbr"] is not None else None
             levels.append(nl)
 
         def build_structure():
@@ -205,8 +225,10 @@ class SpMiddleResNetFHD(nn.Module):
                          self._i3(geo[0]), self._i3(geo[1]), self._i3(geo[2]), (C.c_int32 * 4)(*cur["dims"]), cur["index"].data_ptr(),
                          cur["keys"].data_ptr(), cur["cap"], cur["count"].data_ptr(), st)
                 self._neighbors(cur["keys"], cur["cap"], cur["count"], cur["dims"], prev["index"], prev["dims"], geo, out=cur["dnbr"])
+                group(cur["dnbr"], cur["dgrp"], cur)
                 if cur["nbr"] is not None:
                     self._neighbors(cur["keys"], cur["cap"], cur["count"], cur["dims"], cur["index"], cur["dims"], subm_geo, out=cur["nbr"])
+                    group(cur["nbr"], cur["grp"], cur)
                 cur["ready"] = self._mark(side)
 
         if side is None:
@@ -238,14 +260,14 @@ class SpMiddleResNetFHD(nn.Module):
                 li += 1
                 nxt = levels[li]
                 wait(nxt)
-                x = self._conv(x, cur["cap"], nxt["dnbr"], nxt["count"], nxt["cap"], stage["down"], ops.ACT_RELU)
+                x = self._conv(x, cur["cap"], nxt["dnbr"], nxt["count"], nxt["cap"], stage["down"], ops.ACT_RELU, groups=nxt["dgrp"])
                 cur = nxt
             for c1, c2 in stage["blocks"]:
-                y = self._conv(x, cur["cap"], cur["nbr"], cur["count"], cur["cap"], c1, ops.ACT_RELU)
-                x = self._conv(y, cur["cap"], cur["nbr"], cur["count"], cur["cap"], c2, ops.ACT_RELU, residual=x)
+                y = self._conv(x, cur["cap"], cur["nbr"], cur["count"], cur["cap"], c1, ops.ACT_RELU, groups=cur["grp"])
+                x = self._conv(y, cur["cap"], cur["nbr"], cur["count"], cur["cap"], c2, ops.ACT_RELU, residual=x, groups=cur["grp"])
         last = levels[li + 1]
         wait(last)
-        x = self._conv(x, cur["cap"], last["dnbr"], last["count"], last["cap"], plan["extra"], ops.ACT_RELU)
+        x = self._conv(x, cur["cap"], last["dnbr"], last["count"], last["cap"], plan["extra"], ops.ACT_RELU, groups=last["dgrp"])
         cch = plan["extra"]["cout"]
         odims = last["dims"]
         out = torch.empty((odims[0], odims[2], odims[3], cch * odims[1]), dtype=torch.float32, device=dev)

@@ -478,3 +478,70 @@ def test_sparse_conv_c16_matches_the_gathered_mfma_form_and_fp64(dev, cin, taps,
     with pytest.raises(hip.PartnerHipError):
         hip.call("pn_sparse_conv_c16_f32", x.data_ptr(), rows, 12, nbr.data_ptr(), count.data_ptr(), cap, taps, packed.data_ptr(), None, None, 0, None,
                  out_a.data_ptr(), hip.stream())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,taps,n,cap,res,act", [(32, 32, 27, 9000, 9100, True, 1), (64, 64, 27, 5000, 8192, True, 1), (128, 128, 27, 2100, 2100, False, 1),
+                                                          (16, 32, 27, 4097, 4100, False, 1), (32, 64, 27, 33, 64, False, 0), (128, 128, 3, 1500, 2048, False, 1),
+                                                          (64, 128, 27, 300, 300, True, 0)], ids=str)
+def test_sparse_conv_grouped_matches_the_gathered_tile_form_and_fp64(dev, cin, cout, taps, n, cap, res, act):
+    """pn_sparse_group_rows + pn_sparse_conv_grouped_f32 (one wave per group of 32 sites sorted by neighbourhood, the group's taps only)
+    against pn_sparse_conv_f32 (gathered 128-site tiles) on the same rulebook and against an fp64
+    gather-matmul.  Tables with sparse, clustered neighbourhoods (whole taps empty for runs of sites), counts that end inside a window
+    and inside a group, capacity above the count; perm is a permutation of the live sites, the group masks are the unions of their rows"""
+    from partner_amd import hip
+    lib = hip.load()
+    g = torch.Generator().manual_seed(cin + cout + taps + n)
+    x = torch.randn((n, cin), generator=g)
+    # neighbourhoods: each site keeps tap t with a probability that depends on the run of 40 sites it lies in (structured sparsity)
+    run = torch.arange(cap) // 40
+    keep_p = torch.rand((int(run.max()) + 1, taps), generator=g)[run] * 0.9
+    nbr = torch.randint(0, n, (cap, taps), generator=g, dtype=torch.int32)
+    nbr[torch.rand((cap, taps), generator=g) > keep_p] = -1
+    nbr[n:] = 7                                        # rows past the count must be ignored whatever they hold
+    w = torch.randn((cout, cin, taps), generator=g) * (1.0 / (cin * taps * 0.5) ** 0.5)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    resid = torch.randn((cap, cout), generator=g) if res else None
+    xd, nd, wd, scd, shd = x.to(dev), nbr.to(dev), w.to(dev).contiguous(), scale.to(dev), shift.to(dev)      # (kept alive: the launches are asynchronous)
+    packed = torch.empty(lib.pn_conv_packed_weight_floats(cout, cin, taps, 1, 1), dtype=torch.float32, device=dev)
+    hip.call("pn_pack_conv_weight_f32", wd.data_ptr(), cout, cin, taps, 1, 1, packed.data_ptr(), hip.stream())
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+    perm = torch.full((cap,), -7, dtype=torch.int32, device=dev)
+    gmask = torch.full(((cap + 31) // 32,), -1, dtype=torch.int32, device=dev)
+    hip.call("pn_sparse_group_rows", nd.data_ptr(), cnt.data_ptr(), cap, taps, perm.data_ptr(), gmask.data_ptr(), hip.stream())
+    pc, gc = perm.cpu(), gmask.cpu()
+    live = pc[pc >= 0]
+    assert torch.equal(torch.sort(live).values, torch.arange(n, dtype=torch.int32)) and int((pc >= 0).sum()) == n
+    assert torch.all(pc[:n] >= 0) or n % 4096 != 0          # dead slots only at the end of the last window
+    bits = ((nbr[:n] >= 0).to(torch.int64) * (1 << torch.arange(taps))).sum(1)
+    for gi in range((n + 31) // 32):
+        rows = pc[gi * 32:gi * 32 + 32]
+        rows = rows[rows >= 0].long()
+        want = 0
+        for b in bits[rows].tolist():
+            want |= b
+        assert (int(gc[gi]) & 0xffffffff) == want, gi
+    outs = []
+    for entry in ("pn_sparse_conv_f32", "pn_sparse_conv_grouped_f32"):
+        out = torch.full((cap, cout), 123.0, dtype=torch.float32, device=dev)
+        rd = None if resid is None else resid.to(dev)
+        if entry == "pn_sparse_conv_f32":
+            hip.call(entry, xd.data_ptr(), n, cin, nd.data_ptr(), cnt.data_ptr(), cap, taps, packed.data_ptr(), cout, scd.data_ptr(),
+                     shd.data_ptr(), act, hip.ptr(rd), out.data_ptr(), hip.stream())
+        else:
+            hip.call(entry, xd.data_ptr(), n, cin, nd.data_ptr(), cnt.data_ptr(), cap, taps, perm.data_ptr(), gmask.data_ptr(), packed.data_ptr(), cout,
+                     scd.data_ptr(), shd.data_ptr(), act, hip.ptr(rd), out.data_ptr(), hip.stream())
+        outs.append(out.cpu())      # (synchronises: rd stays alive until here)
+    ref = torch.zeros((n, cout), dtype=torch.float64)
+    for t in range(taps):
+        sel = nbr[:n, t] >= 0
+        ref[sel] += x.double()[nbr[:n, t][sel].long()] @ w[:, :, t].double().t()
+    ref = ref * scale.double() + shift.double()
+    if resid is not None:
+        ref = ref + resid[:n].double()
+    if act:
+        ref = torch.relu(ref)
+    errs = [float((o[:n].double() - ref).abs().max() / ref.abs().max()) for o in outs]
+    assert max(errs) < 1e-5, errs                            # fp32 chains of up to 27 * 128 terms against fp64
+    assert float((outs[0][:n] - outs[1][:n]).abs().max() / ref.abs().max()) < 5e-6, errs       # the two forms against each other
+    assert torch.all(outs[1][n:] == 123.0)                  # rows past the count are not written

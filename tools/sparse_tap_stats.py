@@ -42,3 +42,31 @@ for nbr, n, cin, cout, taps in rec:
     tot_dense += n * taps * cin * cout * 2.0
     tot_pairs += pairs * cin * cout * 2.0
 print(f"GFLOP dense over taps {tot_dense / 1e9:.1f}, over existing pairs {tot_pairs / 1e9:.1f}")
+
+# ---- r4: what would 32-row groups with their OWN tap loop issue (conv_sparse_wave design), with the rows in key order and with the rows
+# of a window sorted by their 27-bit neighbour mask first (similar neighbourhoods share a group)?
+print("\nissued GFLOP by grouping (per frame of one sweep): tile-128 union | 32 consecutive rows | 32 rows after sorting windows of W rows by mask")
+tot = {k: 0.0 for k in ("t128", "g32", "w1024", "w4096", "w16384", "all", "pairs")}
+for nbr, n, cin, cout, taps in rec:
+    v = (nbr[:n] >= 0)
+    w = (1 << torch.arange(taps, device=dev, dtype=torch.int64))
+    mask = (v.to(torch.int64) * w).sum(1)
+    f = cin * cout * 2.0
+
+    def issued(order, T):
+        vv = v[order]
+        nt = (n + T - 1) // T
+        pad = torch.zeros((nt * T - n, taps), dtype=torch.bool, device=dev)
+        return float(torch.cat([vv, pad], 0).view(nt, T, taps).any(1).sum()) * T * f
+
+    ident = torch.arange(n, device=dev)
+    res = dict(t128=issued(ident, 128), g32=issued(ident, 32), pairs=float(v.sum()) * f)
+    for W in (1024, 4096, 16384, 1 << 30):
+        win = ident // W
+        key = win * (1 << taps) + mask          # sort by (window, mask)
+        order = torch.argsort(key, stable=True)
+        res["all" if W == 1 << 30 else f"w{W}"] = issued(order, 32)
+    for k in tot:
+        tot[k] += res[k]
+    print(f"sites {n:7d} taps {taps:2d} {cin:3d}->{cout:3d}: " + " | ".join(f"{k} {res[k] / 1e9:6.2f}" for k in ("t128", "g32", "w1024", "w4096", "w16384", "all", "pairs")))
+print("total: " + " | ".join(f"{k} {tot[k] / 1e9:6.1f}" for k in tot))
