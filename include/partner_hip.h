@@ -302,6 +302,10 @@ typedef struct pn_conv_desc {
                                    that does not fill the chip on its own but wastes less work (pn_conv2d_wino4_nhwc_f32:
                                    the plain F(4,3) form from ~96 tiles on instead of the K-split form).  Results differ
                                    from the unhinted launch only in the summation order of the form. */
+  int32_t transpose_hw;         /* chained F(4,3) entries only (pn_conv*_wino4*_chain*, r4): 1 = work on the TRANSPOSE of the stored map -- the
+                                   Winograd axis is the map's H axis (maps whose width / 4 is not a power of two but whose height / 4 is:
+                                   the Waymo BEV maps, 256 x 144).  in_h / in_w and the strides keep describing the stored NHWC map; the
+                                   packed weights must be those of the transposed kernel (w[.][.][kw][kh]). */
 } pn_conv_desc;
 
 size_t pn_conv_packed_weight_floats(int cout, int cin, int kh, int kw, int groups);
@@ -959,14 +963,15 @@ int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc *desc, const float *in, const fl
  *   V[p 6][cg C/8][h 2][b][y H+2][xq W/4][j 4]     (channel 8 cg + 4 h + j; rows y = 0 and y = H + 1 of every image are zero padding)
  * = the transformed quads in the MFMA fragment layout, and its epilogue writes the next layer's planes (output transform, scale / shift /
  * activation, input transform) and / or the NHWC map.  pn_wino4_planes_floats = size of such a buffer (0: shape not representable);
- * pn_wino4_planes_from_nhwc_f32 forms the planes of an NHWC channel slice (head of a chain); the writers also write the padding rows, so
+ * pn_wino4_planes_from_nhwc_f32 forms the planes of an NHWC channel slice (head of a chain; transpose_hw: of the transposed map, then pn_wino4_planes_floats
+ * takes (w, h)); the writers also write the padding rows, so
  * the buffers need no initialisation.  Weights: pn_pack_conv_weight_wino4_f32 unchanged.  pn_conv_wino4_chain_supported: 3x3 / stride 1 /
  * pad 1, cin and cout multiples of 32, activation none or ReLU, whole map rows per 32- or 64-quad tile (W / 4 divides 64).  planes_out or
  * out_nhwc may be NULL (not both); desc->out_* address out_nhwc, desc->in_pixel_stride / in_channel_offset are not used.  Results agree
  * with pn_conv2d_wino4_nhwc_f32 up to the summation order over K. */
 size_t pn_wino4_planes_floats(int batch, int h, int w, int c);
 int pn_wino4_planes_from_nhwc_f32(const float *in, int batch, int h, int w, int c, int in_pixel_stride, int in_channel_offset,
-                                  float *planes, pn_stream_t stream);
+                                  int transpose_hw, float *planes, pn_stream_t stream);
 int pn_conv_wino4_chain_supported(const pn_conv_desc *desc);
 int pn_conv2d_wino4_chain_f32(const pn_conv_desc *desc, const float *planes_in, const float *packed_w, const float *scale,
                               const float *shift, float *planes_out, float *out_nhwc, pn_stream_t stream);

@@ -45,7 +45,8 @@ struct WChainArgs {
   float* out;      // NHWC output (may be null)
   int B, H, W, Wq, Cin, Cout;
   int wq_log2;            // Wq is a power of two (it divides a 32- or 64-quad tile)
-  int out_ps, out_co;
+  int out_ps, out_co;      // out_ps here = floats between consecutive pixels ALONG the Winograd axis
+  long long out_img, out_row;      // floats between images / between rows of the (possibly transposed) frame
   int act;
   int total_quads;
   int qtiles, ctiles;     // block tiles: quads / columns
@@ -164,7 +165,7 @@ __device__ __forceinline__ void wchain_finish(const WChainArgs& a, int c0, int l
       }
     }
     if (a.out) {
-      float* o = a.out + ((size_t)(img * a.H + r) * a.W + 4 * xq) * a.out_ps + a.out_co + c0;
+      float* o = a.out + (size_t)img * a.out_img + (size_t)r * a.out_row + (size_t)(4 * xq) * a.out_ps + a.out_co + c0;
 #pragma unroll
       for (int px = 0; px < 4; ++px) *reinterpret_cast<f32x4*>(o + (size_t)px * a.out_ps) = y[b][px];
     }
@@ -461,14 +462,15 @@ __global__ void pack_wino24_weight_kernel(const float* __restrict__ w, int cout,
 // NHWC map -> the six planes (head of a chain).  One thread = one (quad, four channels): lanes along quads, so the plane stores are
 // whole 16-byte fragments in quad order.
 __global__ __launch_bounds__(256) void wchain_v_from_nhwc_kernel(const float* __restrict__ in, float* __restrict__ vout, int B, int H, int W, int Wq, int C,
-                                                                 int in_ps, int in_co, int total_quads, unsigned plane_floats) {
+                                                                 long long in_img, long long in_row, int in_ps, int in_co, int total_quads,
+                                                                 unsigned plane_floats) {
   const int c4n = C >> 2;
   for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < (long long)total_quads * c4n; it += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(it / total_quads);
     const int Q = (int)(it - (long long)c4 * total_quads);
     const int rowi = Q / Wq, xq = Q - rowi * Wq;
     const int img = rowi / H, r = rowi - img * H;
-    const float* px = in + ((size_t)(img * H + r) * W + 4 * xq) * in_ps + in_co + c4 * 4;
+    const float* px = in + (size_t)img * in_img + (size_t)r * in_row + (size_t)(4 * xq) * in_ps + in_co + c4 * 4;
     f32x4 d[6], v[6];
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     d[0] = xq > 0 ? *reinterpret_cast<const f32x4*>(px - in_ps) : z;
@@ -510,10 +512,16 @@ static int chain_grid_limit() {
 struct ChainForm { int na, nb, ks, ct; };
 
 // the form a layer takes: wave tile 32 NA columns x 32 NB quads, K split KS ways, CT column tiles per block (always 12 waves)
+// (h, w: the frame the kernel works in -- the stored map, or its transpose when desc->transpose_hw)
+static inline int frame_h(const pn_conv_desc* d) { return d->transpose_hw ? d->in_w : d->in_h; }
+static inline int frame_w(const pn_conv_desc* d) { return d->transpose_hw ? d->in_h : d->in_w; }
+
 static bool chain_form(const pn_conv_desc* d, ChainForm& f) {
-  if (d->in_w % 4) return false;
-  const int wq = d->in_w / 4;
-  const long long quads = (long long)d->batch * d->in_h * wq;
+  const int fh = frame_h(d), fw = frame_w(d);
+  if (fw % 4) return false;
+  const int wq = fw / 4;
+  if (wq & (wq - 1)) return false;
+  const long long quads = (long long)d->batch * fh * wq;
   static const int force = [] { const char* e = getenv("PN_WCHAIN_FORM"); return e ? atoi(e) : 0; }();
   // candidates, widest register tile first; a form fits when its block tile is whole rows and the grid covers the chip about once
   const ChainForm cands[] = {{2, 2, 1, 2}, {1, 2, 2, 1}, {1, 1, 2, 1}};
@@ -522,7 +530,7 @@ static bool chain_form(const pn_conv_desc* d, ChainForm& f) {
     ++idx;
     if (force && force != idx) continue;
     const int tq = 32 * c.nb, tc = 32 * c.na * c.ct;
-    if (tq % wq != 0 || quads % tq != 0 || d->cout % tc != 0 || (d->cin / 8) % c.ks != 0 || tq / wq > d->in_h) continue;
+    if (tq % wq != 0 || quads % tq != 0 || d->cout % tc != 0 || (d->cin / 8) % c.ks != 0 || tq / wq > fh) continue;
     const long long blocks = quads / tq * (d->cout / tc);
     if (!force && blocks < 192 && idx < 3) continue;      // a narrower form fills the chip better
     f = c;
@@ -547,13 +555,15 @@ struct Chain2Form { int ks, ct, qt; };
 
 // F(2,3) x F(4,3) form: octet tiles of 32 QT octets = whole row pairs; 12 waves per block
 static bool chain2_form(const pn_conv_desc* d, Chain2Form& f) {
-  if (d->in_w % 4 || d->in_h % 2) return false;
-  const int wq = d->in_w / 4;
-  const long long octs = (long long)d->batch * (d->in_h / 2) * wq;
+  const int fh = frame_h(d), fw = frame_w(d);
+  if (fw % 4 || fh % 2) return false;
+  const int wq = fw / 4;
+  if (wq & (wq - 1)) return false;
+  const long long octs = (long long)d->batch * (fh / 2) * wq;
   const Chain2Form cands[] = {{2, 1, 1}, {1, 1, 2}};
   for (const Chain2Form& c : cands) {
     const int tq = 32 * c.qt, tc = 32 * c.ct;
-    if (tq % wq != 0 || octs % tq != 0 || d->cout % tc != 0 || (d->cin / 8) % (2 * c.ks) != 0 || tq / wq > d->in_h / 2) continue;
+    if (tq % wq != 0 || octs % tq != 0 || d->cout % tc != 0 || (d->cin / 8) % (2 * c.ks) != 0 || tq / wq > fh / 2) continue;
     f = c;
     return true;
   }
@@ -586,15 +596,18 @@ int pn_conv_wino4_chain_supported(const pn_conv_desc* d) {
   if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->groups == 1 && !d->deconv2x2 && d->range_strata <= 1 &&
         !d->accumulate && d->pad_h_end == 0 && d->pad_w_end == 0))
     return 0;
-  if (d->batch < 1 || d->in_h < 1 || d->in_w < 4 || d->cin % 32 || d->cout % 32 || d->cin < 32) return 0;
+  if (d->batch < 1 || frame_h(d) < 1 || frame_w(d) < 4 || d->cin % 32 || d->cout % 32 || d->cin < 32) return 0;
   if (!(d->act == PN_ACT_NONE || d->act == PN_ACT_RELU)) return 0;
-  if ((unsigned long long)pn_wino4_planes_floats(d->batch, d->in_h, d->in_w, std::max(d->cin, d->cout)) * 4ull >= (1ull << 32)) return 0;
+  if ((unsigned long long)pn_wino4_planes_floats(d->batch, frame_h(d), frame_w(d), std::max(d->cin, d->cout)) * 4ull >= (1ull << 32)) return 0;
   ChainForm f;
   return chain_form(d, f) ? 1 : 0;
 }
 
-int pn_wino4_planes_from_nhwc_f32(const float* in, int batch, int h, int w, int c, int in_pixel_stride, int in_channel_offset, float* planes,
-                                  pn_stream_t stream) {
+int pn_wino4_planes_from_nhwc_f32(const float* in, int batch, int h, int w, int c, int in_pixel_stride, int in_channel_offset, int transpose_hw,
+                                  float* planes, pn_stream_t stream) {
+  // h, w: the STORED map; transposed, the planes are those of its transpose (w rows of h pixels: the Winograd axis is the map's H axis)
+  const int stored_w = w;
+  if (transpose_hw) std::swap(h, w);
   PN_REQUIRE(in && planes && pn_wino4_planes_floats(batch, h, w, c) > 0, "wino4_planes_from_nhwc: bad arguments");
   PN_REQUIRE(in_pixel_stride % 4 == 0 && in_channel_offset % 4 == 0 && in_pixel_stride >= in_channel_offset + c && ((uintptr_t)in & 15) == 0 &&
                  ((uintptr_t)planes & 15) == 0,
@@ -604,8 +617,11 @@ int pn_wino4_planes_from_nhwc_f32(const float* in, int batch, int h, int w, int 
   PN_REQUIRE(quads < (1ll << 30), "wino4_planes_from_nhwc: map too large");
   const unsigned plane_floats = (unsigned)((size_t)batch * (h + 2) * wq * 4);
   const long long items = quads * (c / 4);
+  const long long in_img = (long long)h * w * in_pixel_stride;
+  const long long in_row = transpose_hw ? in_pixel_stride : (long long)stored_w * in_pixel_stride;
+  const int in_px = transpose_hw ? stored_w * in_pixel_stride : in_pixel_stride;
   hipLaunchKernelGGL(wchain_v_from_nhwc_kernel, dim3((unsigned)std::min<long long>(8192, (items + 255) / 256)), dim3(256), 0, pn::S(stream), in, planes, batch, h,
-                     w, wq, c, in_pixel_stride, in_channel_offset, (int)quads, plane_floats);
+                     w, wq, c, in_img, in_row, in_px, in_channel_offset, (int)quads, plane_floats);
   return pn::check_launch("wchain_v_from_nhwc_kernel");
 }
 
@@ -618,23 +634,27 @@ int pn_conv2d_wino4_chain_f32(const pn_conv_desc* d, const float* planes_in, con
                  ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
              "conv_wino4_chain: pointers must be 16-byte aligned");
   if (out_nhwc)
-    PN_REQUIRE(d->out_pixel_stride >= d->out_channel_offset + d->cout && d->out_pixel_stride % 4 == 0 && d->out_channel_offset % 4 == 0,
+    PN_REQUIRE(d->out_pixel_stride >= d->out_channel_offset + d->cout && d->out_pixel_stride % 4 == 0 && d->out_channel_offset % 4 == 0 &&
+                   (unsigned long long)d->batch * d->in_h * d->in_w * d->out_pixel_stride < (1ull << 40),
                "conv_wino4_chain: output channel slice must fit the pixel stride, in multiples of 4 floats");
   ChainForm f;
   chain_form(d, f);
   WChainArgs a{};
   a.vin = planes_in; a.w = packed_w; a.scale = scale; a.shift = shift; a.vout = planes_out; a.out = out_nhwc;
-  a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Wq = d->in_w / 4; a.Cin = d->cin; a.Cout = d->cout;
-  a.out_ps = d->out_pixel_stride; a.out_co = d->out_channel_offset;
+  a.B = d->batch; a.H = frame_h(d); a.W = frame_w(d); a.Wq = a.W / 4; a.Cin = d->cin; a.Cout = d->cout;
+  a.out_co = d->out_channel_offset;
+  a.out_img = (long long)d->in_h * d->in_w * d->out_pixel_stride;
+  a.out_ps = d->transpose_hw ? d->in_w * d->out_pixel_stride : d->out_pixel_stride;
+  a.out_row = d->transpose_hw ? d->out_pixel_stride : (long long)d->in_w * d->out_pixel_stride;
   a.wq_log2 = __builtin_ctz((unsigned)a.Wq);
   a.act = d->act;
-  a.total_quads = d->batch * d->in_h * a.Wq;
+  a.total_quads = d->batch * a.H * a.Wq;
   a.qtiles = a.total_quads / (32 * f.nb);
   a.ctiles = d->cout / (32 * f.na * f.ct);
   a.cg_in = d->cin / 8; a.cg_out = d->cout / 8;
   a.cout_pad = pn::cdiv(d->cout, 128) * 128;
-  a.plane_bytes = (unsigned)((size_t)d->batch * (d->in_h + 2) * a.Wq * 16);
-  a.vin_bytes = (unsigned)(pn_wino4_planes_floats(d->batch, d->in_h, d->in_w, d->cin) * 4);
+  a.plane_bytes = (unsigned)((size_t)d->batch * (a.H + 2) * a.Wq * 16);
+  a.vin_bytes = (unsigned)(pn_wino4_planes_floats(d->batch, a.H, a.W, d->cin) * 4);
   a.w_bytes = (unsigned)(pn_conv_wino4_packed_weight_floats(d->cout, d->cin) * 4);
 #ifdef PN_WCHAIN_STAMP
   a.stamps = pn_wchain_stamp_buffer;
@@ -681,17 +701,20 @@ int pn_conv2d_wino24_chain_f32(const pn_conv_desc* d, const float* planes_in, co
   chain2_form(d, f);
   WChainArgs a{};
   a.vin = planes_in; a.w = packed_w24; a.scale = scale; a.shift = shift; a.vout = planes_out; a.out = out_nhwc;
-  a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Wq = d->in_w / 4; a.Cin = d->cin; a.Cout = d->cout;
-  a.out_ps = d->out_pixel_stride; a.out_co = d->out_channel_offset;
+  a.B = d->batch; a.H = frame_h(d); a.W = frame_w(d); a.Wq = a.W / 4; a.Cin = d->cin; a.Cout = d->cout;
+  a.out_co = d->out_channel_offset;
+  a.out_img = (long long)d->in_h * d->in_w * d->out_pixel_stride;
+  a.out_ps = d->transpose_hw ? d->in_w * d->out_pixel_stride : d->out_pixel_stride;
+  a.out_row = d->transpose_hw ? d->out_pixel_stride : (long long)d->in_w * d->out_pixel_stride;
   a.wq_log2 = __builtin_ctz((unsigned)a.Wq);
   a.act = d->act;
-  a.total_quads = d->batch * d->in_h * a.Wq;
+  a.total_quads = d->batch * a.H * a.Wq;
   a.qtiles = (a.total_quads / 2) / (32 * f.qt);
   a.ctiles = d->cout / (32 * f.ct);
   a.cg_in = d->cin / 8; a.cg_out = d->cout / 8;
   a.cout_pad = pn::cdiv(d->cout, 128) * 128;
-  a.plane_bytes = (unsigned)((size_t)d->batch * (d->in_h + 2) * a.Wq * 16);
-  a.vin_bytes = (unsigned)(pn_wino4_planes_floats(d->batch, d->in_h, d->in_w, d->cin) * 4);
+  a.plane_bytes = (unsigned)((size_t)d->batch * (a.H + 2) * a.Wq * 16);
+  a.vin_bytes = (unsigned)(pn_wino4_planes_floats(d->batch, a.H, a.W, d->cin) * 4);
   a.w_bytes = (unsigned)(pn_conv_wino24_packed_weight_floats(d->cout, d->cin) * 4);
 #ifdef PN_WCHAIN_STAMP
   a.stamps = pn_wchain_stamp_buffer;

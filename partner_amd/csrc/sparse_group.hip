@@ -86,21 +86,158 @@ struct SpwArgs {
   float* out;
   int cap, taps, cin, cout;
   int cin_chunks, cout_pad;
-  unsigned in_bytes, w_bytes;
+  unsigned in_bytes, w_bytes, out_bytes;
   int act;
+  int wide4_groups, wide2_groups;      // a wave takes 4 / at least 2 column tiles from this many live groups on
 };
 
 // wave = one group of 32 sites x 32 NC columns (blockIdx.y walks further column groups).  packed weights: pn_pack_conv_weight_f32's layout
 // with (kh, kw) = (taps, 1): [tap][chunk][k4 8][cout_pad][4]
-template <int NC>
-__global__ __launch_bounds__(256) void sparse_conv_wave_kernel(SpwArgs a) {
-  __shared__ int32_t s_src[4][32 * 28];      // per wave: [tap][site] neighbour rows of the group, then the group's own rows (slot 27)
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+// Input rows reach the MFMA operands through a wave-private LDS image in WHOLE 128-byte lines: a chunk (32 channels of the 32 neighbour
+// rows of one tap) is fetched by four loads of 8 rows x 128 bytes, written row-major (row stride CH + 4 floats) and read back as the four
+// K steps' fragments.  (The first version had lane (site, half) fetch its own 16 bytes per K step: 32 different lines per load, each
+// touched again by the next three steps -- with 16 waves per CU those lines no longer sit in the 32 KB L1, and the 64 -> 64 layers ran at
+// 0.47 of the MFMA peak on 4x the L2 traffic.)  The LDS executes a wave's accesses in order, so the image needs no barrier and no
+// second buffer: a chunk's four fragment reads are issued before the next chunk's stores.
+template <int NC, int CH>
+__device__ __forceinline__ void sparse_conv_wave_body(const SpwArgs& a, int32_t* src, float* stage, int g, int n0, int lane) {
+  constexpr int LPR = CH / 4;          // lanes per row of a staging load
+  constexpr int RPI = 64 / LPR;        // rows per staging load
+  constexpr int NI = 32 / RPI;         // staging loads per chunk
+  constexpr int SPC = CH / 8;          // K steps (8 channels) per chunk
+  constexpr int LD = CH + 4;           // floats per row of the image (rows 16 bytes apart modulo the bank row: conflict-free b128 accesses)
   const int li = lane & 31, lh = lane >> 5;
+  const unsigned gm = a.gmask[g];
+  const int prow = g * 32 + li < a.cap ? a.perm[g * 32 + li] : -1;
+  for (int t = lh; t < a.taps; t += 2) src[t * 32 + li] = prow >= 0 ? a.nbr[(size_t)prow * a.taps + t] : -1;
+  if (lh == 0) src[27 * 32 + li] = prow;
+  const int srow = lane / LPR, scol = (lane % LPR) * 4;      // staging role: rows srow + RPI q, 16 bytes at float scol of the chunk
+  unsigned uoff[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) uoff[c] = (unsigned)(((size_t)lh * a.cout_pad + n0 + 32 * c + li) * 16);
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const unsigned cp16 = (unsigned)a.cout_pad * 16u;
+  const unsigned row_bytes = (unsigned)a.cin * 4u;
+  const int nch = a.cin / CH;          // chunks per tap
+  const int CG = a.cin >> 3;           // K steps per tap
+
+  f32x16 acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  // two request pointers walk the same sequence (taps of the group's mask ascending, channels ascending): the input rows one CHUNK ahead
+  // of the MFMAs, the weight fragments two K STEPS ahead
+  unsigned am = gm;
+  int at = 0, ach = nch;
+  unsigned avo[NI];
+  f32x4 ra[NI];
+  auto request_a = [&]() __attribute__((always_inline)) {
+    if (ach == nch) {
+      ach = 0;
+      if (am) {
+        at = __builtin_ctz(am);
+        am &= am - 1u;
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+          const int sidx = src[at * 32 + srow + RPI * q];      // (written by this wave: the LDS executes a wave's accesses in order)
+          avo[q] = sidx >= 0 ? (unsigned)sidx * row_bytes + (unsigned)scol * 4u : 0xffffffffu;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NI; ++q) avo[q] = 0xffffffffu;      // past the last chunk: zeros that nobody multiplies
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NI; ++q) ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, avo[q], (unsigned)ach * (CH * 4u), 0));
+    ++ach;
+  };
+  unsigned bm = gm;
+  int bt = 0, bcg = CG;
+  f32x4 fb[2][NC];
+  auto request_b = [&](int slot) __attribute__((always_inline)) {
+    if (bcg == CG) {
+      bcg = 0;
+      if (bm) {
+        bt = __builtin_ctz(bm);
+        bm &= bm - 1u;
+      }
+    }
+    const unsigned so_w = (unsigned)(((bt * a.cin_chunks + (bcg >> 2)) * 8 + (bcg & 3) * 2)) * cp16;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) fb[slot][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, uoff[c], so_w, 0));
+    ++bcg;
+  };
+  const int nunits = __builtin_popcount(gm) * nch;
+  request_a();
+  request_b(0);
+  request_b(1);
+  for (int u = 0; u < nunits; ++u) {
+#pragma unroll
+    for (int q = 0; q < NI; ++q) *reinterpret_cast<f32x4*>(stage + (srow + RPI * q) * LD + scol) = ra[q];
+    request_a();
+    f32x4 fa[SPC];
+#pragma unroll
+    for (int k = 0; k < SPC; ++k) fa[k] = *reinterpret_cast<const f32x4*>(stage + li * LD + (2 * k + lh) * 4);
+#pragma unroll
+    for (int k = 0; k < SPC; ++k) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k][j], fb[k & 1][c][j], acc[c], 0, 0, 0);
+      request_b(k & 1);
+    }
+  }
+
+  // ---- epilogue: rows back to their own places.  No branches: dead rows / columns are redirected out of the descriptors' range
+  // (loads return 0, stores are dropped), the residuals of a column tile are all requested before the first store
+  const bool relu = a.act == PN_ACT_RELU;
+  const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res), 0, a.res ? a.out_bytes : 0u, 0x00020000);
+  unsigned ro[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int orow = src[27 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+    ro[r] = orow >= 0 ? (unsigned)orow * (unsigned)a.cout * 4u : 0xffffffffu;
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = n0 + 32 * c + li;
+    const bool cok = col < a.cout;
+    const float sc = (cok && a.scale) ? a.scale[col] : 1.f;
+    const float sh = (cok && a.shift) ? a.shift[col] : 0.f;
+    float rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, (cok && ro[r] != 0xffffffffu) ? ro[r] + (unsigned)col * 4u : 0xffffffffu, 0, 0));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = fmaf(acc[c][r], sc, sh) + rv[r];
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu ? fmaxf(v, 0.f) : v), rsrc_o,
+                                            (cok && ro[r] != 0xffffffffu) ? ro[r] + (unsigned)col * 4u : 0xffffffffu, 0, 0);
+    }
+  }
+}
+
+// grid.y = the layer's 32-column tiles; how many of them a wave takes (NC) is decided here from the LIVE site count, which only the device
+// knows: few groups (the 128-channel level: 24k sites = 750 groups for 1024 SIMDs) -> narrow waves, so that every SIMD has two or three
+template <int NCMAX>
+__global__ __launch_bounds__(256, 3) void sparse_conv_wave_kernel(SpwArgs a) {
+  __shared__ int32_t s_src[4][32 * 28];      // per wave: [tap][site] neighbour rows of the group, then the group's own rows (slot 27)
+  __shared__ __attribute__((aligned(16))) float s_stage[4][32 * 36];      // per wave: the current chunk of the 32 gathered rows
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = min(*a.n_valid, a.cap);
+  const int groups = (n + 31) / 32;
+  int nc = NCMAX;
+  if (NCMAX >= 4 && groups < a.wide4_groups) nc = 2;
+  if (NCMAX >= 2 && groups < a.wide2_groups) nc = 1;
+  if (NCMAX >= 4 && (a.cin % 32) && nc == 4) nc = 2;      // (the 16-channel-input bodies exist for one and two column tiles)
+  if ((int)blockIdx.y * nc >= NCMAX) return;
   // live groups: windows are sorted with their dead slots last, so the groups below ceil(n / 32) are exactly the ones with a live site;
   // blocks of 4 groups are dealt over the XCDs in contiguous runs (neighbouring groups gather neighbouring rows: one L2)
-  const int nblk = ((n + 31) / 32 + 3) / 4;
+  const int nblk = (groups + 3) / 4;
   int mb;
   {
     const int q = nblk >> 3, r = nblk & 7, x = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -109,11 +246,59 @@ __global__ __launch_bounds__(256) void sparse_conv_wave_kernel(SpwArgs a) {
   }
   const int g = mb * 4 + wv;
   if (g * 32 >= n) return;      // (wave-uniform; no block barrier anywhere below)
+  const int n0 = blockIdx.y * 32 * nc;
+  if (a.cin % 32) {      // 16 input channels (the first strided stage): 64-byte rows, chunks of 16 channels
+    if (NCMAX >= 2 && nc == 2) sparse_conv_wave_body<2, 16>(a, s_src[wv], s_stage[wv], g, n0, lane);
+    else sparse_conv_wave_body<1, 16>(a, s_src[wv], s_stage[wv], g, n0, lane);
+    return;
+  }
+  if (NCMAX >= 4 && nc == 4) sparse_conv_wave_body<4, 32>(a, s_src[wv], s_stage[wv], g, n0, lane);
+  else if (NCMAX >= 2 && nc == 2) sparse_conv_wave_body<2, 32>(a, s_src[wv], s_stage[wv], g, n0, lane);
+  else sparse_conv_wave_body<1, 32>(a, s_src[wv], s_stage[wv], g, n0, lane);
+}
+
+// ---- block = ONE group, its (tap, 32-channel chunk) units split over the block's four waves (K split), every wave with all
+// NC column tiles; the four partial tiles are summed in a fixed order through LDS, wave w finishing a quarter.  For the 64- and
+// 128-channel levels: a group is 20-80 us of MFMA work there, and with one WAVE per group the 1800-5800 waves of a level left the SIMDs
+// with one or two waves each, unevenly (0.55 of the MFMA peak); blocks of a quarter of that work each, handed out as CUs free up, level it.
+// A wave's share must not depend on WHICH sites share its group (the same site lands in other groups when the batch changes, and its sum
+// must stay bit for bit the same: key-point selections downstream amplify last-bit differences): wave w takes channel chunk w & (nch - 1)
+// of the taps whose NUMBER falls in its class -- every tap for four chunks (128 channels), t & 1 == w >> 1 for two (64 channels).  A site's
+// four partial sums are then sums over its own neighbours in ascending tap order (absent ones add exact zeros), joined as ((0 + 1) + 2) + 3.
+struct UnitCursor {
+  unsigned m;            // this wave's taps after the current one
+  int t;                 // current tap
+  bool live;
+  __device__ __forceinline__ void start(unsigned own) { m = own; live = true; t = 0; next(); }
+  __device__ __forceinline__ void next() {
+    if (m) { t = __builtin_ctz(m); m &= m - 1u; } else live = false;
+  }
+};
+
+template <int NC>
+__global__ __launch_bounds__(256, 2) void sparse_conv_group4_kernel(SpwArgs a) {
+  constexpr int LD = 36;
+  __shared__ int32_t s_src[32 * 28];
+  __shared__ __attribute__((aligned(16))) float s_buf[4 * 32 * 32 * NC];      // the waves' chunk images (4 x 32 x 36 floats) / afterwards the four partial tiles
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int n = min(*a.n_valid, a.cap);
+  const int groups = (n + 31) / 32;
+  int g;
+  {
+    const int q = groups >> 3, r = groups & 7, x = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    if (idx >= (x < r ? q + 1 : q)) return;
+    g = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+  }
   const unsigned gm = a.gmask[g];
-  const int prow = g * 32 + li < a.cap ? a.perm[g * 32 + li] : -1;
-  int32_t* src = s_src[wv];
-  for (int t = lh; t < a.taps; t += 2) src[t * 32 + li] = prow >= 0 ? a.nbr[(size_t)prow * a.taps + t] : -1;
-  if (lh == 0) src[27 * 32 + li] = prow;
+  {
+    const int i = tid & 31, prow = g * 32 + i < a.cap ? a.perm[g * 32 + i] : -1;
+    for (int t = tid >> 5; t < a.taps; t += 8) s_src[t * 32 + i] = prow >= 0 ? a.nbr[(size_t)prow * a.taps + t] : -1;
+    if (tid < 32) s_src[27 * 32 + i] = prow;
+  }
+  __syncthreads();
+  float* stage = s_buf + wv * (32 * LD);
+  const int srow = lane >> 3, scol = (lane & 7) * 4;
   const int n0 = blockIdx.y * 32 * NC;
   unsigned uoff[NC];
 #pragma unroll
@@ -122,7 +307,10 @@ __global__ __launch_bounds__(256) void sparse_conv_wave_kernel(SpwArgs a) {
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
   const unsigned cp16 = (unsigned)a.cout_pad * 16u;
   const unsigned row_bytes = (unsigned)a.cin * 4u;
-  const int CG = a.cin >> 3;      // K steps (8 channels) per tap: even (cin a multiple of 16)
+  const int nch = a.cin >> 5;                                    // 4 or 2 chunks of 32 channels
+  const int ch = wv & (nch - 1);
+  const unsigned own = nch == 4 ? gm : gm & (0x55555555u << (wv >> 1));
+  const int mine = __builtin_popcount(own);                      // units of this wave: (its taps) x (its chunk)
 
   f32x16 acc[NC];
 #pragma unroll
@@ -130,51 +318,56 @@ __global__ __launch_bounds__(256) void sparse_conv_wave_kernel(SpwArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-  // the step sequence = (tap in the group's mask, ascending) x (8-channel group); the loads run two steps ahead of the MFMAs
-  unsigned pm = gm;            // taps not yet requested
-  int pt = 0, pcg = CG;        // the step requested next (pcg == CG: take the next tap first)
-  unsigned pvo = 0xffffffffu;
-  f32x4 fa[2], fb[2][NC];
-  auto request = [&](int slot) __attribute__((always_inline)) {
-    if (pcg == CG) {
-      if (pm) {
-        pt = __builtin_ctz(pm);
-        pm &= pm - 1u;
-        pcg = 0;
-        const int s = src[pt * 32 + li];      // (written by this wave: the LDS executes a wave's accesses in order)
-        pvo = s >= 0 ? (unsigned)s * row_bytes + (unsigned)lh * 16u : 0xffffffffu;
-      } else {
-        pvo = 0xffffffffu;      // past the last step: the loads return zeros and nobody multiplies them
-        pcg = 0;
-      }
+  UnitCursor ca, cb;
+  ca.start(own);
+  cb.start(own);
+  int bk = 0;      // K step inside cb's unit
+  f32x4 ra[4], fb[2][NC];
+  auto request_a = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int sidx = ca.live ? s_src[ca.t * 32 + srow + 8 * q] : -1;
+      const unsigned vo = sidx >= 0 ? (unsigned)sidx * row_bytes + (unsigned)scol * 4u : 0xffffffffu;
+      ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, (unsigned)ch * 128u, 0));
     }
-    const unsigned so_a = (unsigned)pcg * 32u;
-    const unsigned so_w = (unsigned)(((pt * a.cin_chunks + (pcg >> 2)) * 8 + (pcg & 3) * 2)) * cp16;
-    fa[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, pvo, so_a, 0));
-#pragma unroll
-    for (int c = 0; c < NC; ++c) fb[slot][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, uoff[c], so_w, 0));
-    ++pcg;
+    ca.next();
   };
-  const int nsteps = __builtin_popcount(gm) * CG;
-  request(0);
-  __builtin_amdgcn_sched_barrier(0);
-  request(1);
-  __builtin_amdgcn_sched_barrier(0);
-  for (int s = 0; s < nsteps; s += 2) {
+  auto request_b = [&](int slot) __attribute__((always_inline)) {
+    const int bcg = ch * 4 + bk;
+    const unsigned so_w = (unsigned)(((cb.t * a.cin_chunks + (bcg >> 2)) * 8 + (bcg & 3) * 2)) * cp16;
 #pragma unroll
-    for (int slot = 0; slot < 2; ++slot) {
+    for (int c = 0; c < NC; ++c) fb[slot][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, cb.live ? uoff[c] : 0xffffffffu, so_w, 0));
+    if (++bk == 4) { bk = 0; cb.next(); }
+  };
+  request_a();
+  request_b(0);
+  request_b(1);
+  for (int u = 0; u < mine; ++u) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(stage + (srow + 8 * q) * LD + scol) = ra[q];
+    request_a();
+    f32x4 fa[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fa[k] = *reinterpret_cast<const f32x4*>(stage + li * LD + (2 * k + lh) * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][j], fb[slot][c][j], acc[c], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      request(slot);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k][j], fb[k & 1][c][j], acc[c], 0, 0, 0);
+      request_b(k & 1);
     }
   }
-
-  // ---- epilogue: rows back to their own places
+  // ---- join: [wave][c][r][lane] partial tiles, summed wave 0 + 1 + 2 + 3; wave w finishes registers 4 w .. 4 w + 3 (rows 8 w' .. ) of every tile
+  __syncthreads();      // every wave is done with its chunk image
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_buf[((wv * NC + c) * 16 + r) * 64 + lane] = acc[c][r];
+  __syncthreads();
   const bool relu = a.act == PN_ACT_RELU;
+  const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res), 0, a.res ? a.out_bytes : 0u, 0x00020000);
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int col = n0 + 32 * c + li;
@@ -182,12 +375,15 @@ __global__ __launch_bounds__(256) void sparse_conv_wave_kernel(SpwArgs a) {
     const float sc = (cok && a.scale) ? a.scale[col] : 1.f;
     const float sh = (cok && a.shift) ? a.shift[col] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int orow = src[27 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
-      if (orow < 0 || !cok) continue;
-      float v = fmaf(acc[c][r], sc, sh);
-      if (a.res) v += a.res[(size_t)orow * a.cout + col];
-      a.out[(size_t)orow * a.cout + col] = relu ? fmaxf(v, 0.f) : v;
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = 4 * wv + rr;
+      const int orow = s_src[27 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+      const unsigned off = (cok && orow >= 0) ? ((unsigned)orow * (unsigned)a.cout + (unsigned)col) * 4u : 0xffffffffu;
+      const float rv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, off, 0, 0));
+      float v = ((s_buf[((0 * NC + c) * 16 + r) * 64 + lane] + s_buf[((1 * NC + c) * 16 + r) * 64 + lane]) + s_buf[((2 * NC + c) * 16 + r) * 64 + lane]) +
+                s_buf[((3 * NC + c) * 16 + r) * 64 + lane];
+      v = fmaf(v, sc, sh) + rv;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu ? fmaxf(v, 0.f) : v), rsrc_o, off, 0, 0);
     }
   }
 }
@@ -209,7 +405,8 @@ int pn_sparse_conv_grouped_f32(const float* in, int in_rows, int cin, const int3
   PN_REQUIRE(in && nbr && n_out && perm && group_mask && packed_w && out, "sparse_conv_grouped: null pointer");
   PN_REQUIRE(in_rows >= 1 && cin >= 16 && cin % 16 == 0 && cout >= 1 && out_capacity >= 1 && taps >= 1 && taps <= 27, "sparse_conv_grouped: cin must be a "
                                                                                                                      "multiple of 16, taps <= 27");
-  PN_REQUIRE((unsigned long long)in_rows * cin * 4ull < (1ull << 32), "sparse_conv_grouped: input feature matrix too large for the buffer descriptor");
+  PN_REQUIRE((unsigned long long)in_rows * cin * 4ull < (1ull << 32) && (unsigned long long)out_capacity * cout * 4ull < (1ull << 32),
+             "sparse_conv_grouped: feature matrix too large for the buffer descriptor");
   PN_REQUIRE(act == PN_ACT_NONE || act == PN_ACT_RELU, "sparse_conv_grouped: activation none or ReLU");
   PN_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "sparse_conv_grouped: pointers must be 16-byte aligned");
   SpwArgs a{};
@@ -218,20 +415,37 @@ int pn_sparse_conv_grouped_f32(const float* in, int in_rows, int cin, const int3
   a.cin_chunks = pn::cdiv(cin, 32); a.cout_pad = pn::cdiv(cout, 32) * 32;
   a.in_bytes = (unsigned)((size_t)in_rows * cin * 4);
   a.w_bytes = (unsigned)((size_t)taps * a.cin_chunks * 8 * a.cout_pad * 16);
+  a.out_bytes = (unsigned)((size_t)out_capacity * cout * 4);
   a.act = act;
+  static const int t4 = [] { const char* e = getenv("PN_SPARSE_WIDE4"); return e ? atoi(e) : 1536; }();
+  static const int t2 = [] { const char* e = getenv("PN_SPARSE_WIDE2"); return e ? atoi(e) : 512; }();
+  a.wide4_groups = t4; a.wide2_groups = t2;
   hipStream_t st = pn::S(stream);
   const int blocks = (pn::cdiv(pn::cdiv(out_capacity, 32), 4) + 7) / 8 * 8;
   pn::ProfileSlot ps{};
   const bool prof = pn::take_profile_slot(ps);
   const int ncol32 = a.cout_pad / 32;
-  auto launch = [&](auto kern, int nc) {
-    const dim3 grid((unsigned)blocks, (unsigned)pn::cdiv(ncol32, nc));
+  PN_REQUIRE(ncol32 == 1 || ncol32 == 2 || ncol32 == 4, "sparse_conv_grouped: 32, 64 or 128 output channels");
+  auto launch = [&](auto kern) {
+    const dim3 grid((unsigned)blocks, (unsigned)ncol32);
     if (prof) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, st, ps.start, ps.stop, 0, a);
     else hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a);
   };
-  if (ncol32 >= 4) launch(&sparse_conv_wave_kernel<4>, 4);
-  else if (ncol32 >= 2) launch(&sparse_conv_wave_kernel<2>, 2);
-  else launch(&sparse_conv_wave_kernel<1>, 1);
+  static const int g4 = [] { const char* e = getenv("PN_SPARSE_GROUP4"); return e ? atoi(e) : 1; }();
+  if (g4 && cin % 32 == 0 && cin >= 64 && ncol32 >= 2) {      // block per group, K split over its waves
+    const dim3 grid((unsigned)((pn::cdiv(out_capacity, 32) + 7) / 8 * 8), 1);
+    if (ncol32 == 4) {
+      if (prof) hipExtLaunchKernelGGL(sparse_conv_group4_kernel<4>, grid, dim3(256), 0, st, ps.start, ps.stop, 0, a);
+      else hipLaunchKernelGGL(sparse_conv_group4_kernel<4>, grid, dim3(256), 0, st, a);
+    } else {
+      if (prof) hipExtLaunchKernelGGL(sparse_conv_group4_kernel<2>, grid, dim3(256), 0, st, ps.start, ps.stop, 0, a);
+      else hipLaunchKernelGGL(sparse_conv_group4_kernel<2>, grid, dim3(256), 0, st, a);
+    }
+    return pn::check_launch("sparse_conv_group4_kernel");
+  }
+  if (ncol32 == 4) launch(&sparse_conv_wave_kernel<4>);
+  else if (ncol32 == 2) launch(&sparse_conv_wave_kernel<2>);
+  else launch(&sparse_conv_wave_kernel<1>);
   return pn::check_launch("sparse_conv_wave_kernel");
 }
 

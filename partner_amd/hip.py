@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "batch", "in_h", "in_w", "cin", "cout", "groups", "kh", "kw", "stride", "pad_h", "pad_w",
         "in_pixel_stride", "in_channel_offset", "out_pixel_stride", "out_channel_offset", "act", "deconv2x2",
-        "range_strata", "pad_h_end", "pad_w_end", "accumulate", "frames_in_flight")]
+        "range_strata", "pad_h_end", "pad_w_end", "accumulate", "frames_in_flight", "transpose_hw")]
 
 
 class RowPiece(C.Structure):
@@ -193,7 +193,7 @@ SIGNATURES = {
     "pn_conv_wino4_tiles": (_I, [_P]),
     "pn_conv2d_wino4_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "pn_wino4_planes_floats": (_SZ, [_I, _I, _I, _I]),
-    "pn_wino4_planes_from_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "pn_wino4_planes_from_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "pn_conv_wino4_chain_supported": (_I, [_P]),
     "pn_conv2d_wino4_chain_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "pn_conv_wino24_packed_weight_floats": (_SZ, [_I, _I]),

@@ -134,8 +134,9 @@ class RPN(nn.Module):
                 p0 = plan.get("pillar0") if (i == 0 and k == 0 and pillars is not None and dtype == "f32") else None
                 if p0 is not None and p0.worth_it(pillars, x.shape[0], x.shape[1], x.shape[2]):
                     x = p0(x, pillars)
-                elif k == 1 and dtype == "f32" and ops.conv_chain_supported(layers[1:], x.shape[0], x.shape[1], x.shape[2]):
-                    x = ops.conv_chain(layers[1:], x)     # the block's same-shape layers stay in the F(4, 3) domain (conv_wchain.hip)
+                elif k <= 1 and dtype == "f32" and layer.stride == 1 and ops.conv_chain_supported(layers[k:], x.shape[0], x.shape[1], x.shape[2]):
+                    # the block's same-shape layers stay in the F(4, 3) domain (conv_wchain.hip); a stride-1 first layer (Waymo block 0) joins them
+                    x = ops.conv_chain(layers[k:], x)
                     break
                 else:
                     x = layer(x)

@@ -465,9 +465,12 @@ class ConvLayer:
             hip.call("pn_pack_conv_weight_wino4_f32", w.data_ptr(), self.cout, self.cin, self.wino4_packed.data_ptr(), st)
         # ... and the F(2, 3) x F(4, 3) weights of the chained form (conv_wchain.hip, ops.conv_chain: 3 MFMA equivalents per output)
         self.wino24_packed = None
+        self._w_ref = None               # the layer's weight, for the packs of the TRANSPOSED kernel a chain on a transposed map takes (lazy)
+        self._chain_t: dict = {}
         if self.wino4_packed is not None and _CHAIN2D_ON and self.cin % 32 == 0:
             self.wino24_packed = _f32(lib.pn_conv_wino24_packed_weight_floats(self.cout, self.cin), dev)
             hip.call("pn_pack_conv_weight_wino24_f32", w.data_ptr(), self.cout, self.cin, self.wino24_packed.data_ptr(), st)
+            self._w_ref = w
 
         # ... and 3x3 layers with one to three output channels over many input channels (the geometry-aware head's 256 -> 1 heat-map and
         # vote-class convolutions): a GEMM over the pixels against the (9 cout, cin) tap matrix + a nine-term shifted sum
@@ -478,6 +481,29 @@ class ConvLayer:
             self.tap_n = (9 * self.cout + 3) // 4 * 4
             self.tap_packed = _f32(lib.pn_linear_packed_weight_floats(self.tap_n, self.cin), dev)
             self._pack_taps(w)
+
+    def chain_weights(self, two_d: bool, transposed: bool) -> torch.Tensor:
+        """packed weights of the chained F(4,3) / F(2,3)xF(4,3) forms; ``transposed``: of the kernel with kh and kw swapped (the chain then runs
+        on the transposed map), packed on first use"""
+        if not transposed:
+            self._ensure("wino24" if two_d else "wino4")
+            return self.wino24_packed if two_d else self.wino4_packed
+        stale = getattr(self, "_stale", None) or ()
+        key = "wino24" if two_d else "wino4"
+        if key not in self._chain_t or (key + "_t") in stale:
+            lib, w = hip.load(), getattr(self, "_stale_w", None)
+            w = self._w_ref if w is None else w
+            wt = w.detach().float().transpose(2, 3).contiguous()
+            fam = "wino24" if two_d else "wino4"
+            buf = self._chain_t.get(key)
+            if buf is None:
+                buf = _f32(getattr(lib, f"pn_conv_{fam}_packed_weight_floats")(self.cout, self._pack_cin), w.device)
+            hip.call(f"pn_pack_conv_weight_{fam}_f32", wt.data_ptr(), self.cout, self._pack_cin, buf.data_ptr(), hip.stream())
+            self._chain_t[key] = buf
+            self._chain_t_src = wt        # (the launch is asynchronous: the transposed copy stays referenced)
+            if stale:
+                stale.discard(key + "_t")
+        return self._chain_t[key]
 
     def _pack_taps(self, w: torch.Tensor) -> None:
         w9 = torch.zeros((self.tap_n, self.cin), dtype=torch.float32, device=w.device)
@@ -497,6 +523,8 @@ class ConvLayer:
             self._stale.add("tap")
         if getattr(self, "wino24_packed", None) is not None:
             self._stale.add("wino24")
+        for k in getattr(self, "_chain_t", {}):
+            self._stale.add(k + "_t")
         if shift is not None:
             self.shift = shift
 
@@ -620,23 +648,33 @@ class ConvLayer:
 _CHAIN_ON = os.environ.get("PN_CONV_CHAIN", "1") != "0"
 
 
-def _chain_desc(layer: "ConvLayer", b: int, h: int, w: int, out_ps: int = 0, out_co: int = 0):
+def _chain_desc(layer: "ConvLayer", b: int, h: int, w: int, out_ps: int = 0, out_co: int = 0, transposed: bool = False):
     d = ConvDesc(b, h, w, layer.cin, layer.cout, 1, 3, 3, 1, 1, 1, layer.cin, 0, out_ps or layer.cout, out_co, layer.act, 0, 0, 0, 0, 0)
     d.frames_in_flight = _FRAMES_IN_FLIGHT
+    d.transpose_hw = int(transposed)
     return d
+
+
+def _chain_orientation(layers, b: int, h: int, w: int):
+    """None, or whether the chain works on the transposed map (False: the Winograd axis is W; True: it is H -- maps like the Waymo BEV's
+    256 x 144, whose W / 4 = 36 is not a power of two)"""
+    if not _CHAIN_ON or not layers:
+        return None
+    lib = hip.load()
+    for k, l in enumerate(layers):
+        if l.dtype != "f32" or l.wino4_packed is None or l.cin != l._pack_cin or (k and l.cin != layers[k - 1].cout):
+            return None
+    for transposed in (False, True):
+        if transposed and any(getattr(l, "_w_ref", None) is None for l in layers):
+            break
+        if all(lib.pn_conv_wino4_chain_supported(C.byref(_chain_desc(l, b, h, w, transposed=transposed))) for l in layers):
+            return transposed
+    return None
 
 
 def conv_chain_supported(layers, b: int, h: int, w: int) -> bool:
     """can ``layers`` (consecutive ConvLayers, each feeding the next) run as one Winograd-domain chain on a (b, h, w) map?"""
-    if not _CHAIN_ON or not layers:
-        return False
-    lib = hip.load()
-    for k, l in enumerate(layers):
-        if l.dtype != "f32" or l.wino4_packed is None or l.cin != l._pack_cin or (k and l.cin != layers[k - 1].cout):
-            return False
-        if not lib.pn_conv_wino4_chain_supported(C.byref(_chain_desc(l, b, h, w))):
-            return False
-    return True
+    return _chain_orientation(layers, b, h, w) is not None
 
 
 def conv_chain(layers, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_channel_offset=0, in_channel_offset=0) -> torch.Tensor:
@@ -647,10 +685,12 @@ def conv_chain(layers, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_
     assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
     b, h, w, ct = x.shape
     lib, st, dev = hip.load(), hip.stream(), x.device
+    tr = _chain_orientation(layers, b, h, w)
+    assert tr is not None, "conv_chain: check conv_chain_supported first"
     cmax = max([layers[0].cin] + [l.cout for l in layers[:-1]])
-    n = lib.pn_wino4_planes_floats(b, h, w, cmax)
+    n = lib.pn_wino4_planes_floats(b, w if tr else h, h if tr else w, cmax)
     bufs = [torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev) if len(layers) > 1 else None]
-    hip.call("pn_wino4_planes_from_nhwc_f32", x.data_ptr(), b, h, w, layers[0].cin, ct, in_channel_offset, bufs[0].data_ptr(), st)
+    hip.call("pn_wino4_planes_from_nhwc_f32", x.data_ptr(), b, h, w, layers[0].cin, ct, in_channel_offset, int(tr), bufs[0].data_ptr(), st)
     last = layers[-1]
     if out is None:
         out = torch.empty((b, h, w, last.cout), dtype=torch.float32, device=dev)
@@ -658,13 +698,13 @@ def conv_chain(layers, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_
     prof = _PROFILER
     for k, l in enumerate(layers):
         is_last = k == len(layers) - 1
-        d = _chain_desc(l, b, h, w, out.shape[3], out_channel_offset) if is_last else _chain_desc(l, b, h, w)
+        d = _chain_desc(l, b, h, w, out.shape[3], out_channel_offset, transposed=tr) if is_last else _chain_desc(l, b, h, w, transposed=tr)
         two_d = l.wino24_packed is not None and _chain_two_d(lib, d)
-        l._ensure("wino24" if two_d else "wino4")
+        wts = l.chain_weights(two_d, tr)
         if prof is not None:
             ev = prof.begin(st)
         hip.call("pn_conv2d_wino24_chain_f32" if two_d else "pn_conv2d_wino4_chain_f32", C.byref(d), bufs[k & 1].data_ptr(),
-                 (l.wino24_packed if two_d else l.wino4_packed).data_ptr(), hip.ptr(l.scale), hip.ptr(l.shift),
+                 wts.data_ptr(), hip.ptr(l.scale), hip.ptr(l.shift),
                  None if is_last else bufs[(k + 1) & 1].data_ptr(), out.data_ptr() if is_last else None, st)
         if prof is not None:
             flops = 2.0 * b * h * w * l.cout * l.cin * 9
@@ -679,7 +719,8 @@ def _chain_two_d(lib, d) -> bool:
     issues 1.5x fewer MFMAs); alone on the chip the 1-D form's 256 blocks finish sooner"""
     if not _CHAIN2D_ON or not lib.pn_conv_wino24_chain_supported(C.byref(d)):
         return False
-    octs, wq = d.batch * (d.in_h // 2) * (d.in_w // 4), d.in_w // 4
+    fh, fw = (d.in_w, d.in_h) if d.transpose_hw else (d.in_h, d.in_w)
+    octs, wq = d.batch * (fh // 2) * (fw // 4), fw // 4
     blocks = (octs // (64 if wq > 32 else 32)) * (d.cout // 32)
     return blocks >= 192 or d.frames_in_flight > 1
 

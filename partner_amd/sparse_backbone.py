@@ -123,7 +123,7 @@ class SpMiddleResNetFHD(nn.Module):
     @staticmethod
     def _conv(feats, n_rows, nbr, count, cap, layer, act, residual=None, groups=None):
         out = torch.empty((cap, layer["cout"]), dtype=torch.float32, device=feats.device)
-        if groups is not None and layer["cin"] % 16 == 0 and layer["cout"] >= 32 and layer["taps"] <= 27:
+        if groups is not None and layer["cin"] % 16 == 0 and layer["cout"] in (32, 64, 128) and layer["taps"] <= 27:
             # 32 / 64 / 128-channel levels and the strided stages: one wave per group of 32 similar sites, the group's taps only (sparse_group.hip)
             hip.call("pn_sparse_conv_grouped_f32", feats.data_ptr(), n_rows, layer["cin"], nbr.data_ptr(), count.data_ptr(), cap, layer["taps"],
                      groups[0].data_ptr(), groups[1].data_ptr(), layer["packed"].data_ptr(), layer["cout"], layer["scale"].data_ptr(),

@@ -39,7 +39,7 @@ def test_host_only_entry_points():
     # argument validation happens on the host, before any launch
     rc = lib.pn_conv2d_nhwc_f32(None, None, None, None, None, None, None)
     assert rc == -1 and "null descriptor" in hip.last_error()
-    assert C.sizeof(hip.ConvDesc) == 22 * 4     # pn_conv_desc: 22 int32 fields (r3: + frames_in_flight)
+    assert C.sizeof(hip.ConvDesc) == 23 * 4     # pn_conv_desc: 23 int32 fields (r3: + frames_in_flight, r4: + transpose_hw)
     # the entries added for the frame engines / reproducible training validate on the host as well
     rc = lib.pn_clear_canvas_cells(None, None, 10, None, 128, None, None)
     assert rc == -1 and "clear_canvas_cells" in hip.last_error()

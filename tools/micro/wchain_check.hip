@@ -49,9 +49,9 @@ int main(int argc, char** argv) {
     char buf[256];
     if (!pn_conv_wino4_chain_supported(&d)) { printf("%dx%dx%d %d->%d: chain form not supported\n", sh.b, sh.h, sh.w, sh.cin, sh.cout); continue; }
     int rc = pn_conv2d_wino4_nhwc_f32(&d, x, pw, sc, shf, o_ref, nullptr);
-    rc |= pn_wino4_planes_from_nhwc_f32(x, sh.b, sh.h, sh.w, sh.cin, sh.cin, 0, vin, nullptr);
+    rc |= pn_wino4_planes_from_nhwc_f32(x, sh.b, sh.h, sh.w, sh.cin, sh.cin, 0, 0, vin, nullptr);
     rc |= pn_conv2d_wino4_chain_f32(&d, vin, pw, sc, shf, vout, o_ch, nullptr);
-    rc |= pn_wino4_planes_from_nhwc_f32(o_ref, sh.b, sh.h, sh.w, sh.cout, sh.cout, 0, vref, nullptr);
+    rc |= pn_wino4_planes_from_nhwc_f32(o_ref, sh.b, sh.h, sh.w, sh.cout, sh.cout, 0, 0, vref, nullptr);
     if (rc) { pn_last_error(buf, 256); printf("error: %s\n", buf); return 1; }
     hipDeviceSynchronize();
     std::vector<float> a(nout), b(nout), va(nvo), vb(nvo);
@@ -93,14 +93,14 @@ int main(int argc, char** argv) {
       timeit("2-D: 5 chained layers (x5)", [&] {
         for (int l = 0; l < 5; ++l) pn_conv2d_wino24_chain_f32(&d, (l & 1) ? vout : vin, pw24, sc, shf, (l & 1) ? vin : vout, nullptr, nullptr);
       });
-      pn_wino4_planes_from_nhwc_f32(x, sh.b, sh.h, sh.w, sh.cin, sh.cin, 0, vin, nullptr);
+      pn_wino4_planes_from_nhwc_f32(x, sh.b, sh.h, sh.w, sh.cin, sh.cin, 0, 0, vin, nullptr);
     }
-    timeit("planes from nhwc", [&] { pn_wino4_planes_from_nhwc_f32(x, sh.b, sh.h, sh.w, sh.cin, sh.cin, 0, vin, nullptr); });
+    timeit("planes from nhwc", [&] { pn_wino4_planes_from_nhwc_f32(x, sh.b, sh.h, sh.w, sh.cin, sh.cin, 0, 0, vin, nullptr); });
     // ping-pong chain of 5 layers, as the block runs them
     timeit("5 chained layers (per layer)", [&] {
       for (int l = 0; l < 5; ++l) pn_conv2d_wino4_chain_f32(&d, (l & 1) ? vout : vin, pw, sc, shf, (l & 1) ? vin : vout, nullptr, nullptr);
     });
-    pn_wino4_planes_from_nhwc_f32(x, sh.b, sh.h, sh.w, sh.cin, sh.cin, 0, vin, nullptr);
+    pn_wino4_planes_from_nhwc_f32(x, sh.b, sh.h, sh.w, sh.cin, sh.cin, 0, 0, vin, nullptr);
     {  // stamps of one launch (every wave): prologue | K loop | join + epilogue, and the spread of block starts / ends
       hipMemset(stamps, 0, 2048 * 16 * 4 * 8);
       hipDeviceSynchronize();

@@ -25,28 +25,33 @@ rec = []
 orig = SpMiddleResNetFHD._conv
 
 
-def spy(feats, n_rows, nbr, count, cap, layer, act, residual=None):
-    rec.append((feats, n_rows, nbr, count, cap, layer, act, residual))
-    return orig(feats, n_rows, nbr, count, cap, layer, act, residual)
+def spy(feats, n_rows, nbr, count, cap, layer, act, residual=None, groups=None):
+    rec.append((feats, n_rows, nbr, count, cap, layer, act, residual, groups))
+    return orig(feats, n_rows, nbr, count, cap, layer, act, residual, groups)
 
 
 SpMiddleResNetFHD._conv = staticmethod(spy)
 m.backbone.forward_nhwc(m.reader(voxels, num), coords4, batch, [1152, 2048, 40])
 SpMiddleResNetFHD._conv = staticmethod(orig)
 tot = 0.0
-for feats, n_rows, nbr, count, cap, layer, act, residual in rec:
+for feats, n_rows, nbr, count, cap, layer, act, residual, groups in rec:
     n = int(count.item())
     for _ in range(2):
-        orig(feats, n_rows, nbr, count, cap, layer, act, residual)
+        orig(feats, n_rows, nbr, count, cap, layer, act, residual, groups)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        orig(feats, n_rows, nbr, count, cap, layer, act, residual)
+        orig(feats, n_rows, nbr, count, cap, layer, act, residual, groups)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100.0
     tot += us
     pairs = float((nbr[:n] >= 0).sum()) / max(n, 1)
+    if groups is not None:      # issued by the grouped form: 32 rows x the union mask of every live group
+        gm = groups[1][:(n + 31) // 32].to(torch.int64) & 0xffffffff
+        bits = sum(((gm >> t) & 1) for t in range(layer['taps']))
+        iss = float(bits.sum()) * 32 * layer['cin'] * layer['cout'] * 2
+        print(f"   grouped: issued {iss / 1e9:6.2f} GFLOP -> {iss * 1e-6 / us:6.1f} TFLOP/s issued; existing pairs {pairs * n * layer['cin'] * layer['cout'] * 2 / 1e9:6.2f} GFLOP")
     print(f"sites {n:7d} cap {cap:7d} in_rows {n_rows:7d} {layer['cin']:3d}->{layer['cout']:3d} taps {layer['taps']:2d} pairs/site {pairs:5.2f}: {us:7.1f} us  "
           f"{2e-6 * n * layer['taps'] * layer['cin'] * layer['cout'] / us:6.1f} TFLOP/s over all taps")
 print(f"sum {tot / 1e3:.3f} ms")
