@@ -116,6 +116,38 @@ def _stage(timed, acct=None, survey_gflop=None):
     return row
 
 
+def sparse_account(backbone, fn):
+    """matrix work of one pass of the sparse encoder (``fn`` runs it): issued = what its kernels put on the MFMA (grouped form: 32 rows x the
+    union mask of every live group, sparse_group.hip; the 16-channel level runs on the VALU and is counted by its pairs), useful = the
+    existing (site, tap) pairs only.  Reads device counts back: call outside timed regions."""
+    from ..sparse_backbone import SpMiddleResNetFHD
+    rec, orig = [], SpMiddleResNetFHD._conv
+
+    def spy(feats, n_rows, nbr, count, cap, layer, act, residual=None, groups=None):
+        rec.append((nbr, count, layer, groups))
+        return orig(feats, n_rows, nbr, count, cap, layer, act, residual, groups)
+
+    SpMiddleResNetFHD._conv = staticmethod(spy)
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        SpMiddleResNetFHD._conv = staticmethod(orig)
+    issued = useful = 0.0
+    for nbr, count, layer, groups in rec:
+        n = int(count.item())
+        f = 2.0 * layer["cin"] * layer["cout"]
+        pairs = float((nbr[:n] >= 0).sum())
+        useful += pairs * f
+        if groups is not None and layer["cout"] >= 32:
+            gm = groups[1][:(n + 31) // 32].to(torch.int64) & 0xffffffff
+            bits = sum(((gm >> t) & 1) for t in range(layer["taps"]))
+            issued += float(bits.sum()) * 32 * f
+        else:
+            issued += pairs * f
+    return dict(gflop_issued=issued / 1e9, gflop_useful=useful / 1e9, convolutions=len(rec))
+
+
 def build_waymo_partner(dev):
     import partner_amd as P
     cfg = P.Config.fromfile(os.path.join(ROOT, "configs", "waymo", "polar_partner_c4.py"))
@@ -174,6 +206,16 @@ def c4_leg(dev, batch: int = 2, points: int = 180000, reps: int = 10, warm: int 
     stages = dict()
     stages["voxelize_vfe"] = _stage(time_ms(st_vox, reps, warm))         # ends in a host read of the voxel count (the example dict carries python ints)
     stages["sparse_encoder"] = _stage(graph_time_ms(st_sparse, reps, warm))
+    try:      # the stage's matrix work: issued (groups x their tap unions) and useful (existing pairs), as fractions of the f32 MFMA peak
+        sa = sparse_account(m.backbone, st_sparse)
+        ms_sp = stages["sparse_encoder"]["ms"]
+        stages["sparse_encoder"].update(gflop_issued=round(sa["gflop_issued"], 2), gflop_useful=round(sa["gflop_useful"], 2), convolutions=sa["convolutions"],
+                                        tflops_issued=round(sa["gflop_issued"] / ms_sp, 2), frac=round(sa["gflop_issued"] / ms_sp / PEAK_F32_MFMA_TFLOPS, 4),
+                                        frac_useful=round(sa["gflop_useful"] / ms_sp / PEAK_F32_MFMA_TFLOPS, 4),
+                                        frac_of="issued (resp. existing-pair) MFMA FLOPs of the 21 sparse convolutions / stage wall time (index builds, neighbour "
+                                                "tables and group sorts included) / 157.3 TFLOP/s")
+    except Exception as e:   # noqa: BLE001 -- an accounting row must not take the line down
+        stages["sparse_encoder"]["account_error"] = repr(e)[:200]
     stages["setblocks_x2"] = _stage(graph_time_ms(st_attn, reps, warm), mfma_account(st_attn), survey_gflop=123.2 * batch)
     stages["rpn"] = _stage(graph_time_ms(st_rpn, reps, warm), mfma_account(st_rpn), survey_gflop=143.14 * batch)
     stages["e2e_swv_head"] = _stage(graph_time_ms(st_head, reps, warm), mfma_account(st_head), survey_gflop=290.0 * batch)
@@ -235,7 +277,10 @@ def c4_leg(dev, batch: int = 2, points: int = 180000, reps: int = 10, warm: int 
     st_head16 = lambda: m.bbox_head.forward_nhwc(x_rpn16)                                 # noqa: E731
     b16["stages"] = dict(rpn=_stage(graph_time_ms(st_rpn, reps, warm), mfma_account(st_rpn), survey_gflop=143.14 * batch),
                          e2e_swv_head=_stage(graph_time_ms(st_head16, reps, warm), mfma_account(st_head16), survey_gflop=290.0 * batch))
-    out["bf16_bev_convs"] = b16
+    b16["note"] = ("OPTION, not the configs[3] figure: the f32 path above is the product path of this config.  set_compute_dtype('bf16') runs the BEV "
+                   "convolutions on a template variant of the f32 kernel (v_mfma_f32_32x32x16_bf16) at ~0.17 of the dense bf16 peak; no kernel designed for "
+                   "the bf16 pipe exists (r4 decision, VERDICT r3 item 3)")
+    out["option_bf16_bev_convs"] = b16
     m.neck.set_compute_dtype("f32")
     m.bbox_head.set_compute_dtype("f32")
     return out

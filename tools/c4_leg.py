@@ -14,7 +14,7 @@ hip.load()
 out = legs.c4_leg(torch.device("cuda:0"), batch=int(sys.argv[1]) if len(sys.argv) > 1 else 2)
 for k in sorted(k for k in out if k.startswith("one_graph") or k.startswith("two_graphs")):
     print(k, out[k])
-for prec in ("f32", "bf16_bev_convs"):
+for prec in ("f32", "option_bf16_bev_convs"):
     o = out[prec]
     print(f"{prec}: {o['ms_per_step']} ms per step, {o['frames_per_s']} frames/s")
     for k, v in o["stages"].items():
