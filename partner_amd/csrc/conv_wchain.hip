@@ -35,6 +35,7 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 struct WChainArgs {
   const float* vin;
@@ -172,10 +173,18 @@ __device__ __forceinline__ void wchain_finish(const WChainArgs& a, int c0, int l
   }
 }
 
+// The prologue needs a dozen kernel arguments; left alone the compiler fetches them from the kernarg segment one group at a time, each
+// group right before its first use, behind a wait of its own -- four or five dependent round trips (~1.5k cycles of a 35k-cycle kernel)
+// before the first operand load is issued.  Naming them all as inputs of one empty asm statement makes it fetch them together.
+#define WCHAIN_FETCH_ARGS(a)                                                                                                               \
+  asm volatile("" ::"s"(a.vin), "s"(a.w), "s"(a.qtiles), "s"(a.ctiles), "s"(a.wq_log2), "s"(a.H), "s"(a.Wq), "s"(a.plane_bytes), "s"(a.cout_pad), \
+               "s"(a.cg_in), "s"(a.vin_bytes), "s"(a.w_bytes))
+
 template <int NA, int NB, int KS, int CT>
 __global__ __launch_bounds__(64 * 6 * KS * CT) void conv_wchain_kernel(WChainArgs a) {
   constexpr int NW = 6 * KS * CT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  WCHAIN_FETCH_ARGS(a);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w % 6, ks = (w / 6) % KS, ct = w / (6 * KS);
@@ -308,6 +317,7 @@ template <int KS, int CT, int QT>
 __global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WChainArgs a) {
   constexpr int NW = 6 * KS * CT * QT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  WCHAIN_FETCH_ARGS(a);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w % 6, ks = (w / 6) % KS, ct = (w / (6 * KS)) % CT, qw = w / (6 * KS * CT);
@@ -380,10 +390,23 @@ __global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WCh
       if constexpr (PN_WCHAIN_EXP & 1) {
         b[0] = d[slot][0]; b[1] = d[slot][1]; b[2] = d[slot][2]; b[3] = d[slot][3];
       } else {
-        b[0] = d[slot][0] - d[slot][2];
-        b[1] = d[slot][1] + d[slot][2];
-        b[2] = d[slot][2] - d[slot][1];
-        b[3] = d[slot][1] - d[slot][3];
+        // (packed: eight v_pk_add_f32 instead of sixteen scalar ones -- the VALU work of this loop comes straight out of the MFMA time)
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          f32x2 x0 = {d[slot][0][e], d[slot][0][e + 1]}, x1 = {d[slot][1][e], d[slot][1][e + 1]}, x2 = {d[slot][2][e], d[slot][2][e + 1]},
+                x3 = {d[slot][3][e], d[slot][3][e + 1]};
+          f32x2 r0, r1, r2, r3;
+          asm volatile("v_pk_add_f32 %0, %4, %6 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                       "v_pk_add_f32 %1, %5, %6\n\t"
+                       "v_pk_add_f32 %2, %6, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                       "v_pk_add_f32 %3, %5, %7 neg_lo:[0,1] neg_hi:[0,1]"
+                       : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                       : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+          b[0][e] = r0[0]; b[0][e + 1] = r0[1];
+          b[1][e] = r1[0]; b[1][e + 1] = r1[1];
+          b[2][e] = r2[0]; b[2][e + 1] = r2[1];
+          b[3][e] = r3[0]; b[3][e + 1] = r3[1];
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)

@@ -490,7 +490,7 @@ def test_full_c2_train_step_grads_vs_fp64_autograd(dev, batch):
         return float(loss["det_loss"].detach()), {k: v.grad for k, v in sd.items() if getattr(v, "grad", None) is not None}
 
     loss64, g64 = oracle_grads(torch.float64)
-    loss32, g32 = oracle_grads(torch.float32) if batch == 1 else (None, None)   # the fp32-oracle accuracy class is established at one sample
+    loss32, g32 = oracle_grads(torch.float32)      # torch's own fp32 autograd over the same oracle: the accuracy class fp32 gives at this depth
     ts = PolarPillarTrainStep(m, total_steps=100)
     tg = ops.CenterLossTargets(*(torch.from_numpy(a) for a in (hm, ind, mask, cat, anno)), dev)
     offs = torch.tensor([30000 * b for b in range(batch + 1)], dtype=torch.int32, device=dev)
@@ -512,9 +512,19 @@ def test_full_c2_train_step_grads_vs_fp64_autograd(dev, batch):
             e_o32.append(float((g32[name].double() - t).abs().max() / sc))
     e_hip, e_o32 = np.array(e_hip), np.array(e_o32)
     assert len(e_hip) > 90
-    assert np.median(e_hip) < 5e-3 and np.quantile(e_hip, 0.95) < 2e-2 and e_hip.max() < 6e-2, (np.median(e_hip), np.quantile(e_hip, 0.95), e_hip.max())
-    if g32 is not None:
-        assert np.median(e_hip) < 3 * np.median(e_o32) + 1e-3, (np.median(e_hip), np.median(e_o32))
+    stats = dict(hip=(np.median(e_hip), np.quantile(e_hip, 0.95), e_hip.max()), fp32_oracle=(np.median(e_o32), np.quantile(e_o32, 0.95), e_o32.max()))
+    print("full-size gradient errors vs fp64 (median, q95, max), batch", batch, stats)
+    # r4: the bound is PINNED TO THE fp32 ORACLE.  Measured on MI355X against float64:
+    #   batch 4 (the config):  HIP median 2.2e-3 / q95 1.07e-2 / max 1.7e-2;  torch fp32 autograd over the oracle 1.8e-3 / 1.0e-2 / 1.7e-2
+    #   batch 1:               HIP        2.4e-3 /     1.36e-2 /     3.7e-2;  torch fp32                          1.8e-3 / 7.2e-3 / 1.1e-2
+    # i.e. at the config's batch torch's own fp32 gradients miss q95 < 1e-2 as well: the HIP step must stay within 2x of that class in
+    # every statistic (single sample: 4x in the maximum -- one-sample BatchNorm statistics amplify the forward's rounding),
+    # under absolute caps that are those numbers with ~2x head-room.
+    hip_m, hip_q, hip_x = stats["hip"]
+    o_m, o_q, o_x = stats["fp32_oracle"]
+    caps = (4e-3, 2e-2, 3.5e-2) if batch == 4 else (5e-3, 2e-2, 6e-2)
+    assert hip_m < caps[0] and hip_q < caps[1] and hip_x < caps[2], stats
+    assert hip_m < 2 * o_m + 5e-4 and hip_q < 2 * o_q + 1e-3 and hip_x < (2 if batch == 4 else 4) * o_x + 2e-3, stats
 
 
 def test_train_step_plain_center_head_vs_oracle_autograd(dev, golden):
