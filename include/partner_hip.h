@@ -404,6 +404,13 @@ int pn_groupnorm_strat_fwd(const float *x, int batch, int h, int w, int c, int p
                            int out_pixel_stride, int out_channel_offset, const float *mul,
                            const float *add, float *out2, void *workspace, size_t workspace_bytes,
                            pn_stream_t stream);
+/* pn_groupnorm_strat_fwd whose result leaves as the F(4, 3) planes of conv_wchain.hip instead of the map (planes2, nullable: the planes of
+ * out * mul + add); transpose_hw: the planes of the transposed map.  Each buffer: pn_wino4_planes_floats(batch, h, w, c) floats (transposed:
+ * (batch, w, h, c)).  norm.py:58-75 + the input transform of the convolutions that follow. */
+int pn_groupnorm_strat_planes_f32(const float *x, int batch, int h, int w, int c, int pixel_stride, int channel_offset, int channel_groups,
+                                  int range_strata, const float *gamma, const float *beta, float eps, int act, const float *mul,
+                                  const float *add, int transpose_hw, float *planes, float *planes2, void *workspace,
+                                  size_t workspace_bytes, pn_stream_t stream);
 /* the normalisation pass of pn_groupnorm_strat_fwd alone: mean_rstd [batch][range_strata][channel_groups][2] comes from the
  * producing convolution's epilogue (pn_conv2d_multi_f32 stat_mean_rstd); out2 = out*mul + add goes to its own
  * pixel stride / channel offset (e.g. the second half of a concatenated map) */
@@ -984,6 +991,40 @@ int pn_pack_conv_weight_wino24_f32(const float *w_oihw, int cout, int cin, float
 int pn_conv_wino24_chain_supported(const pn_conv_desc *desc);
 int pn_conv2d_wino24_chain_f32(const pn_conv_desc *desc, const float *planes_in, const float *packed_w24, const float *scale,
                                const float *shift, float *planes_out, float *out_nhwc, pn_stream_t stream);
+/* The centre head's branch convolutions in the same domain (r4; center_head_parallel.py:120-196 behind its RSNorm: Conv2d / RangeStratified
+ * 64 -> 64 + GroupNorm + ReLU + last convolution).  pn_groupnorm_strat_planes_f32 (below, with the GroupNorm entries) writes the normalised
+ * shared map as planes; pn_conv2d_wino24_chain_head_f32 = pn_conv2d_wino24_chain_f32 plus
+ *   stat_partials   (nullable) per-channel (sum, sum of squares) of the output per tile and row: [tile][2][cout][2] floats
+ *                   (pn_conv_wino24_chain_stat_floats; a tile covers pn_conv_wino24_chain_stat_tile_rows frame rows; activation must be none)
+ *   desc->range_strata > 1: RangeStratified weights (center_head_parallel.py:27-59) on the TRANSPOSED map (transpose_hw = 1: the frame's rows
+ *                   are the range positions): range_strata weight sets packed one after the other, rows [s R / S, (s + 1) R / S) take set s
+ * pn_wino24_chain_head_finalize_f32 folds the partials of up to 8 channel slices into the affine tables (A, B) (y = x A + B) that
+ * pn_conv2d_small_n_multi_f32 applies on load: per-channel groups (strata <= 1) or one group per stratum over the slice's channels. */
+typedef struct pn_head_stat_job {
+  const float *partials;      /* of the launch the slice belongs to */
+  int32_t cout_total;         /* output channels of that launch */
+  int32_t channel_offset;     /* first channel of the slice */
+  int32_t channels;
+  int32_t strata;             /* 0 / 1: GroupNorm(C, C); > 1: GroupNorm(strata, strata * C) over range strata */
+  const float *gamma;         /* [max(strata, 1)][channels], NULL = 1 */
+  const float *beta;
+  float eps;
+  float *table;               /* out: [batch][max(strata, 1)][channels][2] */
+} pn_head_stat_job;
+size_t pn_conv_wino24_chain_stat_floats(const pn_conv_desc *desc);
+int pn_conv_wino24_chain_stat_tile_rows(const pn_conv_desc *desc);
+int pn_conv2d_wino24_chain_head_f32(const pn_conv_desc *desc, const float *planes_in, const float *packed_w24, const float *scale,
+                                    const float *shift, float *planes_out, float *out_nhwc, float *stat_partials, pn_stream_t stream);
+int pn_wino24_chain_head_finalize_f32(const pn_head_stat_job *jobs, int njobs, int batch, int frame_rows, int frame_row_pixels, int tile_rows,
+                                      pn_stream_t stream);
+/* Up to 4 pn_conv2d_wino24_chain_head_f32 layers of one map and cin as ONE launch (the head's branch groups are 128 - 384 short blocks
+ * each; apart they leave the chip half empty between launches).  Results are those of the separate calls, bit for bit. */
+typedef struct pn_chain_head_job {
+  const pn_conv_desc *desc;
+  const float *planes_in, *packed_w24, *scale, *shift;
+  float *planes_out, *out_nhwc, *stat_partials;
+} pn_chain_head_job;
+int pn_conv2d_wino24_chain_head_multi_f32(const pn_chain_head_job *jobs, int njobs, pn_stream_t stream);
 /* Weight gradient of a plain 3x3 / stride 1 / pad 1 convolution in the F(4, 3) domain (map width a multiple of 4): six GEMMs per kernel
  * row over the quads, dW = G^T [ (B^T d) (A dy)^T ], half the MFMA work of pn_conv2d_wgrad_f32; desc as for pn_conv2d_wgrad_f32 (in_* = the
  * layer's input x, out_* = dout); slices summed in fixed order (deterministic).  Autograd of the RPN's Conv2d layers, rpn.py:124-142 under

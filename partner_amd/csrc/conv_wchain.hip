@@ -28,6 +28,7 @@
 // Numerics: the same products and the same two transforms as conv_wino4.hip; only the summation order over K differs (per position,
 // two halves).
 #include "pn_common.h"
+#include "wino_planes.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -55,6 +56,11 @@ struct WChainArgs {
   int cout_pad;
   unsigned plane_bytes;   // B (H + 2) Wq 16: one (p, cg, h) plane, the same for input and output (same map)
   unsigned vin_bytes, w_bytes;
+  // ---- head branches (r4): statistics of the output for the GroupNorm that follows, and range-stratified weights
+  float* st_part;         // nullable: [tile][row 2][Cout][2] (2-D kernel) per-channel (sum, sum of squares) of the tile's outputs
+  int strata_rows;        // > 0: the layer is range-stratified along the frame's ROWS (center_head_parallel.py:27-59 on the transposed map): rows
+                          // [s strata_rows, (s + 1) strata_rows) of every image use weight set s
+  unsigned w_stratum_bytes;      // bytes between two weight sets
 #ifdef PN_WCHAIN_STAMP
   unsigned long long* stamps;   // diagnostic build only (tools/micro/wchain_check.hip): [block][wave][4] shader-clock stamps
 #endif
@@ -73,18 +79,8 @@ unsigned long long* pn_wchain_stamp_buffer = nullptr;
 #define PN_WCHAIN_EXP 0   // diagnostic builds only (tools/micro/wchain_check.hip), 2-D kernel's K loop: bit 0 no height transform, 1 no plane loads, 2 no weight loads
 #endif
 
-// B^T d for four channels at once (the same expression tree as conv_wino4.hip's wino4_input_transform: bit-identical values)
-__device__ __forceinline__ void wchain_input_transform(const f32x4 (&d)[6], f32x4 (&v)[6]) {
-  const f32x4 c4 = {4.f, 4.f, 4.f, 4.f}, m4 = {-4.f, -4.f, -4.f, -4.f}, m5 = {-5.f, -5.f, -5.f, -5.f}, c2 = {2.f, 2.f, 2.f, 2.f}, m2 = {-2.f, -2.f, -2.f, -2.f};
-  const f32x4 e = __builtin_elementwise_fma(m4, d[2], d[4]), o = __builtin_elementwise_fma(m4, d[1], d[3]);
-  const f32x4 f = d[4] - d[2], t = d[3] - d[1];
-  v[0] = __builtin_elementwise_fma(c4, d[0], __builtin_elementwise_fma(m5, d[2], d[4]));
-  v[1] = e + o;
-  v[2] = e - o;
-  v[3] = __builtin_elementwise_fma(c2, t, f);
-  v[4] = __builtin_elementwise_fma(m2, t, f);
-  v[5] = __builtin_elementwise_fma(c4, d[1], __builtin_elementwise_fma(m5, d[3], d[5]));
-}
+// B^T d for four channels at once: wino_planes.h (the same expression tree as conv_wino4.hip's wino4_input_transform: bit-identical values)
+__device__ __forceinline__ void wchain_input_transform(const f32x4 (&d)[6], f32x4 (&v)[6]) { pn::wino4_input_transform4(d, v); }
 
 // Where element k (0 .. 63) of a tile lies, from the tile's block-uniform first row (image img0, row r0 of `rows` per image): tiles are
 // whole rows of Wq = 1 << lg quads and never taller than an image, so no vector division
@@ -103,10 +99,11 @@ __device__ __forceinline__ void wchain_coords(int img0, int r0, int rows, int lg
 // the lane's quad of tile b lies.  Output transform, affine + activation, the neighbours' edge pixels by lane shuffles, the next layer's
 // input transform, stores: six plane fragments (+ the zero padding rows next to the first / last image row) and / or four NHWC pixels.
 template <int NT, typename GetM, typename QuadOf>
-__device__ __forceinline__ void wchain_finish(const WChainArgs& a, int c0, int li, int lh, float lo, GetM get_m, QuadOf quad_of) {
+__device__ __forceinline__ void wchain_finish(const WChainArgs& a, int c0, int li, int lh, float lo, GetM get_m, QuadOf quad_of, float* part = nullptr,
+                                              int aff_off = 0) {
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-  if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + c0);
-  if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + c0);
+  if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + aff_off + c0);      // (aff_off: the tile's stratum x Cout of a stratified layer)
+  if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + aff_off + c0);
   f32x4 y[NT][4];
 #pragma unroll
   for (int b = 0; b < NT; ++b) {
@@ -123,6 +120,29 @@ __device__ __forceinline__ void wchain_finish(const WChainArgs& a, int c0, int l
     y[b][1] = __builtin_elementwise_max(__builtin_elementwise_fma(y1, sc, sh), lo4);
     y[b][2] = __builtin_elementwise_max(__builtin_elementwise_fma(y2, sc, sh), lo4);
     y[b][3] = __builtin_elementwise_max(__builtin_elementwise_fma(y3, sc, sh), lo4);
+  }
+  if (part) {
+    // per-channel (sum, sum of squares) of this virtual wave's outputs (NT x 32 quads x 4 pixels per channel), lanes folded by a fixed
+    // xor butterfly inside each lane half (a half = four channels): part[c0 + j] = (sum, sumsq)
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        s1 += y[b][px];
+        s2 += y[b][px] * y[b][px];
+      }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s1[j] += __shfl_xor(s1[j], o, 32);
+        s2[j] += __shfl_xor(s2[j], o, 32);
+      }
+    if (li == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<float2*>(part + (size_t)(c0 + j) * 2) = make_float2(s1[j], s2[j]);
+    }
   }
 #pragma unroll
   for (int b = 0; b < NT; ++b) {
@@ -314,7 +334,7 @@ __global__ __launch_bounds__(64 * 6 * KS * CT) void conv_wchain_kernel(WChainArg
 // r1 = m1 - m2 - m3), the tail is wchain_finish per output row.  Block = 6 KS CT QT waves: K halves, column tiles, and QT octet tiles
 // that follow each other along a row pair (QT 32 octets = whole row pairs).
 template <int KS, int CT, int QT>
-__global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WChainArgs a) {
+__device__ __forceinline__ void wchain2_body(const WChainArgs& a, const int bid0, const int bid_step) {
   constexpr int NW = 6 * KS * CT * QT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   WCHAIN_FETCH_ARGS(a);
@@ -330,8 +350,8 @@ __global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WCh
   const int Hh = a.H >> 1;
   f32x4* J = reinterpret_cast<f32x4*>(smem);
   const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
-  // persistent blocks (see conv_wchain_kernel): tiles bid, bid + grid, ...
-  for (int bid = blockIdx.x; bid < a.qtiles * a.ctiles; bid += gridDim.x) {
+  // persistent blocks (see conv_wchain_kernel): tiles bid0, bid0 + step, ...
+  for (int bid = bid0; bid < a.qtiles * a.ctiles; bid += bid_step) {
   int qt, ctile;       // the tile's octet-tile group / column-tile group (a.qtiles / a.ctiles of them)
   {
     if ((a.qtiles & 7) == 0) {
@@ -354,7 +374,8 @@ __global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WCh
     // padded row index of image row 2 t - 1 is 2 t
     voff = (unsigned)(((img * (a.H + 2) + 2 * t) * a.Wq + xq) * 16) + (unsigned)lh * a.plane_bytes;
   }
-  const unsigned uoff = (unsigned)(((size_t)lh * a.cout_pad + n0 + li) * 16);
+  // range-stratified layer: the tile's rows (row pairs t0 ..) lie in ONE stratum (strata_rows is a multiple of the tile's rows)
+  const unsigned uoff = (unsigned)(((size_t)lh * a.cout_pad + n0 + li) * 16) + (a.strata_rows > 0 ? (unsigned)((2 * t0) / a.strata_rows) * a.w_stratum_bytes : 0u);
 
   f32x16 acc[4];
 #pragma unroll
@@ -419,7 +440,7 @@ __global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WCh
   }
   WC_STAMP(2);
   // fold the four height positions to the two output rows, leave them in LDS: [wave][row][g][lane] x 4 registers
-  if (bid != (int)blockIdx.x) __syncthreads();      // the previous tile has been read by its virtual waves
+  if (bid != bid0) __syncthreads();      // the previous tile has been read by its virtual waves
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     f32x4 r0, r1;
@@ -448,10 +469,45 @@ __global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WCh
           int t;
           wchain_coords(img0, t0, Hh, a.wq_log2, 32 * b + li, img, t, xq);
           r = 2 * t + row;
-        });
+        },
+        a.st_part ? a.st_part + ((size_t)qt * 2 + row) * a.Cout * 2 : nullptr, a.strata_rows > 0 ? ((2 * t0) / a.strata_rows) * a.Cout : 0);
   }
   WC_STAMP(3);
   }
+}
+
+template <int KS, int CT, int QT>
+__global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WChainArgs a) {
+  wchain2_body<KS, CT, QT>(a, blockIdx.x, gridDim.x);
+}
+
+// several layers of the same map and form as ONE launch (the head's branch groups: three launches of 128 - 384 short blocks each left the
+// chip half empty between them): block -> (job, tile), one tile per block.  The job's arguments are copied out of the kernarg segment with
+// scalar loads (a run-time index into a by-value array would go through scratch).
+constexpr int kChainMultiJobs = 4;
+struct WChainMulti {
+  int njobs;
+  int first[kChainMultiJobs + 1];
+  WChainArgs job[kChainMultiJobs];
+};
+
+template <int KS, int CT, int QT>
+__global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_multi_kernel(WChainMulti by_value) {
+  typedef const __attribute__((address_space(4))) int* kptr_t;
+  const kptr_t base = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const int njobs = base[offsetof(WChainMulti, njobs) / 4];
+  const int t = blockIdx.x;
+  int j = 0;
+  for (int k = 1; k < njobs; ++k)
+    if (t >= base[offsetof(WChainMulti, first) / 4 + k]) j = k;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const int local = t - base[offsetof(WChainMulti, first) / 4 + j];
+  constexpr int JW = sizeof(WChainArgs) / 4;
+  union { WChainArgs a; int w[JW]; } u;
+  const kptr_t src = base + offsetof(WChainMulti, job) / 4 + j * JW;
+#pragma unroll
+  for (int i = 0; i < JW; ++i) u.w[i] = src[i];
+  wchain2_body<KS, CT, QT>(u.a, local, 1 << 30);
 }
 
 // torch (Cout, Cin, 3, 3) -> [chunk][s 4][p 6][k4 8][cout_pad][4] = Gh g Gw^T in double, rounded once (Gw: conv_wino4.hip's F(4, 3) rows,
@@ -513,6 +569,100 @@ __global__ __launch_bounds__(256) void wchain_v_from_nhwc_kernel(const float* __
 #pragma unroll
       for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride + (size_t)Wq * 4) = z;
     }
+  }
+}
+
+// ---- the head's GroupNorm-family statistics from the partials of pn_conv2d_wino24_chain_head_f32 -> affine tables (A, B): y = x A + B, the
+// form conv_small_n_multi_kernel applies while it loads (conv_mfma.hip's conv_stats_finalize_kernel for the tiled kernels' partials).
+// A job = a slice of `cmid` channels of one launch's output: per-channel groups (GroupNorm(C, C): statistics over the sample's pixels) or
+// one group per range stratum over all the slice's channels (RangeStratified's GroupNorm(strata, strata C)).  Fixed order, fp64.
+constexpr int kHeadFinJobs = 8;
+struct HeadFinJob {
+  const float* part;      // [tile][row 2][cout_total][2]
+  int cout_total, c_off, cmid;
+  int strata;             // 0 / 1: per-channel groups; > 1: all-channel groups per stratum of the frame's rows
+  const float* gamma;     // [strata or 1][cmid]
+  const float* beta;
+  float eps;
+  float* tab;             // [B][strata or 1][cmid][2]
+};
+struct HeadFinArgs {
+  int njobs, B, rows, tile_rows;      // frame rows per sample; rows a partial tile covers
+  long long row_pixels;               // pixels of one frame row
+  HeadFinJob job[kHeadFinJobs];
+};
+
+__global__ __launch_bounds__(256) void wchain_head_finalize_kernel(HeadFinArgs f) {
+  __shared__ double red[2][4];
+  const int S0 = 8;      // blocks per (job, sample): strata (<= 8) or 1
+  const int j = blockIdx.x / (f.B * S0), rem = blockIdx.x - j * (f.B * S0), b = rem / S0, s = rem - b * S0;
+  if (j >= f.njobs) return;
+  const HeadFinJob& jb = f.job[j];
+  const int S = jb.strata > 1 ? jb.strata : 1;
+  if (s >= S) return;
+  const int tid = threadIdx.x;
+  const int tiles_b = f.rows / f.tile_rows;      // tiles per sample
+  const float2* part = reinterpret_cast<const float2*>(jb.part);
+  if (S == 1) {
+    // per-channel groups, <= 64 channels per pass: 256 / 64 slices of the sample's entries per channel (all their loads in flight), joined
+    // through LDS in a fixed order
+    __shared__ double sl1[4][64], sl2[4][64];
+    for (int c0 = 0; c0 < jb.cmid; c0 += 64) {
+      const int c = c0 + (tid & 63), slice = tid >> 6;
+      double a1 = 0.0, a2 = 0.0;
+      if (c < jb.cmid) {
+#pragma unroll 8
+        for (int e = slice; e < tiles_b * 2; e += 4) {
+          const float2 v = part[((size_t)b * tiles_b * 2 + e) * jb.cout_total + jb.c_off + c];
+          a1 += (double)v.x;
+          a2 += (double)v.y;
+        }
+      }
+      __syncthreads();
+      sl1[slice][tid & 63] = a1;
+      sl2[slice][tid & 63] = a2;
+      __syncthreads();
+      if (tid < 64 && c < jb.cmid) {
+        const double t1 = ((sl1[0][tid] + sl1[1][tid]) + sl1[2][tid]) + sl1[3][tid], t2 = ((sl2[0][tid] + sl2[1][tid]) + sl2[2][tid]) + sl2[3][tid];
+        const double n = (double)f.rows * (double)f.row_pixels;
+        const double mean = t1 / n;
+        double var = t2 / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const float rstd = (float)(1.0 / sqrt(var + (double)jb.eps));
+        const float ga = jb.gamma ? jb.gamma[c] : 1.f, be = jb.beta ? jb.beta[c] : 0.f;
+        const float A = ga * rstd;
+        reinterpret_cast<float2*>(jb.tab)[(size_t)b * jb.cmid + c] = make_float2(A, be - (float)mean * A);
+      }
+    }
+    return;
+  }
+  // stratum s of sample b: tiles [s tiles_s, (s + 1) tiles_s) of the sample, both rows, all cmid channels
+  const int tiles_s = tiles_b / S;
+  const int count = tiles_s * 2 * jb.cmid;
+  double t1 = 0.0, t2 = 0.0;
+  for (int e = tid; e < count; e += 256) {
+    const int ent = e / jb.cmid, c = e - ent * jb.cmid;
+    const float2 v = part[((size_t)(b * tiles_b + s * tiles_s) * 2 + ent) * jb.cout_total + jb.c_off + c];
+    t1 += (double)v.x;
+    t2 += (double)v.y;
+  }
+  t1 = pn::wave_sum(t1);
+  t2 = pn::wave_sum(t2);
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = t1;
+    red[1][tid >> 6] = t2;
+  }
+  __syncthreads();
+  const double u1 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3], u2 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+  const double n = (double)(f.rows / S) * (double)f.row_pixels * jb.cmid;
+  const double mean = u1 / n;
+  double var = u2 / n - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  const float fmean = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)jb.eps));
+  for (int c = tid; c < jb.cmid; c += 256) {
+    const float ga = jb.gamma ? jb.gamma[s * jb.cmid + c] : 1.f, be = jb.beta ? jb.beta[s * jb.cmid + c] : 0.f;
+    const float A = ga * rstd;
+    reinterpret_cast<float2*>(jb.tab)[((size_t)b * S + s) * jb.cmid + c] = make_float2(A, be - fmean * A);
   }
 }
 
@@ -605,6 +755,18 @@ static void launch_chain2(const WChainArgs& a, hipStream_t st, bool prof, const 
   else hipLaunchKernelGGL((conv_wchain2_kernel<KS, CT, QT>), grid, dim3(64 * NW), smem, st, a);
 }
 
+template <int KS, int CT, int QT>
+static void launch_chain2_multi(const WChainMulti& m, hipStream_t st, bool prof, const pn::ProfileSlot& ps) {
+  constexpr int NW = 6 * KS * CT * QT;
+  constexpr size_t smem = (size_t)NW * 2 * 4 * 64 * 16;
+  static bool done[64] = {false};
+  if (pn::first_use_on_device(done))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wchain2_multi_kernel<KS, CT, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const dim3 grid((unsigned)m.first[m.njobs]);
+  if (prof) hipExtLaunchKernelGGL((conv_wchain2_multi_kernel<KS, CT, QT>), grid, dim3(64 * NW), smem, st, ps.start, ps.stop, 0, m);
+  else hipLaunchKernelGGL((conv_wchain2_multi_kernel<KS, CT, QT>), grid, dim3(64 * NW), smem, st, m);
+}
+
 }  // namespace
 
 extern "C" {
@@ -614,16 +776,23 @@ size_t pn_wino4_planes_floats(int batch, int h, int w, int c) {
   return (size_t)6 * c * batch * (h + 2) * (w / 4);
 }
 
+static int chain_basic_ok(const pn_conv_desc* d, bool allow_strata);
+
 int pn_conv_wino4_chain_supported(const pn_conv_desc* d) {
+  if (!chain_basic_ok(d, false)) return 0;
+  ChainForm f;
+  return chain_form(d, f) ? 1 : 0;
+}
+
+static int chain_basic_ok(const pn_conv_desc* d, bool allow_strata) {
   if (!d) return 0;
-  if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->groups == 1 && !d->deconv2x2 && d->range_strata <= 1 &&
-        !d->accumulate && d->pad_h_end == 0 && d->pad_w_end == 0))
+  if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->groups == 1 && !d->deconv2x2 &&
+        (d->range_strata <= 1 || allow_strata) && !d->accumulate && d->pad_h_end == 0 && d->pad_w_end == 0))
     return 0;
   if (d->batch < 1 || frame_h(d) < 1 || frame_w(d) < 4 || d->cin % 32 || d->cout % 32 || d->cin < 32) return 0;
   if (!(d->act == PN_ACT_NONE || d->act == PN_ACT_RELU)) return 0;
   if ((unsigned long long)pn_wino4_planes_floats(d->batch, frame_h(d), frame_w(d), std::max(d->cin, d->cout)) * 4ull >= (1ull << 32)) return 0;
-  ChainForm f;
-  return chain_form(d, f) ? 1 : 0;
+  return 1;
 }
 
 int pn_wino4_planes_from_nhwc_f32(const float* in, int batch, int h, int w, int c, int in_pixel_stride, int in_channel_offset, int transpose_hw,
@@ -703,26 +872,36 @@ int pn_pack_conv_weight_wino24_f32(const float* w_oihw, int cout, int cin, float
   return pn::check_launch("pack_wino24_weight_kernel");
 }
 
-int pn_conv_wino24_chain_supported(const pn_conv_desc* d) {
-  if (!pn_conv_wino4_chain_supported(d)) return 0;
-  Chain2Form f;
-  return chain2_form(d, f) ? 1 : 0;
+// range_strata > 1 (head entry only): RangeStratified convolution on the TRANSPOSED map -- the frame's rows are range positions, every tile
+// (whole row pairs) lies in one stratum and takes that stratum's weight set
+static int chain2_ok(const pn_conv_desc* d, bool head, Chain2Form& f) {
+  if (!chain_basic_ok(d, head) || !chain2_form(d, f)) return 0;
+  if (d->range_strata > 1) {
+    if (!d->transpose_hw || frame_h(d) % d->range_strata) return 0;
+    const int rows = frame_h(d) / d->range_strata, tile_rows = 2 * (32 * f.qt) / (frame_w(d) / 4);
+    if (rows % tile_rows) return 0;
+  }
+  return 1;
 }
 
-int pn_conv2d_wino24_chain_f32(const pn_conv_desc* d, const float* planes_in, const float* packed_w24, const float* scale, const float* shift,
-                               float* planes_out, float* out_nhwc, pn_stream_t stream) {
+int pn_conv_wino24_chain_supported(const pn_conv_desc* d) {
+  Chain2Form f;
+  return chain2_ok(d, false, f);
+}
+
+static int chain2_fill(const pn_conv_desc* d, const float* planes_in, const float* packed_w24, const float* scale, const float* shift, float* planes_out,
+                       float* out_nhwc, float* stat_partials, bool head, WChainArgs& a, Chain2Form& f) {
   PN_REQUIRE(d && planes_in && packed_w24 && (planes_out || out_nhwc), "conv_wino24_chain: null pointer");
-  PN_REQUIRE(pn_conv_wino24_chain_supported(d), "conv_wino24_chain: layer shape not supported (3x3 / stride 1 / pad 1, even height, cin and cout "
-                                                "multiples of 32, row-pair-aligned tiles)");
+  PN_REQUIRE(chain2_ok(d, head, f), "conv_wino24_chain: layer shape not supported (3x3 / stride 1 / pad 1, even height, cin and cout multiples of 32, "
+                                    "row-pair-aligned tiles; range strata: transposed map, whole tiles per stratum)");
   PN_REQUIRE(((uintptr_t)planes_in & 15) == 0 && ((uintptr_t)packed_w24 & 15) == 0 && ((uintptr_t)planes_out & 15) == 0 && ((uintptr_t)out_nhwc & 15) == 0 &&
-                 ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
+                 ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0 && ((uintptr_t)stat_partials & 7) == 0,
              "conv_wino24_chain: pointers must be 16-byte aligned");
+  PN_REQUIRE(!stat_partials || d->act == PN_ACT_NONE, "conv_wino24_chain: statistics are those of the stored output (no activation)");
   if (out_nhwc)
     PN_REQUIRE(d->out_pixel_stride >= d->out_channel_offset + d->cout && d->out_pixel_stride % 4 == 0 && d->out_channel_offset % 4 == 0,
                "conv_wino24_chain: output channel slice must fit the pixel stride, in multiples of 4 floats");
-  Chain2Form f;
-  chain2_form(d, f);
-  WChainArgs a{};
+  a = WChainArgs{};
   a.vin = planes_in; a.w = packed_w24; a.scale = scale; a.shift = shift; a.vout = planes_out; a.out = out_nhwc;
   a.B = d->batch; a.H = frame_h(d); a.W = frame_w(d); a.Wq = a.W / 4; a.Cin = d->cin; a.Cout = d->cout;
   a.out_co = d->out_channel_offset;
@@ -738,16 +917,96 @@ int pn_conv2d_wino24_chain_f32(const pn_conv_desc* d, const float* planes_in, co
   a.cout_pad = pn::cdiv(d->cout, 128) * 128;
   a.plane_bytes = (unsigned)((size_t)d->batch * (a.H + 2) * a.Wq * 16);
   a.vin_bytes = (unsigned)(pn_wino4_planes_floats(d->batch, a.H, a.W, d->cin) * 4);
-  a.w_bytes = (unsigned)(pn_conv_wino24_packed_weight_floats(d->cout, d->cin) * 4);
+  const int sets = d->range_strata > 1 ? d->range_strata : 1;
+  a.w_stratum_bytes = (unsigned)(pn_conv_wino24_packed_weight_floats(d->cout, d->cin) * 4);
+  a.w_bytes = a.w_stratum_bytes * (unsigned)sets;
+  a.strata_rows = sets > 1 ? a.H / sets : 0;
+  a.st_part = stat_partials;
 #ifdef PN_WCHAIN_STAMP
   a.stamps = pn_wchain_stamp_buffer;
 #endif
+  return PN_OK;
+}
+
+static int chain2_run(const pn_conv_desc* d, const float* planes_in, const float* packed_w24, const float* scale, const float* shift, float* planes_out,
+                      float* out_nhwc, float* stat_partials, bool head, pn_stream_t stream) {
+  WChainArgs a;
+  Chain2Form f;
+  const int rc = chain2_fill(d, planes_in, packed_w24, scale, shift, planes_out, out_nhwc, stat_partials, head, a, f);
+  if (rc != PN_OK) return rc;
   pn::ProfileSlot ps{};
   const bool prof = pn::take_profile_slot(ps);
   hipStream_t st = pn::S(stream);
   if (f.ks == 2) launch_chain2<2, 1, 1>(a, st, prof, ps);
   else launch_chain2<1, 1, 2>(a, st, prof, ps);
   return pn::check_launch("conv_wchain2_kernel");
+}
+
+int pn_conv2d_wino24_chain_f32(const pn_conv_desc* d, const float* planes_in, const float* packed_w24, const float* scale, const float* shift,
+                               float* planes_out, float* out_nhwc, pn_stream_t stream) {
+  return chain2_run(d, planes_in, packed_w24, scale, shift, planes_out, out_nhwc, nullptr, false, stream);
+}
+
+// floats of the statistics partials of pn_conv2d_wino24_chain_head_f32: [tile][row 2][cout][2]
+size_t pn_conv_wino24_chain_stat_floats(const pn_conv_desc* d) {
+  Chain2Form f;
+  if (!chain2_ok(d, true, f)) return 0;
+  const long long octs = (long long)d->batch * (frame_h(d) / 2) * (frame_w(d) / 4);
+  return (size_t)(octs / (32 * f.qt)) * 2 * d->cout * 2;
+}
+
+// rows of the frame (in the transposed frame: range positions) one tile of the partials covers: tile t = rows [t * rows_per_tile, ...) of
+// the images laid end to end, both rows of a row pair kept apart ([tile][row][cout][2]: row r of pair k of the tile is index k = 0 only
+// when the tile is one pair)
+int pn_conv_wino24_chain_stat_tile_rows(const pn_conv_desc* d) {
+  Chain2Form f;
+  if (!chain2_ok(d, true, f)) return 0;
+  return 2 * (32 * f.qt) / (frame_w(d) / 4);
+}
+
+int pn_conv2d_wino24_chain_head_f32(const pn_conv_desc* d, const float* planes_in, const float* packed_w24, const float* scale, const float* shift,
+                                    float* planes_out, float* out_nhwc, float* stat_partials, pn_stream_t stream) {
+  return chain2_run(d, planes_in, packed_w24, scale, shift, planes_out, out_nhwc, stat_partials, true, stream);
+}
+
+int pn_conv2d_wino24_chain_head_multi_f32(const pn_chain_head_job* jobs, int njobs, pn_stream_t stream) {
+  PN_REQUIRE(jobs && njobs >= 1 && njobs <= kChainMultiJobs, "conv_wino24_chain_head_multi: 1 - 4 jobs");
+  WChainMulti m{};
+  m.njobs = njobs;
+  Chain2Form f0{};
+  for (int j = 0; j < njobs; ++j) {
+    const pn_chain_head_job& q = jobs[j];
+    Chain2Form f;
+    const int rc = chain2_fill(q.desc, q.planes_in, q.packed_w24, q.scale, q.shift, q.planes_out, q.out_nhwc, q.stat_partials, true, m.job[j], f);
+    if (rc != PN_OK) return rc;
+    if (j == 0) f0 = f;
+    PN_REQUIRE(f.ks == f0.ks && f.ct == f0.ct && f.qt == f0.qt, "conv_wino24_chain_head_multi: the jobs must share one kernel form (same map, same cin)");
+    m.first[j + 1] = m.first[j] + m.job[j].qtiles * m.job[j].ctiles;
+  }
+  pn::ProfileSlot ps{};
+  const bool prof = pn::take_profile_slot(ps);
+  hipStream_t st = pn::S(stream);
+  if (f0.ks == 2) launch_chain2_multi<2, 1, 1>(m, st, prof, ps);
+  else launch_chain2_multi<1, 1, 2>(m, st, prof, ps);
+  return pn::check_launch("conv_wchain2_multi_kernel");
+}
+
+int pn_wino24_chain_head_finalize_f32(const pn_head_stat_job* jobs, int njobs, int batch, int frame_rows, int frame_row_pixels, int tile_rows,
+                                      pn_stream_t stream) {
+  PN_REQUIRE(jobs && njobs >= 1 && njobs <= kHeadFinJobs && batch >= 1 && frame_rows >= 1 && tile_rows >= 1 && frame_rows % tile_rows == 0,
+             "wino24_chain_head_finalize: bad arguments");
+  HeadFinArgs f{};
+  f.njobs = njobs; f.B = batch; f.rows = frame_rows; f.tile_rows = tile_rows; f.row_pixels = frame_row_pixels;
+  for (int j = 0; j < njobs; ++j) {
+    const pn_head_stat_job& q = jobs[j];
+    PN_REQUIRE(q.partials && q.table && q.channels >= 1 && q.channel_offset >= 0 && q.channel_offset + q.channels <= q.cout_total,
+               "wino24_chain_head_finalize: bad job");
+    PN_REQUIRE(q.strata <= 8 && (q.strata <= 1 ? q.channels <= 256 : (frame_rows / tile_rows) % q.strata == 0),
+               "wino24_chain_head_finalize: per-channel jobs take <= 256 channels; strata (<= 8) must divide the sample's tiles");
+    f.job[j] = HeadFinJob{q.partials, q.cout_total, q.channel_offset, q.channels, q.strata, q.gamma, q.beta, q.eps, q.table};
+  }
+  hipLaunchKernelGGL(wchain_head_finalize_kernel, dim3((unsigned)(njobs * batch * 8)), dim3(256), 0, pn::S(stream), f);
+  return pn::check_launch("wchain_head_finalize_kernel");
 }
 
 }  // extern "C"

@@ -12,6 +12,7 @@
 // Thread mapping: 16-byte (4-channel) vectors; a block of 256 threads covers 256*4/C pixels per
 // pass, consecutive lanes read consecutive 16 B => every wave instruction moves 1 KiB.
 #include "pn_common.h"
+#include "wino_planes.h"
 
 namespace {
 
@@ -152,6 +153,70 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(GnArgs a) {
   }
 }
 
+// The normalisation pass writing the F(4, 3) PLANES of its result (conv_wchain.hip) instead of the map: RSNorm + ReLU of the head's shared
+// convolution feed only 3x3 convolutions, which then run in the Winograd domain without a separate transform pass.  One thread = one quad
+// of the frame (four pixels along the Winograd axis) x four channels: it normalises the quad's six input pixels itself (the two
+// neighbours' values are recomputed, nothing is exchanged) and stores six fragments; out2 = out * mul + add likewise (the
+// position-calibrated copy for the heat-map branch).  transposed: the Winograd axis is the map's H (rows of the frame = range positions).
+struct GnPlanesArgs {
+  GnArgs g;
+  float* planes;
+  float* planes2;
+  int transposed;
+  int FH, FW, Wq;      // the frame
+  unsigned plane_floats;
+};
+
+__global__ __launch_bounds__(256) void gn_apply_planes_kernel(GnPlanesArgs p) {
+  const GnArgs& a = p.g;
+  const int c4n = a.C >> 2;
+  const int wps = a.W / a.strata, cpg = a.C / a.cgroups;
+  const long long total = (long long)a.B * p.FH * p.Wq * c4n;
+  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+    // lanes along the quads of a frame row (the planes' contiguous axis), then rows, channel vectors, images
+    const int xq = (int)(it % p.Wq);
+    long long rest = it / p.Wq;
+    const int r = (int)(rest % p.FH); rest /= p.FH;
+    const int c4 = (int)(rest % c4n);
+    const int b = (int)(rest / c4n);
+    f32x4 d[6], d2[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int fx = 4 * xq - 1 + k;      // position along the Winograd axis
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      d[k] = z;
+      d2[k] = z;
+      if (fx < 0 || fx >= p.FW) continue;
+      const int my = p.transposed ? fx : r, mx = p.transposed ? r : fx;      // map coordinates
+      const int s = mx / wps;
+      const float* smean = a.stat + ((size_t)b * a.strata + s) * a.cgroups * 2;
+      f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + my) * a.W + mx) * a.ps + a.co + c4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = c4 * 4 + e;
+        const float mean = smean[2 * (c / cpg)], rstd = smean[2 * (c / cpg) + 1];
+        const float ga = a.gamma ? a.gamma[s * a.C + c] : 1.f, be = a.beta ? a.beta[s * a.C + c] : 0.f;
+        v[e] = pn::apply_act((v[e] - mean) * rstd * ga + be, a.act);      // (the expression of gn_apply_kernel: bit-identical values)
+      }
+      d[k] = v;
+      if (p.planes2) {
+        const size_t q = ((size_t)my * a.W + mx) * a.C + c4 * 4;
+        const f32x4 m = *reinterpret_cast<const f32x4*>(a.mul + q);
+        const f32x4 ad = *reinterpret_cast<const f32x4*>(a.add + q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d2[k][e] = v[e] * m[e] + ad[e];
+      }
+    }
+    f32x4 v6[6];
+    pn::wino4_input_transform4(d, v6);
+    pn::wino4_store_planes(p.planes, v6, c4, c4n, p.plane_floats, b, r, xq, p.FH, p.Wq);
+    if (p.planes2) {
+      pn::wino4_input_transform4(d2, v6);
+      pn::wino4_store_planes(p.planes2, v6, c4, c4n, p.plane_floats, b, r, xq, p.FH, p.Wq);
+    }
+  }
+}
+
 int pick_splits(int B, int H, int strata) {
   int splits = 1;
   while (splits < H && (long long)B * strata * splits < 512) splits *= 2;
@@ -198,6 +263,44 @@ int pn_groupnorm_strat_fwd(const float* x, int batch, int h, int w, int c, int p
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ngroups), dim3(64), 0, pn::S(stream), a);
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(kThreads), 0, pn::S(stream), a);
   return pn::check_launch("groupnorm_strat");
+}
+
+/* pn_groupnorm_strat_fwd whose result leaves as F(4, 3) planes (pn_wino4_planes_floats(batch, h, w, c) floats each; transpose_hw: of the
+ * transposed map, then sized (batch, w, h, c)); planes2 (nullable) = the planes of out * mul + add */
+int pn_groupnorm_strat_planes_f32(const float* x, int batch, int h, int w, int c, int pixel_stride, int channel_offset, int channel_groups,
+                                  int range_strata, const float* gamma, const float* beta, float eps, int act, const float* mul, const float* add,
+                                  int transpose_hw, float* planes, float* planes2, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(x && planes && workspace, "groupnorm_planes: null pointer");
+  PN_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && c >= 8 && c % 8 == 0 && c <= 4 * kThreads && (4 * kThreads) % c == 0, "groupnorm_planes: bad sizes");
+  PN_REQUIRE(pixel_stride % 4 == 0 && channel_offset % 4 == 0, "groupnorm_planes: strides / offsets must be multiples of 4 floats");
+  PN_REQUIRE(channel_groups >= 1 && c % channel_groups == 0 && channel_groups <= 128 && (channel_groups & (channel_groups - 1)) == 0,
+             "groupnorm_planes: channel_groups must be a power of two <= 128 dividing the channel count");
+  PN_REQUIRE(range_strata >= 1 && w % range_strata == 0, "groupnorm_planes: range axis not divisible by range_strata");
+  PN_REQUIRE((planes2 == nullptr) || (mul && add), "groupnorm_planes: planes2 needs mul and add");
+  const int fh = transpose_hw ? w : h, fw = transpose_hw ? h : w;
+  PN_REQUIRE(fw % 4 == 0, "groupnorm_planes: the Winograd axis must be a multiple of 4 pixels");
+  if (workspace_bytes < pn_groupnorm_workspace_bytes(batch, channel_groups, range_strata))
+    return pn::fail(PN_ERR_WORKSPACE, "groupnorm_planes: workspace too small");
+  GnPlanesArgs p{};
+  GnArgs& a = p.g;
+  a.x = x; a.B = batch; a.H = h; a.W = w; a.C = c; a.ps = pixel_stride; a.co = channel_offset;
+  a.cgroups = channel_groups; a.strata = range_strata;
+  a.splits = pick_splits(batch, h, range_strata);
+  if (a.splits > 256) a.splits = 256;
+  a.rows_per_split = pn::cdiv(h, a.splits);
+  a.gamma = gamma; a.beta = beta; a.eps = eps; a.act = act;
+  a.out = nullptr; a.ops = 0; a.oco = 0; a.mul = mul; a.add = add; a.out2 = nullptr; a.o2ps = 0; a.o2co = 0;
+  a.part = static_cast<double*>(workspace);
+  const size_t ngroups = (size_t)batch * range_strata * channel_groups;
+  a.stat = reinterpret_cast<float*>(a.part + ngroups * 256 * 2);
+  p.planes = planes; p.planes2 = planes2; p.transposed = transpose_hw; p.FH = fh; p.FW = fw; p.Wq = fw / 4;
+  p.plane_floats = (unsigned)((size_t)batch * (fh + 2) * p.Wq * 4);
+  dim3 grid(a.splits, range_strata, batch);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(kThreads), 0, pn::S(stream), a);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ngroups), dim3(64), 0, pn::S(stream), a);
+  const long long total = (long long)batch * fh * p.Wq * (c / 4);
+  hipLaunchKernelGGL(gn_apply_planes_kernel, dim3((unsigned)std::min<long long>(4096, (total + 255) / 256)), dim3(256), 0, pn::S(stream), p);
+  return pn::check_launch("groupnorm_planes");
 }
 
 /* normalisation pass alone, with the group statistics already on the device (written by the producing convolution's

@@ -11,7 +11,9 @@ to two constant (H,W,C) maps at plan-build time (they do not depend on the input
 from __future__ import annotations
 
 import copy
+import ctypes as C
 import logging
+import os
 from typing import Dict, List
 
 import torch
@@ -20,6 +22,8 @@ from torch import nn
 from . import hip, ops
 from .builder import BBOX_HEADS
 from .nn_utils import PlanCache, RSNorm, Sequential, eval_only
+
+_HEAD_CHAIN = os.environ.get("PN_HEAD_CHAIN", "1") != "0"      # first-stage branch convolutions chained in the Winograd domain (conv_wchain.hip)
 
 
 class RangeStratified(nn.Module):
@@ -394,7 +398,7 @@ class CenterHeadSingle(CenterHead):
         c_sh = self.shared_conv[0].out_channels
         if c_sh % 32 != 0 or c_sh > 128:
             return None
-        first, last = [], []
+        first, last, raws = [], [], []
         for name in self.heads:
             mods = list(getattr(self, name)._modules.values())
             if isinstance(mods[0], RangeStratified):
@@ -418,8 +422,11 @@ class CenterHeadSingle(CenterHead):
             if cmid % 32 != 0 or cmid > 128 or fin.kernel_size[0] != fin.kernel_size[1]:
                 return None
             first.append((name, lay, st, cmid))
+            raws.append(dict(w=(conv.weight if isinstance(mods[0], RangeStratified) else _dense_weight(conv)).detach().float().contiguous(),
+                             bias=None if conv.bias is None else conv.bias.detach().float().contiguous(),
+                             strata=mods[0].ngroups if isinstance(mods[0], RangeStratified) else 0))
             last.append((name, ops.ConvLayer(_dense_weight(fin), stride=1, pad=fin.padding[0], shift=fin.bias, act=ops.ACT_NONE), fin.out_channels))
-        return dict(shared=_conv_bias(self.shared_conv[0], ops.ACT_NONE), first=first, last=last, c_sh=c_sh,
+        return dict(shared=_conv_bias(self.shared_conv[0], ops.ACT_NONE), first=first, last=last, c_sh=c_sh, first_raw=raws, chain={},
                     rs=(rs.num_groups, rs.groupnorm.weight.detach().float().contiguous(), rs.groupnorm.bias.detach().float().contiguous(), rs.groupnorm.eps))
 
     def _fused_ok(self, fz, b, h, w) -> bool:
@@ -433,6 +440,122 @@ class CenterHeadSingle(CenterHead):
                 return False
         return b == 1 or (h * w) % 64 == 0
 
+    # ---- r4: the first-stage branches in the Winograd domain (csrc/conv_wchain.hip, pn_conv2d_wino24_chain_head_f32) ----------------------
+    def _chain_head_plan(self, fz, b, h, w, dev, calibrated: bool):
+        """The branch convolutions 64 -> 64 as chained F(2,3)xF(4,3) launches on the TRANSPOSED map (the Winograd axis is the azimuth, the
+        frame's rows are the range positions -- a RangeStratified branch then takes one weight set per row stratum): the RSNorm pass writes
+        planes instead of the map, the launches write the raw branch maps and the GroupNorm statistics partials, one small launch folds
+        those into the affine tables the last convolutions apply on load.  None when a shape does not fit (the tiled multi-job launch runs)."""
+        key = (b, h, w, calibrated)
+        if key in fz["chain"]:
+            return fz["chain"][key]
+        plan = None
+        lib = hip.load()
+        c_sh = fz["c_sh"]
+        ok = ops._CHAIN_ON and _HEAD_CHAIN and c_sh % 32 == 0 and h % 4 == 0 and w % 2 == 0 and lib.pn_wino4_planes_floats(b, w, h, c_sh) > 0
+        if ok:
+            # launches: every stratified branch alone; the heat-map branch alone when it reads the calibrated copy; the rest together
+            groups, rest = [], []
+            for (name, lay, st, cmid), raw in zip(fz["first"], fz["first_raw"]):
+                if raw["strata"] > 1:
+                    groups.append(dict(src="xs", members=[(name, st, cmid, raw)], strata=raw["strata"]))
+                elif name == "hm" and calibrated:
+                    groups.append(dict(src="hm", members=[(name, st, cmid, raw)], strata=0))
+                else:
+                    rest.append((name, st, cmid, raw))
+            if rest:
+                groups.insert(0, dict(src="xs", members=rest, strata=0))
+            cm_tot, off = sum(cm for *_, cm in fz["first"]), 0
+            offsets, tile_rows = {}, None
+            for g in groups:
+                cout = sum(m[2] for m in g["members"])
+                S = g["strata"]
+                d = ops.ConvDesc(b, h, w, c_sh, cout, 1, 3, 3, 1, 1, 1, c_sh, 0, cm_tot, off, ops.ACT_NONE, 0, S, 0, 0, 0)
+                d.transpose_hw = 1
+                nstat = lib.pn_conv_wino24_chain_stat_floats(C.byref(d))
+                if nstat == 0 or cout % 32:
+                    ok = False
+                    break
+                tr = lib.pn_conv_wino24_chain_stat_tile_rows(C.byref(d))
+                tile_rows = tr if tile_rows is None else tile_rows
+                ok = ok and tr == tile_rows
+                nw = lib.pn_conv_wino24_packed_weight_floats(cout, c_sh)
+                sets = max(S, 1)
+                packed = torch.empty(nw * sets, dtype=torch.float32, device=dev)
+                keep = []
+                if S > 1:      # one member: weight (S * cmid, c_sh, 3, 3), bias (S * cmid)
+                    wr = g["members"][0][3]["w"]
+                    cm = g["members"][0][2]
+                    for k in range(S):
+                        wt = wr[k * cm:(k + 1) * cm].transpose(2, 3).contiguous()
+                        keep.append(wt)
+                        hip.call("pn_pack_conv_weight_wino24_f32", wt.data_ptr(), cout, c_sh, packed.data_ptr() + 4 * nw * k, hip.stream())
+                    bias = g["members"][0][3]["bias"]
+                else:
+                    wt = torch.cat([m[3]["w"] for m in g["members"]], 0).transpose(2, 3).contiguous()
+                    keep.append(wt)
+                    hip.call("pn_pack_conv_weight_wino24_f32", wt.data_ptr(), cout, c_sh, packed.data_ptr(), hip.stream())
+                    bs = [m[3]["bias"] if m[3]["bias"] is not None else torch.zeros(m[2], dtype=torch.float32, device=dev) for m in g["members"]]
+                    bias = torch.cat(bs).contiguous()
+                g.update(desc=d, packed=packed, bias=bias, cout=cout, nstat=int(nstat), off=off, keep=keep)
+                o2 = 0
+                for name, st, cmid, raw in g["members"]:
+                    offsets[name] = (off + o2, o2, g)
+                    o2 += cmid
+                off += cout
+            if ok:
+                torch.cuda.current_stream().synchronize()      # (the transposed weight copies are temporaries of the packing launches)
+                for g in groups:
+                    g.pop("keep")
+                plan = dict(groups=groups, offsets=offsets, cm_tot=cm_tot, tile_rows=int(tile_rows), planes=int(lib.pn_wino4_planes_floats(b, w, h, c_sh)))
+        fz["chain"][key] = plan
+        return plan
+
+    def _first_stage_chained(self, fz, cp, raw, mul, add):
+        """-> (mid, {name: (table, strata, cmid, channel offset in mid)})"""
+        lib = hip.load()
+        b, h, w, c_sh = raw.shape
+        dev, st = raw.device, hip.stream()
+        f32 = dict(dtype=torch.float32, device=dev)
+        s_rs, g_rs, b_rs, eps_rs = fz["rs"]
+        planes_xs = torch.empty(cp["planes"], **f32)
+        planes_hm = torch.empty(cp["planes"], **f32) if mul is not None else None
+        nbytes = lib.pn_groupnorm_workspace_bytes(b, 1, s_rs)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        hip.call("pn_groupnorm_strat_planes_f32", raw.data_ptr(), b, h, w, c_sh, c_sh, 0, 1, s_rs, hip.ptr(g_rs), hip.ptr(b_rs), float(eps_rs), ops.ACT_RELU,
+                 hip.ptr(mul), hip.ptr(add), 1, planes_xs.data_ptr(), hip.ptr(planes_hm), ws.data_ptr(), nbytes, st)
+        mid = torch.empty((b, h, w, cp["cm_tot"]), **f32)
+        prof = ops._PROFILER
+        parts = [torch.empty(g["nstat"], **f32) for g in cp["groups"]]
+        cjobs = (hip.ChainHeadJob * len(parts))()
+        for cj, g, part in zip(cjobs, cp["groups"], parts):
+            src = planes_hm if (g["src"] == "hm" and planes_hm is not None) else planes_xs
+            cj.desc = C.pointer(g["desc"])
+            cj.planes_in, cj.packed_w24, cj.scale, cj.shift = src.data_ptr(), g["packed"].data_ptr(), None, hip.ptr(g["bias"])
+            cj.planes_out, cj.out_nhwc, cj.stat_partials = None, mid.data_ptr(), part.data_ptr()
+        if prof is not None:
+            ev = prof.begin(st)
+        # one launch for every branch group (apart: 128 - 384 short blocks each, the chip half empty between them)
+        hip.call("pn_conv2d_wino24_chain_head_multi_f32", cjobs, len(parts), st)
+        if prof is not None:
+            flops = 2.0 * b * h * w * cp["cm_tot"] * c_sh * 9
+            prof.end(ev, flops, st, tag=f"{h}x{w} {c_sh}->{cp['cm_tot']} k3 F(2,3)xF(4,3) head", issued=flops / 3.0)
+        jobs = (hip.HeadStatJob * len(fz["first"]))()
+        tabs = {}
+        keep = []
+        for k, (name, lay, stt, cmid) in enumerate(fz["first"]):
+            moff, goff, g = cp["offsets"][name]
+            gi = cp["groups"].index(g)
+            S = g["strata"] if g["strata"] > 1 else 1
+            tab = torch.empty((b, S, cmid, 2), **f32)
+            j = jobs[k]
+            j.partials, j.cout_total, j.channel_offset, j.channels, j.strata = parts[gi].data_ptr(), g["cout"], goff, cmid, g["strata"]
+            j.gamma, j.beta, j.eps, j.table = hip.ptr(stt["gamma"]), hip.ptr(stt["beta"]), float(stt["eps"]), tab.data_ptr()
+            tabs[name] = (tab, S, cmid, moff)
+            keep.append(tab)
+        hip.call("pn_wino24_chain_head_finalize_f32", jobs, len(fz["first"]), b, w, h, cp["tile_rows"], st)
+        return mid, tabs
+
     def _forward_fused(self, plan, x: torch.Tensor):
         fz = plan["fused"]
         b, h, w, _ = x.shape
@@ -442,12 +565,19 @@ class CenterHeadSingle(CenterHead):
         mul, add = self._calibration(plan, x[..., :c_sh])
         s_rs, g_rs, b_rs, eps_rs = fz["rs"]
         raw = torch.empty((b, h, w, c_sh), **f32)
+        wino_shared = fz["shared"]._use_wino4(b, h, w, False) and not getattr(self, "force_stats_epilogue", False)
+        cp = self._chain_head_plan(fz, b, h, w, dev, mul is not None) if (wino_shared and not getattr(self, "force_tiled_branches", False)) else None
+        if cp is not None:
+            # r4: shared convolution (F(4,3)), RSNorm + ReLU straight into planes, the branch convolutions chained in the Winograd domain
+            fz["shared"](x, out=raw)
+            mid, tabs_by_name = self._first_stage_chained(fz, cp, raw, mul, add)
+            return self._last_stage(fz, mid, [tabs_by_name[name] for name, *_ in fz["first"]], f32)
         j0 = ops.ConvJob(fz["shared"], x, raw)
         xcat = torch.empty((b, h, w, c_sh * (2 if mul is not None else 1)), **f32)
         cm_tot = sum(cm for *_, cm in fz["first"])
         mid = torch.empty((b, h, w, cm_tot), **f32)
         srcs = {name: (xcat, c_sh if (name == "hm" and mul is not None) else 0) for name, *_ in fz["first"]}   # branch input: (map, channel offset)
-        if fz["shared"]._use_wino4(b, h, w, False) and not getattr(self, "force_stats_epilogue", False):
+        if wino_shared:
             # the shared convolution on the F(4, 3) kernel (44 us against 73 for the direct multi-job launch with the statistics
             # epilogue, 384 -> 64 at 128 x 128) + the stand-alone RSNorm pass (statistics, finalize, apply: the kernels of 4.3)
             fz["shared"](x, out=raw)
@@ -478,7 +608,12 @@ class CenterHeadSingle(CenterHead):
             off += cmid
         ops.conv_multi(jobs1, 3)
         ops.conv_stats_finalize(jobs1, 3)
-        # launch 4: every last convolution, GroupNorm + ReLU applied while the input tile is loaded
+        return self._last_stage(fz, mid, tabs, f32)
+
+    def _last_stage(self, fz, mid, tabs, f32):
+        """launch 4: every last convolution, GroupNorm + ReLU applied while the input tile is loaded.  tabs: per branch (affine table, strata,
+        channels, channel offset in mid)"""
+        b, h, w, _ = mid.shape
         widths = [(co + 3) // 4 * 4 for *_, co in fz["last"]]
         out = torch.empty((b, h, w, sum(widths)), **f32)
         jobs, off, outs = [], 0, {}

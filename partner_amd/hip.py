@@ -36,6 +36,20 @@ class RowPiece(C.Structure):
     _fields_ = [("src", C.c_void_p), ("pixel_stride", C.c_int32), ("rows", C.c_int32)]
 
 
+class HeadStatJob(C.Structure):
+    """mirror of ``pn_head_stat_job``"""
+
+    _fields_ = [("partials", C.c_void_p), ("cout_total", C.c_int32), ("channel_offset", C.c_int32), ("channels", C.c_int32), ("strata", C.c_int32),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("table", C.c_void_p)]
+
+
+class ChainHeadJob(C.Structure):
+    """mirror of ``pn_chain_head_job``"""
+
+    _fields_ = [("desc", C.POINTER(ConvDesc)), ("planes_in", C.c_void_p), ("packed_w24", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("planes_out", C.c_void_p), ("out_nhwc", C.c_void_p), ("stat_partials", C.c_void_p)]
+
+
 class ConvJob(C.Structure):
     """mirror of ``pn_conv_job``"""
 
@@ -200,6 +214,12 @@ SIGNATURES = {
     "pn_pack_conv_weight_wino24_f32": (_I, [_P, _I, _I, _P, _P]),
     "pn_conv_wino24_chain_supported": (_I, [_P]),
     "pn_conv2d_wino24_chain_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "pn_conv_wino24_chain_stat_floats": (_SZ, [_P]),
+    "pn_conv_wino24_chain_stat_tile_rows": (_I, [_P]),
+    "pn_conv2d_wino24_chain_head_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pn_wino24_chain_head_finalize_f32": (_I, [_P, _I, _I, _I, _I, _I, _P]),
+    "pn_conv2d_wino24_chain_head_multi_f32": (_I, [_P, _I, _P]),
+    "pn_groupnorm_strat_planes_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _I, _P, _P, _P, _SZ, _P]),
     "pn_conv2d_wgrad_wino4_workspace_bytes": (_SZ, [_P]),
     "pn_conv2d_wgrad_wino4_f32": (_I, [_P, _P, _P, _P, _I, _P, _SZ, _P]),
     "pn_pillar_conv_packed_weight_floats": (_SZ, [_I, _I]),

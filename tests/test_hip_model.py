@@ -474,6 +474,11 @@ FUSED_HEAD_CASES = [
     (2, 12, 128, 40, "CenterHeadSinglePos"),
     (3, 8, 256, 24, "CenterHeadSingle"),
     (1, 37, 128, 96, "CenterHeadSinglePos"),     # odd row count: the last m tile is ragged
+    # r4: maps large enough for the F(4,3) shared convolution take the CHAINED first stage (RSNorm -> planes, branch convolutions in the Winograd
+    # domain on the transposed map incl. the range-stratified one, statistics partials in their epilogue): checked against the tiled one too
+    (1, 128, 128, 24, "CenterHeadSinglePos"),
+    (2, 64, 128, 40, "CenterHeadSinglePos"),
+    (1, 128, 128, 32, "CenterHeadSingle"),
 ]
 
 
@@ -515,6 +520,15 @@ def test_fused_head_vs_oracle_and_unfused(dev, case):
         assert tuple(out[k].shape) == tuple(r.shape), k
         assert rel_err(out[k], r.numpy()) < REL, k
         np.testing.assert_allclose(out[k].cpu().numpy(), r.numpy(), rtol=1e-4, atol=1e-4 * float(r.abs().max()))
+    chained = h._chain_head_plan(plan["fused"], b, a_rows, r_cols, dev, cls == "CenterHeadSinglePos") is not None and plan["fused"]["shared"]._use_wino4(b, a_rows, r_cols, False)
+    assert chained == (a_rows * b >= 128), "the large maps must take the chained first stage"
+    if chained:
+        h.force_tiled_branches = True
+        tl = h(x.to(dev))["det_preds"][0]
+        h.force_tiled_branches = False
+        for k in out:
+            assert rel_err(out[k], tl[k].cpu().numpy()) < 2e-5, k
+            assert not all(torch.equal(out[j], tl[j]) for j in out)          # (another kernel family did run)
     h.force_unfused = True
     un = h(x.to(dev))["det_preds"][0]
     for k in out:
