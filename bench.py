@@ -684,25 +684,35 @@ def main():
                           frac=round(iss / (m * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3), tflops_algorithmic_equiv=round(den / (m * 1e-3) / 1e12, 1))
                   for t, (f, m, n, iss, den) in sorted(tags.items(), key=lambda kv: -kv[1][1])}
         dom_tag, dom = max(tags.items(), key=lambda kv: kv[1][1])
-        roofline = dict(bound="mfma", kernel="conv_wchain2_kernel / conv_wchain_kernel (the RPN blocks' stride-1 3x3 layers chained in the Winograd domain, "
-                                             "F(2,3)xF(4,3) or F(4,3): conv_wchain.hip) + conv_mfma_kernel (stride-2 layers, deblocks, head branches) + "
-                                             "conv_wino4_ks_kernel (head's shared convolution) + pillar_conv.hip (block 0's first layer on (pillar, tap) pairs); "
-                                             "all on fp32 v_mfma_f32_32x32x2_f32",
-                        achieved=round(issued, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(issued / PEAK_F32_MFMA_TFLOPS, 4),
-                        counts="FLOPs the kernels ISSUE to the matrix pipes (chained F(2,3)xF(4,3) launches: 1/3 of the direct algorithm's 9 MACs per "
-                               "output, F(4,3): 1/2, F(2,3): 2/3; first layer: the pairs it multiplies) / the kernels' own execution time.  r4 cut the "
-                               "ISSUED work of the 256^2 / 128^2 layers by a third at shorter kernel times, so this fraction fell (r3: 0.556) while frames/s "
-                               "rose: compare kernel times (by_layer), not fractions, across rounds",
-                        frac_in_flight=round(issued_f / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),      # (both loops ran args.steps steps)
-                        frac_in_flight_of="issued FLOPs per frame / ms_per_step (the headline regime, frames in flight) / peak",
+        dom_kernel = ("conv_wchain2_kernel" if "F(2,3)xF(4,3)" in dom_tag else "conv_wchain_kernel" if "chain" in dom_tag else "conv_mfma_kernel") + \
+                     " (conv_wchain.hip / conv_mfma.hip), fp32 v_mfma_f32_32x32x2_f32: layer " + dom_tag
+        dom_tf = dom[3] / (dom[1] * 1e-3) / 1e12
+        dom_pmc_name = "conv_wchain2_kernel<1, 1, 2>" if ("F(2,3)xF(4,3) chain" in dom_tag and dom_tag.startswith("256x256")) else None
+        roofline = dict(bound="mfma", kernel=dom_kernel,
+                        achieved=round(dom_tf, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(dom_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                        counts="the DOMINANT kernel (most time per frame): the FLOPs it ISSUES to the matrix pipes per launch (chained F(2,3)xF(4,3): "
+                               "24 products per 8 outputs = 1/3 of the direct algorithm's 9 MACs per output; F(4,3): 1/2) / its average launch duration "
+                               "(start/stop events on its own dispatches).  Up to r3 this object's frac was the average over ALL conv launches (r3: "
+                               "0.556); that figure is all_conv.frac now -- r4 cut the issued work of the 256^2 / 128^2 layers by a third at shorter "
+                               "kernel times, so the all-launch fraction fell while frames/s rose",
                         dominant_kernel=dict(layer=dom_tag, launches_per_step=round(dom[2] / args.steps, 2), us=round(1e3 * dom[1] / dom[2], 2),
-                                             gflop_issued_per_launch=round(dom[3] / dom[2] / 1e9, 3),
-                                             frac=round(dom[3] / (dom[1] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)),
+                                             gflop_issued_per_launch=round(dom[3] / dom[2] / 1e9, 3), share_of_conv_time=round(dom[1] / ms, 3)),
+                        all_conv=dict(achieved=round(issued, 3), frac=round(issued / PEAK_F32_MFMA_TFLOPS, 4),
+                                      kernels="conv_wchain2_kernel / conv_wchain_kernel (the RPN blocks' stride-1 3x3 layers and the head's branch "
+                                              "convolutions chained in the Winograd domain) + conv_mfma_kernel (stride-2 layers, deblocks) + "
+                                              "conv_wino4_ks_kernel (head's shared convolution) + conv_small_n_multi_kernel (head's last convolutions, "
+                                              "VALU) + pillar_conv.hip (block 0's first layer on (pillar, tap) pairs)"),
+                        frac_in_flight=round(issued_f / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),      # (both loops ran args.steps steps)
+                        frac_in_flight_of="issued FLOPs of ALL conv launches per frame / ms_per_step (the headline regime, frames in flight) / peak",
                         algorithmic_equiv=dict(tflops=round(dense, 3), over_peak=round(dense / PEAK_F32_MFMA_TFLOPS, 4),
                                                note="the direct dense algorithm's FLOPs (every layer 2*pixels*Cout*Cin*KH*KW, first layer included) over the "
-                                                    "same kernel time: what the FLOP-reducing forms buy; not a roofline fraction, may exceed 1"),
-                        traffic=committed_pmc_bytes(("conv_mfma_kernel", "conv_wino", "conv_wchain", "conv_small_n", "conv_multi", "pair_gemm", "pair_reduce"), per="launch"),
-                        traffic_unit="HBM bytes per conv launch (offline PMC passes of this command, profiles/%s)" % os.path.basename(pmc_traffic_path() or "none"),
+                                                    "kernel time of all conv launches: what the FLOP-reducing forms buy; not a roofline fraction, may exceed 1"),
+                        traffic=committed_pmc_bytes((dom_pmc_name,), per="launch") if dom_pmc_name else None,
+                        traffic_unit="HBM bytes per launch of the dominant kernel (offline PMC passes of this command, profiles/%s); algorithmic: "
+                                     "planes in + planes out = 2 x 1.5 x pixels x C x 4 B = 100.7 MB at 256^2 x 128 (+ 1.2 MB of weights)"
+                                     % os.path.basename(pmc_traffic_path() or "none"),
+                        traffic_all_conv=committed_pmc_bytes(("conv_mfma_kernel", "conv_wino", "conv_wchain", "conv_small_n", "conv_multi", "pair_gemm",
+                                                              "pair_reduce"), per="launch"),
                         launches=launches, launches_per_step=round(launches / args.steps, 2), flops_issued_per_launch=round(issued_f / launches),
                         avg_launch_us=round(1e3 * ms / launches, 2), conv_ms_per_step=round(ms / args.steps, 4),
                         paired_with="single_stream_ms_per_step (one frame in flight)",

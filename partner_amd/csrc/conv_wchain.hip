@@ -71,6 +71,7 @@ unsigned long long* pn_wchain_stamp_buffer = nullptr;
 #define WC_STAMP(k)                                                                                                      \
   do {                                                                                                                   \
     if (lane == 0) a.stamps[((size_t)blockIdx.x * 16 + w) * 4 + (k)] = __builtin_amdgcn_s_memtime();                       \
+    if (lane == 0 && w == 0 && ((k) == 0 || (k) == 3)) a.stamps[((size_t)blockIdx.x * 16 + 12) * 4 + (k)] = wall_clock64(); /* 100 MHz */ \
   } while (0)
 #else
 #define WC_STAMP(k) do { } while (0)
@@ -429,10 +430,12 @@ __device__ __forceinline__ void wchain2_body(const WChainArgs& a, const int bid0
           b[3][e] = r3[0]; b[3][e + 1] = r3[1];
         }
       }
+      if constexpr (PN_WCHAIN_EXP & 8) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) acc[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[slot][s2][j], b[s2][j], acc[s2], 0, 0, 0);
+      if constexpr (PN_WCHAIN_EXP & 8) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       load_step(nx, slot);
       __builtin_amdgcn_sched_barrier(0);

@@ -24,9 +24,20 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int SG_WIN = 4096;      // sites per sorted window
+#ifndef PN_SG_EXP
+#define PN_SG_EXP 0      // diagnostic builds only (tools/micro/group_rows_check.hip): bit 0 no mask build, bit 1 no sort
+#endif
 
-// one block per window: masks -> bitonic sort of (mask, site) in LDS -> perm (site per slot, -1 past the live sites) and the union mask
-// of every 32-slot group
+// one block per window: masks -> bitonic sort of (mask, site) -> perm (site per slot, -1 past the live sites) and the union mask of every
+// 32-slot group.  A thread keeps FOUR consecutive keys in registers: the exchange distances 1, 2 stay inside the thread, 4 .. 128 inside
+// the wave (lane shuffles), only distances >= 256 go through LDS -- 10 of the 78 stages (the all-LDS version spent 63 us per launch, most
+// of it in 78 block-wide barriers, on the 25 - 50 blocks a frame has).
+__device__ __forceinline__ void sg_cmpx(unsigned long long& x, unsigned long long& y, bool up) {
+  const unsigned long long lo = x < y ? x : y, hi = x < y ? y : x;
+  x = up ? lo : hi;
+  y = up ? hi : lo;
+}
+
 __global__ __launch_bounds__(1024) void sparse_group_rows_kernel(const int32_t* __restrict__ nbr, const int32_t* __restrict__ n_valid, int cap, int taps,
                                                                  int32_t* __restrict__ perm, uint32_t* __restrict__ gmask) {
   __shared__ unsigned long long key[SG_WIN];
@@ -37,40 +48,94 @@ __global__ __launch_bounds__(1024) void sparse_group_rows_kernel(const int32_t* 
     for (int i = threadIdx.x; i < SG_WIN / 32 && (base >> 5) + i < (cap + 31) / 32; i += 1024) gmask[(base >> 5) + i] = 0u;
     return;
   }
-  for (int i = threadIdx.x; i < SG_WIN; i += 1024) {
-    const int row = base + i;
-    unsigned long long k = 1ull << 40;       // dead slots sort behind every live one
-    if (row < n) {
-      unsigned m = 0;
-      const int32_t* p = nbr + (size_t)row * taps;
-      for (int t = 0; t < taps; ++t) m |= (p[t] >= 0 ? 1u : 0u) << t;
-      k = ((unsigned long long)m << 12) | (unsigned)i;
+  const int t = threadIdx.x;
+  // the window's masks: its rows of the neighbour table are one contiguous block of taps-bit records -- read it coalesced, one ballot per 64
+  // entries = 64 bits of the window's bit stream in LDS, a row's mask = bits [taps i, taps (i + 1)) of the stream.  (A thread walking its own
+  // rows' 27 entries issued 108 scattered loads; OR-ing bits into per-row words with LDS atomics put ~27 lanes on one address: 42 of the
+  // kernel's 63 us either way.)
+  {
+    const int live = min(n - base, SG_WIN) * taps;
+    const int words = (SG_WIN * taps + 63) / 64;       // <= 4096 * 32 / 64 = 2048 of the array's 4096
+    const int32_t* p = nbr + (size_t)base * taps;
+    const int wave = t >> 6, lane = t & 63;
+    constexpr int UN = 12;
+    for (int w0 = wave; w0 < words && !(PN_SG_EXP & 1); w0 += 16 * UN) {
+      int32_t v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int f = (w0 + 16 * u) * 64 + lane;
+        v[u] = f < live ? p[f] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const unsigned long long bits = __ballot(v[u] >= 0);
+        if (lane == 0 && w0 + 16 * u < words) key[w0 + 16 * u] = bits;
+      }
     }
-    key[i] = k;
+    if (t == 0) key[words] = 0ull;      // (a record that ends on the stream's last bit still reads the word behind it)
   }
   __syncthreads();
-  for (int k = 2; k <= SG_WIN; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < SG_WIN / 2; i += 1024) {
-        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
-        const bool up = (lo & k) == 0;
-        const unsigned long long x = key[lo], y = key[hi];
-        if ((x > y) == up) {
-          key[lo] = y;
-          key[hi] = x;
-        }
+  unsigned long long e[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * t + r;
+    const unsigned o = (unsigned)(i * taps), sh = o & 63u;
+    const unsigned long long lo = key[o >> 6], hi = key[(o >> 6) + 1];
+    const unsigned m = (unsigned)((lo >> sh) | (sh ? hi << (64u - sh) : 0ull)) & (taps >= 32 ? ~0u : (1u << taps) - 1u);
+    e[r] = base + i < n ? (((unsigned long long)m << 12) | (unsigned)i) : (1ull << 40);       // dead slots sort behind every live one
+  }
+  __syncthreads();      // (the LDS stages below reuse the array)
+  for (int k = 2; k <= SG_WIN && !(PN_SG_EXP & 2); k <<= 1) {
+    const bool up = ((4 * t) & k) == 0;      // (k >= 4: the same for the thread's four keys; k = 2 handled below)
+    for (int j = k >> 1; j >= 256; j >>= 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) key[4 * t + r] = e[r];
+      __syncthreads();
+      const bool lower = ((4 * t) & j) == 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned long long o = key[(4 * t + r) ^ j];
+        const bool take_min = lower == up;
+        e[r] = take_min ? (e[r] < o ? e[r] : o) : (e[r] < o ? o : e[r]);
       }
       __syncthreads();
     }
-  for (int i = threadIdx.x; i < SG_WIN; i += 1024) {
-    const unsigned long long k = key[i];
+    for (int j = min(k >> 1, 128); j >= 4; j >>= 1) {
+      const bool lower = ((4 * t) & j) == 0;
+      const bool take_min = lower == up;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned lo32 = __shfl_xor((unsigned)e[r], j >> 2, 64), hi32 = __shfl_xor((unsigned)(e[r] >> 32), j >> 2, 64);
+        const unsigned long long o = ((unsigned long long)hi32 << 32) | lo32;
+        e[r] = take_min ? (e[r] < o ? e[r] : o) : (e[r] < o ? o : e[r]);
+      }
+    }
+    if (k == 2) {
+      sg_cmpx(e[0], e[1], true);
+      sg_cmpx(e[2], e[3], false);
+    } else {
+      if (k > 2) {
+        sg_cmpx(e[0], e[2], up);
+        sg_cmpx(e[1], e[3], up);
+      }
+      sg_cmpx(e[0], e[1], up);
+      sg_cmpx(e[2], e[3], up);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * t + r;
+    const unsigned long long k = e[r];
     const bool live = k < (1ull << 40);
     if (base + i < cap) perm[base + i] = live ? base + (int)(k & 4095ull) : -1;
-    unsigned m = live ? (unsigned)(k >> 12) : 0u;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) m |= __shfl_xor(m, o, 32);
-    if ((i & 31) == 0 && (base + i) / 32 < (cap + 31) / 32) gmask[(base + i) >> 5] = m;
   }
+  // union mask of the 32-slot groups: 8 threads x 4 keys
+  unsigned m = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) m |= e[r] < (1ull << 40) ? (unsigned)(e[r] >> 12) : 0u;
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) m |= __shfl_xor(m, o, 8);
+  if ((t & 7) == 0 && (base + 4 * t) / 32 < (cap + 31) / 32) gmask[(base + 4 * t) >> 5] = m;
 }
 
 struct SpwArgs {

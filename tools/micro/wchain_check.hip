@@ -112,7 +112,7 @@ int main(int argc, char** argv) {
       std::vector<double> pro, loop, epi, tot;
       unsigned long long t0 = ~0ull, t1 = 0, ls = 0;
       for (int blk = 0; blk < 2048; ++blk)
-        for (int wv = 0; wv < 16; ++wv) {
+        for (int wv = 0; wv < 12; ++wv) {
           const unsigned long long* s4 = &st[((size_t)blk * 16 + wv) * 4];
           if (!s4[0] || !s4[3]) continue;
           t0 = std::min(t0, s4[0]); t1 = std::max(t1, s4[3]); ls = std::max(ls, s4[0]);
@@ -130,10 +130,50 @@ int main(int argc, char** argv) {
           printf("\n");
         }
       }
+      {  // shader clock during the launch: wave 0's s_memtime span over its wall_clock64 (100 MHz) span, per block
+        std::vector<double> mhz;
+        for (int blk = 0; blk < 2048; ++blk) {
+          const unsigned long long* s4 = &st[((size_t)blk * 16 + 0) * 4];
+          const unsigned long long* w4 = &st[((size_t)blk * 16 + 12) * 4];
+          if (s4[0] && s4[3] && w4[3] > w4[0]) mhz.push_back(100.0 * (double)(s4[3] - s4[0]) / (double)(w4[3] - w4[0]));
+        }
+        std::sort(mhz.begin(), mhz.end());
+        if (!mhz.empty()) printf("  shader clock over wave 0's last tile: min %.0f med %.0f max %.0f MHz\n", mhz.front(), mhz[mhz.size() / 2], mhz.back());
+      }
+      {  // when the blocks' last tiles start / end inside the launch: wave 0's wall_clock64 stamps (one 100 MHz counter for the device; s_memtime has a
+         // base of its own per XCD / CU and cannot be compared across blocks)
+        std::vector<double> bs, be;
+        unsigned long long x0 = ~0ull;
+        for (int blk = 0; blk < 2048; ++blk) {
+          const unsigned long long* w4 = &st[((size_t)blk * 16 + 12) * 4];
+          if (w4[3] > w4[0] && w4[0]) x0 = std::min(x0, w4[0]);
+        }
+        for (int blk = 0; blk < 2048; ++blk) {
+          const unsigned long long* w4 = &st[((size_t)blk * 16 + 12) * 4];
+          if (w4[3] > w4[0] && w4[0]) { bs.push_back((double)(w4[0] - x0) * 0.01); be.push_back((double)(w4[3] - x0) * 0.01); }
+        }
+        std::sort(bs.begin(), bs.end()); std::sort(be.begin(), be.end());
+        if (!bs.empty())
+          printf("  last tiles on the device clock (us after the first of them starts): starts p50 %.2f p90 %.2f p100 %.2f | ends p0 %.2f p10 %.2f p50 %.2f p90 %.2f p100 %.2f\n",
+                 bs[bs.size() / 2], bs[bs.size() * 9 / 10], bs.back(), be.front(), be[be.size() / 10], be[be.size() / 2], be[be.size() * 9 / 10], be.back());
+      }
+      std::vector<double> bjoin, bepi, bspread;     // per block (last tile of a persistent block): start -> last wave out of the K loop | -> block end | K-loop exit spread
+      for (int blk = 0; blk < 2048; ++blk) {
+        unsigned long long s0 = ~0ull, k0 = ~0ull, k1 = 0, e1 = 0;
+        for (int wv = 0; wv < 12; ++wv) {
+          const unsigned long long* s4 = &st[((size_t)blk * 16 + wv) * 4];
+          if (!s4[0] || !s4[3]) continue;
+          s0 = std::min(s0, s4[0]); k0 = std::min(k0, s4[2]); k1 = std::max(k1, s4[2]); e1 = std::max(e1, s4[3]);
+        }
+        if (!e1) continue;
+        bjoin.push_back((double)(k1 - s0)); bepi.push_back((double)(e1 - k1)); bspread.push_back((double)(k1 - k0));
+      }
       auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
       auto mx = [](std::vector<double>& v) { return v.empty() ? 0.0 : *std::max_element(v.begin(), v.end()); };
       printf("  stamps of the last form (%zu waves, shader clocks): prologue med %.0f | K loop med %.0f max %.0f | join+epilogue med %.0f max %.0f | wave med %.0f ; last start -> last end %.0f\n",
              pro.size(), med(pro), med(loop), mx(loop), med(epi), mx(epi), med(tot), (double)(t1 - ls));
+      printf("  per block (last tile): start -> join med %.0f max %.0f | join -> end med %.0f max %.0f | K-loop exit spread med %.0f max %.0f\n", med(bjoin), mx(bjoin), med(bepi),
+             mx(bepi), med(bspread), mx(bspread));
     }
     hipFree(x); hipFree(w); hipFree(pw); hipFree(pw24); hipFree(o_ref); hipFree(o_ch); hipFree(sc); hipFree(shf); hipFree(vin); hipFree(vout); hipFree(vref);
   }
