@@ -1047,6 +1047,15 @@ int pn_pillar_conv3x3_f32(const float *canvas, int batch, int h, int w, int cin,
                           const float *packed_w, int cout, const float *scale, const float *shift, int act, float *out,
                           int out_pixel_stride, int out_channel_offset, void *workspace, size_t workspace_bytes,
                           pn_stream_t stream);
+/* The same layer with its output written as the F(4, 3) planes the chained layers read (pn_wino4_planes_floats(batch, oh, ow, cout)
+ * floats, not transposed; r4): the reduction over the taps forms them directly, the NHWC map is never stored.  Bit-identical to
+ * pn_pillar_conv3x3_f32 + pn_wino4_planes_from_nhwc_f32.  pn_pillar_conv_planes_supported: ow % 4 == 0, cout % 8 == 0, whole waves of
+ * quads (batch * oh * ow / 4 a multiple of 64). */
+int pn_pillar_conv_planes_supported(int batch, int oh, int ow, int cout);
+int pn_pillar_conv3x3_planes_f32(const float *canvas, int batch, int h, int w, int cin, int in_pixel_stride, int in_channel_offset,
+                                 const uint32_t *unq_keys, const int32_t *num_voxels, int v_capacity, int stride,
+                                 const float *packed_w, int cout, const float *scale, const float *shift, int act, float *planes,
+                                 void *workspace, size_t workspace_bytes, pn_stream_t stream);
 /* The same convolution in TRAINING: the pair tables are built once per iteration (pn_pillar_pairs_build; pn_pillar_pairs_bytes of
  * caller-owned memory that lives from the forward to the backward) and shared by
  *   forward          pn_pillar_conv3x3_tables_f32        (oh, ow = the output map; workspace 9 * cap * cout floats, cap = v_capacity

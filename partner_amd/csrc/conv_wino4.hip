@@ -69,6 +69,7 @@ struct Wino4Args {
   float* out;
   int B, H, W, Cin, Cout;
   int in_ps, in_co, out_ps, out_co;
+  int out_t;      // 1: the output map is stored transposed, [b][x][y][channels] (pn_conv_desc.transpose_hw)
   int act;
   int quads_per_row, total_quads, qtiles;
   int qt0;                 // first 32-quad tile of this launch (two-phase launches: the tail of a map goes to a second launch)
@@ -308,11 +309,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
           const float y2 = s12 + 4.f * s34;
           const float y3 = (d12 + 8.f * d34) + m5;
           const int rowi = p / a.quads_per_row, oq = p - rowi * a.quads_per_row;
+          size_t px = (size_t)a.out_ps;
           float* o = a.out + ((size_t)rowi * a.W + 4 * oq) * a.out_ps + a.out_co + col;
+          if (a.out_t) {
+            const int img = rowi / a.H, y = rowi - img * a.H;
+            px = (size_t)a.H * a.out_ps;
+            o = a.out + ((size_t)img * a.W + 4 * oq) * px + (size_t)y * a.out_ps + a.out_co + col;
+          }
           o[0] = fmaxf(fmaf(y0, sc, sh), lo);
-          o[a.out_ps] = fmaxf(fmaf(y1, sc, sh), lo);
-          o[2 * (size_t)a.out_ps] = fmaxf(fmaf(y2, sc, sh), lo);
-          o[3 * (size_t)a.out_ps] = fmaxf(fmaf(y3, sc, sh), lo);
+          o[px] = fmaxf(fmaf(y1, sc, sh), lo);
+          o[2 * px] = fmaxf(fmaf(y2, sc, sh), lo);
+          o[3 * px] = fmaxf(fmaf(y3, sc, sh), lo);
         }
     }
   };
@@ -535,11 +542,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_ks_kernel(Wino4Args a) {
         const float y2 = s12 + 4.f * s34;
         const float y3 = (d12 + 8.f * d34) + m5;
         const int rowi = p / a.quads_per_row, oq = p - rowi * a.quads_per_row;
+        size_t px = (size_t)a.out_ps;
         float* o = a.out + ((size_t)rowi * a.W + 4 * oq) * a.out_ps + a.out_co + col;
+        if (a.out_t) {
+          const int img = rowi / a.H, y = rowi - img * a.H;
+          px = (size_t)a.H * a.out_ps;
+          o = a.out + ((size_t)img * a.W + 4 * oq) * px + (size_t)y * a.out_ps + a.out_co + col;
+        }
         o[0] = fmaxf(fmaf(y0, sc, sh), lo);
-        o[a.out_ps] = fmaxf(fmaf(y1, sc, sh), lo);
-        o[2 * (size_t)a.out_ps] = fmaxf(fmaf(y2, sc, sh), lo);
-        o[3 * (size_t)a.out_ps] = fmaxf(fmaf(y3, sc, sh), lo);
+        o[px] = fmaxf(fmaf(y1, sc, sh), lo);
+        o[2 * px] = fmaxf(fmaf(y2, sc, sh), lo);
+        o[3 * px] = fmaxf(fmaf(y3, sc, sh), lo);
       }
     }
     __syncthreads();   // the join buffer overlaps the next tile's stages
@@ -666,6 +679,7 @@ int pn_conv2d_wino4_nhwc_f32(const pn_conv_desc* d, const float* in, const float
   a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Cin = d->cin; a.Cout = d->cout;
   a.in_ps = d->in_pixel_stride; a.in_co = d->in_channel_offset; a.out_ps = d->out_pixel_stride; a.out_co = d->out_channel_offset;
   a.act = d->act;
+  a.out_t = d->transpose_hw ? 1 : 0;
   a.quads_per_row = d->in_w / 4;
   a.total_quads = d->batch * d->in_h * a.quads_per_row;
   a.chunks = pn::cdiv(d->cin, 32);

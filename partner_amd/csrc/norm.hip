@@ -35,6 +35,7 @@ struct GnArgs {
   int o2ps, o2co;
   double* part;  // [B][strata][cgroups][splits][2]
   float* stat;   // [B][strata][cgroups][2] = (mean, rstd), written by gn_finalize_kernel
+  int xt;        // 1: x is stored transposed, [b][x][y][channels] (pn_groupnorm_strat_planes_f32 mode 2); 0 everywhere else
 };
 
 // grid: (splits, strata, B)
@@ -48,9 +49,12 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(GnArgs a) {
   const int y0 = split * a.rows_per_split, y1 = min(a.H, y0 + a.rows_per_split);
   double sum[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
   const int npix = (y1 - y0) * wps;
+  const int rows = y1 - y0;
   for (int p = pl; p < npix; p += ppb) {
-    const int y = y0 + p / wps, x = s * wps + p % wps;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + y) * a.W + x) * a.ps + a.co + cv * 4);
+    // (a transposed source is walked along its own contiguous axis: y fastest)
+    const int y = a.xt ? y0 + p % rows : y0 + p / wps, x = s * wps + (a.xt ? p / rows : p % wps);
+    const size_t pix = a.xt ? ((size_t)b * a.W + x) * a.H + y : ((size_t)b * a.H + y) * a.W + x;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + pix * a.ps + a.co + cv * 4);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       sum[k] += v[k];
@@ -96,25 +100,26 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(GnArgs a) {
 }
 
 // one wave per statistics group: fixed-order sum of the row-split partials -> (mean, rstd)
-__global__ __launch_bounds__(64) void gn_finalize_kernel(GnArgs a) {
-  const int gidx = blockIdx.x;  // (b * strata + s) * cgroups + g
+__device__ __forceinline__ void gn_finalize_group(const GnArgs& a, int gidx, int lane, float* stat) {      // gidx = (b * strata + s) * cgroups + g
   const double* o = a.part + (size_t)gidx * a.splits * 2;
   double t0 = 0.0, t1 = 0.0;
-  for (int k = threadIdx.x; k < a.splits; k += 64) {
+  for (int k = lane; k < a.splits; k += 64) {
     t0 += o[2 * k];
     t1 += o[2 * k + 1];
   }
   t0 = pn::wave_sum(t0);  // xor butterfly: the same association order on every run
   t1 = pn::wave_sum(t1);
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     const double n = (double)(a.C / a.cgroups) * a.H * (a.W / a.strata);
     const double mean = t0 / n;
     double var = t1 / n - mean * mean;
     var = var < 0.0 ? 0.0 : var;
-    a.stat[2 * gidx] = (float)mean;
-    a.stat[2 * gidx + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+    stat[2 * gidx] = (float)mean;
+    stat[2 * gidx + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
   }
 }
+
+__global__ __launch_bounds__(64) void gn_finalize_kernel(GnArgs a) { gn_finalize_group(a, blockIdx.x, threadIdx.x, a.stat); }
 
 __global__ __launch_bounds__(kThreads) void gn_apply_kernel(GnArgs a) {
   const int split = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
@@ -158,10 +163,12 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(GnArgs a) {
 // of the frame (four pixels along the Winograd axis) x four channels: it normalises the quad's six input pixels itself (the two
 // neighbours' values are recomputed, nothing is exchanged) and stores six fragments; out2 = out * mul + add likewise (the
 // position-calibrated copy for the heat-map branch).  transposed: the Winograd axis is the map's H (rows of the frame = range positions).
+constexpr int kFoldGroups = 64;      // up to this many statistics groups gn_apply_planes_kernel finalizes itself (no finalize launch)
 struct GnPlanesArgs {
   GnArgs g;
   float* planes;
   float* planes2;
+  int fold;            // every block folds the row-split partials of all groups first (the arithmetic of gn_finalize_kernel, wave per group)
   int transposed;
   int FH, FW, Wq;      // the frame
   unsigned plane_floats;
@@ -169,6 +176,14 @@ struct GnPlanesArgs {
 
 __global__ __launch_bounds__(256) void gn_apply_planes_kernel(GnPlanesArgs p) {
   const GnArgs& a = p.g;
+  __shared__ float folded[2 * kFoldGroups];
+  const float* stat = a.stat;
+  if (p.fold) {
+    const int ngroups = a.B * a.strata * a.cgroups;
+    for (int g = threadIdx.x >> 6; g < ngroups; g += 4) gn_finalize_group(a, g, threadIdx.x & 63, folded);
+    __syncthreads();
+    stat = folded;
+  }
   const int c4n = a.C >> 2;
   const int wps = a.W / a.strata, cpg = a.C / a.cgroups;
   const long long total = (long long)a.B * p.FH * p.Wq * c4n;
@@ -180,31 +195,58 @@ __global__ __launch_bounds__(256) void gn_apply_planes_kernel(GnPlanesArgs p) {
     const int c4 = (int)(rest % c4n);
     const int b = (int)(rest / c4n);
     f32x4 d[6], d2[6];
+    // every load of the quad is requested before the first use (the kernel is a few waves per CU: its time is the memory latency times the
+    // number of dependent rounds); out-of-map neighbours read a clamped pixel and are zeroed afterwards
+    f32x4 xv[6], mv[6], av[6];
+    size_t q6[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const int fx = 4 * xq - 1 + k;      // position along the Winograd axis
+      const int fx = min(max(4 * xq - 1 + k, 0), p.FW - 1);      // position along the Winograd axis
+      const int my = p.transposed ? fx : r, mx = p.transposed ? r : fx;      // map coordinates
+      // (xt: the source, mul and add are stored as the frame, [b][mx][my][channels])
+      const size_t pix = a.xt ? ((size_t)b * a.W + mx) * a.H + my : ((size_t)b * a.H + my) * a.W + mx;
+      xv[k] = *reinterpret_cast<const f32x4*>(a.x + pix * a.ps + a.co + c4 * 4);
+      q6[k] = (a.xt ? (size_t)mx * a.H + my : (size_t)my * a.W + mx) * a.C + c4 * 4;
+    }
+    if (p.planes2) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        mv[k] = *reinterpret_cast<const f32x4*>(a.mul + q6[k]);
+        av[k] = *reinterpret_cast<const f32x4*>(a.add + q6[k]);
+      }
+    }
+    // the stratum's (mean, rstd) and the channels' (gamma, beta) are reloaded only when the stratum changes along the quad (never, on a
+    // transposed frame: its rows are the range positions)
+    int s_cur = -1;
+    float mean[4], rstd[4], ga[4], be[4];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int fx = 4 * xq - 1 + k;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       d[k] = z;
       d2[k] = z;
       if (fx < 0 || fx >= p.FW) continue;
-      const int my = p.transposed ? fx : r, mx = p.transposed ? r : fx;      // map coordinates
+      const int mx = p.transposed ? r : fx;
       const int s = mx / wps;
-      const float* smean = a.stat + ((size_t)b * a.strata + s) * a.cgroups * 2;
-      f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + my) * a.W + mx) * a.ps + a.co + c4 * 4);
+      if (s != s_cur) {
+        s_cur = s;
+        const float* smean = stat + ((size_t)b * a.strata + s) * a.cgroups * 2;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int c = c4 * 4 + e;
-        const float mean = smean[2 * (c / cpg)], rstd = smean[2 * (c / cpg) + 1];
-        const float ga = a.gamma ? a.gamma[s * a.C + c] : 1.f, be = a.beta ? a.beta[s * a.C + c] : 0.f;
-        v[e] = pn::apply_act((v[e] - mean) * rstd * ga + be, a.act);      // (the expression of gn_apply_kernel: bit-identical values)
+        for (int e = 0; e < 4; ++e) {
+          const int c = c4 * 4 + e;
+          mean[e] = smean[2 * (c / cpg)];
+          rstd[e] = smean[2 * (c / cpg) + 1];
+          ga[e] = a.gamma ? a.gamma[s * a.C + c] : 1.f;
+          be[e] = a.beta ? a.beta[s * a.C + c] : 0.f;
+        }
       }
+      f32x4 v = xv[k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = pn::apply_act((v[e] - mean[e]) * rstd[e] * ga[e] + be[e], a.act);      // (the expression of gn_apply_kernel: bit-identical values)
       d[k] = v;
       if (p.planes2) {
-        const size_t q = ((size_t)my * a.W + mx) * a.C + c4 * 4;
-        const f32x4 m = *reinterpret_cast<const f32x4*>(a.mul + q);
-        const f32x4 ad = *reinterpret_cast<const f32x4*>(a.add + q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d2[k][e] = v[e] * m[e] + ad[e];
+        for (int e = 0; e < 4; ++e) d2[k][e] = v[e] * mv[k][e] + av[k][e];
       }
     }
     f32x4 v6[6];
@@ -246,7 +288,7 @@ int pn_groupnorm_strat_fwd(const float* x, int batch, int h, int w, int c, int p
   PN_REQUIRE((out2 == nullptr) || (mul && add), "groupnorm: out2 needs mul and add");
   if (workspace_bytes < pn_groupnorm_workspace_bytes(batch, channel_groups, range_strata))
     return pn::fail(PN_ERR_WORKSPACE, "groupnorm: workspace too small");
-  GnArgs a;
+  GnArgs a{};
   a.x = x; a.B = batch; a.H = h; a.W = w; a.C = c; a.ps = pixel_stride; a.co = channel_offset;
   a.cgroups = channel_groups; a.strata = range_strata;
   a.splits = pick_splits(batch, h, range_strata);
@@ -265,8 +307,10 @@ int pn_groupnorm_strat_fwd(const float* x, int batch, int h, int w, int c, int p
   return pn::check_launch("groupnorm_strat");
 }
 
-/* pn_groupnorm_strat_fwd whose result leaves as F(4, 3) planes (pn_wino4_planes_floats(batch, h, w, c) floats each; transpose_hw: of the
- * transposed map, then sized (batch, w, h, c)); planes2 (nullable) = the planes of out * mul + add */
+/* pn_groupnorm_strat_fwd whose result leaves as F(4, 3) planes (pn_wino4_planes_floats(batch, h, w, c) floats each; transpose_hw 1: of the
+ * transposed map, then sized (batch, w, h, c); transpose_hw 2: the same planes from a source that is STORED transposed -- x [b][w][h][c]
+ * as pn_conv2d_wino4_nhwc_f32 writes it under pn_conv_desc.transpose_hw, mul / add [w][h][c] -- so that both the reads and the plane
+ * stores run along contiguous memory); planes2 (nullable) = the planes of out * mul + add */
 int pn_groupnorm_strat_planes_f32(const float* x, int batch, int h, int w, int c, int pixel_stride, int channel_offset, int channel_groups,
                                   int range_strata, const float* gamma, const float* beta, float eps, int act, const float* mul, const float* add,
                                   int transpose_hw, float* planes, float* planes2, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
@@ -277,6 +321,7 @@ int pn_groupnorm_strat_planes_f32(const float* x, int batch, int h, int w, int c
              "groupnorm_planes: channel_groups must be a power of two <= 128 dividing the channel count");
   PN_REQUIRE(range_strata >= 1 && w % range_strata == 0, "groupnorm_planes: range axis not divisible by range_strata");
   PN_REQUIRE((planes2 == nullptr) || (mul && add), "groupnorm_planes: planes2 needs mul and add");
+  PN_REQUIRE(transpose_hw >= 0 && transpose_hw <= 2, "groupnorm_planes: transpose_hw 0, 1 or 2");
   const int fh = transpose_hw ? w : h, fw = transpose_hw ? h : w;
   PN_REQUIRE(fw % 4 == 0, "groupnorm_planes: the Winograd axis must be a multiple of 4 pixels");
   if (workspace_bytes < pn_groupnorm_workspace_bytes(batch, channel_groups, range_strata))
@@ -293,11 +338,13 @@ int pn_groupnorm_strat_planes_f32(const float* x, int batch, int h, int w, int c
   a.part = static_cast<double*>(workspace);
   const size_t ngroups = (size_t)batch * range_strata * channel_groups;
   a.stat = reinterpret_cast<float*>(a.part + ngroups * 256 * 2);
-  p.planes = planes; p.planes2 = planes2; p.transposed = transpose_hw; p.FH = fh; p.FW = fw; p.Wq = fw / 4;
+  a.xt = transpose_hw == 2;
+  p.planes = planes; p.planes2 = planes2; p.transposed = transpose_hw != 0; p.FH = fh; p.FW = fw; p.Wq = fw / 4;
   p.plane_floats = (unsigned)((size_t)batch * (fh + 2) * p.Wq * 4);
+  p.fold = ngroups <= (size_t)kFoldGroups;
   dim3 grid(a.splits, range_strata, batch);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(kThreads), 0, pn::S(stream), a);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ngroups), dim3(64), 0, pn::S(stream), a);
+  if (!p.fold) hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ngroups), dim3(64), 0, pn::S(stream), a);
   const long long total = (long long)batch * fh * p.Wq * (c / 4);
   hipLaunchKernelGGL(gn_apply_planes_kernel, dim3((unsigned)std::min<long long>(4096, (total + 255) / 256)), dim3(256), 0, pn::S(stream), p);
   return pn::check_launch("groupnorm_planes");
@@ -317,7 +364,7 @@ int pn_groupnorm_apply_f32(const float* x, int batch, int h, int w, int c, int p
   PN_REQUIRE(channel_groups >= 1 && c % channel_groups == 0, "groupnorm_apply: channel_groups must divide the channel count");
   PN_REQUIRE(range_strata >= 1 && w % range_strata == 0, "groupnorm_apply: range axis not divisible by range_strata");
   PN_REQUIRE((out2 == nullptr) || (mul && add && out2_pixel_stride % 4 == 0 && out2_channel_offset % 4 == 0), "groupnorm_apply: out2 needs mul, add and aligned strides");
-  GnArgs a;
+  GnArgs a{};
   a.x = x; a.B = batch; a.H = h; a.W = w; a.C = c; a.ps = pixel_stride; a.co = channel_offset;
   a.cgroups = channel_groups; a.strata = range_strata;
   a.splits = pick_splits(batch, h, range_strata);

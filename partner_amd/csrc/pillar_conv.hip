@@ -18,6 +18,7 @@
 // Same terms as the dense convolution, summed per tap first (128-term dot products) and then over taps: agreement with the dense
 // kernel ~1e-6 of the map's range.  The caller promises that every non-zero pixel of the canvas is in the key list.
 #include "pn_common.h"
+#include "wino_planes.h"
 #include <algorithm>
 
 namespace {
@@ -262,6 +263,91 @@ __global__ void pair_reduce_kernel(ReduceArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) y[c] = pn::apply_act(fmaf(s[c], sc[c], sh[c]), a.act);
     *reinterpret_cast<f32x4*>(a.out + o * a.out_ps + a.out_co + c4 * 4) = y;
+  }
+}
+
+// The same reduction written as the F(4, 3) planes conv_wchain.hip's layers read (wino_planes.h): thread = one quad of four output pixels x
+// four channels, lanes = 64 consecutive quads of a row (the edge pixels of the neighbouring quads come by lane shuffles; a lane whose
+// neighbour lies in another wave sums that pixel itself).  Saves the NHWC round trip of the 33.5 MB map (pair_reduce 17 us + the planes
+// conversion 20 us at 256 x 256 x 128 -> one pass).  Every pixel is summed exactly as in pair_reduce_kernel: the planes are bit-identical
+// to pair_reduce_kernel + wchain_v_from_nhwc_kernel.
+struct ReducePlanesArgs {
+  const float* partial;
+  const int32_t* slots;
+  const float* scale;
+  const float* shift;
+  float* planes;
+  int cap, cout, act;
+  int H, W, Wq, total_quads;
+  unsigned plane_floats;
+};
+
+__global__ __launch_bounds__(256) void pair_reduce_planes_kernel(ReducePlanesArgs a) {
+  const int c4n = a.cout >> 2;
+  const int lane = threadIdx.x & 63;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  // (total_quads is a multiple of 64: whole waves share c4 and stay together through the shuffles)
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < (long long)a.total_quads * c4n; it += (long long)gridDim.x * 256) {
+    const int c4 = (int)(it / a.total_quads);
+    const int Q = (int)(it - (long long)c4 * a.total_quads);
+    const int rowi = Q / a.Wq, xq = Q - rowi * a.Wq;
+    const int img = rowi / a.H, r = rowi - img * a.H;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = z;
+    if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + c4 * 4);
+    if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + c4 * 4);
+    const float* part = a.partial + c4 * 4;
+    auto finish = [&](const f32x4 (&v)[9], const int (&slot)[9]) {
+      f32x4 s = z;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) s += slot[t] >= 0 ? v[t] : z;
+      f32x4 y;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) y[c] = pn::apply_act(fmaf(s[c], sc[c], sh[c]), a.act);
+      return y;
+    };
+    auto pixel = [&](long long o) {      // one pixel on its own (wave-edge neighbours)
+      int slot[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) slot[t] = a.slots[o * 9 + t];
+      f32x4 v[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v[t] = *reinterpret_cast<const f32x4*>(part + ((size_t)t * a.cap + max(slot[t], 0)) * a.cout);
+      return finish(v, slot);
+    };
+    const long long o0 = (long long)rowi * a.W + 4 * xq;
+    // the quad's 36 slots are one 144-byte run
+    int sl[36];
+    {
+      const int4* s4 = reinterpret_cast<const int4*>(a.slots + o0 * 9);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int4 q = s4[k];
+        sl[4 * k] = q.x; sl[4 * k + 1] = q.y; sl[4 * k + 2] = q.z; sl[4 * k + 3] = q.w;
+      }
+    }
+    f32x4 d[6];
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      int slot[9];
+      f32x4 v[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) slot[t] = sl[px * 9 + t];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v[t] = *reinterpret_cast<const f32x4*>(part + ((size_t)t * a.cap + max(slot[t], 0)) * a.cout);
+      d[1 + px] = finish(v, slot);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      d[0][j] = __shfl_up(d[4][j], 1, 64);
+      d[5][j] = __shfl_down(d[1][j], 1, 64);
+    }
+    if (xq == 0) d[0] = z;
+    else if (lane == 0) d[0] = pixel(o0 - 1);
+    if (xq + 1 == a.Wq) d[5] = z;
+    else if (lane == 63) d[5] = pixel(o0 + 4);
+    f32x4 vv[6];
+    pn::wino4_input_transform4(d, vv);
+    pn::wino4_store_planes(a.planes, vv, c4, c4n, a.plane_floats, img, r, xq, a.H, a.Wq);
   }
 }
 
@@ -522,15 +608,35 @@ size_t pn_pillar_conv_workspace_bytes(int v_capacity, int batch, int oh, int ow,
 }
 
 // forward on prebuilt tables: gathered GEMM per tap + fixed-order reduction.  workspace: 9 * cap * cout floats (cap = v_capacity rounded up to 128)
+// planes output of the forward: the (oh, ow) map as pn_wino4_planes_floats(batch, oh, ow, cout) floats, not transposed
+int pn_pillar_conv_planes_supported(int batch, int oh, int ow, int cout) {
+  return batch >= 1 && oh >= 1 && ow >= 4 && ow % 4 == 0 && cout >= 8 && cout % 8 == 0 && ((long long)batch * oh * (ow / 4)) % 64 == 0 &&
+         (long long)batch * (oh + 2) * (ow / 4) * 4 < (1ll << 31);
+}
+
+static int pillar_forward(const float* canvas, int batch, int oh, int ow, int cin, int in_pixel_stride, int in_channel_offset, const void* pair_tables,
+                          int v_capacity, const float* packed_w, int cout, const float* scale, const float* shift, int act, float* out,
+                          int out_pixel_stride, int out_channel_offset, float* planes, void* workspace, size_t workspace_bytes, pn_stream_t stream);
+
 int pn_pillar_conv3x3_tables_f32(const float* canvas, int batch, int oh, int ow, int cin, int in_pixel_stride, int in_channel_offset, const void* pair_tables,
                                  int v_capacity, const float* packed_w, int cout, const float* scale, const float* shift, int act, float* out,
                                  int out_pixel_stride, int out_channel_offset, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
-  PN_REQUIRE(canvas && pair_tables && packed_w && out && workspace, "pillar_conv: null pointer");
+  PN_REQUIRE(out, "pillar_conv: null pointer");
+  return pillar_forward(canvas, batch, oh, ow, cin, in_pixel_stride, in_channel_offset, pair_tables, v_capacity, packed_w, cout, scale, shift, act, out,
+                        out_pixel_stride, out_channel_offset, nullptr, workspace, workspace_bytes, stream);
+}
+
+static int pillar_forward(const float* canvas, int batch, int oh, int ow, int cin, int in_pixel_stride, int in_channel_offset, const void* pair_tables,
+                          int v_capacity, const float* packed_w, int cout, const float* scale, const float* shift, int act, float* out,
+                          int out_pixel_stride, int out_channel_offset, float* planes, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(canvas && pair_tables && packed_w && (out || planes) && workspace, "pillar_conv: null pointer");
   PN_REQUIRE((cin == 32 || cin == 64 || cin == 128) && in_pixel_stride % 4 == 0 && in_channel_offset % 4 == 0 && in_pixel_stride >= in_channel_offset + cin,
              "pillar_conv: cin 32, 64 or 128, 16-byte aligned channel slice");
-  PN_REQUIRE(cout >= 4 && cout % 4 == 0 && out_pixel_stride % 4 == 0 && out_channel_offset % 4 == 0 && out_pixel_stride >= out_channel_offset + cout,
+  PN_REQUIRE(cout >= 4 && cout % 4 == 0 && (!out || (out_pixel_stride % 4 == 0 && out_channel_offset % 4 == 0 && out_pixel_stride >= out_channel_offset + cout)),
              "pillar_conv: cout a multiple of 4, 16-byte aligned output slice");
-  PN_REQUIRE(((uintptr_t)canvas & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)packed_w & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
+  PN_REQUIRE(!planes || pn_pillar_conv_planes_supported(batch, oh, ow, cout), "pillar_conv: planes want ow % 4 == 0, cout % 8 == 0 and whole waves of quads");
+  PN_REQUIRE(((uintptr_t)canvas & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)planes & 15) == 0 && ((uintptr_t)packed_w & 15) == 0 &&
+                 ((uintptr_t)workspace & 15) == 0,
              "pillar_conv: pointers must be 16-byte aligned");
   const int cap = cap_rows(v_capacity);
   if (workspace_bytes < (size_t)9 * cap * cout * 4) return pn::fail(PN_ERR_WORKSPACE, "pillar_conv: workspace too small");
@@ -540,16 +646,26 @@ int pn_pillar_conv3x3_tables_f32(const float* canvas, int batch, int oh, int ow,
   float* partial = static_cast<float*>(workspace);
   hipStream_t st = pn::S(stream);
   launch_pair_gemm(canvas, cin, in_pixel_stride, in_channel_offset, packed_w, cnt, reinterpret_cast<const int32_t*>(base + tb.pair_in), partial, cap, cout, st);
-  ReduceArgs ra{partial, reinterpret_cast<const int32_t*>(base + tb.slots), scale, shift, out, cap, cout, out_pixel_stride, out_channel_offset, act,
-                (long long)batch * oh * ow};
-  const long long total = ra.npix * (cout / 4);
-  hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)std::min<long long>(65535, (total + 255) / 256)), dim3(256), 0, st, ra);
+  if (planes) {
+    const int wq = ow / 4;
+    ReducePlanesArgs pa{partial, reinterpret_cast<const int32_t*>(base + tb.slots), scale, shift, planes, cap, cout, act, oh, ow, wq, batch * oh * wq,
+                        (unsigned)((size_t)batch * (oh + 2) * wq * 4)};
+    const long long items = (long long)pa.total_quads * (cout / 4);
+    hipLaunchKernelGGL(pair_reduce_planes_kernel, dim3((unsigned)std::min<long long>(65535, (items + 255) / 256)), dim3(256), 0, st, pa);
+  }
+  if (out) {
+    ReduceArgs ra{partial, reinterpret_cast<const int32_t*>(base + tb.slots), scale, shift, out, cap, cout, out_pixel_stride, out_channel_offset, act,
+                  (long long)batch * oh * ow};
+    const long long total = ra.npix * (cout / 4);
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)std::min<long long>(65535, (total + 255) / 256)), dim3(256), 0, st, ra);
+  }
   return pn::check_launch("pillar_conv kernels");
 }
 
-int pn_pillar_conv3x3_f32(const float* canvas, int batch, int h, int w, int cin, int in_pixel_stride, int in_channel_offset, const uint32_t* unq_keys,
-                          const int32_t* num_voxels, int v_capacity, int stride, const float* packed_w, int cout, const float* scale, const float* shift,
-                          int act, float* out, int out_pixel_stride, int out_channel_offset, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+static int pillar_conv_run(const float* canvas, int batch, int h, int w, int cin, int in_pixel_stride, int in_channel_offset, const uint32_t* unq_keys,
+                           const int32_t* num_voxels, int v_capacity, int stride, const float* packed_w, int cout, const float* scale, const float* shift,
+                           int act, float* out, int out_pixel_stride, int out_channel_offset, float* planes, void* workspace, size_t workspace_bytes,
+                           pn_stream_t stream) {
   PN_REQUIRE(workspace && (stride == 1 || stride == 2) && h >= 1 && w >= 1, "pillar_conv: bad arguments");
   const int oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
   if (workspace_bytes < pn_pillar_conv_workspace_bytes(v_capacity, batch, oh, ow, cout)) return pn::fail(PN_ERR_WORKSPACE, "pillar_conv: workspace too small");
@@ -561,10 +677,26 @@ int pn_pillar_conv3x3_f32(const float* canvas, int batch, int h, int w, int cin,
   hipStream_t st = pn::S(stream);
   if (prof) (void)hipEventRecord(ps.start, st);
   if (int rc = pairs_build(unq_keys, num_voxels, v_capacity, batch, h, w, stride, workspace, tbytes, false, stream)) return rc;
-  const int rc = pn_pillar_conv3x3_tables_f32(canvas, batch, oh, ow, cin, in_pixel_stride, in_channel_offset, workspace, v_capacity, packed_w, cout, scale, shift, act,
-                                              out, out_pixel_stride, out_channel_offset, static_cast<char*>(workspace) + tbytes, workspace_bytes - tbytes, stream);
+  const int rc = pillar_forward(canvas, batch, oh, ow, cin, in_pixel_stride, in_channel_offset, workspace, v_capacity, packed_w, cout, scale, shift, act,
+                                out, out_pixel_stride, out_channel_offset, planes, static_cast<char*>(workspace) + tbytes, workspace_bytes - tbytes, stream);
   if (prof) (void)hipEventRecord(ps.stop, st);
   return rc;
+}
+
+int pn_pillar_conv3x3_f32(const float* canvas, int batch, int h, int w, int cin, int in_pixel_stride, int in_channel_offset, const uint32_t* unq_keys,
+                          const int32_t* num_voxels, int v_capacity, int stride, const float* packed_w, int cout, const float* scale, const float* shift,
+                          int act, float* out, int out_pixel_stride, int out_channel_offset, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(out, "pillar_conv: null pointer");
+  return pillar_conv_run(canvas, batch, h, w, cin, in_pixel_stride, in_channel_offset, unq_keys, num_voxels, v_capacity, stride, packed_w, cout, scale, shift, act, out,
+                         out_pixel_stride, out_channel_offset, nullptr, workspace, workspace_bytes, stream);
+}
+
+int pn_pillar_conv3x3_planes_f32(const float* canvas, int batch, int h, int w, int cin, int in_pixel_stride, int in_channel_offset, const uint32_t* unq_keys,
+                                 const int32_t* num_voxels, int v_capacity, int stride, const float* packed_w, int cout, const float* scale, const float* shift,
+                                 int act, float* planes, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  PN_REQUIRE(planes, "pillar_conv: null pointer");
+  return pillar_conv_run(canvas, batch, h, w, cin, in_pixel_stride, in_channel_offset, unq_keys, num_voxels, v_capacity, stride, packed_w, cout, scale, shift, act,
+                         nullptr, 0, 0, planes, workspace, workspace_bytes, stream);
 }
 
 // training: d(pillar features) [v_capacity][cin] from the output gradient.  packed_wt = pn_pack_pillar_conv_weight_f32 of the weight with its

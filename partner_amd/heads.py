@@ -512,9 +512,10 @@ class CenterHeadSingle(CenterHead):
         return plan
 
     def _first_stage_chained(self, fz, cp, raw, mul, add):
-        """-> (mid, {name: (table, strata, cmid, channel offset in mid)})"""
+        """raw: the shared convolution's output stored TRANSPOSED (b, w, h, c); mul / add likewise (w, h, c)
+        -> (mid, {name: (table, strata, cmid, channel offset in mid)})"""
         lib = hip.load()
-        b, h, w, c_sh = raw.shape
+        b, w, h, c_sh = raw.shape
         dev, st = raw.device, hip.stream()
         f32 = dict(dtype=torch.float32, device=dev)
         s_rs, g_rs, b_rs, eps_rs = fz["rs"]
@@ -523,7 +524,7 @@ class CenterHeadSingle(CenterHead):
         nbytes = lib.pn_groupnorm_workspace_bytes(b, 1, s_rs)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         hip.call("pn_groupnorm_strat_planes_f32", raw.data_ptr(), b, h, w, c_sh, c_sh, 0, 1, s_rs, hip.ptr(g_rs), hip.ptr(b_rs), float(eps_rs), ops.ACT_RELU,
-                 hip.ptr(mul), hip.ptr(add), 1, planes_xs.data_ptr(), hip.ptr(planes_hm), ws.data_ptr(), nbytes, st)
+                 hip.ptr(mul), hip.ptr(add), 2, planes_xs.data_ptr(), hip.ptr(planes_hm), ws.data_ptr(), nbytes, st)
         mid = torch.empty((b, h, w, cp["cm_tot"]), **f32)
         prof = ops._PROFILER
         parts = [torch.empty(g["nstat"], **f32) for g in cp["groups"]]
@@ -568,8 +569,14 @@ class CenterHeadSingle(CenterHead):
         wino_shared = fz["shared"]._use_wino4(b, h, w, False) and not getattr(self, "force_stats_epilogue", False)
         cp = self._chain_head_plan(fz, b, h, w, dev, mul is not None) if (wino_shared and not getattr(self, "force_tiled_branches", False)) else None
         if cp is not None:
-            # r4: shared convolution (F(4,3)), RSNorm + ReLU straight into planes, the branch convolutions chained in the Winograd domain
-            fz["shared"](x, out=raw)
+            # r4: shared convolution (F(4,3)) stored transposed -- the head's chain runs on the transposed map, and a transposed source lets
+            # the RSNorm pass read and write along contiguous memory --, RSNorm + ReLU straight into planes, the branch convolutions chained
+            # in the Winograd domain
+            raw = torch.empty((b, w, h, c_sh), **f32)
+            fz["shared"](x, out=raw, out_transposed=True)
+            if mul is not None and "cal_t" not in cp:
+                cp["cal_t"] = (mul.transpose(0, 1).contiguous(), add.transpose(0, 1).contiguous())
+            mul, add = cp["cal_t"] if mul is not None else (None, None)
             mid, tabs_by_name = self._first_stage_chained(fz, cp, raw, mul, add)
             return self._last_stage(fz, mid, [tabs_by_name[name] for name, *_ in fz["first"]], f32)
         j0 = ops.ConvJob(fz["shared"], x, raw)

@@ -226,6 +226,8 @@ SIGNATURES = {
     "pn_pack_pillar_conv_weight_f32": (_I, [_P, _I, _I, _P, _P]),
     "pn_pillar_conv_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "pn_pillar_conv3x3_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _SZ, _P]),
+    "pn_pillar_conv_planes_supported": (_I, [_I, _I, _I, _I]),
+    "pn_pillar_conv3x3_planes_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _SZ, _P]),
     "pn_pillar_pairs_bytes": (_SZ, [_I, _I, _I, _I]),
     "pn_pillar_pairs_build": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "pn_pillar_conv3x3_tables_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _SZ, _P]),

@@ -133,6 +133,14 @@ class RPN(nn.Module):
             for k, layer in enumerate(layers):
                 p0 = plan.get("pillar0") if (i == 0 and k == 0 and pillars is not None and dtype == "f32") else None
                 if p0 is not None and p0.worth_it(pillars, x.shape[0], x.shape[1], x.shape[2]):
+                    b0, oh, ow = x.shape[0], (x.shape[1] - 1) // p0.stride + 1, (x.shape[2] - 1) // p0.stride + 1
+                    rest = layers[1:]
+                    if (rest and all(l.stride == 1 for l in rest) and p0.planes_supported(b0, x.shape[1], x.shape[2])
+                            and ops.conv_chain_orientation(rest, b0, oh, ow) is False):
+                        # the pillar layer's tap reduction writes the chain's planes itself: its 33 MB map never exists in NHWC
+                        canvas = x
+                        x = ops.conv_chain(rest, None, shape=(b0, oh, ow), device=x.device, planes_from=lambda buf: p0(canvas, pillars, planes=buf))
+                        break
                     x = p0(x, pillars)
                 elif k <= 1 and dtype == "f32" and layer.stride == 1 and ops.conv_chain_supported(layers[k:], x.shape[0], x.shape[1], x.shape[2]):
                     # the block's same-shape layers stay in the F(4, 3) domain (conv_wchain.hip); a stride-1 first layer (Waymo block 0) joins them

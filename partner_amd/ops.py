@@ -574,10 +574,11 @@ class ConvLayer:
         return ((h + 2 * self.pad[0] - self.kh) // self.stride + 1, (w + 2 * self.pad[1] - self.kw) // self.stride + 1)
 
     def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_channel_offset=0, in_channel_offset=0,
-                 in_channels: Optional[int] = None, accumulate=False, out_f32=False) -> torch.Tensor:
+                 in_channels: Optional[int] = None, accumulate=False, out_f32=False, out_transposed=False) -> torch.Tensor:
         """x: NHWC (B,H,W,Ct).  Reads channels [in_channel_offset, +cin*groups); writes channels
         [out_channel_offset, +out_channels) of ``out`` (allocated if None).  bf16 layers take / return
-        torch.bfloat16 maps (``out_f32``: f32 output)."""
+        torch.bfloat16 maps (``out_f32``: f32 output).  ``out_transposed`` (layers on the F(4,3) kernel only): ``out`` is (B, W, H, C), the
+        map stored transposed (pn_conv_desc.transpose_hw)."""
         hip.require_device(x)
         in_dt = torch.bfloat16 if self.dtype == "bf16" else torch.float32
         assert x.dim() == 4 and x.is_contiguous() and x.dtype == in_dt
@@ -600,11 +601,12 @@ class ConvLayer:
                 macs = b * h * w * 4 * self.cout * self.cin if self.deconv2x2 else b * oh * ow * self.groups * self.cout * self.cin * self.kh * self.kw
                 prof.end(ev, 2.0 * macs, st, tag=f"{oh}x{ow} {self.cin * self.groups}->{self.out_channels} k{self.kh} bf16")
             return out
-        assert out.shape[:3] == (b, oh, ow) and out.is_contiguous()
+        assert out.shape[:3] == ((b, ow, oh) if out_transposed else (b, oh, ow)) and out.is_contiguous()
         d = ConvDesc(b, h, w, self.cin, self.cout, self.groups, self.kh, self.kw, self.stride, self.pad[0], self.pad[1],
                      ct, in_channel_offset, out.shape[3], out_channel_offset, self.act, int(self.deconv2x2),
                      self.range_strata, 0, 0, int(accumulate))
         d.frames_in_flight = _FRAMES_IN_FLIGHT
+        d.transpose_hw = int(bool(out_transposed))
         st = hip.stream()
         prof = _PROFILER
         if prof is not None:
@@ -612,6 +614,7 @@ class ConvLayer:
         use_tap = self.tap_packed is not None and not accumulate and self.cin == self._pack_cin and in_channel_offset % 4 == 0 and ct % 4 == 0
         use_wino4 = not use_tap and self._use_wino4(b, h, w, accumulate)
         use_wino = not use_tap and not use_wino4 and self._use_wino(b, h, w, accumulate)
+        assert use_wino4 or not out_transposed, "ConvLayer: a transposed output needs the F(4,3) kernel (check _use_wino4 first)"
         self._ensure("tap" if use_tap else "wino4" if use_wino4 else "wino" if use_wino else "direct")
         if use_tap:
             m = b * h * w
@@ -672,25 +675,41 @@ def _chain_orientation(layers, b: int, h: int, w: int):
     return None
 
 
+def conv_chain_orientation(layers, b: int, h: int, w: int):
+    """None: the layers cannot run as a chain on a (b, h, w) map; False / True: they can, on the map as stored / transposed"""
+    return _chain_orientation(layers, b, h, w)
+
+
 def conv_chain_supported(layers, b: int, h: int, w: int) -> bool:
     """can ``layers`` (consecutive ConvLayers, each feeding the next) run as one Winograd-domain chain on a (b, h, w) map?"""
     return _chain_orientation(layers, b, h, w) is not None
 
 
-def conv_chain(layers, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_channel_offset=0, in_channel_offset=0) -> torch.Tensor:
+def conv_chain(layers, x: Optional[torch.Tensor], out: Optional[torch.Tensor] = None, out_channel_offset=0, in_channel_offset=0, planes_from=None,
+               shape=None, device=None) -> torch.Tensor:
     """x NHWC (B, H, W, Ct) -> the NHWC output of the last layer.  One launch forms the six F(4, 3) planes of x, then every layer reads
     planes and writes planes (two buffers, alternating); the last one writes the map.  Same arithmetic as the layers one by one
-    (ConvLayer.__call__ on pn_conv2d_wino4_nhwc_f32) up to the summation order over the input channels."""
-    hip.require_device(x)
-    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
-    b, h, w, ct = x.shape
-    lib, st, dev = hip.load(), hip.stream(), x.device
+    (ConvLayer.__call__ on pn_conv2d_wino4_nhwc_f32) up to the summation order over the input channels.
+    ``planes_from(buffer)`` (with ``shape`` = (B, H, W), ``device``, x None): the producer writes the NOT transposed planes of the first
+    layer's input itself (PillarConvLayer: the map never exists in NHWC)."""
+    if planes_from is None:
+        hip.require_device(x)
+        assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+        b, h, w, ct = x.shape
+        dev = x.device
+    else:
+        (b, h, w), dev = shape, device
+    lib, st = hip.load(), hip.stream()
     tr = _chain_orientation(layers, b, h, w)
     assert tr is not None, "conv_chain: check conv_chain_supported first"
+    assert planes_from is None or not tr, "conv_chain: a planes producer writes the map's own orientation"
     cmax = max([layers[0].cin] + [l.cout for l in layers[:-1]])
     n = lib.pn_wino4_planes_floats(b, w if tr else h, h if tr else w, cmax)
     bufs = [torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev) if len(layers) > 1 else None]
-    hip.call("pn_wino4_planes_from_nhwc_f32", x.data_ptr(), b, h, w, layers[0].cin, ct, in_channel_offset, int(tr), bufs[0].data_ptr(), st)
+    if planes_from is None:
+        hip.call("pn_wino4_planes_from_nhwc_f32", x.data_ptr(), b, h, w, layers[0].cin, ct, in_channel_offset, int(tr), bufs[0].data_ptr(), st)
+    else:
+        planes_from(bufs[0])
     last = layers[-1]
     if out is None:
         out = torch.empty((b, h, w, last.cout), dtype=torch.float32, device=dev)
@@ -726,6 +745,7 @@ def _chain_two_d(lib, d) -> bool:
 
 
 _PILLAR_CONV_ON = os.environ.get("PN_PILLAR_CONV", "1") != "0"
+_PILLAR_PLANES_ON = os.environ.get("PN_PILLAR_PLANES", "1") != "0"      # the pillar layer writes the chain's planes itself (no NHWC map in between)
 # taken when the pillar capacity bounds the (pillar, tap) pairs to this fraction of the dense (output, tap) pairs
 _PILLAR_CONV_MAX_FILL = float(os.environ.get("PN_PILLAR_CONV_MAX_FILL", "0.35"))
 
@@ -758,14 +778,20 @@ class PillarConvLayer:
         oh, ow = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
         return vi.n_cap * 9.0 / (self.stride * self.stride) <= _PILLAR_CONV_MAX_FILL * 9.0 * b * oh * ow
 
-    def __call__(self, canvas: torch.Tensor, vi: "VoxelIndex", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def planes_supported(self, b: int, h: int, w: int) -> bool:
+        oh, ow = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
+        return _PILLAR_PLANES_ON and bool(hip.load().pn_pillar_conv_planes_supported(b, oh, ow, self.cout))
+
+    def __call__(self, canvas: torch.Tensor, vi: "VoxelIndex", out: Optional[torch.Tensor] = None, planes: Optional[torch.Tensor] = None):
+        """-> the NHWC output, or (``planes`` given: a buffer of pn_wino4_planes_floats(b, oh, ow, cout) floats) None with the output written as
+        the F(4, 3) planes of ops.conv_chain"""
         hip.require_device(canvas)
         lib = hip.load()
         assert canvas.dim() == 4 and canvas.is_contiguous() and canvas.dtype == torch.float32 and canvas.shape[3] >= self.cin
         b, h, w, ct = canvas.shape
         assert (w, h) == (vi.spec.grid[0], vi.spec.grid[1]) and b == vi.batch and vi.spec.grid[2] == 1, "the voxel index does not describe this canvas"
         oh, ow = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
-        if out is None:
+        if out is None and planes is None:
             out = torch.empty((b, oh, ow, self.cout), dtype=torch.float32, device=canvas.device)
         nbytes = lib.pn_pillar_conv_workspace_bytes(vi.n_cap, b, oh, ow, self.cout)
         ws = _workspace(nbytes, canvas.device)
@@ -773,9 +799,15 @@ class PillarConvLayer:
         prof = _PROFILER
         if prof is not None:
             ev = prof.begin(st)
-        hip.call("pn_pillar_conv3x3_f32", canvas.data_ptr(), b, h, w, self.cin, ct, 0, vi.unq_keys_ptr, vi.num_voxels.data_ptr(), vi.n_cap, self.stride,
-                 self.packed.data_ptr(), self.cout, hip.ptr(self.scale), hip.ptr(self.shift), self.act, out.data_ptr(), out.shape[3], 0,
-                 ws.data_ptr(), nbytes, st)
+        if planes is not None:
+            assert planes.numel() >= lib.pn_wino4_planes_floats(b, oh, ow, self.cout)
+            hip.call("pn_pillar_conv3x3_planes_f32", canvas.data_ptr(), b, h, w, self.cin, ct, 0, vi.unq_keys_ptr, vi.num_voxels.data_ptr(), vi.n_cap,
+                     self.stride, self.packed.data_ptr(), self.cout, hip.ptr(self.scale), hip.ptr(self.shift), self.act, planes.data_ptr(),
+                     ws.data_ptr(), nbytes, st)
+        else:
+            hip.call("pn_pillar_conv3x3_f32", canvas.data_ptr(), b, h, w, self.cin, ct, 0, vi.unq_keys_ptr, vi.num_voxels.data_ptr(), vi.n_cap, self.stride,
+                     self.packed.data_ptr(), self.cout, hip.ptr(self.scale), hip.ptr(self.shift), self.act, out.data_ptr(), out.shape[3], 0,
+                     ws.data_ptr(), nbytes, st)
         if prof is not None:
             # FLOPs actually multiplied: the (pillar, tap) pairs of THIS frame (the nine counters head the workspace; reading them
             # synchronises -- profiling runs only); the events bracket the pair, GEMM and reduce kernels
