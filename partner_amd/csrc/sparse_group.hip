@@ -154,6 +154,8 @@ struct SpwArgs {
   unsigned in_bytes, w_bytes, out_bytes;
   int act;
   int wide4_groups, wide2_groups;      // a wave takes 4 / at least 2 column tiles from this many live groups on
+  int exp;                             // diagnostics (PN_SPARSE_EXP, group4 kernel): bit 0 every weight load reads tap 0 (cache resident), bit 1 every
+                                       // input row load reads one of the first 32 rows
 };
 
 // wave = one group of 32 sites x 32 NC columns (blockIdx.y walks further column groups).  packed weights: pn_pack_conv_weight_f32's layout
@@ -341,10 +343,11 @@ struct UnitCursor {
 };
 
 template <int NC>
-__global__ __launch_bounds__(256, 2) void sparse_conv_group4_kernel(SpwArgs a) {
+__global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel(SpwArgs a) {
   constexpr int LD = 36;
   __shared__ int32_t s_src[32 * 28];
-  __shared__ __attribute__((aligned(16))) float s_buf[4 * 32 * 32 * NC];      // the waves' chunk images (4 x 32 x 36 floats) / afterwards the four partial tiles
+  constexpr int JC = NC > 2 ? 2 : NC;      // column tiles per join pass: 32 KB of LDS instead of 64 for NC = 4 (three blocks per CU instead of two)
+  __shared__ __attribute__((aligned(16))) float s_buf[4 * 32 * 32 * JC];      // the waves' chunk images (4 x 32 x 36 floats) / afterwards the four partial tiles
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int n = min(*a.n_valid, a.cap);
@@ -391,7 +394,8 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_group4_kernel(SpwArgs a) {
   auto request_a = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int sidx = ca.live ? s_src[ca.t * 32 + srow + 8 * q] : -1;
+      int sidx = ca.live ? s_src[ca.t * 32 + srow + 8 * q] : -1;
+      if ((a.exp & 2) && sidx >= 0) sidx = srow + 8 * q;
       const unsigned vo = sidx >= 0 ? (unsigned)sidx * row_bytes + (unsigned)scol * 4u : 0xffffffffu;
       ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, (unsigned)ch * 128u, 0));
     }
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_group4_kernel(SpwArgs a) {
   };
   auto request_b = [&](int slot) __attribute__((always_inline)) {
     const int bcg = ch * 4 + bk;
-    const unsigned so_w = (unsigned)(((cb.t * a.cin_chunks + (bcg >> 2)) * 8 + (bcg & 3) * 2)) * cp16;
+    const unsigned so_w = (unsigned)((((a.exp & 1) ? 0 : cb.t) * a.cin_chunks + (bcg >> 2)) * 8 + (bcg & 3) * 2) * cp16;
 #pragma unroll
     for (int c = 0; c < NC; ++c) fb[slot][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, cb.live ? uoff[c] : 0xffffffffu, so_w, 0));
     if (++bk == 4) { bk = 0; cb.next(); }
@@ -423,32 +427,36 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_group4_kernel(SpwArgs a) {
       request_b(k & 1);
     }
   }
-  // ---- join: [wave][c][r][lane] partial tiles, summed wave 0 + 1 + 2 + 3; wave w finishes registers 4 w .. 4 w + 3 (rows 8 w' .. ) of every tile
-  __syncthreads();      // every wave is done with its chunk image
-#pragma unroll
-  for (int c = 0; c < NC; ++c)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s_buf[((wv * NC + c) * 16 + r) * 64 + lane] = acc[c][r];
-  __syncthreads();
+  // ---- join: [wave][c][r][lane] partial tiles, summed wave 0 + 1 + 2 + 3; wave w finishes registers 4 w .. 4 w + 3 (rows 8 w' .. ) of every tile;
+  // JC column tiles per pass
   const bool relu = a.act == PN_ACT_RELU;
   const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res), 0, a.res ? a.out_bytes : 0u, 0x00020000);
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const int col = n0 + 32 * c + li;
-    const bool cok = col < a.cout;
-    const float sc = (cok && a.scale) ? a.scale[col] : 1.f;
-    const float sh = (cok && a.shift) ? a.shift[col] : 0.f;
+  for (int c0 = 0; c0 < NC; c0 += JC) {
+    __syncthreads();      // every wave is done with its chunk image / the previous pass
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int r = 4 * wv + rr;
-      const int orow = s_src[27 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
-      const unsigned off = (cok && orow >= 0) ? ((unsigned)orow * (unsigned)a.cout + (unsigned)col) * 4u : 0xffffffffu;
-      const float rv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, off, 0, 0));
-      float v = ((s_buf[((0 * NC + c) * 16 + r) * 64 + lane] + s_buf[((1 * NC + c) * 16 + r) * 64 + lane]) + s_buf[((2 * NC + c) * 16 + r) * 64 + lane]) +
-                s_buf[((3 * NC + c) * 16 + r) * 64 + lane];
-      v = fmaf(v, sc, sh) + rv;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu ? fmaxf(v, 0.f) : v), rsrc_o, off, 0, 0);
+    for (int c = 0; c < JC; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_buf[((wv * JC + c) * 16 + r) * 64 + lane] = acc[c0 + c][r];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < JC; ++c) {
+      const int col = n0 + 32 * (c0 + c) + li;
+      const bool cok = col < a.cout;
+      const float sc = (cok && a.scale) ? a.scale[col] : 1.f;
+      const float sh = (cok && a.shift) ? a.shift[col] : 0.f;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = 4 * wv + rr;
+        const int orow = s_src[27 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+        const unsigned off = (cok && orow >= 0) ? ((unsigned)orow * (unsigned)a.cout + (unsigned)col) * 4u : 0xffffffffu;
+        const float rv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, off, 0, 0));
+        float v = ((s_buf[((0 * JC + c) * 16 + r) * 64 + lane] + s_buf[((1 * JC + c) * 16 + r) * 64 + lane]) + s_buf[((2 * JC + c) * 16 + r) * 64 + lane]) +
+                  s_buf[((3 * JC + c) * 16 + r) * 64 + lane];
+        v = fmaf(v, sc, sh) + rv;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu ? fmaxf(v, 0.f) : v), rsrc_o, off, 0, 0);
+      }
     }
   }
 }
@@ -485,6 +493,9 @@ int pn_sparse_conv_grouped_f32(const float* in, int in_rows, int cin, const int3
   static const int t4 = [] { const char* e = getenv("PN_SPARSE_WIDE4"); return e ? atoi(e) : 1536; }();
   static const int t2 = [] { const char* e = getenv("PN_SPARSE_WIDE2"); return e ? atoi(e) : 512; }();
   a.wide4_groups = t4; a.wide2_groups = t2;
+  static const int ex = [] { const char* e = getenv("PN_SPARSE_EXP"); return e ? atoi(e) : 0; }();
+  a.exp = ex;
+
   hipStream_t st = pn::S(stream);
   const int blocks = (pn::cdiv(pn::cdiv(out_capacity, 32), 4) + 7) / 8 * 8;
   pn::ProfileSlot ps{};
@@ -499,7 +510,15 @@ int pn_sparse_conv_grouped_f32(const float* in, int in_rows, int cin, const int3
   static const int g4 = [] { const char* e = getenv("PN_SPARSE_GROUP4"); return e ? atoi(e) : 1; }();
   if (g4 && cin % 32 == 0 && cin >= 64 && ncol32 >= 2) {      // block per group, K split over its waves
     const dim3 grid((unsigned)((pn::cdiv(out_capacity, 32) + 7) / 8 * 8), 1);
-    if (ncol32 == 4) {
+    // 128 columns: two blocks of 64 columns per group (the input rows are gathered twice; blocks half as long, four per CU instead of three:
+    // 380 -> 365 us on the bench frame's 128 -> 128 layers).  Heavy-groups-first block orders were tried and lose: the contiguous run of
+    // groups an XCD walks shares neighbour rows in its L2 (global order by tap count: +15 %)
+    static const int split = [] { const char* e = getenv("PN_SPARSE_G4SPLIT"); return e ? atoi(e) : 1; }();
+    if (ncol32 == 4 && split) {
+      const dim3 grid2(grid.x, 2);
+      if (prof) hipExtLaunchKernelGGL(sparse_conv_group4_kernel<2>, grid2, dim3(256), 0, st, ps.start, ps.stop, 0, a);
+      else hipLaunchKernelGGL(sparse_conv_group4_kernel<2>, grid2, dim3(256), 0, st, a);
+    } else if (ncol32 == 4) {
       if (prof) hipExtLaunchKernelGGL(sparse_conv_group4_kernel<4>, grid, dim3(256), 0, st, ps.start, ps.stop, 0, a);
       else hipLaunchKernelGGL(sparse_conv_group4_kernel<4>, grid, dim3(256), 0, st, a);
     } else {
