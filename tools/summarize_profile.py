@@ -57,15 +57,22 @@ def main(stats_dir, fetch_dir, write_dir, bench_log, out_prefix):
     if sq_dir:
         sq = pmc(sq_dir)
         with open(out_prefix + "_pmc_mfma.csv", "w") as f:
+            # mfma_util divides by the cycles the GPU is active AROUND the kernel in the counter pass, which carry a fixed ~11-14 us of
+            # counter start / stop per launch (a 19 us kernel shows 30 us of GRBM_GUI_ACTIVE): the last two columns put the same busy cycles
+            # over the kernel's duration in the undisturbed kernel-trace pass, at the 2.4 GHz peak clock (the clock under these kernels is
+            # 2.25-2.4 GHz, tools/micro/wchain_check.hip)
+            trace_ns = {short(r["Name"]): float(r["AverageNs"]) for r in stats}
             f.write("kernel,launches,SQ_VALU_MFMA_BUSY_CYCLES_avg,GRBM_GUI_ACTIVE_avg(sum of 8 XCDs),mfma_util,SQ_WAIT_ANY/SQ_WAVE_CYCLES,"
-                    "SQ_WAIT_INST_ANY/SQ_WAVE_CYCLES,SQ_LDS_BANK_CONFLICT_avg\n")
+                    "SQ_WAIT_INST_ANY/SQ_WAVE_CYCLES,SQ_LDS_BANK_CONFLICT_avg,avg_us_kernel_trace,mfma_busy_over_trace_time_at_2.4GHz\n")
             for k in sorted(sq):
                 a = lambda c: (sum(sq[k][c]) / len(sq[k][c])) if sq[k].get(c) else float("nan")
                 busy, gui, wc = a("SQ_VALU_MFMA_BUSY_CYCLES"), a("GRBM_GUI_ACTIVE"), a("SQ_WAVE_CYCLES")
                 if not busy or busy != busy or busy == 0:
                     continue
+                t = trace_ns.get(k)
                 f.write(f"\"{k}\",{len(sq[k]['SQ_WAVE_CYCLES'])},{busy:.0f},{gui:.0f},{busy / (gui / 8 * 1024):.3f},"
-                        f"{a('SQ_WAIT_ANY') / wc:.3f},{a('SQ_WAIT_INST_ANY') / wc:.3f},{a('SQ_LDS_BANK_CONFLICT'):.0f}\n")
+                        f"{a('SQ_WAIT_ANY') / wc:.3f},{a('SQ_WAIT_INST_ANY') / wc:.3f},{a('SQ_LDS_BANK_CONFLICT'):.0f},"
+                        + (f"{t / 1e3:.2f},{busy / 1024 / (t * 2.4):.3f}" if t else ",") + "\n")
     if bench:
         json.dump(bench, open(out_prefix + "_bench_line.json", "w"), indent=1)
     print("wrote", out_prefix + "_kernel_stats.csv", out_prefix + "_pmc_traffic.csv")
