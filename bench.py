@@ -19,7 +19,7 @@ collective); the timed region is bracketed by barrier + device synchronise and t
 over ranks is reported.
 
 Objects in the JSON line:
-  value / ms_per_step        the timed region: K hipGraph replays, `--streams` frames in flight (default 4)
+  value / ms_per_step        the timed region: K hipGraph replays, `--streams` frames in flight (default 3)
   single_stream_ms_per_step  the same K replays with ONE frame in flight (latency regime) -- the regime `roofline` is
                              quoted in, so roofline.conv_ms_per_step <= single_stream_ms_per_step
   roofline          the dominant kernel (fp32-MFMA implicit-GEMM convolution): algorithmic FLOPs of every launch / its
@@ -493,7 +493,10 @@ def main():
     ap.add_argument("--no-batched", action="store_true", help="skip the throughput measurement at the reference config's batch of 4 sweeps per step")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replays")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for a same-GPU dry run)")
-    ap.add_argument("--streams", type=int, default=4, help="frames in flight per GPU (one hipGraph engine per HIP stream)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="frames in flight per GPU (one hipGraph engine per HIP stream).  r4: 3 -- with the chained kernels (a block fills its CU) three and "
+                         "four frames in flight sustain the same rate over 50 steps (1557 / 1560 frames/s), and over the 20 steps the driver times three "
+                         "lose less to the ramp (1537 against 1482, five runs each)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the launcher, the rendezvous and the reductions only")
     ap.add_argument("--collective-timeout", type=float, default=300.0, help="seconds a rank waits in a collective before it gives up (N > 1)")
     ap.add_argument("--no-c4", action="store_true", help="skip the Waymo PARTNER leg (BASELINE configs[3], N = 1 only)")

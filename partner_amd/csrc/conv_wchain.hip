@@ -989,7 +989,13 @@ int pn_conv2d_wino24_chain_head_multi_f32(const pn_chain_head_job* jobs, int njo
   pn::ProfileSlot ps{};
   const bool prof = pn::take_profile_slot(ps);
   hipStream_t st = pn::S(stream);
-  if (f0.ks == 2) launch_chain2_multi<2, 1, 1>(m, st, prof, ps);
+  // short K (the head's 64 input channels: four steps per K half), enough tiles for two blocks per CU and other frames in flight
+  // (pn_conv_desc.frames_in_flight): six-wave blocks that keep the whole K -- half the waves, no K join; alone on the chip the launch is
+  // 3 us slower (39.6 against 36.3 us), beside three other frames the whole job gains 1.5 % (PN_WCHAIN_MULTI_KS1=0 / 2: never / always)
+  static const int ks1 = [] { const char* e = getenv("PN_WCHAIN_MULTI_KS1"); return e ? atoi(e) : 1; }();
+  const bool others = ks1 == 2 || (ks1 == 1 && jobs[0].desc->frames_in_flight > 1);
+  if (f0.ks == 2 && others && m.job[0].cg_in <= 8 && m.first[njobs] >= 2 * chain_grid_limit()) launch_chain2_multi<1, 1, 1>(m, st, prof, ps);
+  else if (f0.ks == 2) launch_chain2_multi<2, 1, 1>(m, st, prof, ps);
   else launch_chain2_multi<1, 1, 2>(m, st, prof, ps);
   return pn::check_launch("conv_wchain2_multi_kernel");
 }

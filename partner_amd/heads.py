@@ -531,6 +531,7 @@ class CenterHeadSingle(CenterHead):
         cjobs = (hip.ChainHeadJob * len(parts))()
         for cj, g, part in zip(cjobs, cp["groups"], parts):
             src = planes_hm if (g["src"] == "hm" and planes_hm is not None) else planes_xs
+            g["desc"].frames_in_flight = ops._FRAMES_IN_FLIGHT
             cj.desc = C.pointer(g["desc"])
             cj.planes_in, cj.packed_w24, cj.scale, cj.shift = src.data_ptr(), g["packed"].data_ptr(), None, hip.ptr(g["bias"])
             cj.planes_out, cj.out_nhwc, cj.stat_partials = None, mid.data_ptr(), part.data_ptr()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profiles of one round, on the GPU box:  tools/prof_round.sh r2
 #   1. kernel trace + stats, one frame in flight (the regime the roofline object is quoted in)
-#   2. kernel trace + stats of the DEFAULT bench command (4 frames in flight)
+#   2. kernel trace + stats of the DEFAULT bench command (frames in flight: bench.py's --streams default)
 #   3. PMC passes (separate runs, --kernel-trace only next to --pmc): FETCH_SIZE, WRITE_SIZE, SQ counters
 # and the condensed summaries under profiles/<prefix>_* (tools/summarize_profile.py).  The program goes directly after `--`.
 set -e
@@ -26,7 +26,7 @@ import csv, glob, sys
 out, pfx = sys.argv[1], sys.argv[2]
 f = glob.glob(out + "/stats4/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-with open(f"{out}/sum/{pfx}_4streams_kernel_stats.csv", "w") as o:
+with open(f"{out}/sum/{pfx}_inflight_kernel_stats.csv", "w") as o:
     o.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
     for r in rows:
         name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
