@@ -1155,6 +1155,15 @@ def concurrent_stream(device=None) -> "torch.cuda.Stream":
     return best
 
 
+def probe_streams(device=None) -> None:
+    """Explicit form of the probing ``concurrent_stream`` does on first use: ~60 device-wide synchronisations and up to twelve
+    stream creations.  Serving / training loops call it once up front, on the stream they will run on and BEFORE any hipGraph capture
+    starts on another thread (a device-wide synchronisation invalidates a capture in progress); afterwards ``concurrent_stream`` is a
+    dictionary lookup.  The frames-in-flight hint (``frames_in_flight``) is a process global: engines are captured from one thread."""
+    if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        concurrent_stream(device)
+
+
 def concurrent_streams(k: int, device=None, candidates: int = 16):
     """k streams that overlap with EACH OTHER (several hipGraph engines replaying at once: engines whose streams share a hardware queue run
     their frames one after the other).  Greedy: a candidate joins the set when a spin kernel on it and one on every member finish in about
