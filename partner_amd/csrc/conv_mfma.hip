@@ -1240,7 +1240,12 @@ __device__ __forceinline__ void small_n_tiled_body(const ConvArgs& a, const int 
         const float* wp = w_lds + ((t * 16 + (c0 >> 2) + cc) * NOUT) * 4;
 #pragma unroll
         for (int n = 0; n < NOUT; ++n) {   // columns past Cout are zero in the packed weights
+#ifdef PN_SNT_EXP
+          const f32x4 wv = {(float)n, (float)t, (float)cc, 1.f};      // diagnostic build: no weight reads
+          (void)wp;
+#else
           const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + n * 4);
+#endif
 #pragma unroll
           for (int k = 0; k < 4; ++k) acc[n] = fmaf(xv[k], wv[k], acc[n]);
         }

@@ -15,6 +15,7 @@
 // Rotated IoU: overlap polygon = edge crossings + contained corners (1e-2 margin), ordered by angle about their mean,
 // fan-summed cross products -- the oracle's box_nms.c is the same arithmetic on the CPU.
 #include "pn_common.h"
+#include <type_traits>
 #include "box_geom.h"
 #include <algorithm>
 
@@ -201,6 +202,14 @@ __global__ void double_flip_merge_kernel(FlipArgs a) {
   }
 }
 
+#ifdef PN_SORT_STAMP
+unsigned long long* pn_sort_stamps = nullptr;      // diagnostic build only (tools/micro/select_sort_check.hip): shader-clock stamps of the phases
+#define SORT_STAMP(k) do { if (threadIdx.x == 0 && pn_sort_stamps_dev) pn_sort_stamps_dev[k] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long* pn_sort_stamps_dev = nullptr;
+#else
+#define SORT_STAMP(k) do { } while (0)
+#endif
+
 // one block per sample
 constexpr int kHistBins = 4096;   // score bits [30:19]: exponent + 4 mantissa bits
 constexpr size_t kSortLds = (size_t)kCap * sizeof(unsigned long long) + (size_t)kHistBins * sizeof(int);
@@ -213,9 +222,11 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
   unsigned long long* keys = sort_lds;                       // [kCap]
   int* hist = reinterpret_cast<int*>(sort_lds + kCap);       // [kHistBins]
   __shared__ int wave_cnt[kSortThreads / 64];
+  __shared__ int chunk_tot[kHistBins / 64];
   __shared__ int n_valid, cut_bin, n_ge, n_kept, sub_cut;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float* sc = score + (size_t)b * cells;
+  SORT_STAMP(0);
   if (tid == 0) { n_valid = 0; n_kept = 0; }
   for (int i = tid; i < kHistBins; i += kSortThreads) hist[i] = 0;
   __syncthreads();
@@ -240,59 +251,84 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
     if (lane == 0 && mine) atomicAdd(&n_valid, mine);
   }
   __syncthreads();
-  // ---- the bin in which the `need`-th best falls: one wave walks the histogram from the top, 64 bins per step
-  //      -> (bin, number of entries at or above it); bin 0 / total when fewer than `need` entries exist
-  auto find_cut = [&](int need, int total, int& bin_out, int& ge_out) {
-    int acc = 0, found = -1, ge = total;
-    if (total > need) {
-      for (int hi = kHistBins - 64; hi >= 0 && found < 0; hi -= 64) {
-        const int v = hist[hi + 63 - lane];                 // lane 0 = highest bin of the chunk
-        int inc = v;
+  SORT_STAMP(1);
+  // ---- the bin in which the `need`-th best falls -> (bin, number of entries at or above it); bin 0 / total when fewer than `need` entries
+  //      exist.  Two levels: every wave totals four 64-bin chunks, then one wave scans the 64 chunk totals from the top and the bins of
+  //      the chunk that holds the `need`-th (r4; one wave walking the histogram 64 bins per step took 9 us on a score map whose top bins
+  //      are empty -- 32 dependent steps before the first occupied bin).  Called by every thread of the block.
+  auto find_cut = [&](int need, int total, int* bin_out, int* ge_out) {
+    for (int c = wv; c < kHistBins / 64; c += kSortThreads / 64) {
+      int v = hist[64 * c + lane];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int t = __shfl_up(inc, o, 64);
-          if (lane >= o) inc += t;
-        }
-        const unsigned long long hit = __ballot(acc + inc >= need);
-        if (hit) {
-          const int l = __ffsll((long long)hit) - 1;
-          found = hi + 63 - l;
-          ge = acc + __shfl(inc, l, 64);
-        }
-        acc += __shfl(inc, 63, 64);
-      }
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) chunk_tot[c] = v;
     }
-    bin_out = found < 0 ? 0 : found;
-    ge_out = ge;
+    __syncthreads();
+    if (wv == 0) {
+      int found = 0, ge = total;
+      if (total > need) {
+        auto scan_from_top = [&](int v, int base, int& pos, int& upto) {      // lane 0 = the highest entry; -> first lane whose inclusive sum reaches need
+          int inc = v;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+          }
+          const unsigned long long hit = __ballot(base + inc >= need);
+          pos = hit ? __ffsll((long long)hit) - 1 : 63;
+          upto = base + __shfl(inc, pos, 64);
+        };
+        int lc, upto_c;
+        scan_from_top(chunk_tot[kHistBins / 64 - 1 - lane], 0, lc, upto_c);
+        const int chunk = kHistBins / 64 - 1 - lc;
+        const int above = upto_c - chunk_tot[chunk];                          // entries in the chunks above
+        int lb, upto_b;
+        scan_from_top(hist[64 * chunk + 63 - lane], above, lb, upto_b);
+        found = 64 * chunk + 63 - lb;
+        ge = upto_b;
+      }
+      if (lane == 0) { *bin_out = found; *ge_out = ge; }
+    }
+    __syncthreads();
   };
-  if (wv == 0) {
-    int cb, ge;
-    find_cut(pre_max, n_valid, cb, ge);
-    if (lane == 0) { cut_bin = cb; n_ge = ge; sub_cut = 0; }
-  }
+  find_cut(pre_max, n_valid, &cut_bin, &n_ge);
+  if (tid == 0) sub_cut = 0;
   __syncthreads();
+  SORT_STAMP(2);
   const unsigned cut = (unsigned)cut_bin;
-  // More candidates at or above the cut bin than the sort buffer holds (a near-constant score map: an untrained head puts a whole
-  // map into one bin of the top 12 score bits): refine INSIDE the cut bin with a second histogram on the next 12 bits, so that the
-  // candidates are still the best by score and not the first in cell order.
-  if (n_ge > kCap) {
+  // More candidates at or above the cut bin than ONE power of two above pre_max (r4; before: than the sort buffer holds): refine INSIDE the
+  // cut bin with a second histogram on the next 12 bits.  The sort then runs on ~pre_max keys instead of every key of the cut bin (a
+  // 2048- or 4096-key bitonic sort was 31 - 62 us of this kernel; the extra pass over the L2-resident scores is 3 us), and on a
+  // near-constant score map (an untrained head puts a whole map into one bin of the top 12 score bits) the candidates are still the
+  // best by score and not the first in cell order.
+  int refine_above = 1;
+  while (refine_above < pre_max) refine_above <<= 1;
+  refine_above = min(refine_above, kCap);
+  if (n_ge > refine_above) {
     const int n_above = n_ge - hist[cut];    // entries in the bins above the cut: fewer than pre_max by construction
     __syncthreads();
     for (int i = tid; i < kHistBins; i += kSortThreads) hist[i] = 0;
     __syncthreads();
-    for (int c = tid; c < cells; c += kSortThreads) {
-      const float s = sc[c];
-      const unsigned u = __builtin_bit_cast(unsigned, s);
-      if (s >= 0.f && ((u >> 19) & (kHistBins - 1)) == cut) atomicAdd(&hist[(u >> 7) & (kHistBins - 1)], 1);
+    for (int c0 = 0; c0 < cells; c0 += kSortThreads * kBatch) {
+      float sv[kBatch];
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) {
+        const int c = c0 + k * kSortThreads + tid;
+        sv[k] = c < cells ? sc[c] : -1.f;
+      }
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) {
+        const unsigned u = __builtin_bit_cast(unsigned, sv[k]);
+        if (sv[k] >= 0.f && ((u >> 19) & (kHistBins - 1)) == cut) atomicAdd(&hist[(u >> 7) & (kHistBins - 1)], 1);
+      }
     }
     __syncthreads();
-    if (wv == 0) {
-      int sb, ge;
-      find_cut(pre_max - n_above, n_ge - n_above, sb, ge);
-      if (lane == 0) { sub_cut = sb; n_ge = n_above + ge; }
-    }
+    const int n_ge_before = n_ge;
+    find_cut(pre_max - n_above, n_ge_before - n_above, &sub_cut, &n_ge);
+    if (tid == 0) n_ge += n_above;
     __syncthreads();
   }
+  SORT_STAMP(3);
   const unsigned scut = (unsigned)sub_cut;
   auto at_or_above = [&](float s) {
     const unsigned u = __builtin_bit_cast(unsigned, s), bin = (u >> 19) & (kHistBins - 1);
@@ -348,12 +384,62 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
       }
   }
   __syncthreads();
+  SORT_STAMP(4);
   const int n = min(n_kept, kCap);
   int npad = 1;
   while (npad < n) npad <<= 1;
   for (int i = n + tid; i < npad; i += kSortThreads) keys[i] = 0ull;
   __syncthreads();
-  // ---- bitonic sort, descending
+  // ---- bitonic sort, descending.  Up to 2048 keys (the usual case since r4's refinement: ~pre_max candidates) stay in REGISTERS, one or two
+  //      per thread: exchange distances inside a wave are lane shuffles -- no LDS write -> read round trip per pass, 45 of the 55 passes of a
+  //      1024-key sort --, only distances >= 64 E go through LDS.  Same network, same result.
+  auto reg_sort = [&](auto e_tag) {
+    constexpr int E = decltype(e_tag)::value;
+    const bool active = E * tid < npad;
+    unsigned long long e[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) e[r] = active ? keys[E * tid + r] : 0ull;
+    auto take = [](unsigned long long x, unsigned long long o, bool mx) { return mx ? (x > o ? x : o) : (x < o ? x : o); };
+    for (int k = 2; k <= npad; k <<= 1) {
+      for (int j = k >> 1; j >= 64 * E; j >>= 1) {
+        __syncthreads();      // (the previous LDS stage's reads)
+        if (active) {
+#pragma unroll
+          for (int r = 0; r < E; ++r) keys[E * tid + r] = e[r];
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+          for (int r = 0; r < E; ++r) {
+            const int i = E * tid + r;
+            e[r] = take(e[r], keys[i ^ j], ((i & j) == 0) == ((i & k) == 0));
+          }
+        }
+      }
+      for (int j = min(k >> 1, 32 * E); j >= E; j >>= 1) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const int i = E * tid + r;
+          const unsigned lo32 = __shfl_xor((unsigned)e[r], j / E, 64), hi32 = __shfl_xor((unsigned)(e[r] >> 32), j / E, 64);
+          e[r] = take(e[r], ((unsigned long long)hi32 << 32) | lo32, ((i & j) == 0) == ((i & k) == 0));
+        }
+      }
+      if constexpr (E == 2) {
+        const bool desc = ((2 * tid) & k) == 0;
+        const unsigned long long hi = e[0] > e[1] ? e[0] : e[1], lo = e[0] > e[1] ? e[1] : e[0];
+        e[0] = desc ? hi : lo;
+        e[1] = desc ? lo : hi;
+      }
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < E; ++r) keys[E * tid + r] = e[r];
+    }
+  };
+  if (npad <= kSortThreads) reg_sort(std::integral_constant<int, 1>{});
+  else if (npad <= 2 * kSortThreads) reg_sort(std::integral_constant<int, 2>{});
+  else
   for (int k = 2; k <= npad; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int i = tid; i < npad; i += kSortThreads) {
@@ -370,6 +456,7 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
       if (!(cur_local && next_local)) __syncthreads();
     }
   __syncthreads();
+  SORT_STAMP(5);
   const int m = min(n, pre_max);
   if (tid == 0) n_sel[b] = m;
   for (int i = tid; i < m; i += kSortThreads) {
@@ -382,6 +469,11 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const float* 
     d[0] = src[0]; d[1] = src[1]; d[2] = src[2]; d[3] = src[4]; d[4] = src[3]; d[5] = src[5];
     d[6] = -src[nb - 1] - 1.57079632679489661923f;
   }
+  SORT_STAMP(6);
+  if (tid == 0) { SORT_STAMP(7); }
+#ifdef PN_SORT_STAMP
+  if (tid == 0 && pn_sort_stamps_dev) { pn_sort_stamps_dev[8] = (unsigned long long)n_valid; pn_sort_stamps_dev[9] = (unsigned long long)n_ge; pn_sort_stamps_dev[10] = (unsigned long long)n; pn_sort_stamps_dev[11] = (unsigned long long)npad; }
+#endif
 }
 
 // cheap necessary condition for a non-empty overlap (the test at the top of iou_bev)
@@ -397,52 +489,67 @@ __device__ __forceinline__ bool may_overlap(const float* a, const float* b) {
 // laid out as one list in LDS and dealt evenly over the 64 lanes; hits are OR-ed into the row masks (integer atomics).
 // per_class: boxes of different classes never suppress each other (detectron2's batched_nms_rotated moves every class to its
 // own region of the plane before one NMS; the same decision without the coordinate offsets).
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ nms_boxes, const int* __restrict__ n_sel, int pre_max, int col_blocks,
-                                                      float thresh, unsigned long long* __restrict__ mask, const int* __restrict__ sel_label,
-                                                      int per_class) {
+constexpr int kMaskThreads = 256;
+__global__ __launch_bounds__(kMaskThreads) void nms_mask_kernel(const float* __restrict__ nms_boxes, const int* __restrict__ n_sel, int pre_max, int col_blocks,
+                                                                float thresh, unsigned long long* __restrict__ mask, const int* __restrict__ sel_label,
+                                                                int per_class) {
+  // r4: four waves per tile.  Phase 1 (row = lane of wave 0 .. 3: each wave tests a quarter of the columns) and the pair list are cheap; the
+  // polygon intersections of phase 2 -- up to 4096 candidate pairs on a tile of crowded boxes, ~2 k clocks each and divergent -- are dealt over
+  // 256 lanes instead of 64 (one wave per tile left 136 waves on the chip for 63 us at 1000 boxes).
   __shared__ float cb[64 * 7], rbx[64 * 7];
   __shared__ int clab[64];
   __shared__ unsigned long long cand[64], hit[64];
   __shared__ unsigned short pairs[64 * 64];
-  const int b = blockIdx.z, rb = blockIdx.y, cbk = blockIdx.x, lane = threadIdx.x;
+  __shared__ int total_s;
+  const int b = blockIdx.z, rb = blockIdx.y, cbk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = n_sel[b];
   if (cbk < rb || rb * 64 >= n || cbk * 64 >= n) return;
   const float* bx = nms_boxes + (size_t)b * pre_max * 7;
   const int col_size = min(64, n - cbk * 64), row_size = min(64, n - rb * 64);
-  if (lane < col_size)
-    for (int k = 0; k < 7; ++k) cb[lane * 7 + k] = bx[(size_t)(cbk * 64 + lane) * 7 + k];
-  if (lane < row_size)
-    for (int k = 0; k < 7; ++k) rbx[lane * 7 + k] = bx[(size_t)(rb * 64 + lane) * 7 + k];
-  clab[lane] = (per_class && lane < col_size) ? sel_label[(size_t)b * pre_max + cbk * 64 + lane] : 0;
+  for (int i = tid; i < col_size * 7; i += kMaskThreads) cb[i] = bx[(size_t)cbk * 64 * 7 + i];
+  for (int i = tid; i < row_size * 7; i += kMaskThreads) rbx[i] = bx[(size_t)rb * 64 * 7 + i];
+  if (tid < 64) {
+    clab[tid] = (per_class && tid < col_size) ? sel_label[(size_t)b * pre_max + cbk * 64 + tid] : 0;
+    hit[tid] = 0ull;
+    cand[tid] = 0ull;
+  }
   const int my_label = (per_class && lane < row_size) ? sel_label[(size_t)b * pre_max + rb * 64 + lane] : 0;
-  hit[lane] = 0ull;
   __syncthreads();
-  unsigned long long c = 0ull;
-  if (lane < row_size)
-    for (int i = (rb == cbk ? lane + 1 : 0); i < col_size; ++i)
-      if (clab[i] == my_label && may_overlap(rbx + lane * 7, cb + i * 7)) c |= 1ull << i;
-  cand[lane] = c;
-  // exclusive prefix of the per-row candidate counts -> each row writes its (row, col) pairs into the list
-  int cnt = __popcll(c), inc = cnt;
+  {
+    unsigned long long c = 0ull;
+    if (lane < row_size) {
+      const int i0 = max(16 * wv, rb == cbk ? lane + 1 : 0), i1 = min(16 * wv + 16, col_size);
+      for (int i = i0; i < i1; ++i)
+        if (clab[i] == my_label && may_overlap(rbx + lane * 7, cb + i * 7)) c |= 1ull << i;
+    }
+    if (c) atomicOr(&cand[lane], c);
+  }
+  __syncthreads();
+  if (wv == 0) {
+    // exclusive prefix of the per-row candidate counts -> each row writes its (row, col) pairs into the list
+    unsigned long long c = cand[lane];
+    int cnt = __popcll(c), inc = cnt;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
-  }
-  const int total = __shfl(inc, 63, 64);
-  int pos = inc - cnt;
-  while (c) {
-    const int i = __ffsll((long long)c) - 1;
-    c &= c - 1;
-    pairs[pos++] = (unsigned short)(lane << 6 | i);
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) total_s = inc;
+    int pos = inc - cnt;
+    while (c) {
+      const int i = __ffsll((long long)c) - 1;
+      c &= c - 1;
+      pairs[pos++] = (unsigned short)(lane << 6 | i);
+    }
   }
   __syncthreads();
-  for (int p = lane; p < total; p += 64) {
+  const int total = total_s;
+  for (int p = tid; p < total; p += kMaskThreads) {
     const int r = pairs[p] >> 6, i = pairs[p] & 63;
     if (iou_bev(rbx + r * 7, cb + i * 7) > thresh) atomicOr(&hit[r], 1ull << i);
   }
   __syncthreads();
-  if (lane < row_size) mask[((size_t)b * pre_max + rb * 64 + lane) * col_blocks + cbk] = hit[lane];
+  if (tid < row_size) mask[((size_t)b * pre_max + rb * 64 + tid) * col_blocks + cbk] = hit[tid];
 }
 
 // grid B, one wave: lane l owns word l of the removed set (pre_max <= 4096)
@@ -462,6 +569,52 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long
       if (lane == 0) keep[(size_t)b * post_max + m] = i;
       ++m;
       if (lane >= (i >> 6)) removed |= row;  // words before the row's own block were never written (upper triangle only)
+    }
+  }
+  if (lane == 0) n_keep[b] = m;
+}
+
+// r4: the same greedy walk with the sample's mask rows staged in LDS first (pre_max * col_blocks * 8 bytes <= 128 KB: 1000 boxes) and the
+// suppressed boxes skipped by bit scans: one LDS row read per KEPT box (<= post_max of them) instead of one global row per candidate -- the
+// walk over 1000 candidates of crowded boxes took 26 us, a quarter of the post-processing.  Identical keep list.
+constexpr int kReduceThreads = 1024;
+__global__ __launch_bounds__(kReduceThreads) void nms_reduce_lds_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ n_sel, int pre_max,
+                                                                        int col_blocks, int post_max, int* __restrict__ keep, int* __restrict__ n_keep) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long rows[];      // [n][col_blocks]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int n = n_sel[b];
+  const unsigned long long* mk = mask + (size_t)b * pre_max * col_blocks;
+  // (words left of a row's own block were never written by nms_mask_kernel: they are staged as they are and masked out below)
+  // (every load of a thread in flight before the first lands: one at a time the staging alone took 30 us)
+  {
+    const int total = n * col_blocks;
+    constexpr int UN = 8;
+    for (int i0 = tid; i0 < total; i0 += kReduceThreads * UN) {
+      unsigned long long v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) v[u] = i0 + u * kReduceThreads < total ? mk[i0 + u * kReduceThreads] : 0ull;
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (i0 + u * kReduceThreads < total) rows[i0 + u * kReduceThreads] = v[u];
+    }
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  unsigned long long removed = 0ull;
+  int m = 0;
+  const int nblk = (n + 63) >> 6;
+  for (int blk = 0; blk < nblk && m < post_max; ++blk) {
+    const int left = n - 64 * blk;
+    const unsigned long long valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+    unsigned long long done = 0ull;      // bits of this block already decided
+    while (m < post_max) {
+      const unsigned long long alive = ~__shfl(removed, blk, 64) & valid & ~done;
+      if (!alive) break;
+      const int bit = __ffsll((long long)alive) - 1, i = 64 * blk + bit;
+      if (lane == 0) keep[(size_t)b * post_max + m] = i;
+      ++m;
+      if (lane >= blk && lane < col_blocks) removed |= rows[(size_t)i * col_blocks + lane];
+      done |= bit == 63 ? ~0ull : ((2ull << bit) - 1ull);
     }
   }
   if (lane == 0) n_keep[b] = m;
@@ -529,9 +682,17 @@ int run_decode_nms(DecodeArgs a, const float* post_center_range, float nms_iou_t
   hipLaunchKernelGGL(select_sort_kernel, dim3(batch), dim3(kSortThreads), kSortLds, st, ws.score, ws.boxes, cells, nb, pre_max, ws.sel_cell,
                      ws.nms_boxes, ws.n_sel, ws.label, ws.sel_label);
   const int cbk = (pre_max + 63) / 64;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(cbk, cbk, batch), dim3(64), 0, st, ws.nms_boxes, ws.n_sel, pre_max, cbk, nms_iou_threshold, ws.mask,
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(cbk, cbk, batch), dim3(kMaskThreads), 0, st, ws.nms_boxes, ws.n_sel, pre_max, cbk, nms_iou_threshold, ws.mask,
                      ws.sel_label, per_class_nms != 0);
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(batch), dim3(64), 0, st, ws.mask, ws.n_sel, pre_max, cbk, post_max, ws.keep, out_count);
+  const size_t rows_bytes = (size_t)pre_max * cbk * sizeof(unsigned long long);
+  if (rows_bytes <= 128 * 1024) {
+    static bool red_attr[64] = {false};
+    if (pn::first_use_on_device(red_attr))
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_reduce_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipLaunchKernelGGL(nms_reduce_lds_kernel, dim3(batch), dim3(kReduceThreads), rows_bytes, st, ws.mask, ws.n_sel, pre_max, cbk, post_max, ws.keep, out_count);
+  } else {
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(batch), dim3(64), 0, st, ws.mask, ws.n_sel, pre_max, cbk, post_max, ws.keep, out_count);
+  }
   hipLaunchKernelGGL(gather_kernel, dim3((post_max + 127) / 128, batch), dim3(128), 0, st, ws.keep, out_count, ws.sel_cell, ws.boxes, ws.score,
                      ws.label, cells, nb, pre_max, post_max, out_boxes, out_scores, out_labels, out_cells);
   return pn::check_launch("decode_nms");
