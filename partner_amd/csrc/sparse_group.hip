@@ -196,7 +196,8 @@ __device__ __forceinline__ void sparse_conv_wave_body(const SpwArgs& a, int32_t*
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
   // two request pointers walk the same sequence (taps of the group's mask ascending, channels ascending): the input rows one CHUNK ahead
-  // of the MFMAs, the weight fragments two K STEPS ahead
+  // of the MFMAs, the weight fragments two K STEPS ahead (r4: a whole chunk ahead changes nothing on the 32 -> 32 layers, 137 us either
+  // way, and neither does serving every weight or every input row from a cache-resident set: the loop is not waiting for memory)
   unsigned am = gm;
   int at = 0, ach = nch;
   unsigned avo[NI];
