@@ -154,7 +154,7 @@ struct SpwArgs {
   unsigned in_bytes, w_bytes, out_bytes;
   int act;
   int wide4_groups, wide2_groups;      // a wave takes 4 / at least 2 column tiles from this many live groups on
-  int exp;                             // diagnostics (PN_SPARSE_EXP, group4 kernel): bit 0 every weight load reads tap 0 (cache resident), bit 1 every
+  int exp;                             // diagnostics (PN_SPARSE_EXP, group4 kernel): bit 0 every weight load reads tap 0 (cache resident), bit 2 no MFMAs, bit 1 every
                                        // input row load reads one of the first 32 rows
 };
 
@@ -421,10 +421,15 @@ __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel
     for (int k = 0; k < 4; ++k) fa[k] = *reinterpret_cast<const f32x4*>(stage + li * LD + (2 * k + lh) * 4);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      if (!(a.exp & 4)) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k][j], fb[k & 1][c][j], acc[c], 0, 0, 0);
+          for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k][j], fb[k & 1][c][j], acc[c], 0, 0, 0);
+      } else {      // diagnostics: everything but the MFMAs (the operands stay live)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c][k] += fa[k][c & 3] * fb[k & 1][c][0];
+      }
       request_b(k & 1);
     }
   }
