@@ -154,8 +154,23 @@ struct SpwArgs {
   unsigned in_bytes, w_bytes, out_bytes;
   int act;
   int wide4_groups, wide2_groups;      // a wave takes 4 / at least 2 column tiles from this many live groups on
-  int exp;                             // diagnostics (PN_SPARSE_EXP, group4 kernel): bit 0 every weight load reads tap 0 (cache resident), bit 2 no MFMAs, bit 1 every
-                                       // input row load reads one of the first 32 rows
+  int exp;                             // (unused; r4's PN_SPARSE_EXP ablations lived in the K loops, where a run-time branch costs 12 %)
+};
+
+// the taps of a mask in ascending order, one at a time
+struct UnitCursor {
+  unsigned m;            // this wave's taps after the current one
+  int t;                 // current tap
+  bool live;
+  __device__ __forceinline__ void start(unsigned own) { m = own; live = true; t = 0; next(); }
+  // branch-free (scalar selects): a branch inside the K loop splits it into basic blocks, and the register allocator then copies the
+  // accumulator tiles in and out of the MFMA registers at every block boundary (59 v_mov + a drain of the matrix pipe per 8 MFMAs: r4 found
+  // the block-per-group kernel at 0.59 of the peak for this reason alone)
+  __device__ __forceinline__ void next() {
+    live = m != 0u;
+    t = live ? (int)__builtin_ctz(m | 0x80000000u) : t;
+    m &= m - 1u;
+  }
 };
 
 // wave = one group of 32 sites x 32 NC columns (blockIdx.y walks further column groups).  packed weights: pn_pack_conv_weight_f32's layout
@@ -166,7 +181,7 @@ struct SpwArgs {
 // touched again by the next three steps -- with 16 waves per CU those lines no longer sit in the 32 KB L1, and the 64 -> 64 layers ran at
 // 0.47 of the MFMA peak on 4x the L2 traffic.)  The LDS executes a wave's accesses in order, so the image needs no barrier and no
 // second buffer: a chunk's four fragment reads are issued before the next chunk's stores.
-template <int NC, int CH>
+template <int NC, int CH, bool ONE = false>      // ONE: the layer's input is one chunk wide (cin == CH): a unit = a tap, branch-free loop
 __device__ __forceinline__ void sparse_conv_wave_body(const SpwArgs& a, int32_t* src, float* stage, int g, int n0, int lane) {
   constexpr int LPR = CH / 4;          // lanes per row of a staging load
   constexpr int RPI = 64 / LPR;        // rows per staging load
@@ -176,7 +191,22 @@ __device__ __forceinline__ void sparse_conv_wave_body(const SpwArgs& a, int32_t*
   const int li = lane & 31, lh = lane >> 5;
   const unsigned gm = a.gmask[g];
   const int prow = g * 32 + li < a.cap ? a.perm[g * 32 + li] : -1;
-  for (int t = lh; t < a.taps; t += 2) src[t * 32 + li] = prow >= 0 ? a.nbr[(size_t)prow * a.taps + t] : -1;
+  {
+    // the site's row of the neighbour table: every load requested before the first LDS store (one at a time the 14 loads of a lane were a
+    // chain of memory latencies in front of the wave's first MFMA)
+    int32_t nv[14];
+    const int32_t* np = a.nbr + (size_t)max(prow, 0) * a.taps;
+#pragma unroll
+    for (int k = 0; k < 14; ++k) {
+      const int t = lh + 2 * k;
+      nv[k] = (prow >= 0 && t < a.taps) ? np[min(t, a.taps - 1)] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < 14; ++k) {
+      const int t = lh + 2 * k;
+      if (t < 27) src[t * 32 + li] = nv[k];
+    }
+  }
   if (lh == 0) src[27 * 32 + li] = prow;
   const int srow = lane / LPR, scol = (lane % LPR) * 4;      // staging role: rows srow + RPI q, 16 bytes at float scol of the chunk
   unsigned uoff[NC];
@@ -195,6 +225,54 @@ __device__ __forceinline__ void sparse_conv_wave_body(const SpwArgs& a, int32_t*
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
+  if constexpr (ONE) {
+    // r4: the K loop as ONE basic block per tap.  The generic loop below keeps (tap, chunk) cursors with branches; the compiler cut it into
+    // blocks of 4 - 8 MFMAs with ~40 scalar / vector instructions between them (0.43 of the MFMA peak on the 32 -> 32 layers).  Here the
+    // cursors advance by scalar selects and the K step of every weight request is a compile-time constant.
+    UnitCursor ca, cb;
+    ca.start(gm);
+    cb.start(gm);
+    f32x4 ra[NI], fb[2][NC];
+    auto request_a = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < NI; ++q) {
+        const int sv = src[ca.t * 32 + srow + RPI * q];      // (written by this wave: the LDS executes a wave's accesses in order)
+        const int sidx = ca.live ? sv : -1;
+        const unsigned vo = sidx >= 0 ? (unsigned)sidx * (unsigned)(CH * 4) + (unsigned)scol * 4u : 0xffffffffu;      // (cin == CH: a shift)
+        ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, 0, 0));
+      }
+      ca.next();
+    };
+    auto request_b = [&](int slot, int kk) __attribute__((always_inline)) {
+      const unsigned so_w = (unsigned)((cb.t * a.cin_chunks * 8 + kk * 2)) * cp16;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) fb[slot][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, cb.live ? uoff[c] : 0xffffffffu, so_w, 0));
+    };
+    const int nunits = __builtin_popcount(gm);
+    request_a();
+    request_b(0, 0);
+    request_b(1, 1);
+    if (SPC == 2) cb.next();
+    for (int u = 0; u < nunits; ++u) {
+#pragma unroll
+      for (int q = 0; q < NI; ++q) *reinterpret_cast<f32x4*>(stage + (srow + RPI * q) * LD + scol) = ra[q];
+      request_a();
+      f32x4 fa[SPC];
+#pragma unroll
+      for (int k = 0; k < SPC; ++k) fa[k] = *reinterpret_cast<const f32x4*>(stage + li * LD + (2 * k + lh) * 4);
+#pragma unroll
+      for (int k = 0; k < SPC; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k][j], fb[k & 1][c][j], acc[c], 0, 0, 0);
+        // the slot just used takes step k + 2: of this tap, or (past its last step) of the next one
+        if (SPC == 4 && k == 2) cb.next();
+        request_b(k & 1, (k + 2) % SPC);
+        if (SPC == 2 && k == 1) cb.next();
+      }
+    }
+  } else {
   // two request pointers walk the same sequence (taps of the group's mask ascending, channels ascending): the input rows one CHUNK ahead
   // of the MFMAs, the weight fragments two K STEPS ahead (r4: a whole chunk ahead changes nothing on the 32 -> 32 layers, 137 us either
   // way, and neither does serving every weight or every input row from a cache-resident set: the loop is not waiting for memory)
@@ -259,6 +337,7 @@ __device__ __forceinline__ void sparse_conv_wave_body(const SpwArgs& a, int32_t*
     }
   }
 
+  }
   // ---- epilogue: rows back to their own places.  No branches: dead rows / columns are redirected out of the descriptors' range
   // (loads return 0, stores are dropped), the residuals of a column tile are all requested before the first store
   const bool relu = a.act == PN_ACT_RELU;
@@ -316,8 +395,19 @@ __global__ __launch_bounds__(256, 3) void sparse_conv_wave_kernel(SpwArgs a) {
   if (g * 32 >= n) return;      // (wave-uniform; no block barrier anywhere below)
   const int n0 = blockIdx.y * 32 * nc;
   if (a.cin % 32) {      // 16 input channels (the first strided stage): 64-byte rows, chunks of 16 channels
+    if (a.cin == 16) {
+      if (NCMAX >= 2 && nc == 2) sparse_conv_wave_body<2, 16, true>(a, s_src[wv], s_stage[wv], g, n0, lane);
+      else sparse_conv_wave_body<1, 16, true>(a, s_src[wv], s_stage[wv], g, n0, lane);
+      return;
+    }
     if (NCMAX >= 2 && nc == 2) sparse_conv_wave_body<2, 16>(a, s_src[wv], s_stage[wv], g, n0, lane);
     else sparse_conv_wave_body<1, 16>(a, s_src[wv], s_stage[wv], g, n0, lane);
+    return;
+  }
+  if (a.cin == 32) {
+    if (NCMAX >= 4 && nc == 4) sparse_conv_wave_body<4, 32, true>(a, s_src[wv], s_stage[wv], g, n0, lane);
+    else if (NCMAX >= 2 && nc == 2) sparse_conv_wave_body<2, 32, true>(a, s_src[wv], s_stage[wv], g, n0, lane);
+    else sparse_conv_wave_body<1, 32, true>(a, s_src[wv], s_stage[wv], g, n0, lane);
     return;
   }
   if (NCMAX >= 4 && nc == 4) sparse_conv_wave_body<4, 32>(a, s_src[wv], s_stage[wv], g, n0, lane);
@@ -333,15 +423,6 @@ __global__ __launch_bounds__(256, 3) void sparse_conv_wave_kernel(SpwArgs a) {
 // must stay bit for bit the same: key-point selections downstream amplify last-bit differences): wave w takes channel chunk w & (nch - 1)
 // of the taps whose NUMBER falls in its class -- every tap for four chunks (128 channels), t & 1 == w >> 1 for two (64 channels).  A site's
 // four partial sums are then sums over its own neighbours in ascending tap order (absent ones add exact zeros), joined as ((0 + 1) + 2) + 3.
-struct UnitCursor {
-  unsigned m;            // this wave's taps after the current one
-  int t;                 // current tap
-  bool live;
-  __device__ __forceinline__ void start(unsigned own) { m = own; live = true; t = 0; next(); }
-  __device__ __forceinline__ void next() {
-    if (m) { t = __builtin_ctz(m); m &= m - 1u; } else live = false;
-  }
-};
 
 template <int NC>
 __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel(SpwArgs a) {
@@ -362,7 +443,18 @@ __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel
   const unsigned gm = a.gmask[g];
   {
     const int i = tid & 31, prow = g * 32 + i < a.cap ? a.perm[g * 32 + i] : -1;
-    for (int t = tid >> 5; t < a.taps; t += 8) s_src[t * 32 + i] = prow >= 0 ? a.nbr[(size_t)prow * a.taps + t] : -1;
+    int32_t nv[4];
+    const int32_t* np = a.nbr + (size_t)max(prow, 0) * a.taps;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = (tid >> 5) + 8 * k;
+      nv[k] = (prow >= 0 && t < a.taps) ? np[min(t, a.taps - 1)] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = (tid >> 5) + 8 * k;
+      if (t < 27) s_src[t * 32 + i] = nv[k];
+    }
     if (tid < 32) s_src[27 * 32 + i] = prow;
   }
   __syncthreads();
@@ -390,29 +482,27 @@ __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel
   UnitCursor ca, cb;
   ca.start(own);
   cb.start(own);
-  int bk = 0;      // K step inside cb's unit
   f32x4 ra[4], fb[2][NC];
   auto request_a = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      int sidx = ca.live ? s_src[ca.t * 32 + srow + 8 * q] : -1;
-      if ((a.exp & 2) && sidx >= 0) sidx = srow + 8 * q;
+      const int sv = s_src[ca.t * 32 + srow + 8 * q];
+      const int sidx = ca.live ? sv : -1;
       const unsigned vo = sidx >= 0 ? (unsigned)sidx * row_bytes + (unsigned)scol * 4u : 0xffffffffu;
       ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, (unsigned)ch * 128u, 0));
     }
     ca.next();
   };
-  auto request_b = [&](int slot) __attribute__((always_inline)) {
-    const int bcg = ch * 4 + bk;
-    const unsigned so_w = (unsigned)((((a.exp & 1) ? 0 : cb.t) * a.cin_chunks + (bcg >> 2)) * 8 + (bcg & 3) * 2) * cp16;
+  // kk = the K step inside cb's unit: a compile-time constant at every call (the unit loop below is unrolled over its four steps)
+  auto request_b = [&](int slot, int kk) __attribute__((always_inline)) {
+    const unsigned so_w = (unsigned)(((cb.t * a.cin_chunks + ch) * 8 + kk * 2)) * cp16;
 #pragma unroll
     for (int c = 0; c < NC; ++c) fb[slot][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, cb.live ? uoff[c] : 0xffffffffu, so_w, 0));
-    if (++bk == 4) { bk = 0; cb.next(); }
   };
   request_a();
-  request_b(0);
-  request_b(1);
-  for (int u = 0; u < mine; ++u) {
+  request_b(0, 0);
+  request_b(1, 1);
+  for (int u = 0; u < mine; ++u) {      // ONE basic block: no branch below (see UnitCursor)
 #pragma unroll
     for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(stage + (srow + 8 * q) * LD + scol) = ra[q];
     request_a();
@@ -421,16 +511,19 @@ __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel
     for (int k = 0; k < 4; ++k) fa[k] = *reinterpret_cast<const f32x4*>(stage + li * LD + (2 * k + lh) * 4);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (!(a.exp & 4)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k][j], fb[k & 1][c][j], acc[c], 0, 0, 0);
-      } else {      // diagnostics: everything but the MFMAs (the operands stay live)
-#pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c][k] += fa[k][c & 3] * fb[k & 1][c][0];
+        for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k][j], fb[k & 1][c][j], acc[c], 0, 0, 0);
+      // the slot just used takes step k + 2: steps 2, 3 of this unit, then steps 0, 1 of the next one
+      if (k == 1) {
+        request_b(1, 3);
+        cb.next();
+      } else if (k == 0) {
+        request_b(0, 2);
+      } else {
+        request_b(k & 1, k - 2);
       }
-      request_b(k & 1);
     }
   }
   // ---- join: [wave][c][r][lane] partial tiles, summed wave 0 + 1 + 2 + 3; wave w finishes registers 4 w .. 4 w + 3 (rows 8 w' .. ) of every tile;
