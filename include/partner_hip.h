@@ -763,6 +763,9 @@ int pn_sparse_conv_grouped_f32(const float *in, int in_rows, int cin, const int3
 int pn_sparse_to_dense_nhwc(const float *feats, const uint32_t *keys, int capacity,
                             const int32_t *n_dev, const int32_t *dims, int c, float *out,
                             pn_stream_t stream);
+/* r4: the same map written from the output side -- per pixel the level's index (pn_sparse_index_*) says which cells are active; every
+ * element is stored once in the map's own order, no zero fill and no scatter (c a multiple of 4).  scn.py:176-179. */
+int pn_sparse_to_dense_index_nhwc(const float *feats, const void *index_buf, const int32_t *dims, int c, float *out, pn_stream_t stream);
 
 /* Backward side of the sparse convolutions (scn.py:97-192 under autograd; spconv's own backward in the reference).
  *   pn_sparse_neighbors_transpose  inv[in row][tap] = the output row that reads it through that tap, or -1 (at most one

@@ -38,38 +38,39 @@ __device__ __forceinline__ void sg_cmpx(unsigned long long& x, unsigned long lon
   y = up ? hi : lo;
 }
 
-__global__ __launch_bounds__(1024) void sparse_group_rows_kernel(const int32_t* __restrict__ nbr, const int32_t* __restrict__ n_valid, int cap, int taps,
+template <int WIN>
+__global__ __launch_bounds__(WIN / 4) void sparse_group_rows_kernel(const int32_t* __restrict__ nbr, const int32_t* __restrict__ n_valid, int cap, int taps,
                                                                  int32_t* __restrict__ perm, uint32_t* __restrict__ gmask) {
-  __shared__ unsigned long long key[SG_WIN];
+  constexpr int NWV = WIN / 256;      // waves of the block (four keys per thread)
+  __shared__ unsigned long long key[WIN];
   const int n = min(*n_valid, cap);
-  const int base = blockIdx.x * SG_WIN;
-  if (base >= n) {      // a window without live sites: mark its slots empty (the convolution never reaches them, but keep the buffers defined)
-    for (int i = threadIdx.x; i < SG_WIN && base + i < cap; i += 1024) perm[base + i] = -1;
-    for (int i = threadIdx.x; i < SG_WIN / 32 && (base >> 5) + i < (cap + 31) / 32; i += 1024) gmask[(base >> 5) + i] = 0u;
-    return;
-  }
+  const int base = blockIdx.x * WIN;
+  // a window without live sites: nothing to do -- the convolutions walk the groups below ceil(n / 32) only, the slots behind stay undefined (the
+  // capacity is several times the live count: filling them wrote 12 MB per call on the level with 3.2 M slots, from 750 blocks of 1024
+  // threads that stood in the way of the convolutions on the other stream)
+  if (base >= n) return;
   const int t = threadIdx.x;
   // the window's masks: its rows of the neighbour table are one contiguous block of taps-bit records -- read it coalesced, one ballot per 64
   // entries = 64 bits of the window's bit stream in LDS, a row's mask = bits [taps i, taps (i + 1)) of the stream.  (A thread walking its own
   // rows' 27 entries issued 108 scattered loads; OR-ing bits into per-row words with LDS atomics put ~27 lanes on one address: 42 of the
   // kernel's 63 us either way.)
   {
-    const int live = min(n - base, SG_WIN) * taps;
-    const int words = (SG_WIN * taps + 63) / 64;       // <= 4096 * 32 / 64 = 2048 of the array's 4096
+    const int live = min(n - base, WIN) * taps;
+    const int words = (WIN * taps + 63) / 64;       // <= WIN * 32 / 64 = half of the array
     const int32_t* p = nbr + (size_t)base * taps;
     const int wave = t >> 6, lane = t & 63;
     constexpr int UN = 12;
-    for (int w0 = wave; w0 < words && !(PN_SG_EXP & 1); w0 += 16 * UN) {
+    for (int w0 = wave; w0 < words && !(PN_SG_EXP & 1); w0 += NWV * UN) {
       int32_t v[UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
-        const int f = (w0 + 16 * u) * 64 + lane;
+        const int f = (w0 + NWV * u) * 64 + lane;
         v[u] = f < live ? p[f] : -1;
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
         const unsigned long long bits = __ballot(v[u] >= 0);
-        if (lane == 0 && w0 + 16 * u < words) key[w0 + 16 * u] = bits;
+        if (lane == 0 && w0 + NWV * u < words) key[w0 + NWV * u] = bits;
       }
     }
     if (t == 0) key[words] = 0ull;      // (a record that ends on the stream's last bit still reads the word behind it)
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(1024) void sparse_group_rows_kernel(const int32_t* 
     e[r] = base + i < n ? (((unsigned long long)m << 12) | (unsigned)i) : (1ull << 40);       // dead slots sort behind every live one
   }
   __syncthreads();      // (the LDS stages below reuse the array)
-  for (int k = 2; k <= SG_WIN && !(PN_SG_EXP & 2); k <<= 1) {
+  for (int k = 2; k <= WIN && !(PN_SG_EXP & 2); k <<= 1) {
     const bool up = ((4 * t) & k) == 0;      // (k >= 4: the same for the thread's four keys; k = 2 handled below)
     for (int j = k >> 1; j >= 256; j >>= 1) {
 #pragma unroll
@@ -566,8 +567,12 @@ extern "C" {
 
 int pn_sparse_group_rows(const int32_t* nbr, const int32_t* n_out, int out_capacity, int taps, int32_t* perm, uint32_t* group_mask, pn_stream_t stream) {
   PN_REQUIRE(nbr && n_out && perm && group_mask && out_capacity >= 1 && taps >= 1 && taps <= 27, "sparse_group_rows: bad arguments");
-  const int windows = pn::cdiv(out_capacity, SG_WIN);
-  hipLaunchKernelGGL(sparse_group_rows_kernel, dim3((unsigned)windows), dim3(1024), 0, pn::S(stream), nbr, n_out, out_capacity, taps, perm, group_mask);
+  // window = the span inside which sites may change places: 4096 groups best, 1024 finishes four times sooner per block (PN_SPARSE_WINDOW)
+  static const int win = [] { const char* e = getenv("PN_SPARSE_WINDOW"); const int v = e ? atoi(e) : SG_WIN; return v == 1024 || v == 2048 ? v : SG_WIN; }();
+  const int windows = pn::cdiv(out_capacity, win);
+  if (win == 1024) hipLaunchKernelGGL(sparse_group_rows_kernel<1024>, dim3((unsigned)windows), dim3(256), 0, pn::S(stream), nbr, n_out, out_capacity, taps, perm, group_mask);
+  else if (win == 2048) hipLaunchKernelGGL(sparse_group_rows_kernel<2048>, dim3((unsigned)windows), dim3(512), 0, pn::S(stream), nbr, n_out, out_capacity, taps, perm, group_mask);
+  else hipLaunchKernelGGL(sparse_group_rows_kernel<SG_WIN>, dim3((unsigned)windows), dim3(SG_WIN / 4), 0, pn::S(stream), nbr, n_out, out_capacity, taps, perm, group_mask);
   return pn::check_launch("sparse_group_rows_kernel");
 }
 

@@ -160,6 +160,7 @@ SIGNATURES = {
     "pn_sparse_group_rows": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "pn_sparse_conv_grouped_f32": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
     "pn_sparse_to_dense_nhwc": (_I, [_P, _P, _I, _P, _P, _I, _P, _P]),
+    "pn_sparse_to_dense_index_nhwc": (_I, [_P, _P, _P, _I, _P, _P]),
     "pn_assign_heatmap_workspace_bytes": (_SZ, [_I, _I]),
     "pn_assign_heatmap_polar_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "pn_accumulate_sweeps_workspace_bytes": (_SZ, [_I]),

@@ -217,6 +217,7 @@ class SpMiddleResNetFHD(nn.Module):
             l0 = levels[0]
             hip.call("pn_sparse_index_from_coords", coors.data_ptr(), V, n_voxels.data_ptr(), (C.c_int32 * 4)(*dims), l0["index"].data_ptr(),
                      l0["keys"].data_ptr(), l0["count"].data_ptr(), rank.data_ptr(), st)
+            l0["indexed"] = self._mark(side)      # the rank of every voxel is known: the features can go into key order beside the neighbour table
             self._neighbors(l0["keys"], l0["cap"], l0["count"], l0["dims"], l0["index"], l0["dims"], subm_geo, out=l0["nbr"])
             l0["ready"] = self._mark(side)
             for prev, cur in zip(levels[:-1], levels[1:]):
@@ -251,8 +252,12 @@ class SpMiddleResNetFHD(nn.Module):
             src = torch.cat([src, torch.zeros((V, c0 - cin), dtype=torch.float32, device=dev)], 1).contiguous()
         feats = torch.zeros((cap, c0), dtype=torch.float32, device=dev)
         cur = levels[0]
-        wait(cur)
+        if cur.get("indexed") is not None:
+            main.wait_event(cur["indexed"])
+        else:
+            wait(cur)
         hip.call("pn_sparse_permute_rows", src.data_ptr(), rank.data_ptr(), V, n_voxels.data_ptr(), c0, feats.data_ptr(), st)
+        wait(cur)
         x = self._conv(feats, cur["cap"], cur["nbr"], cur["count"], cur["cap"], plan["input"], ops.ACT_RELU)
         li = 0
         for stage in plan["stages"]:
@@ -271,8 +276,11 @@ class SpMiddleResNetFHD(nn.Module):
         cch = plan["extra"]["cout"]
         odims = last["dims"]
         out = torch.empty((odims[0], odims[2], odims[3], cch * odims[1]), dtype=torch.float32, device=dev)
-        hip.call("pn_sparse_to_dense_nhwc", x.data_ptr(), last["keys"].data_ptr(), last["cap"], last["count"].data_ptr(), (C.c_int32 * 4)(*odims), cch,
-                 out.data_ptr(), st)
+        if cch % 4 == 0:      # written from the output side through the level's index: one coalesced pass, no zero fill (r4)
+            hip.call("pn_sparse_to_dense_index_nhwc", x.data_ptr(), last["index"].data_ptr(), (C.c_int32 * 4)(*odims), cch, out.data_ptr(), st)
+        else:
+            hip.call("pn_sparse_to_dense_nhwc", x.data_ptr(), last["keys"].data_ptr(), last["cap"], last["count"].data_ptr(), (C.c_int32 * 4)(*odims), cch,
+                     out.data_ptr(), st)
         return out
 
     @staticmethod
