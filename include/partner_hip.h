@@ -757,6 +757,15 @@ int pn_sparse_conv_c16_f32(const float *in, int in_rows, int cin, const int32_t 
  * ascending, channels ascending within a tap; ~2e-6 of the output's range).  scn.py:25-48,112-181. */
 int pn_sparse_group_rows(const int32_t *nbr, const int32_t *n_out, int out_capacity, int taps, int32_t *perm, uint32_t *group_mask,
                          pn_stream_t stream);
+/* r4: the neighbour kernel can leave one byte per (site, kz, ky) -- bit kx set when tap (kz, ky, kx) exists; [out_capacity][k0 k1] bytes --
+ * and the grouping sort assembles a site's mask from those k0 k1 bytes instead of re-reading the table (442 KB per window through one CU).
+ * Same table, same perm and group masks as pn_sparse_neighbors + pn_sparse_group_rows.  Slots of windows without a live site are left
+ * undefined by both forms (the convolutions walk the groups below ceil(n / 32) only). */
+int pn_sparse_neighbors_rows(const uint32_t *out_keys, int out_capacity, const int32_t *n_out, const int32_t *out_dims, const void *in_index_buf,
+                             const int32_t *in_dims, const int32_t *kernel, const int32_t *stride, const int32_t *pad, int32_t *nbr,
+                             uint8_t *row_bits, pn_stream_t stream);
+int pn_sparse_group_rows_bits(const uint8_t *row_bits, int rows, int bits_per_row, const int32_t *n_out, int out_capacity, int32_t *perm,
+                              uint32_t *group_mask, pn_stream_t stream);
 int pn_sparse_conv_grouped_f32(const float *in, int in_rows, int cin, const int32_t *nbr, const int32_t *n_out, int out_capacity, int taps,
                                const int32_t *perm, const uint32_t *group_mask, const float *packed_w, int cout, const float *scale,
                                const float *shift, int act, const float *residual, float *out, pn_stream_t stream);

@@ -1653,7 +1653,8 @@ int pn_sparse_conv_c16_f32(const float* in, int in_rows, int cin, const int32_t*
   // persistent: two blocks per CU (233 registers), the 27 KB of weights staged once per block (one block per group: 75 us per layer at
   // 207 k sites, this form 64); fewer than 512 groups of capacity: one block each
   const int cap_groups = pn::cdiv(out_capacity, 64);
-  const dim3 grid((unsigned)(cap_groups >= 512 ? 512 : cap_groups));
+  static const int pgrid = [] { const char* e = getenv("PN_SPARSE_C16_GRID"); const int v = e ? atoi(e) : 512; return v >= 64 ? v : 512; }();
+  const dim3 grid((unsigned)(cap_groups >= pgrid ? pgrid : cap_groups));
   const unsigned in_bytes = (unsigned)((size_t)in_rows * cin * 4);
   const int quads = pn::cdiv(cin, 32) * 8, cout_pad = 32;          // the layout pn_pack_conv_weight_f32 gives (16, cin, taps, 1)
   auto kern = cin == 8 ? &sparse_conv_c16_kernel<8> : &sparse_conv_c16_kernel<16>;

@@ -133,7 +133,7 @@ __global__ void rank_of_coords_kernel(const int32_t* __restrict__ coords, int n_
 // scattered loads each took 90 us on the finest level, in front of the encoder's first convolution)
 __global__ void neighbor_kernel(const uint32_t* __restrict__ out_keys, int out_cap, const int32_t* __restrict__ n_out, Dims dout,
                                 const uint32_t* __restrict__ in_bitmap, const uint32_t* __restrict__ in_rank, Dims di, Geo g, int taps,
-                                int32_t* __restrict__ nbr) {
+                                int32_t* __restrict__ nbr, uint8_t* __restrict__ row_bits) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   const int n = min(*n_out, out_cap);
   const int rows = g.k[0] * g.k[1];
@@ -145,7 +145,7 @@ __global__ void neighbor_kernel(const uint32_t* __restrict__ out_keys, int out_c
   const int iz = z * g.s[0] - g.p[0] + kz, iy = y * g.s[1] - g.p[1] + ky, ix0 = x * g.s[2] - g.p[2];
   int32_t* o = nbr + (size_t)site * taps + rt * g.k[2];
   const bool row_ok = (unsigned)iz < (unsigned)di.D && (unsigned)iy < (unsigned)di.H;
-  uint32_t w_cur = 0xffffffffu, bits = 0, base = 0;
+  uint32_t w_cur = 0xffffffffu, bits = 0, base = 0, present = 0;
   for (int kx = 0; kx < g.k[2]; ++kx) {
     const int ix = ix0 + kx;
     int r = -1;
@@ -159,7 +159,10 @@ __global__ void neighbor_kernel(const uint32_t* __restrict__ out_keys, int out_c
       if ((bits >> bit) & 1u) r = (int)(base + __popc(bits & ((1u << bit) - 1u)));
     }
     o[kx] = r;
+    present |= (r >= 0 ? 1u : 0u) << kx;
   }
+  // (nullable) which taps of this row exist: the grouping sort assembles a site's mask from its k0 k1 bytes instead of re-reading the table
+  if (row_bits) row_bits[i] = (uint8_t)present;
 }
 
 __global__ void permute_rows_kernel(const float* __restrict__ in, const int32_t* __restrict__ rank, int n_cap, const int32_t* __restrict__ n_dev, int c,
@@ -268,16 +271,32 @@ int pn_sparse_index_downsample(const uint32_t* in_keys, int in_capacity, const i
   return scan_and_emit(ib, out_keys, out_capacity, out_count, st);
 }
 
-int pn_sparse_neighbors(const uint32_t* out_keys, int out_capacity, const int32_t* n_out, const int32_t* out_dims, const void* in_index_buf,
-                        const int32_t* in_dims, const int32_t* kernel, const int32_t* stride, const int32_t* pad, int32_t* nbr, pn_stream_t stream) {
+static int neighbors_run(const uint32_t* out_keys, int out_capacity, const int32_t* n_out, const int32_t* out_dims, const void* in_index_buf,
+                         const int32_t* in_dims, const int32_t* kernel, const int32_t* stride, const int32_t* pad, int32_t* nbr, uint8_t* row_bits,
+                         pn_stream_t stream) {
   PN_REQUIRE(out_keys && n_out && out_dims && in_index_buf && in_dims && kernel && stride && pad && nbr, "sparse_neighbors: null pointer");
   const int taps = kernel[0] * kernel[1] * kernel[2];
   PN_REQUIRE(taps >= 1 && taps <= 32 && out_capacity >= 1, "sparse_neighbors: at most 32 taps");
+  PN_REQUIRE(!row_bits || kernel[2] <= 8, "sparse_neighbors: row bits want at most 8 taps along x");
   IndexBuf ib(const_cast<void*>(in_index_buf), cells_of(in_dims));
   const size_t total = (size_t)out_capacity * kernel[0] * kernel[1];
   hipLaunchKernelGGL(neighbor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, pn::S(stream), out_keys, out_capacity, n_out, mk(out_dims),
-                     ib.bitmap, ib.word_rank, mk(in_dims), mkg(kernel, stride, pad), taps, nbr);
+                     ib.bitmap, ib.word_rank, mk(in_dims), mkg(kernel, stride, pad), taps, nbr, row_bits);
   return pn::check_launch("neighbor_kernel");
+}
+
+int pn_sparse_neighbors(const uint32_t* out_keys, int out_capacity, const int32_t* n_out, const int32_t* out_dims, const void* in_index_buf,
+                        const int32_t* in_dims, const int32_t* kernel, const int32_t* stride, const int32_t* pad, int32_t* nbr, pn_stream_t stream) {
+  return neighbors_run(out_keys, out_capacity, n_out, out_dims, in_index_buf, in_dims, kernel, stride, pad, nbr, nullptr, stream);
+}
+
+// the same table plus, per (site, kz, ky), one byte whose bit kx says whether tap (kz, ky, kx) exists: [out_capacity][k0 k1] bytes, the input
+// of pn_sparse_group_rows_bits (r4)
+int pn_sparse_neighbors_rows(const uint32_t* out_keys, int out_capacity, const int32_t* n_out, const int32_t* out_dims, const void* in_index_buf,
+                             const int32_t* in_dims, const int32_t* kernel, const int32_t* stride, const int32_t* pad, int32_t* nbr, uint8_t* row_bits,
+                             pn_stream_t stream) {
+  PN_REQUIRE(row_bits, "sparse_neighbors_rows: null pointer");
+  return neighbors_run(out_keys, out_capacity, n_out, out_dims, in_index_buf, in_dims, kernel, stride, pad, nbr, row_bits, stream);
 }
 
 int pn_sparse_permute_rows(const float* in, const int32_t* rank, int n_capacity, const int32_t* n_dev, int c, float* out, pn_stream_t stream) {

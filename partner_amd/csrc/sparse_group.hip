@@ -40,7 +40,8 @@ __device__ __forceinline__ void sg_cmpx(unsigned long long& x, unsigned long lon
 
 template <int WIN>
 __global__ __launch_bounds__(WIN / 4) void sparse_group_rows_kernel(const int32_t* __restrict__ nbr, const int32_t* __restrict__ n_valid, int cap, int taps,
-                                                                 int32_t* __restrict__ perm, uint32_t* __restrict__ gmask) {
+                                                                 int32_t* __restrict__ perm, uint32_t* __restrict__ gmask,
+                                                                 const uint8_t* __restrict__ row_bits, int rows, int bits_per_row) {
   constexpr int NWV = WIN / 256;      // waves of the block (four keys per thread)
   __shared__ unsigned long long key[WIN];
   const int n = min(*n_valid, cap);
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(WIN / 4) void sparse_group_rows_kernel(const int32_
   // entries = 64 bits of the window's bit stream in LDS, a row's mask = bits [taps i, taps (i + 1)) of the stream.  (A thread walking its own
   // rows' 27 entries issued 108 scattered loads; OR-ing bits into per-row words with LDS atomics put ~27 lanes on one address: 42 of the
   // kernel's 63 us either way.)
-  {
+  if (row_bits == nullptr) {
     const int live = min(n - base, WIN) * taps;
     const int words = (WIN * taps + 63) / 64;       // <= WIN * 32 / 64 = half of the array
     const int32_t* p = nbr + (size_t)base * taps;
@@ -80,9 +81,19 @@ __global__ __launch_bounds__(WIN / 4) void sparse_group_rows_kernel(const int32_
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = 4 * t + r;
-    const unsigned o = (unsigned)(i * taps), sh = o & 63u;
-    const unsigned long long lo = key[o >> 6], hi = key[(o >> 6) + 1];
-    const unsigned m = (unsigned)((lo >> sh) | (sh ? hi << (64u - sh) : 0ull)) & (taps >= 32 ? ~0u : (1u << taps) - 1u);
+    unsigned m = 0;
+    if (row_bits) {
+      // r4: the neighbour kernel left one byte per (site, row of taps): 9 bytes per site instead of 27 table entries (the window's read of the
+      // table, 442 KB through one CU, was 19 of the sort's 47 us)
+      if (base + i < n) {
+        const uint8_t* rb = row_bits + (size_t)(base + i) * rows;
+        for (int q = 0; q < rows; ++q) m |= (unsigned)rb[q] << (q * bits_per_row);
+      }
+    } else {
+      const unsigned o = (unsigned)(i * taps), sh = o & 63u;
+      const unsigned long long lo = key[o >> 6], hi = key[(o >> 6) + 1];
+      m = (unsigned)((lo >> sh) | (sh ? hi << (64u - sh) : 0ull)) & (taps >= 32 ? ~0u : (1u << taps) - 1u);
+    }
     e[r] = base + i < n ? (((unsigned long long)m << 12) | (unsigned)i) : (1ull << 40);       // dead slots sort behind every live one
   }
   __syncthreads();      // (the LDS stages below reuse the array)
@@ -565,15 +576,28 @@ __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel
 
 extern "C" {
 
-int pn_sparse_group_rows(const int32_t* nbr, const int32_t* n_out, int out_capacity, int taps, int32_t* perm, uint32_t* group_mask, pn_stream_t stream) {
-  PN_REQUIRE(nbr && n_out && perm && group_mask && out_capacity >= 1 && taps >= 1 && taps <= 27, "sparse_group_rows: bad arguments");
+static int group_rows_run(const int32_t* nbr, const uint8_t* row_bits, int rows, int bits_per_row, const int32_t* n_out, int out_capacity, int taps, int32_t* perm,
+                          uint32_t* group_mask, pn_stream_t stream) {
+  PN_REQUIRE((nbr || row_bits) && n_out && perm && group_mask && out_capacity >= 1 && taps >= 1 && taps <= 27, "sparse_group_rows: bad arguments");
   // window = the span inside which sites may change places: 4096 groups best, 1024 finishes four times sooner per block (PN_SPARSE_WINDOW)
   static const int win = [] { const char* e = getenv("PN_SPARSE_WINDOW"); const int v = e ? atoi(e) : SG_WIN; return v == 1024 || v == 2048 ? v : SG_WIN; }();
   const int windows = pn::cdiv(out_capacity, win);
-  if (win == 1024) hipLaunchKernelGGL(sparse_group_rows_kernel<1024>, dim3((unsigned)windows), dim3(256), 0, pn::S(stream), nbr, n_out, out_capacity, taps, perm, group_mask);
-  else if (win == 2048) hipLaunchKernelGGL(sparse_group_rows_kernel<2048>, dim3((unsigned)windows), dim3(512), 0, pn::S(stream), nbr, n_out, out_capacity, taps, perm, group_mask);
-  else hipLaunchKernelGGL(sparse_group_rows_kernel<SG_WIN>, dim3((unsigned)windows), dim3(SG_WIN / 4), 0, pn::S(stream), nbr, n_out, out_capacity, taps, perm, group_mask);
+  if (win == 1024) hipLaunchKernelGGL(sparse_group_rows_kernel<1024>, dim3((unsigned)windows), dim3(256), 0, pn::S(stream), nbr, n_out, out_capacity, taps, perm, group_mask, row_bits, rows, bits_per_row);
+  else if (win == 2048) hipLaunchKernelGGL(sparse_group_rows_kernel<2048>, dim3((unsigned)windows), dim3(512), 0, pn::S(stream), nbr, n_out, out_capacity, taps, perm, group_mask, row_bits, rows, bits_per_row);
+  else hipLaunchKernelGGL(sparse_group_rows_kernel<SG_WIN>, dim3((unsigned)windows), dim3(SG_WIN / 4), 0, pn::S(stream), nbr, n_out, out_capacity, taps, perm, group_mask, row_bits, rows, bits_per_row);
   return pn::check_launch("sparse_group_rows_kernel");
+}
+
+int pn_sparse_group_rows(const int32_t* nbr, const int32_t* n_out, int out_capacity, int taps, int32_t* perm, uint32_t* group_mask, pn_stream_t stream) {
+  PN_REQUIRE(nbr, "sparse_group_rows: null pointer");
+  return group_rows_run(nbr, nullptr, 0, 0, n_out, out_capacity, taps, perm, group_mask, stream);
+}
+
+// the same grouping from the row bytes of pn_sparse_neighbors_rows (rows = k0 k1 bytes per site, bits_per_row = k2): same perm and masks
+int pn_sparse_group_rows_bits(const uint8_t* row_bits, int rows, int bits_per_row, const int32_t* n_out, int out_capacity, int32_t* perm, uint32_t* group_mask,
+                              pn_stream_t stream) {
+  PN_REQUIRE(row_bits && rows >= 1 && bits_per_row >= 1 && bits_per_row <= 8 && rows * bits_per_row <= 27, "sparse_group_rows_bits: bad arguments");
+  return group_rows_run(nullptr, row_bits, rows, bits_per_row, n_out, out_capacity, rows * bits_per_row, perm, group_mask, stream);
 }
 
 int pn_sparse_conv_grouped_f32(const float* in, int in_rows, int cin, const int32_t* nbr, const int32_t* n_out, int out_capacity, int taps,

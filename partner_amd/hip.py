@@ -154,6 +154,8 @@ SIGNATURES = {
     "pn_sparse_index_from_coords": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "pn_sparse_index_downsample": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "pn_sparse_neighbors": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pn_sparse_neighbors_rows": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pn_sparse_group_rows_bits": (_I, [_P, _I, _I, _P, _I, _P, _P, _P]),
     "pn_sparse_permute_rows": (_I, [_P, _P, _I, _P, _I, _P, _P]),
     "pn_sparse_conv_f32": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P]),
     "pn_sparse_conv_c16_f32": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P]),

@@ -25,6 +25,7 @@ from .builder import BACKBONES
 from .nn_utils import PlanCache, build_norm_layer, eval_only
 
 _C16 = os.environ.get("PN_SPARSE_C16", "1") != "0"     # 0: the 16-channel level on the gathered MFMA kernel as well
+_ROW_BITS = os.environ.get("PN_SPARSE_ROW_BITS", "1") != "0"     # the grouping sort reads per-row tap bytes left by the neighbour kernel (r4)
 _GROUPED = os.environ.get("PN_SPARSE_GROUPED", "1") != "0"     # 0: every level >= 32 channels on the gathered tile kernel (r3) instead of sparse_group.hip
 _STRUCT_STREAM = os.environ.get("PN_SPARSE_STRUCT_STREAM", "1") != "0"   # 0: index builds / neighbour tables on the calling stream
 
@@ -144,9 +145,13 @@ class SpMiddleResNetFHD(nn.Module):
     def _i3(v):
         return (C.c_int32 * 3)(*[int(x) for x in v])
 
-    def _neighbors(self, keys, cap, count, out_dims, in_index, in_dims, geo, out=None):
+    def _neighbors(self, keys, cap, count, out_dims, in_index, in_dims, geo, out=None, row_bits=None):
         taps = geo[0][0] * geo[0][1] * geo[0][2]
         nbr = out if out is not None else torch.empty((cap, taps), dtype=torch.int32, device=keys.device)
+        if row_bits is not None:      # (+ one byte per (site, row of taps) for the grouping sort)
+            hip.call("pn_sparse_neighbors_rows", keys.data_ptr(), cap, count.data_ptr(), (C.c_int32 * 4)(*out_dims), in_index.data_ptr(),
+                     (C.c_int32 * 4)(*in_dims), self._i3(geo[0]), self._i3(geo[1]), self._i3(geo[2]), nbr.data_ptr(), row_bits.data_ptr(), hip.stream())
+            return nbr
         hip.call("pn_sparse_neighbors", keys.data_ptr(), cap, count.data_ptr(), (C.c_int32 * 4)(*out_dims), in_index.data_ptr(),
                  (C.c_int32 * 4)(*in_dims), self._i3(geo[0]), self._i3(geo[1]), self._i3(geo[2]), nbr.data_ptr(), hip.stream())
         return nbr
@@ -187,8 +192,16 @@ class SpMiddleResNetFHD(nn.Module):
                 return None
             return (torch.empty(rows, dtype=torch.int32, device=dev), torch.empty((rows + 31) // 32, dtype=torch.int32, device=dev))
 
-        def group(table, g, level):
-            if g is not None:
+        def bits(rows, geo, g):      # the row bytes the neighbour kernel leaves for the sort (only where a sort follows)
+            return torch.empty((rows, geo[0][0] * geo[0][1]), dtype=torch.uint8, device=dev) if (g is not None and _ROW_BITS and geo[0][2] <= 8) else None
+
+        def group(table, g, level, rb=None, geo=None):
+            if g is None:
+                return
+            if rb is not None:
+                hip.call("pn_sparse_group_rows_bits", rb.data_ptr(), rb.shape[1], geo[0][2], level["count"].data_ptr(), level["cap"], g[0].data_ptr(),
+                         g[1].data_ptr(), hip.stream())
+            else:
                 hip.call("pn_sparse_group_rows", table.data_ptr(), level["count"].data_ptr(), level["cap"], table.shape[1], g[0].data_ptr(), g[1].data_ptr(),
                          hip.stream())
 
@@ -210,6 +223,7 @@ class SpMiddleResNetFHD(nn.Module):
             nl["nbr"] = tbl(ocap, subm_geo) if gi + 1 < len(geos) else None      # the last level (extra_conv) has no submanifold layers
             nl["dgrp"] = grp(ocap)
             nl["grp"] = grp(ocap) if nl["nbr"] is not None else None
+            nl["dbits"], nl["bits"] = bits(ocap, geo, nl["dgrp"]), bits(ocap, subm_geo, nl["grp"])
             levels.append(nl)
 
         def build_structure():
@@ -225,11 +239,12 @@ class SpMiddleResNetFHD(nn.Module):
                 hip.call("pn_sparse_index_downsample", prev["keys"].data_ptr(), prev["cap"], prev["count"].data_ptr(), (C.c_int32 * 4)(*prev["dims"]),
                          self._i3(geo[0]), self._i3(geo[1]), self._i3(geo[2]), (C.c_int32 * 4)(*cur["dims"]), cur["index"].data_ptr(),
                          cur["keys"].data_ptr(), cur["cap"], cur["count"].data_ptr(), st)
-                self._neighbors(cur["keys"], cur["cap"], cur["count"], cur["dims"], prev["index"], prev["dims"], geo, out=cur["dnbr"])
-                group(cur["dnbr"], cur["dgrp"], cur)
+                self._neighbors(cur["keys"], cur["cap"], cur["count"], cur["dims"], prev["index"], prev["dims"], geo, out=cur["dnbr"], row_bits=cur["dbits"])
+                group(cur["dnbr"], cur["dgrp"], cur, cur["dbits"], geo)
                 if cur["nbr"] is not None:
-                    self._neighbors(cur["keys"], cur["cap"], cur["count"], cur["dims"], cur["index"], cur["dims"], subm_geo, out=cur["nbr"])
-                    group(cur["nbr"], cur["grp"], cur)
+                    self._neighbors(cur["keys"], cur["cap"], cur["count"], cur["dims"], cur["index"], cur["dims"], subm_geo, out=cur["nbr"],
+                                    row_bits=cur["bits"])
+                    group(cur["nbr"], cur["grp"], cur, cur["bits"], subm_geo)
                 cur["ready"] = self._mark(side)
 
         if side is None:
