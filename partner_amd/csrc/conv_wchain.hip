@@ -730,14 +730,22 @@ static void launch_chain(const WChainArgs& a, hipStream_t st, bool prof, const p
 struct Chain2Form { int ks, ct, qt; };
 
 // F(2,3) x F(4,3) form: octet tiles of 32 QT octets = whole row pairs; 12 waves per block
-static bool chain2_form(const pn_conv_desc* d, Chain2Form& f) {
+static bool chain2_form(const pn_conv_desc* d, Chain2Form& f, bool head = false) {
   const int fh = frame_h(d), fw = frame_w(d);
   if (fw % 4 || fh % 2) return false;
   const int wq = fw / 4;
   if (wq & (wq - 1)) return false;
   const long long octs = (long long)d->batch * (fh / 2) * wq;
-  const Chain2Form cands[] = {{2, 1, 1}, {1, 1, 2}};
-  for (const Chain2Form& c : cands) {
+  // beside other frames (pn_conv_desc.frames_in_flight > 1) the two-tile form without the K split comes first: half as many blocks, each with
+  // twice the K loop and no K join -- alone on the chip a 128 x 128 map would leave half the CUs idle with it, with three frames in flight the
+  // other frames take them (PN_WCHAIN2_PREFER: 0 never, 1 on the hint, 2 always)
+  static const int prefer = [] { const char* e = getenv("PN_WCHAIN2_PREFER"); return e ? atoi(e) : 1; }();
+  // (not for the head's multi-job launch, whose jobs share one form, and only while the wide form still has 128 blocks)
+  const bool wide_first = !head && (prefer == 2 || (prefer == 1 && d->frames_in_flight > 1)) && (octs / 64) * (d->cout / 32) >= 128;
+  const Chain2Form cands_a[] = {{2, 1, 1}, {1, 1, 2}}, cands_b[] = {{1, 1, 2}, {2, 1, 1}};
+  const Chain2Form* cands = wide_first ? cands_b : cands_a;
+  for (int ci = 0; ci < 2; ++ci) {
+    const Chain2Form& c = cands[ci];
     const int tq = 32 * c.qt, tc = 32 * c.ct;
     if (tq % wq != 0 || octs % tq != 0 || d->cout % tc != 0 || (d->cin / 8) % (2 * c.ks) != 0 || tq / wq > fh / 2) continue;
     f = c;
@@ -878,7 +886,7 @@ int pn_pack_conv_weight_wino24_f32(const float* w_oihw, int cout, int cin, float
 // range_strata > 1 (head entry only): RangeStratified convolution on the TRANSPOSED map -- the frame's rows are range positions, every tile
 // (whole row pairs) lies in one stratum and takes that stratum's weight set
 static int chain2_ok(const pn_conv_desc* d, bool head, Chain2Form& f) {
-  if (!chain_basic_ok(d, head) || !chain2_form(d, f)) return 0;
+  if (!chain_basic_ok(d, head) || !chain2_form(d, f, head)) return 0;
   if (d->range_strata > 1) {
     if (!d->transpose_hw || frame_h(d) % d->range_strata) return 0;
     const int rows = frame_h(d) / d->range_strata, tile_rows = 2 * (32 * f.qt) / (frame_w(d) / 4);
