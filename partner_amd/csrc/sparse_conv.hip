@@ -70,41 +70,64 @@ __global__ void mark_down_kernel(const uint32_t* __restrict__ in_keys, int n_cap
 __global__ void tile_totals_kernel(const uint32_t* __restrict__ bitmap, size_t nwords, uint32_t* __restrict__ tile_total) {
   const size_t base = (size_t)blockIdx.x * kTile + (size_t)threadIdx.x * kItems;
   uint32_t s = 0;
+  if (base + kItems <= nwords) {      // the thread's eight words as two 16-byte loads (the index buffers are 256-byte aligned)
+    const uint4 a = *reinterpret_cast<const uint4*>(bitmap + base), b = *reinterpret_cast<const uint4*>(bitmap + base + 4);
+    s = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+  } else {
 #pragma unroll
-  for (int k = 0; k < kItems; ++k) s += base + k < nwords ? __popc(bitmap[base + k]) : 0;
+    for (int k = 0; k < kItems; ++k) s += base + k < nwords ? __popc(bitmap[base + k]) : 0;
+  }
   uint32_t tot;
   pn::block_exclusive_scan<kT>(s, &tot);
   if (threadIdx.x == 0) tile_total[blockIdx.x] = tot;
 }
 
 __global__ void tile_offsets_kernel(uint32_t* __restrict__ tile_total, int ntiles, int32_t* __restrict__ grand_total, int cap) {
-  uint32_t carry = 0;
-  for (int base = 0; base < ntiles; base += kT) {
-    const int i = base + threadIdx.x;
-    const uint32_t v = i < ntiles ? tile_total[i] : 0;
-    uint32_t tot;
-    const uint32_t ex = pn::block_exclusive_scan<kT>(v, &tot);
-    if (i < ntiles) tile_total[i] = carry + ex;
-    carry += tot;
+  // a thread takes a run of consecutive tiles, ONE block scan over the runs (a scan per 256 tiles was twelve dependent rounds on the finest
+  // level's 2880 tiles: 9.6 us in front of the encoder's first convolution)
+  const int per = (ntiles + kT - 1) / kT, i0 = threadIdx.x * per, i1 = min(ntiles, i0 + per);
+  uint32_t run = 0;
+  for (int i = i0; i < i1; ++i) run += tile_total[i];
+  uint32_t tot;
+  uint32_t ex = pn::block_exclusive_scan<kT>(run, &tot);
+  for (int i = i0; i < i1; ++i) {
+    const uint32_t v = tile_total[i];
+    tile_total[i] = ex;
+    ex += v;
   }
-  if (threadIdx.x == 0) *grand_total = (int32_t)min(carry, (uint32_t)cap);
+  if (threadIdx.x == 0) *grand_total = (int32_t)min(tot, (uint32_t)cap);
 }
 
 __global__ void emit_kernel(const uint32_t* __restrict__ bitmap, size_t nwords, const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ word_rank,
                             uint32_t* __restrict__ keys, int cap) {
   const size_t base = (size_t)blockIdx.x * kTile + (size_t)threadIdx.x * kItems;
   uint32_t words[kItems], s = 0;
+  const bool whole = base + kItems <= nwords;
+  if (whole) {
+    const uint4 a = *reinterpret_cast<const uint4*>(bitmap + base), b = *reinterpret_cast<const uint4*>(bitmap + base + 4);
+    words[0] = a.x; words[1] = a.y; words[2] = a.z; words[3] = a.w; words[4] = b.x; words[5] = b.y; words[6] = b.z; words[7] = b.w;
 #pragma unroll
-  for (int k = 0; k < kItems; ++k) {
-    words[k] = base + k < nwords ? bitmap[base + k] : 0u;
-    s += __popc(words[k]);
+    for (int k = 0; k < kItems; ++k) s += __popc(words[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+      words[k] = base + k < nwords ? bitmap[base + k] : 0u;
+      s += __popc(words[k]);
+    }
   }
   uint32_t tot;
   uint32_t rank = tile_offset[blockIdx.x] + pn::block_exclusive_scan<kT>(s, &tot);
+  if (whole) {      // the eight ranks as two 16-byte stores
+    uint32_t r8[kItems], r = rank;
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) { r8[k] = r; r += __popc(words[k]); }
+    *reinterpret_cast<uint4*>(word_rank + base) = make_uint4(r8[0], r8[1], r8[2], r8[3]);
+    *reinterpret_cast<uint4*>(word_rank + base + 4) = make_uint4(r8[4], r8[5], r8[6], r8[7]);
+  }
 #pragma unroll
   for (int k = 0; k < kItems; ++k) {
     if (base + k >= nwords) break;
-    word_rank[base + k] = rank;
+    if (!whole) word_rank[base + k] = rank;
     uint32_t wb = words[k];
     while (wb) {
       const int bit = __ffs(wb) - 1;
