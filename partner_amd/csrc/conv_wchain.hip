@@ -61,7 +61,7 @@ struct WChainArgs {
   int strata_rows;        // > 0: the layer is range-stratified along the frame's ROWS (center_head_parallel.py:27-59 on the transposed map): rows
                           // [s strata_rows, (s + 1) strata_rows) of every image use weight set s
   unsigned w_stratum_bytes;      // bytes between two weight sets
-  int qt_begin;                  // 2-D kernel: the launch covers octet tiles [qt_begin, qt_begin + qtiles) (two-phase launches: the whole rounds, then the rest)
+  int qt_begin;                  // 2-D kernel: the launch covers octet tiles [qt_begin, qt_begin + qtiles) (0 everywhere today)
 #ifdef PN_WCHAIN_STAMP
   unsigned long long* stamps;   // diagnostic build only (tools/micro/wchain_check.hip): [block][wave][4] shader-clock stamps
 #endif
@@ -950,25 +950,6 @@ static int chain2_run(const pn_conv_desc* d, const float* planes_in, const float
   pn::ProfileSlot ps{};
   const bool prof = pn::take_profile_slot(ps);
   hipStream_t st = pn::S(stream);
-  // two-phase launch (the Waymo maps: 576 two-octet tiles on 256 persistent blocks are 2.25 rounds, i.e. three for a quarter of the blocks):
-  // the whole rounds in the two-tile form, the remaining octet tiles in the 12-wave K-split form, whose tiles are half as large -- the tail
-  // spreads over twice as many blocks.
-  static const int two_phase = [] { const char* e = getenv("PN_WCHAIN_TWO_PHASE"); return e ? atoi(e) : 1; }();
-  const int G = chain_grid_limit(), tiles = a.qtiles * a.ctiles;
-  if (two_phase && !head && f.ks == 1 && f.qt == 2 && tiles > G && tiles % G != 0 && (tiles % G) * 10 <= G * 6 && (G % a.ctiles) == 0 &&
-      (d->cin / 8) % 4 == 0) {
-    const int whole_q = (tiles / G) * (G / a.ctiles);      // octet tiles (of 64 octets) in the whole rounds
-    WChainArgs b = a;
-    a.qtiles = whole_q;
-    pn::ProfileSlot ps_a = ps, ps_b = ps;      // the pair's start rides on the first launch, its stop on the second
-    ps_a.stop = nullptr;
-    ps_b.start = nullptr;
-    launch_chain2<1, 1, 2>(a, st, prof, ps_a);
-    b.qt_begin = 2 * whole_q;                              // in tiles of 32 octets
-    b.qtiles = 2 * (b.qtiles - whole_q);
-    launch_chain2<2, 1, 1>(b, st, prof, ps_b);
-    return pn::check_launch("conv_wchain2_kernel");
-  }
   if (f.ks == 2) launch_chain2<2, 1, 1>(a, st, prof, ps);
   else launch_chain2<1, 1, 2>(a, st, prof, ps);
   return pn::check_launch("conv_wchain2_kernel");
