@@ -261,3 +261,19 @@ def test_side_stream_is_a_no_op_without_a_gpu():
     s.run(lambda: ran.append(1), None)
     s.join()
     assert ran == [1] and s.stream is None and not s.keep
+
+
+def test_readme_names_every_environment_switch_of_the_product():
+    """every PN_* variable the library or the Python layer reads is listed in README.md, and README lists none that does not exist"""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    readme = open(os.path.join(root, "README.md")).read()
+    listed = set(re.findall(r"`(PN_[A-Z0-9_]+)`", readme))
+    src = ""
+    for f in glob.glob(os.path.join(root, "partner_amd", "**", "*"), recursive=True) + [os.path.join(root, "bench.py")]:
+        if f.endswith((".py", ".hip", ".h")):
+            src += open(f, errors="ignore").read()
+    used = set(re.findall(r'getenv\("(PN_[A-Z0-9_]+)"\)', src)) | set(re.findall(r'environ\.get\("(PN_[A-Z0-9_]+)"', src))
+    assert not (used - listed), sorted(used - listed)
+    assert not [e for e in listed if e not in src], [e for e in listed if e not in src]
