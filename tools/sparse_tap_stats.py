@@ -21,9 +21,9 @@ rec = []
 orig = SpMiddleResNetFHD._conv
 
 
-def spy(feats, n_rows, nbr, count, cap, layer, act, residual=None):
+def spy(feats, n_rows, nbr, count, cap, layer, act, residual=None, groups=None):
     rec.append((nbr, int(count.item()), layer["cin"], layer["cout"], layer["taps"]))
-    return orig(feats, n_rows, nbr, count, cap, layer, act, residual)
+    return orig(feats, n_rows, nbr, count, cap, layer, act, residual, groups)
 
 
 SpMiddleResNetFHD._conv = staticmethod(spy)
@@ -70,3 +70,34 @@ for nbr, n, cin, cout, taps in rec:
         tot[k] += res[k]
     print(f"sites {n:7d} taps {taps:2d} {cin:3d}->{cout:3d}: " + " | ".join(f"{k} {res[k] / 1e9:6.2f}" for k in ("t128", "g32", "w1024", "w4096", "w16384", "all", "pairs")))
 print("total: " + " | ".join(f"{k} {tot[k] / 1e9:6.1f}" for k in tot))
+
+
+# ---- r4: does the ORDER of the taps inside the sort key matter?  The window sort is lexicographic in the mask, so sites whose masks differ in
+# a low bit end up adjacent and sites that differ in a high bit far apart: try the tap-to-bit assignment by tap frequency p (rare taps high,
+# frequent taps high, most / least "undecided" |p - 0.5| high) and the reversed identity, windows of 4096, groups of 32
+print("\nissued GFLOP with other tap orders in the sort key (windows of 4096): identity | reversed | rare high | frequent high | undecided high | decided high")
+tot2 = [0.0] * 6
+for nbr, n, cin, cout, taps in rec:
+    if cout < 32:
+        continue
+    v = (nbr[:n] >= 0)
+    f = cin * cout * 2.0
+    pfreq = v.float().mean(0)
+    orders = [torch.arange(taps, device=dev), torch.arange(taps - 1, -1, -1, device=dev), torch.argsort(-pfreq), torch.argsort(pfreq),
+              torch.argsort((pfreq - 0.5).abs()), torch.argsort(-(pfreq - 0.5).abs())]      # orders[k][i] = the tap that gets bit i (bit 0 = lowest)
+    ident = torch.arange(n, device=dev)
+    win = ident // 4096
+    out = []
+    for k, o in enumerate(orders):
+        w = torch.zeros(taps, dtype=torch.int64, device=dev)
+        w[o] = 1 << torch.arange(taps, device=dev, dtype=torch.int64)
+        key = win * (1 << taps) + (v.to(torch.int64) * w).sum(1)
+        order = torch.argsort(key, stable=True)
+        vv = v[order]
+        nt = (n + 31) // 32
+        pad = torch.zeros((nt * 32 - n, taps), dtype=torch.bool, device=dev)
+        g = float(torch.cat([vv, pad], 0).view(nt, 32, taps).any(1).sum()) * 32 * f
+        out.append(g)
+        tot2[k] += g
+    print(f"sites {n:7d} taps {taps:2d} {cin:3d}->{cout:3d}: " + " | ".join(f"{g / 1e9:6.2f}" for g in out))
+print("total: " + " | ".join(f"{g / 1e9:6.1f}" for g in tot2))
