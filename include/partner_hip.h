@@ -358,6 +358,9 @@ int pn_fold_bn_f32(const float *gamma, const float *beta, const float *mean, con
  * Deterministic: pixel slices are reduced in a fixed order, no float atomics.
  * A ConvTranspose2d(k=2,s=2) weight gradient is the weight gradient of the 2x2 / stride-2
  * convolution that maps its OUTPUT gradient to its INPUT (swap the roles of the two tensors).
+ * desc->range_strata > 1 (r4; RangeStratified, center_head_parallel.py:27-59: stride 1, width a multiple of the strata, cin and
+ * cout <= 64 per stratum): `dout` is the (B, H, W, cout) gradient, dweight (strata * cout, cin, KH, KW); stratum s sums the
+ * pixels of its own column band (the input's halo columns come from the neighbouring bands), one GEMM per stratum in one launch.
  */
 size_t pn_conv2d_wgrad_workspace_bytes(const pn_conv_desc *desc);
 int pn_conv2d_wgrad_f32(const pn_conv_desc *desc, const float *in, const float *dout, float *dweight,
@@ -610,6 +613,12 @@ int pn_relu_bwd_f32(const float *y, const float *dy, float *dx, size_t n, pn_str
 int pn_add_f32(const float *a, const float *b, float *out, size_t n, pn_stream_t stream);
 int pn_strat_expand_f32(const float *dy, int batch, int h, int w, int c, int strata, float *out,
                         pn_stream_t stream);
+/* r4: data gradient of the RangeStratified 3x3 convolution without the expansion.  With z (B,H,W,3c) = the stratified 3x1
+ * convolution of dy whose weight set s holds, for width tap kx, rows [kx*c, (kx+1)*c) = W_s[:, :, 2-ky, kx]^T (pn_conv2d_nhwc_f32,
+ * range_strata, kh 3, kw 1 -- the weights follow the stratum of the dy pixel, which is what the gradient needs),
+ * dx[y, x] (+)= z[y, x+1, 0:c] + z[y, x, c:2c] + z[y, x-1, 2c:3c]: this call.  1/strata of the expansion's multiply-adds. */
+int pn_strat_dgrad_combine_f32(const float *z, int batch, int h, int w, int c, float *dx, int dx_pixel_stride, int dx_channel_offset,
+                               int accumulate, pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * next-2  decode + rotated NMS: head tensors -> boxes, entirely on the device and on the caller's stream.

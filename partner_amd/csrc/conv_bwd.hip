@@ -64,12 +64,14 @@ struct WgradArgs {
   // nbr[m * taps + t] (-1: inactive); n_valid = device count of live output sites
   const int* nbr;
   const int* n_valid;
+  // range-stratified convolution (STRAT): blockIdx.y = stratum, the pixel index runs over the stratum's OWsub columns of every row
+  int OWsub;        // OW unless stratified
 };
 
 constexpr int WK = 32;  // pixels per K step
 
 
-template <int TM, int TN, bool GATHER>
+template <int TM, int TN, bool GATHER, bool STRAT = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int BM = TM * 64, BN = TN * 64;
   constexpr int LDA = BM + 8, LDB = BN + 8;
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
   const int split = (kq / per_split) * 8 + xcd;
   if (split >= a.splits) return;
+  const int z = STRAT ? (int)blockIdx.y : 0;
   int t = kq - (kq / per_split) * per_split;
   const int cot = t % a.co_tiles; t /= a.co_tiles;
   const int cit = t % a.ci_tiles;
@@ -124,9 +127,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         continue;
       }
       const unsigned b = fast_div(m, a.div_ohw);
-      const unsigned rem = m - b * (unsigned)(a.OH * a.OW);
+      const unsigned rem = m - b * (unsigned)(a.OH * a.OWsub);
       const unsigned oh = fast_div(rem, a.div_ow);
-      const unsigned ow = rem - oh * (unsigned)a.OW;
+      const unsigned ow = rem - oh * (unsigned)a.OWsub + (unsigned)(z * a.OWsub);
       const int ih = (int)oh * a.stride - a.pad_h + kh, iw = (int)ow * a.stride - a.pad_w + kw;
       const bool ok = a_cok && ((int)m < m_end) && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
       const unsigned pix = (b * (unsigned)a.H + (unsigned)ih) * (unsigned)a.W + (unsigned)iw;  // < 2^29 pixels (2 GiB map)
@@ -136,7 +139,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < B_PER_T; ++j) {
       const int m = ld_m + pb + B_ROWS * j;
-      const unsigned vo = (b_cok && m < m_end) ? ((unsigned)m * (unsigned)a.dy_ps + b_chan) * 4u : 0xffffffffu;
+      unsigned pix = (unsigned)m;
+      if constexpr (STRAT) {   // pixel m of the stratum -> its place in the full-width map
+        const unsigned b = fast_div(pix, a.div_ohw);
+        const unsigned rem = pix - b * (unsigned)(a.OH * a.OWsub);
+        const unsigned oh = fast_div(rem, a.div_ow);
+        pix = (b * (unsigned)a.OH + oh) * (unsigned)a.OW + rem - oh * (unsigned)a.OWsub + (unsigned)(z * a.OWsub);
+      }
+      const unsigned vo = (b_cok && m < m_end) ? (pix * (unsigned)a.dy_ps + b_chan) * 4u : 0xffffffffu;
       rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vo, 0, 0));
     }
     ld_m += WK;
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 
   // partial tile -> workspace [split][tap][ci][co]; D map: row (ci) = (r&3) + 8*(r>>2) + 4*lh, col (co) = li
-  float* dst = a.part + ((size_t)(split * (a.KH * a.KW) + tap) * a.cin_pad + ci0 + wm * TM * 32) * a.cout_pad + co0 + wn * TN * 32 + li;
+  float* dst = a.part + ((size_t)((z * a.splits + split) * (a.KH * a.KW) + tap) * a.cin_pad + ci0 + wm * TM * 32) * a.cout_pad + co0 + wn * TN * 32 + li;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -215,6 +225,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
                                     int cout_pad, float* __restrict__ dw, int accumulate, int tap_major = 0) {
   const size_t total = (size_t)taps * cin * cout;
   const size_t slice = (size_t)taps * cin_pad * cout_pad;
+  part += blockIdx.y * (size_t)splits * slice;   // range-stratified convolution: one weight set per blockIdx.y
+  dw += blockIdx.y * total;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int co = (int)(i % cout);
     size_t r = i / cout;
@@ -311,18 +323,23 @@ static const int kWgradTargetBlocks = [] { const char* e = getenv("PN_WGRAD_BLOC
 struct WgradPlan {
   int tm, tn, bm, bn, ci_tiles, co_tiles, cin_pad, cout_pad, splits, m_per_split, taps;
   long long M;
-  int OH, OW;
+  int OH, OW, strata;
 };
 
 int plan_wgrad(const pn_conv_desc* d, WgradPlan& p) {
   PN_REQUIRE(d != nullptr, "wgrad: null descriptor");
   PN_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0, "wgrad: bad sizes");
-  PN_REQUIRE(d->groups == 1 && !d->deconv2x2 && d->range_strata <= 1, "wgrad: plain convolutions only");
+  PN_REQUIRE(d->groups == 1 && !d->deconv2x2, "wgrad: plain and range-stratified convolutions only");
   PN_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->stride >= 1, "wgrad: bad kernel params");
   p.OH = (d->in_h + 2 * d->pad_h + d->pad_h_end - d->kh) / d->stride + 1;
   p.OW = (d->in_w + 2 * d->pad_w + d->pad_w_end - d->kw) / d->stride + 1;
   PN_REQUIRE(p.OH > 0 && p.OW > 0, "wgrad: empty output");
-  p.M = (long long)d->batch * p.OH * p.OW;
+  // range-stratified (center_head_parallel.py:27-59): `cout` filters PER stratum, dweight (strata * cout, cin, kh, kw); every stratum is
+  // its own GEMM over the pixels of its column band (the halo columns of the input come from the neighbouring bands)
+  p.strata = d->range_strata > 1 ? d->range_strata : 1;
+  PN_REQUIRE(p.strata == 1 || (d->stride == 1 && p.OW % p.strata == 0 && d->cin <= 64 && d->cout <= 64),
+             "wgrad: range strata need stride 1, a width divisible into the strata and at most 64 channels per stratum");
+  p.M = (long long)d->batch * p.OH * (p.OW / p.strata);
   PN_REQUIRE(p.M < (1ll << 31) - 64, "wgrad: too many output pixels");
   p.tm = d->cin > 64 ? 2 : 1;
   p.tn = d->cout > 64 ? 2 : 1;
@@ -338,23 +355,23 @@ int plan_wgrad(const pn_conv_desc* d, WgradPlan& p) {
   return PN_OK;
 }
 
-template <int TM, int TN, bool GATHER = false>
-int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
+template <int TM, int TN, bool GATHER = false, bool STRAT = false>
+int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st, int strata = 1) {
   constexpr size_t smem = 2 * (size_t)WK * (TM * 64 + 8 + TN * 64 + 8) * sizeof(float);
   static bool attr_done[64] = {false};
   if (pn::first_use_on_device(attr_done)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TM, TN, GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TM, TN, GATHER, STRAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   const int per_split = p.taps * p.ci_tiles * p.co_tiles;
   const int groups8 = pn::cdiv(p.splits, 8);  // splits are handed out in groups of 8, one per XCD
-  hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, GATHER>), dim3(groups8 * per_split * 8), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, GATHER, STRAT>), dim3(groups8 * per_split * 8, strata), dim3(256), smem, st, a);
   return pn::check_launch("conv_wgrad_kernel");
 }
 
 // plan of the gathered (sparse) weight gradient: rows = output sites, `taps` neighbour columns
 int plan_sparse_wgrad(int out_capacity, int taps, int cout, int cin, WgradPlan& p) {
   PN_REQUIRE(out_capacity >= 1 && taps >= 1 && taps <= 64 && cout >= 1 && cin >= 4 && cin % 4 == 0, "sparse_conv_wgrad: bad sizes (row width a multiple of 4)");
-  p.OH = out_capacity; p.OW = 1;
+  p.OH = out_capacity; p.OW = 1; p.strata = 1;
   p.M = out_capacity;
   p.tm = cin > 64 ? 2 : 1;
   p.tn = cout > 64 ? 2 : 1;
@@ -379,7 +396,7 @@ extern "C" {
 size_t pn_conv2d_wgrad_workspace_bytes(const pn_conv_desc* d) {
   WgradPlan p;
   if (plan_wgrad(d, p)) return 0;
-  return (size_t)p.splits * p.taps * p.cin_pad * p.cout_pad * sizeof(float);
+  return (size_t)p.strata * p.splits * p.taps * p.cin_pad * p.cout_pad * sizeof(float);
 }
 
 int pn_conv2d_wgrad_f32(const pn_conv_desc* d, const float* in, const float* dout, float* dweight, int accumulate,
@@ -394,7 +411,7 @@ int pn_conv2d_wgrad_f32(const pn_conv_desc* d, const float* in, const float* dou
   PN_REQUIRE(d->in_pixel_stride >= d->in_channel_offset + d->cin && d->out_pixel_stride >= d->out_channel_offset + d->cout,
              "wgrad: channel slice does not fit the pixel stride");
   const unsigned long long in_bytes = (unsigned long long)d->batch * d->in_h * d->in_w * d->in_pixel_stride * 4ull;
-  const unsigned long long dy_bytes = (unsigned long long)p.M * d->out_pixel_stride * 4ull;
+  const unsigned long long dy_bytes = (unsigned long long)p.M * p.strata * d->out_pixel_stride * 4ull;
   PN_REQUIRE(in_bytes < (1ull << 31) && dy_bytes < (1ull << 31), "wgrad: maps larger than 2 GiB are not addressable by the buffer descriptor");
   WgradArgs a;
   a.in = in; a.dy = dout; a.part = static_cast<float*>(workspace);
@@ -404,16 +421,18 @@ int pn_conv2d_wgrad_f32(const pn_conv_desc* d, const float* in, const float* dou
   a.M = (int)p.M; a.m_per_split = p.m_per_split; a.ci_tiles = p.ci_tiles; a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;
   a.co_tiles = p.co_tiles; a.tiles_per_split = p.taps * p.ci_tiles * p.co_tiles; a.splits = p.splits;
   a.in_bytes = (unsigned)in_bytes; a.dy_bytes = (unsigned)dy_bytes;
-  a.div_ohw = make_fastdiv((unsigned)(p.OH * p.OW)); a.div_ow = make_fastdiv((unsigned)p.OW);
+  a.OWsub = p.OW / p.strata;
+  a.div_ohw = make_fastdiv((unsigned)(p.OH * a.OWsub)); a.div_ow = make_fastdiv((unsigned)a.OWsub);
   hipStream_t st = pn::S(stream);
   int rc;
-  if (p.tm == 2 && p.tn == 2) rc = launch_wgrad<2, 2>(a, p, st);
+  if (p.strata > 1) rc = launch_wgrad<1, 1, false, true>(a, p, st, p.strata);
+  else if (p.tm == 2 && p.tn == 2) rc = launch_wgrad<2, 2>(a, p, st);
   else if (p.tm == 2) rc = launch_wgrad<2, 1>(a, p, st);
   else if (p.tn == 2) rc = launch_wgrad<1, 2>(a, p, st);
   else rc = launch_wgrad<1, 1>(a, p, st);
   if (rc) return rc;
   const size_t total = (size_t)p.taps * d->cin * d->cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256), p.strata), dim3(256), 0, st,
                      a.part, p.splits, p.taps, d->cin, d->cout, p.cin_pad, p.cout_pad, dweight, accumulate);
   return pn::check_launch("wgrad_reduce_kernel");
 }
@@ -437,7 +456,7 @@ int pn_sparse_conv_wgrad_f32(const float* in, int in_rows, int cin, int cin_real
   PN_REQUIRE(in_rows > 0 && (unsigned long long)in_rows * cin * 4ull < (1ull << 31), "sparse_conv_wgrad: feature matrix (in_rows x cin) must be under 2 GiB");
   WgradArgs a{};
   a.in = in; a.dy = dout; a.part = static_cast<float*>(workspace);
-  a.B = 1; a.H = out_capacity; a.W = 1; a.Cin = cin; a.Cout = cout; a.OH = out_capacity; a.OW = 1;
+  a.B = 1; a.H = out_capacity; a.W = 1; a.Cin = cin; a.Cout = cout; a.OH = out_capacity; a.OW = 1; a.OWsub = 1;
   a.KH = taps; a.KW = 1; a.stride = 1; a.pad_h = 0; a.pad_w = 0;
   a.in_ps = cin; a.in_co = 0; a.dy_ps = cout; a.dy_co = 0;
   a.M = out_capacity; a.m_per_split = p.m_per_split; a.ci_tiles = p.ci_tiles; a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;

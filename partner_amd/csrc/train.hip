@@ -99,6 +99,26 @@ __global__ void strat_expand_kernel(const float* __restrict__ dy, int W, int C, 
   }
 }
 
+// data gradient of the range-stratified 3x3 convolution, second half.  z (B,H,W,3*C) holds, per width tap kx, the column convolution of
+// dy with the weights of the dy pixel's OWN stratum (a stratified 3x1 convolution, conv_mfma.hip MODE_STRAT):
+// dx[y, x] = z[y, x+1, 0:C] + z[y, x, C:2C] + z[y, x-1, 2C:3C], columns outside the map contributing zero
+__global__ void strat_dgrad_combine_kernel(const float* __restrict__ z, int W, int C, float* __restrict__ dx, int dx_ps, int dx_co, int accumulate,
+                                           size_t total4) {
+  const int vpc = C / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / vpc;
+    const int c = (int)(i - pix * vpc) * 4;
+    const int x = (int)(pix % W);
+    const float* zp = z + pix * (size_t)(3 * C) + c;
+    f32x4 v = *reinterpret_cast<const f32x4*>(zp + C);
+    if (x + 1 < W) v += *reinterpret_cast<const f32x4*>(zp + 3 * C);
+    if (x > 0) v += *reinterpret_cast<const f32x4*>(zp - 3 * C + 2 * C);
+    float* o = dx + pix * (size_t)dx_ps + dx_co + c;
+    if (accumulate) v += *reinterpret_cast<const f32x4*>(o);
+    *reinterpret_cast<f32x4*>(o) = v;
+  }
+}
+
 inline unsigned grid_for(size_t n) { return (unsigned)std::min<size_t>(4096, (n + 255) / 256); }
 
 }  // namespace
@@ -152,6 +172,16 @@ int pn_strat_expand_f32(const float* dy, int batch, int h, int w, int c, int str
   const size_t total4 = (size_t)batch * h * w * strata * (c / 4);
   hipLaunchKernelGGL(strat_expand_kernel, dim3(grid_for(total4)), dim3(256), 0, pn::S(stream), dy, w, c, strata, out, total4);
   return pn::check_launch("strat_expand_kernel");
+}
+
+int pn_strat_dgrad_combine_f32(const float* z, int batch, int h, int w, int c, float* dx, int dx_pixel_stride, int dx_channel_offset, int accumulate,
+                               pn_stream_t stream) {
+  PN_REQUIRE(z && dx && batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && dx_pixel_stride % 4 == 0 && dx_channel_offset % 4 == 0 &&
+             dx_pixel_stride >= dx_channel_offset + c, "strat_dgrad_combine: bad arguments");
+  const size_t total4 = (size_t)batch * h * w * (c / 4);
+  hipLaunchKernelGGL(strat_dgrad_combine_kernel, dim3(grid_for(total4)), dim3(256), 0, pn::S(stream), z, w, c, dx, dx_pixel_stride, dx_channel_offset,
+                     accumulate, total4);
+  return pn::check_launch("strat_dgrad_combine_kernel");
 }
 
 }  // extern "C"

@@ -261,6 +261,7 @@ SIGNATURES = {
     "pn_relu_bwd_f32": (_I, [_P, _P, _P, _SZ, _P]),
     "pn_add_f32": (_I, [_P, _P, _P, _SZ, _P]),
     "pn_strat_expand_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "pn_strat_dgrad_combine_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
     "pn_center_loss_workspace_bytes": (_SZ, []),
     "pn_center_loss_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _F, _P, _P, _SZ, _P]),
     "pn_center_loss_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _F, _P, _F, _P, _I, _P, _P, _P]),

@@ -1282,8 +1282,9 @@ def shared_side_stream(device) -> SideStream:
 
 def conv_wgrad(x: torch.Tensor, dout: torch.Tensor, kh: int, kw: int, stride=1, pad=0, cin: Optional[int] = None,
                in_channel_offset=0, cout: Optional[int] = None, dout_channel_offset=0, out: Optional[torch.Tensor] = None,
-               accumulate=False) -> torch.Tensor:
-    """dW (Cout, Cin, KH, KW) of a convolution x -> y given dout = dL/dy; NHWC maps."""
+               accumulate=False, range_strata=0) -> torch.Tensor:
+    """dW (Cout, Cin, KH, KW) of a convolution x -> y given dout = dL/dy; NHWC maps.  ``range_strata`` > 1: the RangeStratified
+    convolution (one weight set per band of W / strata columns) -> dW (strata * Cout, Cin, KH, KW)."""
     hip.require_device(x, dout)
     lib = hip.load()
     assert x.dim() == 4 and dout.dim() == 4 and x.is_contiguous() and dout.is_contiguous()
@@ -1291,12 +1292,12 @@ def conv_wgrad(x: torch.Tensor, dout: torch.Tensor, kh: int, kw: int, stride=1, 
     cin = ct - in_channel_offset if cin is None else cin
     cout = dout.shape[3] - dout_channel_offset if cout is None else cout
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
-    d = ConvDesc(b, h, w, cin, cout, 1, kh, kw, stride, ph, pw, ct, in_channel_offset, dout.shape[3], dout_channel_offset, 0, 0, 0)
+    d = ConvDesc(b, h, w, cin, cout, 1, kh, kw, stride, ph, pw, ct, in_channel_offset, dout.shape[3], dout_channel_offset, 0, 0, int(range_strata))
     oh, ow = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
     assert dout.shape[:3] == (b, oh, ow), (dout.shape, (b, oh, ow))
     if out is None:
-        out = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device)
-    if (_WGRAD_WINO4 and (kh, kw, stride, ph, pw) == (3, 3, 1, 1, 1) and w % 4 == 0 and cin % 4 == 0 and cout % 4 == 0 and in_channel_offset % 4 == 0
+        out = torch.empty((max(1, int(range_strata)) * cout, cin, kh, kw), dtype=torch.float32, device=x.device)
+    if (range_strata <= 1 and _WGRAD_WINO4 and (kh, kw, stride, ph, pw) == (3, 3, 1, 1, 1) and w % 4 == 0 and cin % 4 == 0 and cout % 4 == 0 and in_channel_offset % 4 == 0
             and dout_channel_offset % 4 == 0 and ct % 4 == 0 and dout.shape[3] % 4 == 0 and b * h * (w // 4) >= _WGRAD_WINO4_MIN_QUADS
             and cin * cout >= 0.75 * (-(-cin // 128) * 128) * (-(-cout // 128) * 128)):      # its 128 x 128 (ci, co) tiles mostly full
         # F(4, 3) weight gradient (conv_wgrad_wino4.hip): half the MFMA work on the maps large enough to fill the chip with its slices
@@ -1670,6 +1671,50 @@ def strat_expand(dy: torch.Tensor, strata: int, out: Optional[torch.Tensor] = No
     if out is None:
         out = torch.empty((b, h, w, strata * c), dtype=torch.float32, device=dy.device)
     hip.call("pn_strat_expand_f32", dy.data_ptr(), b, h, w, c, strata, out.data_ptr(), hip.stream())
+    return out
+
+
+class StratConvDgrad:
+    """Data gradient of the RangeStratified 3x3 convolution (weight (strata * Cout, Cin, 3, 3), center_head_parallel.py:27-59) at the
+    convolution's own multiply-add count.  The weight set a tap takes follows the stratum of the dy pixel it reads, so per width tap kx
+    the column convolution z_kx[y, x] = sum_ky W_s(x)[:, :, ky, kx]^T dy[y - ky + 1, x] is a STRATIFIED 3x1 convolution of dy (the forward
+    kernel, 3 * Cin outputs per stratum), and dx[y, x] = z_0[y, x + 1] + z_1[y, x] + z_2[y, x - 1] (pn_strat_dgrad_combine_f32).  r3 expanded
+    dy to strata * Cout channels and ran an ordinary gradient convolution over mostly zeros (8 x the work on the reference's head)."""
+
+    def __init__(self, weight: torch.Tensor, strata: int):
+        hip.require_device(weight)
+        ct, cin, kh, kw = weight.shape
+        assert (kh, kw) == (3, 3) and ct % strata == 0 and cin % 4 == 0
+        self.strata, self.cin, self.cout = int(strata), cin, ct // strata
+        # w'[s, kx * Cin + ci, co, ky', 0] = w[s * Cout + co, ci, 2 - ky', kx]: one gather of the flat weight
+        idx = torch.arange(weight.numel(), device=weight.device).view(strata, self.cout, cin, 3, 3)
+        self._idx = idx.flip(3).permute(0, 4, 2, 1, 3).reshape(-1).contiguous()
+        self._shape = (strata * 3 * cin, self.cout, 3, 1)
+        self._w = weight.detach().reshape(-1)[self._idx].view(self._shape)
+        self.layer = ConvLayer(self._w, stride=1, pad=(1, 0), range_strata=self.strata)
+
+    def repack(self, weight: torch.Tensor) -> None:
+        torch.index_select(weight.detach().reshape(-1), 0, self._idx, out=self._w.view(-1))
+        self.layer.repack(self._w)
+
+    def __call__(self, dy: torch.Tensor, out: Optional[torch.Tensor] = None, out_channel_offset=0, accumulate=False) -> torch.Tensor:
+        hip.require_device(dy)
+        b, h, w, c = dy.shape
+        assert c == self.cout and dy.is_contiguous()
+        z = self.layer(dy)
+        if out is None:
+            out = torch.empty((b, h, w, self.cin), dtype=torch.float32, device=dy.device)
+        assert out.shape[:3] == (b, h, w) and out.is_contiguous()
+        hip.call("pn_strat_dgrad_combine_f32", z.data_ptr(), b, h, w, self.cin, out.data_ptr(), out.shape[3], out_channel_offset, int(accumulate),
+                 hip.stream())
+        return out
+
+
+def strat_channel_sum(dy: torch.Tensor, strata: int, out: torch.Tensor) -> torch.Tensor:
+    """bias gradient of the RangeStratified convolution: sums of dy (B,H,W,C) over the pixels of every column band -> out (strata * C)"""
+    b, h, w, c = dy.shape
+    cols = channel_sum(dy.view(1, b * h, 1, w * c))       # per (column, channel) over the rows, fixed order
+    torch.sum(cols.view(strata, w // strata, c), dim=1, out=out.view(strata, c))
     return out
 
 
