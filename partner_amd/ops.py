@@ -510,11 +510,16 @@ class ConvLayer:
         w9[:9 * self.cout] = w.reshape(self.cout, -1, 9)[:, :self.cin].permute(2, 0, 1).reshape(9 * self.cout, -1)   # row t * cout + co
         hip.call("pn_pack_linear_weight_f32", w9.data_ptr(), self.tap_n, self.cin, self.tap_packed.data_ptr(), hip.stream())
 
-    def repack(self, weight: torch.Tensor, shift: Optional[torch.Tensor] = None) -> None:
+    def repack(self, weight: torch.Tensor, shift: Optional[torch.Tensor] = None, token=None) -> None:
         """refresh the packed copies from an updated weight of the same shape (training: once per step).  LAZY: a layout (direct,
         F(2, 3), F(4, 3)) is packed when the next call takes it -- a layer keeps up to three and uses one per map size, and the
         tiny pack launches were 0.8 ms of an 18.8 ms training iteration.  ``weight`` must stay valid (and unchanged) until then: the
-        training steps hand in views of their flat parameter buffer, which the optimizer rewrites only after the backward."""
+        training steps hand in views of their flat parameter buffer, which the optimizer rewrites only after the backward.
+        ``token``: a call with the token of the previous call is a no-op (the training steps refresh every layer once at the start of an
+        iteration, ``prepack_used``, and pass the iteration's token from the layers' forward / backward)"""
+        if token is not None and getattr(self, "_token", None) is token:
+            return
+        self._token = token
         w = weight.detach()
         assert w.is_contiguous() and w.dtype == torch.float32
         self._stale_w = w
@@ -528,7 +533,14 @@ class ConvLayer:
         if shift is not None:
             self.shift = shift
 
+    def prepack_used(self) -> None:
+        """pack, on the current stream, the layouts the layer's calls have taken so far (after ``repack``)"""
+        for layout in sorted(getattr(self, "_used", ())):
+            self._ensure(layout)
+
     def _ensure(self, layout: str) -> None:
+        if not layout.endswith("_t"):
+            self.__dict__.setdefault("_used", set()).add(layout)
         stale = getattr(self, "_stale", None)
         if not stale or layout not in stale:
             return
@@ -817,7 +829,10 @@ class PillarConvLayer:
         return out
 
     # ---- training: pair tables built once per iteration, shared by forward, data gradient and weight gradient
-    def repack(self, weight: torch.Tensor) -> None:
+    def repack(self, weight: torch.Tensor, token=None) -> None:
+        if token is not None and getattr(self, "_token", None) is token:
+            return
+        self._token = token
         w = weight.detach().contiguous().float()
         hip.call("pn_pack_pillar_conv_weight_f32", w.data_ptr(), self.cout, self.cin, self.packed.data_ptr(), hip.stream())
         if getattr(self, "packed_t", None) is None:
@@ -1383,12 +1398,20 @@ class ConvDgrad:
                 self.wino4_packed = _f32(lib.pn_conv_wino4_packed_weight_floats(cin, cout), dev)
         self.repack(weight)
 
-    def repack(self, weight: torch.Tensor) -> None:
+    def repack(self, weight: torch.Tensor, token=None) -> None:
         """lazy, as ConvLayer.repack: the layout a call takes is packed on first use"""
+        if token is not None and getattr(self, "_token", None) is token:
+            return
+        self._token = token
         self._stale_w = weight.detach().contiguous().float()
         self._stale = {"direct"} | ({"wino"} if self.wino_packed is not None else set()) | ({"wino4"} if self.wino4_packed is not None else set())
 
+    def prepack_used(self) -> None:
+        for layout in sorted(getattr(self, "_used", ())):
+            self._ensure(layout)
+
     def _ensure(self, layout: str) -> None:
+        self.__dict__.setdefault("_used", set()).add(layout)
         if layout not in self._stale:
             return
         self._stale.discard(layout)
@@ -1693,9 +1716,15 @@ class StratConvDgrad:
         self._w = weight.detach().reshape(-1)[self._idx].view(self._shape)
         self.layer = ConvLayer(self._w, stride=1, pad=(1, 0), range_strata=self.strata)
 
-    def repack(self, weight: torch.Tensor) -> None:
+    def repack(self, weight: torch.Tensor, token=None) -> None:
+        if token is not None and getattr(self, "_token", None) is token:
+            return
+        self._token = token
         torch.index_select(weight.detach().reshape(-1), 0, self._idx, out=self._w.view(-1))
         self.layer.repack(self._w)
+
+    def prepack_used(self) -> None:
+        self.layer.prepack_used()
 
     def __call__(self, dy: torch.Tensor, out: Optional[torch.Tensor] = None, out_channel_offset=0, accumulate=False) -> torch.Tensor:
         hip.require_device(dy)

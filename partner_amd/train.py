@@ -78,6 +78,8 @@ class ParamStore:
         self.flat_m = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat_v = torch.zeros(off, dtype=torch.float32, device=device)
         self.side = _SideStream(device)
+        self.fresh = None            # token of the iteration whose packed weights were refreshed ahead (PolarPillarTrainStep._prepack)
+        self.convs: List[object] = []   # the step's convolution wrappers (prepack_fwd / prepack_bwd), in construction order
         self.p: Dict[str, torch.Tensor] = {}
         self.g: Dict[str, torch.Tensor] = {}
         for name, p in model.named_parameters():
@@ -141,6 +143,7 @@ import os as _os
 # through the batch statistics); the data gradients take F(4, 3) everywhere (ops.ConvDgrad)
 _TRAIN_WINO4_MAX_PIXELS = int(_os.environ.get("PN_TRAIN_WINO4_MAX_PIXELS", "16384"))
 _TRAIN_PILLAR_CONV = _os.environ.get("PN_TRAIN_PILLAR_CONV", "1") != "0"
+_TRAIN_PREPACK = _os.environ.get("PN_TRAIN_PREPACK", "1") != "0"
 
 
 class _Conv:
@@ -165,10 +168,19 @@ class _Conv:
         self.cin_real = w.shape[1] if not transposed else w.shape[0]
         self.x = None
         self.in_co = 0
+        ps.convs.append(self)
+
+    def prepack_fwd(self, token):
+        self.layer.repack(self.ps.p[self.wname], None if self.bname is None else self.ps.p[self.bname], token=token)
+        self.layer.prepack_used()
+
+    def prepack_bwd(self, token):
+        self.dgrad.repack(self.ps.p[self.wname], token=token)
+        self.dgrad.prepack_used()
 
     def fwd(self, x, out=None, out_co=0, in_co=0):
         w = self.ps.p[self.wname]
-        self.layer.repack(w, None if self.bname is None else self.ps.p[self.bname])
+        self.layer.repack(w, None if self.bname is None else self.ps.p[self.bname], token=self.ps.fresh)
         self.x, self.in_co = x, in_co
         return self.layer(x, out=out, out_channel_offset=out_co, in_channel_offset=in_co)
 
@@ -179,7 +191,7 @@ class _Conv:
         if self.transposed:
             self.ps.side.run(lambda: ops.conv_wgrad(dout, self.x, 2, 2, 2, 0, cout=w.shape[0], dout_channel_offset=self.in_co, out=gw), dout, self.x)
             if need_dx:
-                self.dgrad.repack(w)
+                self.dgrad.repack(w, token=self.ps.fresh)
                 return self.dgrad(dout, out=dx, out_channel_offset=dx_co, accumulate=accumulate)
             return None
         cout = w.shape[0] if cout is None else cout
@@ -192,7 +204,7 @@ class _Conv:
 
         self.ps.side.run(weight_grads, dout, self.x)
         if need_dx:
-            self.dgrad.repack(w)
+            self.dgrad.repack(w, token=self.ps.fresh)
             return self.dgrad(dout, out=dx, out_channel_offset=dx_co, accumulate=accumulate)
         return None
 
@@ -206,10 +218,17 @@ class _PillarConv:
         self.ps, self.wname = ps, wname
         self.layer = ops.PillarConvLayer(ps.p[wname], stride)
         self.vi = self.x = self.tables = None
+        ps.convs.append(self)
+
+    def prepack_fwd(self, token):
+        self.layer.repack(self.ps.p[self.wname], token=token)
+
+    def prepack_bwd(self, token):
+        pass
 
     def fwd(self, x, out=None, out_co=0, in_co=0):
         assert out is None and in_co == 0
-        self.layer.repack(self.ps.p[self.wname])
+        self.layer.repack(self.ps.p[self.wname], token=self.ps.fresh)
         self.x = x
         self.tables = self.layer.build_tables(self.vi, x.shape[0], x.shape[1], x.shape[2])
         return self.layer.forward_tables(x, self.vi, self.tables)
@@ -331,10 +350,19 @@ class _StratConvGNReLU:
         self.masked = _os.environ.get("PN_TRAIN_STRAT_EXPAND", "0") == "0"
         self.dgrad = ops.StratConvDgrad(w, self.strata) if self.masked else ops.ConvDgrad(w, 1, 1)
         self.x = self.y = None
+        ps.convs.append(self)
+
+    def prepack_fwd(self, token):
+        self.layer.repack(self.ps.p[self.wname], self.ps.p[self.bname], token=token)
+        self.layer.prepack_used()
+
+    def prepack_bwd(self, token):
+        self.dgrad.repack(self.ps.p[self.wname], token=token)
+        self.dgrad.prepack_used()
 
     def fwd(self, x):
         self.x = x
-        self.layer.repack(self.ps.p[self.wname], self.ps.p[self.bname])
+        self.layer.repack(self.ps.p[self.wname], self.ps.p[self.bname], token=self.ps.fresh)
         self.y = self.layer(x)
         return ops.groupnorm_strat(self.y, self.nheads, self.strata, self.ps.p[self.gname], self.ps.p[self.bename], self.eps, act=RELU)
 
@@ -348,7 +376,7 @@ class _StratConvGNReLU:
                 ops.strat_channel_sum(dy, self.strata, self.ps.g[self.bname])
 
             self.ps.side.run(weight_grads, dy, self.x)
-            self.dgrad.repack(w)
+            self.dgrad.repack(w, token=self.ps.fresh)
             return self.dgrad(dy, out=dx, accumulate=accumulate)
         full = ops.strat_expand(dy, self.strata)  # zeros outside the pixel's stratum: an ordinary conv gradient (the r3 form)
 
@@ -357,7 +385,7 @@ class _StratConvGNReLU:
             ops.channel_sum(full, out=self.ps.g[self.bname])
 
         self.ps.side.run(weight_grads, full, self.x)
-        self.dgrad.repack(w)
+        self.dgrad.repack(w, token=self.ps.fresh)
         return self.dgrad(full, out=dx, accumulate=accumulate)
 
 
@@ -500,6 +528,8 @@ class PolarPillarTrainStep:
         out, off = None, 0
         self.block_out = []
         for i, layers in enumerate(self.blocks):
+            if i < 2:
+                self._packs_ready(i)
             for layer in layers:
                 x = layer.fwd(x)
             self.block_out.append(x)
@@ -654,12 +684,52 @@ class PolarPillarTrainStep:
             self._exchange.ready(k)
 
     # ------------------------------------------------------------------------------------------
+    def _prepack(self):
+        """Refresh the packed weight copies of the iteration AHEAD of their use, on the side stream: the forward is a serial chain on the
+        main stream with the side stream idle, and every layer's pack launch (2 - 10 us, ~65 per iteration) sat in that chain in front of
+        its convolution.  Three events: the first RPN stage's forward layouts (the main stream meets them after the PFN), the other forward
+        layouts, the data-gradient layouts.  A layout is refreshed here once a call has taken it (the first iteration packs lazily as
+        before); ``ps.fresh`` is the iteration's token, the wrappers' own repack calls see it and do nothing."""
+        ps = self.ps
+        side = ps.side.stream if _TRAIN_PREPACK else None
+        self._pack_events = None
+        if side is None:
+            ps.fresh = None
+            return
+        tok = ps.fresh = object()
+        first = {id(layer.conv) for layer in self.blocks[0]}
+        groups = ([c for c in ps.convs if id(c) in first], [c for c in ps.convs if id(c) not in first])
+        if getattr(self, "_pack_ev", None) is None:
+            self._pack_ev = [torch.cuda.Event() for _ in range(3)]
+
+        def packs():
+            for k, group in enumerate(groups):
+                for c in group:
+                    c.prepack_fwd(tok)
+                self._pack_ev[k].record()
+            for c in ps.convs:
+                c.prepack_bwd(tok)
+            self._pack_ev[2].record()
+
+        ps.side.run(packs)
+        self._pack_events = self._pack_ev
+
+    def _packs_ready(self, k: int) -> None:
+        if getattr(self, "_pack_events", None) is not None:
+            torch.cuda.current_stream().wait_event(self._pack_events[k])
+
     def forward_backward(self, points, sample_offsets, batch, targets: ops.CenterLossTargets, grid_ind=None, grad_scale=1.0):
         """forward + loss + backward; gradients land in ``self.ps.flat_g`` (overwritten, not accumulated)"""
-        preds = self._forward(points, sample_offsets, batch, grid_ind)
-        order, boxes = self._loss_sources()
-        loss = ops.center_loss(preds["hm"], self.ncls, boxes, targets, self.code_weights, self.loss_weight, with_vel="vel" in preds)
-        self._backward(targets, loss, grad_scale)
+        self._prepack()
+        try:
+            preds = self._forward(points, sample_offsets, batch, grid_ind)
+            order, boxes = self._loss_sources()
+            loss = ops.center_loss(preds["hm"], self.ncls, boxes, targets, self.code_weights, self.loss_weight, with_vel="vel" in preds)
+            self._packs_ready(2)
+            self._backward(targets, loss, grad_scale)
+        finally:
+            self.ps.fresh = None
+            self._pack_events = None
         return loss
 
     def optimizer_step(self):
