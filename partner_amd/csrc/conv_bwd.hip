@@ -320,6 +320,8 @@ __global__ void pack_dgrad_s2_kernel(const float* __restrict__ w, int cout, int 
 // blocks per launch the pixel range is split for (512 block slots per launch: 2 blocks x 256 CUs; 1536 = three full rounds measured best at B=4, 94 TFLOP/s over the model layers)
 static const int kWgradTargetBlocks = [] { const char* e = getenv("PN_WGRAD_BLOCKS"); return e ? atoi(e) : 1536; }();
 
+static const int kWgradCapPartials = [] { const char* e = getenv("PN_WGRAD_CAP_PARTIALS"); return e ? atoi(e) : 4; }();   // divisor of the cap (4 measured best on both training steps), 0 = no cap
+
 struct WgradPlan {
   int tm, tn, bm, bn, ci_tiles, co_tiles, cin_pad, cout_pad, splits, m_per_split, taps;
   long long M;
@@ -349,6 +351,16 @@ int plan_wgrad(const pn_conv_desc* d, WgradPlan& p) {
   p.taps = d->kh * d->kw;
   const long long tiles = (long long)p.taps * p.ci_tiles * p.co_tiles;
   long long s = std::max<long long>(1, kWgradTargetBlocks / tiles);  // never one block over a full round of the 512 block slots
+  // r4: every slice writes a full (taps, cin, cout) partial and the reduction reads it back -- on a layer with few pixels and many
+  // weights (128 -> 256 at 64 x 64: 85 slices x 1.2 MB against 50 MB of maps) that traffic was most of the launch pair.  The slice count
+  // is capped where the partials reach a quarter of the maps' bytes, but not below one round of the block slots (13.3 -> 13.1 ms per training
+  // iteration of the pillar model; the Waymo detector's large maps keep their three rounds: fewer cost it 4 ms)
+  if (kWgradCapPartials) {
+    const long long map_bytes = ((long long)d->batch * d->in_h * d->in_w * d->cin + p.M * d->cout) * 4;
+    const long long w_bytes = (long long)p.taps * p.cin_pad * p.cout_pad * 4;
+    const long long one_round = std::max<long long>(1, 512 / tiles);
+    s = std::min(s, std::max(one_round, map_bytes / (kWgradCapPartials * w_bytes)));
+  }
   s = std::min<long long>(s, std::max<long long>(1, p.M / 256));
   p.m_per_split = (int)(((p.M + s - 1) / s + WK - 1) / WK * WK);
   p.splits = (int)((p.M + p.m_per_split - 1) / p.m_per_split);
