@@ -255,6 +255,7 @@ def run_train(args, model, dev, rank, world, red_dev, steps, warmup):
     t0 = time.perf_counter()
     for i in range(steps):
         loss = leg.step(i)
+    host_issue_ms = 1e3 * (time.perf_counter() - t0) / steps     # the host's share: time to QUEUE an iteration (no synchronisation in the loop)
     barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, red_dev)
     last_loss = float(loss[0])
@@ -275,7 +276,7 @@ def run_train(args, model, dev, rank, world, red_dev, steps, warmup):
         leg.ts.exchange_enabled = True
     B = args.train_batch
     return dict(ms_per_iter=round(1e3 * elapsed / steps, 3), frames_per_s=round(world * steps * B / elapsed, 3), sweeps_per_iter_per_gpu=B,
-                iters=steps, warmup=warmup, n_gpus=world,
+                iters=steps, warmup=warmup, n_gpus=world, host_issue_ms_per_iter=round(host_issue_ms, 3),
                 ms_per_iter_no_exchange=None if no_ex is None else round(no_ex, 3),
                 exposed_exchange_ms=None if no_ex is None else round(1e3 * elapsed / steps - no_ex, 3),
                 all_reduce_ms=round(ar, 3), all_reduce="flat fp32 gradient buffer in reverse-layer-order buckets, issued during backward "

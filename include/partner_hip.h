@@ -407,6 +407,14 @@ int pn_groupnorm_strat_fwd(const float *x, int batch, int h, int w, int c, int p
                            int out_pixel_stride, int out_channel_offset, const float *mul,
                            const float *add, float *out2, void *workspace, size_t workspace_bytes,
                            pn_stream_t stream);
+/* r4 (training): the same call that also leaves mean_rstd [batch][range_strata][channel_groups][2] with the caller (nullable), for
+ * pn_groupnorm_strat_bwd_stat -- the backward then starts from the forward's statistics instead of two more passes over x. */
+int pn_groupnorm_strat_fwd_stat(const float *x, int batch, int h, int w, int c, int pixel_stride,
+                                int channel_offset, int channel_groups, int range_strata,
+                                const float *gamma, const float *beta, float eps, int act, float *out,
+                                int out_pixel_stride, int out_channel_offset, const float *mul,
+                                const float *add, float *out2, float *mean_rstd_out, void *workspace,
+                                size_t workspace_bytes, pn_stream_t stream);
 /* pn_groupnorm_strat_fwd whose result leaves as the F(4, 3) planes of conv_wchain.hip instead of the map (planes2, nullable: the planes of
  * out * mul + add); transpose_hw: the planes of the transposed map.  Each buffer: pn_wino4_planes_floats(batch, h, w, c) floats (transposed:
  * (batch, w, h, c)).  norm.py:58-75 + the input transform of the convolutions that follow. */
@@ -438,6 +446,15 @@ int pn_groupnorm_strat_bwd(const float *x, const float *dout, const float *dout2
                            int act, float *dx, int dx_pixel_stride, int dx_channel_offset,
                            float *dgamma, float *dbeta, float *dmul, float *dadd, int accumulate,
                            void *workspace, size_t workspace_bytes, pn_stream_t stream);
+/* mean_rstd: the statistics pn_groupnorm_strat_fwd_stat kept (NULL: recomputed, as pn_groupnorm_strat_bwd) */
+int pn_groupnorm_strat_bwd_stat(const float *x, const float *dout, const float *dout2, const float *mul,
+                                int batch, int h, int w, int c, int pixel_stride, int channel_offset,
+                                int dout_pixel_stride, int dout_channel_offset, int channel_groups,
+                                int range_strata, const float *gamma, const float *beta, float eps,
+                                int act, float *dx, int dx_pixel_stride, int dx_channel_offset,
+                                float *dgamma, float *dbeta, float *dmul, float *dadd, int accumulate,
+                                const float *mean_rstd, void *workspace, size_t workspace_bytes,
+                                pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * BatchNorm2d in training mode + the activation that follows it (rpn.py:128-140 under

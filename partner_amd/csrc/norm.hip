@@ -277,6 +277,14 @@ int pn_groupnorm_strat_fwd(const float* x, int batch, int h, int w, int c, int p
                            int channel_groups, int range_strata, const float* gamma, const float* beta, float eps, int act,
                            float* out, int out_pixel_stride, int out_channel_offset, const float* mul, const float* add,
                            float* out2, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  return pn_groupnorm_strat_fwd_stat(x, batch, h, w, c, pixel_stride, channel_offset, channel_groups, range_strata, gamma, beta, eps, act, out,
+                                     out_pixel_stride, out_channel_offset, mul, add, out2, nullptr, workspace, workspace_bytes, stream);
+}
+
+int pn_groupnorm_strat_fwd_stat(const float* x, int batch, int h, int w, int c, int pixel_stride, int channel_offset,
+                                int channel_groups, int range_strata, const float* gamma, const float* beta, float eps, int act,
+                                float* out, int out_pixel_stride, int out_channel_offset, const float* mul, const float* add,
+                                float* out2, float* mean_rstd_out, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
   PN_REQUIRE(x && out && workspace, "groupnorm: null pointer");
   PN_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && c >= 1, "groupnorm: bad sizes");
   PN_REQUIRE(c % 4 == 0 && c <= 4 * kThreads && (4 * kThreads) % c == 0, "groupnorm: channel count must be a multiple of 4 dividing 1024");
@@ -299,7 +307,7 @@ int pn_groupnorm_strat_fwd(const float* x, int batch, int h, int w, int c, int p
   a.mul = mul; a.add = add; a.out2 = out2; a.o2ps = c; a.o2co = 0;
   a.part = static_cast<double*>(workspace);
   const size_t ngroups = (size_t)batch * range_strata * channel_groups;
-  a.stat = reinterpret_cast<float*>(a.part + ngroups * 256 * 2);
+  a.stat = mean_rstd_out ? mean_rstd_out : reinterpret_cast<float*>(a.part + ngroups * 256 * 2);   // kept by the caller for the backward
   dim3 grid(a.splits, range_strata, batch);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(kThreads), 0, pn::S(stream), a);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ngroups), dim3(64), 0, pn::S(stream), a);
@@ -839,6 +847,17 @@ int pn_groupnorm_strat_bwd(const float* x, const float* dout, const float* dout2
                            int channel_groups, int range_strata, const float* gamma, const float* beta, float eps, int act,
                            float* dx, int dx_pixel_stride, int dx_channel_offset, float* dgamma, float* dbeta, float* dmul,
                            float* dadd, int accumulate, void* workspace, size_t workspace_bytes, pn_stream_t stream) {
+  return pn_groupnorm_strat_bwd_stat(x, dout, dout2, mul, batch, h, w, c, pixel_stride, channel_offset, dout_pixel_stride, dout_channel_offset,
+                                     channel_groups, range_strata, gamma, beta, eps, act, dx, dx_pixel_stride, dx_channel_offset, dgamma, dbeta,
+                                     dmul, dadd, accumulate, nullptr, workspace, workspace_bytes, stream);
+}
+
+int pn_groupnorm_strat_bwd_stat(const float* x, const float* dout, const float* dout2, const float* mul, int batch, int h, int w, int c,
+                                int pixel_stride, int channel_offset, int dout_pixel_stride, int dout_channel_offset,
+                                int channel_groups, int range_strata, const float* gamma, const float* beta, float eps, int act,
+                                float* dx, int dx_pixel_stride, int dx_channel_offset, float* dgamma, float* dbeta, float* dmul,
+                                float* dadd, int accumulate, const float* mean_rstd, void* workspace, size_t workspace_bytes,
+                                pn_stream_t stream) {
   PN_REQUIRE(x && dout && dx && workspace, "groupnorm_bwd: null pointer");
   PN_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && c >= 1, "groupnorm_bwd: bad sizes");
   PN_REQUIRE(c % 4 == 0 && c <= kThreads && (4 * kThreads) % c == 0, "groupnorm_bwd: channel count must be a multiple of 4 dividing 1024, at most 256");
@@ -860,7 +879,7 @@ int pn_groupnorm_strat_bwd(const float* x, const float* dout, const float* dout2
   f.gamma = gamma; f.beta = beta; f.eps = eps; f.act = act; f.mul = mul;
   f.part = static_cast<double*>(workspace);
   const size_t ngroups = (size_t)batch * range_strata * channel_groups;
-  f.stat = reinterpret_cast<float*>(f.part + ngroups * 256 * 2);
+  f.stat = mean_rstd ? const_cast<float*>(mean_rstd) : reinterpret_cast<float*>(f.part + ngroups * 256 * 2);
   char* p = static_cast<char*>(workspace) + pn_groupnorm_workspace_bytes(batch, channel_groups, range_strata);
   a.part2 = reinterpret_cast<double*>(p);
   a.chan = reinterpret_cast<double*>(p + (size_t)batch * range_strata * 256 * c * 2 * sizeof(double));
@@ -870,8 +889,10 @@ int pn_groupnorm_strat_bwd(const float* x, const float* dout, const float* dout2
   a.dgamma = dgamma; a.dbeta = dbeta; a.dmul = dmul; a.dadd = dadd; a.accumulate = accumulate;
   hipStream_t st = pn::S(stream);
   dim3 grid(f.splits, range_strata, batch);
-  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(kThreads), 0, st, f);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ngroups), dim3(64), 0, st, f);
+  if (!mean_rstd) {   // the forward's statistics were not kept: two more passes
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(kThreads), 0, st, f);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ngroups), dim3(64), 0, st, f);
+  }
   hipLaunchKernelGGL(gn_bwd_partial_kernel, grid, dim3(kThreads), 0, st, a);
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(range_strata, batch), dim3(kThreads), (size_t)kThreads * 2 * sizeof(double), st, a);
   if (dgamma || dbeta)

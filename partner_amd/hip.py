@@ -126,6 +126,9 @@ SIGNATURES = {
     "pn_groupnorm_bwd_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "pn_groupnorm_strat_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _I, _P, _P, _P, _P, _I,
                                     _P, _SZ, _P]),
+    "pn_groupnorm_strat_bwd_stat": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _I, _P, _P, _P, _P, _I,
+                                         _P, _P, _SZ, _P]),
+    "pn_groupnorm_strat_fwd_stat": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "pn_batchnorm_workspace_bytes": (_SZ, [_I]),
     "pn_batchnorm_train_fwd": (_I, [_P, C.c_longlong, _I, _I, _I, _P, _P, _F, _F, _I, _P, _P, _P, _I, _I, _P, _P, _SZ, _P]),
     "pn_batchnorm_bwd": (_I, [_P, _P, C.c_longlong, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _P, _SZ, _P]),

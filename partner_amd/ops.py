@@ -1013,9 +1013,10 @@ def fold_bn(gamma, beta, mean, var, eps: float, conv_bias=None):
 # ------------------------------------------------------------------------------ norms
 def groupnorm_strat(x: torch.Tensor, channel_groups: int, range_strata: int, gamma: torch.Tensor, beta: torch.Tensor,
                     eps=1e-5, act=ACT_NONE, out: Optional[torch.Tensor] = None, mul: Optional[torch.Tensor] = None,
-                    add: Optional[torch.Tensor] = None):
+                    add: Optional[torch.Tensor] = None, stat_out: Optional[torch.Tensor] = None):
     """x NHWC (B,H,W,C).  gamma/beta have range_strata*C entries in stacked order [stratum][channel].
-    Returns out, or (out, out*mul+add) when mul/add ((H,W,C) maps) are given."""
+    Returns out, or (out, out*mul+add) when mul/add ((H,W,C) maps) are given.  ``stat_out`` (B * strata * groups * 2 floats): keeps the
+    (mean, rstd) pairs for ``groupnorm_strat_bwd(..., stat=)``."""
     hip.require_device(x)
     lib = hip.load()
     assert x.is_contiguous()
@@ -1025,8 +1026,9 @@ def groupnorm_strat(x: torch.Tensor, channel_groups: int, range_strata: int, gam
     out2 = torch.empty_like(x) if mul is not None else None
     ws_bytes = lib.pn_groupnorm_workspace_bytes(b, channel_groups, range_strata)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-    hip.call("pn_groupnorm_strat_fwd", x.data_ptr(), b, h, w, c, c, 0, channel_groups, range_strata, hip.ptr(gamma),
-             hip.ptr(beta), float(eps), int(act), out.data_ptr(), c, 0, hip.ptr(mul), hip.ptr(add), hip.ptr(out2),
+    assert stat_out is None or (stat_out.numel() >= 2 * b * range_strata * channel_groups and stat_out.dtype == torch.float32)
+    hip.call("pn_groupnorm_strat_fwd_stat", x.data_ptr(), b, h, w, c, c, 0, channel_groups, range_strata, hip.ptr(gamma),
+             hip.ptr(beta), float(eps), int(act), out.data_ptr(), c, 0, hip.ptr(mul), hip.ptr(add), hip.ptr(out2), hip.ptr(stat_out),
              ws.data_ptr(), ws_bytes, hip.stream())
     return out if out2 is None else (out, out2)
 
@@ -1251,12 +1253,16 @@ class SideStream:
         if value is None:
             self.on = False
 
-    def run(self, fn, *reads):
+    def run(self, fn, *reads, after=None):
+        """``after``: an event of the main stream the launches wait for instead of everything queued on it so far"""
         side = self.stream
         if side is None:
             fn()
             return
-        side.wait_stream(torch.cuda.current_stream())
+        if after is not None:
+            side.wait_event(after)
+        else:
+            side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             fn()
         # the buffers the side stream reads stay referenced until the join: freed earlier, the caching allocator would hand them to the
@@ -1519,8 +1525,9 @@ def batchnorm_bwd(x: torch.Tensor, dout: torch.Tensor, gamma: torch.Tensor, beta
 def groupnorm_strat_bwd(x: torch.Tensor, dout: torch.Tensor, channel_groups: int, range_strata: int, gamma: torch.Tensor,
                         beta: torch.Tensor, eps=1e-5, act=ACT_NONE, dout2: Optional[torch.Tensor] = None,
                         mul: Optional[torch.Tensor] = None, dx: Optional[torch.Tensor] = None, dgamma=None, dbeta=None,
-                        dmul=None, dadd=None, accumulate=False):
-    """backward of groupnorm_strat -> (dx, dgamma, dbeta[, dmul, dadd]); dx may be dout"""
+                        dmul=None, dadd=None, accumulate=False, stat: Optional[torch.Tensor] = None):
+    """backward of groupnorm_strat -> (dx, dgamma, dbeta[, dmul, dadd]); dx may be dout.  ``stat``: the forward's ``stat_out`` (else the
+    statistics are recomputed from x)"""
     hip.require_device(x, dout)
     lib = hip.load()
     assert x.is_contiguous() and dout.is_contiguous()
@@ -1540,9 +1547,9 @@ def groupnorm_strat_bwd(x: torch.Tensor, dout: torch.Tensor, channel_groups: int
             dadd = torch.empty((h, w, c), dtype=torch.float32, device=dev)
     nbytes = lib.pn_groupnorm_bwd_workspace_bytes(b, c, channel_groups, range_strata)
     ws = _workspace(nbytes, dev)
-    hip.call("pn_groupnorm_strat_bwd", x.data_ptr(), dout.data_ptr(), hip.ptr(dout2), hip.ptr(mul), b, h, w, c, c, 0, dout.shape[-1], 0,
+    hip.call("pn_groupnorm_strat_bwd_stat", x.data_ptr(), dout.data_ptr(), hip.ptr(dout2), hip.ptr(mul), b, h, w, c, c, 0, dout.shape[-1], 0,
              channel_groups, range_strata, hip.ptr(gamma), hip.ptr(beta), float(eps), int(act), dx.data_ptr(), dx.shape[-1], 0,
-             dgamma.data_ptr(), dbeta.data_ptr(), hip.ptr(dmul), hip.ptr(dadd), int(accumulate), ws.data_ptr(), nbytes, hip.stream())
+             dgamma.data_ptr(), dbeta.data_ptr(), hip.ptr(dmul), hip.ptr(dadd), int(accumulate), hip.ptr(stat), ws.data_ptr(), nbytes, hip.stream())
     if dout2 is not None:
         return dx, dgamma, dbeta, dmul, dadd
     return dx, dgamma, dbeta

@@ -306,13 +306,14 @@ class _ConvGNReLU:
             self.layer.repack(self.ps.p[self.wname], self.ps.p[self.bname])
             self.y = self.layer(x)
         self.mul = mul
+        self.stat = torch.empty(2 * self.y.shape[0] * self.strata * self.cgroups, dtype=torch.float32, device=self.y.device)
         return ops.groupnorm_strat(self.y, self.cgroups, self.strata, self.ps.p[self.gname], self.ps.p[self.bename], self.eps,
-                                   act=RELU, mul=mul, add=add)
+                                   act=RELU, mul=mul, add=add, stat_out=self.stat)
 
     def bwd(self, dout, dout2=None, dx=None, accumulate=False, need_dx=True):
         res = ops.groupnorm_strat_bwd(self.y, dout, self.cgroups, self.strata, self.ps.p[self.gname], self.ps.p[self.bename], self.eps,
                                       RELU, dout2=dout2, mul=self.mul if dout2 is not None else None, dx=dout,
-                                      dgamma=self.ps.g[self.gname], dbeta=self.ps.g[self.bename])
+                                      dgamma=self.ps.g[self.gname], dbeta=self.ps.g[self.bename], stat=self.stat)
         dy = res[0]
         extra = res[3:] if dout2 is not None else ()
         if self.groups == 1:
@@ -364,11 +365,13 @@ class _StratConvGNReLU:
         self.x = x
         self.layer.repack(self.ps.p[self.wname], self.ps.p[self.bname], token=self.ps.fresh)
         self.y = self.layer(x)
-        return ops.groupnorm_strat(self.y, self.nheads, self.strata, self.ps.p[self.gname], self.ps.p[self.bename], self.eps, act=RELU)
+        self.stat = torch.empty(2 * self.y.shape[0] * self.strata * self.nheads, dtype=torch.float32, device=self.y.device)
+        return ops.groupnorm_strat(self.y, self.nheads, self.strata, self.ps.p[self.gname], self.ps.p[self.bename], self.eps, act=RELU,
+                                   stat_out=self.stat)
 
     def bwd(self, dout, dx, accumulate):
         dy, _, _ = ops.groupnorm_strat_bwd(self.y, dout, self.nheads, self.strata, self.ps.p[self.gname], self.ps.p[self.bename], self.eps,
-                                           RELU, dx=dout, dgamma=self.ps.g[self.gname], dbeta=self.ps.g[self.bename])
+                                           RELU, dx=dout, dgamma=self.ps.g[self.gname], dbeta=self.ps.g[self.bename], stat=self.stat)
         w = self.ps.p[self.wname]
         if self.masked:
             def weight_grads():
@@ -524,6 +527,7 @@ class PolarPillarTrainStep:
             hip.call("pn_fill_zero", canvas.data_ptr(), canvas.numel() * 4, hip.stream())
         r = self.reader
         ops.dynamic_pfn(points, self.vi, ps.p[self.w0], ps.p[self.w1], r.vx, r.vy, r.x_offset, r.y_offset, None, canvas)
+        self._prepack()     # issued behind the scatter stage's launches, runs beside them
         x = canvas
         out, off = None, 0
         self.block_out = []
@@ -691,7 +695,8 @@ class PolarPillarTrainStep:
         layouts, the data-gradient layouts.  A layout is refreshed here once a call has taken it (the first iteration packs lazily as
         before); ``ps.fresh`` is the iteration's token, the wrappers' own repack calls see it and do nothing."""
         ps = self.ps
-        side = ps.side.stream if _TRAIN_PREPACK else None
+        side = ps.side.stream if _TRAIN_PREPACK and getattr(self, "_prepack_armed", False) else None   # armed by forward_backward only
+        self._prepack_armed = False
         self._pack_events = None
         if side is None:
             ps.fresh = None
@@ -711,7 +716,7 @@ class PolarPillarTrainStep:
                 c.prepack_bwd(tok)
             self._pack_ev[2].record()
 
-        ps.side.run(packs)
+        ps.side.run(packs, after=self._iter_start)
         self._pack_events = self._pack_ev
 
     def _packs_ready(self, k: int) -> None:
@@ -720,7 +725,11 @@ class PolarPillarTrainStep:
 
     def forward_backward(self, points, sample_offsets, batch, targets: ops.CenterLossTargets, grid_ind=None, grad_scale=1.0):
         """forward + loss + backward; gradients land in ``self.ps.flat_g`` (overwritten, not accumulated)"""
-        self._prepack()
+        if getattr(self, "_iter_start", None) is None and self.dev.type == "cuda":
+            self._iter_start = torch.cuda.Event()
+        if getattr(self, "_iter_start", None) is not None:
+            self._iter_start.record()     # the previous iteration's optimizer step is queued before it: the packs wait for this, not for the PFN
+            self._prepack_armed = True
         try:
             preds = self._forward(points, sample_offsets, batch, grid_ind)
             order, boxes = self._loss_sources()
