@@ -91,6 +91,12 @@ def test_channel_sum(dev):
     assert float((s.cpu().double() - ref).abs().max()) < 2e-3
     s2 = ops.channel_sum(x.to(dev), c=40, channel_offset=8, out=s.clone(), accumulate=True)
     assert float((s2.cpu().double() - 2 * ref).abs().max()) < 4e-3
+    # both partial kernels: channel counts / offsets that are not multiples of 4 take the scalar one; few and many pixels; 16 .. 1024 channels
+    for (pixels, ct, c, co) in [(150001, 16, 16, 0), (5, 64, 64, 0), (4097, 264, 256, 8), (333, 1024, 1024, 0), (777, 10, 3, 5), (2049, 64, 62, 1), (70000, 128, 128, 0)]:
+        y = torch.from_numpy(rng.standard_normal((pixels, ct)).astype(np.float32))
+        got = ops.channel_sum(y.to(dev).view(1, pixels, 1, ct), c=c, channel_offset=co)
+        ref = y[:, co:co + c].double().sum(0)
+        assert float((got.cpu().double() - ref).abs().max()) < 1e-4 * max(1.0, pixels ** 0.5), (pixels, ct, c, co)
 
 
 STRAT_CASES = [(2, 12, 32, 64, 64, 8), (4, 128, 128, 64, 64, 8), (1, 9, 24, 32, 48, 4), (3, 7, 16, 64, 20, 2)]
