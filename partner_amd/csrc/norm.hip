@@ -444,13 +444,14 @@ __global__ __launch_bounds__(kThreads) void bn_partial_kernel(BnArgs a) {
     }
   }
   if (threadIdx.x < vpc * ppb) {
-    for (long long p = p0 + pl; p < p1; p += ppb) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + p * a.ps + a.co + cv * 4);
+    // four pixels per trip, their loads issued before the first is used: beside the F(4,3) weight gradient of the side stream (178 VGPRs,
+    // eight waves per CU) a CU has room for one or two of these waves per SIMD, and with one 16-byte load in flight per lane the pass
+    // ran at a third of its speed.  The sums keep their order (p, p + ppb, ...): same bits as the one-pixel loop.
+    auto accum = [&](const f32x4& v, const f32x4& d) {
       if (MODE == 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { s0[k] += v[k]; s1[k] += (double)v[k] * v[k]; }
       } else {
-        const f32x4 d = *reinterpret_cast<const f32x4*>(a.dout + p * a.dps + a.dco + cv * 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float xh = (v[k] - mean[k]) * rstd[k];
@@ -459,6 +460,26 @@ __global__ __launch_bounds__(kThreads) void bn_partial_kernel(BnArgs a) {
           s0[k] += g; s1[k] += (double)g * xh;
         }
       }
+    };
+    const float* xb = a.x + a.co + cv * 4;
+    const float* db = MODE == 1 ? a.dout + a.dco + cv * 4 : nullptr;
+    long long p = p0 + pl;
+    for (; p + 3 * ppb < p1; p += 4 * ppb) {
+      f32x4 v[4], d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(xb + (p + u * ppb) * a.ps);
+      if (MODE == 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = *reinterpret_cast<const f32x4*>(db + (p + u * ppb) * a.dps);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accum(v[u], d[u]);
+    }
+    for (; p < p1; p += ppb) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xb + p * a.ps);
+      f32x4 d = v;
+      if (MODE == 1) d = *reinterpret_cast<const f32x4*>(db + p * a.dps);
+      accum(v, d);
     }
   }
   if (threadIdx.x < vpc * ppb) {
@@ -538,20 +559,13 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(BnArgs a) {
     }
   };
   if (i < total) load_consts(cv);
-  for (; i < total; i += stride) {
-    if (!fixed) {
-      p = i / vpc;
-      cv = (int)(i - p * vpc);
-      load_consts(cv);
-    }
-    const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + p * a.ps + a.co + cv * 4);
+  auto one = [&](const f32x4& v, const f32x4& d, long long pp) {
     f32x4 o;
     if (MODE == 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = pn::apply_act((v[k] - mean[k]) * rstd[k] * ga[k] + be[k], a.act);
-      *reinterpret_cast<f32x4*>(a.out + p * a.ops + a.oco + cv * 4) = o;
+      *reinterpret_cast<f32x4*>(a.out + pp * a.ops + a.oco + cv * 4) = o;
     } else {
-      const f32x4 d = *reinterpret_cast<const f32x4*>(a.dout + p * a.dps + a.dco + cv * 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float xh = (v[k] - mean[k]) * rstd[k];
@@ -559,8 +573,34 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(BnArgs a) {
         const float g = (a.act == PN_ACT_RELU && !(y > 0.f)) ? 0.f : d[k];
         o[k] = ga[k] * rstd[k] * (g - c0[k] - xh * c1[k]);
       }
-      *reinterpret_cast<f32x4*>(a.dx + p * a.xps + a.xco + cv * 4) = o;
+      *reinterpret_cast<f32x4*>(a.dx + pp * a.xps + a.xco + cv * 4) = o;
     }
+  };
+  if (fixed) {
+    // four elements per trip with their loads in flight together (see bn_partial_kernel)
+    for (; i + 3 * stride < total; i += 4 * stride) {
+      f32x4 v[4], d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(a.x + (p + u * pstep) * a.ps + a.co + cv * 4);
+      if (MODE == 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = *reinterpret_cast<const f32x4*>(a.dout + (p + u * pstep) * a.dps + a.dco + cv * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(v[u], d[u], p + u * pstep);
+      p += 4 * pstep;
+    }
+  }
+  for (; i < total; i += stride) {
+    if (!fixed) {
+      p = i / vpc;
+      cv = (int)(i - p * vpc);
+      load_consts(cv);
+    }
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + p * a.ps + a.co + cv * 4);
+    f32x4 d = v;
+    if (MODE == 1) d = *reinterpret_cast<const f32x4*>(a.dout + p * a.dps + a.dco + cv * 4);
+    one(v, d, p);
     p += pstep;
   }
 }
