@@ -668,7 +668,9 @@ def main():
     # (hipExtLaunchKernelGGL start/stop events = the kernel's own execution time; events cannot ride inside a replayed graph)
     roofline = None
     if not args.no_roofline_events:
-        for i in range(2):
+        # (eager launches keep the GPU a third busy: after two warm-up frames the first timed ones still ran at the clocks of an idle
+        # device and the dominant kernel's fraction moved between 0.63 and 0.67 from run to run; 30 frames = 60 ms settle it)
+        for i in range(30):
             step_eager(i)
         prof = ops.enable_conv_profiling()
         barrier()

@@ -93,6 +93,7 @@ struct ConvArgs {
   int ni_S, ni_C;
   int st_segs_z;         // 32-row segments per z (rounded up to whole tiles)
   int zdim;              // multi-job launches: number of z slices of this job
+  int snt2;              // conv_small_n_multi_kernel: this job's blocks are 8 x 16 pixel tiles, two pixels per lane (small_n_tiled2_body)
 };
 
 constexpr int BK = 32;
@@ -1252,6 +1253,7 @@ __device__ __forceinline__ void small_n_tiled_body(const ConvArgs& a, const int 
       }
     }
   }
+  __syncthreads();   // (the partial sums share the tiles' LDS: every wave is done reading)
 #pragma unroll
   for (int n = 0; n < NOUT; ++n) part[q][lane][n] = acc[n];
   __syncthreads();
@@ -1265,15 +1267,123 @@ __device__ __forceinline__ void small_n_tiled_body(const ConvArgs& a, const int 
   }
 }
 
-__device__ __forceinline__ bool small_n_tiled_ok(const ConvArgs& a) {
+// r4: the same tile form with TWO pixels per lane -- an 8 x 16 tile, lane (r, c) owns rows r and r + 4.  The nine-tap loop of the form above
+// issues one broadcast ds_read_b128 of weights per FOUR v_fma; the block's four waves share one LDS pipe (8 cycles per 64-lane b128 read),
+// so the loop ran at the LDS's pace, not the VALU's (a build without the weight reads: 28 -> 15 us for the five branches).  With two pixels
+// a weight read feeds eight v_fma.  The halo tile is 10 x 18 pixels x 16 channels per wave; instead of padding a pixel to 20 floats its four
+// 16-byte slots are rotated by (pixel / 4) mod 4 -- 16 consecutive pixels x one slot then hit 16 different slot columns, conflict-free like
+// the padded layout -- so four waves' tiles + the weights stay under 80 KB (two blocks per CU).  The partial sums reuse the tile's LDS.
+// Same order of additions per output as the one-pixel form: same bits.
+constexpr int SN2_H = 8, SN2_PX = (SN2_H + 2) * SNT_HW;
+__device__ __forceinline__ int sn2_slot(int px, int cc) { return 4 * px + ((cc + (px >> 2)) & 3); }
+template <int NOUT>
+__device__ __forceinline__ void small_n_tiled2_body(const ConvArgs& a, const int tile, float* w_lds, float* xt_all) {
+  const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tx_n = a.OW / SNT_W, ty_n = a.OH / SN2_H;
+  const int b = tile / (tx_n * ty_n), tr = tile - b * (tx_n * ty_n), ty = tr / tx_n, tx = tr - ty * tx_n;
+  const int oh0 = ty * SN2_H, ow0 = tx * SNT_W;
+  const int cq = ((a.Cin + 15) / 16) * 4;                 // channels per wave: whole quads, at most 16 (Cin <= 64)
+  const int c0 = q * cq, c1 = min(a.Cin, c0 + cq);
+  float* xt = xt_all + q * (SN2_PX * 16);
+  constexpr int XI = (SN2_PX * 4 + 63) / 64;      // tile items per lane: (halo pixel, channel quad of the wave's 16); the quad is lane & 3 for all
+  f32x4 xv[XI];
+  bool xin[XI];
+  const int cc_l = lane & 3, c_l = c0 + 4 * cc_l, ccl = min(c_l, a.Cin - 4);
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int px = min((lane + 64 * i) >> 2, SN2_PX - 1);
+    const int hr = px / SNT_HW, hc = px - hr * SNT_HW;
+    const int ih = oh0 - 1 + hr, iw = ow0 - 1 + hc;
+    xin[i] = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W && c_l < c1;
+    const int ihc = min(max(ih, 0), a.H - 1), iwc = min(max(iw, 0), a.W - 1);
+    xv[i] = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.H + ihc) * a.W + iwc) * a.in_ps + a.in_co + ccl);
+  }
+  f32x4 t0 = {1.f, 0.f, 1.f, 0.f}, t1 = {1.f, 0.f, 1.f, 0.f};
+  if (a.ni_ab) {      // the producing norm's (A, B) pairs of the lane's four channels
+    const float* tab = a.ni_ab + ((size_t)b * a.ni_C + ccl) * 2;
+    t0 = *reinterpret_cast<const f32x4*>(tab);
+    t1 = *reinterpret_cast<const f32x4*>(tab + 4);
+  }
+  {  // the job's weights: packed global [tap][cin_pad/4][cout_pad][4] -> LDS [tap][16 quads][NOUT][4]
+    const int quads = a.cin_chunks * 8;
+    constexpr int WI = (9 * 16 * NOUT + 255) / 256;
+    f32x4 wv[WI];
+#pragma unroll
+    for (int k = 0; k < WI; ++k) {
+      const int i = min((int)threadIdx.x + 256 * k, 9 * 16 * NOUT - 1);
+      const int n = i % NOUT, qd = (i / NOUT) % 16, t = i / (NOUT * 16);
+      const bool ok = qd < quads && n < a.cout_pad;
+      wv[k] = *reinterpret_cast<const f32x4*>(a.w + (((size_t)t * quads + min(qd, quads - 1)) * a.cout_pad + min(n, a.cout_pad - 1)) * 4);
+      if (!ok) wv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < WI; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < 9 * 16 * NOUT) *reinterpret_cast<f32x4*>(w_lds + (size_t)i * 4) = wv[k];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int idx = lane + 64 * i;
+    f32x4 v = xv[i];
+    if (a.ni_ab) {
+      v[0] = fmaxf(fmaf(v[0], t0[0], t0[1]), 0.f);
+      v[1] = fmaxf(fmaf(v[1], t0[2], t0[3]), 0.f);
+      v[2] = fmaxf(fmaf(v[2], t1[0], t1[1]), 0.f);
+      v[3] = fmaxf(fmaf(v[3], t1[2], t1[3]), 0.f);
+    }
+    if (!xin[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (idx < SN2_PX * 4) *reinterpret_cast<f32x4*>(xt + sn2_slot(idx >> 2, cc_l) * 4) = v;
+  }
+  float acc0[NOUT], acc1[NOUT];
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) acc0[n] = acc1[n] = 0.f;
+  __syncthreads();   // the staged weights and tiles are complete
+  const int r = lane >> 4, cl = lane & 15;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int kh = t / 3, kw = t - kh * 3;
+    const int p0 = (r + kh) * SNT_HW + cl + kw, p1 = p0 + 4 * SNT_HW;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      if (c0 + 4 * cc < c1) {                                                   // wave-uniform
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xt + sn2_slot(p0, cc) * 4);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(xt + sn2_slot(p1, cc) * 4);
+        const float* wp = w_lds + ((t * 16 + (c0 >> 2) + cc) * NOUT) * 4;
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {   // columns past Cout are zero in the packed weights
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + n * 4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { acc0[n] = fmaf(x0[k], wv[k], acc0[n]); acc1[n] = fmaf(x1[k], wv[k], acc1[n]); }
+        }
+      }
+    }
+  }
+  __syncthreads();   // every wave is done with its tile: the partial sums go into the same LDS
+  float (*part)[128][13] = reinterpret_cast<float (*)[128][13]>(xt_all);
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) { part[q][lane][n] = acc0[n]; part[q][64 + lane][n] = acc1[n]; }
+  __syncthreads();
+  // thread (pixel p = tid & 127: rows 0 .. 3 then 4 .. 7, output group g = tid >> 7): outputs n = g, g + 2, ...
+  const int p = threadIdx.x & 127, g = threadIdx.x >> 7;
+  const size_t mo = ((size_t)(b * a.OH + oh0 + ((p & 63) >> 4) + 4 * (p >> 6)) * a.OW + ow0 + (p & 15));
+  for (int n = g; n < a.Cout; n += 2) {
+    const float v = (part[0][p][n] + part[1][p][n]) + (part[2][p][n] + part[3][p][n]);
+    const float sc = a.scale ? a.scale[n] : 1.f, sh = a.shift ? a.shift[n] : 0.f;
+    a.out[mo * a.out_ps + a.out_co + n] = pn::apply_act(fmaf(v, sc, sh), a.act);
+  }
+}
+
+__host__ __device__ __forceinline__ bool small_n_tiled_ok(const ConvArgs& a) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_h == 1 && a.pad_w == 1 && a.OW % SNT_W == 0 && a.OH % SNT_H == 0 && a.OH == a.H && a.OW == a.W &&
          (a.ni_ab == nullptr || a.ni_S == 1) && (a.in_ps % 4) == 0 && (a.in_co % 4) == 0;
 }
 
 __global__ __launch_bounds__(256) void conv_small_n_multi_kernel(MultiArgs m_by_value) {
-  __shared__ float part[4][64][13];
   __shared__ __attribute__((aligned(16))) float w_lds[9 * 16 * 12 * 4];
-  __shared__ __attribute__((aligned(16))) float xt_lds[4 * SNT_PX * SNT_LD];
+  constexpr int kXt = 4 * SNT_PX * SNT_LD > 4 * SN2_PX * 16 ? 4 * SNT_PX * SNT_LD : 4 * SN2_PX * 16;
+  __shared__ __attribute__((aligned(16))) float xt_lds[kXt];
+  float (*part)[64][13] = reinterpret_cast<float (*)[64][13]>(xt_lds);    // the partial sums reuse the tile's LDS (tiles + weights < 80 KB: two blocks per CU)
   typedef const __attribute__((address_space(4))) int* kptr_t;
   const kptr_t base = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   const int njobs = base[offsetof(MultiArgs, njobs) / 4];
@@ -1293,6 +1403,10 @@ __global__ __launch_bounds__(256) void conv_small_n_multi_kernel(MultiArgs m_by_
   if (taps == 1) {
     if (a.ncols <= 4) small_n_body<4, 1>(a, local, part, w_lds);
     else small_n_body<12, 1>(a, local, part, w_lds);
+  } else if (a.snt2) {
+    if (a.ncols <= 4) small_n_tiled2_body<4>(a, local, w_lds, xt_lds);
+    else if (a.ncols <= 8) small_n_tiled2_body<8>(a, local, w_lds, xt_lds);
+    else small_n_tiled2_body<12>(a, local, w_lds, xt_lds);
   } else if (small_n_tiled_ok(a)) {
     if (a.ncols <= 4) small_n_tiled_body<4>(a, local, part, w_lds, xt_lds);
     else if (a.ncols <= 8) small_n_tiled_body<8>(a, local, part, w_lds, xt_lds);
@@ -1883,7 +1997,9 @@ int pn_conv2d_small_n_multi_f32(const pn_conv_job* jobs, int njobs, pn_stream_t 
     PN_REQUIRE(!a.ni_ab || a.ni_S == 1 || taps == 1, "conv_small_n_multi: a range-stratified norm table needs a 1x1 kernel");
     PN_REQUIRE(!a.ni_ab || a.ni_S > 1 || a.B == 1 || (a.OH * a.OW) % 64 == 0, "conv_small_n_multi: with batch > 1 a sample must be a whole number of 64-pixel tiles");
     m.first[j] = total;
-    total += pn::cdiv(a.M, 64);
+    static const int two = [] { const char* e = getenv("PN_SMALL_N_TWO"); return e ? atoi(e) : 1; }();
+    a.snt2 = two && taps == 9 && small_n_tiled_ok(a) && a.OH % SN2_H == 0 && a.Cin % 4 == 0;
+    total += a.snt2 ? a.M / 128 : pn::cdiv(a.M, 64);
   }
   m.first[njobs] = total;
   m.total = total;
