@@ -737,13 +737,28 @@ __global__ __launch_bounds__(256) void pfn_bwd_reduce_kernel(const float* __rest
   const int o = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
   float t = 0.f;
   if (o < w1_floats + c0 * 16) {
+    // eight slabs per trip, their loads in flight together, eight running sums joined in a fixed order (r4: one dependent load per trip
+    // made the 38 MB of slabs a 124 us launch at the very end of the iteration, where nothing overlaps it)
+    auto sum_pass = [&](int ps, int local) {
+      const float* base = slabs + (size_t)ps * nwaves * slab + local;
+      float u[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int w = part;
+      for (; w + 28 < nwaves; w += 32) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = base[(size_t)(w + 4 * j) * slab];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] += v[j];
+      }
+      for (int j = 0; w < nwaves; w += 4, ++j) u[j & 7] += base[(size_t)w * slab];
+      return ((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]));
+    };
     if (o < w1_floats) {
       const int row = o / k1, pass = row >> 6, local = (row & 63) * k1 + (o - row * k1);
-      for (int w = part; w < nwaves; w += 4) t += slabs[((size_t)pass * nwaves + w) * slab + local];
+      t = sum_pass(pass, local);
     } else {
       const int local = 64 * k1 + (o - w1_floats);
-      for (int ps = 0; ps < passes; ++ps)
-        for (int w = part; w < nwaves; w += 4) t += slabs[((size_t)ps * nwaves + w) * slab + local];
+      for (int ps = 0; ps < passes; ++ps) t += sum_pass(ps, local);
     }
   }
   red[part][threadIdx.x & 63] = t;
