@@ -514,7 +514,7 @@ constexpr int kBwdPts = 4;     // points per pillar staged in LDS (pillars with 
 template <int C0, int C1>
 __global__ __launch_bounds__(256) void dynamic_pfn_bwd_kernel(PfnArgs a, const float* __restrict__ cs_table,
                                                               const float* __restrict__ dfeat, const float* __restrict__ dcanvas,
-                                                              float* __restrict__ slabs) {
+                                                              float* __restrict__ slabs, int slab_waves, int skip_single) {
   constexpr int K1 = 2 * C0;             // row length of W1
   constexpr int SLAB = 64 * K1 + C0 * 16;
   constexpr int NB = kBwdBatch, KP = kBwdPts;
@@ -528,7 +528,6 @@ __global__ __launch_bounds__(256) void dynamic_pfn_bwd_kernel(PfnArgs a, const f
   __shared__ float d_l[NB][64];
   const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
   const int wave = blockIdx.x * 4 + wib;
-  const int nwaves = gridDim.x * 4;
   const int row0 = blockIdx.y * 64, row = row0 + lane;
   const bool la = row < C1;
   const int V = min(*a.v_dev, a.v_cap);
@@ -582,6 +581,7 @@ __global__ __launch_bounds__(256) void dynamic_pfn_bwd_kernel(PfnArgs a, const f
 
     for (int q = wib; q < NB && v0 + q < V; q += 4) {
       const int s = m_s[q], e = m_e[q], n = e - s;
+      if (skip_single && n == 1) continue;      // pfn_bwd_single_kernel takes the one-point pillars
       uint32_t key = m_key[q];
       const int ri = key % a.R; key /= a.R;
       const int ti = key % a.T;
@@ -719,12 +719,170 @@ __global__ __launch_bounds__(256) void dynamic_pfn_bwd_kernel(PfnArgs a, const f
       }
     }
   }
-  float* slab = slabs + ((size_t)blockIdx.y * nwaves + wave) * SLAB;
+  float* slab = slabs + ((size_t)blockIdx.y * slab_waves + wave) * SLAB;
 #pragma unroll
   for (int k = 0; k < K1; ++k) slab[lane * K1 + k] = dw1[k];
   if (lane < C0) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) slab[64 * K1 + lane * 16 + k] = dw0[k];
+  }
+}
+
+// ---- r4: the ONE-POINT pillars of the (32, 128) reader on the matrix cores ----------------------------------------------------------
+// On the reference's 0.098 m x 0.0123 rad grid a 30k-point sweep fills 28k pillars: 93 % of them hold a single point, and the kernel
+// above spends a wave, two 31-step cross-lane reduce-scatters and ~4 us on each (497 us for the 113 k pillars of a batch of 4, alone at
+// the end of the iteration).  With one point the maxima are the point itself (m0 = h, argmax = the point wherever h > 0 / y > 0), so a
+// tile of 32 such pillars is five small GEMMs on v_mfma_f32_32x32x2_f32 (p = pillar, c = layer-0 channel, row = layer-1 row):
+//   H  [p][c]   = relu(D [p][16] W0^T)                         D = the decorated point (same arithmetic as the kernel above)
+//   Y  [p][row] = H Wsum^T,  Wsum[row][c] = W1[row][c] + W1[row][32 + c]   (the point and the pillar maximum are the same vector)
+//   DA [p][row] = Y > 0 ? dY[p][row] : 0
+//   dW1[row][c] += DA^T H      (both halves of W1's row receive it)         dH[p][c] = DA Wsum,  DY0 = H > 0 ? dH : 0
+//   dW0[c][k]  += DY0^T D
+// One wave per tile, operands re-laid through the wave's own LDS strip (H, DA, DY0, D), Wsum staged once per block; the four waves of a block
+// join their accumulators in a fixed order and write ONE slab pair in the layout of the kernel above, pfn_bwd_reduce_kernel adds them
+// all.  Pillars with another point count are zero rows of a tile (dynamic_pfn_bwd_kernel skips the one-point ones in turn).
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int kS1H = 33, kS1DA = 129, kS1D = 17;
+constexpr int kS1WaveFloats = 32 * kS1H + 32 * kS1DA + 32 * kS1H + 32 * kS1D + 64;   // H, DA, DY0, D, 32 row offsets (64-bit)
+constexpr int kS1WsFloats = 128 * kS1H;
+constexpr size_t kS1Smem = (size_t)(kS1WsFloats + 4 * kS1WaveFloats) * sizeof(float);
+
+__global__ __launch_bounds__(256) void pfn_bwd_single_kernel(PfnArgs a, const float* __restrict__ cs_table, const float* __restrict__ dfeat,
+                                                             const float* __restrict__ dcanvas, float* __restrict__ slabs, int slab_waves, int wave_base) {
+  constexpr int C0 = 32, C1 = 128, K1 = 64, SLAB = 64 * K1 + C0 * 16;
+  extern __shared__ __attribute__((aligned(16))) float s1_lds[];
+  float* Ws = s1_lds;
+  const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6, li = lane & 31, lh = lane >> 5;
+  float* Hs = s1_lds + kS1WsFloats + wib * kS1WaveFloats;
+  float* DAs = Hs + 32 * kS1H;
+  float* Y0s = DAs + 32 * kS1DA;
+  float* Ds = Y0s + 32 * kS1H;
+  unsigned long long* Offs = reinterpret_cast<unsigned long long*>(Ds + 32 * kS1D);
+  for (int i = tid; i < C1 * C0; i += 256) {
+    const int row = i >> 5, c = i & 31;
+    Ws[row * kS1H + c] = a.w1[row * K1 + c] + a.w1[row * K1 + C0 + c];
+  }
+  float w0r[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) w0r[k] = a.w0[li * 16 + k];
+  __syncthreads();
+  f32x16 dw1acc[4];
+  f32x16 dw0acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dw0acc[r] = 0.f; dw1acc[0][r] = dw1acc[1][r] = dw1acc[2][r] = dw1acc[3][r] = 0.f; }
+  const int V = min(*a.v_dev, a.v_cap);
+  const int ntiles = (V + 31) / 32;
+  const int wave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
+  auto prow = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * lh; };
+  for (int tile = wave; tile < ntiles; tile += nwaves) {
+    const int v = tile * 32 + li;
+    int s = 0, n = 0;
+    uint32_t key = 0;
+    if (v < V) { s = a.vstart[v]; n = a.vstart[v + 1] - s; key = a.ukeys[v]; }
+    const bool one = n == 1;
+    if (__ballot(one) == 0ull) continue;        // wave-uniform: no one-point pillar in the tile
+    float d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = 0.f;
+    uint32_t kk_ = key;
+    const int ri = kk_ % a.R; kk_ /= a.R;
+    const int ti = kk_ % a.T; kk_ /= a.T;
+    const int bi = kk_ / a.Z;
+    if (one) {
+      const float* p = a.pts + (size_t)a.order[s] * a.stride;
+      const float rho = p[0], phi = p[1], z = p[2], x = p[3], y = p[4], p5 = p[5], p6 = p[6];
+      const float rc = __fadd_rn(__fmul_rn((float)ri, a.vx), a.xoff);
+      const float pc = __fadd_rn(__fmul_rn((float)ti, a.vy), a.yoff);
+      const float xc = __fmul_rn(rc, cs_table[2 * ti]), yc = __fmul_rn(rc, cs_table[2 * ti + 1]);
+      const double inv_n = 1.0 / kFix;
+      const float mx = (float)((double)to_fix(x) * inv_n), my = (float)((double)to_fix(y) * inv_n), mz = (float)((double)to_fix(z) * inv_n);
+      const float mr = (float)((double)to_fix(rho) * inv_n), mp = (float)((double)to_fix(phi) * inv_n);
+      const float t[16] = {rho, phi, z, x, y, p5, p6, x - mx, y - my, z - mz, x - xc, y - yc, rho - mr, phi - mp, rho - rc, phi - pc};
+#pragma unroll
+      for (int k = 0; k < 16; ++k) d[k] = t[k];
+    }
+    if (lh == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) Ds[li * kS1D + k] = d[k];
+      Offs[li] = dcanvas ? ((((unsigned long long)bi * a.T + ti) * a.R + ri) * C1) : ((unsigned long long)v * C1);
+    }
+    // H = relu(D W0^T)
+    f32x16 H;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) H[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) H = __builtin_amdgcn_mfma_f32_32x32x2f32(lh ? d[2 * kk + 1] : d[2 * kk], lh ? w0r[2 * kk + 1] : w0r[2 * kk], H, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { H[r] = H[r] > 0.f ? H[r] : 0.f; Hs[prow(r) * kS1H + li] = H[r]; }
+    // Y = H Wsum^T, DA = Y > 0 ? dY : 0
+    float ha[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) ha[kk] = Hs[li * kS1H + 2 * kk + lh];
+    const float* dsrc = dcanvas ? dcanvas : dfeat;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      float g[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pv = tile * 32 + prow(r);
+        g[r] = pv < V ? dsrc[Offs[prow(r)] + 32 * nt + li] : 0.f;
+      }
+      f32x16 Y;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) Y = __builtin_amdgcn_mfma_f32_32x32x2f32(ha[kk], Ws[(32 * nt + li) * kS1H + 2 * kk + lh], Y, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) DAs[prow(r) * kS1DA + 32 * nt + li] = Y[r] > 0.f ? g[r] : 0.f;
+    }
+    // dW1 += DA^T H
+    float hb[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) hb[kk] = Hs[(2 * kk + lh) * kS1H + li];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+        dw1acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(DAs[(2 * kk + lh) * kS1DA + 32 * nt + li], hb[kk], dw1acc[nt], 0, 0, 0);
+    // dH = DA Wsum, DY0 = H > 0 ? dH : 0
+    f32x16 dH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dH[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 64; ++kk) dH = __builtin_amdgcn_mfma_f32_32x32x2f32(DAs[li * kS1DA + 2 * kk + lh], Ws[(2 * kk + lh) * kS1H + li], dH, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Y0s[prow(r) * kS1H + li] = H[r] > 0.f ? dH[r] : 0.f;
+    // dW0 += DY0^T D
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+      dw0acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Y0s[(2 * kk + lh) * kS1H + li], li < 16 ? Ds[(2 * kk + lh) * kS1D + li] : 0.f, dw0acc, 0, 0, 0);
+  }
+  // the block's four waves join (wave order) and write one slab per pass: rows x (h half | m0 half, the same values), then dW0 with pass 0
+  __syncthreads();
+  float* mine = s1_lds + kS1WsFloats + wib * kS1WaveFloats;      // 4096 + 512 floats of the wave's strip
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[(32 * nt + prow(r)) * 32 + li] = dw1acc[nt][r];
+  if (li < 16) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[4096 + prow(r) * 16 + li] = dw0acc[r];
+  }
+  __syncthreads();
+  const float* w0s = s1_lds + kS1WsFloats;
+  const int bslot = wave_base + blockIdx.x;
+  for (int i = tid; i < 4096 + 512; i += 256) {
+    const float t = (w0s[i] + w0s[kS1WaveFloats + i]) + (w0s[2 * kS1WaveFloats + i] + w0s[3 * kS1WaveFloats + i]);
+    if (i < 4096) {
+      const int row = i >> 5, c = i & 31, pass = row >> 6, lrow = row & 63;
+      float* slab = slabs + ((size_t)pass * slab_waves + bslot) * SLAB;
+      slab[lrow * K1 + c] = t;
+      slab[lrow * K1 + C0 + c] = t;
+    } else {
+      const int j = i - 4096;
+      slabs[((size_t)0 * slab_waves + bslot) * SLAB + 64 * K1 + j] = t;
+      slabs[((size_t)1 * slab_waves + bslot) * SLAB + 64 * K1 + j] = 0.f;
+    }
   }
 }
 
@@ -913,8 +1071,10 @@ int pn_scatter_canvas_fwd(const float* features, const int64_t* unq, const int32
 
 constexpr int kPfnBwdBlocks = 256;  // x 2 passes x 4 waves = two waves per SIMD for the (32, 128) reader
 constexpr int kPfnBwdSlabMax = 64 * 64 + 32 * 16;
+constexpr int kPfnBwdSingleBlocks = 256;   // pfn_bwd_single_kernel: one slab pair per block
+static const int kPfnBwdSingle = [] { const char* e = getenv("PN_PFN_BWD_SINGLE"); return e ? atoi(e) : 1; }();
 
-size_t pn_dynamic_pfn_bwd_workspace_bytes(void) { return (size_t)kPfnBwdBlocks * 4 * 2 * kPfnBwdSlabMax * sizeof(float); }
+size_t pn_dynamic_pfn_bwd_workspace_bytes(void) { return (size_t)(kPfnBwdBlocks * 4 + kPfnBwdSingleBlocks) * 2 * kPfnBwdSlabMax * sizeof(float); }
 
 int pn_dynamic_pfn_bwd(const float* points, int point_stride, const int32_t* voxel_start, const int32_t* order,
                        const int32_t* num_voxels, int v_capacity, const uint32_t* unq_keys, const int32_t* grid, const float* w0,
@@ -931,12 +1091,23 @@ int pn_dynamic_pfn_bwd(const float* points, int point_stride, const int32_t* vox
             w0, c0, w1, c1, vx, vy, x_offset, y_offset, nullptr, nullptr};
   float* slabs = static_cast<float*>(workspace);
   const int passes = pn::cdiv(c1, 64);
+  const bool single = c0 == 32 && kPfnBwdSingle;
+  const int slab_waves = kPfnBwdBlocks * 4 + (single ? kPfnBwdSingleBlocks : 0);
+  if (single) {
+    static bool done[64] = {false};
+    if (pn::first_use_on_device(done))
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pfn_bwd_single_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS1Smem);
+    hipLaunchKernelGGL(pfn_bwd_single_kernel, dim3(kPfnBwdSingleBlocks), dim3(256), kS1Smem, pn::S(stream), a, center_table, d_features, d_canvas, slabs, slab_waves,
+                       kPfnBwdBlocks * 4);
+  }
   if (c0 == 32)
-    hipLaunchKernelGGL((dynamic_pfn_bwd_kernel<32, 128>), dim3(kPfnBwdBlocks, passes), dim3(256), 0, pn::S(stream), a, center_table, d_features, d_canvas, slabs);
+    hipLaunchKernelGGL((dynamic_pfn_bwd_kernel<32, 128>), dim3(kPfnBwdBlocks, passes), dim3(256), 0, pn::S(stream), a, center_table, d_features, d_canvas, slabs,
+                       slab_waves, (int)single);
   else
-    hipLaunchKernelGGL((dynamic_pfn_bwd_kernel<16, 32>), dim3(kPfnBwdBlocks, passes), dim3(256), 0, pn::S(stream), a, center_table, d_features, d_canvas, slabs);
+    hipLaunchKernelGGL((dynamic_pfn_bwd_kernel<16, 32>), dim3(kPfnBwdBlocks, passes), dim3(256), 0, pn::S(stream), a, center_table, d_features, d_canvas, slabs,
+                       slab_waves, 0);
   const int outs = c1 * 2 * c0 + c0 * 16;
-  hipLaunchKernelGGL(pfn_bwd_reduce_kernel, dim3(pn::cdiv(outs, 64)), dim3(256), 0, pn::S(stream), slabs, kPfnBwdBlocks * 4, passes, c0, c1,
+  hipLaunchKernelGGL(pfn_bwd_reduce_kernel, dim3(pn::cdiv(outs, 64)), dim3(256), 0, pn::S(stream), slabs, slab_waves, passes, c0, c1,
                      dw0, dw1, accumulate);
   return pn::check_launch("dynamic_pfn_bwd");
 }
