@@ -766,8 +766,8 @@ __global__ __launch_bounds__(256) void dynamic_pfn_bwd_kernel(PfnArgs a, const f
 // join their accumulators in a fixed order and write ONE slab pair in the layout of the kernel above, pfn_bwd_reduce_kernel adds them
 // all.  Pillars with another point count are zero rows of a tile (dynamic_pfn_bwd_kernel skips the one-point ones in turn).
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int kS1H = 33, kS1DA = 129, kS1D = 17;
-constexpr int kS1WaveFloats = 32 * kS1H + 32 * kS1DA + 32 * kS1H + 32 * kS1D + 64;   // H, DA, DY0, D, 32 row offsets (64-bit)
+constexpr int kS1H = 33, kS1D = 17;
+constexpr int kS1WaveFloats = 3 * 32 * kS1H + 32 * kS1D + 64;   // H, DA tile, DY0 (32 x 33 each), D (32 x 17), 32 row offsets (64-bit): with Wsum 76 KB per block, two blocks per CU
 constexpr int kS1WsFloats = 128 * kS1H;
 constexpr size_t kS1Smem = (size_t)(kS1WsFloats + 4 * kS1WaveFloats) * sizeof(float);
 
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256) void pfn_bwd_single_kernel(PfnArgs a, const fl
   const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6, li = lane & 31, lh = lane >> 5;
   float* Hs = s1_lds + kS1WsFloats + wib * kS1WaveFloats;
   float* DAs = Hs + 32 * kS1H;
-  float* Y0s = DAs + 32 * kS1DA;
+  float* Y0s = DAs + 32 * kS1H;
   float* Ds = Y0s + 32 * kS1H;
   unsigned long long* Offs = reinterpret_cast<unsigned long long*>(Ds + 32 * kS1D);
   for (int i = tid; i < C1 * C0; i += 256) {
@@ -838,11 +838,17 @@ __global__ __launch_bounds__(256) void pfn_bwd_single_kernel(PfnArgs a, const fl
     for (int kk = 0; kk < 8; ++kk) H = __builtin_amdgcn_mfma_f32_32x32x2f32(lh ? d[2 * kk + 1] : d[2 * kk], lh ? w0r[2 * kk + 1] : w0r[2 * kk], H, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { H[r] = H[r] > 0.f ? H[r] : 0.f; Hs[prow(r) * kS1H + li] = H[r]; }
-    // Y = H Wsum^T, DA = Y > 0 ? dY : 0
+    // per 32-row tile nt of layer 1:  Y = H Wsum^T,  DA = Y > 0 ? dY : 0,  dW1[nt] += DA^T H,  dH += DA Wsum[nt rows]
+    // DA leaves the MFMA as [p][row] with the row on the lane: that IS the A operand of DA^T H when K step (r, lane half) stands for
+    // pillar prow(r) -- and H's accumulators hold exactly those pillars for the B operand -- so dW1 needs no LDS at all; only dH wants DA
+    // with the pillar on the lane and goes through a 32 x 32 strip (per tile: 4 KB, not the 16 KB of the whole DA).
     float ha[16];
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) ha[kk] = Hs[li * kS1H + 2 * kk + lh];
     const float* dsrc = dcanvas ? dcanvas : dfeat;
+    f32x16 dH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dH[r] = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       float g[16];
@@ -856,24 +862,15 @@ __global__ __launch_bounds__(256) void pfn_bwd_single_kernel(PfnArgs a, const fl
       for (int r = 0; r < 16; ++r) Y[r] = 0.f;
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) Y = __builtin_amdgcn_mfma_f32_32x32x2f32(ha[kk], Ws[(32 * nt + li) * kS1H + 2 * kk + lh], Y, 0, 0, 0);
+      float da[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) DAs[prow(r) * kS1DA + 32 * nt + li] = Y[r] > 0.f ? g[r] : 0.f;
-    }
-    // dW1 += DA^T H
-    float hb[16];
+      for (int r = 0; r < 16; ++r) { da[r] = Y[r] > 0.f ? g[r] : 0.f; DAs[prow(r) * kS1H + li] = da[r]; }
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) hb[kk] = Hs[(2 * kk + lh) * kS1H + li];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+      for (int r = 0; r < 16; ++r) dw1acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[r], H[r], dw1acc[nt], 0, 0, 0);
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk)
-        dw1acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(DAs[(2 * kk + lh) * kS1DA + 32 * nt + li], hb[kk], dw1acc[nt], 0, 0, 0);
-    // dH = DA Wsum, DY0 = H > 0 ? dH : 0
-    f32x16 dH;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dH[r] = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 64; ++kk) dH = __builtin_amdgcn_mfma_f32_32x32x2f32(DAs[li * kS1DA + 2 * kk + lh], Ws[(2 * kk + lh) * kS1H + li], dH, 0, 0, 0);
+        dH = __builtin_amdgcn_mfma_f32_32x32x2f32(DAs[li * kS1H + 2 * kk + lh], Ws[(32 * nt + 2 * kk + lh) * kS1H + li], dH, 0, 0, 0);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) Y0s[prow(r) * kS1H + li] = H[r] > 0.f ? dH[r] : 0.f;
     // dW0 += DY0^T D
@@ -881,31 +878,34 @@ __global__ __launch_bounds__(256) void pfn_bwd_single_kernel(PfnArgs a, const fl
     for (int kk = 0; kk < 16; ++kk)
       dw0acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Y0s[(2 * kk + lh) * kS1H + li], li < 16 ? Ds[(2 * kk + lh) * kS1D + li] : 0.f, dw0acc, 0, 0, 0);
   }
-  // the block's four waves join (wave order) and write one slab per pass: rows x (h half | m0 half, the same values), then dW0 with pass 0
-  __syncthreads();
-  float* mine = s1_lds + kS1WsFloats + wib * kS1WaveFloats;      // 4096 + 512 floats of the wave's strip
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mine[(32 * nt + prow(r)) * 32 + li] = dw1acc[nt][r];
-  if (li < 16) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mine[4096 + prow(r) * 16 + li] = dw0acc[r];
-  }
-  __syncthreads();
+  // the block's four waves join (wave order), one 32-row tile of dW1 at a time through their strips, and write one slab per pass: rows x
+  // (h half | m0 half, the same values), then dW0 with pass 0
+  float* mine = s1_lds + kS1WsFloats + wib * kS1WaveFloats;
   const float* w0s = s1_lds + kS1WsFloats;
   const int bslot = wave_base + blockIdx.x;
-  for (int i = tid; i < 4096 + 512; i += 256) {
-    const float t = (w0s[i] + w0s[kS1WaveFloats + i]) + (w0s[2 * kS1WaveFloats + i] + w0s[3 * kS1WaveFloats + i]);
-    if (i < 4096) {
-      const int row = i >> 5, c = i & 31, pass = row >> 6, lrow = row & 63;
-      float* slab = slabs + ((size_t)pass * slab_waves + bslot) * SLAB;
-      slab[lrow * K1 + c] = t;
-      slab[lrow * K1 + C0 + c] = t;
-    } else {
-      const int j = i - 4096;
-      slabs[((size_t)0 * slab_waves + bslot) * SLAB + 64 * K1 + j] = t;
-      slabs[((size_t)1 * slab_waves + bslot) * SLAB + 64 * K1 + j] = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 5; ++nt) {
+    __syncthreads();
+    if (nt < 4) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mine[prow(r) * 32 + li] = dw1acc[nt < 4 ? nt : 0][r];
+    } else if (li < 16) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mine[prow(r) * 16 + li] = dw0acc[r];
+    }
+    __syncthreads();
+    const int count = nt < 4 ? 1024 : 512;
+    for (int i = tid; i < count; i += 256) {
+      const float t = (w0s[i] + w0s[kS1WaveFloats + i]) + (w0s[2 * kS1WaveFloats + i] + w0s[3 * kS1WaveFloats + i]);
+      if (nt < 4) {
+        const int row = 32 * nt + (i >> 5), c = i & 31, pass = row >> 6, lrow = row & 63;
+        float* slab = slabs + ((size_t)pass * slab_waves + bslot) * SLAB;
+        slab[lrow * K1 + c] = t;
+        slab[lrow * K1 + C0 + c] = t;
+      } else {
+        slabs[((size_t)0 * slab_waves + bslot) * SLAB + 64 * K1 + i] = t;
+        slabs[((size_t)1 * slab_waves + bslot) * SLAB + 64 * K1 + i] = 0.f;
+      }
     }
   }
 }
@@ -1095,7 +1095,7 @@ int pn_scatter_canvas_fwd(const float* features, const int64_t* unq, const int32
 
 constexpr int kPfnBwdBlocks = 256;  // x 2 passes x 4 waves = two waves per SIMD for the (32, 128) reader
 constexpr int kPfnBwdSlabMax = 64 * 64 + 32 * 16;
-constexpr int kPfnBwdSingleBlocks = 256;   // pfn_bwd_single_kernel: one slab pair per block
+constexpr int kPfnBwdSingleBlocks = 256;   // pfn_bwd_single_kernel: one slab pair per block (512 blocks, two per CU: the same 88 us and more slabs to add)
 static const int kPfnBwdSingle = [] { const char* e = getenv("PN_PFN_BWD_SINGLE"); return e ? atoi(e) : 1; }();
 
 size_t pn_dynamic_pfn_bwd_workspace_bytes(void) { return (size_t)(kPfnBwdBlocks * 4 + kPfnBwdSingleBlocks) * 2 * kPfnBwdSlabMax * sizeof(float); }
