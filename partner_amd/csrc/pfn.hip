@@ -769,9 +769,10 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kS1H = 33, kS1D = 17;
 constexpr int kS1WaveFloats = 3 * 32 * kS1H + 32 * kS1D + 64;   // H, DA tile, DY0 (32 x 33 each), D (32 x 17), 32 row offsets (64-bit): with Wsum 76 KB per block, two blocks per CU
 constexpr int kS1WsFloats = 128 * kS1H;
-constexpr size_t kS1Smem = (size_t)(kS1WsFloats + 4 * kS1WaveFloats) * sizeof(float);
+constexpr int kS1Waves = 8;     // two waves per SIMD: a tile's dependent index / point / dY loads hide behind the other wave's MFMAs
+constexpr size_t kS1Smem = (size_t)(kS1WsFloats + kS1Waves * kS1WaveFloats) * sizeof(float);
 
-__global__ __launch_bounds__(256) void pfn_bwd_single_kernel(PfnArgs a, const float* __restrict__ cs_table, const float* __restrict__ dfeat,
+__global__ __launch_bounds__(64 * kS1Waves) void pfn_bwd_single_kernel(PfnArgs a, const float* __restrict__ cs_table, const float* __restrict__ dfeat,
                                                              const float* __restrict__ dcanvas, float* __restrict__ slabs, int slab_waves, int wave_base) {
   constexpr int C0 = 32, C1 = 128, K1 = 64, SLAB = 64 * K1 + C0 * 16;
   extern __shared__ __attribute__((aligned(16))) float s1_lds[];
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(256) void pfn_bwd_single_kernel(PfnArgs a, const fl
   float* Y0s = DAs + 32 * kS1H;
   float* Ds = Y0s + 32 * kS1H;
   unsigned long long* Offs = reinterpret_cast<unsigned long long*>(Ds + 32 * kS1D);
-  for (int i = tid; i < C1 * C0; i += 256) {
+  for (int i = tid; i < C1 * C0; i += 64 * kS1Waves) {
     const int row = i >> 5, c = i & 31;
     Ws[row * kS1H + c] = a.w1[row * K1 + c] + a.w1[row * K1 + C0 + c];
   }
@@ -796,7 +797,7 @@ __global__ __launch_bounds__(256) void pfn_bwd_single_kernel(PfnArgs a, const fl
   for (int r = 0; r < 16; ++r) { dw0acc[r] = 0.f; dw1acc[0][r] = dw1acc[1][r] = dw1acc[2][r] = dw1acc[3][r] = 0.f; }
   const int V = min(*a.v_dev, a.v_cap);
   const int ntiles = (V + 31) / 32;
-  const int wave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
+  const int wave = blockIdx.x * kS1Waves + wib, nwaves = gridDim.x * kS1Waves;
   auto prow = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * lh; };
   for (int tile = wave; tile < ntiles; tile += nwaves) {
     const int v = tile * 32 + li;
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(256) void pfn_bwd_single_kernel(PfnArgs a, const fl
     if (lh == 0) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) Ds[li * kS1D + k] = d[k];
-      Offs[li] = dcanvas ? ((((unsigned long long)bi * a.T + ti) * a.R + ri) * C1) : ((unsigned long long)v * C1);
+      Offs[li] = v >= V ? 0ull : dcanvas ? ((((unsigned long long)bi * a.T + ti) * a.R + ri) * C1) : ((unsigned long long)v * C1);
     }
     // H = relu(D W0^T)
     f32x16 H;
@@ -853,30 +854,35 @@ __global__ __launch_bounds__(256) void pfn_bwd_single_kernel(PfnArgs a, const fl
     for (int nt = 0; nt < 4; ++nt) {
       float g[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int pv = tile * 32 + prow(r);
-        g[r] = pv < V ? dsrc[Offs[prow(r)] + 32 * nt + li] : 0.f;
-      }
+      for (int r = 0; r < 16; ++r) g[r] = dsrc[Offs[prow(r)] + 32 * nt + li];   // unconditional (rows past V read row 0 and are masked by Y = 0): a branch here
+                                                                                // cuts the MFMA run into basic blocks with accumulator copies between them
       f32x16 Y;
 #pragma unroll
       for (int r = 0; r < 16; ++r) Y[r] = 0.f;
+      float wy[16];      // (operands of a whole MFMA run read first: one wait instead of a read - wait - MFMA chain at one wave per SIMD)
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) Y = __builtin_amdgcn_mfma_f32_32x32x2f32(ha[kk], Ws[(32 * nt + li) * kS1H + 2 * kk + lh], Y, 0, 0, 0);
+      for (int kk = 0; kk < 16; ++kk) wy[kk] = Ws[(32 * nt + li) * kS1H + 2 * kk + lh];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) Y = __builtin_amdgcn_mfma_f32_32x32x2f32(ha[kk], wy[kk], Y, 0, 0, 0);
       float da[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) { da[r] = Y[r] > 0.f ? g[r] : 0.f; DAs[prow(r) * kS1H + li] = da[r]; }
 #pragma unroll
       for (int r = 0; r < 16; ++r) dw1acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[r], H[r], dw1acc[nt], 0, 0, 0);
+      float ad[16], wd[16];
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk)
-        dH = __builtin_amdgcn_mfma_f32_32x32x2f32(DAs[li * kS1H + 2 * kk + lh], Ws[(32 * nt + 2 * kk + lh) * kS1H + li], dH, 0, 0, 0);
+      for (int kk = 0; kk < 16; ++kk) { ad[kk] = DAs[li * kS1H + 2 * kk + lh]; wd[kk] = Ws[(32 * nt + 2 * kk + lh) * kS1H + li]; }
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) dH = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[kk], wd[kk], dH, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) Y0s[prow(r) * kS1H + li] = H[r] > 0.f ? dH[r] : 0.f;
     // dW0 += DY0^T D
+    float ay[16], bd[16];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
-      dw0acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Y0s[(2 * kk + lh) * kS1H + li], li < 16 ? Ds[(2 * kk + lh) * kS1D + li] : 0.f, dw0acc, 0, 0, 0);
+    for (int kk = 0; kk < 16; ++kk) { ay[kk] = Y0s[(2 * kk + lh) * kS1H + li]; bd[kk] = li < 16 ? Ds[(2 * kk + lh) * kS1D + li] : 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) dw0acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[kk], bd[kk], dw0acc, 0, 0, 0);
   }
   // the block's four waves join (wave order), one 32-row tile of dW1 at a time through their strips, and write one slab per pass: rows x
   // (h half | m0 half, the same values), then dW0 with pass 0
@@ -895,8 +901,11 @@ __global__ __launch_bounds__(256) void pfn_bwd_single_kernel(PfnArgs a, const fl
     }
     __syncthreads();
     const int count = nt < 4 ? 1024 : 512;
-    for (int i = tid; i < count; i += 256) {
-      const float t = (w0s[i] + w0s[kS1WaveFloats + i]) + (w0s[2 * kS1WaveFloats + i] + w0s[3 * kS1WaveFloats + i]);
+    for (int i = tid; i < count; i += 64 * kS1Waves) {
+      float t = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < kS1Waves; wv += 4)     // wave order, four at a time
+        t += (w0s[wv * kS1WaveFloats + i] + w0s[(wv + 1) * kS1WaveFloats + i]) + (w0s[(wv + 2) * kS1WaveFloats + i] + w0s[(wv + 3) * kS1WaveFloats + i]);
       if (nt < 4) {
         const int row = 32 * nt + (i >> 5), c = i & 31, pass = row >> 6, lrow = row & 63;
         float* slab = slabs + ((size_t)pass * slab_waves + bslot) * SLAB;
@@ -1121,7 +1130,7 @@ int pn_dynamic_pfn_bwd(const float* points, int point_stride, const int32_t* vox
     static bool done[64] = {false};
     if (pn::first_use_on_device(done))
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pfn_bwd_single_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS1Smem);
-    hipLaunchKernelGGL(pfn_bwd_single_kernel, dim3(kPfnBwdSingleBlocks), dim3(256), kS1Smem, pn::S(stream), a, center_table, d_features, d_canvas, slabs, slab_waves,
+    hipLaunchKernelGGL(pfn_bwd_single_kernel, dim3(kPfnBwdSingleBlocks), dim3(64 * kS1Waves), kS1Smem, pn::S(stream), a, center_table, d_features, d_canvas, slabs, slab_waves,
                        kPfnBwdBlocks * 4);
   }
   if (c0 == 32)
