@@ -636,7 +636,8 @@ int pn_sparse_conv_grouped_f32(const float* in, int in_rows, int cin, const int3
     else hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a);
   };
   static const int g4 = [] { const char* e = getenv("PN_SPARSE_GROUP4"); return e ? atoi(e) : 1; }();
-  if (g4 && cin % 32 == 0 && cin >= 64 && ncol32 >= 2) {      // block per group, K split over its waves
+  if (g4 && (cin == 64 || cin == 128) && ncol32 >= 2) {      // block per group, K split over its waves: the wave -> (channel chunk, tap subset)
+    // map of the kernel exists for 2 or 4 chunks of 32 input channels only; every other width takes the wave kernel, which loops over chunks
     const dim3 grid((unsigned)((pn::cdiv(out_capacity, 32) + 7) / 8 * 8), 1);
     // 128 columns: two blocks of 64 columns per group (the input rows are gathered twice; blocks half as long, four per CU instead of three:
     // 380 -> 365 us on the bench frame's 128 -> 128 layers).  Heavy-groups-first block orders were tried and lose: the contiguous run of

@@ -18,12 +18,18 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend: str, device: Optional[torch.device] = None, timeout_s: Optional[float] = None) -> bool:
+def init(backend: str, device: Optional[torch.device] = None, timeout_s: Optional[float] = None, single_rank_group: bool = False) -> bool:
     """initialise the default process group from the torchrun environment; False when world size is 1.
-    ``timeout_s`` bounds every collective wait (a rank that faults leaves the others with an error, not a hang)."""
+    ``timeout_s`` bounds every collective wait (a rank that faults leaves the others with an error, not a hang).
+    ``single_rank_group``: create the group at world size 1 too -- the one-GPU box's way to run the RCCL code path itself
+    (communicator creation with ``device_id``, asynchronous collectives on device slices, stream-level waits); the exchange
+    helpers below then take ``force=True``."""
     _, _, world = env_rank_world()
-    if world <= 1:
+    if world <= 1 and not single_rank_group:
         return False
+    if world <= 1:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     kw = {}
@@ -63,12 +69,17 @@ def sum_over_ranks(value: float, device: Optional[torch.device] = None) -> float
 
 
 # ---- training step: the one exchange per iteration ------------------------------------
-def allreduce_flat_grads(flat_g: torch.Tensor) -> None:
+def _group_live(force: bool) -> bool:
+    """a collective is issued when the group has more than one rank, or on request at world size 1 (``force``)"""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
+
+
+def allreduce_flat_grads(flat_g: torch.Tensor, force: bool = False) -> None:
     """SUM all-reduce of the flat fp32 gradient buffer, in place (one collective per step; the
     reference coalesces per-parameter grads into buckets, det3d/core/utils/dist_utils.py:8-28).
     The 1/world of the reference's average is folded into the loss gradient by the caller, so after
     this call every rank holds the mean gradient."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _group_live(force):
         dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
 
 
@@ -77,11 +88,12 @@ class GradExchange:
     order, det3d/torchie/apis/train.py:330-336).  ``buckets`` are contiguous [lo, hi) ranges of the flat gradient buffer in the
     order backward completes them; ``ready(k)`` starts the asynchronous SUM all-reduce of bucket k (RCCL's stream waits for the
     kernels queued so far and runs next to the rest of backward), ``finish()`` starts whatever has not been started and makes
-    the compute stream wait for all of them.  World size 1: no-ops."""
+    the compute stream wait for all of them.  World size 1: no-ops, unless ``force`` (the collectives then run over the
+    one-rank group and leave the buffer as it was -- the path itself is what is exercised)."""
 
-    def __init__(self, flat_g: torch.Tensor, buckets):
+    def __init__(self, flat_g: torch.Tensor, buckets, force: bool = False):
         self.flat_g, self.buckets = flat_g, list(buckets)
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.active = _group_live(force)
         self.issued = [False] * len(self.buckets)
         self.pending = []
 
@@ -99,8 +111,8 @@ class GradExchange:
         self.pending = []
 
 
-def broadcast_flat_params(flat_p: torch.Tensor, src: int = 0) -> None:
+def broadcast_flat_params(flat_p: torch.Tensor, src: int = 0, force: bool = False) -> None:
     """rank `src` -> all, once before training (what DistributedDataParallel's constructor does,
     det3d/torchie/apis/train.py:330-336)"""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _group_live(force):
         dist.broadcast(flat_p, src=src)

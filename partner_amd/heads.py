@@ -467,6 +467,11 @@ class CenterHeadSingle(CenterHead):
                 groups.insert(0, dict(src="xs", members=rest, strata=0))
             cm_tot, off = sum(cm for *_, cm in fz["first"]), 0
             offsets, tile_rows = {}, None
+            # fixed limits of the entry points this plan feeds (conv_wchain.hip kChainMultiJobs = 4 launches' jobs; norm.hip kHeadFinJobs = 8
+            # branches, 8 strata, 256 channels per branch): a head beyond them takes the tiled multi-job launch, as the docstring says
+            if (len(groups) > 4 or len(fz["first"]) > 8 or any(g["strata"] > 8 for g in groups)
+                    or any(cm > 256 for *_, cm in fz["first"])):
+                ok, groups = False, []
             for g in groups:
                 cout = sum(m[2] for m in g["members"])
                 S = g["strata"]

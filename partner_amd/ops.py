@@ -484,7 +484,8 @@ class ConvLayer:
 
     def chain_weights(self, two_d: bool, transposed: bool) -> torch.Tensor:
         """packed weights of the chained F(4,3) / F(2,3)xF(4,3) forms; ``transposed``: of the kernel with kh and kw swapped (the chain then runs
-        on the transposed map), packed on first use"""
+        on the transposed map), packed on first use.  The transposed layouts belong to the inference path (the head's
+        branch chain): they are not tracked by ``prepack_used`` and a stale one is repacked lazily on the caller's stream"""
         if not transposed:
             self._ensure("wino24" if two_d else "wino4")
             return self.wino24_packed if two_d else self.wino4_packed
@@ -500,7 +501,9 @@ class ConvLayer:
                 buf = _f32(getattr(lib, f"pn_conv_{fam}_packed_weight_floats")(self.cout, self._pack_cin), w.device)
             hip.call(f"pn_pack_conv_weight_{fam}_f32", wt.data_ptr(), self.cout, self._pack_cin, buf.data_ptr(), hip.stream())
             self._chain_t[key] = buf
-            self._chain_t_src = wt        # (the launch is asynchronous: the transposed copy stays referenced)
+            if not isinstance(getattr(self, "_chain_t_src", None), dict):
+                self._chain_t_src = {}
+            self._chain_t_src[key] = wt   # (the launch is asynchronous: the transposed copy stays referenced, one per layout)
             if stale:
                 stale.discard(key + "_t")
         return self._chain_t[key]

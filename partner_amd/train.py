@@ -556,6 +556,7 @@ class PolarPillarTrainStep:
                     out = torch.empty((batch, oh, ow, sum(self.up_filters)), dtype=torch.float32, device=self.dev)
                 de.fwd(x, out=out, out_co=off)
                 off += self.up_filters[j]
+        self._packs_ready(1)    # models with a single block reach the head without having met event 1 in the loop
         self.x2 = out
         # ---- head
         mul = add = None
@@ -713,7 +714,10 @@ class PolarPillarTrainStep:
             ps.fresh = None
             return
         tok = ps.fresh = object()
+        # group 0 = every layout the main stream takes before it waits for event 1: block 0 and the deblock fed by block 0
         first = {id(layer.conv) for layer in self.blocks[0]}
+        if self.up_start == 0 and self.deblocks:
+            first.add(id(self.deblocks[0].conv))
         groups = ([c for c in ps.convs if id(c) in first], [c for c in ps.convs if id(c) not in first])
         if getattr(self, "_pack_ev", None) is None:
             self._pack_ev = [torch.cuda.Event() for _ in range(3)]
@@ -790,7 +794,10 @@ class PolarPillarTrainStep:
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         from .dist_utils import GradExchange
         # exchange_enabled = False: a timing-only mode of bench.py (the same iteration without the collectives; ranks then diverge)
-        self._exchange = GradExchange(self.ps.flat_g, self.buckets) if world > 1 and getattr(self, "exchange_enabled", True) else None
+        # exchange_at_world_1 = True: the collectives run over a ONE-rank group too (dist_utils.init(single_rank_group=True)): the RCCL path
+        # of a one-GPU box; the result is the no-exchange step's, bit for bit
+        force = bool(getattr(self, "exchange_at_world_1", False)) and world == 1 and dist.is_available() and dist.is_initialized()
+        self._exchange = GradExchange(self.ps.flat_g, self.buckets, force=force) if (world > 1 or force) and getattr(self, "exchange_enabled", True) else None
         # the reference averages the gradients over ranks (dist_utils.py:17-28): fold 1/world into the loss gradient
         try:
             loss = self.forward_backward(points, sample_offsets, batch, targets, grid_ind, grad_scale=1.0 / world)
@@ -804,7 +811,8 @@ class PolarPillarTrainStep:
     def sync_initial_params(self):
         """rank 0's parameters (and BatchNorm running statistics) to every rank, once before the first step"""
         from .dist_utils import broadcast_flat_params
-        broadcast_flat_params(self.ps.flat_p)
+        force = bool(getattr(self, "exchange_at_world_1", False))
+        broadcast_flat_params(self.ps.flat_p, force=force)
         for b in self.model.buffers():
             if b.dtype.is_floating_point:
-                broadcast_flat_params(b)
+                broadcast_flat_params(b, force=force)

@@ -483,7 +483,9 @@ def test_sparse_conv_c16_matches_the_gathered_mfma_form_and_fp64(dev, cin, taps,
 @pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout,taps,n,cap,res,act", [(32, 32, 27, 9000, 9100, True, 1), (64, 64, 27, 5000, 8192, True, 1), (128, 128, 27, 2100, 2100, False, 1),
                                                           (16, 32, 27, 4097, 4100, False, 1), (32, 64, 27, 33, 64, False, 0), (128, 128, 3, 1500, 2048, False, 1),
-                                                          (64, 128, 27, 300, 300, True, 0)], ids=str)
+                                                          (64, 128, 27, 300, 300, True, 0),
+                                                          # widths outside the block-per-group kernel's 64 / 128 (r4 advisor finding: they went to it anyway)
+                                                          (96, 64, 27, 1200, 1280, False, 1), (256, 128, 27, 700, 704, True, 1), (192, 64, 9, 500, 512, False, 0)], ids=str)
 def test_sparse_conv_grouped_matches_the_gathered_tile_form_and_fp64(dev, cin, cout, taps, n, cap, res, act):
     """pn_sparse_group_rows + pn_sparse_conv_grouped_f32 (one wave per group of 32 sites sorted by neighbourhood, the group's taps only)
     against pn_sparse_conv_f32 (gathered 128-site tiles) on the same rulebook and against an fp64
