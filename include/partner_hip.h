@@ -332,6 +332,20 @@ int pn_pack_conv_weight_bf16(const float *w_oihw, int cout_total, int cin_per_gr
 int pn_conv2d_nhwc_bf16(const pn_conv_desc *desc, const void *in_bf16, const void *packed_w_bf16,
                         const float *scale, const float *shift, void *out, int out_is_f32,
                         pn_stream_t stream);
+
+/* r5: the bf16 BEV convolutions as a kernel of their own (csrc/conv_bf16.hip; replaces for the bf16 option the cuDNN convolutions of
+ * det3d/models/necks/rpn.py:80-110,124-142 and of det3d/models/bbox_heads/e2e_swv_head.py:57-118): implicit GEMM on
+ * v_mfma_f32_16x16x32_bf16, both operands global -> LDS by LDS-DMA, LDS-staged whole-line stores; 3x3 / stride 1 layers on maps whose rows
+ * tile 288 pixels keep the input patch of a 64-channel chunk in LDS and read it for all nine taps (the "rows" form).
+ * Layers it takes (pn_conv2d_igemm_bf16_supported): one group, no range strata, cin a multiple of 64, cout of 16, activation none / ReLU,
+ * pixel strides / channel offsets multiples of 8 (in) and 4 (out); ConvTranspose2d(k = s = 2) as deconv2x2 with kh = kw = 1 and the weight
+ * rows ordered (2 di + dj) * cout + n.  Weights: pn_pack_conv_weight_bf16_rows -> bf16 [rows padded to 16][kh * kw][cin].
+ * Same descriptor, operands, scale / shift / act and output conventions as pn_conv2d_nhwc_bf16. */
+size_t pn_conv_bf16_rows_packed_elems(int cout_total, int cin, int kh, int kw);
+int pn_pack_conv_weight_bf16_rows(const float *w_oihw, int cout_total, int cin, int kh, int kw, void *packed, pn_stream_t stream);
+int pn_conv2d_igemm_bf16_supported(const pn_conv_desc *desc);
+int pn_conv2d_igemm_bf16(const pn_conv_desc *desc, const void *in_bf16, const void *packed_rows_bf16, const float *scale,
+                         const float *shift, void *out, int out_is_f32, pn_stream_t stream);
 int pn_f32_to_bf16(const float *x, void *y, size_t n, pn_stream_t stream);
 int pn_bf16_to_f32(const void *x, float *y, size_t n, pn_stream_t stream);
 
@@ -561,13 +575,22 @@ int pn_setblock_sector_col_attn(const float *q, const float *kv_raw, const float
  * pos: (H,W,2) Cartesian cell centres; vote MLP 3->16->C, rpe MLP 2->16->heads (1x1 conv weights),
  * tau (heads).  window = 7, head_dim = 64; shift = 0 or window/2.  out: (B,H,W,C) attention output
  * before the projection.  Zero padding to window multiples, cyclic shift, window partition, the shift
- * mask and their inverses are index arithmetic inside the kernel. */
+ * mask and their inverses are index arithmetic inside the kernel.
+ * bias_table (nullable): the relative-position bias rpe(pos_i - pos_j) of every (window, head, query,
+ * key), pn_swv_window_bias_floats(h, w, heads, window) floats written by pn_swv_window_bias_table
+ * for the same pos / rpe weights / shift -- it depends on the model and the map only, so a caller
+ * builds it once per set of weights; the rpe pointers may then be null.  Null: computed per call.
+ * Both forms give the same bits. */
 int pn_swv_window_attn(const float *qkv, const float *vote, int vote_pixel_stride, const float *pos,
                        const float *qkv_bias, const float *vote_w1, const float *vote_b1,
                        const float *vote_w2, const float *vote_b2, const float *rpe_w1,
                        const float *rpe_b1, const float *rpe_w2, const float *rpe_b2, const float *tau,
-                       int batch, int h, int w, int c, int heads, int window, int shift, float *out,
-                       pn_stream_t stream);
+                       int batch, int h, int w, int c, int heads, int window, int shift,
+                       const float *bias_table, float *out, pn_stream_t stream);
+size_t pn_swv_window_bias_floats(int h, int w, int heads, int window);
+int pn_swv_window_bias_table(const float *pos, const float *rpe_w1, const float *rpe_b1,
+                             const float *rpe_w2, const float *rpe_b2, int h, int w, int heads,
+                             int window, int shift, float *table, pn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * L1  CenterPoint loss, forward value.

@@ -47,9 +47,18 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // The relative-position MLP (2 -> 16 -> heads, per (query, key) pair) and the softmax stay on the VALU: ~3.5 k instructions per lane.
 __device__ __forceinline__ int rowmap(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
+//
+// r5: the relative-position bias depends on the cell positions, the window frame and the rpe weights only -- not on the frame's features --
+// and its hidden layer not on the head: TAB = true reads it from a table built once per (weights, map, shift) by swv_window_bias_kernel in
+// THIS kernel's accumulator layout ([window][head][query tile][28 live key registers][64 lanes]: a register's 64 values are one 256-byte
+// line), instead of ~64 VALU instructions per (query, key, head).  The table holds the values the on-the-fly form computes, bit for bit.
+constexpr int kBiasRegs = 28;       // key registers per query tile: 16 of key tile 0 + the 12 of key tile 1 that are tokens (keys < 56)
+__host__ __device__ constexpr size_t swv_bias_floats_per_window_head() { return 2 * kBiasRegs * 64; }
+
+template <bool TAB>
 __global__ __launch_bounds__(256) void swv_window_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ vote, int vote_ps,
                                                               const float* __restrict__ pos, SwvParams P, int H, int W, int C, int heads, int shift,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, const float* __restrict__ bias_tab) {
   __shared__ int tok[64];
   __shared__ __attribute__((aligned(16))) float tinfo[64][4];      // px, py, region, key-valid (1 / 0)
   __shared__ __attribute__((aligned(16))) float vhid[64][20];      // hidden layer of the vote MLP per token (16 + pad)
@@ -167,14 +176,23 @@ __global__ __launch_bounds__(256) void swv_window_attn_kernel(const float* __res
     }
   // relative-position MLP and temperature
   float rw1x[16], rw1y[16], rb1[16], rw2[16];
+  float rb2 = 0.f;
+  if constexpr (!TAB) {
 #pragma unroll
-  for (int m = 0; m < 16; ++m) { rw1x[m] = P.rp_w1[m * 2]; rw1y[m] = P.rp_w1[m * 2 + 1]; rb1[m] = P.rp_b1[m]; rw2[m] = P.rp_w2[head * 16 + m]; }
-  const float rb2 = P.rp_b2[head];
+    for (int m = 0; m < 16; ++m) { rw1x[m] = P.rp_w1[m * 2]; rw1y[m] = P.rp_w1[m * 2 + 1]; rb1[m] = P.rp_b1[m]; rw2[m] = P.rp_w2[head * 16 + m]; }
+    rb2 = P.rp_b2[head];
+  }
+  const float* tab = TAB ? bias_tab + ((size_t)blockIdx.x * heads + head) * swv_bias_floats_per_window_head() + lane : nullptr;
   const float inv_tau = 1.f / fmaxf(P.tau[head], 0.01f);
   // ---- per query tile: S^T = K Q^T (lane = query), logits, softmax over the keys, out^T = V^T P^T
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
     const int qi = ti * 32 + li;
+    float rpt[kBiasRegs];        // TAB: this query tile's biases, requested before the products
+    if constexpr (TAB) {
+#pragma unroll
+      for (int k = 0; k < kBiasRegs; ++k) rpt[k] = tab[(ti * kBiasRegs + k) * 64];
+    }
     f32x16 st[2] = {zero16, zero16};
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
@@ -193,12 +211,16 @@ __global__ __launch_bounds__(256) void swv_window_attn_kernel(const float* __res
         if (tj == 1 && (r >> 2) > 2) { st[tj][r] = -3.0e38f; continue; }     // keys >= 56: MFMA padding (compile-time skip)
         const f32x4 oj = *reinterpret_cast<const f32x4*>(tinfo[j]);
         float a = st[tj][r] / fmaxf(nqi * nkw[head][j], 1e-6f) * inv_tau;
-        const float dx = me[0] - oj[0], dy = me[1] - oj[1];
         float rp = rb2;
+        if constexpr (TAB) {
+          rp = rpt[tj * 16 + r];
+        } else {
+          const float dx = me[0] - oj[0], dy = me[1] - oj[1];
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-          const float hdn = fmaf(rw1x[m], dx, fmaf(rw1y[m], dy, rb1[m]));
-          rp = fmaf(rw2[m], hdn > 0.f ? hdn : 0.f, rp);
+          for (int m = 0; m < 16; ++m) {
+            const float hdn = fmaf(rw1x[m], dx, fmaf(rw1y[m], dy, rb1[m]));
+            rp = fmaf(rw2[m], hdn > 0.f ? hdn : 0.f, rp);
+          }
         }
         a += rp;
         if (oj[2] != me[2]) a += -100.f;
@@ -242,24 +264,87 @@ __global__ __launch_bounds__(256) void swv_window_attn_kernel(const float* __res
   }
 }
 
+// the bias table of swv_window_attn_kernel<true>: block = window of the (shifted, padded) frame, wave = head; the arithmetic of the
+// on-the-fly form, term for term (positions of padded tokens are zero there too)
+__global__ __launch_bounds__(256) void swv_window_bias_kernel(const float* __restrict__ pos, SwvParams P, int H, int W, int heads, int shift,
+                                                              float* __restrict__ tab) {
+  __shared__ float px[64], py[64];
+  const int tid = threadIdx.x, lane = tid & 63, head = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int Hp = (H + WS - 1) / WS * WS, Wp = (W + WS - 1) / WS * WS;
+  const int nww = Wp / WS;
+  const int wy = blockIdx.x / nww, wx = blockIdx.x - wy * nww;
+  if (tid < 64) {
+    const int t = tid;
+    const int r = t / WS, c = t - r * WS;
+    const int hp = (wy * WS + r + shift) % Hp, wp = (wx * WS + c + shift) % Wp;
+    const bool valid = t < NT && hp < H && wp < W;
+    px[t] = valid ? pos[(hp * W + wp) * 2] : 0.f;
+    py[t] = valid ? pos[(hp * W + wp) * 2 + 1] : 0.f;
+  }
+  __syncthreads();
+  if (head >= heads) return;
+  float rw1x[16], rw1y[16], rb1[16], rw2[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) { rw1x[m] = P.rp_w1[m * 2]; rw1y[m] = P.rp_w1[m * 2 + 1]; rb1[m] = P.rp_b1[m]; rw2[m] = P.rp_w2[head * 16 + m]; }
+  const float rb2 = P.rp_b2[head];
+  float* dst = tab + ((size_t)blockIdx.x * heads + head) * swv_bias_floats_per_window_head() + lane;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    const float mx = px[ti * 32 + li], my = py[ti * 32 + li];
+#pragma unroll 1
+    for (int k = 0; k < kBiasRegs; ++k) {
+      const int tj = k >> 4, r = k & 15;
+      const int j = tj * 32 + rowmap(r, lh);
+      const float dx = mx - px[j], dy = my - py[j];
+      float rp = rb2;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const float hdn = fmaf(rw1x[m], dx, fmaf(rw1y[m], dy, rb1[m]));
+        rp = fmaf(rw2[m], hdn > 0.f ? hdn : 0.f, rp);
+      }
+      dst[(ti * kBiasRegs + k) * 64] = rp;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
+size_t pn_swv_window_bias_floats(int h, int w, int heads, int window) {
+  if (window != WS || h < 1 || w < 1 || heads < 1 || heads > 4) return 0;
+  return (size_t)((h + WS - 1) / WS) * ((w + WS - 1) / WS) * heads * swv_bias_floats_per_window_head();
+}
+
+int pn_swv_window_bias_table(const float* pos, const float* rpe_w1, const float* rpe_b1, const float* rpe_w2, const float* rpe_b2, int h, int w, int heads,
+                             int window, int shift, float* table, pn_stream_t stream) {
+  PN_REQUIRE(pos && rpe_w1 && rpe_b1 && rpe_w2 && rpe_b2 && table, "swv_window_bias_table: null pointer");
+  PN_REQUIRE(window == WS && heads >= 1 && heads <= 4 && shift >= 0 && shift < WS && h >= 1 && w >= 1, "swv_window_bias_table: window 7, at most 4 heads");
+  SwvParams p{nullptr, nullptr, nullptr, nullptr, nullptr, rpe_w1, rpe_b1, rpe_w2, rpe_b2, nullptr};
+  const int nwh = (h + WS - 1) / WS, nww = (w + WS - 1) / WS;
+  hipLaunchKernelGGL(swv_window_bias_kernel, dim3(nwh * nww), dim3(256), 0, pn::S(stream), pos, p, h, w, heads, shift, table);
+  return pn::check_launch("swv_window_bias_kernel");
+}
+
 int pn_swv_window_attn(const float* qkv, const float* vote, int vote_pixel_stride, const float* pos, const float* qkv_bias,
                        const float* vote_w1, const float* vote_b1, const float* vote_w2, const float* vote_b2, const float* rpe_w1,
                        const float* rpe_b1, const float* rpe_w2, const float* rpe_b2, const float* tau, int batch, int h, int w, int c,
-                       int heads, int window, int shift, float* out, pn_stream_t stream) {
-  PN_REQUIRE(qkv && vote && pos && vote_w1 && vote_b1 && vote_w2 && vote_b2 && rpe_w1 && rpe_b1 && rpe_w2 && rpe_b2 && tau && out,
-             "swv_window_attn: null pointer");
+                       int heads, int window, int shift, const float* bias_table, float* out, pn_stream_t stream) {
+  PN_REQUIRE(qkv && vote && pos && vote_w1 && vote_b1 && vote_w2 && vote_b2 && tau && out, "swv_window_attn: null pointer");
+  PN_REQUIRE(bias_table || (rpe_w1 && rpe_b1 && rpe_w2 && rpe_b2), "swv_window_attn: the rpe weights or their bias table");
   PN_REQUIRE(window == WS && heads >= 1 && heads <= 4 && c == heads * HD, "swv_window_attn: built for window 7, head_dim 64 and at most 4 heads");
   PN_REQUIRE(shift >= 0 && shift < WS && batch >= 1 && h >= 1 && w >= 1 && vote_pixel_stride >= 3, "swv_window_attn: bad sizes");
   PN_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)vote_b2 & 15) == 0 && ((uintptr_t)qkv_bias & 15) == 0,
              "swv_window_attn: qkv, out, the vote bias and the qkv bias must be 16-byte aligned");
   SwvParams p{qkv_bias, vote_w1, vote_b1, vote_w2, vote_b2, rpe_w1, rpe_b1, rpe_w2, rpe_b2, tau};
   const int nwh = (h + WS - 1) / WS, nww = (w + WS - 1) / WS;
-  hipLaunchKernelGGL(swv_window_attn_kernel, dim3(nwh * nww, batch), dim3(256), 0, pn::S(stream), qkv, vote, vote_pixel_stride, pos,
-                     p, h, w, c, heads, shift, out);
+  if (bias_table)
+    hipLaunchKernelGGL(swv_window_attn_kernel<true>, dim3(nwh * nww, batch), dim3(256), 0, pn::S(stream), qkv, vote, vote_pixel_stride, pos, p, h, w, c,
+                       heads, shift, out, bias_table);
+  else
+    hipLaunchKernelGGL(swv_window_attn_kernel<false>, dim3(nwh * nww, batch), dim3(256), 0, pn::S(stream), qkv, vote, vote_pixel_stride, pos, p, h, w, c,
+                       heads, shift, out, bias_table);
   return pn::check_launch("swv_window_attn_kernel");
 }
 

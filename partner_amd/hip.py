@@ -113,6 +113,10 @@ SIGNATURES = {
     "pn_conv_packed_weight_bf16_elems": (_SZ, [_I, _I, _I, _I, _I]),
     "pn_pack_conv_weight_bf16": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "pn_conv2d_nhwc_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "pn_conv_bf16_rows_packed_elems": (_SZ, [_I, _I, _I, _I]),
+    "pn_pack_conv_weight_bf16_rows": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "pn_conv2d_igemm_bf16_supported": (_I, [_P]),
+    "pn_conv2d_igemm_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "pn_f32_to_bf16": (_I, [_P, _P, _SZ, _P]),
     "pn_bf16_to_f32": (_I, [_P, _P, _SZ, _P]),
     "pn_fold_bn_f32": (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _P]),
@@ -140,7 +144,9 @@ SIGNATURES = {
     "pn_setblock_sector_kp_attn": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "pn_setblock_range_attn": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "pn_setblock_sector_col_attn": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
-    "pn_swv_window_attn": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "pn_swv_window_attn": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "pn_swv_window_bias_floats": (_SZ, [_I, _I, _I, _I]),
+    "pn_swv_window_bias_table": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "pn_center_decode_nms_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "pn_center_decode_nms_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _P, _F, _I, _I, _I,
                                       _P, _P, _P, _P, _P, _P, _SZ, _P]),

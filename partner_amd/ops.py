@@ -428,6 +428,7 @@ class ConvLayer:
                 wc = w.permute(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1).contiguous()  # row (2*di+dj)*Cout + n
                 self.packed = torch.empty(lib.pn_conv_packed_weight_bf16_elems(4 * cout, cin, 1, 1, 1), dtype=torch.bfloat16, device=dev)
                 hip.call("pn_pack_conv_weight_bf16", wc.data_ptr(), 4 * cout, cin, 1, 1, 1, self.packed.data_ptr(), st)
+                self._pack_bf16_rows(lib, wc, 4 * cout, cin, 1, 1, st)
             else:
                 pack_groups = self.range_strata if self.range_strata > 1 else self.groups
                 cout_t, cin_g, kh, kw = w.shape
@@ -435,6 +436,8 @@ class ConvLayer:
                 self.packed = torch.empty(lib.pn_conv_packed_weight_bf16_elems(self.cout, cin_g, kh, kw, pack_groups), dtype=torch.bfloat16,
                                           device=dev)
                 hip.call("pn_pack_conv_weight_bf16", w.data_ptr(), cout_t, cin_g, kh, kw, pack_groups, self.packed.data_ptr(), st)
+                if pack_groups == 1:
+                    self._pack_bf16_rows(lib, w, cout_t, cin_g, kh, kw, st)
         elif deconv2x2:
             cin, cout = w.shape[0], w.shape[1]
             assert tuple(w.shape[2:]) == (2, 2)
@@ -481,6 +484,14 @@ class ConvLayer:
             self.tap_n = (9 * self.cout + 3) // 4 * 4
             self.tap_packed = _f32(lib.pn_linear_packed_weight_floats(self.tap_n, self.cin), dev)
             self._pack_taps(w)
+
+    def _pack_bf16_rows(self, lib, w: torch.Tensor, rows: int, cin: int, kh: int, kw: int, st) -> None:
+        """the [row][tap][cin] weights of the bf16 implicit-GEMM kernel (csrc/conv_bf16.hip, r5): the layers of the Waymo BEV maps -- cin a
+        multiple of 64, cout of 16 -- run there, every other bf16 layer on the general kernel (pn_conv2d_nhwc_bf16)"""
+        self.packed_rows = None
+        if cin % 64 == 0 and self.cout % 16 == 0 and self.act in (ACT_NONE, ACT_RELU):
+            self.packed_rows = torch.empty(lib.pn_conv_bf16_rows_packed_elems(rows, cin, kh, kw), dtype=torch.bfloat16, device=w.device)
+            hip.call("pn_pack_conv_weight_bf16_rows", w.data_ptr(), rows, cin, kh, kw, self.packed_rows.data_ptr(), st)
 
     def chain_weights(self, two_d: bool, transposed: bool) -> torch.Tensor:
         """packed weights of the chained F(4,3) / F(2,3)xF(4,3) forms; ``transposed``: of the kernel with kh and kw swapped (the chain then runs
@@ -610,8 +621,13 @@ class ConvLayer:
             prof = _PROFILER
             if prof is not None:
                 ev = prof.begin(st)
-            hip.call("pn_conv2d_nhwc_bf16", C.byref(d), x.data_ptr(), self.packed.data_ptr(), hip.ptr(self.scale), hip.ptr(self.shift),
-                     out.data_ptr(), int(out.dtype == torch.float32), st)
+            igemm = getattr(self, "packed_rows", None) is not None and hip.load().pn_conv2d_igemm_bf16_supported(C.byref(d)) == 1
+            if igemm:
+                hip.call("pn_conv2d_igemm_bf16", C.byref(d), x.data_ptr(), self.packed_rows.data_ptr(), hip.ptr(self.scale), hip.ptr(self.shift),
+                         out.data_ptr(), int(out.dtype == torch.float32), st)
+            else:
+                hip.call("pn_conv2d_nhwc_bf16", C.byref(d), x.data_ptr(), self.packed.data_ptr(), hip.ptr(self.scale), hip.ptr(self.shift),
+                         out.data_ptr(), int(out.dtype == torch.float32), st)
             if prof is not None:
                 macs = b * h * w * 4 * self.cout * self.cin if self.deconv2x2 else b * oh * ow * self.groups * self.cout * self.cin * self.kh * self.kw
                 prof.end(ev, 2.0 * macs, st, tag=f"{oh}x{ow} {self.cin * self.groups}->{self.out_channels} k{self.kh} bf16")

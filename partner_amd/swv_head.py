@@ -206,6 +206,19 @@ class E2ESWVoteHead(nn.Module):
                 vw2=f(a.vote_mlp[2].weight).view(-1, 16), vb2=f(a.vote_mlp[2].bias), rw1=f(a.rpe[0].weight).view(16, 2), rb1=f(a.rpe[0].bias),
                 rw2=f(a.rpe[2].weight).view(-1, 16), rb2=f(a.rpe[2].bias), tau=f(a.tau).view(-1), shift=blk.shift_size, mod=blk))
         plan["pos"] = self.offset_grid[0].permute(1, 2, 0).contiguous().float()  # (H, W, 2)
+        # the relative-position bias of every (window, head, query, key): a function of the cell positions and the rpe weights only, built
+        # here once per set of weights (pn_swv_window_bias_table) in the attention kernel's accumulator layout
+        lib = hip.load()
+        hh, ww = plan["pos"].shape[:2]
+        for bp in plan["blocks"]:
+            heads = bp["rw2"].shape[0]
+            n = lib.pn_swv_window_bias_floats(hh, ww, heads, self.window_size)
+            bp["bias_table"] = None
+            if n > 0 and plan["pos"].is_cuda:
+                tab = torch.empty(n, dtype=torch.float32, device=plan["pos"].device)
+                hip.call("pn_swv_window_bias_table", plan["pos"].data_ptr(), bp["rw1"].data_ptr(), bp["rb1"].data_ptr(), bp["rw2"].data_ptr(),
+                         bp["rb2"].data_ptr(), hh, ww, heads, self.window_size, int(bp["shift"]), tab.data_ptr(), hip.stream())
+                bp["bias_table"] = tab
         return plan
 
     def forward_nhwc(self, x: torch.Tensor):
@@ -263,7 +276,7 @@ class E2ESWVoteHead(nn.Module):
         hip.call("pn_swv_window_attn", qkv.data_ptr(), vote.data_ptr(), 4, plan["pos"].data_ptr(), hip.ptr(bp["qkv_bias"]),
                  bp["vw1"].data_ptr(), bp["vb1"].data_ptr(), bp["vw2"].data_ptr(), bp["vb2"].data_ptr(), bp["rw1"].data_ptr(),
                  bp["rb1"].data_ptr(), bp["rw2"].data_ptr(), bp["rb2"].data_ptr(), bp["tau"].data_ptr(), b, h, w, C, heads, ws,
-                 int(bp["shift"]), att.data_ptr(), hip.stream())
+                 int(bp["shift"]), hip.ptr(bp.get("bias_table")), att.data_ptr(), hip.stream())
         t = bp["proj"](att, residual=t)
         z = ops.layernorm(t, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
         return bp["fc2"](bp["fc1"](z, act=ops.ACT_GELU), residual=t)

@@ -18,6 +18,6 @@ for prec in ("f32", "option_bf16_bev_convs"):
     o = out[prec]
     print(f"{prec}: {o['ms_per_step']} ms per step, {o['frames_per_s']} frames/s")
     for k, v in o["stages"].items():
-        print(f"   {k:16s} {v['ms']:8.3f} ms" + (f"   issued {v['gflop_issued']:7.1f} GFLOP  {v['tflops_issued']:6.1f} TF  frac {v['frac']:.3f}  (mfma kernels {v['mfma_kernel_ms']:.3f} ms, {v['mfma_launches']} launches)" if "frac" in v else ""))
+        print(f"   {k:16s} {v['ms']:8.3f} ms" + (f"   issued {v['gflop_issued']:7.1f} GFLOP  {v['tflops_issued']:6.1f} TF  frac {v['frac']:.3f}  (mfma kernels {v['mfma_kernel_ms']:.3f} ms, {v['mfma_launches']} launches)" if "mfma_kernel_ms" in v else (f"   frac {v['frac']:.3f}" if "frac" in v else "")))
 if "--json" in sys.argv:
     print(json.dumps(out))
