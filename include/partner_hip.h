@@ -346,6 +346,12 @@ int pn_pack_conv_weight_bf16_rows(const float *w_oihw, int cout_total, int cin, 
 int pn_conv2d_igemm_bf16_supported(const pn_conv_desc *desc);
 int pn_conv2d_igemm_bf16(const pn_conv_desc *desc, const void *in_bf16, const void *packed_rows_bf16, const float *scale,
                          const float *shift, void *out, int out_is_f32, pn_stream_t stream);
+/* nn.Linear on the same kernel (bf16 option of the SetBlock / Swin token GEMMs, det3d/models/utils/set_transformer.py:37-53,118-166 and
+ * swin_utils/sw2votev4_util.py qkv / proj / Mlp): out[m][:n] = act(x[m][:k] @ W^T + bias) (+ residual[m][:n]).  x: bf16 rows of ldx
+ * elements; W: pn_pack_conv_weight_bf16_rows(w (n, k), n, k, 1, 1); k a multiple of 64, n of 16; act PN_ACT_NONE | RELU | GELU (exact
+ * erf); residual: f32, only with the f32 output.  out: bf16 or f32 rows of ldo elements. */
+int pn_linear_bf16(const void *x_bf16, int m, int k, int ldx, const void *packed_rows_bf16, int n, const float *bias, int act,
+                   const float *residual, int ldr, void *out, int ldo, int out_is_f32, pn_stream_t stream);
 int pn_f32_to_bf16(const float *x, void *y, size_t n, pn_stream_t stream);
 int pn_bf16_to_f32(const void *x, float *y, size_t n, pn_stream_t stream);
 
@@ -539,6 +545,9 @@ int pn_linear_set_tile(int form);
 /* nn.LayerNorm over C; chan_mean (rows) optional = mean_C(out)  (set_transformer.py:121,135) */
 int pn_layernorm_f32(const float *x, size_t rows, int c, const float *gamma, const float *beta,
                      float eps, float *out, float *chan_mean, pn_stream_t stream);
+/* the same rows with a bf16 copy (round to nearest even) for pn_linear_bf16; out_f32 may be NULL when only the copy is consumed */
+int pn_layernorm_bf16out_f32(const float *x, size_t rows, int c, const float *gamma, const float *beta, float eps, float *out_f32,
+                             void *out_bf16, float *chan_mean, pn_stream_t stream);
 /* Token order of the three column-wise entries below: col_major = 0: range-major (B, H, W) tokens, the reference's order
  * (set_transformer.py:118-131); col_major = 1: azimuth-major (B, W, H) tokens -- the order the dense BEV map arrives in (NHWC, theta
  * outermost), every azimuth column one contiguous slab, no transpose around the blocks (voxelnet.py:211,219 permute instead). */

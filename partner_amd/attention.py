@@ -102,6 +102,15 @@ class SetBlock(nn.Module):
         self.attns = SetAttention(in_dim, reso, H_sp=H_sp, W_sp=W_sp, H=H, W=W, num_heads=num_heads, mlp_ratio=mlp_ratio,
                                   qkv_bias=qkv_bias, qk_scale=qk_scale, norm_layer=norm_layer, act_layer=act_layer, shift=shift)
         self._plan = PlanCache()
+        self.compute_dtype = "f32"
+
+    def set_compute_dtype(self, dtype: str) -> "SetBlock":
+        """"f32" (default, the reference's arithmetic) or "bf16": the five token GEMMs over all H x W tokens (key / value and query
+        projections, output projection, the MLP) on the bf16 matrix pipe (pn_linear_bf16: bf16 operands, f32 accumulation; LayerNorm,
+        attention cores, the key-point chain, bias / GELU / residuals stay f32).  The option of BASELINE configs[3]; not the parity path."""
+        assert dtype in ("f32", "bf16")
+        self.compute_dtype = dtype
+        return self
 
     def _build_plan(self):
         a = self.attns
@@ -150,7 +159,12 @@ class SetBlock(nn.Module):
         cm = int(col_major)
         ln = lambda t, n: ops.layernorm(t, n.weight.detach(), n.bias.detach(), n.eps)  # noqa: E731
         x2 = x.contiguous().view(B * L, C).float()
-        xn, cmean = ops.layernorm(x2, a.norm1.weight.detach(), a.norm1.bias.detach(), a.norm1.eps, want_chan_mean=True)
+        b16 = self.compute_dtype == "bf16" and C % 64 == 0
+        if b16:
+            xn, cmean, xn_in = ops.layernorm(x2, a.norm1.weight.detach(), a.norm1.bias.detach(), a.norm1.eps, want_chan_mean=True, bf16_copy=True)
+        else:
+            xn, cmean = ops.layernorm(x2, a.norm1.weight.detach(), a.norm1.bias.detach(), a.norm1.eps, want_chan_mean=True)
+            xn_in = xn
         dev = x.device
         top = torch.empty((B, K, W), dtype=torch.int32, device=dev)
         kp = torch.empty((B * K * W, C), dtype=torch.float32, device=dev)
@@ -159,7 +173,7 @@ class SetBlock(nn.Module):
                  kp.data_ptr(), kpos.data_ptr(), st)
         self.last_top_idx = top
         # sector attention 1: key points <- column
-        q1, kv1 = p["s1_q"](kp), p["s1_kv"](xn)
+        q1, kv1 = p["s1_q"](kp), p["s1_kv"](xn_in)
         o1 = torch.empty_like(kp)
         hip.call("pn_setblock_sector_kp_attn", q1.data_ptr(), kv1.data_ptr(), p["pos"].data_ptr(), kpos.data_ptr(),
                  p["s1_pe"].data_ptr(), B, H, W, C, heads, K, sh, cm, float(a.scale), o1.data_ptr(), st)
@@ -175,10 +189,15 @@ class SetBlock(nn.Module):
         # sector attention 2: column <- key points
         # (measured and dropped, r3: the query projection on a second stream beside the key-point chain -- one block per CU so that the
         # chain's kernels still get dispatched -- 1.442 against 1.423 ms for the two blocks in one hipGraph: nothing to win)
-        q3, kv3 = p["s2_q"](xn), p["s2_kv"](s2)
+        q3, kv3 = p["s2_q"](xn_in), p["s2_kv"](s2)
         o3 = torch.empty_like(x2)
         hip.call("pn_setblock_sector_col_attn", q3.data_ptr(), kv3.data_ptr(), p["pos"].data_ptr(), kpos.data_ptr(),
                  p["s2_pe"].data_ptr(), B, H, W, C, heads, K, sh, cm, float(a.scale), o3.data_ptr(), st)
+        if b16:
+            y = p["proj"](ops.to_bf16(o3), residual=x2)
+            z16 = ops.layernorm(y, a.norm2.weight.detach(), a.norm2.bias.detach(), a.norm2.eps, bf16_copy=True, f32_out=False)
+            y = p["mlp"][1](p["mlp"][0](z16, act=ops.ACT_GELU, out_bf16=True), residual=y)
+            return y.view(B, L, C)
         y = p["proj"](o3, residual=x2)
         y = p["mlp"][1](p["mlp"][0](ln(y, a.norm2), act=ops.ACT_GELU), residual=y)
         return y.view(B, L, C)

@@ -26,10 +26,17 @@ __device__ __forceinline__ size_t tok(int b, int h, int w, int H, int W, int cm)
 // LayerNorm over the channel axis, one wavefront per token row.  NPL > 0: the row (c = 64 NPL values) stays in registers -- one pass
 // over memory, NPL loads in flight per lane; element -> lane assignment and summation order are those of the generic loop (NPL = 0),
 // so both give the same bits.
+__device__ __forceinline__ unsigned short ln_bf16_bits(float f) {      // round to nearest even (the conversion of pn_f32_to_bf16)
+  unsigned u = __builtin_bit_cast(unsigned, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
 template <int NPL>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, size_t rows, int c, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, float* __restrict__ out,
-                                                        float* __restrict__ chan_mean) {
+                                                        float* __restrict__ chan_mean, unsigned short* __restrict__ out16) {
   const int lane = threadIdx.x & 63;
   const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -52,7 +59,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
       const float y = (v[j] - mean) * rstd * g[j] + be[j];
-      out[row * c + lane + 64 * j] = y;
+      if (out) out[row * c + lane + 64 * j] = y;
+      if (out16) out16[row * c + lane + 64 * j] = ln_bf16_bits(y);
       acc += y;
     }
     if (chan_mean) {
@@ -72,7 +80,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     float acc = 0.f;
     for (int k = lane; k < c; k += 64) {
       const float y = (xr[k] - mean) * rstd * gamma[k] + beta[k];
-      out[row * c + k] = y;
+      if (out) out[row * c + k] = y;
+      if (out16) out16[row * c + k] = ln_bf16_bits(y);
       acc += y;
     }
     if (chan_mean) {
@@ -471,21 +480,33 @@ __global__ __launch_bounds__(1024) void sector_col_attn_kernel(const float* __re
 
 extern "C" {
 
-int pn_layernorm_f32(const float* x, size_t rows, int c, const float* gamma, const float* beta, float eps, float* out,
-                     float* chan_mean, pn_stream_t stream) {
-  PN_REQUIRE(x && gamma && beta && out && c >= 1, "layernorm: bad arguments");
+static int layernorm_run(const float* x, size_t rows, int c, const float* gamma, const float* beta, float eps, float* out, float* chan_mean,
+                         unsigned short* out16, pn_stream_t stream) {
   if (rows == 0) return PN_OK;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t st = pn::S(stream);
   switch (c % 64 == 0 ? c / 64 : 0) {      // register-resident rows for the channel counts of the model (64 .. 1024)
-    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean); break;
-    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean); break;
-    case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean); break;
-    case 8: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean); break;
-    case 16: hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean); break;
-    default: hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean); break;
+    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean, out16); break;
+    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean, out16); break;
+    case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean, out16); break;
+    case 8: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean, out16); break;
+    case 16: hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean, out16); break;
+    default: hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, st, x, rows, c, gamma, beta, eps, out, chan_mean, out16); break;
   }
   return pn::check_launch("layernorm_kernel");
+}
+
+int pn_layernorm_f32(const float* x, size_t rows, int c, const float* gamma, const float* beta, float eps, float* out,
+                     float* chan_mean, pn_stream_t stream) {
+  PN_REQUIRE(x && gamma && beta && out && c >= 1, "layernorm: bad arguments");
+  return layernorm_run(x, rows, c, gamma, beta, eps, out, chan_mean, nullptr, stream);
+}
+
+// the same rows with a bf16 copy of the result for the bf16 GEMMs (pn_linear_bf16); out_f32 may be null when only the copy is consumed
+int pn_layernorm_bf16out_f32(const float* x, size_t rows, int c, const float* gamma, const float* beta, float eps, float* out_f32, void* out_bf16,
+                             float* chan_mean, pn_stream_t stream) {
+  PN_REQUIRE(x && gamma && beta && out_bf16 && c >= 1, "layernorm_bf16out: bad arguments");
+  return layernorm_run(x, rows, c, gamma, beta, eps, out_f32, chan_mean, static_cast<unsigned short*>(out_bf16), stream);
 }
 
 int pn_setblock_keypoints(const float* chan_mean, const float* xn, const float* pos, int batch, int h, int w, int c, int k,

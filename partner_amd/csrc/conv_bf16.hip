@@ -44,7 +44,26 @@ struct CbArgs {
   int Kw;                                             // elements per packed weight row = taps x cin
   int ptiles, ctiles;
   unsigned in_bytes, w_bytes;
+  const float* res;                                   // GEMM use (pn_linear_bf16): f32 residual rows added after the activation, f32 output only
+  int res_ps;
 };
+
+// exact-erf GELU as in linear.hip (erfc by a Chebyshev fit, |gelu - exact| < 3e-7 max(|x|, 1)): the f32 and the bf16 GEMMs share it
+__device__ __forceinline__ float cb_gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.5f, z, 1.f));
+  float p = fmaf(t, 0.17087277f, -0.82215223f);
+  p = fmaf(t, p, 1.48851587f);
+  p = fmaf(t, p, -1.13520398f);
+  p = fmaf(t, p, 0.27886807f);
+  p = fmaf(t, p, -0.18628806f);
+  p = fmaf(t, p, 0.09678418f);
+  p = fmaf(t, p, 0.37409196f);
+  p = fmaf(t, p, 1.00002368f);
+  p = fmaf(t, p, -1.26551223f);
+  const float e = t * __builtin_amdgcn_exp2f(fmaf(-z, z, p) * 1.44269504088896341f);
+  return 0.5f * x * (x >= 0.f ? 2.f - e : e);
+}
 
 __host__ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
   unsigned u = __builtin_bit_cast(unsigned, f);
@@ -59,7 +78,19 @@ __host__ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
 constexpr unsigned kOob = 0x80000000u;      // beyond every buffer this kernel is handed (sizes < 2 GiB are required)
 
 // WP x WC waves; a wave owns (PT x 16) pixels x (CT x 16) output channels
-template <int WP, int WC, int PT, int CT, bool F32OUT>
+// NS stages: 2 = the loads of step s + 1 fly during step s (two blocks per CU cover each other's waits); 4 = three steps ahead with counted
+// vmcnt, for launches of at most one block per CU (the block then has the CU's LDS to itself)
+#define CB_WAIT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+__device__ __forceinline__ void cb_wait_vmcnt(int n) {      // n is wave-uniform
+  switch (n) {
+    CB_WAIT_CASE(0) CB_WAIT_CASE(1) CB_WAIT_CASE(2) CB_WAIT_CASE(3) CB_WAIT_CASE(4) CB_WAIT_CASE(5) CB_WAIT_CASE(6) CB_WAIT_CASE(7) CB_WAIT_CASE(8)
+    CB_WAIT_CASE(9) CB_WAIT_CASE(10) CB_WAIT_CASE(11) CB_WAIT_CASE(12) CB_WAIT_CASE(13) CB_WAIT_CASE(14) CB_WAIT_CASE(15) CB_WAIT_CASE(16)
+    CB_WAIT_CASE(17) CB_WAIT_CASE(18) CB_WAIT_CASE(19) CB_WAIT_CASE(20) CB_WAIT_CASE(21) CB_WAIT_CASE(22) CB_WAIT_CASE(23) CB_WAIT_CASE(24)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+template <int WP, int WC, int PT, int CT, bool F32OUT, int NS>
 __global__ __launch_bounds__(WP* WC * 64) void conv_bf16_igemm_kernel(const CbArgs a) {
   constexpr int NW = WP * WC;
   constexpr int BP = WP * PT * 16, BC = WC * CT * 16;
@@ -148,12 +179,25 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_bf16_igemm_kernel(const CbAr
     for (int j = 0; j < PT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   bf16x8 wf[2][CT], pf[2][PT];
-  issue(0, 0);
+  constexpr int D = NS - 1;                    // prefetch distance in steps
+  int nw_loads = 0;                            // LDS-DMA instructions this wave issues per stage
+#pragma unroll
+  for (int j = 0; j < NPI; ++j) nw_loads += (wv + j * NW < PI);
+#pragma unroll
+  for (int j = 0; j < NCI; ++j) nw_loads += (wv + j * NW < CI);
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < a.ksteps) issue(d, d);
   for (int s = 0; s < a.ksteps; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (s + 1 < a.ksteps) issue(s + 1, (s + 1) & 1);
-    const char* st = smem + (s & 1) * STAGE;
+    if constexpr (NS == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    } else {
+      cb_wait_vmcnt(min(D - 1, a.ksteps - 1 - s) * nw_loads);      // the stages requested after step s's may stay in flight
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (s + D < a.ksteps) issue(s + D, (s + D) % NS);
+    const char* st = smem + (s % NS) * STAGE;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (!((PN_CB_EXP & 8) && s > 0)) {
@@ -181,7 +225,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_bf16_igemm_kernel(const CbAr
     // instead of 8-byte pieces.  Output pixels of a tile are consecutive in memory (linear pixel index).
     constexpr int EB = F32OUT ? 4 : 2;
     constexpr int ROWB = BC * EB + 16;
-    constexpr int PASSES = (BP * ROWB + 2 * STAGE - 1) / (2 * STAGE);          // 1, or 2 for f32 rows
+    constexpr int PASSES = (BP * ROWB + 2 * STAGE - 1) / (2 * STAGE);          // 1, or 2 for f32 rows (sized for the two-stage form)
     constexpr int PTP = (PT + PASSES - 1) / PASSES;                            // pixel tiles of a wave per pass
     constexpr int SEGS = BC * EB / 16;
     __syncthreads();
@@ -204,6 +248,9 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_bf16_igemm_kernel(const CbAr
           if (a.act == PN_ACT_RELU) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+          } else if (a.act == PN_ACT_GELU) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = cb_gelu_erf(v[k]);
           }
           char* dst = smem + pl * ROWB + nl * EB;
           if constexpr (F32OUT) {
@@ -223,7 +270,13 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_bf16_igemm_kernel(const CbAr
         const int jt = pass * PTP + rest / 16;
         const int m = m0 + (w_ * PT + jt) * 16 + (rest & 15);
         if (jt >= PT || m >= a.M || seg >= nseg) continue;
-        const uint4 val = *reinterpret_cast<const uint4*>(smem + pl * ROWB + seg * 16);
+        uint4 val = *reinterpret_cast<const uint4*>(smem + pl * ROWB + seg * 16);
+        if constexpr (F32OUT) {
+          if (a.res) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(a.res + (size_t)m * (size_t)a.res_ps + n0 + seg * 4);
+            val = __builtin_bit_cast(uint4, __builtin_bit_cast(f32x4, val) + r);
+          }
+        }
         char* o = static_cast<char*>(a.out) + ((size_t)m * (size_t)a.out_ps + a.out_co + n0) * EB + seg * 16;
         *reinterpret_cast<uint4*>(o) = val;
       }
@@ -391,10 +444,12 @@ __global__ __launch_bounds__(kRowsWaves * 64) void conv_bf16_rows_kernel(const C
         }
       }
       if (!(PN_CB_EXP & 4)) {
+        if (PN_CB_EXP & 128) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < CT; ++i)
 #pragma unroll
           for (int j = 0; j < PT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[h][i], pf[h][j], acc[i][j], 0, 0, 0);
+        if (PN_CB_EXP & 128) __builtin_amdgcn_s_setprio(0);
       } else {
 #pragma unroll
         for (int i = 0; i < CT; ++i) acc[i][0][0] += (float)wf[h][i][0] + (float)pf[h][i % PT][1];
@@ -532,28 +587,32 @@ __global__ void pack_conv_weight_bf16_rows_kernel(const float* __restrict__ w, i
 
 struct CbTile { int wp, wc, pt, ct; };
 
+template <int WP, int WC, int PT, int CT, bool F32OUT, int NS>
+int launch_tile_ns(CbArgs& a, hipStream_t st) {
+  constexpr int BP = WP * PT * 16, BC = WC * CT * 16;
+  static const int lds_pad = [] { const char* e = getenv("PN_CB_LDS_PAD"); return e ? atoi(e) : 0; }();      // diagnostic: forces one block per CU
+  const int lds = NS * (BP + BC) * 128 + lds_pad;
+  auto kern = conv_bf16_igemm_kernel<WP, WC, PT, CT, F32OUT, NS>;
+  static bool attr[64] = {};
+  if (pn::first_use_on_device(attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  pn::ProfileSlot ps{};
+  if (pn::take_profile_slot(ps)) hipExtLaunchKernelGGL(kern, dim3((unsigned)(a.ptiles * a.ctiles)), dim3(WP * WC * 64), lds, st, ps.start, ps.stop, 0, a);
+  else hipLaunchKernelGGL(kern, dim3((unsigned)(a.ptiles * a.ctiles)), dim3(WP * WC * 64), lds, st, a);
+  return pn::check_launch("conv_bf16_igemm_kernel");
+}
+
 template <int WP, int WC, int PT, int CT>
 int launch_tile(CbArgs& a, bool f32out, hipStream_t st) {
   constexpr int BP = WP * PT * 16, BC = WC * CT * 16;
-  static const int lds_pad = [] { const char* e = getenv("PN_CB_LDS_PAD"); return e ? atoi(e) : 0; }();      // diagnostic: forces one block per CU
-  const int lds = 2 * (BP + BC) * 128 + lds_pad;
   a.ptiles = pn::cdiv(a.M, BP);
   a.ctiles = pn::cdiv(a.N, BC);
-  static bool attr_f32[64] = {}, attr_b16[64] = {};
-  if (f32out) {
-    auto kern = conv_bf16_igemm_kernel<WP, WC, PT, CT, true>;
-    if (pn::first_use_on_device(attr_f32)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    pn::ProfileSlot ps{};
-    if (pn::take_profile_slot(ps)) hipExtLaunchKernelGGL(kern, dim3((unsigned)(a.ptiles * a.ctiles)), dim3(WP * WC * 64), lds, st, ps.start, ps.stop, 0, a);
-    else hipLaunchKernelGGL(kern, dim3((unsigned)(a.ptiles * a.ctiles)), dim3(WP * WC * 64), lds, st, a);
-  } else {
-    auto kern = conv_bf16_igemm_kernel<WP, WC, PT, CT, false>;
-    if (pn::first_use_on_device(attr_b16)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    pn::ProfileSlot ps{};
-    if (pn::take_profile_slot(ps)) hipExtLaunchKernelGGL(kern, dim3((unsigned)(a.ptiles * a.ctiles)), dim3(WP * WC * 64), lds, st, ps.start, ps.stop, 0, a);
-    else hipLaunchKernelGGL(kern, dim3((unsigned)(a.ptiles * a.ctiles)), dim3(WP * WC * 64), lds, st, a);
+  // at most one block per CU: four stages, three steps of loads in flight (PN_CONV_BF16_STAGES=2 / 4 forces a form)
+  static const int forced = [] { const char* e = getenv("PN_CONV_BF16_STAGES"); return e ? atoi(e) : 0; }();
+  const bool deep = forced ? forced == 4 : (a.ptiles * a.ctiles <= 256 && a.ksteps >= 4);
+  if constexpr (4 * (BP + BC) * 128 <= 160 * 1024) {
+    if (deep) return f32out ? launch_tile_ns<WP, WC, PT, CT, true, 4>(a, st) : launch_tile_ns<WP, WC, PT, CT, false, 4>(a, st);
   }
-  return pn::check_launch("conv_bf16_igemm_kernel");
+  return f32out ? launch_tile_ns<WP, WC, PT, CT, true, 2>(a, st) : launch_tile_ns<WP, WC, PT, CT, false, 2>(a, st);
 }
 
 // tile id: 0 = 144 px x 128 ch (6 waves), 1 = 144 x 64 (3 waves), 2 = 128 x 128 (4 waves), 3 = 128 x 64 (2 waves)
@@ -639,6 +698,35 @@ int pn_conv2d_igemm_bf16(const pn_conv_desc* d, const void* in_bf16, const void*
     r.kchunks = a.kchunks; r.ksteps = a.ksteps; r.Kw = a.Kw; r.in_bytes = a.in_bytes; r.w_bytes = a.w_bytes;
     return launch_rows(d, r, out_is_f32 != 0, st);
   }
+  switch (pick_tile(a)) {
+    case 0: return launch_tile<3, 2, 3, 4>(a, out_is_f32 != 0, st);
+    case 1: return launch_tile<3, 1, 3, 4>(a, out_is_f32 != 0, st);
+    case 2: return launch_tile<2, 2, 4, 4>(a, out_is_f32 != 0, st);
+    default: return launch_tile<2, 1, 4, 4>(a, out_is_f32 != 0, st);
+  }
+}
+
+// nn.Linear on the same kernel (a 1x1 convolution over m "pixels"): out[m][:n] = act(x[m][:k] @ W^T + bias) (+ residual[m][:n], f32 output only).
+// x: bf16 rows of ldx elements; W: pn_pack_conv_weight_bf16_rows(w (n, k), n, k, 1, 1); act none / ReLU / GELU (exact erf)
+int pn_linear_bf16(const void* x_bf16, int m, int k, int ldx, const void* packed_rows_bf16, int n, const float* bias, int act, const float* residual,
+                   int ldr, void* out, int ldo, int out_is_f32, pn_stream_t stream) {
+  PN_REQUIRE(x_bf16 && packed_rows_bf16 && out && m >= 1, "linear_bf16: null pointer");
+  PN_REQUIRE(k >= 64 && k % 64 == 0 && n >= 16 && n % 16 == 0 && ldx >= k && ldx % 8 == 0 && ldo >= n && ldo % 4 == 0,
+             "linear_bf16: k a multiple of 64, n of 16, ldx of 8, ldo of 4");
+  PN_REQUIRE(act == PN_ACT_NONE || act == PN_ACT_RELU || act == PN_ACT_GELU, "linear_bf16: activation none, ReLU or GELU");
+  PN_REQUIRE(!residual || (out_is_f32 && ldr >= n && ldr % 4 == 0), "linear_bf16: a residual needs the f32 output and ldr a multiple of 4");
+  PN_REQUIRE(((uintptr_t)x_bf16 & 15) == 0 && ((uintptr_t)packed_rows_bf16 & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)bias & 15) == 0 &&
+                 ((uintptr_t)residual & 15) == 0,
+             "linear_bf16: pointers must be 16-byte aligned");
+  CbArgs a{};
+  a.in = x_bf16; a.w = packed_rows_bf16; a.scale = nullptr; a.shift = bias; a.out = out;
+  a.B = 1; a.H = 1; a.W = m; a.OH = 1; a.OW = m; a.cin = k; a.cout = n; a.kh = a.kw = 1; a.stride = 1;
+  a.in_ps = ldx; a.out_ps = ldo; a.act = act; a.M = m; a.N = n; a.kchunks = k / 64; a.ksteps = a.kchunks; a.Kw = k;
+  a.res = residual; a.res_ps = ldr;
+  const unsigned long long in_bytes = (unsigned long long)m * ldx * 2ull, w_bytes = (unsigned long long)((n + 15) / 16 * 16) * k * 2ull;
+  PN_REQUIRE(in_bytes < (1ull << 31) && w_bytes < (1ull << 31), "linear_bf16: matrix too large for the buffer descriptor");
+  a.in_bytes = (unsigned)in_bytes; a.w_bytes = (unsigned)w_bytes;
+  hipStream_t st = pn::S(stream);
   switch (pick_tile(a)) {
     case 0: return launch_tile<3, 2, 3, 4>(a, out_is_f32 != 0, st);
     case 1: return launch_tile<3, 1, 3, 4>(a, out_is_f32 != 0, st);

@@ -456,6 +456,23 @@ class VoxelNetV3(SingleStageDetector):
                      H_sp=144, W_sp=1, H=4, W=8, drop=0.1, attn_drop=0.1, drop_path=0.1, norm_layer=nn.LayerNorm,
                      pos=self.bev_pos, shift=(i % 2 == 1)) for i in range(2)])
 
+    def set_compute_dtype(self, dtype: str) -> "VoxelNetV3":
+        """"f32" (default: the reference's arithmetic, the parity path) or "bf16" (BASELINE configs[3]): the dense BEV stages on the bf16
+        matrix pipe -- the RPN's and the head's convolutions (csrc/conv_bf16.hip) and the token GEMMs of the SetBlocks and of the head's
+        Swin stage (pn_linear_bf16) -- with f32 accumulation; voxelization, the sparse encoder, LayerNorm / attention cores / GroupNorm,
+        residual streams and every output stay f32."""
+        assert dtype in ("f32", "bf16")
+        # Only the LAST SetBlock: a block's output feeds the next block's key-point selection (top-4 local maxima per azimuth column, a discrete
+        # choice among near-ties), and a bf16-sized perturbation of block 0's output flips enough of block 1's key points to move the head
+        # tensors by 7 % of their range (measured, seeded weights) -- block 0 therefore stays f32; inside the last block the selection reads the
+        # f32 LayerNorm output before any bf16 product.
+        for i, attn in enumerate(self.attns):
+            attn.set_compute_dtype(dtype if i == len(self.attns) - 1 else "f32")
+        if self.with_neck:
+            self.neck.set_compute_dtype(dtype)
+        self.bbox_head.set_compute_dtype(dtype)
+        return self
+
     def realign(self, x: torch.Tensor) -> torch.Tensor:
         """x: logical (B, C=256, theta=256, r=144) dense BEV map -> same shape (voxelnet.py:210-221)"""
         hip.require_device(x)

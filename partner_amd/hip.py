@@ -117,6 +117,7 @@ SIGNATURES = {
     "pn_pack_conv_weight_bf16_rows": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "pn_conv2d_igemm_bf16_supported": (_I, [_P]),
     "pn_conv2d_igemm_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "pn_linear_bf16": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P]),
     "pn_f32_to_bf16": (_I, [_P, _P, _SZ, _P]),
     "pn_bf16_to_f32": (_I, [_P, _P, _SZ, _P]),
     "pn_fold_bn_f32": (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _P]),
@@ -140,6 +141,7 @@ SIGNATURES = {
     "pn_groupnorm_strat_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "pn_gemm_bias_act_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),
     "pn_layernorm_f32": (_I, [_P, _SZ, _I, _P, _P, _F, _P, _P, _P]),
+    "pn_layernorm_bf16out_f32": (_I, [_P, _SZ, _I, _P, _P, _F, _P, _P, _P, _P]),
     "pn_setblock_keypoints": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "pn_setblock_sector_kp_attn": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "pn_setblock_range_attn": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P]),

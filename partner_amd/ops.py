@@ -1106,14 +1106,35 @@ class GemmLayer:
             self.packed = _f32(lib.pn_conv_packed_weight_floats(self.n, self.k, 1, 1, 1), w.device)
             hip.call("pn_pack_conv_weight_f32", w.data_ptr(), self.n, self.k, 1, 1, 1, self.packed.data_ptr(), hip.stream())
         self.bias = None if bias is None else bias.detach().contiguous().float()
+        self._w_f32 = w                  # source of the bf16 pack (made on the first bf16 call)
 
-    def __call__(self, x: torch.Tensor, act=ACT_NONE, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, act=ACT_NONE, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                 out_bf16: bool = False) -> torch.Tensor:
+        """x: (m, k) f32 -- or bf16: the layer then runs on the bf16 matrix pipe (pn_linear_bf16, csrc/conv_bf16.hip; weights packed as bf16
+        on first use, f32 accumulation, bias / activation / residual in f32) and returns f32, or bf16 with ``out_bf16`` (the input of
+        another bf16 layer)"""
         assert x.dim() == 2 and x.is_contiguous() and x.shape[1] == self.k
         m = x.shape[0]
-        if out is None:
-            out = torch.empty((m, self.n), dtype=torch.float32, device=x.device)
         st = hip.stream()
         prof = _PROFILER
+        if x.dtype == torch.bfloat16:
+            assert self.k % 64 == 0 and self.n % 16 == 0, "bf16 GEMM: k a multiple of 64, n of 16"
+            if getattr(self, "packed_bf16", None) is None:
+                lib = hip.load()
+                self.packed_bf16 = torch.empty(lib.pn_conv_bf16_rows_packed_elems(self.n, self.k, 1, 1), dtype=torch.bfloat16, device=x.device)
+                hip.call("pn_pack_conv_weight_bf16_rows", self._w_f32.data_ptr(), self.n, self.k, 1, 1, self.packed_bf16.data_ptr(), st)
+            if out is None:
+                out = torch.empty((m, self.n), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+            if prof is not None:
+                ev = prof.begin(st)
+            hip.call("pn_linear_bf16", x.data_ptr(), m, self.k, self.k, self.packed_bf16.data_ptr(), self.n, hip.ptr(self.bias), int(act),
+                     hip.ptr(residual), self.n, out.data_ptr(), self.n, int(out.dtype == torch.float32), st)
+            if prof is not None:
+                prof.end(ev, 2.0 * m * self.n * self.k, st, tag=f"gemm {m}x{self.k}->{self.n} bf16")
+            return out
+        assert not out_bf16, "a bf16 output needs a bf16 input"
+        if out is None:
+            out = torch.empty((m, self.n), dtype=torch.float32, device=x.device)
         if prof is not None:
             ev = prof.begin(st)
         hip.call(self.entry, x.data_ptr(), m, self.k, self.k, self.packed.data_ptr(), self.n,
@@ -1123,12 +1144,21 @@ class GemmLayer:
         return out
 
 
-def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_chan_mean=False):
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_chan_mean=False, bf16_copy=False, f32_out=True):
+    """-> out [, chan_mean] [, bf16 copy]; ``bf16_copy``: also the result rounded to bf16 (input of the bf16 GEMMs); with ``f32_out`` False
+    only the copy is written (and returned in place of ``out``)"""
     hip.require_device(x)
     assert x.dim() == 2 and x.is_contiguous()
     rows, c = x.shape
-    out = torch.empty_like(x)
+    out = torch.empty_like(x) if f32_out else None
     cm = torch.empty((rows,), dtype=torch.float32, device=x.device) if want_chan_mean else None
+    if bf16_copy:
+        o16 = torch.empty((rows, c), dtype=torch.bfloat16, device=x.device)
+        hip.call("pn_layernorm_bf16out_f32", x.data_ptr(), rows, c, gamma.data_ptr(), beta.data_ptr(), float(eps), hip.ptr(out), o16.data_ptr(),
+                 hip.ptr(cm), hip.stream())
+        res = ((out,) if f32_out else ()) + ((cm,) if want_chan_mean else ()) + (o16,)
+        return res if len(res) > 1 else res[0]
+    assert f32_out
     hip.call("pn_layernorm_f32", x.data_ptr(), rows, c, gamma.data_ptr(), beta.data_ptr(), float(eps), out.data_ptr(),
              hip.ptr(cm), hip.stream())
     return (out, cm) if want_chan_mean else out

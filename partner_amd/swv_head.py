@@ -170,8 +170,9 @@ class E2ESWVoteHead(nn.Module):
 
     # ---------------------------------------------------------------------------------------
     def set_compute_dtype(self, dtype: str) -> "E2ESWVoteHead":
-        """"f32" (default) or "bf16": the 3x3 convolution branches (vote / vote_cls / cls / bbox / iou) run with bf16
-        activations and weights and f32 accumulation (BASELINE configs[3]); the Swin stage and all outputs stay f32."""
+        """"f32" (default) or "bf16": the 3x3 convolution branches (vote / vote_cls / cls / bbox / iou) and the token GEMMs of the Swin stage
+        (patch embedding, qkv, proj, MLP) run with bf16 operands and f32 accumulation (BASELINE configs[3]); LayerNorm, the window
+        attention core, the residual stream and all outputs stay f32."""
         assert dtype in ("f32", "bf16")
         self.compute_dtype = dtype
         self._plan = PlanCache()
@@ -237,7 +238,7 @@ class E2ESWVoteHead(nn.Module):
         plan["vote"][1](plan["vote"][0](xc), out=vote, out_channel_offset=0)
         plan["vote_cls"][1](plan["vote_cls"][0](xc), out=vote, out_channel_offset=2)
         L = self.layer
-        t = self.patch_embed_tokens(x)
+        t = self.patch_embed_tokens(xc if (bf16 and x.shape[3] % 64 == 0) else x)
         for i in range(len(plan["blocks"])):
             t = self.swin_block_tokens(i, t, vote, b, h, w)
         feat = ops.layernorm(t, L.norm0.weight, L.norm0.bias, L.norm0.eps).view(b, h, w, C)
@@ -270,13 +271,21 @@ class E2ESWVoteHead(nn.Module):
         blk = bp["mod"]
         C, heads, ws = self.layer.embed_dim, self.layer.num_heads, self.window_size
         n = b * h * w
-        y = ops.layernorm(t, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+        b16 = getattr(self, "compute_dtype", "f32") == "bf16" and C % 64 == 0
+        if b16:      # bf16 option: the four token GEMMs of the block on the bf16 matrix pipe; LayerNorm, the attention core, GELU, residuals in f32
+            y = ops.layernorm(t, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, bf16_copy=True, f32_out=False)
+        else:
+            y = ops.layernorm(t, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
         qkv = bp["qkv"](y)
         att = torch.empty((n, C), dtype=torch.float32, device=t.device)
         hip.call("pn_swv_window_attn", qkv.data_ptr(), vote.data_ptr(), 4, plan["pos"].data_ptr(), hip.ptr(bp["qkv_bias"]),
                  bp["vw1"].data_ptr(), bp["vb1"].data_ptr(), bp["vw2"].data_ptr(), bp["vb2"].data_ptr(), bp["rw1"].data_ptr(),
                  bp["rb1"].data_ptr(), bp["rw2"].data_ptr(), bp["rb2"].data_ptr(), bp["tau"].data_ptr(), b, h, w, C, heads, ws,
                  int(bp["shift"]), hip.ptr(bp.get("bias_table")), att.data_ptr(), hip.stream())
+        if b16:
+            t = bp["proj"](ops.to_bf16(att), residual=t)
+            z = ops.layernorm(t, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, bf16_copy=True, f32_out=False)
+            return bp["fc2"](bp["fc1"](z, act=ops.ACT_GELU, out_bf16=True), residual=t)
         t = bp["proj"](att, residual=t)
         z = ops.layernorm(t, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
         return bp["fc2"](bp["fc1"](z, act=ops.ACT_GELU), residual=t)

@@ -156,3 +156,47 @@ def test_first_ksplit_call_of_a_process_uses_the_ksplit_form():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("case", [(300, 256, 256, "none", True, True, False), (1000, 256, 1024, "gelu", True, False, True), (4097, 1024, 256, "none", True, True, False),
+                                  (145, 64, 48, "relu", False, False, False), (2304, 512, 256, "none", True, False, False), (576, 256, 768, "none", True, False, True)],
+                         ids=str)
+def test_linear_bf16(dev, case):
+    """pn_linear_bf16 (csrc/conv_bf16.hip: the bf16 option of the token GEMMs): bf16 operands are exact in f32, so the float64 product of the
+    bf16-rounded x and W is the exact reference of the bf16-in / f32-accumulate kernel up to summation order: 2e-5 of the output's range
+    for the f32 output (bias, exact-erf GELU and the residual are applied in f32), one more bf16 rounding (2^-8 relative) for the bf16 output.
+    Row counts that are not a multiple of the 144 / 128-row tiles, n not a multiple of the 128-column tile."""
+    from partner_amd import ops
+    m, k, n, act, bias, res, out16 = case
+    g = torch.Generator().manual_seed(sum(case[:3]))
+    x = torch.randn((m, k), generator=g)
+    w = torch.randn((n, k), generator=g) / np.sqrt(k)
+    b = torch.randn((n,), generator=g) if bias else None
+    r = torch.randn((m, n), generator=g) if res else None
+    layer = ops.GemmLayer(w.to(dev), None if b is None else b.to(dev))
+    x16 = ops.to_bf16(x.to(dev))
+    a = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "gelu": ops.ACT_GELU}[act]
+    ref = reference(x.bfloat16().float(), w.bfloat16().float(), b, act, r)
+    y = layer(x16, act=a, residual=None if r is None else r.to(dev))
+    assert y.dtype == torch.float32
+    assert float((y.double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-5
+    if out16:
+        y16 = layer(x16, act=a, out_bf16=True)
+        assert y16.dtype == torch.bfloat16
+        assert ((y16.float().double().cpu() - ref).abs() <= ref.abs() * 2.0 ** -8 + 2e-5 * ref.abs().max()).all()
+    # the f32 form of the same layer still runs and is a different arithmetic
+    y32 = layer(x.to(dev), act=a, residual=None if r is None else r.to(dev))
+    assert not torch.equal(y32, y)
+
+
+def test_layernorm_bf16_copy(dev):
+    """pn_layernorm_bf16out_f32: the f32 rows are those of pn_layernorm_f32 bit for bit, the copy is their round-to-nearest-even bf16"""
+    from partner_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn((777, 256), generator=g) * 3 + 0.5).to(dev)
+    gamma, beta = torch.randn(256, generator=g).to(dev), torch.randn(256, generator=g).to(dev)
+    ref, cm = ops.layernorm(x, gamma, beta, 1e-5, want_chan_mean=True)
+    out, cm2, o16 = ops.layernorm(x, gamma, beta, 1e-5, want_chan_mean=True, bf16_copy=True)
+    assert torch.equal(out, ref) and torch.equal(cm, cm2) and torch.equal(o16, ref.bfloat16())
+    only = ops.layernorm(x, gamma, beta, 1e-5, bf16_copy=True, f32_out=False)
+    assert torch.equal(only, o16)

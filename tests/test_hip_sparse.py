@@ -222,25 +222,29 @@ def test_voxelnet_v3_batch_of_two(dev):
         for k, v in one.items():
             e = float((both[k][b:b + 1] - v).abs().max() / (v.abs().max() + 1e-30))
             assert e < 1e-4, (b, k, e)
-    # BASELINE configs[3] proper: the same batch with the bf16 BEV convolutions (RPN + the head's 3x3 branches; bf16 activations and
-    # weights, f32 accumulation) against the f32 run of the same weights.  bf16 carries 8 mantissa bits, so after the RPN's 12 layers and
-    # the head the tolerance is relative to each tensor's magnitude: mean |d| <= 5e-3 * max|ref|, 99.9th percentile <= 4e-2 and max <= 0.15.
-    # The MAXIMUM over a tensor's ~150k values is an outlier statistic -- it moved from 4.4e-2 to 1.0e-1 ('reg', the worst tensor) when
-    # the f32 SetBlock changed in the 7th digit (r3, K-split key-point GEMMs) at an unchanged mean of 3.5e-3 -- so the tight bounds sit
-    # on the mean and the 99.9th percentile.
-    m.neck.set_compute_dtype("bf16")
-    m.bbox_head.set_compute_dtype("bf16")
+    # BASELINE configs[3] proper: the same batch with VoxelNetV3.set_compute_dtype("bf16") -- the SetBlocks' and the Swin stage's token GEMMs and
+    # the RPN's / head's convolutions with bf16 operands and f32 accumulation -- against the f32 run of the same weights (the f32 run is pinned to
+    # the oracle above and in test_voxelnet_v3_end_to_end_waymo_config; the bf16 kernels against the oracle directly:
+    # test_hip_swv.py::test_bf16_bev_stage_against_the_oracle, test_hip_attention.py::test_setblock_bf16_option_against_the_reference).
+    # bf16 carries 8 mantissa bits; the last SetBlock, the RPN's 12 layers and the head deep the tolerance is relative to each tensor's
+    # magnitude: mean |d| <= 6e-3 * max|ref|, 99.9th percentile <= 4e-2, max <= 0.15 (measured: 4.4e-3 / 2.3e-2 / 4.8e-2 on the worst tensor).
+    # The FIRST SetBlock stays f32 in this mode: its output feeds the second block's key-point selection, a discrete choice among near-ties,
+    # and with it in bf16 the same statistics are 0.11 / 0.49 / 0.64 (VoxelNetV3.set_compute_dtype).
+    m.set_compute_dtype("bf16")
     try:
         b16 = run(sweeps)
     finally:
-        m.neck.set_compute_dtype("f32")
-        m.bbox_head.set_compute_dtype("f32")
+        m.set_compute_dtype("f32")
+    worst = {}
     for k, v in both.items():
         sc = float(v.abs().max()) + 1e-30
         d = (b16[k] - v).abs()
         assert torch.isfinite(b16[k]).all(), k
         q999 = float(torch.quantile(d.flatten().float()[:: max(1, d.numel() // 1000000)], 0.999))
-        assert float(d.max()) <= 0.15 * sc and q999 <= 4e-2 * sc and float(d.mean()) <= 5e-3 * sc, (k, float(d.max()) / sc, q999 / sc, float(d.mean()) / sc)
+        worst[k] = (round(float(d.mean()) / sc, 5), round(q999 / sc, 4), round(float(d.max()) / sc, 3))
+    print("bf16 vs f32, (mean, q99.9, max) / max|ref|:", worst)
+    for k, (mean, q999, mx) in worst.items():
+        assert mean <= 6e-3 and q999 <= 4e-2 and mx <= 0.15, (k, mean, q999, mx)
     assert any(not torch.equal(b16[k], both[k]) for k in both)   # the bf16 kernels really ran
 
 
