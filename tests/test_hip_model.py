@@ -5,6 +5,7 @@ inputs and weights.
 Tolerance for floating-point tensors (north_star: "fp32 head tensors within 1e-4 rel"):
 max |got - ref| <= 1e-4 * max |ref| per tensor.  Indices are compared bit-exactly."""
 import logging
+import os
 
 import numpy as np
 import pytest
@@ -521,7 +522,8 @@ def test_fused_head_vs_oracle_and_unfused(dev, case):
         assert rel_err(out[k], r.numpy()) < REL, k
         np.testing.assert_allclose(out[k].cpu().numpy(), r.numpy(), rtol=1e-4, atol=1e-4 * float(r.abs().max()))
     chained = h._chain_head_plan(plan["fused"], b, a_rows, r_cols, dev, cls == "CenterHeadSinglePos") is not None and plan["fused"]["shared"]._use_wino4(b, a_rows, r_cols, False)
-    assert chained == (a_rows * b >= 128), "the large maps must take the chained first stage"
+    if not any(k.startswith("PN_") for k in os.environ):      # (tests/test_hip_routes.py re-runs this test with routes switched off)
+        assert chained == (a_rows * b >= 128), "the large maps must take the chained first stage"
     if chained:
         h.force_tiled_branches = True
         tl = h(x.to(dev))["det_preds"][0]
