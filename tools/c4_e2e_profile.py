@@ -20,7 +20,7 @@ for k, v in geo.items():
     getattr(m4.bbox_head, k).data.copy_(v)
 m4 = m4.to(dev).eval()
 if mode == "bf16":
-    m4.neck.set_compute_dtype("bf16"); m4.bbox_head.set_compute_dtype("bf16")
+    m4.set_compute_dtype("bf16")
 vg = VoxelGenerator(synth.WAYMO_VOXEL, synth.WAYMO_RANGE, 5, 150000)
 sws = [torch.from_numpy(synth.synth_sweep_beams_polar(180000, seed=b)).to(dev) for b in range(batch)]
 
