@@ -57,6 +57,8 @@ __global__ void hard_voxel_mean_kernel(const float* __restrict__ vox, const int3
 }
 
 // ------------------------------------------------------------------------------- V4 (+V5)
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
 struct PfnArgs {
   const float* pts;
   int stride;
@@ -204,14 +206,17 @@ __device__ __forceinline__ void pfn_32_128_main(const PfnArgs& a, const float* _
   __shared__ __attribute__((aligned(16))) float p_l[CAP][8];
   const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
   const int V = min(*a.v_dev, a.v_cap);
-  float w0[16], w1a[64], w1b[64];
+  // r5: rows n and n + 64 of W1 as PAIRS: layer 1 runs on v_pk_fma_f32 (two IEEE fmas per lane and instruction -- the bits of two v_fma_f32).
+  // Ablation at 300 k points (10 sweeps, 177 k pillars): 140 of the kernel's 192 us are this layer arithmetic, at 2/3 of the vector fp32 rate;
+  // staging, per-pillar scalars and the stores together 52.  With the pairs: 171 us.  (Both layers as MFMA tiles over ALL point rows --
+  // G = M0 W1b^T, Y = G[pillar] + H W1a^T, LDS-atomic maxima -- were built and measured: 183 us at 300 k, 52 against 33 us at 30 k points;
+  // the per-batch chain of barriers and the bank-conflicting pillar-strided LDS accesses cost more than the matrix pipe saved.  Dropped.)
+  float w0[16];
+  f32x2 w1[64];
 #pragma unroll
   for (int k = 0; k < 16; ++k) w0[k] = lane < 32 ? a.w0[lane * 16 + k] : 0.f;
 #pragma unroll
-  for (int k = 0; k < 64; ++k) {
-    w1a[k] = a.w1[lane * 64 + k];
-    w1b[k] = a.w1[(lane + 64) * 64 + k];
-  }
+  for (int k = 0; k < 64; ++k) w1[k] = f32x2{a.w1[lane * 64 + k], a.w1[(lane + 64) * 64 + k]};
   for (int v0 = bid * NB; v0 < V; v0 += nblk * NB) {
     const int nb = min(NB, V - v0);
     __syncthreads();  // the previous batch has been consumed
@@ -282,42 +287,34 @@ __device__ __forceinline__ void pfn_32_128_main(const PfnArgs& a, const float* _
           if (i == s) h_first = h;
           m0 = fmaxf(m0, h);
         }
-        float g0 = 0.f, g1 = 0.f;
+        f32x2 g = {0.f, 0.f};
         float f0 = 0.f, f1 = 0.f;
         if (e - s == 1) {  // one point (most pillars of a single sweep): maximum == the point, one broadcast serves both halves
           float hb[32];
 #pragma unroll
           for (int k = 0; k < 32; ++k) hb[k] = lane_bcast(h_first, k);
 #pragma unroll
-          for (int k = 0; k < 32; ++k) {
-            g0 = fmaf(w1a[32 + k], hb[k], g0);
-            g1 = fmaf(w1b[32 + k], hb[k], g1);
-          }
+          for (int k = 0; k < 32; ++k) g = __builtin_elementwise_fma(w1[32 + k], f32x2{hb[k], hb[k]}, g);
 #pragma unroll
-          for (int k = 0; k < 32; ++k) {
-            g0 = fmaf(w1a[k], hb[k], g0);
-            g1 = fmaf(w1b[k], hb[k], g1);
-          }
-          f0 = fmaxf(0.f, g0);
-          f1 = fmaxf(0.f, g1);
+          for (int k = 0; k < 32; ++k) g = __builtin_elementwise_fma(w1[k], f32x2{hb[k], hb[k]}, g);
+          f0 = fmaxf(0.f, g[0]);
+          f1 = fmaxf(0.f, g[1]);
         } else {
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
           const float m = lane_bcast(m0, k);
-          g0 = fmaf(w1a[32 + k], m, g0);
-          g1 = fmaf(w1b[32 + k], m, g1);
+          g = __builtin_elementwise_fma(w1[32 + k], f32x2{m, m}, g);
         }
         for (int i = s; i < e; ++i) {
           const float h = (i == s) ? h_first : layer0(p_l[i]);
-          float y0 = g0, y1 = g1;
+          f32x2 y = g;
 #pragma unroll
           for (int k = 0; k < 32; ++k) {
             const float hc = lane_bcast(h, k);
-            y0 = fmaf(w1a[k], hc, y0);
-            y1 = fmaf(w1b[k], hc, y1);
+            y = __builtin_elementwise_fma(w1[k], f32x2{hc, hc}, y);
           }
-          f0 = fmaxf(f0, y0);
-          f1 = fmaxf(f1, y1);
+          f0 = fmaxf(f0, y[0]);
+          f1 = fmaxf(f1, y[1]);
         }
         }
         if (a.feat) {
