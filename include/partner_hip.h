@@ -824,9 +824,13 @@ int pn_sparse_neighbors_rows(const uint32_t *out_keys, int out_capacity, const i
                              uint8_t *row_bits, pn_stream_t stream);
 int pn_sparse_group_rows_bits(const uint8_t *row_bits, int rows, int bits_per_row, const int32_t *n_out, int out_capacity, int32_t *perm,
                               uint32_t *group_mask, pn_stream_t stream);
+/* r5: xcd_bounds (nullable, 18 int32 written by pn_sparse_group_balance from the same masks): cut points of the XCDs' contiguous runs of
+ * groups chosen for equal WORK (taps of the groups' masks) instead of equal counts -- with equal counts one XCD carried 1.18 - 1.30 x the mean
+ * on the bench frame and every layer waited for it.  Results do not depend on it. */
+int pn_sparse_group_balance(const uint32_t *group_mask, const int32_t *n_out, int out_capacity, int32_t *xcd_bounds, pn_stream_t stream);
 int pn_sparse_conv_grouped_f32(const float *in, int in_rows, int cin, const int32_t *nbr, const int32_t *n_out, int out_capacity, int taps,
-                               const int32_t *perm, const uint32_t *group_mask, const float *packed_w, int cout, const float *scale,
-                               const float *shift, int act, const float *residual, float *out, pn_stream_t stream);
+                               const int32_t *perm, const uint32_t *group_mask, const int32_t *xcd_bounds, const float *packed_w, int cout,
+                               const float *scale, const float *shift, int act, const float *residual, float *out, pn_stream_t stream);
 int pn_sparse_to_dense_nhwc(const float *feats, const uint32_t *keys, int capacity,
                             const int32_t *n_dev, const int32_t *dims, int c, float *out,
                             pn_stream_t stream);

@@ -165,6 +165,7 @@ struct SpwArgs {
   int cin_chunks, cout_pad;
   unsigned in_bytes, w_bytes, out_bytes;
   int act;
+  const int32_t* bounds;               // nullable: [0..8] XCD cut points in groups, [9..17] in blocks of 4 groups (pn_sparse_group_balance)
   int wide4_groups, wide2_groups;      // a wave takes 4 / at least 2 column tiles from this many live groups on
   int exp;                             // (unused; r4's PN_SPARSE_EXP ablations lived in the K loops, where a run-time branch costs 12 %)
 };
@@ -231,6 +232,8 @@ __device__ __forceinline__ void sparse_conv_wave_body(const SpwArgs& a, int32_t*
   const int nch = a.cin / CH;          // chunks per tap
   const int CG = a.cin >> 3;           // K steps per tap
 
+  // (r5: splitting a tile's K steps over four accumulators, as sparse_conv_group4_kernel does, changed nothing here: 117 us on the 32 -> 32
+  // layers either way -- a unit is four K steps, the wave spends its time between them)
   f32x16 acc[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c)
@@ -398,7 +401,11 @@ __global__ __launch_bounds__(256, 3) void sparse_conv_wave_kernel(SpwArgs a) {
   // blocks of 4 groups are dealt over the XCDs in contiguous runs (neighbouring groups gather neighbouring rows: one L2)
   const int nblk = (groups + 3) / 4;
   int mb;
-  {
+  if (a.bounds) {      // XCD x walks the run [bounds[9 + x], bounds[10 + x]) of 4-group blocks: equal WORK (taps of the groups' masks) per XCD
+    const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    mb = a.bounds[9 + x] + idx;
+    if (mb >= a.bounds[10 + x]) return;
+  } else {
     const int q = nblk >> 3, r = nblk & 7, x = blockIdx.x & 7, idx = blockIdx.x >> 3;
     if (idx >= (x < r ? q + 1 : q)) return;
     mb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
@@ -436,6 +443,9 @@ __global__ __launch_bounds__(256, 3) void sparse_conv_wave_kernel(SpwArgs a) {
 // of the taps whose NUMBER falls in its class -- every tap for four chunks (128 channels), t & 1 == w >> 1 for two (64 channels).  A site's
 // four partial sums are then sums over its own neighbours in ascending tap order (absent ones add exact zeros), joined as ((0 + 1) + 2) + 3.
 
+#ifndef PN_SG_EXP
+#define PN_SG_EXP 0      // diagnostic builds (tools/sparseq.sh): 1 no input gathers after the first, 2 no weight loads after the first, 4 no LDS image,
+#endif                   // 8 no MFMAs, 16 no join / stores, 32 no neighbour-table prologue -- wrong results, the time shows what a unit waits for
 template <int NC>
 __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel(SpwArgs a) {
   constexpr int LD = 36;
@@ -447,13 +457,19 @@ __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel
   const int n = min(*a.n_valid, a.cap);
   const int groups = (n + 31) / 32;
   int g;
-  {
+  if (a.bounds) {      // XCD x walks the groups [bounds[x], bounds[x + 1]): contiguous (neighbouring groups gather neighbouring rows: one L2) AND
+    const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;      // equal in work -- equal COUNTS left one XCD with 1.18 - 1.30 x the mean taps
+    g = a.bounds[x] + idx;
+    if (g >= a.bounds[x + 1]) return;
+  } else {
     const int q = groups >> 3, r = groups & 7, x = blockIdx.x & 7, idx = blockIdx.x >> 3;
     if (idx >= (x < r ? q + 1 : q)) return;
     g = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
   }
   const unsigned gm = a.gmask[g];
-  {
+  if (PN_SG_EXP & 32) {
+    for (int i = tid; i < 28 * 32; i += 256) s_src[i] = (g * 32 + (i & 31)) % max(n, 1);
+  } else {
     const int i = tid & 31, prow = g * 32 + i < a.cap ? a.perm[g * 32 + i] : -1;
     int32_t nv[4];
     const int32_t* np = a.nbr + (size_t)max(prow, 0) * a.taps;
@@ -485,17 +501,29 @@ __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel
   const unsigned own = nch == 4 ? gm : gm & (0x55555555u << (wv >> 1));
   const int mine = __builtin_popcount(own);                      // units of this wave: (its taps) x (its chunk)
 
-  f32x16 acc[NC];
+  // r5: FOUR independent accumulator tiles per wave.  tools/micro/mfma_dep_chain.hip: with three or four waves on a SIMD (this kernel's
+  // occupancy) v_mfma_f32_32x32x2_f32 chains on one or two accumulator tiles per wave run at 103 - 122 TFLOP/s chip-wide, on four at 155 (with
+  // one or two waves per SIMD the count does not matter) -- the two-tile form of this kernel was at exactly that: its bare MFMA loop, every
+  // load / LDS access / join switched off, took 346 of the 128 -> 128 layer's 354 us.  NC = 2 therefore splits each tile's K steps by
+  // parity over two accumulators (even steps of a unit into one, odd into the other, summed once before the join): the summation order
+  // of a site is still a function of its own neighbours only (taps ascending, fixed step parity), so grouping and batch do not change a bit.
+  constexpr int P = NC == 2 ? 2 : 1;
+  f32x16 acc[NC][P];
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][p][r] = 0.f;
 
   UnitCursor ca, cb;
   ca.start(own);
   cb.start(own);
   f32x4 ra[4], fb[2][NC];
+  bool first_a = true, first_b = true;
   auto request_a = [&]() __attribute__((always_inline)) {
+    if ((PN_SG_EXP & 1) && !first_a) { ca.next(); return; }
+    first_a = false;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int sv = s_src[ca.t * 32 + srow + 8 * q];
@@ -507,6 +535,7 @@ __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel
   };
   // kk = the K step inside cb's unit: a compile-time constant at every call (the unit loop below is unrolled over its four steps)
   auto request_b = [&](int slot, int kk) __attribute__((always_inline)) {
+    if ((PN_SG_EXP & 2) && !first_b) return;
     const unsigned so_w = (unsigned)(((cb.t * a.cin_chunks + ch) * 8 + kk * 2)) * cp16;
 #pragma unroll
     for (int c = 0; c < NC; ++c) fb[slot][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, cb.live ? uoff[c] : 0xffffffffu, so_w, 0));
@@ -514,19 +543,29 @@ __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel
   request_a();
   request_b(0, 0);
   request_b(1, 1);
+  first_b = false;
   for (int u = 0; u < mine; ++u) {      // ONE basic block: no branch below (see UnitCursor)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(stage + (srow + 8 * q) * LD + scol) = ra[q];
-    request_a();
     f32x4 fa[4];
+    if (PN_SG_EXP & 4) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) fa[k] = *reinterpret_cast<const f32x4*>(stage + li * LD + (2 * k + lh) * 4);
+      for (int k = 0; k < 4; ++k) fa[k] = ra[k];
+      request_a();
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(stage + (srow + 8 * q) * LD + scol) = ra[q];
+      request_a();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fa[k] = *reinterpret_cast<const f32x4*>(stage + li * LD + (2 * k + lh) * 4);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k][j], fb[k & 1][c][j], acc[c], 0, 0, 0);
+        for (int c = 0; c < NC; ++c) {
+          if (PN_SG_EXP & 8) acc[c][j & (P - 1)][j] += fa[k][j] * fb[k & 1][c][j];
+          else acc[c][j & (P - 1)] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k][j], fb[k & 1][c][j], acc[c][j & (P - 1)], 0, 0, 0);
+        }
       // the slot just used takes step k + 2: steps 2, 3 of this unit, then steps 0, 1 of the next one
       if (k == 1) {
         request_b(1, 3);
@@ -540,6 +579,13 @@ __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel
   }
   // ---- join: [wave][c][r][lane] partial tiles, summed wave 0 + 1 + 2 + 3; wave w finishes registers 4 w .. 4 w + 3 (rows 8 w' .. ) of every tile;
   // JC column tiles per pass
+  if constexpr (P == 2) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][0][r] += acc[c][1][r];
+  }
+  if ((PN_SG_EXP & 16) && acc[0][0][0] != 12345.f) return;
   const bool relu = a.act == PN_ACT_RELU;
   const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res), 0, a.res ? a.out_bytes : 0u, 0x00020000);
@@ -549,7 +595,7 @@ __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel
 #pragma unroll
     for (int c = 0; c < JC; ++c)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s_buf[((wv * JC + c) * 16 + r) * 64 + lane] = acc[c0 + c][r];
+      for (int r = 0; r < 16; ++r) s_buf[((wv * JC + c) * 16 + r) * 64 + lane] = acc[c0 + c][0][r];
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < JC; ++c) {
@@ -572,9 +618,66 @@ __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel
   }
 }
 
+// XCD cut points of equal work: prefix sums of the groups' tap counts (one block; <= ~100 k groups), cut where the prefix crosses k / 8 of the
+// total.  bounds[0..8]: in groups; bounds[9..17]: in blocks of four groups (the wave-per-group kernel's blocks), cut on block boundaries.
+__global__ __launch_bounds__(1024) void sparse_group_balance_kernel(const uint32_t* __restrict__ gmask, const int32_t* __restrict__ n_valid, int cap,
+                                                                    int32_t* __restrict__ bounds) {
+  __shared__ long long part[1024];
+  __shared__ long long total_s;
+  const int tid = threadIdx.x;
+  const int n = min(*n_valid, cap), groups = (n + 31) / 32, nblk = (groups + 3) / 4;
+  const int per = (nblk + 1023) / 1024;                       // 4-group blocks per thread (contiguous)
+  const int b0 = min(nblk, tid * per), b1 = min(nblk, b0 + per);
+  long long s = 0;
+  for (int b = b0; b < b1; ++b)
+    for (int g = 4 * b; g < min(groups, 4 * b + 4); ++g) s += __builtin_popcount(gmask[g]) + 1;      // + 1: a group's fixed cost (table, join)
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    long long run = 0;
+    for (int i = 0; i < 1024; ++i) { const long long v = part[i]; part[i] = run; run += v; }
+    total_s = run;
+    bounds[0] = 0; bounds[8] = groups; bounds[9] = 0; bounds[17] = nblk;
+    for (int k = 1; k < 8; ++k) { bounds[k] = 0; bounds[9 + k] = 0; }      // a cut whose target is 0 stays here (tiny inputs)
+  }
+  __syncthreads();
+  const long long total = total_s;
+  long long run = part[tid];
+  for (int b = b0; b < b1; ++b) {
+    long long w = 0;
+    for (int g = 4 * b; g < min(groups, 4 * b + 4); ++g) w += __builtin_popcount(gmask[g]) + 1;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const long long target = total * k / 8;
+      if (run < target && run + w >= target) { bounds[9 + k] = b + 1; bounds[k] = min(groups, 4 * (b + 1)); }
+    }
+    run += w;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // a run is at most twice the mean (+ 4): the launchers size their grids for that (kBalanceSlack); the cuts stay ascending and cover everything
+    const int maxb = 2 * ((nblk + 7) / 8) + 4;
+    for (int k = 1; k < 8; ++k) {
+      int c = bounds[9 + k];
+      c = max(c, bounds[9 + k - 1]);
+      c = min(c, bounds[9 + k - 1] + maxb);
+      c = max(c, nblk - (8 - k) * maxb);
+      c = min(max(c, 0), nblk);
+      bounds[9 + k] = c;
+      bounds[k] = min(groups, 4 * c);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pn_sparse_group_balance(const uint32_t* group_mask, const int32_t* n_out, int out_capacity, int32_t* bounds, pn_stream_t stream) {
+  PN_REQUIRE(group_mask && n_out && bounds && out_capacity >= 1, "sparse_group_balance: bad arguments");
+  hipLaunchKernelGGL(sparse_group_balance_kernel, dim3(1), dim3(1024), 0, pn::S(stream), group_mask, n_out, out_capacity, bounds);
+  return pn::check_launch("sparse_group_balance_kernel");
+}
 
 static int group_rows_run(const int32_t* nbr, const uint8_t* row_bits, int rows, int bits_per_row, const int32_t* n_out, int out_capacity, int taps, int32_t* perm,
                           uint32_t* group_mask, pn_stream_t stream) {
@@ -601,8 +704,8 @@ int pn_sparse_group_rows_bits(const uint8_t* row_bits, int rows, int bits_per_ro
 }
 
 int pn_sparse_conv_grouped_f32(const float* in, int in_rows, int cin, const int32_t* nbr, const int32_t* n_out, int out_capacity, int taps,
-                               const int32_t* perm, const uint32_t* group_mask, const float* packed_w, int cout, const float* scale, const float* shift,
-                               int act, const float* residual, float* out, pn_stream_t stream) {
+                               const int32_t* perm, const uint32_t* group_mask, const int32_t* xcd_bounds, const float* packed_w, int cout, const float* scale,
+                               const float* shift, int act, const float* residual, float* out, pn_stream_t stream) {
   PN_REQUIRE(in && nbr && n_out && perm && group_mask && packed_w && out, "sparse_conv_grouped: null pointer");
   PN_REQUIRE(in_rows >= 1 && cin >= 16 && cin % 16 == 0 && cout >= 1 && out_capacity >= 1 && taps >= 1 && taps <= 27, "sparse_conv_grouped: cin must be a "
                                                                                                                      "multiple of 16, taps <= 27");
@@ -611,7 +714,7 @@ int pn_sparse_conv_grouped_f32(const float* in, int in_rows, int cin, const int3
   PN_REQUIRE(act == PN_ACT_NONE || act == PN_ACT_RELU, "sparse_conv_grouped: activation none or ReLU");
   PN_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "sparse_conv_grouped: pointers must be 16-byte aligned");
   SpwArgs a{};
-  a.in = in; a.nbr = nbr; a.n_valid = n_out; a.perm = perm; a.gmask = group_mask; a.w = packed_w; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
+  a.in = in; a.nbr = nbr; a.n_valid = n_out; a.perm = perm; a.gmask = group_mask; a.bounds = xcd_bounds; a.w = packed_w; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
   a.cap = out_capacity; a.taps = taps; a.cin = cin; a.cout = cout;
   a.cin_chunks = pn::cdiv(cin, 32); a.cout_pad = pn::cdiv(cout, 32) * 32;
   a.in_bytes = (unsigned)((size_t)in_rows * cin * 4);
@@ -625,7 +728,9 @@ int pn_sparse_conv_grouped_f32(const float* in, int in_rows, int cin, const int3
   a.exp = ex;
 
   hipStream_t st = pn::S(stream);
-  const int blocks = (pn::cdiv(pn::cdiv(out_capacity, 32), 4) + 7) / 8 * 8;
+  // grid: 8 XCDs x the longest run a balanced cut may give an XCD (sparse_group_balance_kernel: at most twice the mean + 4 blocks)
+  const int nblk_cap = pn::cdiv(pn::cdiv(out_capacity, 32), 4);
+  const int blocks = xcd_bounds ? 8 * (2 * ((nblk_cap + 7) / 8) + 4) : (nblk_cap + 7) / 8 * 8;
   pn::ProfileSlot ps{};
   const bool prof = pn::take_profile_slot(ps);
   const int ncol32 = a.cout_pad / 32;
@@ -638,7 +743,8 @@ int pn_sparse_conv_grouped_f32(const float* in, int in_rows, int cin, const int3
   static const int g4 = [] { const char* e = getenv("PN_SPARSE_GROUP4"); return e ? atoi(e) : 1; }();
   if (g4 && (cin == 64 || cin == 128) && ncol32 >= 2) {      // block per group, K split over its waves: the wave -> (channel chunk, tap subset)
     // map of the kernel exists for 2 or 4 chunks of 32 input channels only; every other width takes the wave kernel, which loops over chunks
-    const dim3 grid((unsigned)((pn::cdiv(out_capacity, 32) + 7) / 8 * 8), 1);
+    const int g_cap = pn::cdiv(out_capacity, 32);
+    const dim3 grid((unsigned)(xcd_bounds ? 8 * (4 * (2 * ((nblk_cap + 7) / 8) + 4)) : (g_cap + 7) / 8 * 8), 1);
     // 128 columns: two blocks of 64 columns per group (the input rows are gathered twice; blocks half as long, four per CU instead of three:
     // 380 -> 365 us on the bench frame's 128 -> 128 layers).  Heavy-groups-first block orders were tried and lose: the contiguous run of
     // groups an XCD walks shares neighbour rows in its L2 (global order by tap count: +15 %)

@@ -171,7 +171,8 @@ SIGNATURES = {
     "pn_sparse_conv_f32": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P]),
     "pn_sparse_conv_c16_f32": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "pn_sparse_group_rows": (_I, [_P, _P, _I, _I, _P, _P, _P]),
-    "pn_sparse_conv_grouped_f32": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
+    "pn_sparse_conv_grouped_f32": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
+    "pn_sparse_group_balance": (_I, [_P, _P, _I, _P, _P]),
     "pn_sparse_to_dense_nhwc": (_I, [_P, _P, _I, _P, _P, _I, _P, _P]),
     "pn_sparse_to_dense_index_nhwc": (_I, [_P, _P, _P, _I, _P, _P]),
     "pn_assign_heatmap_workspace_bytes": (_SZ, [_I, _I]),

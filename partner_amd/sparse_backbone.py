@@ -127,7 +127,8 @@ class SpMiddleResNetFHD(nn.Module):
         if groups is not None and layer["cin"] % 16 == 0 and layer["cout"] in (32, 64, 128) and layer["taps"] <= 27:
             # 32 / 64 / 128-channel levels and the strided stages: one wave per group of 32 similar sites, the group's taps only (sparse_group.hip)
             hip.call("pn_sparse_conv_grouped_f32", feats.data_ptr(), n_rows, layer["cin"], nbr.data_ptr(), count.data_ptr(), cap, layer["taps"],
-                     groups[0].data_ptr(), groups[1].data_ptr(), layer["packed"].data_ptr(), layer["cout"], layer["scale"].data_ptr(),
+                     groups[0].data_ptr(), groups[1].data_ptr(), groups[2].data_ptr() if len(groups) > 2 else None, layer["packed"].data_ptr(),
+                     layer["cout"], layer["scale"].data_ptr(),
                      layer["shift"].data_ptr(), int(act), hip.ptr(residual), out.data_ptr(), hip.stream())
             return out
         if _C16 and layer["cout"] == 16 and layer["cin"] in (8, 16) and layer["taps"] <= 27:
@@ -190,7 +191,9 @@ class SpMiddleResNetFHD(nn.Module):
         def grp(rows):      # (perm, group masks) of a neighbour table: the sites sorted by neighbourhood, pn_sparse_group_rows
             if not _GROUPED:
                 return None
-            return (torch.empty(rows, dtype=torch.int32, device=dev), torch.empty((rows + 31) // 32, dtype=torch.int32, device=dev))
+            # (perm, group masks, XCD cut points of equal work: pn_sparse_group_balance)
+            return (torch.empty(rows, dtype=torch.int32, device=dev), torch.empty((rows + 31) // 32, dtype=torch.int32, device=dev),
+                    torch.zeros(18, dtype=torch.int32, device=dev))
 
         def bits(rows, geo, g):      # the row bytes the neighbour kernel leaves for the sort (only where a sort follows)
             return torch.empty((rows, geo[0][0] * geo[0][1]), dtype=torch.uint8, device=dev) if (g is not None and _ROW_BITS and geo[0][2] <= 8) else None
@@ -204,6 +207,7 @@ class SpMiddleResNetFHD(nn.Module):
             else:
                 hip.call("pn_sparse_group_rows", table.data_ptr(), level["count"].data_ptr(), level["cap"], table.shape[1], g[0].data_ptr(), g[1].data_ptr(),
                          hip.stream())
+            hip.call("pn_sparse_group_balance", g[1].data_ptr(), level["count"].data_ptr(), level["cap"], g[2].data_ptr(), hip.stream())
 
         levels = []          # per level: dict(index, keys, count, cap, dims, nbr, down=(dnbr) or None)
         cap = V

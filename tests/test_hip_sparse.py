@@ -545,8 +545,19 @@ def test_sparse_conv_grouped_matches_the_gathered_tile_form_and_fp64(dev, cin, c
             hip.call(entry, xd.data_ptr(), n, cin, nd.data_ptr(), cnt.data_ptr(), cap, taps, packed.data_ptr(), cout, scd.data_ptr(),
                      shd.data_ptr(), act, hip.ptr(rd), out.data_ptr(), hip.stream())
         else:
-            hip.call(entry, xd.data_ptr(), n, cin, nd.data_ptr(), cnt.data_ptr(), cap, taps, perm.data_ptr(), gmask.data_ptr(), packed.data_ptr(), cout,
+            hip.call(entry, xd.data_ptr(), n, cin, nd.data_ptr(), cnt.data_ptr(), cap, taps, perm.data_ptr(), gmask.data_ptr(), None, packed.data_ptr(), cout,
                      scd.data_ptr(), shd.data_ptr(), act, hip.ptr(rd), out.data_ptr(), hip.stream())
+            # r5: the same launch with the XCDs' runs cut for equal work (pn_sparse_group_balance): another block order, the same bits
+            bounds = torch.full((18,), -1, dtype=torch.int32, device=dev)
+            hip.call("pn_sparse_group_balance", gmask.data_ptr(), cnt.data_ptr(), cap, bounds.data_ptr(), hip.stream())
+            out_b = torch.full((cap, cout), 123.0, dtype=torch.float32, device=dev)
+            hip.call(entry, xd.data_ptr(), n, cin, nd.data_ptr(), cnt.data_ptr(), cap, taps, perm.data_ptr(), gmask.data_ptr(), bounds.data_ptr(), packed.data_ptr(),
+                     cout, scd.data_ptr(), shd.data_ptr(), act, hip.ptr(rd), out_b.data_ptr(), hip.stream())
+            assert torch.equal(out_b, out)
+            bc = bounds.cpu().tolist()
+            ng = (n + 31) // 32
+            assert bc[0] == 0 and bc[8] == ng and bc[9] == 0 and bc[17] == (ng + 3) // 4
+            assert all(bc[i] <= bc[i + 1] for i in range(8)) and all(bc[9 + i] <= bc[10 + i] for i in range(8))
         outs.append(out.cpu())      # (synchronises: rd stays alive until here)
     ref = torch.zeros((n, cout), dtype=torch.float64)
     for t in range(taps):

@@ -51,5 +51,13 @@ int main() {
     run<2>(src, dst, 256, threads);
     run<4>(src, dst, 256, threads);
   }
+  // r5: more waves per SIMD (blocks per CU), the occupancy of the sparse block-per-group kernel: 4 waves per SIMD, two accumulators each
+  run<2>(src, dst, 512, 512);
+  run<2>(src, dst, 1024, 256);
+  run<2>(src, dst, 1024, 512);
+  run<2>(src, dst, 768, 256);      // 3 waves per SIMD
+  run<4>(src, dst, 768, 256);
+  run<1>(src, dst, 1024, 256);
+  run<4>(src, dst, 1024, 256);
   return 0;
 }
