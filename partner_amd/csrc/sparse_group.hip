@@ -167,7 +167,6 @@ struct SpwArgs {
   int act;
   const int32_t* bounds;               // nullable: [0..8] XCD cut points in groups, [9..17] in blocks of 4 groups (pn_sparse_group_balance)
   int wide4_groups, wide2_groups;      // a wave takes 4 / at least 2 column tiles from this many live groups on
-  int exp;                             // (unused; r4's PN_SPARSE_EXP ablations lived in the K loops, where a run-time branch costs 12 %)
 };
 
 // the taps of a mask in ascending order, one at a time
@@ -724,8 +723,6 @@ int pn_sparse_conv_grouped_f32(const float* in, int in_rows, int cin, const int3
   static const int t4 = [] { const char* e = getenv("PN_SPARSE_WIDE4"); return e ? atoi(e) : 1536; }();
   static const int t2 = [] { const char* e = getenv("PN_SPARSE_WIDE2"); return e ? atoi(e) : 512; }();
   a.wide4_groups = t4; a.wide2_groups = t2;
-  static const int ex = [] { const char* e = getenv("PN_SPARSE_EXP"); return e ? atoi(e) : 0; }();
-  a.exp = ex;
 
   hipStream_t st = pn::S(stream);
   // grid: 8 XCDs x the longest run a balanced cut may give an XCD (sparse_group_balance_kernel: at most twice the mean + 4 blocks)
