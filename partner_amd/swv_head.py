@@ -197,6 +197,24 @@ class E2ESWVoteHead(nn.Module):
                     cls=(conv(self.cls_head[0][0], ops.ACT_RELU, self.cls_head[0][1]), conv(self.cls_head[1][0], ops.ACT_RELU, self.cls_head[1][1]),
                          conv(self.cls_head[2], ops.ACT_NONE)),
                     bbox=two(self.bbox_head), iou=two(self.iou_head) if self.iou_loss else None, blocks=[])
+        # r5: the first convolutions of the box and the IoU branch read the same feature map (e2e_swv_head.py: Conv3x3 256 -> 64 + ReLU each): ONE
+        # 256 -> 128 launch (the 64-column launches ran the K-split F(4,3) kernel at half the matrix rate; bf16: the rows form needs 128 columns),
+        # the second convolutions read their 64-channel halves of its output.  Same arithmetic per output channel.
+        # ... and the vote / vote-class branches' first convolutions on the head's input (512 -> 64 + ReLU, 512 -> 256 + BatchNorm + ReLU) as one
+        # 512 -> 320 launch in the f32 mode (the bf16 rows form wants a multiple of 128 columns: two launches there)
+        plan["vote0"] = None
+        v0, vc0, vbn = self.vote_head[0], self.vote_cls_head[0], self.vote_cls_head[1]
+        if dt == "f32" and v0.weight.shape[1:] == vc0.weight.shape[1:] and v0.padding == vc0.padding and (v0.weight.shape[0] + vc0.weight.shape[0]) % 32 == 0:
+            sc, sh = ops.fold_bn(vbn.weight, vbn.bias, vbn.running_mean, vbn.running_var, vbn.eps, vc0.bias)
+            plan["vote0"] = (ops.ConvLayer(torch.cat([v0.weight.detach(), vc0.weight.detach()], 0), stride=1, pad=v0.padding[0],
+                                           scale=torch.cat([torch.ones_like(v0.bias.detach()), sc], 0), shift=torch.cat([v0.bias.detach(), sh], 0),
+                                           act=ops.ACT_RELU, dtype=dt), int(v0.weight.shape[0]), int(vc0.weight.shape[0]))
+        plan["box_iou0"] = None
+        if self.iou_loss:
+            c0, c1 = self.bbox_head[0], self.iou_head[0]
+            if c0.weight.shape == c1.weight.shape and c0.padding == c1.padding and (c0.weight.shape[0] * 2) % 32 == 0:
+                plan["box_iou0"] = ops.ConvLayer(torch.cat([c0.weight.detach(), c1.weight.detach()], 0), stride=1, pad=c0.padding[0],
+                                                 shift=torch.cat([c0.bias.detach(), c1.bias.detach()], 0), act=ops.ACT_RELU, dtype=dt)
         for blk in L.layers[0].blocks:
             a = blk.attn
             f = lambda t: t.detach().float().contiguous()  # noqa: E731
@@ -235,8 +253,14 @@ class E2ESWVoteHead(nn.Module):
         bf16 = getattr(self, "compute_dtype", "f32") == "bf16"
         xc = ops.to_bf16(x) if bf16 else x
         vote = torch.zeros((b, h, w, 4), dtype=torch.float32, device=x.device)
-        plan["vote"][1](plan["vote"][0](xc), out=vote, out_channel_offset=0)
-        plan["vote_cls"][1](plan["vote_cls"][0](xc), out=vote, out_channel_offset=2)
+        if plan["vote0"] is not None:
+            v0, n_vote, n_cls = plan["vote0"]
+            mid0 = v0(xc)
+            plan["vote"][1](mid0, out=vote, out_channel_offset=0, in_channel_offset=0, in_channels=n_vote)
+            plan["vote_cls"][1](mid0, out=vote, out_channel_offset=2, in_channel_offset=n_vote, in_channels=n_cls)
+        else:
+            plan["vote"][1](plan["vote"][0](xc), out=vote, out_channel_offset=0)
+            plan["vote_cls"][1](plan["vote_cls"][0](xc), out=vote, out_channel_offset=2)
         L = self.layer
         t = self.patch_embed_tokens(xc if (bf16 and x.shape[3] % 64 == 0) else x)
         for i in range(len(plan["blocks"])):
@@ -244,11 +268,20 @@ class E2ESWVoteHead(nn.Module):
         feat = ops.layernorm(t, L.norm0.weight, L.norm0.bias, L.norm0.eps).view(b, h, w, C)
         fc = ops.to_bf16(feat) if bf16 else feat
         hm = plan["cls"][2](plan["cls"][1](plan["cls"][0](fc)), out_f32=True)
-        boxes = plan["bbox"][1](plan["bbox"][0](fc), out_f32=True)
+        iou = None
+        if plan["box_iou0"] is not None:
+            mid = plan["box_iou0"](fc)
+            cm = mid.shape[3] // 2
+            boxes = plan["bbox"][1](mid, in_channel_offset=0, in_channels=cm, out_f32=True)
+            iou = plan["iou"][1](mid, in_channel_offset=cm, in_channels=cm, out_f32=True)
+        else:
+            boxes = plan["bbox"][1](plan["bbox"][0](fc), out_f32=True)
+            if self.iou_loss:
+                iou = plan["iou"][1](plan["iou"][0](fc), out_f32=True)
         ret = dict(pred_centers=vote[..., 0:2], pred_vote_cls=vote[..., 2:3], hm=hm, reg=boxes[..., 0:2], height=boxes[..., 2:3],
                    dim=boxes[..., 3:6], rot=boxes[..., 6:8])
-        if self.iou_loss:
-            ret["iou"] = plan["iou"][1](plan["iou"][0](fc), out_f32=True)
+        if iou is not None:
+            ret["iou"] = iou
         ret["_feat"] = feat
         return ret
 
