@@ -500,6 +500,7 @@ def main():
                          "lose less to the ramp (1537 against 1482, five runs each)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the launcher, the rendezvous and the reductions only")
     ap.add_argument("--collective-timeout", type=float, default=300.0, help="seconds a rank waits in a collective before it gives up (N > 1)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 200-step repeat of the timed loop (`value_sustained`; counter passes of the profiler)")
     ap.add_argument("--no-c4", action="store_true", help="skip the Waymo PARTNER leg (BASELINE configs[3], N = 1 only)")
     ap.add_argument("--no-c5", action="store_true", help="skip the 300k-point streaming leg (BASELINE configs[4], N = 1 only)")
     args = ap.parse_args()
@@ -612,7 +613,7 @@ def main():
 
     # the same loop over >= 200 steps (the K timed steps above are 13 ms at the default K = 20: this is the sustained figure beside them)
     sustained = None
-    if engines:
+    if engines and not args.no_sustained:
         ks = max(200, 4 * args.steps)
         barrier()
         t1 = time.perf_counter()
