@@ -198,17 +198,9 @@ class E2ESWVoteHead(nn.Module):
                          conv(self.cls_head[2], ops.ACT_NONE)),
                     bbox=two(self.bbox_head), iou=two(self.iou_head) if self.iou_loss else None, blocks=[])
         # r5: the first convolutions of the box and the IoU branch read the same feature map (e2e_swv_head.py: Conv3x3 256 -> 64 + ReLU each): ONE
-        # 256 -> 128 launch (the 64-column launches ran the K-split F(4,3) kernel at half the matrix rate; bf16: the rows form needs 128 columns),
-        # the second convolutions read their 64-channel halves of its output.  Same arithmetic per output channel.
-        # ... and the vote / vote-class branches' first convolutions on the head's input (512 -> 64 + ReLU, 512 -> 256 + BatchNorm + ReLU) as one
-        # 512 -> 320 launch in the f32 mode (the bf16 rows form wants a multiple of 128 columns: two launches there)
-        plan["vote0"] = None
-        v0, vc0, vbn = self.vote_head[0], self.vote_cls_head[0], self.vote_cls_head[1]
-        if dt == "f32" and v0.weight.shape[1:] == vc0.weight.shape[1:] and v0.padding == vc0.padding and (v0.weight.shape[0] + vc0.weight.shape[0]) % 32 == 0:
-            sc, sh = ops.fold_bn(vbn.weight, vbn.bias, vbn.running_mean, vbn.running_var, vbn.eps, vc0.bias)
-            plan["vote0"] = (ops.ConvLayer(torch.cat([v0.weight.detach(), vc0.weight.detach()], 0), stride=1, pad=v0.padding[0],
-                                           scale=torch.cat([torch.ones_like(v0.bias.detach()), sc], 0), shift=torch.cat([v0.bias.detach(), sh], 0),
-                                           act=ops.ACT_RELU, dtype=dt), int(v0.weight.shape[0]), int(vc0.weight.shape[0]))
+        # 256 -> 128 launch (bf16: the rows form of conv_bf16.hip needs 128 columns -- 50 us instead of 2 x 50; f32: one launch less), the second
+        # convolutions read their 64-channel halves of its output.  Same arithmetic per output channel.  (The vote / vote-class pair as one
+        # 512 -> 320 launch was measured too: the F(4,3) dispatch then takes its K-split form at bs = 1, 628 us against 203 + 68: not kept.)
         plan["box_iou0"] = None
         if self.iou_loss:
             c0, c1 = self.bbox_head[0], self.iou_head[0]
@@ -253,14 +245,8 @@ class E2ESWVoteHead(nn.Module):
         bf16 = getattr(self, "compute_dtype", "f32") == "bf16"
         xc = ops.to_bf16(x) if bf16 else x
         vote = torch.zeros((b, h, w, 4), dtype=torch.float32, device=x.device)
-        if plan["vote0"] is not None:
-            v0, n_vote, n_cls = plan["vote0"]
-            mid0 = v0(xc)
-            plan["vote"][1](mid0, out=vote, out_channel_offset=0, in_channel_offset=0, in_channels=n_vote)
-            plan["vote_cls"][1](mid0, out=vote, out_channel_offset=2, in_channel_offset=n_vote, in_channels=n_cls)
-        else:
-            plan["vote"][1](plan["vote"][0](xc), out=vote, out_channel_offset=0)
-            plan["vote_cls"][1](plan["vote_cls"][0](xc), out=vote, out_channel_offset=2)
+        plan["vote"][1](plan["vote"][0](xc), out=vote, out_channel_offset=0)
+        plan["vote_cls"][1](plan["vote_cls"][0](xc), out=vote, out_channel_offset=2)
         L = self.layer
         t = self.patch_embed_tokens(xc if (bf16 and x.shape[3] % 64 == 0) else x)
         for i in range(len(plan["blocks"])):
