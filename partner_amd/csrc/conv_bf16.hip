@@ -659,6 +659,11 @@ int pn_conv2d_igemm_bf16_supported(const pn_conv_desc* d) {
   if (!(d->act == PN_ACT_NONE || d->act == PN_ACT_RELU)) return 0;
   if (d->deconv2x2 && !(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0)) return 0;
   if (d->stride < 1 || d->kh < 1 || d->kw < 1 || d->kh > 7 || d->kw > 7) return 0;
+  // the buffer descriptors address the map and the packed weights with 32-bit offsets below 2 GiB (larger maps stay on pn_conv2d_nhwc_bf16)
+  const unsigned long long in_bytes = (unsigned long long)d->batch * d->in_h * d->in_w * d->in_pixel_stride * 2ull;
+  const unsigned long long n_rows = (unsigned long long)(d->deconv2x2 ? 4 * d->cout : d->cout);
+  const unsigned long long w_bytes = (n_rows + 15) / 16 * 16 * (unsigned long long)d->kh * d->kw * d->cin * 2ull;
+  if (d->batch < 1 || d->in_h < 1 || d->in_w < 1 || in_bytes >= (1ull << 31) || w_bytes >= (1ull << 31)) return 0;
   return 1;
 }
 
