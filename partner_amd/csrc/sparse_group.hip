@@ -169,6 +169,9 @@ struct SpwArgs {
   int wide4_groups, wide2_groups;      // a wave takes 4 / at least 2 column tiles from this many live groups on
 };
 
+#ifndef PN_SG_EXP
+#define PN_SG_EXP 0      // diagnostic builds (tools/sparseq.sh): 1 no input gathers after the first, 2 no weight loads after the first, 4 no LDS image,
+#endif                   // 8 no MFMAs, 16 no join / stores, 32 no neighbour-table prologue -- wrong results, the time shows what a unit waits for
 // the taps of a mask in ascending order, one at a time
 struct UnitCursor {
   unsigned m;            // this wave's taps after the current one
@@ -247,7 +250,10 @@ __device__ __forceinline__ void sparse_conv_wave_body(const SpwArgs& a, int32_t*
     ca.start(gm);
     cb.start(gm);
     f32x4 ra[NI], fb[2][NC];
+    bool first_a = true, first_b = true;      // (diagnostic builds only)
     auto request_a = [&]() __attribute__((always_inline)) {
+      if ((PN_SG_EXP & 1) && !first_a) { ca.next(); return; }
+      first_a = false;
 #pragma unroll
       for (int q = 0; q < NI; ++q) {
         const int sv = src[ca.t * 32 + srow + RPI * q];      // (written by this wave: the LDS executes a wave's accesses in order)
@@ -258,6 +264,7 @@ __device__ __forceinline__ void sparse_conv_wave_body(const SpwArgs& a, int32_t*
       ca.next();
     };
     auto request_b = [&](int slot, int kk) __attribute__((always_inline)) {
+      if ((PN_SG_EXP & 2) && !first_b) return;
       const unsigned so_w = (unsigned)((cb.t * a.cin_chunks * 8 + kk * 2)) * cp16;
 #pragma unroll
       for (int c = 0; c < NC; ++c) fb[slot][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, cb.live ? uoff[c] : 0xffffffffu, so_w, 0));
@@ -266,20 +273,30 @@ __device__ __forceinline__ void sparse_conv_wave_body(const SpwArgs& a, int32_t*
     request_a();
     request_b(0, 0);
     request_b(1, 1);
+    first_b = false;
     if (SPC == 2) cb.next();
     for (int u = 0; u < nunits; ++u) {
-#pragma unroll
-      for (int q = 0; q < NI; ++q) *reinterpret_cast<f32x4*>(stage + (srow + RPI * q) * LD + scol) = ra[q];
-      request_a();
       f32x4 fa[SPC];
+      if (PN_SG_EXP & 4) {
 #pragma unroll
-      for (int k = 0; k < SPC; ++k) fa[k] = *reinterpret_cast<const f32x4*>(stage + li * LD + (2 * k + lh) * 4);
+        for (int k = 0; k < SPC; ++k) fa[k] = ra[k % NI];
+        request_a();
+      } else {
+#pragma unroll
+        for (int q = 0; q < NI; ++q) *reinterpret_cast<f32x4*>(stage + (srow + RPI * q) * LD + scol) = ra[q];
+        request_a();
+#pragma unroll
+        for (int k = 0; k < SPC; ++k) fa[k] = *reinterpret_cast<const f32x4*>(stage + li * LD + (2 * k + lh) * 4);
+      }
 #pragma unroll
       for (int k = 0; k < SPC; ++k) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k][j], fb[k & 1][c][j], acc[c], 0, 0, 0);
+          for (int c = 0; c < NC; ++c) {
+            if (PN_SG_EXP & 8) acc[c][j] += fa[k][j] * fb[k & 1][c][j];
+            else acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k][j], fb[k & 1][c][j], acc[c], 0, 0, 0);
+          }
         // the slot just used takes step k + 2: of this tap, or (past its last step) of the next one
         if (SPC == 4 && k == 2) cb.next();
         request_b(k & 1, (k + 2) % SPC);
@@ -352,6 +369,7 @@ __device__ __forceinline__ void sparse_conv_wave_body(const SpwArgs& a, int32_t*
   }
 
   }
+  if ((PN_SG_EXP & 16) && acc[0][0] != 12345.f) return;
   // ---- epilogue: rows back to their own places.  No branches: dead rows / columns are redirected out of the descriptors' range
   // (loads return 0, stores are dropped), the residuals of a column tile are all requested before the first store
   const bool relu = a.act == PN_ACT_RELU;
@@ -442,9 +460,6 @@ __global__ __launch_bounds__(256, 3) void sparse_conv_wave_kernel(SpwArgs a) {
 // of the taps whose NUMBER falls in its class -- every tap for four chunks (128 channels), t & 1 == w >> 1 for two (64 channels).  A site's
 // four partial sums are then sums over its own neighbours in ascending tap order (absent ones add exact zeros), joined as ((0 + 1) + 2) + 3.
 
-#ifndef PN_SG_EXP
-#define PN_SG_EXP 0      // diagnostic builds (tools/sparseq.sh): 1 no input gathers after the first, 2 no weight loads after the first, 4 no LDS image,
-#endif                   // 8 no MFMAs, 16 no join / stores, 32 no neighbour-table prologue -- wrong results, the time shows what a unit waits for
 template <int NC>
 __global__ __launch_bounds__(256, NC > 2 ? 3 : 4) void sparse_conv_group4_kernel(SpwArgs a) {
   constexpr int LD = 36;

@@ -7,7 +7,7 @@ for e in ${EXPS:-0}; do
   rm -f partner_amd/lib/sparse_group.o
   make -C partner_amd/csrc -j8 CXXFLAGS="$FLAGS -DPN_SG_EXP=$e" > /tmp/sg_make.log 2>&1 || tail -5 /tmp/sg_make.log
   echo "== exp $e"
-  python tools/sparse_conv_isolated.py 2>&1 | grep -E " 64-> 64 taps 27| 128->128 taps 27| 64->128|sum " | head -12
+  python tools/sparse_conv_isolated.py 2>&1 | grep -E "${SHOW:- 64-> 64 taps 27| 128->128 taps 27| 64->128|sum }" | head -24
 done
 rm -f partner_amd/lib/sparse_group.o
 make -C partner_amd/csrc -j8 > /tmp/sg_make.log 2>&1
