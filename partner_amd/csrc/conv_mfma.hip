@@ -1316,10 +1316,17 @@ __device__ __forceinline__ void small_n_tiled2_body(const ConvArgs& a, const int
       wv[k] = *reinterpret_cast<const f32x4*>(a.w + (((size_t)t * quads + min(qd, quads - 1)) * a.cout_pad + min(n, a.cout_pad - 1)) * 4);
       if (!ok) wv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // LDS [tap][quad][n / 2][k / 2][k & 1][n & 1]: a 16-byte read holds the weights of TWO outputs for two channels, the (w[n][k], w[n + 1][k])
+    // pairs v_pk_fma_f32 takes as they lie
 #pragma unroll
     for (int k = 0; k < WI; ++k) {
       const int i = threadIdx.x + 256 * k;
-      if (i < 9 * 16 * NOUT) *reinterpret_cast<f32x4*>(w_lds + (size_t)i * 4) = wv[k];
+      if (i < 9 * 16 * NOUT) {
+        const int n = i % NOUT, tq = i / NOUT;
+        float* dst = w_lds + ((size_t)tq * (NOUT / 2) + (n >> 1)) * 8 + (n & 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[(c >> 1) * 4 + (c & 1) * 2] = wv[k][c];
+      }
     }
   }
 #pragma unroll
@@ -1335,9 +1342,14 @@ __device__ __forceinline__ void small_n_tiled2_body(const ConvArgs& a, const int
     if (!xin[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (idx < SN2_PX * 4) *reinterpret_cast<f32x4*>(xt + sn2_slot(idx >> 2, cc_l) * 4) = v;
   }
-  float acc0[NOUT], acc1[NOUT];
+  // outputs n, n + 1 of one pixel as the halves of a v_pk_fma_f32 (two IEEE fmas per instruction: the bits of two v_fma_f32 at half the VALU
+  // issue): the weight pairs come out of LDS adjacent, the pixel's channel value is selected by op_sel -- no register moves to build operands
+  // (the compiler's own pairing of the two PIXELS spent 1.2 v_mov per packed fma on it)
+  using f32x2 = __attribute__((ext_vector_type(2))) float;
+  static_assert(NOUT % 2 == 0, "outputs are processed in pairs");
+  f32x2 acc0[NOUT / 2], acc1[NOUT / 2];
 #pragma unroll
-  for (int n = 0; n < NOUT; ++n) acc0[n] = acc1[n] = 0.f;
+  for (int n = 0; n < NOUT / 2; ++n) acc0[n] = acc1[n] = f32x2{0.f, 0.f};
   __syncthreads();   // the staged weights and tiles are complete
   const int r = lane >> 4, cl = lane & 15;
 #pragma unroll
@@ -1351,10 +1363,14 @@ __device__ __forceinline__ void small_n_tiled2_body(const ConvArgs& a, const int
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(xt + sn2_slot(p1, cc) * 4);
         const float* wp = w_lds + ((t * 16 + (c0 >> 2) + cc) * NOUT) * 4;
 #pragma unroll
-        for (int n = 0; n < NOUT; ++n) {   // columns past Cout are zero in the packed weights
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + n * 4);
+        for (int n = 0; n < NOUT / 2; ++n) {   // columns past Cout are zero in the packed weights
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(wp + n * 8), wb = *reinterpret_cast<const f32x4*>(wp + n * 8 + 4);
+          const f32x2 w[4] = {f32x2{wa[0], wa[1]}, f32x2{wa[2], wa[3]}, f32x2{wb[0], wb[1]}, f32x2{wb[2], wb[3]}};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { acc0[n] = fmaf(x0[k], wv[k], acc0[n]); acc1[n] = fmaf(x1[k], wv[k], acc1[n]); }
+          for (int k = 0; k < 4; ++k) {
+            acc0[n] = __builtin_elementwise_fma(f32x2{x0[k], x0[k]}, w[k], acc0[n]);
+            acc1[n] = __builtin_elementwise_fma(f32x2{x1[k], x1[k]}, w[k], acc1[n]);
+          }
         }
       }
     }
@@ -1362,7 +1378,7 @@ __device__ __forceinline__ void small_n_tiled2_body(const ConvArgs& a, const int
   __syncthreads();   // every wave is done with its tile: the partial sums go into the same LDS
   float (*part)[128][13] = reinterpret_cast<float (*)[128][13]>(xt_all);
 #pragma unroll
-  for (int n = 0; n < NOUT; ++n) { part[q][lane][n] = acc0[n]; part[q][64 + lane][n] = acc1[n]; }
+  for (int n = 0; n < NOUT; ++n) { part[q][lane][n] = acc0[n >> 1][n & 1]; part[q][64 + lane][n] = acc1[n >> 1][n & 1]; }
   __syncthreads();
   // thread (pixel p = tid & 127: rows 0 .. 3 then 4 .. 7, output group g = tid >> 7): outputs n = g, g + 2, ...
   const int p = threadIdx.x & 127, g = threadIdx.x >> 7;
