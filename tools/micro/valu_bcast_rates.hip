@@ -7,6 +7,10 @@
 //   4  32 v_readlane_b32 alone
 //   5  h through LDS: one ds_write_b32 + 8 ds_read_b128 (same address in every lane) per 32 values, then v_pk_fma_f32 on VGPRs, one chain
 //   6  v_fma_f32 (not packed) with v_readlane operands, two chains (the r4 form)
+//   7  scalar fmaf source the compiler pairs into v_pk_fma_f32 + one v_mov_b32 per packed fma: the moves cost nothing beside the packed fmas
+//   8  v_pk_fma_f32 on distinct register pairs, four chains
+// MI355X, r5: 0: 7.6   1: 6.6   2: 10.2   3: 9.7   5: 9.9   6: 9.9   7: 6.2   8: 6.2 cycles of the SIMD per term (at 2.4 GHz): a packed fp32 fma
+// does not issue every 4 cycles from two waves per SIMD, the readlane in front of it costs 3.6, LDS instead of readlane buys nothing.
 //   hipcc -O3 --offload-arch=gfx950 tools/micro/valu_bcast_rates.hip -o /tmp/vbr && /tmp/vbr
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -52,6 +56,16 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* _
         for (int i = 0; i < 8; ++i) hv[i] = *reinterpret_cast<const f32x4*>(&s_h[wv][4 * i]);
 #pragma unroll
         for (int i = 0; i < 32; ++i) acc[0] = __builtin_elementwise_fma(w[i], f32x2{hv[i >> 2][i & 3], hv[i >> 2][i & 3]}, acc[0]);
+      } else if constexpr (V == 7) {      // clock calibration: plain v_fma_f32, eight independent chains (4 cycles per instruction by the book)
+        float c[8] = {acc[0][0], acc[0][1], acc[1][0], acc[1][1], acc[2][0], acc[2][1], acc[3][0], acc[3][1]};
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { c[i & 7] = fmaf(w[i][0], h, c[i & 7]); }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { c[i & 7] = fmaf(w[i][1], h, c[i & 7]); }
+        acc[0] = f32x2{c[0], c[1]}; acc[1] = f32x2{c[2], c[3]}; acc[2] = f32x2{c[4], c[5]}; acc[3] = f32x2{c[6], c[7]};
+      } else if constexpr (V == 8) {      // packed fma, both sources register PAIRS that differ (no op_sel broadcast), four chains
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[i & 3] = __builtin_elementwise_fma(w[i], w[(i + 5) & 31], acc[i & 3]);
       } else {
         float a0 = acc[0][0], a1 = acc[0][1];
 #pragma unroll
@@ -93,5 +107,7 @@ int main() {
   run<4>(src, dst, "32 readlanes alone");
   run<5>(src, dst, "h through LDS (1 write + 8 broadcast b128 reads), pk_fma, one chain");
   run<6>(src, dst, "readlane -> two v_fma_f32, two chains (r4 form)");
+  run<7>(src, dst, "plain v_fma_f32, eight chains: 64 instructions per 64 'terms' (clock calibration)");
+  run<8>(src, dst, "pk_fma, distinct register pairs, four chains");
   return 0;
 }
