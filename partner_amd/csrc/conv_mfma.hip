@@ -1390,9 +1390,254 @@ __device__ __forceinline__ void small_n_tiled2_body(const ConvArgs& a, const int
   }
 }
 
+// r5: the same 8 x 16 tile on the MATRIX pipe.  The two-pixel form above is bound by the LDS pipe again -- a broadcast ds_read_b128 of weights
+// costs the pipe as much as a read of 64 different addresses (8 cycles), 504 of them per wave and tile, two blocks per CU: 13 us of LDS time per
+// pair of tiles -- and its weights (28 KB of LDS) keep a CU at two blocks.  v_mfma_f32_16x16x4_f32 takes the weights as a B fragment that lives in
+// REGISTERS for the whole kernel (lane (n, j): w[tap][4 i + j][n], 36 registers for the wave's 16 channels x 9 taps, outputs padded to 16
+// columns) and the pixels as the A operand straight from the tile (lane (m, j): channel 4 i + j of pixel m of an output row: one ds_read_b32,
+// conflict-free by the slot rotation): 288 MFMAs per wave and tile instead of 1728 packed fmas + 504 LDS reads, no weights in LDS (three
+// blocks per CU: the 768 tiles of the nuScenes head are ONE round).  An MFMA is a k-ordered fmaf chain (guide, "FP32-input MFMA") and the
+// steps are issued in the order of the loop above (tap, channel quad, channel), so the outputs are bit-identical to it.
+template <int KQ>      // channel quads per wave (cq / 4): compile time, so that the K loop is ONE basic block (a wave-uniform branch per step cut it into
+                       // 120 blocks and the register allocator moved all eight accumulators at every boundary: 37 us instead of 15)
+__device__ __forceinline__ void small_n_mfma_body(const ConvArgs& a, const int tile, float* xt_all) {
+  const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tx_n = a.OW / SNT_W, ty_n = a.OH / SN2_H;
+  const int b = tile / (tx_n * ty_n), tr = tile - b * (tx_n * ty_n), ty = tr / tx_n, tx = tr - ty * tx_n;
+  const int oh0 = ty * SN2_H, ow0 = tx * SNT_W;
+  const int cq = ((a.Cin + 15) / 16) * 4;                 // channels per wave: whole quads, at most 16 (Cin <= 64)
+  const int c0 = q * cq, c1 = min(a.Cin, c0 + cq);
+  float* xt = xt_all + q * (SN2_PX * 16);
+  constexpr int XI = (SN2_PX * 4 + 63) / 64;
+  f32x4 xv[XI];
+  bool xin[XI];
+  const int cc_l = lane & 3, c_l = c0 + 4 * cc_l, ccl = min(c_l, a.Cin - 4);
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int px = min((lane + 64 * i) >> 2, SN2_PX - 1);
+    const int hr = px / SNT_HW, hc = px - hr * SNT_HW;
+    const int ih = oh0 - 1 + hr, iw = ow0 - 1 + hc;
+    xin[i] = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W && c_l < c1;
+    const int ihc = min(max(ih, 0), a.H - 1), iwc = min(max(iw, 0), a.W - 1);
+    xv[i] = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.H + ihc) * a.W + iwc) * a.in_ps + a.in_co + ccl);
+  }
+  f32x4 t0 = {1.f, 0.f, 1.f, 0.f}, t1 = {1.f, 0.f, 1.f, 0.f};
+  if (a.ni_ab) {      // the producing norm's (A, B) pairs of the lane's four channels
+    const float* tab = a.ni_ab + ((size_t)b * a.ni_C + ccl) * 2;
+    t0 = *reinterpret_cast<const f32x4*>(tab);
+    t1 = *reinterpret_cast<const f32x4*>(tab + 4);
+  }
+  // B fragments: lane (n = lane & 15, j = lane >> 4) holds w[tap][channel c0 + 4 i + j][n] of the packed [tap][cin_pad / 4][cout_pad][4]
+  const int mn = lane & 15, j = lane >> 4;
+  const int quads = a.cin_chunks * 8;
+  float wr[9][KQ];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      const int quad = (c0 >> 2) + i;
+      const bool ok = quad < quads && c0 + 4 * i < c1 && mn < a.cout_pad;
+      const float v = a.w[(((size_t)t * quads + min(quad, quads - 1)) * a.cout_pad + min(mn, a.cout_pad - 1)) * 4 + j];
+      wr[t][i] = ok ? v : 0.f;
+    }
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int idx = lane + 64 * i;
+    f32x4 v = xv[i];
+    if (a.ni_ab) {
+      v[0] = fmaxf(fmaf(v[0], t0[0], t0[1]), 0.f);
+      v[1] = fmaxf(fmaf(v[1], t0[2], t0[3]), 0.f);
+      v[2] = fmaxf(fmaf(v[2], t1[0], t1[1]), 0.f);
+      v[3] = fmaxf(fmaf(v[3], t1[2], t1[3]), 0.f);
+    }
+    if (!xin[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (idx < SN2_PX * 4) *reinterpret_cast<f32x4*>(xt + sn2_slot(idx >> 2, cc_l) * 4) = v;
+  }
+  f32x4 acc[SN2_H];
+#pragma unroll
+  for (int g = 0; g < SN2_H; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();   // the tiles are complete
+  // halo row rr, column offset kw: the pixel value is read ONCE and feeds the (up to) three output rows g = rr - kh it is a tap (kh, kw) of.
+  // Output row g still sees its steps in the order (kh, kw, channel) -- rr ascending is kh ascending for a fixed g.
+#pragma unroll
+  for (int rr = 0; rr < SN2_H + 2; ++rr) {
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int p = rr * SNT_HW + mn + kw;
+      const float* px = xt + 16 * p + j;
+      const int r0 = p >> 2;
+#pragma unroll
+      for (int i = 0; i < KQ; ++i) {      // quads past the wave's last channel: zeros in the tile and in wr (the last wave of a Cin that is no multiple of 16)
+        const float xa = px[((i + r0) & 3) * 4];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int g = rr - kh;
+          if (g >= 0 && g < SN2_H) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wr[kh * 3 + kw][i], acc[g], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();   // every wave is done with its tile: the partial sums go into the same LDS
+  float (*part)[128][13] = reinterpret_cast<float (*)[128][13]>(xt_all);
+  if (mn < 13) {     // D: lane holds rows (pixels of the output row) 4 j + r, column (output) mn
+#pragma unroll
+    for (int g = 0; g < SN2_H; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[q][g * 16 + 4 * j + r][mn] = acc[g][r];
+  }
+  __syncthreads();
+  // thread (pixel p = tid & 127 = 16 row + column, output group g = tid >> 7): outputs n = g, g + 2, ...
+  const int p = threadIdx.x & 127, g2 = threadIdx.x >> 7;
+  const size_t mo = ((size_t)(b * a.OH + oh0 + (p >> 4)) * a.OW + ow0 + (p & 15));
+  for (int n = g2; n < a.Cout; n += 2) {
+    const float v = (part[0][p][n] + part[1][p][n]) + (part[2][p][n] + part[3][p][n]);
+    const float sc = a.scale ? a.scale[n] : 1.f, sh = a.shift ? a.shift[n] : 0.f;
+    a.out[mo * a.out_ps + a.out_co + n] = pn::apply_act(fmaf(v, sc, sh), a.act);
+  }
+}
+
 __host__ __device__ __forceinline__ bool small_n_tiled_ok(const ConvArgs& a) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_h == 1 && a.pad_w == 1 && a.OW % SNT_W == 0 && a.OH % SNT_H == 0 && a.OH == a.H && a.OW == a.W &&
          (a.ni_ab == nullptr || a.ni_S == 1) && (a.in_ps % 4) == 0 && (a.in_co % 4) == 0;
+}
+
+// One to three output channels (every branch of a centre head but the heat map): even the 16-column MFMA tile above is 6 - 19 % used.  The
+// G form uses the columns for (tap, output) instead: G[halo pixel][(t, n)] = sum_c x[pixel][c] w[t][c][n] is ONE 1 x 1 GEMM over the 10 x 18
+// halo pixels (12 row tiles, 9 Cout <= 27 columns = NT <= 2 column tiles, K = Cin), a wave takes three row tiles with ALL channels, and
+// out[p][n] = sum_t G[p + offset(t)][(t, n)] is a nine-term sum per output read back from LDS: 96 MFMAs per wave instead of 288.
+// Summation order: channels first (a k-ordered fma chain per tap, the MFMA's), then the taps in order -- not the order of the forms above.
+template <int NT>
+__device__ __forceinline__ void small_n_gform_body(const ConvArgs& a, const int tile, float* xt_all) {
+  const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tx_n = a.OW / SNT_W, ty_n = a.OH / SN2_H;
+  const int b = tile / (tx_n * ty_n), tr = tile - b * (tx_n * ty_n), ty = tr / tx_n, tx = tr - ty * tx_n;
+  const int oh0 = ty * SN2_H, ow0 = tx * SNT_W;
+  // loader: wave q brings channels 16 q .. 16 q + 15 of every halo pixel (chunks past Cin: zeros), the image of chunk q is xt_all + q * SN2_PX * 16
+  const int c0 = q * 16, c1 = min(a.Cin, c0 + 16);
+  float* xt = xt_all + q * (SN2_PX * 16);
+  constexpr int XI = (SN2_PX * 4 + 63) / 64;
+  f32x4 xv[XI];
+  bool xin[XI];
+  const int cc_l = lane & 3, c_l = c0 + 4 * cc_l, ccl = max(0, min(c_l, a.Cin - 4));
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int px = min((lane + 64 * i) >> 2, SN2_PX - 1);
+    const int hr = px / SNT_HW, hc = px - hr * SNT_HW;
+    const int ih = oh0 - 1 + hr, iw = ow0 - 1 + hc;
+    xin[i] = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W && c_l < c1;
+    const int ihc = min(max(ih, 0), a.H - 1), iwc = min(max(iw, 0), a.W - 1);
+    xv[i] = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.H + ihc) * a.W + iwc) * a.in_ps + a.in_co + ccl);
+  }
+  f32x4 t0 = {1.f, 0.f, 1.f, 0.f}, t1 = {1.f, 0.f, 1.f, 0.f};
+  if (a.ni_ab) {
+    const float* tab = a.ni_ab + ((size_t)b * a.ni_C + ccl) * 2;
+    t0 = *reinterpret_cast<const f32x4*>(tab);
+    t1 = *reinterpret_cast<const f32x4*>(tab + 4);
+  }
+  // B fragments of all 16 K steps: lane (col = lane & 15, j = lane >> 4), column 16 nt + col = (tap t, output n), channel 4 k4 + j
+  const int mn = lane & 15, j = lane >> 4;
+  const int quads = a.cin_chunks * 8, ncol = 9 * a.Cout;
+  float wr[16][NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = 16 * nt + mn, t = min(col / a.Cout, 8), n = col - (col / a.Cout) * a.Cout;
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+      const bool ok = col < ncol && k4 < quads && 4 * k4 < a.Cin;
+      const float v = a.w[(((size_t)t * quads + min(k4, quads - 1)) * a.cout_pad + n) * 4 + j];
+      wr[k4][nt] = ok ? v : 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int idx = lane + 64 * i;
+    f32x4 v = xv[i];
+    if (a.ni_ab) {
+      v[0] = fmaxf(fmaf(v[0], t0[0], t0[1]), 0.f);
+      v[1] = fmaxf(fmaf(v[1], t0[2], t0[3]), 0.f);
+      v[2] = fmaxf(fmaf(v[2], t1[0], t1[1]), 0.f);
+      v[3] = fmaxf(fmaf(v[3], t1[2], t1[3]), 0.f);
+    }
+    if (!xin[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (idx < SN2_PX * 4) *reinterpret_cast<f32x4*>(xt + sn2_slot(idx >> 2, cc_l) * 4) = v;
+  }
+  f32x4 acc[3][NT];
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();   // the tiles are complete
+  // wave q: halo pixels 48 q .. 48 q + 47 (rows past the 180th are clamped: computed, never read)
+#pragma unroll
+  for (int k4 = 0; k4 < 16; ++k4) {
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) {
+      const int px = min(48 * q + 16 * mt + mn, SN2_PX - 1);
+      const float xa = xt_all[(k4 >> 2) * (SN2_PX * 16) + sn2_slot(px, k4 & 3) * 4 + j];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wr[k4][nt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+  __syncthreads();   // every wave is done with the tiles: G goes into the same LDS
+  constexpr int GLD = 16 * NT + 1;
+  float* G = xt_all;      // [SN2_PX][GLD]
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int px = 48 * q + 16 * mt + 4 * j + r;
+        if (px < SN2_PX) G[px * GLD + 16 * nt + mn] = acc[mt][nt][r];
+      }
+  __syncthreads();
+  // thread -> (pixel p = 16 row + column, output n): the nine taps in order
+  for (int o = threadIdx.x; o < 128 * a.Cout; o += 256) {
+    const int n = o >> 7, p = o & 127, row = p >> 4, colp = p & 15;
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v += G[((row + t / 3) * SNT_HW + colp + t % 3) * GLD + t * a.Cout + n];
+    const float sc = a.scale ? a.scale[n] : 1.f, sh = a.shift ? a.shift[n] : 0.f;
+    a.out[((size_t)(b * a.OH + oh0 + row) * a.OW + ow0 + colp) * a.out_ps + a.out_co + n] = pn::apply_act(fmaf(v, sc, sh), a.act);
+  }
+}
+
+// every job an 8 x 16-tile job (MultiArgs.job[].snt2) or a 1 x 1 job: the matrix-pipe body for the tiles, only the tiles in LDS
+__global__ __launch_bounds__(256, 3) void conv_small_n_mfma_multi_kernel(MultiArgs m_by_value) {
+  __shared__ __attribute__((aligned(16))) float xt_lds[4 * SN2_PX * 16];
+  static_assert(4 * SN2_PX * 16 >= 4 * 128 * 13 && 4 * SN2_PX * 16 >= SN2_PX * 33, "the partial sums / the G image reuse the tiles' LDS");
+  typedef const __attribute__((address_space(4))) int* kptr_t;
+  const kptr_t base = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const int njobs = base[offsetof(MultiArgs, njobs) / 4];
+  const int t = blockIdx.x;
+  int j = 0;
+  for (int k = 1; k < njobs; ++k)
+    if (t >= base[offsetof(MultiArgs, first) / 4 + k]) j = k;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const int local = t - base[offsetof(MultiArgs, first) / 4 + j];
+  constexpr int JW = sizeof(ConvArgs) / 4;
+  union { ConvArgs a; int w[JW]; } u;
+  const kptr_t src = base + offsetof(MultiArgs, job) / 4 + j * JW;
+#pragma unroll
+  for (int i = 0; i < JW; ++i) u.w[i] = src[i];
+  const ConvArgs& a = u.a;
+  if (a.snt2 && a.Cout <= 3) {
+    if (a.Cout == 1) small_n_gform_body<1>(a, local, xt_lds);
+    else small_n_gform_body<2>(a, local, xt_lds);
+  } else if (a.snt2) {
+    switch ((a.Cin + 15) / 16) {
+      case 1: small_n_mfma_body<1>(a, local, xt_lds); break;
+      case 2: small_n_mfma_body<2>(a, local, xt_lds); break;
+      case 3: small_n_mfma_body<3>(a, local, xt_lds); break;
+      default: small_n_mfma_body<4>(a, local, xt_lds); break;
+    }
+  } else {      // a 1 x 1 job of the same launch (the range-stratified branch's last layer): the vector body, its partial sums and weights in the tiles' LDS
+    float (*part)[64][13] = reinterpret_cast<float (*)[64][13]>(xt_lds);
+    float* w_lds = xt_lds + 4 * 64 * 13;
+    static_assert(4 * 64 * 13 + 16 * 12 * 4 <= 4 * SN2_PX * 16, "the 1 x 1 body fits the tiles' LDS");
+    if (a.ncols <= 4) small_n_body<4, 1>(a, local, part, w_lds);
+    else small_n_body<12, 1>(a, local, part, w_lds);
+  }
 }
 
 __global__ __launch_bounds__(256) void conv_small_n_multi_kernel(MultiArgs m_by_value) {
@@ -2003,12 +2248,18 @@ int pn_conv2d_small_n_multi_f32(const pn_conv_job* jobs, int njobs, pn_stream_t 
   memset(&m, 0, sizeof(m));
   m.njobs = njobs;
   int total = 0;
-  for (int j = 0; j < njobs; ++j) {
+  // the 3 x 3 jobs first: their blocks are the long ones (the hardware starts blocks in index order, the short 1 x 1 blocks fill the tail)
+  int order[kMaxJobs], no = 0;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int j = 0; j < njobs; ++j)
+      if ((jobs[j].desc.kh * jobs[j].desc.kw == 9) == (pass == 0)) order[no++] = j;
+  for (int jo = 0; jo < njobs; ++jo) {
+    const int j = jo;
     ConvArgs& a = m.job[j];
     size_t extra = 0;
-    if (int rc = job_to_args(jobs[j], 3, a, extra)) return rc;
+    if (int rc = job_to_args(jobs[order[jo]], 3, a, extra)) return rc;
     const int taps = a.KH * a.KW;
-    PN_REQUIRE(a.mode == MODE_CONV && a.zdim == 1 && a.ncols <= 12 && a.Cin <= 64 && (taps == 9 || taps == 1) && !jobs[j].stat_partials,
+    PN_REQUIRE(a.mode == MODE_CONV && a.zdim == 1 && a.ncols <= 12 && a.Cin <= 64 && (taps == 9 || taps == 1) && !jobs[order[jo]].stat_partials,
                "conv_small_n_multi: plain 1x1 / 3x3 convolutions with <= 64 input channels and <= 12 output columns, no statistics");
     PN_REQUIRE(!a.ni_ab || a.ni_S == 1 || taps == 1, "conv_small_n_multi: a range-stratified norm table needs a 1x1 kernel");
     PN_REQUIRE(!a.ni_ab || a.ni_S > 1 || a.B == 1 || (a.OH * a.OW) % 64 == 0, "conv_small_n_multi: with batch > 1 a sample must be a whole number of 64-pixel tiles");
@@ -2021,6 +2272,15 @@ int pn_conv2d_small_n_multi_f32(const pn_conv_job* jobs, int njobs, pn_stream_t 
   m.total = total;
   hipStream_t st = pn::S(stream);
   pn::ProfileSlot ps;
+  // every job in 8 x 16 tiles: the matrix-pipe form (same bits; PN_SMALL_N_MFMA=0: the packed-fma form)
+  static const int use_mfma = [] { const char* e = getenv("PN_SMALL_N_MFMA"); return e ? atoi(e) : 1; }();
+  bool all_tiles = use_mfma != 0;
+  for (int j = 0; j < njobs; ++j) all_tiles = all_tiles && (m.job[j].snt2 || m.job[j].KH * m.job[j].KW == 1);
+  if (all_tiles) {
+    if (pn::take_profile_slot(ps)) hipExtLaunchKernelGGL(conv_small_n_mfma_multi_kernel, dim3(total), dim3(256), 0, st, ps.start, ps.stop, 0, m);
+    else hipLaunchKernelGGL(conv_small_n_mfma_multi_kernel, dim3(total), dim3(256), 0, st, m);
+    return pn::check_launch("conv_small_n_mfma_multi_kernel");
+  }
   if (pn::take_profile_slot(ps)) hipExtLaunchKernelGGL(conv_small_n_multi_kernel, dim3(total), dim3(256), 0, st, ps.start, ps.stop, 0, m);
   else hipLaunchKernelGGL(conv_small_n_multi_kernel, dim3(total), dim3(256), 0, st, m);
   return pn::check_launch("conv_small_n_multi_kernel");

@@ -637,7 +637,7 @@ class CenterHeadSingle(CenterHead):
         small = all(j.layer.cin <= 64 and j.layer.out_channels <= 12 and (j.layer.kh, j.layer.kw) in ((1, 1), (3, 3)) and j.layer.stride == 1
                     and (strata == 1 or j.layer.kh == 1) for j, (_, strata, _, _) in zip(jobs, tabs))
         if small and not getattr(self, "force_mfma_last", False):
-            ops.conv_small_n_multi(jobs)     # few output columns: the VALU kernel (an MFMA tile would be 3 % used)
+            ops.conv_small_n_multi(jobs)     # few output columns: 16-column MFMA tiles over (tap, output) columns (r5; conv_mfma.hip small_n_gform_body)
         else:
             ops.conv_multi(jobs, 4)
         return outs
