@@ -72,6 +72,14 @@ __host__ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
   return (unsigned short)(u >> 16);
 }
 
+// two f32 -> one register of two bf16, round to nearest even, on gfx950's v_cvt_pk_bf16_f32 (the bits of f32_to_bf16_bits for every finite value;
+// the epilogue of a bf16 GEMM is vector work -- ten integer operations per value here were a third of the 256 -> 1024 GELU launch)
+__device__ __forceinline__ unsigned cb_pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
+
 #ifndef PN_CB_EXP
 #define PN_CB_EXP 0      // diagnostic builds (tools/convbf16q.sh DEFS=-DPN_CB_EXP=k): 1 no pixel loads after step 0, 2 no weight loads after step 0,
 #endif                   // 4 no MFMAs, 8 no fragment reads after step 0 -- wrong results, the time shows what a K step waits for
@@ -256,8 +264,8 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_bf16_igemm_kernel(const CbAr
           if constexpr (F32OUT) {
             *reinterpret_cast<f32x4*>(dst) = v;
           } else {
-            const unsigned lo = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-            const unsigned hi = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+            const unsigned lo = cb_pack_bf16x2(v[0], v[1]);
+            const unsigned hi = cb_pack_bf16x2(v[2], v[3]);
             *reinterpret_cast<uint2*>(dst) = uint2{lo, hi};
           }
         }
@@ -309,8 +317,8 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_bf16_igemm_kernel(const CbAr
       if constexpr (F32OUT) {
         *reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + o) = v;
       } else {
-        const unsigned lo = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-        const unsigned hi = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+        const unsigned lo = cb_pack_bf16x2(v[0], v[1]);
+        const unsigned hi = cb_pack_bf16x2(v[2], v[3]);
         *reinterpret_cast<uint2*>(static_cast<unsigned short*>(a.out) + o) = uint2{lo, hi};
       }
     }
@@ -515,8 +523,8 @@ __global__ __launch_bounds__(kRowsWaves * 64) void conv_bf16_rows_kernel(const C
           if constexpr (F32OUT) {
             *reinterpret_cast<f32x4*>(dst) = v;
           } else {
-            const unsigned lo = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-            const unsigned hi = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+            const unsigned lo = cb_pack_bf16x2(v[0], v[1]);
+            const unsigned hi = cb_pack_bf16x2(v[2], v[3]);
             *reinterpret_cast<uint2*>(dst) = uint2{lo, hi};
           }
         }

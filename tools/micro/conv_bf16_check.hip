@@ -133,5 +133,37 @@ int main(int argc, char** argv) {
            flop / us * 1e-6, flop / us * 1e-6 / 2500.0);
     hipFree(d_in); hipFree(d_w); hipFree(d_sc); hipFree(d_sh); hipFree(d_ref); hipFree(d_out); hipFree(d_pk);
   }
+  // the token GEMMs of the SetBlock / Swin stages on the same kernel (pn_linear_bf16): times only (tests/test_hip_linear.py checks the values)
+  struct Lin { int m, k, n, f32out, act, res; };
+  const Lin lins[] = {{73728, 256, 256, 1, 0, 1}, {73728, 256, 512, 1, 0, 0}, {73728, 256, 768, 1, 0, 0}, {73728, 256, 1024, 0, PN_ACT_GELU, 0},
+                      {73728, 1024, 256, 1, 0, 1}, {73728, 256, 256, 0, 0, 0}};
+  for (const Lin& l : lins) {
+    void *x, *w, *out; float *wf, *bias, *res;
+    CK(hipMalloc(&x, (size_t)l.m * l.k * 2)); CK(hipMalloc(&wf, (size_t)l.n * l.k * 4)); CK(hipMalloc(&bias, l.n * 4));
+    CK(hipMalloc(&res, (size_t)l.m * l.n * 4)); CK(hipMalloc(&out, (size_t)l.m * l.n * 4));
+    CK(hipMemset(x, 0x3c, (size_t)l.m * l.k * 2)); CK(hipMemset(wf, 0, (size_t)l.n * l.k * 4)); CK(hipMemset(bias, 0, l.n * 4)); CK(hipMemset(res, 0, (size_t)l.m * l.n * 4));
+    const size_t pk = pn_conv_bf16_rows_packed_elems(l.n, l.k, 1, 1);
+    CK(hipMalloc(&w, pk * 2));
+    if (pn_pack_conv_weight_bf16_rows(wf, l.n, l.k, 1, 1, w, nullptr) != 0) { printf("pack failed\n"); return 1; }
+    hipStream_t st; CK(hipStreamCreate(&st));
+    auto run = [&]() { return pn_linear_bf16(x, l.m, l.k, l.k, w, l.n, bias, l.act, l.res ? res : nullptr, l.n, out, l.n, l.f32out, st); };
+    for (int i = 0; i < 3; ++i) if (run() != 0) { char buf[256]; pn_last_error(buf, sizeof buf); printf("linear failed: %s\n", buf); return 1; }
+    CK(hipStreamSynchronize(st));
+    hipGraph_t graph; hipGraphExec_t gexec;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < reps; ++i) run();
+    CK(hipStreamEndCapture(st, &graph));
+    CK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(gexec, st)); CK(hipStreamSynchronize(st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, st)); CK(hipGraphLaunch(gexec, st)); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / reps, flop = 2.0 * l.m * (double)l.k * l.n;
+    const double bytes = (double)l.m * l.k * 2 + (double)l.m * l.n * (l.f32out ? 4 : 2) + (l.res ? (double)l.m * l.n * 4 : 0);
+    printf("linear %d x %4d -> %4d %s%s%s  %8.2f us  %7.1f TFLOP/s  %.3f of 2.5 PF   %.2f TB/s of compulsory traffic\n", l.m, l.k, l.n, l.f32out ? "f32 out" : "bf16 out",
+           l.act ? " gelu" : "", l.res ? " +res" : "", us, flop / us * 1e-6, flop / us * 1e-6 / 2500.0, bytes / us * 1e-6);
+    CK(hipGraphExecDestroy(gexec)); CK(hipGraphDestroy(graph)); CK(hipStreamDestroy(st));
+    hipFree(x); hipFree(wf); hipFree(bias); hipFree(res); hipFree(out); hipFree(w);
+  }
   return 0;
 }
