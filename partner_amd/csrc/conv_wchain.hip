@@ -486,6 +486,181 @@ __global__ __launch_bounds__(64 * 6 * KS * CT * QT) void conv_wchain2_kernel(WCh
   wchain2_body<KS, CT, QT>(a, blockIdx.x, gridDim.x);
 }
 
+// ---- F(4, 3) along the map HEIGHT as well (r5): a HEXADECET (four rows x four pixels) from 6 x 6 = 36 products per channel pair -- 2.25 per
+// output against 3 -- with the planes format unchanged.  A wave that kept all six height positions would need 96 accumulator registers (two
+// waves per SIMD: eight per CU where six width positions want twelve), so the height positions are split over TWO waves: wave (p, sh) holds
+// positions 3 sh .. 3 sh + 2 of width position p (three accumulators), reads the five input rows its positions depend on (sh = 0: rows
+// 4 t - 1 .. 4 t + 3, sh = 1: rows 4 t .. 4 t + 4 of position p), forms B^T d on the fly and folds its three positions to partial values of the
+// four output rows (A^T is linear: the two halves add).  Join: the sh = 0 waves write the 6 x 4 row tiles, the sh = 1 waves add theirs
+// (a fixed order), then wchain_finish per row.  Block = 12 waves = one tile of 32 hexadecets (whole row groups) x 32 columns, K = Cin
+// unsplit; the join is 96 KB of LDS, which is why a 64-quad row (two tiles that the finish must see together) does not fit: frames of
+// 32 quads and less.  Half the blocks of the 12-wave F(2,3) x F(4,3) form on the same map: chosen where other frames fill the chip.
+template <int SH>
+__device__ __forceinline__ void wchain3_kloop(const WChainArgs& a, const __amdgpu_buffer_rsrc_t rsrc_v, const __amdgpu_buffer_rsrc_t rsrc_w, const int p,
+                                              const unsigned voff, const unsigned uoff, f32x16 (&acc)[3]) {
+  const unsigned cp16 = (unsigned)a.cout_pad * 16u;
+  const unsigned row16 = (unsigned)a.Wq * 16u;
+  f32x4 d[2][5], u[2][3];
+  auto load_step = [&](int cg, int slot) __attribute__((always_inline)) {
+    const unsigned so_v = (unsigned)((p * a.cg_in + cg) * 2) * a.plane_bytes + (unsigned)SH * row16;
+    const unsigned so_u = (unsigned)((((cg >> 2) * 6 + 3 * SH) * 6 + p) * 8 + (cg & 3) * 2) * cp16;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) d[slot][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, voff, so_v + (unsigned)r * row16, 0));
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) u[slot][s2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, uoff, so_u + (unsigned)(s2 * 48) * cp16, 0));
+  };
+  const int cg_last = a.cg_in - 1;
+  load_step(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  load_step(1, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int cg = 0; cg <= cg_last; cg += 2) {
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      const int nx = cg + 2 + slot <= cg_last ? cg + 2 + slot : cg_last;      // the last refills re-read a live group (stay inside the buffers)
+      f32x4 b[3];
+      const f32x4 c4 = {4.f, 4.f, 4.f, 4.f}, m4 = {-4.f, -4.f, -4.f, -4.f}, m5 = {-5.f, -5.f, -5.f, -5.f}, c2 = {2.f, 2.f, 2.f, 2.f}, m2 = {-2.f, -2.f, -2.f, -2.f};
+      if constexpr (SH == 0) {      // d[.][r] = input row 4 t - 1 + r: positions 0 .. 2 of B^T (wino4_input_transform4's tree)
+        const f32x4 e = __builtin_elementwise_fma(m4, d[slot][2], d[slot][4]), o = __builtin_elementwise_fma(m4, d[slot][1], d[slot][3]);
+        b[0] = __builtin_elementwise_fma(c4, d[slot][0], __builtin_elementwise_fma(m5, d[slot][2], d[slot][4]));
+        b[1] = e + o;
+        b[2] = e - o;
+      } else {                      // d[.][r] = input row 4 t + r (row 1 + r of the six): positions 3 .. 5
+        const f32x4 f = d[slot][3] - d[slot][1], t = d[slot][2] - d[slot][0];
+        b[0] = __builtin_elementwise_fma(c2, t, f);
+        b[1] = __builtin_elementwise_fma(m2, t, f);
+        b[2] = __builtin_elementwise_fma(c4, d[slot][0], __builtin_elementwise_fma(m5, d[slot][2], d[slot][4]));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) acc[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[slot][s2][j], b[s2][j], acc[s2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_step(nx, slot);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * 12) void conv_wchain3_kernel(WChainArgs a) {
+  constexpr int NW = 12;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  WCHAIN_FETCH_ARGS(a);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = w % 6, sh = w / 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.vin), 0, a.vin_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const int Hq = a.H >> 2;
+  f32x4* J = reinterpret_cast<f32x4*>(smem);      // [p 6][row 4][g 4][lane 64]
+  const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
+  const int bid = blockIdx.x;
+  int qt, ctile;
+  if ((a.qtiles & 7) == 0) {      // an XCD takes a contiguous run of hexadecet tiles (neighbouring row groups share input rows)
+    const int xcd = bid & 7, slot = bid >> 3;
+    qt = xcd * (a.qtiles >> 3) + slot / a.ctiles;
+    ctile = slot - (slot / a.ctiles) * a.ctiles;
+  } else {
+    qt = bid / a.ctiles;
+    ctile = bid - qt * a.ctiles;
+  }
+  const int n0 = ctile * 32;
+  const int o0 = qt * 32;               // first hexadecet of the block
+  const int rg0 = o0 >> a.wq_log2, img0 = rg0 / Hq, t0 = rg0 - img0 * Hq;      // block-uniform; rows = row groups
+  unsigned voff;
+  {
+    int img, t, xq;
+    wchain_coords(img0, t0, Hq, a.wq_log2, li, img, t, xq);
+    // padded row index of image row 4 t - 1 is 4 t
+    voff = (unsigned)(((img * (a.H + 2) + 4 * t) * a.Wq + xq) * 16) + (unsigned)lh * a.plane_bytes;
+  }
+  const unsigned uoff = (unsigned)(((size_t)lh * a.cout_pad + n0 + li) * 16);
+  f32x16 acc[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+  if (sh == 0) wchain3_kloop<0>(a, rsrc_v, rsrc_w, p, voff, uoff, acc);
+  else wchain3_kloop<1>(a, rsrc_v, rsrc_w, p, voff, uoff, acc);
+  // this half's share of the four output rows (A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1])
+  if (sh == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 r0, r1, r2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = 4 * g + k;
+        r0[k] = (acc[0][r] + acc[1][r]) + acc[2][r];
+        r1[k] = acc[1][r] - acc[2][r];
+        r2[k] = acc[1][r] + acc[2][r];
+      }
+      J[((p * 4 + 0) * 4 + g) * 64 + lane] = r0;
+      J[((p * 4 + 1) * 4 + g) * 64 + lane] = r1;
+      J[((p * 4 + 2) * 4 + g) * 64 + lane] = r2;
+      J[((p * 4 + 3) * 4 + g) * 64 + lane] = r1;
+    }
+  }
+  __syncthreads();
+  if (sh == 1) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 r0, r1, r2, r3;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = 4 * g + k;
+        const float s34 = acc[0][r] + acc[1][r], d34 = acc[0][r] - acc[1][r];
+        r0[k] = s34;
+        r1[k] = 2.f * d34;
+        r2[k] = 4.f * s34;
+        r3[k] = 8.f * d34 + acc[2][r];
+      }
+      J[((p * 4 + 0) * 4 + g) * 64 + lane] += r0;
+      J[((p * 4 + 1) * 4 + g) * 64 + lane] += r1;
+      J[((p * 4 + 2) * 4 + g) * 64 + lane] += r2;
+      J[((p * 4 + 3) * 4 + g) * 64 + lane] += r3;
+    }
+  }
+  __syncthreads();
+  for (int vw = w; vw < 16; vw += NW) {
+    const int g = vw >> 2, row = vw & 3;
+    const int c0 = ctile * 32 + 8 * g + 4 * lh;
+    wchain_finish<1>(
+        a, c0, li, lh, lo, [&](int q, int) { return J[((q * 4 + row) * 4 + g) * 64 + lane]; },
+        [&](int, int& img, int& r, int& xq) {
+          int t;
+          wchain_coords(img0, t0, Hq, a.wq_log2, li, img, t, xq);
+          r = 4 * t + row;
+        });
+  }
+}
+
+// torch (Cout, Cin, 3, 3) -> [chunk][s 6][p 6][k4 8][cout_pad][4] = G g G^T in double, rounded once (G: F(4, 3), conv_wino4.hip's rows, for both axes)
+__global__ void pack_wino44_weight_kernel(const float* __restrict__ w, int cout, int cin, int cout_pad, float* __restrict__ packed, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int k1 = r & 3; r >>= 2;
+    const int n = (int)(r % cout_pad); r /= cout_pad;
+    const int k4 = r & 7; r >>= 3;
+    const int q = (int)(r % 6); r /= 6;
+    const int s = (int)(r % 6);
+    const int chunk = (int)(r / 6);
+    const int c = chunk * 32 + k4 * 4 + k1;
+    double v = 0.0;
+    if (n < cout && c < cin) {
+      const float* g = w + ((size_t)n * cin + c) * 9;
+      auto fold = [](int pos, double g0, double g1, double g2) {
+        return pos == 0 ? g0 / 4.0 : pos == 1 ? -(g0 + g1 + g2) / 6.0 : pos == 2 ? -(g0 - g1 + g2) / 6.0 : pos == 3 ? g0 / 24.0 + g1 / 12.0 + g2 / 6.0
+               : pos == 4 ? g0 / 24.0 - g1 / 12.0 + g2 / 6.0 : g2;
+      };
+      double row[3];      // the kernel rows folded by G[s]
+      for (int kw = 0; kw < 3; ++kw) row[kw] = fold(s, g[kw], g[3 + kw], g[6 + kw]);
+      v = fold(q, row[0], row[1], row[2]);
+    }
+    packed[i] = (float)v;
+  }
+}
+
 // several layers of the same map and form as ONE launch (the head's branch groups: three launches of 128 - 384 short blocks each left the
 // chip half empty between them): block -> (job, tile), one tile per block.  The job's arguments are copied out of the kernarg segment with
 // scalar loads (a run-time index into a by-value array would go through scratch).
@@ -958,6 +1133,73 @@ static int chain2_run(const pn_conv_desc* d, const float* planes_in, const float
 int pn_conv2d_wino24_chain_f32(const pn_conv_desc* d, const float* planes_in, const float* packed_w24, const float* scale, const float* shift,
                                float* planes_out, float* out_nhwc, pn_stream_t stream) {
   return chain2_run(d, planes_in, packed_w24, scale, shift, planes_out, out_nhwc, nullptr, false, stream);
+}
+
+// ---- F(4,3) x F(4,3) (conv_wchain3_kernel): frames of at most 32 quads per row (the join holds one 32-hexadecet tile), height a multiple of 4
+size_t pn_conv_wino44_packed_weight_floats(int cout, int cin) {
+  return (size_t)pn::cdiv(cin, 32) * 6 * 6 * 8 * (size_t)(pn::cdiv(cout, 128) * 128) * 4;
+}
+
+int pn_pack_conv_weight_wino44_f32(const float* w_oihw, int cout, int cin, float* packed, pn_stream_t stream) {
+  PN_REQUIRE(w_oihw && packed && cout >= 1 && cin >= 1, "pack_conv_weight_wino44: bad arguments");
+  const size_t total = pn_conv_wino44_packed_weight_floats(cout, cin);
+  hipLaunchKernelGGL(pack_wino44_weight_kernel, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0, pn::S(stream), w_oihw, cout, cin,
+                     pn::cdiv(cout, 128) * 128, packed, total);
+  return pn::check_launch("pack_wino44_weight_kernel");
+}
+
+int pn_conv_wino44_chain_supported(const pn_conv_desc* d) {
+  if (!chain_basic_ok(d, false) || d->range_strata > 1) return 0;
+  const int fh = frame_h(d), fw = frame_w(d);
+  if (fw % 4 || fh % 4) return 0;
+  const int wq = fw / 4;
+  if ((wq & (wq - 1)) || wq > 32 || 32 % wq) return 0;
+  const long long hexes = (long long)d->batch * (fh / 4) * wq;
+  if (hexes % 32 || 32 / wq > fh / 4 || (d->cin / 8) % 2) return 0;      // whole row groups per tile, tiles no taller than an image, cg pairs
+  return 1;
+}
+
+int pn_conv2d_wino44_chain_f32(const pn_conv_desc* d, const float* planes_in, const float* packed_w44, const float* scale, const float* shift,
+                               float* planes_out, float* out_nhwc, pn_stream_t stream) {
+  PN_REQUIRE(d && planes_in && packed_w44 && (planes_out || out_nhwc), "conv_wino44_chain: null pointer");
+  PN_REQUIRE(pn_conv_wino44_chain_supported(d), "conv_wino44_chain: layer shape not supported (3x3 / stride 1 / pad 1, height a multiple of 4, at most 32 quads "
+                                                "per row, cin and cout multiples of 32)");
+  PN_REQUIRE(((uintptr_t)planes_in & 15) == 0 && ((uintptr_t)packed_w44 & 15) == 0 && ((uintptr_t)planes_out & 15) == 0 && ((uintptr_t)out_nhwc & 15) == 0 &&
+                 ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
+             "conv_wino44_chain: pointers must be 16-byte aligned");
+  if (out_nhwc)
+    PN_REQUIRE(d->out_pixel_stride >= d->out_channel_offset + d->cout && d->out_pixel_stride % 4 == 0 && d->out_channel_offset % 4 == 0,
+               "conv_wino44_chain: output channel slice must fit the pixel stride, in multiples of 4 floats");
+  WChainArgs a{};
+  a.vin = planes_in; a.w = packed_w44; a.scale = scale; a.shift = shift; a.vout = planes_out; a.out = out_nhwc;
+  a.B = d->batch; a.H = frame_h(d); a.W = frame_w(d); a.Wq = a.W / 4; a.Cin = d->cin; a.Cout = d->cout;
+  a.out_co = d->out_channel_offset;
+  a.out_img = (long long)d->in_h * d->in_w * d->out_pixel_stride;
+  a.out_ps = d->transpose_hw ? d->in_w * d->out_pixel_stride : d->out_pixel_stride;
+  a.out_row = d->transpose_hw ? d->out_pixel_stride : (long long)d->in_w * d->out_pixel_stride;
+  a.wq_log2 = __builtin_ctz((unsigned)a.Wq);
+  a.act = d->act;
+  a.total_quads = d->batch * a.H * a.Wq;
+  a.qtiles = (a.total_quads / 4) / 32;
+  a.ctiles = d->cout / 32;
+  a.cg_in = d->cin / 8; a.cg_out = d->cout / 8;
+  a.cout_pad = pn::cdiv(d->cout, 128) * 128;
+  a.plane_bytes = (unsigned)((size_t)d->batch * (a.H + 2) * a.Wq * 16);
+  a.vin_bytes = (unsigned)(pn_wino4_planes_floats(d->batch, a.H, a.W, d->cin) * 4);
+  a.w_bytes = (unsigned)(pn_conv_wino44_packed_weight_floats(d->cout, d->cin) * 4);
+#ifdef PN_WCHAIN_STAMP
+  a.stamps = pn_wchain_stamp_buffer;
+#endif
+  constexpr size_t smem = (size_t)6 * 4 * 4 * 64 * 16;
+  static bool done[64] = {false};
+  if (pn::first_use_on_device(done))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wchain3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  pn::ProfileSlot ps{};
+  const bool prof = pn::take_profile_slot(ps);
+  const dim3 grid((unsigned)(a.qtiles * a.ctiles));
+  if (prof) hipExtLaunchKernelGGL(conv_wchain3_kernel, grid, dim3(64 * 12), smem, pn::S(stream), ps.start, ps.stop, 0, a);
+  else hipLaunchKernelGGL(conv_wchain3_kernel, grid, dim3(64 * 12), smem, pn::S(stream), a);
+  return pn::check_launch("conv_wchain3_kernel");
 }
 
 // floats of the statistics partials of pn_conv2d_wino24_chain_head_f32: [tile][row 2][cout][2]

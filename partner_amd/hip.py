@@ -229,6 +229,10 @@ SIGNATURES = {
     "pn_pack_conv_weight_wino24_f32": (_I, [_P, _I, _I, _P, _P]),
     "pn_conv_wino24_chain_supported": (_I, [_P]),
     "pn_conv2d_wino24_chain_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "pn_conv_wino44_packed_weight_floats": (_SZ, [_I, _I]),
+    "pn_pack_conv_weight_wino44_f32": (_I, [_P, _I, _I, _P, _P]),
+    "pn_conv_wino44_chain_supported": (_I, [_P]),
+    "pn_conv2d_wino44_chain_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "pn_conv_wino24_chain_stat_floats": (_SZ, [_P]),
     "pn_conv_wino24_chain_stat_tile_rows": (_I, [_P]),
     "pn_conv2d_wino24_chain_head_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),

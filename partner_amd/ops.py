@@ -497,16 +497,24 @@ class ConvLayer:
         """packed weights of the chained F(4,3) / F(2,3)xF(4,3) forms; ``transposed``: of the kernel with kh and kw swapped (the chain then runs
         on the transposed map), packed on first use.  The transposed layouts belong to the inference path (the head's
         branch chain): they are not tracked by ``prepack_used`` and a stale one is repacked lazily on the caller's stream"""
+        key = "wino44" if two_d == "wino44" else ("wino24" if two_d else "wino4")
         if not transposed:
-            self._ensure("wino24" if two_d else "wino4")
-            return self.wino24_packed if two_d else self.wino4_packed
+            if key == "wino44" and getattr(self, "wino44_packed", None) is None:      # F(4,3) x F(4,3) (r5): packed on first use
+                lib, w = hip.load(), getattr(self, "_stale_w", None)
+                w = self._w_ref if w is None else w
+                self.wino44_packed = _f32(lib.pn_conv_wino44_packed_weight_floats(self.cout, self._pack_cin), w.device)
+                hip.call("pn_pack_conv_weight_wino44_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino44_packed.data_ptr(), hip.stream())
+                self.__dict__.setdefault("_used", set()).add("wino44")
+                (getattr(self, "_stale", None) or set()).discard("wino44")
+                return self.wino44_packed
+            self._ensure(key)
+            return {"wino44": getattr(self, "wino44_packed", None), "wino24": self.wino24_packed, "wino4": self.wino4_packed}[key]
         stale = getattr(self, "_stale", None) or ()
-        key = "wino24" if two_d else "wino4"
         if key not in self._chain_t or (key + "_t") in stale:
             lib, w = hip.load(), getattr(self, "_stale_w", None)
             w = self._w_ref if w is None else w
             wt = w.detach().float().transpose(2, 3).contiguous()
-            fam = "wino24" if two_d else "wino4"
+            fam = key
             buf = self._chain_t.get(key)
             if buf is None:
                 buf = _f32(getattr(lib, f"pn_conv_{fam}_packed_weight_floats")(self.cout, self._pack_cin), w.device)
@@ -542,6 +550,8 @@ class ConvLayer:
             self._stale.add("tap")
         if getattr(self, "wino24_packed", None) is not None:
             self._stale.add("wino24")
+        if getattr(self, "wino44_packed", None) is not None:
+            self._stale.add("wino44")
         for k in getattr(self, "_chain_t", {}):
             self._stale.add(k + "_t")
         if shift is not None:
@@ -573,6 +583,8 @@ class ConvLayer:
             hip.call("pn_pack_conv_weight_wino_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino_packed.data_ptr(), st)
         elif layout == "wino24":
             hip.call("pn_pack_conv_weight_wino24_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino24_packed.data_ptr(), st)
+        elif layout == "wino44":
+            hip.call("pn_pack_conv_weight_wino44_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino44_packed.data_ptr(), st)
         else:
             hip.call("pn_pack_conv_weight_wino4_f32", w.data_ptr(), self.cout, self._pack_cin, self.wino4_packed.data_ptr(), st)
 
@@ -750,16 +762,18 @@ def conv_chain(layers, x: Optional[torch.Tensor], out: Optional[torch.Tensor] = 
         is_last = k == len(layers) - 1
         d = _chain_desc(l, b, h, w, out.shape[3], out_channel_offset, transposed=tr) if is_last else _chain_desc(l, b, h, w, transposed=tr)
         two_d = l.wino24_packed is not None and _chain_two_d(lib, d)
+        if two_d and _chain_44(lib, d):
+            two_d = "wino44"
         wts = l.chain_weights(two_d, tr)
         if prof is not None:
             ev = prof.begin(st)
-        hip.call("pn_conv2d_wino24_chain_f32" if two_d else "pn_conv2d_wino4_chain_f32", C.byref(d), bufs[k & 1].data_ptr(),
+        hip.call("pn_conv2d_wino44_chain_f32" if two_d == "wino44" else ("pn_conv2d_wino24_chain_f32" if two_d else "pn_conv2d_wino4_chain_f32"), C.byref(d), bufs[k & 1].data_ptr(),
                  wts.data_ptr(), hip.ptr(l.scale), hip.ptr(l.shift),
                  None if is_last else bufs[(k + 1) & 1].data_ptr(), out.data_ptr() if is_last else None, st)
         if prof is not None:
             flops = 2.0 * b * h * w * l.cout * l.cin * 9
-            prof.end(ev, flops, st, tag=f"{h}x{w} {l.cin}->{l.cout} k3 F(2,3)xF(4,3) chain" if two_d else f"{h}x{w} {l.cin}->{l.cout} k3 F(4,3) chain",
-                     issued=flops / 3.0 if two_d else None)
+            tag = "F(4,3)xF(4,3) chain" if two_d == "wino44" else ("F(2,3)xF(4,3) chain" if two_d else "F(4,3) chain")
+            prof.end(ev, flops, st, tag=f"{h}x{w} {l.cin}->{l.cout} k3 {tag}", issued=flops / 4.0 if two_d == "wino44" else (flops / 3.0 if two_d else None))
     return out
 
 
@@ -773,6 +787,21 @@ def _chain_two_d(lib, d) -> bool:
     octs, wq = d.batch * (fh // 2) * (fw // 4), fw // 4
     blocks = (octs // (64 if wq > 32 else 32)) * (d.cout // 32)
     return blocks >= 192 or d.frames_in_flight > 1
+
+
+_CHAIN44_ON = os.environ.get("PN_CONV_CHAIN44", "1") != "0"            # chained layers on 128-pixel rows: F(4, 3) along the height as well where it pays
+
+
+def _chain_44(lib, d) -> bool:
+    """F(4,3) x F(4,3) (conv_wchain3_kernel, r5: 2.25 MFMA equivalents per output, one block per four rows x 128 pixels x 32 channels -- half
+    the blocks of the 12-wave F(2,3) x F(4,3) form): where its blocks are whole rounds of the 256 CUs (a batch of four 128 x 128 maps: 55
+    against 72 us per layer), or with other frames in flight when they are at least half a round (one 128 x 128 map, 128 blocks: 26 against
+    30 us for the form the hint picks otherwise; alone on the chip the 256-block form finishes in 21)"""
+    if not _CHAIN44_ON or not lib.pn_conv_wino44_chain_supported(C.byref(d)):
+        return False
+    fh, fw = (d.in_w, d.in_h) if d.transpose_hw else (d.in_h, d.in_w)
+    blocks = (d.batch * (fh // 4) * (fw // 4) // 32) * (d.cout // 32)
+    return blocks % 256 == 0 or (d.frames_in_flight > 1 and 128 <= blocks <= 256)
 
 
 _PILLAR_CONV_ON = os.environ.get("PN_PILLAR_CONV", "1") != "0"
