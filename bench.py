@@ -701,19 +701,26 @@ def main():
                           frac=round(iss / (m * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3), tflops_algorithmic_equiv=round(den / (m * 1e-3) / 1e12, 1))
                   for t, (f, m, n, iss, den) in sorted(tags.items(), key=lambda kv: -kv[1][1])}
         dom_tag, dom = max(tags.items(), key=lambda kv: kv[1][1])
-        dom_kernel = ("conv_wchain2_kernel" if "F(2,3)xF(4,3)" in dom_tag else "conv_wchain_kernel" if "chain" in dom_tag else "conv_mfma_kernel") + \
+        dom_kernel = ("conv_wchain3_kernel" if "F(4,3)xF(4,3)" in dom_tag else "conv_wchain2_kernel" if "F(2,3)xF(4,3)" in dom_tag else
+                      "conv_wchain_kernel" if "chain" in dom_tag else "conv_mfma_kernel") + \
                      " (conv_wchain.hip / conv_mfma.hip), fp32 v_mfma_f32_32x32x2_f32: layer " + dom_tag
         dom_tf = dom[3] / (dom[1] * 1e-3) / 1e12
-        dom_pmc_name = "conv_wchain2_kernel<1, 1, 2>" if ("F(2,3)xF(4,3) chain" in dom_tag and dom_tag.startswith("256x256")) else None
+        dom_pmc_name = ("conv_wchain3_kernel<2>" if "F(4,3)xF(4,3) chain" in dom_tag else "conv_wchain2_kernel<1, 1, 2>" if "F(2,3)xF(4,3) chain" in dom_tag
+                        else None) if dom_tag.startswith("256x256") else None
         roofline = dict(bound="mfma", kernel=dom_kernel, schema="r4+: frac / achieved = the dominant kernel; all_conv.frac = the r1-r3 definition",
                         achieved=round(dom_tf, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(dom_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                        counts="the DOMINANT kernel (most time per frame): the FLOPs it ISSUES to the matrix pipes per launch (chained F(2,3)xF(4,3): "
-                               "24 products per 8 outputs = 1/3 of the direct algorithm's 9 MACs per output; F(4,3): 1/2) / its average launch duration "
+                        counts="the DOMINANT kernel (most time per frame): the FLOPs it ISSUES to the matrix pipes per launch (chained F(4,3)xF(4,3), "
+                               "r5 late: 36 products per 16 outputs = 1/4 of the direct algorithm's 9 MACs per output; F(2,3)xF(4,3): 1/3; F(4,3): 1/2) / its "
+                               "average launch duration.  r5 moved the 256^2 layers from F(2,3)xF(4,3) (6.44 GFLOP issued, 61.5 us, frac 0.665) to "
+                               "F(4,3)xF(4,3) (4.83 GFLOP issued, 55-58 us): a quarter less issued work at a LOWER issued fraction and a shorter launch "
                                "(start/stop events on its own dispatches).  Up to r3 this object's frac was the average over ALL conv launches (r3: "
                                "0.556); that figure is all_conv.frac now -- r4 cut the issued work of the 256^2 / 128^2 layers by a third at shorter "
                                "kernel times, so the all-launch fraction fell while frames/s rose",
                         dominant_kernel=dict(layer=dom_tag, launches_per_step=round(dom[2] / args.steps, 2), us=round(1e3 * dom[1] / dom[2], 2),
                                              gflop_issued_per_launch=round(dom[3] / dom[2] / 1e9, 3), share_of_conv_time=round(dom[1] / ms, 3)),
+                        # the same launches priced at the work the r4 form of the layer issued (F(2,3)xF(4,3): a third of the direct algorithm's
+                        # FLOPs): comparable with the r4 line's frac, not a roofline fraction of this kernel
+                        frac_at_r4_issued_flops=(round(dom[0] / 3.0 / (dom[1] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if "F(4,3)xF(4,3)" in dom_tag else None),
                         all_conv=dict(achieved=round(issued, 3), frac=round(issued / PEAK_F32_MFMA_TFLOPS, 4),
                                       kernels="conv_wchain2_kernel / conv_wchain_kernel (the RPN blocks' stride-1 3x3 layers and the head's branch "
                                               "convolutions chained in the Winograd domain) + conv_mfma_kernel (stride-2 layers, deblocks) + "

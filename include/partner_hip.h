@@ -1067,9 +1067,10 @@ int pn_conv2d_wino24_chain_f32(const pn_conv_desc *desc, const float *planes_in,
                                const float *shift, float *planes_out, float *out_nhwc, pn_stream_t stream);
 
 /* r5: the same chain step with F(4,3) along the map height as well (csrc/conv_wchain.hip, conv_wchain3_kernel): 2.25 MFMA-equivalents per
- * output, tiles of four rows x 128 pixels x 32 channels, the six height positions split over two waves.  Frames of at most 32 quads per row
- * (128 pixels along the Winograd axis) and a height that is a multiple of 4; half as many blocks as the F(2,3) x F(4,3) form on the same map,
- * so it is chosen where other frames fill the chip (pn_conv_desc.frames_in_flight > 1).  Planes format unchanged (reads and writes the planes
+ * output, tiles of four rows x 128 pixels x 32 channels, the six height positions split over two waves.  Frames of at most 64 quads per row
+ * (256 pixels along the Winograd axis: two 128-pixel halves per block, one after the other) and a height that is a multiple of 4; half as
+ * many blocks as the F(2,3) x F(4,3) form on the same map -- the host side picks it where other frames fill the chip
+ * (pn_conv_desc.frames_in_flight > 1).  Planes format unchanged (reads and writes the planes
  * of pn_wino4_planes_floats); weights from pn_pack_conv_weight_wino44_f32.  Replaces the same reference layers as pn_conv2d_wino4_chain_f32
  * (det3d/models/necks/rpn.py:124-142). */
 size_t pn_conv_wino44_packed_weight_floats(int cout, int cin);

@@ -501,26 +501,35 @@ __device__ __forceinline__ void wchain3_kloop(const WChainArgs& a, const __amdgp
   const unsigned cp16 = (unsigned)a.cout_pad * 16u;
   const unsigned row16 = (unsigned)a.Wq * 16u;
   f32x4 d[2][5], u[2][3];
+  bool first = false;      // (diagnostic builds only: PN_WCHAIN_EXP)
   auto load_step = [&](int cg, int slot) __attribute__((always_inline)) {
     const unsigned so_v = (unsigned)((p * a.cg_in + cg) * 2) * a.plane_bytes + (unsigned)SH * row16;
     const unsigned so_u = (unsigned)((((cg >> 2) * 6 + 3 * SH) * 6 + p) * 8 + (cg & 3) * 2) * cp16;
+    if (!(PN_WCHAIN_EXP & 2) || first) {
 #pragma unroll
-    for (int r = 0; r < 5; ++r) d[slot][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, voff, so_v + (unsigned)r * row16, 0));
+      for (int r = 0; r < 5; ++r) d[slot][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, voff, so_v + (unsigned)r * row16, 0));
+    }
+    if (!(PN_WCHAIN_EXP & 4) || first) {
 #pragma unroll
-    for (int s2 = 0; s2 < 3; ++s2) u[slot][s2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, uoff, so_u + (unsigned)(s2 * 48) * cp16, 0));
+      for (int s2 = 0; s2 < 3; ++s2) u[slot][s2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, uoff, so_u + (unsigned)(s2 * 48) * cp16, 0));
+    }
   };
   const int cg_last = a.cg_in - 1;
+  first = true;
   load_step(0, 0);
   __builtin_amdgcn_sched_barrier(0);
   load_step(1, 1);
   __builtin_amdgcn_sched_barrier(0);
+  first = false;
   for (int cg = 0; cg <= cg_last; cg += 2) {
 #pragma unroll
     for (int slot = 0; slot < 2; ++slot) {
       const int nx = cg + 2 + slot <= cg_last ? cg + 2 + slot : cg_last;      // the last refills re-read a live group (stay inside the buffers)
       f32x4 b[3];
       const f32x4 c4 = {4.f, 4.f, 4.f, 4.f}, m4 = {-4.f, -4.f, -4.f, -4.f}, m5 = {-5.f, -5.f, -5.f, -5.f}, c2 = {2.f, 2.f, 2.f, 2.f}, m2 = {-2.f, -2.f, -2.f, -2.f};
-      if constexpr (SH == 0) {      // d[.][r] = input row 4 t - 1 + r: positions 0 .. 2 of B^T (wino4_input_transform4's tree)
+      if constexpr (PN_WCHAIN_EXP & 1) {
+        b[0] = d[slot][0]; b[1] = d[slot][1]; b[2] = d[slot][2];
+      } else if constexpr (SH == 0) {      // d[.][r] = input row 4 t - 1 + r: positions 0 .. 2 of B^T (wino4_input_transform4's tree)
         const f32x4 e = __builtin_elementwise_fma(m4, d[slot][2], d[slot][4]), o = __builtin_elementwise_fma(m4, d[slot][1], d[slot][3]);
         b[0] = __builtin_elementwise_fma(c4, d[slot][0], __builtin_elementwise_fma(m5, d[slot][2], d[slot][4]));
         b[1] = e + o;
@@ -542,6 +551,12 @@ __device__ __forceinline__ void wchain3_kloop(const WChainArgs& a, const __amdgp
   }
 }
 
+// QT = 2: rows of 64 quads (the 256-pixel rows).  The join holds ONE 32-quad tile, so the two halves of a row group are computed one after
+// the other; what the finish of one half needs from the other is one pixel per row and channel on either side of the cut -- the next layer's
+// input transform of quad 31 takes the first pixel of quad 32 and vice versa.  Half 0 therefore leaves quad 31's four pixels and quad 30's
+// last one in a 2.5 KB carry instead of storing quad 31's planes; half 1 takes its left neighbour from there and its first lane completes
+// quad 31.  Same values as an undivided row.
+template <int QT>
 __global__ __launch_bounds__(64 * 12) void conv_wchain3_kernel(WChainArgs a) {
   constexpr int NW = 12;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -554,6 +569,7 @@ __global__ __launch_bounds__(64 * 12) void conv_wchain3_kernel(WChainArgs a) {
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
   const int Hq = a.H >> 2;
   f32x4* J = reinterpret_cast<f32x4*>(smem);      // [p 6][row 4][g 4][lane 64]
+  f32x4* carry = J + 6 * 4 * 4 * 64;              // QT = 2: [row 4][g 4][lh 2][5]: quad 31's pixels 0 .. 3 and quad 30's pixel 3
   const float lo = a.act == PN_ACT_RELU ? 0.f : -__builtin_inff();
   const int bid = blockIdx.x;
   int qt, ctile;
@@ -566,72 +582,143 @@ __global__ __launch_bounds__(64 * 12) void conv_wchain3_kernel(WChainArgs a) {
     ctile = bid - qt * a.ctiles;
   }
   const int n0 = ctile * 32;
-  const int o0 = qt * 32;               // first hexadecet of the block
+  const int o0 = qt * 32 * QT;          // first hexadecet of the block
   const int rg0 = o0 >> a.wq_log2, img0 = rg0 / Hq, t0 = rg0 - img0 * Hq;      // block-uniform; rows = row groups
-  unsigned voff;
-  {
-    int img, t, xq;
-    wchain_coords(img0, t0, Hq, a.wq_log2, li, img, t, xq);
-    // padded row index of image row 4 t - 1 is 4 t
-    voff = (unsigned)(((img * (a.H + 2) + 4 * t) * a.Wq + xq) * 16) + (unsigned)lh * a.plane_bytes;
-  }
   const unsigned uoff = (unsigned)(((size_t)lh * a.cout_pad + n0 + li) * 16);
-  f32x16 acc[3];
+#pragma unroll 1
+  for (int sub = 0; sub < QT; ++sub) {
+    int img, t, xq;
+    wchain_coords(img0, t0, Hq, a.wq_log2, 32 * sub + li, img, t, xq);
+    // padded row index of image row 4 t - 1 is 4 t
+    const unsigned voff = (unsigned)(((img * (a.H + 2) + 4 * t) * a.Wq + xq) * 16) + (unsigned)lh * a.plane_bytes;
+    f32x16 acc[3];
 #pragma unroll
-  for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < 3; ++s)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-  if (sh == 0) wchain3_kloop<0>(a, rsrc_v, rsrc_w, p, voff, uoff, acc);
-  else wchain3_kloop<1>(a, rsrc_v, rsrc_w, p, voff, uoff, acc);
-  // this half's share of the four output rows (A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1])
-  if (sh == 0) {
+      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+    if (sh == 0) wchain3_kloop<0>(a, rsrc_v, rsrc_w, p, voff, uoff, acc);
+    else wchain3_kloop<1>(a, rsrc_v, rsrc_w, p, voff, uoff, acc);
+    if (sub > 0) __syncthreads();      // the previous half's join has been read
+    // this half's share of the four output rows (A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1])
+    if (sh == 0) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 r0, r1, r2;
+      for (int g = 0; g < 4; ++g) {
+        f32x4 r0, r1, r2;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int r = 4 * g + k;
-        r0[k] = (acc[0][r] + acc[1][r]) + acc[2][r];
-        r1[k] = acc[1][r] - acc[2][r];
-        r2[k] = acc[1][r] + acc[2][r];
+        for (int k = 0; k < 4; ++k) {
+          const int r = 4 * g + k;
+          r0[k] = (acc[0][r] + acc[1][r]) + acc[2][r];
+          r1[k] = acc[1][r] - acc[2][r];
+          r2[k] = acc[1][r] + acc[2][r];
+        }
+        J[((p * 4 + 0) * 4 + g) * 64 + lane] = r0;
+        J[((p * 4 + 1) * 4 + g) * 64 + lane] = r1;
+        J[((p * 4 + 2) * 4 + g) * 64 + lane] = r2;
+        J[((p * 4 + 3) * 4 + g) * 64 + lane] = r1;
       }
-      J[((p * 4 + 0) * 4 + g) * 64 + lane] = r0;
-      J[((p * 4 + 1) * 4 + g) * 64 + lane] = r1;
-      J[((p * 4 + 2) * 4 + g) * 64 + lane] = r2;
-      J[((p * 4 + 3) * 4 + g) * 64 + lane] = r1;
     }
-  }
-  __syncthreads();
-  if (sh == 1) {
+    __syncthreads();
+    if (sh == 1) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 r0, r1, r2, r3;
+      for (int g = 0; g < 4; ++g) {
+        f32x4 r0, r1, r2, r3;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int r = 4 * g + k;
-        const float s34 = acc[0][r] + acc[1][r], d34 = acc[0][r] - acc[1][r];
-        r0[k] = s34;
-        r1[k] = 2.f * d34;
-        r2[k] = 4.f * s34;
-        r3[k] = 8.f * d34 + acc[2][r];
+        for (int k = 0; k < 4; ++k) {
+          const int r = 4 * g + k;
+          const float s34 = acc[0][r] + acc[1][r], d34 = acc[0][r] - acc[1][r];
+          r0[k] = s34;
+          r1[k] = 2.f * d34;
+          r2[k] = 4.f * s34;
+          r3[k] = 8.f * d34 + acc[2][r];
+        }
+        J[((p * 4 + 0) * 4 + g) * 64 + lane] += r0;
+        J[((p * 4 + 1) * 4 + g) * 64 + lane] += r1;
+        J[((p * 4 + 2) * 4 + g) * 64 + lane] += r2;
+        J[((p * 4 + 3) * 4 + g) * 64 + lane] += r3;
       }
-      J[((p * 4 + 0) * 4 + g) * 64 + lane] += r0;
-      J[((p * 4 + 1) * 4 + g) * 64 + lane] += r1;
-      J[((p * 4 + 2) * 4 + g) * 64 + lane] += r2;
-      J[((p * 4 + 3) * 4 + g) * 64 + lane] += r3;
     }
-  }
-  __syncthreads();
-  for (int vw = w; vw < 16; vw += NW) {
-    const int g = vw >> 2, row = vw & 3;
-    const int c0 = ctile * 32 + 8 * g + 4 * lh;
-    wchain_finish<1>(
-        a, c0, li, lh, lo, [&](int q, int) { return J[((q * 4 + row) * 4 + g) * 64 + lane]; },
-        [&](int, int& img, int& r, int& xq) {
-          int t;
-          wchain_coords(img0, t0, Hq, a.wq_log2, li, img, t, xq);
-          r = 4 * t + row;
-        });
+    __syncthreads();
+    for (int vw = w; vw < 16; vw += NW) {
+      const int g = vw >> 2, row = vw & 3;
+      const int c0 = ctile * 32 + 8 * g + 4 * lh;
+      if constexpr (QT == 1) {
+        wchain_finish<1>(
+            a, c0, li, lh, lo, [&](int q, int) { return J[((q * 4 + row) * 4 + g) * 64 + lane]; },
+            [&](int, int& im, int& r, int& x) { im = img; r = 4 * t + row; x = xq; });
+      } else {
+        // wchain_finish for one half of a 64-quad row (see above); sub = 0: quads 0 .. 31, sub = 1: quads 32 .. 63
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, shf = {0.f, 0.f, 0.f, 0.f};
+        if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + c0);
+        if (a.shift) shf = *reinterpret_cast<const f32x4*>(a.shift + c0);
+        f32x4 m[6], y[4];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) m[q] = J[((q * 4 + row) * 4 + g) * 64 + lane];
+        {
+          const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+          const f32x4 lo4 = {lo, lo, lo, lo};
+          y[0] = __builtin_elementwise_max(__builtin_elementwise_fma((m[0] + s12) + s34, sc, shf), lo4);
+          y[1] = __builtin_elementwise_max(__builtin_elementwise_fma(d12 + 2.f * d34, sc, shf), lo4);
+          y[2] = __builtin_elementwise_max(__builtin_elementwise_fma(s12 + 4.f * s34, sc, shf), lo4);
+          y[3] = __builtin_elementwise_max(__builtin_elementwise_fma((d12 + 8.f * d34) + m[5], sc, shf), lo4);
+        }
+        const int r = 4 * t + row;
+        if (a.out) {
+          float* o = a.out + (size_t)img * a.out_img + (size_t)r * a.out_row + (size_t)(4 * xq) * a.out_ps + a.out_co + c0;
+#pragma unroll
+          for (int px = 0; px < 4; ++px) *reinterpret_cast<f32x4*>(o + (size_t)px * a.out_ps) = y[px];
+        }
+        if (a.vout) {
+          f32x4* cr = carry + ((row * 4 + g) * 2 + lh) * 5;
+          f32x4 l, rr;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            l[j] = __shfl_up(y[3][j], 1, 32);
+            rr[j] = __shfl_down(y[0][j], 1, 32);
+          }
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+          auto store_planes = [&](const f32x4 (&d)[6], int xs) {
+            f32x4 vv[6];
+            wchain_input_transform(d, vv);
+            float* o = a.vout + ((size_t)(c0 >> 3) * 2 + lh) * (a.plane_bytes >> 2) + ((size_t)(img * (a.H + 2) + r + 1) * a.Wq + xs) * 4;
+            const size_t pstride = (size_t)a.cg_out * 2 * (a.plane_bytes >> 2);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride) = vv[q];
+            if (r == 0) {
+#pragma unroll
+              for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride - (size_t)a.Wq * 4) = z4;
+            }
+            if (r == a.H - 1) {
+#pragma unroll
+              for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(o + q * pstride + (size_t)a.Wq * 4) = z4;
+            }
+          };
+          if (sub == 0) {
+            if (li == 31) {      // quad 31 waits for quad 32's first pixel: its pixels and its left neighbour into the carry
+              cr[0] = y[0]; cr[1] = y[1]; cr[2] = y[2]; cr[3] = y[3]; cr[4] = l;
+            } else {
+              f32x4 d[6];
+              d[0] = xq > 0 ? l : z4;
+              d[1] = y[0]; d[2] = y[1]; d[3] = y[2]; d[4] = y[3];
+              d[5] = rr;
+              store_planes(d, xq);
+            }
+          } else {
+            if (li == 0) {       // quad 31 (carry) with this lane's first pixel as its right neighbour, and quad 31's last pixel as this lane's left
+              f32x4 d[6];
+              d[0] = cr[4]; d[1] = cr[0]; d[2] = cr[1]; d[3] = cr[2]; d[4] = cr[3];
+              d[5] = y[0];
+              store_planes(d, xq - 1);
+              l = cr[3];
+            }
+            f32x4 d[6];
+            d[0] = l;
+            d[1] = y[0]; d[2] = y[1]; d[3] = y[2]; d[4] = y[3];
+            d[5] = xq + 1 < a.Wq ? rr : z4;
+            store_planes(d, xq);
+          }
+        }
+      }
+    }
   }
 }
 
@@ -1153,9 +1240,10 @@ int pn_conv_wino44_chain_supported(const pn_conv_desc* d) {
   const int fh = frame_h(d), fw = frame_w(d);
   if (fw % 4 || fh % 4) return 0;
   const int wq = fw / 4;
-  if ((wq & (wq - 1)) || wq > 32 || 32 % wq) return 0;
+  if ((wq & (wq - 1)) || wq > 64) return 0;
+  const int tq = wq == 64 ? 64 : 32;                                      // hexadecets per block: whole row groups
   const long long hexes = (long long)d->batch * (fh / 4) * wq;
-  if (hexes % 32 || 32 / wq > fh / 4 || (d->cin / 8) % 2) return 0;      // whole row groups per tile, tiles no taller than an image, cg pairs
+  if (tq % wq || hexes % tq || tq / wq > fh / 4 || (d->cin / 8) % 2) return 0;      // tiles no taller than an image, cg pairs
   return 1;
 }
 
@@ -1180,7 +1268,8 @@ int pn_conv2d_wino44_chain_f32(const pn_conv_desc* d, const float* planes_in, co
   a.wq_log2 = __builtin_ctz((unsigned)a.Wq);
   a.act = d->act;
   a.total_quads = d->batch * a.H * a.Wq;
-  a.qtiles = (a.total_quads / 4) / 32;
+  const int qt2 = a.Wq == 64 ? 2 : 1;
+  a.qtiles = (a.total_quads / 4) / (32 * qt2);
   a.ctiles = d->cout / 32;
   a.cg_in = d->cin / 8; a.cg_out = d->cout / 8;
   a.cout_pad = pn::cdiv(d->cout, 128) * 128;
@@ -1190,15 +1279,22 @@ int pn_conv2d_wino44_chain_f32(const pn_conv_desc* d, const float* planes_in, co
 #ifdef PN_WCHAIN_STAMP
   a.stamps = pn_wchain_stamp_buffer;
 #endif
-  constexpr size_t smem = (size_t)6 * 4 * 4 * 64 * 16;
+  constexpr size_t smem = (size_t)6 * 4 * 4 * 64 * 16 + (size_t)4 * 4 * 2 * 5 * 16;      // the join + the carry of the two-half form
   static bool done[64] = {false};
-  if (pn::first_use_on_device(done))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wchain3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (pn::first_use_on_device(done)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wchain3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wchain3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  }
   pn::ProfileSlot ps{};
   const bool prof = pn::take_profile_slot(ps);
   const dim3 grid((unsigned)(a.qtiles * a.ctiles));
-  if (prof) hipExtLaunchKernelGGL(conv_wchain3_kernel, grid, dim3(64 * 12), smem, pn::S(stream), ps.start, ps.stop, 0, a);
-  else hipLaunchKernelGGL(conv_wchain3_kernel, grid, dim3(64 * 12), smem, pn::S(stream), a);
+  if (qt2 == 2) {
+    if (prof) hipExtLaunchKernelGGL(conv_wchain3_kernel<2>, grid, dim3(64 * 12), smem, pn::S(stream), ps.start, ps.stop, 0, a);
+    else hipLaunchKernelGGL(conv_wchain3_kernel<2>, grid, dim3(64 * 12), smem, pn::S(stream), a);
+  } else {
+    if (prof) hipExtLaunchKernelGGL(conv_wchain3_kernel<1>, grid, dim3(64 * 12), smem, pn::S(stream), ps.start, ps.stop, 0, a);
+    else hipLaunchKernelGGL(conv_wchain3_kernel<1>, grid, dim3(64 * 12), smem, pn::S(stream), a);
+  }
   return pn::check_launch("conv_wchain3_kernel");
 }
 

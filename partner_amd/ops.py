@@ -793,15 +793,19 @@ _CHAIN44_ON = os.environ.get("PN_CONV_CHAIN44", "1") != "0"            # chained
 
 
 def _chain_44(lib, d) -> bool:
-    """F(4,3) x F(4,3) (conv_wchain3_kernel, r5: 2.25 MFMA equivalents per output, one block per four rows x 128 pixels x 32 channels -- half
-    the blocks of the 12-wave F(2,3) x F(4,3) form): where its blocks are whole rounds of the 256 CUs (a batch of four 128 x 128 maps: 55
-    against 72 us per layer), or with other frames in flight when they are at least half a round (one 128 x 128 map, 128 blocks: 26 against
-    30 us for the form the hint picks otherwise; alone on the chip the 256-block form finishes in 21)"""
-    if not _CHAIN44_ON or not lib.pn_conv_wino44_chain_supported(C.byref(d)):
+    """F(4,3) x F(4,3) (conv_wchain3_kernel, r5: 2.25 MFMA equivalents per output; one block per four rows x 128 pixels x 32 channels, a 256-pixel
+    row as two such halves one after the other): WITH OTHER FRAMES IN FLIGHT, where its blocks are whole rounds of the 256 CUs (256 x 256 x 128:
+    256 blocks, 55 against 62 us per layer; a batch of four 128 x 128 maps 55 against 72) or at least half a round (one 128 x 128 map, 128 blocks:
+    26 against 30 us for the form the hint picks otherwise; alone on the chip the 256-block K-split form finishes in 21).  Not for a frame
+    alone on the chip: the 256 x 256 launch itself is 4 - 9 us shorter there too, but on two of the four boxes it was measured on every OTHER
+    matrix kernel of the frame then ran 4 - 5 % longer (853.8 against 843.1 us of kernel time per frame; on the other boxes 796 against 812) --
+    the one-frame latency moved by -20 .. +17 us with the box, the in-flight rate rose on all of them (+2 .. 3 %)"""
+    if not _CHAIN44_ON or d.frames_in_flight <= 1 or not lib.pn_conv_wino44_chain_supported(C.byref(d)):
         return False
     fh, fw = (d.in_w, d.in_h) if d.transpose_hw else (d.in_h, d.in_w)
-    blocks = (d.batch * (fh // 4) * (fw // 4) // 32) * (d.cout // 32)
-    return blocks % 256 == 0 or (d.frames_in_flight > 1 and 128 <= blocks <= 256)
+    tq = 64 if fw // 4 == 64 else 32
+    blocks = (d.batch * (fh // 4) * (fw // 4) // tq) * (d.cout // 32)
+    return blocks % 256 == 0 or 128 <= blocks <= 256
 
 
 _PILLAR_CONV_ON = os.environ.get("PN_PILLAR_CONV", "1") != "0"

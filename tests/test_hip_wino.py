@@ -665,9 +665,10 @@ def test_rpn_blocks_run_as_chains_and_match_the_layerwise_path(dev):
 
 
 def test_conv_chain_takes_f43xf43_where_its_blocks_fill_the_chip(dev):
-    """ops.conv_chain on 128-pixel rows (r5, conv_wchain3_kernel): a batch of four 128 x 128 maps (512 blocks: whole rounds) and one map with
-    other frames in flight (128 blocks) take the F(4,3)xF(4,3) form, one map alone keeps F(2,3)xF(4,3); all three agree with float64
-    convolutions to 2e-5 of the output's maximum per layer, and PN_CONV_CHAIN44's off position gives the r4 forms"""
+    """ops.conv_chain with other frames in flight (r5, conv_wchain3_kernel): a batch of four 128 x 128 maps (512 blocks: whole rounds), one
+    128 x 128 map (128 blocks) and one 256 x 256 map (256 blocks of two row halves) take the F(4,3)xF(4,3) form, a map alone on the chip keeps
+    F(2,3)xF(4,3); all agree with float64 convolutions to 2e-5 of the output's maximum per layer, and PN_CONV_CHAIN44's off position gives
+    the r4 forms"""
     from partner_amd import ops
     g = torch.Generator().manual_seed(44)
     ws = [(torch.randn((128, 128, 3, 3), generator=g) * (1.5 / (9 * 128) ** 0.5)).to(dev) for _ in range(2)]
@@ -685,8 +686,8 @@ def test_conv_chain_takes_f43xf43_where_its_blocks_fill_the_chip(dev):
             ops.disable_conv_profiling()
         return y, sum(v[2] for t, v in tags.items() if "F(4,3)xF(4,3) chain" in t), sum(v[2] for t, v in tags.items() if "F(2,3)xF(4,3) chain" in t)
 
-    for b, fif, want44 in ((4, 1, 2), (1, 3, 2), (1, 1, 0)):
-        x = torch.randn((b, 128, 128, 128), generator=g).to(dev)
+    for b, hw, fif, want44 in ((4, 128, 2, 2), (1, 128, 3, 2), (1, 256, 3, 2), (1, 128, 1, 0), (1, 256, 1, 0)):
+        x = torch.randn((b, hw, hw, 128), generator=g).to(dev)
         y, n44, n24 = run(x, fif)
         assert (n44, n24) == (want44, 2 - want44), (b, fif, n44, n24)
         r = x.double()
@@ -696,7 +697,7 @@ def test_conv_chain_takes_f43xf43_where_its_blocks_fill_the_chip(dev):
     keep = ops._CHAIN44_ON
     ops._CHAIN44_ON = False
     try:
-        _, n44, n24 = run(torch.randn((4, 128, 128, 128), generator=g).to(dev), 1)
+        _, n44, n24 = run(torch.randn((4, 128, 128, 128), generator=g).to(dev), 2)
     finally:
         ops._CHAIN44_ON = keep
     assert (n44, n24) == (0, 2)
