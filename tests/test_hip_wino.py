@@ -511,9 +511,6 @@ def test_frames_in_flight_hint_changes_the_form_not_the_result(dev):
 
 
 # ------------------------------------------------------------------------------------------ F(4, 3) chains  (csrc/conv_wchain.hip)
-RUN_CHAIN_FORMS = []      # (the forms the last calls of run_chain took: the 44 test checks that its cases did run on the new kernel)
-
-
 def run_chain(x, ws, scales, shifts, acts, out=None, out_co=0, in_co=0, cin=None, want_planes=False, two_d=False):
     """x NHWC -> the layers through pn_wino4_planes_from_nhwc_f32 + pn_conv2d_wino4_chain_f32 (planes between layers, NHWC at the end);
     two_d: pn_conv2d_wino24_chain_f32 (F(2,3) along the height on top) where it supports the layer"""
@@ -539,7 +536,6 @@ def run_chain(x, ws, scales, shifts, acts, out=None, out_co=0, in_co=0, cin=None
         fam = "wino24" if use2 else "wino4"
         if two_d == 44 and lib.pn_conv_wino44_chain_supported(C.byref(d)):      # F(4,3) along the height as well (r5)
             fam = "wino44"
-            RUN_CHAIN_FORMS.append(fam)
         packed = torch.empty(getattr(lib, f"pn_conv_{fam}_packed_weight_floats")(cout, c), dtype=torch.float32, device=x.device)
         hip.call(f"pn_pack_conv_weight_{fam}_f32", w.contiguous().data_ptr(), cout, c, packed.data_ptr(), hip.stream())
         hip.call(f"pn_conv2d_{fam}_chain_f32", C.byref(d), bufs[k & 1].data_ptr(), packed.data_ptr(), hip.ptr(scales[k]), hip.ptr(shifts[k]),
