@@ -11,6 +11,7 @@
 // banks), the layer-0 activations of the current point go through a per-wave LDS row and are
 // read back as broadcasts.
 #include "pn_common.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -337,6 +338,7 @@ __device__ __forceinline__ void pfn_32_128_main(const PfnArgs& a, const float* _
 // sweep): one 8-wave block per pillar, the three phases (means, layer-0 maxima, layer-1 maxima)
 // meet in LDS.  Sums are exact int64 and maxima order independent, so the values are bit-identical
 // to what the one-wave path would have produced.
+template <int TH = kHeavyPillar>      // pillars with more than TH points (the tile path hands over at 16)
 __device__ __forceinline__ void pfn_32_128_heavy(const PfnArgs& a, const float* __restrict__ cs_table, const int bid, const int nblk) {
   __shared__ long long part_sum[kHeavyWaves][5];
   __shared__ float part_max[kHeavyWaves][128];
@@ -352,7 +354,7 @@ __device__ __forceinline__ void pfn_32_128_heavy(const PfnArgs& a, const float* 
     if (threadIdx.x == 0) heavy_n = 0;
     __syncthreads();
     const int cand = base + bid + nblk * threadIdx.x;
-    if (cand < V && a.vstart[cand + 1] - a.vstart[cand] > kHeavyPillar) heavy_list[atomicAdd(&heavy_n, 1)] = cand;
+    if (cand < V && a.vstart[cand + 1] - a.vstart[cand] > TH) heavy_list[atomicAdd(&heavy_n, 1)] = cand;
     __syncthreads();
     const int n_heavy = heavy_n;
   for (int hi = 0; hi < n_heavy; ++hi) {
@@ -445,6 +447,255 @@ __device__ __forceinline__ void pfn_32_128_heavy(const PfnArgs& a, const float* 
   }
 }
 
+// ---- r5 (late): the same arithmetic on the matrix pipe, WITHOUT giving up a bit.  v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (guide,
+// "FP32-input MFMA"; conv_mfma.hip's small_n_mfma_body reproduces a vector kernel's bits with it), so layer 0 (16 features, k ascending) and
+// layer 1 (the 32 maxima against W1's columns 32 .. 63, then the 32 activations against columns 0 .. 31 -- the order of the loop above) can run
+// as chains inside MFMAs with POINT ROWS as the 16 columns of a tile: H^T = W0 D^T, Y^T = W1' [M0; H].  The weights are A fragments that live in
+// registers for the whole kernel (136), and layer 0's accumulators ARE layer 1's B operand: W0's rows are fed in the order (16 nt + 4 r + g)
+// for accumulator register r of lane group g, so that K step i = 4 nt + r of layer 1 finds channel 4 i + g in lane group g -- no LDS, no
+// cross-lane traffic between the layers.  A pillar's rows are neighbouring LANES of a 16-lane row: its maxima (layer 0's for M0, layer 1's for
+// the result) are segmented lane scans, skipped when every row of the tile is its own pillar.  Tiles are packed from whole pillars of at most
+// 16 points (consecutive staged rows); larger pillars take the block-per-pillar kernel.  136 MFMAs per 16 point rows against 64 - 96 packed
+// fmas + broadcasts per point.
+constexpr int kTileRows = 16;
+// lane i of a 16-lane row takes the value of lane i + N (row_shl) / i - N (row_shr); lanes without a source keep `old`
+template <int N> __device__ __forceinline__ float row_down(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, false));
+}
+template <int N> __device__ __forceinline__ float row_up(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, false));
+}
+template <int N> __device__ __forceinline__ int row_down_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x100 + N, 0xf, 0xf, false); }
+template <int N> __device__ __forceinline__ int row_up_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x110 + N, 0xf, 0xf, false); }
+#ifndef PN_PFN_EXP
+#define PN_PFN_EXP 0      // diagnostic builds (-DPN_PFN_EXP=k): 1 no tiles at all, 2 layer 1 cut to one K step, 4 no segment scans, 8 no stores -- wrong results, times only
+#endif
+__device__ __forceinline__ void pfn_32_128_tiles(const PfnArgs& a, const float* __restrict__ cs_table, const int bid, const int nblk) {
+  constexpr int NB = kFwdBatch, CAP = kFwdPoints;
+  __shared__ int m_s[NB], m_e[NB];
+  __shared__ uint32_t m_key[NB];
+  __shared__ __attribute__((aligned(16))) float m_c[NB][12];  // per pillar: mx my mz mr mp rc pc xc yc, canvas cell (int bits)
+  __shared__ __attribute__((aligned(16))) float p_l[CAP][8];
+  __shared__ unsigned char row_q[CAP];                         // the pillar (index in the batch) of every staged row
+  __shared__ short t_row0[NB], t_rows[NB];
+  __shared__ int t_count;
+  const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+  const int V = min(*a.v_dev, a.v_cap);
+  const int rho = lane & 15, jj = lane >> 4;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  // A fragments: lane (row rho of the 16-row tile, k = jj of the step)
+  // (through LDS: a lane's 136 values are 4-byte pieces of 136 different lines -- fetched straight from memory by every wave that was 230 MB of
+  // L2 traffic and 25 us at 30 k points.  The block copies W1 / W0 once, whole lines, W1's columns xor-ed with 4 (row mod 16) so that the
+  // sixteen rows a read touches lie in sixteen different banks)
+  float a0[2][4], a1[8][16];
+  {
+    float* w1s = &p_l[0][0];      // 128 x 64 floats: the staging rows are not in use yet
+    float* w0s = &m_c[0][0];      // 32 x 16
+    for (int i = tid; i < 128 * 16; i += 256) {
+      const int row = i >> 4, c4 = (i & 15) * 4;
+      *reinterpret_cast<f32x4*>(w1s + row * 64 + (c4 ^ (4 * (row & 15)))) = *reinterpret_cast<const f32x4*>(a.w1 + row * 64 + c4);
+    }
+    for (int i = tid; i < 32 * 4; i += 256) *reinterpret_cast<f32x4*>(w0s + i * 4) = *reinterpret_cast<const f32x4*>(a.w0 + i * 4);
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) a0[nt][k4] = w0s[(16 * nt + 4 * (rho & 3) + (rho >> 2)) * 16 + 4 * k4 + jj];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a1[mt][i] = w1s[(16 * mt + rho) * 64 + (((i < 8 ? 32 + 4 * i : 4 * (i - 8)) + jj) ^ (4 * rho))];
+  }      // (the batch loop opens with a barrier: every wave has its fragments before the rows are staged)
+  for (int v0 = bid * NB; v0 < V; v0 += nblk * NB) {
+    const int nb = min(NB, V - v0);
+    __syncthreads();  // the previous batch has been consumed
+    if (tid < nb) {
+      m_s[tid] = a.vstart[v0 + tid];
+      m_e[tid] = a.vstart[v0 + tid + 1];
+      m_key[tid] = a.ukeys[v0 + tid];
+    }
+    __syncthreads();
+    int q0 = 0;
+    while (q0 < nb) {  // block-uniform
+      const int base = m_s[q0];
+      if (m_e[q0] - base > kTileRows) { ++q0; continue; }  // the block-per-pillar kernel of the same call takes those
+      int q1 = q0 + 1;
+      while (q1 < nb && m_e[q1] - m_s[q1] <= kTileRows && m_e[q1] - base <= CAP) ++q1;
+      const int npts = m_e[q1 - 1] - base;
+      for (int t = tid; t < npts; t += 256) {
+        const float* src = a.pts + (size_t)a.order[base + t] * a.stride;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) p_l[t][k] = src[k];
+      }
+      __syncthreads();
+      // per-pillar scalars, one THREAD per pillar: key decode, cell centre, exact fixed-point means (as in pfn_32_128_main); the pillar's rows
+      if (q0 + tid < q1) {
+        const int q = q0 + tid;
+        uint32_t key = m_key[q];
+        const int ri = key % a.R; key /= a.R;
+        const int ti = key % a.T; key /= a.T;
+        const int bi = key / a.Z;
+        const int s = m_s[q] - base, e = m_e[q] - base;
+        long long sx = 0, sy = 0, sz = 0, sr = 0, sp = 0;
+        for (int i = s; i < e; ++i) {
+          const float* p = p_l[i];
+          sr += to_fix(p[0]); sp += to_fix(p[1]); sz += to_fix(p[2]); sx += to_fix(p[3]); sy += to_fix(p[4]);
+          row_q[i] = (unsigned char)q;
+        }
+        const double inv_n = 1.0 / ((double)(e - s) * kFix);
+        float* c = m_c[q];
+        c[0] = (float)((double)sx * inv_n); c[1] = (float)((double)sy * inv_n); c[2] = (float)((double)sz * inv_n);
+        c[3] = (float)((double)sr * inv_n); c[4] = (float)((double)sp * inv_n);
+        const float rc = __fadd_rn(__fmul_rn((float)ri, a.vx), a.xoff);
+        c[5] = rc;
+        c[6] = __fadd_rn(__fmul_rn((float)ti, a.vy), a.yoff);
+        c[7] = __fmul_rn(rc, cs_table[2 * ti]);
+        c[8] = __fmul_rn(rc, cs_table[2 * ti + 1]);
+        c[9] = __builtin_bit_cast(float, (bi * a.T + ti) * a.R + ri);
+      }
+      if (wib == 3) {      // tiles: whole pillars, at most 16 consecutive rows, packed greedily.  One wave: lane k holds pillar k's row count, the walk
+                           // over the <= 64 pillars reads them with v_readlane (scalar arithmetic, no LDS round trip per step)
+        const int nq = (q0 + lane < q1) ? m_e[q0 + lane] - m_s[q0 + lane] : 0;
+        int nt = 0, start = 0, rows = 0;
+        const int np = q1 - q0;
+        for (int k = 0; k < np; ++k) {
+          const int n = __builtin_amdgcn_readlane(nq, k);
+          if (rows + n > kTileRows) {
+            if (lane == 0) { t_row0[nt] = (short)start; t_rows[nt] = (short)rows; }
+            ++nt;
+            start += rows;
+            rows = 0;
+          }
+          rows += n;
+        }
+        if (lane == 0) { t_row0[nt] = (short)start; t_rows[nt] = (short)rows; t_count = nt + 1; }
+      }
+      __syncthreads();
+      const int ntiles = (PN_PFN_EXP & 1) ? 0 : t_count;
+      for (int t = wib; t < ntiles; t += 4) {
+        const int r0 = t_row0[t], nr = t_rows[t];
+        const bool live = rho < nr;
+        const int row = r0 + (live ? rho : 0);
+        const f32x4 pa = *reinterpret_cast<const f32x4*>(&p_l[row][0]), pb = *reinterpret_cast<const f32x4*>(&p_l[row][4]);
+        const int q = row_q[row];
+        const int qid = live ? q : -1 - rho;      // rows past the tile's last never join a segment
+        const f32x4 ca = *reinterpret_cast<const f32x4*>(&m_c[q][0]), cb = *reinterpret_cast<const f32x4*>(&m_c[q][4]),
+                    cc = *reinterpret_cast<const f32x4*>(&m_c[q][8]);
+        const float rho_ = pa[0], phi = pa[1], z = pa[2], x = pa[3], y = pb[0];
+        const float mx = ca[0], my = ca[1], mz = ca[2], mr = ca[3], mp = cb[0], rc = cb[1], pc = cb[2], xc = cb[3], yc = cc[0];
+        // the 16 features of pfn_32_128_main's layer0; this lane supplies feature 4 k4 + jj of its row to K step k4
+        const float d0[4] = {rho_, phi, z, x}, d1[4] = {y, pb[1], pb[2], x - mx}, d2[4] = {y - my, z - mz, x - xc, y - yc},
+                    d3[4] = {rho_ - mr, phi - mp, rho_ - rc, phi - pc};
+        const float b0 = jj == 0 ? d0[0] : jj == 1 ? d0[1] : jj == 2 ? d0[2] : d0[3];
+        const float b1 = jj == 0 ? d1[0] : jj == 1 ? d1[1] : jj == 2 ? d1[2] : d1[3];
+        const float b2 = jj == 0 ? d2[0] : jj == 1 ? d2[1] : jj == 2 ? d2[2] : d2[3];
+        const float b3 = jj == 0 ? d3[0] : jj == 1 ? d3[1] : jj == 2 ? d3[2] : d3[3];
+        f32x4 h[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nt][0], b0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nt][1], b1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nt][2], b2, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nt][3], b3, acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[nt][r] = acc[r] > 0.f ? acc[r] : 0.f;
+        }
+        // segments: rows of one pillar are neighbouring lanes of the 16-lane row.  prev / next pillar ids decide; the longest pillar of the
+        // tile bounds the scan distance (wave-uniform)
+        const int q_up = __shfl_up(qid, 1, 16), q_dn = __shfl_down(qid, 1, 16);
+        const bool head = live && (rho == 0 || q_up != qid);
+        const bool multi_lane = live && ((rho > 0 && q_up == qid) || (rho < 15 && q_dn == qid));
+        const bool multi = (PN_PFN_EXP & 4) ? false : __ballot(multi_lane) != 0ull;
+        int maxlen = 1;
+        if (multi) {
+          const int len = live ? m_e[q] - m_s[q] : 1;
+          int ml = len;
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) ml = max(ml, __shfl_xor(ml, o, 16));
+          maxlen = __builtin_amdgcn_readfirstlane(ml);      // (the four lane groups hold the same rows)
+        }
+        f32x4 m0[2] = {h[0], h[1]};
+        if (multi) {
+          // towards the pillar's first row: lane i takes lane i + o while it belongs to the same pillar (a lane without a source keeps a value no row has)
+          auto down = [&](auto O) {
+            constexpr int o = decltype(O)::value;
+            if (o < maxlen) {      // wave-uniform
+              const bool same = row_down_i<o>(0x7fffffff, qid) == qid;
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const float tv = row_down<o>(m0[nt][r], m0[nt][r]);
+                  m0[nt][r] = same ? fmaxf(m0[nt][r], tv) : m0[nt][r];
+                }
+            }
+          };
+          down(std::integral_constant<int, 1>{}); down(std::integral_constant<int, 2>{}); down(std::integral_constant<int, 4>{}); down(std::integral_constant<int, 8>{});
+          // the pillar's first row holds its maximum: hand it down the segment
+          auto up = [&](auto O) {
+            constexpr int o = decltype(O)::value;
+            if (o < maxlen) {
+              const bool same = row_up_i<o>(0x7fffffff, qid) == qid;
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const float tv = row_up<o>(m0[nt][r], m0[nt][r]);
+                  m0[nt][r] = same ? fmaxf(m0[nt][r], tv) : m0[nt][r];
+                }
+            }
+          };
+          up(std::integral_constant<int, 1>{}); up(std::integral_constant<int, 2>{}); up(std::integral_constant<int, 4>{}); up(std::integral_constant<int, 8>{});
+        }
+        f32x4 yv[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) yv[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < ((PN_PFN_EXP & 2) ? 1 : 16); ++i) {
+          const float act = i < 8 ? m0[i >> 2][i & 3] : h[(i - 8) >> 2][(i - 8) & 3];
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) yv[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mt][i], act, yv[mt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yv[mt][r] = fmaxf(0.f, yv[mt][r]);
+        if (multi) {
+          auto down = [&](auto O) {
+            constexpr int o = decltype(O)::value;
+            if (o < maxlen) {
+              const bool same = row_down_i<o>(0x7fffffff, qid) == qid;
+#pragma unroll
+              for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const float tv = row_down<o>(yv[mt][r], yv[mt][r]);
+                  yv[mt][r] = same ? fmaxf(yv[mt][r], tv) : yv[mt][r];
+                }
+            }
+          };
+          down(std::integral_constant<int, 1>{}); down(std::integral_constant<int, 2>{}); down(std::integral_constant<int, 4>{}); down(std::integral_constant<int, 8>{});
+        }
+        if (head && !(PN_PFN_EXP & 8)) {      // accumulator register r of lane group jj = channel 16 mt + 4 jj + r: 16 bytes per store
+          const int v = v0 + q;
+          const int cell = reinterpret_cast<const int*>(&m_c[q][0])[9];      // (read here, as an integer: carried as cc[1] across the MFMAs the value came back as cc[0]'s bits)
+          if (a.feat) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) *reinterpret_cast<f32x4*>(a.feat + (size_t)v * 128 + 16 * mt + 4 * jj) = yv[mt];
+          }
+          if (a.canvas) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) *reinterpret_cast<f32x4*>(a.canvas + (size_t)cell * 128 + 16 * mt + 4 * jj) = yv[mt];
+          }
+        }
+      }
+      q0 = q1;
+      if (q0 < nb) __syncthreads();  // the staged rows are rewritten by the next sub-batch
+    }
+  }
+}
+
 // ONE launch for both populations of pillars: blocks [0, main_blocks) run the batched one-wave-per-pillar path, the remaining
 // blocks look for pillars of more than kHeavyPillar points.  (Two launches cost ~5 us of dependent-dispatch latency inside a
 // replayed graph, more than the heavy path's own work on a sweep that has no such pillar.  Both bodies are 4-wave blocks: an
@@ -453,6 +704,13 @@ __device__ __forceinline__ void pfn_32_128_heavy(const PfnArgs& a, const float* 
 static_assert(kHeavyWaves * 64 == 256, "both bodies of dynamic_pfn_32_128_kernel are 256-thread blocks");
 __global__ __launch_bounds__(256) void dynamic_pfn_32_128_main_kernel(PfnArgs a, const float* __restrict__ cs_table) {
   pfn_32_128_main(a, cs_table, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256) void dynamic_pfn_32_128_tile_kernel(PfnArgs a, const float* __restrict__ cs_table) {
+  pfn_32_128_tiles(a, cs_table, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void dynamic_pfn_32_128_heavy16_kernel(PfnArgs a, const float* __restrict__ cs_table) {
+  pfn_32_128_heavy<kTileRows>(a, cs_table, blockIdx.x, gridDim.x);
 }
 __global__ __launch_bounds__(256) void dynamic_pfn_32_128_heavy_kernel(PfnArgs a, const float* __restrict__ cs_table) {
   pfn_32_128_heavy(a, cs_table, blockIdx.x, gridDim.x);
@@ -1079,6 +1337,15 @@ int pn_dynamic_pfn_fwd_table(const float* points, int point_stride, const int32_
   const int hblocks = std::max(1, std::min(256, pn::cdiv(v_capacity, kHeavyPillar)));
   // two launches by default: the merged kernel (PN_PFN_SPLIT=0) was measured 7 us SLOWER than main + heavy back to back
   // (45.3 vs 33.3 + 4.8 us inside a frame) although its register count and LDS are those of the batched path alone
+  // r5 (late): point rows as 16-column MFMA tiles (same bits; PN_PFN_TILES=0: the wave-per-pillar kernel)
+  static const int tiles = [] { const char* e = getenv("PN_PFN_TILES"); return e ? atoi(e) : 1; }();
+  if (tiles) {
+    const int hb16 = std::max(1, std::min(512, pn::cdiv(v_capacity, 64)));
+    // (two launches: both bodies in one kernel measured 38 against 28 us at 30 k points and 207 against 137 at 300 k -- as for the r4 pair)
+    hipLaunchKernelGGL(dynamic_pfn_32_128_tile_kernel, dim3(blocks), dim3(256), 0, pn::S(stream), a, center_table);
+    hipLaunchKernelGGL(dynamic_pfn_32_128_heavy16_kernel, dim3(hb16), dim3(256), 0, pn::S(stream), a, center_table);
+    return pn::check_launch("dynamic_pfn_32_128_tile_kernel");
+  }
   static const int split = [] { const char* e = getenv("PN_PFN_SPLIT"); return e ? atoi(e) : 1; }();
   if (split) {
     hipLaunchKernelGGL(dynamic_pfn_32_128_main_kernel, dim3(blocks), dim3(256), 0, pn::S(stream), a, center_table);
