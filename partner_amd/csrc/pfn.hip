@@ -465,6 +465,12 @@ template <int N> __device__ __forceinline__ float row_down(float old, float v) {
 template <int N> __device__ __forceinline__ float row_up(float old, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, false));
 }
+// max of two values that are >= 0 (layer outputs behind max(0, .)): the order of their bit patterns as signed integers is their order as
+// floats (-0.0, the one negative pattern fmaxf(0, y) could leave, is the smallest) -- one v_max_i32 instead of fmaxf's canonicalising three
+__device__ __forceinline__ float seg_max(float a, float b, bool take) {
+  const int ia = __builtin_bit_cast(int, a), ib = __builtin_bit_cast(int, b);
+  return __builtin_bit_cast(float, take ? max(ia, ib) : ia);
+}
 template <int N> __device__ __forceinline__ int row_down_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x100 + N, 0xf, 0xf, false); }
 template <int N> __device__ __forceinline__ int row_up_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x110 + N, 0xf, 0xf, false); }
 #ifndef PN_PFN_EXP
@@ -626,8 +632,7 @@ __device__ __forceinline__ void pfn_32_128_tiles(const PfnArgs& a, const float* 
               for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                  const float tv = row_down<o>(m0[nt][r], m0[nt][r]);
-                  m0[nt][r] = same ? fmaxf(m0[nt][r], tv) : m0[nt][r];
+                  m0[nt][r] = seg_max(m0[nt][r], row_down<o>(m0[nt][r], m0[nt][r]), same);
                 }
             }
           };
@@ -641,8 +646,7 @@ __device__ __forceinline__ void pfn_32_128_tiles(const PfnArgs& a, const float* 
               for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                  const float tv = row_up<o>(m0[nt][r], m0[nt][r]);
-                  m0[nt][r] = same ? fmaxf(m0[nt][r], tv) : m0[nt][r];
+                  m0[nt][r] = seg_max(m0[nt][r], row_up<o>(m0[nt][r], m0[nt][r]), same);
                 }
             }
           };
@@ -670,8 +674,7 @@ __device__ __forceinline__ void pfn_32_128_tiles(const PfnArgs& a, const float* 
               for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                  const float tv = row_down<o>(yv[mt][r], yv[mt][r]);
-                  yv[mt][r] = same ? fmaxf(yv[mt][r], tv) : yv[mt][r];
+                  yv[mt][r] = seg_max(yv[mt][r], row_down<o>(yv[mt][r], yv[mt][r]), same);
                 }
             }
           };
