@@ -388,27 +388,34 @@ def scatter_roofline(model, dev, n_points, spec):
 
 
 def pmc_traffic_path():
-    """the newest committed PMC traffic summary (profiles/rN_pmc_traffic.csv)"""
-    for r in ("r4", "r3", "r2"):
-        path = os.path.join(ROOT, "profiles", f"{r}_pmc_traffic.csv")
-        if os.path.exists(path):
-            return path
-    return None
+    """the newest committed PMC traffic summary (profiles/rN_pmc_traffic.csv, highest N)"""
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.csv")):
+        m = re.match(r"r(\d+)_pmc_traffic\.csv$", os.path.basename(path))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), path)
+    return None if best is None else best[1]
+
+
+PMC_FRAME_KERNEL = "fused_polar_index_kernel"      # one launch per frame in every regime: the frame count of a PMC pass
 
 
 def committed_pmc_bytes(kernel_prefixes, per="frame"):
     """HBM bytes from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the gfx950 guide prescribes + WRITE_SIZE, separate
-    --pmc passes of this command with --streams 1): summed over the kernels whose name contains one of the prefixes, per frame
-    (per='frame') or averaged per launch (per='launch'); None if the summary is absent"""
+    --pmc passes of this command): summed over the kernels whose name contains one of the prefixes, per frame (per='frame') or averaged
+    per launch (per='launch').  None if there is no summary at all or no kernel matches; a summary WITHOUT the per-frame kernel is an
+    error (the frame count would be a guess)."""
     import csv
     path = pmc_traffic_path()
     if path is None:
         return None
     rows = list(csv.DictReader(open(path)))
-    frames = None
-    for r in rows:
-        if "dynamic_pfn_32_128_kernel" in r["kernel"] or "dynamic_pfn_32_128_main_kernel" in r["kernel"]:
-            frames = int(r["launches"])     # one launch per frame
+    frames = [int(r["launches"]) for r in rows if PMC_FRAME_KERNEL in r["kernel"]]
+    if not frames:
+        raise RuntimeError(f"{os.path.basename(path)}: no row for {PMC_FRAME_KERNEL} -- the frame count of the PMC pass is unknown")
+    frames = frames[0]
     tot, n = 0.0, 0
     for r in rows:
         if any(p in r["kernel"] for p in kernel_prefixes):
@@ -417,7 +424,7 @@ def committed_pmc_bytes(kernel_prefixes, per="frame"):
             n += k
     if not n:
         return None
-    return round(tot / frames) if (per == "frame" and frames) else round(tot / n)
+    return round(tot / frames) if per == "frame" else round(tot / n)
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -674,75 +681,81 @@ def main():
                        launch=f"hipGraph replay per {GB} frames (the reference config's samples_per_gpu), {GS} replays in flight")
         eng2.clear()
 
-    # roofline pass: the same K steps launched eagerly on one stream with an event pair attached to every conv DISPATCH
-    # (hipExtLaunchKernelGGL start/stop events = the kernel's own execution time; events cannot ride inside a replayed graph)
-    roofline = None
-    if not args.no_roofline_events:
-        # (eager launches keep the GPU a third busy: after two warm-up frames the first timed ones still ran at the clocks of an idle
-        # device and the dominant kernel's fraction moved between 0.63 and 0.67 from run to run; 30 frames = 60 ms settle it)
-        for i in range(30):
-            step_eager(i)
-        prof = ops.enable_conv_profiling()
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            step_eager(i)
-        barrier()
-        eager_ms = 1e3 * (time.perf_counter() - t1) / args.steps
-        flops, ms, launches, tags = prof.collect(by_tag=True, full=True)
-        ops.disable_conv_profiling()
-        # roofline.frac: the matrix work ISSUED / kernel time / peak.  Winograd launches issue 6 (F(2,3)) or 4.5
+    # roofline passes: the same K steps launched eagerly on one stream with an event pair attached to every conv DISPATCH
+    # (hipExtLaunchKernelGGL start/stop events = the kernel's own execution time; events cannot ride inside a replayed graph).
+    # r6: `roofline` describes the kernel FORMS of the regime `value` is timed in -- the launches carry the
+    # frames-in-flight hint and the chain form FramePipeline chose, so its dominant kernel is the headline's (conv_wchain3_kernel<2> when
+    # F(4,3)xF(4,3) was chosen) --, each launch timed alone on the chip (a kernel's own roofline); the forms a frame takes when it has the
+    # chip to itself are the same measurement under `roofline_single_stream`.
+    def conv_roofline(hint, chain44_on, full):
+        with ops.frames_in_flight(hint), ops.chain44(chain44_on):
+            # (eager launches keep the GPU a third busy: after two warm-up frames the first timed ones still ran at the clocks of an idle
+            # device and the dominant kernel's fraction moved between 0.63 and 0.67 from run to run; 30 frames = 60 ms settle it)
+            for i in range(30):
+                step_eager(i)
+            prof = ops.enable_conv_profiling()
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                step_eager(i)
+            barrier()
+            eager_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+            flops, ms, launches, tags = prof.collect(by_tag=True, full=True)
+            ops.disable_conv_profiling()
+        # frac: the matrix work ISSUED / kernel time / peak.  Winograd launches issue 6 (F(2,3)) or 4.5
         # (F(4,3)) of the direct algorithm's 9 MACs per output; block 0's first layer multiplies its (pillar, tap) pairs only.
         issued_f = sum(t[3] for t in tags.values())
         dense_f = sum(t[4] for t in tags.values())
         issued = issued_f / (ms * 1e-3) / 1e12
         dense = dense_f / (ms * 1e-3) / 1e12
+        dom_tag, dom = max(tags.items(), key=lambda kv: kv[1][1])
+        dom_tf = dom[3] / (dom[1] * 1e-3) / 1e12
+        if dom_tag.startswith("256x256") and "F(4,3)xF(4,3) chain" in dom_tag:
+            dom_name, dom_pmc_name, alg = "conv_wchain3_kernel<2>", "conv_wchain3_kernel<2>", "1/4"
+        elif dom_tag.startswith("256x256") and "F(2,3)xF(4,3) chain" in dom_tag:
+            dom_name, dom_pmc_name, alg = "conv_wchain2_kernel<1,1,2>", "conv_wchain2_kernel<1, 1, 2>", "1/3"
+        else:
+            dom_name, dom_pmc_name, alg = ("conv_wchain_kernel" if "chain" in dom_tag else "conv_mfma_kernel"), None, "see by_layer"
+        traffic = committed_pmc_bytes((dom_pmc_name,), per="launch") if dom_pmc_name else None
+        r = dict(bound="mfma", kernel=f"{dom_name} (conv_wchain.hip), fp32 v_mfma_f32_32x32x2_f32: layer {dom_tag}",
+                 regime=(f"kernel forms of the headline regime ({hint} frames in flight, chain form chosen by FramePipeline's measurement), each launch "
+                         "timed alone on the chip") if hint > 1 else "kernel forms of ONE frame in flight (a frame has the chip to itself)",
+                 achieved=round(dom_tf, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(dom_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                 traffic=traffic, traffic_source=os.path.basename(pmc_traffic_path() or "none"),
+                 dominant_us=round(1e3 * dom[1] / dom[2], 2), dominant_launches_per_step=round(dom[2] / args.steps, 2),
+                 dominant_gflop_issued_per_launch=round(dom[3] / dom[2] / 1e9, 3), dominant_share_of_conv_time=round(dom[1] / ms, 3),
+                 all_conv_frac=round(issued / PEAK_F32_MFMA_TFLOPS, 4), conv_ms_per_step=round(ms / args.steps, 4),
+                 launches_per_step=round(launches / args.steps, 2))
+        if hint > 1:
+            r["frac_in_flight"] = round(issued_f / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)      # (both loops ran args.steps steps)
+        if not full:
+            return r
         layers = {t: dict(launches_per_step=round(n / args.steps, 2), us=round(1e3 * m / n, 2), tflops_issued=round(iss / (m * 1e-3) / 1e12, 1),
                           frac=round(iss / (m * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3), tflops_algorithmic_equiv=round(den / (m * 1e-3) / 1e12, 1))
                   for t, (f, m, n, iss, den) in sorted(tags.items(), key=lambda kv: -kv[1][1])}
-        dom_tag, dom = max(tags.items(), key=lambda kv: kv[1][1])
-        dom_kernel = ("conv_wchain3_kernel" if "F(4,3)xF(4,3)" in dom_tag else "conv_wchain2_kernel" if "F(2,3)xF(4,3)" in dom_tag else
-                      "conv_wchain_kernel" if "chain" in dom_tag else "conv_mfma_kernel") + \
-                     " (conv_wchain.hip / conv_mfma.hip), fp32 v_mfma_f32_32x32x2_f32: layer " + dom_tag
-        dom_tf = dom[3] / (dom[1] * 1e-3) / 1e12
-        dom_pmc_name = ("conv_wchain3_kernel<2>" if "F(4,3)xF(4,3) chain" in dom_tag else "conv_wchain2_kernel<1, 1, 2>" if "F(2,3)xF(4,3) chain" in dom_tag
-                        else None) if dom_tag.startswith("256x256") else None
-        roofline = dict(bound="mfma", kernel=dom_kernel, schema="r4+: frac / achieved = the dominant kernel; all_conv.frac = the r1-r3 definition",
-                        achieved=round(dom_tf, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(dom_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                        counts="the DOMINANT kernel (most time per frame): the FLOPs it ISSUES to the matrix pipes per launch (chained F(4,3)xF(4,3), "
-                               "r5 late: 36 products per 16 outputs = 1/4 of the direct algorithm's 9 MACs per output; F(2,3)xF(4,3): 1/3; F(4,3): 1/2) / its "
-                               "average launch duration.  r5 moved the 256^2 layers from F(2,3)xF(4,3) (6.44 GFLOP issued, 61.5 us, frac 0.665) to "
-                               "F(4,3)xF(4,3) (4.83 GFLOP issued, 55-58 us): a quarter less issued work at a LOWER issued fraction and a shorter launch "
-                               "(start/stop events on its own dispatches).  Up to r3 this object's frac was the average over ALL conv launches (r3: "
-                               "0.556); that figure is all_conv.frac now -- r4 cut the issued work of the 256^2 / 128^2 layers by a third at shorter "
-                               "kernel times, so the all-launch fraction fell while frames/s rose",
-                        dominant_kernel=dict(layer=dom_tag, launches_per_step=round(dom[2] / args.steps, 2), us=round(1e3 * dom[1] / dom[2], 2),
-                                             gflop_issued_per_launch=round(dom[3] / dom[2] / 1e9, 3), share_of_conv_time=round(dom[1] / ms, 3)),
-                        # the same launches priced at the work the r4 form of the layer issued (F(2,3)xF(4,3): a third of the direct algorithm's
-                        # FLOPs): comparable with the r4 line's frac, not a roofline fraction of this kernel
-                        frac_at_r4_issued_flops=(round(dom[0] / 3.0 / (dom[1] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if "F(4,3)xF(4,3)" in dom_tag else None),
-                        all_conv=dict(achieved=round(issued, 3), frac=round(issued / PEAK_F32_MFMA_TFLOPS, 4),
-                                      kernels="conv_wchain2_kernel / conv_wchain_kernel (the RPN blocks' stride-1 3x3 layers and the head's branch "
-                                              "convolutions chained in the Winograd domain) + conv_mfma_kernel (stride-2 layers, deblocks) + "
-                                              "conv_wino4_ks_kernel (head's shared convolution) + conv_small_n_multi_kernel (head's last convolutions, "
-                                              "VALU) + pillar_conv.hip (block 0's first layer on (pillar, tap) pairs)"),
-                        frac_in_flight=round(issued_f / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),      # (both loops ran args.steps steps)
-                        frac_in_flight_of="issued FLOPs of ALL conv launches per frame / ms_per_step (the headline regime, frames in flight) / peak",
-                        algorithmic_equiv=dict(tflops=round(dense, 3), over_peak=round(dense / PEAK_F32_MFMA_TFLOPS, 4),
-                                               note="the direct dense algorithm's FLOPs (every layer 2*pixels*Cout*Cin*KH*KW, first layer included) over the "
-                                                    "kernel time of all conv launches: what the FLOP-reducing forms buy; not a roofline fraction, may exceed 1"),
-                        traffic=committed_pmc_bytes((dom_pmc_name,), per="launch") if dom_pmc_name else None,
-                        traffic_unit="HBM bytes per launch of the dominant kernel (offline PMC passes of this command, profiles/%s); algorithmic: "
-                                     "planes in + planes out = 2 x 1.5 x pixels x C x 4 B = 100.7 MB at 256^2 x 128 (+ 1.2 MB of weights)"
-                                     % os.path.basename(pmc_traffic_path() or "none"),
-                        traffic_all_conv=committed_pmc_bytes(("conv_mfma_kernel", "conv_wino", "conv_wchain", "conv_small_n", "conv_multi", "pair_gemm",
-                                                              "pair_reduce"), per="launch"),
-                        launches=launches, launches_per_step=round(launches / args.steps, 2), flops_issued_per_launch=round(issued_f / launches),
-                        avg_launch_us=round(1e3 * ms / launches, 2), conv_ms_per_step=round(ms / args.steps, 4),
-                        paired_with="single_stream_ms_per_step (one frame in flight)",
-                        measured="start/stop events attached to every conv dispatch (hipExtLaunchKernelGGL) over the same K steps "
-                                 "launched eagerly on one stream: per-kernel execution time as in a rocprofv3 kernel trace",
-                        eager_ms_per_step=round(eager_ms, 4), by_layer=layers)
+        r.update(counts="the DOMINANT kernel of these forms (most time per frame): the FLOPs it ISSUES to the matrix pipes per launch "
+                        f"({alg} of the direct algorithm's 9 MACs per output: chained F(4,3)xF(4,3) issues 36 products per 16 outputs, F(2,3)xF(4,3) "
+                        "1/3, F(4,3) 1/2) / its average launch duration (start/stop events on its own dispatches); frac_in_flight = issued FLOPs of "
+                        "ALL conv launches per frame / ms_per_step (the timed headline loop itself) / peak; all_conv_frac = the r1-r3 definition",
+                 traffic_unit="HBM bytes per launch of the dominant kernel (offline PMC passes of this command: FETCH_SIZE x 2 + WRITE_SIZE); algorithmic: "
+                              "planes in + planes out = 2 x 1.5 x pixels x C x 4 B = 100.7 MB at 256^2 x 128 (+ 1.2 MB of weights)",
+                 traffic_all_conv=committed_pmc_bytes(("conv_mfma_kernel", "conv_wino", "conv_wchain", "conv_small_n", "conv_multi", "pair_gemm",
+                                                       "pair_reduce", "conv_s2", "pillar_tile"), per="launch"),
+                 algorithmic_equiv=dict(tflops=round(dense, 3), over_peak=round(dense / PEAK_F32_MFMA_TFLOPS, 4),
+                                        note="the direct dense algorithm's FLOPs (every layer 2*pixels*Cout*Cin*KH*KW, first layer included) over the "
+                                             "kernel time of all conv launches: what the FLOP-reducing forms buy; not a roofline fraction, may exceed 1"),
+                 measured="start/stop events attached to every conv dispatch (hipExtLaunchKernelGGL) over the same K steps "
+                          "launched eagerly on one stream: per-kernel execution time as in a rocprofv3 kernel trace",
+                 eager_ms_per_step=round(eager_ms, 4), by_layer=layers)
+        return r
+
+    roofline = roofline_single = None
+    if not args.no_roofline_events:
+        k_hint = max(1, args.streams) if engines else 1
+        roofline = conv_roofline(k_hint, pipe.chain44 if engines else True, full=True)
+        if k_hint > 1:
+            roofline_single = conv_roofline(1, True, full=False)
+            roofline_single["paired_with"] = "single_stream_ms_per_step"
 
     # every rank runs the stage measurement (rank 0's is reported): no rank waits in a collective while another measures alone
     scatter = coarse = scatter300 = None
@@ -794,24 +807,59 @@ def main():
     torch.cuda.set_stream(torch.cuda.default_stream(dev))
     if rank == 0:
         fps = world * args.steps * B / elapsed
+
+        def get(d, *ks):
+            for k in ks:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+
+        form = get(stream_tuning, "chain_form") or {}
+        # the secondary figures in one flat object, printed FIRST and LAST in the line (records that keep only the head or the tail of
+        # the line keep them) and, as one short string, inside `config` (records that keep the contract's keys only)
+        summary = dict(
+            value=round(fps, 3), value_sustained=None if sustained is None else sustained["value"],
+            single_stream_ms_per_step=None if single_ms is None else round(single_ms, 4),
+            chain_form=form.get("chosen"), chain_form_ms_per_frame=form.get("candidates"),
+            roofline_kernel=None if roofline is None else roofline["kernel"].split(" ")[0], roofline_frac=get(roofline, "frac"),
+            roofline_frac_in_flight=get(roofline, "frac_in_flight"), roofline_single_stream_frac=get(roofline_single, "frac"),
+            scatter_us=get(scatter, "us"), scatter_300k_us=get(scatter300, "us"),
+            train_ms_per_iter=get(train, "ms_per_iter"), batched_frames_per_s=get(batched, "value"),
+            c4_f32_ms_per_step=get(c4, "f32", "ms_per_step"), c4_f32_one_graph_p50_ms=get(c4, "one_graph_bs2", "p50_ms"),
+            c4_f32_sparse_encoder_ms=get(c4, "f32", "stages", "sparse_encoder", "ms"), c4_f32_setblocks_x2_ms=get(c4, "f32", "stages", "setblocks_x2", "ms"),
+            c4_f32_rpn_ms=get(c4, "f32", "stages", "rpn", "ms"), c4_f32_head_ms=get(c4, "f32", "stages", "e2e_swv_head", "ms"),
+            c4_bf16_ms_per_step=get(c4, "option_bf16_bev_convs", "ms_per_step"),
+            c4_bf16_one_graph_p50_ms=get(c4, "option_bf16_bev_convs", "one_graph_bs2", "p50_ms"),
+            c4_bf16_rpn_ms=get(c4, "option_bf16_bev_convs", "stages", "rpn", "ms"), c4_bf16_head_ms=get(c4, "option_bf16_bev_convs", "stages", "e2e_swv_head", "ms"),
+            c5_p50_ms=get(c5, "p50_ms"), c5_p99_ms=get(c5, "p99_ms"))
+
+        def f(x, nd=2):
+            return "-" if x is None else (f"{x:.{nd}f}" if isinstance(x, float) else str(x))
+
+        cands = form.get("candidates") or {}
+        secondary = (f"sust {f(summary['value_sustained'], 0)}|1s {f(summary['single_stream_ms_per_step'], 3)}|tr {f(summary['train_ms_per_iter'])}|"
+                     f"c4 {f(summary['c4_f32_one_graph_p50_ms'])}/{f(summary['c4_bf16_one_graph_p50_ms'])}|c5 {f(summary['c5_p50_ms'], 3)}|"
+                     f"f44 {f(cands.get('F(4,3)xF(4,3)'), 3)} f24 {f(cands.get('F(2,3)xF(4,3)'), 3)}")
         line = {
             "metric": "frames/sec polar voxelize+PFN+BEV+head, 30k-pt sweep (whole job)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "summary": summary,
             "config": {"workload": "nuScenes polar-pillar PARTNER cfg (DynamicPFNet -> DynamicPPScatter -> RPN -> "
                                    "CenterHeadSinglePos), grid 512x512x1, forward only (BASELINE configs[1])",
-                       "points_per_sweep": N, "sweeps_per_step_per_gpu": B, "parallelism": f"frame-replicas x{world}", "device": hip.device_info(dev.index or 0),
-                       "launch": "eager" if args.eager else f"hipGraph replay per frame, {max(1, args.streams)} frame(s) in flight on separate HIP streams"},
+                       "points_per_sweep": N, "sweeps_per_step_per_gpu": B, "parallelism": f"frame-replicas x{world}",
+                       "launch": "eager" if args.eager else f"hipGraph replay per frame, {max(1, args.streams)} frame(s) in flight on separate HIP streams",
+                       "chain_form": form.get("chosen"), "secondary": secondary, "device": hip.device_info(dev.index or 0)},
             "value_sustained": None if sustained is None else sustained["value"], "sustained": sustained,
             "single_stream_ms_per_step": None if single_ms is None else round(single_ms, 4),
             "replay_stream_tuning": stream_tuning,
-            "batched": batched, "roofline": roofline, "roofline_scatter": scatter, "roofline_scatter_300k": scatter300, "roofline_scatter_coarse": coarse, "train_step": train,
-            "c4": c4, "c5": c5, "ranks_seen": ranks_seen, "ranks": ranks,
+            "roofline": roofline, "roofline_single_stream": roofline_single,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, B)
             line["gpu_over_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)
+        line.update({"batched": batched, "roofline_scatter": scatter, "roofline_scatter_300k": scatter300, "roofline_scatter_coarse": coarse,
+                     "train_step": train, "c4": c4, "c5": c5, "ranks_seen": ranks_seen, "ranks": ranks, "summary_tail": summary})
         print(json.dumps(line), flush=True)
     if world > 1:
         D.barrier()

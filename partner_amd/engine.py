@@ -13,12 +13,15 @@ from . import hip, ops
 
 class FrameEngine:
     def __init__(self, model, batch: int, points_per_sweep: int, spec: ops.GridSpec = None, point_features: int = 5, test_cfg=None,
-                 frames_in_flight: int = 1):
+                 frames_in_flight: int = 1, chain44: bool = True):
         """``test_cfg``: when given, the frame ends in ``bbox_head.predict(..., device_only=True)`` inside the same graph
         (fixed-size box / score / label buffers + a device count); otherwise the outputs are the head tensors.
         ``frames_in_flight``: how many engines replay at the same time on their own streams (throughput serving); the captured
-        kernels may then take forms that leave CUs to the other frames (ops.frames_in_flight).  1 = a frame has the chip to itself."""
+        kernels may then take forms that leave CUs to the other frames (ops.frames_in_flight).  1 = a frame has the chip to itself.
+        ``chain44``: False captures the chained layers as F(2,3)xF(4,3) where the hint alone would pick F(4,3)xF(4,3) (ops.chain44;
+        FramePipeline measures which of the two is faster on this box)."""
         self.frames_in_flight = max(1, int(frames_in_flight))
+        self.chain44 = bool(chain44)
         hip.load()
         self.test_cfg = test_cfg
         self.model = model.eval()
@@ -62,13 +65,13 @@ class FrameEngine:
         self.stream = stream
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), ops.frames_in_flight(self.frames_in_flight):
+        with torch.cuda.stream(side), ops.frames_in_flight(self.frames_in_flight), ops.chain44(self.chain44):
             for _ in range(warmup):  # builds plans / packs weights / sets kernel attributes outside the capture
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), ops.frames_in_flight(self.frames_in_flight):
+        with torch.cuda.graph(self.graph), ops.frames_in_flight(self.frames_in_flight), ops.chain44(self.chain44):
             self.outputs = self._step()
         return self
 
@@ -135,27 +138,85 @@ def tune_replay_streams(engines, cart: torch.Tensor, trials: int = 8, frames: in
     return dict(ms_per_frame=round(results[best], 4), trials=[round(r, 4) for r in results])
 
 
+def _time_round_robin(engines, cart: torch.Tensor, frames: int) -> float:
+    """ms per frame of ``frames`` replays round-robin over ``engines`` (their streams as assigned), after one untimed round"""
+    import time
+    k = len(engines)
+    for i in range(k):
+        engines[i % k].run(cart, sync=False)
+    torch.cuda.synchronize(cart.device)
+    t0 = time.perf_counter()
+    for i in range(frames):
+        engines[i % k].run(cart, sync=False)
+    torch.cuda.synchronize(cart.device)
+    return 1e3 * (time.perf_counter() - t0) / frames
+
+
 class FramePipeline:
-    """Throughput serving: ``k`` FrameEngines of one model replaying round-robin on their own streams, with the stream assignment
-    MEASURED at construction (``tune_replay_streams``) -- the multi-frame regime bench.py's headline is quoted in, as one object.
+    """Throughput serving: ``k`` FrameEngines of one model replaying round-robin on their own streams, with the stream assignment AND the
+    chained layers' kernel form MEASURED at construction -- the multi-frame regime bench.py's headline is quoted in, as one object.
 
     Why this exists: engines on arbitrary streams work, but which hardware queues their streams share decides how the frames
     interleave, and an unmeasured assignment can sit up to 20 % below the best one (r4 driver run: 0.637 - 0.761 ms per frame over
     the eight trials).  A user who builds the engines by hand and skips the tuner takes that risk; ``FramePipeline`` does not offer
     the choice.  ``tuning`` keeps what was measured ({"ms_per_frame", "trials", "untuned_ms_per_frame"} -- the last is the
-    as-captured assignment, i.e. the penalty of not tuning on this box)."""
+    as-captured assignment re-timed AFTER the other trials (the first-timed trial is the coldest one), i.e. the penalty of
+    not tuning on this box).
+
+    r6: with frames in flight the 256^2 / 128^2 chained layers have two forms, F(4,3)xF(4,3) (a quarter of the
+    direct algorithm's products) and F(2,3)xF(4,3) (a third, at a higher issued fraction).  Which is faster in flight differed by box
+    in r5 (+2 .. 3 % on four boxes, -4.5 % on the driver's), so both sets of engines are captured, each gets its stream assignment
+    tuned, and the two are then timed INTERLEAVED (``form_rounds`` rounds of ``form_frames`` frames each, alternating); the set with the
+    lower median stays, the other is released.  ``tuning["chain_form"]`` records both figures and the choice."""
 
     def __init__(self, model, batch: int, points_per_sweep: int, spec: ops.GridSpec = None, frames_in_flight: int = 3, point_features: int = 5,
-                 test_cfg=None, trials: int = 8):
+                 test_cfg=None, trials: int = 8, form_rounds: int = 4, form_frames: int = 64):
         k = max(1, int(frames_in_flight))
-        self.engines = []
-        for _ in range(k):
-            st = torch.cuda.Stream() if k > 1 else None
-            self.engines.append(FrameEngine(model, batch, points_per_sweep, spec, point_features, test_cfg, frames_in_flight=k).capture(stream=st))
+
+        def build(chain44):
+            es = []
+            for _ in range(k):
+                st = torch.cuda.Stream() if k > 1 else None
+                es.append(FrameEngine(model, batch, points_per_sweep, spec, point_features, test_cfg, frames_in_flight=k, chain44=chain44).capture(stream=st))
+            return es
+
+        def tune(es):
+            captured = [e.stream for e in es]
+            t = tune_replay_streams(es, es[0].cart.clone(), trials=trials)
+            chosen = [e.stream for e in es]
+            for e, st in zip(es, captured):          # the as-captured assignment once more, warm
+                e.stream = st
+            t["untuned_ms_per_frame"] = round(_time_round_robin(es, es[0].cart.clone(), 32), 4)
+            for e, st in zip(es, chosen):
+                e.stream = st
+            return t
+
+        self.engines = build(True)
         self.tuning = None
         if k > 1:
-            self.tuning = tune_replay_streams(self.engines, self.engines[0].cart.clone(), trials=trials)
-            self.tuning["untuned_ms_per_frame"] = self.tuning["trials"][0]
+            self.tuning = tune(self.engines)
+            # does the hint pick F(4,3)xF(4,3) anywhere in this model on this map?  (ops counts the launches of the form per capture)
+            if ops.chain44_launches_seen():
+                alt = build(False)
+                alt_tuning = tune(alt)
+                cart = self.engines[0].cart.clone()
+                a, b = [], []
+                for _ in range(max(1, form_rounds)):
+                    a.append(_time_round_robin(self.engines, cart, form_frames))
+                    b.append(_time_round_robin(alt, cart, form_frames))
+                med = lambda v: sorted(v)[len(v) // 2]
+                ma, mb = med(a), med(b)
+                form = dict(candidates={"F(4,3)xF(4,3)": round(ma, 4), "F(2,3)xF(4,3)": round(mb, 4)}, unit="ms per frame, median of "
+                            f"{max(1, form_rounds)} interleaved rounds of {form_frames} frames, {k} frames in flight",
+                            rounds={"F(4,3)xF(4,3)": [round(x, 4) for x in a], "F(2,3)xF(4,3)": [round(x, 4) for x in b]},
+                            chosen="F(4,3)xF(4,3)" if ma <= mb else "F(2,3)xF(4,3)")
+                if mb < ma:
+                    self.engines, self.tuning = alt, alt_tuning
+                del alt
+                self.tuning["chain_form"] = form
+            else:
+                self.tuning["chain_form"] = dict(candidates=None, chosen="F(2,3)xF(4,3)", unit="the F(4,3)xF(4,3) form is not taken on this map / build")
+        self.chain44 = self.engines[0].chain44
         self._next = 0
 
     def submit(self, cart: torch.Tensor) -> FrameEngine:

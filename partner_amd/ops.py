@@ -764,6 +764,7 @@ def conv_chain(layers, x: Optional[torch.Tensor], out: Optional[torch.Tensor] = 
         two_d = l.wino24_packed is not None and _chain_two_d(lib, d)
         if two_d and _chain_44(lib, d):
             two_d = "wino44"
+            _CHAIN44_LAUNCHES[0] += 1
         wts = l.chain_weights(two_d, tr)
         if prof is not None:
             ev = prof.begin(st)
@@ -792,6 +793,35 @@ def _chain_two_d(lib, d) -> bool:
 _CHAIN44_ON = os.environ.get("PN_CONV_CHAIN44", "1") != "0"            # chained layers on 128-pixel rows: F(4, 3) along the height as well where it pays
 
 
+class chain44:
+    """``with ops.chain44(False):`` -- the chained layers launched (or captured) inside the block take F(2,3)xF(4,3) where the
+    frames-in-flight hint alone would pick F(4,3)xF(4,3) (``True``: the default rule of ``_chain_44``).  Which form is faster with other
+    frames in flight differs from box to box (r5: +2 .. 3 % on the builder's boxes, -4.5 % on the driver's), so engine.FramePipeline
+    captures both and keeps the one it MEASURES faster; PN_CONV_CHAIN44=0 still forces the form off process-wide."""
+
+    def __init__(self, on: bool):
+        self.on, self.prev = bool(on), True
+
+    def __enter__(self):
+        global _CHAIN44_ROUTE
+        self.prev, _CHAIN44_ROUTE = _CHAIN44_ROUTE, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _CHAIN44_ROUTE
+        _CHAIN44_ROUTE = self.prev
+        return False
+
+
+_CHAIN44_ROUTE = True
+_CHAIN44_LAUNCHES = [0]
+
+
+def chain44_launches_seen() -> int:
+    """how many chained-layer launches took the F(4,3)xF(4,3) form so far in this process (engine.FramePipeline: is there a choice to measure?)"""
+    return _CHAIN44_LAUNCHES[0]
+
+
 def _chain_44(lib, d) -> bool:
     """F(4,3) x F(4,3) (conv_wchain3_kernel, r5: 2.25 MFMA equivalents per output; one block per four rows x 128 pixels x 32 channels, a 256-pixel
     row as two such halves one after the other): WITH OTHER FRAMES IN FLIGHT, where its blocks are whole rounds of the 256 CUs (256 x 256 x 128:
@@ -800,7 +830,7 @@ def _chain_44(lib, d) -> bool:
     alone on the chip: the 256 x 256 launch itself is 4 - 9 us shorter there too, but on two of the four boxes it was measured on every OTHER
     matrix kernel of the frame then ran 4 - 5 % longer (853.8 against 843.1 us of kernel time per frame; on the other boxes 796 against 812) --
     the one-frame latency moved by -20 .. +17 us with the box, the in-flight rate rose on all of them (+2 .. 3 %)"""
-    if not _CHAIN44_ON or d.frames_in_flight <= 1 or not lib.pn_conv_wino44_chain_supported(C.byref(d)):
+    if not (_CHAIN44_ON and _CHAIN44_ROUTE) or d.frames_in_flight <= 1 or not lib.pn_conv_wino44_chain_supported(C.byref(d)):
         return False
     fh, fw = (d.in_w, d.in_h) if d.transpose_hw else (d.in_h, d.in_w)
     tq = 64 if fw // 4 == 64 else 32
