@@ -530,6 +530,20 @@ int pn_linear_f32(const float *x, int m, int k, int ldx, const float *packed_w, 
  * never depend on a form picked behind its back. */
 int pn_linear_ksplit_f32(const float *x, int m, int k, int ldx, const float *packed_w, int n, const float *bias, int act,
                          const float *residual, int ldr, float *out, int ldo, pn_stream_t stream);
+/* pn_linear_f32 with a LayerNorm folded around it (r6): the norm -> Linear pairs of the attention block and of the Swin stage
+ * (set_transformer.py:160-165 `x + mlp(norm2(x))`, sw2votev4_util.py:127-188 `attn(norm1(x))`, `mlp(norm2(x))`) without the normalised
+ * tokens ever being written.  LayerNorm(x) W^T + b = rstd (x (W gamma)^T - mean colsum) + (b + W beta), so the normalisation is an affine
+ * map of the GEMM's own accumulators once (mean, rstd) of every input row are known:
+ *   producer  (row_stats_out != NULL, n % 32 == 0, no GELU): besides its output the launch leaves, per output row and 32-column group,
+ *             (sum, sum of squares) of the values it stores (after activation and residual) in row_stats_out [m][n / 32][2];
+ *   consumer  (ln_stats != NULL, k % 64 == 0): x is the producer's output; ln_stats [m][k / 32][2] its statistics table; packed_w the
+ *             packed (W gamma) (columns of W scaled by the LayerNorm weight), ln_colsum [n] its row sums over k, bias = b + W beta;
+ *             the epilogue forms mean / rstd = 1 / sqrt(var + ln_eps) per row (var = E[x^2] - mean^2, the partials added in group order)
+ *             and applies them before activation and residual.
+ * A launch is one or the other (or neither: then it is pn_linear_f32).  Tiled forms only. */
+int pn_linear_ln_f32(const float *x, int m, int k, int ldx, const float *packed_w, int n, const float *bias, int act,
+                     const float *residual, int ldr, float *out, int ldo, const float *ln_stats, const float *ln_colsum, float ln_eps,
+                     float *row_stats_out, pn_stream_t stream);
 /* tuning hook (tools/linear_bench.py): pins the tile form of every following pn_linear_f32 of the process -- 22 / 21 / 12 / 11 =
  * (64 TM) x (64 TN) block tiles, 1 = the K-split form, 0 = automatic (default; also PN_LINEAR_TILE in the environment) */
 int pn_linear_set_tile(int form);

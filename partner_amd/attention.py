@@ -127,14 +127,19 @@ class SetBlock(nn.Module):
             return ops.GemmLayer(w, b, ksplit=ksplit)
 
         s1, ra, s2 = a.sector_attn1, a.range_attn, a.sector_attn2
+        proj, mlp_g = G(a.proj.weight, a.proj.bias), mlp(a.mlp, G)
+        # r6: norm2 is folded into the MLP's first GEMM (GemmLayer.fold_layernorm): the output projection leaves the row statistics of
+        # x + proj(.) in its epilogue and fc1 normalises its own accumulators -- the normalised tokens are never written or read
+        ln2_folded = proj.stats_ok and mlp_g[0].fold_layernorm(a.norm2)
         return dict(
+            ln2_folded=ln2_folded,
             pos=self.pos_cart.reshape(self.patches_resolution[0], self.patches_resolution[1], 2).to(dev).float().contiguous(),
             s1_q=S(s1.proj_q.weight, s1.proj_q.bias), s1_kv=cat(s1.proj_k, s1.proj_v), s1_proj=S(s1.proj.weight, s1.proj.bias),
             s1_mlp=mlp(s1.mlp, S), s1_pe=_fold_pos_mlp(s1.pos_embedding_cart),
             ra_qkv=cat(ra.proj_q, ra.proj_k, ra.proj_v, ksplit=True), ra_proj=S(ra.proj.weight, ra.proj.bias), ra_mlp=mlp(ra.mlp, S),
             ra_pe=_fold_pos_mlp(ra.pos_embedding_cart),
             s2_q=G(s2.proj_q.weight, s2.proj_q.bias), s2_kv=cat(s2.proj_k, s2.proj_v, ksplit=True), s2_pe=_fold_pos_mlp(s2.pos_embedding_cart),
-            proj=G(a.proj.weight, a.proj.bias), mlp=mlp(a.mlp, G))
+            proj=proj, mlp=mlp_g)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (B, H*W, C) tokens (range-major, the reference's order) -> same shape"""
@@ -197,6 +202,10 @@ class SetBlock(nn.Module):
             y = p["proj"](ops.to_bf16(o3), residual=x2)
             z16 = ops.layernorm(y, a.norm2.weight.detach(), a.norm2.bias.detach(), a.norm2.eps, bf16_copy=True, f32_out=False)
             y = p["mlp"][1](p["mlp"][0](z16, act=ops.ACT_GELU, out_bf16=True), residual=y)
+            return y.view(B, L, C)
+        if p["ln2_folded"]:
+            y, ystats = p["proj"](o3, residual=x2, stats_out=True)
+            y = p["mlp"][1](p["mlp"][0](y, act=ops.ACT_GELU, ln_stats=ystats), residual=y)
             return y.view(B, L, C)
         y = p["proj"](o3, residual=x2)
         y = p["mlp"][1](p["mlp"][0](ln(y, a.norm2), act=ops.ACT_GELU), residual=y)

@@ -41,6 +41,16 @@ struct LinArgs {
   int mtiles, ntiles;      // small-M form only
   int M1;                  // rows of the first phase
   unsigned x_bytes, w_bytes, r_bytes, o_bytes;
+  // ---- LayerNorm folded around the GEMM (r6, pn_linear_ln_f32).  EX = 1: the input rows are LayerNorm(x) -- the caller passes the weight with
+  // gamma multiplied in, its column sums and the bias with beta folded in; the epilogue applies rstd[m] (acc - mean[m] colsum[n]) from the
+  // (sum, sum of squares) partials a producer left per row and 32-column group.  EX = 2: this launch IS such a producer: per row and
+  // 32-column group of its own output (after activation and residual) it leaves (sum, sum of squares) in stat_out [M][N / 32][2].
+  const float* ln_stat;    // EX = 1: [M][ln_parts][2]
+  const float* ln_csum;    // EX = 1: [N]
+  float* stat_out;         // EX = 2: [M][N / 32][2]
+  int ln_parts;
+  float ln_eps, ln_inv_k;
+  unsigned ls_bytes, so_bytes;
 #ifdef PN_LINEAR_STAMP
   unsigned long long* stamps;   // diagnostic build only (tools/micro/linear_stamps.hip): [block][tile < 4][8] shader-clock stamps of wave 0
 #endif
@@ -77,7 +87,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 // One PHASE of a launch: the rows [row_lo, row_hi) of the output in (64 TM) x (64 TN) tiles, persistent blocks, XCD-local tile runs.
-template <int TM, int TN, bool GELU>
+template <int TM, int TN, bool GELU, int EX>
 __device__ __forceinline__ void linear_phase(const LinArgs& a, const int row_lo, const int row_hi, float* smem) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int STAGE = BM * LA_LD;
@@ -214,6 +224,8 @@ __device__ __forceinline__ void linear_phase(const LinArgs& a, const int row_lo,
   // makes the compiler fall back to s_waitcnt vmcnt(0) -- i.e. to one store round trip per pass (measured: 21 k cycles per tile).
   const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res), 0, a.res ? a.r_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.o_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_ls = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ln_stat), 0, EX == 1 ? a.ls_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_so = __builtin_amdgcn_make_buffer_rsrc(a.stat_out, 0, EX == 2 ? a.so_bytes : 0u, 0x00020000);
   auto epilogue = [&](int em0, int en0, f32x4 bias4) {
     float* slab = smem + wv * (32 * TLD);
     constexpr int TC4 = TC / 4, NP = 32 * TC4 / 64, RPP = 64 / TC4;     // float4 per row, passes per slab, rows per pass
@@ -221,6 +233,10 @@ __device__ __forceinline__ void linear_phase(const LinArgs& a, const int row_lo,
     const int n = en0 + wn * TC + q * 4;
     const bool nok = n < a.N;
     const bool relu = a.act == PN_ACT_RELU;
+    f32x4 csum4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EX == 1) {
+      if (nok) csum4 = *reinterpret_cast<const f32x4*>(a.ln_csum + n);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -228,6 +244,22 @@ __device__ __forceinline__ void linear_phase(const LinArgs& a, const int row_lo,
 #pragma unroll
         for (int r = 0; r < 16; ++r) slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + j * 32 + li] = acc[i][j][r];
       const int mb = em0 + wm * TM * 32 + i * 32 + rrow;
+      // EX = 1: lane L finalises the LayerNorm statistics of slab row L & 31 (the partials of the row's 32-column groups, summed in
+      // group order); the passes below fetch their row's pair by lane shuffles
+      float ln_mean = 0.f, ln_rstd = 1.f;
+      if constexpr (EX == 1) {
+        const int srow = em0 + wm * TM * 32 + i * 32 + li;
+        const unsigned so = srow < row_hi ? (unsigned)srow * (unsigned)a.ln_parts * 8u : 0xffffffffu;
+        float s1 = 0.f, s2 = 0.f;
+        for (int g = 0; g < a.ln_parts; g += 2) {      // (ln_parts is even: K a multiple of 64)
+          const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_ls, so, (unsigned)g * 8u, 0));
+          s1 = (s1 + t[0]) + t[2];
+          s2 = (s2 + t[1]) + t[3];
+        }
+        ln_mean = s1 * a.ln_inv_k;
+        const float var = fmaxf(fmaf(-ln_mean, ln_mean, s2 * a.ln_inv_k), 0.f);
+        ln_rstd = 1.0f / sqrtf(var + a.ln_eps);
+      }
       // (no short-circuit: a && here becomes a divergent branch around the access)
       auto roff = [&](int p) { const bool ok = nok & (mb + p * RPP < row_hi); return ok ? ((unsigned)(mb + p * RPP) * (unsigned)a.ldr + (unsigned)n) * 4u : 0xffffffffu; };
       auto ooff = [&](int p) { const bool ok = nok & (mb + p * RPP < row_hi); return ok ? ((unsigned)(mb + p * RPP) * (unsigned)a.ldo + (unsigned)n) * 4u : 0xffffffffu; };
@@ -236,7 +268,13 @@ __device__ __forceinline__ void linear_phase(const LinArgs& a, const int row_lo,
       for (int p = 0; p < NP; ++p) {
         f32x4 rnext = {0.f, 0.f, 0.f, 0.f};
         if (p + 1 < NP) rnext = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, roff(p + 1), 0, 0));
-        f32x4 v = *reinterpret_cast<const f32x4*>(slab + (p * RPP + rrow) * TLD + q * 4) + bias4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(slab + (p * RPP + rrow) * TLD + q * 4);
+        if constexpr (EX == 1) {
+          const float mu = __shfl(ln_mean, p * RPP + rrow, 64), rs = __shfl(ln_rstd, p * RPP + rrow, 64);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(-mu, csum4[e], v[e]) * rs;
+        }
+        v += bias4;
         if constexpr (GELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);      // (a vector-wide v_pk_fma form of the polynomial measured the same)
@@ -246,6 +284,19 @@ __device__ __forceinline__ void linear_phase(const LinArgs& a, const int row_lo,
         }
         v += rcur;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsrc_o, ooff(p), 0, 0);
+        if constexpr (EX == 2) {
+          // (sum, sum of squares) of this row's 32-column group: the group's eight lanes, folded by a fixed xor butterfly
+          float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+          float s2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+#pragma unroll
+          for (int o = 1; o < 8; o <<= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+          }
+          const bool ok = nok & (mb + p * RPP < row_hi) & ((q & 7) == 0);
+          const unsigned off = ok ? ((unsigned)(mb + p * RPP) * (unsigned)(a.N >> 5) + (unsigned)(n >> 5)) * 8u : 0xffffffffu;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, float2{s1, s2}), rsrc_so, off, 0, 0);
+        }
         rcur = rnext;
       }
     }
@@ -300,14 +351,14 @@ __device__ __forceinline__ void linear_phase(const LinArgs& a, const int row_lo,
 // A launch = the rows [0, M1) in (64 TM) x (64 TN) tiles -- a whole number of rounds of the persistent grid -- and, when the row count
 // does not divide that way, the REST [M1, M) in smaller (64 TM2) x (64 TN2) tiles, so that the last round is not a handful of big
 // tiles on an otherwise idle chip (73 728 x 256: 1152 big tiles on 512 slots were three rounds for 2.25 rounds of work).
-template <int TM, int TN, int TM2, int TN2, int OCC, bool GELU>
+template <int TM, int TN, int TM2, int TN2, int OCC, bool GELU, int EX>
 __global__ __launch_bounds__(256, OCC) void linear_kernel(LinArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  linear_phase<TM, TN, GELU>(a, 0, a.M1, smem);
+  linear_phase<TM, TN, GELU, EX>(a, 0, a.M1, smem);
   if constexpr (TM2 > 0) {
     if (a.M1 < a.M) {
       __syncthreads();      // the first phase's last epilogue slabs are read back before the stages are refilled
-      linear_phase<TM2, TN2, GELU>(a, a.M1, a.M, smem);
+      linear_phase<TM2, TN2, GELU, EX>(a, a.M1, a.M, smem);
     }
   }
 }
@@ -421,7 +472,7 @@ __global__ void pack_linear_weight_kernel(const float* __restrict__ w, int n, in
   }
 }
 
-template <int TM, int TN, int TM2, int TN2, bool GELU>
+template <int TM, int TN, int TM2, int TN2, bool GELU, int EX>
 int launch_linear_t(const LinArgs& a, int ncu, hipStream_t st, const pn::ProfileSlot* ps, int blocks_per_cu) {
   constexpr int OCC = 2;
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -429,19 +480,24 @@ int launch_linear_t(const LinArgs& a, int ncu, hipStream_t st, const pn::Profile
   const size_t smem = std::max(floats(TM, TN), TM2 > 0 ? floats(TM2, TN2) : (size_t)0) * sizeof(float);
   static bool done[64] = {false};
   if (pn::first_use_on_device(done))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<TM, TN, TM2, TN2, OCC, GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<TM, TN, TM2, TN2, OCC, GELU, EX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   long long tiles = (long long)pn::cdiv(a.M1, BM) * pn::cdiv(a.N, BN);
   if (TM2 > 0 && a.M1 < a.M) tiles = std::max(tiles, (long long)pn::cdiv(a.M - a.M1, 64 * std::max(TM2, 1)) * pn::cdiv(a.N, 64 * std::max(TN2, 1)));
   const dim3 grid((unsigned)std::min<long long>((long long)blocks_per_cu * ncu, (tiles + 7) / 8 * 8));
-  if (ps) hipExtLaunchKernelGGL((linear_kernel<TM, TN, TM2, TN2, OCC, GELU>), grid, dim3(256), smem, st, ps->start, ps->stop, 0, a);
-  else hipLaunchKernelGGL((linear_kernel<TM, TN, TM2, TN2, OCC, GELU>), grid, dim3(256), smem, st, a);
+  if (ps) hipExtLaunchKernelGGL((linear_kernel<TM, TN, TM2, TN2, OCC, GELU, EX>), grid, dim3(256), smem, st, ps->start, ps->stop, 0, a);
+  else hipLaunchKernelGGL((linear_kernel<TM, TN, TM2, TN2, OCC, GELU, EX>), grid, dim3(256), smem, st, a);
   return pn::check_launch("linear_kernel");
 }
 
+// the combinations the callers use: plain (any activation), LayerNorm-in (none / GELU), statistics-out (no activation)
 template <int TM, int TN, int TM2, int TN2>
 int launch_linear(const LinArgs& a, int ncu, hipStream_t st, const pn::ProfileSlot* ps, int blocks_per_cu = 2) {
-  return a.act == PN_ACT_GELU ? launch_linear_t<TM, TN, TM2, TN2, true>(a, ncu, st, ps, blocks_per_cu)
-                              : launch_linear_t<TM, TN, TM2, TN2, false>(a, ncu, st, ps, blocks_per_cu);
+  if (a.ln_stat)
+    return a.act == PN_ACT_GELU ? launch_linear_t<TM, TN, TM2, TN2, true, 1>(a, ncu, st, ps, blocks_per_cu)
+                                : launch_linear_t<TM, TN, TM2, TN2, false, 1>(a, ncu, st, ps, blocks_per_cu);
+  if (a.stat_out) return launch_linear_t<TM, TN, TM2, TN2, false, 2>(a, ncu, st, ps, blocks_per_cu);
+  return a.act == PN_ACT_GELU ? launch_linear_t<TM, TN, TM2, TN2, true, 0>(a, ncu, st, ps, blocks_per_cu)
+                              : launch_linear_t<TM, TN, TM2, TN2, false, 0>(a, ncu, st, ps, blocks_per_cu);
 }
 
 }  // namespace
@@ -516,8 +572,14 @@ int pn_linear_set_tile(int form) {
 
 enum { LIN_TILED = 0, LIN_KSPLIT = 1 };
 static int linear_launch(const float* x, int m, int k, int ldx, const float* packed_w, int n, const float* bias, int act, const float* residual, int ldr,
-                         float* out, int ldo, pn_stream_t stream, int mode) {
+                         float* out, int ldo, pn_stream_t stream, int mode, const float* ln_stats = nullptr, const float* ln_colsum = nullptr,
+                         float ln_eps = 0.f, float* row_stats_out = nullptr) {
   const bool ksplit = mode == LIN_KSPLIT;
+  PN_REQUIRE(!(ln_stats && row_stats_out), "linear_ln: a launch either consumes row statistics or produces them");
+  PN_REQUIRE(!ln_stats || (ln_colsum && k % 64 == 0 && ((uintptr_t)ln_stats & 15) == 0 && ((uintptr_t)ln_colsum & 15) == 0 && !ksplit),
+             "linear_ln: LayerNorm-in needs the column sums, k a multiple of 64 and 16-byte aligned tables");
+  PN_REQUIRE(!row_stats_out || (n % 32 == 0 && act != PN_ACT_GELU && ((uintptr_t)row_stats_out & 7) == 0 && !ksplit),
+             "linear_ln: statistics-out needs n a multiple of 32 and no GELU");
   PN_REQUIRE(x && packed_w && out && m > 0 && k > 0 && n > 0, "linear: bad arguments");
   PN_REQUIRE(k % 4 == 0 && ldx % 4 == 0 && ldx >= k && ldo >= n, "linear: k and the row strides must be multiples of 4");
   PN_REQUIRE(n % 4 == 0 && ldo % 4 == 0 && (residual == nullptr || (ldr >= n && ldr % 4 == 0)), "linear: n and the output / residual strides must be multiples of 4");
@@ -539,6 +601,13 @@ static int linear_launch(const float* x, int m, int k, int ldx, const float* pac
   a.stamps = pn_linear_stamp_buffer;
 #endif
   a.w_bytes = (unsigned)(pn_linear_packed_weight_floats(n, k) * 4);
+  a.ln_stat = ln_stats; a.ln_csum = ln_colsum; a.stat_out = row_stats_out;
+  a.ln_parts = k / 32; a.ln_eps = ln_eps; a.ln_inv_k = 1.0f / (float)k;
+  {
+    const unsigned long long lsb = ln_stats ? (unsigned long long)m * (k / 32) * 8ull : 0ull, sob = row_stats_out ? (unsigned long long)m * (n / 32) * 8ull : 0ull;
+    PN_REQUIRE(lsb < (1ull << 32) && sob < (1ull << 32), "linear_ln: statistics tables of 4 GiB or more");
+    a.ls_bytes = (unsigned)lsb; a.so_bytes = (unsigned)sob;
+  }
   static int cus[64] = {0};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -555,6 +624,7 @@ static int linear_launch(const float* x, int m, int k, int ldx, const float* pac
   // and ran a tiled form -- one call with the other summation order, enough to flip key points in the first frame of a process)
   const LinPlan plan = (ksplit && !linear_tile_pin()) ? LinPlan{1, 0, m} : linear_plan(m, n, k, ncu);
   a.M1 = plan.m1;
+  PN_REQUIRE(plan.form != 1 || (!ln_stats && !row_stats_out), "linear_ln: not with the pinned K-split form");
   if (plan.form == 1) {
     a.mtiles = pn::cdiv(m, 32);
     a.ntiles = pn::cdiv(n, 32);
@@ -592,6 +662,11 @@ int pn_linear_f32(const float* x, int m, int k, int ldx, const float* packed_w, 
 int pn_linear_ksplit_f32(const float* x, int m, int k, int ldx, const float* packed_w, int n, const float* bias, int act, const float* residual,
                          int ldr, float* out, int ldo, pn_stream_t stream) {
   return linear_launch(x, m, k, ldx, packed_w, n, bias, act, residual, ldr, out, ldo, stream, LIN_KSPLIT);
+}
+
+int pn_linear_ln_f32(const float* x, int m, int k, int ldx, const float* packed_w, int n, const float* bias, int act, const float* residual, int ldr,
+                     float* out, int ldo, const float* ln_stats, const float* ln_colsum, float ln_eps, float* row_stats_out, pn_stream_t stream) {
+  return linear_launch(x, m, k, ldx, packed_w, n, bias, act, residual, ldr, out, ldo, stream, LIN_TILED, ln_stats, ln_colsum, ln_eps, row_stats_out);
 }
 
 }  // extern "C"

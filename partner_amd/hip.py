@@ -212,6 +212,7 @@ SIGNATURES = {
     "pn_linear_set_tile": (_I, [_I]),
     "pn_linear_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),
     "pn_linear_ksplit_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),
+    "pn_linear_ln_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _F, _P, _P]),
     "pn_conv_wino_packed_weight_floats": (_SZ, [_I, _I]),
     "pn_pack_conv_weight_wino_f32": (_I, [_P, _I, _I, _P, _P]),
     "pn_pack_conv_dgrad_weight_wino_f32": (_I, [_P, _I, _I, _P, _P]),

@@ -1147,6 +1147,7 @@ ACT_GELU = hip.ACT_GELU
 
 
 _LINEAR_ON = os.environ.get("PN_LINEAR", "1") != "0"     # 0: the r2 route (1x1 convolution on conv_mfma_kernel)
+_LN_FOLD_ON = os.environ.get("PN_LN_FOLD", "1") != "0"   # 0: every LayerNorm in front of a token GEMM as its own pass (r3 - r5)
 
 
 class GemmLayer:
@@ -1170,9 +1171,33 @@ class GemmLayer:
             hip.call("pn_pack_conv_weight_f32", w.data_ptr(), self.n, self.k, 1, 1, 1, self.packed.data_ptr(), hip.stream())
         self.bias = None if bias is None else bias.detach().contiguous().float()
         self._w_f32 = w                  # source of the bf16 pack (made on the first bf16 call)
+        self.ln = None
+
+    @property
+    def stats_ok(self) -> bool:
+        """can this layer leave the row statistics a LayerNorm-folding consumer needs (``__call__(..., stats_out=True)``)?"""
+        return self.linear and self.entry == "pn_linear_f32" and self.n % 32 == 0 and _LN_FOLD_ON
+
+    def fold_layernorm(self, norm) -> bool:
+        """Fold ``norm`` (an nn.LayerNorm over this layer's k inputs) into the layer: LayerNorm(x) W^T + b = rstd (x (W gamma)^T - mean colsum)
+        + (b + W beta).  After this ``__call__(x, ln_stats=table)`` takes the UN-normalised rows and the statistics table their producer left
+        (pn_linear_ln_f32); plain calls keep the plain weights.  False (nothing changed) where the fold does not apply."""
+        if not (self.linear and self.entry == "pn_linear_f32" and self.k % 64 == 0 and _LN_FOLD_ON):
+            return False
+        lib = hip.load()
+        w64 = self._w_f32.double()
+        g, b = norm.weight.detach().double().to(w64.device), norm.bias.detach().double().to(w64.device)
+        wg = (w64 * g[None, :])
+        wg32 = wg.float().contiguous()
+        packed = _f32(lib.pn_linear_packed_weight_floats(self.n, self.k), wg32.device)
+        hip.call("pn_pack_linear_weight_f32", wg32.data_ptr(), self.n, self.k, packed.data_ptr(), hip.stream())
+        b0 = self.bias.double() if self.bias is not None else torch.zeros(self.n, dtype=torch.float64, device=w64.device)
+        # colsum over the ROUNDED folded weights: what the MFMA multiplies, so mean * colsum cancels the accumulated mean term exactly in exact arithmetic
+        self.ln = dict(packed=packed, colsum=wg32.double().sum(1).float().contiguous(), bias=(b0 + w64 @ b).float().contiguous(), eps=float(norm.eps))
+        return True
 
     def __call__(self, x: torch.Tensor, act=ACT_NONE, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                 out_bf16: bool = False) -> torch.Tensor:
+                 out_bf16: bool = False, ln_stats: Optional[torch.Tensor] = None, stats_out: bool = False):
         """x: (m, k) f32 -- or bf16: the layer then runs on the bf16 matrix pipe (pn_linear_bf16, csrc/conv_bf16.hip; weights packed as bf16
         on first use, f32 accumulation, bias / activation / residual in f32) and returns f32, or bf16 with ``out_bf16`` (the input of
         another bf16 layer)"""
@@ -1200,11 +1225,26 @@ class GemmLayer:
             out = torch.empty((m, self.n), dtype=torch.float32, device=x.device)
         if prof is not None:
             ev = prof.begin(st)
-        hip.call(self.entry, x.data_ptr(), m, self.k, self.k, self.packed.data_ptr(), self.n,
-                 hip.ptr(self.bias), int(act), hip.ptr(residual), self.n, out.data_ptr(), self.n, st)
+        stats = None
+        if ln_stats is not None or stats_out:
+            # LayerNorm folded around the GEMM (pn_linear_ln_f32): consumer of a statistics table (``ln_stats``: x is the UN-normalised rows;
+            # needs fold_layernorm) or producer of one (``stats_out``: -> (out, table [m][n / 32][2]))
+            assert not (ln_stats is not None and stats_out)
+            if ln_stats is not None:
+                assert self.ln is not None and tuple(ln_stats.shape) == (m, self.k // 32, 2) and ln_stats.is_contiguous()
+                hip.call("pn_linear_ln_f32", x.data_ptr(), m, self.k, self.k, self.ln["packed"].data_ptr(), self.n, self.ln["bias"].data_ptr(), int(act),
+                         hip.ptr(residual), self.n, out.data_ptr(), self.n, ln_stats.data_ptr(), self.ln["colsum"].data_ptr(), self.ln["eps"], None, st)
+            else:
+                assert self.stats_ok
+                stats = torch.empty((m, self.n // 32, 2), dtype=torch.float32, device=x.device)
+                hip.call("pn_linear_ln_f32", x.data_ptr(), m, self.k, self.k, self.packed.data_ptr(), self.n, hip.ptr(self.bias), int(act),
+                         hip.ptr(residual), self.n, out.data_ptr(), self.n, None, None, 0.0, stats.data_ptr(), st)
+        else:
+            hip.call(self.entry, x.data_ptr(), m, self.k, self.k, self.packed.data_ptr(), self.n,
+                     hip.ptr(self.bias), int(act), hip.ptr(residual), self.n, out.data_ptr(), self.n, st)
         if prof is not None:
             prof.end(ev, 2.0 * m * self.n * self.k, st, tag=f"gemm {m}x{self.k}->{self.n}")
-        return out
+        return (out, stats) if stats_out else out
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_chan_mean=False, bf16_copy=False, f32_out=True):

@@ -18,6 +18,7 @@ set criterion with its gradients w.r.t. the head tensors (SetCriterion) -- is ``
 from __future__ import annotations
 
 import logging
+from typing import Optional
 
 import numpy as np
 import torch
@@ -210,9 +211,16 @@ class E2ESWVoteHead(nn.Module):
         for blk in L.layers[0].blocks:
             a = blk.attn
             f = lambda t: t.detach().float().contiguous()  # noqa: E731
+            qkv_g, proj_g = ops.GemmLayer(a.qkv.weight, a.qkv.bias), ops.GemmLayer(a.proj.weight, a.proj.bias)
+            fc1_g, fc2_g = ops.GemmLayer(blk.mlp.fc1.weight, blk.mlp.fc1.bias), ops.GemmLayer(blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+            # r6 (f32 path): norm2 folded into fc1 (the projection's epilogue leaves the row statistics of t + proj(.)), and norm1 folded into
+            # qkv where the block's input comes out of a GEMM that can leave them (the previous block's fc2) -- GemmLayer.fold_layernorm
+            ln2_folded = dt == "f32" and proj_g.stats_ok and fc1_g.fold_layernorm(blk.norm2)
+            ln1_folded = dt == "f32" and bool(plan["blocks"]) and plan["blocks"][-1]["fc2"].stats_ok and qkv_g.fold_layernorm(blk.norm1)
+            if ln1_folded:
+                plan["blocks"][-1]["fc2_stats"] = True
             plan["blocks"].append(dict(
-                qkv=ops.GemmLayer(a.qkv.weight, a.qkv.bias), proj=ops.GemmLayer(a.proj.weight, a.proj.bias),
-                fc1=ops.GemmLayer(blk.mlp.fc1.weight, blk.mlp.fc1.bias), fc2=ops.GemmLayer(blk.mlp.fc2.weight, blk.mlp.fc2.bias),
+                qkv=qkv_g, proj=proj_g, fc1=fc1_g, fc2=fc2_g, ln1_folded=ln1_folded, ln2_folded=ln2_folded, fc2_stats=False,
                 qkv_bias=None if a.qkv.bias is None else f(a.qkv.bias), vw1=f(a.vote_mlp[0].weight).view(16, 3), vb1=f(a.vote_mlp[0].bias),
                 vw2=f(a.vote_mlp[2].weight).view(-1, 16), vb2=f(a.vote_mlp[2].bias), rw1=f(a.rpe[0].weight).view(16, 2), rb1=f(a.rpe[0].bias),
                 rw2=f(a.rpe[2].weight).view(-1, 16), rb2=f(a.rpe[2].bias), tau=f(a.tau).view(-1), shift=blk.shift_size, mod=blk))
@@ -249,8 +257,13 @@ class E2ESWVoteHead(nn.Module):
         plan["vote_cls"][1](plan["vote_cls"][0](xc), out=vote, out_channel_offset=2)
         L = self.layer
         t = self.patch_embed_tokens(xc if (bf16 and x.shape[3] % 64 == 0) else x)
+        t_stats = None
         for i in range(len(plan["blocks"])):
-            t = self.swin_block_tokens(i, t, vote, b, h, w)
+            if plan["blocks"][i]["fc2_stats"]:      # the next block's norm1 is folded into its qkv GEMM: this block's fc2 leaves the row statistics
+                t, t_stats = self.swin_block_tokens(i, t, vote, b, h, w, t_stats=t_stats, want_stats=True)
+            else:
+                t = self.swin_block_tokens(i, t, vote, b, h, w, t_stats=t_stats)
+                t_stats = None
         feat = ops.layernorm(t, L.norm0.weight, L.norm0.bias, L.norm0.eps).view(b, h, w, C)
         fc = ops.to_bf16(feat) if bf16 else feat
         hm = plan["cls"][2](plan["cls"][1](plan["cls"][0](fc)), out_f32=True)
@@ -280,11 +293,14 @@ class E2ESWVoteHead(nn.Module):
         t = plan["patch"](x.contiguous().view(b * h * w, cin))
         return ops.layernorm(t, L.patch_embed.norm.weight, L.patch_embed.norm.bias, L.patch_embed.norm.eps)
 
-    def swin_block_tokens(self, i: int, t: torch.Tensor, vote: torch.Tensor, b: int, h: int, w: int) -> torch.Tensor:
+    def swin_block_tokens(self, i: int, t: torch.Tensor, vote: torch.Tensor, b: int, h: int, w: int, t_stats: Optional[torch.Tensor] = None,
+                          want_stats: bool = False):
         """block i of the Swin stage (SwinTransformerBlock.forward, sw2votev4_util.py:125-188) on tokens (B*H*W, C); ``vote``: the
         (B, H, W, 4) map [pred_centers | vote_cls | pad] the attention kernel reads.  Zero padding to window multiples, the cyclic
         shift, the window partition and their inverses are index arithmetic inside pn_swv_window_attn; the plumbing is pinned to
-        the reference's block by swv_fragments.npz (test_hip_swv.py::test_swin_stage_pieces_match_the_reference_fragments)."""
+        the reference's block by swv_fragments.npz (test_hip_swv.py::test_swin_stage_pieces_match_the_reference_fragments).
+        ``t_stats``: the row statistics table of ``t`` left by the GEMM that produced it (then norm1 is applied inside the qkv GEMM when the
+        plan folded it); ``want_stats``: -> (t, statistics table of the returned tokens) for the next block."""
         plan = self._plan.get(self, self._build_plan)
         bp = plan["blocks"][i]
         blk = bp["mod"]
@@ -293,9 +309,11 @@ class E2ESWVoteHead(nn.Module):
         b16 = getattr(self, "compute_dtype", "f32") == "bf16" and C % 64 == 0
         if b16:      # bf16 option: the four token GEMMs of the block on the bf16 matrix pipe; LayerNorm, the attention core, GELU, residuals in f32
             y = ops.layernorm(t, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, bf16_copy=True, f32_out=False)
+        elif t_stats is not None and bp["ln1_folded"]:
+            y = None
         else:
             y = ops.layernorm(t, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
-        qkv = bp["qkv"](y)
+        qkv = bp["qkv"](t, ln_stats=t_stats) if y is None else bp["qkv"](y)
         att = torch.empty((n, C), dtype=torch.float32, device=t.device)
         hip.call("pn_swv_window_attn", qkv.data_ptr(), vote.data_ptr(), 4, plan["pos"].data_ptr(), hip.ptr(bp["qkv_bias"]),
                  bp["vw1"].data_ptr(), bp["vb1"].data_ptr(), bp["vw2"].data_ptr(), bp["vb2"].data_ptr(), bp["rw1"].data_ptr(),
@@ -305,9 +323,15 @@ class E2ESWVoteHead(nn.Module):
             t = bp["proj"](ops.to_bf16(att), residual=t)
             z = ops.layernorm(t, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, bf16_copy=True, f32_out=False)
             return bp["fc2"](bp["fc1"](z, act=ops.ACT_GELU, out_bf16=True), residual=t)
-        t = bp["proj"](att, residual=t)
-        z = ops.layernorm(t, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-        return bp["fc2"](bp["fc1"](z, act=ops.ACT_GELU), residual=t)
+        if bp["ln2_folded"]:
+            t, st2 = bp["proj"](att, residual=t, stats_out=True)
+            hid = bp["fc1"](t, act=ops.ACT_GELU, ln_stats=st2)
+        else:
+            t = bp["proj"](att, residual=t)
+            hid = bp["fc1"](ops.layernorm(t, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), act=ops.ACT_GELU)
+        if want_stats:
+            return bp["fc2"](hid, residual=t, stats_out=True)
+        return bp["fc2"](hid, residual=t)
 
     def forward(self, x, **kwargs):
         """logical (B,C,H,W) in; {'det_preds': [dict of logical (B,c,H,W) views]} as e2e_swv_head.py:150-173"""
