@@ -136,6 +136,15 @@ int pn_voxel_index_fused_f32(const float *cart, int n_capacity, int f_in, const 
                              uint32_t *cell_count, void *scan_state, size_t scan_state_bytes,
                              uint32_t *unq_keys, int32_t *voxel_start, int32_t *order,
                              int32_t *num_voxels, pn_stream_t stream);
+/* The same index, also leaving row_start [batch * grid[2] * grid[1] + 1] (r6): the number of voxels in the grid rows (runs of grid[0]
+ * cells) before row g.  unq_keys is in key order, so the voxels of row g are the run [row_start[g], row_start[g + 1]) of it: what
+ * pn_pillar_conv3x3_rows_f32 walks (one canvas row of the pillar map per run).  Written by the scan itself; grid[0] % 8 == 0. */
+int pn_voxel_index_fused_rows_f32(const float *cart, int n_capacity, int f_in, const int32_t *sample_offsets,
+                                  int batch, const float *range_lo, const float *voxel_size,
+                                  const int32_t *grid, float *polar, uint32_t *keys, int32_t *pos,
+                                  uint32_t *cell_count, void *scan_state, size_t scan_state_bytes,
+                                  uint32_t *unq_keys, int32_t *voxel_start, int32_t *order,
+                                  int32_t *num_voxels, int32_t *row_start, pn_stream_t stream);
 /* end of frame: zero the canvas cells (nullable) and the cell_count entries (nullable) of the frame's voxels */
 int pn_clear_frame_cells(const uint32_t *unq_keys, const int32_t *num_voxels, int v_capacity,
                          const int32_t *grid, int c, float *canvas, uint32_t *cell_count,
@@ -1157,6 +1166,21 @@ int pn_pillar_conv3x3_planes_f32(const float *canvas, int batch, int h, int w, i
                                  const uint32_t *unq_keys, const int32_t *num_voxels, int v_capacity, int stride,
                                  const float *packed_w, int cout, const float *scale, const float *shift, int act, float *planes,
                                  void *workspace, size_t workspace_bytes, pn_stream_t stream);
+/* The same layer in its ROW-BAND form (r6, csrc/pillar_rows.hip; stride 2): one block per OUTPUT ROW keeps the row's Cout channels in LDS,
+ * walks the three canvas rows it reads as runs of the sorted key list (row_start of pn_voxel_index_fused_rows_f32), multiplies every pillar
+ * by the taps its column parity reaches (v_mfma_f32_16x16x4_f32 chains, canvas rows and weights straight from L2) and finishes the row from
+ * LDS -- no pair lists, no per-pair partial rows in memory (pn_pillar_conv3x3_f32 moves 64 MB of them per frame), one launch instead of four.
+ * Same terms as the dense convolution, fixed summation order (bitwise reproducible), not the bits of pn_pillar_conv3x3_f32.
+ *   packed_rows_w: pn_pack_pillar_conv_rows_weight_f32 ([tap][cin / 16][cout padded to 16][4][4] floats)
+ *   planes and / or out: the F(4, 3) planes (pn_wino4_planes_floats(batch, oh, ow, cout) floats, not transposed) and / or the NHWC map
+ *   pn_pillar_conv_rows_supported: stride 2, w % 8 == 0, w <= 512, ow / 4 in {16, 32, 64}, cin in {32, 64, 128}, cout <= 128, cout % 4 == 0 */
+int pn_pillar_conv_rows_supported(int batch, int h, int w, int cin, int cout, int stride);
+size_t pn_pillar_conv_rows_packed_weight_floats(int cout, int cin);
+int pn_pack_pillar_conv_rows_weight_f32(const float *w_oihw, int cout, int cin, float *packed, pn_stream_t stream);
+int pn_pillar_conv3x3_rows_f32(const float *canvas, int batch, int h, int w, int cin, int in_pixel_stride, int in_channel_offset,
+                               const uint32_t *unq_keys, const int32_t *row_start, int v_capacity, const float *packed_rows_w, int cout,
+                               const float *scale, const float *shift, int act, float *planes, float *out, int out_pixel_stride,
+                               int out_channel_offset, pn_stream_t stream);
 /* The same convolution in TRAINING: the pair tables are built once per iteration (pn_pillar_pairs_build; pn_pillar_pairs_bytes of
  * caller-owned memory that lives from the forward to the backward) and shared by
  *   forward          pn_pillar_conv3x3_tables_f32        (oh, ow = the output map; workspace 9 * cap * cout floats, cap = v_capacity

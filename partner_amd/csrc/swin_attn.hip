@@ -29,6 +29,9 @@ struct SwvParams {
 };
 
 constexpr int WS = 7, NT = WS * WS, HD = 64;
+#ifndef PN_SWV_EXP
+#define PN_SWV_EXP 0   // diagnostic builds only: 1 no q/k/v loads, 2 no bias-table loads, 4 cheap logits (no division / exp), 8 no vote-embedding MFMAs
+#endif
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -120,13 +123,13 @@ __global__ __launch_bounds__(256) void swv_window_attn_kernel(const float* __res
     for (int ct = 0; ct < 2; ++ct) {
       f32x16 ve = zero16;                // ve^T tile: rows = channels of tile ct, columns = tokens of tile tt
 #pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) ve = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[ct][s8], vhf[tt][s8], ve, 0, 0, 0);
+      for (int s8 = 0; s8 < ((PN_SWV_EXP & 8) ? 0 : 8); ++s8) ve = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[ct][s8], vhf[tt][s8], ve, 0, 0, 0);
       f32x16 q, k;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int ch = ct * 32 + 8 * g + 4 * lh;
         f32x4 qv = {0.f, 0.f, 0.f, 0.f}, kv = {0.f, 0.f, 0.f, 0.f};
-        if (tk >= 0) {
+        if (tk >= 0 && !(PN_SWV_EXP & 1)) {
           qv = *reinterpret_cast<const f32x4*>(row + ch);
           kv = *reinterpret_cast<const f32x4*>(row + C + ch);
         }
@@ -162,14 +165,14 @@ __global__ __launch_bounds__(256) void swv_window_attn_kernel(const float* __res
     for (int ct = 0; ct < 2; ++ct) {
       f32x16 ve = zero16;                // ve tile: rows = tokens of tile tj, columns = channels of tile ct
 #pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) ve = __builtin_amdgcn_mfma_f32_32x32x2f32(vhf[tj][s8], w2f[ct][s8], ve, 0, 0, 0);
+      for (int s8 = 0; s8 < ((PN_SWV_EXP & 8) ? 0 : 8); ++s8) ve = __builtin_amdgcn_mfma_f32_32x32x2f32(vhf[tj][s8], w2f[ct][s8], ve, 0, 0, 0);
       const int ch = hc + ct * 32 + li;
       const float b2 = P.vm_b2[ch], bv = P.qkv_bias ? P.qkv_bias[2 * C + ch] : 0.f;
       f32x16 v;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int tk = tok[tj * 32 + rowmap(r, lh)];
-        const float x = tk >= 0 ? qkv[(size_t)tk * 3 * C + 2 * C + ch] : bv;
+        const float x = (tk >= 0 && !(PN_SWV_EXP & 1)) ? qkv[(size_t)tk * 3 * C + 2 * C + ch] : bv;
         v[r] = x + ve[r] + b2;
       }
       vreg[tj][ct] = v;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void swv_window_attn_kernel(const float* __res
     float rpt[kBiasRegs];        // TAB: this query tile's biases, requested before the products
     if constexpr (TAB) {
 #pragma unroll
-      for (int k = 0; k < kBiasRegs; ++k) rpt[k] = tab[(ti * kBiasRegs + k) * 64];
+      for (int k = 0; k < kBiasRegs; ++k) rpt[k] = (PN_SWV_EXP & 2) ? 0.01f * k : tab[(ti * kBiasRegs + k) * 64];
     }
     f32x16 st[2] = {zero16, zero16};
 #pragma unroll
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256) void swv_window_attn_kernel(const float* __res
         const int j = tj * 32 + rowmap(r, lh);
         if (tj == 1 && (r >> 2) > 2) { st[tj][r] = -3.0e38f; continue; }     // keys >= 56: MFMA padding (compile-time skip)
         const f32x4 oj = *reinterpret_cast<const f32x4*>(tinfo[j]);
-        float a = st[tj][r] / fmaxf(nqi * nkw[head][j], 1e-6f) * inv_tau;
+        float a = (PN_SWV_EXP & 4) ? st[tj][r] * inv_tau : st[tj][r] / fmaxf(nqi * nkw[head][j], 1e-6f) * inv_tau;
         float rp = rb2;
         if constexpr (TAB) {
           rp = rpt[tj * 16 + r];
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void swv_window_attn_kernel(const float* __res
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = (tj == 1 && (r >> 2) > 2) ? 0.f : expf(st[tj][r] - smax);
+        const float e = (tj == 1 && (r >> 2) > 2) ? 0.f : ((PN_SWV_EXP & 4) ? st[tj][r] - smax : expf(st[tj][r] - smax));
         st[tj][r] = e;
         sum += e;
       }

@@ -269,7 +269,7 @@ __device__ __forceinline__ unsigned long long pack_state(unsigned status, uint32
 __global__ __launch_bounds__(kScanThreads) void cell_scan_kernel(uint32_t* __restrict__ cell_count, size_t ncells, int ntiles,
                                                                  unsigned long long* __restrict__ tile_state, uint32_t* __restrict__ counters,
                                                                  uint32_t* __restrict__ unq_keys, int32_t* __restrict__ voxel_start,
-                                                                 int32_t* __restrict__ num_voxels, int v_cap) {
+                                                                 int32_t* __restrict__ num_voxels, int v_cap, int32_t* __restrict__ row_start, int row_cells) {
   __shared__ uint32_t s_tile, s_pre_nz, s_pre_pts;
   const int tid = threadIdx.x;
   if (tid == 0) s_tile = __hip_atomic_fetch_add(&counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tiles in start order
@@ -321,11 +321,15 @@ __global__ __launch_bounds__(kScanThreads) void cell_scan_kernel(uint32_t* __res
         const uint32_t V = min(pre_nz + tot_nz, (uint32_t)v_cap);
         *num_voxels = (int32_t)V;
         voxel_start[V] = (int32_t)(pre_pts + tot_pts);
+        if (row_start) row_start[ncells / (size_t)row_cells] = (int32_t)V;
       }
     }
   }
   __syncthreads();
   uint32_t rank = s_pre_nz + ex_nz, start = s_pre_pts + ex_pts;
+  // r6: the voxels are emitted in key order, i.e. grid row by grid row (a row = row_cells consecutive cells, a multiple of a thread's
+  // kScanItems): row_start[g] = number of voxels in rows before g -- the row runs of unq_keys that pillar_rows.hip walks, for free
+  if (row_start && base < ncells && base % (size_t)row_cells == 0) row_start[base / (size_t)row_cells] = (int32_t)min(rank, (uint32_t)v_cap);
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     if (c[k] != 0u) {
@@ -606,10 +610,10 @@ size_t pn_voxel_index_fused_state_bytes(uint64_t num_cells) {
   return align256(ntiles * 8) + 256;
 }
 
-int pn_voxel_index_fused_f32(const float* cart, int n_capacity, int f_in, const int32_t* sample_offsets, int batch, const float* range_lo,
+static int voxel_index_fused(const float* cart, int n_capacity, int f_in, const int32_t* sample_offsets, int batch, const float* range_lo,
                              const float* voxel_size, const int32_t* grid, float* polar, uint32_t* keys, int32_t* pos, uint32_t* cell_count,
                              void* scan_state, size_t scan_state_bytes, uint32_t* unq_keys, int32_t* voxel_start, int32_t* order,
-                             int32_t* num_voxels, pn_stream_t stream) {
+                             int32_t* num_voxels, int32_t* row_start, pn_stream_t stream) {
   PN_REQUIRE(sample_offsets && range_lo && voxel_size && grid && keys && pos && cell_count && scan_state && unq_keys && voxel_start && order &&
                  num_voxels && (n_capacity == 0 || (cart && polar)), "voxel_index_fused: null pointer");
   PN_REQUIRE(f_in >= 3 && n_capacity >= 0 && batch >= 1, "voxel_index_fused: bad sizes");
@@ -631,11 +635,31 @@ int pn_voxel_index_fused_f32(const float* cart, int n_capacity, int f_in, const 
   if (n_capacity > 0)
     hipLaunchKernelGGL(fused_polar_index_kernel, dim3(pblocks), dim3(256), 0, st, cart, n_capacity, f_in, sample_offsets, batch, gp, polar, keys,
                        pos, cell_count);
+  PN_REQUIRE(!row_start || grid[0] % kScanItems == 0, "voxel_index_fused_rows: the grid's first axis must be a multiple of 8 cells");
   hipLaunchKernelGGL(cell_scan_kernel, dim3(ntiles), dim3(kScanThreads), 0, st, cell_count, (size_t)cells, ntiles, tile_state, counters, unq_keys,
-                     voxel_start, num_voxels, n_capacity);
+                     voxel_start, num_voxels, n_capacity, row_start, grid[0]);
   if (n_capacity > 0)
     hipLaunchKernelGGL(order_fill_kernel, dim3(pblocks), dim3(256), 0, st, keys, pos, n_capacity, sample_offsets + batch, cell_count, order);
   return pn::check_launch("voxel_index_fused");
+}
+
+int pn_voxel_index_fused_f32(const float* cart, int n_capacity, int f_in, const int32_t* sample_offsets, int batch, const float* range_lo,
+                             const float* voxel_size, const int32_t* grid, float* polar, uint32_t* keys, int32_t* pos, uint32_t* cell_count,
+                             void* scan_state, size_t scan_state_bytes, uint32_t* unq_keys, int32_t* voxel_start, int32_t* order,
+                             int32_t* num_voxels, pn_stream_t stream) {
+  return voxel_index_fused(cart, n_capacity, f_in, sample_offsets, batch, range_lo, voxel_size, grid, polar, keys, pos, cell_count, scan_state,
+                           scan_state_bytes, unq_keys, voxel_start, order, num_voxels, nullptr, stream);
+}
+
+// the same, also leaving row_start [batch * grid[2] * grid[1] + 1]: the number of voxels in the grid rows (runs of grid[0] cells) before row g --
+// unq_keys is sorted by key, so a row's voxels are the run [row_start[g], row_start[g + 1]).  grid[0] % 8 == 0.
+int pn_voxel_index_fused_rows_f32(const float* cart, int n_capacity, int f_in, const int32_t* sample_offsets, int batch, const float* range_lo,
+                                  const float* voxel_size, const int32_t* grid, float* polar, uint32_t* keys, int32_t* pos, uint32_t* cell_count,
+                                  void* scan_state, size_t scan_state_bytes, uint32_t* unq_keys, int32_t* voxel_start, int32_t* order,
+                                  int32_t* num_voxels, int32_t* row_start, pn_stream_t stream) {
+  PN_REQUIRE(row_start, "voxel_index_fused_rows: null pointer");
+  return voxel_index_fused(cart, n_capacity, f_in, sample_offsets, batch, range_lo, voxel_size, grid, polar, keys, pos, cell_count, scan_state,
+                           scan_state_bytes, unq_keys, voxel_start, order, num_voxels, row_start, stream);
 }
 
 int pn_clear_frame_cells(const uint32_t* unq_keys, const int32_t* num_voxels, int v_capacity, const int32_t* grid, int c, float* canvas,

@@ -81,6 +81,7 @@ SIGNATURES = {
     "pn_bucket_points": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "pn_voxel_index_fused_state_bytes": (_SZ, [_U64]),
     "pn_voxel_index_fused_f32": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _P, _P]),
+    "pn_voxel_index_fused_rows_f32": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _P, _P, _P]),
     "pn_clear_frame_cells": (_I, [_P, _P, _I, _P, _I, _P, _P, _P]),
     "pn_sort_voxel_runs": (_I, [_P, _P, _I, _P, _P, _P]),
     "pn_hard_voxelize_workspace_bytes": (_SZ, [_U64, _I, _I]),
@@ -247,6 +248,10 @@ SIGNATURES = {
     "pn_pillar_conv_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "pn_pillar_conv3x3_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _SZ, _P]),
     "pn_pillar_conv_planes_supported": (_I, [_I, _I, _I, _I]),
+    "pn_pillar_conv_rows_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "pn_pillar_conv_rows_packed_weight_floats": (_SZ, [_I, _I]),
+    "pn_pack_pillar_conv_rows_weight_f32": (_I, [_P, _I, _I, _P, _P]),
+    "pn_pillar_conv3x3_rows_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P]),
     "pn_pillar_conv3x3_planes_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _SZ, _P]),
     "pn_pillar_pairs_bytes": (_SZ, [_I, _I, _I, _I]),
     "pn_pillar_pairs_build": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),

@@ -190,6 +190,9 @@ class FrameIndexState:
         return spec.num_cells(batch) <= FrameIndexState.MAX_CELLS
 
 
+_PILLAR_ROWS_ON = os.environ.get("PN_PILLAR_ROWS", "1") != "0"      # 0: the first convolution on (pillar, tap) pair lists (r2 - r5) everywhere
+
+
 def fused_voxel_index(cart: torch.Tensor, sample_offsets: torch.Tensor, batch: int, spec: GridSpec, state: Optional[FrameIndexState] = None):
     """cart (N, F>=3) Cartesian points -> (polar (N, F+2), VoxelIndex) in three launches (V0 + V1 + unique + bucketing).
     ``state``: persistent zeroed scratch (see FrameIndexState); without it a fresh zero-filled one is used (two extra fills)."""
@@ -209,11 +212,20 @@ def fused_voxel_index(cart: torch.Tensor, sample_offsets: torch.Tensor, batch: i
     order = torch.empty((max(n, 1),), **i32)
     nv = torch.empty((1,), **i32)
     lo, vs, g = spec.c_arrays()
-    hip.call("pn_voxel_index_fused_f32", cart.data_ptr(), n, f, sample_offsets.data_ptr(), batch, lo, vs, g, polar.data_ptr(), keys.data_ptr(),
-             pos.data_ptr(), state.cell_count.data_ptr(), state.scan_state.data_ptr(), state.scan_state.numel(), ukeys.data_ptr(), vstart.data_ptr(),
-             order.data_ptr(), nv.data_ptr(), hip.stream())
+    # r6: a pillar grid (one cell along z) whose rows are whole groups of eight cells also gets row_start -- the runs of unq_keys per canvas row
+    # that the row-band first convolution walks (PillarConvLayer, csrc/pillar_rows.hip); the scan writes it on the way
+    row_start = None
+    if spec.grid[2] == 1 and spec.grid[0] % 8 == 0 and _PILLAR_ROWS_ON:
+        row_start = torch.empty((batch * spec.grid[1] + 1,), **i32)
+        hip.call("pn_voxel_index_fused_rows_f32", cart.data_ptr(), n, f, sample_offsets.data_ptr(), batch, lo, vs, g, polar.data_ptr(), keys.data_ptr(),
+                 pos.data_ptr(), state.cell_count.data_ptr(), state.scan_state.data_ptr(), state.scan_state.numel(), ukeys.data_ptr(), vstart.data_ptr(),
+                 order.data_ptr(), nv.data_ptr(), row_start.data_ptr(), hip.stream())
+    else:
+        hip.call("pn_voxel_index_fused_f32", cart.data_ptr(), n, f, sample_offsets.data_ptr(), batch, lo, vs, g, polar.data_ptr(), keys.data_ptr(),
+                 pos.data_ptr(), state.cell_count.data_ptr(), state.scan_state.data_ptr(), state.scan_state.numel(), ukeys.data_ptr(), vstart.data_ptr(),
+                 order.data_ptr(), nv.data_ptr(), hip.stream())
     vi = VoxelIndex(n, state.cells, spec, batch, None, None, None, nv, vstart, order, ukeys, ukeys.data_ptr())
-    vi.keys, vi.state = keys, state
+    vi.keys, vi.state, vi.row_start = keys, state, row_start
     return polar, vi
 
 
@@ -861,6 +873,15 @@ class PillarConvLayer:
         hip.call("pn_pack_pillar_conv_weight_f32", w.data_ptr(), self.cout, self.cin, self.packed.data_ptr(), hip.stream())
         self.scale = None if scale is None else scale.detach().contiguous().float()
         self.shift = None if shift is None else shift.detach().contiguous().float()
+        self.packed_rows = None
+        if self.stride == 2 and self.cin % 16 == 0 and self.cout <= 128:      # the row-band form (csrc/pillar_rows.hip) where the frame index leaves row_start
+            self.packed_rows = _f32(lib.pn_pillar_conv_rows_packed_weight_floats(self.cout, self.cin), w.device)
+            hip.call("pn_pack_pillar_conv_rows_weight_f32", w.data_ptr(), self.cout, self.cin, self.packed_rows.data_ptr(), hip.stream())
+
+    def rows_form(self, vi: "VoxelIndex", b: int, h: int, w: int) -> bool:
+        """does this frame take the row-band kernel?  (the fused frame index left row_start and the shape is covered)"""
+        return (self.packed_rows is not None and getattr(vi, "row_start", None) is not None and _PILLAR_ROWS_ON
+                and bool(hip.load().pn_pillar_conv_rows_supported(b, h, w, self.cin, self.cout, self.stride)))
 
     @staticmethod
     def supports(conv_weight: torch.Tensor, stride: int, groups: int) -> bool:
@@ -887,6 +908,27 @@ class PillarConvLayer:
         oh, ow = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
         if out is None and planes is None:
             out = torch.empty((b, oh, ow, self.cout), dtype=torch.float32, device=canvas.device)
+        if self.rows_form(vi, b, h, w):
+            st = hip.stream()
+            prof = _PROFILER
+            if prof is not None:
+                ev = prof.begin(st)
+            if planes is not None:
+                assert planes.numel() >= lib.pn_wino4_planes_floats(b, oh, ow, self.cout)
+            hip.call("pn_pillar_conv3x3_rows_f32", canvas.data_ptr(), b, h, w, self.cin, ct, 0, vi.unq_keys_ptr, vi.row_start.data_ptr(), vi.n_cap,
+                     self.packed_rows.data_ptr(), self.cout, hip.ptr(self.scale), hip.ptr(self.shift), self.act, hip.ptr(planes),
+                     None if planes is not None else out.data_ptr(), 0 if planes is not None else out.shape[3], 0, st)
+            if prof is not None:
+                # FLOPs actually multiplied: the frame's (pillar, tap) pairs, counted on the host from the key list (profiling runs only)
+                v = vi.count()
+                k = vi.workspace[:v].to(torch.int64) & 0xffffffff
+                ix, iy = k % w, (k // w) % h
+                tx = torch.where(ix % 2 == 0, 1, 1 + ((ix + 1) // 2 < ow).long())
+                ty = torch.where(iy % 2 == 0, 1, 1 + ((iy + 1) // 2 < oh).long())
+                pairs = int((tx * ty).sum())
+                prof.end(ev, 2.0 * pairs * self.cout * self.cin, st, tag=f"{oh}x{ow} {self.cin}->{self.cout} k3 pillars (row bands)",
+                         dense=2.0 * b * oh * ow * 9 * self.cout * self.cin)
+            return out
         nbytes = lib.pn_pillar_conv_workspace_bytes(vi.n_cap, b, oh, ow, self.cout)
         ws = _workspace(nbytes, canvas.device)
         st = hip.stream()

@@ -246,6 +246,51 @@ def test_pillar_conv_matches_dense_convolution(dev, case):
     assert torch.equal(layer(canvas, vi), y)                                # fixed summation order: bitwise reproducible
 
 
+@pytest.mark.parametrize("case", [(1, 64, 128, 32, 64, 700), (2, 33, 256, 64, 36, 2500), (1, 512, 512, 128, 128, 30000), (2, 40, 128, 128, 128, 40000),
+                                  (1, 7, 128, 128, 8, 3), (4, 512, 512, 128, 128, 90000)], ids=str)
+def test_pillar_conv_row_band_form_matches_dense_convolution(dev, case):
+    """r6, csrc/pillar_rows.hip: one block per OUTPUT ROW walks the three canvas rows it reads as runs of the sorted key list (row_start) and
+    keeps the row in LDS -- against float64 and against the pair form, NHWC and planes outputs: odd heights, batch > 1, ragged channel
+    counts, a canvas wider than Cin, a nearly full map (lists longer than one tile), a nearly empty one (rows without pillars), the
+    nuScenes frame's own shape; bitwise reproducible; the planes are the planes of the NHWC map bit for bit."""
+    from partner_amd import hip, ops
+    lib = hip.load()
+    b, h, w, cin, cout, npts = case
+    g = torch.Generator().manual_seed(sum(case))
+    spec = ops.GridSpec((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (w, h, 1))
+    cell = torch.randint(0, b * h * w, (npts,), generator=g)
+    vi = ops.build_voxel_index(cell.to(torch.int32).to(dev), spec, b, want_unq=False)
+    uniq = torch.unique(cell)                                               # sorted: the order of the index's key list
+    vi.row_start = torch.searchsorted(uniq, torch.arange(b * h + 1) * w).to(torch.int32).to(dev)
+    ct = cin + 8
+    canvas = torch.zeros((b * h * w, ct))
+    canvas[uniq] = torch.randn((uniq.numel(), ct), generator=g)
+    canvas = canvas.view(b, h, w, ct).to(dev)
+    wt = (torch.randn((cout, cin, 3, 3), generator=g) * 0.1).to(dev)
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(dev), torch.randn(cout, generator=g).to(dev)
+    layer = ops.PillarConvLayer(wt, 2, scale=scale, shift=shift, act=ops.ACT_RELU)
+    assert layer.rows_form(vi, b, h, w)
+    y = layer(canvas, vi)
+    x64 = canvas[..., :cin].permute(0, 3, 1, 2).double()
+    r = torch.relu(torch.nn.functional.conv2d(x64, wt.double(), stride=2, padding=1) * scale.double()[None, :, None, None]
+                   + shift.double()[None, :, None, None]).permute(0, 2, 3, 1)
+    assert y.shape == r.shape
+    assert float((y.double() - r).abs().max() / r.abs().max()) < 2e-5, case
+    assert torch.equal(layer(canvas, vi), y)                                # fixed summation order: bitwise reproducible
+    keep, vi.row_start = vi.row_start, None                                 # the pair form on the same frame
+    yp = layer(canvas, vi)
+    vi.row_start = keep
+    assert float((y - yp).abs().max() / yp.abs().max()) < 2e-5
+    oh, ow = y.shape[1], y.shape[2]
+    if cout % 8 == 0:                                                       # planes of the map: bit for bit the planes pass over the NHWC output
+        n = lib.pn_wino4_planes_floats(b, oh, ow, cout)
+        planes = torch.full((n,), float("nan"), device=dev)
+        layer(canvas, vi, planes=planes)
+        ref = torch.full((n,), float("nan"), device=dev)
+        hip.call("pn_wino4_planes_from_nhwc_f32", y.data_ptr(), b, oh, ow, cout, cout, 0, 0, ref.data_ptr(), hip.stream())
+        assert torch.equal(planes.view(torch.int32), ref.view(torch.int32))
+
+
 def test_c2_model_takes_the_sparse_first_convolution(dev):
     """the hot path of BASELINE configs[1] runs RPN block 0's stride-2 convolution on the pillars (30k-point capacity: 67k pairs against
     590k dense (output, tap) pairs); a 300k-point engine keeps the dense kernel.  The golden parity tests of the full model cover it."""
