@@ -1181,6 +1181,14 @@ int pn_pillar_conv3x3_rows_f32(const float *canvas, int batch, int h, int w, int
                                const uint32_t *unq_keys, const int32_t *row_start, int v_capacity, const float *packed_rows_w, int cout,
                                const float *scale, const float *shift, int act, float *planes, float *out, int out_pixel_stride,
                                int out_channel_offset, pn_stream_t stream);
+/* pn_conv2d_nhwc_f32 with its output written as the F(4, 3) planes the chained layers read (r6): the stride-2 convolution at the head of an
+ * RPN block (det3d/models/necks/rpn.py:124-142) feeds the block's chain (pn_conv2d_wino*_chain_f32) without the NHWC map and the
+ * pn_wino4_planes_from_nhwc_f32 pass in between.  planes: pn_wino4_planes_floats(batch, oh, ow, cout) floats, not transposed; bit for bit the
+ * planes of the NHWC result.  Supported: groups 1, no deconvolution / strata / accumulate, cout % 8 == 0, output rows of 128 pixels or of a
+ * width dividing 64, whole block tiles of rows. */
+int pn_conv2d_nhwc_planes_supported(const pn_conv_desc *d);
+int pn_conv2d_nhwc_planes_f32(const pn_conv_desc *d, const float *in, const float *packed_w, const float *scale, const float *shift,
+                              float *planes, pn_stream_t stream);
 /* The same convolution in TRAINING: the pair tables are built once per iteration (pn_pillar_pairs_build; pn_pillar_pairs_bytes of
  * caller-owned memory that lives from the forward to the backward) and shared by
  *   forward          pn_pillar_conv3x3_tables_f32        (oh, ow = the output map; workspace 9 * cap * cout floats, cap = v_capacity

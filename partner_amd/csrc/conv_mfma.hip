@@ -23,6 +23,7 @@
 // k = 8s+4+j from lane half 1, for A and B alike (the sum is order independent up to fp32
 // rounding).
 #include "pn_common.h"
+#include "wino_planes.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -73,6 +74,10 @@ struct ConvArgs {
   const int* nbr;
   const int* n_valid;    // device count of valid output sites (rows beyond it are neither computed nor written)
   int res_pre_act;       // 1: out = act(conv*scale + shift + residual) (residual blocks); 0: act(...) + residual
+  // r6 (pn_conv2d_nhwc_planes_f32): the output goes out as the F(4, 3) planes of conv_wchain.hip (wino_planes.h) instead of NHWC -- the
+  // epilogue's LDS tiles hold whole map rows (BM % OW == 0), so a quad's neighbour pixels are in the block
+  float* planes;
+  unsigned plane_floats;
   // ---- statistics of the (affine-applied, pre-activation) output for the GroupNorm-family layer that follows
   // (st_part != null).  Every block writes ONE partial (sum, sum of squares) per column and tile (per-channel groups) or per
   // 32-row segment and wave column (all-channel groups); conv_stats_finalize_kernel (a separate small launch: folding them
@@ -455,6 +460,39 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           tile[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + j * 32 + li] = acc[i][j][r];
+    if (a.planes) {
+      // ---- planes epilogue: item = (channel quad of the block's columns, pixel quad of the block's rows), pixel quads fastest (a wave's plane
+      // stores are runs of a plane row).  Pixel p, column c of the block tile lie in wave (p / TR, c / TC)'s LDS tile.
+      __syncthreads();      // the tiles are read across waves here
+      constexpr int QT = BM / 4, C4T = BN / 4;
+      const int Wq = a.OW >> 2, c4n = a.Cout >> 2;
+      for (int it = tid; it < QT * C4T; it += NT) {
+        const int c4l = it / QT, q = it - c4l * QT;
+        const int gn = n0 + c4l * 4, gm0 = m0 + 4 * q;
+        if (gn >= a.ncols || gm0 >= m_valid) continue;
+        const int rowi = gm0 / a.OW, xq = (gm0 - rowi * a.OW) >> 2;
+        const int img = rowi / a.OH, r = rowi - img * a.OH;
+        f32x4 vs = {1.f, 1.f, 1.f, 1.f}, vh = {0.f, 0.f, 0.f, 0.f};
+        if (a.scale) vs = *reinterpret_cast<const f32x4*>(a.scale + gn);
+        if (a.shift) vh = *reinterpret_cast<const f32x4*>(a.shift + gn);
+        const int cl = c4l * 4;
+        const float* tcol = smem + (size_t)(cl / TC) * (TR * TLD) + (cl % TC);      // + wave row wm * WN * (TR * TLD) + row * TLD
+        f32x4 d[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int p = 4 * q - 1 + i;                 // pixel of the block tile; out of the map row: zero padding
+          const bool inside = (i > 0 || xq > 0) && (i < 5 || xq + 1 < Wq);
+          const int pc = inside ? p : 4 * q;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(tcol + (size_t)(pc / TR) * (WN * TR * TLD) + (pc % TR) * TLD);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[i][k] = inside ? pn::apply_act(fmaf(v[k], vs[k], vh[k]), a.act) : 0.f;
+        }
+        f32x4 vv[6];
+        pn::wino4_input_transform4(d, vv);
+        pn::wino4_store_planes(a.planes, vv, gn >> 2, c4n, a.plane_floats, img, r, xq, a.OH, Wq);
+      }
+      return;
+    }
     // lanes: c4 = 16-byte column group, rr = row within a pass
     constexpr int CG = TC / 4;            // column groups per row (8 or 16)
     constexpr int RPP = 64 / CG;          // rows per pass
@@ -2147,6 +2185,40 @@ int pn_conv2d_nhwc_f32(const pn_conv_desc* d, const float* in, const float* pack
     if (taps == 9) launch_small_n<9>(a, zdim, st);
     else launch_small_n<1>(a, zdim, st);
     return pn::check_launch("conv_small_n_kernel");
+  }
+  return dispatch_conv(a, zdim, st);
+}
+
+// r6: the same convolution with its output written as the F(4, 3) planes the chained layers read (pn_wino4_planes_floats(batch, oh, ow,
+// cout) floats, not transposed) -- the stride-2 layer at the head of an RPN block feeds the block's chain without the NHWC map and the
+// NHWC -> planes pass in between.  The epilogue transposes the accumulators through LDS anyway; with block tiles of whole map rows a quad's
+// two neighbour pixels are in the same block.  Same values as pn_conv2d_nhwc_f32 + pn_wino4_planes_from_nhwc_f32, bit for bit.
+int pn_conv2d_nhwc_planes_supported(const pn_conv_desc* d) {
+  ConvArgs a;
+  int zdim = 1;
+  if (!d || fill_args(d, a, zdim)) return 0;
+  if (a.mode != MODE_CONV || zdim != 1 || d->accumulate || (d->cout & 7) || (d->cin & 3) || (d->in_pixel_stride & 3) || (d->in_channel_offset & 3)) return 0;
+  if ((a.OW & 3) || !((a.OW <= 64 && 64 % a.OW == 0) || a.OW == 128)) return 0;
+  if (a.M % (a.OW == 128 ? 128 : 64)) return 0;
+  return 1;
+}
+
+int pn_conv2d_nhwc_planes_f32(const pn_conv_desc* d, const float* in, const float* packed_w, const float* scale, const float* shift, float* planes,
+                              pn_stream_t stream) {
+  PN_REQUIRE(pn_conv2d_nhwc_planes_supported(d), "conv_planes: not covered (groups 1, cout % 8 == 0, output rows of 4 .. 64 pixels dividing 64, or of 128)");
+  PN_REQUIRE(in && packed_w && planes && ((uintptr_t)in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0 && ((uintptr_t)planes & 15) == 0 &&
+                 ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0, "conv_planes: null or misaligned pointer");
+  ConvArgs a;
+  int zdim = 1;
+  if (int rc = fill_args(d, a, zdim)) return rc;
+  a.in = in; a.w = packed_w; a.scale = scale; a.shift = shift;
+  a.out = planes; a.out_ps = d->cout; a.out_co = 0;      // (the vectorised epilogue's preconditions; nothing is stored NHWC)
+  a.planes = planes;
+  a.plane_floats = (unsigned)((size_t)d->batch * (a.OH + 2) * (a.OW / 4) * 4);
+  hipStream_t st = pn::S(stream);
+  if (a.OW == 128) {      // block tiles of 128 pixels: 128 x 128 where those fill the chip, else 128 x 64 on eight waves
+    const long long t128 = (long long)pn::cdiv(a.M, 128) * pn::cdiv(a.ncols, 128);
+    return t128 >= 384 ? launch_conv<2, 2, 2, 2>(a, zdim, st) : launch_conv<4, 2, 1, 1>(a, zdim, st);
   }
   return dispatch_conv(a, zdim, st);
 }

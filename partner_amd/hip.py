@@ -208,6 +208,8 @@ SIGNATURES = {
     "pn_handle_info": (_I, [_P, _P, _P, _P, _P, _P, _SZ]),
     "pn_handle_pci_bus_id": (_I, [_P, _P, _SZ]),
     "pn_conv3x3_tap_sum_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
+    "pn_conv2d_nhwc_planes_supported": (_I, [_P]),
+    "pn_conv2d_nhwc_planes_f32": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "pn_linear_packed_weight_floats": (_SZ, [_I, _I]),
     "pn_pack_linear_weight_f32": (_I, [_P, _I, _I, _P, _P]),
     "pn_linear_set_tile": (_I, [_I]),

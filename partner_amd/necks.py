@@ -142,6 +142,15 @@ class RPN(nn.Module):
                         x = ops.conv_chain(rest, None, shape=(b0, oh, ow), device=x.device, planes_from=lambda buf: p0(canvas, pillars, planes=buf))
                         break
                     x = p0(x, pillars)
+                elif (k == 0 and dtype == "f32" and layer.stride > 1 and len(layers) > 1 and all(l.stride == 1 for l in layers[1:])
+                      and layer.planes_desc(*x.shape) is not None
+                      and ops.conv_chain_orientation(layers[1:], x.shape[0], *layer.out_hw(x.shape[1], x.shape[2])) is False):
+                    # r6: the block's stride-2 layer writes the chain's planes from its own epilogue (csrc/conv_mfma.hip): no NHWC map, no
+                    # NHWC -> planes pass between it and the block's stride-1 layers
+                    src, b0 = x, x.shape[0]
+                    oh, ow = layer.out_hw(x.shape[1], x.shape[2])
+                    x = ops.conv_chain(layers[1:], None, shape=(b0, oh, ow), device=x.device, planes_from=lambda buf, l=layer, s=src: l.to_planes(s, buf))
+                    break
                 elif k <= 1 and dtype == "f32" and layer.stride == 1 and ops.conv_chain_supported(layers[k:], x.shape[0], x.shape[1], x.shape[2]):
                     # the block's same-shape layers stay in the F(4, 3) domain (conv_wchain.hip); a stride-1 first layer (Waymo block 0) joins them
                     x = ops.conv_chain(layers[k:], x)

@@ -505,6 +505,33 @@ class ConvLayer:
             self.packed_rows = torch.empty(lib.pn_conv_bf16_rows_packed_elems(rows, cin, kh, kw), dtype=torch.bfloat16, device=w.device)
             hip.call("pn_pack_conv_weight_bf16_rows", w.data_ptr(), rows, cin, kh, kw, self.packed_rows.data_ptr(), st)
 
+    def planes_desc(self, b: int, h: int, w: int, ct: int, in_channel_offset: int = 0):
+        """the descriptor of ``to_planes`` on a (b, h, w, ct) map, or None where the direct kernel's planes epilogue does not apply"""
+        if self.dtype != "f32" or self.deconv2x2 or self.range_strata > 1 or self.groups != 1 or not _CONV_PLANES_ON:
+            return None
+        d = ConvDesc(b, h, w, self.cin, self.cout, 1, self.kh, self.kw, self.stride, self.pad[0], self.pad[1], ct, in_channel_offset, self.cout, 0,
+                     self.act, 0, 0, 0, 0, 0)
+        return d if hip.load().pn_conv2d_nhwc_planes_supported(C.byref(d)) else None
+
+    def to_planes(self, x: torch.Tensor, planes: torch.Tensor, in_channel_offset: int = 0) -> None:
+        """this convolution (direct implicit-GEMM kernel) with its output written as the F(4, 3) planes of ``conv_chain`` (csrc/conv_mfma.hip,
+        r6): the stride-2 layer at the head of an RPN block feeds the block's chain without the NHWC map in between"""
+        hip.require_device(x, planes)
+        b, h, w, ct = x.shape
+        d = self.planes_desc(b, h, w, ct, in_channel_offset)
+        assert d is not None, "ConvLayer.to_planes: check planes_desc first"
+        self._ensure("direct")
+        oh, ow = self.out_hw(h, w)
+        assert planes.numel() >= hip.load().pn_wino4_planes_floats(b, oh, ow, self.cout)
+        st = hip.stream()
+        prof = _PROFILER
+        if prof is not None:
+            ev = prof.begin(st)
+        hip.call("pn_conv2d_nhwc_planes_f32", C.byref(d), x.data_ptr(), self.packed.data_ptr(), hip.ptr(self.scale), hip.ptr(self.shift),
+                 planes.data_ptr(), st)
+        if prof is not None:
+            prof.end(ev, 2.0 * b * oh * ow * self.cout * self.cin * self.kh * self.kw, st, tag=f"{oh}x{ow} {self.cin}->{self.cout} k{self.kh} -> planes")
+
     def chain_weights(self, two_d: bool, transposed: bool) -> torch.Tensor:
         """packed weights of the chained F(4,3) / F(2,3)xF(4,3) forms; ``transposed``: of the kernel with kh and kw swapped (the chain then runs
         on the transposed map), packed on first use.  The transposed layouts belong to the inference path (the head's
@@ -704,6 +731,7 @@ class ConvLayer:
 # Runs of same-map 3x3 / stride-1 layers kept in the F(4, 3) domain between layers (csrc/conv_wchain.hip): PN_CONV_CHAIN=0 runs them one
 # pn_conv2d_wino4_nhwc_f32 launch each, as r3 did
 _CHAIN_ON = os.environ.get("PN_CONV_CHAIN", "1") != "0"
+_CONV_PLANES_ON = os.environ.get("PN_CONV_PLANES", "1") != "0"     # 0: a block's first (stride-2) layer writes NHWC and a separate pass forms the chain's planes (r4, r5)
 
 
 def _chain_desc(layer: "ConvLayer", b: int, h: int, w: int, out_ps: int = 0, out_co: int = 0, transposed: bool = False):

@@ -29,7 +29,8 @@ ROUTES = {
                         PN_CONV_SMALL_N="0", PN_TRAIN_WGRAD_STREAM="0", PN_TRAIN_CHAIN_MAX_PIXELS="0"),
     # the one-dimensional chain, F(2,3) without F(4,3), the wave-per-group sparse kernel, row bits off, planes off
     "r4_alternates": dict(PN_CONV_CHAIN2D="0", PN_SPARSE_GROUP4="0", PN_SPARSE_ROW_BITS="0", PN_PILLAR_PLANES="0", PN_WINO4_KSPLIT="0",
-                          PN_TRAIN_STRAT_EXPAND="1", PN_SPARSE_G4SPLIT="0", PN_PFN_SPLIT="0", PN_CHANNEL_SUM_V4="0", PN_SMALL_N_MFMA="0", PN_CONV_CHAIN44="0", PN_PFN_TILES="0"),
+                          PN_TRAIN_STRAT_EXPAND="1", PN_SPARSE_G4SPLIT="0", PN_PFN_SPLIT="0", PN_CHANNEL_SUM_V4="0", PN_SMALL_N_MFMA="0", PN_CONV_CHAIN44="0", PN_PFN_TILES="0",
+                          PN_PILLAR_ROWS="0", PN_LN_FOLD="0"),      # (r6: the pair-list first convolution, LayerNorm passes in front of the token GEMMs)
     "f23_only": dict(PN_CONV_WINO4="0", PN_CONV_CHAIN="0", PN_HEAD_CHAIN="0", PN_WINO_BDIRECT="0", PN_SPARSE_WINDOW="1024", PN_WINO4_TWO_PHASE="0"),
 }
 
