@@ -882,6 +882,7 @@ _PILLAR_CONV_ON = os.environ.get("PN_PILLAR_CONV", "1") != "0"
 _PILLAR_PLANES_ON = os.environ.get("PN_PILLAR_PLANES", "1") != "0"      # the pillar layer writes the chain's planes itself (no NHWC map in between)
 # taken when the pillar capacity bounds the (pillar, tap) pairs to this fraction of the dense (output, tap) pairs
 _PILLAR_CONV_MAX_FILL = float(os.environ.get("PN_PILLAR_CONV_MAX_FILL", "0.35"))
+_PILLAR_ROWS_MAX_FILL = float(os.environ.get("PN_PILLAR_ROWS_MAX_FILL", "1.25"))
 
 
 class PillarConvLayer:
@@ -917,9 +918,13 @@ class PillarConvLayer:
         return _PILLAR_CONV_ON and (kh, kw) == (3, 3) and stride in (1, 2) and groups == 1 and ci in (32, 64, 128) and co % 4 == 0
 
     def worth_it(self, vi: "VoxelIndex", b: int, h: int, w: int) -> bool:
-        """the pillar capacity (known on the host: no sync) bounds the pairs: 9 / stride^2 per pillar"""
+        """the pillar capacity (known on the host: no sync) bounds the pairs: 9 / stride^2 per pillar.  The pair-list form pays up to 0.35 of
+        the dense (output, tap) pairs; the row-band form (no partial rows in memory, the planes straight from LDS) still wins on the 300k-point
+        frames of BASELINE configs[4] -- 180k pillars, 2/3 of the cells: p50 1.208 -> 1.186 ms -- so it is taken up to a capacity bound of 1.25
+        (the capacity counts points, not pillars; a completely full canvas would lose about a third on this one layer)."""
         oh, ow = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
-        return vi.n_cap * 9.0 / (self.stride * self.stride) <= _PILLAR_CONV_MAX_FILL * 9.0 * b * oh * ow
+        limit = max(_PILLAR_CONV_MAX_FILL, _PILLAR_ROWS_MAX_FILL) if self.rows_form(vi, b, h, w) else _PILLAR_CONV_MAX_FILL
+        return vi.n_cap * 9.0 / (self.stride * self.stride) <= limit * 9.0 * b * oh * ow
 
     def planes_supported(self, b: int, h: int, w: int) -> bool:
         oh, ow = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
