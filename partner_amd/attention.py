@@ -164,7 +164,8 @@ class SetBlock(nn.Module):
         cm = int(col_major)
         ln = lambda t, n: ops.layernorm(t, n.weight.detach(), n.bias.detach(), n.eps)  # noqa: E731
         x2 = x.contiguous().view(B * L, C).float()
-        b16 = self.compute_dtype == "bf16" and C % 64 == 0
+        # (every GEMM of the bf16 route must be packable for the bf16 pipe -- k % 64, n % 16 --, else the block stays in f32)
+        b16 = self.compute_dtype == "bf16" and C % 64 == 0 and all(g.bf16_ok for g in (p["s1_kv"], p["s2_q"], p["proj"], p["mlp"][0], p["mlp"][1]))
         if b16:
             xn, cmean, xn_in = ops.layernorm(x2, a.norm1.weight.detach(), a.norm1.bias.detach(), a.norm1.eps, want_chan_mean=True, bf16_copy=True)
         else:

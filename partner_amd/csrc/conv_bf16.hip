@@ -331,7 +331,8 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_bf16_igemm_kernel(const CbAr
 // matrix pipe (loads alone: 57 GB/s per CU, the same time as the whole kernel).  Here a block owns TR whole output rows (TR x W = 288
 // pixels, one block per CU, 12 waves) x 128 output channels and keeps, per 64-channel chunk, the (TR + 2) x (W + 2) input PATCH in LDS:
 // a pixel is fetched once per chunk and read by all nine taps at shifted patch positions; only the 16 KB weight tile of a (chunk, tap)
-// step is streamed, four stages deep (three steps ahead, counted vmcnt, raw barriers).  L2 -> LDS traffic per output drops 2.8 x.
+// step is streamed through two alternating groups of stages (the next group requested while the current one multiplies, vmcnt(0) at the
+// group boundary, raw barriers).  L2 -> LDS traffic per output drops 2.8 x.
 // The patch image is [patch pixel][128 B] with chunk c of pixel r at c ^ (r & 7): 16 consecutive patch pixels from ANY start are
 // conflict free for ds_read_b128 (a tile that straddles two output rows jumps by PS - W = 8 patch pixels: same residues, same banks).
 struct CrArgs {
@@ -663,7 +664,12 @@ int pn_conv2d_igemm_bf16_supported(const pn_conv_desc* d) {
   if (!d) return 0;
   if (d->groups != 1 || d->range_strata > 1 || d->accumulate || d->pad_h_end || d->pad_w_end || d->transpose_hw) return 0;
   if (d->cin < 64 || d->cin % 64 || d->cout < 16 || d->cout % 16) return 0;
-  if (d->in_pixel_stride % 8 || d->in_channel_offset % 8 || d->out_pixel_stride % 4 || d->out_channel_offset % 4) return 0;
+  // (the output stores are 16 bytes wide also for bf16 outputs -- 8 elements --, so strides and offsets of 8; the slices must fit
+  // their pixel strides: a wider slice would read / write into the next pixel, or past the buffer descriptor for the last one)
+  if (d->in_pixel_stride % 8 || d->in_channel_offset % 8 || d->out_pixel_stride % 8 || d->out_channel_offset % 8) return 0;
+  if (d->in_channel_offset < 0 || d->out_channel_offset < 0 || d->in_channel_offset + d->cin > d->in_pixel_stride ||
+      d->out_channel_offset + d->cout > d->out_pixel_stride)
+    return 0;
   if (!(d->act == PN_ACT_NONE || d->act == PN_ACT_RELU)) return 0;
   if (d->deconv2x2 && !(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0)) return 0;
   if (d->stride < 1 || d->kh < 1 || d->kw < 1 || d->kh > 7 || d->kw > 7) return 0;

@@ -2344,7 +2344,9 @@ int pn_conv2d_small_n_multi_f32(const pn_conv_job* jobs, int njobs, pn_stream_t 
   m.total = total;
   hipStream_t st = pn::S(stream);
   pn::ProfileSlot ps;
-  // every job in 8 x 16 tiles: the matrix-pipe form (same bits; PN_SMALL_N_MFMA=0: the packed-fma form)
+  // every job in 8 x 16 tiles: the matrix-pipe form (PN_SMALL_N_MFMA=0: the packed-fma form).  Jobs with Cout >= 4 give the packed-fma form's
+  // bits (an MFMA is a k-ordered fma chain); jobs with Cout <= 3 take small_n_gform_body, which sums the channels first and the taps last:
+  // another fp32 order, same parity tests -- the switch is NOT a bitwise A/B for the reg / height / rot branches
   static const int use_mfma = [] { const char* e = getenv("PN_SMALL_N_MFMA"); return e ? atoi(e) : 1; }();
   bool all_tiles = use_mfma != 0;
   for (int j = 0; j < njobs; ++j) all_tiles = all_tiles && (m.job[j].snt2 || m.job[j].KH * m.job[j].KW == 1);

@@ -1249,6 +1249,17 @@ class GemmLayer:
         self.ln = None
 
     @property
+    def bf16_ok(self) -> bool:
+        """can this layer run on the bf16 matrix pipe (pn_linear_bf16: k a multiple of 64, n of 16)?  Callers keep a GEMM in f32 where not."""
+        return self.k % 64 == 0 and self.n % 16 == 0
+
+    def prepack_bf16(self) -> None:
+        """pack the bf16 weights now (set_compute_dtype('bf16')), not on the first call -- which may be inside a hipGraph capture"""
+        if self.bf16_ok and getattr(self, "packed_bf16", None) is None:
+            self.packed_bf16 = torch.empty(hip.load().pn_conv_bf16_rows_packed_elems(self.n, self.k, 1, 1), dtype=torch.bfloat16, device=self._w_f32.device)
+            hip.call("pn_pack_conv_weight_bf16_rows", self._w_f32.data_ptr(), self.n, self.k, 1, 1, self.packed_bf16.data_ptr(), hip.stream())
+
+    @property
     def stats_ok(self) -> bool:
         """can this layer leave the row statistics a LayerNorm-folding consumer needs (``__call__(..., stats_out=True)``)?"""
         return self.linear and self.entry == "pn_linear_f32" and self.n % 32 == 0 and _LN_FOLD_ON
@@ -1281,11 +1292,8 @@ class GemmLayer:
         st = hip.stream()
         prof = _PROFILER
         if x.dtype == torch.bfloat16:
-            assert self.k % 64 == 0 and self.n % 16 == 0, "bf16 GEMM: k a multiple of 64, n of 16"
-            if getattr(self, "packed_bf16", None) is None:
-                lib = hip.load()
-                self.packed_bf16 = torch.empty(lib.pn_conv_bf16_rows_packed_elems(self.n, self.k, 1, 1), dtype=torch.bfloat16, device=x.device)
-                hip.call("pn_pack_conv_weight_bf16_rows", self._w_f32.data_ptr(), self.n, self.k, 1, 1, self.packed_bf16.data_ptr(), st)
+            assert self.bf16_ok, "bf16 GEMM: k a multiple of 64, n of 16 (check GemmLayer.bf16_ok and keep the layer in f32 otherwise)"
+            self.prepack_bf16()
             if out is None:
                 out = torch.empty((m, self.n), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
             if prof is not None:

@@ -197,7 +197,7 @@ class E2ESWVoteHead(nn.Module):
                     patch=ops.GemmLayer(L.patch_embed.proj.weight.flatten(1), L.patch_embed.proj.bias),
                     cls=(conv(self.cls_head[0][0], ops.ACT_RELU, self.cls_head[0][1]), conv(self.cls_head[1][0], ops.ACT_RELU, self.cls_head[1][1]),
                          conv(self.cls_head[2], ops.ACT_NONE)),
-                    bbox=two(self.bbox_head), iou=two(self.iou_head) if self.iou_loss else None, blocks=[])
+                    bbox=None, iou=None, blocks=[])
         # r5: the first convolutions of the box and the IoU branch read the same feature map (e2e_swv_head.py: Conv3x3 256 -> 64 + ReLU each): ONE
         # 256 -> 128 launch (bf16: the rows form of conv_bf16.hip needs 128 columns -- 50 us instead of 2 x 50; f32: one launch less), the second
         # convolutions read their 64-channel halves of its output.  Same arithmetic per output channel.  (The vote / vote-class pair as one
@@ -208,6 +208,10 @@ class E2ESWVoteHead(nn.Module):
             if c0.weight.shape == c1.weight.shape and c0.padding == c1.padding and (c0.weight.shape[0] * 2) % 32 == 0:
                 plan["box_iou0"] = ops.ConvLayer(torch.cat([c0.weight.detach(), c1.weight.detach()], 0), stride=1, pad=c0.padding[0],
                                                  shift=torch.cat([c0.bias.detach(), c1.bias.detach()], 0), act=ops.ACT_RELU, dtype=dt)
+        # (with the fused first convolution the branches' own first layers are never called: they are not built or packed then)
+        fused0 = plan["box_iou0"] is not None
+        plan["bbox"] = (None if fused0 else conv(self.bbox_head[0], ops.ACT_RELU), conv(self.bbox_head[2], ops.ACT_NONE))
+        plan["iou"] = ((None if fused0 else conv(self.iou_head[0], ops.ACT_RELU), conv(self.iou_head[2], ops.ACT_NONE))) if self.iou_loss else None
         for blk in L.layers[0].blocks:
             a = blk.attn
             f = lambda t: t.detach().float().contiguous()  # noqa: E731
@@ -306,7 +310,8 @@ class E2ESWVoteHead(nn.Module):
         blk = bp["mod"]
         C, heads, ws = self.layer.embed_dim, self.layer.num_heads, self.window_size
         n = b * h * w
-        b16 = getattr(self, "compute_dtype", "f32") == "bf16" and C % 64 == 0
+        b16 = (getattr(self, "compute_dtype", "f32") == "bf16" and C % 64 == 0
+               and all(bp[k].bf16_ok for k in ("qkv", "proj", "fc1", "fc2")))      # (else the block's GEMMs stay in f32)
         if b16:      # bf16 option: the four token GEMMs of the block on the bf16 matrix pipe; LayerNorm, the attention core, GELU, residuals in f32
             y = ops.layernorm(t, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, bf16_copy=True, f32_out=False)
         elif t_stats is not None and bp["ln1_folded"]:
