@@ -226,10 +226,13 @@ def test_sparse_first_convolution_policy():
     assert ops.PillarConvLayer.supports(torch.empty(128, 128, 3, 3), 2, 1) and ops.PillarConvLayer.supports(torch.empty(64, 32, 3, 3), 1, 1)
     assert not ops.PillarConvLayer.supports(torch.empty(128, 128, 1, 1), 1, 1) and not ops.PillarConvLayer.supports(torch.empty(128, 48, 3, 3), 2, 1)
     assert not ops.PillarConvLayer.supports(torch.empty(128, 128, 3, 3), 2, 2)          # grouped
-    layer = types.SimpleNamespace(stride=2)
-    worth = lambda n_cap, b=1: ops.PillarConvLayer.worth_it(layer, types.SimpleNamespace(n_cap=n_cap), b, 512, 512)   # noqa: E731
-    assert worth(30000) and worth(120000, 4)            # BASELINE configs[1] / [2]: 67k of 590k pairs
-    assert not worth(300000)                            # the 10-sweep streaming frames of configs[4] keep the dense kernel
+    pairs = types.SimpleNamespace(stride=2, rows_form=lambda vi, b, h, w: False)        # the pair-list form (no row_start in the index)
+    worth = lambda layer, n_cap, b=1: ops.PillarConvLayer.worth_it(layer, types.SimpleNamespace(n_cap=n_cap), b, 512, 512)   # noqa: E731
+    assert worth(pairs, 30000) and worth(pairs, 120000, 4)      # BASELINE configs[1] / [2]: 67k of 590k pairs
+    assert not worth(pairs, 300000)                             # the pair lists lose on the 10-sweep streaming frames of configs[4]
+    rows = types.SimpleNamespace(stride=2, rows_form=lambda vi, b, h, w: True)          # r6: the row-band form (csrc/pillar_rows.hip)
+    assert worth(rows, 30000) and worth(rows, 300000)           # ... which still wins there (180k pillars, 2/3 of the cells)
+    assert not worth(rows, 1000000)                             # a capacity far beyond the cell count keeps the dense kernel
 
 
 def test_frames_in_flight_context_is_scoped_and_exception_safe():
