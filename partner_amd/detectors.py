@@ -150,16 +150,22 @@ class PointPillars(SingleStageDetector):
         return vi
 
     def forward_cart(self, cart: torch.Tensor, sample_offsets: torch.Tensor, batch: int, spec: Optional[ops.GridSpec] = None,
-                     canvas: Optional[torch.Tensor] = None, index_state=None) -> Dict[str, torch.Tensor]:
+                     canvas: Optional[torch.Tensor] = None, index_state=None, canvas_may_stay_dirty: bool = False) -> Dict[str, torch.Tensor]:
         """The hot path from CARTESIAN points (N, 5) [x, y, z, intensity, dt] resident on the device: V0 .. H2, head tensors out.
         ``canvas`` / ``index_state``: persistent buffers owned by the caller (``new_canvas`` / ``new_index_state``), all zero on
-        entry and on exit (the frame's cells are cleared once the backbone's first layer has consumed the canvas)."""
+        entry and on exit (the frame's cells are cleared once the backbone's first layer has consumed the canvas).
+        ``canvas_may_stay_dirty`` (r6; the frame engines, whose canvas nobody else sees): where the first convolution took the row-band pillar
+        form -- it reads exactly the cells of the frame's key list and nothing else does -- the old frame's feature rows are left in the
+        canvas (only the index counters are cleared): 14.5 MB of zero stores less per 30k-point frame, 92 MB per 300k-point frame.  Such a
+        canvas must never reach a dense consumer."""
         eval_only(self, "PointPillars")
         spec = spec or ops.GridSpec.from_range(self.reader.pc_range, self.reader.voxel_size)
         cv, vi, _ = self.encode_cart(cart, sample_offsets, batch, spec, canvas=canvas, index_state=index_state)
         x2 = self._neck_on_canvas(cv, vi)
         if canvas is not None or index_state is not None:
-            ops.clear_frame_cells(cv if canvas is not None else None, vi, index_state)
+            leave = (canvas_may_stay_dirty and canvas is not None and index_state is not None and self.seg_head is None
+                     and getattr(self.neck, "canvas_read_by_pillars_only", False))
+            ops.clear_frame_cells(None if leave else (cv if canvas is not None else None), vi, index_state)
         return self.bbox_head(ops.as_nchw(x2))["det_preds"][0]
 
     def extract_preds(self, example) -> Dict[str, object]:

@@ -52,7 +52,8 @@ class FrameEngine:
         if hasattr(self.model, "attns"):   # VoxelNetV3 (Waymo PARTNER config): hard-voxel path, every sample voxelized on its own
             preds = self.model.forward_points(ops.cart_to_polar(self.cart), sample_offsets=[self.n * b for b in range(self.batch + 1)])
         elif self.index_state is not None:
-            preds = self.model.forward_cart(self.cart, self.offsets, self.batch, self.spec, canvas=self.canvas, index_state=self.index_state)
+            preds = self.model.forward_cart(self.cart, self.offsets, self.batch, self.spec, canvas=self.canvas, index_state=self.index_state,
+                                            canvas_may_stay_dirty=True)      # (the engine's canvas is private)
         else:
             preds = self.model.forward_points(ops.cart_to_polar(self.cart), self.offsets, self.batch, self.spec, canvas=self.canvas)
         if self.test_cfg is None:
@@ -260,7 +261,7 @@ class StreamingFrameEngine:
     def _step(self):
         cart, _ = ops.accumulate_sweeps(self.raw, self.sweep_offsets, self.transforms, self.time_lags, 1.0, count=self.offsets[1:2])
         # rows past the count are ignored downstream
-        preds = self.model.forward_cart(cart, self.offsets, 1, self.spec, canvas=self.canvas, index_state=self.index_state)
+        preds = self.model.forward_cart(cart, self.offsets, 1, self.spec, canvas=self.canvas, index_state=self.index_state, canvas_may_stay_dirty=True)
         if self.test_cfg is None:
             return dict(preds)
         return self.model.bbox_head.predict(dict(metadata=[None]), {"det_preds": [preds]}, self.test_cfg, device_only=True)

@@ -129,12 +129,14 @@ class RPN(nn.Module):
         else:
             plan = self._plan.get(self, self._build_plan)
         out, off, block_outs = None, 0, []
+        self.canvas_read_by_pillars_only = False      # set below when the first layer took the row-band pillar form (it reads the frame's cells only)
         for i, layers in enumerate(plan["blocks"]):
             for k, layer in enumerate(layers):
                 p0 = plan.get("pillar0") if (i == 0 and k == 0 and pillars is not None and dtype == "f32") else None
                 if p0 is not None and p0.worth_it(pillars, x.shape[0], x.shape[1], x.shape[2]):
                     b0, oh, ow = x.shape[0], (x.shape[1] - 1) // p0.stride + 1, (x.shape[2] - 1) // p0.stride + 1
                     rest = layers[1:]
+                    self.canvas_read_by_pillars_only = p0.rows_form(pillars, b0, x.shape[1], x.shape[2])
                     if (rest and all(l.stride == 1 for l in rest) and p0.planes_supported(b0, x.shape[1], x.shape[2])
                             and ops.conv_chain_orientation(rest, b0, oh, ow) is False):
                         # the pillar layer's tap reduction writes the chain's planes itself: its 33 MB map never exists in NHWC
