@@ -17,6 +17,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 
 from . import hip, ops
+from .routes import R
 
 
 class Node:
@@ -376,15 +377,14 @@ def _pad4(dy: torch.Tensor) -> torch.Tensor:
     return out
 
 
-_WINO4_MAX_PIXELS = int(os.environ.get("PN_TRAIN_WINO4_MAX_PIXELS", "16384"))
 
 
 def conv2d(t: Tape, x: Node, w: Node, b: Optional[Node], stride=1, pad=0, relu=False) -> Node:
     """Conv2d(+bias)(+ReLU) on an NHWC map; w (Cout, Cin, k, k).  x may carry zero pad channels past Cin."""
     wv = w.v
     cout, cin, k, _ = wv.shape
-    layer = ops.ConvLayer(wv, stride=stride, pad=pad, shift=None if b is None else b.v, act=ops.ACT_RELU if relu else ops.ACT_NONE, wino4=_WINO4_MAX_PIXELS > 0)
-    layer.wino4_max_pixels = _WINO4_MAX_PIXELS       # F(4, 3) forward on the smaller maps only, as in train.py
+    layer = ops.ConvLayer(wv, stride=stride, pad=pad, shift=None if b is None else b.v, act=ops.ACT_RELU if relu else ops.ACT_NONE, wino4=R.train_wino4_max_pixels > 0)
+    layer.wino4_max_pixels = R.train_wino4_max_pixels       # F(4, 3) forward on the smaller maps only, as in train.py
     ct = x.v.shape[3]
     if ct != cin:
         layer.pad_input_channels(ct)

@@ -20,10 +20,10 @@ import torch
 from torch import nn
 
 from . import hip, ops
+from .routes import R
 from .builder import BBOX_HEADS
 from .nn_utils import PlanCache, RSNorm, Sequential, eval_only
 
-_HEAD_CHAIN = os.environ.get("PN_HEAD_CHAIN", "1") != "0"      # first-stage branch convolutions chained in the Winograd domain (conv_wchain.hip)
 
 
 class RangeStratified(nn.Module):
@@ -452,7 +452,7 @@ class CenterHeadSingle(CenterHead):
         plan = None
         lib = hip.load()
         c_sh = fz["c_sh"]
-        ok = ops._CHAIN_ON and _HEAD_CHAIN and c_sh % 32 == 0 and h % 4 == 0 and w % 2 == 0 and lib.pn_wino4_planes_floats(b, w, h, c_sh) > 0
+        ok = R.conv_chain and R.head_chain and c_sh % 32 == 0 and h % 4 == 0 and w % 2 == 0 and lib.pn_wino4_planes_floats(b, w, h, c_sh) > 0
         if ok:
             # launches: every stratified branch alone; the heat-map branch alone when it reads the calibrated copy; the rest together
             groups, rest = [], []
@@ -531,12 +531,12 @@ class CenterHeadSingle(CenterHead):
         hip.call("pn_groupnorm_strat_planes_f32", raw.data_ptr(), b, h, w, c_sh, c_sh, 0, 1, s_rs, hip.ptr(g_rs), hip.ptr(b_rs), float(eps_rs), ops.ACT_RELU,
                  hip.ptr(mul), hip.ptr(add), 2, planes_xs.data_ptr(), hip.ptr(planes_hm), ws.data_ptr(), nbytes, st)
         mid = torch.empty((b, h, w, cp["cm_tot"]), **f32)
-        prof = ops._PROFILER
+        prof = ops.S.profiler
         parts = [torch.empty(g["nstat"], **f32) for g in cp["groups"]]
         cjobs = (hip.ChainHeadJob * len(parts))()
         for cj, g, part in zip(cjobs, cp["groups"], parts):
             src = planes_hm if (g["src"] == "hm" and planes_hm is not None) else planes_xs
-            g["desc"].frames_in_flight = ops._FRAMES_IN_FLIGHT
+            g["desc"].frames_in_flight = ops.S.frames_in_flight
             cj.desc = C.pointer(g["desc"])
             cj.planes_in, cj.packed_w24, cj.scale, cj.shift = src.data_ptr(), g["packed"].data_ptr(), None, hip.ptr(g["bias"])
             cj.planes_out, cj.out_nhwc, cj.stat_partials = None, mid.data_ptr(), part.data_ptr()

@@ -21,13 +21,10 @@ import torch
 from torch import nn
 
 from . import hip, ops
+from .routes import R
 from .builder import BACKBONES
 from .nn_utils import PlanCache, build_norm_layer, eval_only
 
-_C16 = os.environ.get("PN_SPARSE_C16", "1") != "0"     # 0: the 16-channel level on the gathered MFMA kernel as well
-_ROW_BITS = os.environ.get("PN_SPARSE_ROW_BITS", "1") != "0"     # the grouping sort reads per-row tap bytes left by the neighbour kernel (r4)
-_GROUPED = os.environ.get("PN_SPARSE_GROUPED", "1") != "0"     # 0: every level >= 32 channels on the gathered tile kernel (r3) instead of sparse_group.hip
-_STRUCT_STREAM = os.environ.get("PN_SPARSE_STRUCT_STREAM", "1") != "0"   # 0: index builds / neighbour tables on the calling stream
 
 
 class SubMConv3d(nn.Module):
@@ -131,7 +128,7 @@ class SpMiddleResNetFHD(nn.Module):
                      layer["cout"], layer["scale"].data_ptr(),
                      layer["shift"].data_ptr(), int(act), hip.ptr(residual), out.data_ptr(), hip.stream())
             return out
-        if _C16 and layer["cout"] == 16 and layer["cin"] in (8, 16) and layer["taps"] <= 27:
+        if R.sparse_c16 and layer["cout"] == 16 and layer["cin"] in (8, 16) and layer["taps"] <= 27:
             # conv_input / conv1 (scn.py:112-123): the 16-channel level has its own kernel (inference; the training tape keeps one form)
             hip.call("pn_sparse_conv_c16_f32", feats.data_ptr(), n_rows, layer["cin"], nbr.data_ptr(), count.data_ptr(), cap, layer["taps"],
                      layer["packed"].data_ptr(), layer["scale"].data_ptr(), layer["shift"].data_ptr(), int(act), hip.ptr(residual), out.data_ptr(),
@@ -183,20 +180,20 @@ class SpMiddleResNetFHD(nn.Module):
         # convolutions wait for that level's event.  Inside a hipGraph capture the fork / joins become graph dependencies.
         subm_geo = ((3, 3, 3), (1, 1, 1), (1, 1, 1))
         main = torch.cuda.current_stream()
-        side = ops.concurrent_stream(dev) if _STRUCT_STREAM else None     # a stream that really overlaps with this one (hardware-queue mapping)
+        side = ops.concurrent_stream(dev) if R.sparse_struct_stream else None     # a stream that really overlaps with this one (hardware-queue mapping)
 
         def tbl(rows, geo):
             return torch.empty((rows, geo[0][0] * geo[0][1] * geo[0][2]), dtype=torch.int32, device=dev)
 
         def grp(rows):      # (perm, group masks) of a neighbour table: the sites sorted by neighbourhood, pn_sparse_group_rows
-            if not _GROUPED:
+            if not R.sparse_grouped:
                 return None
             # (perm, group masks, XCD cut points of equal work: pn_sparse_group_balance)
             return (torch.empty(rows, dtype=torch.int32, device=dev), torch.empty((rows + 31) // 32, dtype=torch.int32, device=dev),
                     torch.zeros(18, dtype=torch.int32, device=dev))
 
         def bits(rows, geo, g):      # the row bytes the neighbour kernel leaves for the sort (only where a sort follows)
-            return torch.empty((rows, geo[0][0] * geo[0][1]), dtype=torch.uint8, device=dev) if (g is not None and _ROW_BITS and geo[0][2] <= 8) else None
+            return torch.empty((rows, geo[0][0] * geo[0][1]), dtype=torch.uint8, device=dev) if (g is not None and R.sparse_row_bits and geo[0][2] <= 8) else None
 
         def group(table, g, level, rb=None, geo=None):
             if g is None:

@@ -27,6 +27,7 @@ import torch
 from torch import nn
 
 from . import hip, ops
+from .routes import R
 from .heads import CenterHeadSingle, CenterHeadSinglePos, RangeStratified
 from .nn_utils import RSNorm
 from .readers import DynamicPFNet
@@ -137,17 +138,12 @@ def load_optimizer_state(ps: ParamStore, state: Dict[str, object]) -> int:
     return int(state["iter"])
 
 
-import os as _os
 # F(4, 3) in the training FORWARD only on maps of at most this many pixels (the 128 x 128 and 64 x 64 layers): with it on the 256 x 256
 # layers too the full-size gradient test misses its 2e-2 bound on the 95th percentile (2.2e-2: the forward's rounding is amplified
 # through the batch statistics); the data gradients take F(4, 3) everywhere (ops.ConvDgrad)
-_TRAIN_WINO4_MAX_PIXELS = int(_os.environ.get("PN_TRAIN_WINO4_MAX_PIXELS", "16384"))
-_TRAIN_PILLAR_CONV = _os.environ.get("PN_TRAIN_PILLAR_CONV", "1") != "0"
-_TRAIN_PREPACK = _os.environ.get("PN_TRAIN_PREPACK", "1") != "0"
 # forward of the 3x3 / stride-1 layers on maps up to this size on the chained F(2,3) x F(4,3) kernel (NHWC -> planes + one launch: 77 against
 # 91 us on the 64 x 64 x 256 layers at batch 4, -0.05 ms per iteration; the gradient statistics of the full-size test do not move; the
 # same kernel as the data gradient measured no gain beside the weight gradients and is not used)
-_TRAIN_CHAIN_MAX_PIXELS = int(_os.environ.get("PN_TRAIN_CHAIN_MAX_PIXELS", "4096"))
 
 
 class _Conv:
@@ -164,8 +160,8 @@ class _Conv:
             # its data gradient is the stride-2 convolution with the same tensor read as (Cout_conv, Cin_conv, 2, 2)
             self.dgrad = ops.ConvLayer(w, stride=2, pad=0)
         else:
-            self.layer = ops.ConvLayer(w, stride=stride, pad=pad, shift=None if bname is None else ps.p[bname], act=act, wino4=_TRAIN_WINO4_MAX_PIXELS > 0)
-            self.layer.wino4_max_pixels = _TRAIN_WINO4_MAX_PIXELS
+            self.layer = ops.ConvLayer(w, stride=stride, pad=pad, shift=None if bname is None else ps.p[bname], act=act, wino4=R.train_wino4_max_pixels > 0)
+            self.layer.wino4_max_pixels = R.train_wino4_max_pixels
             if cin_pad is not None:
                 self.layer.pad_input_channels(cin_pad)
             self.dgrad = ops.ConvDgrad(w, stride, pad)
@@ -183,8 +179,8 @@ class _Conv:
         self.dgrad.prepack_used()
 
     def _chain_ok(self, t, layer) -> bool:
-        return (_TRAIN_CHAIN_MAX_PIXELS > 0 and not self.transposed and self.k == 3 and self.stride == 1 and self.pad == 1
-                and t.shape[1] * t.shape[2] <= _TRAIN_CHAIN_MAX_PIXELS and t.shape[3] == layer.cin
+        return (R.train_chain_max_pixels > 0 and not self.transposed and self.k == 3 and self.stride == 1 and self.pad == 1
+                and t.shape[1] * t.shape[2] <= R.train_chain_max_pixels and t.shape[3] == layer.cin
                 and ops.conv_chain_supported([layer], t.shape[0], t.shape[1], t.shape[2]))
 
     def fwd(self, x, out=None, out_co=0, in_co=0):
@@ -359,7 +355,7 @@ class _StratConvGNReLU:
         self.layer = ops.ConvLayer(w, stride=1, pad=1, range_strata=self.strata, shift=ps.p[self.bname])
         # r4: gradients at the convolution's own multiply-add count (ops.StratConvDgrad, pn_conv2d_wgrad_f32 with range_strata); r3
         # expanded dy to strata * C channels and ran ordinary gradient convolutions over the zeros: 1.0 ms of a 14 ms iteration
-        self.masked = _os.environ.get("PN_TRAIN_STRAT_EXPAND", "0") == "0"
+        self.masked = not R.train_strat_expand
         self.dgrad = ops.StratConvDgrad(w, self.strata) if self.masked else ops.ConvDgrad(w, 1, 1)
         self.x = self.y = None
         ps.convs.append(self)
@@ -457,7 +453,7 @@ class PolarPillarTrainStep:
         for i, blk in enumerate(neck.blocks):
             mods = list(blk._modules.values())
             layers = [_ConvBNReLU(ps, f"neck.blocks.{i}.", 1, mods[2], mods[1])]
-            if i == 0 and _TRAIN_PILLAR_CONV and ops.PillarConvLayer.supports(mods[1].weight, mods[1].stride[0], mods[1].groups) and mods[1].out_channels <= 128 \
+            if i == 0 and R.train_pillar_conv and ops.PillarConvLayer.supports(mods[1].weight, mods[1].stride[0], mods[1].groups) and mods[1].out_channels <= 128 \
                     and mods[1].out_channels in (32, 64, 128):
                 layers[0].conv = _PillarConv(ps, f"neck.blocks.{i}.1.weight", mods[1].stride[0])
             for k in range(4, len(mods), 3):
@@ -707,7 +703,7 @@ class PolarPillarTrainStep:
         layouts, the data-gradient layouts.  A layout is refreshed here once a call has taken it (the first iteration packs lazily as
         before); ``ps.fresh`` is the iteration's token, the wrappers' own repack calls see it and do nothing."""
         ps = self.ps
-        side = ps.side.stream if _TRAIN_PREPACK and getattr(self, "_prepack_armed", False) else None   # armed by forward_backward only
+        side = ps.side.stream if R.train_prepack and getattr(self, "_prepack_armed", False) else None   # armed by forward_backward only
         self._prepack_armed = False
         self._pack_events = None
         if side is None:

@@ -71,11 +71,11 @@ def test_linear_matches_the_convolution_route_bitwise_on_plain_sums(dev):
     g = torch.Generator().manual_seed(5)
     x, w, b = torch.randn((16384, 256), generator=g).to(dev), (torch.randn((512, 256), generator=g) / 16).to(dev), torch.randn((512,), generator=g).to(dev)
     new = ops.GemmLayer(w, b)
-    ops._LINEAR_ON = False
+    ops.R.linear = False
     try:
         old = ops.GemmLayer(w, b)
     finally:
-        ops._LINEAR_ON = True
+        ops.R.linear = True
     assert new.linear and not old.linear
     assert torch.equal(new(x), old(x))
 

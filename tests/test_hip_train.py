@@ -515,7 +515,7 @@ def test_prepack_on_a_delayed_side_stream_is_bit_identical(dev, golden, monkeypa
     from partner_amd import train as T
 
     def run(prepack: bool, delay: bool):
-        monkeypatch.setattr(T, "_TRAIN_PREPACK", prepack)
+        monkeypatch.setattr(T.R, "train_prepack", prepack)      # (routes.R: the one switch object every stage module reads)
         g, m, ts, tg, pts, gi = _small_train_setup(dev, golden)
         if delay:
             side = ts.ps.side

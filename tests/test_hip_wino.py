@@ -570,10 +570,10 @@ def test_frames_in_flight_hint_changes_the_form_not_the_result(dev):
     layer = ops.ConvLayer(w, stride=1, pad=1, shift=shift, act=ops.ACT_RELU)
     y1 = layer(x).clone()
     with ops.frames_in_flight(4):
-        assert ops._FRAMES_IN_FLIGHT == 4
+        assert ops.S.frames_in_flight == 4
         y4 = layer(x).clone()
         y4b = layer(x).clone()
-    assert ops._FRAMES_IN_FLIGHT == 1
+    assert ops.S.frames_in_flight == 1
     r = ref64(x, w, None, shift, True)
     for y in (y1, y4):
         assert float((y.double() - r).abs().max() / r.abs().max()) < 2e-5
@@ -723,12 +723,12 @@ def test_rpn_blocks_run_as_chains_and_match_the_layerwise_path(dev):
         ops.disable_conv_profiling()
     assert sum(v[2] for t, v in tags.items() if "chain" in t) == 13, tags
     assert sum(v[2] for t, v in tags.items() if "F(2,3)xF(4,3) chain" in t) == 8, tags      # the 256 x 256 and 128 x 128 blocks; 64 x 64 alone on the chip: 1-D
-    keep = ops._CHAIN_ON
-    ops._CHAIN_ON = False
+    keep = ops.R.conv_chain
+    ops.R.conv_chain = False
     try:
         y0 = neck.forward_nhwc(x)
     finally:
-        ops._CHAIN_ON = keep
+        ops.R.conv_chain = keep
     assert float((y - y0).abs().max() / y0.abs().max()) < 1e-5
 
 
@@ -762,12 +762,12 @@ def test_conv_chain_takes_f43xf43_where_its_blocks_fill_the_chip(dev):
         for w, sh in zip(ws, shs):
             r = ref64(r, w, None, sh, True)
         assert float((y.double() - r).abs().max() / r.abs().max()) < 4e-5, (b, fif)
-    keep = ops._CHAIN44_ON
-    ops._CHAIN44_ON = False
+    keep = ops.R.conv_chain44
+    ops.R.conv_chain44 = False
     try:
         _, n44, n24 = run(torch.randn((4, 128, 128, 128), generator=g).to(dev), 2)
     finally:
-        ops._CHAIN44_ON = keep
+        ops.R.conv_chain44 = keep
     assert (n44, n24) == (0, 2)
 
 

@@ -41,9 +41,9 @@ for (m, k, n, act, res) in shapes:
     r = torch.randn((m, n), generator=g).to(dev) if res else None
     new = ops.GemmLayer(w, b)
     assert new.linear
-    ops._LINEAR_ON = False
+    ops.R.linear = False
     old = ops.GemmLayer(w, b)
-    ops._LINEAR_ON = True
+    ops.R.linear = True
     y_new, y_old = new(x, act=act, residual=r), old(x, act=act, residual=r)
     rows = torch.randint(0, m, (256,), generator=g)
     ref = x[rows].double().cpu() @ w.double().cpu().T + b.double().cpu()

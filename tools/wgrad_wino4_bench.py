@@ -11,10 +11,10 @@ for (b, h, w, cin, cout) in [(1, 8, 16, 8, 12), (2, 33, 64, 36, 20), (4, 256, 25
     torch.manual_seed(0)
     x = torch.randn((b, h, w, cin), device=dev)
     dy = torch.randn((b, h, w, cout), device=dev)
-    ops._WGRAD_WINO4_MIN_QUADS = 0
-    ops._WGRAD_WINO4 = True
+    ops.R.conv_wgrad_wino4_min_quads = 0
+    ops.R.conv_wgrad_wino4 = True
     g4 = ops.conv_wgrad(x, dy, 3, 3, 1, 1)
-    ops._WGRAD_WINO4 = False
+    ops.R.conv_wgrad_wino4 = False
     gd = ops.conv_wgrad(x, dy, 3, 3, 1, 1)
     xr = x.permute(0, 3, 1, 2).double().requires_grad_(False)
     wt = torch.zeros((cout, cin, 3, 3), dtype=torch.float64, device=dev, requires_grad=True)
@@ -30,6 +30,6 @@ for (b, h, w, cin, cout) in [(1, 8, 16, 8, 12), (2, 33, 64, 36, 20), (4, 256, 25
         for _ in range(n): fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e3
-    ops._WGRAD_WINO4 = True; t4 = t(lambda: ops.conv_wgrad(x, dy, 3, 3, 1, 1))
-    ops._WGRAD_WINO4 = False; td = t(lambda: ops.conv_wgrad(x, dy, 3, 3, 1, 1))
+    ops.R.conv_wgrad_wino4 = True; t4 = t(lambda: ops.conv_wgrad(x, dy, 3, 3, 1, 1))
+    ops.R.conv_wgrad_wino4 = False; td = t(lambda: ops.conv_wgrad(x, dy, 3, 3, 1, 1))
     print(f"{b}x{h}x{w} {cin}->{cout}: err F(4,3) {e4:.2e} direct {ed:.2e} | F(4,3) {t4:.1f} us  direct {td:.1f} us  x{td / t4:.2f}")
