@@ -77,6 +77,9 @@ unsigned long long* pn_wchain_stamp_buffer = nullptr;
 #else
 #define WC_STAMP(k) do { } while (0)
 #endif
+#ifndef PN_WC3_EXP
+#define PN_WC3_EXP 0      // diagnostic builds only (tools/micro/wchain3_ablate.hip), conv_wchain3_kernel: bit 0 no MFMAs, 1 no join, 2 no finish
+#endif
 #ifndef PN_WCHAIN_EXP
 #define PN_WCHAIN_EXP 0   // diagnostic builds only (tools/micro/wchain_check.hip), 2-D kernel's K loop: bit 0 no height transform, 1 no plane loads, 2 no weight loads
 #endif
@@ -543,7 +546,10 @@ __device__ __forceinline__ void wchain3_kloop(const WChainArgs& a, const __amdgp
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int s2 = 0; s2 < 3; ++s2) acc[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[slot][s2][j], b[s2][j], acc[s2], 0, 0, 0);
+        for (int s2 = 0; s2 < 3; ++s2) {
+          if (PN_WC3_EXP & 1) acc[s2][0] += u[slot][s2][j] * b[s2][j];      // (keeps the operands alive)
+          else acc[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[slot][s2][j], b[s2][j], acc[s2], 0, 0, 0);
+        }
       __builtin_amdgcn_sched_barrier(0);
       load_step(nx, slot);
       __builtin_amdgcn_sched_barrier(0);
@@ -598,9 +604,12 @@ __global__ __launch_bounds__(64 * 12) void conv_wchain3_kernel(WChainArgs a) {
       for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
     if (sh == 0) wchain3_kloop<0>(a, rsrc_v, rsrc_w, p, voff, uoff, acc);
     else wchain3_kloop<1>(a, rsrc_v, rsrc_w, p, voff, uoff, acc);
+    if (PN_WC3_EXP & 2) {      // no join: the accumulators only have to stay alive
+      if (acc[0][0] + acc[1][3] + acc[2][7] == 1234.5f) J[lane] = f32x4{acc[0][1], acc[1][1], acc[2][1], 0.f};
+    }
     if (sub > 0) __syncthreads();      // the previous half's join has been read
     // this half's share of the four output rows (A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1])
-    if (sh == 0) {
+    if (sh == 0 && !(PN_WC3_EXP & 2)) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 r0, r1, r2;
@@ -618,7 +627,7 @@ __global__ __launch_bounds__(64 * 12) void conv_wchain3_kernel(WChainArgs a) {
       }
     }
     __syncthreads();
-    if (sh == 1) {
+    if (sh == 1 && !(PN_WC3_EXP & 2)) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 r0, r1, r2, r3;
@@ -638,7 +647,7 @@ __global__ __launch_bounds__(64 * 12) void conv_wchain3_kernel(WChainArgs a) {
       }
     }
     __syncthreads();
-    for (int vw = w; vw < 16; vw += NW) {
+    for (int vw = w; vw < ((PN_WC3_EXP & 4) ? 0 : 16); vw += NW) {
       const int g = vw >> 2, row = vw & 3;
       const int c0 = ctile * 32 + 8 * g + 4 * lh;
       if constexpr (QT == 1) {
