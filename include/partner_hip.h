@@ -539,6 +539,20 @@ int pn_linear_f32(const float *x, int m, int k, int ldx, const float *packed_w, 
  * never depend on a form picked behind its back. */
 int pn_linear_ksplit_f32(const float *x, int m, int k, int ldx, const float *packed_w, int n, const float *bias, int act,
                          const float *residual, int ldr, float *out, int ldo, pn_stream_t stream);
+/* ---------------------------------------------------------------------------------------
+ * Gradient exchange of the DDP training step for hosts that do not go through torch.distributed (r6; SURVEY 8(b) "optional"): a thin wrapper
+ * over RCCL.  Replaces what the reference's trainer gets from torch.nn.parallel.DistributedDataParallel (det3d/torchie/apis/train.py:325-336:
+ * one process per GPU, NCCL backend; coalesced all-reduce det3d/core/utils/dist_utils.py:8-57) and the parameter broadcast of its construction.
+ * One communicator per process on the CURRENT device; collectives are enqueued on the caller's HIP stream, nothing synchronises the host.
+ * RCCL is bound at run time (dlopen on the first call): the library loads without it and these entry points then fail with PN_ERR_INVALID.
+ *   pn_comm_unique_id: rank 0 draws the 128-byte id (pn_comm_unique_id_bytes) and hands it to the other ranks by the host's side channel
+ *   pn_allreduce_f32: out[i] = sum (op 0) / max (op 1) over the ranks of in[i]; in == out allowed.  pn_broadcast_f32: rank root's buffer to all. */
+size_t pn_comm_unique_id_bytes(void);
+int pn_comm_unique_id(void *id_out);
+int pn_comm_create(const void *id, int rank, int world, void **comm_out);
+int pn_comm_destroy(void *comm);
+int pn_allreduce_f32(void *comm, const float *in, float *out, size_t count, int op, pn_stream_t stream);
+int pn_broadcast_f32(void *comm, float *buf, size_t count, int root, pn_stream_t stream);
 /* pn_linear_f32 with a LayerNorm folded around it (r6): the norm -> Linear pairs of the attention block and of the Swin stage
  * (set_transformer.py:160-165 `x + mlp(norm2(x))`, sw2votev4_util.py:127-188 `attn(norm1(x))`, `mlp(norm2(x))`) without the normalised
  * tokens ever being written.  LayerNorm(x) W^T + b = rstd (x (W gamma)^T - mean colsum) + (b + W beta), so the normalisation is an affine

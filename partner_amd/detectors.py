@@ -544,15 +544,27 @@ class VoxelNetV3(SingleStageDetector):
         out.pop("_feat", None)
         return {k: v.permute(0, 3, 1, 2) for k, v in out.items()}
 
+    def extract_feat_dynamic(self, data):
+        """voxelnet.py:228-237: dynamic voxel encoder -> sparse backbone on unq -> RPN.  As in the reference this branch does NOT pass through
+        the re-alignment attention (only ``extract_feat_hard`` does); returns the NHWC neck output"""
+        feats, unq = self.reader(data)
+        x = self.backbone.forward_nhwc(feats, unq.to(torch.int32), data["batch_size"], [int(v) for v in data["grid_size"]])
+        return self.neck.forward_nhwc(x) if self.with_neck else x
+
     def forward(self, example, return_loss=True, **kwargs):
-        """hard-voxel branch of voxelnet.py:239-301 (the Waymo PARTNER config); example keys: voxels (V,P,F), coordinates (V,4)
-        [b,z,y,x], num_points (V,), num_voxels (B,), shape [[x,y,z]]"""
+        """voxelnet.py:239-301.  Hard-voxel branch (the Waymo PARTNER config): example keys voxels (V,P,F), coordinates (V,4) [b,z,y,x],
+        num_points (V,), num_voxels (B,), shape [[x,y,z]]; dynamic branch (r6): points, grid_ind, num_points, voxel_size, pc_range, grid_size"""
         if "voxels" not in example:
-            raise NotImplementedError("VoxelNetV3: only the hard-voxel branch of the PARTNER config is built")
-        hip.require_device(example["voxels"], example["coordinates"])
-        data = dict(features=example["voxels"], num_voxels=example["num_points"], coors=example["coordinates"],
-                    batch_size=len(example["num_voxels"]), input_shape=[int(v) for v in example["shape"][0]])
-        x = self.extract_feat_hard(data)
+            hip.require_device(example["points"], example["grid_ind"])
+            data = dict(points=example["points"], grid_ind=example["grid_ind"], num_points=example["num_points"],
+                        batch_size=len(example["num_points"]), voxel_size=example["voxel_size"][0], pc_range=example["pc_range"][0],
+                        grid_size=example["grid_size"][0])
+            x = self.extract_feat_dynamic(data)
+        else:
+            hip.require_device(example["voxels"], example["coordinates"])
+            data = dict(features=example["voxels"], num_voxels=example["num_points"], coors=example["coordinates"],
+                        batch_size=len(example["num_voxels"]), input_shape=[int(v) for v in example["shape"][0]])
+            x = self.extract_feat_hard(data)
         head_out = self.bbox_head.forward_nhwc(x) if hasattr(self.bbox_head, "forward_nhwc") else None
         if head_out is not None:
             head_out.pop("_feat", None)

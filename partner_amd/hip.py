@@ -210,6 +210,12 @@ SIGNATURES = {
     "pn_conv3x3_tap_sum_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
     "pn_conv2d_nhwc_planes_supported": (_I, [_P]),
     "pn_conv2d_nhwc_planes_f32": (_I, [_P, _P, _P, _P, _P, _P, _P]),
+    "pn_comm_unique_id_bytes": (_SZ, []),
+    "pn_comm_unique_id": (_I, [_P]),
+    "pn_comm_create": (_I, [_P, _I, _I, _P]),
+    "pn_comm_destroy": (_I, [_P]),
+    "pn_allreduce_f32": (_I, [_P, _P, _P, _SZ, _I, _P]),
+    "pn_broadcast_f32": (_I, [_P, _P, _SZ, _I, _P]),
     "pn_linear_packed_weight_floats": (_SZ, [_I, _I]),
     "pn_pack_linear_weight_f32": (_I, [_P, _I, _I, _P, _P]),
     "pn_linear_set_tile": (_I, [_I]),

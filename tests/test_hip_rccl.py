@@ -128,3 +128,59 @@ def test_bench_train_two_ranks_on_nccl():
     assert np.isfinite(tr["ms_per_iter"]) and tr["ms_per_iter"] > 0
     assert tr["exposed_exchange_ms"] is not None and np.isfinite(tr["exposed_exchange_ms"])
     assert np.isfinite(tr["last_loss"])
+
+
+def _capi_comm_child(q):
+    """fresh interpreter: the C ABI's own RCCL wrapper (csrc/comm.hip) on a one-rank communicator"""
+    import ctypes as C
+    import torch
+    from partner_amd import hip
+    out = {}
+    try:
+        lib = hip.load()
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        n = lib.pn_comm_unique_id_bytes()
+        uid = (C.c_char * n)()
+        hip.call("pn_comm_unique_id", uid)
+        comm = C.c_void_p()
+        hip.call("pn_comm_create", uid, 0, 1, C.byref(comm))
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            v = torch.arange(1 << 18, dtype=torch.float32, device=dev) * 0.5 - 7.0
+            ref = v.clone()
+            o = torch.empty_like(v)
+            hip.call("pn_allreduce_f32", comm, v.data_ptr(), o.data_ptr(), v.numel(), 0, hip.stream())       # out of place, sum
+            hip.call("pn_allreduce_f32", comm, v.data_ptr(), v.data_ptr(), v.numel(), 1, hip.stream())       # in place, max
+            hip.call("pn_broadcast_f32", comm, v.data_ptr(), v.numel(), 0, hip.stream())
+        st.synchronize()
+        out["sum_equal"], out["inplace_equal"] = bool(torch.equal(o, ref)), bool(torch.equal(v, ref))
+        try:
+            hip.call("pn_allreduce_f32", comm, v.data_ptr(), o.data_ptr(), v.numel(), 5, hip.stream())
+            out["bad_op_raises"] = False
+        except hip.PartnerHipError:
+            out["bad_op_raises"] = True
+        hip.call("pn_comm_destroy", comm)
+        out["ok"] = True
+    except Exception as e:  # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    q.put(out)
+
+
+def test_capi_rccl_wrapper_one_rank():
+    """pn_comm_* / pn_allreduce_f32 / pn_broadcast_f32 (r6, SURVEY 8(b) optional row): the C ABI's direct RCCL binding -- unique id, one-rank
+    communicator on the current device, sum / max all-reduce out of place and in place and a broadcast on a side stream leave a one-rank buffer
+    as it was; a bad reduction code fails loudly"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_capi_comm_child, args=(q,))
+    p.start()
+    try:
+        out = q.get(timeout=300)
+    finally:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    assert out.get("ok"), out
+    assert out["sum_equal"] and out["inplace_equal"] and out["bad_op_raises"], out
