@@ -116,3 +116,31 @@ def broadcast_flat_params(flat_p: torch.Tensor, src: int = 0, force: bool = Fals
     det3d/torchie/apis/train.py:330-336)"""
     if _group_live(force):
         dist.broadcast(flat_p, src=src)
+
+
+class BufferSync:
+    """DistributedDataParallel's ``broadcast_buffers=True`` (its default, which det3d/torchie/apis/train.py:330-336 keeps): at the start of every
+    forward rank 0's BUFFERS -- the BatchNorm running statistics -- replace every other rank's, so the ranks never drift apart in what an
+    evaluation between epochs would see.  (The reference converts to SyncBN only when apex is installed; without it -- "No APEX!" -- this
+    broadcast is all the coupling the BatchNorm layers of the ranks have, and it is what this class reproduces.)
+    The floating-point buffers of ``model`` are re-pointed, once, at views of ONE flat tensor (as ParamStore does with the parameters), so a
+    sync is a single broadcast with no packing; integer buffers (``num_batches_tracked``) advance in lock step and are left alone."""
+
+    def __init__(self, model: torch.nn.Module, device=None):
+        bufs = [(n, b) for n, b in model.named_buffers() if b is not None and b.dtype == torch.float32 and b.numel() > 0]
+        device = device if device is not None else (bufs[0][1].device if bufs else torch.device("cpu"))
+        self.names = [n for n, _ in bufs]
+        self.total = sum(b.numel() for _, b in bufs)
+        self.flat = torch.empty(self.total, dtype=torch.float32, device=device)
+        off = 0
+        for _, b in bufs:
+            n = b.numel()
+            view = self.flat[off:off + n].view(b.shape)
+            view.copy_(b.detach().to(device))
+            b.data = view
+            off += n
+
+    def sync(self, src: int = 0, force: bool = False) -> None:
+        """rank ``src``'s buffers to every rank (one broadcast); a no-op without a process group of more than one rank (unless ``force``)"""
+        if self.total and _group_live(force):
+            dist.broadcast(self.flat, src=src)

@@ -794,6 +794,13 @@ class PolarPillarTrainStep:
         # of a one-GPU box; the result is the no-exchange step's, bit for bit
         force = bool(getattr(self, "exchange_at_world_1", False)) and world == 1 and dist.is_available() and dist.is_initialized()
         self._exchange = GradExchange(self.ps.flat_g, self.buckets, force=force) if (world > 1 or force) and getattr(self, "exchange_enabled", True) else None
+        # DDP's broadcast_buffers=True (the reference's setting, dist_utils.BufferSync): rank 0's BatchNorm running statistics to every rank
+        # at the start of the forward -- one broadcast of one flat tensor, queued in front of the iteration
+        if (world > 1 or force) and getattr(self, "broadcast_buffers", True) and getattr(self, "exchange_enabled", True):
+            if getattr(self, "_bufsync", None) is None:
+                from .dist_utils import BufferSync
+                self._bufsync = BufferSync(self.model, self.dev)
+            self._bufsync.sync(force=force)
         # the reference averages the gradients over ranks (dist_utils.py:17-28): fold 1/world into the loss gradient
         try:
             loss = self.forward_backward(points, sample_offsets, batch, targets, grid_ind, grad_scale=1.0 / world)

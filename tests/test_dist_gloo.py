@@ -241,3 +241,44 @@ def test_grad_exchange_single_process_is_inert():
     ex.ready(0)
     ex.finish()
     assert torch.equal(flat, torch.ones(8))
+
+
+def _buffer_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from partner_amd import dist_utils as D
+    assert D.init("gloo") is True
+    torch.manual_seed(7)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3, bias=False), torch.nn.BatchNorm2d(5), torch.nn.Conv2d(5, 4, 1), torch.nn.BatchNorm2d(4))
+    bs = D.BufferSync(model)
+    with torch.no_grad():                       # every rank's running statistics drift apart (per-rank batches)...
+        model[1].running_mean += 1.0 + rank
+        model[3].running_var *= 2.0 + rank
+    mine = [model[1].running_mean.clone(), model[3].running_var.clone()]
+    bs.sync()
+    # ... the modules see rank 0's values afterwards (their buffers ARE views of the flat tensor), integer buffers untouched
+    q.put((rank, [t.numpy() for t in mine], model[1].running_mean.numpy().copy(), model[3].running_var.numpy().copy(), bs.total, sorted(bs.names),
+           int(model[1].num_batches_tracked)))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_buffer_broadcast_like_ddp():
+    """dist_utils.BufferSync = DistributedDataParallel(broadcast_buffers=True) of det3d/torchie/apis/train.py:330-336: rank 0's BatchNorm running
+    statistics replace every rank's with ONE broadcast of a flat tensor the module buffers are views of"""
+    import numpy as np
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_buffer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert not np.array_equal(res[0][1][0], res[1][1][0])                 # they had drifted apart
+    for k in (2, 3):
+        np.testing.assert_array_equal(res[0][k], res[1][k])               # ... and agree afterwards
+    np.testing.assert_array_equal(res[1][2], res[0][1][0])                # on rank 0's values
+    np.testing.assert_array_equal(res[1][3], res[0][1][1])
+    assert res[0][4] == 5 + 5 + 4 + 4 and res[0][5] == ["1.running_mean", "1.running_var", "3.running_mean", "3.running_var"] and res[0][6] == 0
