@@ -443,7 +443,8 @@ class E2ESWVoteHead(nn.Module):
         import torch.distributed as dist
         lib = hip.load()
         if len(preds_dicts["det_preds"]) != 1:
-            raise NotImplementedError("E2ESWVoteHead.loss: one task (the reference's Waymo config has one)")
+            raise ValueError("E2ESWVoteHead.loss: one prediction dict -- the reference's forward builds ONE set of branches and returns "
+                             "{'det_preds': [ret_dict]} (e2e_swv_head.py:150-173), so its task loop (:211) runs once")
         pd = preds_dicts["det_preds"][0]
         gbox = example["global_box"]
         if not torch.is_tensor(gbox):
@@ -512,7 +513,8 @@ class E2ESWVoteHead(nn.Module):
         if kwargs.get("prev_dets") is not None or kwargs.get("sec_id", 0) != 0:
             raise NotImplementedError("predict: sector streaming (prev_dets / sec_id > 0) is not built")
         if len(preds_dicts["det_preds"]) != 1:
-            raise NotImplementedError("E2ESWVoteHead.predict: one task (the reference's Waymo config has one)")
+            raise ValueError("E2ESWVoteHead.predict: one prediction dict (the reference's forward returns one, e2e_swv_head.py:150-173; its "
+                             "task loop at :276 runs once)")
         nms = get("nms")
         nget = (lambda k: nms[k]) if isinstance(nms, dict) else (lambda k: getattr(nms, k))
         pre_max, post_max, iou_thr = int(nget("nms_pre_max_size")), int(nget("nms_post_max_size")), float(nget("nms_iou_threshold"))

@@ -415,8 +415,6 @@ class PolarPillarTrainStep:
         self.plain_head = type(head).__name__ == "CenterHead"
         if not (isinstance(head, CenterHeadSingle) or self.plain_head):
             raise NotImplementedError("training step: the head must be CenterHead, CenterHeadSingle or CenterHeadSinglePos")
-        if self.plain_head and len(head.tasks) != 1:
-            raise NotImplementedError("training step: the plain CenterHead is supported with a single task")
         reader._check_supported()
         dev = next(model.parameters()).device
         hip.require_device(next(model.parameters()))
@@ -469,14 +467,17 @@ class PolarPillarTrainStep:
         self.has_pos = False
         if self.plain_head:
             self.shared = _ConvReLU(ps, hp + "shared_conv.0.weight", hp + "shared_conv.0.bias", 1)
+            # one set of branches per task (center_head.py:166-242: `for task in self.tasks`); r6: any number of tasks -- the branch key is
+            # (task, name), every task has its own loss (center_head.py:250: one term per task, summed by the trainer) and its own targets
             self.branches = {}
-            task = head.tasks[0]
-            for name in task.heads:
-                convs = [(i, mod) for i, mod in enumerate(getattr(task, name)._modules.values()) if isinstance(mod, nn.Conv2d)]
-                bp = f"{hp}tasks.0.{name}."
-                hidden = [_ConvReLU(ps, f"{bp}{i}.weight", f"{bp}{i}.bias", mod.padding[0]) for i, mod in convs[:-1]]
-                i, mod = convs[-1]
-                self.branches[name] = ("plain", hidden, _Conv(ps, f"{bp}{i}.weight", f"{bp}{i}.bias", 1, mod.padding[0]), 1)
+            self.task_ncls = [int(n) for n in head.num_classes]
+            for t, task in enumerate(head.tasks):
+                for name in task.heads:
+                    convs = [(i, mod) for i, mod in enumerate(getattr(task, name)._modules.values()) if isinstance(mod, nn.Conv2d)]
+                    bp = f"{hp}tasks.{t}.{name}."
+                    hidden = [_ConvReLU(ps, f"{bp}{i}.weight", f"{bp}{i}.bias", mod.padding[0]) for i, mod in convs[:-1]]
+                    i, mod = convs[-1]
+                    self.branches[(t, name)] = ("plain", hidden, _Conv(ps, f"{bp}{i}.weight", f"{bp}{i}.bias", 1, mod.padding[0]), 1)
             return
         rs = head.shared_conv[1]
         assert isinstance(rs, RSNorm)
@@ -574,12 +575,16 @@ class PolarPillarTrainStep:
         self.xs, self.x_hm = xs, x_hm
         preds = {}
         self.branch_mid = {}
+        self.preds_tasks = None
         for name, (kind, first, last, groups) in self.branches.items():
             if kind == "plain":
+                t, nm = name
+                if self.preds_tasks is None:
+                    self.preds_tasks = [dict() for _ in self.task_ncls]
                 z = xs
                 for layer in first:
                     z = layer.fwd(z)
-                preds[name] = last.fwd(z)
+                self.preds_tasks[t][nm] = last.fwd(z)
                 continue
             z = first.fwd(x_hm if name == "hm" else xs)
             self.branch_mid[name] = z
@@ -595,22 +600,37 @@ class PolarPillarTrainStep:
                     preds[nm] = y[..., k * dim:(k + 1) * dim]
             else:
                 preds[name] = y
+        if self.preds_tasks is not None:
+            preds = self.preds_tasks[0]
         self.preds = preds
         return preds
 
-    def _loss_sources(self):
-        order = ["reg", "height", "dim"] + (["vel"] if "vel" in self.preds else []) + ["rot"]
-        return order, [(self.preds[k], self.preds[k].shape[3]) for k in order]
+    def _loss_sources(self, preds=None):
+        preds = self.preds if preds is None else preds
+        order = ["reg", "height", "dim"] + (["vel"] if "vel" in preds else []) + ["rot"]
+        return order, [(preds[k], preds[k].shape[3]) for k in order]
+
+    def _task_list(self, targets):
+        """-> [(prediction dict, class count, targets)] per task; a single-task step takes its targets bare, several tasks a list"""
+        if getattr(self, "preds_tasks", None) is None or len(self.preds_tasks) == 1:
+            tg = targets[0] if isinstance(targets, (list, tuple)) else targets
+            return [(self.preds, self.ncls, tg)]
+        assert isinstance(targets, (list, tuple)) and len(targets) == len(self.preds_tasks), "one CenterLossTargets per task"
+        return [(p, n, tg) for p, n, tg in zip(self.preds_tasks, self.task_ncls, targets)]
 
     # ------------------------------------------------------------------------------------------
     def _backward(self, targets: ops.CenterLossTargets, loss_out, grad_scale: float):
         ps = self.ps
-        order, boxes = self._loss_sources()
-        with_vel = "vel" in self.preds
-        d_hm, d_boxes = ops.center_loss_bwd(self.preds["hm"], self.ncls, boxes, targets, self.code_weights, self.loss_weight, loss_out,
-                                            grad_scale=grad_scale, with_vel=with_vel)
-        d_pred = dict(zip(order, d_boxes))
-        d_pred["hm"] = d_hm
+        tasks = self._task_list(targets)
+        loss_out = loss_out if isinstance(loss_out, (list, tuple)) else [loss_out]
+        multi = len(tasks) > 1
+        d_pred = {}
+        for t, ((preds, ncls, tg), lo) in enumerate(zip(tasks, loss_out)):
+            order, boxes = self._loss_sources(preds)
+            d_hm, d_boxes = ops.center_loss_bwd(preds["hm"], ncls, boxes, tg, self.code_weights, self.loss_weight, lo,
+                                                grad_scale=grad_scale, with_vel="vel" in preds)
+            for nm, d in list(zip(order, d_boxes)) + [("hm", d_hm)]:
+                d_pred[(t, nm) if (multi or self.plain_head) else nm] = d
         d_xs = torch.empty_like(self.xs)
         d_xhm = None
         first_into_xs = True
@@ -742,11 +762,14 @@ class PolarPillarTrainStep:
             self._iter_start.record()     # the previous iteration's optimizer step is queued before it: the packs wait for this, not for the PFN
             self._prepack_armed = True
         try:
-            preds = self._forward(points, sample_offsets, batch, grid_ind)
-            order, boxes = self._loss_sources()
-            loss = ops.center_loss(preds["hm"], self.ncls, boxes, targets, self.code_weights, self.loss_weight, with_vel="vel" in preds)
+            self._forward(points, sample_offsets, batch, grid_ind)
+            losses = []
+            for preds, ncls, tg in self._task_list(targets):
+                order, boxes = self._loss_sources(preds)
+                losses.append(ops.center_loss(preds["hm"], ncls, boxes, tg, self.code_weights, self.loss_weight, with_vel="vel" in preds))
             self._packs_ready(2)
-            self._backward(targets, loss, grad_scale)
+            self._backward(targets, losses, grad_scale)
+            loss = losses[0] if len(losses) == 1 else torch.stack(losses)      # several tasks: one row per task (the trainer sums the det_loss terms)
         finally:
             self.ps.fresh = None
             self._pack_events = None
