@@ -447,59 +447,61 @@ __device__ __forceinline__ void pfn_32_128_heavy(const PfnArgs& a, const float* 
   }
 }
 
-// ---- r5 (late): the same arithmetic on the matrix pipe, WITHOUT giving up a bit.  v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (guide,
+// ---- r5 (late) / r6: the same arithmetic on the matrix pipe, WITHOUT giving up a bit.  v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (guide,
 // "FP32-input MFMA"; conv_mfma.hip's small_n_mfma_body reproduces a vector kernel's bits with it), so layer 0 (16 features, k ascending) and
 // layer 1 (the 32 maxima against W1's columns 32 .. 63, then the 32 activations against columns 0 .. 31 -- the order of the loop above) can run
-// as chains inside MFMAs with POINT ROWS as the 16 columns of a tile: H^T = W0 D^T, Y^T = W1' [M0; H].  The weights are A fragments that live in
-// registers for the whole kernel (136), and layer 0's accumulators ARE layer 1's B operand: W0's rows are fed in the order (16 nt + 4 r + g)
-// for accumulator register r of lane group g, so that K step i = 4 nt + r of layer 1 finds channel 4 i + g in lane group g -- no LDS, no
-// cross-lane traffic between the layers.  A pillar's rows are neighbouring LANES of a 16-lane row: its maxima (layer 0's for M0, layer 1's for
-// the result) are segmented lane scans, skipped when every row of the tile is its own pillar.  Tiles are packed from whole pillars of at most
-// 16 points (consecutive staged rows); larger pillars take the block-per-pillar kernel.  136 MFMAs per 16 point rows against 64 - 96 packed
-// fmas + broadcasts per point.
+// as chains inside MFMAs: H^T = W0 D^T, G^T = W1b M0, Y^T = G^T + W1a H.  Layer 0's accumulators ARE layer 1's B operand: W0's rows are fed in
+// the order (16 nt + 4 r + g) for accumulator register r of lane group g, so that K step i = 4 nt + r of layer 1 finds channel 4 i + g in lane
+// group g -- no LDS, no cross-lane traffic between the layers.
+// r6: the sixteen columns of a tile are sixteen PILLARS, and a pillar's points are successive PASSES of its column (r5 had point rows as columns and
+// a pillar's rows as neighbouring lanes: the two maxima were segmented lane scans, 17 of 124 us at 300 k points, and W1b M0 -- the same for every
+// point of a pillar -- was multiplied once per point).  Now the maxima are elementwise v_max_i32 between passes, G costs 64 MFMAs per sixteen
+// pillars, each pass 8 + 64.  The pillars of a batch are counting-sorted by their number of points (LDS atomics; a pillar's result does not depend on
+// its column or its neighbours, so the order inside a count does not matter), a group of sixteen takes as many passes as its last pillar has
+// points, and a shorter pillar repeats its last point (a maximum does not mind).  At 300 k points (1.7 per pillar): 3.1 k MFMAs per 256 pillars against
+// 3.8 k, no scans.  W1a (64 registers) and W0 (8) stay in registers, W1b is read from a bank-conflict-free LDS copy once per group.  Pillars of more
+// than 16 points take the block-per-pillar kernel.
 constexpr int kTileRows = 16;
-// lane i of a 16-lane row takes the value of lane i + N (row_shl) / i - N (row_shr); lanes without a source keep `old`
-template <int N> __device__ __forceinline__ float row_down(float old, float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, false));
-}
-template <int N> __device__ __forceinline__ float row_up(float old, float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, false));
-}
-// max of two values that are >= 0 (layer outputs behind max(0, .)): the order of their bit patterns as signed integers is their order as
-// floats (-0.0, the one negative pattern fmaxf(0, y) could leave, is the smallest) -- one v_max_i32 instead of fmaxf's canonicalising three
-__device__ __forceinline__ float seg_max(float a, float b, bool take) {
-  const int ia = __builtin_bit_cast(int, a), ib = __builtin_bit_cast(int, b);
-  return __builtin_bit_cast(float, take ? max(ia, ib) : ia);
-}
-template <int N> __device__ __forceinline__ int row_down_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x100 + N, 0xf, 0xf, false); }
-template <int N> __device__ __forceinline__ int row_up_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x110 + N, 0xf, 0xf, false); }
+constexpr int kTileBatchMax = 256, kTileBatchMin = 64;      // pillars per block and round of the tile kernel
+constexpr int kW1bPitch = 36;                               // 36 rho mod 64 are the sixteen multiples of 4: lanes (rho, jj) read 64 different banks
+#ifndef PN_PFN_NB
+#define PN_PFN_NB 0       // diagnostic builds: a fixed batch
+#endif
 #ifndef PN_PFN_EXP
-#define PN_PFN_EXP 0      // diagnostic builds (-DPN_PFN_EXP=k): 1 no tiles at all, 2 layer 1 cut to one K step, 4 no segment scans, 8 no stores -- wrong results, times only
+#define PN_PFN_EXP 0      // diagnostic builds (-DPN_PFN_EXP=k): 1 no groups at all, 2 layer 1 cut to one K step, 16 rows staged in memory order, 32 no point loads, 64 no fixed-point sums, 128 no pillars (prologue only), 512 no azimuth table -- wrong results, times only
 #endif
 __device__ __forceinline__ void pfn_32_128_tiles(const PfnArgs& a, const float* __restrict__ cs_table, const int bid, const int nblk) {
-  constexpr int NB = kFwdBatch, CAP = kFwdPoints;
-  __shared__ int m_s[NB], m_e[NB];
-  __shared__ uint32_t m_key[NB];
-  __shared__ __attribute__((aligned(16))) float m_c[NB][12];  // per pillar: mx my mz mr mp rc pc xc yc, canvas cell (int bits)
-  __shared__ __attribute__((aligned(16))) float p_l[CAP][8];
-  __shared__ unsigned char row_q[CAP];                         // the pillar (index in the batch) of every staged row
-  __shared__ short t_row0[NB], t_rows[NB];
-  __shared__ int t_count;
-  const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
-  const int V = min(*a.v_dev, a.v_cap);
-  const int rho = lane & 15, jj = lane >> 4;
+  // the batch is up to 256 pillars (one per thread), sized from the frame: a 64-pillar batch of a dense multi-sweep frame is ~110 point rows behind
+  // three barrier-separated latency phases (run bounds -> order -> point rows; the per-pillar scalars)
   using f32x4 = __attribute__((ext_vector_type(4))) float;
+  using i32x4 = __attribute__((ext_vector_type(4))) int;
+  constexpr int NBMAX = kTileBatchMax, CAP = kFwdPoints;
+  __shared__ int m_s[NBMAX], m_e[NBMAX];
+  __shared__ uint32_t m_key[NBMAX];
+  __shared__ __attribute__((aligned(16))) float m_c[NBMAX][12];  // per pillar: mx my mz mr mp rc pc xc yc, canvas cell (int bits)
+  __shared__ __attribute__((aligned(16))) float p_l[CAP][8];
+  __shared__ __attribute__((aligned(16))) float w1b_s[128 * kW1bPitch];      // W1's columns 32 .. 63 (the half that meets the pillar maxima)
+  __shared__ unsigned char perm[NBMAX];                        // the sub-batch's pillars (index in the batch) in ascending order of their point count
+  __shared__ int bins[kTileRows + 1], q_stop[4], g_next;
+  const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+  const int V = (PN_PFN_EXP & 128) ? 0 : min(*a.v_dev, a.v_cap);
+  // every block the same number of rounds: share = pillars per block, cut into ceil(share / NBMAX) equal batches
+  const int share = (V + nblk - 1) / nblk, rounds = max(1, (share + NBMAX - 1) / NBMAX);
+  const int NB = PN_PFN_NB ? PN_PFN_NB : min(NBMAX, max(kTileBatchMin, (share + rounds - 1) / rounds));
+  const int rho = lane & 15, jj = lane >> 4;
   // A fragments: lane (row rho of the 16-row tile, k = jj of the step)
-  // (through LDS: a lane's 136 values are 4-byte pieces of 136 different lines -- fetched straight from memory by every wave that was 230 MB of
+  // (through LDS: a lane's values are 4-byte pieces of as many different lines -- fetched straight from memory by every wave that was 230 MB of
   // L2 traffic and 25 us at 30 k points.  The block copies W1 / W0 once, whole lines, W1's columns xor-ed with 4 (row mod 16) so that the
   // sixteen rows a read touches lie in sixteen different banks)
-  float a0[2][4], a1[8][16];
+  float a0[2][4], a1h[8][8];
   {
     float* w1s = &p_l[0][0];      // 128 x 64 floats: the staging rows are not in use yet
     float* w0s = &m_c[0][0];      // 32 x 16
     for (int i = tid; i < 128 * 16; i += 256) {
       const int row = i >> 4, c4 = (i & 15) * 4;
-      *reinterpret_cast<f32x4*>(w1s + row * 64 + (c4 ^ (4 * (row & 15)))) = *reinterpret_cast<const f32x4*>(a.w1 + row * 64 + c4);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(a.w1 + row * 64 + c4);
+      *reinterpret_cast<f32x4*>(w1s + row * 64 + (c4 ^ (4 * (row & 15)))) = w;
+      if (c4 >= 32) *reinterpret_cast<f32x4*>(w1b_s + row * kW1bPitch + (c4 - 32)) = w;
     }
     for (int i = tid; i < 32 * 4; i += 256) *reinterpret_cast<f32x4*>(w0s + i * 4) = *reinterpret_cast<const f32x4*>(a.w0 + i * 4);
     __syncthreads();
@@ -510,8 +512,12 @@ __device__ __forceinline__ void pfn_32_128_tiles(const PfnArgs& a, const float* 
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) a1[mt][i] = w1s[(16 * mt + rho) * 64 + (((i < 8 ? 32 + 4 * i : 4 * (i - 8)) + jj) ^ (4 * rho))];
+      for (int i = 0; i < 8; ++i) a1h[mt][i] = w1s[(16 * mt + rho) * 64 + ((4 * i + jj) ^ (4 * rho))];
   }      // (the batch loop opens with a barrier: every wave has its fragments before the rows are staged)
+  const int p1_idx = jj == 3 ? 3 : 4 + jj;                                      // y p5 p6 x
+  const int p2_idx = jj == 0 ? 4 : jj == 1 ? 2 : jj == 2 ? 3 : 4;              // y z x y
+  const int c2_idx = jj == 0 ? 1 : jj == 1 ? 2 : jj == 2 ? 7 : 8;              // my mz xc yc
+  const float* w1b_l = w1b_s + rho * kW1bPitch + jj;      // + 16 mt pitch + 4 i: row 16 mt + rho, column 32 + 4 i + jj
   for (int v0 = bid * NB; v0 < V; v0 += nblk * NB) {
     const int nb = min(NB, V - v0);
     __syncthreads();  // the previous batch has been consumed
@@ -525,18 +531,38 @@ __device__ __forceinline__ void pfn_32_128_tiles(const PfnArgs& a, const float* 
     while (q0 < nb) {  // block-uniform
       const int base = m_s[q0];
       if (m_e[q0] - base > kTileRows) { ++q0; continue; }  // the block-per-pillar kernel of the same call takes those
-      int q1 = q0 + 1;
-      while (q1 < nb && m_e[q1] - m_s[q1] <= kTileRows && m_e[q1] - base <= CAP) ++q1;
-      const int npts = m_e[q1 - 1] - base;
-      for (int t = tid; t < npts; t += 256) {
-        const float* src = a.pts + (size_t)a.order[base + t] * a.stride;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) p_l[t][k] = src[k];
+      // the sub-batch ends in front of the first pillar that is large or no longer fits the staging rows: every thread tests one pillar, a ballot
+      // per wave, the minimum over the four waves through LDS (r6: the serial walk -- three dependent LDS reads per pillar, by every thread -- was
+      // 21 of the kernel's 124 us at 300 k points)
+      {
+        const bool stop = tid > q0 && tid < nb && (m_e[tid] - m_s[tid] > kTileRows || m_e[tid] - base > CAP);
+        const unsigned long long sm = __ballot(stop);
+        if (lane == 0) q_stop[wib] = sm ? 64 * wib + __builtin_ctzll(sm) : nb;
+        if (tid <= kTileRows) bins[tid] = 0;
+        if (tid == 64) g_next = 0;
       }
       __syncthreads();
-      // per-pillar scalars, one THREAD per pillar: key decode, cell centre, exact fixed-point means (as in pfn_32_128_main); the pillar's rows
-      if (q0 + tid < q1) {
-        const int q = q0 + tid;
+      const int q1 = min(min(q_stop[0], q_stop[1]), min(q_stop[2], q_stop[3]));
+      const int npts = m_e[q1 - 1] - base;
+      // thread t <-> pillar q0 + t of the sub-batch: its place among the pillars of the same point count
+      const int myq = q0 + tid;
+      int my_cnt = 0, my_slot = 0;
+      if (myq < q1) {
+        my_cnt = m_e[myq] - m_s[myq];
+        my_slot = atomicAdd(&bins[my_cnt], 1);
+      }
+      for (int t = tid; t < npts; t += 256) {
+        const float* src = a.pts + (size_t)((PN_PFN_EXP & 16) ? base + t : a.order[base + t]) * a.stride;
+        float sv[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) sv[k] = (PN_PFN_EXP & 32) ? (float)(t + k) : src[k];
+        *reinterpret_cast<f32x4*>(&p_l[t][0]) = f32x4{sv[0], sv[1], sv[2], sv[3]};      // two 16-byte writes per row (seven 4-byte ones at a 32-byte pitch: 8-way conflicts)
+        *reinterpret_cast<f32x4*>(&p_l[t][4]) = f32x4{sv[4], sv[5], sv[6], 0.f};
+      }
+      __syncthreads();
+      // per-pillar scalars, one THREAD per pillar: key decode, cell centre, exact fixed-point means (as in pfn_32_128_main); the pillar's place
+      if (myq < q1) {
+        const int q = myq;
         uint32_t key = m_key[q];
         const int ri = key % a.R; key /= a.R;
         const int ti = key % a.T; key /= a.T;
@@ -545,8 +571,7 @@ __device__ __forceinline__ void pfn_32_128_tiles(const PfnArgs& a, const float* 
         long long sx = 0, sy = 0, sz = 0, sr = 0, sp = 0;
         for (int i = s; i < e; ++i) {
           const float* p = p_l[i];
-          sr += to_fix(p[0]); sp += to_fix(p[1]); sz += to_fix(p[2]); sx += to_fix(p[3]); sy += to_fix(p[4]);
-          row_q[i] = (unsigned char)q;
+          if (!(PN_PFN_EXP & 64)) { sr += to_fix(p[0]); sp += to_fix(p[1]); sz += to_fix(p[2]); sx += to_fix(p[3]); sy += to_fix(p[4]); }
         }
         const double inv_n = 1.0 / ((double)(e - s) * kFix);
         float* c = m_c[q];
@@ -555,141 +580,108 @@ __device__ __forceinline__ void pfn_32_128_tiles(const PfnArgs& a, const float* 
         const float rc = __fadd_rn(__fmul_rn((float)ri, a.vx), a.xoff);
         c[5] = rc;
         c[6] = __fadd_rn(__fmul_rn((float)ti, a.vy), a.yoff);
-        c[7] = __fmul_rn(rc, cs_table[2 * ti]);
-        c[8] = __fmul_rn(rc, cs_table[2 * ti + 1]);
+        c[7] = (PN_PFN_EXP & 512) ? rc : __fmul_rn(rc, cs_table[2 * ti]);
+        c[8] = (PN_PFN_EXP & 512) ? rc : __fmul_rn(rc, cs_table[2 * ti + 1]);
         c[9] = __builtin_bit_cast(float, (bi * a.T + ti) * a.R + ri);
-      }
-      if (wib == 3) {      // tiles: whole pillars, at most 16 consecutive rows, packed greedily.  One wave: lane k holds pillar k's row count, the walk
-                           // over the <= 64 pillars reads them with v_readlane (scalar arithmetic, no LDS round trip per step)
-        const int nq = (q0 + lane < q1) ? m_e[q0 + lane] - m_s[q0 + lane] : 0;
-        int nt = 0, start = 0, rows = 0;
-        const int np = q1 - q0;
-        for (int k = 0; k < np; ++k) {
-          const int n = __builtin_amdgcn_readlane(nq, k);
-          if (rows + n > kTileRows) {
-            if (lane == 0) { t_row0[nt] = (short)start; t_rows[nt] = (short)rows; }
-            ++nt;
-            start += rows;
-            rows = 0;
-          }
-          rows += n;
-        }
-        if (lane == 0) { t_row0[nt] = (short)start; t_rows[nt] = (short)rows; t_count = nt + 1; }
+        int place = my_slot;
+#pragma unroll
+        for (int n = 1; n < kTileRows; ++n) place += n < my_cnt ? bins[n] : 0;
+        perm[place] = (unsigned char)q;
       }
       __syncthreads();
-      const int ntiles = (PN_PFN_EXP & 1) ? 0 : t_count;
-      for (int t = wib; t < ntiles; t += 4) {
-        const int r0 = t_row0[t], nr = t_rows[t];
-        const bool live = rho < nr;
-        const int row = r0 + (live ? rho : 0);
-        const f32x4 pa = *reinterpret_cast<const f32x4*>(&p_l[row][0]), pb = *reinterpret_cast<const f32x4*>(&p_l[row][4]);
-        const int q = row_q[row];
-        const int qid = live ? q : -1 - rho;      // rows past the tile's last never join a segment
-        const f32x4 ca = *reinterpret_cast<const f32x4*>(&m_c[q][0]), cb = *reinterpret_cast<const f32x4*>(&m_c[q][4]),
-                    cc = *reinterpret_cast<const f32x4*>(&m_c[q][8]);
-        const float rho_ = pa[0], phi = pa[1], z = pa[2], x = pa[3], y = pb[0];
-        const float mx = ca[0], my = ca[1], mz = ca[2], mr = ca[3], mp = cb[0], rc = cb[1], pc = cb[2], xc = cb[3], yc = cc[0];
-        // the 16 features of pfn_32_128_main's layer0; this lane supplies feature 4 k4 + jj of its row to K step k4
-        const float d0[4] = {rho_, phi, z, x}, d1[4] = {y, pb[1], pb[2], x - mx}, d2[4] = {y - my, z - mz, x - xc, y - yc},
-                    d3[4] = {rho_ - mr, phi - mp, rho_ - rc, phi - pc};
-        const float b0 = jj == 0 ? d0[0] : jj == 1 ? d0[1] : jj == 2 ? d0[2] : d0[3];
-        const float b1 = jj == 0 ? d1[0] : jj == 1 ? d1[1] : jj == 2 ? d1[2] : d1[3];
-        const float b2 = jj == 0 ? d2[0] : jj == 1 ? d2[1] : jj == 2 ? d2[2] : d2[3];
-        const float b3 = jj == 0 ? d3[0] : jj == 1 ? d3[1] : jj == 2 ? d3[2] : d3[3];
-        f32x4 h[2];
+      const int np = q1 - q0;
+      const int ngroups = (PN_PFN_EXP & 1) ? 0 : (np + 15) >> 4;
+      // groups from the last (most passes) to the first, each wave taking the next one when it is free: the sorted order makes the costs uneven
+      // (64 + 72 n MFMAs for n passes), a fixed round robin left the waves at 0.7 of their mean load
+      for (;;) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(&g_next, 1);
+        g = ngroups - 1 - __builtin_amdgcn_readfirstlane(g);
+        if (g < 0) break;
+        const int pi = 16 * g + rho;
+        const bool live = pi < np;
+        const int q = perm[live ? pi : 16 * g];
+        const int q_last = perm[min(16 * g + 15, np - 1)];
+        const int n_pass = __builtin_amdgcn_readfirstlane(m_e[q_last] - m_s[q_last]);      // ascending counts: the group's last pillar has the most points
+        const int row0 = m_s[q] - base, last = m_e[q] - m_s[q] - 1;
+        // layer 0 of pass j (the pillar's point min(j, last)): the 16 features of pfn_32_128_main's layer0 -- rho phi z x | y p5 p6 x-mx | y-my z-mz
+        // x-xc y-yc | rho-mr phi-mp rho-rc phi-pc; this lane supplies feature 4 k4 + jj of its column to K step k4: one point component (a 4-byte
+        // LDS read at a lane-constant offset) minus one pillar scalar (read once per group), no selects between them
+        const float* mc = m_c[q];
+        const float c1 = mc[0], c2 = mc[c2_idx], c3 = mc[3 + jj];      // (c1: mx, used by lane group 3 only)
+        auto layer0 = [&](int j, f32x4 (&h)[2]) {
+          const float* pr = p_l[row0 + min(j, last)];
+          const float p0 = pr[jj], p1 = pr[p1_idx], p2 = pr[p2_idx], p3 = pr[jj & 1];
+          const float b0 = p0, b1 = jj == 3 ? p1 - c1 : p1, b2 = p2 - c2, b3 = p3 - c3;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nt][0], b0, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nt][1], b1, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nt][2], b2, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nt][3], b3, acc, 0, 0, 0);
+          for (int nt = 0; nt < 2; ++nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nt][0], b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nt][1], b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nt][2], b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nt][3], b3, acc, 0, 0, 0);
+            h[nt] = __builtin_bit_cast(f32x4, __builtin_elementwise_max(__builtin_bit_cast(i32x4, acc), i32x4{0, 0, 0, 0}));      // max(0, .) on the bit patterns (below)
+          }
+        };
+        // maxima of values >= 0 as signed-integer maxima of their bit patterns (the order of the patterns is the order of the floats; against 0 it
+        // is max(0, .) as well: every negative float, -0.0 included, is a negative integer)
+        f32x4 h0[2], m0[2];
+        layer0(0, h0);
+        m0[0] = h0[0]; m0[1] = h0[1];
+        for (int j = 1; j < n_pass; ++j) {      // wave-uniform
+          f32x4 h[2];
+          layer0(j, h);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[nt][r] = acc[r] > 0.f ? acc[r] : 0.f;
+          for (int nt = 0; nt < 2; ++nt) m0[nt] = __builtin_bit_cast(f32x4, __builtin_elementwise_max(__builtin_bit_cast(i32x4, m0[nt]), __builtin_bit_cast(i32x4, h[nt])));
         }
-        // segments: rows of one pillar are neighbouring lanes of the 16-lane row.  prev / next pillar ids decide; the longest pillar of the
-        // tile bounds the scan distance (wave-uniform)
-        const int q_up = __shfl_up(qid, 1, 16), q_dn = __shfl_down(qid, 1, 16);
-        const bool head = live && (rho == 0 || q_up != qid);
-        const bool multi_lane = live && ((rho > 0 && q_up == qid) || (rho < 15 && q_dn == qid));
-        const bool multi = (PN_PFN_EXP & 4) ? false : __ballot(multi_lane) != 0ull;
-        int maxlen = 1;
-        if (multi) {
-          const int len = live ? m_e[q] - m_s[q] : 1;
-          int ml = len;
+        // G = W1b M0: once per pillar (the pointer depends on the group so that the 64 values are READ here -- hoisted out of the loop they are 64 more
+        // registers than the wave has)
+        const float* w1b_g = w1b_l + (n_pass >> 5);
+        f32x4 gv[8];
 #pragma unroll
-          for (int o = 8; o > 0; o >>= 1) ml = max(ml, __shfl_xor(ml, o, 16));
-          maxlen = __builtin_amdgcn_readfirstlane(ml);      // (the four lane groups hold the same rows)
+        for (int mt = 0; mt < 8; ++mt) gv[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < ((PN_PFN_EXP & 2) ? 1 : 8); ++i) {
+          const float act = m0[i >> 2][i & 3];
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) gv[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1b_g[16 * mt * kW1bPitch + 4 * i], act, gv[mt], 0, 0, 0);
         }
-        f32x4 m0[2] = {h[0], h[1]};
-        if (multi) {
-          // towards the pillar's first row: lane i takes lane i + o while it belongs to the same pillar (a lane without a source keeps a value no row has)
-          auto down = [&](auto O) {
-            constexpr int o = decltype(O)::value;
-            if (o < maxlen) {      // wave-uniform
-              const bool same = row_down_i<o>(0x7fffffff, qid) == qid;
+        // Y = G + W1a H per pass; the running maximum starts at 0 (= the ReLU)
+        i32x4 fv[8];
 #pragma unroll
-              for (int nt = 0; nt < 2; ++nt)
+        for (int mt = 0; mt < 8; ++mt) fv[mt] = i32x4{0, 0, 0, 0};
+        auto layer1 = [&](const f32x4 (&h)[2]) {      // (four row tiles at a time: 16 accumulators in flight beside G and the maxima)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  m0[nt][r] = seg_max(m0[nt][r], row_down<o>(m0[nt][r], m0[nt][r]), same);
-                }
+          for (int mh = 0; mh < 8; mh += 4) {
+            f32x4 yv[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) yv[mt] = gv[mh + mt];
+#pragma unroll
+            for (int i = 0; i < ((PN_PFN_EXP & 2) ? 1 : 8); ++i) {
+              const float act = h[i >> 2][i & 3];
+#pragma unroll
+              for (int mt = 0; mt < 4; ++mt) yv[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[mh + mt][i], act, yv[mt], 0, 0, 0);
             }
-          };
-          down(std::integral_constant<int, 1>{}); down(std::integral_constant<int, 2>{}); down(std::integral_constant<int, 4>{}); down(std::integral_constant<int, 8>{});
-          // the pillar's first row holds its maximum: hand it down the segment
-          auto up = [&](auto O) {
-            constexpr int o = decltype(O)::value;
-            if (o < maxlen) {
-              const bool same = row_up_i<o>(0x7fffffff, qid) == qid;
 #pragma unroll
-              for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  m0[nt][r] = seg_max(m0[nt][r], row_up<o>(m0[nt][r], m0[nt][r]), same);
-                }
-            }
-          };
-          up(std::integral_constant<int, 1>{}); up(std::integral_constant<int, 2>{}); up(std::integral_constant<int, 4>{}); up(std::integral_constant<int, 8>{});
+            for (int mt = 0; mt < 4; ++mt) fv[mh + mt] = __builtin_elementwise_max(fv[mh + mt], __builtin_bit_cast(i32x4, yv[mt]));
+          }
+        };
+        layer1(h0);
+        for (int j = 1; j < n_pass; ++j) {
+          f32x4 h[2];
+          layer0(j, h);
+          layer1(h);
         }
-        f32x4 yv[8];
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) yv[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < ((PN_PFN_EXP & 2) ? 1 : 16); ++i) {
-          const float act = i < 8 ? m0[i >> 2][i & 3] : h[(i - 8) >> 2][(i - 8) & 3];
-#pragma unroll
-          for (int mt = 0; mt < 8; ++mt) yv[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mt][i], act, yv[mt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) yv[mt][r] = fmaxf(0.f, yv[mt][r]);
-        if (multi) {
-          auto down = [&](auto O) {
-            constexpr int o = decltype(O)::value;
-            if (o < maxlen) {
-              const bool same = row_down_i<o>(0x7fffffff, qid) == qid;
-#pragma unroll
-              for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  yv[mt][r] = seg_max(yv[mt][r], row_down<o>(yv[mt][r], yv[mt][r]), same);
-                }
-            }
-          };
-          down(std::integral_constant<int, 1>{}); down(std::integral_constant<int, 2>{}); down(std::integral_constant<int, 4>{}); down(std::integral_constant<int, 8>{});
-        }
-        if (head && !(PN_PFN_EXP & 8)) {      // accumulator register r of lane group jj = channel 16 mt + 4 jj + r: 16 bytes per store
+        if (live) {      // accumulator register r of lane group jj = channel 16 mt + 4 jj + r: 16 bytes per store
           const int v = v0 + q;
-          const int cell = reinterpret_cast<const int*>(&m_c[q][0])[9];      // (read here, as an integer: carried as cc[1] across the MFMAs the value came back as cc[0]'s bits)
+          const int cell = reinterpret_cast<const int*>(&m_c[q][0])[9];
           if (a.feat) {
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) *reinterpret_cast<f32x4*>(a.feat + (size_t)v * 128 + 16 * mt + 4 * jj) = yv[mt];
+            for (int mt = 0; mt < 8; ++mt) *reinterpret_cast<i32x4*>(a.feat + (size_t)v * 128 + 16 * mt + 4 * jj) = fv[mt];
           }
           if (a.canvas) {
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) *reinterpret_cast<f32x4*>(a.canvas + (size_t)cell * 128 + 16 * mt + 4 * jj) = yv[mt];
+            for (int mt = 0; mt < 8; ++mt) *reinterpret_cast<i32x4*>(a.canvas + (size_t)cell * 128 + 16 * mt + 4 * jj) = fv[mt];
           }
         }
       }
@@ -708,7 +700,7 @@ static_assert(kHeavyWaves * 64 == 256, "both bodies of dynamic_pfn_32_128_kernel
 __global__ __launch_bounds__(256) void dynamic_pfn_32_128_main_kernel(PfnArgs a, const float* __restrict__ cs_table) {
   pfn_32_128_main(a, cs_table, blockIdx.x, gridDim.x);
 }
-__global__ __launch_bounds__(256) void dynamic_pfn_32_128_tile_kernel(PfnArgs a, const float* __restrict__ cs_table) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dynamic_pfn_32_128_tile_kernel(PfnArgs a, const float* __restrict__ cs_table) {
   pfn_32_128_tiles(a, cs_table, blockIdx.x, gridDim.x);
 }
 
