@@ -458,14 +458,29 @@ def conv_chain_supported(layers, b: int, h: int, w: int) -> bool:
     return _chain_orientation(layers, b, h, w) is not None
 
 
+def chain_planes(x: torch.Tensor, layers, in_channel_offset: int = 0) -> torch.Tensor:
+    """the F(4, 3) planes of NHWC ``x`` in the orientation ``conv_chain(layers, ...)`` works in, for SEVERAL chains that read the same map
+    (``conv_chain(..., planes=)``: E2ESWVoteHead's class and box / IoU branches) -- one NHWC -> planes pass instead of one per chain"""
+    hip.require_device(x)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    b, h, w, ct = x.shape
+    tr = _chain_orientation(layers, b, h, w)
+    assert tr is not None, "chain_planes: check conv_chain_supported first"
+    lib = hip.load()
+    buf = torch.empty(lib.pn_wino4_planes_floats(b, w if tr else h, h if tr else w, layers[0].cin), dtype=torch.float32, device=x.device)
+    hip.call("pn_wino4_planes_from_nhwc_f32", x.data_ptr(), b, h, w, layers[0].cin, ct, in_channel_offset, int(tr), buf.data_ptr(), hip.stream())
+    return buf
+
+
 def conv_chain(layers, x: Optional[torch.Tensor], out: Optional[torch.Tensor] = None, out_channel_offset=0, in_channel_offset=0, planes_from=None,
-               shape=None, device=None) -> torch.Tensor:
+               shape=None, device=None, planes: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x NHWC (B, H, W, Ct) -> the NHWC output of the last layer.  One launch forms the six F(4, 3) planes of x, then every layer reads
     planes and writes planes (two buffers, alternating); the last one writes the map.  Same arithmetic as the layers one by one
     (ConvLayer.__call__ on pn_conv2d_wino4_nhwc_f32) up to the summation order over the input channels.
     ``planes_from(buffer)`` (with ``shape`` = (B, H, W), ``device``, x None): the producer writes the NOT transposed planes of the first
-    layer's input itself (PillarConvLayer: the map never exists in NHWC)."""
-    if planes_from is None:
+    layer's input itself (PillarConvLayer: the map never exists in NHWC).  ``planes`` (with ``shape``, ``device``, x None): the first layer's
+    input as ``chain_planes`` built it; it is only read (other chains share it)."""
+    if planes_from is None and planes is None:
         hip.require_device(x)
         assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
         b, h, w, ct = x.shape
@@ -476,13 +491,24 @@ def conv_chain(layers, x: Optional[torch.Tensor], out: Optional[torch.Tensor] = 
     tr = _chain_orientation(layers, b, h, w)
     assert tr is not None, "conv_chain: check conv_chain_supported first"
     assert planes_from is None or not tr, "conv_chain: a planes producer writes the map's own orientation"
-    cmax = max([layers[0].cin] + [l.cout for l in layers[:-1]])
-    n = lib.pn_wino4_planes_floats(b, w if tr else h, h if tr else w, cmax)
-    bufs = [torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev) if len(layers) > 1 else None]
-    if planes_from is None:
-        hip.call("pn_wino4_planes_from_nhwc_f32", x.data_ptr(), b, h, w, layers[0].cin, ct, in_channel_offset, int(tr), bufs[0].data_ptr(), st)
+    if planes is not None:      # shared input planes: layer 0 reads them, the layers behind alternate between two buffers of their own
+        nmid = len(layers) - 1
+        n = lib.pn_wino4_planes_floats(b, w if tr else h, h if tr else w, max([8] + [l.cout for l in layers[:-1]]))
+        own = [torch.empty(n, dtype=torch.float32, device=dev) if nmid > k else None for k in range(2)]
+        bufs = None
     else:
-        planes_from(bufs[0])
+        cmax = max([layers[0].cin] + [l.cout for l in layers[:-1]])
+        n = lib.pn_wino4_planes_floats(b, w if tr else h, h if tr else w, cmax)
+        bufs = [torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev) if len(layers) > 1 else None]
+        if planes_from is None:
+            hip.call("pn_wino4_planes_from_nhwc_f32", x.data_ptr(), b, h, w, layers[0].cin, ct, in_channel_offset, int(tr), bufs[0].data_ptr(), st)
+        else:
+            planes_from(bufs[0])
+
+    def src_dst(k):
+        if bufs is not None:
+            return bufs[k & 1], bufs[(k + 1) & 1]
+        return (planes if k == 0 else own[(k - 1) & 1]), own[k & 1]
     last = layers[-1]
     if out is None:
         out = torch.empty((b, h, w, last.cout), dtype=torch.float32, device=dev)
@@ -498,9 +524,10 @@ def conv_chain(layers, x: Optional[torch.Tensor], out: Optional[torch.Tensor] = 
         wts = l.chain_weights(two_d, tr)
         if prof is not None:
             ev = prof.begin(st)
-        hip.call("pn_conv2d_wino44_chain_f32" if two_d == "wino44" else ("pn_conv2d_wino24_chain_f32" if two_d else "pn_conv2d_wino4_chain_f32"), C.byref(d), bufs[k & 1].data_ptr(),
+        src, dst = src_dst(k)
+        hip.call("pn_conv2d_wino44_chain_f32" if two_d == "wino44" else ("pn_conv2d_wino24_chain_f32" if two_d else "pn_conv2d_wino4_chain_f32"), C.byref(d), src.data_ptr(),
                  wts.data_ptr(), hip.ptr(l.scale), hip.ptr(l.shift),
-                 None if is_last else bufs[(k + 1) & 1].data_ptr(), out.data_ptr() if is_last else None, st)
+                 None if is_last else dst.data_ptr(), out.data_ptr() if is_last else None, st)
         if prof is not None:
             flops = 2.0 * b * h * w * l.cout * l.cin * 9
             tag = "F(4,3)xF(4,3) chain" if two_d == "wino44" else ("F(2,3)xF(4,3) chain" if two_d else "F(4,3) chain")

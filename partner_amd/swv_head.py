@@ -25,6 +25,7 @@ import torch
 from torch import nn
 
 from . import hip, ops
+from .routes import R
 from .builder import BBOX_HEADS
 from .nn_utils import PlanCache, Sequential, eval_only
 
@@ -270,10 +271,21 @@ class E2ESWVoteHead(nn.Module):
                 t_stats = None
         feat = ops.layernorm(t, L.norm0.weight, L.norm0.bias, L.norm0.eps).view(b, h, w, C)
         fc = ops.to_bf16(feat) if bf16 else feat
-        hm = plan["cls"][2](plan["cls"][1](plan["cls"][0](fc)), out_f32=True)
+        # r6 (f32): the class branch's two 256 -> 256 convolutions and the box / IoU branches' fused first convolution read the same map: its
+        # F(4, 3) planes are formed once and the three layers run as Winograd-domain chains (F(2,3) x F(4,3): 3 multiplications per output and
+        # tap set against the routed 1-D form's 4.5 -- 715 -> 585 us for the pair, 198 -> 157 us for the third at bs 2, tools/head_conv_forms.py)
+        cls_pair = [plan["cls"][0], plan["cls"][1]]
+        chained = (not bf16 and R.head_chain and plan["box_iou0"] is not None
+                   and ops.conv_chain_orientation(cls_pair, b, h, w) is not None
+                   and ops.conv_chain_orientation(cls_pair, b, h, w) == ops.conv_chain_orientation([plan["box_iou0"]], b, h, w))
+        pl = ops.chain_planes(feat, cls_pair) if chained else None
+        if chained:
+            hm = plan["cls"][2](ops.conv_chain(cls_pair, None, planes=pl, shape=(b, h, w), device=x.device), out_f32=True)
+        else:
+            hm = plan["cls"][2](plan["cls"][1](plan["cls"][0](fc)), out_f32=True)
         iou = None
         if plan["box_iou0"] is not None:
-            mid = plan["box_iou0"](fc)
+            mid = ops.conv_chain([plan["box_iou0"]], None, planes=pl, shape=(b, h, w), device=x.device) if chained else plan["box_iou0"](fc)
             cm = mid.shape[3] // 2
             boxes = plan["bbox"][1](mid, in_channel_offset=0, in_channels=cm, out_f32=True)
             iou = plan["iou"][1](mid, in_channel_offset=cm, in_channels=cm, out_f32=True)
