@@ -145,6 +145,20 @@ int pn_voxel_index_fused_rows_f32(const float *cart, int n_capacity, int f_in, c
                                   uint32_t *cell_count, void *scan_state, size_t scan_state_bytes,
                                   uint32_t *unq_keys, int32_t *voxel_start, int32_t *order,
                                   int32_t *num_voxels, int32_t *row_start, pn_stream_t stream);
+/* The frame index of a MULTI-SWEEP frame straight from its raw sweeps (r6; BASELINE configs[4]; one sample): the accumulation of
+ * pn_accumulate_sweeps_f32 (det3d/datasets/pipelines/loading.py:215-260: remove_close on the non-key sweeps, rigid transform, time lag) and
+ * pn_voxel_index_fused[_rows]_f32 in the same three launches.  raw (n_capacity, raw_cols >= 4) concatenated sweeps, key frame first;
+ * sweep_offsets (sweeps + 1) on the device; transforms (sweeps, 4, 4) float64; time_lags (sweeps).  The kept points are NOT compacted: point i of
+ * the index is row i of raw, a removed point has keys[i] = 0xffffffff, pos[i] = -1 and appears in no voxel; polar (n_capacity, 7) rows
+ * [rho, phi, z, x, y, intensity, dt] of removed points are not written.  row_start: nullable (as pn_voxel_index_fused_rows_f32).  Per kept
+ * point the same arithmetic as the two calls one after the other. */
+int pn_voxel_index_fused_sweeps_f32(const float *raw, int n_capacity, int raw_cols, const int32_t *sweep_offsets,
+                                    int sweeps, const double *transforms, const float *time_lags,
+                                    float min_distance, const float *range_lo, const float *voxel_size,
+                                    const int32_t *grid, float *polar, uint32_t *keys, int32_t *pos,
+                                    uint32_t *cell_count, void *scan_state, size_t scan_state_bytes,
+                                    uint32_t *unq_keys, int32_t *voxel_start, int32_t *order,
+                                    int32_t *num_voxels, int32_t *row_start, pn_stream_t stream);
 /* end of frame: zero the canvas cells (nullable) and the cell_count entries (nullable) of the frame's voxels */
 int pn_clear_frame_cells(const uint32_t *unq_keys, const int32_t *num_voxels, int v_capacity,
                          const int32_t *grid, int c, float *canvas, uint32_t *cell_count,

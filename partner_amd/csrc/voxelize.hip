@@ -259,6 +259,46 @@ __global__ void fused_polar_index_kernel(const float* __restrict__ cart, int n_c
   pos[i] = (int32_t)atomicAdd(&cell_count[key], 1u);
 }
 
+// r6: the same from the RAW sweeps of a multi-sweep frame (BASELINE configs[4]): remove_close, the rigid transform and the time lag of
+// pn_accumulate_sweeps_f32 (assign.hip; det3d/datasets/pipelines/loading.py:215-260) applied on the way, WITHOUT compacting the kept points first
+// -- a removed point gets the key 0xffffffff (no cell has it: cells < 2^32), joins no cell, and order_fill_kernel skips it; its polar row is
+// never read.  Three launches (count, offsets, scatter: 36 us at 300 k points) and the (n, 5) Cartesian copy are gone.  Same arithmetic per kept
+// point as the two steps one after the other (double-precision transform rounded to float, then cart_to_polar_kernel's).
+__global__ void fused_sweeps_index_kernel(const float* __restrict__ raw, int n_cap, int in_cols, const int32_t* __restrict__ sweep_offs, int sweeps,
+                                          const double* __restrict__ mats, const float* __restrict__ lags, float radius, GridParams gp,
+                                          float* __restrict__ polar, uint32_t* __restrict__ keys, int32_t* __restrict__ pos,
+                                          uint32_t* __restrict__ cell_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = min(sweep_offs[sweeps], n_cap);
+  if (i >= n) return;
+  int s = 0;
+  while (s + 1 < sweeps && i >= sweep_offs[s + 1]) ++s;
+  const float* p = raw + (size_t)i * in_cols;
+  float x = p[0], y = p[1], zc = p[2];
+  if (s != 0) {      // the key frame is taken as it is
+    if (fabsf(x) < radius && fabsf(y) < radius) {
+      keys[i] = 0xffffffffu;
+      pos[i] = -1;
+      return;
+    }
+    const double* m = mats + (size_t)s * 16;
+    const double xd = x, yd = y, zd = zc;
+    x = (float)(m[0] * xd + m[1] * yd + m[2] * zd + m[3]);
+    y = (float)(m[4] * xd + m[5] * yd + m[6] * zd + m[7]);
+    zc = (float)(m[8] * xd + m[9] * yd + m[10] * zd + m[11]);
+  }
+  float* o = polar + (size_t)i * 7;
+  const float rho = (float)sqrt((double)__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)));   // as cart_to_polar_kernel
+  const float phi = (float)atan2((double)y, (double)x);
+  o[0] = rho; o[1] = phi; o[2] = zc; o[3] = x; o[4] = y; o[5] = p[3]; o[6] = lags[s];
+  const int r = cell_index(rho, gp.lo[0], gp.vs[0], gp.g[0]);
+  const int t = cell_index(phi, gp.lo[1], gp.vs[1], gp.g[1]);
+  const int z = cell_index(zc, gp.lo[2], gp.vs[2], gp.g[2]);
+  const uint32_t key = (uint32_t)(((size_t)z * gp.g[1] + t) * gp.g[0] + r);
+  keys[i] = key;
+  pos[i] = (int32_t)atomicAdd(&cell_count[key], 1u);
+}
+
 // tile state of the look-back scan: status (2 bits: 0 = nothing yet, 1 = tile aggregate, 2 = inclusive prefix) | occupied
 // cells (30 bits) | points (32 bits).  Written / read with agent-scope relaxed atomics: the tiles of one launch sit on different
 // XCDs whose L2s are not coherent with each other.
@@ -365,7 +405,9 @@ __global__ void order_fill_kernel(const uint32_t* __restrict__ keys, const int32
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = min(*n_dev, n_cap);
   if (i >= n) return;
-  order[cell_count[keys[i]] + (uint32_t)pos[i]] = i;
+  const uint32_t key = keys[i];
+  if (key == 0xffffffffu) return;      // a point fused_sweeps_index_kernel removed
+  order[cell_count[key] + (uint32_t)pos[i]] = i;
 }
 
 // sparse clear at the end of a frame: the canvas cells of the frame's voxels (16 bytes per thread, c / 4 threads per cell) and
@@ -660,6 +702,38 @@ int pn_voxel_index_fused_rows_f32(const float* cart, int n_capacity, int f_in, c
   PN_REQUIRE(row_start, "voxel_index_fused_rows: null pointer");
   return voxel_index_fused(cart, n_capacity, f_in, sample_offsets, batch, range_lo, voxel_size, grid, polar, keys, pos, cell_count, scan_state,
                            scan_state_bytes, unq_keys, voxel_start, order, num_voxels, row_start, stream);
+}
+
+int pn_voxel_index_fused_sweeps_f32(const float* raw, int n_capacity, int raw_cols, const int32_t* sweep_offsets, int sweeps, const double* transforms,
+                                    const float* time_lags, float min_distance, const float* range_lo, const float* voxel_size, const int32_t* grid,
+                                    float* polar, uint32_t* keys, int32_t* pos, uint32_t* cell_count, void* scan_state, size_t scan_state_bytes,
+                                    uint32_t* unq_keys, int32_t* voxel_start, int32_t* order, int32_t* num_voxels, int32_t* row_start,
+                                    pn_stream_t stream) {
+  PN_REQUIRE(raw && sweep_offsets && transforms && time_lags && range_lo && voxel_size && grid && polar && keys && pos && cell_count && scan_state &&
+                 unq_keys && voxel_start && order && num_voxels, "voxel_index_fused_sweeps: null pointer");
+  PN_REQUIRE(n_capacity >= 1 && raw_cols >= 4 && sweeps >= 1, "voxel_index_fused_sweeps: bad sizes");
+  const uint64_t cells = (uint64_t)grid[0] * grid[1] * grid[2];
+  PN_REQUIRE(cells > 0 && cells < 0xffffffffull, "voxel_index_fused_sweeps: more than 2^32 - 1 cells");
+  PN_REQUIRE((uint64_t)n_capacity < (1ull << 30), "voxel_index_fused_sweeps: too many points");
+  PN_REQUIRE(!row_start || grid[0] % kScanItems == 0, "voxel_index_fused_sweeps: the grid's first axis must be a multiple of 8 cells for row_start");
+  if (scan_state_bytes < pn_voxel_index_fused_state_bytes(cells)) return pn::fail(PN_ERR_WORKSPACE, "voxel_index_fused_sweeps: scan state too small");
+  GridParams gp;
+  for (int k = 0; k < 3; ++k) {
+    gp.lo[k] = range_lo[k];
+    gp.vs[k] = voxel_size[k];
+    gp.g[k] = grid[k];
+  }
+  hipStream_t st = pn::S(stream);
+  const int ntiles = (int)((cells + kScanTile - 1) / kScanTile);
+  unsigned long long* tile_state = static_cast<unsigned long long*>(scan_state);
+  uint32_t* counters = reinterpret_cast<uint32_t*>(static_cast<char*>(scan_state) + align256((size_t)ntiles * 8));
+  const int pblocks = pn::cdiv(n_capacity, 256);
+  hipLaunchKernelGGL(fused_sweeps_index_kernel, dim3(pblocks), dim3(256), 0, st, raw, n_capacity, raw_cols, sweep_offsets, sweeps, transforms, time_lags,
+                     min_distance, gp, polar, keys, pos, cell_count);
+  hipLaunchKernelGGL(cell_scan_kernel, dim3(ntiles), dim3(kScanThreads), 0, st, cell_count, (size_t)cells, ntiles, tile_state, counters, unq_keys,
+                     voxel_start, num_voxels, n_capacity, row_start, grid[0]);
+  hipLaunchKernelGGL(order_fill_kernel, dim3(pblocks), dim3(256), 0, st, keys, pos, n_capacity, sweep_offsets + sweeps, cell_count, order);
+  return pn::check_launch("voxel_index_fused_sweeps");
 }
 
 int pn_clear_frame_cells(const uint32_t* unq_keys, const int32_t* num_voxels, int v_capacity, const int32_t* grid, int c, float* canvas,

@@ -140,6 +140,24 @@ class PointPillars(SingleStageDetector):
         self.reader.encode(polar, vi, None, canvas)
         return canvas, vi, polar
 
+    def forward_sweeps(self, raw: torch.Tensor, sweep_offsets: torch.Tensor, transforms: torch.Tensor, time_lags: torch.Tensor, spec: ops.GridSpec,
+                       canvas: torch.Tensor, index_state, canvas_may_stay_dirty: bool = False, min_distance: float = 1.0) -> Dict[str, torch.Tensor]:
+        """``forward_cart`` for ONE multi-sweep frame handed over as its raw sweeps (BASELINE configs[4]): the accumulation
+        (``ops.accumulate_sweeps``: remove_close, rigid transforms, time lags) happens inside the frame index's first launch
+        (``ops.fused_voxel_index_sweeps``, r6) -- no compaction, no Cartesian copy, three launches less.  Same head tensors, bit for bit
+        (the reader's sums and maxima do not depend on the order or the numbering of a pillar's points)."""
+        eval_only(self, "PointPillars")
+        if not isinstance(self.reader, DynamicPFNet):
+            raise NotImplementedError("fused encode path needs a DynamicPFNet reader")
+        hip.require_device(canvas)
+        assert tuple(canvas.shape) == (1, spec.grid[1], spec.grid[0], self.reader.out_channels) and canvas.is_contiguous()
+        polar, vi = ops.fused_voxel_index_sweeps(raw, sweep_offsets, transforms, time_lags, spec, index_state, min_distance)
+        self.reader.encode(polar, vi, None, canvas)
+        x2 = self._neck_on_canvas(canvas, vi)
+        leave = canvas_may_stay_dirty and self.seg_head is None and getattr(self.neck, "canvas_read_by_pillars_only", False)
+        ops.clear_frame_cells(None if leave else canvas, vi, index_state)
+        return self.bbox_head(ops.as_nchw(x2))["det_preds"][0]
+
     def scatter_stage(self, cart: torch.Tensor, sample_offsets: torch.Tensor, batch: int, spec: ops.GridSpec, canvas: torch.Tensor,
                       index_state=None):
         """V0..V5 alone, exactly as a frame of ``forward_cart(canvas=, index_state=)`` runs them (fused frame index, fused PFN

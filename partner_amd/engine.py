@@ -4,11 +4,12 @@ between the ~90 kernels of a frame.  Every kernel of the path is capturable by c
 (no host sync, no allocation inside the C ABI, voxel count stays on the device)."""
 from __future__ import annotations
 
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 
 from . import hip, ops
+from .routes import R
 
 
 class FrameEngine:
@@ -235,8 +236,9 @@ class StreamingFrameEngine:
     PFN -> RPN -> head -> decode + rotated NMS.  Inputs are static device buffers refreshed by ``run``; nothing in the
     replayed graph touches the host (the box count comes back as a device tensor)."""
 
-    def __init__(self, model, n_sweeps: int, raw_capacity: int, test_cfg=None, spec: ops.GridSpec = None, raw_cols: int = 5):
+    def __init__(self, model, n_sweeps: int, raw_capacity: int, test_cfg=None, spec: ops.GridSpec = None, raw_cols: int = 5, fused_sweeps: Optional[bool] = None):
         hip.load()
+        self.fused_sweeps = R.fused_sweeps if fused_sweeps is None else bool(fused_sweeps)
         self.model = model.eval()
         dev = next(model.parameters()).device
         hip.require_device(next(model.parameters()))
@@ -255,13 +257,18 @@ class StreamingFrameEngine:
         self.offsets = torch.zeros(2, dtype=torch.int32, device=dev)   # [0, number of accumulated points]: written by the accumulation kernel
         self.canvas = model.new_canvas(1, self.spec, dev)               # persistent, zero between frames
         self.index_state = model.new_index_state(1, self.spec, dev)
+        self.fused_sweeps = self.fused_sweeps and self.index_state is not None and hasattr(model, "forward_sweeps")
         self.graph = None
         self.outputs: Dict[str, torch.Tensor] = {}
 
     def _step(self):
-        cart, _ = ops.accumulate_sweeps(self.raw, self.sweep_offsets, self.transforms, self.time_lags, 1.0, count=self.offsets[1:2])
-        # rows past the count are ignored downstream
-        preds = self.model.forward_cart(cart, self.offsets, 1, self.spec, canvas=self.canvas, index_state=self.index_state, canvas_may_stay_dirty=True)
+        if self.fused_sweeps:      # r6: accumulation inside the frame index (three launches and the Cartesian copy less)
+            preds = self.model.forward_sweeps(self.raw, self.sweep_offsets, self.transforms, self.time_lags, self.spec, self.canvas, self.index_state,
+                                              canvas_may_stay_dirty=True)
+        else:
+            cart, _ = ops.accumulate_sweeps(self.raw, self.sweep_offsets, self.transforms, self.time_lags, 1.0, count=self.offsets[1:2])
+            # rows past the count are ignored downstream
+            preds = self.model.forward_cart(cart, self.offsets, 1, self.spec, canvas=self.canvas, index_state=self.index_state, canvas_may_stay_dirty=True)
         if self.test_cfg is None:
             return dict(preds)
         return self.model.bbox_head.predict(dict(metadata=[None]), {"det_preds": [preds]}, self.test_cfg, device_only=True)

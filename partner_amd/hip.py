@@ -82,6 +82,7 @@ SIGNATURES = {
     "pn_voxel_index_fused_state_bytes": (_SZ, [_U64]),
     "pn_voxel_index_fused_f32": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _P, _P]),
     "pn_voxel_index_fused_rows_f32": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _P, _P, _P]),
+    "pn_voxel_index_fused_sweeps_f32": (_I, [_P, _I, _I, _P, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _P, _P, _P]),
     "pn_clear_frame_cells": (_I, [_P, _P, _I, _P, _I, _P, _P, _P]),
     "pn_sort_voxel_runs": (_I, [_P, _P, _I, _P, _P, _P]),
     "pn_hard_voxelize_workspace_bytes": (_SZ, [_U64, _I, _I]),

@@ -184,6 +184,32 @@ def fused_voxel_index(cart: torch.Tensor, sample_offsets: torch.Tensor, batch: i
     return polar, vi
 
 
+def fused_voxel_index_sweeps(raw: torch.Tensor, sweep_offsets: torch.Tensor, transforms: torch.Tensor, time_lags: torch.Tensor, spec: GridSpec,
+                             state: FrameIndexState, min_distance: float = 1.0):
+    """the RAW sweeps of one multi-sweep frame (as ``accumulate_sweeps`` takes them) -> (polar (n, 7), VoxelIndex): accumulation and frame
+    index in the three launches of ``fused_voxel_index`` (pn_voxel_index_fused_sweeps_f32, r6).  The kept points are not compacted: point i
+    is row i of ``raw``; removed points are in no voxel and their polar rows are unwritten."""
+    hip.require_device(raw, sweep_offsets, transforms, time_lags)
+    assert raw.is_contiguous() and raw.dtype == torch.float32 and transforms.dtype == torch.float64 and transforms.is_contiguous()
+    assert sweep_offsets.dtype == torch.int32 and state.cells == spec.num_cells(1)
+    n, cols = raw.shape
+    dev = raw.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    polar = torch.empty((n, 7), dtype=torch.float32, device=dev)
+    keys, pos, ukeys, order = (torch.empty((n,), **i32) for _ in range(4))
+    vstart = torch.empty((n + 1,), **i32)
+    nv = torch.empty((1,), **i32)
+    lo, vs, g = spec.c_arrays()
+    row_start = torch.empty((spec.grid[1] + 1,), **i32) if (spec.grid[2] == 1 and spec.grid[0] % 8 == 0 and R.pillar_rows) else None
+    hip.call("pn_voxel_index_fused_sweeps_f32", raw.data_ptr(), n, cols, sweep_offsets.data_ptr(), transforms.shape[0], transforms.data_ptr(),
+             time_lags.data_ptr(), float(min_distance), lo, vs, g, polar.data_ptr(), keys.data_ptr(), pos.data_ptr(), state.cell_count.data_ptr(),
+             state.scan_state.data_ptr(), state.scan_state.numel(), ukeys.data_ptr(), vstart.data_ptr(), order.data_ptr(), nv.data_ptr(),
+             hip.ptr(row_start), hip.stream())
+    vi = VoxelIndex(n, state.cells, spec, 1, None, None, None, nv, vstart, order, ukeys, ukeys.data_ptr())
+    vi.keys, vi.state, vi.row_start = keys, state, row_start
+    return polar, vi
+
+
 def clear_frame_cells(canvas: Optional[torch.Tensor], vi: VoxelIndex, state: Optional[FrameIndexState] = None, v_cap: Optional[int] = None) -> None:
     """sparse clear at the end of a frame: the canvas cells of the frame's voxels and their ``cell_count`` entries"""
     _, _, g = vi.spec.c_arrays()

@@ -38,6 +38,7 @@ class Routes:
         self.pillar_rows = os.environ.get("PN_PILLAR_ROWS", "1") != "0"              # ... as the row-band kernel (pillar_rows.hip, r6); 0: pair lists
         self.pillar_conv_max_fill = float(os.environ.get("PN_PILLAR_CONV_MAX_FILL", "0.35"))
         self.pillar_rows_max_fill = float(os.environ.get("PN_PILLAR_ROWS_MAX_FILL", "1.25"))
+        self.fused_sweeps = os.environ.get("PN_FUSED_SWEEPS", "1") != "0"            # streaming frames: sweep accumulation inside the frame index (r6)
         # ---- token GEMMs
         self.linear = os.environ.get("PN_LINEAR", "1") != "0"                        # 0: the r2 route (1x1 convolution on conv_mfma_kernel)
         self.ln_fold = os.environ.get("PN_LN_FOLD", "1") != "0"                      # LayerNorm folded into the consuming GEMM (r6)
