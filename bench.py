@@ -827,6 +827,7 @@ def main():
             c4_f32_ms_per_step=get(c4, "f32", "ms_per_step"), c4_f32_one_graph_p50_ms=get(c4, "one_graph_bs2", "p50_ms"),
             c4_f32_sparse_encoder_ms=get(c4, "f32", "stages", "sparse_encoder", "ms"), c4_f32_setblocks_x2_ms=get(c4, "f32", "stages", "setblocks_x2", "ms"),
             c4_f32_rpn_ms=get(c4, "f32", "stages", "rpn", "ms"), c4_f32_head_ms=get(c4, "f32", "stages", "e2e_swv_head", "ms"),
+            c4_f32_dense_as_run_ms=get(c4, "f32", "dense_stages_as_run", "ms"),
             c4_bf16_ms_per_step=get(c4, "option_bf16_bev_convs", "ms_per_step"),
             c4_bf16_one_graph_p50_ms=get(c4, "option_bf16_bev_convs", "one_graph_bs2", "p50_ms"),
             c4_bf16_rpn_ms=get(c4, "option_bf16_bev_convs", "stages", "rpn", "ms"), c4_bf16_head_ms=get(c4, "option_bf16_bev_convs", "stages", "e2e_swv_head", "ms"),

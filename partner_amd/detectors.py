@@ -18,6 +18,7 @@ from . import builder, hip, ops
 from .builder import DETECTORS
 from .nn_utils import eval_only
 from .readers import DynamicPFNet
+from .routes import R, S
 
 
 @DETECTORS.register_module
@@ -512,6 +513,40 @@ class VoxelNetV3(SingleStageDetector):
             y = attn.forward_cols(y)
         return y.view(b, t, r, c)
 
+    def dense_stages_nhwc(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """the dense BEV map of the sparse backbone (B, theta, r, C) -> the head's NHWC tensors: 2 x SetBlock -> RPN -> head.
+        r6: a batch of several samples runs them PER SAMPLE on two streams (branches of the same hipGraph when captured): the 2-D chain
+        launches of a bs = 2 map are 576 tiles on 256 CUs -- 2.25 rounds paid as 3 --, two per-sample sequences of 288-tile launches fill
+        each other's tails (tools/c4_sample_streams.py: SetBlocks + RPN + head 7.36 -> 6.99 ms).  Every kernel of these stages works on one
+        sample's rows at a time, so a sample's tensors are those of the same sample alone (``PN_SAMPLE_STREAMS=0``: one sequence over the batch)."""
+        def one(xs):
+            y = self.realign_nhwc(xs)
+            if self.with_neck:
+                y = self.neck.forward_nhwc(y)
+            out = self.bbox_head.forward_nhwc(y)
+            out.pop("_feat", None)
+            return out
+        b = x.shape[0]
+        if b < 2 or not R.sample_streams or not x.is_cuda:
+            return one(x)
+        main = torch.cuda.current_stream(x.device)
+        side = ops.concurrent_stream(x.device)
+        side.wait_stream(main)
+        outs = [None] * b
+        built = S.lazy_builds
+        for i in range(0, b, 2):
+            outs[i] = one(x[i:i + 1])
+        if S.lazy_builds != built:      # plans / weight layouts were built on the way (the first call): they are queued on THIS stream
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for i in range(1, b, 2):
+                outs[i] = one(x[i:i + 1])
+        main.wait_stream(side)
+        for i in range(1, b, 2):
+            for v in outs[i].values():
+                v.record_stream(main)
+        return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+
     def extract_feat_hard(self, data):
         """voxelnet.py:202-227: mean VFE -> sparse 3-D backbone -> 2 x SetBlock -> RPN; returns the NHWC neck output"""
         feats = self.reader(data["features"], data["num_voxels"])
@@ -554,12 +589,7 @@ class VoxelNetV3(SingleStageDetector):
             nv = torch.empty((1,), dtype=torch.int32, device=points.device)
             hip.call("pn_concat_voxel_segments_f32", seg_f.data_ptr(), seg_c.data_ptr(), counts.data_ptr(), batch, mv, int(seg_f.shape[2]),
                      feats.data_ptr(), coords4.data_ptr(), nv.data_ptr(), hip.stream())
-        x = self.backbone.forward_nhwc(feats, coords4, batch, grid, n_voxels=nv)
-        x = self.realign_nhwc(x)
-        if self.with_neck:
-            x = self.neck.forward_nhwc(x)
-        out = self.bbox_head.forward_nhwc(x)
-        out.pop("_feat", None)
+        out = self.dense_stages_nhwc(self.backbone.forward_nhwc(feats, coords4, batch, grid, n_voxels=nv))
         return {k: v.permute(0, 3, 1, 2) for k, v in out.items()}
 
     def extract_feat_dynamic(self, data):
@@ -582,8 +612,13 @@ class VoxelNetV3(SingleStageDetector):
             hip.require_device(example["voxels"], example["coordinates"])
             data = dict(features=example["voxels"], num_voxels=example["num_points"], coors=example["coordinates"],
                         batch_size=len(example["num_voxels"]), input_shape=[int(v) for v in example["shape"][0]])
-            x = self.extract_feat_hard(data)
-        head_out = self.bbox_head.forward_nhwc(x) if hasattr(self.bbox_head, "forward_nhwc") else None
+            x = None
+        if x is None and hasattr(self.bbox_head, "forward_nhwc"):
+            feats = self.reader(data["features"], data["num_voxels"])
+            head_out = self.dense_stages_nhwc(self.backbone.forward_nhwc(feats, data["coors"], data["batch_size"], data["input_shape"]))
+        else:
+            x = self.extract_feat_hard(data) if x is None else x
+            head_out = self.bbox_head.forward_nhwc(x) if hasattr(self.bbox_head, "forward_nhwc") else None
         if head_out is not None:
             head_out.pop("_feat", None)
             preds = {"det_preds": [{k: v.permute(0, 3, 1, 2) for k, v in head_out.items()}]}

@@ -372,4 +372,7 @@ def device_info(device: int = 0) -> dict:
 
 
 def call(name: str, *args) -> None:
+    if name.startswith("pn_pack_"):      # a lazily built layout was just queued on the calling stream (routes.S.lazy_builds: see its users)
+        from .routes import S
+        S.lazy_builds += 1
     check(getattr(load(), name)(*args), name)

@@ -93,6 +93,8 @@ class PlanCache:
     def get(self, module: nn.Module, builder):
         sig = tuple((t.data_ptr(), t._version, str(t.device)) for t in list(module.parameters()) + list(module.buffers()))
         if self.plan is None or sig != self._sig:
+            from .routes import S
+            S.lazy_builds += 1
             with torch.no_grad():
                 self.plan = builder()
             self._sig = sig

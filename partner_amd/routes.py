@@ -39,6 +39,7 @@ class Routes:
         self.pillar_conv_max_fill = float(os.environ.get("PN_PILLAR_CONV_MAX_FILL", "0.35"))
         self.pillar_rows_max_fill = float(os.environ.get("PN_PILLAR_ROWS_MAX_FILL", "1.25"))
         self.fused_sweeps = os.environ.get("PN_FUSED_SWEEPS", "1") != "0"            # streaming frames: sweep accumulation inside the frame index (r6)
+        self.sample_streams = os.environ.get("PN_SAMPLE_STREAMS", "1") != "0"        # VoxelNetV3: the dense stages of a batch per sample on two streams (r6)
         # ---- token GEMMs
         self.linear = os.environ.get("PN_LINEAR", "1") != "0"                        # 0: the r2 route (1x1 convolution on conv_mfma_kernel)
         self.ln_fold = os.environ.get("PN_LN_FOLD", "1") != "0"                      # LayerNorm folded into the consuming GEMM (r6)
@@ -75,6 +76,10 @@ class State:
         self.chain44_route = True      # False: the frame takes F(2,3)xF(4,3) where the hint alone would pick F(4,3)xF(4,3) (ops.chain44)
         self.chain44_launches = 0      # launches that took the F(4,3)xF(4,3) form so far (engine.FramePipeline: is there a choice to measure?)
         self.profiler = None           # ops.ConvProfiler while bench.py's roofline pass runs
+        # weight layouts / plans built lazily so far (hip.call("pn_pack_*"), nn_utils.PlanCache rebuilds): each is queued on the stream that first
+        # needs it -- a caller that spreads work over several streams looks at this counter to see whether anything was built during its
+        # first stream's launches and, if so, lets the other streams wait for it (VoxelNetV3.dense_stages_nhwc)
+        self.lazy_builds = 0
 
 
 R = Routes()

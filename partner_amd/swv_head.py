@@ -258,9 +258,9 @@ class E2ESWVoteHead(nn.Module):
         bf16 = getattr(self, "compute_dtype", "f32") == "bf16"
         xc = ops.to_bf16(x) if bf16 else x
         vote = torch.zeros((b, h, w, 4), dtype=torch.float32, device=x.device)
+        L = self.layer
         plan["vote"][1](plan["vote"][0](xc), out=vote, out_channel_offset=0)
         plan["vote_cls"][1](plan["vote_cls"][0](xc), out=vote, out_channel_offset=2)
-        L = self.layer
         t = self.patch_embed_tokens(xc if (bf16 and x.shape[3] % 64 == 0) else x)
         t_stats = None
         for i in range(len(plan["blocks"])):

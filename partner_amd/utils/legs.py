@@ -221,6 +221,12 @@ def c4_leg(dev, batch: int = 2, points: int = 180000, reps: int = 10, warm: int 
     stages["e2e_swv_head"] = _stage(graph_time_ms(st_head, reps, warm), mfma_account(st_head), survey_gflop=290.0 * batch)
     f32["stages"] = stages
     f32["stage_sum_ms"] = round(sum(s["ms"] for s in stages.values()), 4)
+    # r6: as the detector runs the three dense stages of a batch (VoxelNetV3.dense_stages_nhwc): per sample on two streams -- the stage rows
+    # above time each stage's batch launches alone on one stream
+    if batch > 1:
+        ms_d, how = graph_time_ms(lambda: m.dense_stages_nhwc(x_sp), reps, warm)
+        f32["dense_stages_as_run"] = dict(ms=round(ms_d, 4), timed_as=how, what="2 x SetBlock -> RPN -> head of the batch, per sample on two streams "
+                                          "(branches of one hipGraph); the same three stages one after the other over the batch: the sum of their rows")
     out["f32"] = f32
 
     # the same detector as ONE hipGraph replay per frame from Cartesian points (VoxelNetV3.forward_points: voxel / site counts never leave the
