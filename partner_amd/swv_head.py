@@ -95,6 +95,8 @@ def _cfg_get(cfg, *names, default=None):
 
 @BBOX_HEADS.register_module
 class E2ESWVoteHead(nn.Module):
+    bias_table_max_bytes = 256 << 20      # per Swin block: larger relative-position bias tables are not kept, see _build_plan
+
     def __init__(self, in_channels=[128, ], tasks=[], dataset="nuscenes", weight=0.25, code_weights=[], common_heads=dict(),
                  logger=None, init_bias=-2.19, share_conv_channel=64, num_hm_conv=2, dcn_head=False, voxel_shape="cuboid",
                  voxel_generator=None, out_size_factor=4, npixels=0, SET_CRIT_CONFIG=dict(), MATCHER_CONFIG=dict(),
@@ -238,7 +240,9 @@ class E2ESWVoteHead(nn.Module):
             heads = bp["rw2"].shape[0]
             n = lib.pn_swv_window_bias_floats(hh, ww, heads, self.window_size)
             bp["bias_table"] = None
-            if n > 0 and plan["pos"].is_cuda:
+            # windows x heads x 3584 floats: 45 MB per block on the Waymo head map, held for the life of the plan; above the cap the attention
+            # kernel evaluates the position MLP on the fly (pn_swv_window_attn with a null table: the r4 form)
+            if 0 < n * 4 <= self.bias_table_max_bytes and plan["pos"].is_cuda:
                 tab = torch.empty(n, dtype=torch.float32, device=plan["pos"].device)
                 hip.call("pn_swv_window_bias_table", plan["pos"].data_ptr(), bp["rw1"].data_ptr(), bp["rb1"].data_ptr(), bp["rw2"].data_ptr(),
                          bp["rb2"].data_ptr(), hh, ww, heads, self.window_size, int(bp["shift"]), tab.data_ptr(), hip.stream())
