@@ -243,6 +243,14 @@ int pn_dynamic_pfn_fwd_table(const float *points, int point_stride, const int32_
                              const float *w1, int c1, float vx, float vy, float x_offset,
                              float y_offset, const float *center_table, float *features, float *canvas,
                              pn_stream_t stream);
+/* The same launch, which also zeroes cell_count[key] (the per-cell counters of pn_voxel_index_fused_*) for the frame's voxels (r6): the index
+ * launches in front are done with them, so a frame engine that leaves its canvas dirty needs no pn_clear_frame_cells launch.  (c0, c1) = (32, 128). */
+int pn_dynamic_pfn_fwd_table_clear(const float *points, int point_stride, const int32_t *voxel_start,
+                                   const int32_t *order, const int32_t *num_voxels, int v_capacity,
+                                   const uint32_t *unq_keys, const int32_t *grid, const float *w0, int c0,
+                                   const float *w1, int c1, float vx, float vy, float x_offset,
+                                   float y_offset, const float *center_table, float *features,
+                                   float *canvas, uint32_t *cell_count, pn_stream_t stream);
 
 /* pointer to the uint32 key-per-voxel array inside a pn_unique_rank_bitmap workspace */
 const uint32_t *pn_unique_keys_ptr(const void *workspace, uint64_t num_cells, int n_capacity);

@@ -76,6 +76,7 @@ struct PfnArgs {
   float vx, vy, xoff, yoff;
   float* feat;
   float* canvas;
+  uint32_t* cell_count;      // nullable (r6, the (32, 128) kernels): the frame index's per-cell counters, zeroed for this frame's voxels on the way
 };
 
 constexpr int kPfnWaves = 8;  // 8 waves share one LDS copy of the weights: 4 blocks (32 waves) per CU
@@ -225,6 +226,7 @@ __device__ __forceinline__ void pfn_32_128_main(const PfnArgs& a, const float* _
       m_s[tid] = a.vstart[v0 + tid];
       m_e[tid] = a.vstart[v0 + tid + 1];
       m_key[tid] = a.ukeys[v0 + tid];
+      if (a.cell_count) a.cell_count[a.ukeys[v0 + tid]] = 0u;      // (the index launches are done with the counter: the next frame finds it zero)
     }
     __syncthreads();
     int q0 = 0;
@@ -525,6 +527,7 @@ __device__ __forceinline__ void pfn_32_128_tiles(const PfnArgs& a, const float* 
       m_s[tid] = a.vstart[v0 + tid];
       m_e[tid] = a.vstart[v0 + tid + 1];
       m_key[tid] = a.ukeys[v0 + tid];
+      if (a.cell_count) a.cell_count[a.ukeys[v0 + tid]] = 0u;      // (the index launches are done with the counter: the next frame finds it zero)
     }
     __syncthreads();
     int q0 = 0;
@@ -1315,10 +1318,10 @@ int pn_pfn_center_table_f32(int t, float vy, float y_offset, float* table, pn_st
 
 // same contract as pn_dynamic_pfn_fwd plus the azimuth table of pn_pfn_center_table_f32; takes the
 // register-resident fast path when (C0, C1) == (32, 128), otherwise falls back to the generic kernel
-int pn_dynamic_pfn_fwd_table(const float* points, int point_stride, const int32_t* voxel_start, const int32_t* order,
-                             const int32_t* num_voxels, int v_capacity, const uint32_t* unq_keys, const int32_t* grid,
-                             const float* w0, int c0, const float* w1, int c1, float vx, float vy, float x_offset, float y_offset,
-                             const float* center_table, float* features, float* canvas, pn_stream_t stream) {
+static int dynamic_pfn_fwd_table(const float* points, int point_stride, const int32_t* voxel_start, const int32_t* order,
+                                 const int32_t* num_voxels, int v_capacity, const uint32_t* unq_keys, const int32_t* grid,
+                                 const float* w0, int c0, const float* w1, int c1, float vx, float vy, float x_offset, float y_offset,
+                                 const float* center_table, float* features, float* canvas, uint32_t* cell_count, pn_stream_t stream) {
   if (!(c0 == 32 && c1 == 128 && center_table))
     return pn_dynamic_pfn_fwd(points, point_stride, voxel_start, order, num_voxels, v_capacity, unq_keys, grid, w0, c0, w1, c1, vx, vy,
                               x_offset, y_offset, features, canvas, stream);
@@ -1326,7 +1329,7 @@ int pn_dynamic_pfn_fwd_table(const float* points, int point_stride, const int32_
   PN_REQUIRE(point_stride >= 7 && (features || canvas), "dynamic_pfn: bad arguments");
   if (v_capacity == 0) return PN_OK;
   PfnArgs a{points, point_stride, voxel_start, order, num_voxels, v_capacity, unq_keys, grid[0], grid[1], grid[2],
-            w0, c0, w1, c1, vx, vy, x_offset, y_offset, features, canvas};
+            w0, c0, w1, c1, vx, vy, x_offset, y_offset, features, canvas, cell_count};
   const int blocks = std::max(1, std::min(512, pn::cdiv(v_capacity, kFwdBatch)));  // persistent: 2 waves per SIMD, weights loaded once per wave
   // at most n / kHeavyPillar pillars can be heavy; the blocks find them by scanning voxel_start
   const int hblocks = std::max(1, std::min(256, pn::cdiv(v_capacity, kHeavyPillar)));
@@ -1349,6 +1352,26 @@ int pn_dynamic_pfn_fwd_table(const float* points, int point_stride, const int32_
   }
   hipLaunchKernelGGL(dynamic_pfn_32_128_kernel, dim3(blocks + hblocks), dim3(kHeavyWaves * 64), 0, pn::S(stream), a, center_table, blocks);
   return pn::check_launch("dynamic_pfn_32_128_kernel");
+}
+
+// r6: the same launch also zeroes the frame index's per-cell counters (pn_voxel_index_fused_*'s cell_count) of the frame's voxels -- the index
+// launches in front are done with them, and a frame engine whose canvas may stay dirty (PointPillars.forward_cart) then needs no
+// pn_clear_frame_cells launch at all.  (32, 128) readers with an azimuth table only.
+int pn_dynamic_pfn_fwd_table_clear(const float* points, int point_stride, const int32_t* voxel_start, const int32_t* order,
+                                   const int32_t* num_voxels, int v_capacity, const uint32_t* unq_keys, const int32_t* grid,
+                                   const float* w0, int c0, const float* w1, int c1, float vx, float vy, float x_offset, float y_offset,
+                                   const float* center_table, float* features, float* canvas, uint32_t* cell_count, pn_stream_t stream) {
+  PN_REQUIRE(c0 == 32 && c1 == 128 && center_table && cell_count, "dynamic_pfn_fwd_table_clear: the (32, 128) reader with its azimuth table and the cell counters");
+  return dynamic_pfn_fwd_table(points, point_stride, voxel_start, order, num_voxels, v_capacity, unq_keys, grid, w0, c0, w1, c1, vx, vy, x_offset, y_offset,
+                               center_table, features, canvas, cell_count, stream);
+}
+
+int pn_dynamic_pfn_fwd_table(const float* points, int point_stride, const int32_t* voxel_start, const int32_t* order,
+                             const int32_t* num_voxels, int v_capacity, const uint32_t* unq_keys, const int32_t* grid,
+                             const float* w0, int c0, const float* w1, int c1, float vx, float vy, float x_offset, float y_offset,
+                             const float* center_table, float* features, float* canvas, pn_stream_t stream) {
+  return dynamic_pfn_fwd_table(points, point_stride, voxel_start, order, num_voxels, v_capacity, unq_keys, grid, w0, c0, w1, c1, vx, vy, x_offset, y_offset,
+                               center_table, features, canvas, nullptr, stream);
 }
 
 int pn_scatter_canvas_fwd(const float* features, const int64_t* unq, const int32_t* num_voxels, int v_capacity, int c,

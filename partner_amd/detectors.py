@@ -138,7 +138,7 @@ class PointPillars(SingleStageDetector):
         else:
             hip.require_device(canvas)
             assert tuple(canvas.shape) == shape and canvas.is_contiguous() and canvas.dtype == torch.float32
-        self.reader.encode(polar, vi, None, canvas)
+        vi.index_cleared = self.reader.encode(polar, vi, None, canvas, clear_index=index_state)      # (r6: the reader's launch zeroes the index counters)
         return canvas, vi, polar
 
     def forward_sweeps(self, raw: torch.Tensor, sweep_offsets: torch.Tensor, transforms: torch.Tensor, time_lags: torch.Tensor, spec: ops.GridSpec,
@@ -153,10 +153,10 @@ class PointPillars(SingleStageDetector):
         hip.require_device(canvas)
         assert tuple(canvas.shape) == (1, spec.grid[1], spec.grid[0], self.reader.out_channels) and canvas.is_contiguous()
         polar, vi = ops.fused_voxel_index_sweeps(raw, sweep_offsets, transforms, time_lags, spec, index_state, min_distance)
-        self.reader.encode(polar, vi, None, canvas)
+        cleared = self.reader.encode(polar, vi, None, canvas, clear_index=index_state)
         x2 = self._neck_on_canvas(canvas, vi)
         leave = canvas_may_stay_dirty and self.seg_head is None and getattr(self.neck, "canvas_read_by_pillars_only", False)
-        ops.clear_frame_cells(None if leave else canvas, vi, index_state)
+        ops.clear_frame_cells(None if leave else canvas, vi, None if cleared else index_state)
         return self.bbox_head(ops.as_nchw(x2))["det_preds"][0]
 
     def scatter_stage(self, cart: torch.Tensor, sample_offsets: torch.Tensor, batch: int, spec: ops.GridSpec, canvas: torch.Tensor,
@@ -165,7 +165,7 @@ class PointPillars(SingleStageDetector):
         writing the persistent canvas, sparse clear): what bench.py's ``roofline_scatter`` times.
         -> the VoxelIndex (voxel count on the device)"""
         cv, vi, _ = self.encode_cart(cart, sample_offsets, batch, spec, canvas=canvas, index_state=index_state)
-        ops.clear_frame_cells(cv, vi, getattr(vi, "state", None) if index_state is not None else None)
+        ops.clear_frame_cells(cv, vi, getattr(vi, "state", None) if (index_state is not None and not getattr(vi, "index_cleared", False)) else None)
         return vi
 
     def forward_cart(self, cart: torch.Tensor, sample_offsets: torch.Tensor, batch: int, spec: Optional[ops.GridSpec] = None,
@@ -184,7 +184,7 @@ class PointPillars(SingleStageDetector):
         if canvas is not None or index_state is not None:
             leave = (canvas_may_stay_dirty and canvas is not None and index_state is not None and self.seg_head is None
                      and getattr(self.neck, "canvas_read_by_pillars_only", False))
-            ops.clear_frame_cells(None if leave else (cv if canvas is not None else None), vi, index_state)
+            ops.clear_frame_cells(None if leave else (cv if canvas is not None else None), vi, None if getattr(vi, "index_cleared", False) else index_state)
         return self.bbox_head(ops.as_nchw(x2))["det_preds"][0]
 
     def extract_preds(self, example) -> Dict[str, object]:

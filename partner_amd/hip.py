@@ -94,6 +94,7 @@ SIGNATURES = {
     "pn_pfn_center_table_floats": (_SZ, [_I]),
     "pn_pfn_center_table_f32": (_I, [_I, _F, _F, _P, _P]),
     "pn_dynamic_pfn_fwd_table": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P]),
+    "pn_dynamic_pfn_fwd_table_clear": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
     "pn_dynamic_pfn_bwd_workspace_bytes": (_SZ, []),
     "pn_dynamic_pfn_bwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _I, _P, _SZ, _P]),
     "pn_static_pfn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P]),

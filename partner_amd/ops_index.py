@@ -212,6 +212,8 @@ def fused_voxel_index_sweeps(raw: torch.Tensor, sweep_offsets: torch.Tensor, tra
 
 def clear_frame_cells(canvas: Optional[torch.Tensor], vi: VoxelIndex, state: Optional[FrameIndexState] = None, v_cap: Optional[int] = None) -> None:
     """sparse clear at the end of a frame: the canvas cells of the frame's voxels and their ``cell_count`` entries"""
+    if canvas is None and state is None:
+        return
     _, _, g = vi.spec.c_arrays()
     hip.call("pn_clear_frame_cells", vi.unq_keys_ptr, vi.num_voxels.data_ptr(), vi.n_cap if v_cap is None else v_cap, g,
              0 if canvas is None else canvas.shape[-1], hip.ptr(canvas), None if state is None else state.cell_count.data_ptr(), hip.stream())
@@ -252,17 +254,26 @@ def pfn_center_table(t: int, vy: float, y_offset: float, device) -> torch.Tensor
 
 def dynamic_pfn(points: torch.Tensor, vi: VoxelIndex, w0: torch.Tensor, w1: torch.Tensor, vx: float, vy: float,
                 x_offset: float, y_offset: float, features: Optional[torch.Tensor], canvas: Optional[torch.Tensor],
-                v_cap: Optional[int] = None) -> None:
+                v_cap: Optional[int] = None, clear_index: Optional[FrameIndexState] = None) -> bool:
+    """``clear_index`` (r6): the frame-index state whose per-cell counters the launch zeroes for the frame's voxels on the way (the (32, 128) reader's
+    kernels; -> True when it did, False when the caller still has to clear them with ``clear_frame_cells``)"""
     hip.require_device(points, w0, w1)
     assert w0.is_contiguous() and w1.is_contiguous() and points.is_contiguous()
     c0, c1 = w0.shape[0], w1.shape[0]
     assert w0.shape[1] == 16 and w1.shape[1] == 2 * c0
     _, _, g = vi.spec.c_arrays()
     tab = pfn_center_table(vi.spec.grid[1], vy, y_offset, points.device)
+    if clear_index is not None and (c0, c1) == (32, 128) and R.pfn_clears_index:
+        hip.call("pn_dynamic_pfn_fwd_table_clear", points.data_ptr(), points.stride(0), vi.voxel_start.data_ptr(), vi.order.data_ptr(),
+                 vi.num_voxels.data_ptr(), vi.n_cap if v_cap is None else v_cap, vi.unq_keys_ptr, g, w0.data_ptr(), c0,
+                 w1.data_ptr(), c1, float(vx), float(vy), float(x_offset), float(y_offset), tab.data_ptr(), hip.ptr(features),
+                 hip.ptr(canvas), clear_index.cell_count.data_ptr(), hip.stream())
+        return True
     hip.call("pn_dynamic_pfn_fwd_table", points.data_ptr(), points.stride(0), vi.voxel_start.data_ptr(), vi.order.data_ptr(),
              vi.num_voxels.data_ptr(), vi.n_cap if v_cap is None else v_cap, vi.unq_keys_ptr, g, w0.data_ptr(), c0,
              w1.data_ptr(), c1, float(vx), float(vy), float(x_offset), float(y_offset), tab.data_ptr(), hip.ptr(features),
              hip.ptr(canvas), hip.stream())
+    return False
 
 
 def clear_canvas_cells(canvas: torch.Tensor, vi: VoxelIndex, v_cap: Optional[int] = None) -> None:

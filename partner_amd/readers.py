@@ -72,11 +72,12 @@ class DynamicPFNet(nn.Module):
     def out_channels(self) -> int:
         return self.pfn_layers[-1].units
 
-    def encode(self, points: torch.Tensor, vi: ops.VoxelIndex, features, canvas):
-        """device-only entry used by the detector fast path (no host sync)"""
+    def encode(self, points: torch.Tensor, vi: ops.VoxelIndex, features, canvas, clear_index=None) -> bool:
+        """device-only entry used by the detector fast path (no host sync).  ``clear_index``: the frame-index state whose counters the launch may
+        zero on the way (-> True when it did: ops.dynamic_pfn)"""
         self._check_supported()
-        ops.dynamic_pfn(points, vi, self.pfn_layers[0].linear.weight.detach(), self.pfn_layers[1].linear.weight.detach(),
-                        self.vx, self.vy, self.x_offset, self.y_offset, features, canvas)
+        return ops.dynamic_pfn(points, vi, self.pfn_layers[0].linear.weight.detach(), self.pfn_layers[1].linear.weight.detach(),
+                               self.vx, self.vy, self.x_offset, self.y_offset, features, canvas, clear_index=clear_index)
 
     def forward(self, data):
         """data: dict(points (N,7) f32, grid_ind (N,4) int64 [b,z,theta,r], [batch_size]) ->

@@ -40,6 +40,7 @@ class Routes:
         self.pillar_rows_max_fill = float(os.environ.get("PN_PILLAR_ROWS_MAX_FILL", "1.25"))
         self.fused_sweeps = os.environ.get("PN_FUSED_SWEEPS", "1") != "0"            # streaming frames: sweep accumulation inside the frame index (r6)
         self.sample_streams = os.environ.get("PN_SAMPLE_STREAMS", "1") != "0"        # VoxelNetV3: the dense stages of a batch per sample on two streams (r6)
+        self.pfn_clears_index = os.environ.get("PN_PFN_CLEARS_INDEX", "1") != "0"    # frame engines: the reader's launch zeroes the frame's index counters (r6)
         # ---- token GEMMs
         self.linear = os.environ.get("PN_LINEAR", "1") != "0"                        # 0: the r2 route (1x1 convolution on conv_mfma_kernel)
         self.ln_fold = os.environ.get("PN_LN_FOLD", "1") != "0"                      # LayerNorm folded into the consuming GEMM (r6)

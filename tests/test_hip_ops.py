@@ -736,5 +736,8 @@ def test_frame_index_from_raw_sweeps_matches_accumulate_then_index(dev, n_sweeps
     fa = torch.zeros((va, 128), device=dev)
     fb = torch.zeros((vb, 128), device=dev)
     ops.dynamic_pfn(pol_a, vi_a, w0, w1, spec.vs[0], spec.vs[1], spec.lo[0] + spec.vs[0] / 2, spec.lo[1] + spec.vs[1] / 2, fa, None)
-    ops.dynamic_pfn(pol_b, vi_b, w0, w1, spec.vs[0], spec.vs[1], spec.lo[0] + spec.vs[0] / 2, spec.lo[1] + spec.vs[1] / 2, fb, None)
+    assert int(torch.count_nonzero(st_b.cell_count)) >= vb - 1      # (the index leaves every voxel's first point slot in its counter: one of them is slot 0)
+    did = ops.dynamic_pfn(pol_b, vi_b, w0, w1, spec.vs[0], spec.vs[1], spec.lo[0] + spec.vs[0] / 2, spec.lo[1] + spec.vs[1] / 2, fb, None, clear_index=st_b)
     assert torch.equal(fa, fb)
+    # r6 (pn_dynamic_pfn_fwd_table_clear): the reader's launch zeroed the frame's counters on the way -- the state is ready for the next frame
+    assert did and int(torch.count_nonzero(st_b.cell_count)) == 0
