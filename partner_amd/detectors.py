@@ -496,6 +496,10 @@ class VoxelNetV3(SingleStageDetector):
         if self.with_neck:
             self.neck.set_compute_dtype(dtype)
         self.bbox_head.set_compute_dtype(dtype)
+        if self.with_neck:
+            # r6: the RPN hands its output map over in bf16 (its deblocks' epilogues round once) where the head reads it in bf16 anyway: the
+            # f32 map (151 MB at bs 2) and the head's f32 -> bf16 pass over it are gone.  Same bits as rounding the f32 map.
+            self.neck.bf16_output = bool(dtype == "bf16" and getattr(self.bbox_head, "takes_bf16_input", lambda: False)())
         return self
 
     def realign(self, x: torch.Tensor) -> torch.Tensor:

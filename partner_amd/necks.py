@@ -165,7 +165,8 @@ class RPN(nn.Module):
                 de = plan["deblocks"][j]
                 if out is None:
                     oh, ow = de.out_hw(x.shape[1], x.shape[2])
-                    out = torch.empty((x.shape[0], oh, ow, sum(self._num_upsample_filters)), dtype=torch.float32, device=x.device)
+                    odt = torch.bfloat16 if (dtype == "bf16" and getattr(self, "bf16_output", False) and not return_blocks) else torch.float32
+                    out = torch.empty((x.shape[0], oh, ow, sum(self._num_upsample_filters)), dtype=odt, device=x.device)
                 de(x, out=out, out_channel_offset=off)
                 off += self._num_upsample_filters[j]
         res = out if out is not None else x

@@ -249,6 +249,11 @@ class E2ESWVoteHead(nn.Module):
                 bp["bias_table"] = tab
         return plan
 
+    def takes_bf16_input(self) -> bool:
+        """in the bf16 mode every reader of the input map -- the vote convolutions and the patch embedding -- takes its bf16 rounding (needs an
+        input width that is a multiple of 64); the RPN may then hand the map over in bf16 (VoxelNetV3.set_compute_dtype)"""
+        return getattr(self, "compute_dtype", "f32") == "bf16" and self.vote_head[0].in_channels % 64 == 0
+
     def forward_nhwc(self, x: torch.Tensor):
         """x: NHWC (B,H,W,Cin) -> dict of NHWC tensors"""
         eval_only(self, "E2ESWVoteHead")
@@ -260,7 +265,11 @@ class E2ESWVoteHead(nn.Module):
         C, heads, ws = self.layer.embed_dim, self.layer.num_heads, self.window_size
         # vote branch: (pred_centers | vote_cls | pad) in one 4-channel map read by the attention kernel
         bf16 = getattr(self, "compute_dtype", "f32") == "bf16"
-        xc = ops.to_bf16(x) if bf16 else x
+        if x.dtype == torch.bfloat16:      # (the RPN's bf16 hand-over, see takes_bf16_input)
+            assert bf16 and self.takes_bf16_input()
+            xc = x
+        else:
+            xc = ops.to_bf16(x) if bf16 else x
         vote = torch.zeros((b, h, w, 4), dtype=torch.float32, device=x.device)
         L = self.layer
         plan["vote"][1](plan["vote"][0](xc), out=vote, out_channel_offset=0)
@@ -273,8 +282,12 @@ class E2ESWVoteHead(nn.Module):
             else:
                 t = self.swin_block_tokens(i, t, vote, b, h, w, t_stats=t_stats)
                 t_stats = None
-        feat = ops.layernorm(t, L.norm0.weight, L.norm0.bias, L.norm0.eps).view(b, h, w, C)
-        fc = ops.to_bf16(feat) if bf16 else feat
+        if bf16:      # (r6: the bf16 copy the branch convolutions read comes out of the LayerNorm launch itself)
+            feat, fc = ops.layernorm(t, L.norm0.weight, L.norm0.bias, L.norm0.eps, bf16_copy=True)
+            feat, fc = feat.view(b, h, w, C), fc.view(b, h, w, C)
+        else:
+            feat = ops.layernorm(t, L.norm0.weight, L.norm0.bias, L.norm0.eps).view(b, h, w, C)
+            fc = feat
         # r6 (f32): the class branch's two 256 -> 256 convolutions and the box / IoU branches' fused first convolution read the same map: its
         # F(4, 3) planes are formed once and the three layers run as Winograd-domain chains (F(2,3) x F(4,3): 3 multiplications per output and
         # tap set against the routed 1-D form's 4.5 -- 715 -> 585 us for the pair, 198 -> 157 us for the third at bs 2, tools/head_conv_forms.py)
