@@ -58,3 +58,4 @@ if "--diff" in sys.argv:
     a1 = m.bbox_head.forward_nhwc(x_rpn[0:1].contiguous())
     for k in a:
         print("single vs batch", k, (a[k][0:1] - a1[k]).abs().max().item())
+
