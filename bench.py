@@ -19,7 +19,7 @@ collective); the timed region is bracketed by barrier + device synchronise and t
 over ranks is reported.
 
 Objects in the JSON line:
-  value / ms_per_step        the timed region: K hipGraph replays, `--streams` frames in flight (default 3)
+  value / ms_per_step        the timed region: K hipGraph replays, `--streams` frames in flight (default: 3 or 4, measured)
   single_stream_ms_per_step  the same K replays with ONE frame in flight (latency regime) -- the regime `roofline` is
                              quoted in, so roofline.conv_ms_per_step <= single_stream_ms_per_step
   roofline          the dominant kernel (fp32-MFMA implicit-GEMM convolution): algorithmic FLOPs of every launch / its
@@ -501,10 +501,10 @@ def main():
     ap.add_argument("--no-batched", action="store_true", help="skip the throughput measurement at the reference config's batch of 4 sweeps per step")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replays")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for a same-GPU dry run)")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="frames in flight per GPU (one hipGraph engine per HIP stream).  r4: 3 -- with the chained kernels (a block fills its CU) three and "
-                         "four frames in flight sustain the same rate over 50 steps (1557 / 1560 frames/s), and over the 20 steps the driver times three "
-                         "lose less to the ramp (1537 against 1482, five runs each)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="frames in flight per GPU (one hipGraph engine per HIP stream); 0 (default, r6): FramePipeline captures four engines and MEASURES "
+                         "three against four in flight at construction, like the stream assignment and the chain form (r4 fixed 3: 1537 against 1482 "
+                         "frames/s over the driver's 20 steps; with the r6 kernels four are 2.5 % faster sustained and 0.5 - 2 % over 20 steps)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the launcher, the rendezvous and the reductions only")
     ap.add_argument("--collective-timeout", type=float, default=300.0, help="seconds a rank waits in a collective before it gives up (N > 1)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 200-step repeat of the timed loop (`value_sustained`; counter passes of the profiler)")
@@ -602,8 +602,9 @@ def main():
         # the multi-frame regime as ONE object: FramePipeline captures the engines and measures their stream assignment at construction
         # (engine.py: an unmeasured assignment can sit 20 % lower; "untuned_ms_per_frame" in the line is that penalty on this box)
         from partner_amd.engine import FrameEngine, FramePipeline, tune_replay_streams
-        pipe = FramePipeline(model, B, N, spec, frames_in_flight=max(1, args.streams))
+        pipe = FramePipeline(model, B, N, spec, frames_in_flight=(3, 4) if args.streams <= 0 else args.streams)
         engines, stream_tuning = pipe.engines, pipe.tuning
+    depth = len(engines) if engines else 1      # frames in flight of the timed loop (measured by FramePipeline when --streams is 0)
 
     def step(i):
         # consecutive frames go to alternating streams: independent frames overlap on the GPU
@@ -660,7 +661,7 @@ def main():
     batched = None
     if engines and B == 1 and not args.no_batched:
         from partner_amd.engine import FrameEngine
-        GB, GS = 4, min(2, max(1, args.streams))
+        GB, GS = 4, min(2, depth)
         groups = [torch.cat([frames[(GB * f + j) % pool] for j in range(GB)], 0) for f in range(max(1, pool // GB))]
         eng2 = []
         for k in range(GS):
@@ -751,7 +752,7 @@ def main():
 
     roofline = roofline_single = None
     if not args.no_roofline_events:
-        k_hint = max(1, args.streams) if engines else 1
+        k_hint = depth
         roofline = conv_roofline(k_hint, pipe.chain44 if engines else True, full=True)
         if k_hint > 1:
             roofline_single = conv_roofline(1, True, full=False)
@@ -820,6 +821,7 @@ def main():
             value=round(fps, 3), value_sustained=None if sustained is None else sustained["value"],
             single_stream_ms_per_step=None if single_ms is None else round(single_ms, 4),
             chain_form=form.get("chosen"), chain_form_ms_per_frame=form.get("candidates"),
+            frames_in_flight=depth, depth_ms_per_frame=get(stream_tuning, "depth", "candidates"),
             roofline_kernel=None if roofline is None else roofline["kernel"].split(" ")[0], roofline_frac=get(roofline, "frac"),
             roofline_frac_in_flight=get(roofline, "frac_in_flight"), roofline_single_stream_frac=get(roofline_single, "frac"),
             scatter_us=get(scatter, "us"), scatter_300k_us=get(scatter300, "us"),
@@ -849,7 +851,7 @@ def main():
             "config": {"workload": "nuScenes polar-pillar PARTNER cfg (DynamicPFNet -> DynamicPPScatter -> RPN -> "
                                    "CenterHeadSinglePos), grid 512x512x1, forward only (BASELINE configs[1])",
                        "points_per_sweep": N, "sweeps_per_step_per_gpu": B, "parallelism": f"frame-replicas x{world}",
-                       "launch": "eager" if args.eager else f"hipGraph replay per frame, {max(1, args.streams)} frame(s) in flight on separate HIP streams",
+                       "launch": "eager" if args.eager else f"hipGraph replay per frame, {depth} frame(s) in flight on separate HIP streams" + (" (depth measured: 3 against 4)" if args.streams <= 0 else ""),
                        "chain_form": form.get("chosen"), "secondary": secondary, "device": hip.device_info(dev.index or 0)},
             "value_sustained": None if sustained is None else sustained["value"], "sustained": sustained,
             "single_stream_ms_per_step": None if single_ms is None else round(single_ms, 4),

@@ -171,15 +171,20 @@ class FramePipeline:
     tuned, and the two are then timed INTERLEAVED (``form_rounds`` rounds of ``form_frames`` frames each, alternating); the set with the
     lower median stays, the other is released.  ``tuning["chain_form"]`` records both figures and the choice."""
 
-    def __init__(self, model, batch: int, points_per_sweep: int, spec: ops.GridSpec = None, frames_in_flight: int = 3, point_features: int = 5,
+    def __init__(self, model, batch: int, points_per_sweep: int, spec: ops.GridSpec = None, frames_in_flight=3, point_features: int = 5,
                  test_cfg=None, trials: int = 8, form_rounds: int = 4, form_frames: int = 64):
-        k = max(1, int(frames_in_flight))
+        """``frames_in_flight``: an int, or (r6) a sequence of candidate depths -- e.g. (3, 4): engines for the deepest are captured, every
+        (depth, chain form) pair gets its stream assignment tuned, and the pairs are then timed interleaved; the fastest stays
+        (``tuning["depth"]`` records the figures).  Three against four frames in flight moved with the kernel mix from round to round
+        (r4: 3, r6: 4 is 2.5 % faster sustained on the boxes it was measured on), so it is measured like the other two choices."""
+        depths = sorted({max(1, int(v)) for v in (frames_in_flight if isinstance(frames_in_flight, (list, tuple)) else [frames_in_flight])})
+        kmax = depths[-1]
 
         def build(chain44):
             es = []
-            for _ in range(k):
-                st = torch.cuda.Stream() if k > 1 else None
-                es.append(FrameEngine(model, batch, points_per_sweep, spec, point_features, test_cfg, frames_in_flight=k, chain44=chain44).capture(stream=st))
+            for _ in range(kmax):
+                st = torch.cuda.Stream() if kmax > 1 else None
+                es.append(FrameEngine(model, batch, points_per_sweep, spec, point_features, test_cfg, frames_in_flight=kmax, chain44=chain44).capture(stream=st))
             return es
 
         def tune(es):
@@ -191,33 +196,48 @@ class FramePipeline:
             t["untuned_ms_per_frame"] = round(_time_round_robin(es, es[0].cart.clone(), 32), 4)
             for e, st in zip(es, chosen):
                 e.stream = st
+            t["streams"] = chosen
             return t
 
         self.engines = build(True)
         self.tuning = None
-        if k > 1:
-            self.tuning = tune(self.engines)
+        if kmax > 1:
+            sets = {"F(4,3)xF(4,3)": self.engines}
             # does the hint pick F(4,3)xF(4,3) anywhere in this model on this map?  (ops counts the launches of the form per capture)
-            if ops.chain44_launches_seen():
-                alt = build(False)
-                alt_tuning = tune(alt)
-                cart = self.engines[0].cart.clone()
-                a, b = [], []
-                for _ in range(max(1, form_rounds)):
-                    a.append(_time_round_robin(self.engines, cart, form_frames))
-                    b.append(_time_round_robin(alt, cart, form_frames))
-                med = lambda v: sorted(v)[len(v) // 2]
-                ma, mb = med(a), med(b)
-                form = dict(candidates={"F(4,3)xF(4,3)": round(ma, 4), "F(2,3)xF(4,3)": round(mb, 4)}, unit="ms per frame, median of "
-                            f"{max(1, form_rounds)} interleaved rounds of {form_frames} frames, {k} frames in flight",
-                            rounds={"F(4,3)xF(4,3)": [round(x, 4) for x in a], "F(2,3)xF(4,3)": [round(x, 4) for x in b]},
-                            chosen="F(4,3)xF(4,3)" if ma <= mb else "F(2,3)xF(4,3)")
-                if mb < ma:
-                    self.engines, self.tuning = alt, alt_tuning
-                del alt
-                self.tuning["chain_form"] = form
+            have44 = bool(ops.chain44_launches_seen())
+            if have44:
+                sets["F(2,3)xF(4,3)"] = build(False)
+            else:
+                sets = {"F(2,3)xF(4,3)": self.engines}
+            # every (form, depth) candidate: the first k engines of the form's set on their own tuned streams
+            cands = {}
+            for form, es in sets.items():
+                for k in depths:
+                    if k > 1:
+                        cands[(form, k)] = (es[:k], tune(es[:k]))
+            cart = self.engines[0].cart.clone()
+            times = {key: [] for key in cands}
+            for _ in range(max(1, form_rounds)):
+                for key, (es, t) in cands.items():
+                    for e, st in zip(es, t["streams"]):
+                        e.stream = st
+                    times[key].append(_time_round_robin(es, cart, form_frames))
+            med = {key: sorted(v)[len(v) // 2] for key, v in times.items()}
+            best = min(med, key=lambda key: med[key])
+            self.engines, self.tuning = cands[best]
+            for e, st in zip(self.engines, self.tuning["streams"]):
+                e.stream = st
+            self.tuning = {k2: v for k2, v in self.tuning.items() if k2 != "streams"}
+            unit = f"ms per frame, median of {max(1, form_rounds)} interleaved rounds of {form_frames} frames"
+            kbest = best[1]
+            if have44:
+                self.tuning["chain_form"] = dict(candidates={f: round(med[(f, kbest)], 4) for f in sets}, unit=unit + f", {kbest} frames in flight",
+                                                 rounds={f: [round(x, 4) for x in times[(f, kbest)]] for f in sets}, chosen=best[0])
             else:
                 self.tuning["chain_form"] = dict(candidates=None, chosen="F(2,3)xF(4,3)", unit="the F(4,3)xF(4,3) form is not taken on this map / build")
+            self.tuning["depth"] = dict(candidates={str(k): round(med[(best[0], k)], 4) for k in depths if k > 1}, unit=unit + ", chain form " + best[0],
+                                        chosen=kbest)
+            del sets, cands
         self.chain44 = self.engines[0].chain44
         self._next = 0
 
