@@ -17,7 +17,10 @@ SUBSET = ["tests/test_hip_model.py::test_small_model_stage_by_stage", "tests/tes
           "tests/test_hip_model.py::test_center_head_plain_and_single", "tests/test_hip_model.py::test_fused_head_vs_oracle_and_unfused",
           "tests/test_hip_attention.py::test_setblock_small", "tests/test_hip_sparse.py::test_sp_middle_resnet_fhd_matches_oracle",
           "tests/test_hip_swv.py::test_e2e_swv_head_matches_oracle", "tests/test_hip_train.py::test_small_model_train_step_grads",
-          "tests/test_hip_train.py::test_small_model_train_steps_run"]
+          "tests/test_hip_train.py::test_small_model_train_steps_run",
+          # r6: the frame engines (the reader's launch clearing the index counters, sweeps inside the index launch) and the per-sample streams
+          "tests/test_hip_model.py::test_frame_engine_keeps_a_dirty_canvas_only_where_nothing_reads_it",
+          "tests/test_hip_model.py::test_streaming_engine_raw_sweeps_to_boxes", "tests/test_hip_sparse.py::test_voxelnet_v3_batch_of_two"]
 
 ROUTES = {
     # r3 and earlier forms of everything r4 / r5 replaced: one F(4,3) launch per layer instead of the chains, the head's multi-job launches,
@@ -30,7 +33,8 @@ ROUTES = {
     # the one-dimensional chain, F(2,3) without F(4,3), the wave-per-group sparse kernel, row bits off, planes off
     "r4_alternates": dict(PN_CONV_CHAIN2D="0", PN_SPARSE_GROUP4="0", PN_SPARSE_ROW_BITS="0", PN_PILLAR_PLANES="0", PN_WINO4_KSPLIT="0",
                           PN_TRAIN_STRAT_EXPAND="1", PN_SPARSE_G4SPLIT="0", PN_PFN_SPLIT="0", PN_CHANNEL_SUM_V4="0", PN_SMALL_N_MFMA="0", PN_CONV_CHAIN44="0", PN_PFN_TILES="0",
-                          PN_PILLAR_ROWS="0", PN_LN_FOLD="0"),      # (r6: the pair-list first convolution, LayerNorm passes in front of the token GEMMs)
+                          PN_PILLAR_ROWS="0", PN_LN_FOLD="0",       # (r6: the pair-list first convolution, LayerNorm passes in front of the token GEMMs,
+                          PN_SAMPLE_STREAMS="0", PN_PFN_CLEARS_INDEX="0", PN_FUSED_SWEEPS="0", PN_CONV_PLANES="0"),      # one launch sequence per batch, a clear launch per frame, ...)
     "f23_only": dict(PN_CONV_WINO4="0", PN_CONV_CHAIN="0", PN_HEAD_CHAIN="0", PN_WINO_BDIRECT="0", PN_SPARSE_WINDOW="1024", PN_WINO4_TWO_PHASE="0"),
 }
 
