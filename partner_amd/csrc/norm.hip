@@ -606,6 +606,9 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(BnArgs a) {
 }
 
 constexpr int kBnSlices = 1024;
+#ifndef PN_BN_EXP
+#define PN_BN_EXP 0      // diagnostic builds (tools/bnq.sh): 1 no forward statistics pass, 2 no backward statistics pass -- wrong results; the iteration
+#endif                   // time then bounds what fusing that pass into the producing convolution's epilogue could save
 
 int bn_common(BnArgs& a, long long pixels, int c, void* workspace, size_t workspace_bytes) {
   PN_REQUIRE(pixels >= 1 && c >= 4 && c % 4 == 0 && c <= 4 * kThreads, "batchnorm: channel count must be a multiple of 4, at most 1024");
@@ -640,7 +643,7 @@ int pn_batchnorm_train_fwd(const float* x, long long pixels, int c, int pixel_st
   a.out = out; a.ops = out_pixel_stride; a.oco = out_channel_offset; a.running_mean = running_mean; a.running_var = running_var;
   a.stat = saved_stat;
   hipStream_t st = pn::S(stream);
-  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(a.slices), dim3(kThreads), 0, st, a);
+  if (!(PN_BN_EXP & 1)) hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(a.slices), dim3(kThreads), 0, st, a);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(64), 0, st, a);
   const long long total = pixels * (c / 4);
   hipLaunchKernelGGL(bn_apply_kernel<0>, dim3((unsigned)std::min<long long>(4096, pn::cdiv(total, kThreads))), dim3(kThreads), 0, st, a);
@@ -661,7 +664,7 @@ int pn_batchnorm_bwd(const float* x, const float* dout, long long pixels, int c,
   a.dout = dout; a.dps = dout_pixel_stride; a.dco = dout_channel_offset;
   a.dx = dx; a.xps = dx_pixel_stride; a.xco = dx_channel_offset; a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate;
   hipStream_t st = pn::S(stream);
-  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(a.slices), dim3(kThreads), 0, st, a);
+  if (!(PN_BN_EXP & 2)) hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(a.slices), dim3(kThreads), 0, st, a);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(64), 0, st, a);
   const long long total = pixels * (c / 4);
   hipLaunchKernelGGL(bn_apply_kernel<1>, dim3((unsigned)std::min<long long>(4096, pn::cdiv(total, kThreads))), dim3(kThreads), 0, st, a);
