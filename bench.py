@@ -602,7 +602,10 @@ def main():
         # the multi-frame regime as ONE object: FramePipeline captures the engines and measures their stream assignment at construction
         # (engine.py: an unmeasured assignment can sit 20 % lower; "untuned_ms_per_frame" in the line is that penalty on this box)
         from partner_amd.engine import FrameEngine, FramePipeline, tune_replay_streams
-        pipe = FramePipeline(model, B, N, spec, frames_in_flight=(3, 4) if args.streams <= 0 else args.streams)
+        # (the candidates are timed in bursts of the length this run times, from an idle chip like the timed loop itself: over 20 steps the
+        # fill of a four-deep pipeline costs what it gains over 200)
+        pipe = FramePipeline(model, B, N, spec, frames_in_flight=(3, 4) if args.streams <= 0 else args.streams, form_rounds=6,
+                             form_frames=min(128, max(16, args.steps)))
         engines, stream_tuning = pipe.engines, pipe.tuning
     depth = len(engines) if engines else 1      # frames in flight of the timed loop (measured by FramePipeline when --streams is 0)
 
