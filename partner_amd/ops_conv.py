@@ -137,11 +137,13 @@ class ConvLayer:
                 pack_groups = self.range_strata if self.range_strata > 1 else self.groups
                 cout_t, cin_g, kh, kw = w.shape
                 self.cin, self.cout, self.kh, self.kw = cin_g, cout_t // pack_groups, kh, kw
-                self.packed = torch.empty(lib.pn_conv_packed_weight_bf16_elems(self.cout, cin_g, kh, kw, pack_groups), dtype=torch.bfloat16,
-                                          device=dev)
-                hip.call("pn_pack_conv_weight_bf16", w.data_ptr(), cout_t, cin_g, kh, kw, pack_groups, self.packed.data_ptr(), st)
+                self.packed = None
+                self._bf16_general = (w, cout_t, cin_g, kh, kw, pack_groups)      # (a reference to the caller's f32 weight, no copy)
                 if pack_groups == 1:
                     self._pack_bf16_rows(lib, w, cout_t, cin_g, kh, kw, st)
+                if getattr(self, "packed_rows", None) is None:
+                    self._ensure_bf16_general()      # no rows form for this shape: the general layout is the one that runs
+                # (with a rows form the general layout is packed only if a call ever needs it -- one packed copy per layer, not two)
         elif deconv2x2:
             cin, cout = w.shape[0], w.shape[1]
             assert tuple(w.shape[2:]) == (2, 2)
@@ -188,6 +190,13 @@ class ConvLayer:
             self.tap_n = (9 * self.cout + 3) // 4 * 4
             self.tap_packed = _f32(lib.pn_linear_packed_weight_floats(self.tap_n, self.cin), dev)
             self._pack_taps(w)
+
+    def _ensure_bf16_general(self) -> None:
+        if self.packed is None:
+            w, cout_t, cin_g, kh, kw, pack_groups = self._bf16_general
+            self.packed = torch.empty(hip.load().pn_conv_packed_weight_bf16_elems(self.cout, cin_g, kh, kw, pack_groups), dtype=torch.bfloat16,
+                                      device=w.device)
+            hip.call("pn_pack_conv_weight_bf16", w.data_ptr(), cout_t, cin_g, kh, kw, pack_groups, self.packed.data_ptr(), hip.stream())
 
     def _pack_bf16_rows(self, lib, w: torch.Tensor, rows: int, cin: int, kh: int, kw: int, st) -> None:
         """the [row][tap][cin] weights of the bf16 implicit-GEMM kernel (csrc/conv_bf16.hip, r5): the layers of the Waymo BEV maps -- cin a
@@ -369,6 +378,8 @@ class ConvLayer:
                 hip.call("pn_conv2d_igemm_bf16", C.byref(d), x.data_ptr(), self.packed_rows.data_ptr(), hip.ptr(self.scale), hip.ptr(self.shift),
                          out.data_ptr(), int(out.dtype == torch.float32), st)
             else:
+                if self.packed is None:
+                    self._ensure_bf16_general()
                 hip.call("pn_conv2d_nhwc_bf16", C.byref(d), x.data_ptr(), self.packed.data_ptr(), hip.ptr(self.scale), hip.ptr(self.shift),
                          out.data_ptr(), int(out.dtype == torch.float32), st)
             if prof is not None:
